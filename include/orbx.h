@@ -1,0 +1,245 @@
+/*
+ * orbx.h -- C ABI of liborbx.so: the MI355X (gfx950) ORB front-end for ORB-SLAM3.
+ *
+ * This is the drop-in boundary.  The reference has no FFI seam: ORBextractor / ORBmatcher are ordinary C++
+ * classes (/root/reference/include/ORBextractor.h:43-109, include/ORBmatcher.h:36-103).  The replacement is
+ * a same-named C++ adapter (orb_slam3_amd/cpp/ORBextractor.h, ORBmatcher.h) whose methods forward to the
+ * entry points below; INTEGRATION.md shows the binding a maintainer adds.  Plain pointers and sizes only --
+ * no C++ types, no OpenCV types, no torch types, no exceptions cross this ABI.
+ *
+ * All compute entry points run hand-written HIP kernels on the selected GPU.  There is no CPU fallback:
+ * if no HIP device is usable the create functions fail with ORBX_E_NO_DEVICE.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_VERSION 100
+
+/* status codes: >= 0 success, < 0 error.  ORBX_E_EMPTY mirrors the reference's "return -1" for an empty
+ * image (ORBextractor.cc:1090). */
+enum {
+    ORBX_OK = 0,
+    ORBX_E_EMPTY = -1,
+    ORBX_E_BAD_ARG = -2,
+    ORBX_E_TOO_SMALL = -3,   /* a pyramid level would have no 35-px FAST cell (the reference divides by zero) */
+    ORBX_E_CAPACITY = -4,    /* output capacity too small */
+    ORBX_E_NO_DEVICE = -5,
+    ORBX_E_HIP = -6,         /* a HIP runtime call failed; see orbx_last_error() */
+    ORBX_E_TOO_LARGE = -7,   /* image / batch exceeds the limits given at creation, or a dimension > 4095 px */
+    ORBX_E_INTERNAL = -8     /* device-side consistency check failed (workspace overflow) */
+};
+
+/* 28-byte POD with the field layout of cv::KeyPoint {Point2f pt; float size, angle, response; int octave,
+ * class_id} -- what ORBextractor::operator() fills (ORBextractor.cc:861-869, 884-890). */
+typedef struct orbx_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} orbx_keypoint;
+
+/* flags in orbx_params.flags */
+enum {
+    /* Round descriptor sample coordinates with separate multiply and add (strict ISO evaluation of
+     * ORBextractor.cc:117-119).  Default (flag clear): the fused form GCC emits for the reference's own
+     * build flags (-O3 -march=native, CMakeLists.txt:10-13) on an FMA-capable x86. */
+    ORBX_FLAG_DESC_STRICT = 1u,
+    /* 7x7 Gaussian taps of OpenCV <= 4.5.0 ([18,34,49,55,49,34,18]/256) instead of >= 4.5.1
+     * ([18,34,48,56,48,34,18]/256). */
+    ORBX_FLAG_BLUR_OCV440 = 2u
+};
+
+/* ORBextractor constructor arguments (ORBextractor.h:50-51; values from Settings.cc:443-451) */
+typedef struct orbx_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    uint32_t flags;
+} orbx_params;
+
+typedef struct orbx_extractor orbx_extractor;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Extractor  (replaces ORBextractor, include/ORBextractor.h:43-109)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* ORBextractor::ORBextractor (ORBextractor.cc:409-469).  `device` is the HIP device ordinal.  Workspaces are
+ * sized lazily for the largest (width, height, batch) seen; max_* are optional pre-allocation hints (0 = lazy). */
+int orbx_create(const orbx_params *params, int device, int max_width, int max_height, int max_batch,
+                orbx_extractor **out);
+void orbx_destroy(orbx_extractor *ex);
+
+/* ORBextractor::operator() (ORBextractor.cc:1086-1168) on a host image (8-bit, 1 channel, `stride` bytes per row).
+ * vLappingArea = {lap0, lap1}.  Writes up to `cap` keypoints / 32-byte descriptors; *n_out = number of keypoints,
+ * *mono_index = the reference's return value.  Synchronous (H2D, kernels, D2H on the extractor's stream).
+ * Returns ORBX_OK, ORBX_E_EMPTY (image NULL or 0-sized: the reference returns -1), or another error. */
+int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, size_t stride, int lap0, int lap1,
+                 orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *n_out, int *mono_index);
+
+/* Batched form over device-resident frames (one camera stream = one extractor = one HIP stream).
+ * d_images: device pointer; frame f row y starts at d_images + f*frame_stride + y*row_stride.
+ * Enqueues all kernels asynchronously on the extractor's stream; results stay in HBM until downloaded. */
+int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int n_frames, int width, int height,
+                              size_t row_stride, size_t frame_stride, int lap0, int lap1);
+
+/* Device-side view of the last batch (valid until the next extract call on this extractor). */
+typedef struct orbx_batch_view {
+    int32_t n_frames;
+    int32_t cap;                    /* per-frame capacity of keypoints / descriptors */
+    const orbx_keypoint *d_keypoints; /* [n_frames][cap] */
+    const uint8_t *d_descriptors;     /* [n_frames][cap][32] */
+    const int32_t *d_count;           /* [n_frames] keypoints per frame */
+    const int32_t *d_mono_index;      /* [n_frames] */
+} orbx_batch_view;
+int orbx_batch_view_get(orbx_extractor *ex, orbx_batch_view *view);
+
+/* Wait for the extractor's stream. */
+int orbx_sync(orbx_extractor *ex);
+/* D2H of one frame of the last batch (synchronises the stream). */
+int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *keypoints, uint8_t *descriptors, int cap,
+                        int *n_out, int *mono_index);
+/* D2H of all frames of the last batch into packed host arrays: counts[n_frames], mono[n_frames], keypoints and
+ * descriptors laid out [n_frames][cap_per_frame] (cap_per_frame from orbx_output_capacity). Synchronous. */
+int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *keypoints, uint8_t *descriptors, int32_t *counts,
+                            int32_t *mono_index);
+int orbx_output_capacity(orbx_extractor *ex, int width, int height);
+
+/* mvImagePyramid[level] (public member read by Frame::ComputeStereoMatches, Frame.cc:818,908,923): copies the
+ * padded level (19-px REFLECT_101 ring included) of `frame` of the last batch to host memory.
+ * dst must hold (h+38) rows of dst_stride >= w+38 bytes; the ROI origin is dst + 19*dst_stride + 19. */
+int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_t dst_stride);
+int orbx_level_size(orbx_extractor *ex, int width, int height, int level, int *w, int *h);
+/* Device pointer to the padded level (for device-resident consumers such as the stereo matcher). */
+int orbx_get_level_device(orbx_extractor *ex, int frame, int level, const uint8_t **d_padded, size_t *pitch);
+
+/* GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (ORBextractor.h:62-83).  Arrays hold nlevels floats; any pointer may be NULL. */
+int orbx_get_levels(const orbx_extractor *ex);
+float orbx_get_scale_factor(const orbx_extractor *ex);
+int orbx_get_scale_tables(const orbx_extractor *ex, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2);
+/* mnFeaturesPerLevel (nlevels ints) and umax (16 ints) -- for known-answer tests */
+int orbx_get_feature_tables(const orbx_extractor *ex, int32_t *features_per_level, int32_t *umax16);
+
+/* Stage introspection of the last batch (parity tests): FAST candidates of a level in reference order
+ * (x, y relative to the 16-px border; response = score) and the level's keypoints after the quad-tree cull
+ * (level coordinates).  Return the count, or < 0. */
+int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, orbx_keypoint *out, int cap);
+int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_keypoint *out, int cap);
+int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_t dst_stride);
+
+/* Average GPU time (ms) per launch of each extractor kernel over the calls since the last reset, measured with
+ * HIP events on the extractor's stream when profiling is enabled.  names/ms arrays of `cap` entries; returns the
+ * number of kernels. */
+int orbx_profile_enable(orbx_extractor *ex, int enable);
+int orbx_profile_read(orbx_extractor *ex, const char **names, double *avg_ms, int64_t *launches, int cap);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Matcher  (replaces ORBmatcher, include/ORBmatcher.h:36-103, and the Hamming stages of Frame.cc)
+ * One context per host thread (own HIP stream): re-entrant across Tracking / LocalMapping / LoopClosing.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct orbx_matcher orbx_matcher;
+int orbx_matcher_create(int device, orbx_matcher **out);
+void orbx_matcher_destroy(orbx_matcher *m);
+
+/* ORBmatcher::TH_LOW / TH_HIGH / HISTO_LENGTH (ORBmatcher.cc:35-37) */
+#define ORBX_TH_LOW 50
+#define ORBX_TH_HIGH 100
+#define ORBX_HISTO_LENGTH 30
+
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2058-2074) for every candidate of a CSR candidate list:
+ * query i is compared with train rows cand[row_ptr[i] .. row_ptr[i+1]); dist_out[k] = Hamming(q_i, t_cand[k]).
+ * Host pointers; synchronous.  The caller replays best / second-best / ratio / taken-mask logic in reference order. */
+int orbx_hamming_csr(orbx_matcher *m, const uint8_t *q_desc, int n_q, const uint8_t *t_desc, int n_t,
+                     const int32_t *row_ptr, const int32_t *cand, uint16_t *dist_out);
+
+/* Best and second-best candidate per query, ties resolved to the EARLIEST candidate position (strict '<' scan,
+ * as every matcher except SearchForTriangulation does).  best_pos/second_pos are positions inside the query's
+ * candidate list (-1 if none); distances are 256 if none. */
+int orbx_hamming_best2_csr(orbx_matcher *m, const uint8_t *q_desc, int n_q, const uint8_t *t_desc, int n_t,
+                           const int32_t *row_ptr, const int32_t *cand, int32_t *best_pos, int32_t *best_dist,
+                           int32_t *second_pos, int32_t *second_dist);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2) as used by Frame::ComputeStereoFishEyeMatches
+ * (Frame.cc:1144): idx[2*i], idx[2*i+1] = best / second-best train row (lower index wins ties), -1 if absent. */
+int orbx_knn2(orbx_matcher *m, const uint8_t *q_desc, int n_q, const uint8_t *t_desc, int n_t, int32_t *idx,
+              int32_t *dist);
+
+/* Hamming stage of Frame::ComputeStereoMatches (Frame.cc:849-894): for each left keypoint the best right keypoint
+ * among those registered on row (int)yL with |octave difference| <= 1 and uL-maxD <= uR <= uL-minD.
+ * best_idx_r = -1 / best_dist = ORBX_TH_HIGH when no candidate is closer than TH_HIGH. */
+int orbx_stereo_rowband(orbx_matcher *m, const orbx_keypoint *kp_left, const uint8_t *desc_left, int n_left,
+                        const orbx_keypoint *kp_right, const uint8_t *desc_right, int n_right,
+                        const float *scale_factors, int nlevels, int n_rows, float min_d, float max_d,
+                        int32_t *best_idx_r, int32_t *best_dist);
+
+/* Frame::ComputeStereoMatches complete (Frame.cc:811-981): row-band Hamming + 11x11 SAD sub-pixel refinement on the
+ * pyramid levels + median outlier rejection.  pyr_left/right[l] point at the level ROI origin (host memory),
+ * as mvImagePyramid[l] does.  Fills u_right[n_left], depth[n_left] (-1 where unmatched); returns #matches. */
+int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kp_left, const uint8_t *desc_left, int n_left,
+                                const orbx_keypoint *kp_right, const uint8_t *desc_right, int n_right,
+                                const float *scale_factors, const float *inv_scale_factors, int nlevels,
+                                const uint8_t *const *pyr_left, const uint8_t *const *pyr_right, const int32_t *pyr_w,
+                                const int32_t *pyr_h, const size_t *pyr_stride, float bf, float b, float *u_right,
+                                float *depth);
+
+/* Frame description for the projection matchers: undistorted keypoints (mvKeysUn), descriptors, image bounds
+ * (mnMinX..mnMaxY) from which the 64x48 grid (Frame.h:44-45, Frame.cc:385-416) is built, per-level scale factors,
+ * optional right coordinates (mvuRight, NULL for mono). */
+typedef struct orbx_frame_desc {
+    const orbx_keypoint *keypoints_un;
+    const uint8_t *descriptors;
+    int32_t n;
+    float min_x, max_x, min_y, max_y;
+    const float *scale_factors;
+    int32_t nlevels;
+    const float *u_right;
+} orbx_frame_desc;
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
+ * (ORBmatcher.cc:43-213), monocular / rectified-stereo form (Nleft == -1).  Map points are passed flattened:
+ * the MapPoint scratch fields the loop reads (MapPoint.h:171-179) and a 32-byte descriptor each.
+ * mp_in_view[j] != 0  <=> mbTrackInView && !isBad() && !(bFarPoints && mTrackDepth > thFarPoints).
+ * frame_occupied[i] != 0 <=> F.mvpMapPoints[i] != NULL with Observations() > 0 on entry (may be NULL).
+ * mp_has_obs[j] = Observations() > 0 of map point j (may be NULL = all true).
+ * Output frame_match[i] = j if map point j was assigned to feature i, else -1.  Returns nmatches (>= 0). */
+int orbx_search_by_projection_mappoints(orbx_matcher *m, const orbx_frame_desc *frame, const uint8_t *frame_occupied,
+                                        int n_mp, const float *proj_x, const float *proj_y, const float *proj_xr,
+                                        const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc,
+                                        const uint8_t *mp_in_view, const uint8_t *mp_has_obs, float th, float nnratio,
+                                        int32_t *frame_match);
+
+/* ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (ORBmatcher.cc:1676-1887) after the
+ * adapter has projected the last frame's map points (one query per point that passed the projection gates).
+ * level_mode: 0 = [o-1, o+1], 1 = forward [o, inf), 2 = backward [0, o].  Rotation-histogram filter applied when
+ * check_orientation != 0.  cur_match[i] = query index or -1.  Returns nmatches. */
+int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur, const uint8_t *cur_occupied, int n_q,
+                                    const float *q_u, const float *q_v, const float *q_ur, const int32_t *q_octave,
+                                    const float *q_angle, const uint8_t *q_desc, const uint8_t *q_has_obs, float th,
+                                    int level_mode, int check_orientation, int32_t *cur_match);
+
+/* Device-resident, batched frame-to-frame matcher used by the throughput path: for every frame f >= 1 of the
+ * extractor's last batch, the keypoints of frame f-1 (queries, at their own position shifted by (du, dv)) are
+ * matched against frame f exactly as orbx_search_by_projection_frame does with level_mode 0, all features free on
+ * entry and every query "has observations".  d_match: device int32 [n_frames][cap] (query index in frame f-1 or -1),
+ * d_nmatches: device int32 [n_frames].  Asynchronous on the extractor's stream. */
+int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
+                                  int32_t *d_match, int32_t *d_nmatches);
+
+const char *orbx_last_error(void);
+const char *orbx_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,342 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (orb_slam3_amd) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+_SO = _DIR / "liborb_oracle.so"
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+FLAG_DESC_FMA = 1
+FLAG_BLUR_OCV440 = 2
+FLAG_LIBM_SINCOS = 4
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with g++ (seconds).  The GPU box uses the prebuilt .so if present."""
+    srcs = [_DIR / "orb_oracle.cc", _DIR / "orb_oracle_match.cc", _DIR / "orb_oracle.h", _DIR / "orb_pattern_data.inc"]
+    if force or not _SO.exists() or any(s.stat().st_mtime > _SO.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(_DIR), "-B", "liborb_oracle.so"], check=True, capture_output=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(str(_SO))
+        vp, i32, u32, f32, sz, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t, C.c_uint64
+        L.orbo_create.restype = vp
+        L.orbo_create.argtypes = [i32, f32, i32, i32, i32, i32]
+        L.orbo_destroy.argtypes = [vp]
+        L.orbo_extract.restype = i32
+        L.orbo_extract.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, vp, i32, vp]
+        L.orbo_get_tables.restype = i32
+        L.orbo_get_tables.argtypes = [vp] * 7
+        L.orbo_level_size.argtypes = [vp, i32, vp, vp]
+        L.orbo_level_padded.restype = vp
+        L.orbo_level_padded.argtypes = [vp, i32, vp]
+        L.orbo_level_blurred.restype = vp
+        L.orbo_level_blurred.argtypes = [vp, i32, vp]
+        L.orbo_level_candidates.restype = i32
+        L.orbo_level_candidates.argtypes = [vp, i32, vp, i32]
+        L.orbo_level_keypoints.restype = i32
+        L.orbo_level_keypoints.argtypes = [vp, i32, vp, i32]
+        L.orbo_cv_round_f.restype = i32
+        L.orbo_cv_round_f.argtypes = [f32]
+        L.orbo_resize_linear_u8.argtypes = [vp, i32, i32, sz, vp, i32, i32, sz]
+        L.orbo_border_reflect101.argtypes = [vp, i32, i32, sz, i32]
+        L.orbo_fast9_16.restype = i32
+        L.orbo_fast9_16.argtypes = [vp, i32, i32, sz, i32, vp, i32]
+        L.orbo_fast_score.restype = i32
+        L.orbo_fast_score.argtypes = [vp, sz]
+        L.orbo_gauss7_u8.argtypes = [vp, i32, i32, sz, vp, sz, i32]
+        L.orbo_fast_atan2.restype = f32
+        L.orbo_fast_atan2.argtypes = [f32, f32]
+        L.orbo_ic_angle.restype = f32
+        L.orbo_ic_angle.argtypes = [vp, sz]
+        L.orbo_sinf.restype = f32
+        L.orbo_sinf.argtypes = [f32]
+        L.orbo_cosf.restype = f32
+        L.orbo_cosf.argtypes = [f32]
+        L.orbo_check_sincos_vs_libm.restype = u64
+        L.orbo_check_sincos_vs_libm.argtypes = [u32, u32, vp]
+        L.orbo_orb_descriptor.argtypes = [vp, sz, f32, i32, i32, vp]
+        L.orbo_distribute_octree.restype = i32
+        L.orbo_distribute_octree.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32]
+        L.orbo_sort_nodes.argtypes = [vp, vp, i32, vp]
+        L.orbo_descriptor_distance.restype = i32
+        L.orbo_descriptor_distance.argtypes = [vp, vp]
+        L.orbo_grid_create.restype = vp
+        L.orbo_grid_create.argtypes = [vp, i32, f32, f32, f32, f32]
+        L.orbo_grid_destroy.argtypes = [vp]
+        L.orbo_grid_query.restype = i32
+        L.orbo_grid_query.argtypes = [vp, f32, f32, f32, i32, i32, vp, i32]
+        L.orbo_search_by_projection_mappoints.restype = i32
+        L.orbo_search_by_projection_mappoints.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp,
+                                                          vp, vp, f32, f32, vp]
+        L.orbo_search_by_projection_frame.restype = i32
+        L.orbo_search_by_projection_frame.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp,
+                                                      f32, i32, i32, vp]
+        L.orbo_compute_stereo_matches.restype = i32
+        L.orbo_compute_stereo_matches.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, f32, f32,
+                                                  vp, vp, vp, vp]
+        L.orbo_knn2.argtypes = [vp, i32, vp, i32, vp, vp]
+        L.orbo_three_maxima.argtypes = [vp, i32, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """ORBextractor restated on the CPU (the parity oracle)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, flags=FLAG_DESC_FMA):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orbo_create(nfeatures, scale_factor, nlevels, ini_th, min_th, flags)
+        if not self.h:
+            raise ValueError("bad extractor parameters")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orbo_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        quota = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.orbo_get_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(quota), _p(umax))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+    def extract(self, img: np.ndarray, lap=(0, 0)):
+        """Returns (mono_index, keypoints[KP_DTYPE], descriptors[N,32])."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures * 4 + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        r = self.L.orbo_extract(self.h, _p(img), w, h, img.strides[0], lap[0], lap[1], _p(kps), _p(desc), cap,
+                                C.byref(n))
+        if r < 0:
+            return r, kps[:0], desc[:0]
+        return r, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_size(self, lvl):
+        w, h = C.c_int(0), C.c_int(0)
+        self.L.orbo_level_size(self.h, lvl, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_padded(self, lvl) -> np.ndarray:
+        w, h = self.level_size(lvl)
+        st = C.c_size_t(0)
+        p = self.L.orbo_level_padded(self.h, lvl, C.byref(st))
+        buf = (C.c_uint8 * (st.value * (h + 38))).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(h + 38, st.value)[:, :w + 38].copy()
+
+    def level_blurred(self, lvl):
+        w, h = self.level_size(lvl)
+        st = C.c_size_t(0)
+        p = self.L.orbo_level_blurred(self.h, lvl, C.byref(st))
+        if not p:
+            return None
+        buf = (C.c_uint8 * (st.value * h)).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(h, st.value)[:, :w].copy()
+
+    def level_candidates(self, lvl) -> np.ndarray:
+        n = self.L.orbo_level_candidates(self.h, lvl, None, 0)
+        out = np.zeros(n, KP_DTYPE)
+        self.L.orbo_level_candidates(self.h, lvl, _p(out), n)
+        return out
+
+    def level_keypoints(self, lvl) -> np.ndarray:
+        n = self.L.orbo_level_keypoints(self.h, lvl, None, 0)
+        out = np.zeros(n, KP_DTYPE)
+        self.L.orbo_level_keypoints(self.h, lvl, _p(out), n)
+        return out
+
+
+# ---- primitive wrappers -------------------------------------------------------------------------
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orbo_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dst.strides[0])
+    return dst
+
+
+def fast9_16(img: np.ndarray, threshold: int) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().orbo_fast9_16(_p(img), img.shape[1], img.shape[0], img.strides[0], threshold, _p(out), cap)
+    return out[:n].copy()
+
+
+def fast_score_map(img: np.ndarray) -> np.ndarray:
+    """score(p) for every pixel at least 3 px from the border (others 0); negative clamps to 0."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.int32)
+    L = lib()
+    base = img.ctypes.data
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            out[y, x] = L.orbo_fast_score(C.c_void_p(base + y * img.strides[0] + x), img.strides[0])
+    return out
+
+
+def gauss7(img: np.ndarray, ocv440: bool = False) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    dst = np.zeros_like(img)
+    lib().orbo_gauss7_u8(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(dst), dst.strides[0], int(ocv440))
+    return dst
+
+
+def fast_atan2(y: float, x: float) -> float:
+    return lib().orbo_fast_atan2(y, x)
+
+
+def ic_angle(img: np.ndarray, x: int, y: int) -> float:
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orbo_ic_angle(C.c_void_p(img.ctypes.data + y * img.strides[0] + x), img.strides[0])
+
+
+def orb_descriptor(img: np.ndarray, x: int, y: int, angle_deg: float, fma: bool = True, libm: bool = False):
+    img = np.ascontiguousarray(img, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orbo_orb_descriptor(C.c_void_p(img.ctypes.data + y * img.strides[0] + x), img.strides[0], angle_deg,
+                              int(fma), int(libm), _p(d))
+    return d
+
+
+def distribute_octree(cands: np.ndarray, minX, maxX, minY, maxY, N) -> np.ndarray:
+    cands = np.ascontiguousarray(cands, KP_DTYPE)
+    out = np.zeros(len(cands) + 8, KP_DTYPE)
+    n = lib().orbo_distribute_octree(_p(cands), len(cands), minX, maxX, minY, maxY, N, _p(out), len(out))
+    return out[:n].copy()
+
+
+def sort_nodes(count: np.ndarray, ulx: np.ndarray) -> np.ndarray:
+    count = np.ascontiguousarray(count, np.int32)
+    ulx = np.ascontiguousarray(ulx, np.int32)
+    perm = np.zeros(len(count), np.int32)
+    lib().orbo_sort_nodes(_p(count), _p(ulx), len(count), _p(perm))
+    return perm
+
+
+def descriptor_distance(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orbo_descriptor_distance(_p(a), _p(b))
+
+
+class OracleGrid:
+    def __init__(self, kps_un: np.ndarray, minx, maxx, miny, maxy):
+        self.kps = np.ascontiguousarray(kps_un, KP_DTYPE)
+        self.L = lib()
+        self.h = self.L.orbo_grid_create(_p(self.kps), len(self.kps), minx, maxx, miny, maxy)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orbo_grid_destroy(self.h)
+            self.h = None
+
+    def query(self, x, y, r, min_level=-1, max_level=-1) -> np.ndarray:
+        out = np.zeros(len(self.kps) + 1, np.int32)
+        n = self.L.orbo_grid_query(self.h, x, y, r, min_level, max_level, _p(out), len(out))
+        return out[:n].copy()
+
+
+def search_by_projection_mappoints(grid: OracleGrid, frame_desc, scale_factors, mp, th, nnratio, u_right=None,
+                                   occupied=None):
+    """mp: dict(proj_x, proj_y, proj_xr, level, view_cos, desc, in_view, has_obs). Returns (nmatches, frame_match)."""
+    nF = len(grid.kps)
+    frame_desc = np.ascontiguousarray(frame_desc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    fm = np.full(nF, -1, np.int32)
+    a = {k: np.ascontiguousarray(v) for k, v in mp.items()}
+    n = lib().orbo_search_by_projection_mappoints(
+        grid.h, _p(grid.kps), _p(frame_desc), nF, _p(sf), _p(u_right), _p(occupied), len(a["proj_x"]),
+        _p(a["proj_x"].astype(np.float32)), _p(a["proj_y"].astype(np.float32)),
+        _p(a["proj_xr"].astype(np.float32)), _p(a["level"].astype(np.int32)), _p(a["view_cos"].astype(np.float32)),
+        _p(a["desc"].astype(np.uint8)), _p(a["in_view"].astype(np.uint8)), _p(a["has_obs"].astype(np.uint8)),
+        th, nnratio, _p(fm))
+    return n, fm
+
+
+def search_by_projection_frame(grid: OracleGrid, cur_desc, scale_factors, q, th, mode=0, check_orientation=True,
+                               cur_u_right=None, cur_occupied=None):
+    nC = len(grid.kps)
+    cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    cm = np.full(nC, -1, np.int32)
+    a = {k: np.ascontiguousarray(v) for k, v in q.items()}
+    n = lib().orbo_search_by_projection_frame(
+        grid.h, _p(grid.kps), _p(cur_desc), nC, _p(sf), _p(cur_u_right), _p(cur_occupied), len(a["u"]),
+        _p(a["u"].astype(np.float32)), _p(a["v"].astype(np.float32)), _p(a["ur"].astype(np.float32)),
+        _p(a["octave"].astype(np.int32)), _p(a["angle"].astype(np.float32)), _p(a["desc"].astype(np.uint8)),
+        _p(a["has_obs"].astype(np.uint8)), th, mode, int(check_orientation), _p(cm))
+    return n, cm
+
+
+def knn2(q: np.ndarray, t: np.ndarray):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    idx = np.zeros((len(q), 2), np.int32)
+    dist = np.zeros((len(q), 2), np.int32)
+    lib().orbo_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx, dist
+
+
+def compute_stereo_matches(kl, dl, kr, dr, scale, inv_scale, pyr_l, pyr_r, bf, b):
+    """pyr_l / pyr_r: lists of contiguous uint8 level images (ROI, no ring)."""
+    kl = np.ascontiguousarray(kl, KP_DTYPE)
+    kr = np.ascontiguousarray(kr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8)
+    dr = np.ascontiguousarray(dr, np.uint8)
+    nl = len(pyr_l)
+    pl = (C.c_void_p * nl)(*[p.ctypes.data for p in pyr_l])
+    pr = (C.c_void_p * nl)(*[p.ctypes.data for p in pyr_r])
+    pw = np.array([p.shape[1] for p in pyr_l], np.int32)
+    ph = np.array([p.shape[0] for p in pyr_l], np.int32)
+    ps = np.array([p.strides[0] for p in pyr_l], np.uint64)
+    N = len(kl)
+    ur = np.zeros(N, np.float32)
+    depth = np.zeros(N, np.float32)
+    bi = np.zeros(N, np.int32)
+    bd = np.zeros(N, np.int32)
+    sc = np.ascontiguousarray(scale, np.float32)
+    isc = np.ascontiguousarray(inv_scale, np.float32)
+    n = lib().orbo_compute_stereo_matches(_p(kl), _p(dl), N, _p(kr), _p(dr), len(kr), _p(sc), _p(isc), nl,
+                                          C.cast(pl, C.c_void_p), C.cast(pr, C.c_void_p), _p(pw), _p(ph), _p(ps),
+                                          bf, b, _p(ur), _p(depth), _p(bi), _p(bd))
+    return n, ur, depth, bi, bd
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    a, b, c = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    lib().orbo_three_maxima(_p(sizes), len(sizes), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value

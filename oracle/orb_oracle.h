@@ -1,0 +1,148 @@
+/*
+ * orb_oracle.h -- C interface of the CPU ORACLE for the ORB-SLAM3 front-end hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (include/orbx.h, orb_slam3_amd/) may
+ * include, link or call this library.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it -- as the checker, never as the thing measured or shipped.
+ *
+ * The oracle is a dependency-free C++17 restatement of the reference algorithm:
+ *   /root/reference/src/ORBextractor.cc:71-146, 409-896, 1077-1195   (extractor)
+ *   /root/reference/src/ORBmatcher.cc                                 (matchers)
+ *   /root/reference/src/Frame.cc:385-416, 657-735, 811-981, 1126-1166 (grid, stereo)
+ * plus restatements of the OpenCV 4.x primitives the reference calls (resize, copyMakeBorder,
+ * FAST, GaussianBlur, fastAtan2, cvRound, BFMatcher) and of glibc 2.35 sinf/cosf.
+ *
+ * PARITY STATUS: **parity unpinned**.  The reference tree holds no golden vectors or tests for
+ * this path and the reference itself cannot be built here (OpenCV/Eigen absent),
+ * so the oracle is pinned only by (a) analytic known answers derived from the cited lines and
+ * (b) an exhaustive check of the restated sinf/cosf against this image's glibc.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same layout as cv::KeyPoint (28 bytes) */
+typedef struct orbo_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} orbo_keypoint;
+
+/* flags for orbo_create */
+enum {
+    ORBO_FLAG_DESC_FMA = 1,   /* descriptor sample rounding contracted to FMA, as GCC -O3 -march=native does
+                                 for ORBextractor.cc:117-119 on an FMA CPU (the reference's own build flags) */
+    ORBO_FLAG_BLUR_OCV440 = 2,/* Gaussian taps of OpenCV <= 4.5.0 ([18,34,49,55,49,34,18]) instead of the
+                                 >= 4.5.1 error-diffused taps ([18,34,48,56,48,34,18]) */
+    ORBO_FLAG_LIBM_SINCOS = 4 /* call the host libm sinf/cosf instead of the restated glibc routines */
+};
+
+typedef struct orbo_extractor orbo_extractor;
+
+orbo_extractor *orbo_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                            int flags);
+void orbo_destroy(orbo_extractor *ex);
+
+/* ORBextractor::operator().  Returns monoIndex (>=0), -1 for an empty image, < -1 on other errors.
+ * kps/desc hold up to cap entries; *n_out is the number produced (may exceed nfeatures slightly). */
+int orbo_extract(orbo_extractor *ex, const uint8_t *img, int w, int h, size_t stride, int lap0, int lap1,
+                 orbo_keypoint *kps, uint8_t *desc, int cap, int *n_out);
+
+/* tables (T1) */
+int orbo_get_tables(const orbo_extractor *ex, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                    int *features_per_level, int *umax16);
+
+/* introspection of the last orbo_extract call (stage-wise parity) */
+int orbo_level_size(const orbo_extractor *ex, int level, int *w, int *h);
+/* padded level (ring of 19 px, REFLECT_101): pointer to the padded image's (0,0), stride in bytes */
+const uint8_t *orbo_level_padded(const orbo_extractor *ex, int level, size_t *stride);
+/* blurred level (no ring), NULL if the level had no keypoints (reference skips the blur then) */
+const uint8_t *orbo_level_blurred(const orbo_extractor *ex, int level, size_t *stride);
+/* FAST candidates of a level in reference order (coords relative to the 16 px border, as vToDistributeKeys) */
+int orbo_level_candidates(const orbo_extractor *ex, int level, orbo_keypoint *out, int cap);
+/* keypoints of a level after the quad-tree cull + orientation (level coordinates, octave/size set) */
+int orbo_level_keypoints(const orbo_extractor *ex, int level, orbo_keypoint *out, int cap);
+
+/* ---- individual primitives (unit tests / kernel-level parity) ---- */
+int orbo_cv_round_f(float v);
+void orbo_resize_linear_u8(const uint8_t *src, int sw, int sh, size_t sstride, uint8_t *dst, int dw, int dh,
+                           size_t dstride);
+void orbo_border_reflect101(uint8_t *padded, int w, int h, size_t stride, int border);
+/* cv::FAST(img, keys, threshold, nonmax=true), TYPE_9_16.  Returns count. */
+int orbo_fast9_16(const uint8_t *img, int cols, int rows, size_t stride, int threshold, orbo_keypoint *out, int cap);
+/* corner score of a single pixel (needs 3 px of valid pixels all around); score < threshold <=> not a corner */
+int orbo_fast_score(const uint8_t *center, size_t stride);
+void orbo_gauss7_u8(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride, int ocv440);
+float orbo_fast_atan2(float y, float x);
+float orbo_ic_angle(const uint8_t *center, size_t stride);
+float orbo_sinf(float x);
+float orbo_cosf(float x);
+/* exhaustive comparison of the restated sinf/cosf with the host libm over float bit patterns [lo,hi); returns #mismatches */
+uint64_t orbo_check_sincos_vs_libm(uint32_t lo_bits, uint32_t hi_bits, uint32_t *first_bad_bits);
+void orbo_orb_descriptor(const uint8_t *center, size_t stride, float angle_deg, int fma_mode, int libm, uint8_t *desc32);
+/* DistributeOctTree on explicit candidates.  Returns count. */
+int orbo_distribute_octree(const orbo_keypoint *in, int n_in, int minX, int maxX, int minY, int maxY, int N,
+                           orbo_keypoint *out, int cap);
+/* replica check of std::sort tie behaviour is done inside the GPU tests through this entry:
+ * sorts (count, ulx) pairs exactly as compareNodes + std::sort do and returns the permutation */
+void orbo_sort_nodes(const int *count, const int *ulx, int n, int *perm);
+
+/* ---- matchers (flattened data; see orb_oracle_match.cc) ---- */
+int orbo_descriptor_distance(const uint8_t *a, const uint8_t *b);
+
+typedef struct orbo_grid orbo_grid; /* Frame 64x48 grid (Frame.cc:385-416) */
+orbo_grid *orbo_grid_create(const orbo_keypoint *kps_un, int n, float minx, float maxx, float miny, float maxy);
+void orbo_grid_destroy(orbo_grid *g);
+/* Frame::GetFeaturesInArea (Frame.cc:657-723); returns count, indices in reference order */
+int orbo_grid_query(const orbo_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out, int cap);
+
+/* M1: SearchByProjection(Frame&, vector<MapPoint*>&, th, bFarPoints, thFarPoints), mono (Nleft == -1) form.
+ * Map points are flattened: proj x/y, predicted level, view cosine, descriptor, and the flags the loop reads.
+ * frame_occupied[i] != 0 <=> F.mvpMapPoints[i] && Observations()>0 on entry.  mp_has_obs[j] = Observations()>0
+ * of map point j (what a later query sees once j is assigned).  u_right may be NULL (all <= 0).
+ * Output: frame_match[i] = index of the map point assigned to feature i or -1 (unchanged).  Returns nmatches. */
+int orbo_search_by_projection_mappoints(const orbo_grid *grid, const orbo_keypoint *kps_un, const uint8_t *frame_desc,
+                                        int n_frame, const float *scale_factors, const float *u_right,
+                                        const uint8_t *frame_occupied, int n_mp, const float *proj_x,
+                                        const float *proj_y, const float *proj_xr, const int32_t *pred_level,
+                                        const float *view_cos, const uint8_t *mp_desc, const uint8_t *mp_in_view,
+                                        const uint8_t *mp_has_obs, float th, float nnratio, int32_t *frame_match);
+
+/* M2: SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) after projection: one query per last-frame
+ * map point that survived the projection gates; level window selected by mode (0: [o-1,o+1], 1 forward: [o,-1],
+ * 2 backward: [0,o]).  Returns nmatches after the rotation-histogram filter. */
+int orbo_search_by_projection_frame(const orbo_grid *grid, const orbo_keypoint *cur_kps_un, const uint8_t *cur_desc,
+                                    int n_cur, const float *scale_factors, const float *cur_u_right,
+                                    const uint8_t *cur_occupied, int n_q, const float *q_u, const float *q_v,
+                                    const float *q_ur, const int32_t *q_octave, const float *q_angle,
+                                    const uint8_t *q_desc, const uint8_t *q_has_obs, float th, int mode,
+                                    int check_orientation, int32_t *cur_match);
+
+/* M8: Frame::ComputeStereoMatches (Frame.cc:811-981).  Fills u_right/depth (N_left), and the raw Hamming stage
+ * result best_idx_r / best_dist (-1 / TH_HIGH when none) for kernel-level parity. */
+int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int nl, const orbo_keypoint *kr,
+                                const uint8_t *dr, int nr, const float *scale_factors,
+                                const float *inv_scale_factors, int nlevels, const uint8_t *const *pyr_left,
+                                const uint8_t *const *pyr_right, const int *pyr_w, const int *pyr_h,
+                                const size_t *pyr_stride, float bf, float b, float *u_right, float *depth,
+                                int32_t *best_idx_r, int32_t *best_dist);
+
+/* M9: BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2): idx[2*i..], dist[2*i..]; -1 when fewer than k train rows */
+void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist);
+
+/* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2012-2053) on bin sizes */
+void orbo_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORB_ORACLE_H */

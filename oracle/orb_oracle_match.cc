@@ -1,0 +1,352 @@
+/*
+ * orb_oracle_match.cc -- CPU ORACLE (matcher half).  TEST INFRASTRUCTURE ONLY -- see orb_oracle.h.
+ *
+ * Restates, over flattened arrays instead of the Frame/KeyFrame/MapPoint pointer graph:
+ *   ORBmatcher::DescriptorDistance          /root/reference/src/ORBmatcher.cc:2058-2074
+ *   ORBmatcher::ComputeThreeMaxima          ORBmatcher.cc:2012-2053
+ *   Frame::AssignFeaturesToGrid / PosInGrid Frame.cc:385-416, 725-735
+ *   Frame::GetFeaturesInArea                Frame.cc:657-723
+ *   ORBmatcher::SearchByProjection (M1)     ORBmatcher.cc:43-213   (mono form, Nleft == -1)
+ *   ORBmatcher::SearchByProjection (M2)     ORBmatcher.cc:1676-1887 (after the 3-D projection)
+ *   Frame::ComputeStereoMatches (M8)        Frame.cc:811-981
+ *   cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) as used by Frame.cc:1144 (M9) [OCV]
+ */
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+namespace {
+
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30; /* ORBmatcher.cc:35-37 */
+const int GRID_COLS = 64, GRID_ROWS = 48;                /* Frame.h:44-45 */
+
+int descriptor_distance(const uint8_t *a, const uint8_t *b) { /* ORBmatcher.cc:2058-2074, SWAR popcount */
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+void three_maxima(const int *sizes, int L, int &ind1, int &ind2, int &ind3) { /* ORBmatcher.cc:2012-2053 */
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+}  // namespace
+
+struct orbo_grid {
+    float minx, maxx, miny, maxy, inv_w, inv_h;
+    const orbo_keypoint *kps;
+    int n;
+    std::vector<int32_t> cell[GRID_COLS][GRID_ROWS];
+};
+
+namespace {
+
+int grid_query(const orbo_grid *g, float x, float y, float r, int minLevel, int maxLevel, std::vector<int32_t> &out) {
+    out.clear();
+    const float factorX = r, factorY = r; /* Frame.cc:662-663 */
+    const int nMinCellX = std::max(0, (int)std::floor((x - g->minx - factorX) * g->inv_w));
+    if (nMinCellX >= GRID_COLS) return 0;
+    const int nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - g->minx + factorX) * g->inv_w));
+    if (nMaxCellX < 0) return 0;
+    const int nMinCellY = std::max(0, (int)std::floor((y - g->miny - factorY) * g->inv_h));
+    if (nMinCellY >= GRID_ROWS) return 0;
+    const int nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - g->miny + factorY) * g->inv_h));
+    if (nMaxCellY < 0) return 0;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int32_t> &vCell = g->cell[ix][iy];
+            for (int32_t idx : vCell) {
+                const orbo_keypoint &kp = g->kps[idx];
+                if (bCheckLevels) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                const float distx = kp.x - x, disty = kp.y - y;
+                if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) out.push_back(idx);
+            }
+        }
+    return (int)out.size();
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbo_descriptor_distance(const uint8_t *a, const uint8_t *b) { return descriptor_distance(a, b); }
+
+void orbo_three_maxima(const int *sizes, int L, int *ind1, int *ind2, int *ind3) {
+    int a = -1, b = -1, c = -1;
+    three_maxima(sizes, L, a, b, c);
+    *ind1 = a; *ind2 = b; *ind3 = c;
+}
+
+orbo_grid *orbo_grid_create(const orbo_keypoint *kps, int n, float minx, float maxx, float miny, float maxy) {
+    orbo_grid *g = new orbo_grid();
+    g->minx = minx; g->maxx = maxx; g->miny = miny; g->maxy = maxy;
+    g->inv_w = static_cast<float>(GRID_COLS) / (maxx - minx); /* Frame.cc:342-343 */
+    g->inv_h = static_cast<float>(GRID_ROWS) / (maxy - miny);
+    g->kps = kps; g->n = n;
+    for (int i = 0; i < n; i++) { /* Frame.cc:403-415 + PosInGrid :725-735 */
+        int px = (int)std::round((kps[i].x - minx) * g->inv_w);
+        int py = (int)std::round((kps[i].y - miny) * g->inv_h);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        g->cell[px][py].push_back(i);
+    }
+    return g;
+}
+void orbo_grid_destroy(orbo_grid *g) { delete g; }
+
+int orbo_grid_query(const orbo_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out, int cap) {
+    std::vector<int32_t> v;
+    grid_query(g, x, y, r, min_level, max_level, v);
+    for (int i = 0; i < (int)v.size() && i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+
+/* M1, ORBmatcher.cc:43-142 (left / mono branch; Nleft == -1) */
+int orbo_search_by_projection_mappoints(const orbo_grid *grid, const orbo_keypoint *kps, const uint8_t *fdesc, int nF,
+                                        const float *scale_factors, const float *u_right, const uint8_t *occupied,
+                                        int n_mp, const float *proj_x, const float *proj_y, const float *proj_xr,
+                                        const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc,
+                                        const uint8_t *mp_in_view, const uint8_t *mp_has_obs, float th, float nnratio,
+                                        int32_t *frame_match) {
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    std::vector<uint8_t> occ(occupied ? std::vector<uint8_t>(occupied, occupied + nF) : std::vector<uint8_t>(nF, 0));
+    for (int i = 0; i < nF; i++) frame_match[i] = -1;
+    std::vector<int32_t> vIndices;
+    for (int iMP = 0; iMP < n_mp; iMP++) {
+        if (!mp_in_view[iMP]) continue; /* mbTrackInView; isBad / far points are folded into this flag by the caller */
+        const int nPredictedLevel = pred_level[iMP];
+        float r = (view_cos[iMP] > 0.998) ? 2.5f : 4.0f; /* RadiusByViewingCos :215-221 */
+        if (bFactor) r *= th;
+        grid_query(grid, proj_x[iMP], proj_y[iMP], r * scale_factors[nPredictedLevel], nPredictedLevel - 1,
+                   nPredictedLevel, vIndices);
+        if (vIndices.empty()) continue;
+        const uint8_t *MPdescriptor = mp_desc + (size_t)iMP * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int32_t idx : vIndices) {
+            if (occ[idx]) continue; /* F.mvpMapPoints[idx] && Observations()>0 : read-after-write inside the loop */
+            if (u_right && u_right[idx] > 0) {
+                const float er = std::fabs(proj_xr[iMP] - u_right[idx]);
+                if (er > r * scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = descriptor_distance(MPdescriptor, fdesc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = kps[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kps[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                frame_match[bestIdx] = iMP;
+                occ[bestIdx] = mp_has_obs ? mp_has_obs[iMP] : 1;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
+/* M2, ORBmatcher.cc:1676-1887 (mono form), queries = last-frame map points already projected */
+int orbo_search_by_projection_frame(const orbo_grid *grid, const orbo_keypoint *ckps, const uint8_t *cdesc, int nC,
+                                    const float *scale_factors, const float *cur_u_right, const uint8_t *cur_occupied,
+                                    int n_q, const float *q_u, const float *q_v, const float *q_ur,
+                                    const int32_t *q_octave, const float *q_angle, const uint8_t *q_desc,
+                                    const uint8_t *q_has_obs, float th, int mode, int check_orientation,
+                                    int32_t *cur_match) {
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH; /* :1684 -- NB: 1/30, so only bins 0..12 are reachable */
+    std::vector<uint8_t> occ(cur_occupied ? std::vector<uint8_t>(cur_occupied, cur_occupied + nC)
+                                          : std::vector<uint8_t>(nC, 0));
+    for (int i = 0; i < nC; i++) cur_match[i] = -1;
+    std::vector<int32_t> vIndices2;
+    for (int i = 0; i < n_q; i++) {
+        const int nLastOctave = q_octave[i];
+        const float radius = th * scale_factors[nLastOctave];
+        if (mode == 1) grid_query(grid, q_u[i], q_v[i], radius, nLastOctave, -1, vIndices2);
+        else if (mode == 2) grid_query(grid, q_u[i], q_v[i], radius, 0, nLastOctave, vIndices2);
+        else grid_query(grid, q_u[i], q_v[i], radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+        if (vIndices2.empty()) continue;
+        const uint8_t *dMP = q_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int32_t i2 : vIndices2) {
+            if (occ[i2]) continue;
+            if (cur_u_right && cur_u_right[i2] > 0) {
+                const float er = std::fabs(q_ur[i] - cur_u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = descriptor_distance(dMP, cdesc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            cur_match[bestIdx2] = i;
+            occ[bestIdx2] = q_has_obs ? q_has_obs[i] : 1;
+            nmatches++;
+            if (check_orientation) {
+                float rot = q_angle[i] - ckps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) { /* :1865-1884 */
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { cur_match[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+/* M8, Frame.cc:811-981 */
+int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int N, const orbo_keypoint *kr,
+                                const uint8_t *dr, int Nr, const float *scale_factors, const float *inv_scale_factors,
+                                int nlevels, const uint8_t *const *pyr_left, const uint8_t *const *pyr_right,
+                                const int *pyr_w, const int *pyr_h, const size_t *pyr_stride, float bf, float b,
+                                float *u_right, float *depth, int32_t *best_idx_r, int32_t *best_dist) {
+    for (int i = 0; i < N; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = pyr_h[0];
+    std::vector<std::vector<int>> vRowIndices(nRows);
+    for (int iR = 0; iR < Nr; iR++) { /* :824-838 */
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * scale_factors[kr[iR].octave];
+        const int maxr = (int)std::ceil(kpY + r), minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR); /* unguarded in the reference (Appendix A.8) */
+    }
+    const float minZ = b, minD = 0, maxD = bf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    vDistIdx.reserve(N);
+    int nmatched = 0;
+    for (int iL = 0; iL < N; iL++) {
+        if (best_idx_r) best_idx_r[iL] = -1;
+        if (best_dist) best_dist[iL] = TH_HIGH;
+        const orbo_keypoint &kpL = kl[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y, uL = kpL.x;
+        const std::vector<int> &vCandidates = vRowIndices[(int)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        bool any = false;
+        const uint8_t *dL = dl + (size_t)iL * 32;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const int iR = vCandidates[iC];
+            const orbo_keypoint &kpR = kr[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = descriptor_distance(dL, dr + (size_t)iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; any = true; }
+            }
+        }
+        if (any) {
+            if (best_idx_r) best_idx_r[iL] = (int)bestIdxR;
+            if (best_dist) best_dist[iL] = bestDist;
+        }
+        if (bestDist < thOrbDist) { /* :897-964 sub-pixel SAD refinement */
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = inv_scale_factors[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const int lvl = kpL.octave;
+            int bestDistS = INT_MAX, bestincR = 0;
+            std::vector<float> vDists(2 * L + 1);
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= pyr_w[lvl]) continue;
+            const uint8_t *IL = pyr_left[lvl], *IRb = pyr_right[lvl];
+            const size_t sl = pyr_stride[lvl];
+            const int y0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w);
+            for (int incR = -L; incR <= +L; incR++) {
+                const int xr0 = (int)(scaleduR0 + incR - w);
+                int sad = 0; /* cv::norm(IL, IR, NORM_L1) on 8U: exact integer sum */
+                for (int yy = 0; yy < 2 * w + 1; yy++)
+                    for (int xx = 0; xx < 2 * w + 1; xx++)
+                        sad += std::abs((int)IL[(size_t)(y0 + yy) * sl + xl0 + xx] -
+                                        (int)IRb[(size_t)(y0 + yy) * sl + xr0 + xx]);
+                float dist = (float)sad;
+                if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = scale_factors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                depth[iL] = bf / disparity;
+                u_right[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+                nmatched++;
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0; /* the reference indexes an empty vector here */
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        u_right[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+        nmatched--;
+    }
+    return nmatched;
+}
+
+/* M9 [OCV]: BFMatcher(NORM_HAMMING).knnMatch(k=2): ascending train scan, strict '<' insertion => the
+ * lower train index wins ties; Frame.cc:1144 */
+void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist) {
+    for (int i = 0; i < nq; i++) {
+        int d0 = INT_MAX, d1 = INT_MAX, i0 = -1, i1 = -1;
+        for (int j = 0; j < nt; j++) {
+            int d = descriptor_distance(q + (size_t)i * 32, t + (size_t)j * 32);
+            if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+            else if (d < d1) { d1 = d; i1 = j; }
+        }
+        idx[2 * i] = i0; idx[2 * i + 1] = i1;
+        dist[2 * i] = i0 < 0 ? -1 : d0; dist[2 * i + 1] = i1 < 0 ? -1 : d1;
+    }
+}
+
+}  // extern "C"

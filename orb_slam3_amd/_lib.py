@@ -1,0 +1,131 @@
+"""ctypes loader for liborbx.so (the C ABI declared in include/orbx.h).
+
+torch is imported first on purpose: PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's);
+loading liborbx after torch makes both share ONE HIP runtime in the process, which is what lets bench.py use
+torch.distributed (RCCL) for the cross-rank barrier next to our own HIP streams.  There is no CPU fallback:
+a missing or unloadable library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "liborbx.so"
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+ORBX_OK = 0
+ORBX_E_EMPTY = -1
+FLAG_DESC_STRICT = 1
+FLAG_BLUR_OCV440 = 2
+TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        L = lib()
+        msg = L.orbx_status_string(status).decode()
+        detail = L.orbx_last_error().decode()
+        super().__init__(f"{where}: {msg} ({status}) {detail}")
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("flags", C.c_uint32)]
+
+
+class BatchView(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("cap", C.c_int32), ("d_keypoints", C.c_void_p),
+                ("d_descriptors", C.c_void_p), ("d_count", C.c_void_p), ("d_mono_index", C.c_void_p)]
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("keypoints_un", C.c_void_p), ("descriptors", C.c_void_p), ("n", C.c_int32),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("scale_factors", C.c_void_p), ("nlevels", C.c_int32), ("u_right", C.c_void_p)]
+
+
+_lib = None
+
+# every symbol include/orbx.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch_device", "orbx_batch_view_get", "orbx_sync",
+    "orbx_batch_download", "orbx_batch_download_all", "orbx_output_capacity", "orbx_get_level", "orbx_level_size",
+    "orbx_get_level_device", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_scale_tables",
+    "orbx_get_feature_tables", "orbx_debug_level_candidates", "orbx_debug_level_keypoints",
+    "orbx_debug_level_blurred", "orbx_profile_enable", "orbx_profile_read", "orbx_matcher_create",
+    "orbx_matcher_destroy", "orbx_hamming_csr", "orbx_hamming_best2_csr", "orbx_knn2", "orbx_stereo_rowband",
+    "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
+    "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string",
+]
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  liborbx has no CPU fallback.")
+    import torch  # noqa: F401  (see module docstring: share one HIP runtime with torch)
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orbx_last_error.restype = C.c_char_p
+    L.orbx_status_string.restype = C.c_char_p
+    L.orbx_status_string.argtypes = [i32]
+    L.orbx_create.argtypes = [C.POINTER(Params), i32, i32, i32, i32, C.POINTER(vp)]
+    L.orbx_destroy.argtypes = [vp]
+    L.orbx_extract.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, vp, i32, vp, vp]
+    L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, i32, i32]
+    L.orbx_batch_view_get.argtypes = [vp, C.POINTER(BatchView)]
+    L.orbx_sync.argtypes = [vp]
+    L.orbx_batch_download.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+    L.orbx_batch_download_all.argtypes = [vp, vp, vp, vp, vp]
+    L.orbx_output_capacity.argtypes = [vp, i32, i32]
+    L.orbx_get_level.argtypes = [vp, i32, i32, vp, sz]
+    L.orbx_level_size.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.orbx_get_level_device.argtypes = [vp, i32, i32, vp, vp]
+    L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_scale_factor.argtypes = [vp]
+    L.orbx_get_scale_factor.restype = f32
+    L.orbx_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orbx_get_feature_tables.argtypes = [vp, vp, vp]
+    L.orbx_debug_level_candidates.argtypes = [vp, i32, i32, vp, i32]
+    L.orbx_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32]
+    L.orbx_debug_level_blurred.argtypes = [vp, i32, i32, vp, sz]
+    L.orbx_debug_sort_nodes.argtypes = [i32, vp, vp, i32, vp]
+    L.orbx_profile_enable.argtypes = [vp, i32]
+    L.orbx_profile_read.argtypes = [vp, vp, vp, vp, i32]
+    L.orbx_matcher_create.argtypes = [i32, C.POINTER(vp)]
+    L.orbx_matcher_destroy.argtypes = [vp]
+    L.orbx_hamming_csr.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+    L.orbx_hamming_best2_csr.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.orbx_knn2.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.orbx_stereo_rowband.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, f32, f32, vp, vp]
+    L.orbx_compute_stereo_matches.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, f32, f32,
+                                              vp, vp]
+    L.orbx_search_by_projection_mappoints.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, vp,
+                                                      vp, f32, f32, vp]
+    L.orbx_search_by_projection_frame.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, vp, f32,
+                                                  i32, i32, vp]
+    L.orbx_match_consecutive_device.argtypes = [vp, f32, f32, f32, i32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(status: int, where: str) -> int:
+    if status < 0:
+        raise OrbxError(status, where)
+    return status
+
+
+def ptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,519 @@
+// extractor_kernels.hip.h -- hand-written HIP kernels (gfx950, wave64) of the ORB extractor hot path.
+//
+// Stage -> reference function (all line numbers in /root/reference/src/ORBextractor.cc):
+//   k_pyr_base        copyMakeBorder of the input into level 0                 :1188-1191
+//   k_pyr_resize      cv::resize(INTER_LINEAR) level l-1 -> l + REFLECT_101    :1183-1186
+//   k_fast_cells      per-cell cv::FAST(ini) / fallback cv::FAST(min) + NMS    :805-870
+//   k_octree          DistributeOctTree / DivideNode / compareNodes            :480-779
+//   k_finalize        level concatenation + lapping split slots                :1117-1162
+//   k_blur            GaussianBlur 7x7 sigma 2 (fixed point)                   :1132-1133
+//   k_describe        IC_Angle + computeOrbDescriptor + keypoint record        :76-146, 1143-1162
+//
+// Integer pixel / bit work: no MFMA.  Built with -ffp-contract=off; the only fused float ops are the explicit
+// __fmaf_rn / __fma_rn calls that reproduce the reference binary (see k_describe).
+#pragma once
+
+#include "orbx_internal.h"
+
+namespace orbx {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    // [OCV] borderInterpolate(BORDER_REFLECT_101); |p| excursions here are < len
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * len - 2 - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Level 0: copy the input image into the padded level-0 slab, ring = REFLECT_101 of the image.
+// One thread writes 4 consecutive bytes of a padded row (aligned dword store).
+// grid (ceil(pitch/4/256), h+38, B)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo *__restrict__ lv, const uint8_t *__restrict__ img,
+                                                  size_t row_stride, size_t frame_stride, uint8_t *__restrict__ pyr,
+                                                  size_t pyr_frame_stride) {
+    const LevelInfo L = lv[0];
+    const int wi = blockIdx.x * 256 + threadIdx.x;
+    const int py = blockIdx.y;
+    const int f = blockIdx.z;
+    if (wi * 4 >= L.pitch) return;
+    const uint8_t *src = img + (size_t)f * frame_stride;
+    const int sy = reflect101(py - kEdge, L.h);
+    const uint8_t *srow = src + (size_t)sy * row_stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int px = wi * 4 + k - kRingX;  // padded column
+        if (px >= 0 && px < L.w + 2 * kEdge) {
+            const int sx = reflect101(px - kEdge, L.w);
+            out |= (uint32_t)srow[sx] << (8 * k);
+        }
+    }
+    uint8_t *drow = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)py * L.pitch;
+    *reinterpret_cast<uint32_t *>(drow + wi * 4) = out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Level l from level l-1: [OCV] resize INTER_LINEAR 8U (Q11 taps, (b*(H>>4))>>16 vertical form) evaluated at
+// the REFLECT_101-mapped coordinate, so ROI and ring are written in one pass.
+// grid (ceil(pitch/4/256), h+38, B)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict__ lv, int level,
+                                                    const ResizeTap *__restrict__ xtab,
+                                                    const ResizeTap *__restrict__ ytab, uint8_t *__restrict__ pyr,
+                                                    size_t pyr_frame_stride) {
+    const LevelInfo L = lv[level];
+    const LevelInfo P = lv[level - 1];
+    const int wi = blockIdx.x * 256 + threadIdx.x;
+    const int py = blockIdx.y;
+    const int f = blockIdx.z;
+    if (wi * 4 >= L.pitch) return;
+    uint8_t *frame = pyr + (size_t)f * pyr_frame_stride;
+    const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX;  // previous level ROI origin
+    const int ry = reflect101(py - kEdge, L.h);
+    const ResizeTap ty = ytab[L.ytab_off + ry];
+    const int sy0 = min(max(ty.ofs, 0), P.h - 1), sy1 = min(max(ty.ofs + 1, 0), P.h - 1);
+    const uint8_t *S0 = proi + (size_t)sy0 * P.pitch;
+    const uint8_t *S1 = proi + (size_t)sy1 * P.pitch;
+    const int b0 = ty.c0, b1 = ty.c1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int px = wi * 4 + k - kRingX;
+        if (px >= 0 && px < L.w + 2 * kEdge) {
+            const int rx = reflect101(px - kEdge, L.w);
+            const ResizeTap tx = xtab[L.xtab_off + rx];
+            // when ofs+1 == P.w the tap c1 is 0 and the byte read is the (valid) ring pixel
+            const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
+            const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            out |= (uint32_t)v << (8 * k);
+        }
+    }
+    uint8_t *drow = frame + L.off + (size_t)py * L.pitch;
+    *reinterpret_cast<uint32_t *>(drow + wi * 4) = out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FAST-9/16 corner score of one pixel.  [OCV] cornerScore<16>: with d[k] = v - p[k] on the Bresenham circle,
+//   score = max( max_arcs min(d over 9 contiguous), max_arcs min(-d over 9 contiguous) ) - 1
+// and "p is a corner at threshold t"  <=>  score >= t  (SURVEY.md 8c-R2).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
+
+__device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int pp) {
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * pp];
+    d[1] = v - c[3 * pp + 1];
+    d[2] = v - c[2 * pp + 2];
+    d[3] = v - c[pp + 3];
+    d[4] = v - c[3];
+    d[5] = v - c[-pp + 3];
+    d[6] = v - c[-2 * pp + 2];
+    d[7] = v - c[-3 * pp + 1];
+    d[8] = v - c[-3 * pp];
+    d[9] = v - c[-3 * pp - 1];
+    d[10] = v - c[-2 * pp - 2];
+    d[11] = v - c[-pp - 3];
+    d[12] = v - c[-3];
+    d[13] = v - c[pp - 3];
+    d[14] = v - c[2 * pp - 2];
+    d[15] = v - c[3 * pp - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    }
+    int A = -256, B = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        A = max(A, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));  // min over d[k..k+8]
+        B = min(B, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));  // max over d[k..k+8]
+    }
+    return max(A, -B) - 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One workgroup per FAST cell (ORBextractor.cc:805-870).  The cell sub-image [iniX, maxX) x [iniY, maxY) is
+// staged in LDS; scores are computed for its interior (3 px inside), NMS sees only same-cell neighbours (the
+// reference runs cv::FAST on the sub-image, so outside-interior neighbours score 0), then the cell emits
+//   S20 = {survivors with score >= iniTh}  if non-empty, else  S7 = {survivors with score >= minTh}
+// in row-major order into its slot of the frame's candidate slab.
+// grid (total_cells, B), block 256, dynamic LDS: pix tile + score tile
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+                                                    const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                    int32_t *__restrict__ cellcnt, int total_cells,
+                                                    uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
+                                                    int minTh) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int wsum[4];
+    const TileRef t = tiles[blockIdx.x];
+    const int f = blockIdx.y;
+    const LevelInfo L = lv[t.level];
+    const int tid = threadIdx.x;
+    const int cell = t.ti * L.nCols + t.tj;
+    int32_t *cnt_out = cellcnt + (size_t)f * total_cells + L.cell_base + cell;
+
+    const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+    const int iniX = kBorder + t.tj * L.wCell, iniY = kBorder + t.ti * L.hCell;
+    const int maxX = min(iniX + L.wCell + 6, maxBX), maxY = min(iniY + L.hCell + 6, maxBY);
+    const int cols = maxX - iniX, rows = maxY - iniY;
+    const int iw = cols - 6, ih = rows - 6;
+    // :813 / :821 skip rules, plus sub-images too small to have an interior
+    if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || iw <= 0 || ih <= 0) {
+        if (tid == 0) *cnt_out = 0;
+        return;
+    }
+    const int pp = (cols + 3) & ~3;            // LDS pitch of the pixel tile
+    const int sp = iw + 2;                     // pitch of the score tile (1-px zero apron)
+    uint8_t *pix = smem;                       // rows * pp   (later reused as the survivor map, iw*ih)
+    uint8_t *sco = smem + ((rows * pp + 15) & ~15);  // (ih+2) * sp
+
+    const uint8_t *src = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX;
+    for (int i = tid; i < rows * cols; i += 256) {
+        const int r = i / cols, c = i - r * cols;
+        pix[r * pp + c] = src[(size_t)r * L.pitch + c];
+    }
+    for (int i = tid; i < (ih + 2) * sp; i += 256) sco[i] = 0;
+    __syncthreads();
+
+    const int n = iw * ih;
+    for (int i = tid; i < n; i += 256) {
+        const int y = i / iw, x = i - y * iw;
+        int s = fast_score16(pix + (y + 3) * pp + x + 3, pp);
+        s = (s >= minTh) ? s : 0;
+        sco[(y + 1) * sp + x + 1] = (uint8_t)s;
+    }
+    __syncthreads();
+
+    // NMS: strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); survivors keep their score
+    int any_ini = 0;
+    for (int i = tid; i < n; i += 256) {
+        const int y = i / iw, x = i - y * iw;
+        const uint8_t *p = sco + (y + 1) * sp + x + 1;
+        const int s = p[0];
+        const bool keep = s > 0 && s > p[-1] && s > p[1] && s > p[-sp - 1] && s > p[-sp] && s > p[-sp + 1] &&
+                          s > p[sp - 1] && s > p[sp] && s > p[sp + 1];
+        pix[i] = keep ? (uint8_t)s : 0;  // pixel tile is dead now: reuse as survivor map
+        any_ini |= (keep && s >= iniTh);
+    }
+    any_ini = __syncthreads_or(any_ini);
+    const int thr = any_ini ? iniTh : minTh;
+
+    // ordered (row-major) compaction of the selected set into the cell slot
+    uint32_t *slot = cellent + (size_t)f * ent_frame_stride + L.cand_off + (size_t)cell * L.cell_cap;
+    const int lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        int s = 0;
+        if (i < n) s = pix[i];
+        const bool sel = s > 0 && s >= thr;
+        const unsigned long long b = __ballot(sel);
+        if (lane == 0) wsum[wv] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wv; k++) off += wsum[k];
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (sel) {
+            const int rank = off + __popcll(b & ((1ull << lane) - 1ull));
+            const int y = i / iw, x = i - y * iw;
+            if (rank < L.cell_cap) slot[rank] = pack_key(x + 3 + t.tj * L.wCell, y + 3 + t.ti * L.hCell, s);
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *cnt_out = min(base, L.cell_cap);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Quad-tree cull: one wave per (frame, level) emulating DistributeOctTree exactly (sequential list semantics,
+// libstdc++ std::sort replica for the size-ordered expansion).  See octree.hip.h.
+// ---------------------------------------------------------------------------------------------------------
+}  // namespace orbx
+
+#include "octree.hip.h"
+
+namespace orbx {
+
+// ---------------------------------------------------------------------------------------------------------
+// Output slots (ORBextractor.cc:1117-1162): keypoints of all levels in level order; a keypoint whose SCALED x
+// lies in [lap0, lap1] is written from the back (stereoIndex--), the others from the front (monoIndex++).
+// One workgroup per frame.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(const LevelInfo *__restrict__ lv, int nlevels,
+                                                  const uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride,
+                                                  const int32_t *__restrict__ lvlcnt, WorkItem *__restrict__ work,
+                                                  int cap, int32_t *__restrict__ count, int32_t *__restrict__ mono,
+                                                  int lap0, int lap1, int32_t *__restrict__ err) {
+    __shared__ int wsum[4];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int N = 0;
+    for (int l = 0; l < nlevels; l++) N += lvlcnt[f * nlevels + l];
+    if (N > cap) {
+        if (tid == 0) { atomicExch(err, 1); count[f] = 0; mono[f] = 0; }
+        return;
+    }
+    int g0 = 0, monoIdx = 0, stereoIdx = N - 1;
+    const float flap0 = (float)lap0, flap1 = (float)lap1;
+    for (int l = 0; l < nlevels; l++) {
+        const LevelInfo L = lv[l];
+        const int nl = lvlcnt[f * nlevels + l];
+        const uint32_t *src = lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off;
+        for (int i0 = 0; i0 < nl; i0 += 256) {
+            const int i = i0 + tid;
+            uint32_t key = 0;
+            bool valid = i < nl, lap = false;
+            if (valid) {
+                key = src[i];
+                float x = (float)key_x(key);
+                if (l != 0) x = x * L.scale;  // keypoint->pt *= scale (:1150)
+                lap = (x >= flap0 && x <= flap1);
+            }
+            const unsigned long long bl = __ballot(valid && lap), bm = __ballot(valid && !lap);
+            if (lane == 0) wsum[wv] = (__popcll(bl) << 16) | __popcll(bm);
+            __syncthreads();
+            int offl = 0, offm = 0, totl = 0, totm = 0;
+            for (int k = 0; k < 4; k++) {
+                const int v = wsum[k];
+                if (k < wv) { offl += v >> 16; offm += v & 0xffff; }
+                totl += v >> 16; totm += v & 0xffff;
+            }
+            if (valid) {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                int pos;
+                if (lap) pos = stereoIdx - (offl + __popcll(bl & lt));
+                else pos = monoIdx + offm + __popcll(bm & lt);
+                WorkItem w;
+                w.key = key; w.level = l; w.pos = pos;
+                work[(size_t)f * cap + g0 + i] = w;
+            }
+            monoIdx += totm;
+            stereoIdx -= totl;
+            __syncthreads();
+        }
+        g0 += nl;
+    }
+    if (tid == 0) { count[f] = N; mono[f] = monoIdx; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// [OCV] GaussianBlur 7x7 sigma 2 on 8U, fixed-point (Q8 taps, exact 2-D sum, one rounding, saturate).
+// Borders REFLECT_101 of the level itself (the reference blurs a ring-less clone, :1132-1133).
+// Tile 64 x 16 outputs per workgroup; horizontal pass into LDS (u16), vertical pass from LDS.
+// grid (n_blur_tiles, B)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kBlurTW = 64, kBlurTH = 16;
+
+__global__ __launch_bounds__(256) void k_blur(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+                                              const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                              uint8_t *__restrict__ blur, size_t blur_frame_stride, int g0, int g1,
+                                              int g2, int g3) {
+    __shared__ uint8_t pix[(kBlurTH + 6) * (kBlurTW + 8)];
+    __shared__ uint16_t hor[(kBlurTH + 6) * kBlurTW];
+    const TileRef t = tiles[blockIdx.x];
+    const int f = blockIdx.y;
+    const LevelInfo L = lv[t.level];
+    const int tid = threadIdx.x;
+    const int x0 = t.tj * kBlurTW, y0 = t.ti * kBlurTH;
+    const uint8_t *roi = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)kEdge * L.pitch + kRoiX;
+    constexpr int PW = kBlurTW + 8;  // 70 used
+    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
+        const int r = i / (kBlurTW + 6), c = i - r * (kBlurTW + 6);
+        const int sy = reflect101(min(y0 + r - 3, L.h + 2), L.h);  // rows beyond the level are never used
+        const int sx = reflect101(min(x0 + c - 3, L.w + 2), L.w);
+        pix[r * PW + c] = roi[(size_t)sy * L.pitch + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
+        const int r = i / kBlurTW, c = i - r * kBlurTW;
+        const uint8_t *p = pix + r * PW + c;
+        const int s = g0 * (p[0] + p[6]) + g1 * (p[1] + p[5]) + g2 * (p[2] + p[4]) + g3 * p[3];
+        hor[i] = (uint16_t)s;  // <= 255*257
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    const int x = x0 + tx;
+    if (x < L.w) {
+        uint8_t *dst = blur + (size_t)f * blur_frame_stride + L.boff;
+#pragma unroll
+        for (int k = 0; k < kBlurTH / 4; k++) {
+            const int yy = ty * (kBlurTH / 4) + k;
+            const int y = y0 + yy;
+            if (y < L.h) {
+                const uint16_t *h = hor + yy * kBlurTW + tx;
+                const uint32_t s = (uint32_t)g0 * (h[0] + h[6 * kBlurTW]) + (uint32_t)g1 * (h[kBlurTW] + h[5 * kBlurTW]) +
+                                   (uint32_t)g2 * (h[2 * kBlurTW] + h[4 * kBlurTW]) + (uint32_t)g3 * h[3 * kBlurTW];
+                const uint32_t v = (s + 32768u) >> 16;
+                dst[(size_t)y * L.bpitch + x] = (uint8_t)min(v, 255u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// glibc 2.35 sinf / cosf ("fma" ifunc variant: every multiply-add of the double polynomial fused), restated
+// for |x| < 120; bit-identical to the x86-64 libm the reference links against (validated exhaustively on the
+// CPU oracle, which uses the same formulation).  Tables: __sincosf_table.
+// ---------------------------------------------------------------------------------------------------------
+struct SinCosTab {
+    double c0, c1, c2, c3, c4, s1, s2, s3;
+};
+__device__ __forceinline__ float sc_sin_poly(double x, double x2, const SinCosTab &p) {
+    const double x3 = __dmul_rn(x, x2);
+    const double s1 = __fma_rn(x2, p.s3, p.s2);
+    const double x7 = __dmul_rn(x3, x2);
+    const double s = __fma_rn(x3, p.s1, x);
+    return (float)__fma_rn(x7, s1, s);
+}
+__device__ __forceinline__ float sc_cos_poly(double x2, const SinCosTab &p) {
+    const double x4 = __dmul_rn(x2, x2);
+    const double c2 = __fma_rn(x2, p.c4, p.c3);
+    const double c1 = __fma_rn(x2, p.c1, p.c0);
+    const double x6 = __dmul_rn(x4, x2);
+    const double c = __fma_rn(x4, p.c2, c1);
+    return (float)__fma_rn(x6, c2, c);
+}
+__device__ __forceinline__ void glibc_sincosf(float y, float *sn, float *cs) {
+    const SinCosTab T0 = {0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10,
+                          0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
+    const SinCosTab T1 = {-0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10,
+                          -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
+    double x = (double)y;
+    if (top < 0x3f4) {  // |y| < pi/4
+        if (top < 0x398) { *sn = y; *cs = 1.0f; return; }
+        const double x2 = __dmul_rn(x, x);
+        *sn = sc_sin_poly(x, x2, T0);
+        *cs = sc_cos_poly(x2, T0);
+        return;
+    }
+    // |y| < 120: fast range reduction, hpi_inv pre-scaled by 2^24
+    const double r = __dmul_rn(x, 0x1.45F306DC9C883p+23);
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = __fma_rn(-(double)n, 0x1.921FB54442D18p0, x);
+    const double x2 = __dmul_rn(x, x);
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;  // sign[n&3] = {1,-1,-1,1}
+    // sinf: p = table[(n&2)?1:0]; odd n -> cos poly, even n -> sin poly of x*sign
+    // cosf: same table choice; odd n -> sin poly of x*sign, even n -> cos poly
+    if (n & 2) {
+        if (n & 1) { *sn = sc_cos_poly(x2, T1); *cs = sc_sin_poly(__dmul_rn(x, sgn), x2, T1); }
+        else { *sn = sc_sin_poly(__dmul_rn(x, sgn), x2, T1); *cs = sc_cos_poly(x2, T1); }
+    } else {
+        if (n & 1) { *sn = sc_cos_poly(x2, T0); *cs = sc_sin_poly(__dmul_rn(x, sgn), x2, T0); }
+        else { *sn = sc_sin_poly(__dmul_rn(x, sgn), x2, T0); *cs = sc_cos_poly(x2, T0); }
+    }
+}
+
+// [OCV] cv::fastAtan2 (degrees), plain float ops
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
+                p7 = -0.04432655554792128f * scale;
+    const float eps = 2.2204460492503131e-16f;  // (float)DBL_EPSILON
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One wave per keypoint: IC_Angle on the UNBLURRED level (:76-103), steered 256-pair BRIEF on the BLURRED level
+// (:107-146), keypoint record + descriptor written to the final slot.
+//   disc  : 749 (u,v) offsets of the orientation patch, lane-strided, two int32 moments reduced with shuffles
+//   brief : lane i evaluates pattern pairs i, i+64, i+128, i+192; 4 ballots = 4 x u64 = the 32-byte descriptor
+// grid (ceil(cap/4), B), block 256
+// ---------------------------------------------------------------------------------------------------------
+struct DescConst {
+    int8_t disc_u[752], disc_v[752];   // 749 used
+    int8_t pat[1024];                  // bit_pattern_31_ (x0,y0,x1,y1) x 256
+};
+
+__global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ lv, const DescConst *__restrict__ dc,
+                                                  const WorkItem *__restrict__ work, const int32_t *__restrict__ count,
+                                                  int cap, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                  const uint8_t *__restrict__ blur, size_t blur_frame_stride,
+                                                  orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                                  int strict_mul_add) {
+    const int f = blockIdx.y;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= count[f]) return;
+    const WorkItem w = work[(size_t)f * cap + g];
+    const LevelInfo L = lv[w.level];
+    const int kx = key_x(w.key), ky = key_y(w.key);
+
+    // ---- IC_Angle ----
+    const uint8_t *c0 = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + ky) * L.pitch + kRoiX + kx;
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 749; i += 64) {
+        const int u = dc->disc_u[i], v = dc->disc_v[i];
+        const int I = c0[v * L.pitch + u];
+        m10 += u * I;
+        m01 += v * I;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        m10 += __shfl_xor(m10, s);
+        m01 += __shfl_xor(m01, s);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- steered BRIEF ----
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    glibc_sincosf(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
+    const uint8_t *cb = blur + (size_t)f * blur_frame_stride + L.boff + (size_t)ky * L.bpitch + kx;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int p = it * 64 + lane;
+        const float x0 = (float)dc->pat[4 * p], y0 = (float)dc->pat[4 * p + 1];
+        const float x1 = (float)dc->pat[4 * p + 2], y1 = (float)dc->pat[4 * p + 3];
+        float r0, q0, r1, q1;
+        if (strict_mul_add) {
+            r0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
+            q0 = __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
+            r1 = __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
+            q1 = __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
+        } else {  // GCC -O3 -march=native: fma(x, b, y*a), fma(x, a, -(y*b))
+            r0 = __fmaf_rn(x0, b, __fmul_rn(y0, a));
+            q0 = __fmaf_rn(x0, a, -__fmul_rn(y0, b));
+            r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
+            q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
+        }
+        const int t0 = cb[__float2int_rn(r0) * L.bpitch + __float2int_rn(q0)];
+        const int t1 = cb[__float2int_rn(r1) * L.bpitch + __float2int_rn(q1)];
+        bits[it] = __ballot(t0 < t1);
+    }
+    const size_t slot = (size_t)f * cap + w.pos;
+    if (lane < 4) {
+        const unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<unsigned long long *>(desc + slot * 32)[lane] = v;
+    }
+    if (lane == 0) {
+        orbx_keypoint kp;
+        float x = (float)kx, y = (float)ky;
+        if (w.level != 0) { x = __fmul_rn(x, L.scale); y = __fmul_rn(y, L.scale); }
+        kp.x = x; kp.y = y; kp.size = L.size; kp.angle = angle; kp.response = (float)key_s(w.key);
+        kp.octave = w.level; kp.class_id = -1;
+        kps[slot] = kp;
+    }
+}
+
+}  // namespace orbx

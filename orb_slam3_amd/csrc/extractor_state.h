@@ -1,0 +1,84 @@
+// extractor_state.h -- host-side state of an extractor (shared by orbx_extractor.hip and orbx_matcher.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "orbx_internal.h"
+
+namespace orbx {
+
+extern thread_local std::string g_last_error;
+void set_error(const std::string &s);
+
+#define ORBX_HIP(expr)                                                                                 \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            orbx::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+            return ORBX_E_HIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return ORBX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        ORBX_HIP(hipMalloc(&p, need));
+        bytes = need;
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+enum { K_PYR_BASE, K_PYR_RESIZE, K_FAST, K_OCTREE, K_FINALIZE, K_BLUR, K_DESCRIBE, K_MATCH_SCAN, K_MATCH_RESOLVE, K_COUNT };
+
+}  // namespace orbx
+
+struct orbx_extractor {
+    typedef orbx::DevBuf DevBuf;
+    typedef orbx::LevelInfo LevelInfo;
+    enum { K_COUNT = orbx::K_COUNT };
+    orbx_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // T1 tables (ORBextractor.cc:414-468)
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> quota;
+    int umax[16];
+    // geometry of the current configuration
+    int width = 0, height = 0, batch_cap = 0, last_batch = 0;
+    std::vector<LevelInfo> lv;
+    size_t pyr_frame = 0, blur_frame = 0, cand_frame = 0, lvl_frame = 0;
+    int total_cells = 0, cap = 0, max_pool = 0;
+    size_t fast_lds = 0;
+    int n_fast_tiles = 0, n_blur_tiles = 0;
+    // device memory
+    DevBuf d_lv, d_xtab, d_ytab, d_fast_tiles, d_blur_tiles, d_dc;
+    DevBuf d_pyr, d_blur, d_cellcnt, d_cellent, d_keys0, d_keys1, d_lvlkp, d_lvlcnt, d_candtot, d_work;
+    DevBuf d_kps, d_desc, d_count, d_mono, d_err, d_img;
+    DevBuf d_mkey1, d_mkey2, d_mocc, d_mentries, d_mprobs, d_mres, d_mscale;  // batched frame-to-frame matcher scratch
+    // pinned host staging
+    void *h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    // profiling
+    bool profile = false;
+    double prof_ms[K_COUNT] = {0};
+    int64_t prof_n[K_COUNT] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int ensure_stage(size_t bytes) {
+        if (bytes <= h_stage_bytes) return ORBX_OK;
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr; h_stage_bytes = 0;
+        ORBX_HIP(hipHostMalloc(&h_stage, bytes, hipHostMallocDefault));
+        h_stage_bytes = bytes;
+        return ORBX_OK;
+    }
+};
+

@@ -1,0 +1,388 @@
+// matcher_kernels.hip.h -- hand-written HIP kernels (gfx950, wave64) for the Hamming matchers.
+//
+//   k_hamming_csr        DescriptorDistance over a CSR candidate list     /root/reference/src/ORBmatcher.cc:2058-2074
+//   k_hamming_best2_csr  best / second-best per query (first minimum wins) e.g. ORBmatcher.cc:103-119
+//   k_knn2               cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)         Frame.cc:1144
+//   k_stereo_rowband     Hamming stage of Frame::ComputeStereoMatches      Frame.cc:849-894
+//   k_window_best2       GetFeaturesInArea + Hamming scan of the projection matchers (Frame.cc:657-723,
+//                        ORBmatcher.cc:71-119, 1728-1768): candidates enumerated on the fly, ties resolved in the
+//                        reference's candidate order through a packed (dist, cellx, celly, idx) key
+//   k_greedy_resolve     the sequential part of SearchByProjection (taken-mask read-after-write, ratio test,
+//                        rotation histogram) replayed in query order by one wave per frame
+//
+// A descriptor is 4 x u64; distance = 4 x __popcll(a ^ b).  No MFMA: this is bitwise work.
+#pragma once
+
+#include "orbx_internal.h"
+
+namespace orbx {
+
+typedef unsigned long long u64;
+
+struct Desc { u64 w[4]; };
+
+__device__ __forceinline__ Desc load_desc(const uint8_t *p) {
+    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p);  // rows are 32-byte aligned
+    const ulonglong2 a = q[0], b = q[1];
+    Desc d;
+    d.w[0] = a.x; d.w[1] = a.y; d.w[2] = b.x; d.w[3] = b.y;
+    return d;
+}
+__device__ __forceinline__ int hamming(const Desc &a, const Desc &b) {
+    return __popcll(a.w[0] ^ b.w[0]) + __popcll(a.w[1] ^ b.w[1]) + __popcll(a.w[2] ^ b.w[2]) + __popcll(a.w[3] ^ b.w[3]);
+}
+
+constexpr u64 kNoKey = ~0ull;
+
+// keep the two smallest keys
+__device__ __forceinline__ void push2(u64 &k1, u64 &k2, u64 k) {
+    if (k < k1) { k2 = k1; k1 = k; }
+    else if (k < k2) k2 = k;
+}
+__device__ __forceinline__ void wave_min2(u64 &k1, u64 &k2) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const u64 o1 = __shfl_xor(k1, s), o2 = __shfl_xor(k2, s);
+        // merge (k1<=k2) with (o1<=o2): two smallest of the four
+        const u64 lo = k1 < o1 ? k1 : o1;
+        const u64 hi = k1 < o1 ? (k2 < o1 ? k2 : o1) : (o2 < k1 ? o2 : k1);
+        k1 = lo; k2 = hi;
+    }
+}
+__device__ __forceinline__ u64 wave_min1(u64 k) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const u64 o = __shfl_xor(k, s);
+        k = o < k ? o : k;
+    }
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one wave per query; lanes stride the query's candidate list
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hamming_csr(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
+                                                     const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ cand,
+                                                     uint16_t *__restrict__ dist) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (qi >= nq) return;
+    const int b = row_ptr[qi], e = row_ptr[qi + 1];
+    if (b >= e) return;
+    const Desc dq = load_desc(q + (size_t)qi * 32);
+    for (int k = b + lane; k < e; k += 64) dist[k] = (uint16_t)hamming(dq, load_desc(t + (size_t)cand[k] * 32));
+}
+
+__global__ __launch_bounds__(256) void k_hamming_best2_csr(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
+                                                           const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ cand,
+                                                           int32_t *__restrict__ best_pos, int32_t *__restrict__ best_dist,
+                                                           int32_t *__restrict__ second_pos, int32_t *__restrict__ second_dist) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (qi >= nq) return;
+    const int b = row_ptr[qi], e = row_ptr[qi + 1];
+    u64 k1 = kNoKey, k2 = kNoKey;
+    if (b < e) {
+        const Desc dq = load_desc(q + (size_t)qi * 32);
+        for (int k = b + lane; k < e; k += 64) {
+            const int d = hamming(dq, load_desc(t + (size_t)cand[k] * 32));
+            push2(k1, k2, ((u64)d << 32) | (u64)(uint32_t)(k - b));
+        }
+    }
+    wave_min2(k1, k2);
+    if (lane == 0) {
+        best_pos[qi] = k1 == kNoKey ? -1 : (int32_t)(k1 & 0xffffffffu);
+        best_dist[qi] = k1 == kNoKey ? 256 : (int32_t)(k1 >> 32);
+        second_pos[qi] = k2 == kNoKey ? -1 : (int32_t)(k2 & 0xffffffffu);
+        second_dist[qi] = k2 == kNoKey ? 256 : (int32_t)(k2 >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// brute-force kNN-2: one wave per query, train rows staged through LDS in tiles of kKnnTile rows
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kKnnTile = 1024;  // 32 KiB
+
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t, int nt,
+                                              int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
+    __shared__ ulonglong2 tile[kKnnTile * 2];
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    Desc dq;
+    if (qi < nq) dq = load_desc(q + (size_t)qi * 32);
+    u64 k1 = kNoKey, k2 = kNoKey;
+    for (int t0 = 0; t0 < nt; t0 += kKnnTile) {
+        const int n = min(kKnnTile, nt - t0);
+        __syncthreads();
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(t + (size_t)t0 * 32);
+        for (int i = threadIdx.x; i < n * 2; i += 256) tile[i] = src[i];
+        __syncthreads();
+        if (qi < nq) {
+            for (int j = lane; j < n; j += 64) {
+                const ulonglong2 a = tile[2 * j], b = tile[2 * j + 1];
+                const int d = __popcll(dq.w[0] ^ a.x) + __popcll(dq.w[1] ^ a.y) + __popcll(dq.w[2] ^ b.x) + __popcll(dq.w[3] ^ b.y);
+                push2(k1, k2, ((u64)d << 32) | (u64)(uint32_t)(t0 + j));
+            }
+        }
+    }
+    if (qi >= nq) return;
+    wave_min2(k1, k2);
+    if (lane == 0) {
+        idx[2 * qi] = k1 == kNoKey ? -1 : (int32_t)(k1 & 0xffffffffu);
+        dist[2 * qi] = k1 == kNoKey ? -1 : (int32_t)(k1 >> 32);
+        idx[2 * qi + 1] = k2 == kNoKey ? -1 : (int32_t)(k2 & 0xffffffffu);
+        dist[2 * qi + 1] = k2 == kNoKey ? -1 : (int32_t)(k2 >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches, Hamming stage (Frame.cc:824-894).  Right keypoint iR is a candidate of left
+// keypoint iL iff floor(yR - r) <= (int)yL <= ceil(yR + r), r = 2*scale[octaveR] (the row table :828-838),
+// |octaveR - octaveL| <= 1 and uL - maxD <= uR <= uL - minD.  Candidates are visited in iR order with a strict
+// '<' against bestDist = TH_HIGH, so the packed key (dist << 32 | iR) minimum reproduces the result.
+// One wave per left keypoint.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stereo_rowband(const orbx_keypoint *__restrict__ kl, const uint8_t *__restrict__ dl, int nl,
+                                                        const orbx_keypoint *__restrict__ kr, const uint8_t *__restrict__ dr, int nr,
+                                                        const float *__restrict__ scale, int n_rows, float minD, float maxD,
+                                                        int32_t *__restrict__ best_idx, int32_t *__restrict__ best_dist) {
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (iL >= nl) return;
+    const orbx_keypoint kpL = kl[iL];
+    const int row = (int)kpL.y;  // vRowIndices[vL]: float -> index truncation (:856)
+    const float minU = kpL.x - maxD, maxU = kpL.x - minD;
+    u64 best = kNoKey;
+    if (!(maxU < 0) && row >= 0 && row < n_rows) {
+        const Desc dq = load_desc(dl + (size_t)iL * 32);
+        for (int iR = lane; iR < nr; iR += 64) {
+            const orbx_keypoint kpR = kr[iR];
+            const float r = 2.0f * scale[kpR.octave];
+            const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+            if (row < minr || row > maxr) continue;
+            if (kpR.octave < kpL.octave - 1 || kpR.octave > kpL.octave + 1) continue;
+            if (kpR.x >= minU && kpR.x <= maxU) {
+                const int d = hamming(dq, load_desc(dr + (size_t)iR * 32));
+                const u64 k = ((u64)d << 32) | (u64)(uint32_t)iR;
+                best = k < best ? k : best;
+            }
+        }
+    }
+    best = wave_min1(best);
+    if (lane == 0) {
+        const int d = best == kNoKey ? 256 : (int)(best >> 32);
+        if (d < ORBX_TH_HIGH) { best_idx[iL] = (int32_t)(best & 0xffffffffu); best_dist[iL] = d; }
+        else { best_idx[iL] = -1; best_dist[iL] = ORBX_TH_HIGH; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Projection matchers.  A "problem" p is one (query set, current frame) pair; problems are batched along
+// blockIdx.y so that a whole batch of frames is matched in one launch.
+// ---------------------------------------------------------------------------------------------------------
+struct GridParams {  // Frame::mnMinX.., mfGridElementWidthInv.. (Frame.cc:342-343)
+    float minx, miny, inv_w, inv_h;
+};
+
+struct WindowProblem {
+    // current frame
+    const orbx_keypoint *kps;   // undistorted keypoints (mvKeysUn)
+    const uint8_t *desc;
+    const int32_t *n_ptr;       // number of features (device scalar; batches have per-frame counts)
+    const float *u_right;       // mvuRight or NULL
+    const uint8_t *occupied0;   // taken on entry or NULL
+    // queries
+    const float *qx, *qy, *qr;  // window centre and half size
+    const int32_t *qmin, *qmax; // level range passed to GetFeaturesInArea
+    const float *qxr;           // right-coordinate prediction (with u_right) or NULL
+    const uint8_t *qdesc;
+    const uint8_t *qvalid;      // skip query when 0 (NULL = all valid)
+    const int32_t *nq_ptr;
+    // derived-query mode (consecutive frames): when q_from_kps != NULL the query i is keypoint i of that frame:
+    // centre = kp + (du,dv), radius = th*scale[octave], levels [o-1,o+1], descriptor q_from_desc
+    const orbx_keypoint *q_from_kps;
+    const float *scale;         // mvScaleFactors
+    float th, du, dv;
+    // outputs
+    u64 *key1, *key2;           // per query: two smallest candidate keys (kNoKey = none)
+};
+
+// candidate key: dist << 32 | cellx << 24 | celly << 16 | idx   (candidate order of GetFeaturesInArea: ix outer,
+// iy inner, insertion (= ascending idx) inside a cell; first minimum wins)
+__device__ __forceinline__ u64 cand_key(int dist, int cx, int cy, int idx) {
+    return ((u64)(uint32_t)dist << 32) | ((u64)(uint32_t)cx << 24) | ((u64)(uint32_t)cy << 16) | (u64)(uint32_t)idx;
+}
+
+struct QueryWin {
+    float x, y, r, xr;
+    int minL, maxL, cx0, cx1, cy0, cy1;
+    bool check_levels, empty;
+};
+
+__device__ __forceinline__ QueryWin make_window(const GridParams &g, float x, float y, float r, int minL, int maxL, float xr) {
+    QueryWin w;
+    w.x = x; w.y = y; w.r = r; w.xr = xr; w.minL = minL; w.maxL = maxL;
+    // Frame::GetFeaturesInArea :665-687
+    w.cx0 = max(0, (int)floorf((x - g.minx - r) * g.inv_w));
+    w.cx1 = min(63, (int)ceilf((x - g.minx + r) * g.inv_w));
+    w.cy0 = max(0, (int)floorf((y - g.miny - r) * g.inv_h));
+    w.cy1 = min(47, (int)ceilf((y - g.miny + r) * g.inv_h));
+    w.empty = (w.cx0 >= 64) || (w.cx1 < 0) || (w.cy0 >= 48) || (w.cy1 < 0);
+    w.check_levels = (minL > 0) || (maxL >= 0);
+    return w;
+}
+
+// returns true and the candidate's grid cell if keypoint kp is returned by GetFeaturesInArea for window w
+__device__ __forceinline__ bool in_window(const GridParams &g, const QueryWin &w, const orbx_keypoint &kp, int *cx, int *cy) {
+    // AssignFeaturesToGrid / PosInGrid :725-735
+    const int px = (int)roundf((kp.x - g.minx) * g.inv_w), py = (int)roundf((kp.y - g.miny) * g.inv_h);
+    if (px < 0 || px >= 64 || py < 0 || py >= 48) return false;
+    if (px < w.cx0 || px > w.cx1 || py < w.cy0 || py > w.cy1) return false;
+    if (w.check_levels) {
+        if (kp.octave < w.minL) return false;
+        if (w.maxL >= 0 && kp.octave > w.maxL) return false;
+    }
+    const float dx = kp.x - w.x, dy = kp.y - w.y;
+    if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) return false;
+    *cx = px; *cy = py;
+    return true;
+}
+
+__device__ __forceinline__ bool load_query(const WindowProblem &P, int qi, QueryWin *w, const GridParams &g, Desc *dq) {
+    if (P.qvalid && !P.qvalid[qi]) return false;
+    if (P.q_from_kps) {
+        const orbx_keypoint k = P.q_from_kps[qi];
+        const float radius = P.th * P.scale[k.octave];
+        *w = make_window(g, k.x + P.du, k.y + P.dv, radius, k.octave - 1, k.octave + 1, 0.f);
+    } else {
+        *w = make_window(g, P.qx[qi], P.qy[qi], P.qr[qi], P.qmin[qi], P.qmax[qi], P.qxr ? P.qxr[qi] : 0.f);
+    }
+    *dq = load_desc(P.qdesc + (size_t)qi * 32);
+    return !w->empty;
+}
+
+// scan all features of the current frame for query window w; skip features flagged in `occ` (may be NULL)
+__device__ __forceinline__ void scan_window(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
+                                            const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
+    for (int i = lane; i < n; i += 64) {
+        if (occ && occ[i]) continue;
+        const orbx_keypoint kp = P.kps[i];
+        int cx, cy;
+        if (!in_window(g, w, kp, &cx, &cy)) continue;
+        if (P.u_right && P.u_right[i] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
+            const float er = fabsf(w.xr - P.u_right[i]);
+            if (er > w.r) continue;
+        }
+        const int d = hamming(dq, load_desc(P.desc + (size_t)i * 32));
+        push2(k1, k2, cand_key(d, cx, cy, i));
+    }
+}
+
+// grid (ceil(max_q/4), n_problems), block 256: one wave per query
+__global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__restrict__ probs, GridParams g) {
+    const WindowProblem P = probs[blockIdx.y];
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (qi >= *P.nq_ptr) return;
+    QueryWin w;
+    Desc dq;
+    u64 k1 = kNoKey, k2 = kNoKey;
+    if (load_query(P, qi, &w, g, &dq)) {
+        scan_window(P, g, w, dq, *P.n_ptr, P.occupied0, lane, k1, k2);
+        wave_min2(k1, k2);
+    }
+    if (lane == 0) { P.key1[qi] = k1; P.key2[qi] = k2; }
+}
+
+struct ResolveProblem {
+    int mode;                 // 1 = SearchByProjection(Frame, MapPoints) (M1), 2 = SearchByProjection(Cur, Last) (M2)
+    float nnratio;            // M1
+    int check_orientation;    // M2
+    const float *q_angle;     // M2 (NULL with q_from_kps)
+    const uint8_t *q_has_obs; // NULL = all true
+    int32_t *match;           // [n] query index per feature or -1
+    int32_t *nmatches;        // scalar out
+    uint8_t *occ;             // [n] scratch: occupancy during the replay
+    int32_t *entries;         // [nq] scratch: rotation histogram entries bin << 16 | feature (M2)
+};
+
+// one wave per problem: sequential replay in query order; rescans a query's window only when one of its
+// two best candidates was taken by an earlier query.
+__global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
+                                                       GridParams g) {
+    __shared__ int hist[ORBX_HISTO_LENGTH];
+    const WindowProblem P = probs[blockIdx.x];
+    const ResolveProblem R = res[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = *P.n_ptr, nq = *P.nq_ptr;
+    for (int i = lane; i < n; i += 64) {
+        R.occ[i] = P.occupied0 ? P.occupied0[i] : 0;
+        R.match[i] = -1;
+    }
+    if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0, n_entries = 0;
+    const float factor = 1.0f / ORBX_HISTO_LENGTH;
+    for (int qi = 0; qi < nq; qi++) {
+        u64 k1 = P.key1[qi], k2 = P.key2[qi];
+        if (k1 == kNoKey) continue;
+        const int i1 = (int)(k1 & 0xffff), i2 = (k2 == kNoKey) ? -1 : (int)(k2 & 0xffff);
+        const bool stale = R.occ[i1] || (R.mode == 1 && i2 >= 0 && R.occ[i2]);
+        if (stale) {  // rare: redo this query's scan against the current occupancy
+            QueryWin w;
+            Desc dq;
+            k1 = kNoKey; k2 = kNoKey;
+            if (load_query(P, qi, &w, g, &dq)) {
+                scan_window(P, g, w, dq, n, R.occ, lane, k1, k2);
+                wave_min2(k1, k2);
+            }
+            if (k1 == kNoKey) continue;
+        }
+        const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xffff);
+        if (bestDist > ORBX_TH_HIGH) continue;
+        if (R.mode == 1) {
+            // ORBmatcher.cc:123-139: ratio test only when best and second-best share the octave
+            const int bestDist2 = (k2 == kNoKey) ? 256 : (int)(k2 >> 32);
+            const int bestLevel = P.kps[bestIdx].octave;
+            const int bestLevel2 = (k2 == kNoKey) ? -1 : P.kps[(int)(k2 & 0xffff)].octave;
+            if (bestLevel == bestLevel2 && (float)bestDist > R.nnratio * (float)bestDist2) continue;
+            if (!(bestLevel != bestLevel2 || (float)bestDist <= R.nnratio * (float)bestDist2)) continue;
+        }
+        if (lane == 0) {
+            R.match[bestIdx] = qi;
+            R.occ[bestIdx] = R.q_has_obs ? R.q_has_obs[qi] : 1;
+            if (R.mode == 2 && R.check_orientation) {  // :1775-1792
+                const float qa = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
+                float rot = qa - P.kps[bestIdx].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int b = (int)roundf(rot * factor);
+                if (b == ORBX_HISTO_LENGTH) b = 0;
+                R.entries[n_entries] = (b << 16) | bestIdx;  // rotHist[bin].push_back(bestIdx2)
+                hist[b]++;
+            }
+        }
+        nmatches++;
+        if (R.mode == 2 && R.check_orientation) n_entries++;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (R.mode == 2 && R.check_orientation) {
+        // ComputeThreeMaxima :2012-2053
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        // :1871-1881: every entry of a rejected bin clears its feature and decrements nmatches
+        for (int e = lane; e < n_entries; e += 64) {
+            const int v = R.entries[e], b = v >> 16;
+            if (b != ind1 && b != ind2 && b != ind3) R.match[v & 0xffff] = -1;
+        }
+        int dropped = 0;
+        for (int i = 0; i < ORBX_HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3) dropped += hist[i];
+        nmatches -= dropped;
+    }
+    if (lane == 0) *R.nmatches = nmatches;
+}
+
+}  // namespace orbx

@@ -1,0 +1,587 @@
+// orbx_extractor.hip -- host side of the extractor: tables (ORBextractor ctor), workspace layout in HBM,
+// kernel launch sequence on the extractor's HIP stream, and the C ABI of include/orbx.h.
+//
+// HBM layout per extractor for a (width, height, batch) configuration, all slabs frame-major:
+//   pyr    [B][pyr_frame]   8 padded levels; row = 45 B slack | 19 B ring | w ROI | 19 B ring | pad to 64 B
+//   blur   [B][blur_frame]  8 blurred levels (no ring), 64-B pitched rows
+//   cellcnt[B][cells]       FAST survivors per cell          cellent[B][cand] per-cell slots (packed keys)
+//   keys0/1[B][cand]        quad-tree ping-pong key buffers   lvlkp [B][lvl]  selected keypoints per level
+//   work   [B][cap]         keypoints in level order + output slot
+//   kps    [B][cap] (28 B)  desc [B][cap][32]  count[B] mono[B]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "extractor_kernels.hip.h"
+#include "extractor_state.h"
+
+namespace orbx {
+
+thread_local std::string g_last_error;
+
+void set_error(const std::string &s) { g_last_error = s; }
+
+static const int8_t kPatternData[1024] = {
+#include "orb_pattern.inc"
+};
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+
+static const char *kKernelNames[K_COUNT] = {"k_pyr_base", "k_pyr_resize", "k_fast_cells", "k_octree", "k_finalize",
+                                            "k_blur", "k_describe", "k_window_best2", "k_greedy_resolve"};
+
+}  // namespace orbx
+
+using namespace orbx;
+
+namespace orbx {
+
+static int configure(orbx_extractor *ex, int width, int height, int batch) {
+    if (width > kMaxDim || height > kMaxDim) return ORBX_E_TOO_LARGE;
+    const bool same_geom = (width == ex->width && height == ex->height);
+    if (same_geom && batch <= ex->batch_cap) return ORBX_OK;
+    const int nl = ex->prm.nlevels;
+    std::vector<LevelInfo> lv(nl);
+    std::vector<ResizeTap> xtab, ytab;
+    std::vector<TileRef> fast_tiles, blur_tiles;
+    size_t pyr_off = 0, blur_off = 0;
+    uint32_t cand_off = 0, lvl_off = 0;
+    int cell_base = 0, cap = 0, max_pool = 0;
+    size_t fast_lds = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelInfo &L = lv[l];
+        memset(&L, 0, sizeof(L));
+        // ComputePyramid :1174-1175
+        L.w = cv_round_f((float)width * ex->inv_scale[l]);
+        L.h = cv_round_f((float)height * ex->inv_scale[l]);
+        const float fw = (float)(L.w - 2 * kBorder), fh = (float)(L.h - 2 * kBorder);
+        if (fw < 35.f || fh < 35.f) return ORBX_E_TOO_SMALL;
+        L.pitch = (kRoiX + L.w + kEdge + 63) & ~63;
+        L.bpitch = (L.w + 63) & ~63;
+        L.off = pyr_off;
+        pyr_off += (size_t)L.pitch * (L.h + 2 * kEdge);
+        pyr_off = (pyr_off + 255) & ~(size_t)255;
+        L.boff = blur_off;
+        blur_off += (size_t)L.bpitch * L.h;
+        blur_off = (blur_off + 255) & ~(size_t)255;
+        // ComputeKeyPointsOctTree :794-803
+        const float W = 35;
+        L.nCols = (int)(fw / W);
+        L.nRows = (int)(fh / W);
+        L.wCell = (int)std::ceil(fw / L.nCols);
+        L.hCell = (int)std::ceil(fh / L.nRows);
+        L.cell_base = cell_base;
+        cell_base += L.nCols * L.nRows;
+        // NMS survivors are pairwise non-adjacent => at most ceil(w/2)*ceil(h/2) per cell
+        L.cell_cap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+        L.cand_off = cand_off;
+        L.cand_cap = (uint32_t)(L.nCols * L.nRows * L.cell_cap);
+        cand_off += (L.cand_cap + 63u) & ~63u;
+        L.quota = ex->quota[l];
+        // DistributeOctTree :559-560
+        L.nIni = (int)std::round((float)(L.w - 2 * kBorder) / (float)(L.h - 2 * kBorder));
+        if (L.nIni < 1) return ORBX_E_TOO_SMALL;  // the reference divides by zero for such aspect ratios
+        L.hX = (float)(L.w - 2 * kBorder) / L.nIni;
+        L.lvl_cap = std::max(L.quota + 4, 4 * L.nIni) + 4;
+        L.pool = std::max(L.quota, 4 * L.nIni) + 16;
+        if (L.pool >= 0xfff0) return ORBX_E_TOO_LARGE;
+        max_pool = std::max(max_pool, L.pool);
+        L.lvl_off = lvl_off;
+        lvl_off += (uint32_t)((L.lvl_cap + 63) & ~63);
+        cap += L.lvl_cap;
+        L.scale = ex->scale[l];
+        L.size = (float)(int)(kPatch * ex->scale[l]);  // :880
+        // resize tables ([OCV] resize INTER_LINEAR 8U), from level l-1
+        L.xtab_off = (uint32_t)xtab.size();
+        L.ytab_off = (uint32_t)ytab.size();
+        if (l > 0) {
+            const LevelInfo &P = lv[l - 1];
+            auto build = [](int ssize, int dsize, bool horizontal, std::vector<ResizeTap> &out) {
+                const double inv = (double)dsize / ssize;
+                const double sc = 1. / inv;
+                for (int d = 0; d < dsize; d++) {
+                    float fx = (float)((d + 0.5) * sc - 0.5);
+                    int s = (int)std::floor(fx);
+                    fx -= s;
+                    if (horizontal) {
+                        if (s < 0) { fx = 0; s = 0; }
+                        if (s >= ssize - 1) { fx = 0; s = ssize - 1; }
+                    }
+                    ResizeTap t;
+                    t.ofs = s;
+                    t.c0 = (int16_t)std::min(std::max(cv_round_f((1.f - fx) * 2048.f), -32768), 32767);
+                    t.c1 = (int16_t)std::min(std::max(cv_round_f(fx * 2048.f), -32768), 32767);
+                    out.push_back(t);
+                }
+            };
+            build(P.w, L.w, true, xtab);
+            build(P.h, L.h, false, ytab);
+        }
+        for (int i = 0; i < L.nRows; i++)
+            for (int j = 0; j < L.nCols; j++) fast_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
+        for (int i = 0; i < (L.h + kBlurTH - 1) / kBlurTH; i++)
+            for (int j = 0; j < (L.w + kBlurTW - 1) / kBlurTW; j++)
+                blur_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
+        const int cols = L.wCell + 6, rows = L.hCell + 6;
+        const size_t lds = (((size_t)rows * ((cols + 3) & ~3) + 15) & ~(size_t)15) + (size_t)(L.hCell + 2) * (L.wCell + 2) + 16;
+        fast_lds = std::max(fast_lds, lds);
+    }
+    if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
+
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    const int B = std::max(batch, ex->batch_cap);
+    int r;
+#define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
+    ENS(ex->d_lv, sizeof(LevelInfo) * nl);
+    ENS(ex->d_xtab, sizeof(ResizeTap) * std::max<size_t>(xtab.size(), 1));
+    ENS(ex->d_ytab, sizeof(ResizeTap) * std::max<size_t>(ytab.size(), 1));
+    ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
+    ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
+    ENS(ex->d_pyr, pyr_off * B);
+    ENS(ex->d_blur, blur_off * B);
+    ENS(ex->d_cellcnt, sizeof(int32_t) * (size_t)cell_base * B);
+    ENS(ex->d_cellent, sizeof(uint32_t) * (size_t)cand_off * B);
+    ENS(ex->d_keys0, sizeof(uint32_t) * (size_t)cand_off * B);
+    ENS(ex->d_keys1, sizeof(uint32_t) * (size_t)cand_off * B);
+    ENS(ex->d_lvlkp, sizeof(uint32_t) * (size_t)lvl_off * B);
+    ENS(ex->d_lvlcnt, sizeof(int32_t) * (size_t)nl * B);
+    ENS(ex->d_candtot, sizeof(int32_t) * (size_t)nl * B);
+    ENS(ex->d_work, sizeof(WorkItem) * (size_t)cap * B);
+    ENS(ex->d_kps, sizeof(orbx_keypoint) * (size_t)cap * B);
+    ENS(ex->d_desc, (size_t)32 * cap * B);
+    ENS(ex->d_count, sizeof(int32_t) * (size_t)B);
+    ENS(ex->d_mono, sizeof(int32_t) * (size_t)B);
+    ENS(ex->d_err, sizeof(int32_t));
+#undef ENS
+    ORBX_HIP(hipMemcpy(ex->d_lv.p, lv.data(), sizeof(LevelInfo) * nl, hipMemcpyHostToDevice));
+    if (!xtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xtab.p, xtab.data(), sizeof(ResizeTap) * xtab.size(), hipMemcpyHostToDevice));
+    if (!ytab.empty()) ORBX_HIP(hipMemcpy(ex->d_ytab.p, ytab.data(), sizeof(ResizeTap) * ytab.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(ex->d_blur_tiles.p, blur_tiles.data(), sizeof(TileRef) * blur_tiles.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
+    ex->lv = lv;
+    ex->width = width; ex->height = height; ex->batch_cap = B;
+    ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
+    ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds;
+    ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size();
+    ex->last_batch = 0;
+    return ORBX_OK;
+}
+
+struct ProfScope {
+    orbx_extractor *ex;
+    int k;
+    ProfScope(orbx_extractor *e, int kernel) : ex(e), k(kernel) {
+        if (ex->profile) (void)hipEventRecord(ex->ev0, ex->stream);
+    }
+    ~ProfScope() {
+        if (ex->profile) {
+            (void)hipEventRecord(ex->ev1, ex->stream);
+            (void)hipEventSynchronize(ex->ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ex->ev0, ex->ev1);
+            ex->prof_ms[k] += ms;
+            ex->prof_n[k] += 1;
+        }
+    }
+};
+
+// enqueue the whole extraction of `n` device-resident frames on ex->stream
+static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride,
+                           int lap0, int lap1) {
+    const int nl = ex->prm.nlevels;
+    const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
+    uint8_t *pyr = (uint8_t *)ex->d_pyr.p;
+    hipStream_t st = ex->stream;
+    {
+        ProfScope ps(ex, K_PYR_BASE);
+        const LevelInfo &L = ex->lv[0];
+        dim3 grid((L.pitch / 4 + 255) / 256, L.h + 2 * kEdge, n);
+        hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, d_lv, d_images, row_stride, frame_stride, pyr, ex->pyr_frame);
+    }
+    for (int l = 1; l < nl; l++) {
+        ProfScope ps(ex, K_PYR_RESIZE);
+        const LevelInfo &L = ex->lv[l];
+        dim3 grid((L.pitch / 4 + 255) / 256, L.h + 2 * kEdge, n);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, d_lv, l, (const ResizeTap *)ex->d_xtab.p,
+                           (const ResizeTap *)ex->d_ytab.p, pyr, ex->pyr_frame);
+    }
+    {
+        ProfScope ps(ex, K_BLUR);
+        static const int kNew[4] = {18, 34, 48, 56}, kOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
+        const int *g = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kOld : kNew;
+        hipLaunchKernelGGL(k_blur, dim3(ex->n_blur_tiles, n), dim3(256), 0, st, d_lv, (const TileRef *)ex->d_blur_tiles.p,
+                           (const uint8_t *)pyr, ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, g[0], g[1], g[2], g[3]);
+    }
+    {
+        ProfScope ps(ex, K_FAST);
+        const int ini = std::min(std::max(ex->prm.ini_th_fast, 0), 255), mn = std::min(std::max(ex->prm.min_th_fast, 0), 255);
+        hipLaunchKernelGGL(k_fast_cells, dim3(ex->n_fast_tiles, n), dim3(256), ex->fast_lds, st, d_lv,
+                           (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,
+                           ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn);
+    }
+    {
+        ProfScope ps(ex, K_OCTREE);
+        hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), oct_lds_bytes(ex->max_pool), st, d_lv,
+                           (const int32_t *)ex->d_cellcnt.p, ex->total_cells, (const uint32_t *)ex->d_cellent.p, ex->cand_frame,
+                           (uint32_t *)ex->d_keys0.p, (uint32_t *)ex->d_keys1.p, (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame,
+                           (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p);
+    }
+    {
+        ProfScope ps(ex, K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize, dim3(n), dim3(256), 0, st, d_lv, nl, (const uint32_t *)ex->d_lvlkp.p, ex->lvl_frame,
+                           (const int32_t *)ex->d_lvlcnt.p, (WorkItem *)ex->d_work.p, ex->cap, (int32_t *)ex->d_count.p,
+                           (int32_t *)ex->d_mono.p, lap0, lap1, (int32_t *)ex->d_err.p);
+    }
+    {
+        ProfScope ps(ex, K_DESCRIBE);
+        hipLaunchKernelGGL(k_describe, dim3((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
+                           (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
+                           ex->pyr_frame, (const uint8_t *)ex->d_blur.p, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
+                           (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0);
+    }
+    ORBX_HIP(hipGetLastError());
+    ex->last_batch = n;
+    return ORBX_OK;
+}
+
+static int check_device_error(orbx_extractor *ex) {
+    int32_t e = 0;
+    ORBX_HIP(hipMemcpyAsync(&e, ex->d_err.p, sizeof(e), hipMemcpyDeviceToHost, ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    if (e != 0) {
+        set_error("device-side consistency check failed, code " + std::to_string(e));
+        (void)hipMemsetAsync(ex->d_err.p, 0, sizeof(int32_t), ex->stream);
+        return ORBX_E_INTERNAL;
+    }
+    return ORBX_OK;
+}
+
+}  // namespace orbx
+
+extern "C" {
+
+const char *orbx_last_error(void) { return g_last_error.c_str(); }
+
+const char *orbx_status_string(int s) {
+    switch (s) {
+        case ORBX_OK: return "ok";
+        case ORBX_E_EMPTY: return "empty image";
+        case ORBX_E_BAD_ARG: return "bad argument";
+        case ORBX_E_TOO_SMALL: return "image too small for the pyramid";
+        case ORBX_E_CAPACITY: return "output capacity too small";
+        case ORBX_E_NO_DEVICE: return "no usable HIP device";
+        case ORBX_E_HIP: return "HIP runtime error";
+        case ORBX_E_TOO_LARGE: return "image or batch too large";
+        case ORBX_E_INTERNAL: return "internal device-side check failed";
+        default: return s > 0 ? "ok" : "unknown error";
+    }
+}
+
+int orbx_create(const orbx_params *p, int device, int max_width, int max_height, int max_batch, orbx_extractor **out) {
+    if (!p || !out) return ORBX_E_BAD_ARG;
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > kMaxLevels || p->nfeatures < 1 || !(p->scale_factor > 1.0f)) return ORBX_E_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        set_error("no usable HIP device (liborbx has no CPU fallback)");
+        return ORBX_E_NO_DEVICE;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    orbx_extractor *ex = new orbx_extractor();
+    ex->prm = *p;
+    ex->device = device;
+    const int nl = p->nlevels;
+    // ---- ORBextractor ctor :414-445 ----
+    const double scaleFactor = p->scale_factor;  // the member is a double (ORBextractor.h:94)
+    ex->scale.resize(nl); ex->sigma2.resize(nl); ex->inv_scale.resize(nl); ex->inv_sigma2.resize(nl); ex->quota.resize(nl);
+    ex->scale[0] = 1.0f; ex->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) {
+        ex->scale[i] = (float)(ex->scale[i - 1] * scaleFactor);
+        ex->sigma2[i] = ex->scale[i] * ex->scale[i];
+    }
+    for (int i = 0; i < nl; i++) {
+        ex->inv_scale[i] = 1.0f / ex->scale[i];
+        ex->inv_sigma2[i] = 1.0f / ex->sigma2[i];
+    }
+    const float factor = (float)(1.0f / scaleFactor);
+    float desired = p->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        ex->quota[l] = cv_round_f(desired);
+        sum += ex->quota[l];
+        desired *= factor;
+    }
+    ex->quota[nl - 1] = std::max(p->nfeatures - sum, 0);
+    // ---- umax :453-468 ----
+    {
+        int v, v0;
+        const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+        const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+        const double hp2 = kHalfPatch * kHalfPatch;
+        for (v = 0; v < 16; v++) ex->umax[v] = 0;
+        for (v = 0; v <= vmax; ++v) ex->umax[v] = cv_round_d(std::sqrt(hp2 - v * v));
+        for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+            while (ex->umax[v0] == ex->umax[v0 + 1]) ++v0;
+            ex->umax[v] = v0;
+            ++v0;
+        }
+    }
+    hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); delete ex; return ORBX_E_HIP; }
+    (void)hipEventCreate(&ex->ev0);
+    (void)hipEventCreate(&ex->ev1);
+    // descriptor constants: orientation disc offsets + BRIEF pattern
+    DescConst dc;
+    memset(&dc, 0, sizeof(dc));
+    int n = 0;
+    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
+        const int d = ex->umax[std::abs(v)];
+        for (int u = -d; u <= d; u++) { dc.disc_u[n] = (int8_t)u; dc.disc_v[n] = (int8_t)v; n++; }
+    }
+    if (n != 749) { set_error("orientation disc has " + std::to_string(n) + " pixels"); orbx_destroy(ex); return ORBX_E_INTERNAL; }
+    memcpy(dc.pat, kPatternData, 1024);
+    int r = ex->d_dc.ensure(sizeof(DescConst));
+    if (r != ORBX_OK) { orbx_destroy(ex); return r; }
+    if (hipMemcpy(ex->d_dc.p, &dc, sizeof(dc), hipMemcpyHostToDevice) != hipSuccess) { orbx_destroy(ex); return ORBX_E_HIP; }
+    if (max_width > 0 && max_height > 0) {
+        r = configure(ex, max_width, max_height, std::max(max_batch, 1));
+        if (r != ORBX_OK) { orbx_destroy(ex); return r; }
+    }
+    *out = ex;
+    return ORBX_OK;
+}
+
+void orbx_destroy(orbx_extractor *ex) {
+    if (!ex) return;
+    (void)hipSetDevice(ex->device);
+    if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
+                      &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_lvlkp, &ex->d_lvlcnt,
+                      &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
+                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale};
+    for (DevBuf *b : bufs) b->release();
+    if (ex->h_stage) (void)hipHostFree(ex->h_stage);
+    if (ex->ev0) (void)hipEventDestroy(ex->ev0);
+    if (ex->ev1) (void)hipEventDestroy(ex->ev1);
+    if (ex->stream) (void)hipStreamDestroy(ex->stream);
+    delete ex;
+}
+
+int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int n_frames, int width, int height,
+                              size_t row_stride, size_t frame_stride, int lap0, int lap1) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    if (!d_images || width <= 0 || height <= 0 || n_frames <= 0) return ORBX_E_EMPTY;
+    if (row_stride < (size_t)width) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    int r = configure(ex, width, height, n_frames);
+    if (r != ORBX_OK) return r;
+    return enqueue_extract(ex, d_images, n_frames, row_stride, frame_stride, lap0, lap1);
+}
+
+int orbx_output_capacity(orbx_extractor *ex, int width, int height) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    if (hipSetDevice(ex->device) != hipSuccess) return ORBX_E_HIP;
+    int r = configure(ex, width, height, std::max(ex->batch_cap, 1));
+    if (r != ORBX_OK) return r;
+    return ex->cap;
+}
+
+int orbx_sync(orbx_extractor *ex) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    return ORBX_OK;
+}
+
+int orbx_batch_view_get(orbx_extractor *ex, orbx_batch_view *v) {
+    if (!ex || !v) return ORBX_E_BAD_ARG;
+    v->n_frames = ex->last_batch;
+    v->cap = ex->cap;
+    v->d_keypoints = (const orbx_keypoint *)ex->d_kps.p;
+    v->d_descriptors = (const uint8_t *)ex->d_desc.p;
+    v->d_count = (const int32_t *)ex->d_count.p;
+    v->d_mono_index = (const int32_t *)ex->d_mono.p;
+    return ORBX_OK;
+}
+
+int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, int *mono) {
+    if (!ex || frame < 0 || frame >= ex->last_batch) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    int r = check_device_error(ex);
+    if (r != ORBX_OK) return r;
+    int32_t cm[2];
+    ORBX_HIP(hipMemcpyAsync(&cm[0], (int32_t *)ex->d_count.p + frame, 4, hipMemcpyDeviceToHost, ex->stream));
+    ORBX_HIP(hipMemcpyAsync(&cm[1], (int32_t *)ex->d_mono.p + frame, 4, hipMemcpyDeviceToHost, ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    if (n_out) *n_out = cm[0];
+    if (mono) *mono = cm[1];
+    if (cm[0] > cap) return ORBX_E_CAPACITY;
+    if (cm[0] > 0) {
+        if (kps) ORBX_HIP(hipMemcpyAsync(kps, (orbx_keypoint *)ex->d_kps.p + (size_t)frame * ex->cap, sizeof(orbx_keypoint) * cm[0], hipMemcpyDeviceToHost, ex->stream));
+        if (desc) ORBX_HIP(hipMemcpyAsync(desc, (uint8_t *)ex->d_desc.p + (size_t)frame * ex->cap * 32, (size_t)32 * cm[0], hipMemcpyDeviceToHost, ex->stream));
+        ORBX_HIP(hipStreamSynchronize(ex->stream));
+    }
+    return ORBX_OK;
+}
+
+int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts, int32_t *mono) {
+    if (!ex || ex->last_batch <= 0) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    const int n = ex->last_batch;
+    if (counts) ORBX_HIP(hipMemcpyAsync(counts, ex->d_count.p, 4 * (size_t)n, hipMemcpyDeviceToHost, ex->stream));
+    if (mono) ORBX_HIP(hipMemcpyAsync(mono, ex->d_mono.p, 4 * (size_t)n, hipMemcpyDeviceToHost, ex->stream));
+    if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, ex->stream));
+    if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, ex->stream));
+    return check_device_error(ex);
+}
+
+int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, size_t stride, int lap0, int lap1,
+                 orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, int *mono_index) {
+    if (n_out) *n_out = 0;
+    if (mono_index) *mono_index = 0;
+    if (!ex) return ORBX_E_BAD_ARG;
+    if (!image || width <= 0 || height <= 0) return ORBX_E_EMPTY;  // ORBextractor.cc:1090
+    if (stride < (size_t)width) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    int r = configure(ex, width, height, 1);
+    if (r != ORBX_OK) return r;
+    const size_t dpitch = ((size_t)width + 63) & ~(size_t)63;
+    if ((r = ex->d_img.ensure(dpitch * height)) != ORBX_OK) return r;
+    ORBX_HIP(hipMemcpy2DAsync(ex->d_img.p, dpitch, image, stride, width, height, hipMemcpyHostToDevice, ex->stream));
+    r = enqueue_extract(ex, (const uint8_t *)ex->d_img.p, 1, dpitch, dpitch * height, lap0, lap1);
+    if (r != ORBX_OK) return r;
+    return orbx_batch_download(ex, 0, kps, desc, cap, n_out, mono_index);
+}
+
+int orbx_level_size(orbx_extractor *ex, int width, int height, int level, int *w, int *h) {
+    if (!ex || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
+    if (w) *w = cv_round_f((float)width * ex->inv_scale[level]);
+    if (h) *h = cv_round_f((float)height * ex->inv_scale[level]);
+    return ORBX_OK;
+}
+
+int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_t dst_stride) {
+    if (!ex || !dst || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
+    const LevelInfo &L = ex->lv[level];
+    if (dst_stride < (size_t)(L.w + 2 * kEdge)) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    const uint8_t *src = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off + kRingX;
+    ORBX_HIP(hipMemcpy2DAsync(dst, dst_stride, src, L.pitch, L.w + 2 * kEdge, L.h + 2 * kEdge, hipMemcpyDeviceToHost, ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    return ORBX_OK;
+}
+
+int orbx_get_level_device(orbx_extractor *ex, int frame, int level, const uint8_t **d_padded, size_t *pitch) {
+    if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
+    const LevelInfo &L = ex->lv[level];
+    if (d_padded) *d_padded = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off + kRingX;
+    if (pitch) *pitch = L.pitch;
+    return ORBX_OK;
+}
+
+int orbx_get_levels(const orbx_extractor *ex) { return ex ? ex->prm.nlevels : ORBX_E_BAD_ARG; }
+float orbx_get_scale_factor(const orbx_extractor *ex) { return ex ? (float)(double)ex->prm.scale_factor : 0.f; }
+int orbx_get_scale_tables(const orbx_extractor *ex, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    const size_t b = sizeof(float) * ex->prm.nlevels;
+    if (scale) memcpy(scale, ex->scale.data(), b);
+    if (inv_scale) memcpy(inv_scale, ex->inv_scale.data(), b);
+    if (sigma2) memcpy(sigma2, ex->sigma2.data(), b);
+    if (inv_sigma2) memcpy(inv_sigma2, ex->inv_sigma2.data(), b);
+    return ex->prm.nlevels;
+}
+int orbx_get_feature_tables(const orbx_extractor *ex, int32_t *quota, int32_t *umax16) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    if (quota) memcpy(quota, ex->quota.data(), sizeof(int32_t) * ex->prm.nlevels);
+    if (umax16) memcpy(umax16, ex->umax, sizeof(ex->umax));
+    return ex->prm.nlevels;
+}
+
+int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, orbx_keypoint *out, int cap) {
+    if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    const LevelInfo &L = ex->lv[level];
+    const int ncell = L.nCols * L.nRows;
+    std::vector<int32_t> cnt(ncell);
+    ORBX_HIP(hipMemcpy(cnt.data(), (int32_t *)ex->d_cellcnt.p + (size_t)frame * ex->total_cells + L.cell_base, 4 * (size_t)ncell, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> ent(L.cand_cap);
+    ORBX_HIP(hipMemcpy(ent.data(), (uint32_t *)ex->d_cellent.p + (size_t)frame * ex->cand_frame + L.cand_off, 4 * (size_t)L.cand_cap, hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int c = 0; c < ncell; c++)
+        for (int k = 0; k < cnt[c]; k++) {
+            const uint32_t key = ent[(size_t)c * L.cell_cap + k];
+            if (out && n < cap) out[n] = orbx_keypoint{(float)key_x(key), (float)key_y(key), 7.f, -1.f, (float)key_s(key), 0, -1};
+            n++;
+        }
+    return n;
+}
+
+int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_keypoint *out, int cap) {
+    if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    const LevelInfo &L = ex->lv[level];
+    int32_t n = 0;
+    ORBX_HIP(hipMemcpy(&n, (int32_t *)ex->d_lvlcnt.p + (size_t)frame * ex->prm.nlevels + level, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> keys(std::max(n, 1));
+    if (n > 0) ORBX_HIP(hipMemcpy(keys.data(), (uint32_t *)ex->d_lvlkp.p + (size_t)frame * ex->lvl_frame + L.lvl_off, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < cap && out; i++)
+        out[i] = orbx_keypoint{(float)key_x(keys[i]), (float)key_y(keys[i]), L.size, -1.f, (float)key_s(keys[i]), level, -1};
+    return n;
+}
+
+int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_t dst_stride) {
+    if (!ex || !dst || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
+    const LevelInfo &L = ex->lv[level];
+    if (dst_stride < (size_t)L.w) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipMemcpy2DAsync(dst, dst_stride, (const uint8_t *)ex->d_blur.p + (size_t)frame * ex->blur_frame + L.boff, L.bpitch, L.w, L.h, hipMemcpyDeviceToHost, ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    return ORBX_OK;
+}
+
+int orbx_debug_sort_nodes(int device, const int32_t *count, const int32_t *ulx, int n, int32_t *perm) {
+    if (n <= 0 || n > 65535) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(device));
+    int32_t *d_c, *d_u, *d_p;
+    uint64_t *d_s;
+    ORBX_HIP(hipMalloc((void **)&d_c, 4 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_u, 4 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_p, 4 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_s, 8 * (size_t)n));
+    ORBX_HIP(hipMemcpy(d_c, count, 4 * (size_t)n, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(d_u, ulx, 4 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(64), 0, 0, d_c, d_u, n, d_p, d_s);
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(perm, d_p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_c); (void)hipFree(d_u); (void)hipFree(d_p); (void)hipFree(d_s);
+    return ORBX_OK;
+}
+
+int orbx_profile_enable(orbx_extractor *ex, int enable) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    ex->profile = enable != 0;
+    for (int k = 0; k < K_COUNT; k++) { ex->prof_ms[k] = 0; ex->prof_n[k] = 0; }
+    return ORBX_OK;
+}
+int orbx_profile_read(orbx_extractor *ex, const char **names, double *avg_ms, int64_t *launches, int cap) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    for (int k = 0; k < K_COUNT && k < cap; k++) {
+        if (names) names[k] = kKernelNames[k];
+        if (avg_ms) avg_ms[k] = ex->prof_n[k] ? ex->prof_ms[k] / (double)ex->prof_n[k] : 0.0;
+        if (launches) launches[k] = ex->prof_n[k];
+    }
+    return K_COUNT;
+}
+
+}  // extern "C"

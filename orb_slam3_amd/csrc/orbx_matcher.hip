@@ -1,0 +1,448 @@
+// orbx_matcher.hip -- host side of the matchers: per-thread context (own HIP stream + grow-on-demand device
+// scratch), upload / launch / download for the host-pointer entry points, and the device-resident batched
+// frame-to-frame matcher.  See include/orbx.h for the reference functions each entry point replaces.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "matcher_kernels.hip.h"
+#include "extractor_state.h"
+
+using namespace orbx;
+
+namespace {
+
+struct Arena {  // bump allocator over one device buffer, reset per call
+    uint8_t *base = nullptr;
+    size_t cap = 0, used = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return ORBX_OK;
+        if (base) (void)hipFree(base);
+        base = nullptr; cap = 0;
+        bytes = (bytes * 3 / 2 + 4095) & ~(size_t)4095;
+        ORBX_HIP(hipMalloc((void **)&base, bytes));
+        cap = bytes;
+        return ORBX_OK;
+    }
+    void reset() { used = 0; }
+    template <typename T> T *take(size_t n) {
+        used = (used + 255) & ~(size_t)255;
+        T *p = reinterpret_cast<T *>(base + used);
+        used += n * sizeof(T);
+        return p;
+    }
+    static size_t pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+};
+
+}  // namespace
+
+struct orbx_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Arena arena;
+};
+
+extern "C" {
+
+int orbx_matcher_create(int device, orbx_matcher **out) {
+    if (!out) return ORBX_E_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        set_error("no usable HIP device (liborbx has no CPU fallback)");
+        return ORBX_E_NO_DEVICE;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    orbx_matcher *m = new orbx_matcher();
+    m->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); delete m; return ORBX_E_HIP; }
+    *out = m;
+    return ORBX_OK;
+}
+
+void orbx_matcher_destroy(orbx_matcher *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    if (m->arena.base) (void)hipFree(m->arena.base);
+    delete m;
+}
+
+#define H2D(dst, src, bytes) ORBX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->stream))
+#define D2H(dst, src, bytes) ORBX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->stream))
+
+int orbx_hamming_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, const int32_t *row_ptr,
+                     const int32_t *cand, uint16_t *dist_out) {
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !row_ptr))) return ORBX_E_BAD_ARG;
+    if (nq == 0) return ORBX_OK;
+    const int nnz = row_ptr[nq];
+    if (nnz <= 0) return ORBX_OK;
+    if (!t || !cand || !dist_out) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(m->device));
+    int r = m->arena.reserve(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32) + Arena::pad(4 * (size_t)(nq + 1)) +
+                             Arena::pad(4 * (size_t)nnz) + Arena::pad(2 * (size_t)nnz) + 4096);
+    if (r != ORBX_OK) return r;
+    m->arena.reset();
+    uint8_t *dq = m->arena.take<uint8_t>((size_t)nq * 32), *dt = m->arena.take<uint8_t>((size_t)nt * 32);
+    int32_t *drp = m->arena.take<int32_t>(nq + 1), *dc = m->arena.take<int32_t>(nnz);
+    uint16_t *dd = m->arena.take<uint16_t>(nnz);
+    H2D(dq, q, (size_t)nq * 32); H2D(dt, t, (size_t)nt * 32); H2D(drp, row_ptr, 4 * (size_t)(nq + 1)); H2D(dc, cand, 4 * (size_t)nnz);
+    hipLaunchKernelGGL(k_hamming_csr, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, drp, dc, dd);
+    D2H(dist_out, dd, 2 * (size_t)nnz);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbx_hamming_best2_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, const int32_t *row_ptr,
+                           const int32_t *cand, int32_t *best_pos, int32_t *best_dist, int32_t *second_pos,
+                           int32_t *second_dist) {
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !row_ptr))) return ORBX_E_BAD_ARG;
+    if (nq == 0) return ORBX_OK;
+    const int nnz = row_ptr[nq];
+    ORBX_HIP(hipSetDevice(m->device));
+    int r = m->arena.reserve(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32 + 32) + Arena::pad(4 * (size_t)(nq + 1)) +
+                             Arena::pad(4 * (size_t)nnz + 4) + 4 * Arena::pad(4 * (size_t)nq) + 4096);
+    if (r != ORBX_OK) return r;
+    m->arena.reset();
+    uint8_t *dq = m->arena.take<uint8_t>((size_t)nq * 32), *dt = m->arena.take<uint8_t>((size_t)nt * 32 + 32);
+    int32_t *drp = m->arena.take<int32_t>(nq + 1), *dc = m->arena.take<int32_t>(nnz + 1);
+    int32_t *o[4];
+    for (int k = 0; k < 4; k++) o[k] = m->arena.take<int32_t>(nq);
+    H2D(dq, q, (size_t)nq * 32);
+    if (nt > 0) H2D(dt, t, (size_t)nt * 32);
+    H2D(drp, row_ptr, 4 * (size_t)(nq + 1));
+    if (nnz > 0) H2D(dc, cand, 4 * (size_t)nnz);
+    hipLaunchKernelGGL(k_hamming_best2_csr, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, drp, dc, o[0], o[1], o[2], o[3]);
+    int32_t *host[4] = {best_pos, best_dist, second_pos, second_dist};
+    for (int k = 0; k < 4; k++) if (host[k]) D2H(host[k], o[k], 4 * (size_t)nq);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbx_knn2(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist) {
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist))) return ORBX_E_BAD_ARG;
+    if (nq == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(m->device));
+    int r = m->arena.reserve(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32 + 32) + 2 * Arena::pad(8 * (size_t)nq) + 4096);
+    if (r != ORBX_OK) return r;
+    m->arena.reset();
+    uint8_t *dq = m->arena.take<uint8_t>((size_t)nq * 32), *dt = m->arena.take<uint8_t>((size_t)nt * 32 + 32);
+    int32_t *di = m->arena.take<int32_t>(2 * (size_t)nq), *dd = m->arena.take<int32_t>(2 * (size_t)nq);
+    H2D(dq, q, (size_t)nq * 32);
+    if (nt > 0) H2D(dt, t, (size_t)nt * 32);
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, nt, di, dd);
+    D2H(idx, di, 8 * (size_t)nq); D2H(dist, dd, 8 * (size_t)nq);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbx_stereo_rowband(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr,
+                        const uint8_t *dr, int nr, const float *scale, int nlevels, int n_rows, float min_d, float max_d,
+                        int32_t *best_idx_r, int32_t *best_dist) {
+    if (!m || nl < 0 || nr < 0 || nlevels <= 0 || !scale) return ORBX_E_BAD_ARG;
+    if (nl == 0) return ORBX_OK;
+    if (!kl || !dl || !best_idx_r || !best_dist) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(m->device));
+    int r = m->arena.reserve(Arena::pad(28 * (size_t)nl) + Arena::pad(32 * (size_t)nl) + Arena::pad(28 * (size_t)nr + 32) +
+                             Arena::pad(32 * (size_t)nr + 32) + Arena::pad(4 * (size_t)nlevels) + 2 * Arena::pad(4 * (size_t)nl) + 4096);
+    if (r != ORBX_OK) return r;
+    m->arena.reset();
+    orbx_keypoint *dkl = m->arena.take<orbx_keypoint>(nl), *dkr = m->arena.take<orbx_keypoint>(nr + 1);
+    uint8_t *ddl = m->arena.take<uint8_t>(32 * (size_t)nl), *ddr = m->arena.take<uint8_t>(32 * (size_t)nr + 32);
+    float *dsc = m->arena.take<float>(nlevels);
+    int32_t *dbi = m->arena.take<int32_t>(nl), *dbd = m->arena.take<int32_t>(nl);
+    H2D(dkl, kl, 28 * (size_t)nl); H2D(ddl, dl, 32 * (size_t)nl);
+    if (nr > 0) { H2D(dkr, kr, 28 * (size_t)nr); H2D(ddr, dr, 32 * (size_t)nr); }
+    H2D(dsc, scale, 4 * (size_t)nlevels);
+    hipLaunchKernelGGL(k_stereo_rowband, dim3((nl + 3) / 4), dim3(256), 0, m->stream, dkl, ddl, nl, dkr, ddr, nr, dsc, n_rows, min_d,
+                       max_d, dbi, dbd);
+    D2H(best_idx_r, dbi, 4 * (size_t)nl); D2H(best_dist, dbd, 4 * (size_t)nl);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+// Frame::ComputeStereoMatches (Frame.cc:811-981): device Hamming stage, host SAD refinement on the host-resident
+// pyramid (mvImagePyramid is host memory at this boundary), host median rejection.
+int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int N, const orbx_keypoint *kr,
+                                const uint8_t *dr, int Nr, const float *scale_factors, const float *inv_scale_factors,
+                                int nlevels, const uint8_t *const *pyr_left, const uint8_t *const *pyr_right, const int32_t *pyr_w,
+                                const int32_t *pyr_h, const size_t *pyr_stride, float bf, float b, float *u_right, float *depth) {
+    if (!m || !u_right || !depth || N < 0 || !pyr_h || !pyr_w) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < N; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    if (N == 0) return 0;
+    const int thOrbDist = (ORBX_TH_HIGH + ORBX_TH_LOW) / 2;
+    const float minD = 0, maxD = bf / b;
+    std::vector<int32_t> bidx(N), bdist(N);
+    int r = orbx_stereo_rowband(m, kl, dl, N, kr, dr, Nr, scale_factors, nlevels, pyr_h[0], minD, maxD, bidx.data(), bdist.data());
+    if (r != ORBX_OK) return r;
+    std::vector<std::pair<int, int>> vDistIdx;
+    vDistIdx.reserve(N);
+    int nmatched = 0;
+    for (int iL = 0; iL < N; iL++) {
+        if (bidx[iL] < 0 || !(bdist[iL] < thOrbDist)) continue;
+        const orbx_keypoint &kpL = kl[iL];
+        const float uL = kpL.x;
+        const float uR0 = kr[bidx[iL]].x;
+        const int lvl = kpL.octave;
+        const float sf = inv_scale_factors[lvl];
+        const float scaleduL = std::round(kpL.x * sf), scaledvL = std::round(kpL.y * sf), scaleduR0 = std::round(uR0 * sf);
+        const int w = 5, L = 5;
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        if (iniu < 0 || endu >= pyr_w[lvl]) continue;
+        const uint8_t *IL = pyr_left[lvl], *IR = pyr_right[lvl];
+        const size_t sl = pyr_stride[lvl];
+        const int y0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w);
+        int bestDist = INT_MAX, bestincR = 0;
+        float vDists[2 * 5 + 1];
+        for (int incR = -L; incR <= L; incR++) {
+            const int xr0 = (int)(scaleduR0 + incR - w);
+            int sad = 0;
+            for (int yy = 0; yy < 2 * w + 1; yy++) {
+                const uint8_t *pl = IL + (size_t)(y0 + yy) * sl + xl0, *pr = IR + (size_t)(y0 + yy) * sl + xr0;
+                for (int xx = 0; xx < 2 * w + 1; xx++) sad += std::abs((int)pl[xx] - (int)pr[xx]);
+            }
+            const float dist = (float)sad;
+            if (dist < bestDist) { bestDist = (int)dist; bestincR = incR; }
+            vDists[L + incR] = dist;
+        }
+        if (bestincR == -L || bestincR == L) continue;
+        const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+        if (deltaR < -1 || deltaR > 1) continue;
+        float bestuR = scale_factors[lvl] * ((float)scaleduR0 + (float)bestincR + deltaR);
+        float disparity = uL - bestuR;
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+            depth[iL] = bf / disparity;
+            u_right[iL] = bestuR;
+            vDistIdx.push_back(std::pair<int, int>(bestDist, iL));
+            nmatched++;
+        }
+    }
+    if (vDistIdx.empty()) return 0;
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        u_right[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+        nmatched--;
+    }
+    return nmatched;
+}
+
+}  // extern "C"
+
+namespace {
+
+// shared driver of the two projection matchers (host-pointer form)
+struct ProjArgs {
+    const orbx_frame_desc *frame;
+    const uint8_t *occupied;
+    int nq;
+    const float *qx, *qy, *qr, *qxr;
+    const int32_t *qmin, *qmax;
+    const uint8_t *qdesc, *qvalid, *q_has_obs;
+    const float *q_angle;
+    int mode;
+    float nnratio;
+    int check_orientation;
+    int32_t *match_out;
+};
+
+int run_projection(orbx_matcher *m, const ProjArgs &a) {
+    const orbx_frame_desc *F = a.frame;
+    const int n = F->n, nq = a.nq;
+    for (int i = 0; i < n; i++) a.match_out[i] = -1;
+    if (n == 0 || nq == 0) return 0;
+    if (n > 65535) return ORBX_E_TOO_LARGE;
+    ORBX_HIP(hipSetDevice(m->device));
+    size_t need = Arena::pad(28 * (size_t)n) + Arena::pad(32 * (size_t)n) + 3 * Arena::pad((size_t)n) + Arena::pad(4 * (size_t)n) * 2 +
+                  Arena::pad(4 * (size_t)nq) * 7 + Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) * 2 + Arena::pad(8 * (size_t)nq) * 2 +
+                  Arena::pad(sizeof(WindowProblem)) + Arena::pad(sizeof(ResolveProblem)) + 16 * 256 + 4096;
+    int r = m->arena.reserve(need);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    A.reset();
+    WindowProblem P;
+    memset(&P, 0, sizeof(P));
+    ResolveProblem R;
+    memset(&R, 0, sizeof(R));
+    orbx_keypoint *dk = A.take<orbx_keypoint>(n);
+    uint8_t *dd = A.take<uint8_t>(32 * (size_t)n);
+    H2D(dk, F->keypoints_un, 28 * (size_t)n); H2D(dd, F->descriptors, 32 * (size_t)n);
+    P.kps = dk; P.desc = dd;
+    int32_t *dcnt = A.take<int32_t>(4);
+    const int32_t cnts[2] = {n, nq};
+    H2D(dcnt, cnts, 8);
+    P.n_ptr = dcnt; P.nq_ptr = dcnt + 1;
+    if (F->u_right) { float *p = A.take<float>(n); H2D(p, F->u_right, 4 * (size_t)n); P.u_right = p; }
+    if (a.occupied) { uint8_t *p = A.take<uint8_t>(n); H2D(p, a.occupied, (size_t)n); P.occupied0 = p; }
+    float *f3[3]; const float *h3[3] = {a.qx, a.qy, a.qr};
+    for (int k = 0; k < 3; k++) { f3[k] = A.take<float>(nq); H2D(f3[k], h3[k], 4 * (size_t)nq); }
+    P.qx = f3[0]; P.qy = f3[1]; P.qr = f3[2];
+    int32_t *i2[2]; const int32_t *hi2[2] = {a.qmin, a.qmax};
+    for (int k = 0; k < 2; k++) { i2[k] = A.take<int32_t>(nq); H2D(i2[k], hi2[k], 4 * (size_t)nq); }
+    P.qmin = i2[0]; P.qmax = i2[1];
+    if (a.qxr && F->u_right) { float *p = A.take<float>(nq); H2D(p, a.qxr, 4 * (size_t)nq); P.qxr = p; }
+    { uint8_t *p = A.take<uint8_t>(32 * (size_t)nq); H2D(p, a.qdesc, 32 * (size_t)nq); P.qdesc = p; }
+    if (a.qvalid) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.qvalid, (size_t)nq); P.qvalid = p; }
+    P.key1 = A.take<u64>(nq); P.key2 = A.take<u64>(nq);
+    R.mode = a.mode; R.nnratio = a.nnratio; R.check_orientation = a.check_orientation;
+    if (a.q_angle) { float *p = A.take<float>(nq); H2D(p, a.q_angle, 4 * (size_t)nq); R.q_angle = p; }
+    if (a.q_has_obs) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.q_has_obs, (size_t)nq); R.q_has_obs = p; }
+    R.match = A.take<int32_t>(n);
+    R.nmatches = A.take<int32_t>(1);
+    R.occ = A.take<uint8_t>(n);
+    R.entries = A.take<int32_t>(nq);
+    WindowProblem *dP = A.take<WindowProblem>(1);
+    ResolveProblem *dR = A.take<ResolveProblem>(1);
+    H2D(dP, &P, sizeof(P)); H2D(dR, &R, sizeof(R));
+    GridParams g;
+    g.minx = F->min_x; g.miny = F->min_y;
+    g.inv_w = 64.0f / (F->max_x - F->min_x);  // Frame.cc:342-343
+    g.inv_h = 48.0f / (F->max_y - F->min_y);
+    hipLaunchKernelGGL(k_window_best2, dim3((nq + 3) / 4, 1), dim3(256), 0, m->stream, dP, g);
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), 0, m->stream, dP, dR, g);
+    int32_t nm = 0;
+    D2H(a.match_out, R.match, 4 * (size_t)n);
+    D2H(&nm, R.nmatches, 4);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return nm;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbx_search_by_projection_mappoints(orbx_matcher *m, const orbx_frame_desc *frame, const uint8_t *frame_occupied, int n_mp,
+                                        const float *proj_x, const float *proj_y, const float *proj_xr,
+                                        const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc,
+                                        const uint8_t *mp_in_view, const uint8_t *mp_has_obs, float th, float nnratio,
+                                        int32_t *frame_match) {
+    if (!m || !frame || !frame_match || n_mp < 0) return ORBX_E_BAD_ARG;
+    if (n_mp > 0 && (!proj_x || !proj_y || !pred_level || !view_cos || !mp_desc)) return ORBX_E_BAD_ARG;
+    // per-query window: r = RadiusByViewingCos(viewCos) [* th] * scale[level], levels [lvl-1, lvl]  (ORBmatcher.cc:63-72)
+    std::vector<float> qr(n_mp);
+    std::vector<int32_t> qmin(n_mp), qmax(n_mp);
+    std::vector<uint8_t> valid(n_mp);
+    const bool bFactor = th != 1.0;
+    for (int i = 0; i < n_mp; i++) {
+        const int lvl = pred_level[i];
+        valid[i] = (!mp_in_view || mp_in_view[i]) && lvl >= 0 && lvl < frame->nlevels;
+        float r = (view_cos[i] > 0.998) ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        qr[i] = valid[i] ? r * frame->scale_factors[lvl] : 0.f;
+        qmin[i] = lvl - 1; qmax[i] = lvl;
+    }
+    ProjArgs a = {frame, frame_occupied, n_mp, proj_x, proj_y, qr.data(), proj_xr, qmin.data(), qmax.data(), mp_desc, valid.data(),
+                  mp_has_obs, nullptr, 1, nnratio, 0, frame_match};
+    return run_projection(m, a);
+}
+
+int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur, const uint8_t *cur_occupied, int n_q,
+                                    const float *q_u, const float *q_v, const float *q_ur, const int32_t *q_octave,
+                                    const float *q_angle, const uint8_t *q_desc, const uint8_t *q_has_obs, float th, int level_mode,
+                                    int check_orientation, int32_t *cur_match) {
+    if (!m || !cur || !cur_match || n_q < 0) return ORBX_E_BAD_ARG;
+    if (n_q > 0 && (!q_u || !q_v || !q_octave || !q_desc || (check_orientation && !q_angle))) return ORBX_E_BAD_ARG;
+    std::vector<float> qr(n_q);
+    std::vector<int32_t> qmin(n_q), qmax(n_q);
+    std::vector<uint8_t> valid(n_q);
+    for (int i = 0; i < n_q; i++) {
+        const int o = q_octave[i];
+        valid[i] = o >= 0 && o < cur->nlevels;
+        qr[i] = valid[i] ? th * cur->scale_factors[o] : 0.f;  // :1726
+        if (level_mode == 1) { qmin[i] = o; qmax[i] = -1; }          // bForward  :1731
+        else if (level_mode == 2) { qmin[i] = 0; qmax[i] = o; }      // bBackward :1733
+        else { qmin[i] = o - 1; qmax[i] = o + 1; }                   // :1735
+    }
+    ProjArgs a = {cur, cur_occupied, n_q, q_u, q_v, qr.data(), q_ur, qmin.data(), qmax.data(), q_desc, valid.data(), q_has_obs,
+                  q_angle, 2, 0.f, check_orientation, cur_match};
+    return run_projection(m, a);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-resident batched frame-to-frame matcher (throughput path): problem f-1 matches frame f-1 (queries)
+// into frame f of the extractor's last batch; everything stays in HBM on the extractor's stream.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
+                                             int32_t *d_match, int32_t *d_nmatches) {
+    if (!ex || !d_match || !d_nmatches) return ORBX_E_BAD_ARG;
+    const int n = ex->last_batch;
+    if (n < 2) return ORBX_OK;
+    if (ex->cap > 65535) return ORBX_E_TOO_LARGE;
+    ORBX_HIP(hipSetDevice(ex->device));
+    const int np = n - 1, cap = ex->cap;
+    int r;
+#define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
+    ENS(ex->d_mkey1, 8 * (size_t)cap * np);
+    ENS(ex->d_mkey2, 8 * (size_t)cap * np);
+    ENS(ex->d_mocc, (size_t)cap * np);
+    ENS(ex->d_mentries, 4 * (size_t)cap * np);
+    ENS(ex->d_mprobs, sizeof(WindowProblem) * (size_t)np);
+    ENS(ex->d_mres, sizeof(ResolveProblem) * (size_t)np);
+#undef ENS
+    std::vector<WindowProblem> P(np);
+    std::vector<ResolveProblem> R(np);
+    const orbx_keypoint *kps = (const orbx_keypoint *)ex->d_kps.p;
+    const uint8_t *desc = (const uint8_t *)ex->d_desc.p;
+    const int32_t *count = (const int32_t *)ex->d_count.p;
+    // scale factors live in the level table; a small device copy is kept in d_mres tail -> simpler: upload once here
+    for (int p = 0; p < np; p++) {
+        const int f = p + 1;
+        WindowProblem &w = P[p];
+        memset(&w, 0, sizeof(w));
+        w.kps = kps + (size_t)f * cap; w.desc = desc + (size_t)f * cap * 32; w.n_ptr = count + f;
+        w.q_from_kps = kps + (size_t)(f - 1) * cap; w.qdesc = desc + (size_t)(f - 1) * cap * 32; w.nq_ptr = count + (f - 1);
+        w.th = th; w.du = du; w.dv = dv;
+        w.key1 = (u64 *)ex->d_mkey1.p + (size_t)p * cap; w.key2 = (u64 *)ex->d_mkey2.p + (size_t)p * cap;
+        ResolveProblem &q = R[p];
+        memset(&q, 0, sizeof(q));
+        q.mode = 2; q.check_orientation = check_orientation;
+        q.match = d_match + (size_t)f * cap; q.nmatches = d_nmatches + f;
+        q.occ = (uint8_t *)ex->d_mocc.p + (size_t)p * cap;
+        q.entries = (int32_t *)ex->d_mentries.p + (size_t)p * cap;
+    }
+    // mvScaleFactors on the device: reuse a per-extractor buffer appended after the problems
+    static_assert(sizeof(float) == 4, "");
+    orbx::DevBuf &sc = ex->d_mscale;
+    if ((r = sc.ensure(sizeof(float) * ex->prm.nlevels)) != ORBX_OK) return r;
+    ORBX_HIP(hipMemcpyAsync(sc.p, ex->scale.data(), sizeof(float) * ex->prm.nlevels, hipMemcpyHostToDevice, ex->stream));
+    for (int p = 0; p < np; p++) P[p].scale = (const float *)sc.p;
+    ORBX_HIP(hipMemcpyAsync(ex->d_mprobs.p, P.data(), sizeof(WindowProblem) * np, hipMemcpyHostToDevice, ex->stream));
+    ORBX_HIP(hipMemcpyAsync(ex->d_mres.p, R.data(), sizeof(ResolveProblem) * np, hipMemcpyHostToDevice, ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));  // P/R are host temporaries
+    GridParams g;
+    g.minx = 0.f; g.miny = 0.f;  // undistorted bounds of a distortion-free camera: mnMinX = 0, mnMaxX = cols (Frame.cc:804-807)
+    g.inv_w = 64.0f / ((float)ex->width - 0.f);
+    g.inv_h = 48.0f / ((float)ex->height - 0.f);
+    hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
+    if (ex->profile) (void)hipEventRecord(e0, ex->stream);
+    hipLaunchKernelGGL(k_window_best2, dim3((cap + 3) / 4, np), dim3(256), 0, ex->stream, (const WindowProblem *)ex->d_mprobs.p, g);
+    if (ex->profile) {
+        (void)hipEventRecord(e1, ex->stream); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        ex->prof_ms[K_MATCH_SCAN] += ms; ex->prof_n[K_MATCH_SCAN]++;
+        (void)hipEventRecord(e0, ex->stream);
+    }
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), 0, ex->stream, (const WindowProblem *)ex->d_mprobs.p,
+                       (const ResolveProblem *)ex->d_mres.p, g);
+    if (ex->profile) {
+        (void)hipEventRecord(e1, ex->stream); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        ex->prof_ms[K_MATCH_RESOLVE] += ms; ex->prof_n[K_MATCH_RESOLVE]++;
+    }
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}

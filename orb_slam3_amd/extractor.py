@@ -1,0 +1,174 @@
+"""Host-side mirror of ORB_SLAM3::ORBextractor (/root/reference/include/ORBextractor.h:43-109) over the C ABI.
+
+Same constructor arguments, same accessor names, same call result as the reference class; the work is done
+by the HIP kernels in liborbx.so (no CPU path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, Params, check, ptr
+
+
+class ORBextractor:
+    HARRIS_SCORE = 0
+    FAST_SCORE = 1
+
+    def __init__(self, nfeatures: int, scaleFactor: float, nlevels: int, iniThFAST: int, minThFAST: int,
+                 device: int = 0, flags: int = 0):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        prm = Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, flags)
+        check(self._L.orbx_create(C.byref(prm), device, 0, 0, 0, C.byref(self._h)), "orbx_create")
+        self.nfeatures, self.nlevels, self.device = nfeatures, nlevels, device
+        self._last_shape = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orbx_destroy(self._h)
+            self._h = None
+
+    # ---- ORBextractor::operator() (ORBextractor.cc:1086-1168) ----
+    def __call__(self, image: np.ndarray, mask=None, vLappingArea=(0, 0)):
+        """Returns (monoIndex, keypoints[KP_DTYPE], descriptors[N,32] uint8); monoIndex == -1 for an empty image."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (ORBextractor.cc:1094)"
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = check(self._L.orbx_output_capacity(self._h, w, h), "orbx_output_capacity")
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        st = self._L.orbx_extract(self._h, ptr(image), w, h, image.strides[0], int(vLappingArea[0]),
+                                  int(vLappingArea[1]), ptr(kps), ptr(desc), cap, C.byref(n), C.byref(mono))
+        if st == _lib.ORBX_E_EMPTY:
+            return -1, kps[:0], desc[:0]
+        check(st, "orbx_extract")
+        self._last_shape = (w, h)
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    # ---- batched, device-resident form ----
+    def extract_batch_device(self, d_ptr: int, n_frames: int, width: int, height: int, row_stride: int,
+                             frame_stride: int, vLappingArea=(0, 0)):
+        check(self._L.orbx_extract_batch_device(self._h, C.c_void_p(d_ptr), n_frames, width, height, row_stride,
+                                                frame_stride, int(vLappingArea[0]), int(vLappingArea[1])),
+              "orbx_extract_batch_device")
+        self._last_shape = (width, height)
+
+    def sync(self):
+        check(self._L.orbx_sync(self._h), "orbx_sync")
+
+    def output_capacity(self, width, height) -> int:
+        return check(self._L.orbx_output_capacity(self._h, width, height), "orbx_output_capacity")
+
+    def batch_view(self):
+        v = _lib.BatchView()
+        check(self._L.orbx_batch_view_get(self._h, C.byref(v)), "orbx_batch_view_get")
+        return v
+
+    def download(self, frame: int):
+        cap = self.batch_view().cap
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        check(self._L.orbx_batch_download(self._h, frame, ptr(kps), ptr(desc), cap, C.byref(n), C.byref(mono)),
+              "orbx_batch_download")
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def download_all(self, kps=None, desc=None, counts=None, mono=None):
+        v = self.batch_view()
+        n, cap = v.n_frames, v.cap
+        kps = np.zeros((n, cap), KP_DTYPE) if kps is None else kps
+        desc = np.zeros((n, cap, 32), np.uint8) if desc is None else desc
+        counts = np.zeros(n, np.int32) if counts is None else counts
+        mono = np.zeros(n, np.int32) if mono is None else mono
+        check(self._L.orbx_batch_download_all(self._h, ptr(kps), ptr(desc), ptr(counts), ptr(mono)),
+              "orbx_batch_download_all")
+        return kps, desc, counts, mono
+
+    def match_consecutive_device(self, d_match: int, d_nmatches: int, th=15.0, du=0.0, dv=0.0, check_orientation=True):
+        check(self._L.orbx_match_consecutive_device(self._h, th, du, dv, int(check_orientation), C.c_void_p(d_match),
+                                                    C.c_void_p(d_nmatches)), "orbx_match_consecutive_device")
+
+    # ---- accessors (ORBextractor.h:62-83) ----
+    def GetLevels(self) -> int:
+        return self._L.orbx_get_levels(self._h)
+
+    def GetScaleFactor(self) -> float:
+        return self._L.orbx_get_scale_factor(self._h)
+
+    def _tables(self):
+        n = self.nlevels
+        t = [np.zeros(n, np.float32) for _ in range(4)]
+        self._L.orbx_get_scale_tables(self._h, *[ptr(a) for a in t])
+        return t
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def feature_tables(self):
+        quota = np.zeros(self.nlevels, np.int32)
+        umax = np.zeros(16, np.int32)
+        self._L.orbx_get_feature_tables(self._h, ptr(quota), ptr(umax))
+        return quota, umax
+
+    def level_size(self, level: int, shape=None):
+        w, h = shape or self._last_shape
+        lw, lh = C.c_int(0), C.c_int(0)
+        check(self._L.orbx_level_size(self._h, w, h, level, C.byref(lw), C.byref(lh)), "orbx_level_size")
+        return lw.value, lh.value
+
+    def get_level(self, level: int, frame: int = 0) -> np.ndarray:
+        """Padded level (19-px ring) of `frame`: what mvImagePyramid[level]'s parent buffer holds."""
+        w, h = self.level_size(level)
+        out = np.zeros((h + 38, w + 38), np.uint8)
+        check(self._L.orbx_get_level(self._h, frame, level, ptr(out), out.strides[0]), "orbx_get_level")
+        return out
+
+    @property
+    def mvImagePyramid(self):
+        """ROI views of the last single-frame pyramid (public member of the reference, ORBextractor.h:83)."""
+        return [self.get_level(l)[19:-19, 19:-19] for l in range(self.nlevels)]
+
+    # ---- stage introspection for parity tests ----
+    def debug_candidates(self, level: int, frame: int = 0) -> np.ndarray:
+        n = check(self._L.orbx_debug_level_candidates(self._h, frame, level, None, 0), "candidates")
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self._L.orbx_debug_level_candidates(self._h, frame, level, ptr(out), n)
+        return out[:n]
+
+    def debug_level_keypoints(self, level: int, frame: int = 0) -> np.ndarray:
+        n = check(self._L.orbx_debug_level_keypoints(self._h, frame, level, None, 0), "level keypoints")
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self._L.orbx_debug_level_keypoints(self._h, frame, level, ptr(out), n)
+        return out[:n]
+
+    def debug_blurred(self, level: int, frame: int = 0) -> np.ndarray:
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        check(self._L.orbx_debug_level_blurred(self._h, frame, level, ptr(out), out.strides[0]), "blurred")
+        return out
+
+    def profile_enable(self, on=True):
+        self._L.orbx_profile_enable(self._h, int(on))
+
+    def profile_read(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        cnt = (C.c_int64 * 16)()
+        k = self._L.orbx_profile_read(self._h, names, ms, cnt, 16)
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(k)}

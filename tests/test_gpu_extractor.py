@@ -1,0 +1,192 @@
+"""GPU parity tests of the extractor: HIP path (through the C ABI) vs the CPU oracle, bit-exact.
+
+Stage-wise (pyramid, blur, FAST candidates, quad-tree keypoints) and end-to-end (keypoints 28 B, descriptors
+32 B, monoIndex), on the BASELINE.json configurations.  IC angles are compared bit-exactly too (the 1e-5
+tolerance of north_star is therefore met with margin).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(nfeatures=1000, flags=0, oflags=None):
+    import orb_slam3_amd as osa
+    from oracle import oracle_binding as ob
+    if oflags is None:
+        oflags = 0
+        if not (flags & 1):
+            oflags |= ob.FLAG_DESC_FMA
+        if flags & 2:
+            oflags |= ob.FLAG_BLUR_OCV440
+    return osa.ORBextractor(nfeatures, 1.2, 8, 20, 7, flags=flags), ob.OracleExtractor(nfeatures, 1.2, 8, 20, 7, flags=oflags)
+
+
+def _check_frame(ex, oex, img, lap, stagewise=True):
+    mono, kps, desc = ex(img, None, lap)
+    omono, okps, odesc = oex.extract(img, lap=lap)
+    if stagewise:
+        for l in range(8):
+            got = ex.get_level(l)
+            want = oex.level_padded(l)
+            assert got.shape == want.shape, (l, got.shape, want.shape)
+            assert np.array_equal(got, want), f"pyramid level {l}: {np.count_nonzero(got != want)} px differ"
+        for l in range(8):
+            want = oex.level_blurred(l)
+            if want is not None:
+                got = ex.debug_blurred(l)
+                assert np.array_equal(got, want), f"blur level {l}: {np.count_nonzero(got != want)} px differ"
+        for l in range(8):
+            got, want = ex.debug_candidates(l), oex.level_candidates(l)
+            assert len(got) == len(want), f"FAST candidates level {l}: {len(got)} vs {len(want)}"
+            for fld in ("x", "y", "response"):
+                assert np.array_equal(got[fld], want[fld]), f"FAST candidates level {l} field {fld}"
+        for l in range(8):
+            got, want = ex.debug_level_keypoints(l), oex.level_keypoints(l)
+            assert len(got) == len(want), f"quad-tree level {l}: {len(got)} vs {len(want)}"
+            for fld in ("x", "y", "response"):
+                assert np.array_equal(got[fld], want[fld]), f"quad-tree level {l} field {fld} (order matters)"
+    assert mono == omono
+    assert len(kps) == len(okps)
+    for fld in kps.dtype.names:
+        bad = np.nonzero(kps[fld] != okps[fld])[0]
+        assert len(bad) == 0, f"keypoint field {fld}: {len(bad)} differ, first {bad[:5]} got {kps[fld][bad[:5]]} want {okps[fld][bad[:5]]}"
+    assert kps.tobytes() == okps.tobytes()
+    bad = np.nonzero((desc != odesc).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} descriptors differ, first {bad[:5]}"
+    return len(kps)
+
+
+def test_small_image_stagewise():
+    from orb_slam3_amd import synth
+    ex, oex = _pair(500)
+    img = synth.make_test_image(5, 320, 240)
+    assert _check_frame(ex, oex, img, (0, 1000)) > 100
+
+
+def test_euroc_frames_bit_exact(canvas1):
+    """BASELINE config 2: EuRoC 752x480 mono nFeatures=1000, lapping {0,1000} (Frame.cc:311)."""
+    from orb_slam3_amd import synth
+    ex, oex = _pair(1000)
+    total = 0
+    for t in range(6):
+        img = synth.frame_from_canvas(canvas1, t, 752, 480, 1000 + t)
+        total += _check_frame(ex, oex, img, (0, 1000), stagewise=(t == 0))
+    assert total > 5000
+
+
+def test_forward_order_and_partial_lapping(canvas1):
+    """lapping {0,0} (rectified stereo, Frame.cc:122) keeps level order; a partial band splits front/back."""
+    from orb_slam3_amd import synth
+    ex, oex = _pair(1000)
+    img = synth.frame_from_canvas(canvas1, 3, 752, 480, 1003)
+    _check_frame(ex, oex, img, (0, 0), stagewise=False)
+    _check_frame(ex, oex, img, (200, 500), stagewise=False)
+
+
+def test_kitti_shape(canvas1):
+    """BASELINE config 3 shape: 1241x376, nFeatures=2000."""
+    from orb_slam3_amd import synth
+    ex, oex = _pair(2000)
+    img = synth.frame_from_canvas(canvas1, 1, 1241, 376, 3001)
+    _check_frame(ex, oex, img, (0, 0), stagewise=True)
+
+
+def test_tumvi_shape():
+    """BASELINE config 4 shape: 1024x1024, nFeatures=1500."""
+    from orb_slam3_amd import synth
+    ex, oex = _pair(1500)
+    canvas = synth.make_canvas(4)
+    img = synth.frame_from_canvas(canvas, 2, 1024, 1024, 5002)
+    _check_frame(ex, oex, img, (0, 1000), stagewise=True)
+
+
+def test_ini_extractor_5x(canvas1):
+    """Mono initialisation uses 5*nFeatures (Tracking.cc:601)."""
+    from orb_slam3_amd import synth
+    ex, oex = _pair(5000)
+    img = synth.frame_from_canvas(canvas1, 7, 752, 480, 1007)
+    _check_frame(ex, oex, img, (0, 1000), stagewise=True)
+
+
+def test_strict_and_ocv440_modes(canvas1):
+    from orb_slam3_amd import synth
+    img = synth.frame_from_canvas(canvas1, 9, 752, 480, 1009)
+    for flags in (1, 2, 3):
+        ex, oex = _pair(1000, flags=flags)
+        _check_frame(ex, oex, img, (0, 1000), stagewise=False)
+
+
+def test_flat_and_noise_images():
+    """Edge cases: constant image (no corners at all -> 0 keypoints), pure noise (fallback threshold everywhere)."""
+    ex, oex = _pair(1000)
+    flat = np.full((480, 752), 127, np.uint8)
+    mono, kps, desc = ex(flat, None, (0, 1000))
+    omono, okps, odesc = oex.extract(flat, lap=(0, 1000))
+    assert len(kps) == 0 and len(okps) == 0 and mono == omono == 0
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, (480, 752), dtype=np.uint8)
+    _check_frame(ex, oex, noise, (0, 1000), stagewise=True)
+    lowc = (120 + rng.integers(0, 12, (480, 752))).astype(np.uint8)  # only the minThFAST fallback fires
+    _check_frame(ex, oex, lowc, (0, 1000), stagewise=True)
+
+
+def test_empty_and_too_small():
+    import orb_slam3_amd as osa
+    ex = osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    mono, kps, desc = ex(np.zeros((0, 0), np.uint8), None, (0, 0))
+    assert mono == -1 and len(kps) == 0          # ORBextractor.cc:1090
+    with pytest.raises(osa.OrbxError):
+        ex(np.zeros((100, 100), np.uint8), None, (0, 0))   # level 7 would be 28x28: no FAST cell
+
+
+def test_strided_input(canvas1):
+    from orb_slam3_amd import synth
+    ex, oex = _pair(1000)
+    big = synth.frame_from_canvas(canvas1, 11, 800, 500, 1011)
+    view = big[10:490, 20:772]  # non-contiguous rows (stride 800)
+    mono, kps, desc = ex(view, None, (0, 1000))
+    omono, okps, odesc = oex.extract(np.ascontiguousarray(view), lap=(0, 1000))
+    assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_batch_device_matches_single(canvas1):
+    """The batched device-resident entry point returns, per frame, exactly what operator() returns."""
+    import torch
+    from orb_slam3_amd import synth
+    ex, oex = _pair(1000)
+    frames = np.stack([synth.frame_from_canvas(canvas1, t, 752, 480, 1000 + t) for t in range(5)])
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), 5, 752, 480, 752, 752 * 480, (0, 1000))
+    for t in range(5):
+        mono, kps, desc = ex.download(t)
+        omono, okps, odesc = oex.extract(frames[t], lap=(0, 1000))
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), t
+
+
+def test_device_introsort_replica_matches_libstdcxx():
+    """k_octree's std::sort replica vs libstdc++ on (count, UL.x) pairs with many ties, incl. sizes around the
+    insertion-sort threshold and adversarial (heap-sort fallback) inputs."""
+    import ctypes as C
+    from orb_slam3_amd import _lib
+    from oracle import oracle_binding as ob
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 15, 16, 17, 18, 31, 33, 64, 100, 257, 1000, 3000]
+    for n in sizes:
+        for variant in range(3):
+            if variant == 0:
+                cnt = rng.integers(2, 6, n)
+                ulx = rng.integers(0, 8, n) * 45
+            elif variant == 1:
+                cnt = rng.integers(2, 40, n)
+                ulx = rng.integers(0, 700, n)
+            else:  # organ-pipe / sorted runs stress the pivot choice
+                cnt = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]) + 2
+                ulx = np.zeros(n, np.int64)
+            cnt = cnt.astype(np.int32)
+            ulx = ulx.astype(np.int32)
+            perm = np.zeros(n, np.int32)
+            _lib.check(L.orbx_debug_sort_nodes(0, _lib.ptr(cnt), _lib.ptr(ulx), n, _lib.ptr(perm)), "sort")
+            want = ob.sort_nodes(cnt, ulx)
+            assert np.array_equal(perm, want), (n, variant)

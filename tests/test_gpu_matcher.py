@@ -1,0 +1,195 @@
+"""GPU parity tests of the matchers (through the C ABI) vs the CPU oracle: bit-exact index pairs / distances."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_desc(rng, n):
+    return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+def _noisy_copy(rng, d, p):
+    flip = (rng.random((len(d), 256)) < p)
+    return d ^ np.packbits(flip, axis=1, bitorder="little")
+
+
+def test_hamming_csr_and_best2(oracle):
+    import orb_slam3_amd as osa
+    rng = np.random.default_rng(0)
+    m = osa.ORBmatcher()
+    T = _rand_desc(rng, 1500)
+    Q = _noisy_copy(rng, T[rng.integers(0, 1500, 400)], 0.1)
+    Q[5] = T[7]
+    lens = rng.integers(0, 90, 400)
+    lens[3] = 0
+    lens[10] = 200
+    row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cand = rng.integers(0, 1500, row_ptr[-1]).astype(np.int32)
+    # inject exact ties: duplicate candidates
+    cand[row_ptr[10] + 5] = cand[row_ptr[10] + 50]
+    dist = m.hamming_csr(Q, T, row_ptr, cand)
+    want = np.array([oracle.descriptor_distance(Q[i], T[cand[k]]) for i in range(400) for k in range(row_ptr[i], row_ptr[i + 1])])
+    assert np.array_equal(dist, want)
+    bp, bd, sp, sd = m.hamming_best2_csr(Q, T, row_ptr, cand)
+    for i in range(400):
+        ds = want[row_ptr[i]:row_ptr[i + 1]]
+        b, b2, p, p2 = 256, 256, -1, -1
+        for k, d in enumerate(ds):  # the reference's sequential scan (ORBmatcher.cc:103-119)
+            if d < b:
+                b2, p2, b, p = b, p, d, k
+            elif d < b2:
+                b2, p2 = d, k
+        assert (bp[i], bd[i], sp[i], sd[i]) == (p, b, p2, b2), i
+
+
+def test_descriptor_distance_known_answers(oracle):
+    import orb_slam3_amd as osa
+    m = osa.ORBmatcher()
+    z = np.zeros((1, 32), np.uint8)
+    f = np.full((1, 32), 255, np.uint8)
+    one = z.copy()
+    one[0, 17] = 0x10
+    rp = np.array([0, 3], np.int32)
+    T = np.concatenate([z, f, one])
+    d = m.hamming_csr(z, T, rp, np.array([0, 1, 2], np.int32))
+    assert list(d) == [0, 256, 1]
+
+
+def test_knn2_with_ties(oracle):
+    import orb_slam3_amd as osa
+    rng = np.random.default_rng(1)
+    m = osa.ORBmatcher()
+    T = _rand_desc(rng, 2300)   # > one LDS tile
+    T[100] = T[2200]            # exact duplicates -> distance ties, lower train index must win
+    Q = _noisy_copy(rng, T[rng.integers(0, 2300, 700)], 0.05)
+    Q[0] = T[100]
+    idx, dist = m.knn2(Q, T)
+    oi, od = oracle.knn2(Q, T)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    idx, dist = m.knn2(Q[:3], T[:1])   # fewer than k train rows
+    oi, od = oracle.knn2(Q[:3], T[:1])
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def _extract_pair(w=752, h=480, nf=1000):
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    canvas = synth.make_canvas(3)
+    left, right = synth.make_stereo_pair(3, 0, w, h, canvas)
+    exl = osa.ORBextractor(nf, 1.2, 8, 20, 7)
+    exr = osa.ORBextractor(nf, 1.2, 8, 20, 7)
+    _, kl, dl = exl(left, None, (0, 0))
+    _, kr, dr = exr(right, None, (0, 0))
+    return exl, exr, kl, dl, kr, dr
+
+
+def test_stereo_rowband_and_full_stereo(oracle):
+    """BASELINE config 3 (KITTI shape 1241x376, nFeatures=2000): Frame::ComputeStereoMatches."""
+    import orb_slam3_amd as osa
+    exl, exr, kl, dl, kr, dr = _extract_pair(1241, 376, 2000)
+    m = osa.ORBmatcher()
+    sf, isf = exl.GetScaleFactors(), exl.GetInverseScaleFactors()
+    pyl = [np.ascontiguousarray(p) for p in exl.mvImagePyramid]
+    pyr = [np.ascontiguousarray(p) for p in exr.mvImagePyramid]
+    bf, b = 0.53716 * 718.856, 0.53716
+    on, our, odepth, obi, obd = oracle.compute_stereo_matches(kl, dl, kr, dr, sf, isf, pyl, pyr, bf, b)
+    bi, bd = m.stereo_rowband(kl, dl, kr, dr, sf, 376, 0.0, bf / b)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    assert (bi >= 0).sum() > 200
+    n, ur, depth = m.ComputeStereoMatches(kl, dl, kr, dr, sf, isf, pyl, pyr, bf, b)
+    assert n == on and ur.tobytes() == our.tobytes() and depth.tobytes() == odepth.tobytes()
+    assert n > 100
+
+
+def _frame_view(kps, desc, sf, w, h):
+    import orb_slam3_amd as osa
+    return osa.FrameView(kps, desc, 0.0, float(w), 0.0, float(h), sf)
+
+
+def test_search_by_projection_frame(oracle, canvas1):
+    """M2 (ORBmatcher.cc:1676-1887): consecutive EuRoC-shaped frames, th=15, with taken-mask and rotation filter."""
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    ex = osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    f0 = synth.frame_from_canvas(canvas1, 0, 752, 480, 1000)
+    f1 = synth.frame_from_canvas(canvas1, 1, 752, 480, 1001)
+    _, k0, d0 = ex(f0, None, (0, 1000))
+    _, k1, d1 = ex(f1, None, (0, 1000))
+    sf = ex.GetScaleFactors()
+    rng = np.random.default_rng(5)
+    for mode, check_ori, th in ((0, True, 15.0), (1, True, 7.0), (2, False, 15.0), (0, True, 30.0)):
+        q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
+                 desc=d0, has_obs=(rng.random(len(k0)) < 0.9).astype(np.uint8))
+        occ = (rng.random(len(k1)) < 0.05).astype(np.uint8)
+        grid = oracle.OracleGrid(k1, 0.0, 752.0, 0.0, 480.0)
+        on, ocm = oracle.search_by_projection_frame(grid, d1, sf, q, th, mode, check_ori, None, occ)
+        m = osa.ORBmatcher(0.9, check_ori)
+        n, cm = m.SearchByProjectionFrame(_frame_view(k1, d1, sf, 752, 480), q, th, mode, occ)
+        assert n == on and np.array_equal(cm, ocm), (mode, n, on)
+        assert n > 50
+
+
+def test_search_by_projection_mappoints(oracle):
+    """BASELINE config 4 (TUM-VI shape): SearchByProjection against 10k map-point descriptors (M1)."""
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    canvas = synth.make_canvas(4)
+    ex = osa.ORBextractor(1500, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(9)
+    kp_all, d_all = [], []
+    for t in range(1, 8):
+        _, k, d = ex(synth.frame_from_canvas(canvas, t, 1024, 1024, 5000 + t), None, (0, 1000))
+        k = k.copy()
+        k["x"] += 2.0 * t   # frame t is the canvas shifted by (2t, t): bring to frame-0 coordinates
+        k["y"] += 1.0 * t
+        kp_all.append(k)
+        d_all.append(d)
+    _, kf, df = ex(synth.frame_from_canvas(canvas, 0, 1024, 1024, 5000), None, (0, 1000))
+    sf = ex.GetScaleFactors()
+    src_k = np.concatenate(kp_all)[:10000]
+    src_d = np.concatenate(d_all)[:10000]
+    n_mp = len(src_k)
+    assert n_mp == 10000
+    mp = dict(proj_x=src_k["x"] + rng.normal(0, 2, n_mp).astype(np.float32),
+              proj_y=src_k["y"] + rng.normal(0, 2, n_mp).astype(np.float32),
+              proj_xr=np.zeros(n_mp, np.float32), level=src_k["octave"],
+              view_cos=rng.uniform(0.9, 1.0, n_mp).astype(np.float32), desc=_noisy_copy(rng, src_d, 0.04),
+              in_view=(rng.random(n_mp) < 0.95).astype(np.uint8), has_obs=(rng.random(n_mp) < 0.97).astype(np.uint8))
+    occ = (rng.random(len(kf)) < 0.1).astype(np.uint8)
+    for th in (1.0, 3.0):
+        grid = oracle.OracleGrid(kf, 0.0, 1024.0, 0.0, 1024.0)
+        on, ofm = oracle.search_by_projection_mappoints(grid, df, sf, mp, th, 0.8, None, occ)
+        m = osa.ORBmatcher(0.8, True)
+        n, fm = m.SearchByProjection(_frame_view(kf, df, sf, 1024, 1024), mp, th, occ)
+        assert n == on and np.array_equal(fm, ofm), (th, n, on)
+        assert n > 100
+
+
+def test_match_consecutive_device_equals_host_api(oracle, canvas1):
+    """The batched device-resident frame-to-frame matcher returns what M2 returns frame by frame."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    ex = osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    nfr = 4
+    frames = np.stack([synth.frame_from_canvas(canvas1, t, 752, 480, 1000 + t) for t in range(nfr)])
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), nfr, 752, 480, 752, 752 * 480, (0, 1000))
+    cap = ex.batch_view().cap
+    d_match = torch.full((nfr, cap), -7, dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+    ex.match_consecutive_device(d_match.data_ptr(), d_nm.data_ptr(), th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+    ex.sync()
+    match, nm = d_match.cpu().numpy(), d_nm.cpu().numpy()
+    sf = ex.GetScaleFactors()
+    outs = [ex.download(t) for t in range(nfr)]
+    for t in range(1, nfr):
+        _, k0, d0 = outs[t - 1]
+        _, k1, d1 = outs[t]
+        q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
+                 desc=d0, has_obs=np.ones(len(k0), np.uint8))
+        grid = oracle.OracleGrid(k1, 0.0, 752.0, 0.0, 480.0)
+        on, ocm = oracle.search_by_projection_frame(grid, d1, sf, q, 15.0, 0, True, None, None)
+        assert nm[t] == on and np.array_equal(match[t, :len(k1)], ocm), t
+        assert on > 300
