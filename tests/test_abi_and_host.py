@@ -1,0 +1,68 @@
+"""CPU tests: liborbx.so loads and exports every symbol include/orbx.h declares; host-side logic (no compute calls)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_header_symbols_exported():
+    from orb_slam3_amd import _lib
+    hdr = (ROOT / "include" / "orbx.h").read_text()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = C.CDLL(str(_lib.LIB_PATH))
+    for s in declared:
+        assert hasattr(L, s), f"liborbx.so does not export {s}"
+
+
+def test_keypoint_layout_matches_cv_keypoint():
+    from orb_slam3_amd import KP_DTYPE
+    assert KP_DTYPE.itemsize == 28
+    assert [KP_DTYPE.fields[n][1] for n in ("x", "y", "size", "angle", "response", "octave", "class_id")] == [0, 4, 8, 12, 16, 20, 24]
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU the create functions must fail (no CPU fallback).  Skipped on a GPU box."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import orb_slam3_amd as osa
+    with pytest.raises(osa.OrbxError) as ei:
+        osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert ei.value.status == -5
+    with pytest.raises(osa.OrbxError):
+        osa.ORBmatcher()
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through the oracle."""
+    for p in (ROOT / "orb_slam3_amd").rglob("*"):
+        if p.suffix in (".py", ".hip", ".h", ".cpp", ".inc") and p.is_file():
+            txt = p.read_text(errors="ignore")
+            assert "oracle_binding" not in txt and "orb_oracle" not in txt and "liborb_oracle" not in txt, p
+
+
+def test_pattern_tables_pinned():
+    import hashlib
+    want = "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    for p in (ROOT / "oracle" / "orb_pattern_data.inc", ROOT / "orb_slam3_amd" / "csrc" / "orb_pattern.inc"):
+        vals = [int(v) for line in p.read_text().splitlines() if not line.startswith("//") for v in line.split(",") if v.strip()]
+        assert len(vals) == 1024 and max(abs(v) for v in vals) == 13
+        assert hashlib.sha256(bytes(v & 0xFF for v in vals)).hexdigest() == want
+        # pattern radius fits the 19-px border used by the extractor (max radius 18.38)
+        assert max(np.hypot(vals[i], vals[i + 1]) for i in range(0, 1024, 2)) < 19
+
+
+def test_synth_is_deterministic():
+    from orb_slam3_amd import synth
+    a = synth.make_test_image(5, 320, 240)
+    b = synth.make_test_image(5, 320, 240)
+    assert np.array_equal(a, b) and a.shape == (240, 320) and a.dtype == np.uint8
+    import hashlib
+    assert a.std() > 20

@@ -1,0 +1,207 @@
+"""CPU tests: the oracle against analytic known answers derived from the reference source.
+
+The reference has no tests or golden vectors for this path ("parity unpinned"); these pin what can be derived
+by hand from the cited lines, and tests/golden pins the oracle against regressions.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+
+def test_tables_known_answers(oracle):
+    # ORBextractor.cc:414-468
+    t = oracle.OracleExtractor(1000, 1.2, 8, 20, 7).tables()
+    assert list(t["umax"]) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert sum(2 * u + 1 for u in t["umax"][1:]) * 2 + 31 == 749
+    assert list(t["quota"]) == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert list(oracle.OracleExtractor(2000, 1.2, 8, 20, 7).tables()["quota"]) == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert list(oracle.OracleExtractor(1500, 1.2, 8, 20, 7).tables()["quota"]) == [326, 271, 226, 189, 157, 131, 109, 91]
+    assert list(oracle.OracleExtractor(5000, 1.2, 8, 20, 7).tables()["quota"]) == [1086, 905, 754, 628, 524, 436, 364, 303]
+    sc = t["scale"]
+    assert sc[0] == 1.0 and sc[1] == np.float32(1.2)
+    assert [int(31 * s) for s in sc] == [31, 37, 44, 53, 64, 77, 92, 111]
+    assert np.array_equal(t["inv_scale"], (np.float32(1.0) / sc).astype(np.float32))
+
+
+@pytest.mark.parametrize("w,h,sizes", [
+    (752, 480, [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]),
+    (1241, 376, [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]),
+    (1024, 1024, [(1024, 1024), (853, 853), (711, 711), (593, 593), (494, 494), (412, 412), (343, 343), (286, 286)]),
+])
+def test_pyramid_sizes(oracle, w, h, sizes):
+    ex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    img = np.full((h, w), 100, np.uint8)
+    ex.extract(img)
+    assert [ex.level_size(l) for l in range(8)] == sizes
+    assert sum(a * b for a, b in sizes) == {752: 1117367, 1241: 1444097, 1024: 3246580}[w]
+
+
+def test_cv_round_half_even(oracle):
+    L = oracle.lib()
+    assert [L.orbo_cv_round_f(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+
+
+def test_descriptor_distance(oracle):
+    z, f = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert oracle.descriptor_distance(z, f) == 256 and oracle.descriptor_distance(f, f) == 0
+    one = z.copy()
+    one[9] = 4
+    assert oracle.descriptor_distance(z, one) == 1
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+    assert oracle.descriptor_distance(a, b) == int(np.unpackbits(a ^ b).sum())
+
+
+def test_fast_atan2_axes_and_accuracy(oracle):
+    assert oracle.fast_atan2(0, 1) == 0 and oracle.fast_atan2(1, 0) == 90
+    assert oracle.fast_atan2(0, -1) == 180 and oracle.fast_atan2(-1, 0) == 270
+    rng = np.random.default_rng(1)
+    for y, x in rng.integers(-3000000, 3000000, (2000, 2)):
+        got = oracle.fast_atan2(float(y), float(x))
+        want = np.degrees(np.arctan2(float(y), float(x))) % 360
+        assert abs((got - want + 180) % 360 - 180) < 0.31
+
+
+def test_blur_constant_is_identity_and_impulse(oracle):
+    img = np.full((40, 50), 93, np.uint8)
+    assert np.array_equal(oracle.gauss7(img), img)
+    img = np.zeros((41, 41), np.uint8)
+    img[20, 20] = 255
+    out = oracle.gauss7(img)
+    g = np.array([18, 34, 48, 56, 48, 34, 18])
+    want = (255 * np.outer(g, g) + 32768) >> 16
+    assert np.array_equal(out[17:24, 17:24], want)
+    g0 = np.array([18, 34, 49, 55, 49, 34, 18])
+    assert np.array_equal(oracle.gauss7(img, ocv440=True)[17:24, 17:24], (255 * np.outer(g0, g0) + 32768) >> 16)
+    # REFLECT_101 at the border: a pixel at column 0 is seen with weights g3 + 0 (centre) and mirrored taps
+    img = np.zeros((20, 20), np.uint8)
+    img[10, 1] = 200
+    out = oracle.gauss7(img)
+    assert out[10, 0] == (200 * (g[4] + g[2]) * g[3] + 32768) >> 16   # x=1 reached as +1 and as reflect(-1)
+
+
+def test_fast_isolated_pixel(oracle):
+    # a single bright pixel of height hgt on a flat background: all 16 circle pixels are darker by hgt -> score hgt-1
+    for hgt in (8, 21, 100):
+        img = np.full((21, 21), 50, np.uint8)
+        img[10, 10] = 50 + hgt
+        kps = oracle.fast9_16(img, 7)
+        assert len(kps) == 1 and (kps[0]["x"], kps[0]["y"], kps[0]["response"]) == (10, 10, hgt - 1)
+        assert kps[0]["size"] == 7 and kps[0]["angle"] == -1
+        assert len(oracle.fast9_16(img, hgt)) == 0          # needs d > threshold strictly
+        assert len(oracle.fast9_16(img, hgt - 1)) == 1
+
+
+def test_fast_nms_ties_kill_each_other(oracle):
+    img = np.full((21, 24), 50, np.uint8)
+    img[10, 10] = 120
+    img[10, 14] = 120  # far enough apart not to disturb each other's circle: two corners
+    assert len(oracle.fast9_16(img, 20)) == 2
+    img = np.full((21, 24), 50, np.uint8)
+    img[10, 10] = 120
+    img[10, 11] = 120  # adjacent equal-score corners: strict '>' removes both (if both are corners)
+    k = oracle.fast9_16(img, 20)
+    sc = oracle.fast_score_map(img)
+    if sc[10, 10] == sc[10, 11] and sc[10, 10] >= 20:
+        assert all(not (kp["y"] == 10 and kp["x"] in (10, 11)) for kp in k)
+
+
+def test_fast_score_equivalence_to_definition(oracle):
+    """cornerScore formula == largest t with a 9-arc all darker/brighter by more than t, on random patches."""
+    rng = np.random.default_rng(2)
+    circ = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+            (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    for _ in range(300):
+        img = rng.integers(0, 256, (7, 7), dtype=np.uint8)
+        if rng.random() < 0.5:
+            img[3, 3] = rng.integers(200, 256)
+            img[img < 60] += 30
+        got = oracle.lib().orbo_fast_score(C.c_void_p(img.ctypes.data + 3 * 7 + 3), 7)
+        v = int(img[3, 3])
+        d = [v - int(img[3 + dy, 3 + dx]) for dx, dy in circ]
+        best = -10 ** 9
+        for k in range(16):
+            arc = [d[(k + j) % 16] for j in range(9)]
+            best = max(best, min(arc), min(-a for a in arc))
+        assert got == max(best, 0) - 1
+
+
+def test_resize_identity_and_constant(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear(img, 53, 37), img)      # same size: fx = 0 everywhere
+    const = np.full((100, 120), 77, np.uint8)
+    assert np.all(oracle.resize_linear(const, 100, 83) == 77)
+    # 2:1 decimation by INTER_LINEAR samples exactly between pixels: (a+b+c+d+2)>>2 up to the Q11 truncations
+    out = oracle.resize_linear(img[:36, :52], 26, 18)
+    a = img[:36:2, :52:2].astype(int) + img[1:36:2, :52:2] + img[:36:2, 1:52:2] + img[1:36:2, 1:52:2]
+    assert np.max(np.abs(out.astype(int) - ((a + 2) >> 2))) <= 1
+
+
+def test_mono_lapping_reverses_order(oracle, canvas1):
+    from orb_slam3_amd import synth
+    img = synth.frame_from_canvas(canvas1, 0, 752, 480, 1000)
+    ex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    m0, k0, d0 = ex.extract(img, lap=(0, 0))
+    m1, k1, d1 = ex.extract(img, lap=(0, 1000))
+    assert m0 == len(k0) and m1 == 0                       # Frame.cc:311 {0,1000}: everything is "lapping"
+    assert k1.tobytes() == k0[::-1].tobytes() and np.array_equal(d1, d0[::-1])
+    assert np.all(k0["octave"][:-1] <= k0["octave"][1:])   # forward order = level order
+    assert np.all((k0["x"] >= 19) & (k0["class_id"] == -1))
+    assert len(k0) >= 1000 and len(k0) <= 1000 + 8 * 3
+
+
+def test_quadtree_respects_quota_and_picks_max_response(oracle):
+    rng = np.random.default_rng(4)
+    n = 3000
+    pts = rng.permutation(720 * 448)[:n]
+    c = np.zeros(n, oracle.KP_DTYPE)
+    c["x"], c["y"] = pts % 720, pts // 720
+    order = np.lexsort((c["x"], c["y"]))
+    c = c[order]
+    c["response"] = rng.integers(7, 120, n)
+    out = oracle.distribute_octree(c, 16, 736, 16, 464, 217)
+    assert 217 <= len(out) <= 217 + 3
+    assert len({(k["x"], k["y"]) for k in out}) == len(out)
+    few = c[:50]
+    assert len(oracle.distribute_octree(few, 16, 736, 16, 464, 217)) == 50   # fewer than N: every point survives
+
+
+def test_restated_sincos_matches_host_libm_sampled(oracle):
+    """The restated glibc sinf/cosf is bit-identical to this host's libm (exhaustive run: tools/check_sincos.py)."""
+    L = oracle.lib()
+    fb = C.c_uint32(0)
+    lo = struct.unpack("<I", struct.pack("<f", 1e-5))[0]
+    hi = struct.unpack("<I", struct.pack("<f", 6.5))[0]
+    step = (hi - lo) // 64
+    bad = 0
+    for k in range(64):   # 64 windows of 200k consecutive floats each
+        bad += L.orbo_check_sincos_vs_libm(lo + k * step, lo + k * step + 200000, C.byref(fb))
+    assert bad == 0, hex(fb.value)
+
+
+def test_three_maxima(oracle):
+    assert oracle.three_maxima([0] * 30) == (-1, -1, -1)
+    h = [0] * 30
+    h[3], h[7], h[9] = 50, 20, 4
+    assert oracle.three_maxima(h) == (3, 7, -1)     # third < 10% of first
+    h[9] = 6
+    assert oracle.three_maxima(h) == (3, 7, 9)
+    h[7] = 4
+    assert oracle.three_maxima(h) == (3, 9, -1)     # 6 >= 10% of 50, 4 is not
+    h[9] = 4
+    assert oracle.three_maxima(h) == (3, -1, -1)
+
+
+def test_grid_query_order_and_bounds(oracle):
+    k = np.zeros(5, oracle.KP_DTYPE)
+    k["x"] = [100.0, 101.0, 99.0, 100.5, 400.0]
+    k["y"] = [100.0, 100.0, 101.0, 99.0, 300.0]
+    k["octave"] = [0, 1, 2, 0, 0]
+    g = oracle.OracleGrid(k, 0.0, 752.0, 0.0, 480.0)
+    got = list(g.query(100.0, 100.0, 5.0))
+    assert sorted(got) == [0, 1, 2, 3] and 4 not in got
+    assert list(g.query(100.0, 100.0, 5.0, 1, 1)) == [1]
+    assert len(g.query(-500.0, 100.0, 5.0)) == 0 and len(g.query(5000.0, 100.0, 5.0)) == 0
