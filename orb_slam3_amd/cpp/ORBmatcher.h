@@ -1,0 +1,113 @@
+// ORBmatcher.h -- adapter with the surface of /root/reference/include/ORBmatcher.h:36-103 over the C ABI.
+//
+// The reference matchers take Frame / KeyFrame / MapPoint pointer graphs guarded by mutexes.  The adapter's job
+// (see INTEGRATION.md for the Frame-typed overloads a maintainer adds inside the ORB-SLAM3 tree) is to flatten what
+// the loops read under the reference's locks, call the kernels, and write the assignments back in reference order.
+// This header holds the dependency-free core: same constants, same constructor, DescriptorDistance, and the
+// flattened forms of the two SearchByProjection variants and of the stereo matchers.
+#ifndef ORBX_ADAPTER_ORBMATCHER_H
+#define ORBX_ADAPTER_ORBMATCHER_H
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+namespace ORB_SLAM3 {
+
+// What the projection matchers read of a Frame (Frame.h: mvKeysUn, mDescriptors, mnMinX.., mvScaleFactors, mvuRight)
+struct FrameView {
+    const orbx_keypoint *mvKeysUn = nullptr;
+    const uint8_t *mDescriptors = nullptr;  // N x 32
+    int N = 0;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
+    const float *mvScaleFactors = nullptr;
+    int nlevels = 0;
+    const float *mvuRight = nullptr;  // NULL for monocular
+    orbx_frame_desc c() const { return orbx_frame_desc{mvKeysUn, mDescriptors, N, mnMinX, mnMaxX, mnMinY, mnMaxY, mvScaleFactors, nlevels, mvuRight}; }
+};
+
+// The MapPoint scratch fields SearchByProjection reads (MapPoint.h:171-179), one entry per map point
+struct MapPointBatch {
+    std::vector<float> mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos;
+    std::vector<int32_t> mnTrackScaleLevel;
+    std::vector<uint8_t> descriptors;  // n x 32 (MapPoint::GetDescriptor)
+    std::vector<uint8_t> inView;       // mbTrackInView && !isBad() && !(bFarPoints && mTrackDepth > thFarPoints)
+    std::vector<uint8_t> hasObservations;  // Observations() > 0
+    int size() const { return (int)mTrackProjX.size(); }
+};
+
+class ORBmatcher {
+public:
+    static const int TH_LOW = ORBX_TH_LOW;
+    static const int TH_HIGH = ORBX_TH_HIGH;
+    static const int HISTO_LENGTH = ORBX_HISTO_LENGTH;
+
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
+        const int st = orbx_matcher_create(device, &m_);
+        if (st != ORBX_OK) throw std::runtime_error(std::string("orbx_matcher_create: ") + orbx_status_string(st) + " " + orbx_last_error());
+    }
+    ~ORBmatcher() { orbx_matcher_destroy(m_); }
+    ORBmatcher(const ORBmatcher &) = delete;
+    ORBmatcher &operator=(const ORBmatcher &) = delete;
+
+    // ORBmatcher::DescriptorDistance (ORBmatcher.cc:2058-2074); scalar host helper for the adapter's own glue
+    static int DescriptorDistance(const uint8_t *a, const uint8_t *b) {
+        int dist = 0;
+        for (int i = 0; i < 4; i++) {
+            uint64_t x, y;
+            __builtin_memcpy(&x, a + 8 * i, 8);
+            __builtin_memcpy(&y, b + 8 * i, 8);
+            dist += __builtin_popcountll(x ^ y);
+        }
+        return dist;
+    }
+
+    // SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, bFarPoints, thFarPoints)
+    // (ORBmatcher.cc:43-213, Nleft == -1).  vpMatch[i] = index into `mps` assigned to feature i, or -1.
+    int SearchByProjection(const FrameView &F, const std::vector<uint8_t> &occupied, const MapPointBatch &mps, float th,
+                           std::vector<int32_t> &vpMatch) {
+        vpMatch.assign(F.N, -1);
+        orbx_frame_desc fd = F.c();
+        const int r = orbx_search_by_projection_mappoints(
+            m_, &fd, occupied.empty() ? nullptr : occupied.data(), mps.size(), mps.mTrackProjX.data(), mps.mTrackProjY.data(),
+            mps.mTrackProjXR.empty() ? nullptr : mps.mTrackProjXR.data(), mps.mnTrackScaleLevel.data(), mps.mTrackViewCos.data(),
+            mps.descriptors.data(), mps.inView.empty() ? nullptr : mps.inView.data(),
+            mps.hasObservations.empty() ? nullptr : mps.hasObservations.data(), th, mfNNratio, vpMatch.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_search_by_projection_mappoints: ") + orbx_status_string(r));
+        return r;
+    }
+
+    // SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (ORBmatcher.cc:1676-1887) after the
+    // adapter projected LastFrame's map points with CurrentFrame's pose (host float math, unchanged).
+    struct ProjectedQueries {
+        std::vector<float> u, v, ur, angle;
+        std::vector<int32_t> octave;
+        std::vector<uint8_t> descriptors, hasObservations;
+    };
+    int SearchByProjection(const FrameView &Cur, const std::vector<uint8_t> &occupied, const ProjectedQueries &q, float th,
+                           bool bForward, bool bBackward, std::vector<int32_t> &vpMatch) {
+        vpMatch.assign(Cur.N, -1);
+        orbx_frame_desc fd = Cur.c();
+        const int mode = bForward ? 1 : (bBackward ? 2 : 0);
+        const int r = orbx_search_by_projection_frame(
+            m_, &fd, occupied.empty() ? nullptr : occupied.data(), (int)q.u.size(), q.u.data(), q.v.data(),
+            q.ur.empty() ? nullptr : q.ur.data(), q.octave.data(), q.angle.data(), q.descriptors.data(),
+            q.hasObservations.empty() ? nullptr : q.hasObservations.data(), th, mode, mbCheckOrientation ? 1 : 0, vpMatch.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_search_by_projection_frame: ") + orbx_status_string(r));
+        return r;
+    }
+
+    orbx_matcher *handle() { return m_; }
+
+protected:
+    float mfNNratio;
+    bool mbCheckOrientation;
+    orbx_matcher *m_ = nullptr;
+};
+
+}  // namespace ORB_SLAM3
+
+#endif
