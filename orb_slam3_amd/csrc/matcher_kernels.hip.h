@@ -33,6 +33,7 @@ __device__ __forceinline__ int hamming(const Desc &a, const Desc &b) {
 }
 
 constexpr u64 kNoKey = ~0ull;
+constexpr int kTopK = 4;
 
 // keep the two smallest keys
 __device__ __forceinline__ void push2(u64 &k1, u64 &k2, u64 k) {
@@ -200,7 +201,8 @@ struct WindowProblem {
     const float *scale;         // mvScaleFactors
     float th, du, dv;
     // outputs
-    u64 *key1, *key2;           // per query: two smallest candidate keys (kNoKey = none)
+    u64 *keys;                  // per query: the kTopK smallest candidate keys, ascending (kNoKey = none)
+    int32_t *meta;              // per query: valid_len | exhaustive << 8  (see k_window_best2)
 };
 
 // candidate key: dist << 32 | cellx << 24 | celly << 16 | idx   (candidate order of GetFeaturesInArea: ix outer,
@@ -258,8 +260,9 @@ __device__ __forceinline__ bool load_query(const WindowProblem &P, int qi, Query
 }
 
 // scan all features of the current frame for query window w; skip features flagged in `occ` (may be NULL)
-__device__ __forceinline__ void scan_window(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
-                                            const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
+__device__ __forceinline__ int scan_window(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
+                                           const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
+    int cnt = 0;
     for (int i = lane; i < n; i += 64) {
         if (occ && occ[i]) continue;
         const orbx_keypoint kp = P.kps[i];
@@ -271,10 +274,17 @@ __device__ __forceinline__ void scan_window(const WindowProblem &P, const GridPa
         }
         const int d = hamming(dq, load_desc(P.desc + (size_t)i * 32));
         push2(k1, k2, cand_key(d, cx, cy, i));
+        cnt++;
     }
+    return cnt;
 }
 
-// grid (ceil(max_q/4), n_problems), block 256: one wave per query
+// grid (ceil(max_q/4), n_problems), block 256: one wave per query.
+// Output: the kTopK smallest candidate keys in ascending order.  Each lane keeps its own two smallest; the wave
+// extracts minima round by round.  If a lane that saw more than two candidates has both of its entries extracted,
+// later rounds could miss that lane's third candidate, so the list is cut there (valid_len); `exhaustive` says the
+// list holds every candidate of the query.  k_greedy_resolve falls back to a re-scan when it needs more than the
+// valid part of a non-exhaustive list, which keeps the result exact.
 __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__restrict__ probs, GridParams g) {
     const WindowProblem P = probs[blockIdx.y];
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -282,11 +292,29 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
     QueryWin w;
     Desc dq;
     u64 k1 = kNoKey, k2 = kNoKey;
-    if (load_query(P, qi, &w, g, &dq)) {
-        scan_window(P, g, w, dq, *P.n_ptr, P.occupied0, lane, k1, k2);
-        wave_min2(k1, k2);
+    int cnt = 0;
+    if (load_query(P, qi, &w, g, &dq)) cnt = scan_window(P, g, w, dq, *P.n_ptr, P.occupied0, lane, k1, k2);
+    int total = cnt;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) total += __shfl_xor(total, s);
+    u64 out[kTopK];
+    int valid_len = 0, npop = 0;
+    bool cut = false;
+#pragma unroll
+    for (int r = 0; r < kTopK; r++) {
+        const u64 m = wave_min1(k1);
+        out[r] = m;
+        if (m != kNoKey && !cut) valid_len = r + 1;
+        const bool mine = (m != kNoKey) && (k1 == m);
+        if (mine) { k1 = k2; k2 = kNoKey; npop++; }
+        // a lane that ran dry while it had seen more than two candidates invalidates everything after this round
+        cut = cut || (__ballot(mine && npop == 2 && cnt > 2) != 0ull);
     }
-    if (lane == 0) { P.key1[qi] = k1; P.key2[qi] = k2; }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < kTopK; r++) P.keys[(size_t)qi * kTopK + r] = out[r];
+        P.meta[qi] = valid_len | ((total <= valid_len) ? 256 : 0);
+    }
 }
 
 struct ResolveProblem {
@@ -297,71 +325,154 @@ struct ResolveProblem {
     const uint8_t *q_has_obs; // NULL = all true
     int32_t *match;           // [n] query index per feature or -1
     int32_t *nmatches;        // scalar out
-    uint8_t *occ;             // [n] scratch: occupancy during the replay
     int32_t *entries;         // [nq] scratch: rotation histogram entries bin << 16 | feature (M2)
 };
 
-// one wave per problem: sequential replay in query order; rescans a query's window only when one of its
-// two best candidates was taken by an earlier query.
+// One wave per problem: exact replay of the reference's sequential query loop.
+// The dependency between queries is only the taken-mask (occ).  Queries are processed 64 at a time: every lane
+// holds its query's sorted candidate list and picks the first (M1: first two) candidates that are still free.
+// A lane "conflicts" when an earlier lane of the chunk currently wants the same feature.  All lanes before the
+// first conflicting lane commit in parallel (their choices cannot influence each other); the conflicting lane simply
+// re-evaluates in the next round against the updated mask.  Only when a lane exhausts the valid part of a
+// non-exhaustive list does the whole wave re-scan that query's window against the current mask -- exactly what the
+// sequential loop would have seen.  Dynamic LDS: claim[n_alloc] (u32) + occ[n_alloc] (u8).
 __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
-                                                       GridParams g) {
-    __shared__ int hist[ORBX_HISTO_LENGTH];
+                                                       GridParams g, int n_alloc) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ int hist[ORBX_HISTO_LENGTH + 2];
+    uint32_t *claim = reinterpret_cast<uint32_t *>(lds);
+    uint8_t *occ = lds + (size_t)n_alloc * 4;
     const WindowProblem P = probs[blockIdx.x];
     const ResolveProblem R = res[blockIdx.x];
     const int lane = threadIdx.x;
-    const int n = *P.n_ptr, nq = *P.nq_ptr;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    const int n = min(*P.n_ptr, n_alloc), nq = *P.nq_ptr;
     for (int i = lane; i < n; i += 64) {
-        R.occ[i] = P.occupied0 ? P.occupied0[i] : 0;
+        occ[i] = P.occupied0 ? P.occupied0[i] : 0;
+        claim[i] = 0xffffffffu;
         R.match[i] = -1;
     }
     if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
     __syncthreads();
     int nmatches = 0, n_entries = 0;
     const float factor = 1.0f / ORBX_HISTO_LENGTH;
-    for (int qi = 0; qi < nq; qi++) {
-        u64 k1 = P.key1[qi], k2 = P.key2[qi];
-        if (k1 == kNoKey) continue;
-        const int i1 = (int)(k1 & 0xffff), i2 = (k2 == kNoKey) ? -1 : (int)(k2 & 0xffff);
-        const bool stale = R.occ[i1] || (R.mode == 1 && i2 >= 0 && R.occ[i2]);
-        if (stale) {  // rare: redo this query's scan against the current occupancy
-            QueryWin w;
-            Desc dq;
-            k1 = kNoKey; k2 = kNoKey;
-            if (load_query(P, qi, &w, g, &dq)) {
-                scan_window(P, g, w, dq, n, R.occ, lane, k1, k2);
-                wave_min2(k1, k2);
-            }
-            if (k1 == kNoKey) continue;
-        }
-        const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xffff);
-        if (bestDist > ORBX_TH_HIGH) continue;
-        if (R.mode == 1) {
-            // ORBmatcher.cc:123-139: ratio test only when best and second-best share the octave
+    const bool ori = (R.mode == 2 && R.check_orientation);
+    const bool two = (R.mode == 1);
+
+    // decide whether (k1,k2) yields a match; M1 applies the ratio test (ORBmatcher.cc:123-139)
+    auto accept = [&](u64 k1, u64 k2) -> bool {
+        if (k1 == kNoKey) return false;
+        const int bestDist = (int)(k1 >> 32);
+        if (bestDist > ORBX_TH_HIGH) return false;
+        if (two) {
             const int bestDist2 = (k2 == kNoKey) ? 256 : (int)(k2 >> 32);
-            const int bestLevel = P.kps[bestIdx].octave;
+            const int bestLevel = P.kps[(int)(k1 & 0xffff)].octave;
             const int bestLevel2 = (k2 == kNoKey) ? -1 : P.kps[(int)(k2 & 0xffff)].octave;
-            if (bestLevel == bestLevel2 && (float)bestDist > R.nnratio * (float)bestDist2) continue;
-            if (!(bestLevel != bestLevel2 || (float)bestDist <= R.nnratio * (float)bestDist2)) continue;
+            if (bestLevel == bestLevel2 && (float)bestDist > R.nnratio * (float)bestDist2) return false;
+            if (!(bestLevel != bestLevel2 || (float)bestDist <= R.nnratio * (float)bestDist2)) return false;
         }
-        if (lane == 0) {
-            R.match[bestIdx] = qi;
-            R.occ[bestIdx] = R.q_has_obs ? R.q_has_obs[qi] : 1;
-            if (R.mode == 2 && R.check_orientation) {  // :1775-1792
-                const float qa = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
-                float rot = qa - P.kps[bestIdx].angle;
-                if (rot < 0.0f) rot += 360.0f;
-                int b = (int)roundf(rot * factor);
-                if (b == ORBX_HISTO_LENGTH) b = 0;
-                R.entries[n_entries] = (b << 16) | bestIdx;  // rotHist[bin].push_back(bestIdx2)
-                hist[b]++;
+        return true;
+    };
+    auto rot_bin = [&](int qi, int idx) -> int {  // :1775-1792
+        const float qa = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
+        float rot = qa - P.kps[idx].angle;
+        if (rot < 0.0f) rot += 360.0f;
+        int b = (int)roundf(rot * factor);
+        if (b == ORBX_HISTO_LENGTH) b = 0;
+        return b;
+    };
+
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int qi = q0 + lane;
+        const bool active = qi < nq;
+        u64 L0 = kNoKey, L1 = kNoKey, L2 = kNoKey, L3 = kNoKey;
+        int valid_len = 0;
+        bool exhaustive = true;
+        if (active) {
+            const u64 *kp = P.keys + (size_t)qi * kTopK;
+            L0 = kp[0]; L1 = kp[1]; L2 = kp[2]; L3 = kp[3];
+            const int m = P.meta[qi];
+            valid_len = m & 0xff;
+            exhaustive = (m & 256) != 0;
+        }
+        int pos = 0;
+        while (pos < 64) {
+            const bool live = active && lane >= pos;
+            // first (two) still-free candidates of the valid list
+            u64 c1 = kNoKey, c2 = kNoKey;
+            bool need_slow = false;
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < kTopK; e++) {
+                    const u64 k = e == 0 ? L0 : e == 1 ? L1 : e == 2 ? L2 : L3;
+                    if (e < valid_len && !occ[(int)(k & 0xffff)]) {
+                        if (c1 == kNoKey) c1 = k;
+                        else if (c2 == kNoKey) c2 = k;
+                    }
+                }
+                if (!exhaustive) {
+                    if (c1 == kNoKey) need_slow = true;                                   // best unknown
+                    else if (two && c2 == kNoKey && (int)(c1 >> 32) <= ORBX_TH_HIGH) need_slow = true;  // second-best unknown
+                }
             }
+            const bool has = live && !need_slow && c1 != kNoKey && (int)(c1 >> 32) <= ORBX_TH_HIGH;
+            const int t1 = has ? (int)(c1 & 0xffff) : -1;
+            const int t2 = (has && two && c2 != kNoKey) ? (int)(c2 & 0xffff) : -1;
+            if (has) atomicMin(&claim[t1], (uint32_t)lane);
+            __syncthreads();
+            const bool conflict = need_slow || (has && (claim[t1] != (uint32_t)lane || (t2 >= 0 && claim[t2] < (uint32_t)lane)));
+            __syncthreads();
+            if (has) claim[t1] = 0xffffffffu;
+            const u64 cb = __ballot(conflict);
+            const int c = cb ? (__ffsll((long long)cb) - 1) : 64;
+            // parallel commit of the conflict-free prefix [pos, c)
+            const bool ok = has && lane < c && accept(c1, c2);
+            const u64 okb = __ballot(ok);
+            if (ok) {
+                R.match[t1] = qi;
+                occ[t1] = R.q_has_obs ? R.q_has_obs[qi] : 1;
+                if (ori) {
+                    const int b = rot_bin(qi, t1);
+                    R.entries[n_entries + __popcll(okb & lt_mask)] = (b << 16) | t1;  // rotHist[bin].push_back(bestIdx2)
+                    atomicAdd(&hist[b], 1);
+                }
+            }
+            nmatches += __popcll(okb);
+            if (ori) n_entries += __popcll(okb);
+            __syncthreads();
+            if (c >= 64) break;
+            const bool slow = (__shfl((int)need_slow, c) != 0);
+            if (!slow) { pos = c; continue; }  // claim conflict: lane c re-evaluates against the updated mask
+            {   // list exhausted: re-scan query q0+c against the occupancy the sequential loop sees at this point
+                const int qc = q0 + c;
+                QueryWin w;
+                Desc dq;
+                u64 r1 = kNoKey, r2 = kNoKey;
+                if (load_query(P, qc, &w, g, &dq)) {
+                    scan_window(P, g, w, dq, n, occ, lane, r1, r2);
+                    wave_min2(r1, r2);
+                }
+                if (accept(r1, r2)) {
+                    const int idx = (int)(r1 & 0xffff);
+                    if (lane == 0) {
+                        R.match[idx] = qc;
+                        occ[idx] = R.q_has_obs ? R.q_has_obs[qc] : 1;
+                        if (ori) {
+                            const int b = rot_bin(qc, idx);
+                            R.entries[n_entries] = (b << 16) | idx;
+                            hist[b]++;
+                        }
+                    }
+                    nmatches++;
+                    if (ori) n_entries++;
+                }
+                __syncthreads();
+            }
+            pos = c + 1;
         }
-        nmatches++;
-        if (R.mode == 2 && R.check_orientation) n_entries++;
-        __syncthreads();
     }
     __syncthreads();
-    if (R.mode == 2 && R.check_orientation) {
+    if (ori) {
         // ComputeThreeMaxima :2012-2053
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
         for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {

@@ -230,6 +230,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     }
     {
         ProfScope ps(ex, K_OCTREE);
+        if (oct_lds_bytes(ex->max_pool) > 64 * 1024)
+            ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(ex->max_pool)));
         hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), oct_lds_bytes(ex->max_pool), st, d_lv,
                            (const int32_t *)ex->d_cellcnt.p, ex->total_cells, (const uint32_t *)ex->d_cellent.p, ex->cand_frame,
                            (uint32_t *)ex->d_keys0.p, (uint32_t *)ex->d_keys1.p, (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame,

@@ -18,6 +18,9 @@ using namespace orbx;
 
 namespace {
 
+constexpr int kMaxResolveFeatures = 28000;  // claim (4 B) + occ (1 B) per feature must fit the 160 KB LDS
+inline size_t resolve_lds_bytes(int n) { return (size_t)n * 5 + 64; }
+
 struct Arena {  // bump allocator over one device buffer, reset per call
     uint8_t *base = nullptr;
     size_t cap = 0, used = 0;
@@ -266,7 +269,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     if (n > 65535) return ORBX_E_TOO_LARGE;
     ORBX_HIP(hipSetDevice(m->device));
     size_t need = Arena::pad(28 * (size_t)n) + Arena::pad(32 * (size_t)n) + 3 * Arena::pad((size_t)n) + Arena::pad(4 * (size_t)n) * 2 +
-                  Arena::pad(4 * (size_t)nq) * 7 + Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) * 2 + Arena::pad(8 * (size_t)nq) * 2 +
+                  Arena::pad(4 * (size_t)nq) * 7 + Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) * 2 + Arena::pad(8 * (size_t)nq) * 5 +
                   Arena::pad(sizeof(WindowProblem)) + Arena::pad(sizeof(ResolveProblem)) + 16 * 256 + 4096;
     int r = m->arena.reserve(need);
     if (r != ORBX_OK) return r;
@@ -295,13 +298,12 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     if (a.qxr && F->u_right) { float *p = A.take<float>(nq); H2D(p, a.qxr, 4 * (size_t)nq); P.qxr = p; }
     { uint8_t *p = A.take<uint8_t>(32 * (size_t)nq); H2D(p, a.qdesc, 32 * (size_t)nq); P.qdesc = p; }
     if (a.qvalid) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.qvalid, (size_t)nq); P.qvalid = p; }
-    P.key1 = A.take<u64>(nq); P.key2 = A.take<u64>(nq);
+    P.keys = A.take<u64>((size_t)nq * kTopK); P.meta = A.take<int32_t>(nq);
     R.mode = a.mode; R.nnratio = a.nnratio; R.check_orientation = a.check_orientation;
     if (a.q_angle) { float *p = A.take<float>(nq); H2D(p, a.q_angle, 4 * (size_t)nq); R.q_angle = p; }
     if (a.q_has_obs) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.q_has_obs, (size_t)nq); R.q_has_obs = p; }
     R.match = A.take<int32_t>(n);
     R.nmatches = A.take<int32_t>(1);
-    R.occ = A.take<uint8_t>(n);
     R.entries = A.take<int32_t>(nq);
     WindowProblem *dP = A.take<WindowProblem>(1);
     ResolveProblem *dR = A.take<ResolveProblem>(1);
@@ -311,7 +313,10 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     g.inv_w = 64.0f / (F->max_x - F->min_x);  // Frame.cc:342-343
     g.inv_h = 48.0f / (F->max_y - F->min_y);
     hipLaunchKernelGGL(k_window_best2, dim3((nq + 3) / 4, 1), dim3(256), 0, m->stream, dP, g);
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), 0, m->stream, dP, dR, g);
+    if (n > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;
+    if (resolve_lds_bytes(n) > 64 * 1024)
+        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n);
     int32_t nm = 0;
     D2H(a.match_out, R.match, 4 * (size_t)n);
     D2H(&nm, R.nmatches, 4);
@@ -381,14 +386,13 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     if (!ex || !d_match || !d_nmatches) return ORBX_E_BAD_ARG;
     const int n = ex->last_batch;
     if (n < 2) return ORBX_OK;
-    if (ex->cap > 65535) return ORBX_E_TOO_LARGE;
+    if (ex->cap > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;
     ORBX_HIP(hipSetDevice(ex->device));
     const int np = n - 1, cap = ex->cap;
     int r;
 #define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
-    ENS(ex->d_mkey1, 8 * (size_t)cap * np);
-    ENS(ex->d_mkey2, 8 * (size_t)cap * np);
-    ENS(ex->d_mocc, (size_t)cap * np);
+    ENS(ex->d_mkey1, 8 * (size_t)kTopK * cap * np);
+    ENS(ex->d_mkey2, 4 * (size_t)cap * np);
     ENS(ex->d_mentries, 4 * (size_t)cap * np);
     ENS(ex->d_mprobs, sizeof(WindowProblem) * (size_t)np);
     ENS(ex->d_mres, sizeof(ResolveProblem) * (size_t)np);
@@ -406,12 +410,11 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         w.kps = kps + (size_t)f * cap; w.desc = desc + (size_t)f * cap * 32; w.n_ptr = count + f;
         w.q_from_kps = kps + (size_t)(f - 1) * cap; w.qdesc = desc + (size_t)(f - 1) * cap * 32; w.nq_ptr = count + (f - 1);
         w.th = th; w.du = du; w.dv = dv;
-        w.key1 = (u64 *)ex->d_mkey1.p + (size_t)p * cap; w.key2 = (u64 *)ex->d_mkey2.p + (size_t)p * cap;
+        w.keys = (u64 *)ex->d_mkey1.p + (size_t)p * cap * kTopK; w.meta = (int32_t *)ex->d_mkey2.p + (size_t)p * cap;
         ResolveProblem &q = R[p];
         memset(&q, 0, sizeof(q));
         q.mode = 2; q.check_orientation = check_orientation;
         q.match = d_match + (size_t)f * cap; q.nmatches = d_nmatches + f;
-        q.occ = (uint8_t *)ex->d_mocc.p + (size_t)p * cap;
         q.entries = (int32_t *)ex->d_mentries.p + (size_t)p * cap;
     }
     // mvScaleFactors on the device: reuse a per-extractor buffer appended after the problems
@@ -436,8 +439,10 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         ex->prof_ms[K_MATCH_SCAN] += ms; ex->prof_n[K_MATCH_SCAN]++;
         (void)hipEventRecord(e0, ex->stream);
     }
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), 0, ex->stream, (const WindowProblem *)ex->d_mprobs.p,
-                       (const ResolveProblem *)ex->d_mres.p, g);
+    if (resolve_lds_bytes(cap) > 64 * 1024)
+        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), resolve_lds_bytes(cap), ex->stream, (const WindowProblem *)ex->d_mprobs.p,
+                       (const ResolveProblem *)ex->d_mres.p, g, cap);
     if (ex->profile) {
         (void)hipEventRecord(e1, ex->stream); (void)hipEventSynchronize(e1);
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
