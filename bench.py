@@ -111,46 +111,56 @@ def main():
 
     ex = osa.ORBextractor(NFEATURES, 1.2, NLEVELS, 20, 7, device=local_rank)
     cap = ex.output_capacity(W, H)
-    d_match = torch.empty((B, cap), dtype=torch.int32, device="cuda")
-    d_nm = torch.zeros(B, dtype=torch.int32, device="cuda")
-    # pinned host destinations (the Tracking thread's buffers)
-    h_kps = torch.empty((B, cap, 28), dtype=torch.uint8).pin_memory()
-    h_desc = torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory()
-    h_cnt = torch.empty(B, dtype=torch.int32).pin_memory()
-    h_mono = torch.empty(B, dtype=torch.int32).pin_memory()
-    h_match = torch.empty((B, cap), dtype=torch.int32).pin_memory()
-    h_nm = torch.empty(B, dtype=torch.int32).pin_memory()
-    L = ex._L
+    # pinned host destinations (the Tracking thread's buffers), double-buffered: the D2H of step i overlaps the
+    # kernels of step i+1 (copy stream inside liborbx); a step is complete when its results are on the host
+    class HostSet:
+        def __init__(self):
+            self.kps = torch.empty((B, cap, 28), dtype=torch.uint8).pin_memory()
+            self.desc = torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory()
+            self.cnt = torch.zeros(B, dtype=torch.int32).pin_memory()
+            self.mono = torch.zeros(B, dtype=torch.int32).pin_memory()
+            self.match = torch.empty((B, cap), dtype=torch.int32).pin_memory()
+            self.nm = torch.zeros(B, dtype=torch.int32).pin_memory()
+    host = [HostSet(), HostSet()]
 
-    def step():
+    def enqueue(i):
+        hs = host[i % 2]
         ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, (0, 1000))
-        ex.match_consecutive_device(d_match.data_ptr(), d_nm.data_ptr(), th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
-        # results to the host: keypoints, descriptors, counts (+ stream sync inside download_all)
-        st = L.orbx_batch_download_all(ex._h, C.c_void_p(h_kps.data_ptr()), C.c_void_p(h_desc.data_ptr()),
-                                       C.c_void_p(h_cnt.data_ptr()), C.c_void_p(h_mono.data_ptr()))
-        if st < 0:
-            raise RuntimeError(f"orbx_batch_download_all: {st}")
-        h_match.copy_(d_match, non_blocking=True)
-        h_nm.copy_(d_nm, non_blocking=True)
-        torch.cuda.synchronize()
-        return int(h_cnt.sum())
+        ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        ex.download_async(hs.kps.data_ptr(), hs.desc.data_ptr(), hs.cnt.data_ptr(), hs.mono.data_ptr(),
+                          hs.match.data_ptr(), hs.nm.data_ptr())
+
+    def run(nsteps):
+        """nsteps pipelined steps; returns the number of features delivered to the host."""
+        feats = 0
+        for i in range(nsteps):
+            if i > 0:
+                ex.download_wait()        # results of step i-1 are on the host ...
+                # (the next enqueue below waits on-device for that copy before overwriting the outputs)
+                feats += int(host[(i - 1) % 2].cnt.sum())
+            enqueue(i)
+        ex.download_wait()
+        feats += int(host[(nsteps - 1) % 2].cnt.sum())
+        return feats
+
+    def step():   # un-pipelined single step (profiling passes)
+        return run(1)
 
     def barrier():
         torch.cuda.synchronize()
+        ex.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(max(args.warmup, 1))
     barrier()
     t0 = time.perf_counter()
-    feats = 0
-    for _ in range(args.steps):
-        feats += step()
+    feats = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    nmatch = int(h_nm[1:].sum())
+    nmatch = int(host[(args.steps - 1) % 2].nm[1:].sum())
+    h_cnt = host[(args.steps - 1) % 2].cnt
 
     from orb_slam3_amd import sharding
     dt_max, feats_all = sharding.reduce_throughput(dt, feats, device="cuda")

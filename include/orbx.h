@@ -114,6 +114,14 @@ int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *keypoints,
 int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *keypoints, uint8_t *descriptors, int32_t *counts,
                             int32_t *mono_index);
 int orbx_output_capacity(orbx_extractor *ex, int width, int height);
+/* Asynchronous form: the D2H copies run on the extractor's copy stream behind the kernels of the last batch and
+ * overlap the kernels of the NEXT batch (which wait for the copy before overwriting the device outputs).
+ * Host buffers should be pinned.  match / nmatches (optional) receive the internal results of
+ * orbx_match_consecutive_device(..., NULL, NULL): [n_frames][cap] / [n_frames].  orbx_download_wait blocks until
+ * the copies have landed and reports device-side errors. */
+int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *keypoints, uint8_t *descriptors, int32_t *counts,
+                              int32_t *mono_index, int32_t *match, int32_t *nmatches);
+int orbx_download_wait(orbx_extractor *ex);
 
 /* mvImagePyramid[level] (public member read by Frame::ComputeStereoMatches, Frame.cc:818,908,923): copies the
  * padded level (19-px REFLECT_101 ring included) of `frame` of the last batch to host memory.
@@ -232,7 +240,8 @@ int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur,
  * extractor's last batch, the keypoints of frame f-1 (queries, at their own position shifted by (du, dv)) are
  * matched against frame f exactly as orbx_search_by_projection_frame does with level_mode 0, all features free on
  * entry and every query "has observations".  d_match: device int32 [n_frames][cap] (query index in frame f-1 or -1),
- * d_nmatches: device int32 [n_frames].  Asynchronous on the extractor's stream. */
+ * d_nmatches: device int32 [n_frames]; pass NULL for both to use internal buffers (fetched with
+ * orbx_batch_download_async).  Asynchronous on the extractor's stream. */
 int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                   int32_t *d_match, int32_t *d_nmatches);
 

@@ -56,7 +56,7 @@ _lib = None
 # every symbol include/orbx.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch_device", "orbx_batch_view_get", "orbx_sync",
-    "orbx_batch_download", "orbx_batch_download_all", "orbx_output_capacity", "orbx_get_level", "orbx_level_size",
+    "orbx_batch_download", "orbx_batch_download_all", "orbx_batch_download_async", "orbx_download_wait", "orbx_output_capacity", "orbx_get_level", "orbx_level_size",
     "orbx_get_level_device", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_scale_tables",
     "orbx_get_feature_tables", "orbx_debug_level_candidates", "orbx_debug_level_keypoints",
     "orbx_debug_level_blurred", "orbx_profile_enable", "orbx_profile_read", "orbx_matcher_create",
@@ -88,6 +88,8 @@ def lib() -> C.CDLL:
     L.orbx_batch_download.argtypes = [vp, i32, vp, vp, i32, vp, vp]
     L.orbx_batch_download_all.argtypes = [vp, vp, vp, vp, vp]
     L.orbx_output_capacity.argtypes = [vp, i32, i32]
+    L.orbx_batch_download_async.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.orbx_download_wait.argtypes = [vp]
     L.orbx_get_level.argtypes = [vp, i32, i32, vp, sz]
     L.orbx_level_size.argtypes = [vp, i32, i32, i32, vp, vp]
     L.orbx_get_level_device.argtypes = [vp, i32, i32, vp, vp]

@@ -143,7 +143,11 @@ __device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int p
 // reference runs cv::FAST on the sub-image, so outside-interior neighbours score 0), then the cell emits
 //   S20 = {survivors with score >= iniTh}  if non-empty, else  S7 = {survivors with score >= minTh}
 // in row-major order into its slot of the frame's candidate slab.
-// grid (total_cells, B), block 256, dynamic LDS: pix tile + score tile
+//
+// Phases: (0) dword-coalesced tile load; (1) cheap NECESSARY test on the 4 antipodal circle pairs at minTh (a
+// 9-arc contains one pixel of every antipodal pair) -> passing pixels are queued in LDS with a wave-aggregated
+// atomic; (2) exact score only for queued pixels, all lanes busy; (3) NMS; (4) ordered ballot compaction.
+// grid (total_cells, B), block 256, dynamic LDS: pixel tile + score tile + queue
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
                                                     const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
@@ -151,11 +155,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
                                                     uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
                                                     int minTh) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ int wsum[4];
     const TileRef t = tiles[blockIdx.x];
     const int f = blockIdx.y;
     const LevelInfo L = lv[t.level];
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int cell = t.ti * L.nCols + t.tj;
     int32_t *cnt_out = cellcnt + (size_t)f * total_cells + L.cell_base + cell;
 
@@ -169,32 +173,69 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
         if (tid == 0) *cnt_out = 0;
         return;
     }
-    const int pp = (cols + 3) & ~3;            // LDS pitch of the pixel tile
+    const int ax = iniX & 3;                   // the tile is loaded from the enclosing aligned dwords
+    const int pp = (cols + ax + 3) & ~3;       // LDS pitch of the pixel tile (bytes, multiple of 4)
     const int sp = iw + 2;                     // pitch of the score tile (1-px zero apron)
-    uint8_t *pix = smem;                       // rows * pp   (later reused as the survivor map, iw*ih)
-    uint8_t *sco = smem + ((rows * pp + 15) & ~15);  // (ih+2) * sp
+    const int n = iw * ih;
+    // carve (all offsets multiples of 16)
+    int *ctrl = reinterpret_cast<int *>(smem);                 // [0..3] wave sums, [4] queue length
+    uint8_t *pix = smem + 32;                                  // rows * pp   (later reused as the survivor map)
+    uint8_t *sco = pix + ((rows * pp + 15) & ~15);             // (ih+2) * sp
+    uint16_t *queue = reinterpret_cast<uint16_t *>(sco + (((ih + 2) * sp + 15) & ~15));  // n entries
+    const uint32_t rcp = ((1u << 20) + (uint32_t)iw - 1u) / (uint32_t)iw;  // exact i / iw for i < 2^20 / iw
 
-    const uint8_t *src = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX;
-    for (int i = tid; i < rows * cols; i += 256) {
-        const int r = i / cols, c = i - r * cols;
-        pix[r * pp + c] = src[(size_t)r * L.pitch + c];
+    {   // phase 0: dword loads (the ROI row starts 64-B aligned; iniX - ax is 4-B aligned)
+        const uint8_t *src = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + (iniX - ax);
+        const int nd = pp >> 2;
+        const uint32_t rcpd = ((1u << 20) + (uint32_t)nd - 1u) / (uint32_t)nd;
+        for (int i = tid; i < rows * nd; i += 256) {
+            const int r = (int)(((uint32_t)i * rcpd) >> 20), c = i - r * nd;
+            reinterpret_cast<uint32_t *>(pix)[i] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * L.pitch + 4 * c);
+        }
+        for (int i = tid; i < (((ih + 2) * sp + 3) >> 2); i += 256) reinterpret_cast<uint32_t *>(sco)[i] = 0;
+        if (tid == 0) ctrl[4] = 0;
     }
-    for (int i = tid; i < (ih + 2) * sp; i += 256) sco[i] = 0;
     __syncthreads();
 
-    const int n = iw * ih;
-    for (int i = tid; i < n; i += 256) {
-        const int y = i / iw, x = i - y * iw;
-        int s = fast_score16(pix + (y + 3) * pp + x + 3, pp);
+    // phase 1: necessary condition at minTh on the antipodal pairs (0,8) (4,12) (2,10) (6,14)
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        bool pass = false;
+        if (i < n) {
+            const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
+            const uint8_t *c = pix + (y + 3) * pp + x + 3 + ax;
+            const int v = c[0], hi = v + minTh, lo = v - minTh;
+            const int p0 = c[3 * pp], p8 = c[-3 * pp], p4 = c[3], p12 = c[-3];
+            const int p2 = c[2 * pp + 2], p10 = c[-2 * pp - 2], p6 = c[-2 * pp + 2], p14 = c[2 * pp - 2];
+            const bool br = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi) && (p2 > hi || p10 > hi) && (p6 > hi || p14 > hi);
+            const bool dk = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo) && (p2 < lo || p10 < lo) && (p6 < lo || p14 < lo);
+            pass = br || dk;
+        }
+        const unsigned long long b = __ballot(pass);
+        if (b) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ctrl[4], __popcll(b));
+            base = __shfl(base, 0);
+            if (pass) queue[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+
+    // phase 2: exact score of the queued pixels
+    const int qn = ctrl[4];
+    for (int e = tid; e < qn; e += 256) {
+        const int i = queue[e];
+        const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
+        int s = fast_score16(pix + (y + 3) * pp + x + 3 + ax, pp);
         s = (s >= minTh) ? s : 0;
         sco[(y + 1) * sp + x + 1] = (uint8_t)s;
     }
     __syncthreads();
 
-    // NMS: strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); survivors keep their score
+    // phase 3: NMS, strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); survivors keep their score
     int any_ini = 0;
     for (int i = tid; i < n; i += 256) {
-        const int y = i / iw, x = i - y * iw;
+        const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
         const uint8_t *p = sco + (y + 1) * sp + x + 1;
         const int s = p[0];
         const bool keep = s > 0 && s > p[-1] && s > p[1] && s > p[-sp - 1] && s > p[-sp] && s > p[-sp + 1] &&
@@ -205,9 +246,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
     any_ini = __syncthreads_or(any_ini);
     const int thr = any_ini ? iniTh : minTh;
 
-    // ordered (row-major) compaction of the selected set into the cell slot
+    // phase 4: ordered (row-major) compaction of the selected set into the cell slot
     uint32_t *slot = cellent + (size_t)f * ent_frame_stride + L.cand_off + (size_t)cell * L.cell_cap;
-    const int lane = tid & 63, wv = tid >> 6;
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
@@ -215,14 +255,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
         if (i < n) s = pix[i];
         const bool sel = s > 0 && s >= thr;
         const unsigned long long b = __ballot(sel);
-        if (lane == 0) wsum[wv] = __popcll(b);
+        if (lane == 0) ctrl[wv] = __popcll(b);
         __syncthreads();
         int off = base;
-        for (int k = 0; k < wv; k++) off += wsum[k];
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        for (int k = 0; k < wv; k++) off += ctrl[k];
+        const int tot = ctrl[0] + ctrl[1] + ctrl[2] + ctrl[3];
         if (sel) {
             const int rank = off + __popcll(b & ((1ull << lane) - 1ull));
-            const int y = i / iw, x = i - y * iw;
+            const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
             if (rank < L.cell_cap) slot[rank] = pack_key(x + 3 + t.tj * L.wCell, y + 3 + t.ti * L.hCell, s);
         }
         base += tot;
@@ -304,54 +344,79 @@ __global__ __launch_bounds__(256) void k_finalize(const LevelInfo *__restrict__ 
 
 // ---------------------------------------------------------------------------------------------------------
 // [OCV] GaussianBlur 7x7 sigma 2 on 8U, fixed-point (Q8 taps, exact 2-D sum, one rounding, saturate).
-// Borders REFLECT_101 of the level itself (the reference blurs a ring-less clone, :1132-1133).
-// Tile 64 x 16 outputs per workgroup; horizontal pass into LDS (u16), vertical pass from LDS.
-// grid (n_blur_tiles, B)
+// The reference blurs a ring-less clone with BORDER_REFLECT_101 (:1132-1133); the padded pyramid level already
+// carries exactly that reflection in its 19-px ring, so the kernel reads the ring and needs no border logic.
+//
+// Register-marching separable filter, no LDS, no barriers: a lane owns a 4-pixel-wide column strip and walks down
+// kBlurRows output rows.  Per source row it loads three aligned dwords (12 px), forms the four horizontal sums with
+// v_alignbyte + v_dot4_u32_u8 (taps packed as bytes), keeps the last seven rows of sums in registers (rotation
+// resolved at compile time by unrolling 7x) and emits one packed dword of vertical results per row.
+// A wave covers 256 x kBlurRows pixels with fully coalesced 256-B row loads/stores; a workgroup = 4 row blocks.
+// grid (n_blur_tiles, B), block 256
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kBlurTW = 64, kBlurTH = 16;
+constexpr int kBlurTW = 256;            // pixels per wave row
+constexpr int kBlurRows = 42;           // output rows per wave (6 prologue rows + 6 x 7 main-loop rows)
+constexpr int kBlurTH = 4 * kBlurRows;  // rows per workgroup
+
+__device__ __forceinline__ void blur_hrow(const uint8_t *__restrict__ rowp, uint32_t tap_lo, uint32_t tap_hi, uint32_t h[4]) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(rowp);
+    const uint32_t wm = p[-1], wc = p[0], wp = p[1];  // pixels x0-4 .. x0+7
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        // window of pixel x0+j: bytes (x0+j-3 .. x0+j) and (x0+j+1 .. x0+j+4)
+        // (v_alignbyte uses only 2 shift bits: the 4-byte shift of j == 3 is the next dword itself)
+        const uint32_t lo = (j == 3) ? wc : __builtin_amdgcn_alignbyte(wc, wm, 1 + j);
+        const uint32_t hi = (j == 3) ? wp : __builtin_amdgcn_alignbyte(wp, wc, 1 + j);
+        h[j] = __builtin_amdgcn_udot4(hi, tap_hi, __builtin_amdgcn_udot4(lo, tap_lo, 0u, false), false);
+    }
+}
 
 __global__ __launch_bounds__(256) void k_blur(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
                                               const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
                                               uint8_t *__restrict__ blur, size_t blur_frame_stride, int g0, int g1,
                                               int g2, int g3) {
-    __shared__ uint8_t pix[(kBlurTH + 6) * (kBlurTW + 8)];
-    __shared__ uint16_t hor[(kBlurTH + 6) * kBlurTW];
     const TileRef t = tiles[blockIdx.x];
     const int f = blockIdx.y;
     const LevelInfo L = lv[t.level];
-    const int tid = threadIdx.x;
-    const int x0 = t.tj * kBlurTW, y0 = t.ti * kBlurTH;
-    const uint8_t *roi = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)kEdge * L.pitch + kRoiX;
-    constexpr int PW = kBlurTW + 8;  // 70 used
-    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
-        const int r = i / (kBlurTW + 6), c = i - r * (kBlurTW + 6);
-        const int sy = reflect101(min(y0 + r - 3, L.h + 2), L.h);  // rows beyond the level are never used
-        const int sx = reflect101(min(x0 + c - 3, L.w + 2), L.w);
-        pix[r * PW + c] = roi[(size_t)sy * L.pitch + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        const int r = i / kBlurTW, c = i - r * kBlurTW;
-        const uint8_t *p = pix + r * PW + c;
-        const int s = g0 * (p[0] + p[6]) + g1 * (p[1] + p[5]) + g2 * (p[2] + p[4]) + g3 * p[3];
-        hor[i] = (uint16_t)s;  // <= 255*257
-    }
-    __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6;
-    const int x = x0 + tx;
-    if (x < L.w) {
-        uint8_t *dst = blur + (size_t)f * blur_frame_stride + L.boff;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = t.tj * kBlurTW + lane * 4;
+    const int y0 = (t.ti * 4 + wv) * kBlurRows;
+    if (x0 >= L.w || y0 >= L.h) return;
+    const uint32_t tap_lo = (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) | ((uint32_t)g3 << 24);  // x-3..x
+    const uint32_t tap_hi = (uint32_t)g2 | ((uint32_t)g1 << 8) | ((uint32_t)g0 << 16);                          // x+1..x+3
+    const uint8_t *roi = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)kEdge * L.pitch + kRoiX + x0;
+    uint8_t *dst = blur + (size_t)f * blur_frame_stride + L.boff + x0;
+    const int ymax = L.h + kEdge - 1;  // last ring row that exists
+    uint32_t hw[7][4];
+    auto src_row = [&](int r) -> const uint8_t * {  // r-th source row of this strip: level row y0 - 3 + r
+        const int y = min(y0 - 3 + r, ymax);
+        return roi + (ptrdiff_t)y * L.pitch;
+    };
+    auto emit = [&](int yo, int newest) {  // output row yo from the seven rows ending in slot `newest`
+        if (yo >= L.h) return;
+        uint32_t out = 0;
 #pragma unroll
-        for (int k = 0; k < kBlurTH / 4; k++) {
-            const int yy = ty * (kBlurTH / 4) + k;
-            const int y = y0 + yy;
-            if (y < L.h) {
-                const uint16_t *h = hor + yy * kBlurTW + tx;
-                const uint32_t s = (uint32_t)g0 * (h[0] + h[6 * kBlurTW]) + (uint32_t)g1 * (h[kBlurTW] + h[5 * kBlurTW]) +
-                                   (uint32_t)g2 * (h[2 * kBlurTW] + h[4 * kBlurTW]) + (uint32_t)g3 * h[3 * kBlurTW];
-                const uint32_t v = (s + 32768u) >> 16;
-                dst[(size_t)y * L.bpitch + x] = (uint8_t)min(v, 255u);
-            }
+        for (int j = 0; j < 4; j++) {
+            // row r-6+k sits in slot (newest + 1 + k) % 7
+            const uint32_t s = (uint32_t)g0 * (hw[(newest + 1) % 7][j] + hw[newest][j]) +
+                               (uint32_t)g1 * (hw[(newest + 2) % 7][j] + hw[(newest + 6) % 7][j]) +
+                               (uint32_t)g2 * (hw[(newest + 3) % 7][j] + hw[(newest + 5) % 7][j]) +
+                               (uint32_t)g3 * hw[(newest + 4) % 7][j];
+            const uint32_t v = min((s + 32768u) >> 16, 255u);
+            out |= v << (8 * j);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (size_t)yo * L.bpitch) = out;
+    };
+#pragma unroll
+    for (int r = 0; r < 6; r++) blur_hrow(src_row(r), tap_lo, tap_hi, hw[r]);
+    for (int gidx = 0; gidx < kBlurRows / 7; gidx++) {
+        const int rbase = 6 + gidx * 7;
+        if (y0 + rbase - 6 >= L.h) break;
+#pragma unroll
+        for (int sidx = 0; sidx < 7; sidx++) {
+            const int slot = (6 + sidx) % 7;
+            blur_hrow(src_row(rbase + sidx), tap_lo, tap_hi, hw[slot]);
+            emit(y0 + rbase + sidx - 6, slot);
         }
     }
 }

@@ -71,6 +71,14 @@ struct orbx_extractor {
     double prof_ms[K_COUNT] = {0};
     int64_t prof_n[K_COUNT] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // asynchronous result download (copy stream overlaps the next batch's kernels)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_compute_done = nullptr, ev_copy_done = nullptr;
+    bool copy_pending = false;
+    int32_t *h_err = nullptr;  // pinned
+    DevBuf d_match, d_nmatch;  // internal frame-to-frame match outputs [B][cap], [B]
+    // cached problem descriptors of orbx_match_consecutive_device
+    struct MatchKey { int n = 0, cap = 0; const void *match = nullptr, *nm = nullptr; float th = 0, du = 0, dv = 0; int ori = 0; const void *kps = nullptr; } mkey;
 
     int ensure_stage(size_t bytes) {
         if (bytes <= h_stage_bytes) return ORBX_OK;

@@ -130,13 +130,18 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
             for (int j = 0; j < (L.w + kBlurTW - 1) / kBlurTW; j++)
                 blur_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
         const int cols = L.wCell + 6, rows = L.hCell + 6;
-        const size_t lds = (((size_t)rows * ((cols + 3) & ~3) + 15) & ~(size_t)15) + (size_t)(L.hCell + 2) * (L.wCell + 2) + 16;
+        const size_t pp = (size_t)((cols + 3 + 3) & ~3);
+        const size_t lds = 32 + ((rows * pp + 15) & ~(size_t)15) + ((((size_t)(L.hCell + 2) * (L.wCell + 2)) + 15) & ~(size_t)15) +
+                           2 * (size_t)L.wCell * L.hCell + 64;
         fast_lds = std::max(fast_lds, lds);
     }
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
 
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
+    if (ex->copy_stream) ORBX_HIP(hipStreamSynchronize(ex->copy_stream));
+    ex->copy_pending = false;
+    ex->mkey = orbx_extractor::MatchKey();
     const int B = std::max(batch, ex->batch_cap);
     int r;
 #define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
@@ -236,6 +241,9 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const int32_t *)ex->d_cellcnt.p, ex->total_cells, (const uint32_t *)ex->d_cellent.p, ex->cand_frame,
                            (uint32_t *)ex->d_keys0.p, (uint32_t *)ex->d_keys1.p, (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame,
                            (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p);
+    }
+    if (ex->copy_pending) {  // outputs of the previous batch may still be in flight to the host
+        ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done, 0));
     }
     {
         ProfScope ps(ex, K_FINALIZE);
@@ -341,6 +349,11 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); delete ex; return ORBX_E_HIP; }
     (void)hipEventCreate(&ex->ev0);
     (void)hipEventCreate(&ex->ev1);
+    (void)hipStreamCreateWithFlags(&ex->copy_stream, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ex->ev_copy_done, hipEventDisableTiming);
+    (void)hipHostMalloc((void **)&ex->h_err, sizeof(int32_t), hipHostMallocDefault);
+    if (ex->h_err) *ex->h_err = 0;
     // descriptor constants: orientation disc offsets + BRIEF pattern
     DescConst dc;
     memset(&dc, 0, sizeof(dc));
@@ -366,6 +379,11 @@ void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+    if (ex->copy_stream) { (void)hipStreamSynchronize(ex->copy_stream); (void)hipStreamDestroy(ex->copy_stream); }
+    if (ex->ev_compute_done) (void)hipEventDestroy(ex->ev_compute_done);
+    if (ex->ev_copy_done) (void)hipEventDestroy(ex->ev_copy_done);
+    if (ex->h_err) (void)hipHostFree(ex->h_err);
+    ex->d_match.release(); ex->d_nmatch.release();
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
@@ -444,6 +462,40 @@ int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *des
     if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, ex->stream));
     if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, ex->stream));
     return check_device_error(ex);
+}
+
+int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts, int32_t *mono,
+                              int32_t *match, int32_t *nmatches) {
+    if (!ex || ex->last_batch <= 0) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    const int n = ex->last_batch;
+    hipStream_t cs = ex->copy_stream;
+    ORBX_HIP(hipEventRecord(ex->ev_compute_done, ex->stream));
+    ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_compute_done, 0));
+    if (counts) ORBX_HIP(hipMemcpyAsync(counts, ex->d_count.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
+    if (mono) ORBX_HIP(hipMemcpyAsync(mono, ex->d_mono.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
+    if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
+    if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, cs));
+    if (match && ex->d_match.p) ORBX_HIP(hipMemcpyAsync(match, ex->d_match.p, 4 * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
+    if (nmatches && ex->d_nmatch.p) ORBX_HIP(hipMemcpyAsync(nmatches, ex->d_nmatch.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
+    ORBX_HIP(hipMemcpyAsync(ex->h_err, ex->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, cs));
+    ORBX_HIP(hipEventRecord(ex->ev_copy_done, cs));
+    ex->copy_pending = true;
+    return ORBX_OK;
+}
+
+int orbx_download_wait(orbx_extractor *ex) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    if (!ex->copy_pending) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipEventSynchronize(ex->ev_copy_done));
+    if (*ex->h_err != 0) {
+        set_error("device-side consistency check failed, code " + std::to_string(*ex->h_err));
+        *ex->h_err = 0;
+        (void)hipMemsetAsync(ex->d_err.p, 0, sizeof(int32_t), ex->stream);
+        return ORBX_E_INTERNAL;
+    }
+    return ORBX_OK;
 }
 
 int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, size_t stride, int lap0, int lap1,

@@ -383,49 +383,60 @@ int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur,
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                              int32_t *d_match, int32_t *d_nmatches) {
-    if (!ex || !d_match || !d_nmatches) return ORBX_E_BAD_ARG;
+    if (!ex) return ORBX_E_BAD_ARG;
     const int n = ex->last_batch;
     if (n < 2) return ORBX_OK;
     if (ex->cap > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;
     ORBX_HIP(hipSetDevice(ex->device));
     const int np = n - 1, cap = ex->cap;
     int r;
-#define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
-    ENS(ex->d_mkey1, 8 * (size_t)kTopK * cap * np);
-    ENS(ex->d_mkey2, 4 * (size_t)cap * np);
-    ENS(ex->d_mentries, 4 * (size_t)cap * np);
-    ENS(ex->d_mprobs, sizeof(WindowProblem) * (size_t)np);
-    ENS(ex->d_mres, sizeof(ResolveProblem) * (size_t)np);
-#undef ENS
-    std::vector<WindowProblem> P(np);
-    std::vector<ResolveProblem> R(np);
-    const orbx_keypoint *kps = (const orbx_keypoint *)ex->d_kps.p;
-    const uint8_t *desc = (const uint8_t *)ex->d_desc.p;
-    const int32_t *count = (const int32_t *)ex->d_count.p;
-    // scale factors live in the level table; a small device copy is kept in d_mres tail -> simpler: upload once here
-    for (int p = 0; p < np; p++) {
-        const int f = p + 1;
-        WindowProblem &w = P[p];
-        memset(&w, 0, sizeof(w));
-        w.kps = kps + (size_t)f * cap; w.desc = desc + (size_t)f * cap * 32; w.n_ptr = count + f;
-        w.q_from_kps = kps + (size_t)(f - 1) * cap; w.qdesc = desc + (size_t)(f - 1) * cap * 32; w.nq_ptr = count + (f - 1);
-        w.th = th; w.du = du; w.dv = dv;
-        w.keys = (u64 *)ex->d_mkey1.p + (size_t)p * cap * kTopK; w.meta = (int32_t *)ex->d_mkey2.p + (size_t)p * cap;
-        ResolveProblem &q = R[p];
-        memset(&q, 0, sizeof(q));
-        q.mode = 2; q.check_orientation = check_orientation;
-        q.match = d_match + (size_t)f * cap; q.nmatches = d_nmatches + f;
-        q.entries = (int32_t *)ex->d_mentries.p + (size_t)p * cap;
+    if (!d_match || !d_nmatches) {  // internal result buffers (downloaded by orbx_batch_download_async)
+        if ((r = ex->d_match.ensure(4 * (size_t)cap * ex->batch_cap)) != ORBX_OK) return r;
+        if ((r = ex->d_nmatch.ensure(4 * (size_t)ex->batch_cap)) != ORBX_OK) return r;
+        d_match = (int32_t *)ex->d_match.p;
+        d_nmatches = (int32_t *)ex->d_nmatch.p;
     }
-    // mvScaleFactors on the device: reuse a per-extractor buffer appended after the problems
-    static_assert(sizeof(float) == 4, "");
-    orbx::DevBuf &sc = ex->d_mscale;
-    if ((r = sc.ensure(sizeof(float) * ex->prm.nlevels)) != ORBX_OK) return r;
-    ORBX_HIP(hipMemcpyAsync(sc.p, ex->scale.data(), sizeof(float) * ex->prm.nlevels, hipMemcpyHostToDevice, ex->stream));
-    for (int p = 0; p < np; p++) P[p].scale = (const float *)sc.p;
-    ORBX_HIP(hipMemcpyAsync(ex->d_mprobs.p, P.data(), sizeof(WindowProblem) * np, hipMemcpyHostToDevice, ex->stream));
-    ORBX_HIP(hipMemcpyAsync(ex->d_mres.p, R.data(), sizeof(ResolveProblem) * np, hipMemcpyHostToDevice, ex->stream));
-    ORBX_HIP(hipStreamSynchronize(ex->stream));  // P/R are host temporaries
+    const orbx_keypoint *kps = (const orbx_keypoint *)ex->d_kps.p;
+    orbx_extractor::MatchKey key;
+    key.n = n; key.cap = cap; key.match = d_match; key.nm = d_nmatches; key.th = th; key.du = du; key.dv = dv;
+    key.ori = check_orientation; key.kps = kps;
+    const orbx_extractor::MatchKey &old = ex->mkey;
+    const bool cached = old.n == key.n && old.cap == key.cap && old.match == key.match && old.nm == key.nm && old.th == key.th &&
+                        old.du == key.du && old.dv == key.dv && old.ori == key.ori && old.kps == key.kps;
+    if (!cached) {  // (re)build the per-pair problem descriptors; steady-state batches reuse them without any host sync
+#define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
+        ENS(ex->d_mkey1, 8 * (size_t)kTopK * cap * np);
+        ENS(ex->d_mkey2, 4 * (size_t)cap * np);
+        ENS(ex->d_mentries, 4 * (size_t)cap * np);
+        ENS(ex->d_mprobs, sizeof(WindowProblem) * (size_t)np);
+        ENS(ex->d_mres, sizeof(ResolveProblem) * (size_t)np);
+        ENS(ex->d_mscale, sizeof(float) * ex->prm.nlevels);
+#undef ENS
+        std::vector<WindowProblem> P(np);
+        std::vector<ResolveProblem> R(np);
+        const uint8_t *desc = (const uint8_t *)ex->d_desc.p;
+        const int32_t *count = (const int32_t *)ex->d_count.p;
+        for (int p = 0; p < np; p++) {
+            const int f = p + 1;
+            WindowProblem &w = P[p];
+            memset(&w, 0, sizeof(w));
+            w.kps = kps + (size_t)f * cap; w.desc = desc + (size_t)f * cap * 32; w.n_ptr = count + f;
+            w.q_from_kps = kps + (size_t)(f - 1) * cap; w.qdesc = desc + (size_t)(f - 1) * cap * 32; w.nq_ptr = count + (f - 1);
+            w.th = th; w.du = du; w.dv = dv;
+            w.scale = (const float *)ex->d_mscale.p;  // mvScaleFactors
+            w.keys = (u64 *)ex->d_mkey1.p + (size_t)p * cap * kTopK; w.meta = (int32_t *)ex->d_mkey2.p + (size_t)p * cap;
+            ResolveProblem &q = R[p];
+            memset(&q, 0, sizeof(q));
+            q.mode = 2; q.check_orientation = check_orientation;
+            q.match = d_match + (size_t)f * cap; q.nmatches = d_nmatches + f;
+            q.entries = (int32_t *)ex->d_mentries.p + (size_t)p * cap;
+        }
+        ORBX_HIP(hipMemcpyAsync(ex->d_mscale.p, ex->scale.data(), sizeof(float) * ex->prm.nlevels, hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipMemcpyAsync(ex->d_mprobs.p, P.data(), sizeof(WindowProblem) * np, hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipMemcpyAsync(ex->d_mres.p, R.data(), sizeof(ResolveProblem) * np, hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipStreamSynchronize(ex->stream));  // P/R are host temporaries
+        ex->mkey = key;
+    }
     GridParams g;
     g.minx = 0.f; g.miny = 0.f;  // undistorted bounds of a distortion-free camera: mnMinX = 0, mnMaxX = cols (Frame.cc:804-807)
     g.inv_w = 64.0f / ((float)ex->width - 0.f);

@@ -91,9 +91,20 @@ class ORBextractor:
               "orbx_batch_download_all")
         return kps, desc, counts, mono
 
-    def match_consecutive_device(self, d_match: int, d_nmatches: int, th=15.0, du=0.0, dv=0.0, check_orientation=True):
-        check(self._L.orbx_match_consecutive_device(self._h, th, du, dv, int(check_orientation), C.c_void_p(d_match),
-                                                    C.c_void_p(d_nmatches)), "orbx_match_consecutive_device")
+    def download_async(self, kps, desc, counts, mono, match=None, nmatches=None):
+        """Enqueue the D2H of the last batch on the copy stream (arguments: raw host pointers, ideally pinned)."""
+        check(self._L.orbx_batch_download_async(self._h, *[C.c_void_p(p) if p else None
+                                                           for p in (kps, desc, counts, mono, match, nmatches)]),
+              "orbx_batch_download_async")
+
+    def download_wait(self):
+        check(self._L.orbx_download_wait(self._h), "orbx_download_wait")
+
+    def match_consecutive_device(self, d_match: int = 0, d_nmatches: int = 0, th=15.0, du=0.0, dv=0.0, check_orientation=True):
+        check(self._L.orbx_match_consecutive_device(self._h, th, du, dv, int(check_orientation),
+                                                    C.c_void_p(d_match) if d_match else None,
+                                                    C.c_void_p(d_nmatches) if d_nmatches else None),
+              "orbx_match_consecutive_device")
 
     # ---- accessors (ORBextractor.h:62-83) ----
     def GetLevels(self) -> int:

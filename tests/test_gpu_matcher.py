@@ -193,3 +193,47 @@ def test_match_consecutive_device_equals_host_api(oracle, canvas1):
         on, ocm = oracle.search_by_projection_frame(grid, d1, sf, q, 15.0, 0, True, None, None)
         assert nm[t] == on and np.array_equal(match[t, :len(k1)], ocm), t
         assert on > 300
+
+
+def test_async_download_pipeline_equals_sync(canvas1):
+    """Pipelined batches (copy stream overlapping the next batch) deliver exactly the synchronous results."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    nfr = 3
+    ex = osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    batches = [np.stack([synth.frame_from_canvas(canvas1, 10 * b + t, 752, 480, 7000 + 10 * b + t) for t in range(nfr)]) for b in range(3)]
+    d_batches = [torch.from_numpy(x).cuda() for x in batches]
+    cap = ex.output_capacity(752, 480)
+
+    def host_set():
+        return dict(kps=torch.zeros((nfr, cap, 28), dtype=torch.uint8).pin_memory(), desc=torch.zeros((nfr, cap, 32), dtype=torch.uint8).pin_memory(),
+                    cnt=torch.zeros(nfr, dtype=torch.int32).pin_memory(), mono=torch.zeros(nfr, dtype=torch.int32).pin_memory(),
+                    match=torch.zeros((nfr, cap), dtype=torch.int32).pin_memory(), nm=torch.zeros(nfr, dtype=torch.int32).pin_memory())
+    sets = [host_set() for _ in range(3)]
+    for b in range(3):   # enqueue all three batches back to back, never waiting in between
+        ex.extract_batch_device(d_batches[b].data_ptr(), nfr, 752, 480, 752, 752 * 480, (0, 1000))
+        ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        hs = sets[b]
+        if b > 0:
+            ex.download_wait()
+        ex.download_async(hs["kps"].data_ptr(), hs["desc"].data_ptr(), hs["cnt"].data_ptr(), hs["mono"].data_ptr(),
+                          hs["match"].data_ptr(), hs["nm"].data_ptr())
+    ex.download_wait()
+    ex2 = osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    for b in range(3):
+        ex2.extract_batch_device(d_batches[b].data_ptr(), nfr, 752, 480, 752, 752 * 480, (0, 1000))
+        d_match = torch.full((nfr, cap), -1, dtype=torch.int32, device="cuda")
+        d_nm = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+        ex2.match_consecutive_device(d_match.data_ptr(), d_nm.data_ptr(), th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        ex2.sync()
+        hs = sets[b]
+        for t in range(nfr):
+            mono, kps, desc = ex2.download(t)
+            n = len(kps)
+            assert hs["cnt"][t] == n and hs["mono"][t] == mono
+            assert hs["kps"][t, :n].numpy().tobytes() == kps.tobytes()
+            assert np.array_equal(hs["desc"][t, :n].numpy(), desc)
+            if t > 0:
+                assert hs["nm"][t] == d_nm[t].item()
+                assert np.array_equal(hs["match"][t, :n].numpy(), d_match[t, :n].cpu().numpy())
