@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
     const int f = blockIdx.y;
     const LevelInfo L = lv[t.level];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63;
     const int cell = t.ti * L.nCols + t.tj;
     int32_t *cnt_out = cellcnt + (size_t)f * total_cells + L.cell_base + cell;
 
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
     const int sp = iw + 2;                     // pitch of the score tile (1-px zero apron)
     const int n = iw * ih;
     // carve (all offsets multiples of 16)
-    int *ctrl = reinterpret_cast<int *>(smem);                 // [0..3] wave sums, [4] queue length
+    int *ctrl = reinterpret_cast<int *>(smem);                 // [4] queue length, [5] survivor count
     uint8_t *pix = smem + 32;                                  // rows * pp   (later reused as the survivor map)
     uint8_t *sco = pix + ((rows * pp + 15) & ~15);             // (ih+2) * sp
     uint16_t *queue = reinterpret_cast<uint16_t *>(sco + (((ih + 2) * sp + 15) & ~15));  // n entries
@@ -197,21 +197,21 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
     }
     __syncthreads();
 
-    // phase 1: necessary condition at minTh on the antipodal pairs (0,8) (4,12) (2,10) (6,14)
+    // phase 1: necessary condition at minTh on the antipodal pairs (0,8) (4,12) (2,10) (6,14); branch-free
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
-        bool pass = false;
+        int pass = 0;
         if (i < n) {
             const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
             const uint8_t *c = pix + (y + 3) * pp + x + 3 + ax;
             const int v = c[0], hi = v + minTh, lo = v - minTh;
             const int p0 = c[3 * pp], p8 = c[-3 * pp], p4 = c[3], p12 = c[-3];
             const int p2 = c[2 * pp + 2], p10 = c[-2 * pp - 2], p6 = c[-2 * pp + 2], p14 = c[2 * pp - 2];
-            const bool br = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi) && (p2 > hi || p10 > hi) && (p6 > hi || p14 > hi);
-            const bool dk = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo) && (p2 < lo || p10 < lo) && (p6 < lo || p14 < lo);
-            pass = br || dk;
+            const int br = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi)) & ((p2 > hi) | (p10 > hi)) & ((p6 > hi) | (p14 > hi));
+            const int dk = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo)) & ((p2 < lo) | (p10 < lo)) & ((p6 < lo) | (p14 < lo));
+            pass = br | dk;
         }
-        const unsigned long long b = __ballot(pass);
+        const unsigned long long b = __ballot(pass != 0);
         if (b) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&ctrl[4], __popcll(b));
@@ -230,45 +230,62 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
         s = (s >= minTh) ? s : 0;
         sco[(y + 1) * sp + x + 1] = (uint8_t)s;
     }
+    if (tid == 0) ctrl[5] = 0;
     __syncthreads();
 
-    // phase 3: NMS, strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); survivors keep their score
+    // phase 3: NMS over the queued pixels only, strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage);
+    // survivors (few per cell) go to an unordered LDS list as (linear index << 8 | score)
+    uint32_t *surv = reinterpret_cast<uint32_t *>(pix);  // the pixel tile is dead after phase 2
     int any_ini = 0;
-    for (int i = tid; i < n; i += 256) {
-        const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
-        const uint8_t *p = sco + (y + 1) * sp + x + 1;
-        const int s = p[0];
-        const bool keep = s > 0 && s > p[-1] && s > p[1] && s > p[-sp - 1] && s > p[-sp] && s > p[-sp + 1] &&
-                          s > p[sp - 1] && s > p[sp] && s > p[sp + 1];
-        pix[i] = keep ? (uint8_t)s : 0;  // pixel tile is dead now: reuse as survivor map
-        any_ini |= (keep && s >= iniTh);
+    for (int e0 = 0; e0 < qn; e0 += 256) {
+        const int e = e0 + tid;
+        int keep = 0, s = 0, i = 0;
+        if (e < qn) {
+            i = queue[e];
+            const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
+            const uint8_t *p = sco + (y + 1) * sp + x + 1;
+            s = p[0];
+            keep = (s > 0) & (s > p[-1]) & (s > p[1]) & (s > p[-sp - 1]) & (s > p[-sp]) & (s > p[-sp + 1]) &
+                   (s > p[sp - 1]) & (s > p[sp]) & (s > p[sp + 1]);
+        }
+        any_ini |= (keep & (s >= iniTh));
+        const unsigned long long b = __ballot(keep != 0);
+        __syncthreads();  // (first iteration) every wave is done reading the pixel tile before surv overwrites it
+        if (b) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ctrl[5], __popcll(b));
+            base = __shfl(base, 0);
+            if (keep) surv[base + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)i << 8) | (uint32_t)s;
+        }
     }
     any_ini = __syncthreads_or(any_ini);
     const int thr = any_ini ? iniTh : minTh;
+    const int ns = min(ctrl[5], L.cell_cap);
 
-    // phase 4: ordered (row-major) compaction of the selected set into the cell slot
+    // phase 4: ordered (row-major) emission: rank of a selected survivor = number of selected survivors before it
     uint32_t *slot = cellent + (size_t)f * ent_frame_stride + L.cand_off + (size_t)cell * L.cell_cap;
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + tid;
-        int s = 0;
-        if (i < n) s = pix[i];
-        const bool sel = s > 0 && s >= thr;
-        const unsigned long long b = __ballot(sel);
-        if (lane == 0) ctrl[wv] = __popcll(b);
-        __syncthreads();
-        int off = base;
-        for (int k = 0; k < wv; k++) off += ctrl[k];
-        const int tot = ctrl[0] + ctrl[1] + ctrl[2] + ctrl[3];
-        if (sel) {
-            const int rank = off + __popcll(b & ((1ull << lane) - 1ull));
-            const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
-            if (rank < L.cell_cap) slot[rank] = pack_key(x + 3 + t.tj * L.wCell, y + 3 + t.ti * L.hCell, s);
+    int total = 0;
+    for (int e0 = 0; e0 < ns; e0 += 256) {
+        const int e = e0 + tid;
+        if (e < ns) {
+            const uint32_t me = surv[e];
+            const int s = (int)(me & 0xff);
+            if (s >= thr) {
+                int rank = 0;
+                for (int k = 0; k < ns; k++) {
+                    const uint32_t o = surv[k];
+                    rank += ((int)(o & 0xff) >= thr) & (o < me);  // linear index in the high bits orders the keys
+                }
+                const int i = (int)(me >> 8);
+                const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
+                slot[rank] = pack_key(x + 3 + t.tj * L.wCell, y + 3 + t.ti * L.hCell, s);
+            }
         }
-        base += tot;
-        __syncthreads();
     }
-    if (tid == 0) *cnt_out = min(base, L.cell_cap);
+    if (tid == 0) {
+        for (int k = 0; k < ns; k++) total += ((int)(surv[k] & 0xff) >= thr);
+        *cnt_out = total;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
