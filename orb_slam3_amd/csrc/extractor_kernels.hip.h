@@ -526,26 +526,68 @@ struct DescConst {
     int8_t pat[1024];                  // bit_pattern_31_ (x0,y0,x1,y1) x 256
 };
 
+constexpr int kDescAP = 40, kDescAR = 31;   // orientation patch in LDS: 31 rows x 40 B (9 aligned dwords used)
+constexpr int kDescBP = 44, kDescBR = 37;   // BRIEF patch in LDS: 37 rows x 44 B (10 aligned dwords used)
+constexpr int kDescWaveLds = kDescAP * kDescAR + kDescBP * kDescBR + 12;  // 2880 B, multiple of 16
+
 __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ lv, const DescConst *__restrict__ dc,
                                                   const WorkItem *__restrict__ work, const int32_t *__restrict__ count,
                                                   int cap, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
                                                   const uint8_t *__restrict__ blur, size_t blur_frame_stride,
                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                                   int strict_mul_add) {
+    __shared__ __attribute__((aligned(16))) uint8_t patches[4 * kDescWaveLds];
     const int f = blockIdx.y;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (g >= count[f]) return;
+    if (g >= count[f]) return;  // wave-uniform; no block-level barrier below
+    uint8_t *A = patches + (threadIdx.x >> 6) * kDescWaveLds;
+    uint8_t *Bp = A + kDescAP * kDescAR;
     const WorkItem w = work[(size_t)f * cap + g];
     const LevelInfo L = lv[w.level];
     const int kx = key_x(w.key), ky = key_y(w.key);
 
-    // ---- IC_Angle ----
-    const uint8_t *c0 = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + ky) * L.pitch + kRoiX + kx;
+    // ---- stage both patches with aligned dword loads: one memory round trip for the whole keypoint ----
+    const int axA = (kx - kHalfPatch) & 3, axB = (kx - 18) & 3;
+    {
+        const uint8_t *srcA = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + ky - kHalfPatch) * L.pitch + kRoiX +
+                              (kx - kHalfPatch - axA);
+        const uint8_t *srcB = blur + (size_t)f * blur_frame_stride + L.boff + (size_t)(ky - 18) * L.bpitch + (kx - 18 - axB);
+        uint32_t va[5], vb[6];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = lane + 64 * k;
+            const int r = idx / 9, c = idx - r * 9;
+            va[k] = (idx < kDescAR * 9) ? *reinterpret_cast<const uint32_t *>(srcA + (size_t)r * L.pitch + 4 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int idx = lane + 64 * k;
+            const int r = idx / 10, c = idx - r * 10;
+            vb[k] = (idx < kDescBR * 10) ? *reinterpret_cast<const uint32_t *>(srcB + (size_t)r * L.bpitch + 4 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = lane + 64 * k;
+            const int r = idx / 9, c = idx - r * 9;
+            if (idx < kDescAR * 9) *reinterpret_cast<uint32_t *>(A + r * kDescAP + 4 * c) = va[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int idx = lane + 64 * k;
+            const int r = idx / 10, c = idx - r * 10;
+            if (idx < kDescBR * 10) *reinterpret_cast<uint32_t *>(Bp + r * kDescBP + 4 * c) = vb[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (single-wave producer/consumer)
+
+    // ---- IC_Angle on the unblurred patch ----
+    const uint8_t *c0 = A + kHalfPatch * kDescAP + kHalfPatch + axA;
     int m10 = 0, m01 = 0;
     for (int i = lane; i < 749; i += 64) {
         const int u = dc->disc_u[i], v = dc->disc_v[i];
-        const int I = c0[v * L.pitch + u];
+        const int I = c0[v * kDescAP + u];
         m10 += u * I;
         m01 += v * I;
     }
@@ -556,17 +598,17 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- steered BRIEF ----
+    // ---- steered BRIEF on the blurred patch ----
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     glibc_sincosf(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
-    const uint8_t *cb = blur + (size_t)f * blur_frame_stride + L.boff + (size_t)ky * L.bpitch + kx;
+    const uint8_t *cb = Bp + 18 * kDescBP + 18 + axB;
     unsigned long long bits[4];
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int p = it * 64 + lane;
-        const float x0 = (float)dc->pat[4 * p], y0 = (float)dc->pat[4 * p + 1];
-        const float x1 = (float)dc->pat[4 * p + 2], y1 = (float)dc->pat[4 * p + 3];
+        const char4 pt = reinterpret_cast<const char4 *>(dc->pat)[p];
+        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
         float r0, q0, r1, q1;
         if (strict_mul_add) {
             r0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
@@ -579,8 +621,8 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
             r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
             q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
         }
-        const int t0 = cb[__float2int_rn(r0) * L.bpitch + __float2int_rn(q0)];
-        const int t1 = cb[__float2int_rn(r1) * L.bpitch + __float2int_rn(q1)];
+        const int t0 = cb[__float2int_rn(r0) * kDescBP + __float2int_rn(q0)];
+        const int t1 = cb[__float2int_rn(r1) * kDescBP + __float2int_rn(q1)];
         bits[it] = __ballot(t0 < t1);
     }
     const size_t slot = (size_t)f * cap + w.pos;

@@ -335,13 +335,15 @@ struct ResolveProblem {
 // first conflicting lane commit in parallel (their choices cannot influence each other); the conflicting lane simply
 // re-evaluates in the next round against the updated mask.  Only when a lane exhausts the valid part of a
 // non-exhaustive list does the whole wave re-scan that query's window against the current mask -- exactly what the
-// sequential loop would have seen.  Dynamic LDS: claim[n_alloc] (u32) + occ[n_alloc] (u8).
+// sequential loop would have seen.  Dynamic LDS: claim[n_alloc] (u32) + angle[n_alloc] (f32) + occ[n_alloc] (u8);
+// nothing inside the round loop touches global memory except fire-and-forget result stores.
 __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
                                                        GridParams g, int n_alloc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ int hist[ORBX_HISTO_LENGTH + 2];
     uint32_t *claim = reinterpret_cast<uint32_t *>(lds);
-    uint8_t *occ = lds + (size_t)n_alloc * 4;
+    float *ang = reinterpret_cast<float *>(lds + (size_t)n_alloc * 4);
+    uint8_t *occ = lds + (size_t)n_alloc * 8;
     const WindowProblem P = probs[blockIdx.x];
     const ResolveProblem R = res[blockIdx.x];
     const int lane = threadIdx.x;
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
     for (int i = lane; i < n; i += 64) {
         occ[i] = P.occupied0 ? P.occupied0[i] : 0;
         claim[i] = 0xffffffffu;
+        ang[i] = P.kps[i].angle;
         R.match[i] = -1;
     }
     if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
@@ -373,9 +376,8 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         }
         return true;
     };
-    auto rot_bin = [&](int qi, int idx) -> int {  // :1775-1792
-        const float qa = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
-        float rot = qa - P.kps[idx].angle;
+    auto rot_bin = [&](float qa, int idx) -> int {  // :1775-1792
+        float rot = qa - ang[idx];
         if (rot < 0.0f) rot += 360.0f;
         int b = (int)roundf(rot * factor);
         if (b == ORBX_HISTO_LENGTH) b = 0;
@@ -388,12 +390,14 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         u64 L0 = kNoKey, L1 = kNoKey, L2 = kNoKey, L3 = kNoKey;
         int valid_len = 0;
         bool exhaustive = true;
+        float q_ang = 0.f;
         if (active) {
             const u64 *kp = P.keys + (size_t)qi * kTopK;
             L0 = kp[0]; L1 = kp[1]; L2 = kp[2]; L3 = kp[3];
             const int m = P.meta[qi];
             valid_len = m & 0xff;
             exhaustive = (m & 256) != 0;
+            if (ori) q_ang = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
         }
         int pos = 0;
         while (pos < 64) {
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                 R.match[t1] = qi;
                 occ[t1] = R.q_has_obs ? R.q_has_obs[qi] : 1;
                 if (ori) {
-                    const int b = rot_bin(qi, t1);
+                    const int b = rot_bin(q_ang, t1);
                     R.entries[n_entries + __popcll(okb & lt_mask)] = (b << 16) | t1;  // rotHist[bin].push_back(bestIdx2)
                     atomicAdd(&hist[b], 1);
                 }
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
             if (!slow) { pos = c; continue; }  // claim conflict: lane c re-evaluates against the updated mask
             {   // list exhausted: re-scan query q0+c against the occupancy the sequential loop sees at this point
                 const int qc = q0 + c;
+                const float qa_c = __shfl(q_ang, c);  // all lanes participate in the shuffle
                 QueryWin w;
                 Desc dq;
                 u64 r1 = kNoKey, r2 = kNoKey;
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                         R.match[idx] = qc;
                         occ[idx] = R.q_has_obs ? R.q_has_obs[qc] : 1;
                         if (ori) {
-                            const int b = rot_bin(qc, idx);
+                            const int b = rot_bin(qa_c, idx);
                             R.entries[n_entries] = (b << 16) | idx;
                             hist[b]++;
                         }

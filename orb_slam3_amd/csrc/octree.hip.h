@@ -28,10 +28,13 @@ struct OctLds {  // carved from dynamic LDS, `pool` entries each
     uint16_t *order;             // final list order
 };
 
-__host__ __device__ inline size_t oct_lds_bytes(int pool) {
-    // 64 bytes of scalars, then the per-node arrays (8-byte arrays first for alignment)
-    return 64 + (size_t)pool * (8 + 8 + 4 + 4 + 2 * 4 + 2 * 3 + 2 + 1 + 1) + 64;
+constexpr int kOctLdsKeys = 3072;  // keys per ping-pong buffer kept in LDS (levels with more candidates use global memory)
+
+__host__ __device__ inline size_t oct_pool_bytes(int pool) {
+    // 64 bytes of scalars, then the per-node arrays (8-byte arrays first for alignment), rounded to 16
+    return (64 + (size_t)pool * (8 + 8 + 4 + 4 + 2 * 4 + 2 * 3 + 2 + 1 + 1) + 64 + 15) & ~(size_t)15;
 }
+__host__ __device__ inline size_t oct_lds_bytes(int pool) { return oct_pool_bytes(pool) + 2 * (size_t)kOctLdsKeys * 4; }
 
 // ---- libstdc++ (GCC 11) std::sort replica on u64 entries compared by (entry >> 16) ----------------------
 // compareNodes(e1,e2): e1.first < e2.first, or equal and e1.second->UL.x < e2.second->UL.x.  With the packing
@@ -168,13 +171,13 @@ __global__ void k_debug_sort(const int32_t *count, const int32_t *ulx, int n, in
 }
 
 // ---- the quad-tree kernel ----------------------------------------------------------------------------------
-// grid (nlevels, B), block 64, dynamic LDS = oct_lds_bytes(max pool)
+// grid (nlevels, B), block 64, dynamic LDS = oct_lds_bytes(max pool): node pool + two LDS key buffers
 __global__ __launch_bounds__(64) void k_octree(const LevelInfo *__restrict__ lv, const int32_t *__restrict__ cellcnt,
                                                int total_cells, const uint32_t *__restrict__ cellent,
                                                size_t ent_frame_stride, uint32_t *__restrict__ keys0,
                                                uint32_t *__restrict__ keys1, uint32_t *__restrict__ lvlkp,
                                                size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt, int nlevels,
-                                               int32_t *__restrict__ cand_total, int32_t *__restrict__ err) {
+                                               int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int level = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     const LevelInfo L = lv[level];
@@ -209,26 +212,42 @@ __global__ __launch_bounds__(64) void k_octree(const LevelInfo *__restrict__ lv,
         S.buf = p; p += pool;
         S.leaf = p; p += pool;
     }
-    uint32_t *kb[2] = {keys0 + (size_t)f * ent_frame_stride + L.cand_off, keys1 + (size_t)f * ent_frame_stride + L.cand_off};
     const uint32_t *ent = cellent + (size_t)f * ent_frame_stride + L.cand_off;
     const int32_t *ccnt = cellcnt + (size_t)f * total_cells + L.cell_base;
     const int ncell = L.nCols * L.nRows;
 
-    // ---- 1. gather the cell slots in reference order (cell row-major) into kb[1]; C = total ----------------
+    // ---- 1. gather the cell slots in reference order (cell row-major); C = total -----------------------------
     int C = 0;
     for (int c0 = 0; c0 < ncell; c0 += 64) {
-        const int c = c0 + lane;
-        const int n = (c < ncell) ? ccnt[c] : 0;
-        // inclusive scan over the wave
-        int incl = n;
+        int n = (c0 + lane < ncell) ? ccnt[c0 + lane] : 0;
 #pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const int t = __shfl_up(incl, s);
-            if (lane >= s) incl += t;
+        for (int s = 32; s > 0; s >>= 1) n += __shfl_xor(n, s);
+        C += n;
+    }
+    // key ping-pong buffers: LDS when the level's candidates fit, else the global scratch slabs (generic pointers)
+    uint32_t *kb[2];
+    if (C <= kOctLdsKeys) {
+        uint32_t *lk = reinterpret_cast<uint32_t *>(smem + oct_pool_bytes(max_pool));
+        kb[0] = lk; kb[1] = lk + kOctLdsKeys;
+    } else {
+        kb[0] = keys0 + (size_t)f * ent_frame_stride + L.cand_off;
+        kb[1] = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
+    }
+    {
+        int run = 0;
+        for (int c0 = 0; c0 < ncell; c0 += 64) {
+            const int c = c0 + lane;
+            const int n = (c < ncell) ? ccnt[c] : 0;
+            int incl = n;  // inclusive scan over the wave
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const int t = __shfl_up(incl, s);
+                if (lane >= s) incl += t;
+            }
+            const int excl = run + incl - n;
+            for (int k = 0; k < n; k++) kb[1][excl + k] = ent[(size_t)c * L.cell_cap + k];
+            run += __shfl(incl, 63);
         }
-        const int excl = C + incl - n;
-        for (int k = 0; k < n; k++) kb[1][excl + k] = ent[(size_t)c * L.cell_cap + k];
-        C += __shfl(incl, 63);
     }
     __syncthreads();
     if (lane == 0 && cand_total) cand_total[f * nlevels + level] = C;

@@ -240,7 +240,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), oct_lds_bytes(ex->max_pool), st, d_lv,
                            (const int32_t *)ex->d_cellcnt.p, ex->total_cells, (const uint32_t *)ex->d_cellent.p, ex->cand_frame,
                            (uint32_t *)ex->d_keys0.p, (uint32_t *)ex->d_keys1.p, (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame,
-                           (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p);
+                           (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p, ex->max_pool);
     }
     if (ex->copy_pending) {  // outputs of the previous batch may still be in flight to the host
         ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done, 0));

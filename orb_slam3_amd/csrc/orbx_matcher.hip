@@ -18,8 +18,8 @@ using namespace orbx;
 
 namespace {
 
-constexpr int kMaxResolveFeatures = 28000;  // claim (4 B) + occ (1 B) per feature must fit the 160 KB LDS
-inline size_t resolve_lds_bytes(int n) { return (size_t)n * 5 + 64; }
+constexpr int kMaxResolveFeatures = 16000;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
+inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
 
 struct Arena {  // bump allocator over one device buffer, reset per call
     uint8_t *base = nullptr;
