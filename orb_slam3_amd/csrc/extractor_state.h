@@ -62,7 +62,7 @@ struct orbx_extractor {
     DevBuf d_lv, d_xtab, d_ytab, d_fast_tiles, d_blur_tiles, d_dc;
     DevBuf d_pyr, d_blur, d_cellcnt, d_cellent, d_keys0, d_keys1, d_lvlkp, d_lvlcnt, d_candtot, d_work;
     DevBuf d_kps, d_desc, d_count, d_mono, d_err, d_img;
-    DevBuf d_mkey1, d_mkey2, d_mocc, d_mentries, d_mprobs, d_mres, d_mscale;  // batched frame-to-frame matcher scratch
+    DevBuf d_mkey1, d_mkey2, d_mocc, d_mentries, d_mprobs, d_mres, d_mscale, d_mgrid;  // batched frame-to-frame matcher scratch
     // pinned host staging
     void *h_stage = nullptr;
     size_t h_stage_bytes = 0;

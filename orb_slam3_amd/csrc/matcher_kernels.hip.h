@@ -4,9 +4,10 @@
 //   k_hamming_best2_csr  best / second-best per query (first minimum wins) e.g. ORBmatcher.cc:103-119
 //   k_knn2               cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)         Frame.cc:1144
 //   k_stereo_rowband     Hamming stage of Frame::ComputeStereoMatches      Frame.cc:849-894
+//   k_grid_build         Frame::AssignFeaturesToGrid as a counting sort by grid cell (Frame.cc:385-416)
 //   k_window_best2       GetFeaturesInArea + Hamming scan of the projection matchers (Frame.cc:657-723,
-//                        ORBmatcher.cc:71-119, 1728-1768): candidates enumerated on the fly, ties resolved in the
-//                        reference's candidate order through a packed (dist, cellx, celly, idx) key
+//                        ORBmatcher.cc:71-119, 1728-1768): per grid column one contiguous candidate slice, ties
+//                        resolved in the reference's candidate order through a packed (dist, seq, idx) key
 //   k_greedy_resolve     the sequential part of SearchByProjection (taken-mask read-after-write, ratio test,
 //                        rotation histogram) replayed in query order by one wave per frame
 //
@@ -200,6 +201,9 @@ struct WindowProblem {
     const orbx_keypoint *q_from_kps;
     const float *scale;         // mvScaleFactors
     float th, du, dv;
+    // 64x48 grid of the current frame built by k_grid_build: features sorted by (cell x, cell y, index)
+    uint16_t *gstart;           // [64*48 + 1] offsets into gorder, cell id = x * 48 + y
+    uint16_t *gorder;           // [n] feature indices
     // outputs
     u64 *keys;                  // per query: the kTopK smallest candidate keys, ascending (kNoKey = none)
     int32_t *meta;              // per query: valid_len | exhaustive << 8  (see k_window_best2)
@@ -279,38 +283,151 @@ __device__ __forceinline__ int scan_window(const WindowProblem &P, const GridPar
     return cnt;
 }
 
-// grid (ceil(max_q/4), n_problems), block 256: one wave per query.
-// Output: the kTopK smallest candidate keys in ascending order.  Each lane keeps its own two smallest; the wave
-// extracts minima round by round.  If a lane that saw more than two candidates has both of its entries extracted,
-// later rounds could miss that lane's third candidate, so the list is cut there (valid_len); `exhaustive` says the
-// list holds every candidate of the query.  k_greedy_resolve falls back to a re-scan when it needs more than the
-// valid part of a non-exhaustive list, which keeps the result exact.
+// ---------------------------------------------------------------------------------------------------------
+// Frame::AssignFeaturesToGrid (Frame.cc:385-416): one wave per frame builds the 64x48 grid as a counting sort of
+// the feature indices by cell id (x * 48 + y).  Inside a cell the indices stay ascending (= insertion order), and
+// cells of one grid column are contiguous, so the candidates of GetFeaturesInArea for a column range [y0,y1] are
+// ONE contiguous slice of gorder -- already in the reference's enumeration order (x outer, y inner, insertion).
+// grid (n_problems), block 64
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kGridCells = 64 * 48;
+
+__global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restrict__ probs, GridParams g) {
+    __shared__ uint16_t cnt[kGridCells];
+    __shared__ uint16_t start[kGridCells];
+    const WindowProblem P = probs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = *P.n_ptr;
+    for (int i = lane; i < kGridCells; i += 64) cnt[i] = 0;
+    __syncthreads();
+    // pass 1: cell histogram (16-bit LDS counters packed in pairs: use 32-bit atomics on the containing word)
+    uint32_t *cnt32 = reinterpret_cast<uint32_t *>(cnt);
+    for (int i = lane; i < n; i += 64) {
+        const orbx_keypoint kp = P.kps[i];
+        const int px = (int)roundf((kp.x - g.minx) * g.inv_w), py = (int)roundf((kp.y - g.miny) * g.inv_h);  // PosInGrid
+        if (px >= 0 && px < 64 && py >= 0 && py < 48) {
+            const int c = px * 48 + py;
+            atomicAdd(&cnt32[c >> 1], (c & 1) ? 0x10000u : 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the 3072 counters (48 per lane, then a wave scan of the lane totals)
+    int lane_tot = 0;
+    for (int k = 0; k < kGridCells / 64; k++) lane_tot += cnt[lane * (kGridCells / 64) + k];
+    int incl = lane_tot;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int t = __shfl_up(incl, s);
+        if (lane >= s) incl += t;
+    }
+    int run = incl - lane_tot;
+    for (int k = 0; k < kGridCells / 64; k++) {
+        const int c = lane * (kGridCells / 64) + k;
+        start[c] = (uint16_t)run;
+        P.gstart[c] = (uint16_t)run;
+        run += cnt[c];
+    }
+    if (lane == 63) P.gstart[kGridCells] = (uint16_t)run;
+    __syncthreads();
+    // pass 2: stable fill, 64 features at a time in index order
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        int c = -1;
+        if (i < n) {
+            const orbx_keypoint kp = P.kps[i];
+            const int px = (int)roundf((kp.x - g.minx) * g.inv_w), py = (int)roundf((kp.y - g.miny) * g.inv_h);
+            if (px >= 0 && px < 64 && py >= 0 && py < 48) c = px * 48 + py;
+        }
+        int rank = 0, same = 0;  // lanes of this chunk with the same cell: before me / in total
+        for (int k = 0; k < 64; k++) {
+            const int ck = __shfl(c, k);
+            rank += (ck == c) & (k < lane);
+            same += (ck == c);
+        }
+        if (c >= 0) {
+            P.gorder[start[c] + rank] = (uint16_t)i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (c >= 0 && rank == same - 1) start[c] += (uint16_t)same;  // the last lane of each cell group advances the cursor
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// candidate key of the grid scan: dist << 32 | seq << 16 | idx, seq = position in the reference's candidate enumeration
+__device__ __forceinline__ u64 seq_key(int dist, int seq, int idx) {
+    return ((u64)(uint32_t)dist << 32) | ((u64)(uint32_t)seq << 16) | (u64)(uint32_t)idx;
+}
+
+// grid (ceil(max_q/16), n_problems), block 256: 16 lanes per query (4 queries per wave).
+// For every grid column of the window the candidates are one contiguous slice of gorder; the 16 lanes stride it,
+// apply GetFeaturesInArea's level / distance tests (Frame.cc:697-716) and the callers' gates, and keep their two best
+// keys.  Output: the kTopK smallest candidate keys in ascending order, extracted round by round across the 16 lanes.
+// If a lane that saw more than two candidates has both of its entries extracted, later rounds could miss that lane's
+// third candidate, so the list is cut there (valid_len); `exhaustive` says the list holds every candidate of the
+// query.  k_greedy_resolve falls back to a re-scan when it needs more than the valid part of a non-exhaustive list.
 __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__restrict__ probs, GridParams g) {
     const WindowProblem P = probs[blockIdx.y];
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (qi >= *P.nq_ptr) return;
+    const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
+    const int qi = blockIdx.x * 16 + sub;
+    const int nq = *P.nq_ptr;
+    const bool qvalid = qi < nq;
     QueryWin w;
     Desc dq;
     u64 k1 = kNoKey, k2 = kNoKey;
     int cnt = 0;
-    if (load_query(P, qi, &w, g, &dq)) cnt = scan_window(P, g, w, dq, *P.n_ptr, P.occupied0, lane, k1, k2);
+    bool go = false;
+    if (qvalid) go = load_query(P, qi, &w, g, &dq);
+    if (go) {
+        int seq0 = 0;
+        for (int ix = w.cx0; ix <= w.cx1; ix++) {
+            const int s = P.gstart[ix * 48 + w.cy0], e = P.gstart[ix * 48 + w.cy1 + 1];
+            for (int j = s + sl; j < e; j += 16) {
+                const int i = P.gorder[j];
+                if (P.occupied0 && P.occupied0[i]) continue;
+                const orbx_keypoint kp = P.kps[i];
+                if (w.check_levels) {
+                    if (kp.octave < w.minL) continue;
+                    if (w.maxL >= 0 && kp.octave > w.maxL) continue;
+                }
+                const float dx = kp.x - w.x, dy = kp.y - w.y;
+                if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;
+                if (P.u_right && P.u_right[i] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
+                    const float er = fabsf(w.xr - P.u_right[i]);
+                    if (er > w.r) continue;
+                }
+                const int d = hamming(dq, load_desc(P.desc + (size_t)i * 32));
+                push2(k1, k2, seq_key(d, seq0 + (j - s), i));
+                cnt++;
+            }
+            seq0 += e - s;
+        }
+    }
+    // reductions inside the 16-lane group (xor masks 8,4,2,1 stay inside the group)
     int total = cnt;
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) total += __shfl_xor(total, s);
+    for (int s = 8; s > 0; s >>= 1) total += __shfl_xor(total, s);
     u64 out[kTopK];
     int valid_len = 0, npop = 0;
     bool cut = false;
 #pragma unroll
     for (int r = 0; r < kTopK; r++) {
-        const u64 m = wave_min1(k1);
+        u64 m = k1;
+#pragma unroll
+        for (int s = 8; s > 0; s >>= 1) {
+            const u64 o = __shfl_xor(m, s);
+            m = o < m ? o : m;
+        }
         out[r] = m;
         if (m != kNoKey && !cut) valid_len = r + 1;
         const bool mine = (m != kNoKey) && (k1 == m);
         if (mine) { k1 = k2; k2 = kNoKey; npop++; }
         // a lane that ran dry while it had seen more than two candidates invalidates everything after this round
-        cut = cut || (__ballot(mine && npop == 2 && cnt > 2) != 0ull);
+        int dry = (mine && npop == 2 && cnt > 2) ? 1 : 0;
+#pragma unroll
+        for (int s = 8; s > 0; s >>= 1) dry |= __shfl_xor(dry, s);
+        cut = cut || (dry != 0);
     }
-    if (lane == 0) {
+    if (qvalid && sl == 0) {
 #pragma unroll
         for (int r = 0; r < kTopK; r++) P.keys[(size_t)qi * kTopK + r] = out[r];
         P.meta[qi] = valid_len | ((total <= valid_len) ? 256 : 0);

@@ -270,7 +270,8 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     ORBX_HIP(hipSetDevice(m->device));
     size_t need = Arena::pad(28 * (size_t)n) + Arena::pad(32 * (size_t)n) + 3 * Arena::pad((size_t)n) + Arena::pad(4 * (size_t)n) * 2 +
                   Arena::pad(4 * (size_t)nq) * 7 + Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) * 2 + Arena::pad(8 * (size_t)nq) * 5 +
-                  Arena::pad(sizeof(WindowProblem)) + Arena::pad(sizeof(ResolveProblem)) + 16 * 256 + 4096;
+                  Arena::pad(sizeof(WindowProblem)) + Arena::pad(sizeof(ResolveProblem)) + Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)n) +
+                  16 * 256 + 4096;
     int r = m->arena.reserve(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
@@ -299,6 +300,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     { uint8_t *p = A.take<uint8_t>(32 * (size_t)nq); H2D(p, a.qdesc, 32 * (size_t)nq); P.qdesc = p; }
     if (a.qvalid) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.qvalid, (size_t)nq); P.qvalid = p; }
     P.keys = A.take<u64>((size_t)nq * kTopK); P.meta = A.take<int32_t>(nq);
+    P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n);
     R.mode = a.mode; R.nnratio = a.nnratio; R.check_orientation = a.check_orientation;
     if (a.q_angle) { float *p = A.take<float>(nq); H2D(p, a.q_angle, 4 * (size_t)nq); R.q_angle = p; }
     if (a.q_has_obs) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.q_has_obs, (size_t)nq); R.q_has_obs = p; }
@@ -312,7 +314,8 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     g.minx = F->min_x; g.miny = F->min_y;
     g.inv_w = 64.0f / (F->max_x - F->min_x);  // Frame.cc:342-343
     g.inv_h = 48.0f / (F->max_y - F->min_y);
-    hipLaunchKernelGGL(k_window_best2, dim3((nq + 3) / 4, 1), dim3(256), 0, m->stream, dP, g);
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(64), 0, m->stream, dP, g);
+    hipLaunchKernelGGL(k_window_best2, dim3((nq + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
     if (n > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
@@ -408,6 +411,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         ENS(ex->d_mkey1, 8 * (size_t)kTopK * cap * np);
         ENS(ex->d_mkey2, 4 * (size_t)cap * np);
         ENS(ex->d_mentries, 4 * (size_t)cap * np);
+        ENS(ex->d_mgrid, 2 * ((size_t)kGridCells + 1 + 63 + cap) * np);
         ENS(ex->d_mprobs, sizeof(WindowProblem) * (size_t)np);
         ENS(ex->d_mres, sizeof(ResolveProblem) * (size_t)np);
         ENS(ex->d_mscale, sizeof(float) * ex->prm.nlevels);
@@ -424,6 +428,8 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
             w.q_from_kps = kps + (size_t)(f - 1) * cap; w.qdesc = desc + (size_t)(f - 1) * cap * 32; w.nq_ptr = count + (f - 1);
             w.th = th; w.du = du; w.dv = dv;
             w.scale = (const float *)ex->d_mscale.p;  // mvScaleFactors
+            w.gstart = (uint16_t *)ex->d_mgrid.p + (size_t)p * (kGridCells + 64 + cap);
+            w.gorder = w.gstart + kGridCells + 64;
             w.keys = (u64 *)ex->d_mkey1.p + (size_t)p * cap * kTopK; w.meta = (int32_t *)ex->d_mkey2.p + (size_t)p * cap;
             ResolveProblem &q = R[p];
             memset(&q, 0, sizeof(q));
@@ -443,7 +449,8 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     g.inv_h = 48.0f / ((float)ex->height - 0.f);
     hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
     if (ex->profile) (void)hipEventRecord(e0, ex->stream);
-    hipLaunchKernelGGL(k_window_best2, dim3((cap + 3) / 4, np), dim3(256), 0, ex->stream, (const WindowProblem *)ex->d_mprobs.p, g);
+    hipLaunchKernelGGL(k_grid_build, dim3(np), dim3(64), 0, ex->stream, (const WindowProblem *)ex->d_mprobs.p, g);
+    hipLaunchKernelGGL(k_window_best2, dim3((cap + 15) / 16, np), dim3(256), 0, ex->stream, (const WindowProblem *)ex->d_mprobs.p, g);
     if (ex->profile) {
         (void)hipEventRecord(e1, ex->stream); (void)hipEventSynchronize(e1);
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);

@@ -172,7 +172,7 @@ def test_device_introsort_replica_matches_libstdcxx():
     from oracle import oracle_binding as ob
     L = _lib.lib()
     rng = np.random.default_rng(11)
-    sizes = [1, 2, 15, 16, 17, 18, 31, 33, 64, 100, 257, 1000, 3000]
+    sizes = [1, 2, 15, 16, 17, 18, 31, 33, 64, 65, 100, 128, 257, 511, 512, 1000, 3000]
     for n in sizes:
         for variant in range(3):
             if variant == 0:
@@ -186,7 +186,7 @@ def test_device_introsort_replica_matches_libstdcxx():
                 ulx = np.zeros(n, np.int64)
             cnt = cnt.astype(np.int32)
             ulx = ulx.astype(np.int32)
+            want = ob.sort_nodes(cnt, ulx)
             perm = np.zeros(n, np.int32)
             _lib.check(L.orbx_debug_sort_nodes(0, _lib.ptr(cnt), _lib.ptr(ulx), n, _lib.ptr(perm)), "sort")
-            want = ob.sort_nodes(cnt, ulx)
             assert np.array_equal(perm, want), (n, variant)
