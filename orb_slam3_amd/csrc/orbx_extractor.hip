@@ -209,13 +209,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     {
         ProfScope ps(ex, K_PYR_BASE);
         const LevelInfo &L = ex->lv[0];
-        dim3 grid((L.pitch / 4 + 255) / 256, L.h + 2 * kEdge, n);
+        dim3 grid(((L.pitch / 4) * (L.h + 2 * kEdge) + 255) / 256, n);
         hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, d_lv, d_images, row_stride, frame_stride, pyr, ex->pyr_frame);
     }
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
-        dim3 grid((L.pitch / 4 + 255) / 256, L.h + 2 * kEdge, n);
+        dim3 grid(((L.pitch / 4) * (L.h + 2 * kEdge) + 255) / 256, n);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, d_lv, l, (const ResizeTap *)ex->d_xtab.p,
                            (const ResizeTap *)ex->d_ytab.p, pyr, ex->pyr_frame);
     }
