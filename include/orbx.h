@@ -236,6 +236,53 @@ int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur,
                                     const float *q_angle, const uint8_t *q_desc, const uint8_t *q_has_obs, float th,
                                     int level_mode, int check_orientation, int32_t *cur_match);
 
+/* General window form of the projection matchers: one query per projected map point with explicit window half-size
+ * and level range; accept iff (float)bestDist <= max_dist; a matched feature becomes occupied (q_has_obs NULL = always).
+ *   SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)  (ORBmatcher.cc:1889-2010):
+ *       r = th*scale[lvl], levels [lvl-1, lvl+1], max_dist = ORBdist, rotation check, occupied = mvpMapPoints[i] != NULL
+ *   SearchByProjection(KeyFrame*, Sim3f&, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming)
+ *       (ORBmatcher.cc:427-532, 534-646): r = th*scale[lvl], levels [lvl-1, lvl], max_dist = TH_LOW*ratioHamming,
+ *       no rotation check, occupied = vpMatched[i] != NULL
+ * match[i] = query index or -1.  Returns nmatches. */
+int orbx_search_by_projection_window(orbx_matcher *m, const orbx_frame_desc *frame, const uint8_t *occupied, int n_q,
+                                     const float *q_x, const float *q_y, const float *q_r, const int32_t *q_min_level,
+                                     const int32_t *q_max_level, const float *q_angle, const uint8_t *q_desc,
+                                     const uint8_t *q_has_obs, float max_dist, int check_orientation, int32_t *match);
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:648-763).
+ * prev_matched: n1 (x, y) pairs, updated in place (:757-760).  matches12[i1] = index in F2 or -1. */
+int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un, const uint8_t *desc1, int n1,
+                                   const orbx_frame_desc *F2, float *prev_matched, int window_size, float nnratio,
+                                   int check_orientation, int32_t *matches12);
+
+/* DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened: node ids ascending + CSR of indices */
+typedef struct orbx_featvec {
+    const uint32_t *node_id;
+    const int32_t *node_ptr;   /* n_nodes + 1 */
+    const int32_t *index;
+    int32_t n_nodes;
+} orbx_featvec;
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (ORBmatcher.cc:223-425, monocular).
+ * kf_valid[i] != 0 <=> KF feature i has a good map point.  f_match[iF] = KF feature index or -1. */
+int orbx_search_by_bow_frame(orbx_matcher *m, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid,
+                             int n_kf, const orbx_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f,
+                             const orbx_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match);
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (ORBmatcher.cc:765-905).  match12[i1] = i2 or -1 */
+int orbx_search_by_bow_keyframes(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *valid1,
+                                 int n1, const orbx_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                 const uint8_t *valid2, int n2, const orbx_featvec *fv2, float nnratio,
+                                 int check_orientation, int32_t *match12);
+/* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:907-1146).  skipN[i] != 0 <=> feature i already has a map point
+ * (or fails bOnlyStereo).  pair_ok(user, idx1, idx2) evaluates the geometric gates of :1026-1072 (epipole distance,
+ * epipolarConstrain unless bCoarse) -- host float math that stays in the adapter; NULL = always true.
+ * matches12[i1] = idx2 or -1 (vMatchedPairs = the pairs with matches12[i1] >= 0 in i1 order). */
+typedef int (*orbx_pair_predicate)(void *user, int idx1, int idx2);
+int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1,
+                                  const orbx_featvec *fv1, const uint8_t *desc2, const float *angle2, const uint8_t *skip2,
+                                  int n2, const orbx_featvec *fv2, int check_orientation, orbx_pair_predicate pair_ok,
+                                  void *user, int32_t *matches12);
+
 /* Device-resident, batched frame-to-frame matcher used by the throughput path: for every frame f >= 1 of the
  * extractor's last batch, the keypoints of frame f-1 (queries, at their own position shifted by (du, dv)) are
  * matched against frame f exactly as orbx_search_by_projection_frame does with level_mode 0, all features free on

@@ -32,6 +32,12 @@ def build(force: bool = False) -> Path:
     return _SO
 
 
+class OFeatVec(C.Structure):
+    _fields_ = [("node_id", C.c_void_p), ("node_ptr", C.c_void_p), ("index", C.c_void_p), ("n_nodes", C.c_int32)]
+
+
+PAIR_PREDICATE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
 _lib = None
 
 
@@ -97,6 +103,17 @@ def lib() -> C.CDLL:
         L.orbo_compute_stereo_matches.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, f32, f32,
                                                   vp, vp, vp, vp]
         L.orbo_knn2.argtypes = [vp, i32, vp, i32, vp, vp]
+        L.orbo_search_by_projection_window.restype = i32
+        L.orbo_search_by_projection_window.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, i32,
+                                                       i32, vp]
+        L.orbo_search_for_initialization.restype = i32
+        L.orbo_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, i32, f32, i32, vp]
+        L.orbo_search_by_bow_frame.restype = i32
+        L.orbo_search_by_bow_frame.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, f32, i32, vp]
+        L.orbo_search_by_bow_keyframes.restype = i32
+        L.orbo_search_by_bow_keyframes.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, i32, vp]
+        L.orbo_search_for_triangulation.restype = i32
+        L.orbo_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, PAIR_PREDICATE, vp, vp]
         L.orbo_three_maxima.argtypes = [vp, i32, vp, vp, vp]
         _lib = L
     return _lib
@@ -340,3 +357,68 @@ def three_maxima(sizes):
     a, b, c = C.c_int(-1), C.c_int(-1), C.c_int(-1)
     lib().orbo_three_maxima(_p(sizes), len(sizes), C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
+
+
+def _fv(fv):
+    """fv: any object with node_id / node_ptr / index numpy arrays (e.g. orb_slam3_amd.FeatureVector)."""
+    return OFeatVec(fv.node_id.ctypes.data, fv.node_ptr.ctypes.data, fv.index.ctypes.data, len(fv.node_id))
+
+
+def search_by_projection_window(grid: OracleGrid, desc, q, max_dist, check_orientation, level_gate_in_loop=False, occupied=None):
+    n = len(grid.kps)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    match = np.full(n, -1, np.int32)
+    a = {k: np.ascontiguousarray(v) for k, v in q.items()}
+    ang = a["angle"].astype(np.float32) if "angle" in a else np.zeros(len(a["x"]), np.float32)
+    ho = a["has_obs"].astype(np.uint8) if "has_obs" in a else None
+    r = lib().orbo_search_by_projection_window(
+        grid.h, _p(grid.kps), _p(desc), n, _p(occupied), len(a["x"]), _p(a["x"].astype(np.float32)),
+        _p(a["y"].astype(np.float32)), _p(a["r"].astype(np.float32)), _p(a["min_level"].astype(np.int32)),
+        _p(a["max_level"].astype(np.int32)), _p(ang), _p(a["desc"].astype(np.uint8)), _p(ho), max_dist,
+        int(check_orientation), int(level_gate_in_loop), _p(match))
+    return r, match
+
+
+def search_for_initialization(kps1, desc1, grid2: OracleGrid, desc2, prev_matched, window_size, nnratio, check_orientation):
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8)
+    desc2 = np.ascontiguousarray(desc2, np.uint8)
+    assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous
+    m12 = np.full(len(kps1), -1, np.int32)
+    n = lib().orbo_search_for_initialization(_p(kps1), _p(desc1), len(kps1), grid2.h, _p(grid2.kps), _p(desc2), len(grid2.kps),
+                                             _p(prev_matched), window_size, nnratio, int(check_orientation), _p(m12))
+    return n, m12
+
+
+def search_by_bow_frame(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, nnratio, check_orientation):
+    kd, fd = np.ascontiguousarray(kf_desc, np.uint8), np.ascontiguousarray(f_desc, np.uint8)
+    ka, fa = np.ascontiguousarray(kf_angle, np.float32), np.ascontiguousarray(f_angle, np.float32)
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    a, b = _fv(kf_fv), _fv(f_fv)
+    fm = np.full(len(fd), -1, np.int32)
+    n = lib().orbo_search_by_bow_frame(_p(kd), _p(ka), _p(kv), len(kd), C.byref(a), _p(fd), _p(fa), len(fd), C.byref(b), nnratio,
+                                       int(check_orientation), _p(fm))
+    return n, fm
+
+
+def search_by_bow_keyframes(d1, a1, v1, fv1, d2, a2, v2, fv2, nnratio, check_orientation):
+    d1, d2 = np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)
+    a1, a2 = np.ascontiguousarray(a1, np.float32), np.ascontiguousarray(a2, np.float32)
+    v1, v2 = np.ascontiguousarray(v1, np.uint8), np.ascontiguousarray(v2, np.uint8)
+    a, b = _fv(fv1), _fv(fv2)
+    m12 = np.full(len(d1), -1, np.int32)
+    n = lib().orbo_search_by_bow_keyframes(_p(d1), _p(a1), _p(v1), len(d1), C.byref(a), _p(d2), _p(a2), _p(v2), len(d2),
+                                           C.byref(b), nnratio, int(check_orientation), _p(m12))
+    return n, m12
+
+
+def search_for_triangulation(d1, a1, s1, fv1, d2, a2, s2, fv2, check_orientation, pair_ok=None):
+    d1, d2 = np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)
+    a1, a2 = np.ascontiguousarray(a1, np.float32), np.ascontiguousarray(a2, np.float32)
+    s1, s2 = np.ascontiguousarray(s1, np.uint8), np.ascontiguousarray(s2, np.uint8)
+    a, b = _fv(fv1), _fv(fv2)
+    m12 = np.full(len(d1), -1, np.int32)
+    cb = PAIR_PREDICATE((lambda user, i, j: int(bool(pair_ok(i, j)))) if pair_ok else 0)
+    n = lib().orbo_search_for_triangulation(_p(d1), _p(a1), _p(s1), len(d1), C.byref(a), _p(d2), _p(a2), _p(s2), len(d2),
+                                            C.byref(b), int(check_orientation), cb, None, _p(m12))
+    return n, m12

@@ -127,6 +127,49 @@ int orbo_search_by_projection_frame(const orbo_grid *grid, const orbo_keypoint *
                                     const uint8_t *q_desc, const uint8_t *q_has_obs, float th, int mode,
                                     int check_orientation, int32_t *cur_match);
 
+/* M3 / M4 (and M2 again) in their common form: one query per projected map point with an explicit window radius
+ * and level range.  level_gate_in_loop = 0: Frame::GetFeaturesInArea(x,y,r,minLevel,maxLevel) as M3 (ORBmatcher.cc:
+ * 1889-2010) does; = 1: KeyFrame::GetFeaturesInArea(x,y,r) (KeyFrame.cc:704-748, no level test) followed by the explicit
+ * octave gate of the Sim3 variants (ORBmatcher.cc:427-646).  Accept: (float)bestDist <= max_dist.  A matched feature
+ * becomes occupied (q_has_obs NULL) or takes q_has_obs[i].  Rotation histogram when check_orientation. */
+int orbo_search_by_projection_window(const orbo_grid *grid, const orbo_keypoint *kps_un, const uint8_t *desc, int n,
+                                     const uint8_t *occupied, int n_q, const float *q_x, const float *q_y,
+                                     const float *q_r, const int32_t *q_min_level, const int32_t *q_max_level,
+                                     const float *q_angle, const uint8_t *q_desc, const uint8_t *q_has_obs,
+                                     float max_dist, int check_orientation, int level_gate_in_loop, int32_t *match);
+
+/* M6: ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763).  prev_matched: 2*n1 floats (x,y), updated in place. */
+int orbo_search_for_initialization(const orbo_keypoint *kps1_un, const uint8_t *desc1, int n1, const orbo_grid *grid2,
+                                   const orbo_keypoint *kps2_un, const uint8_t *desc2, int n2, float *prev_matched,
+                                   int window_size, float nnratio, int check_orientation, int32_t *matches12);
+
+/* DBoW2::FeatureVector flattened (std::map<NodeId, vector<unsigned>>): node ids ascending, CSR of feature indices */
+typedef struct orbo_featvec {
+    const uint32_t *node_id;
+    const int32_t *node_ptr; /* n_nodes + 1 */
+    const int32_t *index;
+    int32_t n_nodes;
+} orbo_featvec;
+
+/* M5: SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:223-425, mono) -> f_match[iF] = KF feature index or -1.
+ * kf_valid[i] != 0 <=> the KF feature has a good map point. */
+int orbo_search_by_bow_frame(const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                             const orbo_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f,
+                             const orbo_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match);
+/* M5: SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:765-905) -> match12[i1] = KF2 feature index or -1 */
+int orbo_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
+                                 const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                 const uint8_t *valid2, int n2, const orbo_featvec *fv2, float nnratio,
+                                 int check_orientation, int32_t *match12);
+/* M7: SearchForTriangulation (ORBmatcher.cc:907-1146).  skip1/skip2: feature already has a map point (or fails
+ * bOnlyStereo).  pair_ok(user, idx1, idx2) = the geometric gates of :1026-1072 (epipole distance, epipolarConstrain or
+ * bCoarse), evaluated lazily exactly where the reference evaluates them.  matches12[i1] = idx2 or -1. */
+typedef int (*orbo_pair_predicate)(void *user, int idx1, int idx2);
+int orbo_search_for_triangulation(const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1,
+                                  const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                  const uint8_t *skip2, int n2, const orbo_featvec *fv2, int check_orientation,
+                                  orbo_pair_predicate pair_ok, void *user, int32_t *matches12);
+
 /* M8: Frame::ComputeStereoMatches (Frame.cc:811-981).  Fills u_right/depth (N_left), and the raw Hamming stage
  * result best_idx_r / best_dist (-1 / TH_HIGH when none) for kernel-level parity. */
 int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int nl, const orbo_keypoint *kr,

@@ -231,6 +231,262 @@ int orbo_search_by_projection_frame(const orbo_grid *grid, const orbo_keypoint *
     return nmatches;
 }
 
+/* M3 (ORBmatcher.cc:1889-2010) / M4 (ORBmatcher.cc:427-646) common form */
+int orbo_search_by_projection_window(const orbo_grid *grid, const orbo_keypoint *kps, const uint8_t *desc, int n,
+                                     const uint8_t *occupied, int n_q, const float *q_x, const float *q_y,
+                                     const float *q_r, const int32_t *q_min, const int32_t *q_max, const float *q_angle,
+                                     const uint8_t *q_desc, const uint8_t *q_has_obs, float max_dist,
+                                     int check_orientation, int level_gate_in_loop, int32_t *match) {
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<uint8_t> occ(occupied ? std::vector<uint8_t>(occupied, occupied + n) : std::vector<uint8_t>(n, 0));
+    for (int i = 0; i < n; i++) match[i] = -1;
+    std::vector<int32_t> vIndices;
+    for (int i = 0; i < n_q; i++) {
+        if (level_gate_in_loop) grid_query(grid, q_x[i], q_y[i], q_r[i], -1, -1, vIndices);  /* KeyFrame::GetFeaturesInArea */
+        else grid_query(grid, q_x[i], q_y[i], q_r[i], q_min[i], q_max[i], vIndices);
+        if (vIndices.empty()) continue;
+        const uint8_t *dMP = q_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (int32_t idx : vIndices) {
+            if (occ[idx]) continue;
+            if (level_gate_in_loop) {
+                const int kpLevel = kps[idx].octave;
+                if (kpLevel < q_min[i] || kpLevel > q_max[i]) continue;
+            }
+            const int dist = descriptor_distance(dMP, desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if ((float)bestDist <= max_dist) {
+            match[bestIdx] = i;
+            occ[bestIdx] = q_has_obs ? q_has_obs[i] : 1;
+            nmatches++;
+            if (check_orientation) {
+                float rot = q_angle[i] - kps[bestIdx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx);
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { match[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+/* M6, ORBmatcher.cc:648-763 */
+int orbo_search_for_initialization(const orbo_keypoint *kps1, const uint8_t *desc1, int n1, const orbo_grid *grid2,
+                                   const orbo_keypoint *kps2, const uint8_t *desc2, int n2, float *prev, int windowSize,
+                                   float nnratio, int check_orientation, int32_t *vnMatches12) {
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+    std::vector<int32_t> vIndices2;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = kps1[i1].octave;
+        if (level1 > 0) continue;
+        grid_query(grid2, prev[2 * i1], prev[2 * i1 + 1], (float)windowSize, level1, level1, vIndices2);
+        if (vIndices2.empty()) continue;
+        const uint8_t *d1 = desc1 + (size_t)i1 * 32;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int32_t i2 : vIndices2) {
+            const int dist = descriptor_distance(d1, desc2 + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = kps1[i1].angle - kps2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++) /* :757-760 update prev matched */
+        if (vnMatches12[i1] >= 0) { prev[2 * i1] = kps2[vnMatches12[i1]].x; prev[2 * i1 + 1] = kps2[vnMatches12[i1]].y; }
+    return nmatches;
+}
+
+}  // extern "C"
+
+namespace {
+/* the while loop over two DBoW2::FeatureVector maps (e.g. ORBmatcher.cc:239-381): visit equal node ids in ascending order */
+template <class F> void join_nodes(const orbo_featvec *a, const orbo_featvec *b, F visit) {
+    int ia = 0, ib = 0;
+    while (ia < a->n_nodes && ib < b->n_nodes) {
+        if (a->node_id[ia] == b->node_id[ib]) { visit(ia, ib); ia++; ib++; }
+        else if (a->node_id[ia] < b->node_id[ib]) { while (ia < a->n_nodes && a->node_id[ia] < b->node_id[ib]) ia++; } /* lower_bound */
+        else { while (ib < b->n_nodes && b->node_id[ib] < a->node_id[ia]) ib++; }
+    }
+}
+inline int rot_bin(float a1, float a2) {
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+}  // namespace
+
+extern "C" {
+
+/* M5, ORBmatcher.cc:223-425 (F.Nleft == -1) */
+int orbo_search_by_bow_frame(const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                             const orbo_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f,
+                             const orbo_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match) {
+    int nmatches = 0;
+    for (int i = 0; i < n_f; i++) f_match[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    join_nodes(kf_fv, f_fv, [&](int ik, int jf) {
+        for (int a = kf_fv->node_ptr[ik]; a < kf_fv->node_ptr[ik + 1]; a++) {
+            const int realIdxKF = kf_fv->index[a];
+            if (!kf_valid[realIdxKF]) continue; /* !pMP || pMP->isBad() */
+            const uint8_t *dKF = kf_desc + (size_t)realIdxKF * 32;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            for (int b = f_fv->node_ptr[jf]; b < f_fv->node_ptr[jf + 1]; b++) {
+                const int realIdxF = f_fv->index[b];
+                if (f_match[realIdxF] >= 0) continue; /* vpMapPointMatches[realIdxF] */
+                const int dist = descriptor_distance(dKF, f_desc + (size_t)realIdxF * 32);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 <= TH_LOW) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    f_match[bestIdxF] = realIdxKF;
+                    if (check_orientation) rotHist[rot_bin(kf_angle[realIdxKF], f_angle[bestIdxF])].push_back(bestIdxF);
+                    nmatches++;
+                }
+            }
+        }
+    });
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { f_match[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+/* M5, ORBmatcher.cc:765-905 */
+int orbo_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
+                                 const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                 const uint8_t *valid2, int n2, const orbo_featvec *fv2, float nnratio,
+                                 int check_orientation, int32_t *match12) {
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<uint8_t> vbMatched2(n2, 0);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    join_nodes(fv1, fv2, [&](int i1n, int i2n) {
+        for (int a = fv1->node_ptr[i1n]; a < fv1->node_ptr[i1n + 1]; a++) {
+            const int idx1 = fv1->index[a];
+            if (!valid1[idx1]) continue;
+            const uint8_t *d1 = desc1 + (size_t)idx1 * 32;
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            for (int b = fv2->node_ptr[i2n]; b < fv2->node_ptr[i2n + 1]; b++) {
+                const int idx2 = fv2->index[b];
+                if (vbMatched2[idx2] || !valid2[idx2]) continue;
+                const int dist = descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 < TH_LOW) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    match12[idx1] = bestIdx2;
+                    vbMatched2[bestIdx2] = 1;
+                    if (check_orientation) rotHist[rot_bin(angle1[idx1], angle2[bestIdx2])].push_back(idx1);
+                    nmatches++;
+                }
+            }
+        }
+    });
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { match12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+/* M7, ORBmatcher.cc:907-1146.  NB vbMatched2 is never set in v1.0, so queries do not interact. */
+int orbo_search_for_triangulation(const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1,
+                                  const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                  const uint8_t *skip2, int n2, const orbo_featvec *fv2, int check_orientation,
+                                  orbo_pair_predicate pair_ok, void *user, int32_t *vMatches12) {
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) vMatches12[i] = -1;
+    std::vector<uint8_t> vbMatched2(n2, 0);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    join_nodes(fv1, fv2, [&](int i1n, int i2n) {
+        for (int a = fv1->node_ptr[i1n]; a < fv1->node_ptr[i1n + 1]; a++) {
+            const int idx1 = fv1->index[a];
+            if (skip1[idx1]) continue;
+            const uint8_t *d1 = desc1 + (size_t)idx1 * 32;
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int b = fv2->node_ptr[i2n]; b < fv2->node_ptr[i2n + 1]; b++) {
+                const int idx2 = fv2->index[b];
+                if (vbMatched2[idx2] || skip2[idx2]) continue;
+                const int dist = descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                if (!pair_ok || pair_ok(user, idx1, idx2)) { bestIdx2 = idx2; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) {
+                vMatches12[idx1] = bestIdx2;
+                nmatches++;
+                if (check_orientation) rotHist[rot_bin(angle1[idx1], angle2[bestIdx2])].push_back(idx1);
+            }
+        }
+    });
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { vMatches12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 /* M8, Frame.cc:811-981 */
 int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int N, const orbo_keypoint *kr,
                                 const uint8_t *dr, int Nr, const float *scale_factors, const float *inv_scale_factors,

@@ -51,6 +51,13 @@ class FrameDesc(C.Structure):
                 ("scale_factors", C.c_void_p), ("nlevels", C.c_int32), ("u_right", C.c_void_p)]
 
 
+class FeatVec(C.Structure):
+    """DBoW2::FeatureVector flattened: node ids ascending + CSR of feature indices."""
+    _fields_ = [("node_id", C.c_void_p), ("node_ptr", C.c_void_p), ("index", C.c_void_p), ("n_nodes", C.c_int32)]
+
+
+PAIR_PREDICATE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
 _lib = None
 
 # every symbol include/orbx.h declares (tests check that the library exports all of them)
@@ -62,7 +69,9 @@ SYMBOLS = [
     "orbx_debug_level_blurred", "orbx_profile_enable", "orbx_profile_read", "orbx_matcher_create",
     "orbx_matcher_destroy", "orbx_hamming_csr", "orbx_hamming_best2_csr", "orbx_knn2", "orbx_stereo_rowband",
     "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
-    "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string",
+    "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window",
+    "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
+    "orbx_search_for_triangulation",
 ]
 
 
@@ -117,6 +126,13 @@ def lib() -> C.CDLL:
     L.orbx_search_by_projection_frame.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, vp, f32,
                                                   i32, i32, vp]
     L.orbx_match_consecutive_device.argtypes = [vp, f32, f32, f32, i32, vp, vp]
+    L.orbx_search_by_projection_window.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32,
+                                                   i32, vp]
+    L.orbx_search_for_initialization.argtypes = [vp, vp, vp, i32, C.POINTER(FrameDesc), vp, i32, f32, i32, vp]
+    fvp = C.POINTER(FeatVec)
+    L.orbx_search_by_bow_frame.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, i32, fvp, f32, i32, vp]
+    L.orbx_search_by_bow_keyframes.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, vp, i32, fvp, f32, i32, vp]
+    L.orbx_search_for_triangulation.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, vp, i32, fvp, i32, PAIR_PREDICATE, vp, vp]
     _lib = L
     return L
 

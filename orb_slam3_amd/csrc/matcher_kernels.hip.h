@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
 struct ResolveProblem {
     int mode;                 // 1 = SearchByProjection(Frame, MapPoints) (M1), 2 = SearchByProjection(Cur, Last) (M2)
     float nnratio;            // M1
+    float max_dist;           // accept threshold on the best distance (TH_HIGH, ORBdist, TH_LOW*ratioHamming ...)
     int check_orientation;    // M2
     const float *q_angle;     // M2 (NULL with q_from_kps)
     const uint8_t *q_has_obs; // NULL = all true
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
     auto accept = [&](u64 k1, u64 k2) -> bool {
         if (k1 == kNoKey) return false;
         const int bestDist = (int)(k1 >> 32);
-        if (bestDist > ORBX_TH_HIGH) return false;
+        if ((float)bestDist > R.max_dist) return false;
         if (two) {
             const int bestDist2 = (k2 == kNoKey) ? 256 : (int)(k2 >> 32);
             const int bestLevel = P.kps[(int)(k1 & 0xffff)].octave;
@@ -533,10 +534,10 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                 }
                 if (!exhaustive) {
                     if (c1 == kNoKey) need_slow = true;                                   // best unknown
-                    else if (two && c2 == kNoKey && (int)(c1 >> 32) <= ORBX_TH_HIGH) need_slow = true;  // second-best unknown
+                    else if (two && c2 == kNoKey && (float)(int)(c1 >> 32) <= R.max_dist) need_slow = true;  // second-best unknown
                 }
             }
-            const bool has = live && !need_slow && c1 != kNoKey && (int)(c1 >> 32) <= ORBX_TH_HIGH;
+            const bool has = live && !need_slow && c1 != kNoKey && (float)(int)(c1 >> 32) <= R.max_dist;
             const int t1 = has ? (int)(c1 & 0xffff) : -1;
             const int t2 = (has && two && c2 != kNoKey) ? (int)(c2 & 0xffff) : -1;
             if (has) atomicMin(&claim[t1], (uint32_t)lane);

@@ -259,6 +259,7 @@ struct ProjArgs {
     float nnratio;
     int check_orientation;
     int32_t *match_out;
+    float max_dist;
 };
 
 int run_projection(orbx_matcher *m, const ProjArgs &a) {
@@ -301,7 +302,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     if (a.qvalid) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.qvalid, (size_t)nq); P.qvalid = p; }
     P.keys = A.take<u64>((size_t)nq * kTopK); P.meta = A.take<int32_t>(nq);
     P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n);
-    R.mode = a.mode; R.nnratio = a.nnratio; R.check_orientation = a.check_orientation;
+    R.mode = a.mode; R.nnratio = a.nnratio; R.check_orientation = a.check_orientation; R.max_dist = a.max_dist;
     if (a.q_angle) { float *p = A.take<float>(nq); H2D(p, a.q_angle, 4 * (size_t)nq); R.q_angle = p; }
     if (a.q_has_obs) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.q_has_obs, (size_t)nq); R.q_has_obs = p; }
     R.match = A.take<int32_t>(n);
@@ -352,7 +353,7 @@ int orbx_search_by_projection_mappoints(orbx_matcher *m, const orbx_frame_desc *
         qmin[i] = lvl - 1; qmax[i] = lvl;
     }
     ProjArgs a = {frame, frame_occupied, n_mp, proj_x, proj_y, qr.data(), proj_xr, qmin.data(), qmax.data(), mp_desc, valid.data(),
-                  mp_has_obs, nullptr, 1, nnratio, 0, frame_match};
+                  mp_has_obs, nullptr, 1, nnratio, 0, frame_match, (float)ORBX_TH_HIGH};
     return run_projection(m, a);
 }
 
@@ -374,8 +375,296 @@ int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur,
         else { qmin[i] = o - 1; qmax[i] = o + 1; }                   // :1735
     }
     ProjArgs a = {cur, cur_occupied, n_q, q_u, q_v, qr.data(), q_ur, qmin.data(), qmax.data(), q_desc, valid.data(), q_has_obs,
-                  q_angle, 2, 0.f, check_orientation, cur_match};
+                  q_angle, 2, 0.f, check_orientation, cur_match, (float)ORBX_TH_HIGH};
     return run_projection(m, a);
+}
+
+}  // extern "C"
+
+extern "C" int orbx_search_by_projection_window(orbx_matcher *m, const orbx_frame_desc *frame, const uint8_t *occupied, int n_q,
+                                                const float *q_x, const float *q_y, const float *q_r, const int32_t *q_min_level,
+                                                const int32_t *q_max_level, const float *q_angle, const uint8_t *q_desc,
+                                                const uint8_t *q_has_obs, float max_dist, int check_orientation, int32_t *match) {
+    if (!m || !frame || !match || n_q < 0) return ORBX_E_BAD_ARG;
+    if (n_q > 0 && (!q_x || !q_y || !q_r || !q_min_level || !q_max_level || !q_desc || (check_orientation && !q_angle))) return ORBX_E_BAD_ARG;
+    ProjArgs a = {frame, occupied, n_q, q_x, q_y, q_r, nullptr, q_min_level, q_max_level, q_desc, nullptr, q_has_obs,
+                  q_angle, 2, 0.f, check_orientation, match, max_dist};
+    return run_projection(m, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Matchers whose inner loop carries more state than a taken-mask (SearchForInitialization's vMatchedDistance,
+// the BoW merge-joins, SearchForTriangulation's lazily evaluated geometric gate): the GPU evaluates every candidate
+// distance of the reference's enumeration (orbx_hamming_csr), the host replays the reference's sequential logic over
+// those distances in the reference's order -- identical pairs (hard part 4).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct HostGrid {  // Frame::AssignFeaturesToGrid / GetFeaturesInArea (Frame.cc:385-416, 657-723)
+    float minx, miny, inv_w, inv_h;
+    const orbx_keypoint *kps;
+    std::vector<int32_t> cell_start, order;  // counting sort by cell id x*48+y (insertion order inside a cell)
+    HostGrid(const orbx_frame_desc *F) : kps(F->keypoints_un) {
+        minx = F->min_x; miny = F->min_y;
+        inv_w = 64.0f / (F->max_x - F->min_x);
+        inv_h = 48.0f / (F->max_y - F->min_y);
+        std::vector<int32_t> cid(F->n, -1);
+        cell_start.assign(64 * 48 + 1, 0);
+        for (int i = 0; i < F->n; i++) {
+            const int px = (int)std::round((kps[i].x - minx) * inv_w), py = (int)std::round((kps[i].y - miny) * inv_h);
+            if (px < 0 || px >= 64 || py < 0 || py >= 48) continue;
+            cid[i] = px * 48 + py;
+            cell_start[cid[i] + 1]++;
+        }
+        for (int c = 0; c < 64 * 48; c++) cell_start[c + 1] += cell_start[c];
+        order.resize(cell_start[64 * 48]);
+        std::vector<int32_t> cur(cell_start.begin(), cell_start.end() - 1);
+        for (int i = 0; i < F->n; i++) if (cid[i] >= 0) order[cur[cid[i]]++] = i;
+    }
+    void query(float x, float y, float r, int minLevel, int maxLevel, std::vector<int32_t> &out) const {
+        const int cx0 = std::max(0, (int)std::floor((x - minx - r) * inv_w));
+        if (cx0 >= 64) return;
+        const int cx1 = std::min(63, (int)std::ceil((x - minx + r) * inv_w));
+        if (cx1 < 0) return;
+        const int cy0 = std::max(0, (int)std::floor((y - miny - r) * inv_h));
+        if (cy0 >= 48) return;
+        const int cy1 = std::min(47, (int)std::ceil((y - miny + r) * inv_h));
+        if (cy1 < 0) return;
+        const bool check = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = cx0; ix <= cx1; ix++)
+            for (int j = cell_start[ix * 48 + cy0]; j < cell_start[ix * 48 + cy1 + 1]; j++) {
+                const orbx_keypoint &kp = kps[order[j]];
+                if (check && (kp.octave < minLevel || (maxLevel >= 0 && kp.octave > maxLevel))) continue;
+                if (std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r) out.push_back(order[j]);
+            }
+    }
+};
+
+inline int rotation_bin(float a1, float a2) {  // e.g. ORBmatcher.cc:337-343
+    float rot = a1 - a2;
+    if (rot < 0.0f) rot += 360.0f;
+    int bin = (int)std::round(rot * (1.0f / ORBX_HISTO_LENGTH));
+    if (bin == ORBX_HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// ComputeThreeMaxima (ORBmatcher.cc:2012-2053) + removal of the losing bins; entries = (bin, key) in push order
+struct RotHist {
+    std::vector<std::pair<int, int>> entries;
+    void push(int bin, int key) { entries.emplace_back(bin, key); }
+    template <class Drop> void filter(Drop drop) const {
+        int cnt[ORBX_HISTO_LENGTH] = {0};
+        for (auto &e : entries) cnt[e.first]++;
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {
+            const int s = cnt[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (auto &e : entries)
+            if (e.first != ind1 && e.first != ind2 && e.first != ind3) drop(e.second);
+    }
+};
+
+// merge-join of two flattened DBoW2::FeatureVector maps: equal node ids in ascending order
+template <class V> void for_common_nodes(const orbx_featvec *a, const orbx_featvec *b, V visit) {
+    int ia = 0, ib = 0;
+    while (ia < a->n_nodes && ib < b->n_nodes) {
+        const uint32_t na = a->node_id[ia], nb = b->node_id[ib];
+        if (na == nb) { visit(ia, ib); ia++; ib++; }
+        else if (na < nb) ia++;
+        else ib++;
+    }
+}
+
+// queries = features of A listed in the common nodes (those with qmask clear), candidates = the node's list in B.
+// Builds the CSR in the reference's enumeration order and evaluates all distances on the GPU.
+struct BowPairs {
+    std::vector<int32_t> q_idx, row_ptr, cand;
+    std::vector<uint16_t> dist;
+};
+int bow_distances(orbx_matcher *m, const uint8_t *descA, const uint8_t *skipA, const orbx_featvec *fvA, const uint8_t *descB, int nB,
+                  const orbx_featvec *fvB, BowPairs &P) {
+    P.row_ptr.assign(1, 0);
+    for_common_nodes(fvA, fvB, [&](int ia, int ib) {
+        for (int a = fvA->node_ptr[ia]; a < fvA->node_ptr[ia + 1]; a++) {
+            const int i = fvA->index[a];
+            if (skipA && skipA[i]) continue;
+            P.q_idx.push_back(i);
+            for (int b = fvB->node_ptr[ib]; b < fvB->node_ptr[ib + 1]; b++) P.cand.push_back(fvB->index[b]);
+            P.row_ptr.push_back((int32_t)P.cand.size());
+        }
+    });
+    const int nq = (int)P.q_idx.size();
+    P.dist.assign(P.cand.size(), 0);
+    if (nq == 0 || P.cand.empty()) return ORBX_OK;
+    std::vector<uint8_t> qd((size_t)nq * 32);
+    for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], descA + (size_t)P.q_idx[k] * 32, 32);
+    return orbx_hamming_csr(m, qd.data(), nq, descB, nB, P.row_ptr.data(), P.cand.data(), P.dist.data());
+}
+
+}  // namespace
+
+extern "C" {
+
+// ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763)
+int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un, const uint8_t *desc1, int n1, const orbx_frame_desc *F2,
+                                   float *prev_matched, int window_size, float nnratio, int check_orientation, int32_t *matches12) {
+    if (!m || !F2 || !matches12 || n1 < 0 || (n1 > 0 && (!kps1_un || !desc1 || !prev_matched))) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    const int n2 = F2->n;
+    if (n1 == 0 || n2 == 0) return 0;
+    HostGrid grid(F2);
+    std::vector<int32_t> q_idx, row_ptr(1, 0), cand, tmp;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = kps1_un[i1].octave;
+        if (level1 > 0) continue;  // :665
+        tmp.clear();
+        grid.query(prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size, level1, level1, tmp);
+        if (tmp.empty()) continue;
+        q_idx.push_back(i1);
+        cand.insert(cand.end(), tmp.begin(), tmp.end());
+        row_ptr.push_back((int32_t)cand.size());
+    }
+    const int nq = (int)q_idx.size();
+    std::vector<uint16_t> dist(cand.size());
+    if (nq > 0) {
+        std::vector<uint8_t> qd((size_t)nq * 32);
+        for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], desc1 + (size_t)q_idx[k] * 32, 32);
+        const int r = orbx_hamming_csr(m, qd.data(), nq, F2->descriptors, n2, row_ptr.data(), cand.data(), dist.data());
+        if (r != ORBX_OK) return r;
+    }
+    // sequential replay in query order
+    int nmatches = 0;
+    std::vector<int> matched_dist(n2, INT_MAX), matches21(n2, -1);
+    RotHist hist;
+    for (int k = 0; k < nq; k++) {
+        const int i1 = q_idx[k];
+        int best = INT_MAX, second = INT_MAX, best_i2 = -1;
+        for (int c = row_ptr[k]; c < row_ptr[k + 1]; c++) {
+            const int i2 = cand[c], d = dist[c];
+            if (matched_dist[i2] <= d) continue;  // :687-688
+            if (d < best) { second = best; best = d; best_i2 = i2; }
+            else if (d < second) second = d;
+        }
+        if (best <= ORBX_TH_LOW && (float)best < (float)second * nnratio) {
+            if (matches21[best_i2] >= 0) { matches12[matches21[best_i2]] = -1; nmatches--; }
+            matches12[i1] = best_i2;
+            matches21[best_i2] = i1;
+            matched_dist[best_i2] = best;
+            nmatches++;
+            if (check_orientation) hist.push(rotation_bin(kps1_un[i1].angle, F2->keypoints_un[best_i2].angle), i1);
+        }
+    }
+    if (check_orientation)
+        hist.filter([&](int i1) { if (matches12[i1] >= 0) { matches12[i1] = -1; nmatches--; } });
+    for (int i1 = 0; i1 < n1; i1++)  // :757-760
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = F2->keypoints_un[matches12[i1]].x;
+            prev_matched[2 * i1 + 1] = F2->keypoints_un[matches12[i1]].y;
+        }
+    return nmatches;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (ORBmatcher.cc:223-425), monocular form
+int orbx_search_by_bow_frame(orbx_matcher *m, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                             const orbx_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f, const orbx_featvec *f_fv,
+                             float nnratio, int check_orientation, int32_t *f_match) {
+    if (!m || !kf_fv || !f_fv || !f_match || n_kf < 0 || n_f < 0) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n_f; i++) f_match[i] = -1;
+    if (n_kf == 0 || n_f == 0) return 0;
+    std::vector<uint8_t> skip(n_kf);
+    for (int i = 0; i < n_kf; i++) skip[i] = kf_valid ? !kf_valid[i] : 0;
+    BowPairs P;
+    const int r = bow_distances(m, kf_desc, skip.data(), kf_fv, f_desc, n_f, f_fv, P);
+    if (r != ORBX_OK) return r;
+    int nmatches = 0;
+    RotHist hist;
+    for (size_t k = 0; k < P.q_idx.size(); k++) {
+        int best = 256, second = 256, best_f = -1;
+        for (int c = P.row_ptr[k]; c < P.row_ptr[k + 1]; c++) {
+            const int iF = P.cand[c], d = P.dist[c];
+            if (f_match[iF] >= 0) continue;  // vpMapPointMatches[realIdxF] already set (:281)
+            if (d < best) { second = best; best = d; best_f = iF; }
+            else if (d < second) second = d;
+        }
+        if (best <= ORBX_TH_LOW && (float)best < nnratio * (float)second) {
+            f_match[best_f] = P.q_idx[k];
+            if (check_orientation) hist.push(rotation_bin(kf_angle[P.q_idx[k]], f_angle[best_f]), best_f);
+            nmatches++;
+        }
+    }
+    if (check_orientation) hist.filter([&](int iF) { f_match[iF] = -1; nmatches--; });
+    return nmatches;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (ORBmatcher.cc:765-905)
+int orbx_search_by_bow_keyframes(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
+                                 const orbx_featvec *fv1, const uint8_t *desc2, const float *angle2, const uint8_t *valid2, int n2,
+                                 const orbx_featvec *fv2, float nnratio, int check_orientation, int32_t *match12) {
+    if (!m || !fv1 || !fv2 || !match12 || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return 0;
+    std::vector<uint8_t> skip(n1);
+    for (int i = 0; i < n1; i++) skip[i] = valid1 ? !valid1[i] : 0;
+    BowPairs P;
+    const int r = bow_distances(m, desc1, skip.data(), fv1, desc2, n2, fv2, P);
+    if (r != ORBX_OK) return r;
+    int nmatches = 0;
+    std::vector<uint8_t> matched2(n2, 0);
+    RotHist hist;
+    for (size_t k = 0; k < P.q_idx.size(); k++) {
+        int best = 256, second = 256, best2 = -1;
+        for (int c = P.row_ptr[k]; c < P.row_ptr[k + 1]; c++) {
+            const int i2 = P.cand[c], d = P.dist[c];
+            if (matched2[i2] || (valid2 && !valid2[i2])) continue;  // :826-830
+            if (d < best) { second = best; best = d; best2 = i2; }
+            else if (d < second) second = d;
+        }
+        if (best < ORBX_TH_LOW && (float)best < nnratio * (float)second) {  // NB strict '<' here (:848)
+            match12[P.q_idx[k]] = best2;
+            matched2[best2] = 1;
+            if (check_orientation) hist.push(rotation_bin(angle1[P.q_idx[k]], angle2[best2]), P.q_idx[k]);
+            nmatches++;
+        }
+    }
+    if (check_orientation) hist.filter([&](int i1) { match12[i1] = -1; nmatches--; });
+    return nmatches;
+}
+
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:907-1146)
+int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1,
+                                  const orbx_featvec *fv1, const uint8_t *desc2, const float *angle2, const uint8_t *skip2, int n2,
+                                  const orbx_featvec *fv2, int check_orientation, orbx_pair_predicate pair_ok, void *user,
+                                  int32_t *matches12) {
+    if (!m || !fv1 || !fv2 || !matches12 || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return 0;
+    BowPairs P;
+    const int r = bow_distances(m, desc1, skip1, fv1, desc2, n2, fv2, P);
+    if (r != ORBX_OK) return r;
+    int nmatches = 0;
+    RotHist hist;
+    for (size_t k = 0; k < P.q_idx.size(); k++) {
+        const int i1 = P.q_idx[k];
+        int best = ORBX_TH_LOW, best2 = -1;
+        for (int c = P.row_ptr[k]; c < P.row_ptr[k + 1]; c++) {
+            const int i2 = P.cand[c], d = P.dist[c];
+            if (skip2 && skip2[i2]) continue;            // pMP2 (vbMatched2 is never set in v1.0)
+            if (d > ORBX_TH_LOW || d > best) continue;     // :1017 -- '>' : a later equal candidate wins
+            if (!pair_ok || pair_ok(user, i1, i2)) { best2 = i2; best = d; }  // epipole gate + epipolarConstrain / bCoarse
+        }
+        if (best2 >= 0) {
+            matches12[i1] = best2;
+            nmatches++;
+            if (check_orientation) hist.push(rotation_bin(angle1[i1], angle2[best2]), i1);
+        }
+    }
+    if (check_orientation) hist.filter([&](int i1) { matches12[i1] = -1; nmatches--; });
+    return nmatches;
 }
 
 }  // extern "C"
@@ -433,7 +722,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
             w.keys = (u64 *)ex->d_mkey1.p + (size_t)p * cap * kTopK; w.meta = (int32_t *)ex->d_mkey2.p + (size_t)p * cap;
             ResolveProblem &q = R[p];
             memset(&q, 0, sizeof(q));
-            q.mode = 2; q.check_orientation = check_orientation;
+            q.mode = 2; q.check_orientation = check_orientation; q.max_dist = (float)ORBX_TH_HIGH;
             q.match = d_match + (size_t)f * cap; q.nmatches = d_nmatches + f;
             q.entries = (int32_t *)ex->d_mentries.p + (size_t)p * cap;
         }

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import KP_DTYPE, FrameDesc, check, ptr
+from ._lib import KP_DTYPE, FeatVec, FrameDesc, PAIR_PREDICATE, check, ptr
 
 
 @dataclass
@@ -35,6 +35,27 @@ class FrameView:
         return FrameDesc(self.keypoints_un.ctypes.data, self.descriptors.ctypes.data, len(self.keypoints_un),
                          self.min_x, self.max_x, self.min_y, self.max_y, self.scale_factors.ctypes.data,
                          len(self.scale_factors), None if self.u_right is None else self.u_right.ctypes.data)
+
+
+class FeatureVector:
+    """DBoW2::FeatureVector as arrays: `nodes` ascending node ids, `lists[k]` = feature indices of node k."""
+
+    def __init__(self, nodes, lists):
+        self.node_id = np.ascontiguousarray(nodes, np.uint32)
+        assert np.all(np.diff(self.node_id.astype(np.int64)) > 0), "node ids must be strictly ascending (std::map order)"
+        self.node_ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32)
+        self.index = (np.concatenate(lists) if len(lists) else np.zeros(0)).astype(np.int32)
+
+    @classmethod
+    def from_node_of_feature(cls, node_of_feature):
+        """Build from a per-feature node id array (features listed in ascending index inside a node, as
+        TemplatedVocabulary::transform / FeatureVector::addFeature produce)."""
+        node_of_feature = np.asarray(node_of_feature)
+        nodes = np.unique(node_of_feature)
+        return cls(nodes, [np.nonzero(node_of_feature == nd)[0] for nd in nodes])
+
+    def c_struct(self, cls=FeatVec):
+        return cls(self.node_id.ctypes.data, self.node_ptr.ctypes.data, self.index.ctypes.data, len(self.node_id))
 
 
 def _f32(a):
@@ -149,3 +170,65 @@ class ORBmatcher:
             ptr(a["d"]), ptr(a["ho"]), th, level_mode, int(self.mbCheckOrientation), ptr(cm)),
             "orbx_search_by_projection_frame")
         return n, cm
+
+    # ---- general window form: M3 = SearchByProjection(Frame&, KeyFrame*, ...) (ORBmatcher.cc:1889-2010) and
+    #      M4 = SearchByProjection(KeyFrame*, Sim3f&, ...) (ORBmatcher.cc:427-646) ----
+    def SearchByProjectionWindow(self, F: FrameView, q: dict, max_dist: float, check_orientation: bool, occupied=None):
+        """q: x, y, r, min_level, max_level, angle, desc[, has_obs]."""
+        fd = F.c_struct()
+        nq = len(q["x"])
+        match = np.full(fd.n, -1, np.int32)
+        a = dict(x=_f32(q["x"]), y=_f32(q["y"]), r=_f32(q["r"]), lo=_i32(q["min_level"]), hi=_i32(q["max_level"]),
+                 ang=_f32(q.get("angle")), d=_u8(q["desc"]), ho=_u8(q.get("has_obs")))
+        occ = _u8(occupied)
+        n = check(self._L.orbx_search_by_projection_window(
+            self._h, C.byref(fd), ptr(occ), nq, ptr(a["x"]), ptr(a["y"]), ptr(a["r"]), ptr(a["lo"]), ptr(a["hi"]),
+            ptr(a["ang"]), ptr(a["d"]), ptr(a["ho"]), max_dist, int(check_orientation), ptr(match)),
+            "orbx_search_by_projection_window")
+        return n, match
+
+    # ---- SearchForInitialization (ORBmatcher.cc:648-763) ----
+    def SearchForInitialization(self, kps1_un, desc1, F2: FrameView, vbPrevMatched, windowSize=100):
+        """Returns (nmatches, vnMatches12); vbPrevMatched (n1 x 2 float32) is updated in place."""
+        k1 = np.ascontiguousarray(kps1_un, KP_DTYPE)
+        d1 = _u8(desc1)
+        assert vbPrevMatched.dtype == np.float32 and vbPrevMatched.flags.c_contiguous
+        fd = F2.c_struct()
+        m12 = np.full(len(k1), -1, np.int32)
+        n = check(self._L.orbx_search_for_initialization(self._h, ptr(k1), ptr(d1), len(k1), C.byref(fd), ptr(vbPrevMatched),
+                                                         int(windowSize), self.mfNNratio, int(self.mbCheckOrientation),
+                                                         ptr(m12)), "orbx_search_for_initialization")
+        return n, m12
+
+    # ---- SearchByBoW (ORBmatcher.cc:223-425 / 765-905) ----
+    def SearchByBoWFrame(self, kf_desc, kf_angle, kf_valid, kf_fv: FeatureVector, f_desc, f_angle, f_fv: FeatureVector):
+        kd, ka, kv, fdsc, fa = _u8(kf_desc), _f32(kf_angle), _u8(kf_valid), _u8(f_desc), _f32(f_angle)
+        a, b = kf_fv.c_struct(), f_fv.c_struct()
+        fm = np.full(len(fdsc), -1, np.int32)
+        n = check(self._L.orbx_search_by_bow_frame(self._h, ptr(kd), ptr(ka), ptr(kv), len(kd), C.byref(a), ptr(fdsc), ptr(fa),
+                                                   len(fdsc), C.byref(b), self.mfNNratio, int(self.mbCheckOrientation),
+                                                   ptr(fm)), "orbx_search_by_bow_frame")
+        return n, fm
+
+    def SearchByBoWKeyFrames(self, desc1, angle1, valid1, fv1: FeatureVector, desc2, angle2, valid2, fv2: FeatureVector):
+        d1, a1, v1, d2, a2, v2 = _u8(desc1), _f32(angle1), _u8(valid1), _u8(desc2), _f32(angle2), _u8(valid2)
+        a, b = fv1.c_struct(), fv2.c_struct()
+        m12 = np.full(len(d1), -1, np.int32)
+        n = check(self._L.orbx_search_by_bow_keyframes(self._h, ptr(d1), ptr(a1), ptr(v1), len(d1), C.byref(a), ptr(d2),
+                                                       ptr(a2), ptr(v2), len(d2), C.byref(b), self.mfNNratio,
+                                                       int(self.mbCheckOrientation), ptr(m12)),
+                  "orbx_search_by_bow_keyframes")
+        return n, m12
+
+    # ---- SearchForTriangulation (ORBmatcher.cc:907-1146) ----
+    def SearchForTriangulation(self, desc1, angle1, skip1, fv1: FeatureVector, desc2, angle2, skip2, fv2: FeatureVector,
+                               pair_ok=None):
+        """pair_ok(idx1, idx2) -> bool: the geometric gates (epipole distance + epipolarConstrain, or bCoarse)."""
+        d1, a1, s1, d2, a2, s2 = _u8(desc1), _f32(angle1), _u8(skip1), _u8(desc2), _f32(angle2), _u8(skip2)
+        a, b = fv1.c_struct(), fv2.c_struct()
+        m12 = np.full(len(d1), -1, np.int32)
+        cb = PAIR_PREDICATE((lambda user, i, j: int(bool(pair_ok(i, j)))) if pair_ok else 0)
+        n = check(self._L.orbx_search_for_triangulation(self._h, ptr(d1), ptr(a1), ptr(s1), len(d1), C.byref(a), ptr(d2),
+                                                        ptr(a2), ptr(s2), len(d2), C.byref(b), int(self.mbCheckOrientation),
+                                                        cb, None, ptr(m12)), "orbx_search_for_triangulation")
+        return n, m12

@@ -237,3 +237,112 @@ def test_async_download_pipeline_equals_sync(canvas1):
             if t > 0:
                 assert hs["nm"][t] == d_nm[t].item()
                 assert np.array_equal(hs["match"][t, :n].numpy(), d_match[t, :n].cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# M3 - M7
+# ---------------------------------------------------------------------------------------------------------
+def _two_frames(canvas, nf=1000, t0=0, t1=1, w=752, h=480):
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    ex = osa.ORBextractor(nf, 1.2, 8, 20, 7)
+    _, k0, d0 = ex(synth.frame_from_canvas(canvas, t0, w, h, 1000 + t0), None, (0, 1000))
+    _, k1, d1 = ex(synth.frame_from_canvas(canvas, t1, w, h, 1000 + t1), None, (0, 1000))
+    return ex, k0, d0, k1, d1
+
+
+def test_search_by_projection_window_reloc_and_sim3(oracle, canvas1):
+    """M3 (ORBmatcher.cc:1889-2010: levels [l-1,l+1], ORBdist 100 / 64, rotation check) and M4 (ORBmatcher.cc:427-646:
+    levels [l-1,l], TH_LOW*ratioHamming, KeyFrame::GetFeaturesInArea + octave gate)."""
+    import orb_slam3_amd as osa
+    ex, k0, d0, k1, d1 = _two_frames(canvas1)
+    sf = ex.GetScaleFactors()
+    rng = np.random.default_rng(21)
+    F = _frame_view(k1, d1, sf, 752, 480)
+    grid = oracle.OracleGrid(k1, 0.0, 752.0, 0.0, 480.0)
+    lvl = k0["octave"]
+    base = dict(x=k0["x"] - 2.0 + rng.normal(0, 1.0, len(k0)).astype(np.float32), y=k0["y"] - 1.0, angle=k0["angle"], desc=d0)
+    occ = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    for th, orbdist in ((10.0, 100.0), (3.0, 64.0)):   # Tracking.cc:3726,3740
+        q = dict(base, r=(th * sf[lvl]).astype(np.float32), min_level=lvl - 1, max_level=lvl + 1)
+        on, om = oracle.search_by_projection_window(grid, d1, q, orbdist, True, False, occ)
+        n, mt = osa.ORBmatcher(0.9, True).SearchByProjectionWindow(F, q, orbdist, True, occ)
+        assert n == on and np.array_equal(mt, om), (th, n, on)
+        assert n > 100
+    for th, ratio in ((8, 1.5), (5, 1.0), (3, 1.5)):    # LoopClosing.cc:755,777,964
+        q = dict(base, r=(np.float32(th) * sf[lvl]).astype(np.float32), min_level=lvl - 1, max_level=lvl)
+        on, om = oracle.search_by_projection_window(grid, d1, q, 50 * ratio, False, True, occ)
+        n, mt = osa.ORBmatcher(0.75, True).SearchByProjectionWindow(F, q, 50 * ratio, False, occ)
+        assert n == on and np.array_equal(mt, om), (th, n, on)
+        assert n > 100
+
+
+def test_search_for_initialization(oracle, canvas1):
+    """M6 (ORBmatcher.cc:648-763): 5x extractor, level-0 keypoints, 100-px window, vMatchedDistance reassignment."""
+    import orb_slam3_amd as osa
+    ex, k0, d0, k1, d1 = _two_frames(canvas1, nf=5000, t0=0, t1=4)
+    sf = ex.GetScaleFactors()
+    for ratio, ori in ((0.9, True), (0.7, False)):
+        prev_a = np.ascontiguousarray(np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32))
+        prev_b = prev_a.copy()
+        grid = oracle.OracleGrid(k1, 0.0, 752.0, 0.0, 480.0)
+        on, om = oracle.search_for_initialization(k0, d0, grid, d1, prev_a, 100, ratio, ori)
+        n, m12 = osa.ORBmatcher(ratio, ori).SearchForInitialization(k0, d0, _frame_view(k1, d1, sf, 752, 480), prev_b, 100)
+        assert n == on and np.array_equal(m12, om) and prev_a.tobytes() == prev_b.tobytes()
+        assert n > 200 and (m12[k0["octave"] > 0] == -1).all()
+
+
+def _bow_nodes(rng, k_a, k_b, d_a, d_b, n_nodes=100, noise=0.15):
+    """Synthetic vocabulary nodes: a feature's node is a hash of its position cell, so that true correspondences
+    (frame b is frame a shifted by a few pixels) mostly share a node; `noise` of them are scrambled."""
+    def node(k):
+        return ((np.floor(k["x"] / 60).astype(np.int64) * 7 + np.floor(k["y"] / 60).astype(np.int64) * 13 + k["octave"] * 31) % n_nodes)
+    na, nb = node(k_a), node(k_b)
+    flip = rng.random(len(nb)) < noise
+    nb[flip] = rng.integers(0, n_nodes, flip.sum())
+    return na, nb
+
+
+def test_search_by_bow(oracle, canvas1):
+    """M5 (ORBmatcher.cc:223-425 and 765-905) on synthetic feature vectors."""
+    import orb_slam3_amd as osa
+    ex, k0, d0, k1, d1 = _two_frames(canvas1)
+    rng = np.random.default_rng(31)
+    na, nb = _bow_nodes(rng, k0, k1, d0, d1)
+    fva, fvb = osa.FeatureVector.from_node_of_feature(na), osa.FeatureVector.from_node_of_feature(nb)
+    valid0 = (rng.random(len(k0)) < 0.7).astype(np.uint8)
+    valid1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+    for ratio, ori in ((0.7, True), (0.9, True), (0.75, False)):
+        on, om = oracle.search_by_bow_frame(d0, k0["angle"], valid0, fva, d1, k1["angle"], fvb, ratio, ori)
+        n, fm = osa.ORBmatcher(ratio, ori).SearchByBoWFrame(d0, k0["angle"], valid0, fva, d1, k1["angle"], fvb)
+        assert n == on and np.array_equal(fm, om), (ratio, n, on)
+        assert n > 50
+        on, om = oracle.search_by_bow_keyframes(d0, k0["angle"], valid0, fva, d1, k1["angle"], valid1, fvb, ratio, ori)
+        n, m12 = osa.ORBmatcher(ratio, ori).SearchByBoWKeyFrames(d0, k0["angle"], valid0, fva, d1, k1["angle"], valid1, fvb)
+        assert n == on and np.array_equal(m12, om), (ratio, n, on)
+        assert n > 30
+
+
+def test_search_for_triangulation(oracle, canvas1):
+    """M7 (ORBmatcher.cc:907-1146): later equal-distance candidate wins, lazily evaluated geometric predicate."""
+    import orb_slam3_amd as osa
+    ex, k0, d0, k1, d1 = _two_frames(canvas1)
+    rng = np.random.default_rng(41)
+    na, nb = _bow_nodes(rng, k0, k1, d0, d1, n_nodes=60)
+    fva, fvb = osa.FeatureVector.from_node_of_feature(na), osa.FeatureVector.from_node_of_feature(nb)
+    skip0 = (rng.random(len(k0)) < 0.4).astype(np.uint8)
+    skip1 = (rng.random(len(k1)) < 0.4).astype(np.uint8)
+    # inject exact duplicates in frame 1 so that distance ties occur inside a node ("later wins")
+    d1 = d1.copy()
+    for i in range(0, len(d1) - 1, 7):
+        if nb[i] == nb[i + 1]:
+            d1[i + 1] = d1[i]
+
+    def pair_ok(i, j):   # stand-in for the epipole gate + epipolarConstrain: a pure function of the pair
+        return abs((k0["y"][i] - 1.0) - k1["y"][j]) < 3.0 * (1 + k0["octave"][i])
+
+    for ori, pred in ((False, pair_ok), (True, pair_ok), (False, None)):
+        on, om = oracle.search_for_triangulation(d0, k0["angle"], skip0, fva, d1, k1["angle"], skip1, fvb, ori, pred)
+        n, m12 = osa.ORBmatcher(0.6, ori).SearchForTriangulation(d0, k0["angle"], skip0, fva, d1, k1["angle"], skip1, fvb, pred)
+        assert n == on and np.array_equal(m12, om), (ori, n, on)
+        assert n > 30

@@ -205,3 +205,70 @@ def test_grid_query_order_and_bounds(oracle):
     assert sorted(got) == [0, 1, 2, 3] and 4 not in got
     assert list(g.query(100.0, 100.0, 5.0, 1, 1)) == [1]
     assert len(g.query(-500.0, 100.0, 5.0)) == 0 and len(g.query(5000.0, 100.0, 5.0)) == 0
+
+
+class _FV:   # minimal FeatureVector (node ids ascending + CSR), product-independent
+    def __init__(self, node_of_feature):
+        node_of_feature = np.asarray(node_of_feature)
+        nodes = np.unique(node_of_feature)
+        lists = [np.nonzero(node_of_feature == nd)[0] for nd in nodes]
+        self.node_id = nodes.astype(np.uint32)
+        self.node_ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32)
+        self.index = np.concatenate(lists).astype(np.int32)
+
+
+def _desc_with_distance(base, k):
+    d = base.copy()
+    for b in range(k):
+        d[b // 8] ^= 1 << (b % 8)
+    return d
+
+
+def test_triangulation_later_equal_candidate_wins(oracle):
+    """Appendix A.6: SearchForTriangulation uses 'dist > bestDist -> continue', so the LAST equal candidate wins."""
+    base = np.zeros(32, np.uint8)
+    d1 = np.stack([base])
+    d2 = np.stack([_desc_with_distance(base, 10), _desc_with_distance(base, 10)[::-1].copy(), _desc_with_distance(base, 60)])
+    fv1, fv2 = _FV([5]), _FV([5, 5, 5])
+    z1, z3 = np.zeros(1, np.uint8), np.zeros(3, np.uint8)
+    n, m = oracle.search_for_triangulation(d1, np.zeros(1), z1, fv1, d2, np.zeros(3), z3, fv2, False, None)
+    assert n == 1 and m[0] == 1            # candidates 0 and 1 both at distance 10: the later one
+    n, m = oracle.search_for_triangulation(d1, np.zeros(1), z1, fv1, d2, np.zeros(3), z3, fv2, False, lambda i, j: j != 1)
+    assert m[0] == 0                       # the gate is evaluated lazily and a rejected candidate does not tighten bestDist
+    n, m = oracle.search_for_triangulation(d1, np.zeros(1), z1, fv1, d2[2:], np.zeros(1), z1, _FV([5]), False, None)
+    assert n == 0                          # 60 > TH_LOW
+
+
+def test_bow_thresholds_and_taken_mask(oracle):
+    base = np.zeros(32, np.uint8)
+    # KF-KF uses bestDist < 50 (strict), KF-Frame uses <= 50 (ORBmatcher.cc:848 vs :328)
+    d50 = _desc_with_distance(base, 50)
+    fv = _FV([3])
+    one = np.ones(1, np.uint8)
+    n, m = oracle.search_by_bow_frame(np.stack([base]), np.zeros(1), one, fv, np.stack([d50]), np.zeros(1), fv, 0.7, False)
+    assert n == 1 and m[0] == 0
+    n, m = oracle.search_by_bow_keyframes(np.stack([base]), np.zeros(1), one, fv, np.stack([d50]), np.zeros(1), one, fv, 0.7, False)
+    assert n == 0
+    # two KF features want the same frame feature: the first takes it, the second must settle for the other one
+    dA, dB = _desc_with_distance(base, 3), _desc_with_distance(base, 20)
+    kf = np.stack([base, base])
+    n, m = oracle.search_by_bow_frame(kf, np.zeros(2), np.ones(2, np.uint8), _FV([1, 1]), np.stack([dA, dB]), np.zeros(2), _FV([1, 1]), 0.7, False)
+    assert n == 2 and list(m) == [0, 1]    # q0: 3 < 0.7*20; q1: dA is taken -> best 20, second 256
+    n, m = oracle.search_by_bow_frame(kf, np.zeros(2), np.ones(2, np.uint8), _FV([1, 1]), np.stack([dA, dB]), np.zeros(2), _FV([1, 1]), 0.1, False)
+    assert n == 0                          # ratio test fails for both (nothing gets taken)
+
+
+def test_initialization_reassignment(oracle):
+    """SearchForInitialization: a later query with a smaller distance steals the match (ORBmatcher.cc:706-714)."""
+    base = np.zeros(32, np.uint8)
+    k1 = np.zeros(2, oracle.KP_DTYPE)
+    k1["x"], k1["y"] = [100, 102], [100, 100]
+    k2 = np.zeros(1, oracle.KP_DTYPE)
+    k2["x"], k2["y"] = 101, 100
+    d1 = np.stack([_desc_with_distance(base, 12), _desc_with_distance(base, 4)])
+    d2 = np.stack([base])
+    grid = oracle.OracleGrid(k2, 0.0, 752.0, 0.0, 480.0)
+    prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32))
+    n, m = oracle.search_for_initialization(k1, d1, grid, d2, prev, 100, 0.9, False)
+    assert n == 1 and list(m) == [-1, 0]
+    assert tuple(prev[1]) == (101.0, 100.0) and tuple(prev[0]) == (100.0, 100.0)
