@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -97,6 +98,91 @@ public:
             q.ur.empty() ? nullptr : q.ur.data(), q.octave.data(), q.angle.data(), q.descriptors.data(),
             q.hasObservations.empty() ? nullptr : q.hasObservations.data(), th, mode, mbCheckOrientation ? 1 : 0, vpMatch.data());
         if (r < 0) throw std::runtime_error(std::string("orbx_search_by_projection_frame: ") + orbx_status_string(r));
+        return r;
+    }
+
+    // SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+    // (ORBmatcher.cc:1889-2010) and SearchByProjection(KeyFrame*, Sim3f&, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF],
+    // th, ratioHamming) (ORBmatcher.cc:427-646) share this window form; the adapter projects and fills `q`.
+    struct WindowQueries {
+        std::vector<float> x, y, r, angle;
+        std::vector<int32_t> minLevel, maxLevel;
+        std::vector<uint8_t> descriptors;
+    };
+    int SearchByProjectionWindow(const FrameView &F, const std::vector<uint8_t> &occupied, const WindowQueries &q, float maxDist,
+                                 bool checkOrientation, std::vector<int32_t> &vpMatch) {
+        vpMatch.assign(F.N, -1);
+        orbx_frame_desc fd = F.c();
+        const int r = orbx_search_by_projection_window(m_, &fd, occupied.empty() ? nullptr : occupied.data(), (int)q.x.size(), q.x.data(),
+                                                       q.y.data(), q.r.data(), q.minLevel.data(), q.maxLevel.data(),
+                                                       q.angle.empty() ? nullptr : q.angle.data(), q.descriptors.data(), nullptr, maxDist,
+                                                       checkOrientation ? 1 : 0, vpMatch.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_search_by_projection_window: ") + orbx_status_string(r));
+        return r;
+    }
+
+    // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:648-763)
+    int SearchForInitialization(const orbx_keypoint *mvKeysUn1, const uint8_t *mDescriptors1, int N1, const FrameView &F2,
+                                std::vector<float> &vbPrevMatchedXY, std::vector<int> &vnMatches12, int windowSize = 10) {
+        vnMatches12.assign(N1, -1);
+        orbx_frame_desc fd = F2.c();
+        const int r = orbx_search_for_initialization(m_, mvKeysUn1, mDescriptors1, N1, &fd, vbPrevMatchedXY.data(), windowSize, mfNNratio,
+                                                     mbCheckOrientation ? 1 : 0, vnMatches12.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_search_for_initialization: ") + orbx_status_string(r));
+        return r;
+    }
+
+    // DBoW2::FeatureVector flattened by the adapter (iterate the std::map in order)
+    struct FeatVec {
+        std::vector<uint32_t> node_id;
+        std::vector<int32_t> node_ptr{0}, index;
+        template <class Map> static FeatVec from(const Map &fv) {  // Map = DBoW2::FeatureVector
+            FeatVec f;
+            for (const auto &kv : fv) {
+                f.node_id.push_back((uint32_t)kv.first);
+                for (unsigned int i : kv.second) f.index.push_back((int32_t)i);
+                f.node_ptr.push_back((int32_t)f.index.size());
+            }
+            return f;
+        }
+        orbx_featvec c() const { return orbx_featvec{node_id.data(), node_ptr.data(), index.data(), (int32_t)node_id.size()}; }
+    };
+
+    // SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:223-425): vpMatch[iF] = KF feature index or -1
+    int SearchByBoW(const uint8_t *descKF, const float *angleKF, const uint8_t *validKF, int nKF, const FeatVec &fvKF,
+                    const uint8_t *descF, const float *angleF, int nF, const FeatVec &fvF, std::vector<int32_t> &vpMatch) {
+        vpMatch.assign(nF, -1);
+        orbx_featvec a = fvKF.c(), b = fvF.c();
+        const int r = orbx_search_by_bow_frame(m_, descKF, angleKF, validKF, nKF, &a, descF, angleF, nF, &b, mfNNratio,
+                                               mbCheckOrientation ? 1 : 0, vpMatch.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_search_by_bow_frame: ") + orbx_status_string(r));
+        return r;
+    }
+    // SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:765-905): vpMatches12[i1] = i2 or -1
+    int SearchByBoW(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1, const FeatVec &fv1, const uint8_t *desc2,
+                    const float *angle2, const uint8_t *valid2, int n2, const FeatVec &fv2, std::vector<int32_t> &vpMatches12) {
+        vpMatches12.assign(n1, -1);
+        orbx_featvec a = fv1.c(), b = fv2.c();
+        const int r = orbx_search_by_bow_keyframes(m_, desc1, angle1, valid1, n1, &a, desc2, angle2, valid2, n2, &b, mfNNratio,
+                                                   mbCheckOrientation ? 1 : 0, vpMatches12.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_search_by_bow_keyframes: ") + orbx_status_string(r));
+        return r;
+    }
+    // SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (ORBmatcher.cc:907-1146).  `gate` is a callable
+    // bool(size_t idx1, size_t idx2) holding the reference's epipole-distance test and pCamera1->epipolarConstrain(...) (or
+    // `return true` for bCoarse) -- unchanged host float math.
+    template <class Gate>
+    int SearchForTriangulation(const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1, const FeatVec &fv1,
+                               const uint8_t *desc2, const float *angle2, const uint8_t *skip2, int n2, const FeatVec &fv2, Gate gate,
+                               std::vector<std::pair<size_t, size_t>> &vMatchedPairs) {
+        std::vector<int32_t> m12(n1, -1);
+        orbx_featvec a = fv1.c(), b = fv2.c();
+        auto thunk = [](void *user, int i1, int i2) -> int { return (*static_cast<Gate *>(user))((size_t)i1, (size_t)i2) ? 1 : 0; };
+        const int r = orbx_search_for_triangulation(m_, desc1, angle1, skip1, n1, &a, desc2, angle2, skip2, n2, &b,
+                                                    mbCheckOrientation ? 1 : 0, thunk, &gate, m12.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_search_for_triangulation: ") + orbx_status_string(r));
+        vMatchedPairs.clear();
+        for (int i = 0; i < n1; i++) if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);  // :1138-1143
         return r;
     }
 

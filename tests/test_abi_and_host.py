@@ -66,3 +66,12 @@ def test_synth_is_deterministic():
     assert np.array_equal(a, b) and a.shape == (240, 320) and a.dtype == np.uint8
     import hashlib
     assert a.std() > 20
+
+
+def test_cpp_adapters_compile():
+    """The C++ adapters (reference class surface over the C ABI) compile without OpenCV."""
+    import subprocess
+    src = '#include <map>\n#include "orb_slam3_amd/cpp/ORBextractor.h"\n#include "orb_slam3_amd/cpp/ORBmatcher.h"\nint main(){return 0;}\n'
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", str(ROOT), "-x", "c++", "-"], input=src, text=True,
+                       capture_output=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr

@@ -190,3 +190,40 @@ def test_device_introsort_replica_matches_libstdcxx():
             perm = np.zeros(n, np.int32)
             _lib.check(L.orbx_debug_sort_nodes(0, _lib.ptr(cnt), _lib.ptr(ulx), n, _lib.ptr(perm)), "sort")
             assert np.array_equal(perm, want), (n, variant)
+
+
+def test_cpp_adapter_end_to_end(canvas1, tmp_path):
+    """The C++ adapter classes (what ORB-SLAM3's Tracking thread would call) give the oracle's result."""
+    import hashlib
+    import subprocess
+    from pathlib import Path
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "adapter_demo"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", str(root / "tests/cpp/adapter_demo.cpp"), "-o", str(exe),
+                        str(root / "orb_slam3_amd/liborbx.so"), "-Wl,-rpath," + str(root / "orb_slam3_amd"), "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    img = synth.frame_from_canvas(canvas1, 2, 752, 480, 1002)
+    pgm = tmp_path / "f.pgm"
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n752 480\n255\n")
+        f.write(img.tobytes())
+    out = subprocess.run([str(exe), str(pgm)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = out.stdout.splitlines()
+
+    def fnv(b):
+        h = 1469598103934665603
+        for x in b:
+            h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    oex = ob.OracleExtractor(1000, 1.2, 8, 20, 7)
+    mono, kps, desc = oex.extract(img, lap=(0, 1000))
+    want = f"mono {mono} n {len(kps)} kps {fnv(kps.tobytes()):016x} desc {fnv(desc.tobytes()):016x} levels 8 scale 1.200000"
+    assert line[0] == want, (line[0], want)
+    lvl = oex.level_padded(3)
+    assert line[1] == f"level3 {lvl.shape[1] - 38}x{lvl.shape[0] - 38} {fnv(lvl.tobytes()):016x}"
+    nm, self_ = int(line[2].split()[1]), int(line[2].split()[3])
+    assert nm > 900 and self_ == nm   # every feature matches itself at distance 0 (first minimum), none is lost to the filter
