@@ -227,3 +227,53 @@ def test_cpp_adapter_end_to_end(canvas1, tmp_path):
     assert line[1] == f"level3 {lvl.shape[1] - 38}x{lvl.shape[0] - 38} {fnv(lvl.tobytes()):016x}"
     nm, self_ = int(line[2].split()[1]), int(line[2].split()[3])
     assert nm > 900 and self_ == nm   # every feature matches itself at distance 0 (first minimum), none is lost to the filter
+
+
+@pytest.mark.parametrize("w,h,nf,scale,nlevels,ini,mn", [
+    (641, 479, 300, 1.2, 8, 20, 7),      # odd sizes, non-multiple-of-4 rows
+    (752, 480, 1000, 1.5, 5, 20, 7),     # coarser pyramid
+    (800, 600, 1500, 1.1, 10, 15, 5),    # fine pyramid, other thresholds
+    (320, 240, 200, 1.2, 4, 40, 12),     # small image, high thresholds
+    (1280, 720, 3000, 1.3, 6, 20, 7),    # HD frame, > 2048 candidates on level 0 (quad-tree key buffers spill to global)
+    (1226, 370, 2000, 1.2, 8, 12, 7),    # KITTI 04-12 shape
+])
+def test_parameter_sweep(w, h, nf, scale, nlevels, ini, mn):
+    """Other ORBextractor parameter sets (Settings.cc:443-451) stay bit-exact."""
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    canvas = synth.make_canvas(w + h, size=2048 if max(w, h) <= 1024 else 2 * max(w, h), n_shapes=2400 if max(w, h) <= 1024 else 5000)
+    img = synth.frame_from_canvas(canvas, 3, w, h, 99)
+    ex = osa.ORBextractor(nf, scale, nlevels, ini, mn)
+    oex = ob.OracleExtractor(nf, scale, nlevels, ini, mn, flags=ob.FLAG_DESC_FMA)
+    for lap in ((0, 0), (0, 1000)):
+        mono, kps, desc = ex(img, None, lap)
+        omono, okps, odesc = oex.extract(img, lap=lap)
+        assert mono == omono and len(kps) == len(okps)
+        for l in range(nlevels):
+            got, want = ex.debug_candidates(l), oex.level_candidates(l)
+            assert len(got) == len(want), (l, len(got), len(want))
+            got, want = ex.debug_level_keypoints(l), oex.level_keypoints(l)
+            assert len(got) == len(want) and np.array_equal(got["x"], want["x"]) and np.array_equal(got["y"], want["y"]), l
+        assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+    assert len(kps) > nf // 2
+
+
+def test_reconfigure_between_shapes(canvas1):
+    """One extractor instance used on changing image sizes / batch sizes (workspace reconfiguration)."""
+    import torch
+    from orb_slam3_amd import synth
+    ex, oex = _pair(1000)
+    for (w, h) in ((752, 480), (640, 480), (752, 480), (1024, 768)):
+        img = synth.frame_from_canvas(canvas1, 5, w, h, 555)
+        mono, kps, desc = ex(img, None, (0, 1000))
+        omono, okps, odesc = oex.extract(img, lap=(0, 1000))
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (w, h)
+    frames = np.stack([synth.frame_from_canvas(canvas1, t, 640, 480, 600 + t) for t in range(9)])
+    d = torch.from_numpy(frames).cuda()
+    for nb in (2, 9, 3):
+        ex.extract_batch_device(d.data_ptr(), nb, 640, 480, 640, 640 * 480, (0, 0))
+        for t in (0, nb - 1):
+            mono, kps, desc = ex.download(t)
+            omono, okps, odesc = oex.extract(frames[t], lap=(0, 0))
+            assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (nb, t)
