@@ -131,14 +131,13 @@ def main():
                           hs.match.data_ptr(), hs.nm.data_ptr())
 
     def run(nsteps):
-        """nsteps pipelined steps; returns the number of features delivered to the host."""
+        """nsteps pipelined steps (two batches in flight); returns the number of features delivered to the host."""
         feats = 0
-        for i in range(nsteps):
-            if i > 0:
-                ex.download_wait()        # results of step i-1 are on the host ...
-                # (the next enqueue below waits on-device for that copy before overwriting the outputs)
-                feats += int(host[(i - 1) % 2].cnt.sum())
-            enqueue(i)
+        enqueue(0)
+        for i in range(1, nsteps):
+            enqueue(i)                    # batch i is queued behind batch i-1 on the device ...
+            ex.download_wait()            # ... while the host waits for the results of batch i-1
+            feats += int(host[(i - 1) % 2].cnt.sum())
         ex.download_wait()
         feats += int(host[(nsteps - 1) % 2].cnt.sum())
         return feats

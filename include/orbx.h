@@ -117,8 +117,9 @@ int orbx_output_capacity(orbx_extractor *ex, int width, int height);
 /* Asynchronous form: the D2H copies run on the extractor's copy stream behind the kernels of the last batch and
  * overlap the kernels of the NEXT batch (which wait for the copy before overwriting the device outputs).
  * Host buffers should be pinned.  match / nmatches (optional) receive the internal results of
- * orbx_match_consecutive_device(..., NULL, NULL): [n_frames][cap] / [n_frames].  orbx_download_wait blocks until
- * the copies have landed and reports device-side errors. */
+ * orbx_match_consecutive_device(..., NULL, NULL): [n_frames][cap] / [n_frames].  Up to TWO downloads may be in flight
+ * (enqueue batch i+1 before waiting for batch i, so that the matcher of batch i overlaps the pyramid / FAST of batch
+ * i+1); orbx_download_wait blocks until the OLDEST one has landed and reports device-side errors. */
 int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *keypoints, uint8_t *descriptors, int32_t *counts,
                               int32_t *mono_index, int32_t *match, int32_t *nmatches);
 int orbx_download_wait(orbx_extractor *ex);

@@ -73,9 +73,16 @@ struct orbx_extractor {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // asynchronous result download (copy stream overlaps the next batch's kernels)
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_compute_done = nullptr, ev_copy_done = nullptr;
-    bool copy_pending = false;
-    int32_t *h_err = nullptr;  // pinned
+    // concurrent branches of one batch: blur runs beside FAST/quad-tree (aux), the frame-to-frame matcher of batch i
+    // runs beside the pyramid/FAST/quad-tree of batch i+1 (match)
+    hipStream_t aux_stream = nullptr, match_stream = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
+    bool match_pending = false;
+    hipEvent_t ev_compute_done = nullptr;
+    hipEvent_t ev_copy_done[2] = {nullptr, nullptr};  // ring: up to two downloads in flight
+    unsigned copy_issued = 0, copy_waited = 0;         // copy_issued - copy_waited = downloads in flight
+    bool copy_pending = false;                         // a download was issued since the last (re)configuration
+    int32_t *h_err = nullptr;  // pinned, 2 slots
     DevBuf d_match, d_nmatch;  // internal frame-to-frame match outputs [B][cap], [B]
     // cached problem descriptors of orbx_match_consecutive_device
     struct MatchKey { int n = 0, cap = 0; const void *match = nullptr, *nm = nullptr; float th = 0, du = 0, dv = 0; int ori = 0; const void *kps = nullptr; } mkey;

@@ -139,8 +139,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
 
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
-    if (ex->copy_stream) ORBX_HIP(hipStreamSynchronize(ex->copy_stream));
-    ex->copy_pending = false;
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
+    ex->copy_pending = false; ex->match_pending = false; ex->copy_issued = ex->copy_waited = 0;
     ex->mkey = orbx_extractor::MatchKey();
     const int B = std::max(batch, ex->batch_cap);
     int r;
@@ -220,11 +220,18 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const ResizeTap *)ex->d_ytab.p, pyr, ex->pyr_frame);
     }
     {
+        // blur depends only on the pyramid and is needed only by k_describe: run it beside FAST / quad-tree
+        hipStream_t bs = ex->profile ? st : ex->aux_stream;
+        if (!ex->profile) {
+            ORBX_HIP(hipEventRecord(ex->ev_pyr, st));
+            ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
+        }
         ProfScope ps(ex, K_BLUR);
         static const int kNew[4] = {18, 34, 48, 56}, kOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
         const int *g = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kOld : kNew;
-        hipLaunchKernelGGL(k_blur, dim3(ex->n_blur_tiles, n), dim3(256), 0, st, d_lv, (const TileRef *)ex->d_blur_tiles.p,
+        hipLaunchKernelGGL(k_blur, dim3(ex->n_blur_tiles, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p,
                            (const uint8_t *)pyr, ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, g[0], g[1], g[2], g[3]);
+        if (!ex->profile) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
     }
     {
         ProfScope ps(ex, K_FAST);
@@ -243,7 +250,10 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p, ex->max_pool);
     }
     if (ex->copy_pending) {  // outputs of the previous batch may still be in flight to the host
-        ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done, 0));
+        ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done[(ex->copy_issued - 1) & 1], 0));  // the most recent download
+    }
+    if (ex->match_pending) {  // the previous batch's matcher still reads its counts / keypoints / descriptors
+        ORBX_HIP(hipStreamWaitEvent(st, ex->ev_match, 0));
     }
     {
         ProfScope ps(ex, K_FINALIZE);
@@ -251,6 +261,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const int32_t *)ex->d_lvlcnt.p, (WorkItem *)ex->d_work.p, ex->cap, (int32_t *)ex->d_count.p,
                            (int32_t *)ex->d_mono.p, lap0, lap1, (int32_t *)ex->d_err.p);
     }
+    if (!ex->profile) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
     {
         ProfScope ps(ex, K_DESCRIBE);
         hipLaunchKernelGGL(k_describe, dim3((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
@@ -258,6 +269,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            ex->pyr_frame, (const uint8_t *)ex->d_blur.p, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
                            (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0);
     }
+    ORBX_HIP(hipEventRecord(ex->ev_describe, st));
     ORBX_HIP(hipGetLastError());
     ex->last_batch = n;
     return ORBX_OK;
@@ -350,10 +362,14 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipEventCreate(&ex->ev0);
     (void)hipEventCreate(&ex->ev1);
     (void)hipStreamCreateWithFlags(&ex->copy_stream, hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&ex->aux_stream, hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&ex->match_stream, hipStreamNonBlocking);
+    for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&ex->ev_copy_done, hipEventDisableTiming);
-    (void)hipHostMalloc((void **)&ex->h_err, sizeof(int32_t), hipHostMallocDefault);
-    if (ex->h_err) *ex->h_err = 0;
+    (void)hipEventCreateWithFlags(&ex->ev_copy_done[0], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ex->ev_copy_done[1], hipEventDisableTiming);
+    (void)hipHostMalloc((void **)&ex->h_err, 2 * sizeof(int32_t), hipHostMallocDefault);
+    if (ex->h_err) { ex->h_err[0] = 0; ex->h_err[1] = 0; }
     // descriptor constants: orientation disc offsets + BRIEF pattern
     DescConst dc;
     memset(&dc, 0, sizeof(dc));
@@ -379,9 +395,11 @@ void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    if (ex->copy_stream) { (void)hipStreamSynchronize(ex->copy_stream); (void)hipStreamDestroy(ex->copy_stream); }
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream})
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
     if (ex->ev_compute_done) (void)hipEventDestroy(ex->ev_compute_done);
-    if (ex->ev_copy_done) (void)hipEventDestroy(ex->ev_copy_done);
+    for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
     if (ex->h_err) (void)hipHostFree(ex->h_err);
     ex->d_match.release(); ex->d_nmatch.release();
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
@@ -419,6 +437,8 @@ int orbx_sync(orbx_extractor *ex) {
     if (!ex) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->aux_stream));
+    ORBX_HIP(hipStreamSynchronize(ex->match_stream));
     return ORBX_OK;
 }
 
@@ -467,31 +487,38 @@ int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *des
 int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts, int32_t *mono,
                               int32_t *match, int32_t *nmatches) {
     if (!ex || ex->last_batch <= 0) return ORBX_E_BAD_ARG;
+    if (ex->copy_issued - ex->copy_waited >= 2) { set_error("two downloads already in flight: call orbx_download_wait first"); return ORBX_E_BAD_ARG; }
     ORBX_HIP(hipSetDevice(ex->device));
     const int n = ex->last_batch;
     hipStream_t cs = ex->copy_stream;
     ORBX_HIP(hipEventRecord(ex->ev_compute_done, ex->stream));
     ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_compute_done, 0));
+    if (ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
     if (counts) ORBX_HIP(hipMemcpyAsync(counts, ex->d_count.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     if (mono) ORBX_HIP(hipMemcpyAsync(mono, ex->d_mono.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (match && ex->d_match.p) ORBX_HIP(hipMemcpyAsync(match, ex->d_match.p, 4 * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (nmatches && ex->d_nmatch.p) ORBX_HIP(hipMemcpyAsync(nmatches, ex->d_nmatch.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
-    ORBX_HIP(hipMemcpyAsync(ex->h_err, ex->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, cs));
-    ORBX_HIP(hipEventRecord(ex->ev_copy_done, cs));
+    const unsigned slot = ex->copy_issued & 1;
+    ORBX_HIP(hipMemcpyAsync(ex->h_err + slot, ex->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, cs));
+    ORBX_HIP(hipEventRecord(ex->ev_copy_done[slot], cs));
+    ex->copy_issued++;
     ex->copy_pending = true;
     return ORBX_OK;
 }
 
+// Waits for the OLDEST download still in flight (at most two are).
 int orbx_download_wait(orbx_extractor *ex) {
     if (!ex) return ORBX_E_BAD_ARG;
-    if (!ex->copy_pending) return ORBX_OK;
+    if (ex->copy_issued == ex->copy_waited) return ORBX_OK;
     ORBX_HIP(hipSetDevice(ex->device));
-    ORBX_HIP(hipEventSynchronize(ex->ev_copy_done));
-    if (*ex->h_err != 0) {
-        set_error("device-side consistency check failed, code " + std::to_string(*ex->h_err));
-        *ex->h_err = 0;
+    const unsigned slot = ex->copy_waited & 1;
+    ORBX_HIP(hipEventSynchronize(ex->ev_copy_done[slot]));
+    ex->copy_waited++;
+    if (ex->h_err[slot] != 0) {
+        set_error("device-side consistency check failed, code " + std::to_string(ex->h_err[slot]));
+        ex->h_err[slot] = 0;
         (void)hipMemsetAsync(ex->d_err.p, 0, sizeof(int32_t), ex->stream);
         return ORBX_E_INTERNAL;
     }

@@ -736,25 +736,30 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     g.minx = 0.f; g.miny = 0.f;  // undistorted bounds of a distortion-free camera: mnMinX = 0, mnMaxX = cols (Frame.cc:804-807)
     g.inv_w = 64.0f / ((float)ex->width - 0.f);
     g.inv_h = 48.0f / ((float)ex->height - 0.f);
+    // the matcher of batch i runs on its own stream beside the pyramid / FAST / quad-tree of batch i+1
+    hipStream_t ms = ex->profile ? ex->stream : ex->match_stream;
+    if (!ex->profile) ORBX_HIP(hipStreamWaitEvent(ms, ex->ev_describe, 0));
     hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
-    if (ex->profile) (void)hipEventRecord(e0, ex->stream);
-    hipLaunchKernelGGL(k_grid_build, dim3(np), dim3(64), 0, ex->stream, (const WindowProblem *)ex->d_mprobs.p, g);
-    hipLaunchKernelGGL(k_window_best2, dim3((cap + 15) / 16, np), dim3(256), 0, ex->stream, (const WindowProblem *)ex->d_mprobs.p, g);
+    if (ex->profile) (void)hipEventRecord(e0, ms);
+    hipLaunchKernelGGL(k_grid_build, dim3(np), dim3(64), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
+    hipLaunchKernelGGL(k_window_best2, dim3((cap + 15) / 16, np), dim3(256), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
     if (ex->profile) {
-        (void)hipEventRecord(e1, ex->stream); (void)hipEventSynchronize(e1);
-        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-        ex->prof_ms[K_MATCH_SCAN] += ms; ex->prof_n[K_MATCH_SCAN]++;
-        (void)hipEventRecord(e0, ex->stream);
+        (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
+        float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+        ex->prof_ms[K_MATCH_SCAN] += t; ex->prof_n[K_MATCH_SCAN]++;
+        (void)hipEventRecord(e0, ms);
     }
     if (resolve_lds_bytes(cap) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), resolve_lds_bytes(cap), ex->stream, (const WindowProblem *)ex->d_mprobs.p,
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mprobs.p,
                        (const ResolveProblem *)ex->d_mres.p, g, cap);
     if (ex->profile) {
-        (void)hipEventRecord(e1, ex->stream); (void)hipEventSynchronize(e1);
-        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-        ex->prof_ms[K_MATCH_RESOLVE] += ms; ex->prof_n[K_MATCH_RESOLVE]++;
+        (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
+        float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+        ex->prof_ms[K_MATCH_RESOLVE] += t; ex->prof_n[K_MATCH_RESOLVE]++;
     }
+    ORBX_HIP(hipEventRecord(ex->ev_match, ms));
+    ex->match_pending = true;
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
