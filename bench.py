@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="frames per step (per GPU)")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="extractor instances alternated over consecutive batches (each has its own streams and workspace)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +110,9 @@ def main():
     frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * (10 + rank) + t) for t in range(B)])
     d_frames = torch.from_numpy(frames).cuda()
 
-    ex = osa.ORBextractor(NFEATURES, 1.2, NLEVELS, 20, 7, device=local_rank)
+    exs = [osa.ORBextractor(NFEATURES, 1.2, NLEVELS, 20, 7, device=local_rank) for _ in range(max(1, args.lanes))]
+    ex = exs[0]
+    NL = len(exs)
     cap = ex.output_capacity(W, H)
     # pinned host destinations (the Tracking thread's buffers), double-buffered: the D2H of step i overlaps the
     # kernels of step i+1 (copy stream inside liborbx); a step is complete when its results are on the host
@@ -121,25 +124,27 @@ def main():
             self.mono = torch.zeros(B, dtype=torch.int32).pin_memory()
             self.match = torch.empty((B, cap), dtype=torch.int32).pin_memory()
             self.nm = torch.zeros(B, dtype=torch.int32).pin_memory()
-    host = [HostSet(), HostSet()]
+    host = [HostSet() for _ in range(2 * NL)]
 
     def enqueue(i):
-        hs = host[i % 2]
-        ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, (0, 1000))
-        ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
-        ex.download_async(hs.kps.data_ptr(), hs.desc.data_ptr(), hs.cnt.data_ptr(), hs.mono.data_ptr(),
-                          hs.match.data_ptr(), hs.nm.data_ptr())
+        e, hs = exs[i % NL], host[i % (2 * NL)]
+        e.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, (0, 1000))
+        e.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        e.download_async(hs.kps.data_ptr(), hs.desc.data_ptr(), hs.cnt.data_ptr(), hs.mono.data_ptr(),
+                         hs.match.data_ptr(), hs.nm.data_ptr())
 
     def run(nsteps):
-        """nsteps pipelined steps (two batches in flight); returns the number of features delivered to the host."""
+        """nsteps pipelined steps (two batches in flight per extractor lane, lanes alternate over consecutive batches);
+        returns the number of features delivered to the host."""
         feats = 0
-        enqueue(0)
-        for i in range(1, nsteps):
-            enqueue(i)                    # batch i is queued behind batch i-1 on the device ...
-            ex.download_wait()            # ... while the host waits for the results of batch i-1
-            feats += int(host[(i - 1) % 2].cnt.sum())
-        ex.download_wait()
-        feats += int(host[(nsteps - 1) % 2].cnt.sum())
+        depth = 2 * NL
+        for i in range(nsteps + depth - 1):
+            if i < nsteps:
+                enqueue(i)
+            j = i - (depth - 1)           # oldest batch still in flight
+            if j >= 0:
+                exs[j % NL].download_wait()
+                feats += int(host[j % (2 * NL)].cnt.sum())
         return feats
 
     def step():   # un-pipelined single step (profiling passes)
@@ -147,7 +152,8 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        ex.sync()
+        for e in exs:
+            e.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -158,8 +164,8 @@ def main():
     feats = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    nmatch = int(host[(args.steps - 1) % 2].nm[1:].sum())
-    h_cnt = host[(args.steps - 1) % 2].cnt
+    nmatch = int(host[(args.steps - 1) % (2 * NL)].nm[1:].sum())
+    h_cnt = host[(args.steps - 1) % (2 * NL)].cnt
 
     from orb_slam3_amd import sharding
     dt_max, feats_all = sharding.reduce_throughput(dt, feats, device="cuda")
@@ -213,7 +219,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "EuRoC-shaped 752x480 mono, nFeatures=1000, 8 levels, scale 1.2, FAST 20/7: extract + "
                                    "frame-to-frame SearchByProjection(th=15) + D2H of results",
-                       "frames_per_step_per_gpu": B, "sequences": world, "features_per_frame": round(feats / args.steps / B, 1),
+                       "frames_per_step_per_gpu": B, "sequences": world, "extractor_lanes_per_gpu": NL, "features_per_frame": round(feats / args.steps / B, 1),
                        "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{world} independent sequences"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

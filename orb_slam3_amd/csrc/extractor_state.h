@@ -78,6 +78,7 @@ struct orbx_extractor {
     hipStream_t aux_stream = nullptr, match_stream = nullptr;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
     bool match_pending = false;
+    bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream
     hipEvent_t ev_compute_done = nullptr;
     hipEvent_t ev_copy_done[2] = {nullptr, nullptr};  // ring: up to two downloads in flight
     unsigned copy_issued = 0, copy_waited = 0;         // copy_issued - copy_waited = downloads in flight

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -221,8 +222,9 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     }
     {
         // blur depends only on the pyramid and is needed only by k_describe: run it beside FAST / quad-tree
-        hipStream_t bs = ex->profile ? st : ex->aux_stream;
-        if (!ex->profile) {
+        const bool side = !ex->profile && ex->side_streams;
+        hipStream_t bs = side ? ex->aux_stream : st;
+        if (side) {
             ORBX_HIP(hipEventRecord(ex->ev_pyr, st));
             ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
         }
@@ -231,7 +233,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         const int *g = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kOld : kNew;
         hipLaunchKernelGGL(k_blur, dim3(ex->n_blur_tiles, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p,
                            (const uint8_t *)pyr, ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, g[0], g[1], g[2], g[3]);
-        if (!ex->profile) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
+        if (side) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
     }
     {
         ProfScope ps(ex, K_FAST);
@@ -261,7 +263,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const int32_t *)ex->d_lvlcnt.p, (WorkItem *)ex->d_work.p, ex->cap, (int32_t *)ex->d_count.p,
                            (int32_t *)ex->d_mono.p, lap0, lap1, (int32_t *)ex->d_err.p);
     }
-    if (!ex->profile) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
+    if (!ex->profile && ex->side_streams) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
     {
         ProfScope ps(ex, K_DESCRIBE);
         hipLaunchKernelGGL(k_describe, dim3((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
@@ -362,6 +364,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipEventCreate(&ex->ev0);
     (void)hipEventCreate(&ex->ev1);
     (void)hipStreamCreateWithFlags(&ex->copy_stream, hipStreamNonBlocking);
+    { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
     (void)hipStreamCreateWithFlags(&ex->aux_stream, hipStreamNonBlocking);
     (void)hipStreamCreateWithFlags(&ex->match_stream, hipStreamNonBlocking);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);

@@ -737,8 +737,9 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     g.inv_w = 64.0f / ((float)ex->width - 0.f);
     g.inv_h = 48.0f / ((float)ex->height - 0.f);
     // the matcher of batch i runs on its own stream beside the pyramid / FAST / quad-tree of batch i+1
-    hipStream_t ms = ex->profile ? ex->stream : ex->match_stream;
-    if (!ex->profile) ORBX_HIP(hipStreamWaitEvent(ms, ex->ev_describe, 0));
+    const bool side = !ex->profile && ex->side_streams;
+    hipStream_t ms = side ? ex->match_stream : ex->stream;
+    if (side) ORBX_HIP(hipStreamWaitEvent(ms, ex->ev_describe, 0));
     hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
     if (ex->profile) (void)hipEventRecord(e0, ms);
     hipLaunchKernelGGL(k_grid_build, dim3(np), dim3(64), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
