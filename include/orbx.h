@@ -293,6 +293,13 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
 int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                   int32_t *d_match, int32_t *d_nmatches);
 
+/* Frame::ComputeStereoMatches (Frame.cc:811-981) for every frame of two resident batches: `left` and `right` must have
+ * extracted batches of the same size and image shape (rectified stereo, lapping {0,0}).  Row-band Hamming match, 11x11
+ * SAD sub-pixel refinement on the device-resident pyramids and the median outlier rejection all run on the device, on
+ * the left extractor's stream.  Results (mvuRight, mvDepth; -1 = no match) per frame via orbx_stereo_batch_download. */
+int orbx_stereo_batch_device(orbx_extractor *left, orbx_extractor *right, float bf, float b);
+int orbx_stereo_batch_download(orbx_extractor *left, int frame, float *u_right, float *depth, int *n_left, int *n_matches);
+
 const char *orbx_last_error(void);
 const char *orbx_status_string(int status);
 

@@ -84,6 +84,7 @@ struct orbx_extractor {
     unsigned copy_issued = 0, copy_waited = 0;         // copy_issued - copy_waited = downloads in flight
     bool copy_pending = false;                         // a download was issued since the last (re)configuration
     int32_t *h_err = nullptr;  // pinned, 2 slots
+    DevBuf d_st_bidx, d_st_bdist, d_st_ur, d_st_depth, d_st_sad, d_st_nm, d_st_scales;  // device stereo matcher (left extractor)
     DevBuf d_match, d_nmatch;  // internal frame-to-frame match outputs [B][cap], [B]
     // cached problem descriptors of orbx_match_consecutive_device
     struct MatchKey { int n = 0, cap = 0; const void *match = nullptr, *nm = nullptr; float th = 0, du = 0, dv = 0; int ori = 0; const void *kps = nullptr; } mkey;

@@ -175,6 +175,193 @@ __global__ __launch_bounds__(256) void k_stereo_rowband(const orbx_keypoint *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches fully on the device for a batch of rectified stereo frames whose left / right
+// extractions are resident (keypoints, descriptors, padded pyramids).
+//   k_stereo_rowband_batch : Hamming stage (:849-894), one wave per left keypoint
+//   k_stereo_sad           : 11x11 SAD over 11 shifts on the keypoint's pyramid level, parabola sub-pixel fit,
+//                            disparity -> depth (:896-964), one wave per left keypoint
+//   k_stereo_reject        : median of the SAD distances per frame by a 2-pass LDS radix select, then removal of
+//                            matches with distance >= 1.5*1.4*median (:966-980), one workgroup per frame
+// ---------------------------------------------------------------------------------------------------------
+struct StereoBatch {
+    const orbx_keypoint *kl, *kr;      // [B][capL], [B][capR]
+    const uint8_t *dl, *dr;            // [B][cap][32]
+    const int32_t *nl, *nr;            // [B]
+    int capL, capR;
+    const uint8_t *pyrL, *pyrR;        // pyramid slabs of the two extractors
+    size_t pyr_frame_L, pyr_frame_R;
+    const LevelInfo *lvL, *lvR;        // level tables (identical geometry)
+    const float *scale, *inv_scale;    // mvScaleFactors / mvInvScaleFactors
+    int n_rows;                        // mvImagePyramid[0].rows
+    float bf, b;
+    int32_t *best_idx, *best_dist;     // [B][capL] Hamming stage result
+    float *u_right, *depth;            // [B][capL] outputs (-1 = none)
+    int32_t *sad;                      // [B][capL] SAD distance of accepted matches, -1 otherwise
+    int32_t *nmatches;                 // [B]
+};
+
+__global__ __launch_bounds__(256) void k_stereo_rowband_batch(StereoBatch S) {
+    const int f = blockIdx.y;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nl = S.nl[f], nr = S.nr[f];
+    if (iL >= nl) return;
+    const orbx_keypoint *kr = S.kr + (size_t)f * S.capR;
+    const uint8_t *dr = S.dr + (size_t)f * S.capR * 32;
+    const orbx_keypoint kpL = S.kl[(size_t)f * S.capL + iL];
+    const float minD = 0.f, maxD = S.bf / S.b;  // :841-843 (minZ = mb)
+    const int row = (int)kpL.y;
+    const float minU = kpL.x - maxD, maxU = kpL.x - minD;
+    u64 best = kNoKey;
+    if (!(maxU < 0) && row >= 0 && row < S.n_rows) {
+        const Desc dq = load_desc(S.dl + ((size_t)f * S.capL + iL) * 32);
+        for (int iR = lane; iR < nr; iR += 64) {
+            const orbx_keypoint kpR = kr[iR];
+            const float r = 2.0f * S.scale[kpR.octave];
+            const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+            if (row < minr || row > maxr) continue;
+            if (kpR.octave < kpL.octave - 1 || kpR.octave > kpL.octave + 1) continue;
+            if (kpR.x >= minU && kpR.x <= maxU) {
+                const int d = hamming(dq, load_desc(dr + (size_t)iR * 32));
+                const u64 k = ((u64)d << 32) | (u64)(uint32_t)iR;
+                best = k < best ? k : best;
+            }
+        }
+    }
+    best = wave_min1(best);
+    if (lane == 0) {
+        const int d = best == kNoKey ? 256 : (int)(best >> 32);
+        const size_t o = (size_t)f * S.capL + iL;
+        if (d < ORBX_TH_HIGH) { S.best_idx[o] = (int32_t)(best & 0xffffffffu); S.best_dist[o] = d; }
+        else { S.best_idx[o] = -1; S.best_dist[o] = ORBX_TH_HIGH; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stereo_sad(StereoBatch S) {
+    const int f = blockIdx.y;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (iL >= S.nl[f]) return;
+    const size_t o = (size_t)f * S.capL + iL;
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_sad = -1;
+    const int bidx = S.best_idx[o];
+    const int thOrbDist = (ORBX_TH_HIGH + ORBX_TH_LOW) / 2;
+    if (bidx >= 0 && S.best_dist[o] < thOrbDist) {  // wave-uniform
+        const orbx_keypoint kpL = S.kl[o];
+        const float uL = kpL.x;
+        const float uR0 = S.kr[(size_t)f * S.capR + bidx].x;
+        const int lvl = kpL.octave;
+        const float sf = S.inv_scale[lvl];
+        const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf)), scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const LevelInfo LL = S.lvL[lvl], LR = S.lvR[lvl];
+        const int w = 5, Lh = 5;
+        const float iniu = scaleduR0 + Lh - w, endu = scaleduR0 + Lh + w + 1;
+        if (!(iniu < 0 || endu >= (float)LR.w)) {
+            const uint8_t *IL = S.pyrL + (size_t)f * S.pyr_frame_L + LL.off + (size_t)(kEdge + (int)(scaledvL - w)) * LL.pitch + kRoiX + (int)(scaleduL - w);
+            const uint8_t *IR = S.pyrR + (size_t)f * S.pyr_frame_R + LR.off + (size_t)(kEdge + (int)(scaledvL - w)) * LR.pitch + kRoiX + (int)(scaleduR0 - w);
+            int sums[11];
+#pragma unroll
+            for (int k = 0; k < 11; k++) sums[k] = 0;
+            for (int p = lane; p < 121; p += 64) {
+                const int yy = p / 11, xx = p - yy * 11;
+                const int a = IL[(size_t)yy * LL.pitch + xx];
+                const uint8_t *rr = IR + (size_t)yy * LR.pitch + xx;
+#pragma unroll
+                for (int k = 0; k < 11; k++) sums[k] += abs(a - (int)rr[k - 5]);
+            }
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) sums[k] += __shfl_xor(sums[k], s);
+            }
+            int bestDist = 0x7fffffff, bestinc = 0;
+#pragma unroll
+            for (int k = 0; k < 11; k++)
+                if ((float)sums[k] < (float)bestDist) { bestDist = sums[k]; bestinc = k - 5; }  // :926 (float dist vs int best)
+            if (!(bestinc == -Lh || bestinc == Lh)) {
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int k = 1; k < 10; k++)
+                    if (k - 5 == bestinc) { d1 = (float)sums[k - 1]; d2 = (float)sums[k]; d3 = (float)sums[k + 1]; }
+                // :944  deltaR = (dist1-dist3)/(2.0f*(dist1+dist3-2.0f*dist2))
+                const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
+                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), den);
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(S.scale[lvl], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));  // :950
+                    float disparity = __fsub_rn(uL, bestuR);
+                    const float minD = 0.f, maxD = S.bf / S.b;
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }  // :956-959
+                        out_d = __fdiv_rn(S.bf, disparity);
+                        out_u = bestuR;
+                        out_sad = bestDist;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { S.u_right[o] = out_u; S.depth[o] = out_d; S.sad[o] = out_sad; }
+}
+
+// one workgroup per frame: median SAD distance (element size/2 of the ascending order, :967-968) via radix select,
+// then reject distances >= 1.5f*1.4f*median (:969-980)
+__global__ __launch_bounds__(256) void k_stereo_reject(StereoBatch S) {
+    __shared__ int hist[256];
+    __shared__ int sh_sel, sh_rank, sh_count;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int nl = S.nl[f];
+    const size_t base = (size_t)f * S.capL;
+    // count accepted matches
+    int c = 0;
+    for (int i = tid; i < nl; i += 256) c += (S.sad[base + i] >= 0);
+    if (tid == 0) sh_count = 0;
+    __syncthreads();
+    atomicAdd(&sh_count, c);
+    __syncthreads();
+    const int M = sh_count;
+    if (M == 0) { if (tid == 0) S.nmatches[f] = 0; return; }
+    int k = M / 2;  // rank of the median in ascending order
+    // pass 1: high byte (SAD <= 121*255 < 2^15), pass 2: low byte
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 256) { const int v = S.sad[base + i]; if (v >= 0) atomicAdd(&hist[(v >> 8) & 0xff], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (b = 0; b < 256; b++) { if (acc + hist[b] > k) break; acc += hist[b]; }
+        sh_sel = b; sh_rank = k - acc;
+    }
+    __syncthreads();
+    const int hi = sh_sel;
+    k = sh_rank;
+    __syncthreads();
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 256) { const int v = S.sad[base + i]; if (v >= 0 && ((v >> 8) & 0xff) == hi) atomicAdd(&hist[v & 0xff], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (b = 0; b < 256; b++) { if (acc + hist[b] > k) break; acc += hist[b]; }
+        sh_sel = (hi << 8) | b;
+    }
+    __syncthreads();
+    const float median = (float)sh_sel;
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    int kept = 0;
+    for (int i = tid; i < nl; i += 256) {
+        const int v = S.sad[base + i];
+        if (v >= 0) {
+            if ((float)v < thDist) kept++;
+            else { S.u_right[base + i] = -1.0f; S.depth[base + i] = -1.0f; }
+        }
+    }
+    if (tid == 0) sh_count = 0;
+    __syncthreads();
+    atomicAdd(&sh_count, kept);
+    __syncthreads();
+    if (tid == 0) S.nmatches[f] = sh_count;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Projection matchers.  A "problem" p is one (query set, current frame) pair; problems are batched along
 // blockIdx.y so that a whole batch of frames is matched in one launch.
 // ---------------------------------------------------------------------------------------------------------

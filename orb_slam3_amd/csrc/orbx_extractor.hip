@@ -405,6 +405,7 @@ void orbx_destroy(orbx_extractor *ex) {
     for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
     if (ex->h_err) (void)hipHostFree(ex->h_err);
     ex->d_match.release(); ex->d_nmatch.release();
+    for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales}) b->release();
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,

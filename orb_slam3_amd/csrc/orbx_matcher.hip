@@ -764,3 +764,71 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (Frame.cc:811-981) for every frame of two resident batches (left / right extractor):
+// row-band Hamming, SAD refinement on the device-resident pyramids, median rejection -- nothing leaves HBM until
+// the results are downloaded.  Runs on the left extractor's stream behind both extractions.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, float bf, float b) {
+    if (!L || !R || !(b > 0.f)) return ORBX_E_BAD_ARG;
+    if (L->last_batch <= 0 || L->last_batch != R->last_batch || L->width != R->width || L->height != R->height ||
+        L->prm.nlevels != R->prm.nlevels || L->device != R->device)
+        return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(L->device));
+    const int n = L->last_batch, capL = L->cap, nl = L->prm.nlevels;
+    int r;
+#define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
+    ENS(L->d_st_bidx, 4 * (size_t)capL * L->batch_cap);
+    ENS(L->d_st_bdist, 4 * (size_t)capL * L->batch_cap);
+    ENS(L->d_st_ur, 4 * (size_t)capL * L->batch_cap);
+    ENS(L->d_st_depth, 4 * (size_t)capL * L->batch_cap);
+    ENS(L->d_st_sad, 4 * (size_t)capL * L->batch_cap);
+    ENS(L->d_st_nm, 4 * (size_t)L->batch_cap);
+    ENS(L->d_st_scales, sizeof(float) * 2 * nl);
+#undef ENS
+    hipStream_t st = L->stream;
+    ORBX_HIP(hipMemcpyAsync(L->d_st_scales.p, L->scale.data(), sizeof(float) * nl, hipMemcpyHostToDevice, st));
+    ORBX_HIP(hipMemcpyAsync((float *)L->d_st_scales.p + nl, L->inv_scale.data(), sizeof(float) * nl, hipMemcpyHostToDevice, st));
+    ORBX_HIP(hipStreamWaitEvent(st, R->ev_describe, 0));  // the right extraction of this batch
+    StereoBatch S;
+    S.kl = (const orbx_keypoint *)L->d_kps.p; S.kr = (const orbx_keypoint *)R->d_kps.p;
+    S.dl = (const uint8_t *)L->d_desc.p; S.dr = (const uint8_t *)R->d_desc.p;
+    S.nl = (const int32_t *)L->d_count.p; S.nr = (const int32_t *)R->d_count.p;
+    S.capL = capL; S.capR = R->cap;
+    S.pyrL = (const uint8_t *)L->d_pyr.p; S.pyrR = (const uint8_t *)R->d_pyr.p;
+    S.pyr_frame_L = L->pyr_frame; S.pyr_frame_R = R->pyr_frame;
+    S.lvL = (const LevelInfo *)L->d_lv.p; S.lvR = (const LevelInfo *)R->d_lv.p;
+    S.scale = (const float *)L->d_st_scales.p; S.inv_scale = S.scale + nl;
+    S.n_rows = L->height;
+    S.bf = bf; S.b = b;
+    S.best_idx = (int32_t *)L->d_st_bidx.p; S.best_dist = (int32_t *)L->d_st_bdist.p;
+    S.u_right = (float *)L->d_st_ur.p; S.depth = (float *)L->d_st_depth.p;
+    S.sad = (int32_t *)L->d_st_sad.p; S.nmatches = (int32_t *)L->d_st_nm.p;
+    hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((capL + 3) / 4, n), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(k_stereo_sad, dim3((capL + 3) / 4, n), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(k_stereo_reject, dim3(n), dim3(256), 0, st, S);
+    ORBX_HIP(hipGetLastError());
+    // the extractors must not overwrite their outputs / pyramids before these kernels are done
+    ORBX_HIP(hipEventRecord(L->ev_match, st));
+    L->match_pending = true;
+    ORBX_HIP(hipStreamWaitEvent(R->stream, L->ev_match, 0));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_batch_download(orbx_extractor *L, int frame, float *u_right, float *depth, int *n_left, int *n_matches) {
+    if (!L || frame < 0 || frame >= L->last_batch || !L->d_st_ur.p) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(L->device));
+    int32_t nlv = 0, nm = 0;
+    ORBX_HIP(hipMemcpyAsync(&nlv, (int32_t *)L->d_count.p + frame, 4, hipMemcpyDeviceToHost, L->stream));
+    ORBX_HIP(hipMemcpyAsync(&nm, (int32_t *)L->d_st_nm.p + frame, 4, hipMemcpyDeviceToHost, L->stream));
+    ORBX_HIP(hipStreamSynchronize(L->stream));
+    if (n_left) *n_left = nlv;
+    if (n_matches) *n_matches = nm;
+    if (nlv > 0) {
+        if (u_right) ORBX_HIP(hipMemcpyAsync(u_right, (float *)L->d_st_ur.p + (size_t)frame * L->cap, 4 * (size_t)nlv, hipMemcpyDeviceToHost, L->stream));
+        if (depth) ORBX_HIP(hipMemcpyAsync(depth, (float *)L->d_st_depth.p + (size_t)frame * L->cap, 4 * (size_t)nlv, hipMemcpyDeviceToHost, L->stream));
+        ORBX_HIP(hipStreamSynchronize(L->stream));
+    }
+    return ORBX_OK;
+}

@@ -106,6 +106,20 @@ class ORBextractor:
                                                     C.c_void_p(d_nmatches) if d_nmatches else None),
               "orbx_match_consecutive_device")
 
+    # ---- Frame::ComputeStereoMatches on two resident batches (self = left extractor) ----
+    def stereo_batch_device(self, right: "ORBextractor", bf: float, b: float):
+        check(self._L.orbx_stereo_batch_device(self._h, right._h, bf, b), "orbx_stereo_batch_device")
+
+    def stereo_download(self, frame: int):
+        """Returns (n_matches, mvuRight[N], mvDepth[N]) of `frame` (-1 where unmatched)."""
+        cap = self.batch_view().cap
+        ur = np.zeros(cap, np.float32)
+        depth = np.zeros(cap, np.float32)
+        nl, nm = C.c_int(0), C.c_int(0)
+        check(self._L.orbx_stereo_batch_download(self._h, frame, ptr(ur), ptr(depth), C.byref(nl), C.byref(nm)),
+              "orbx_stereo_batch_download")
+        return nm.value, ur[:nl.value].copy(), depth[:nl.value].copy()
+
     # ---- accessors (ORBextractor.h:62-83) ----
     def GetLevels(self) -> int:
         return self._L.orbx_get_levels(self._h)

@@ -346,3 +346,35 @@ def test_search_for_triangulation(oracle, canvas1):
         n, m12 = osa.ORBmatcher(0.6, ori).SearchForTriangulation(d0, k0["angle"], skip0, fva, d1, k1["angle"], skip1, fvb, pred)
         assert n == on and np.array_equal(m12, om), (ori, n, on)
         assert n > 30
+
+
+def test_stereo_batch_fully_on_device(oracle):
+    """Frame::ComputeStereoMatches with Hamming stage, SAD refinement and median rejection all on the device, on a batch
+    of KITTI-shaped rectified pairs; mvuRight / mvDepth bit-exact vs the oracle."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    w, h, nf, nb = 1241, 376, 2000, 3
+    canvas = synth.make_canvas(3, size=2600, n_shapes=4000)
+    pairs = [synth.make_stereo_pair(3, t, w, h, canvas) for t in range(nb)]
+    left = np.stack([p[0] for p in pairs])
+    right = np.stack([p[1] for p in pairs])
+    dl, dr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    exl, exr = osa.ORBextractor(nf, 1.2, 8, 20, 7), osa.ORBextractor(nf, 1.2, 8, 20, 7)
+    bf, b = np.float32(0.53716 * 718.856), np.float32(0.53716)
+    for rep in range(2):   # second round exercises the cross-extractor event dependencies
+        exl.extract_batch_device(dl.data_ptr(), nb, w, h, w, w * h, (0, 0))
+        exr.extract_batch_device(dr.data_ptr(), nb, w, h, w, w * h, (0, 0))
+        exl.stereo_batch_device(exr, float(bf), float(b))
+    sf, isf = exl.GetScaleFactors(), exl.GetInverseScaleFactors()
+    oexl, oexr = oracle.OracleExtractor(nf, 1.2, 8, 20, 7), oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    for t in range(nb):
+        nm, ur, depth = exl.stereo_download(t)
+        _, kl, dsl = oexl.extract(left[t], lap=(0, 0))
+        _, kr, dsr = oexr.extract(right[t], lap=(0, 0))
+        pyl = [np.ascontiguousarray(oexl.level_padded(l)[19:-19, 19:-19]) for l in range(8)]
+        pyr = [np.ascontiguousarray(oexr.level_padded(l)[19:-19, 19:-19]) for l in range(8)]
+        on, our, odepth, obi, obd = oracle.compute_stereo_matches(kl, dsl, kr, dsr, sf, isf, pyl, pyr, float(bf), float(b))
+        assert nm == on and len(ur) == len(our), (t, nm, on)
+        assert ur.tobytes() == our.tobytes() and depth.tobytes() == odepth.tobytes(), t
+        assert nm > 100
