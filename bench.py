@@ -79,6 +79,64 @@ def cpu_baseline(frames, n_sample):
                       f"oracle/ C++ restatement -O3 x86-64-v3, host CPU {os.cpu_count()} logical cores available"}
 
 
+def bench_kitti(args, rank, local_rank, world, torch, dist, osa, synth):
+    """BASELINE config 3: KITTI-shaped 1241x376 rectified stereo, nFeatures=2000: left + right extraction and
+    Frame::ComputeStereoMatches (Hamming row band + SAD + median rejection) all on the device, results to the host."""
+    from orb_slam3_amd import sharding
+    w, h, nf, B = 1241, 376, 2000, min(args.batch, 64)
+    canvas = synth.make_canvas(30 + rank, size=2600, n_shapes=4000)
+    pairs = [synth.make_stereo_pair(30 + rank, t, w, h, canvas) for t in range(B)]
+    dl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    dr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    exl = osa.ORBextractor(nf, 1.2, NLEVELS, 20, 7, device=local_rank)
+    exr = osa.ORBextractor(nf, 1.2, NLEVELS, 20, 7, device=local_rank)
+    cap = exl.output_capacity(w, h)
+    bf, b = 0.53716 * 718.856, 0.53716
+    host = {k: [torch.empty((B, cap, 28), dtype=torch.uint8).pin_memory(), torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory(),
+                torch.zeros(B, dtype=torch.int32).pin_memory(), torch.zeros(B, dtype=torch.int32).pin_memory()] for k in "lr"}
+
+    def step():
+        exl.extract_batch_device(dl.data_ptr(), B, w, h, w, w * h, (0, 0))
+        exr.extract_batch_device(dr.data_ptr(), B, w, h, w, w * h, (0, 0))
+        exl.stereo_batch_device(exr, bf, b)
+        for e, k in ((exl, "l"), (exr, "r")):
+            e.download_async(*[t.data_ptr() for t in host[k]])
+        exl.download_wait()
+        exr.download_wait()
+        nm = sum(exl.stereo_download(f)[0] for f in (0, B - 1))   # includes the stream sync for the stereo results
+        return int(host["l"][2].sum()) + int(host["r"][2].sum()), nm
+
+    def barrier():
+        torch.cuda.synchronize(); exl.sync(); exr.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    feats = 0
+    for _ in range(args.steps):
+        f, nm = step()
+        feats += f
+    barrier()
+    dt = time.perf_counter() - t0
+    dt_max, feats_all = sharding.reduce_throughput(dt, feats, device="cuda")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ORB kfeatures/sec extract+match, KITTI 1241x376 stereo nFeatures=2000", "value": round(feats_all / dt_max / 1e3, 2),
+            "unit": "kfeatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "KITTI-shaped 1241x376 rectified stereo, nFeatures=2000: left+right extract + ComputeStereoMatches "
+                                   "(row-band Hamming, SAD sub-pixel, median rejection) on device + D2H", "pairs_per_step_per_gpu": B,
+                       "features_per_pair": round(feats / args.steps / B, 1), "stereo_matches_first_last_frame": nm},
+            "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +145,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="frames per step (per GPU)")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--workload", choices=["euroc", "kitti"], default="euroc",
+                    help="euroc = BASELINE metric config (mono extract + frame-to-frame match); kitti = config 3 (stereo extract + ComputeStereoMatches)")
     ap.add_argument("--lanes", type=int, default=1, help="extractor instances alternated over consecutive batches (each has its own streams and workspace)")
     args = ap.parse_args()
 
@@ -104,6 +164,9 @@ def main():
 
     import orb_slam3_amd as osa
     from orb_slam3_amd import synth
+
+    if args.workload == "kitti":
+        return bench_kitti(args, rank, local_rank, world, torch, dist, osa, synth)
 
     B = args.batch
     canvas = synth.make_canvas(10 + rank)
