@@ -293,6 +293,21 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
 int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                   int32_t *d_match, int32_t *d_nmatches);
 
+/* ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> on the device (include/ORBVocabulary.h;
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  The tree crosses the ABI flattened: node 0 is the root, the children
+ * of node i are child_idx[child_ptr[i] .. child_ptr[i+1]) in m_nodes[i].children order, node_desc = n_nodes x 32 bytes,
+ * word_id[i] >= 0 iff node i is a leaf (its WordId).  L = depth (m_L). */
+typedef struct orbx_vocabulary orbx_vocabulary;
+int orbx_vocabulary_create(int device, int L, int n_nodes, const int32_t *child_ptr, const int32_t *child_idx,
+                           const uint8_t *node_desc, const int32_t *word_id, orbx_vocabulary **out);
+void orbx_vocabulary_destroy(orbx_vocabulary *voc);
+/* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (TemplatedVocabulary.h:1206-1250) for the n
+ * descriptors of a frame, as Frame::ComputeBoW needs (Frame.cc:738-745, levelsup = 4): word_id[i] = WordId of the leaf
+ * reached, node_id[i] = NodeId at level L - levelsup (the FeatureVector key).  The adapter builds BowVector (weights from
+ * its own vocabulary copy, tf-idf + L1 in double) and FeatureVector from these ids. */
+int orbx_bow_transform(orbx_matcher *m, const orbx_vocabulary *voc, const uint8_t *descriptors, int n, int levelsup,
+                       int32_t *word_id, int32_t *node_id);
+
 /* Frame::ComputeStereoMatches (Frame.cc:811-981) for every frame of two resident batches: `left` and `right` must have
  * extracted batches of the same size and image shape (rectified stereo, lapping {0,0}).  Row-band Hamming match, 11x11
  * SAD sub-pixel refinement on the device-resident pyramids and the median outlier rejection all run on the device, on

@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         L.orbo_search_for_triangulation.restype = i32
         L.orbo_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, PAIR_PREDICATE, vp, vp]
         L.orbo_three_maxima.argtypes = [vp, i32, vp, vp, vp]
+        L.orbo_bow_transform.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp]
         _lib = L
     return _lib
 
@@ -422,3 +423,13 @@ def search_for_triangulation(d1, a1, s1, fv1, d2, a2, s2, fv2, check_orientation
     n = lib().orbo_search_for_triangulation(_p(d1), _p(a1), _p(s1), len(d1), C.byref(a), _p(d2), _p(a2), _p(s2), len(d2),
                                             C.byref(b), int(check_orientation), cb, None, _p(m12))
     return n, m12
+
+
+def bow_transform(child_ptr, child_idx, node_desc, word_id, L, levelsup, desc):
+    cp, ci = np.ascontiguousarray(child_ptr, np.int32), np.ascontiguousarray(child_idx, np.int32)
+    nd, wi = np.ascontiguousarray(node_desc, np.uint8), np.ascontiguousarray(word_id, np.int32)
+    d = np.ascontiguousarray(desc, np.uint8)
+    word = np.zeros(len(d), np.int32)
+    node = np.zeros(len(d), np.int32)
+    lib().orbo_bow_transform(_p(cp), _p(ci), _p(nd), _p(wi), L, levelsup, _p(d), len(d), _p(word), _p(node))
+    return word, node

@@ -179,6 +179,14 @@ int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int 
                                 const size_t *pyr_stride, float bf, float b, float *u_right, float *depth,
                                 int32_t *best_idx_r, int32_t *best_dist);
 
+/* DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (Thirdparty/DBoW2/DBoW2/
+ * TemplatedVocabulary.h:1206-1250) for n features over a flattened vocabulary tree: node 0 is the root, children of
+ * node i are child_idx[child_ptr[i] .. child_ptr[i+1]) in m_nodes[i].children order, node_desc holds the 32-byte node
+ * descriptors, word_id[i] >= 0 iff node i is a leaf.  FORB::distance = DescriptorDistance (FORB.cpp:88-107).
+ * node_out[i] = node at level L - levelsup (0 = root when L - levelsup <= 0). */
+void orbo_bow_transform(const int32_t *child_ptr, const int32_t *child_idx, const uint8_t *node_desc, const int32_t *word_id,
+                        int L, int levelsup, const uint8_t *desc, int n, int32_t *word_out, int32_t *node_out);
+
 /* M9: BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2): idx[2*i..], dist[2*i..]; -1 when fewer than k train rows */
 void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist);
 

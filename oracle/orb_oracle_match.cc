@@ -590,6 +590,30 @@ int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int 
     return nmatched;
 }
 
+/* TemplatedVocabulary.h:1206-1250 */
+void orbo_bow_transform(const int32_t *child_ptr, const int32_t *child_idx, const uint8_t *node_desc, const int32_t *word_id,
+                        int L, int levelsup, const uint8_t *desc, int n, int32_t *word_out, int32_t *node_out) {
+    const int nid_level = L - levelsup;
+    for (int i = 0; i < n; i++) {
+        const uint8_t *feature = desc + (size_t)i * 32;
+        if (nid_level <= 0) node_out[i] = 0; /* root */
+        int final_id = 0, current_level = 0;
+        do {
+            ++current_level;
+            const int b = child_ptr[final_id], e = child_ptr[final_id + 1];
+            final_id = child_idx[b];
+            double best_d = descriptor_distance(feature, node_desc + (size_t)final_id * 32);
+            for (int c = b + 1; c < e; c++) {
+                const int id = child_idx[c];
+                const double d = descriptor_distance(feature, node_desc + (size_t)id * 32);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (current_level == nid_level) node_out[i] = final_id;
+        } while (child_ptr[final_id + 1] > child_ptr[final_id]); /* !isLeaf() */
+        word_out[i] = word_id[final_id];
+    }
+}
+
 /* M9 [OCV]: BFMatcher(NORM_HAMMING).knnMatch(k=2): ascending train scan, strict '<' insertion => the
  * lower train index wins ties; Frame.cc:1144 */
 void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist) {

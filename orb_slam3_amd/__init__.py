@@ -7,6 +7,6 @@ ORBextractor / ORBmatcher does, and fails loudly when liborbx.so or a HIP device
 """
 from ._lib import KP_DTYPE, OrbxError, LIB_PATH  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
-from .matcher import ORBmatcher, FrameView, FeatureVector  # noqa: F401
+from .matcher import ORBmatcher, ORBVocabulary, FrameView, FeatureVector  # noqa: F401
 
-__all__ = ["ORBextractor", "ORBmatcher", "FrameView", "FeatureVector", "KP_DTYPE", "OrbxError", "LIB_PATH"]
+__all__ = ["ORBextractor", "ORBmatcher", "ORBVocabulary", "FrameView", "FeatureVector", "KP_DTYPE", "OrbxError", "LIB_PATH"]

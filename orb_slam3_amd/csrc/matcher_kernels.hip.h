@@ -175,6 +175,51 @@ __global__ __launch_bounds__(256) void k_stereo_rowband(const orbx_keypoint *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (TemplatedVocabulary.h:1206-1250):
+// descend the k-ary vocabulary tree, at every level to the child with the smallest Hamming distance (strict '<': the
+// first minimum in m_nodes[i].children order wins).  16 lanes per feature; lanes stride the children of the current
+// node, the packed key (dist << 16 | child position) is min-reduced inside the 16-lane group.
+// grid (ceil(n/16)), block 256
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bow_transform(const int32_t *__restrict__ child_ptr, const int32_t *__restrict__ child_idx,
+                                                       const uint8_t *__restrict__ node_desc, const int32_t *__restrict__ word_id, int L,
+                                                       int levelsup, const uint8_t *__restrict__ desc, int n,
+                                                       int32_t *__restrict__ word_out, int32_t *__restrict__ node_out) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+    const bool valid = i < n;
+    Desc dq;
+    if (valid) dq = load_desc(desc + (size_t)i * 32);
+    const int nid_level = L - levelsup;
+    int node = 0, level = 0, nid = 0;
+    bool done = !valid;
+    // all 16 lanes of a group follow the same path; groups of one wave may need a different number of levels
+    while (__ballot(!done) != 0ull) {
+        uint32_t best = 0xffffffffu;
+        int b = 0, e = 0;
+        if (!done) {
+            b = child_ptr[node]; e = child_ptr[node + 1];
+            for (int c = b + sl; c < e; c += 16) {
+                const int d = hamming(dq, load_desc(node_desc + (size_t)child_idx[c] * 32));
+                const uint32_t k = ((uint32_t)d << 16) | (uint32_t)(c - b);
+                best = k < best ? k : best;
+            }
+        }
+#pragma unroll
+        for (int s = 8; s > 0; s >>= 1) {
+            const uint32_t o = __shfl_xor(best, s);
+            best = o < best ? o : best;
+        }
+        if (!done) {
+            ++level;
+            node = child_idx[b + (int)(best & 0xffffu)];
+            if (level == nid_level) nid = node;
+            done = (child_ptr[node + 1] <= child_ptr[node]);  // isLeaf()
+        }
+    }
+    if (valid && sl == 0) { word_out[i] = word_id[node]; node_out[i] = (nid_level <= 0) ? 0 : nid; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Frame::ComputeStereoMatches fully on the device for a batch of rectified stereo frames whose left / right
 // extractions are resident (keypoints, descriptors, padded pyramids).
 //   k_stereo_rowband_batch : Hamming stage (:849-894), one wave per left keypoint

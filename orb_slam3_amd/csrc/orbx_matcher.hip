@@ -51,6 +51,13 @@ struct orbx_matcher {
     Arena arena;
 };
 
+// ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) resident on the device
+struct orbx_vocabulary {
+    int device = 0, k = 0, L = 0, n_nodes = 0;
+    int32_t *child_ptr = nullptr, *child_idx = nullptr, *word_id = nullptr;
+    uint8_t *node_desc = nullptr;
+};
+
 extern "C" {
 
 int orbx_matcher_create(int device, orbx_matcher **out) {
@@ -830,5 +837,60 @@ extern "C" int orbx_stereo_batch_download(orbx_extractor *L, int frame, float *u
         if (depth) ORBX_HIP(hipMemcpyAsync(depth, (float *)L->d_st_depth.p + (size_t)frame * L->cap, 4 * (size_t)nlv, hipMemcpyDeviceToHost, L->stream));
         ORBX_HIP(hipStreamSynchronize(L->stream));
     }
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DBoW2 vocabulary on the device + TemplatedVocabulary::transform for all features of a frame (Frame::ComputeBoW,
+// Frame.cc:738-745).  The tf-idf weighting / L1 normalisation of the BowVector (double arithmetic in std::map order)
+// stays in the adapter: it needs only the word ids returned here.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int orbx_vocabulary_create(int device, int L, int n_nodes, const int32_t *child_ptr, const int32_t *child_idx,
+                                      const uint8_t *node_desc, const int32_t *word_id, orbx_vocabulary **out) {
+    if (!out || n_nodes <= 0 || !child_ptr || !child_idx || !node_desc || !word_id || L < 1) return ORBX_E_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        set_error("no usable HIP device (liborbx has no CPU fallback)");
+        return ORBX_E_NO_DEVICE;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    orbx_vocabulary *v = new orbx_vocabulary();
+    v->device = device; v->L = L; v->n_nodes = n_nodes;
+    const int nchild = child_ptr[n_nodes];
+    ORBX_HIP(hipMalloc((void **)&v->child_ptr, 4 * (size_t)(n_nodes + 1)));
+    ORBX_HIP(hipMalloc((void **)&v->child_idx, 4 * (size_t)std::max(nchild, 1)));
+    ORBX_HIP(hipMalloc((void **)&v->word_id, 4 * (size_t)n_nodes));
+    ORBX_HIP(hipMalloc((void **)&v->node_desc, 32 * (size_t)n_nodes));
+    ORBX_HIP(hipMemcpy(v->child_ptr, child_ptr, 4 * (size_t)(n_nodes + 1), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(v->child_idx, child_idx, 4 * (size_t)nchild, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(v->word_id, word_id, 4 * (size_t)n_nodes, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(v->node_desc, node_desc, 32 * (size_t)n_nodes, hipMemcpyHostToDevice));
+    *out = v;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    (void)hipFree(v->child_ptr); (void)hipFree(v->child_idx); (void)hipFree(v->word_id); (void)hipFree(v->node_desc);
+    delete v;
+}
+
+extern "C" int orbx_bow_transform(orbx_matcher *m, const orbx_vocabulary *v, const uint8_t *desc, int n, int levelsup, int32_t *word_id,
+                                  int32_t *node_id) {
+    if (!m || !v || n < 0 || (n > 0 && (!desc || !word_id || !node_id)) || m->device != v->device) return ORBX_E_BAD_ARG;
+    if (n == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(m->device));
+    int r = m->arena.reserve(Arena::pad(32 * (size_t)n) + 2 * Arena::pad(4 * (size_t)n) + 4096);
+    if (r != ORBX_OK) return r;
+    m->arena.reset();
+    uint8_t *dd = m->arena.take<uint8_t>(32 * (size_t)n);
+    int32_t *dw = m->arena.take<int32_t>(n), *dn = m->arena.take<int32_t>(n);
+    H2D(dd, desc, 32 * (size_t)n);
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + 15) / 16), dim3(256), 0, m->stream, v->child_ptr, v->child_idx, v->node_desc, v->word_id,
+                       v->L, levelsup, dd, n, dw, dn);
+    D2H(word_id, dw, 4 * (size_t)n); D2H(node_id, dn, 4 * (size_t)n);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }

@@ -70,6 +70,24 @@ def _u8(a):
     return None if a is None else np.ascontiguousarray(a, np.uint8)
 
 
+class ORBVocabulary:
+    """DBoW2 vocabulary tree on the device (flattened: child CSR, node descriptors, leaf word ids)."""
+
+    def __init__(self, L: int, child_ptr, child_idx, node_desc, word_id, device: int = 0):
+        self._L_ = _lib.lib()
+        self.L = L
+        cp, ci = _i32(child_ptr), _i32(child_idx)
+        nd, wi = _u8(node_desc), _i32(word_id)
+        self._h = C.c_void_p()
+        check(self._L_.orbx_vocabulary_create(device, L, len(wi), ptr(cp), ptr(ci), ptr(nd), ptr(wi), C.byref(self._h)),
+              "orbx_vocabulary_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L_.orbx_vocabulary_destroy(self._h)
+            self._h = None
+
+
 class ORBmatcher:
     TH_LOW = _lib.TH_LOW
     TH_HIGH = _lib.TH_HIGH
@@ -232,3 +250,12 @@ class ORBmatcher:
                                                         ptr(a2), ptr(s2), len(d2), C.byref(b), int(self.mbCheckOrientation),
                                                         cb, None, ptr(m12)), "orbx_search_for_triangulation")
         return n, m12
+
+    # ---- DBoW2 transform (Frame::ComputeBoW, Frame.cc:738-745) ----
+    def BowTransform(self, voc: "ORBVocabulary", descriptors, levelsup: int = 4):
+        """Returns (word_id[n], node_id[n]) of TemplatedVocabulary::transform for every descriptor."""
+        d = _u8(descriptors)
+        w = np.zeros(len(d), np.int32)
+        nd = np.zeros(len(d), np.int32)
+        check(self._L.orbx_bow_transform(self._h, voc._h, ptr(d), len(d), levelsup, ptr(w), ptr(nd)), "orbx_bow_transform")
+        return w, nd

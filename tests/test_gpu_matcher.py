@@ -378,3 +378,55 @@ def test_stereo_batch_fully_on_device(oracle):
         assert nm == on and len(ur) == len(our), (t, nm, on)
         assert ur.tobytes() == our.tobytes() and depth.tobytes() == odepth.tobytes(), t
         assert nm > 100
+
+
+def _random_vocabulary(rng, k, L, ragged=True):
+    """Random k-ary vocabulary of depth L (some nodes get fewer children, some leaves sit above depth L)."""
+    nwords = 0
+    # simple explicit construction: nodes numbered in BFS order
+    nodes = [dict(children=[], depth=0)]
+    q = [0]
+    while q:
+        i = q.pop(0)
+        d = nodes[i]["depth"]
+        if d == L or (ragged and d >= 2 and rng.random() < 0.1):
+            continue
+        nc = k if not ragged else int(rng.integers(max(2, k - 3), k + 1))
+        for _ in range(nc):
+            nodes.append(dict(children=[], depth=d + 1))
+            nodes[i]["children"].append(len(nodes) - 1)
+            q.append(len(nodes) - 1)
+    n = len(nodes)
+    node_desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    word_id = np.full(n, -1, np.int32)
+    cp, ci = [0], []
+    for i, nd in enumerate(nodes):
+        if rng.random() < 0.2:
+            rng.shuffle(nd["children"])       # children order is not index order in general
+        ci.extend(nd["children"])
+        cp.append(len(ci))
+        if not nd["children"]:
+            word_id[i] = nwords
+            nwords += 1
+    # duplicate some sibling descriptors so that distance ties occur (first child in list order must win)
+    for i, nd in enumerate(nodes):
+        if len(nd["children"]) >= 2 and rng.random() < 0.15:
+            node_desc[nd["children"][1]] = node_desc[nd["children"][0]]
+    return np.array(cp, np.int32), np.array(ci, np.int32), node_desc, word_id
+
+
+def test_bow_transform(oracle, canvas1):
+    """DBoW2 TemplatedVocabulary::transform (k-ary tree descent) on a random vocabulary, incl. ties and ragged trees."""
+    import orb_slam3_amd as osa
+    rng = np.random.default_rng(51)
+    ex, k0, d0, k1, d1 = _two_frames(canvas1)
+    m = osa.ORBmatcher()
+    for k, L in ((10, 4), (6, 6), (17, 3)):
+        cp, ci, nd, wi = _random_vocabulary(rng, k, L)
+        voc = osa.ORBVocabulary(L, cp, ci, nd, wi)
+        feats = np.concatenate([d0, nd[rng.integers(1, len(nd), 300)]])   # real descriptors + exact node descriptors
+        for levelsup in (4, 2, 0, 9):
+            w, n_ = m.BowTransform(voc, feats, levelsup)
+            ow, on = oracle.bow_transform(cp, ci, nd, wi, L, levelsup, feats)
+            assert np.array_equal(w, ow) and np.array_equal(n_, on), (k, L, levelsup)
+        assert (w >= 0).all() and len(np.unique(w)) > 50
