@@ -293,6 +293,13 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
 int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                   int32_t *d_match, int32_t *d_nmatches);
 
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403), batched over map points: set s = the descriptors of the
+ * observations of map point s, descriptors[set_ptr[s] .. set_ptr[s+1]) (gathered by the adapter from
+ * pKF->mDescriptors.row(leftIndex/rightIndex) in std::map order).  best_idx[s] = index inside the set of the descriptor
+ * with the least median Hamming distance to the others (first minimum wins), -1 for an empty set. */
+int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *descriptors, const int32_t *set_ptr, int n_sets,
+                                 int32_t *best_idx);
+
 /* ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> on the device (include/ORBVocabulary.h;
  * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  The tree crosses the ABI flattened: node 0 is the root, the children
  * of node i are child_idx[child_ptr[i] .. child_ptr[i+1]) in m_nodes[i].children order, node_desc = n_nodes x 32 bytes,

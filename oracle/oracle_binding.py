@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         L.orbo_search_for_triangulation.restype = i32
         L.orbo_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, PAIR_PREDICATE, vp, vp]
         L.orbo_three_maxima.argtypes = [vp, i32, vp, vp, vp]
+        L.orbo_distinctive_descriptors.argtypes = [vp, vp, i32, vp]
         L.orbo_bow_transform.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp]
         _lib = L
     return _lib
@@ -433,3 +434,11 @@ def bow_transform(child_ptr, child_idx, node_desc, word_id, L, levelsup, desc):
     node = np.zeros(len(d), np.int32)
     lib().orbo_bow_transform(_p(cp), _p(ci), _p(nd), _p(wi), L, levelsup, _p(d), len(d), _p(word), _p(node))
     return word, node
+
+
+def distinctive_descriptors(desc, set_ptr):
+    d = np.ascontiguousarray(desc, np.uint8)
+    sp = np.ascontiguousarray(set_ptr, np.int32)
+    out = np.zeros(len(sp) - 1, np.int32)
+    lib().orbo_distinctive_descriptors(_p(d), _p(sp), len(sp) - 1, _p(out))
+    return out

@@ -187,6 +187,11 @@ int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int 
 void orbo_bow_transform(const int32_t *child_ptr, const int32_t *child_idx, const uint8_t *node_desc, const int32_t *word_id,
                         int L, int levelsup, const uint8_t *desc, int n, int32_t *word_out, int32_t *node_out);
 
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403) for n_sets observation sets: set s = descriptors
+ * desc[set_ptr[s] .. set_ptr[s+1]); best_idx[s] = index (inside the set) of the descriptor with the least median distance
+ * to the others (median = sorted row [0.5*(N-1)], first minimum wins); -1 for an empty set. */
+void orbo_distinctive_descriptors(const uint8_t *desc, const int32_t *set_ptr, int n_sets, int32_t *best_idx);
+
 /* M9: BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2): idx[2*i..], dist[2*i..]; -1 when fewer than k train rows */
 void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist);
 

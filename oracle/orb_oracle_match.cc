@@ -614,6 +614,32 @@ void orbo_bow_transform(const int32_t *child_ptr, const int32_t *child_idx, cons
     }
 }
 
+/* MapPoint.cc:369-397 */
+void orbo_distinctive_descriptors(const uint8_t *desc, const int32_t *set_ptr, int n_sets, int32_t *best_idx) {
+    for (int s = 0; s < n_sets; s++) {
+        const int N = set_ptr[s + 1] - set_ptr[s];
+        const uint8_t *D = desc + (size_t)set_ptr[s] * 32;
+        if (N <= 0) { best_idx[s] = -1; continue; }
+        std::vector<float> Distances((size_t)N * N);
+        for (int i = 0; i < N; i++) {
+            Distances[(size_t)i * N + i] = 0;
+            for (int j = i + 1; j < N; j++) {
+                int distij = descriptor_distance(D + (size_t)i * 32, D + (size_t)j * 32);
+                Distances[(size_t)i * N + j] = (float)distij;
+                Distances[(size_t)j * N + i] = (float)distij;
+            }
+        }
+        int BestMedian = INT_MAX, BestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            std::vector<int> vDists(Distances.begin() + (size_t)i * N, Distances.begin() + (size_t)(i + 1) * N);
+            std::sort(vDists.begin(), vDists.end());
+            int median = vDists[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        best_idx[s] = BestIdx;
+    }
+}
+
 /* M9 [OCV]: BFMatcher(NORM_HAMMING).knnMatch(k=2): ascending train scan, strict '<' insertion => the
  * lower train index wins ties; Frame.cc:1144 */
 void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist) {

@@ -175,6 +175,54 @@ __global__ __launch_bounds__(256) void k_stereo_rowband(const orbx_keypoint *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403), batched: one wave per observation set.  For every row
+// i of the N x N Hamming matrix the median (sorted row element floor(0.5*(N-1))) is found with a 257-bin LDS histogram
+// and a wave prefix scan; the first row with the smallest median wins.
+// grid (ceil(n_sets/4)), block 256
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__ desc, const int32_t *__restrict__ set_ptr, int n_sets,
+                                                     int32_t *__restrict__ best_idx) {
+    __shared__ int hist_all[4][320];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wv;
+    if (s >= n_sets) return;  // wave-uniform; no block barrier below
+    int *hist = hist_all[wv];
+    const int b = set_ptr[s], N = set_ptr[s + 1] - b;
+    if (N <= 0) { if (lane == 0) best_idx[s] = -1; return; }
+    const uint8_t *D = desc + (size_t)b * 32;
+    const int kth = (int)(0.5 * (N - 1));
+    int bestMedian = 0x7fffffff, bestIdx = 0;
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) hist[lane * 5 + q] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const Desc di = load_desc(D + (size_t)i * 32);
+        for (int j = lane; j < N; j += 64) atomicAdd(&hist[hamming(di, load_desc(D + (size_t)j * 32))], 1);
+        __builtin_amdgcn_wave_barrier();
+        int c[5], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) { c[q] = hist[lane * 5 + q]; tot += c[q]; }
+        int incl = tot;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int t = __shfl_up(incl, sft);
+            if (lane >= sft) incl += t;
+        }
+        int excl = incl - tot, med = -1;
+        if (excl <= kth && kth < incl) {  // exactly one lane
+            int acc = excl;
+#pragma unroll
+            for (int q = 0; q < 5; q++) { if (med < 0 && kth < acc + c[q]) med = lane * 5 + q; acc += c[q]; }
+        }
+        const unsigned long long owner = __ballot(med >= 0);
+        med = __shfl(med, __ffsll((long long)owner) - 1);
+        if (med < bestMedian) { bestMedian = med; bestIdx = i; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) best_idx[s] = bestIdx;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (TemplatedVocabulary.h:1206-1250):
 // descend the k-ary vocabulary tree, at every level to the child with the smallest Hamming distance (strict '<': the
 // first minimum in m_nodes[i].children order wins).  16 lanes per feature; lanes stride the children of the current

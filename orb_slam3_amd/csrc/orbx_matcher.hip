@@ -894,3 +894,23 @@ extern "C" int orbx_bow_transform(orbx_matcher *m, const orbx_vocabulary *v, con
     ORBX_HIP(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }
+
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403) for a batch of map points
+extern "C" int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *desc, const int32_t *set_ptr, int n_sets, int32_t *best_idx) {
+    if (!m || n_sets < 0 || (n_sets > 0 && (!set_ptr || !best_idx))) return ORBX_E_BAD_ARG;
+    if (n_sets == 0) return ORBX_OK;
+    const int total = set_ptr[n_sets];
+    if (total > 0 && !desc) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(m->device));
+    int r = m->arena.reserve(Arena::pad(32 * (size_t)total + 32) + Arena::pad(4 * (size_t)(n_sets + 1)) + Arena::pad(4 * (size_t)n_sets) + 4096);
+    if (r != ORBX_OK) return r;
+    m->arena.reset();
+    uint8_t *dd = m->arena.take<uint8_t>(32 * (size_t)total + 32);
+    int32_t *dp = m->arena.take<int32_t>(n_sets + 1), *db = m->arena.take<int32_t>(n_sets);
+    if (total > 0) H2D(dd, desc, 32 * (size_t)total);
+    H2D(dp, set_ptr, 4 * (size_t)(n_sets + 1));
+    hipLaunchKernelGGL(k_distinctive, dim3((n_sets + 3) / 4), dim3(256), 0, m->stream, dd, dp, n_sets, db);
+    D2H(best_idx, db, 4 * (size_t)n_sets);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}

@@ -259,3 +259,10 @@ class ORBmatcher:
         nd = np.zeros(len(d), np.int32)
         check(self._L.orbx_bow_transform(self._h, voc._h, ptr(d), len(d), levelsup, ptr(w), ptr(nd)), "orbx_bow_transform")
         return w, nd
+
+    # ---- MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403), batched ----
+    def DistinctiveDescriptors(self, descriptors, set_ptr):
+        d, sp = _u8(descriptors), _i32(set_ptr)
+        out = np.zeros(len(sp) - 1, np.int32)
+        check(self._L.orbx_distinctive_descriptors(self._h, ptr(d), ptr(sp), len(sp) - 1, ptr(out)), "orbx_distinctive_descriptors")
+        return out

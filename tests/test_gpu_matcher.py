@@ -430,3 +430,18 @@ def test_bow_transform(oracle, canvas1):
             ow, on = oracle.bow_transform(cp, ci, nd, wi, L, levelsup, feats)
             assert np.array_equal(w, ow) and np.array_equal(n_, on), (k, L, levelsup)
         assert (w >= 0).all() and len(np.unique(w)) > 50
+
+
+def test_distinctive_descriptors(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors batched: least-median descriptor per observation set (first minimum wins)."""
+    import orb_slam3_amd as osa
+    rng = np.random.default_rng(61)
+    sizes = list(rng.integers(1, 40, 300)) + [0, 1, 2, 64, 65, 130, 300]
+    set_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = rng.integers(0, 256, (len(sizes), 32), dtype=np.uint8)
+    desc = np.concatenate([_noisy_copy(rng, np.repeat(base[i:i + 1], n, axis=0), 0.08) for i, n in enumerate(sizes) if n > 0])
+    desc[set_ptr[5]:set_ptr[5] + 2] = desc[set_ptr[5]]   # identical rows -> equal medians -> first wins
+    got = osa.ORBmatcher().DistinctiveDescriptors(desc, set_ptr)
+    want = oracle.distinctive_descriptors(desc, set_ptr)
+    assert np.array_equal(got, want)
+    assert got[len(sizes) - 7] == -1 and (got[:300] >= 0).all()
