@@ -293,6 +293,17 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
 int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                   int32_t *d_match, int32_t *d_nmatches);
 
+/* The matching core of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th, bRight) (ORBmatcher.cc:1148-1337, candidate loop
+ * :1246-1306) and Fuse(KeyFrame*, Sim3f&, vpPoints, th, vpReplacePoint) (:1339-1455, loop :1405-1433): for each projected
+ * map point (u, v[, ur], radius = th*scale[lvl], predicted level) the best feature of the key frame among
+ * KeyFrame::GetFeaturesInArea(u, v, r) with octave in [lvl-1, lvl] and -- when inv_level_sigma2 != NULL (first overload) --
+ * reprojection chi2 <= 5.99 (mono) / 7.8 (kf->u_right[idx] >= 0).  Queries do not interact; best_idx = -1 / best_dist = 256
+ * when nothing qualifies.  The caller accepts best_dist <= ORBX_TH_LOW and performs Replace / AddObservation / AddMapPoint.
+ * strict_fp = 0: e2 summed with the fused multiply-adds GCC emits for the reference's flags; 1: separate mul/add. */
+int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, const float *inv_level_sigma2, int n_q, const float *q_u,
+                     const float *q_v, const float *q_ur, const float *q_r, const int32_t *q_level, const uint8_t *q_desc,
+                     int strict_fp, int32_t *best_idx, int32_t *best_dist);
+
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403), batched over map points: set s = the descriptors of the
  * observations of map point s, descriptors[set_ptr[s] .. set_ptr[s+1]) (gathered by the adapter from
  * pKF->mDescriptors.row(leftIndex/rightIndex) in std::map order).  best_idx[s] = index inside the set of the descriptor

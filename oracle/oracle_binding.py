@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         L.orbo_search_for_triangulation.restype = i32
         L.orbo_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, PAIR_PREDICATE, vp, vp]
         L.orbo_three_maxima.argtypes = [vp, i32, vp, vp, vp]
+        L.orbo_fuse_search.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         L.orbo_distinctive_descriptors.argtypes = [vp, vp, i32, vp]
         L.orbo_bow_transform.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp]
         _lib = L
@@ -442,3 +443,17 @@ def distinctive_descriptors(desc, set_ptr):
     out = np.zeros(len(sp) - 1, np.int32)
     lib().orbo_distinctive_descriptors(_p(d), _p(sp), len(sp) - 1, _p(out))
     return out
+
+
+def fuse_search(grid: OracleGrid, desc, u_right, inv_sigma2, q, fma=True):
+    desc = np.ascontiguousarray(desc, np.uint8)
+    a = {k: np.ascontiguousarray(v) for k, v in q.items()}
+    nq = len(a["u"])
+    bi = np.zeros(nq, np.int32)
+    bd = np.zeros(nq, np.int32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    isg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    lib().orbo_fuse_search(grid.h, _p(grid.kps), _p(desc), len(grid.kps), _p(ur), _p(isg), nq, _p(a["u"].astype(np.float32)),
+                           _p(a["v"].astype(np.float32)), _p(a["ur"].astype(np.float32)), _p(a["r"].astype(np.float32)),
+                           _p(a["level"].astype(np.int32)), _p(a["desc"].astype(np.uint8)), int(fma), _p(bi), _p(bd))
+    return bi, bd

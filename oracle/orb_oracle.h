@@ -187,6 +187,16 @@ int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int 
 void orbo_bow_transform(const int32_t *child_ptr, const int32_t *child_idx, const uint8_t *node_desc, const int32_t *word_id,
                         int L, int levelsup, const uint8_t *desc, int n, int32_t *word_out, int32_t *node_out);
 
+/* The candidate loop of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th, bRight) (ORBmatcher.cc:1246-1306, mono/left form) and
+ * of Fuse(KeyFrame*, Sim3f&, vpPoints, th, vpReplacePoint) (:1405-1433): KeyFrame::GetFeaturesInArea(u, v, r), octave gate
+ * [lvl-1, lvl], optional reprojection chi2 gate (inv_sigma2 != NULL: e2*invSigma2 > 5.99 mono / 7.8 when mvuRight >= 0),
+ * best distance with the first minimum winning.  Queries do not interact.  best_idx = -1 / best_dist = 256 when there is
+ * no candidate.  fma_mode: e2 evaluated as GCC -O3 -march=native contracts it (fma(ex,ex,ey*ey), fma(er,er,...)). */
+void orbo_fuse_search(const orbo_grid *grid, const orbo_keypoint *kps_un, const uint8_t *desc, int n, const float *u_right,
+                      const float *inv_sigma2, int n_q, const float *q_u, const float *q_v, const float *q_ur,
+                      const float *q_r, const int32_t *q_level, const uint8_t *q_desc, int fma_mode, int32_t *best_idx,
+                      int32_t *best_dist);
+
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403) for n_sets observation sets: set s = descriptors
  * desc[set_ptr[s] .. set_ptr[s+1]); best_idx[s] = index (inside the set) of the descriptor with the least median distance
  * to the others (median = sorted row [0.5*(N-1)], first minimum wins); -1 for an empty set. */

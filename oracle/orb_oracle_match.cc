@@ -614,6 +614,41 @@ void orbo_bow_transform(const int32_t *child_ptr, const int32_t *child_idx, cons
     }
 }
 
+/* ORBmatcher.cc:1246-1306 and :1405-1433 */
+void orbo_fuse_search(const orbo_grid *grid, const orbo_keypoint *kps, const uint8_t *desc, int n, const float *u_right,
+                      const float *inv_sigma2, int n_q, const float *q_u, const float *q_v, const float *q_ur,
+                      const float *q_r, const int32_t *q_level, const uint8_t *q_desc, int fma_mode, int32_t *best_idx,
+                      int32_t *best_dist) {
+    std::vector<int32_t> vIndices;
+    for (int i = 0; i < n_q; i++) {
+        best_idx[i] = -1; best_dist[i] = 256;
+        const int nPredictedLevel = q_level[i];
+        grid_query(grid, q_u[i], q_v[i], q_r[i], -1, -1, vIndices); /* KeyFrame::GetFeaturesInArea: no level test */
+        if (vIndices.empty()) continue;
+        const uint8_t *dMP = q_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (int32_t idx : vIndices) {
+            const orbo_keypoint &kp = kps[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (inv_sigma2) {
+                if (u_right && u_right[idx] >= 0) { /* stereo reprojection error :1266-1278 */
+                    const float ex = q_u[i] - kp.x, ey = q_v[i] - kp.y, er = q_ur[i] - u_right[idx];
+                    const float e2 = fma_mode ? fmaf(er, er, fmaf(ex, ex, ey * ey)) : ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[kpLevel] > 7.8) continue;
+                } else { /* :1281-1289 */
+                    const float ex = q_u[i] - kp.x, ey = q_v[i] - kp.y;
+                    const float e2 = fma_mode ? fmaf(ex, ex, ey * ey) : ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = descriptor_distance(dMP, desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+    }
+}
+
 /* MapPoint.cc:369-397 */
 void orbo_distinctive_descriptors(const uint8_t *desc, const int32_t *set_ptr, int n_sets, int32_t *best_idx) {
     for (int s = 0; s < n_sets; s++) {

@@ -72,7 +72,7 @@ SYMBOLS = [
     "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
     "orbx_search_for_triangulation", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_vocabulary_create",
-    "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors",
+    "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors", "orbx_fuse_search",
 ]
 
 
@@ -132,6 +132,7 @@ def lib() -> C.CDLL:
     L.orbx_vocabulary_destroy.argtypes = [vp]
     L.orbx_bow_transform.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     L.orbx_distinctive_descriptors.argtypes = [vp, vp, vp, i32, vp]
+    L.orbx_fuse_search.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.orbx_stereo_batch_download.argtypes = [vp, i32, vp, vp, vp, vp]
     L.orbx_search_by_projection_window.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32,
                                                    i32, vp]

@@ -481,6 +481,10 @@ struct WindowProblem {
     const orbx_keypoint *q_from_kps;
     const float *scale;         // mvScaleFactors
     float th, du, dv;
+    // Fuse reprojection gate (ORBmatcher.cc:1266-1289): active when inv_sigma2 != NULL; u_right is then the KeyFrame's
+    // mvuRight (>= 0 = stereo observation) and qxr the predicted right coordinate
+    const float *inv_sigma2;
+    int chi2_fma;
     // 64x48 grid of the current frame built by k_grid_build: features sorted by (cell x, cell y, index)
     uint16_t *gstart;           // [64*48 + 1] offsets into gorder, cell id = x * 48 + y
     uint16_t *gorder;           // [n] feature indices
@@ -671,7 +675,18 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
                 }
                 const float dx = kp.x - w.x, dy = kp.y - w.y;
                 if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;
-                if (P.u_right && P.u_right[i] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
+                if (P.inv_sigma2) {  // Fuse: chi2 gate on the reprojection error
+                    const float ex = __fsub_rn(w.x, kp.x), ey = __fsub_rn(w.y, kp.y);
+                    if (P.u_right && P.u_right[i] >= 0) {
+                        const float er = __fsub_rn(w.xr, P.u_right[i]);
+                        const float e2 = P.chi2_fma ? __fmaf_rn(er, er, __fmaf_rn(ex, ex, __fmul_rn(ey, ey)))
+                                                    : __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                        if ((double)__fmul_rn(e2, P.inv_sigma2[kp.octave]) > 7.8) continue;
+                    } else {
+                        const float e2 = P.chi2_fma ? __fmaf_rn(ex, ex, __fmul_rn(ey, ey)) : __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                        if ((double)__fmul_rn(e2, P.inv_sigma2[kp.octave]) > 5.99) continue;
+                    }
+                } else if (P.u_right && P.u_right[i] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
                     const float er = fabsf(w.xr - P.u_right[i]);
                     if (er > w.r) continue;
                 }

@@ -914,3 +914,67 @@ extern "C" int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *desc
     ORBX_HIP(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Candidate loop of ORBmatcher::Fuse x2 (ORBmatcher.cc:1246-1306, 1405-1433): queries do not interact, so the device
+// returns the best feature per projected map point; the Replace / AddObservation logic stays in the adapter.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, const float *inv_level_sigma2, int n_q, const float *q_u,
+                                const float *q_v, const float *q_ur, const float *q_r, const int32_t *q_level, const uint8_t *q_desc,
+                                int strict_fp, int32_t *best_idx, int32_t *best_dist) {
+    if (!m || !kf || n_q < 0 || (n_q > 0 && (!q_u || !q_v || !q_r || !q_level || !q_desc || !best_idx || !best_dist))) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n_q; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    const int n = kf->n;
+    if (n == 0 || n_q == 0) return ORBX_OK;
+    if (n > 65535) return ORBX_E_TOO_LARGE;
+    ORBX_HIP(hipSetDevice(m->device));
+    const int nl = kf->nlevels;
+    size_t need = Arena::pad(28 * (size_t)n) + Arena::pad(32 * (size_t)n) + Arena::pad(4 * (size_t)n) + Arena::pad(4 * (size_t)nl) +
+                  Arena::pad(4 * (size_t)n_q) * 6 + Arena::pad(32 * (size_t)n_q) + Arena::pad(8 * (size_t)n_q * kTopK) + Arena::pad(4 * (size_t)n_q) +
+                  Arena::pad(sizeof(WindowProblem)) + Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)n) + 16 * 256 + 4096;
+    int r = m->arena.reserve(need);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    A.reset();
+    WindowProblem P;
+    memset(&P, 0, sizeof(P));
+    orbx_keypoint *dk = A.take<orbx_keypoint>(n);
+    uint8_t *dd = A.take<uint8_t>(32 * (size_t)n);
+    H2D(dk, kf->keypoints_un, 28 * (size_t)n); H2D(dd, kf->descriptors, 32 * (size_t)n);
+    P.kps = dk; P.desc = dd;
+    int32_t *dcnt = A.take<int32_t>(4);
+    const int32_t cnts[2] = {n, n_q};
+    H2D(dcnt, cnts, 8);
+    P.n_ptr = dcnt; P.nq_ptr = dcnt + 1;
+    if (kf->u_right) { float *p = A.take<float>(n); H2D(p, kf->u_right, 4 * (size_t)n); P.u_right = p; }
+    if (inv_level_sigma2) { float *p = A.take<float>(nl); H2D(p, inv_level_sigma2, 4 * (size_t)nl); P.inv_sigma2 = p; }
+    P.chi2_fma = strict_fp ? 0 : 1;
+    float *f3[3]; const float *h3[3] = {q_u, q_v, q_r};
+    for (int k = 0; k < 3; k++) { f3[k] = A.take<float>(n_q); H2D(f3[k], h3[k], 4 * (size_t)n_q); }
+    P.qx = f3[0]; P.qy = f3[1]; P.qr = f3[2];
+    std::vector<int32_t> qmin(n_q), qmax(n_q);
+    for (int i = 0; i < n_q; i++) { qmin[i] = q_level[i] - 1; qmax[i] = q_level[i]; }  // kpLevel<nPredictedLevel-1 || kpLevel>nPredictedLevel
+    int32_t *dmin = A.take<int32_t>(n_q), *dmax = A.take<int32_t>(n_q);
+    H2D(dmin, qmin.data(), 4 * (size_t)n_q); H2D(dmax, qmax.data(), 4 * (size_t)n_q);
+    P.qmin = dmin; P.qmax = dmax;
+    if (q_ur && kf->u_right) { float *p = A.take<float>(n_q); H2D(p, q_ur, 4 * (size_t)n_q); P.qxr = p; }
+    { uint8_t *p = A.take<uint8_t>(32 * (size_t)n_q); H2D(p, q_desc, 32 * (size_t)n_q); P.qdesc = p; }
+    P.keys = A.take<u64>((size_t)n_q * kTopK); P.meta = A.take<int32_t>(n_q);
+    P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n);
+    WindowProblem *dP = A.take<WindowProblem>(1);
+    H2D(dP, &P, sizeof(P));
+    GridParams g;
+    g.minx = kf->min_x; g.miny = kf->min_y;
+    g.inv_w = 64.0f / (kf->max_x - kf->min_x);
+    g.inv_h = 48.0f / (kf->max_y - kf->min_y);
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(64), 0, m->stream, dP, g);
+    hipLaunchKernelGGL(k_window_best2, dim3((n_q + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
+    std::vector<u64> keys((size_t)n_q * kTopK);
+    D2H(keys.data(), P.keys, 8 * (size_t)n_q * kTopK);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < n_q; i++) {
+        const u64 k = keys[(size_t)i * kTopK];
+        if (k != kNoKey) { best_idx[i] = (int32_t)(k & 0xffff); best_dist[i] = (int32_t)(k >> 32); }
+    }
+    return ORBX_OK;
+}

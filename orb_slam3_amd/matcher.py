@@ -266,3 +266,16 @@ class ORBmatcher:
         out = np.zeros(len(sp) - 1, np.int32)
         check(self._L.orbx_distinctive_descriptors(self._h, ptr(d), ptr(sp), len(sp) - 1, ptr(out)), "orbx_distinctive_descriptors")
         return out
+
+    # ---- matching core of Fuse x2 (ORBmatcher.cc:1148-1455) ----
+    def FuseSearch(self, KF: FrameView, q: dict, inv_level_sigma2=None, strict_fp: bool = False):
+        """q: u, v, ur, r, level, desc.  Returns (best_idx[nq], best_dist[nq])."""
+        fd = KF.c_struct()
+        nq = len(q["u"])
+        a = dict(u=_f32(q["u"]), v=_f32(q["v"]), ur=_f32(q.get("ur")), r=_f32(q["r"]), lv=_i32(q["level"]), d=_u8(q["desc"]))
+        isg = _f32(inv_level_sigma2)
+        bi = np.zeros(nq, np.int32)
+        bd = np.zeros(nq, np.int32)
+        check(self._L.orbx_fuse_search(self._h, C.byref(fd), ptr(isg), nq, ptr(a["u"]), ptr(a["v"]), ptr(a["ur"]), ptr(a["r"]),
+                                       ptr(a["lv"]), ptr(a["d"]), int(strict_fp), ptr(bi), ptr(bd)), "orbx_fuse_search")
+        return bi, bd

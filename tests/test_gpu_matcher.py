@@ -445,3 +445,26 @@ def test_distinctive_descriptors(oracle):
     want = oracle.distinctive_descriptors(desc, set_ptr)
     assert np.array_equal(got, want)
     assert got[len(sizes) - 7] == -1 and (got[:300] >= 0).all()
+
+
+def test_fuse_search(oracle, canvas1):
+    """Candidate loop of Fuse x2 (ORBmatcher.cc:1246-1306, 1405-1433): level gate, chi2 reprojection gate (mono 5.99 /
+    stereo 7.8), first minimum wins; with and without the gate, fused and strict float evaluation."""
+    import orb_slam3_amd as osa
+    ex, k0, d0, k1, d1 = _two_frames(canvas1)
+    sf = ex.GetScaleFactors()
+    isg = ex.GetInverseScaleSigmaSquares()
+    rng = np.random.default_rng(71)
+    n_q = len(k0)
+    lvl = k0["octave"]
+    q = dict(u=k0["x"] - 2.0 + rng.normal(0, 1.2, n_q).astype(np.float32), v=k0["y"] - 1.0 + rng.normal(0, 1.2, n_q).astype(np.float32),
+             ur=(k0["x"] - 20.0).astype(np.float32), r=(np.float32(3.0) * sf[lvl]).astype(np.float32), level=lvl, desc=d0)
+    u_right = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 18.0 + rng.normal(0, 1.0, len(k1)), -1.0).astype(np.float32)
+    grid = oracle.OracleGrid(k1, 0.0, 752.0, 0.0, 480.0)
+    m = osa.ORBmatcher()
+    for ur, sig, strict in ((None, isg, False), (u_right, isg, False), (u_right, isg, True), (None, None, False)):
+        F = osa.FrameView(k1, d1, 0.0, 752.0, 0.0, 480.0, sf, ur)
+        obi, obd = oracle.fuse_search(grid, d1, ur, sig, q, fma=not strict)
+        bi, bd = m.FuseSearch(F, q, sig, strict)
+        assert np.array_equal(bi, obi) and np.array_equal(bd, obd), (ur is None, sig is None, strict)
+        assert (bd <= 50).sum() > 100
