@@ -186,12 +186,83 @@ public:
         return r;
     }
 
+    // Matching core of Fuse(KeyFrame*, vpMapPoints, th, bRight) (ORBmatcher.cc:1148-1337) and Fuse(KeyFrame*, Sim3f&, vpPoints, th,
+    // vpReplacePoint) (:1339-1455).  The caller projects the map points exactly as :1186-1244 / :1376-1403 do (host float math), passes
+    // the survivors, and afterwards runs the reference's own tail on (bestIdx[i], bestDist[i] <= TH_LOW): Replace / AddObservation /
+    // AddMapPoint (:1309-1330) or vpReplacePoint[iMP] = pMPinKF (:1436-1449).  mvInvLevelSigma2 = nullptr selects the Sim3 overload
+    // (no chi2 gate).
+    struct FuseQueries {
+        std::vector<float> u, v, ur, radius;   // radius = th * pKF->mvScaleFactors[nPredictedLevel]
+        std::vector<int32_t> nPredictedLevel;
+        std::vector<uint8_t> descriptors;      // 32 B each (pMP->GetDescriptor())
+    };
+    void FuseSearch(const FrameView &KF, const float *mvInvLevelSigma2, const FuseQueries &q, std::vector<int32_t> &bestIdx,
+                    std::vector<int32_t> &bestDist, bool strictFloat = false) {
+        const int nq = (int)q.u.size();
+        bestIdx.assign(nq, -1); bestDist.assign(nq, 256);
+        orbx_frame_desc fd = KF.c();
+        const int r = orbx_fuse_search(m_, &fd, mvInvLevelSigma2, nq, q.u.data(), q.v.data(), q.ur.empty() ? nullptr : q.ur.data(),
+                                       q.radius.data(), q.nPredictedLevel.data(), q.descriptors.data(), strictFloat ? 1 : 0, bestIdx.data(),
+                                       bestDist.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_fuse_search: ") + orbx_status_string(r));
+    }
+
+    // MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403) for a batch of map points: the observations' descriptors of map
+    // point p are rows [setPtr[p], setPtr[p+1]) of `descriptors`; bestIdx[p] is the row offset (within the set) the reference keeps.
+    void ComputeDistinctiveDescriptors(const std::vector<uint8_t> &descriptors, const std::vector<int32_t> &setPtr, std::vector<int32_t> &bestIdx) {
+        const int n_sets = (int)setPtr.size() - 1;
+        bestIdx.assign(n_sets > 0 ? n_sets : 0, -1);
+        if (n_sets <= 0) return;
+        const int r = orbx_distinctive_descriptors(m_, descriptors.data(), setPtr.data(), n_sets, bestIdx.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_distinctive_descriptors: ") + orbx_status_string(r));
+    }
+
+    // Frame::ComputeStereoMatches (Frame.cc:811-981) on host vectors: mvuRight / mvDepth out.  pyrLeft/pyrRight[l] are the level ROI
+    // origins of the two extractors' mvImagePyramid (host copies, e.g. ORBextractor::GetPyramidLevel).  For the device-resident
+    // batched form (no pyramid transfer) use orbx_stereo_batch_device / orbx_stereo_batch_download on the two extractors.
+    int ComputeStereoMatches(const orbx_keypoint *mvKeys, const uint8_t *mDescriptors, int N, const orbx_keypoint *mvKeysRight,
+                             const uint8_t *mDescriptorsRight, int Nr, const float *mvScaleFactors, const float *mvInvScaleFactors, int nlevels,
+                             const uint8_t *const *pyrLeft, const uint8_t *const *pyrRight, const int32_t *pyrW, const int32_t *pyrH,
+                             const size_t *pyrStride, float mbf, float mb, std::vector<float> &mvuRight, std::vector<float> &mvDepth) {
+        mvuRight.assign(N, -1.0f); mvDepth.assign(N, -1.0f);
+        const int r = orbx_compute_stereo_matches(m_, mvKeys, mDescriptors, N, mvKeysRight, mDescriptorsRight, Nr, mvScaleFactors, mvInvScaleFactors,
+                                                  nlevels, pyrLeft, pyrRight, pyrW, pyrH, pyrStride, mbf, mb, mvuRight.data(), mvDepth.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_compute_stereo_matches: ") + orbx_status_string(r));
+        return r;
+    }
+
     orbx_matcher *handle() { return m_; }
 
 protected:
     float mfNNratio;
     bool mbCheckOrientation;
     orbx_matcher *m_ = nullptr;
+};
+
+// ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) flattened for the device: the k-ary tree as CSR children, one
+// 32-byte descriptor and one word id (-1 for inner nodes) per node.  transform() is the tree descent of
+// TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1151-1193)
+// as called from Frame::ComputeBoW (Frame.cc:462-470) / KeyFrame::ComputeBoW: per feature the word id and the node id `levelsup`
+// levels above the leaf; the caller folds them into BowVector (addWeight) and FeatureVector (addFeature) in feature order.
+class ORBVocabularyDevice {
+public:
+    ORBVocabularyDevice(int L, const std::vector<int32_t> &childPtr, const std::vector<int32_t> &childIdx, const std::vector<uint8_t> &nodeDesc,
+                        const std::vector<int32_t> &wordId, int device = 0) {
+        const int st = orbx_vocabulary_create(device, L, (int)wordId.size(), childPtr.data(), childIdx.data(), nodeDesc.data(), wordId.data(), &v_);
+        if (st != ORBX_OK) throw std::runtime_error(std::string("orbx_vocabulary_create: ") + orbx_status_string(st));
+    }
+    ~ORBVocabularyDevice() { orbx_vocabulary_destroy(v_); }
+    ORBVocabularyDevice(const ORBVocabularyDevice &) = delete;
+    ORBVocabularyDevice &operator=(const ORBVocabularyDevice &) = delete;
+    void transform(ORBmatcher &m, const uint8_t *descriptors, int n, int levelsup, std::vector<int32_t> &wordId, std::vector<int32_t> &nodeId) const {
+        wordId.assign(n, -1); nodeId.assign(n, -1);
+        if (n == 0) return;
+        const int r = orbx_bow_transform(m.handle(), v_, descriptors, n, levelsup, wordId.data(), nodeId.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_bow_transform: ") + orbx_status_string(r));
+    }
+
+private:
+    orbx_vocabulary *v_ = nullptr;
 };
 
 }  // namespace ORB_SLAM3

@@ -49,5 +49,22 @@ int main(int argc, char **argv) {
     int self = 0;
     for (size_t i = 0; i < match.size(); i++) self += (match[i] == (int)i);
     std::printf("matches %d self %d\n", nm, self);
+    // Fuse matching core: the frame's own features as projected map points, Sim3 form (no chi2 gate)
+    ORB_SLAM3::ORBmatcher::FuseQueries fq;
+    for (size_t i = 0; i < kps.size(); i++) {
+        fq.u.push_back(kps[i].x); fq.v.push_back(kps[i].y); fq.radius.push_back(3.0f * sf[kps[i].octave]); fq.nPredictedLevel.push_back(kps[i].octave);
+    }
+    fq.descriptors = desc;
+    std::vector<int32_t> bi, bd;
+    matcher.FuseSearch(F, nullptr, fq, bi, bd);
+    int fself = 0;
+    for (size_t i = 0; i < bi.size(); i++) fself += (bd[i] == 0);
+    std::printf("fuse zero-distance %d of %zu\n", fself, bi.size());
+    // ComputeDistinctiveDescriptors on sets of 5 consecutive descriptors
+    std::vector<int32_t> setPtr, best;
+    for (size_t i = 0; i + 5 <= kps.size(); i += 5) setPtr.push_back((int32_t)i);
+    setPtr.push_back((int32_t)(kps.size() / 5 * 5));
+    matcher.ComputeDistinctiveDescriptors(desc, setPtr, best);
+    std::printf("distinctive sets %zu hash %016llx\n", best.size(), (unsigned long long)fnv(best.data(), best.size() * 4));
     return 0;
 }

@@ -227,6 +227,10 @@ def test_cpp_adapter_end_to_end(canvas1, tmp_path):
     assert line[1] == f"level3 {lvl.shape[1] - 38}x{lvl.shape[0] - 38} {fnv(lvl.tobytes()):016x}"
     nm, self_ = int(line[2].split()[1]), int(line[2].split()[3])
     assert nm > 900 and self_ == nm   # every feature matches itself at distance 0 (first minimum), none is lost to the filter
+    assert line[3] == f"fuse zero-distance {len(kps)} of {len(kps)}"
+    ptr = np.arange(0, len(kps) // 5 * 5 + 1, 5, dtype=np.int32)
+    best = ob.distinctive_descriptors(desc, ptr)
+    assert line[4] == f"distinctive sets {len(best)} hash {fnv(best.astype(np.int32).tobytes()):016x}"
 
 
 @pytest.mark.parametrize("w,h,nf,scale,nlevels,ini,mn", [
