@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict__ lv, int level,
                                                     const ResizeTap *__restrict__ xtab,
-                                                    const ResizeTap *__restrict__ ytab, uint8_t *__restrict__ pyr,
+                                                    const ResizeTap *__restrict__ ytab,
+                                                    const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr,
                                                     size_t pyr_frame_stride) {
     const LevelInfo L = lv[level];
     const LevelInfo P = lv[level - 1];
@@ -84,17 +85,39 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict_
     const uint8_t *S1 = proi + (size_t)sy1 * P.pitch;
     const int b0 = ty.c0, b1 = ty.c1;
     uint32_t out = 0;
+    const uint4 gc = *reinterpret_cast<const uint4 *>(&xg[L.xg_off + wi].cc[0]);
+    const uint4 gh = *reinterpret_cast<const uint4 *>(&xg[L.xg_off + wi]);  // base, sel, valid
+    if (gh.z) {
+        // all eight source bytes of a row in one unaligned 8-byte load; v_perm_b32 picks the left / right taps
+        uint2 r0, r1;
+        __builtin_memcpy(&r0, S0 + (int)gh.x, 8);
+        __builtin_memcpy(&r1, S1 + (int)gh.x, 8);
+        const uint32_t selr = gh.y + 0x01010101u;
+        const uint32_t l0 = __builtin_amdgcn_perm(r0.y, r0.x, gh.y), q0 = __builtin_amdgcn_perm(r0.y, r0.x, selr);
+        const uint32_t l1 = __builtin_amdgcn_perm(r1.y, r1.x, gh.y), q1 = __builtin_amdgcn_perm(r1.y, r1.x, selr);
+        const uint32_t cc[4] = {gc.x, gc.y, gc.z, gc.w};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int x = wi * 4 + k - kRoiX;
-        if (x >= -kEdge && x < L.w + kEdge) {
-            const ResizeTap tx = xtab[L.xtab_off + reflect101(x, L.w)];
-            // when ofs+1 == P.w the tap c1 is 0 and the byte read is the (valid) ring pixel
-            const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
-            const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
+        for (int k = 0; k < 4; k++) {
+            const int c0 = (int)(cc[k] & 0xffffu), c1 = (int)(cc[k] >> 16);
+            const int h0 = (int)((l0 >> (8 * k)) & 0xff) * c0 + (int)((q0 >> (8 * k)) & 0xff) * c1;
+            const int h1 = (int)((l1 >> (8 * k)) & 0xff) * c0 + (int)((q1 >> (8 * k)) & 0xff) * c1;
             int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
             v = min(max(v, 0), 255);
             out |= (uint32_t)v << (8 * k);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = wi * 4 + k - kRoiX;
+            if (x >= -kEdge && x < L.w + kEdge) {
+                const ResizeTap tx = xtab[L.xtab_off + reflect101(x, L.w)];
+                // when ofs+1 == P.w the tap c1 is 0 and the byte read is the (valid) ring pixel
+                const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
+                const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
+                int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                out |= (uint32_t)v << (8 * k);
+            }
         }
     }
     uint8_t *drow = frame + L.off + (size_t)py * L.pitch;
@@ -155,7 +178,8 @@ __device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int p
 // atomic; (2) exact score only for queued pixels, all lanes busy; (3) NMS; (4) ordered ballot compaction.
 // grid (total_cells, B), block 256, dynamic LDS: pixel tile + score tile + queue
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_fast_cells(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
                                                     const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
                                                     int32_t *__restrict__ cellcnt, int total_cells,
                                                     uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
@@ -194,17 +218,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
         const uint8_t *src = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + (iniX - ax);
         const int nd = pp >> 2;
         const uint32_t rcpd = ((1u << 20) + (uint32_t)nd - 1u) / (uint32_t)nd;
-        for (int i = tid; i < rows * nd; i += 256) {
+        for (int i = tid; i < rows * nd; i += TPB) {
             const int r = (int)(((uint32_t)i * rcpd) >> 20), c = i - r * nd;
             reinterpret_cast<uint32_t *>(pix)[i] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * L.pitch + 4 * c);
         }
-        for (int i = tid; i < (((ih + 2) * sp + 3) >> 2); i += 256) reinterpret_cast<uint32_t *>(sco)[i] = 0;
+        for (int i = tid; i < (((ih + 2) * sp + 3) >> 2); i += TPB) reinterpret_cast<uint32_t *>(sco)[i] = 0;
         if (tid == 0) ctrl[4] = 0;
     }
     __syncthreads();
 
     // phase 1: necessary condition at minTh on the antipodal pairs (0,8) (4,12) (2,10) (6,14); branch-free
-    for (int i0 = 0; i0 < n; i0 += 256) {
+    for (int i0 = 0; i0 < n; i0 += TPB) {
         const int i = i0 + tid;
         int pass = 0;
         if (i < n) {
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
 
     // phase 2: exact score of the queued pixels
     const int qn = ctrl[4];
-    for (int e = tid; e < qn; e += 256) {
+    for (int e = tid; e < qn; e += TPB) {
         const int i = queue[e];
         const int y = (int)(((uint32_t)i * rcp) >> 20), x = i - y * iw;
         int s = fast_score16(pix + (y + 3) * pp + x + 3 + ax, pp);
@@ -243,7 +267,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
     // survivors (few per cell) go to an unordered LDS list as (linear index << 8 | score)
     uint32_t *surv = reinterpret_cast<uint32_t *>(pix);  // the pixel tile is dead after phase 2
     int any_ini = 0;
-    for (int e0 = 0; e0 < qn; e0 += 256) {
+    for (int e0 = 0; e0 < qn; e0 += TPB) {
         const int e = e0 + tid;
         int keep = 0, s = 0, i = 0;
         if (e < qn) {
@@ -271,7 +295,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
     // phase 4: ordered (row-major) emission: rank of a selected survivor = number of selected survivors before it
     uint32_t *slot = cellent + (size_t)f * ent_frame_stride + L.cand_off + (size_t)cell * L.cell_cap;
     int total = 0;
-    for (int e0 = 0; e0 < ns; e0 += 256) {
+    for (int e0 = 0; e0 < ns; e0 += TPB) {
         const int e = e0 + tid;
         if (e < ns) {
             const uint32_t me = surv[e];
@@ -288,10 +312,187 @@ __global__ __launch_bounds__(256) void k_fast_cells(const LevelInfo *__restrict_
             }
         }
     }
-    if (tid == 0) {
-        for (int k = 0; k < ns; k++) total += ((int)(surv[k] & 0xff) >= thr);
-        *cnt_out = total;
+    if (tid < 64) {  // first wave counts the selected survivors
+        for (int k = tid; k < ns; k += 64) total += ((int)(surv[k] & 0xff) >= thr);
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o);
+        if (tid == 0) *cnt_out = total;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_fast_wave: the same per-cell FAST + NMS as k_fast_cells with ONE WAVE per cell (no barriers, no atomics) and the
+// necessary-condition test evaluated for four horizontally adjacent pixels per lane with packed 16-bit min/max
+// (v_pk_max_u16 / v_pk_min_u16): the kernel is VALU-issue bound, so instructions per pixel is what counts.
+// Used when every level's cell sub-image fits a 64-byte LDS pitch (wCell + 7 <= 64); k_fast_cells otherwise.
+//   LDS: pixel tile rows x 64 (sub-image column s at byte s + 1, interior pixel x at byte x + 4, so 4-pixel groups are
+//   dword aligned), score tile (ih + 2) x 64 with a zero apron, queue of (y << 8 | x) u16 in row-major order.
+// grid (total_cells, B), block 64
+// ---------------------------------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 as_pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ u16x2 pk_even(uint32_t v) { return as_pk(__builtin_amdgcn_perm(0u, v, 0x0c020c00u)); }  // bytes 0, 2
+__device__ __forceinline__ u16x2 pk_odd(uint32_t v) { return as_pk(__builtin_amdgcn_perm(0u, v, 0x0c030c01u)); }   // bytes 1, 3
+__device__ __forceinline__ u16x2 pk_max(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ u16x2 pk_min(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
+
+// nonzero 16-bit half <=> that pixel passes the antipodal-pair test at threshold t (both polarities)
+__device__ __forceinline__ uint32_t quick_pairs(u16x2 c, u16x2 p0, u16x2 p8, u16x2 p4, u16x2 p12, u16x2 p2, u16x2 p10, u16x2 p6,
+                                                u16x2 p14, u16x2 t2) {
+    const u16x2 mb = pk_min(pk_min(pk_max(p0, p8), pk_max(p4, p12)), pk_min(pk_max(p2, p10), pk_max(p6, p14)));
+    const u16x2 md = pk_max(pk_max(pk_min(p0, p8), pk_min(p4, p12)), pk_max(pk_min(p2, p10), pk_min(p6, p14)));
+    const u16x2 hi = c + t2;
+    const u16x2 lo = __builtin_elementwise_sub_sat(c, t2);
+    return as_u32(__builtin_elementwise_sub_sat(mb, hi)) | as_u32(__builtin_elementwise_sub_sat(lo, md));
+}
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_add(int acc, int v) {
+    return acc + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false);
+}
+// inclusive prefix sum over the 64 lanes of a wave (row_shr 1/2/4/8, then row_bcast15 / row_bcast31)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v = dpp_add<0x111, 0xf>(v, v);
+    v = dpp_add<0x112, 0xf>(v, v);
+    v = dpp_add<0x114, 0xf>(v, v);
+    v = dpp_add<0x118, 0xf>(v, v);
+    v = dpp_add<0x142, 0xa>(v, v);
+    v = dpp_add<0x143, 0xc>(v, v);
+    return v;
+}
+
+constexpr int kFwPitch = 64;
+
+__global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+                                                  const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                  int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
+                                                  size_t ent_frame_stride, int iniTh, int minTh) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const TileRef t = tiles[blockIdx.x];
+    const int f = blockIdx.y;
+    const LevelInfo L = lv[t.level];
+    const int lane = threadIdx.x;
+    const int cell = t.ti * L.nCols + t.tj;
+    int32_t *cnt_out = cellcnt + (size_t)f * total_cells + L.cell_base + cell;
+
+    const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+    const int iniX = kBorder + t.tj * L.wCell, iniY = kBorder + t.ti * L.hCell;
+    const int maxX = min(iniX + L.wCell + 6, maxBX), maxY = min(iniY + L.hCell + 6, maxBY);
+    const int cols = maxX - iniX, rows = maxY - iniY;
+    const int iw = cols - 6, ih = rows - 6;
+    if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || iw <= 0 || ih <= 0) {  // :813 / :821 skip rules
+        if (lane == 0) *cnt_out = 0;
+        return;
+    }
+    uint8_t *pix = smem;                                             // rows * 64 (+16 slack)
+    uint8_t *sco = pix + rows * kFwPitch + 16;                       // (ih + 2) * 64
+    uint16_t *queue = reinterpret_cast<uint16_t *>(sco + (ih + 2) * kFwPitch);  // iw * ih entries
+
+    {   // phase 0: 16 lanes per row, (unaligned) dword loads starting one byte left of the sub-image
+        const uint8_t *src = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1;
+        const int c = lane & 15, nd = (cols + 4) >> 2;
+        if (c < nd) {
+            const uint8_t *p = src + (size_t)(lane >> 4) * L.pitch + 4 * c;
+            for (int r = lane >> 4; r < rows; r += 4, p += 4 * (size_t)L.pitch) {
+                uint32_t v;
+                __builtin_memcpy(&v, p, 4);
+                *reinterpret_cast<uint32_t *>(pix + r * kFwPitch + 4 * c) = v;
+            }
+        }
+        for (int i = lane; i < (ih + 2) * (kFwPitch / 4); i += 64) reinterpret_cast<uint32_t *>(sco)[i] = 0;
+    }
+    __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
+
+    // phase 1: antipodal-pair test at minTh, four pixels per lane; passing pixels are queued in row-major order
+    int qn = 0;
+    {
+        const int G = (iw + 3) >> 2, NG = G * ih;
+        const uint32_t rcpG = ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G;
+        const u16x2 t2 = as_pk((uint32_t)minTh * 0x00010001u);
+        for (int i0 = 0; i0 < NG; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < NG;
+            const int ii = act ? i : 0;
+            const int y = (int)(((uint32_t)ii * rcpG) >> 20), gq = ii - y * G;
+            const uint32_t *A = reinterpret_cast<const uint32_t *>(pix + y * kFwPitch + 4 * gq + 4);  // row y-3 of the centre row y+3
+            const uint32_t r8 = A[0], r0 = A[6 * 16];
+            const uint32_t aL = A[1 * 16 - 1], aC = A[1 * 16], aR = A[1 * 16 + 1];    // centre row - 2
+            const uint32_t cL = A[3 * 16 - 1], cC = A[3 * 16], cR = A[3 * 16 + 1];    // centre row
+            const uint32_t bL = A[5 * 16 - 1], bC = A[5 * 16], bR = A[5 * 16 + 1];    // centre row + 2
+            const uint32_t r4 = __builtin_amdgcn_alignbyte(cR, cC, 3), r12 = __builtin_amdgcn_alignbyte(cC, cL, 1);
+            const uint32_t r2 = __builtin_amdgcn_alignbyte(bR, bC, 2), r14 = __builtin_amdgcn_alignbyte(bC, bL, 2);
+            const uint32_t r6 = __builtin_amdgcn_alignbyte(aR, aC, 2), r10 = __builtin_amdgcn_alignbyte(aC, aL, 2);
+            const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), pk_even(r4), pk_even(r12), pk_even(r2), pk_even(r10),
+                                            pk_even(r6), pk_even(r14), t2);   // pixels 0 (low half) and 2
+            const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), pk_odd(r4), pk_odd(r12), pk_odd(r2), pk_odd(r10),
+                                            pk_odd(r6), pk_odd(r14), t2);     // pixels 1 and 3
+            const uint32_t one = 0x00010001u;
+            const uint32_t z = as_u32(pk_min(as_pk(fe), as_pk(one))) | (as_u32(pk_min(as_pk(fo), as_pk(one))) << 1);  // bits 0,1,16,17
+            uint32_t m4 = (z | (z >> 14)) & 0xfu;
+            const int over = max(4 * gq + 3 - (iw - 1), 0);  // pixels of the last group beyond the interior
+            m4 &= act ? (0xfu >> over) : 0u;
+            const int c = __popc(m4);
+            const int incl = wave_incl_scan(c);
+            int pos = qn + incl - c;
+            const uint32_t e0 = ((uint32_t)y << 8) | (uint32_t)(4 * gq);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (m4 & (1u << k)) { queue[pos] = (uint16_t)(e0 + k); pos++; }
+            }
+            qn += __builtin_amdgcn_readlane(incl, 63);
+        }
+    }
+    __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
+
+    // phase 2: exact score of the queued pixels
+    for (int e = lane; e < qn; e += 64) {
+        const int q = queue[e];
+        const int y = q >> 8, x = q & 0xff;
+        int s = fast_score16(pix + (y + 3) * kFwPitch + x + 4, kFwPitch);
+        s = (s >= minTh) ? s : 0;
+        sco[(y + 1) * kFwPitch + x + 1] = (uint8_t)s;
+    }
+    __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
+
+    // phase 3: NMS over the queued pixels, strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); survivors
+    // stay in row-major order as (y << 16 | x << 8 | score)
+    uint32_t *surv = reinterpret_cast<uint32_t *>(pix);  // the pixel tile is dead after phase 2
+    int ns = 0;
+    bool any_ini = false;
+    for (int e0 = 0; e0 < qn; e0 += 64) {
+        const int e = e0 + lane;
+        int keep = 0, s = 0, q = 0;
+        if (e < qn) {
+            q = queue[e];
+            const uint8_t *p = sco + ((q >> 8) + 1) * kFwPitch + (q & 0xff) + 1;
+            s = p[0];
+            keep = (s > 0) & (s > p[-1]) & (s > p[1]) & (s > p[-kFwPitch - 1]) & (s > p[-kFwPitch]) & (s > p[-kFwPitch + 1]) &
+                   (s > p[kFwPitch - 1]) & (s > p[kFwPitch]) & (s > p[kFwPitch + 1]);
+        }
+        const unsigned long long b = __ballot(keep != 0);
+        any_ini |= __ballot(keep && s >= iniTh) != 0ull;
+        if (keep) surv[ns + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)q << 8) | (uint32_t)s;
+        ns += __popcll(b);
+    }
+    __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
+
+    // phase 4: emission in row-major order of the survivors at the cell's threshold
+    const int thr = any_ini ? iniTh : minTh;
+    uint32_t *slot = cellent + (size_t)f * ent_frame_stride + L.cand_off + (size_t)cell * L.cell_cap;
+    int total = 0;
+    for (int e0 = 0; e0 < ns; e0 += 64) {
+        const int e = e0 + lane;
+        uint32_t me = 0;
+        if (e < ns) me = surv[e];
+        const int s = (int)(me & 0xff);
+        const bool sel = e < ns && s >= thr;
+        const unsigned long long b = __ballot(sel);
+        if (sel) slot[total + __popcll(b & ((1ull << lane) - 1ull))] =
+            pack_key((int)((me >> 8) & 0xff) + 3 + t.tj * L.wCell, (int)(me >> 16) + 3 + t.ti * L.hCell, s);
+        total += __popcll(b);
+    }
+    if (lane == 0) *cnt_out = total;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -51,11 +51,13 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     const int nl = ex->prm.nlevels;
     std::vector<LevelInfo> lv(nl);
     std::vector<ResizeTap> xtab, ytab;
+    std::vector<ResizeGroup> xgtab;
     std::vector<TileRef> fast_tiles, blur_tiles;
     size_t pyr_off = 0, blur_off = 0;
     uint32_t cand_off = 0, lvl_off = 0;
     int cell_base = 0, cap = 0, max_pool = 0;
-    size_t fast_lds = 0;
+    size_t fast_lds = 0, fast_wave_lds = 0;
+    bool fast_wave = true;
     for (int l = 0; l < nl; l++) {
         LevelInfo &L = lv[l];
         memset(&L, 0, sizeof(L));
@@ -124,6 +126,30 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
             };
             build(P.w, L.w, true, xtab);
             build(P.h, L.h, false, ytab);
+            L.xg_off = (uint32_t)xgtab.size();
+            for (int wi = 0; wi < L.pitch / 4; wi++) {
+                ResizeGroup g;
+                memset(&g, 0, sizeof(g));
+                int lo = INT32_MAX, hi = INT32_MIN, ofs[4] = {0, 0, 0, 0};
+                bool in[4];
+                for (int k = 0; k < 4; k++) {
+                    const int x = wi * 4 + k - kRoiX;
+                    in[k] = x >= -kEdge && x < L.w + kEdge;
+                    if (!in[k]) continue;
+                    const int rx = x < 0 ? -x : (x >= L.w ? 2 * L.w - 2 - x : x);  // REFLECT_101
+                    const ResizeTap &t = xtab[L.xtab_off + rx];
+                    ofs[k] = t.ofs;
+                    g.cc[k] = (uint32_t)(uint16_t)t.c0 | ((uint32_t)(uint16_t)t.c1 << 16);
+                    lo = std::min(lo, t.ofs); hi = std::max(hi, t.ofs);
+                }
+                if (lo == INT32_MAX) { g.base = 0; g.valid = 1; }
+                else {
+                    g.base = lo;
+                    g.valid = (hi + 1 - lo <= 7) ? 1 : 0;
+                    for (int k = 0; k < 4; k++) g.sel |= (uint32_t)(in[k] ? (ofs[k] - lo) & 7 : 0) << (8 * k);
+                }
+                xgtab.push_back(g);
+            }
         }
         for (int i = 0; i < L.nRows; i++)
             for (int j = 0; j < L.nCols; j++) fast_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
@@ -135,6 +161,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         const size_t lds = 32 + ((rows * pp + 15) & ~(size_t)15) + ((((size_t)(L.hCell + 2) * (L.wCell + 2)) + 15) & ~(size_t)15) +
                            2 * (size_t)L.wCell * L.hCell + 64;
         fast_lds = std::max(fast_lds, lds);
+        if (L.wCell + 6 > 63) fast_wave = false;  // k_fast_wave: the sub-image (+1 byte) must fit its 64-byte LDS pitch
+        fast_wave_lds = std::max(fast_wave_lds, (size_t)(rows * 64 + 16 + (L.hCell + 2) * 64 + 2 * L.wCell * L.hCell + 16));
     }
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
 
@@ -149,6 +177,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_lv, sizeof(LevelInfo) * nl);
     ENS(ex->d_xtab, sizeof(ResizeTap) * std::max<size_t>(xtab.size(), 1));
     ENS(ex->d_ytab, sizeof(ResizeTap) * std::max<size_t>(ytab.size(), 1));
+    ENS(ex->d_xgtab, sizeof(ResizeGroup) * std::max<size_t>(xgtab.size(), 1));
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
     ENS(ex->d_pyr, pyr_off * B);
@@ -170,13 +199,14 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ORBX_HIP(hipMemcpy(ex->d_lv.p, lv.data(), sizeof(LevelInfo) * nl, hipMemcpyHostToDevice));
     if (!xtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xtab.p, xtab.data(), sizeof(ResizeTap) * xtab.size(), hipMemcpyHostToDevice));
     if (!ytab.empty()) ORBX_HIP(hipMemcpy(ex->d_ytab.p, ytab.data(), sizeof(ResizeTap) * ytab.size(), hipMemcpyHostToDevice));
+    if (!xgtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xgtab.p, xgtab.data(), sizeof(ResizeGroup) * xgtab.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_tiles.p, blur_tiles.data(), sizeof(TileRef) * blur_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
     ex->lv = lv;
     ex->width = width; ex->height = height; ex->batch_cap = B;
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
-    ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds;
+    ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave_lds = fast_wave_lds; ex->fast_wave = fast_wave;
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size();
     ex->last_batch = 0;
     return ORBX_OK;
@@ -218,7 +248,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         const LevelInfo &L = ex->lv[l];
         dim3 grid(((L.pitch / 4) * (L.h + 2 * kEdge) + 255) / 256, n);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, d_lv, l, (const ResizeTap *)ex->d_xtab.p,
-                           (const ResizeTap *)ex->d_ytab.p, pyr, ex->pyr_frame);
+                           (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame);
     }
     {
         // blur depends only on the pyramid and is needed only by k_describe: run it beside FAST / quad-tree
@@ -238,9 +268,19 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     {
         ProfScope ps(ex, K_FAST);
         const int ini = std::min(std::max(ex->prm.ini_th_fast, 0), 255), mn = std::min(std::max(ex->prm.min_th_fast, 0), 255);
-        hipLaunchKernelGGL(k_fast_cells, dim3(ex->n_fast_tiles, n), dim3(256), ex->fast_lds, st, d_lv,
-                           (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,
-                           ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn);
+        static const int tpb = [] { const char *v = getenv("ORBX_FAST_TPB"); return v ? atoi(v) : 0; }();
+#define ORBX_FAST_LAUNCH(T)                                                                                                  \
+    hipLaunchKernelGGL(k_fast_cells<T>, dim3(ex->n_fast_tiles, n), dim3(T), ex->fast_lds, st, d_lv,                           \
+                       (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, \
+                       ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn)
+        if (ex->fast_wave && tpb == 0)
+            hipLaunchKernelGGL(k_fast_wave, dim3(ex->n_fast_tiles, n), dim3(64), ex->fast_wave_lds, st, d_lv,
+                               (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,
+                               ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn);
+        else if (tpb == 256) ORBX_FAST_LAUNCH(256);
+        else if (tpb == 128) ORBX_FAST_LAUNCH(128);
+        else ORBX_FAST_LAUNCH(64);
+        if (0) ORBX_FAST_LAUNCH(64);
     }
     {
         ProfScope ps(ex, K_OCTREE);

@@ -43,6 +43,7 @@ struct LevelInfo {
     float scale;             // mvScaleFactor[level]
     float size;              // (float)(int)(31*scale)
     uint32_t xtab_off, ytab_off;  // offsets into the resize tables
+    uint32_t xg_off;         // offset into the ResizeGroup table (pitch/4 entries per level)
     int32_t pool;            // quad-tree node pool size
 };
 
@@ -50,6 +51,17 @@ struct LevelInfo {
 struct ResizeTap {
     int32_t ofs;
     int16_t c0, c1;
+};
+
+// Four horizontally adjacent output pixels (one dword of a padded row) of the bilinear resize: all eight source bytes of a
+// row lie inside [base, base+8), sel holds the byte offset of each pixel's left tap (v_perm_b32 selector), cc the Q11
+// coefficient pairs (c0 | c1 << 16; 0 for pixels outside the ring).  valid = 0: offsets do not fit (scale factor > 2).
+struct ResizeGroup {
+    int32_t base;
+    uint32_t sel;
+    uint32_t valid;
+    uint32_t pad;
+    uint32_t cc[4];
 };
 
 struct TileRef {  // blockIdx.x -> (level, tile) mapping for multi-level launches

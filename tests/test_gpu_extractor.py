@@ -281,3 +281,28 @@ def test_reconfigure_between_shapes(canvas1):
             mono, kps, desc = ex.download(t)
             omono, okps, odesc = oex.extract(frames[t], lap=(0, 0))
             assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (nb, t)
+
+
+def test_generic_fast_kernel_fallback(tmp_path):
+    """k_fast_cells (one 256-thread workgroup per cell, any cell size) is the fallback of the single-wave k_fast_wave;
+    force it through ORBX_FAST_TPB in a fresh process and compare with the oracle."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import numpy as np, sys\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "import orb_slam3_amd as osa\n"
+        "from orb_slam3_amd import synth\n"
+        "from oracle import oracle_binding as ob\n"
+        "img = synth.make_test_image(21, 640, 400)\n"
+        "m, k, d = osa.ORBextractor(800, 1.2, 8, 20, 7)(img, None, (0, 0))\n"
+        "om, ok, od = ob.OracleExtractor(800, 1.2, 8, 20, 7).extract(img, lap=(0, 0))\n"
+        "assert m == om and np.array_equal(k, ok) and np.array_equal(d, od), (len(k), len(ok))\n"
+        "print('same', len(k))\n")
+    for tpb in ("256", "64"):
+        import os
+        env = dict(os.environ, ORBX_FAST_TPB=tpb)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
