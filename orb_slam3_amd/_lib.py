@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
     L.orbx_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32]
     L.orbx_debug_level_blurred.argtypes = [vp, i32, i32, vp, sz]
     L.orbx_debug_sort_nodes.argtypes = [i32, vp, vp, i32, vp]
+    L.orbx_debug_sort_nodes_par.argtypes = [i32, vp, vp, i32, vp, vp]
     L.orbx_profile_enable.argtypes = [vp, i32]
     L.orbx_profile_read.argtypes = [vp, vp, vp, vp, i32]
     L.orbx_matcher_create.argtypes = [i32, C.POINTER(vp)]

@@ -502,6 +502,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
 }  // namespace orbx
 
 #include "octree.hip.h"
+#include "octree_par.hip.h"
 
 namespace orbx {
 

@@ -58,11 +58,12 @@ struct orbx_extractor {
     int total_cells = 0, cap = 0, max_pool = 0;
     size_t fast_lds = 0;
     size_t fast_wave_lds = 0;   // k_fast_wave
+    bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
     bool fast_wave = true;      // every level's cell fits k_fast_wave's fixed LDS pitch
     int n_fast_tiles = 0, n_blur_tiles = 0;
     // device memory
     DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_blur_tiles, d_dc;
-    DevBuf d_pyr, d_blur, d_cellcnt, d_cellent, d_keys0, d_keys1, d_lvlkp, d_lvlcnt, d_candtot, d_work;
+    DevBuf d_pyr, d_blur, d_cellcnt, d_cellent, d_keys0, d_keys1, d_nof0, d_nof1, d_lvlkp, d_lvlcnt, d_candtot, d_work;
     DevBuf d_kps, d_desc, d_count, d_mono, d_err, d_img;
     DevBuf d_mkey1, d_mkey2, d_mocc, d_mentries, d_mprobs, d_mres, d_mscale, d_mgrid;  // batched frame-to-frame matcher scratch
     // pinned host staging

@@ -1,0 +1,658 @@
+// octree_par.hip.h -- k_octree_par: DistributeOctTree (/root/reference/src/ORBextractor.cc:555-779) with every pass of the
+// reference's control flow evaluated data-parallel by one wave per (frame, level), bit-identical to the sequential
+// emulation in octree.hip.h (which stays as the selectable reference, ORBX_OCTREE=seq).  One 256-thread workgroup per
+// (frame, level): the four waves share the key sweeps (each thread owns ceil(C/256)|1 consecutive keys; ranks come from a
+// workgroup-wide SEGMENTED prefix sum of four packed 16-bit child counters), wave 0 runs the node-level steps and the sort.
+// Levels with more keys than the LDS buffers hold (or more than four roots) are processed by wave 0 alone with the
+// chunked single-wave form of the same passes (global-memory key buffers).
+//
+// What makes the reference order sensitive, and how each piece is reproduced without walking a list:
+//   * lNodes is a std::list; a breadth pass (:618-680) erases every node with more than one key and push_front's its
+//     non-empty children n1..n4.  So after a pass the list is   reverse(children in creation order) ++ (the nodes that were
+//     not divided, in their old order)   and the next pass meets the divisible nodes in list order.  The list is kept as an
+//     ARRAY in list order; a pass computes every child's position with prefix sums (children counted in processing order).
+//   * the size-ordered expansion (:686-752) sorts vSizeAndPointerToNode with std::sort and divides from the back until the
+//     list holds N nodes.  std::sort's tie order is reproduced exactly: libstdc++ introsort = median-of-3 Hoare partitions
+//     until every segment has <= 16 elements, then one insertion sort, which is a STABLE sort of whatever the partitions
+//     left.  A Hoare partition's swaps are fully determined by the original values (k-th element from the left that is
+//     not less than the pivot <-> k-th element from the right that is not greater, while they have not crossed), so the
+//     wave evaluates one partition with ballots / ranks; the final pass is a rank sort.  The heap-sort fallback (depth
+//     limit) is delegated to the sequential replica.  The break "list size >= N" is a prefix sum over the sorted order.
+//   * DivideNode's four key vectors keep the parent's key order: all divided nodes are split at once by a segmented
+//     stable scatter (per-node child counters in LDS, in-chunk rank by ballot), keys ping-pong between two buffers.
+//   * the retained keypoint of a node (:757-776, first maximum) is an LDS atomic max over (response, -position).
+#pragma once
+
+#include "octree.hip.h"
+
+namespace orbx {
+
+constexpr int kOctParLdsKeys = 4096;  // keys (and node-of-key entries) per ping-pong buffer kept in LDS
+constexpr int kOctBlkE = 17;          // keys per thread of the 256-thread form: ceil(C / 256) | 1 (odd: conflict-free LDS stride)
+
+// ordering point for code that only ONE wave executes (LDS operations of a wave are performed in issue order; the
+// compiler must not move them across): no s_barrier, so it may sit in wave-divergent sections of a larger workgroup
+#define OCT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__host__ __device__ inline size_t oct_par_pool_bytes(int pool) {
+    // stack + per node: bounds 2x8, segment 2x8, hist 16, cpos 8, sa/sb 16, npos/eof/nebe/cbe/abe/ls/rs 7x2
+    return ((size_t)kOctStackInts * 4 + (size_t)pool * (16 + 16 + 16 + 8 + 16 + 14) + 160 + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t oct_par_lds_bytes(int pool) { return oct_par_pool_bytes(pool) + 2 * (size_t)kOctParLdsKeys * 6; }
+
+struct OctBnd { int16_t x0, y0, x1, y1; };   // UL.x, UL.y, UR.x, BR.y
+struct OctSeg { int32_t beg, cnt; };         // key range of the node
+
+// ---- wave-parallel std::sort replica (see the header comment).  a: n entries (oct_less order), work arrays ls/rs (n u16),
+// tmp (n u64), stack (kOctStackInts).  Returns false when the introsort depth limit was reached (nothing usable in a).
+__device__ inline bool oct_par_sort(uint64_t *a, uint64_t *tmp, int n, uint16_t *ls, uint16_t *rs, int *stack, int lane) {
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (n > 16) {
+        int sp = 0;
+        int first = 0, last = n, depth = 2 * (31 - __clz(n));
+        while (true) {
+            while (last - first > 16) {
+                if (depth == 0) return false;
+                --depth;
+                // __move_median_to_first(first, first+1, mid, last-1)
+                const int mid = first + (last - first) / 2;
+                const int ia = first + 1, ib = mid, ic = last - 1;
+                const uint64_t vf = a[first], va = a[ia], vb = a[ib], vc = a[ic];
+                int m;
+                if (oct_less(va, vb)) {
+                    if (oct_less(vb, vc)) m = ib;
+                    else if (oct_less(va, vc)) m = ic;
+                    else m = ia;
+                } else if (oct_less(va, vc)) m = ia;
+                else if (oct_less(vb, vc)) m = ic;
+                else m = ib;
+                const uint64_t pivot = m == ia ? va : (m == ib ? vb : vc);
+                OCT_WAVE_SYNC();
+                if (lane == 0) { a[first] = pivot; a[m] = vf; }
+                OCT_WAVE_SYNC();
+                // __unguarded_partition(first+1, last, pivot): stoppers of the two scans, by rank
+                int nL = 0, nR = 0;
+                for (int i0 = first + 1; i0 < last; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool act = i < last;
+                    const uint64_t v = act ? a[i] : 0;
+                    const bool isL = act && !oct_less(v, pivot), isR = act && !oct_less(pivot, v);
+                    const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+                    if (isL) ls[nL + __popcll(bL & lt_mask)] = (uint16_t)i;
+                    if (isR) rs[nR + __popcll(bR & lt_mask)] = (uint16_t)i;   // ascending; the k-th from the right is rs[nR-1-k]
+                    nL += __popcll(bL);
+                    nR += __popcll(bR);
+                }
+                OCT_WAVE_SYNC();
+                const int kmax = min(nL, nR);
+                int K = 0;  // pairs that are swapped: ls[k] < rs[nR-1-k] (a prefix, both sequences are monotone)
+                for (int k0 = 0; k0 < kmax; k0 += 64) {
+                    const int k = k0 + lane;
+                    const bool sw = k < kmax && ls[k] < rs[nR - 1 - k];
+                    const unsigned long long b = __ballot(sw);
+                    K += __popcll(b);
+                    if (__popcll(b) < min(64, kmax - k0)) break;
+                }
+                for (int k = lane; k < K; k += 64) {
+                    const int i = ls[k], j = rs[nR - 1 - k];
+                    const uint64_t vi = a[i], vj = a[j];
+                    a[i] = vj; a[j] = vi;
+                }
+                int cut = last;
+                if (K < nL) cut = min(cut, (int)ls[K]);
+                if (K > 0) cut = min(cut, (int)rs[nR - K]);
+                OCT_WAVE_SYNC();
+                // __introsort_loop recurses on [cut, last) and loops on [first, cut)
+                if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; }
+                sp++;
+                last = cut;
+            }
+            if (sp == 0) break;
+            sp--;
+            OCT_WAVE_SYNC();
+            first = stack[3 * sp]; last = stack[3 * sp + 1]; depth = stack[3 * sp + 2];
+        }
+    }
+    // __final_insertion_sort == stable sort of the current arrangement: rank = #less + #equal-before
+    OCT_WAVE_SYNC();
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < n) {
+            const uint64_t v = a[i] >> 16;
+            int r = 0;
+            for (int j = 0; j < n; j++) {
+                const uint64_t w = a[j] >> 16;
+                r += (w < v) || (w == v && j < i);
+            }
+            tmp[r] = a[i];
+        }
+    }
+    OCT_WAVE_SYNC();
+    for (int i = lane; i < n; i += 64) a[i] = tmp[i];
+    OCT_WAVE_SYNC();
+    return true;
+}
+
+// debug kernel: sort (count, ulx) pairs with the wave-parallel replica (falls back like k_octree_par does)
+__global__ __launch_bounds__(64) void k_debug_sort_par(const int32_t *count, const int32_t *ulx, int n, int32_t *perm, uint64_t *scratch,
+                                                       uint64_t *tmp, uint16_t *ls, uint16_t *rs, int32_t *fellback) {
+    __shared__ int stack[kOctStackInts];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64)
+        scratch[i] = ((uint64_t)(uint32_t)count[i] << 32) | ((uint64_t)(uint32_t)ulx[i] << 16) | (uint64_t)i;
+    OCT_WAVE_SYNC();
+    const bool ok = oct_par_sort(scratch, tmp, n, ls, rs, stack, lane);
+    if (!ok) {
+        OCT_WAVE_SYNC();
+        for (int i = lane; i < n; i += 64)
+            scratch[i] = ((uint64_t)(uint32_t)count[i] << 32) | ((uint64_t)(uint32_t)ulx[i] << 16) | (uint64_t)i;
+        OCT_WAVE_SYNC();
+        LdsArr arr{scratch};
+        if (lane == 0) { oct_std_sort(arr, n, stack); *fellback = 1; }
+        OCT_WAVE_SYNC();
+    }
+    for (int i = lane; i < n; i += 64) perm[i] = (int32_t)(scratch[i] & 0xffff);
+}
+
+// ---- k_compact: vToDistributeKeys of every (frame, level) (:805-870 pushes the cells' keypoints in cell row-major order):
+// exclusive scan of the per-cell counts + gather of the cell slots into one dense key array.  A separate, wide launch
+// (256 threads per (frame, level)) because the single quad-tree wave cannot hide the latency of these dependent global
+// loads.  grid (nlevels, B), block 256
+__global__ __launch_bounds__(256) void k_compact(const LevelInfo *__restrict__ lv, const int32_t *__restrict__ cellcnt, int total_cells,
+                                                 const uint32_t *__restrict__ cellent, size_t ent_frame_stride,
+                                                 uint32_t *__restrict__ keys, int32_t *__restrict__ cand_total, int nlevels) {
+    __shared__ int wsum[4];
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelInfo L = lv[level];
+    const int32_t *ccnt = cellcnt + (size_t)f * total_cells + L.cell_base;
+    const uint32_t *ent = cellent + (size_t)f * ent_frame_stride + L.cand_off;
+    uint32_t *dst = keys + (size_t)f * ent_frame_stride + L.cand_off;
+    const int ncell = L.nCols * L.nRows;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int run = 0;
+    for (int c0 = 0; c0 < ncell; c0 += 256) {
+        const int c = c0 + tid;
+        const int n = (c < ncell) ? ccnt[c] : 0;
+        const int incl = wave_incl_scan(n);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        const int s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
+        __syncthreads();
+        const int excl = run + incl - n + (w > 0 ? s0 : 0) + (w > 1 ? s1 : 0) + (w > 2 ? s2 : 0);
+        const uint32_t *src = ent + (size_t)c * L.cell_cap;
+        for (int k = 0; k < n; k += 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = (k + u < n) ? src[k + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (k + u < n) dst[excl + k + u] = v[u];
+        }
+        run += s0 + s1 + s2 + s3;
+    }
+    if (tid == 0) cand_total[f * nlevels + level] = run;
+}
+
+// ---- the kernel body ---------------------------------------------------------------------------------------------
+// exclusive SEGMENTED prefix sum over the 256 threads of the workgroup: the value accumulated since the last segment head
+// (f = this thread contains a head; v = its accumulation after its last head, or over all its keys when it has none)
+__device__ __forceinline__ uint64_t oct_blk_seg_excl(uint64_t v, bool f, uint64_t *wtot, int *wflag, int lane, int wave) {
+    uint64_t iv = v;
+    int ifl = f ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t pv = __shfl_up((unsigned long long)iv, d);
+        const int pf = __shfl_up(ifl, d);
+        if (lane >= d) {
+            if (!ifl) iv += pv;
+            ifl |= pf;
+        }
+    }
+    if (lane == 63) { wtot[wave] = iv; wflag[wave] = ifl; }
+    __syncthreads();
+    uint64_t ev = __shfl_up((unsigned long long)iv, 1);
+    int ef = __shfl_up(ifl, 1);
+    if (lane == 0) { ev = 0; ef = 0; }
+    uint64_t carry = 0;
+    for (int w = 0; w < wave; w++) carry = wflag[w] ? wtot[w] : carry + wtot[w];
+    const uint64_t r = ef ? ev : ev + carry;
+    __syncthreads();
+    return r;
+}
+
+template <bool BLK>
+__device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *smem, int max_pool, const int C, uint32_t *gk0, uint32_t *gk1,
+                                                uint16_t *gn0, uint16_t *gn1, uint32_t *__restrict__ out,
+                                                int32_t *__restrict__ lvlcnt_out, int32_t *__restrict__ err) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = BLK ? 256 : 64;
+    const int pool = L.pool;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#define OCT_SYNC_ALL() do { if (BLK) __syncthreads(); else OCT_WAVE_SYNC(); } while (0)
+
+    // carve (8-byte arrays first)
+    uint8_t *p = smem;
+    int *stack = (int *)p; p += (size_t)kOctStackInts * 4;
+    uint64_t *wtot = (uint64_t *)p; p += 32;
+    int *wflag = (int *)p; p += 16;
+    int *ctl = (int *)p; p += 48;
+    uint64_t *sa = (uint64_t *)p; p += (size_t)pool * 8;
+    uint64_t *sb = (uint64_t *)p; p += (size_t)pool * 8;
+    OctBnd *bnd[2]; OctSeg *seg[2];
+    bnd[0] = (OctBnd *)p; p += (size_t)pool * 8;
+    bnd[1] = (OctBnd *)p; p += (size_t)pool * 8;
+    seg[0] = (OctSeg *)p; p += (size_t)pool * 8;
+    seg[1] = (OctSeg *)p; p += (size_t)pool * 8;
+    uint32_t *hist = (uint32_t *)p; p += (size_t)pool * 16;
+    uint16_t *cpos = (uint16_t *)p; p += (size_t)pool * 8;
+    uint16_t *npos = (uint16_t *)p; p += (size_t)pool * 2;   // new position of a node that is not divided; 0xffff = divided
+    uint16_t *eof = (uint16_t *)p; p += (size_t)pool * 2;    // processing index of a divisible node
+    uint16_t *nebe = (uint16_t *)p; p += (size_t)pool * 2;   // by processing index: #children | #children with >1 keys << 3
+    uint16_t *cbe = (uint16_t *)p; p += (size_t)pool * 2;    // by processing index: children created before
+    uint16_t *abe = (uint16_t *)p; p += (size_t)pool * 2;    // by processing index: divisible children created before
+    uint16_t *ls = (uint16_t *)p; p += (size_t)pool * 2;
+    uint16_t *rs = (uint16_t *)p; p += (size_t)pool * 2;
+
+    uint32_t *kb[2];
+    uint16_t *nof[2];
+    if (BLK) {
+        uint8_t *lk = smem + oct_par_pool_bytes(max_pool);
+        kb[0] = (uint32_t *)lk; kb[1] = kb[0] + kOctParLdsKeys;
+        nof[0] = (uint16_t *)(kb[1] + kOctParLdsKeys); nof[1] = nof[0] + kOctParLdsKeys;
+    } else {
+        kb[0] = gk0; kb[1] = gk1; nof[0] = gn0; nof[1] = gn1;
+    }
+    const int E = ((C + 255) >> 8) | 1;  // BLK: keys per thread (<= kOctBlkE)
+    // per-key registers of the 256-thread form: key, node | q << 16 | head << 19 | last << 20 | valid << 21, rank
+    uint32_t kv[kOctBlkE], r1[kOctBlkE], r2[kOctBlkE];
+    (void)kv; (void)r1; (void)r2;
+
+    // ---- 2./3. roots (:559-602): key -> root (int)(x / hX), stable; empty roots are dropped.  vToDistributeKeys is in gk1
+    int cur = 0, size = 0, nA = 0;
+    if (BLK) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int e = 0; e < kOctBlkE; e++) {
+            const int i = tid * E + e;
+            r1[e] = 0;
+            if (e < E && i < C) {
+                const uint32_t key = gk1[i];
+                int root = (int)((float)key_x(key) / L.hX);
+                root = min(root, L.nIni - 1);
+                kv[e] = key;
+                r1[e] = ((uint32_t)root << 16) | (1u << 21);
+                acc += 1ull << (16 * root);
+            }
+        }
+        const uint64_t cin = oct_blk_seg_excl(acc, false, wtot, wflag, lane, wave);
+        if (tid == 255) *reinterpret_cast<uint64_t *>(ctl + 4) = cin + acc;  // keys per root
+        __syncthreads();
+        const uint64_t tot = *reinterpret_cast<const uint64_t *>(ctl + 4);
+        int rstart[4], rpos[4], off = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int cnt = (int)((tot >> (16 * r)) & 0xffff);
+            rstart[r] = off; rpos[r] = size;
+            if (r < L.nIni && cnt > 0) {
+                if (tid == 0) {
+                    bnd[0][size] = OctBnd{(int16_t)(int)(L.hX * (float)r), 0, (int16_t)(int)(L.hX * (float)(r + 1)), (int16_t)(L.h - 2 * kBorder)};
+                    seg[0][size] = OctSeg{off, cnt};
+                }
+                size++;
+            }
+            off += cnt;
+        }
+        acc = cin;
+#pragma unroll
+        for (int e = 0; e < kOctBlkE; e++) {
+            if (r1[e] >> 21) {
+                const int q = (r1[e] >> 16) & 3;
+                const int pos = (q == 0 ? rstart[0] : q == 1 ? rstart[1] : q == 2 ? rstart[2] : rstart[3]) + (int)((acc >> (16 * q)) & 0xffff);
+                kb[0][pos] = kv[e];
+                nof[0][pos] = (uint16_t)(q == 0 ? rpos[0] : q == 1 ? rpos[1] : q == 2 ? rpos[2] : rpos[3]);
+                acc += 1ull << (16 * q);
+            }
+        }
+        __syncthreads();
+    } else {
+        int wr = 0;
+        for (int r = 0; r < L.nIni; r++) {
+            const int beg = wr;
+            for (int i0 = 0; i0 < C; i0 += 64) {
+                const int i = i0 + lane;
+                uint32_t key = 0;
+                bool mine = false;
+                if (i < C) {
+                    key = kb[1][i];
+                    int root = (int)((float)key_x(key) / L.hX);
+                    root = min(root, L.nIni - 1);
+                    mine = (root == r);
+                }
+                const unsigned long long b = __ballot(mine);
+                if (mine) {
+                    const int pos = wr + __popcll(b & lt_mask);
+                    kb[0][pos] = key;
+                    nof[0][pos] = (uint16_t)size;
+                }
+                wr += __popcll(b);
+            }
+            const int cnt = wr - beg;
+            if (cnt > 0) {
+                if (lane == 0) {
+                    bnd[0][size] = OctBnd{(int16_t)(int)(L.hX * (float)r), 0, (int16_t)(int)(L.hX * (float)(r + 1)), (int16_t)(L.h - 2 * kBorder)};
+                    seg[0][size] = OctSeg{beg, cnt};
+                }
+                size++;
+            }
+        }
+        OCT_WAVE_SYNC();
+    }
+    const int N = L.quota;
+
+    // One pass over the list: every node with more than one key whose processing index is <= the break index is divided.
+    //   sorted == false: breadth pass (:618-680), processing order = list order, no break
+    //   sorted == true : size-ordered round (:690-750), processing order = eof[] (set from the sorted array), break at N
+    auto pass = [&](bool sorted, int nB) {
+        const int nxt = cur ^ 1;
+        const OctBnd *B0 = bnd[cur];
+        const OctSeg *S0 = seg[cur];
+        const uint32_t *K0 = kb[cur];
+        const uint16_t *O0 = nof[cur];
+        // A. child key counts of every divisible node (and, 256-thread form, the rank of every key inside its child)
+        if (BLK) {
+            uint64_t acc = 0;
+            bool seen = false;
+#pragma unroll
+            for (int e = 0; e < kOctBlkE; e++) {
+                const int i = tid * E + e;
+                r1[e] = 0;
+                if (e < E && i < C) {
+                    const uint32_t key = K0[i];
+                    const int j = O0[i];
+                    const OctSeg sg = S0[j];
+                    int q = 4;
+                    if (sg.cnt > 1) {
+                        const OctBnd b = B0[j];
+                        const int sx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), sy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);  // ceil(d / 2), :482-483
+                        q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
+                    }
+                    const bool hd = (i == sg.beg), lst = (i == sg.beg + sg.cnt - 1);
+                    if (hd) { acc = 0; seen = true; }
+                    if (q < 4) acc += 1ull << (16 * q);
+                    kv[e] = key;
+                    r1[e] = (uint32_t)j | ((uint32_t)q << 16) | ((uint32_t)hd << 19) | ((uint32_t)lst << 20) | (1u << 21);
+                }
+            }
+            acc = oct_blk_seg_excl(acc, seen, wtot, wflag, lane, wave);
+#pragma unroll
+            for (int e = 0; e < kOctBlkE; e++) {
+                if (r1[e] >> 21) {
+                    const int q = (r1[e] >> 16) & 7;
+                    if (r1[e] & (1u << 19)) acc = 0;
+                    if (q < 4) {
+                        r2[e] = (uint32_t)((acc >> (16 * q)) & 0xffff);
+                        acc += 1ull << (16 * q);
+                        if (r1[e] & (1u << 20))
+                            *reinterpret_cast<uint4 *>(&hist[4 * (r1[e] & 0xffff)]) =
+                                make_uint4((uint32_t)(acc & 0xffff), (uint32_t)((acc >> 16) & 0xffff), (uint32_t)((acc >> 32) & 0xffff), (uint32_t)(acc >> 48));
+                    }
+                }
+            }
+        } else {
+            for (int i = lane; i < size * 4; i += 64) hist[i] = 0;
+            OCT_WAVE_SYNC();
+            for (int i0 = 0; i0 < C; i0 += 64) {
+                const int i = i0 + lane;
+                if (i < C) {
+                    const uint32_t key = K0[i];
+                    const int j = O0[i];
+                    if (S0[j].cnt > 1) {
+                        const OctBnd b = B0[j];
+                        const int sx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), sy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);
+                        const int q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
+                        atomicAdd(&hist[4 * j + q], 1u);
+                    }
+                }
+            }
+        }
+        OCT_SYNC_ALL();
+        if (wave == 0) {
+            // B1. per node: number of children / divisible children, by processing index
+            {
+                int ebase = 0;
+                for (int j0 = 0; j0 < size; j0 += 64) {
+                    const int j = j0 + lane;
+                    bool cand = false;
+                    int ne = 0, nx = 0;
+                    if (j < size && S0[j].cnt > 1) {
+                        cand = true;
+                        const uint4 h = *reinterpret_cast<const uint4 *>(&hist[4 * j]);
+                        ne = (h.x > 0) + (h.y > 0) + (h.z > 0) + (h.w > 0);
+                        nx = (h.x > 1) + (h.y > 1) + (h.z > 1) + (h.w > 1);
+                    }
+                    const unsigned long long bc = __ballot(cand);
+                    if (cand) {
+                        int e;
+                        if (sorted) e = eof[j];
+                        else { e = ebase + __popcll(bc & lt_mask); eof[j] = (uint16_t)e; }
+                        nebe[e] = (uint16_t)(ne | (nx << 3));
+                    }
+                    ebase += __popcll(bc);
+                }
+                if (!sorted) nB = ebase;
+            }
+            OCT_WAVE_SYNC();
+            // B2. over the processing order: children created before each node, and the break index m (:737)
+            int m = nB - 1, T = 0, newA = 0;
+            {
+                int cb = 0, ab = 0;
+                bool done = false;
+                for (int e0 = 0; e0 < nB && !done; e0 += 64) {
+                    const int e = e0 + lane;
+                    int ne = 0, nx = 0;
+                    if (e < nB) { const int v = nebe[e]; ne = v & 7; nx = v >> 3; }
+                    const int ine = wave_incl_scan(ne), inx = wave_incl_scan(nx);
+                    if (e < nB) { cbe[e] = (uint16_t)(cb + ine - ne); abe[e] = (uint16_t)(ab + inx - nx); }
+                    int last = min(63, nB - 1 - e0);
+                    if (sorted) {  // list size after dividing e: size + (children so far) - (nodes divided so far)
+                        const bool reach = e < nB && size + (cb + ine) - (e + 1) >= N;
+                        const unsigned long long br = __ballot(reach);
+                        if (br) { last = __ffsll((long long)br) - 1; m = e0 + last; done = true; }
+                    }
+                    cb += __builtin_amdgcn_readlane(ine, last);
+                    ab += __builtin_amdgcn_readlane(inx, last);
+                }
+                T = cb; newA = ab;
+            }
+            OCT_WAVE_SYNC();
+            // B3. write the new list: children at T-1-creation index, the others after them in their old order
+            int ubase = 0;
+            for (int j0 = 0; j0 < size; j0 += 64) {
+                const int j = j0 + lane;
+                bool keepn = false, divd = false;
+                OctSeg sg{0, 0};
+                OctBnd b{0, 0, 0, 0};
+                int e = 0;
+                if (j < size) {
+                    sg = S0[j]; b = B0[j];
+                    if (sg.cnt > 1) { e = eof[j]; divd = e <= m; }
+                    keepn = !divd;
+                }
+                const unsigned long long bk = __ballot(keepn);
+                if (keepn) {
+                    const int pos = T + ubase + __popcll(bk & lt_mask);
+                    bnd[nxt][pos] = b; seg[nxt][pos] = sg;
+                    npos[j] = (uint16_t)pos;
+                }
+                ubase += __popcll(bk);
+                if (divd) {
+                    npos[j] = 0xffff;
+                    const uint4 h = *reinterpret_cast<const uint4 *>(&hist[4 * j]);
+                    const int cc[4] = {(int)h.x, (int)h.y, (int)h.z, (int)h.w};
+                    const int sx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), sy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);
+                    const int cx0[4] = {b.x0, sx, b.x0, sx}, cx1[4] = {sx, b.x1, sx, b.x1};
+                    const int cy0[4] = {b.y0, b.y0, sy, sy}, cy1[4] = {sy, sy, b.y1, b.y1};
+                    int ci = cbe[e], ai = abe[e], off = sg.beg;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        hist[4 * j + k] = (uint32_t)off;  // becomes the (running) scatter offset of child k
+                        if (cc[k] > 0) {
+                            const int pos = T - 1 - ci;
+                            ci++;
+                            bnd[nxt][pos] = OctBnd{(int16_t)cx0[k], (int16_t)cy0[k], (int16_t)cx1[k], (int16_t)cy1[k]};
+                            seg[nxt][pos] = OctSeg{off, cc[k]};
+                            cpos[4 * j + k] = (uint16_t)pos;
+                            if (cc[k] > 1) {
+                                sa[ai] = ((uint64_t)(uint32_t)cc[k] << 32) | ((uint64_t)(uint16_t)cx0[k] << 16) | (uint64_t)pos;
+                                ai++;
+                            }
+                        }
+                        off += cc[k];
+                    }
+                }
+            }
+            if (lane == 0) { ctl[0] = T + ubase; ctl[1] = newA; }
+        }
+        OCT_SYNC_ALL();
+        size = ctl[0];
+        nA = ctl[1];
+        // C. stable scatter of the keys of the divided nodes (the parent's key order is kept inside every child)
+        uint32_t *K1 = kb[nxt];
+        uint16_t *O1 = nof[nxt];
+        if (BLK) {
+#pragma unroll
+            for (int e = 0; e < kOctBlkE; e++) {
+                if (r1[e] >> 21) {
+                    const int j = r1[e] & 0xffff, q = (r1[e] >> 16) & 7;
+                    const int np = npos[j];
+                    if (np == 0xffff) {
+                        const int slot = 4 * j + q;
+                        const int pos = (int)hist[slot] + (int)r2[e];
+                        K1[pos] = kv[e];
+                        O1[pos] = cpos[slot];
+                    } else {
+                        const int i = tid * E + e;
+                        K1[i] = kv[e];
+                        O1[i] = (uint16_t)np;
+                    }
+                }
+            }
+        } else {
+            for (int i0 = 0; i0 < C; i0 += 64) {
+                const int i = i0 + lane;
+                uint32_t key = 0;
+                int j = 0, q = 4, np = 0, s0 = 0;
+                if (i < C) {
+                    key = K0[i];
+                    j = O0[i];
+                    np = npos[j];
+                    if (np == 0xffff) {
+                        const OctBnd b = B0[j];
+                        const int sx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), sy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);
+                        q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
+                        s0 = max(S0[j].beg - i0, 0);  // first lane of this node's run inside the chunk
+                    }
+                }
+                const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+                if (i < C) {
+                    if (q < 4) {
+                        const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+                        const int rank = __popcll(bq & lt_mask & ~((1ull << s0) - 1ull));
+                        const int slot = 4 * j + q;
+                        const int pos = (int)hist[slot] + rank;
+                        K1[pos] = key;
+                        O1[pos] = cpos[slot];
+                        atomicAdd(&hist[slot], 1u);  // LDS/memory operations of a wave are performed in order: the next chunk sees it
+                    } else {
+                        K1[i] = key;
+                        O1[i] = (uint16_t)np;
+                    }
+                }
+            }
+        }
+        OCT_SYNC_ALL();
+        cur = nxt;
+    };
+
+    // ---- 4. main loop (:604-755) ----------------------------------------------------------------------------------
+    bool finish = (size == 0);
+    while (!finish) {
+        const int prevSize = size;
+        pass(false, 0);
+        const int nToExpand = nA;
+        if (size >= N || size == prevSize) {
+            finish = true;
+        } else if (size + nToExpand * 3 > N) {
+            while (!finish) {
+                const int prevSize2 = size;
+                const int nB2 = nA;
+                if (wave == 0) {
+                    // vPrevSizeAndPointerToNode = vSizeAndPointerToNode; sort (:694-697)
+                    for (int i = lane; i < nB2; i += 64) sb[i] = sa[i];
+                    OCT_WAVE_SYNC();
+                    if (!oct_par_sort(sb, reinterpret_cast<uint64_t *>(hist), nB2, ls, rs, stack, lane)) {
+                        OCT_WAVE_SYNC();
+                        for (int i = lane; i < nB2; i += 64) sb[i] = sa[i];
+                        OCT_WAVE_SYNC();
+                        LdsArr arr{sb};
+                        if (lane == 0) oct_std_sort(arr, nB2, stack);
+                        OCT_WAVE_SYNC();
+                    }
+                    for (int k = lane; k < nB2; k += 64) eof[(int)(sb[k] & 0xffff)] = (uint16_t)(nB2 - 1 - k);  // divided from the back (:700)
+                }
+                OCT_SYNC_ALL();
+                pass(true, nB2);
+                if (size >= N || size == prevSize2) finish = true;
+            }
+        }
+    }
+
+    // ---- 5. best response per node, first wins ties (:757-776), in list order ---------------------------------------
+    const int nn = size;
+    uint32_t *best = hist;
+    for (int i = tid; i < nn; i += NT) best[i] = 0;
+    OCT_SYNC_ALL();
+    for (int i = tid; i < C; i += NT) {
+        const uint32_t key = kb[cur][i];
+        atomicMax(&best[nof[cur][i]], ((uint32_t)key_s(key) << 20) | (0xfffffu - (uint32_t)i));
+    }
+    OCT_SYNC_ALL();
+    for (int i = tid; i < nn && i < L.lvl_cap; i += NT) {
+        const uint32_t key = kb[cur][0xfffffu - (best[i] & 0xfffffu)];
+        // keypoints[i].pt += minBorder (:884-886): store level coordinates
+        out[i] = pack_key(key_x(key) + kBorder, key_y(key) + kBorder, key_s(key));
+    }
+    if (tid == 0) {
+        if (nn > L.lvl_cap) atomicExch(err, 3);
+        *lvlcnt_out = min(nn, L.lvl_cap);
+    }
+#undef OCT_SYNC_ALL
+}
+
+// grid (nlevels, B), block 256, dynamic LDS = oct_par_lds_bytes(max pool).  k_compact has run before.
+__global__ __launch_bounds__(256) void k_octree_par(const LevelInfo *__restrict__ lv, size_t ent_frame_stride, uint32_t *__restrict__ keys0,
+                                                    uint32_t *__restrict__ keys1, uint16_t *__restrict__ nof0, uint16_t *__restrict__ nof1,
+                                                    uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt,
+                                                    int nlevels, const int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelInfo L = lv[level];
+    uint32_t *gk0 = keys0 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint16_t *gn0 = nof0 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint16_t *gn1 = nof1 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint32_t *out = lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off;
+    int32_t *cnt_out = lvlcnt + f * nlevels + level;
+    const int C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
+    if (C >= 0xfffff) {  // the best-response pick packs the key position into 20 bits
+        if (threadIdx.x == 0) { atomicExch(err, 2); *cnt_out = 0; }
+        return;
+    }
+    if (C <= kOctParLdsKeys && L.nIni <= 4) {
+        octree_par_body<true>(L, smem, max_pool, C, gk0, gk1, gn0, gn1, out, cnt_out, err);
+    } else {
+        if (threadIdx.x >= 64) return;  // one wave, chunked passes over the global key buffers
+        octree_par_body<false>(L, smem, max_pool, C, gk0, gk1, gn0, gn1, out, cnt_out, err);
+    }
+}
+
+}  // namespace orbx

@@ -186,6 +186,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_cellent, sizeof(uint32_t) * (size_t)cand_off * B);
     ENS(ex->d_keys0, sizeof(uint32_t) * (size_t)cand_off * B);
     ENS(ex->d_keys1, sizeof(uint32_t) * (size_t)cand_off * B);
+    ENS(ex->d_nof0, sizeof(uint16_t) * (size_t)cand_off * B);
+    ENS(ex->d_nof1, sizeof(uint16_t) * (size_t)cand_off * B);
     ENS(ex->d_lvlkp, sizeof(uint32_t) * (size_t)lvl_off * B);
     ENS(ex->d_lvlcnt, sizeof(int32_t) * (size_t)nl * B);
     ENS(ex->d_candtot, sizeof(int32_t) * (size_t)nl * B);
@@ -207,6 +209,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->width = width; ex->height = height; ex->batch_cap = B;
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
     ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave_lds = fast_wave_lds; ex->fast_wave = fast_wave;
+    { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size();
     ex->last_batch = 0;
     return ORBX_OK;
@@ -284,12 +287,23 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     }
     {
         ProfScope ps(ex, K_OCTREE);
-        if (oct_lds_bytes(ex->max_pool) > 64 * 1024)
-            ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(ex->max_pool)));
-        hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), oct_lds_bytes(ex->max_pool), st, d_lv,
-                           (const int32_t *)ex->d_cellcnt.p, ex->total_cells, (const uint32_t *)ex->d_cellent.p, ex->cand_frame,
-                           (uint32_t *)ex->d_keys0.p, (uint32_t *)ex->d_keys1.p, (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame,
-                           (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p, ex->max_pool);
+        if (ex->oct_par) {
+            hipLaunchKernelGGL(k_compact, dim3(nl, n), dim3(256), 0, st, d_lv, (const int32_t *)ex->d_cellcnt.p, ex->total_cells,
+                               (const uint32_t *)ex->d_cellent.p, ex->cand_frame, (uint32_t *)ex->d_keys1.p, (int32_t *)ex->d_candtot.p, nl);
+            const size_t lds = oct_par_lds_bytes(ex->max_pool);
+            if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_octree_par, dim3(nl, n), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys0.p,
+                               (uint32_t *)ex->d_keys1.p, (uint16_t *)ex->d_nof0.p, (uint16_t *)ex->d_nof1.p, (uint32_t *)ex->d_lvlkp.p,
+                               ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p,
+                               ex->max_pool);
+        } else {
+            if (oct_lds_bytes(ex->max_pool) > 64 * 1024)
+                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(ex->max_pool)));
+            hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), oct_lds_bytes(ex->max_pool), st, d_lv,
+                               (const int32_t *)ex->d_cellcnt.p, ex->total_cells, (const uint32_t *)ex->d_cellent.p, ex->cand_frame,
+                               (uint32_t *)ex->d_keys0.p, (uint32_t *)ex->d_keys1.p, (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame,
+                               (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p, ex->max_pool);
+        }
     }
     if (ex->copy_pending) {  // outputs of the previous batch may still be in flight to the host
         ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done[(ex->copy_issued - 1) & 1], 0));  // the most recent download
@@ -447,7 +461,7 @@ void orbx_destroy(orbx_extractor *ex) {
     ex->d_match.release(); ex->d_nmatch.release();
     for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales}) b->release();
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
-                      &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_lvlkp, &ex->d_lvlcnt,
+                      &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid};
     for (DevBuf *b : bufs) b->release();
@@ -690,6 +704,32 @@ int orbx_debug_sort_nodes(int device, const int32_t *count, const int32_t *ulx, 
     ORBX_HIP(hipDeviceSynchronize());
     ORBX_HIP(hipMemcpy(perm, d_p, 4 * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(d_c); (void)hipFree(d_u); (void)hipFree(d_p); (void)hipFree(d_s);
+    return ORBX_OK;
+}
+
+int orbx_debug_sort_nodes_par(int device, const int32_t *count, const int32_t *ulx, int n, int32_t *perm, int32_t *fell_back) {
+    if (n <= 0 || n > 65535) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(device));
+    int32_t *d_c, *d_u, *d_p, *d_f;
+    uint64_t *d_s, *d_t;
+    uint16_t *d_l, *d_r;
+    ORBX_HIP(hipMalloc((void **)&d_c, 4 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_u, 4 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_p, 4 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_f, 4));
+    ORBX_HIP(hipMalloc((void **)&d_s, 8 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_t, 8 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_l, 2 * (size_t)n));
+    ORBX_HIP(hipMalloc((void **)&d_r, 2 * (size_t)n));
+    ORBX_HIP(hipMemset(d_f, 0, 4));
+    ORBX_HIP(hipMemcpy(d_c, count, 4 * (size_t)n, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(d_u, ulx, 4 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_sort_par, dim3(1), dim3(64), 0, 0, d_c, d_u, n, d_p, d_s, d_t, d_l, d_r, d_f);
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(perm, d_p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    if (fell_back) ORBX_HIP(hipMemcpy(fell_back, d_f, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_c); (void)hipFree(d_u); (void)hipFree(d_p); (void)hipFree(d_s); (void)hipFree(d_t); (void)hipFree(d_l); (void)hipFree(d_r);
+    (void)hipFree(d_f);
     return ORBX_OK;
 }
 

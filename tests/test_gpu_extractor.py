@@ -173,6 +173,7 @@ def test_device_introsort_replica_matches_libstdcxx():
     L = _lib.lib()
     rng = np.random.default_rng(11)
     sizes = [1, 2, 15, 16, 17, 18, 31, 33, 64, 65, 100, 128, 257, 511, 512, 1000, 3000]
+    fallbacks = 0
     for n in sizes:
         for variant in range(3):
             if variant == 0:
@@ -190,6 +191,13 @@ def test_device_introsort_replica_matches_libstdcxx():
             perm = np.zeros(n, np.int32)
             _lib.check(L.orbx_debug_sort_nodes(0, _lib.ptr(cnt), _lib.ptr(ulx), n, _lib.ptr(perm)), "sort")
             assert np.array_equal(perm, want), (n, variant)
+            # the wave-parallel replica (Hoare partitions by rank + stable rank sort) used by k_octree_par
+            perm2 = np.zeros(n, np.int32)
+            fell = np.zeros(1, np.int32)
+            _lib.check(L.orbx_debug_sort_nodes_par(0, _lib.ptr(cnt), _lib.ptr(ulx), n, _lib.ptr(perm2), _lib.ptr(fell)), "sort_par")
+            assert np.array_equal(perm2, want), (n, variant, int(fell[0]))
+            fallbacks += int(fell[0])
+    assert fallbacks <= 6   # the depth-limit fallback is the exception, not the rule
 
 
 def test_cpp_adapter_end_to_end(canvas1, tmp_path):
@@ -240,6 +248,7 @@ def test_cpp_adapter_end_to_end(canvas1, tmp_path):
     (320, 240, 200, 1.2, 4, 40, 12),     # small image, high thresholds
     (1280, 720, 3000, 1.3, 6, 20, 7),    # HD frame, > 2048 candidates on level 0 (quad-tree key buffers spill to global)
     (1226, 370, 2000, 1.2, 8, 12, 7),    # KITTI 04-12 shape
+    (1600, 300, 1200, 1.2, 4, 20, 7),    # panorama: 6 quad-tree roots (single-wave form of k_octree_par)
 ])
 def test_parameter_sweep(w, h, nf, scale, nlevels, ini, mn):
     """Other ORBextractor parameter sets (Settings.cc:443-451) stay bit-exact."""
