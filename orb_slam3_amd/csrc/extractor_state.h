@@ -58,6 +58,8 @@ struct orbx_extractor {
     int total_cells = 0, cap = 0, max_pool = 0;
     size_t fast_lds = 0;
     size_t fast_wave_lds = 0;   // k_fast_wave
+    DevBuf d_octdbg;            // optional phase timing of k_octree_par (orbx_debug_octree_timing)
+    int octdbg_level = -1;
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
     bool fast_wave = true;      // every level's cell fits k_fast_wave's fixed LDS pitch
     int n_fast_tiles = 0, n_blur_tiles = 0;

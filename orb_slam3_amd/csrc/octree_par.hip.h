@@ -27,7 +27,7 @@
 
 namespace orbx {
 
-constexpr int kOctParLdsKeys = 4096;  // keys (and node-of-key entries) per ping-pong buffer kept in LDS
+constexpr int kOctParLdsKeys = 4096;  // keys (and node-of-key entries) kept in LDS
 constexpr int kOctBlkE = 17;          // keys per thread of the 256-thread form: ceil(C / 256) | 1 (odd: conflict-free LDS stride)
 
 // ordering point for code that only ONE wave executes (LDS operations of a wave are performed in issue order; the
@@ -38,34 +38,46 @@ __host__ __device__ inline size_t oct_par_pool_bytes(int pool) {
     // stack + per node: bounds 2x8, segment 2x8, hist 16, cpos 8, sa/sb 16, npos/eof/nebe/cbe/abe/ls/rs 7x2
     return ((size_t)kOctStackInts * 4 + (size_t)pool * (16 + 16 + 16 + 8 + 16 + 14) + 160 + 15) & ~(size_t)15;
 }
-__host__ __device__ inline size_t oct_par_lds_bytes(int pool) { return oct_par_pool_bytes(pool) + 2 * (size_t)kOctParLdsKeys * 6; }
+__host__ __device__ inline size_t oct_par_lds_bytes(int pool) { return oct_par_pool_bytes(pool) + (size_t)kOctParLdsKeys * 6; }
 
 struct OctBnd { int16_t x0, y0, x1, y1; };   // UL.x, UL.y, UR.x, BR.y
 struct OctSeg { int32_t beg, cnt; };         // key range of the node
 
 // ---- wave-parallel std::sort replica (see the header comment).  a: n entries (oct_less order), work arrays ls/rs (n u16),
 // tmp (n u64), stack (kOctStackInts).  Returns false when the introsort depth limit was reached (nothing usable in a).
-__device__ inline bool oct_par_sort(uint64_t *a, uint64_t *tmp, int n, uint16_t *ls, uint16_t *rs, int *stack, int lane) {
+__device__ __forceinline__ uint64_t oct_readlane64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+// __move_median_to_first(first, first+1, mid, last-1): index of the median among (a, b, c)
+__device__ __forceinline__ int oct_median3(uint64_t va, uint64_t vb, uint64_t vc, int ia, int ib, int ic) {
+    if (oct_less(va, vb)) {
+        if (oct_less(vb, vc)) return ib;
+        if (oct_less(va, vc)) return ic;
+        return ia;
+    }
+    if (oct_less(va, vc)) return ia;
+    if (oct_less(vb, vc)) return ic;
+    return ib;
+}
+
+__device__ inline bool oct_par_sort(uint64_t *a, uint64_t *tmp, int n, uint16_t *ls, uint16_t *rs, int *stack, int lane, long long *dbg = nullptr) {
+    long long tm = dbg ? (long long)wall_clock64() : 0;
+#define SORT_TICK(k) do { if (dbg) { const long long tn = (long long)wall_clock64(); if (lane == 0) dbg[k] += tn - tm; tm = tn; } } while (0)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    uint16_t *posL = reinterpret_cast<uint16_t *>(stack + 128), *posR = posL + 64;  // partner tables of the register partition
     if (n > 16) {
         int sp = 0;
         int first = 0, last = n, depth = 2 * (31 - __clz(n));
         while (true) {
-            while (last - first > 16) {
+            // segments longer than a wave: stoppers ranked through LDS
+            while (last - first > 64) {
                 if (depth == 0) return false;
                 --depth;
-                // __move_median_to_first(first, first+1, mid, last-1)
                 const int mid = first + (last - first) / 2;
                 const int ia = first + 1, ib = mid, ic = last - 1;
                 const uint64_t vf = a[first], va = a[ia], vb = a[ib], vc = a[ic];
-                int m;
-                if (oct_less(va, vb)) {
-                    if (oct_less(vb, vc)) m = ib;
-                    else if (oct_less(va, vc)) m = ic;
-                    else m = ia;
-                } else if (oct_less(va, vc)) m = ia;
-                else if (oct_less(vb, vc)) m = ic;
-                else m = ib;
+                const int m = oct_median3(va, vb, vc, ia, ib, ic);
                 const uint64_t pivot = m == ia ? va : (m == ib ? vb : vc);
                 OCT_WAVE_SYNC();
                 if (lane == 0) { a[first] = pivot; a[m] = vf; }
@@ -106,6 +118,48 @@ __device__ inline bool oct_par_sort(uint64_t *a, uint64_t *tmp, int n, uint16_t 
                 if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; }
                 sp++;
                 last = cut;
+                SORT_TICK(12);
+                if (dbg && lane == 0) dbg[15] += 1;
+            }
+            // at most one element per lane: the segment stays in registers while its left part keeps being partitioned
+            if (last - first > 16) {
+                uint64_t v = (first + lane < last) ? a[first + lane] : 0;
+                while (last - first > 16) {
+                    if (depth == 0) return false;
+                    --depth;
+                    const int len = last - first;
+                    const int ra = 1, rb = len / 2, rc = len - 1;
+                    const uint64_t vf = oct_readlane64(v, 0), va = oct_readlane64(v, ra), vb = oct_readlane64(v, rb), vc = oct_readlane64(v, rc);
+                    const int m = oct_median3(va, vb, vc, ra, rb, rc);
+                    const uint64_t pivot = m == ra ? va : (m == rb ? vb : vc);
+                    if (lane == 0) v = pivot; else if (lane == m) v = vf;
+                    const bool act = lane >= 1 && lane < len;
+                    const bool isL = act && !oct_less(v, pivot), isR = act && !oct_less(pivot, v);
+                    const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+                    const int kL = __popcll(bL & lt_mask), kR = __popcll(bR & gt_mask);  // rank from the left / from the right
+                    // the k-th stopper from the left is exchanged with the k-th from the right while they have not crossed
+                    const bool swL = isL && __popcll(bR & gt_mask) > kL, swR = isR && __popcll(bL & lt_mask) > kR;
+                    const unsigned long long bSL = __ballot(swL), bSR = __ballot(swR);
+                    if (swL) posL[kL] = (uint16_t)lane;
+                    if (swR) posR[kR] = (uint16_t)lane;
+                    OCT_WAVE_SYNC();
+                    int partner = lane;
+                    if (swL) partner = posR[kL];
+                    if (swR) partner = posL[kR];
+                    v = __shfl((unsigned long long)v, partner);
+                    const int K = __popcll(bSL), nL = __popcll(bL);
+                    int cutr = len;
+                    if (K < nL) cutr = min(cutr, __ffsll((long long)(bL & ~bSL)) - 1);
+                    if (K > 0) cutr = min(cutr, __ffsll((long long)bSR) - 1);
+                    if (lane < len) a[first + lane] = v;  // the right part is final for this round; the left part continues in v
+                    const int cut = first + cutr;
+                    if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; }
+                    sp++;
+                    last = cut;
+                    OCT_WAVE_SYNC();
+                    SORT_TICK(13);
+                    if (dbg && lane == 0) dbg[15] += 1;
+                }
             }
             if (sp == 0) break;
             sp--;
@@ -113,23 +167,38 @@ __device__ inline bool oct_par_sort(uint64_t *a, uint64_t *tmp, int n, uint16_t 
             first = stack[3 * sp]; last = stack[3 * sp + 1]; depth = stack[3 * sp + 2];
         }
     }
-    // __final_insertion_sort == stable sort of the current arrangement: rank = #less + #equal-before
+    // __final_insertion_sort == stable sort of the current arrangement.  Every segment the partitions left has <= 16
+    // elements and no element of a later segment is less than one of an earlier segment, so an element's final position
+    // is   lo + #{j in [lo, hi] : a[j] < a[i] or (a[j] == a[i] and j < i)}   for any window [lo, hi] that contains its segment:
+    // 15 neighbours on either side.
     OCT_WAVE_SYNC();
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
-        if (i < n) {
-            const uint64_t v = a[i] >> 16;
-            int r = 0;
-            for (int j = 0; j < n; j++) {
-                const uint64_t w = a[j] >> 16;
-                r += (w < v) || (w == v && j < i);
+        const uint64_t mine = a[min(i, n - 1)];
+        const uint64_t v = mine >> 16;
+        const int lo = max(i - 15, 0);
+        int r = lo;
+#pragma unroll
+        for (int d0 = -15; d0 <= 15; d0 += 8) {
+            uint64_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) w[u] = a[min(max(i + d0 + u, 0), n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int d = d0 + u, j = i + d;
+                if (d <= 15 && d != 0) {
+                    const uint64_t x = w[u] >> 16;
+                    r += (j >= 0 && j < n) && (d < 0 ? x <= v : x < v);
+                }
             }
-            tmp[r] = a[i];
         }
+        if (i < n) tmp[r] = mine;
     }
     OCT_WAVE_SYNC();
     for (int i = lane; i < n; i += 64) a[i] = tmp[i];
     OCT_WAVE_SYNC();
+    SORT_TICK(14);
+#undef SORT_TICK
     return true;
 }
 
@@ -194,24 +263,32 @@ __global__ __launch_bounds__(256) void k_compact(const LevelInfo *__restrict__ l
 
 // ---- the kernel body ---------------------------------------------------------------------------------------------
 // exclusive SEGMENTED prefix sum over the 256 threads of the workgroup: the value accumulated since the last segment head
-// (f = this thread contains a head; v = its accumulation after its last head, or over all its keys when it has none)
-__device__ __forceinline__ uint64_t oct_blk_seg_excl(uint64_t v, bool f, uint64_t *wtot, int *wflag, int lane, int wave) {
-    uint64_t iv = v;
-    int ifl = f ? 1 : 0;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t pv = __shfl_up((unsigned long long)iv, d);
-        const int pf = __shfl_up(ifl, d);
-        if (lane >= d) {
-            if (!ifl) iv += pv;
-            ifl |= pf;
-        }
-    }
-    if (lane == 63) { wtot[wave] = iv; wflag[wave] = ifl; }
+// (fl = this thread contains a head; v = its accumulation after its last head, or over all its keys when it has none);
+// DPP scan inside a wave (row_shr 1/2/4/8, row_bcast15, row_bcast31), LDS across the four waves
+template <int CTRL, int ROWS>
+__device__ __forceinline__ void oct_seg_step(uint32_t &lo, uint32_t &hi, int &f) {
+    const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, ROWS, 0xf, false);
+    const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, ROWS, 0xf, false);
+    const int pf = __builtin_amdgcn_update_dpp(0, f, CTRL, ROWS, 0xf, false);
+    if (!f) { lo += plo; hi += phi; }  // the four 16-bit counters never carry into each other
+    f |= pf;
+}
+__device__ __forceinline__ uint64_t oct_blk_seg_excl(uint64_t v, bool fl, uint64_t *wtot, int *wflag, int lane, int wave) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    int f = fl ? 1 : 0;
+    oct_seg_step<0x111, 0xf>(lo, hi, f);
+    oct_seg_step<0x112, 0xf>(lo, hi, f);
+    oct_seg_step<0x114, 0xf>(lo, hi, f);
+    oct_seg_step<0x118, 0xf>(lo, hi, f);
+    oct_seg_step<0x142, 0xa>(lo, hi, f);
+    oct_seg_step<0x143, 0xc>(lo, hi, f);
+    if (lane == 63) { wtot[wave] = ((uint64_t)hi << 32) | lo; wflag[wave] = f; }
     __syncthreads();
-    uint64_t ev = __shfl_up((unsigned long long)iv, 1);
-    int ef = __shfl_up(ifl, 1);
-    if (lane == 0) { ev = 0; ef = 0; }
+    // exclusive value: the previous lane's inclusive one (wave_shr:1)
+    const uint32_t elo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x138, 0xf, 0xf, false);
+    const uint32_t ehi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x138, 0xf, 0xf, false);
+    const int ef = __builtin_amdgcn_update_dpp(0, f, 0x138, 0xf, 0xf, false);
+    const uint64_t ev = ((uint64_t)ehi << 32) | elo;
     uint64_t carry = 0;
     for (int w = 0; w < wave; w++) carry = wflag[w] ? wtot[w] : carry + wtot[w];
     const uint64_t r = ef ? ev : ev + carry;
@@ -222,8 +299,12 @@ __device__ __forceinline__ uint64_t oct_blk_seg_excl(uint64_t v, bool f, uint64_
 template <bool BLK>
 __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *smem, int max_pool, const int C, uint32_t *gk0, uint32_t *gk1,
                                                 uint16_t *gn0, uint16_t *gn1, uint32_t *__restrict__ out,
-                                                int32_t *__restrict__ lvlcnt_out, int32_t *__restrict__ err) {
+                                                int32_t *__restrict__ lvlcnt_out, int32_t *__restrict__ err, long long *dbg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // optional phase timing of one workgroup (ORBX_OCT_DBG): 100 MHz wall clock ticks per phase
+    long long tmark = dbg ? (long long)wall_clock64() : 0;
+    const long long tstart = tmark;
+#define OCT_TICK(k) do { if (dbg) { const long long tn = (long long)wall_clock64(); if (tid == 0) dbg[k] += tn - tmark; tmark = tn; } } while (0)
     constexpr int NT = BLK ? 256 : 64;
     const int pool = L.pool;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -256,15 +337,17 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
     uint16_t *nof[2];
     if (BLK) {
         uint8_t *lk = smem + oct_par_pool_bytes(max_pool);
-        kb[0] = (uint32_t *)lk; kb[1] = kb[0] + kOctParLdsKeys;
-        nof[0] = (uint16_t *)(kb[1] + kOctParLdsKeys); nof[1] = nof[0] + kOctParLdsKeys;
+        // every thread holds its keys in registers between the read and the write sweep of a pass: one buffer, updated in place
+        kb[0] = kb[1] = (uint32_t *)lk;
+        nof[0] = nof[1] = (uint16_t *)(kb[0] + kOctParLdsKeys);
     } else {
         kb[0] = gk0; kb[1] = gk1; nof[0] = gn0; nof[1] = gn1;
     }
     const int E = ((C + 255) >> 8) | 1;  // BLK: keys per thread (<= kOctBlkE)
-    // per-key registers of the 256-thread form: key, node | q << 16 | head << 19 | last << 20 | valid << 21, rank
-    uint32_t kv[kOctBlkE], r1[kOctBlkE], r2[kOctBlkE];
-    (void)kv; (void)r1; (void)r2;
+    // per-key registers of the 256-thread form: key; node (11 bits: pool <= 2047) | q << 11 | head << 14 | last << 15 |
+    // valid << 16 | rank inside the child << 17 (13 bits: <= kOctParLdsKeys)
+    uint32_t kv[kOctBlkE], r1[kOctBlkE];
+    (void)kv; (void)r1;
 
     // ---- 2./3. roots (:559-602): key -> root (int)(x / hX), stable; empty roots are dropped.  vToDistributeKeys is in gk1
     int cur = 0, size = 0, nA = 0;
@@ -279,7 +362,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
                 int root = (int)((float)key_x(key) / L.hX);
                 root = min(root, L.nIni - 1);
                 kv[e] = key;
-                r1[e] = ((uint32_t)root << 16) | (1u << 21);
+                r1[e] = ((uint32_t)root << 11) | (1u << 16);
                 acc += 1ull << (16 * root);
             }
         }
@@ -304,8 +387,8 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
         acc = cin;
 #pragma unroll
         for (int e = 0; e < kOctBlkE; e++) {
-            if (r1[e] >> 21) {
-                const int q = (r1[e] >> 16) & 3;
+            if (r1[e] & (1u << 16)) {
+                const int q = (r1[e] >> 11) & 3;
                 const int pos = (q == 0 ? rstart[0] : q == 1 ? rstart[1] : q == 2 ? rstart[2] : rstart[3]) + (int)((acc >> (16 * q)) & 0xffff);
                 kb[0][pos] = kv[e];
                 nof[0][pos] = (uint16_t)(q == 0 ? rpos[0] : q == 1 ? rpos[1] : q == 2 ? rpos[2] : rpos[3]);
@@ -347,6 +430,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
         OCT_WAVE_SYNC();
     }
     const int N = L.quota;
+    OCT_TICK(1);
 
     // One pass over the list: every node with more than one key whose processing index is <= the break index is divided.
     //   sorted == false: breadth pass (:618-680), processing order = list order, no break
@@ -361,38 +445,63 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
         if (BLK) {
             uint64_t acc = 0;
             bool seen = false;
+            // groups of six keys: load round (key + node), load round (node record), arithmetic -- the LDS latencies of a
+            // group overlap and the temporaries stay within the register budget of three workgroups per CU
 #pragma unroll
-            for (int e = 0; e < kOctBlkE; e++) {
-                const int i = tid * E + e;
-                r1[e] = 0;
-                if (e < E && i < C) {
-                    const uint32_t key = K0[i];
-                    const int j = O0[i];
-                    const OctSeg sg = S0[j];
-                    int q = 4;
-                    if (sg.cnt > 1) {
-                        const OctBnd b = B0[j];
-                        const int sx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), sy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);  // ceil(d / 2), :482-483
-                        q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
+            for (int g = 0; g < kOctBlkE; g += 6) {
+                if (g < E) {
+                    OctSeg sgs[6];
+                    OctBnd bns[6];
+#pragma unroll
+                    for (int u = 0; u < 6; u++) {
+                        const int e = g + u;
+                        if (e < kOctBlkE) { const int i = min(tid * E + e, C - 1); kv[e] = K0[i]; r1[e] = O0[i]; }
                     }
-                    const bool hd = (i == sg.beg), lst = (i == sg.beg + sg.cnt - 1);
-                    if (hd) { acc = 0; seen = true; }
-                    if (q < 4) acc += 1ull << (16 * q);
-                    kv[e] = key;
-                    r1[e] = (uint32_t)j | ((uint32_t)q << 16) | ((uint32_t)hd << 19) | ((uint32_t)lst << 20) | (1u << 21);
+#pragma unroll
+                    for (int u = 0; u < 6; u++) {
+                        const int e = g + u;
+                        if (e < kOctBlkE) { sgs[u] = S0[r1[e]]; bns[u] = B0[r1[e]]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 6; u++) {
+                        const int e = g + u;
+                        if (e < kOctBlkE) {
+                            const int i = tid * E + e;
+                            if (e < E && i < C) {
+                                const uint32_t key = kv[e];
+                                const int j = (int)r1[e];
+                                const OctSeg sg = sgs[u];
+                                int q = 4;
+                                if (sg.cnt > 1) {
+                                    const OctBnd b = bns[u];
+                                    const int sx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), sy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);  // ceil(d / 2), :482-483
+                                    q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
+                                }
+                                const bool hd = (i == sg.beg), lst = (i == sg.beg + sg.cnt - 1);
+                                if (hd) { acc = 0; seen = true; }
+                                if (q < 4) acc += 1ull << (16 * q);
+                                r1[e] = (uint32_t)j | ((uint32_t)q << 11) | ((uint32_t)hd << 14) | ((uint32_t)lst << 15) | (1u << 16);
+                            } else {
+                                r1[e] = 0;
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 6; u++) if (g + u < kOctBlkE) r1[g + u] = 0;
                 }
             }
             acc = oct_blk_seg_excl(acc, seen, wtot, wflag, lane, wave);
 #pragma unroll
             for (int e = 0; e < kOctBlkE; e++) {
-                if (r1[e] >> 21) {
-                    const int q = (r1[e] >> 16) & 7;
-                    if (r1[e] & (1u << 19)) acc = 0;
+                if (r1[e] & (1u << 16)) {
+                    const int q = (r1[e] >> 11) & 7;
+                    if (r1[e] & (1u << 14)) acc = 0;
                     if (q < 4) {
-                        r2[e] = (uint32_t)((acc >> (16 * q)) & 0xffff);
+                        r1[e] |= (uint32_t)((acc >> (16 * q)) & 0xffff) << 17;
                         acc += 1ull << (16 * q);
-                        if (r1[e] & (1u << 20))
-                            *reinterpret_cast<uint4 *>(&hist[4 * (r1[e] & 0xffff)]) =
+                        if (r1[e] & (1u << 15))
+                            *reinterpret_cast<uint4 *>(&hist[4 * (r1[e] & 0x7ff)]) =
                                 make_uint4((uint32_t)(acc & 0xffff), (uint32_t)((acc >> 16) & 0xffff), (uint32_t)((acc >> 32) & 0xffff), (uint32_t)(acc >> 48));
                     }
                 }
@@ -415,6 +524,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
             }
         }
         OCT_SYNC_ALL();
+        OCT_TICK(2);
         if (wave == 0) {
             // B1. per node: number of children / divisible children, by processing index
             {
@@ -513,6 +623,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
             if (lane == 0) { ctl[0] = T + ubase; ctl[1] = newA; }
         }
         OCT_SYNC_ALL();
+        OCT_TICK(3);
         size = ctl[0];
         nA = ctl[1];
         // C. stable scatter of the keys of the divided nodes (the parent's key order is kept inside every child)
@@ -521,12 +632,12 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
         if (BLK) {
 #pragma unroll
             for (int e = 0; e < kOctBlkE; e++) {
-                if (r1[e] >> 21) {
-                    const int j = r1[e] & 0xffff, q = (r1[e] >> 16) & 7;
+                if (r1[e] & (1u << 16)) {
+                    const int j = r1[e] & 0x7ff, q = (r1[e] >> 11) & 7;
                     const int np = npos[j];
                     if (np == 0xffff) {
                         const int slot = 4 * j + q;
-                        const int pos = (int)hist[slot] + (int)r2[e];
+                        const int pos = (int)hist[slot] + (int)(r1[e] >> 17);
                         K1[pos] = kv[e];
                         O1[pos] = cpos[slot];
                     } else {
@@ -570,40 +681,38 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
             }
         }
         OCT_SYNC_ALL();
+        OCT_TICK(4);
         cur = nxt;
+        if (dbg && tid == 0) dbg[sorted ? 8 : 7] += 1;
     };
 
-    // ---- 4. main loop (:604-755) ----------------------------------------------------------------------------------
-    bool finish = (size == 0);
+    // ---- 4. main loop (:604-755): breadth passes, then size-ordered rounds once size + 3 * nToExpand > N (:686) --------
+    bool finish = (size == 0), sorted = false;
     while (!finish) {
         const int prevSize = size;
-        pass(false, 0);
-        const int nToExpand = nA;
-        if (size >= N || size == prevSize) {
-            finish = true;
-        } else if (size + nToExpand * 3 > N) {
-            while (!finish) {
-                const int prevSize2 = size;
-                const int nB2 = nA;
-                if (wave == 0) {
-                    // vPrevSizeAndPointerToNode = vSizeAndPointerToNode; sort (:694-697)
-                    for (int i = lane; i < nB2; i += 64) sb[i] = sa[i];
+        const int nB = nA;
+        if (sorted) {
+            if (wave == 0) {
+                // vPrevSizeAndPointerToNode = vSizeAndPointerToNode; sort (:694-697)
+                for (int i = lane; i < nB; i += 64) sb[i] = sa[i];
+                OCT_WAVE_SYNC();
+                if (!oct_par_sort(sb, reinterpret_cast<uint64_t *>(hist), nB, ls, rs, stack, lane, dbg)) {
                     OCT_WAVE_SYNC();
-                    if (!oct_par_sort(sb, reinterpret_cast<uint64_t *>(hist), nB2, ls, rs, stack, lane)) {
-                        OCT_WAVE_SYNC();
-                        for (int i = lane; i < nB2; i += 64) sb[i] = sa[i];
-                        OCT_WAVE_SYNC();
-                        LdsArr arr{sb};
-                        if (lane == 0) oct_std_sort(arr, nB2, stack);
-                        OCT_WAVE_SYNC();
-                    }
-                    for (int k = lane; k < nB2; k += 64) eof[(int)(sb[k] & 0xffff)] = (uint16_t)(nB2 - 1 - k);  // divided from the back (:700)
+                    for (int i = lane; i < nB; i += 64) sb[i] = sa[i];
+                    OCT_WAVE_SYNC();
+                    LdsArr arr{sb};
+                    if (lane == 0) oct_std_sort(arr, nB, stack);
+                    OCT_WAVE_SYNC();
                 }
-                OCT_SYNC_ALL();
-                pass(true, nB2);
-                if (size >= N || size == prevSize2) finish = true;
+                for (int k = lane; k < nB; k += 64) eof[(int)(sb[k] & 0xffff)] = (uint16_t)(nB - 1 - k);  // divided from the back (:700)
             }
+            OCT_SYNC_ALL();
+            OCT_TICK(5);
+            if (dbg && tid == 0) dbg[10] = max(dbg[10], (long long)nB);
         }
+        pass(sorted, nB);
+        if (size >= N || size == prevSize) finish = true;
+        else if (!sorted && size + nA * 3 > N) sorted = true;
     }
 
     // ---- 5. best response per node, first wins ties (:757-776), in list order ---------------------------------------
@@ -625,34 +734,53 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
         if (nn > L.lvl_cap) atomicExch(err, 3);
         *lvlcnt_out = min(nn, L.lvl_cap);
     }
+    OCT_TICK(6);
+    if (dbg && tid == 0) { dbg[0] += (long long)wall_clock64() - tstart; dbg[9] = C; dbg[11] = nn; }
+#undef OCT_TICK
 #undef OCT_SYNC_ALL
 }
 
-// grid (nlevels, B), block 256, dynamic LDS = oct_par_lds_bytes(max pool).  k_compact has run before.
-__global__ __launch_bounds__(256) void k_octree_par(const LevelInfo *__restrict__ lv, size_t ent_frame_stride, uint32_t *__restrict__ keys0,
+// The 256-thread form handles a (frame, level) when its keys fit the LDS buffers, it has at most four roots and node indices
+// fit 11 bits; k_octree_par1 (one wave, chunked passes over global key buffers) handles the others.  Both kernels are
+// launched over all (frame, level) pairs and each returns at once for the pairs that belong to the other.
+__device__ __forceinline__ bool oct_blk_form(const LevelInfo &L, int C) { return C <= kOctParLdsKeys && L.nIni <= 4 && L.pool <= 2047; }
+
+// grid (B, nlevels), block 256, dynamic LDS = oct_par_lds_bytes(max pool).  k_compact has run before.
+__global__ __launch_bounds__(256, 3) void k_octree_par(const LevelInfo *__restrict__ lv, size_t ent_frame_stride, uint32_t *__restrict__ keys1,
+                                                       uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt,
+                                                       int nlevels, const int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool,
+                                                       long long *dbg_all, int dbg_level) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int level = blockIdx.y, f = blockIdx.x;  // level-major: the long workgroups start first
+    const LevelInfo L = lv[level];
+    long long *dbg = (dbg_all && f == 0 && level == dbg_level) ? dbg_all : nullptr;
+    const int C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
+    if (!oct_blk_form(L, C)) return;
+    uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
+    octree_par_body<true>(L, smem, max_pool, C, nullptr, gk1, nullptr, nullptr, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off,
+                          lvlcnt + f * nlevels + level, err, dbg);
+}
+
+// grid (B, nlevels), block 64, dynamic LDS = oct_par_pool_bytes(max pool)
+__global__ __launch_bounds__(64) void k_octree_par1(const LevelInfo *__restrict__ lv, size_t ent_frame_stride, uint32_t *__restrict__ keys0,
                                                     uint32_t *__restrict__ keys1, uint16_t *__restrict__ nof0, uint16_t *__restrict__ nof1,
                                                     uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt,
                                                     int nlevels, const int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int level = blockIdx.x, f = blockIdx.y;
+    const int level = blockIdx.y, f = blockIdx.x;
     const LevelInfo L = lv[level];
-    uint32_t *gk0 = keys0 + (size_t)f * ent_frame_stride + L.cand_off;
-    uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
-    uint16_t *gn0 = nof0 + (size_t)f * ent_frame_stride + L.cand_off;
-    uint16_t *gn1 = nof1 + (size_t)f * ent_frame_stride + L.cand_off;
-    uint32_t *out = lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off;
     int32_t *cnt_out = lvlcnt + f * nlevels + level;
     const int C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
+    if (oct_blk_form(L, C)) return;
     if (C >= 0xfffff) {  // the best-response pick packs the key position into 20 bits
         if (threadIdx.x == 0) { atomicExch(err, 2); *cnt_out = 0; }
         return;
     }
-    if (C <= kOctParLdsKeys && L.nIni <= 4) {
-        octree_par_body<true>(L, smem, max_pool, C, gk0, gk1, gn0, gn1, out, cnt_out, err);
-    } else {
-        if (threadIdx.x >= 64) return;  // one wave, chunked passes over the global key buffers
-        octree_par_body<false>(L, smem, max_pool, C, gk0, gk1, gn0, gn1, out, cnt_out, err);
-    }
+    uint32_t *gk0 = keys0 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint16_t *gn0 = nof0 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint16_t *gn1 = nof1 + (size_t)f * ent_frame_stride + L.cand_off;
+    octree_par_body<false>(L, smem, max_pool, C, gk0, gk1, gn0, gn1, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off, cnt_out, err, nullptr);
 }
 
 }  // namespace orbx

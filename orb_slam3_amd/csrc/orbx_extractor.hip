@@ -290,9 +290,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         if (ex->oct_par) {
             hipLaunchKernelGGL(k_compact, dim3(nl, n), dim3(256), 0, st, d_lv, (const int32_t *)ex->d_cellcnt.p, ex->total_cells,
                                (const uint32_t *)ex->d_cellent.p, ex->cand_frame, (uint32_t *)ex->d_keys1.p, (int32_t *)ex->d_candtot.p, nl);
-            const size_t lds = oct_par_lds_bytes(ex->max_pool);
+            const size_t lds = oct_par_lds_bytes(ex->max_pool), lds1 = oct_par_pool_bytes(ex->max_pool);
             if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_octree_par, dim3(nl, n), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys0.p,
+            if (lds1 > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            hipLaunchKernelGGL(k_octree_par, dim3(n, nl), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
+                               (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
+                               (int32_t *)ex->d_err.p, ex->max_pool, (long long *)ex->d_octdbg.p, ex->octdbg_level);
+            hipLaunchKernelGGL(k_octree_par1, dim3(n, nl), dim3(64), lds1, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys0.p,
                                (uint32_t *)ex->d_keys1.p, (uint16_t *)ex->d_nof0.p, (uint16_t *)ex->d_nof1.p, (uint32_t *)ex->d_lvlkp.p,
                                ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p,
                                ex->max_pool);
@@ -463,7 +467,7 @@ void orbx_destroy(orbx_extractor *ex) {
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
-                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid};
+                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);
@@ -704,6 +708,23 @@ int orbx_debug_sort_nodes(int device, const int32_t *count, const int32_t *ulx, 
     ORBX_HIP(hipDeviceSynchronize());
     ORBX_HIP(hipMemcpy(perm, d_p, 4 * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(d_c); (void)hipFree(d_u); (void)hipFree(d_p); (void)hipFree(d_s);
+    return ORBX_OK;
+}
+
+// phase timing of k_octree_par's workgroup (frame 0, level): 16 counters, see OCT_TICK in octree_par.hip.h; level < 0 disables
+int orbx_debug_octree_timing(orbx_extractor *ex, int level, int64_t *out16) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    if (out16 && ex->d_octdbg.p) ORBX_HIP(hipMemcpy(out16, ex->d_octdbg.p, 16 * 8, hipMemcpyDeviceToHost));
+    if (level >= 0) {
+        int r = ex->d_octdbg.ensure(16 * 8);
+        if (r != ORBX_OK) return r;
+        ORBX_HIP(hipMemset(ex->d_octdbg.p, 0, 16 * 8));
+    } else {
+        ex->d_octdbg.release();
+    }
+    ex->octdbg_level = level;
     return ORBX_OK;
 }
 
