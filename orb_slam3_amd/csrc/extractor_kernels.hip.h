@@ -64,6 +64,13 @@ __global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo *__restrict__ 
 // measured 1.6x slower: the footprint set-up adds a third dependent memory round trip per small workgroup.)
 // grid (ceil(words_per_frame/256), B)
 // ---------------------------------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 as_pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+constexpr int kResizeRows = 2;  // output rows per thread (measured: 1 -> 0.032, 2 -> 0.024, 4 -> 0.033 ms per level launch)
+
 __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict__ lv, int level,
                                                     const ResizeTap *__restrict__ xtab,
                                                     const ResizeTap *__restrict__ ytab,
@@ -74,54 +81,70 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict_
     const int wpr = L.pitch >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
-    const int py = idx / wpr, wi = idx - py * wpr;
-    if (py >= L.h + 2 * kEdge) return;
+    const int pg = idx / wpr, wi = idx - pg * wpr;
+    const int rows = L.h + 2 * kEdge;
+    const int py0 = pg * kResizeRows;
+    if (py0 >= rows) return;
     uint8_t *frame = pyr + (size_t)f * pyr_frame_stride;
     const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX;  // previous level ROI origin
-    const int ry = reflect101(py - kEdge, L.h);
-    const ResizeTap ty = ytab[L.ytab_off + ry];
-    const int sy0 = min(max(ty.ofs, 0), P.h - 1), sy1 = min(max(ty.ofs + 1, 0), P.h - 1);
-    const uint8_t *S0 = proi + (size_t)sy0 * P.pitch;
-    const uint8_t *S1 = proi + (size_t)sy1 * P.pitch;
-    const int b0 = ty.c0, b1 = ty.c1;
-    uint32_t out = 0;
     const uint4 gc = *reinterpret_cast<const uint4 *>(&xg[L.xg_off + wi].cc[0]);
     const uint4 gh = *reinterpret_cast<const uint4 *>(&xg[L.xg_off + wi]);  // base, sel, valid
+    ResizeTap ty[kResizeRows];
+#pragma unroll
+    for (int r = 0; r < kResizeRows; r++) ty[r] = ytab[L.ytab_off + reflect101(min(py0 + r, rows - 1) - kEdge, L.h)];
+    uint8_t *drow = frame + L.off + (size_t)py0 * L.pitch + wi * 4;
     if (gh.z) {
         // all eight source bytes of a row in one unaligned 8-byte load; v_perm_b32 picks the left / right taps
-        uint2 r0, r1;
-        __builtin_memcpy(&r0, S0 + (int)gh.x, 8);
-        __builtin_memcpy(&r1, S1 + (int)gh.x, 8);
-        const uint32_t selr = gh.y + 0x01010101u;
-        const uint32_t l0 = __builtin_amdgcn_perm(r0.y, r0.x, gh.y), q0 = __builtin_amdgcn_perm(r0.y, r0.x, selr);
-        const uint32_t l1 = __builtin_amdgcn_perm(r1.y, r1.x, gh.y), q1 = __builtin_amdgcn_perm(r1.y, r1.x, selr);
-        const uint32_t cc[4] = {gc.x, gc.y, gc.z, gc.w};
+        uint2 r0[kResizeRows], r1[kResizeRows];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int c0 = (int)(cc[k] & 0xffffu), c1 = (int)(cc[k] >> 16);
-            const int h0 = (int)((l0 >> (8 * k)) & 0xff) * c0 + (int)((q0 >> (8 * k)) & 0xff) * c1;
-            const int h1 = (int)((l1 >> (8 * k)) & 0xff) * c0 + (int)((q1 >> (8 * k)) & 0xff) * c1;
-            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            out |= (uint32_t)v << (8 * k);
+        for (int r = 0; r < kResizeRows; r++) {
+            const int sy0 = min(max(ty[r].ofs, 0), P.h - 1), sy1 = min(max(ty[r].ofs + 1, 0), P.h - 1);
+            __builtin_memcpy(&r0[r], proi + (size_t)sy0 * P.pitch + (int)gh.x, 8);
+            __builtin_memcpy(&r1[r], proi + (size_t)sy1 * P.pitch + (int)gh.x, 8);
         }
-    } else {
+        const uint32_t selr = gh.y + 0x01010101u;
+        const uint32_t cc[4] = {gc.x, gc.y, gc.z, gc.w};
+        constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = wi * 4 + k - kRoiX;
-            if (x >= -kEdge && x < L.w + kEdge) {
-                const ResizeTap tx = xtab[L.xtab_off + reflect101(x, L.w)];
-                // when ofs+1 == P.w the tap c1 is 0 and the byte read is the (valid) ring pixel
-                const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
-                const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
-                int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        for (int r = 0; r < kResizeRows; r++) {
+            const uint32_t l0 = __builtin_amdgcn_perm(r0[r].y, r0[r].x, gh.y), q0 = __builtin_amdgcn_perm(r0[r].y, r0[r].x, selr);
+            const uint32_t l1 = __builtin_amdgcn_perm(r1[r].y, r1[r].x, gh.y), q1 = __builtin_amdgcn_perm(r1[r].y, r1[r].x, selr);
+            const int b0 = ty[r].c0, b1 = ty[r].c1;
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // horizontal pass: S[sx] * alpha0 + S[sx+1] * alpha1 as one v_dot2_u32_u16 (cc[k] = alpha0 | alpha1 << 16)
+                const int h0 = (int)__builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
+                const int h1 = (int)__builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
+                int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
                 v = min(max(v, 0), 255);
                 out |= (uint32_t)v << (8 * k);
             }
+            if (py0 + r < rows) *reinterpret_cast<uint32_t *>(drow + (size_t)r * L.pitch) = out;
+        }
+    } else {
+        for (int r = 0; r < kResizeRows && py0 + r < rows; r++) {
+            const int sy0 = min(max(ty[r].ofs, 0), P.h - 1), sy1 = min(max(ty[r].ofs + 1, 0), P.h - 1);
+            const uint8_t *S0 = proi + (size_t)sy0 * P.pitch;
+            const uint8_t *S1 = proi + (size_t)sy1 * P.pitch;
+            const int b0 = ty[r].c0, b1 = ty[r].c1;
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = wi * 4 + k - kRoiX;
+                if (x >= -kEdge && x < L.w + kEdge) {
+                    const ResizeTap tx = xtab[L.xtab_off + reflect101(x, L.w)];
+                    // when ofs+1 == P.w the tap c1 is 0 and the byte read is the (valid) ring pixel
+                    const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
+                    const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
+                    int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    v = min(max(v, 0), 255);
+                    out |= (uint32_t)v << (8 * k);
+                }
+            }
+            *reinterpret_cast<uint32_t *>(drow + (size_t)r * L.pitch) = out;
         }
     }
-    uint8_t *drow = frame + L.off + (size_t)py * L.pitch;
-    *reinterpret_cast<uint32_t *>(drow + wi * 4) = out;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -328,10 +351,6 @@ __global__ __launch_bounds__(TPB) void k_fast_cells(const LevelInfo *__restrict_
 //   dword aligned), score tile (ih + 2) x 64 with a zero apron, queue of (y << 8 | x) u16 in row-major order.
 // grid (total_cells, B), block 64
 // ---------------------------------------------------------------------------------------------------------
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ u16x2 as_pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
-__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ u16x2 pk_even(uint32_t v) { return as_pk(__builtin_amdgcn_perm(0u, v, 0x0c020c00u)); }  // bytes 0, 2
 __device__ __forceinline__ u16x2 pk_odd(uint32_t v) { return as_pk(__builtin_amdgcn_perm(0u, v, 0x0c030c01u)); }   // bytes 1, 3
 __device__ __forceinline__ u16x2 pk_max(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }

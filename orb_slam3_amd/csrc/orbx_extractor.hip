@@ -249,7 +249,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
-        dim3 grid(((L.pitch / 4) * (L.h + 2 * kEdge) + 255) / 256, n);
+        dim3 grid(((L.pitch / 4) * ((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255) / 256, n);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, d_lv, l, (const ResizeTap *)ex->d_xtab.p,
                            (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame);
     }
