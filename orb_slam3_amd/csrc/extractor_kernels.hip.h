@@ -744,12 +744,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // ---------------------------------------------------------------------------------------------------------
 // One wave per keypoint: IC_Angle on the UNBLURRED level (:76-103), steered 256-pair BRIEF on the BLURRED level
 // (:107-146), keypoint record + descriptor written to the final slot.
-//   disc  : 749 (u,v) offsets of the orientation patch, lane-strided, two int32 moments reduced with shuffles
+//   disc  : lane = column u of the orientation disc (upper / lower half of the wave = rows v >= 0 / v < 0), 16 row steps;
+//           the moments are integer sums, so the summation order is free; reduced with a DPP scan
 //   brief : lane i evaluates pattern pairs i, i+64, i+128, i+192; 4 ballots = 4 x u64 = the 32-byte descriptor
 // grid (ceil(cap/4), B), block 256
 // ---------------------------------------------------------------------------------------------------------
 struct DescConst {
-    int8_t disc_u[752], disc_v[752];   // 749 used
+    int8_t vmax_of_u[16];              // orientation disc: largest |v| with umax[|v|] >= |u|
     int8_t pat[1024];                  // bit_pattern_31_ (x0,y0,x1,y1) x 256
 };
 
@@ -770,9 +771,16 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
     if (g >= count[f]) return;  // wave-uniform; no block-level barrier below
     uint8_t *A = patches + (threadIdx.x >> 6) * kDescWaveLds;
     uint8_t *Bp = A + kDescAP * kDescAR;
-    const WorkItem w = work[(size_t)f * cap + g];
+    WorkItem w = work[(size_t)f * cap + g];
+    // the keypoint is the same for the whole wave: keep it (and every address derived from it) in scalar registers
+    w.key = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.key);
+    w.level = __builtin_amdgcn_readfirstlane(w.level);
+    w.pos = __builtin_amdgcn_readfirstlane(w.pos);
     const LevelInfo L = lv[w.level];
     const int kx = key_x(w.key), ky = key_y(w.key);
+    // orientation disc column of this lane (loaded early: its latency hides behind the patch loads)
+    const int du = (lane & 31) - kHalfPatch, dhalf = lane >> 5;
+    const int dvmax = (lane & 31) <= 2 * kHalfPatch ? dc->vmax_of_u[du < 0 ? -du : du] : -1;
 
     // ---- stage both patches with aligned dword loads: one memory round trip for the whole keypoint ----
     const int axA = (kx - kHalfPatch) & 3, axB = (kx - 18) & 3;
@@ -785,13 +793,13 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
         for (int k = 0; k < 5; k++) {
             const int idx = lane + 64 * k;
             const int r = idx / 9, c = idx - r * 9;
-            va[k] = (idx < kDescAR * 9) ? *reinterpret_cast<const uint32_t *>(srcA + (size_t)r * L.pitch + 4 * c) : 0u;
+            va[k] = (idx < kDescAR * 9) ? *reinterpret_cast<const uint32_t *>(srcA + (uint32_t)(r * L.pitch + 4 * c)) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const int idx = lane + 64 * k;
             const int r = idx / 10, c = idx - r * 10;
-            vb[k] = (idx < kDescBR * 10) ? *reinterpret_cast<const uint32_t *>(srcB + (size_t)r * L.bpitch + 4 * c) : 0u;
+            vb[k] = (idx < kDescBR * 10) ? *reinterpret_cast<const uint32_t *>(srcB + (uint32_t)(r * L.bpitch + 4 * c)) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -809,20 +817,22 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (single-wave producer/consumer)
 
-    // ---- IC_Angle on the unblurred patch ----
-    const uint8_t *c0 = A + kHalfPatch * kDescAP + kHalfPatch + axA;
-    int m10 = 0, m01 = 0;
-    for (int i = lane; i < 749; i += 64) {
-        const int u = dc->disc_u[i], v = dc->disc_v[i];
-        const int I = c0[v * kDescAP + u];
-        m10 += u * I;
-        m01 += v * I;
-    }
+    // ---- IC_Angle on the unblurred patch (:76-103): m_10 = sum u*I, m_01 = sum v*I over the disc ----
+    const uint8_t *c0 = A + kHalfPatch * kDescAP + kHalfPatch + axA + du;
+    int sumI = 0, m01 = 0;
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        m10 += __shfl_xor(m10, s);
-        m01 += __shfl_xor(m01, s);
+    for (int k = 0; k < 16; k++) {
+        const int av = k + dhalf;            // |v|: rows 0..15 in the upper half, 1..15(16) in the lower half
+        const int v = dhalf ? -av : av;
+        if (av <= dvmax) {
+            const int I = c0[v * kDescAP];
+            sumI += I;
+            m01 += v * I;
+        }
     }
+    int m10 = du * sumI;
+    m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);
+    m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // ---- steered BRIEF on the blurred patch ----

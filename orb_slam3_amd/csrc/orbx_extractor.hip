@@ -435,11 +435,16 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     DescConst dc;
     memset(&dc, 0, sizeof(dc));
     int n = 0;
-    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
-        const int d = ex->umax[std::abs(v)];
-        for (int u = -d; u <= d; u++) { dc.disc_u[n] = (int8_t)u; dc.disc_v[n] = (int8_t)v; n++; }
+    for (int u = 0; u <= kHalfPatch; u++) {   // column form of the disc {(u, v) : |u| <= umax[|v|]} (:82-100)
+        int vm = -1;
+        for (int v = 0; v <= kHalfPatch; v++) if (ex->umax[v] >= u) vm = v;
+        dc.vmax_of_u[u] = (int8_t)vm;
+        if (vm >= 0) n += (u == 0 ? 1 : 2) * (2 * vm + 1);
     }
-    if (n != 749) { set_error("orientation disc has " + std::to_string(n) + " pixels"); orbx_destroy(ex); return ORBX_E_INTERNAL; }
+    // the column form equals the row form of :82-100 only for a monotone umax; 749 = pixel count of the reference's disc
+    bool mono = true;
+    for (int v = 0; v < kHalfPatch; v++) mono = mono && ex->umax[v] >= ex->umax[v + 1];
+    if (n != 749 || !mono) { set_error("orientation disc has " + std::to_string(n) + " pixels"); orbx_destroy(ex); return ORBX_E_INTERNAL; }
     memcpy(dc.pat, kPatternData, 1024);
     int r = ex->d_dc.ensure(sizeof(DescConst));
     if (r != ORBX_OK) { orbx_destroy(ex); return r; }
