@@ -26,35 +26,48 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Level 0: copy the input image into the padded level-0 slab, ring = REFLECT_101 of the image.
-// One thread writes 4 consecutive bytes of a padded row (aligned dword store); threads are mapped flat over
-// (row, dword) so every lane is busy.
+// One thread writes 16 consecutive bytes of a padded row (aligned 16-byte store); threads are mapped flat over
+// (row, chunk) so every lane is busy.
 // grid (ceil(words_per_frame/256), B)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo *__restrict__ lv, const uint8_t *__restrict__ img,
                                                   size_t row_stride, size_t frame_stride, uint8_t *__restrict__ pyr,
                                                   size_t pyr_frame_stride) {
     const LevelInfo L = lv[0];
-    const int wpr = L.pitch >> 2;  // dwords per padded row
+    const int cpr = L.pitch >> 4;  // 16-byte chunks per padded row (the pitch is a multiple of 64)
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
-    const int py = idx / wpr, wi = idx - py * wpr;
+    const int py = idx / cpr, ci = idx - py * cpr;
     if (py >= L.h + 2 * kEdge) return;
     const uint8_t *src = img + (size_t)f * frame_stride;
     const int sy = reflect101(py - kEdge, L.h);
     const uint8_t *srow = src + (size_t)sy * row_stride;
-    const int x0 = wi * 4 - kRoiX;  // ROI x of the first byte
-    uint32_t out = 0;
-    if (x0 >= 0 && x0 + 3 < L.w && ((row_stride | (size_t)(uintptr_t)src) & 3) == 0) {
-        out = *reinterpret_cast<const uint32_t *>(srow + x0);  // interior: aligned dword copy
+    const int x0 = ci * 16 - kRoiX;  // ROI x of the first byte (kRoiX is a multiple of 16)
+    uint4 out;
+    const unsigned align = (unsigned)(row_stride | (size_t)(uintptr_t)src);
+    if (x0 >= 0 && x0 + 15 < L.w && (align & 15) == 0) {
+        out = *reinterpret_cast<const uint4 *>(srow + x0);  // interior: aligned 16-byte copy
     } else {
+        uint32_t o[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = x0 + k;
-            if (x >= -kEdge && x < L.w + kEdge) out |= (uint32_t)srow[reflect101(x, L.w)] << (8 * k);
+        for (int d = 0; d < 4; d++) {
+            const int xd = x0 + 4 * d;
+            uint32_t v = 0;
+            if (xd >= 0 && xd + 3 < L.w && (align & 3) == 0) {
+                v = *reinterpret_cast<const uint32_t *>(srow + xd);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int x = xd + k;
+                    if (x >= -kEdge && x < L.w + kEdge) v |= (uint32_t)srow[reflect101(x, L.w)] << (8 * k);
+                }
+            }
+            o[d] = v;
         }
+        out = make_uint4(o[0], o[1], o[2], o[3]);
     }
     uint8_t *drow = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)py * L.pitch;
-    *reinterpret_cast<uint32_t *>(drow + wi * 4) = out;
+    *reinterpret_cast<uint4 *>(drow + ci * 16) = out;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -83,6 +83,7 @@ struct orbx_extractor {
     hipStream_t aux_stream = nullptr, match_stream = nullptr;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
     bool match_pending = false;
+    bool blur_side = true;     // ORBX_BLUR_SIDE=0: k_blur stays on the main stream (after the pyramid)
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream
     hipEvent_t ev_compute_done = nullptr;
     hipEvent_t ev_copy_done[2] = {nullptr, nullptr};  // ring: up to two downloads in flight

@@ -243,7 +243,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     {
         ProfScope ps(ex, K_PYR_BASE);
         const LevelInfo &L = ex->lv[0];
-        dim3 grid(((L.pitch / 4) * (L.h + 2 * kEdge) + 255) / 256, n);
+        dim3 grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n);
         hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, d_lv, d_images, row_stride, frame_stride, pyr, ex->pyr_frame);
     }
     for (int l = 1; l < nl; l++) {
@@ -255,7 +255,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     }
     {
         // blur depends only on the pyramid and is needed only by k_describe: run it beside FAST / quad-tree
-        const bool side = !ex->profile && ex->side_streams;
+        const bool side = !ex->profile && ex->side_streams && ex->blur_side;
         hipStream_t bs = side ? ex->aux_stream : st;
         if (side) {
             ORBX_HIP(hipEventRecord(ex->ev_pyr, st));
@@ -321,7 +321,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const int32_t *)ex->d_lvlcnt.p, (WorkItem *)ex->d_work.p, ex->cap, (int32_t *)ex->d_count.p,
                            (int32_t *)ex->d_mono.p, lap0, lap1, (int32_t *)ex->d_err.p);
     }
-    if (!ex->profile && ex->side_streams) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
+    if (!ex->profile && ex->side_streams && ex->blur_side) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
     {
         ProfScope ps(ex, K_DESCRIBE);
         hipLaunchKernelGGL(k_describe, dim3((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
@@ -423,6 +423,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipEventCreate(&ex->ev1);
     (void)hipStreamCreateWithFlags(&ex->copy_stream, hipStreamNonBlocking);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
+    { const char *v = getenv("ORBX_BLUR_SIDE"); ex->blur_side = !(v && v[0] == '0'); }
     (void)hipStreamCreateWithFlags(&ex->aux_stream, hipStreamNonBlocking);
     (void)hipStreamCreateWithFlags(&ex->match_stream, hipStreamNonBlocking);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);

@@ -1,6 +1,8 @@
 cd /root/repo
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_extractor.py -x -q 2>&1 | tail -3
-timeout 300 python bench.py --steps 20 --warmup 3 --cpu-frames 0 2>&1 | tail -1 | python -c "
+for b in 1 0; do
+ORBX_BLUR_SIDE=$b timeout 300 python bench.py --steps 30 --warmup 3 --cpu-frames 0 2>&1 | tail -1 | python -c "
 import json,sys
-j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['kernels']['k_describe'])"
+j=json.loads(sys.stdin.read()); print('blur_side=$b', j['value'], j['ms_per_step'], j['kernels']['k_pyr_base'])"
+done
