@@ -43,7 +43,7 @@ def algorithmic_bytes(sizes, n_frames, feats, cands):
     per = {
         "k_pyr_base": 2 * px[0] * n_frames,                       # image read + level-0 write
         "k_pyr_resize": ((P - px[-1]) + (P - px[0])) * n_frames / (NLEVELS - 1),  # per launch (7 launches)
-        "k_fast_cells": P * n_frames + 4 * Cn,                    # pyramid read + packed candidates
+        "k_fast_wave": P * n_frames + 4 * Cn,                     # pyramid read + packed candidates
         "k_blur": 2 * P * n_frames,
         "k_octree": 8 * Cn + 4 * N,                               # candidates read + gathered, keypoints out
         "k_finalize": 16 * N,
@@ -64,7 +64,7 @@ def cpu_baseline(frames, n_sample):
     feats = 0
     prev = None
     for t in range(n_sample):
-        _, k, d = oex.extract(frames[t], lap=(0, 1000))
+        _, k, d = oex.extract(frames[t % len(frames)], lap=(0, 1000))
         feats += len(k)
         if prev is not None:
             k0, d0 = prev
@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frames per step (per GPU)")
-    ap.add_argument("--cpu-frames", type=int, default=96, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=384, help="frames in the CPU baseline sample, cycling over the batch (0 = skip); 384 = about 13 s of one core")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--workload", choices=["euroc", "kitti"], default="euroc",
                     help="euroc = BASELINE metric config (mono extract + frame-to-frame match); kitti = config 3 (stereo extract + ComputeStereoMatches)")
@@ -272,7 +272,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
-        cpu = cpu_baseline(frames, min(args.cpu_frames, B))
+        cpu = cpu_baseline(frames, args.cpu_frames)
 
     if rank == 0:
         out = {
