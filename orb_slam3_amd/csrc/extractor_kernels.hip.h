@@ -44,23 +44,42 @@ __global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo *__restrict__ 
     const uint8_t *srow = src + (size_t)sy * row_stride;
     const int x0 = ci * 16 - kRoiX;  // ROI x of the first byte (kRoiX is a multiple of 16)
     uint4 out;
-    const unsigned align = (unsigned)(row_stride | (size_t)(uintptr_t)src);
-    if (x0 >= 0 && x0 + 15 < L.w && (align & 15) == 0) {
-        out = *reinterpret_cast<const uint4 *>(srow + x0);  // interior: aligned 16-byte copy
-    } else {
-        uint32_t o[4];
+    auto reversed16 = [&](int first, int x_lo) {
+        // out[k] = srow[first + 15 - k] for the bytes whose ROI x = x_lo + k lies inside the 19-px ring, 0 elsewhere
+        // (REFLECT_101 maps a ring segment onto a reversed run of source bytes)
+        uint4 v;
+        __builtin_memcpy(&v, srow + first, 16);
+        uint32_t o[4] = {__builtin_amdgcn_perm(0u, v.w, 0x00010203u), __builtin_amdgcn_perm(0u, v.z, 0x00010203u),
+                         __builtin_amdgcn_perm(0u, v.y, 0x00010203u), __builtin_amdgcn_perm(0u, v.x, 0x00010203u)};
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            const int xd = x0 + 4 * d;
-            uint32_t v = 0;
-            if (xd >= 0 && xd + 3 < L.w && (align & 3) == 0) {
-                v = *reinterpret_cast<const uint32_t *>(srow + xd);
-            } else {
+            uint32_t m = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int x = xd + k;
-                    if (x >= -kEdge && x < L.w + kEdge) v |= (uint32_t)srow[reflect101(x, L.w)] << (8 * k);
-                }
+            for (int k = 0; k < 4; k++) {
+                const int x = x_lo + 4 * d + k;
+                m |= (x >= -kEdge && x < L.w + kEdge) ? (0xffu << (8 * k)) : 0u;
+            }
+            o[d] &= m;
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    if (x0 >= 0 && x0 + 15 < L.w) {
+        __builtin_memcpy(&out, srow + x0, 16);          // interior: 16-byte copy (any source alignment)
+    } else if (x0 + 15 < 0) {
+        if (x0 + 15 < -kEdge) out = make_uint4(0, 0, 0, 0);
+        else out = reversed16(-x0 - 15, x0);            // left ring: x -> -x
+    } else if (x0 >= L.w && L.w >= 48) {
+        if (x0 >= L.w + kEdge) out = make_uint4(0, 0, 0, 0);
+        else out = reversed16(2 * L.w - 2 - x0 - 15, x0);  // right ring: x -> 2w-2-x
+    } else {
+        uint32_t o[4];  // chunk straddling the right end of the ROI
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = x0 + 4 * d + k;
+                if (x >= -kEdge && x < L.w + kEdge) v |= (uint32_t)srow[reflect101(x, L.w)] << (8 * k);
             }
             o[d] = v;
         }
