@@ -458,15 +458,17 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
     // phase 1: antipodal-pair test at minTh, four pixels per lane; passing pixels are queued in row-major order
     int qn = 0;
     {
-        const int G = (iw + 3) >> 2, NG = G * ih;
+        // lane -> (row inside the iteration, 4-pixel group): 64 / G whole rows per iteration, so nothing is divided in the loop
+        const int G = (iw + 3) >> 2, RPI = 64 / G;
         const uint32_t rcpG = ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G;
+        const int lrow = (int)(((uint32_t)lane * rcpG) >> 20), lg = lane - lrow * G;
+        const uint32_t vmask = lrow < RPI ? (0xfu >> max(4 * lg + 3 - (iw - 1), 0)) : 0u;  // pixels of the last group beyond the interior
+        const uint8_t *Abase = pix + lrow * kFwPitch + 4 * lg + 4;
+        const uint32_t ebase = ((uint32_t)lrow << 8) | (uint32_t)(4 * lg);
         const u16x2 t2 = as_pk((uint32_t)minTh * 0x00010001u);
-        for (int i0 = 0; i0 < NG; i0 += 64) {
-            const int i = i0 + lane;
-            const bool act = i < NG;
-            const int ii = act ? i : 0;
-            const int y = (int)(((uint32_t)ii * rcpG) >> 20), gq = ii - y * G;
-            const uint32_t *A = reinterpret_cast<const uint32_t *>(pix + y * kFwPitch + 4 * gq + 4);  // row y-3 of the centre row y+3
+        for (int y0 = 0; y0 < ih; y0 += RPI) {
+            const bool act = y0 + lrow < ih;
+            const uint32_t *A = reinterpret_cast<const uint32_t *>(Abase + y0 * kFwPitch);  // row y-3 of the centre row y+3
             const uint32_t r8 = A[0], r0 = A[6 * 16];
             const uint32_t aL = A[1 * 16 - 1], aC = A[1 * 16], aR = A[1 * 16 + 1];    // centre row - 2
             const uint32_t cL = A[3 * 16 - 1], cC = A[3 * 16], cR = A[3 * 16 + 1];    // centre row
@@ -481,12 +483,11 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
             const uint32_t one = 0x00010001u;
             const uint32_t z = as_u32(pk_min(as_pk(fe), as_pk(one))) | (as_u32(pk_min(as_pk(fo), as_pk(one))) << 1);  // bits 0,1,16,17
             uint32_t m4 = (z | (z >> 14)) & 0xfu;
-            const int over = max(4 * gq + 3 - (iw - 1), 0);  // pixels of the last group beyond the interior
-            m4 &= act ? (0xfu >> over) : 0u;
+            m4 &= act ? vmask : 0u;
             const int c = __popc(m4);
             const int incl = wave_incl_scan(c);
             int pos = qn + incl - c;
-            const uint32_t e0 = ((uint32_t)y << 8) | (uint32_t)(4 * gq);
+            const uint32_t e0 = ebase + ((uint32_t)y0 << 8);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (m4 & (1u << k)) { queue[pos] = (uint16_t)(e0 + k); pos++; }
