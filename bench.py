@@ -192,7 +192,8 @@ def main():
     def enqueue(i):
         e, hs = exs[i % NL], host[i % (2 * NL)]
         e.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, (0, 1000))
-        e.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        if not os.environ.get("ORBX_BENCH_SKIP_MATCH"):   # diagnostic switches, never set for a reported number
+            e.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
         e.download_async(hs.kps.data_ptr(), hs.desc.data_ptr(), hs.cnt.data_ptr(), hs.mono.data_ptr(),
                          hs.match.data_ptr(), hs.nm.data_ptr())
 
