@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step (per GPU)")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step (per GPU)")
     ap.add_argument("--cpu-frames", type=int, default=384, help="frames in the CPU baseline sample, cycling over the batch (0 = skip); 384 = about 13 s of one core")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--workload", choices=["euroc", "kitti"], default="euroc",
