@@ -914,4 +914,204 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
     if (lane == 0) *R.nmatches = nmatches;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Matchers whose inner loop carries more state than the candidate lists of k_window_best2 can encode
+// (SearchForInitialization's vMatchedDistance, the BoW merge-joins): ONE WAVE replays the reference's query loop in its
+// own order; the 64 lanes evaluate the candidates of the current query in parallel (Hamming distance on the fly) against
+// the state left by the queries before it, and a packed-key wave minimum gives "first (or last) minimum in the
+// reference's candidate order" plus the second-best distance.  Everything stays on the device.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dev_rot_bin(float a1, float a2) {  // e.g. ORBmatcher.cc:337-343
+    float rot = a1 - a2;
+    if (rot < 0.0f) rot += 360.0f;
+    int b = (int)roundf(rot * (1.0f / ORBX_HISTO_LENGTH));
+    if (b == ORBX_HISTO_LENGTH) b = 0;
+    return b;
+}
+// ComputeThreeMaxima (ORBmatcher.cc:2012-2053)
+__device__ __forceinline__ void dev_three_maxima(const int *hist, int &ind1, int &ind2, int &ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+struct InitProblem {  // ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763)
+    const orbx_keypoint *kps1; const uint8_t *desc1; int n1;
+    const orbx_keypoint *kps2; const uint8_t *desc2; int n2;
+    float *prev_matched;       // vbPrevMatched (x, y) per F1 feature; updated at the end (:757-760)
+    float window; float nnratio; int check_orientation;
+    int32_t *matches12;        // out [n1]
+    int32_t *matches21;        // scratch [n2]
+    int32_t *matched_dist;     // scratch [n2]  (vMatchedDistance)
+    int32_t *entries;          // scratch [n1]: rotation histogram pushes bin << 16 | i1
+    int32_t *nmatches;         // out
+};
+
+__global__ __launch_bounds__(64) void k_replay_init(InitProblem P, GridParams g) {
+    __shared__ int hist[ORBX_HISTO_LENGTH];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < P.n1; i += 64) P.matches12[i] = -1;
+    for (int i = lane; i < P.n2; i += 64) { P.matches21[i] = -1; P.matched_dist[i] = INT_MAX; }
+    if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0, n_entries = 0;
+    for (int i1 = 0; i1 < P.n1; i1++) {
+        const orbx_keypoint k1p = P.kps1[i1];
+        if (k1p.octave > 0) continue;  // :665
+        const QueryWin w = make_window(g, P.prev_matched[2 * i1], P.prev_matched[2 * i1 + 1], P.window, k1p.octave, k1p.octave, 0.f);
+        if (w.empty) continue;
+        const Desc dq = load_desc(P.desc1 + (size_t)i1 * 32);
+        u64 k1 = kNoKey, k2 = kNoKey;
+        for (int i2 = lane; i2 < P.n2; i2 += 64) {
+            const orbx_keypoint kp = P.kps2[i2];
+            int cx, cy;
+            if (!in_window(g, w, kp, &cx, &cy)) continue;
+            const int d = hamming(dq, load_desc(P.desc2 + (size_t)i2 * 32));
+            if (P.matched_dist[i2] <= d) continue;  // :687-688
+            push2(k1, k2, cand_key(d, cx, cy, i2));
+        }
+        wave_min2(k1, k2);
+        if (k1 == kNoKey) continue;
+        const int best = (int)(k1 >> 32), best2 = (int)(k1 & 0xffff);
+        const float second = (k2 == kNoKey) ? (float)INT_MAX : (float)(int)(k2 >> 32);
+        if (best <= ORBX_TH_LOW && (float)best < second * P.nnratio) {  // :707-711
+            const int old = P.matches21[best2];
+            if (old >= 0) nmatches--;
+            nmatches++;
+            if (lane == 0) {
+                if (old >= 0) P.matches12[old] = -1;
+                P.matches12[i1] = best2;
+                P.matches21[best2] = i1;
+                P.matched_dist[best2] = best;
+                if (P.check_orientation) {
+                    const int b = dev_rot_bin(k1p.angle, P.kps2[best2].angle);
+                    hist[b]++;
+                    P.entries[n_entries] = (b << 16) | i1;
+                }
+            }
+            if (P.check_orientation) n_entries++;
+            __threadfence_block();
+            __syncthreads();  // single wave: orders lane 0's state updates before the next query's reads
+        }
+    }
+    __syncthreads();
+    if (P.check_orientation) {
+        int ind1, ind2, ind3;
+        dev_three_maxima(hist, ind1, ind2, ind3);
+        if (lane == 0) {  // :742-755: sequential, an index may sit in the histogram after it was unmatched
+            for (int e = 0; e < n_entries; e++) {
+                const int v = P.entries[e], b = v >> 16, i1 = v & 0xffff;
+                if (b != ind1 && b != ind2 && b != ind3 && P.matches12[i1] >= 0) { P.matches12[i1] = -1; nmatches--; }
+            }
+        }
+        nmatches = __shfl(nmatches, 0);
+        __syncthreads();
+    }
+    for (int i1 = lane; i1 < P.n1; i1 += 64) {  // :757-760
+        const int m = P.matches12[i1];
+        if (m >= 0) { P.prev_matched[2 * i1] = P.kps2[m].x; P.prev_matched[2 * i1 + 1] = P.kps2[m].y; }
+    }
+    if (lane == 0) *P.nmatches = nmatches;
+}
+
+struct FeatVecDev { const uint32_t *node_id; const int32_t *node_ptr; const int32_t *index; int n_nodes; };
+
+struct BowProblem {
+    int mode;   // 0: SearchByBoW(KeyFrame, Frame) :223-425   1: SearchByBoW(KeyFrame, KeyFrame) :765-905
+                // 2: SearchForTriangulation :907-1146 with the geometric gate always true (bCoarse)
+    FeatVecDev fa, fb;
+    const uint8_t *desc_a; const float *angle_a; const uint8_t *skip_a; int na;   // skip_a[i] != 0: feature i of A is not a query
+    const uint8_t *desc_b; const float *angle_b; const uint8_t *skip_b; int nb;   // skip_b[i] != 0: feature i of B is never a candidate
+    float nnratio; int check_orientation;
+    int32_t *match;      // out: mode 0 [nb] (A index per B feature), modes 1, 2 [na] (B index per A feature)
+    uint8_t *taken_b;    // scratch [nb] (mode 1: vbMatched2)
+    int32_t *entries;    // scratch [max(na, nb)]
+    int32_t *nmatches;
+};
+
+__global__ __launch_bounds__(64) void k_replay_bow(BowProblem P) {
+    __shared__ int hist[ORBX_HISTO_LENGTH];
+    const int lane = threadIdx.x;
+    const int nout = P.mode == 0 ? P.nb : P.na;
+    for (int i = lane; i < nout; i += 64) P.match[i] = -1;
+    if (P.mode == 1) for (int i = lane; i < P.nb; i += 64) P.taken_b[i] = 0;
+    if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0, n_entries = 0;
+    int ia = 0, ib = 0;
+    while (ia < P.fa.n_nodes && ib < P.fb.n_nodes) {  // merge-join of the two FeatureVector maps (:246-250, :800-805, :961-965)
+        const uint32_t na_id = P.fa.node_id[ia], nb_id = P.fb.node_id[ib];
+        if (na_id < nb_id) { ia++; continue; }
+        if (nb_id < na_id) { ib++; continue; }
+        const int a0 = P.fa.node_ptr[ia], a1 = P.fa.node_ptr[ia + 1], b0 = P.fb.node_ptr[ib], b1 = P.fb.node_ptr[ib + 1];
+        for (int a = a0; a < a1; a++) {
+            const int i = P.fa.index[a];
+            if (P.skip_a && P.skip_a[i]) continue;
+            const Desc dq = load_desc(P.desc_a + (size_t)i * 32);
+            u64 k1 = kNoKey, k2 = kNoKey;
+            for (int b = b0 + lane; b < b1; b += 64) {
+                const int j = P.fb.index[b];
+                if (P.skip_b && P.skip_b[j]) continue;
+                if (P.mode == 0 && P.match[j] >= 0) continue;   // vpMapPointMatches[realIdxF] already set (:281)
+                if (P.mode == 1 && P.taken_b[j]) continue;      // vbMatched2 (:826)
+                const int d = hamming(dq, load_desc(P.desc_b + (size_t)j * 32));
+                const uint32_t pos = (uint32_t)(b - b0);
+                if (P.mode == 2) {
+                    if (d > ORBX_TH_LOW) continue;               // :1017: '>' twice, so a later equal candidate wins
+                    push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)(0xffffffffu - pos));
+                } else {
+                    push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)pos);
+                }
+            }
+            wave_min2(k1, k2);
+            if (k1 == kNoKey) continue;
+            const int best = (int)(k1 >> 32);
+            const uint32_t pos = P.mode == 2 ? 0xffffffffu - (uint32_t)(k1 & 0xffffffffu) : (uint32_t)(k1 & 0xffffffffu);
+            const int j = P.fb.index[b0 + (int)pos];
+            const float second = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
+            bool ok;
+            if (P.mode == 0) ok = best <= ORBX_TH_LOW && (float)best < P.nnratio * second;      // :318-320
+            else if (P.mode == 1) ok = best < ORBX_TH_LOW && (float)best < P.nnratio * second;  // :848-850 (strict)
+            else ok = true;
+            if (!ok) continue;
+            const int out_idx = P.mode == 0 ? j : i, out_val = P.mode == 0 ? i : j;
+            nmatches++;
+            if (lane == 0) {
+                P.match[out_idx] = out_val;
+                if (P.mode == 1) P.taken_b[j] = 1;
+                if (P.check_orientation) {
+                    const int bin = dev_rot_bin(P.angle_a[i], P.angle_b[j]);
+                    hist[bin]++;
+                    P.entries[n_entries] = (bin << 16) | out_idx;
+                }
+            }
+            if (P.check_orientation) n_entries++;
+            __threadfence_block();
+            __syncthreads();
+        }
+        ia++; ib++;
+    }
+    __syncthreads();
+    if (P.check_orientation) {
+        int ind1, ind2, ind3;
+        dev_three_maxima(hist, ind1, ind2, ind3);
+        int dropped = 0;
+        for (int e = lane; e < n_entries; e += 64) {
+            const int v = P.entries[e], b = v >> 16;
+            if (b != ind1 && b != ind2 && b != ind3) { P.match[v & 0xffff] = -1; dropped++; }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) dropped += __shfl_xor(dropped, s);
+        nmatches -= dropped;
+    }
+    if (lane == 0) *P.nmatches = nmatches;
+}
+
 }  // namespace orbx

@@ -400,10 +400,11 @@ extern "C" int orbx_search_by_projection_window(orbx_matcher *m, const orbx_fram
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Matchers whose inner loop carries more state than a taken-mask (SearchForInitialization's vMatchedDistance,
-// the BoW merge-joins, SearchForTriangulation's lazily evaluated geometric gate): the GPU evaluates every candidate
-// distance of the reference's enumeration (orbx_hamming_csr), the host replays the reference's sequential logic over
-// those distances in the reference's order -- identical pairs (hard part 4).
+// Matchers whose inner loop carries more state than a taken-mask: SearchForInitialization (vMatchedDistance) and the BoW
+// merge-joins run entirely on the device (k_replay_init / k_replay_bow, one wave replays the reference's query order).
+// SearchForTriangulation with a geometric gate keeps one host piece: the camera model's epipolarConstrain lives in the
+// adapter (camera models are out of scope), so the device evaluates every candidate distance of the reference's enumeration
+// and the loop calls the gate back exactly where the reference evaluates it.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -517,66 +518,102 @@ int bow_distances(orbx_matcher *m, const uint8_t *descA, const uint8_t *skipA, c
 
 extern "C" {
 
-// ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763)
+// ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763): k_replay_init
 int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un, const uint8_t *desc1, int n1, const orbx_frame_desc *F2,
                                    float *prev_matched, int window_size, float nnratio, int check_orientation, int32_t *matches12) {
     if (!m || !F2 || !matches12 || n1 < 0 || (n1 > 0 && (!kps1_un || !desc1 || !prev_matched))) return ORBX_E_BAD_ARG;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     const int n2 = F2->n;
     if (n1 == 0 || n2 == 0) return 0;
-    HostGrid grid(F2);
-    std::vector<int32_t> q_idx, row_ptr(1, 0), cand, tmp;
-    for (int i1 = 0; i1 < n1; i1++) {
-        const int level1 = kps1_un[i1].octave;
-        if (level1 > 0) continue;  // :665
-        tmp.clear();
-        grid.query(prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size, level1, level1, tmp);
-        if (tmp.empty()) continue;
-        q_idx.push_back(i1);
-        cand.insert(cand.end(), tmp.begin(), tmp.end());
-        row_ptr.push_back((int32_t)cand.size());
-    }
-    const int nq = (int)q_idx.size();
-    std::vector<uint16_t> dist(cand.size());
-    if (nq > 0) {
-        std::vector<uint8_t> qd((size_t)nq * 32);
-        for (int k = 0; k < nq; k++) memcpy(&qd[(size_t)k * 32], desc1 + (size_t)q_idx[k] * 32, 32);
-        const int r = orbx_hamming_csr(m, qd.data(), nq, F2->descriptors, n2, row_ptr.data(), cand.data(), dist.data());
-        if (r != ORBX_OK) return r;
-    }
-    // sequential replay in query order
-    int nmatches = 0;
-    std::vector<int> matched_dist(n2, INT_MAX), matches21(n2, -1);
-    RotHist hist;
-    for (int k = 0; k < nq; k++) {
-        const int i1 = q_idx[k];
-        int best = INT_MAX, second = INT_MAX, best_i2 = -1;
-        for (int c = row_ptr[k]; c < row_ptr[k + 1]; c++) {
-            const int i2 = cand[c], d = dist[c];
-            if (matched_dist[i2] <= d) continue;  // :687-688
-            if (d < best) { second = best; best = d; best_i2 = i2; }
-            else if (d < second) second = d;
-        }
-        if (best <= ORBX_TH_LOW && (float)best < (float)second * nnratio) {
-            if (matches21[best_i2] >= 0) { matches12[matches21[best_i2]] = -1; nmatches--; }
-            matches12[i1] = best_i2;
-            matches21[best_i2] = i1;
-            matched_dist[best_i2] = best;
-            nmatches++;
-            if (check_orientation) hist.push(rotation_bin(kps1_un[i1].angle, F2->keypoints_un[best_i2].angle), i1);
-        }
-    }
-    if (check_orientation)
-        hist.filter([&](int i1) { if (matches12[i1] >= 0) { matches12[i1] = -1; nmatches--; } });
-    for (int i1 = 0; i1 < n1; i1++)  // :757-760
-        if (matches12[i1] >= 0) {
-            prev_matched[2 * i1] = F2->keypoints_un[matches12[i1]].x;
-            prev_matched[2 * i1 + 1] = F2->keypoints_un[matches12[i1]].y;
-        }
-    return nmatches;
+    if (n1 > 65535 || n2 > 65535) return ORBX_E_TOO_LARGE;
+    ORBX_HIP(hipSetDevice(m->device));
+    const size_t need = Arena::pad(28 * (size_t)n1) + Arena::pad(32 * (size_t)n1) + Arena::pad(28 * (size_t)n2) + Arena::pad(32 * (size_t)n2) +
+                        Arena::pad(8 * (size_t)n1) + 2 * Arena::pad(4 * (size_t)n1) + 2 * Arena::pad(4 * (size_t)n2) + 4096;
+    int r = m->arena.reserve(need);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    A.reset();
+    InitProblem P;
+    memset(&P, 0, sizeof(P));
+    orbx_keypoint *dk1 = A.take<orbx_keypoint>(n1), *dk2 = A.take<orbx_keypoint>(n2);
+    uint8_t *dd1 = A.take<uint8_t>(32 * (size_t)n1), *dd2 = A.take<uint8_t>(32 * (size_t)n2);
+    float *dprev = A.take<float>(2 * (size_t)n1);
+    H2D(dk1, kps1_un, 28 * (size_t)n1); H2D(dd1, desc1, 32 * (size_t)n1);
+    H2D(dk2, F2->keypoints_un, 28 * (size_t)n2); H2D(dd2, F2->descriptors, 32 * (size_t)n2);
+    H2D(dprev, prev_matched, 8 * (size_t)n1);
+    P.kps1 = dk1; P.desc1 = dd1; P.n1 = n1; P.kps2 = dk2; P.desc2 = dd2; P.n2 = n2; P.prev_matched = dprev;
+    P.window = (float)window_size; P.nnratio = nnratio; P.check_orientation = check_orientation ? 1 : 0;
+    P.matches12 = A.take<int32_t>(n1); P.entries = A.take<int32_t>(n1);
+    P.matches21 = A.take<int32_t>(n2); P.matched_dist = A.take<int32_t>(n2);
+    P.nmatches = A.take<int32_t>(4);
+    GridParams g;
+    g.minx = F2->min_x; g.miny = F2->min_y;
+    g.inv_w = 64.0f / (F2->max_x - F2->min_x);
+    g.inv_h = 48.0f / (F2->max_y - F2->min_y);
+    hipLaunchKernelGGL(k_replay_init, dim3(1), dim3(64), 0, m->stream, P, g);
+    int32_t nm = 0;
+    D2H(matches12, P.matches12, 4 * (size_t)n1);
+    D2H(prev_matched, dprev, 8 * (size_t)n1);
+    D2H(&nm, P.nmatches, 4);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return nm;
 }
 
-// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (ORBmatcher.cc:223-425), monocular form
+}  // extern "C"
+
+namespace {
+// k_replay_bow on host pointers: mode 0 SearchByBoW(KF, Frame), 1 SearchByBoW(KF, KF), 2 SearchForTriangulation without a gate
+int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float *angle_a, const uint8_t *skip_a, int na, const orbx_featvec *fa,
+                   const uint8_t *desc_b, const float *angle_b, const uint8_t *skip_b, int nb, const orbx_featvec *fb, float nnratio,
+                   int check_orientation, int32_t *match_out, int n_out) {
+    if (na > 65535 || nb > 65535) return ORBX_E_TOO_LARGE;
+    ORBX_HIP(hipSetDevice(m->device));
+    const size_t ia = (size_t)fa->node_ptr[fa->n_nodes], ib = (size_t)fb->node_ptr[fb->n_nodes];
+    const size_t need = Arena::pad(33 * (size_t)na) + Arena::pad(33 * (size_t)nb) + 2 * Arena::pad(4 * (size_t)std::max(na, nb)) * 2 +
+                        Arena::pad(8 * (size_t)fa->n_nodes + 8) + Arena::pad(8 * (size_t)fb->n_nodes + 8) + Arena::pad(4 * ia) + Arena::pad(4 * ib) +
+                        Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 8192;
+    int r = m->arena.reserve(need);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    A.reset();
+    BowProblem P;
+    memset(&P, 0, sizeof(P));
+    auto up_fv = [&](const orbx_featvec *f, FeatVecDev &d, size_t nidx) -> int {
+        uint32_t *id = A.take<uint32_t>(f->n_nodes + 1);
+        int32_t *ptr = A.take<int32_t>(f->n_nodes + 1), *idx = A.take<int32_t>(nidx + 1);
+        if (f->n_nodes > 0) H2D(id, f->node_id, 4 * (size_t)f->n_nodes);
+        H2D(ptr, f->node_ptr, 4 * (size_t)(f->n_nodes + 1));
+        if (nidx > 0) H2D(idx, f->index, 4 * nidx);
+        d.node_id = id; d.node_ptr = ptr; d.index = idx; d.n_nodes = f->n_nodes;
+        return ORBX_OK;
+    };
+    if ((r = up_fv(fa, P.fa, ia)) != ORBX_OK || (r = up_fv(fb, P.fb, ib)) != ORBX_OK) return r;
+    auto up = [&](const void *src, size_t bytes) -> const uint8_t * {
+        if (!src) return nullptr;
+        uint8_t *d = A.take<uint8_t>(bytes);
+        if (hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) return nullptr;
+        return d;
+    };
+    P.mode = mode;
+    P.desc_a = up(desc_a, 32 * (size_t)na); P.desc_b = up(desc_b, 32 * (size_t)nb);
+    P.angle_a = (const float *)up(angle_a, 4 * (size_t)na); P.angle_b = (const float *)up(angle_b, 4 * (size_t)nb);
+    P.skip_a = up(skip_a, na); P.skip_b = up(skip_b, nb);
+    if (!P.desc_a || !P.desc_b || (check_orientation && (!P.angle_a || !P.angle_b))) return ORBX_E_BAD_ARG;
+    P.na = na; P.nb = nb; P.nnratio = nnratio; P.check_orientation = check_orientation ? 1 : 0;
+    P.match = A.take<int32_t>(n_out); P.taken_b = A.take<uint8_t>(nb); P.entries = A.take<int32_t>(std::max(na, nb));
+    P.nmatches = A.take<int32_t>(4);
+    hipLaunchKernelGGL(k_replay_bow, dim3(1), dim3(64), 0, m->stream, P);
+    int32_t nm = 0;
+    D2H(match_out, P.match, 4 * (size_t)n_out);
+    D2H(&nm, P.nmatches, 4);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return nm;
+}
+}  // namespace
+
+extern "C" {
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (ORBmatcher.cc:223-425), monocular form: k_replay_bow mode 0
 int orbx_search_by_bow_frame(orbx_matcher *m, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
                              const orbx_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f, const orbx_featvec *f_fv,
                              float nnratio, int check_orientation, int32_t *f_match) {
@@ -585,61 +622,21 @@ int orbx_search_by_bow_frame(orbx_matcher *m, const uint8_t *kf_desc, const floa
     if (n_kf == 0 || n_f == 0) return 0;
     std::vector<uint8_t> skip(n_kf);
     for (int i = 0; i < n_kf; i++) skip[i] = kf_valid ? !kf_valid[i] : 0;
-    BowPairs P;
-    const int r = bow_distances(m, kf_desc, skip.data(), kf_fv, f_desc, n_f, f_fv, P);
-    if (r != ORBX_OK) return r;
-    int nmatches = 0;
-    RotHist hist;
-    for (size_t k = 0; k < P.q_idx.size(); k++) {
-        int best = 256, second = 256, best_f = -1;
-        for (int c = P.row_ptr[k]; c < P.row_ptr[k + 1]; c++) {
-            const int iF = P.cand[c], d = P.dist[c];
-            if (f_match[iF] >= 0) continue;  // vpMapPointMatches[realIdxF] already set (:281)
-            if (d < best) { second = best; best = d; best_f = iF; }
-            else if (d < second) second = d;
-        }
-        if (best <= ORBX_TH_LOW && (float)best < nnratio * (float)second) {
-            f_match[best_f] = P.q_idx[k];
-            if (check_orientation) hist.push(rotation_bin(kf_angle[P.q_idx[k]], f_angle[best_f]), best_f);
-            nmatches++;
-        }
-    }
-    if (check_orientation) hist.filter([&](int iF) { f_match[iF] = -1; nmatches--; });
-    return nmatches;
+    return run_bow_replay(m, 0, kf_desc, kf_angle, skip.data(), n_kf, kf_fv, f_desc, f_angle, nullptr, n_f, f_fv, nnratio, check_orientation,
+                          f_match, n_f);
 }
 
-// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (ORBmatcher.cc:765-905)
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (ORBmatcher.cc:765-905): k_replay_bow mode 1
 int orbx_search_by_bow_keyframes(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
                                  const orbx_featvec *fv1, const uint8_t *desc2, const float *angle2, const uint8_t *valid2, int n2,
                                  const orbx_featvec *fv2, float nnratio, int check_orientation, int32_t *match12) {
     if (!m || !fv1 || !fv2 || !match12 || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
     for (int i = 0; i < n1; i++) match12[i] = -1;
     if (n1 == 0 || n2 == 0) return 0;
-    std::vector<uint8_t> skip(n1);
-    for (int i = 0; i < n1; i++) skip[i] = valid1 ? !valid1[i] : 0;
-    BowPairs P;
-    const int r = bow_distances(m, desc1, skip.data(), fv1, desc2, n2, fv2, P);
-    if (r != ORBX_OK) return r;
-    int nmatches = 0;
-    std::vector<uint8_t> matched2(n2, 0);
-    RotHist hist;
-    for (size_t k = 0; k < P.q_idx.size(); k++) {
-        int best = 256, second = 256, best2 = -1;
-        for (int c = P.row_ptr[k]; c < P.row_ptr[k + 1]; c++) {
-            const int i2 = P.cand[c], d = P.dist[c];
-            if (matched2[i2] || (valid2 && !valid2[i2])) continue;  // :826-830
-            if (d < best) { second = best; best = d; best2 = i2; }
-            else if (d < second) second = d;
-        }
-        if (best < ORBX_TH_LOW && (float)best < nnratio * (float)second) {  // NB strict '<' here (:848)
-            match12[P.q_idx[k]] = best2;
-            matched2[best2] = 1;
-            if (check_orientation) hist.push(rotation_bin(angle1[P.q_idx[k]], angle2[best2]), P.q_idx[k]);
-            nmatches++;
-        }
-    }
-    if (check_orientation) hist.filter([&](int i1) { match12[i1] = -1; nmatches--; });
-    return nmatches;
+    std::vector<uint8_t> skip1(n1), skip2(n2);
+    for (int i = 0; i < n1; i++) skip1[i] = valid1 ? !valid1[i] : 0;
+    for (int i = 0; i < n2; i++) skip2[i] = valid2 ? !valid2[i] : 0;
+    return run_bow_replay(m, 1, desc1, angle1, skip1.data(), n1, fv1, desc2, angle2, skip2.data(), n2, fv2, nnratio, check_orientation, match12, n1);
 }
 
 // ORBmatcher::SearchForTriangulation (ORBmatcher.cc:907-1146)
@@ -650,6 +647,11 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
     if (!m || !fv1 || !fv2 || !matches12 || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return 0;
+    // without a geometric gate (bCoarse) nothing but distances decides: the whole loop runs on the device (k_replay_bow mode 2).
+    // With a gate, the camera model's epipolarConstrain is host code of the adapter: the device evaluates every candidate
+    // distance and the loop below calls the gate exactly where the reference evaluates it.
+    if (!pair_ok)
+        return run_bow_replay(m, 2, desc1, angle1, skip1, n1, fv1, desc2, angle2, skip2, n2, fv2, 0.f, check_orientation, matches12, n1);
     BowPairs P;
     const int r = bow_distances(m, desc1, skip1, fv1, desc2, n2, fv2, P);
     if (r != ORBX_OK) return r;

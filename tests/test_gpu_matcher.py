@@ -341,7 +341,7 @@ def test_search_for_triangulation(oracle, canvas1):
     def pair_ok(i, j):   # stand-in for the epipole gate + epipolarConstrain: a pure function of the pair
         return abs((k0["y"][i] - 1.0) - k1["y"][j]) < 3.0 * (1 + k0["octave"][i])
 
-    for ori, pred in ((False, pair_ok), (True, pair_ok), (False, None)):
+    for ori, pred in ((False, pair_ok), (True, pair_ok), (False, None), (True, None)):  # None: bCoarse, whole loop on the device
         on, om = oracle.search_for_triangulation(d0, k0["angle"], skip0, fva, d1, k1["angle"], skip1, fvb, ori, pred)
         n, m12 = osa.ORBmatcher(0.6, ori).SearchForTriangulation(d0, k0["angle"], skip0, fva, d1, k1["angle"], skip1, fvb, pred)
         assert n == on and np.array_equal(m12, om), (ori, n, on)
