@@ -184,69 +184,62 @@ int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const 
                                 const uint8_t *dr, int Nr, const float *scale_factors, const float *inv_scale_factors,
                                 int nlevels, const uint8_t *const *pyr_left, const uint8_t *const *pyr_right, const int32_t *pyr_w,
                                 const int32_t *pyr_h, const size_t *pyr_stride, float bf, float b, float *u_right, float *depth) {
-    if (!m || !u_right || !depth || N < 0 || !pyr_h || !pyr_w) return ORBX_E_BAD_ARG;
+    if (!m || !u_right || !depth || N < 0 || Nr < 0 || !pyr_h || !pyr_w || !pyr_stride || !pyr_left || !pyr_right || nlevels <= 0 ||
+        !scale_factors || !inv_scale_factors || !(b > 0.f))
+        return ORBX_E_BAD_ARG;
     for (int i = 0; i < N; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
-    if (N == 0) return 0;
-    const int thOrbDist = (ORBX_TH_HIGH + ORBX_TH_LOW) / 2;
-    const float minD = 0, maxD = bf / b;
-    std::vector<int32_t> bidx(N), bdist(N);
-    int r = orbx_stereo_rowband(m, kl, dl, N, kr, dr, Nr, scale_factors, nlevels, pyr_h[0], minD, maxD, bidx.data(), bdist.data());
+    if (N == 0 || Nr == 0) return 0;
+    ORBX_HIP(hipSetDevice(m->device));
+    // the same three kernels as the device-resident batch (Hamming row band, SAD + parabola, median rejection) on a batch
+    // of one: the two pyramids are uploaded as slabs addressed like the extractor's (level origin = off + kEdge rows + kRoiX)
+    const size_t lead = ((size_t)kEdge * 8192 + kRoiX + 255) & ~(size_t)255;
+    std::vector<LevelInfo> lv(nlevels);
+    size_t slab = lead;
+    for (int l = 0; l < nlevels; l++) {
+        if (pyr_stride[l] > 8192 || pyr_w[l] <= 0 || pyr_h[l] <= 0) return ORBX_E_BAD_ARG;
+        memset(&lv[l], 0, sizeof(LevelInfo));
+        lv[l].w = pyr_w[l]; lv[l].h = pyr_h[l]; lv[l].pitch = (int32_t)pyr_stride[l];
+        lv[l].off = slab - (size_t)kEdge * pyr_stride[l] - kRoiX;   // so that the kernels' (kEdge + y) * pitch + kRoiX + x lands on (x, y)
+        slab += (pyr_stride[l] * (size_t)pyr_h[l] + 255) & ~(size_t)255;
+    }
+    const size_t need = 2 * Arena::pad(slab) + Arena::pad(28 * (size_t)N) + Arena::pad(28 * (size_t)Nr) + Arena::pad(32 * (size_t)N) +
+                        Arena::pad(32 * (size_t)Nr) + 5 * Arena::pad(4 * (size_t)N) + Arena::pad(sizeof(LevelInfo) * nlevels) +
+                        Arena::pad(8 * (size_t)nlevels) + 8192;
+    int r = m->arena.reserve(need);
     if (r != ORBX_OK) return r;
-    std::vector<std::pair<int, int>> vDistIdx;
-    vDistIdx.reserve(N);
-    int nmatched = 0;
-    for (int iL = 0; iL < N; iL++) {
-        if (bidx[iL] < 0 || !(bdist[iL] < thOrbDist)) continue;
-        const orbx_keypoint &kpL = kl[iL];
-        const float uL = kpL.x;
-        const float uR0 = kr[bidx[iL]].x;
-        const int lvl = kpL.octave;
-        const float sf = inv_scale_factors[lvl];
-        const float scaleduL = std::round(kpL.x * sf), scaledvL = std::round(kpL.y * sf), scaleduR0 = std::round(uR0 * sf);
-        const int w = 5, L = 5;
-        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
-        if (iniu < 0 || endu >= pyr_w[lvl]) continue;
-        const uint8_t *IL = pyr_left[lvl], *IR = pyr_right[lvl];
-        const size_t sl = pyr_stride[lvl];
-        const int y0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w);
-        int bestDist = INT_MAX, bestincR = 0;
-        float vDists[2 * 5 + 1];
-        for (int incR = -L; incR <= L; incR++) {
-            const int xr0 = (int)(scaleduR0 + incR - w);
-            int sad = 0;
-            for (int yy = 0; yy < 2 * w + 1; yy++) {
-                const uint8_t *pl = IL + (size_t)(y0 + yy) * sl + xl0, *pr = IR + (size_t)(y0 + yy) * sl + xr0;
-                for (int xx = 0; xx < 2 * w + 1; xx++) sad += std::abs((int)pl[xx] - (int)pr[xx]);
-            }
-            const float dist = (float)sad;
-            if (dist < bestDist) { bestDist = (int)dist; bestincR = incR; }
-            vDists[L + incR] = dist;
-        }
-        if (bestincR == -L || bestincR == L) continue;
-        const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
-        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
-        if (deltaR < -1 || deltaR > 1) continue;
-        float bestuR = scale_factors[lvl] * ((float)scaleduR0 + (float)bestincR + deltaR);
-        float disparity = uL - bestuR;
-        if (disparity >= minD && disparity < maxD) {
-            if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
-            depth[iL] = bf / disparity;
-            u_right[iL] = bestuR;
-            vDistIdx.push_back(std::pair<int, int>(bestDist, iL));
-            nmatched++;
-        }
+    Arena &A = m->arena;
+    A.reset();
+    uint8_t *dL = A.take<uint8_t>(slab), *dR = A.take<uint8_t>(slab);
+    for (int l = 0; l < nlevels; l++) {
+        const size_t o = lv[l].off + (size_t)kEdge * pyr_stride[l] + kRoiX, bytes = pyr_stride[l] * (size_t)(pyr_h[l] - 1) + pyr_w[l];
+        H2D(dL + o, pyr_left[l], bytes);
+        H2D(dR + o, pyr_right[l], bytes);
     }
-    if (vDistIdx.empty()) return 0;
-    std::sort(vDistIdx.begin(), vDistIdx.end());
-    const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
-    const float thDist = 1.5f * 1.4f * median;
-    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
-        if (vDistIdx[i].first < thDist) break;
-        u_right[vDistIdx[i].second] = -1;
-        depth[vDistIdx[i].second] = -1;
-        nmatched--;
-    }
-    return nmatched;
+    StereoBatch S;
+    memset(&S, 0, sizeof(S));
+    orbx_keypoint *dkl = A.take<orbx_keypoint>(N), *dkr = A.take<orbx_keypoint>(Nr);
+    uint8_t *ddl = A.take<uint8_t>(32 * (size_t)N), *ddr = A.take<uint8_t>(32 * (size_t)Nr);
+    H2D(dkl, kl, 28 * (size_t)N); H2D(dkr, kr, 28 * (size_t)Nr); H2D(ddl, dl, 32 * (size_t)N); H2D(ddr, dr, 32 * (size_t)Nr);
+    LevelInfo *dlv = A.take<LevelInfo>(nlevels);
+    H2D(dlv, lv.data(), sizeof(LevelInfo) * nlevels);
+    float *dsc = A.take<float>(2 * (size_t)nlevels);
+    H2D(dsc, scale_factors, 4 * (size_t)nlevels); H2D(dsc + nlevels, inv_scale_factors, 4 * (size_t)nlevels);
+    int32_t *dcnt = A.take<int32_t>(4);
+    const int32_t cnts[2] = {N, Nr};
+    H2D(dcnt, cnts, 8);
+    S.kl = dkl; S.kr = dkr; S.dl = ddl; S.dr = ddr; S.nl = dcnt; S.nr = dcnt + 1; S.capL = N; S.capR = Nr;
+    S.pyrL = dL; S.pyrR = dR; S.pyr_frame_L = 0; S.pyr_frame_R = 0; S.lvL = dlv; S.lvR = dlv;
+    S.scale = dsc; S.inv_scale = dsc + nlevels; S.n_rows = pyr_h[0]; S.bf = bf; S.b = b;
+    S.best_idx = A.take<int32_t>(N); S.best_dist = A.take<int32_t>(N);
+    S.u_right = A.take<float>(N); S.depth = A.take<float>(N); S.sad = A.take<int32_t>(N); S.nmatches = A.take<int32_t>(4);
+    hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((N + 3) / 4, 1), dim3(256), 0, m->stream, S);
+    hipLaunchKernelGGL(k_stereo_sad, dim3((N + 3) / 4, 1), dim3(256), 0, m->stream, S);
+    hipLaunchKernelGGL(k_stereo_reject, dim3(1), dim3(256), 0, m->stream, S);
+    ORBX_HIP(hipGetLastError());
+    int32_t nm = 0;
+    D2H(u_right, S.u_right, 4 * (size_t)N); D2H(depth, S.depth, 4 * (size_t)N); D2H(&nm, S.nmatches, 4);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return nm;
 }
 
 }  // extern "C"
@@ -407,46 +400,6 @@ extern "C" int orbx_search_by_projection_window(orbx_matcher *m, const orbx_fram
 // and the loop calls the gate back exactly where the reference evaluates it.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-
-struct HostGrid {  // Frame::AssignFeaturesToGrid / GetFeaturesInArea (Frame.cc:385-416, 657-723)
-    float minx, miny, inv_w, inv_h;
-    const orbx_keypoint *kps;
-    std::vector<int32_t> cell_start, order;  // counting sort by cell id x*48+y (insertion order inside a cell)
-    HostGrid(const orbx_frame_desc *F) : kps(F->keypoints_un) {
-        minx = F->min_x; miny = F->min_y;
-        inv_w = 64.0f / (F->max_x - F->min_x);
-        inv_h = 48.0f / (F->max_y - F->min_y);
-        std::vector<int32_t> cid(F->n, -1);
-        cell_start.assign(64 * 48 + 1, 0);
-        for (int i = 0; i < F->n; i++) {
-            const int px = (int)std::round((kps[i].x - minx) * inv_w), py = (int)std::round((kps[i].y - miny) * inv_h);
-            if (px < 0 || px >= 64 || py < 0 || py >= 48) continue;
-            cid[i] = px * 48 + py;
-            cell_start[cid[i] + 1]++;
-        }
-        for (int c = 0; c < 64 * 48; c++) cell_start[c + 1] += cell_start[c];
-        order.resize(cell_start[64 * 48]);
-        std::vector<int32_t> cur(cell_start.begin(), cell_start.end() - 1);
-        for (int i = 0; i < F->n; i++) if (cid[i] >= 0) order[cur[cid[i]]++] = i;
-    }
-    void query(float x, float y, float r, int minLevel, int maxLevel, std::vector<int32_t> &out) const {
-        const int cx0 = std::max(0, (int)std::floor((x - minx - r) * inv_w));
-        if (cx0 >= 64) return;
-        const int cx1 = std::min(63, (int)std::ceil((x - minx + r) * inv_w));
-        if (cx1 < 0) return;
-        const int cy0 = std::max(0, (int)std::floor((y - miny - r) * inv_h));
-        if (cy0 >= 48) return;
-        const int cy1 = std::min(47, (int)std::ceil((y - miny + r) * inv_h));
-        if (cy1 < 0) return;
-        const bool check = (minLevel > 0) || (maxLevel >= 0);
-        for (int ix = cx0; ix <= cx1; ix++)
-            for (int j = cell_start[ix * 48 + cy0]; j < cell_start[ix * 48 + cy1 + 1]; j++) {
-                const orbx_keypoint &kp = kps[order[j]];
-                if (check && (kp.octave < minLevel || (maxLevel >= 0 && kp.octave > maxLevel))) continue;
-                if (std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r) out.push_back(order[j]);
-            }
-    }
-};
 
 inline int rotation_bin(float a1, float a2) {  // e.g. ORBmatcher.cc:337-343
     float rot = a1 - a2;
