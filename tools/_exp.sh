@@ -1,7 +1,6 @@
 cd /root/repo
 export TMPDIR=/tmp
-for b in 128 256 512; do
-timeout 600 python bench.py --steps 16 --warmup 3 --cpu-frames 0 --no-profile --batch $b 2>&1 | tail -1 | python -c "
+timeout 900 python -m pytest tests/test_gpu_matcher.py -x -q 2>&1 | tail -3
+timeout 300 python bench.py --steps 16 --warmup 3 --cpu-frames 0 2>&1 | tail -1 | python -c "
 import json,sys
-j=json.loads(sys.stdin.read()); print('B=$b', j['value'], j['ms_per_step'])"
-done
+j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], {k:v['avg_ms'] for k,v in j['kernels'].items()})"
