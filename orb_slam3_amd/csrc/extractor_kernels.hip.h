@@ -32,7 +32,8 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo *__restrict__ lv, const uint8_t *__restrict__ img,
                                                   size_t row_stride, size_t frame_stride, uint8_t *__restrict__ pyr,
-                                                  size_t pyr_frame_stride) {
+                                                  size_t pyr_frame_stride, int32_t *__restrict__ zero_word) {
+    if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0;  // k_fast_wave's overflow counter of this batch
     const LevelInfo L = lv[0];
     const int cpr = L.pitch >> 4;  // 16-byte chunks per padded row (the pitch is a multiple of 64)
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -234,14 +235,9 @@ __device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int p
 // grid (total_cells, B), block 256, dynamic LDS: pixel tile + score tile + queue
 // ---------------------------------------------------------------------------------------------------------
 template <int TPB>
-__global__ __launch_bounds__(TPB) void k_fast_cells(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
-                                                    const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                    int32_t *__restrict__ cellcnt, int total_cells,
-                                                    uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
-                                                    int minTh) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const TileRef t = tiles[blockIdx.x];
-    const int f = blockIdx.y;
+__device__ __forceinline__ void fast_cell_body(const TileRef t, const int f, uint8_t *smem, const LevelInfo *__restrict__ lv,
+                                               const uint8_t *__restrict__ pyr, size_t pyr_frame_stride, int32_t *__restrict__ cellcnt,
+                                               int total_cells, uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh, int minTh) {
     const LevelInfo L = lv[t.level];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -374,6 +370,33 @@ __global__ __launch_bounds__(TPB) void k_fast_cells(const LevelInfo *__restrict_
     }
 }
 
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_fast_cells(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+                                                    const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                    int32_t *__restrict__ cellcnt, int total_cells,
+                                                    uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
+                                                    int minTh) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    fast_cell_body<TPB>(tiles[blockIdx.x], blockIdx.y, smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, minTh);
+}
+
+// cells whose candidate queue did not fit k_fast_wave's LDS budget (list = frame << 16 | tile, appended by k_fast_wave):
+// normally empty.  grid (any), block 256, dynamic LDS as k_fast_cells
+__global__ __launch_bounds__(256) void k_fast_overflow(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+                                                       const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                       int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
+                                                       size_t ent_frame_stride, int iniTh, int minTh, const uint32_t *__restrict__ list,
+                                                       const int32_t *__restrict__ list_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int count = *list_count;
+    for (int k = blockIdx.x; k < count; k += gridDim.x) {
+        const uint32_t e = list[k];
+        fast_cell_body<256>(tiles[e & 0xffffu], (int)(e >> 16), smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride,
+                            iniTh, minTh);
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_fast_wave: the same per-cell FAST + NMS as k_fast_cells with ONE WAVE per cell (no barriers, no atomics) and the
 // necessary-condition test evaluated for four horizontally adjacent pixels per lane with packed 16-bit min/max
@@ -413,12 +436,20 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-constexpr int kFwPitch = 64;
+// LDS of one wave (= one cell): pixel tile rows x P | queue[qcap] u16 | score per queue entry [qcap] u8.  After the scores are
+// known the pixel tile is dead and its memory becomes the zero-aproned score tile of the NMS; the survivors of the NMS
+// overwrite the head of the queue in place.  ~4.7 KB for EuRoC (P = 48, qcap = 768) -> 32 waves per CU: the kernel's time
+// falls with occupancy (measured 0.50 / 0.42 / 0.36 / 0.32 ms at 7 / 9 / 11 / 14 waves per CU).
+__host__ __device__ inline size_t fast_wave_lds_bytes(int P, int max_rows, int qcap) {
+    return (((size_t)max_rows * P + 16 + 15) & ~(size_t)15) + (size_t)qcap * 3 + 16;
+}
 
+template <int P>
 __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
                                                   const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
                                                   int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
-                                                  size_t ent_frame_stride, int iniTh, int minTh) {
+                                                  size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
+                                                  uint32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const TileRef t = tiles[blockIdx.x];
     const int f = blockIdx.y;
@@ -436,11 +467,11 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
         if (lane == 0) *cnt_out = 0;
         return;
     }
-    uint8_t *pix = smem;                                             // rows * 64 (+16 slack)
-    uint8_t *sco = pix + rows * kFwPitch + 16;                       // (ih + 2) * 64
-    uint16_t *queue = reinterpret_cast<uint16_t *>(sco + (ih + 2) * kFwPitch);  // iw * ih entries
+    uint8_t *pix = smem;                                                                  // rows * P (+16 slack)
+    uint16_t *queue = reinterpret_cast<uint16_t *>(smem + (((size_t)max_rows * P + 16 + 15) & ~(size_t)15));  // qcap entries
+    uint8_t *scq = reinterpret_cast<uint8_t *>(queue + qcap);                             // qcap scores
 
-    {   // phase 0: 16 lanes per row, (unaligned) dword loads starting one byte left of the sub-image
+    {   // phase 0: P/4 lanes per row, (unaligned) dword loads starting one byte left of the sub-image
         const uint8_t *src = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1;
         const int c = lane & 15, nd = (cols + 4) >> 2;
         if (c < nd) {
@@ -448,10 +479,9 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
             for (int r = lane >> 4; r < rows; r += 4, p += 4 * (size_t)L.pitch) {
                 uint32_t v;
                 __builtin_memcpy(&v, p, 4);
-                *reinterpret_cast<uint32_t *>(pix + r * kFwPitch + 4 * c) = v;
+                *reinterpret_cast<uint32_t *>(pix + r * P + 4 * c) = v;
             }
         }
-        for (int i = lane; i < (ih + 2) * (kFwPitch / 4); i += 64) reinterpret_cast<uint32_t *>(sco)[i] = 0;
     }
     __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
 
@@ -463,16 +493,17 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
         const uint32_t rcpG = ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G;
         const int lrow = (int)(((uint32_t)lane * rcpG) >> 20), lg = lane - lrow * G;
         const uint32_t vmask = lrow < RPI ? (0xfu >> max(4 * lg + 3 - (iw - 1), 0)) : 0u;  // pixels of the last group beyond the interior
-        const uint8_t *Abase = pix + lrow * kFwPitch + 4 * lg + 4;
+        const uint8_t *Abase = pix + lrow * P + 4 * lg + 4;
         const uint32_t ebase = ((uint32_t)lrow << 8) | (uint32_t)(4 * lg);
         const u16x2 t2 = as_pk((uint32_t)minTh * 0x00010001u);
+        constexpr int D = P / 4;  // dwords per tile row
         for (int y0 = 0; y0 < ih; y0 += RPI) {
             const bool act = y0 + lrow < ih;
-            const uint32_t *A = reinterpret_cast<const uint32_t *>(Abase + y0 * kFwPitch);  // row y-3 of the centre row y+3
-            const uint32_t r8 = A[0], r0 = A[6 * 16];
-            const uint32_t aL = A[1 * 16 - 1], aC = A[1 * 16], aR = A[1 * 16 + 1];    // centre row - 2
-            const uint32_t cL = A[3 * 16 - 1], cC = A[3 * 16], cR = A[3 * 16 + 1];    // centre row
-            const uint32_t bL = A[5 * 16 - 1], bC = A[5 * 16], bR = A[5 * 16 + 1];    // centre row + 2
+            const uint32_t *A = reinterpret_cast<const uint32_t *>(Abase + y0 * P);  // row y-3 of the centre row y+3
+            const uint32_t r8 = A[0], r0 = A[6 * D];
+            const uint32_t aL = A[1 * D - 1], aC = A[1 * D], aR = A[1 * D + 1];    // centre row - 2
+            const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];    // centre row
+            const uint32_t bL = A[5 * D - 1], bC = A[5 * D], bR = A[5 * D + 1];    // centre row + 2
             const uint32_t r4 = __builtin_amdgcn_alignbyte(cR, cC, 3), r12 = __builtin_amdgcn_alignbyte(cC, cL, 1);
             const uint32_t r2 = __builtin_amdgcn_alignbyte(bR, bC, 2), r14 = __builtin_amdgcn_alignbyte(bC, bL, 2);
             const uint32_t r6 = __builtin_amdgcn_alignbyte(aR, aC, 2), r10 = __builtin_amdgcn_alignbyte(aC, aL, 2);
@@ -486,30 +517,42 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
             m4 &= act ? vmask : 0u;
             const int c = __popc(m4);
             const int incl = wave_incl_scan(c);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            if (qn + tot > qcap) {  // more candidates than the LDS queue holds: the generic kernel takes this cell (k_fast_overflow)
+                if (lane == 0) ovf_list[atomicAdd(ovf_count, 1)] = ((uint32_t)f << 16) | (uint32_t)blockIdx.x;
+                return;
+            }
             int pos = qn + incl - c;
             const uint32_t e0 = ebase + ((uint32_t)y0 << 8);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (m4 & (1u << k)) { queue[pos] = (uint16_t)(e0 + k); pos++; }
             }
-            qn += __builtin_amdgcn_readlane(incl, 63);
+            qn += tot;
         }
     }
-    __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
+    __syncthreads();
 
-    // phase 2: exact score of the queued pixels
+    // phase 2: exact score of the queued pixels, kept per queue entry while the pixel tile is still being read
     for (int e = lane; e < qn; e += 64) {
         const int q = queue[e];
         const int y = q >> 8, x = q & 0xff;
-        int s = fast_score16(pix + (y + 3) * kFwPitch + x + 4, kFwPitch);
-        s = (s >= minTh) ? s : 0;
-        sco[(y + 1) * kFwPitch + x + 1] = (uint8_t)s;
+        int s = fast_score16(pix + (y + 3) * P + x + 4, P);
+        scq[e] = (uint8_t)((s >= minTh) ? s : 0);
     }
-    __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
+    __syncthreads();
+    // the pixel tile is dead: its memory becomes the score tile (pitch P, 1-px zero apron)
+    uint8_t *sco = pix;
+    for (int i = lane; i < (ih + 2) * (P / 4); i += 64) reinterpret_cast<uint32_t *>(sco)[i] = 0;
+    __syncthreads();
+    for (int e = lane; e < qn; e += 64) {
+        const int s = scq[e];
+        if (s) { const int q = queue[e]; sco[((q >> 8) + 1) * P + (q & 0xff) + 1] = (uint8_t)s; }
+    }
+    __syncthreads();
 
-    // phase 3: NMS over the queued pixels, strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); survivors
-    // stay in row-major order as (y << 16 | x << 8 | score)
-    uint32_t *surv = reinterpret_cast<uint32_t *>(pix);  // the pixel tile is dead after phase 2
+    // phase 3: NMS over the queued pixels, strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); the survivors
+    // (row-major order kept) overwrite the head of the queue
     int ns = 0;
     bool any_ini = false;
     for (int e0 = 0; e0 < qn; e0 += 64) {
@@ -517,17 +560,17 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
         int keep = 0, s = 0, q = 0;
         if (e < qn) {
             q = queue[e];
-            const uint8_t *p = sco + ((q >> 8) + 1) * kFwPitch + (q & 0xff) + 1;
-            s = p[0];
-            keep = (s > 0) & (s > p[-1]) & (s > p[1]) & (s > p[-kFwPitch - 1]) & (s > p[-kFwPitch]) & (s > p[-kFwPitch + 1]) &
-                   (s > p[kFwPitch - 1]) & (s > p[kFwPitch]) & (s > p[kFwPitch + 1]);
+            s = scq[e];
+            const uint8_t *p = sco + ((q >> 8) + 1) * P + (q & 0xff) + 1;
+            keep = (s > 0) & (s > p[-1]) & (s > p[1]) & (s > p[-P - 1]) & (s > p[-P]) & (s > p[-P + 1]) & (s > p[P - 1]) & (s > p[P]) &
+                   (s > p[P + 1]);
         }
         const unsigned long long b = __ballot(keep != 0);
         any_ini |= __ballot(keep && s >= iniTh) != 0ull;
-        if (keep) surv[ns + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)q << 8) | (uint32_t)s;
+        if (keep) queue[ns + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)q;  // ns + rank <= e: never ahead of an unread entry
         ns += __popcll(b);
     }
-    __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
+    __syncthreads();
 
     // phase 4: emission in row-major order of the survivors at the cell's threshold
     const int thr = any_ini ? iniTh : minTh;
@@ -535,13 +578,11 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
     int total = 0;
     for (int e0 = 0; e0 < ns; e0 += 64) {
         const int e = e0 + lane;
-        uint32_t me = 0;
-        if (e < ns) me = surv[e];
-        const int s = (int)(me & 0xff);
+        int q = 0, s = 0;
+        if (e < ns) { q = queue[e]; s = sco[((q >> 8) + 1) * P + (q & 0xff) + 1]; }
         const bool sel = e < ns && s >= thr;
         const unsigned long long b = __ballot(sel);
-        if (sel) slot[total + __popcll(b & ((1ull << lane) - 1ull))] =
-            pack_key((int)((me >> 8) & 0xff) + 3 + t.tj * L.wCell, (int)(me >> 16) + 3 + t.ti * L.hCell, s);
+        if (sel) slot[total + __popcll(b & ((1ull << lane) - 1ull))] = pack_key((q & 0xff) + 3 + t.tj * L.wCell, (q >> 8) + 3 + t.ti * L.hCell, s);
         total += __popcll(b);
     }
     if (lane == 0) *cnt_out = total;

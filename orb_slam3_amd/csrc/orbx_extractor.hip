@@ -56,7 +56,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     size_t pyr_off = 0, blur_off = 0;
     uint32_t cand_off = 0, lvl_off = 0;
     int cell_base = 0, cap = 0, max_pool = 0;
-    size_t fast_lds = 0, fast_wave_lds = 0;
+    size_t fast_lds = 0;
+    int fast_wave_maxw = 0, fast_wave_rows = 0;
     bool fast_wave = true;
     for (int l = 0; l < nl; l++) {
         LevelInfo &L = lv[l];
@@ -162,7 +163,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
                            2 * (size_t)L.wCell * L.hCell + 64;
         fast_lds = std::max(fast_lds, lds);
         if (L.wCell + 6 > 63) fast_wave = false;  // k_fast_wave: the sub-image (+1 byte) must fit its 64-byte LDS pitch
-        fast_wave_lds = std::max(fast_wave_lds, (size_t)(rows * 64 + 16 + (L.hCell + 2) * 64 + 2 * L.wCell * L.hCell + 16));
+        fast_wave_maxw = std::max(fast_wave_maxw, L.wCell);
+        fast_wave_rows = std::max(fast_wave_rows, rows);
     }
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
 
@@ -186,6 +188,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_cellent, sizeof(uint32_t) * (size_t)cand_off * B);
     ENS(ex->d_keys0, sizeof(uint32_t) * (size_t)cand_off * B);
     ENS(ex->d_keys1, sizeof(uint32_t) * (size_t)cand_off * B);
+    ENS(ex->d_fast_ovf, 4 * (16 + fast_tiles.size() * (size_t)B) + 64);
     ENS(ex->d_nof0, sizeof(uint16_t) * (size_t)cand_off * B);
     ENS(ex->d_nof1, sizeof(uint16_t) * (size_t)cand_off * B);
     ENS(ex->d_lvlkp, sizeof(uint32_t) * (size_t)lvl_off * B);
@@ -208,7 +211,10 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->lv = lv;
     ex->width = width; ex->height = height; ex->batch_cap = B;
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
-    ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave_lds = fast_wave_lds; ex->fast_wave = fast_wave;
+    ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave = fast_wave && fast_tiles.size() < 65536 && batch < 65536;
+    ex->fast_wave_pitch = (fast_wave_maxw + 7 <= 48) ? 48 : 64;
+    ex->fast_wave_rows = fast_wave_rows;
+    ex->fast_wave_lds = fast_wave_lds_bytes(ex->fast_wave_pitch, fast_wave_rows, ex->fast_wave_qcap);
     { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size();
     ex->last_batch = 0;
@@ -244,7 +250,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         ProfScope ps(ex, K_PYR_BASE);
         const LevelInfo &L = ex->lv[0];
         dim3 grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n);
-        hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, d_lv, d_images, row_stride, frame_stride, pyr, ex->pyr_frame);
+        hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, d_lv, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
+                           (int32_t *)ex->d_fast_ovf.p);
     }
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
@@ -276,10 +283,21 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     hipLaunchKernelGGL(k_fast_cells<T>, dim3(ex->n_fast_tiles, n), dim3(T), ex->fast_lds, st, d_lv,                           \
                        (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn)
-        if (ex->fast_wave && tpb == 0)
-            hipLaunchKernelGGL(k_fast_wave, dim3(ex->n_fast_tiles, n), dim3(64), ex->fast_wave_lds, st, d_lv,
-                               (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,
-                               ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn);
+        static const size_t ldspad = [] { const char *v = getenv("ORBX_FAST_LDSPAD"); return v ? (size_t)atoi(v) : (size_t)0; }();
+        if (ex->fast_wave && tpb == 0) {
+            int32_t *ovf_count = (int32_t *)ex->d_fast_ovf.p;
+            uint32_t *ovf_list = (uint32_t *)ex->d_fast_ovf.p + 16;
+#define ORBX_FAST_WAVE(PITCH)                                                                                                      \
+    hipLaunchKernelGGL(k_fast_wave<PITCH>, dim3(ex->n_fast_tiles, n), dim3(64), ex->fast_wave_lds + ldspad, st, d_lv,                 \
+                       (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,         \
+                       ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qcap, \
+                       ovf_list, ovf_count)
+            if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE(48); else ORBX_FAST_WAVE(64);
+            // cells with more candidates than k_fast_wave's LDS queue holds (normally none) go through the generic kernel
+            hipLaunchKernelGGL(k_fast_overflow, dim3(512), dim3(256), ex->fast_lds, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,
+                               (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p,
+                               ex->cand_frame, ini, mn, (const uint32_t *)ovf_list, (const int32_t *)ovf_count);
+        }
         else if (tpb == 256) ORBX_FAST_LAUNCH(256);
         else if (tpb == 128) ORBX_FAST_LAUNCH(128);
         else ORBX_FAST_LAUNCH(64);
@@ -424,6 +442,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipStreamCreateWithFlags(&ex->copy_stream, hipStreamNonBlocking);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
     { const char *v = getenv("ORBX_BLUR_SIDE"); ex->blur_side = !(v && v[0] == '0'); }
+    { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 64) ex->fast_wave_qcap = atoi(v) & ~15; }  // test hook: force k_fast_overflow
     (void)hipStreamCreateWithFlags(&ex->aux_stream, hipStreamNonBlocking);
     (void)hipStreamCreateWithFlags(&ex->match_stream, hipStreamNonBlocking);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
@@ -471,7 +490,7 @@ void orbx_destroy(orbx_extractor *ex) {
     ex->d_match.release(); ex->d_nmatch.release();
     for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales}) b->release();
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
-                      &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_lvlkp, &ex->d_lvlcnt,
+                      &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg};
     for (DevBuf *b : bufs) b->release();

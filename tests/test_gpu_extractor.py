@@ -293,8 +293,8 @@ def test_reconfigure_between_shapes(canvas1):
 
 
 def test_generic_fast_kernel_fallback(tmp_path):
-    """k_fast_cells (one 256-thread workgroup per cell, any cell size) is the fallback of the single-wave k_fast_wave;
-    force it through ORBX_FAST_TPB in a fresh process and compare with the oracle."""
+    """k_fast_cells (one 256-thread workgroup per cell, any cell size) is the fallback of the single-wave k_fast_wave, both as
+    a whole (ORBX_FAST_TPB) and per cell through the overflow list (k_fast_overflow, forced with a tiny queue capacity)."""
     import subprocess
     import sys
     from pathlib import Path
@@ -310,8 +310,8 @@ def test_generic_fast_kernel_fallback(tmp_path):
         "om, ok, od = ob.OracleExtractor(800, 1.2, 8, 20, 7).extract(img, lap=(0, 0))\n"
         "assert m == om and np.array_equal(k, ok) and np.array_equal(d, od), (len(k), len(ok))\n"
         "print('same', len(k))\n")
-    for tpb in ("256", "64"):
-        import os
-        env = dict(os.environ, ORBX_FAST_TPB=tpb)
+    import os
+    for var, val in (("ORBX_FAST_TPB", "256"), ("ORBX_FAST_TPB", "64"), ("ORBX_FAST_QCAP", "96")):  # last: most cells overflow k_fast_wave's queue
+        env = dict(os.environ, **{var: val})
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
