@@ -122,10 +122,16 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict_
     const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX;  // previous level ROI origin
     const uint4 gc = *reinterpret_cast<const uint4 *>(&xg[L.xg_off + wi].cc[0]);
     const uint4 gh = *reinterpret_cast<const uint4 *>(&xg[L.xg_off + wi]);  // base, sel, valid
+    uint8_t *drow = frame + L.off + (size_t)py0 * L.pitch + wi * 4;
+    if (gh.z == 2) {  // pitch padding left / right of the ring (about one dword column in seven): nothing to compute
+#pragma unroll
+        for (int r = 0; r < kResizeRows; r++)
+            if (py0 + r < rows) *reinterpret_cast<uint32_t *>(drow + (size_t)r * L.pitch) = 0u;
+        return;
+    }
     ResizeTap ty[kResizeRows];
 #pragma unroll
     for (int r = 0; r < kResizeRows; r++) ty[r] = ytab[L.ytab_off + reflect101(min(py0 + r, rows - 1) - kEdge, L.h)];
-    uint8_t *drow = frame + L.off + (size_t)py0 * L.pitch + wi * 4;
     if (gh.z) {
         // all eight source bytes of a row in one unaligned 8-byte load; v_perm_b32 picks the left / right taps
         uint2 r0[kResizeRows], r1[kResizeRows];

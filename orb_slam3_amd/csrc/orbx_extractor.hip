@@ -143,7 +143,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
                     g.cc[k] = (uint32_t)(uint16_t)t.c0 | ((uint32_t)(uint16_t)t.c1 << 16);
                     lo = std::min(lo, t.ofs); hi = std::max(hi, t.ofs);
                 }
-                if (lo == INT32_MAX) { g.base = 0; g.valid = 1; }
+                if (lo == INT32_MAX) { g.base = 0; g.valid = 2; }  // pitch padding outside the ring: the kernel stores zeros
                 else {
                     g.base = lo;
                     g.valid = (hi + 1 - lo <= 7) ? 1 : 0;
@@ -435,16 +435,21 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
             ++v0;
         }
     }
-    hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    // the main stream carries the critical path; matcher, blur and downloads have a whole step of slack: lower priority
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // lo = numerically greatest = lowest priority
+    static const int use_prio = [] { const char *v = getenv("ORBX_STREAM_PRIO"); return v ? atoi(v) : 1; }();
+    if (!use_prio) prio_lo = prio_hi = 0;
+    hipError_t e = hipStreamCreateWithPriority(&ex->stream, hipStreamNonBlocking, prio_hi);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); delete ex; return ORBX_E_HIP; }
     (void)hipEventCreate(&ex->ev0);
     (void)hipEventCreate(&ex->ev1);
-    (void)hipStreamCreateWithFlags(&ex->copy_stream, hipStreamNonBlocking);
+    (void)hipStreamCreateWithPriority(&ex->copy_stream, hipStreamNonBlocking, prio_lo);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
     { const char *v = getenv("ORBX_BLUR_SIDE"); ex->blur_side = !(v && v[0] == '0'); }
     { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 64) ex->fast_wave_qcap = atoi(v) & ~15; }  // test hook: force k_fast_overflow
-    (void)hipStreamCreateWithFlags(&ex->aux_stream, hipStreamNonBlocking);
-    (void)hipStreamCreateWithFlags(&ex->match_stream, hipStreamNonBlocking);
+    (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, use_prio == 2 ? prio_lo : prio_hi);
+    (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[0], hipEventDisableTiming);

@@ -55,7 +55,8 @@ struct ResizeTap {
 
 // Four horizontally adjacent output pixels (one dword of a padded row) of the bilinear resize: all eight source bytes of a
 // row lie inside [base, base+8), sel holds the byte offset of each pixel's left tap (v_perm_b32 selector), cc the Q11
-// coefficient pairs (c0 | c1 << 16; 0 for pixels outside the ring).  valid = 0: offsets do not fit (scale factor > 2).
+// coefficient pairs (c0 | c1 << 16; 0 for pixels outside the ring).  valid = 0: offsets do not fit (scale factor > 2);
+// valid = 2: the whole dword lies outside the ring (pitch padding), the kernel stores zeros.
 struct ResizeGroup {
     int32_t base;
     uint32_t sel;
