@@ -292,7 +292,7 @@ def test_reconfigure_between_shapes(canvas1):
             assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (nb, t)
 
 
-def test_generic_fast_kernel_fallback(tmp_path):
+def test_alternative_kernel_paths(tmp_path):
     """k_fast_cells (one 256-thread workgroup per cell, any cell size) is the fallback of the single-wave k_fast_wave, both as
     a whole (ORBX_FAST_TPB) and per cell through the overflow list (k_fast_overflow, forced with a tiny queue capacity)."""
     import subprocess
@@ -311,7 +311,9 @@ def test_generic_fast_kernel_fallback(tmp_path):
         "assert m == om and np.array_equal(k, ok) and np.array_equal(d, od), (len(k), len(ok))\n"
         "print('same', len(k))\n")
     import os
-    for var, val in (("ORBX_FAST_TPB", "256"), ("ORBX_FAST_TPB", "64"), ("ORBX_FAST_QCAP", "96")):  # last: most cells overflow k_fast_wave's queue
+    # ORBX_FAST_QCAP=96: most cells overflow k_fast_wave's queue; ORBX_OCTREE=seq: the sequential quad-tree emulation (k_octree);
+    # ORBX_SIDE_STREAMS=0: every kernel on one stream
+    for var, val in (("ORBX_FAST_TPB", "256"), ("ORBX_FAST_TPB", "64"), ("ORBX_FAST_QCAP", "96"), ("ORBX_OCTREE", "seq"), ("ORBX_SIDE_STREAMS", "0")):
         env = dict(os.environ, **{var: val})
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
