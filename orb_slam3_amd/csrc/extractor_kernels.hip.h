@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict_
 #pragma unroll
         for (int r = 0; r < kResizeRows; r++) {
             const int sy0 = min(max(ty[r].ofs, 0), P.h - 1), sy1 = min(max(ty[r].ofs + 1, 0), P.h - 1);
-            __builtin_memcpy(&r0[r], proi + (size_t)sy0 * P.pitch + (int)gh.x, 8);
-            __builtin_memcpy(&r1[r], proi + (size_t)sy1 * P.pitch + (int)gh.x, 8);
+            __builtin_memcpy(&r0[r], proi + (uint32_t)(__umul24((uint32_t)sy0, (uint32_t)P.pitch) + gh.x), 8);
+            __builtin_memcpy(&r1[r], proi + (uint32_t)(__umul24((uint32_t)sy1, (uint32_t)P.pitch) + gh.x), 8);
         }
         const uint32_t selr = gh.y + 0x01010101u;
         const uint32_t cc[4] = {gc.x, gc.y, gc.z, gc.w};
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict_
                 v = min(max(v, 0), 255);
                 out |= (uint32_t)v << (8 * k);
             }
-            if (py0 + r < rows) *reinterpret_cast<uint32_t *>(drow + (size_t)r * L.pitch) = out;
+            if (py0 + r < rows) *reinterpret_cast<uint32_t *>(drow + (uint32_t)(r * L.pitch)) = out;
         }
     } else {
         for (int r = 0; r < kResizeRows && py0 + r < rows; r++) {
@@ -713,8 +713,8 @@ __global__ __launch_bounds__(256) void k_blur(const LevelInfo *__restrict__ lv, 
     const int ymax = L.h + kEdge - 1;  // last ring row that exists
     uint32_t hw[7][4];
     auto src_row = [&](int r) -> const uint8_t * {  // r-th source row of this strip: level row y0 - 3 + r
-        const int y = min(y0 - 3 + r, ymax);
-        return roi + (ptrdiff_t)y * L.pitch;
+        const int y = min(y0 - 3 + r, ymax);   // >= -3: the ring rows above the ROI exist
+        return roi + (ptrdiff_t)__mul24(y, L.pitch);
     };
     auto emit = [&](int yo, int newest) {  // output row yo from the seven rows ending in slot `newest`
         if (yo >= L.h) return;
@@ -722,14 +722,16 @@ __global__ __launch_bounds__(256) void k_blur(const LevelInfo *__restrict__ lv, 
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             // row r-6+k sits in slot (newest + 1 + k) % 7
-            const uint32_t s = (uint32_t)g0 * (hw[(newest + 1) % 7][j] + hw[newest][j]) +
-                               (uint32_t)g1 * (hw[(newest + 2) % 7][j] + hw[(newest + 6) % 7][j]) +
-                               (uint32_t)g2 * (hw[(newest + 3) % 7][j] + hw[(newest + 5) % 7][j]) +
-                               (uint32_t)g3 * hw[(newest + 4) % 7][j];
+            // 24-bit multiplies (taps < 2^8, sums of two horizontal results < 2^18): v_mad_u32_u24 issues at full rate,
+            // a 32-bit v_mul_lo_u32 at a quarter of it
+            const uint32_t s = __umul24((uint32_t)g0, hw[(newest + 1) % 7][j] + hw[newest][j]) +
+                               __umul24((uint32_t)g1, hw[(newest + 2) % 7][j] + hw[(newest + 6) % 7][j]) +
+                               __umul24((uint32_t)g2, hw[(newest + 3) % 7][j] + hw[(newest + 5) % 7][j]) +
+                               __umul24((uint32_t)g3, hw[(newest + 4) % 7][j]);
             const uint32_t v = min((s + 32768u) >> 16, 255u);
             out |= v << (8 * j);
         }
-        *reinterpret_cast<uint32_t *>(dst + (size_t)yo * L.bpitch) = out;
+        *reinterpret_cast<uint32_t *>(dst + (uint32_t)__umul24((uint32_t)yo, (uint32_t)L.bpitch)) = out;
     };
 #pragma unroll
     for (int r = 0; r < 6; r++) blur_hrow(src_row(r), tap_lo, tap_hi, hw[r]);
