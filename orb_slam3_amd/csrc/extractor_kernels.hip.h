@@ -874,25 +874,25 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int idx = lane + 64 * k;
-            const int r = idx / 9, c = idx - r * 9;
-            va[k] = (idx < kDescAR * 9) ? *reinterpret_cast<const uint32_t *>(srcA + (uint32_t)(r * L.pitch + 4 * c)) : 0u;
+            const int r = (int)(__umul24((uint32_t)idx, 7282u) >> 16), c = idx - r * 9;  // idx / 9 for idx < 3640, full-rate multiply
+            va[k] = (idx < kDescAR * 9) ? *reinterpret_cast<const uint32_t *>(srcA + (uint32_t)(__umul24((uint32_t)r, (uint32_t)L.pitch) + 4 * c)) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const int idx = lane + 64 * k;
-            const int r = idx / 10, c = idx - r * 10;
-            vb[k] = (idx < kDescBR * 10) ? *reinterpret_cast<const uint32_t *>(srcB + (uint32_t)(r * L.bpitch + 4 * c)) : 0u;
+            const int r = (int)(__umul24((uint32_t)idx, 6554u) >> 16), c = idx - r * 10;  // idx / 10 for idx < 1638
+            vb[k] = (idx < kDescBR * 10) ? *reinterpret_cast<const uint32_t *>(srcB + (uint32_t)(__umul24((uint32_t)r, (uint32_t)L.bpitch) + 4 * c)) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int idx = lane + 64 * k;
-            const int r = idx / 9, c = idx - r * 9;
+            const int r = (int)(__umul24((uint32_t)idx, 7282u) >> 16), c = idx - r * 9;  // idx / 9 for idx < 3640, full-rate multiply
             if (idx < kDescAR * 9) *reinterpret_cast<uint32_t *>(A + r * kDescAP + 4 * c) = va[k];
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const int idx = lane + 64 * k;
-            const int r = idx / 10, c = idx - r * 10;
+            const int r = (int)(__umul24((uint32_t)idx, 6554u) >> 16), c = idx - r * 10;  // idx / 10 for idx < 1638
             if (idx < kDescBR * 10) *reinterpret_cast<uint32_t *>(Bp + r * kDescBP + 4 * c) = vb[k];
         }
     }
@@ -940,8 +940,8 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
             r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
             q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
         }
-        const int t0 = cb[__float2int_rn(r0) * kDescBP + __float2int_rn(q0)];
-        const int t1 = cb[__float2int_rn(r1) * kDescBP + __float2int_rn(q1)];
+        const int t0 = cb[__mul24(__float2int_rn(r0), kDescBP) + __float2int_rn(q0)];  // |row| <= 18: 24-bit multiply, full rate
+        const int t1 = cb[__mul24(__float2int_rn(r1), kDescBP) + __float2int_rn(q1)];
         bits[it] = __ballot(t0 < t1);
     }
     const size_t slot = (size_t)f * cap + w.pos;
