@@ -400,22 +400,6 @@ __global__ __launch_bounds__(TPB) void k_fast_cells(const LevelInfo *__restrict_
     fast_cell_body<TPB>(tiles[blockIdx.x], blockIdx.y, smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, minTh);
 }
 
-// cells whose candidate queue did not fit k_fast_wave's LDS budget (list = frame << 16 | tile, appended by k_fast_wave):
-// normally empty.  grid (any), block 256, dynamic LDS as k_fast_cells
-__global__ __launch_bounds__(256) void k_fast_overflow(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
-                                                       const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                       int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
-                                                       size_t ent_frame_stride, int iniTh, int minTh, const uint32_t *__restrict__ list,
-                                                       const int32_t *__restrict__ list_count) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int count = *list_count;
-    for (int k = blockIdx.x; k < count; k += gridDim.x) {
-        const uint32_t e = list[k];
-        fast_cell_body<256>(tiles[e & 0xffffu], (int)(e >> 16), smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride,
-                            iniTh, minTh);
-        __syncthreads();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // k_fast_wave: the same per-cell FAST + NMS as k_fast_cells with ONE WAVE per cell (no barriers, no atomics) and the
@@ -465,14 +449,11 @@ __host__ __device__ inline size_t fast_wave_lds_bytes(int P, int max_rows, int q
 }
 
 template <int P>
-__global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
-                                                  const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                  int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
-                                                  size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
-                                                  uint32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const TileRef t = tiles[blockIdx.x];
-    const int f = blockIdx.y;
+__device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, const uint32_t tile_index, uint8_t *smem,
+                                               const LevelInfo *__restrict__ lv, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                               int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
+                                               size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
+                                               uint32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
     const LevelInfo L = lv[t.level];
     const int lane = threadIdx.x;
     const int cell = t.ti * L.nCols + t.tj;
@@ -539,7 +520,7 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
             const int incl = wave_incl_scan(c);
             const int tot = __builtin_amdgcn_readlane(incl, 63);
             if (qn + tot > qcap) {  // more candidates than the LDS queue holds: the generic kernel takes this cell (k_fast_overflow)
-                if (lane == 0) ovf_list[atomicAdd(ovf_count, 1)] = ((uint32_t)f << 16) | (uint32_t)blockIdx.x;
+                if (lane == 0 && ovf_list) ovf_list[atomicAdd(ovf_count, 1)] = ((uint32_t)f << 16) | tile_index;
                 return;
             }
             int pos = qn + incl - c;
@@ -606,6 +587,35 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
         total += __popcll(b);
     }
     if (lane == 0) *cnt_out = total;
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+                                                  const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                  int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
+                                                  size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
+                                                  uint32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    fast_wave_cell<P>(tiles[blockIdx.x], blockIdx.y, blockIdx.x, smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride,
+                      iniTh, minTh, max_rows, qcap, ovf_list, ovf_count);
+}
+
+// the cells k_fast_wave appended to its overflow list (more candidates than its LDS queue holds; about 0.5 % of the cells of
+// the EuRoC-like bench), with a queue that holds a whole cell.  grid (any), block 64, LDS for qcap = max interior pixels
+template <int P>
+__global__ __launch_bounds__(64) void k_fast_wave_list(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+                                                       const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                       int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
+                                                       size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
+                                                       const uint32_t *__restrict__ list, const int32_t *__restrict__ list_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int count = *list_count;
+    for (int k = blockIdx.x; k < count; k += gridDim.x) {
+        const uint32_t e = list[k];
+        fast_wave_cell<P>(tiles[e & 0xffffu], (int)(e >> 16), e & 0xffffu, smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent,
+                          ent_frame_stride, iniTh, minTh, max_rows, qcap, nullptr, nullptr);
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -58,7 +58,7 @@ struct orbx_extractor {
     int total_cells = 0, cap = 0, max_pool = 0;
     size_t fast_lds = 0;
     size_t fast_wave_lds = 0;   // k_fast_wave
-    int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qcap = 768;   // LDS tile pitch (48 / 64), max sub-image rows, queue capacity
+    int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qcap = 768, fast_wave_qfull = 16;   // LDS tile pitch (48 / 64), max sub-image rows, queue capacity
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     DevBuf d_octdbg;            // optional phase timing of k_octree_par (orbx_debug_octree_timing)
     int octdbg_level = -1;

@@ -57,7 +57,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     uint32_t cand_off = 0, lvl_off = 0;
     int cell_base = 0, cap = 0, max_pool = 0;
     size_t fast_lds = 0;
-    int fast_wave_maxw = 0, fast_wave_rows = 0;
+    int fast_wave_maxw = 0, fast_wave_rows = 0, fast_wave_qfull = 16;
     bool fast_wave = true;
     for (int l = 0; l < nl; l++) {
         LevelInfo &L = lv[l];
@@ -165,6 +165,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         if (L.wCell + 6 > 63) fast_wave = false;  // k_fast_wave: the sub-image (+1 byte) must fit its 64-byte LDS pitch
         fast_wave_maxw = std::max(fast_wave_maxw, L.wCell);
         fast_wave_rows = std::max(fast_wave_rows, rows);
+        fast_wave_qfull = std::max(fast_wave_qfull, (L.wCell * L.hCell + 15) & ~15);
     }
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
 
@@ -214,6 +215,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave = fast_wave && fast_tiles.size() < 65536 && batch < 65536;
     ex->fast_wave_pitch = (fast_wave_maxw + 7 <= 48) ? 48 : 64;
     ex->fast_wave_rows = fast_wave_rows;
+    ex->fast_wave_qfull = fast_wave_qfull;
     ex->fast_wave_lds = fast_wave_lds_bytes(ex->fast_wave_pitch, fast_wave_rows, ex->fast_wave_qcap);
     { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size();
@@ -293,10 +295,15 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qcap, \
                        ovf_list, ovf_count)
             if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE(48); else ORBX_FAST_WAVE(64);
-            // cells with more candidates than k_fast_wave's LDS queue holds (normally none) go through the generic kernel
-            hipLaunchKernelGGL(k_fast_overflow, dim3(512), dim3(256), ex->fast_lds, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,
-                               (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p,
-                               ex->cand_frame, ini, mn, (const uint32_t *)ovf_list, (const int32_t *)ovf_count);
+            // cells with more candidates than k_fast_wave's LDS queue holds (about 0.5 % in the EuRoC-like bench): same kernel body,
+            // queue sized for a whole cell
+            const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
+#define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
+    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(2048), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
+                       (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p, \
+                       ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qfull, (const uint32_t *)ovf_list,                  \
+                       (const int32_t *)ovf_count)
+            if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE_LIST(48); else ORBX_FAST_WAVE_LIST(64);
         }
         else if (tpb == 256) ORBX_FAST_LAUNCH(256);
         else if (tpb == 128) ORBX_FAST_LAUNCH(128);

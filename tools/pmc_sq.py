@@ -2,6 +2,7 @@
 """Per-kernel averages of SQ counters from one or more rocprofv3 --pmc result .db files -> CSV (profiles/<tag>_pmc_sq_counters.csv).
 Derived columns: VALU issue time (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs) in us at 2.4 GHz, VALU instructions per wave."""
 import csv
+import re
 import sqlite3
 import sys
 from collections import defaultdict
@@ -11,7 +12,7 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for db in dbs:
     c = sqlite3.connect(db)
     for name, cn, val in c.execute("select kernel_name, counter_name, value from counters_collection"):
-        k = name.split("(")[0].replace("orbx::", "").replace("void ", "")
+        k = re.sub(r"<.*>", "", name.split("(")[0].replace("orbx::", "").replace("void ", ""))
         a = acc[k][cn]
         a[0] += val
         a[1] += 1

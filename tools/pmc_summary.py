@@ -10,6 +10,7 @@ FETCH_SIZE = 135,301 KiB = 138.5 MB, i.e. factor 0.97 -> our 4-B/lane kernels ne
 Writes profiles/<tag>_pmc_traffic.csv and profiles/pmc_traffic.json (bytes per launch, read by bench.py).
 """
 import csv
+import re
 import json
 import sqlite3
 import sys
@@ -22,7 +23,7 @@ def per_kernel(db, counter):
     c = sqlite3.connect(db)
     acc = defaultdict(lambda: [0.0, 0])
     for name, val in c.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)):
-        k = name.split("(")[0].replace("orbx::", "")
+        k = re.sub(r"<.*>", "", name.split("(")[0].replace("void ", "").replace("orbx::", ""))  # template instances share a row
         acc[k][0] += val
         acc[k][1] += 1
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
