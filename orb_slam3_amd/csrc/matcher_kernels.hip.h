@@ -662,10 +662,28 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
     bool go = false;
     if (qvalid) go = load_query(P, qi, &w, g, &dq);
     if (go) {
+        // The window's grid columns are contiguous slices of gorder (one per column).  Their bounds are fetched for up to eight
+        // columns at once and the 16 lanes walk the CONCATENATED candidate sequence (= the reference's enumeration order, which
+        // is also the tie-break order): one dependent load chain per query instead of one per column.
         int seq0 = 0;
-        for (int ix = w.cx0; ix <= w.cx1; ix++) {
-            const int s = P.gstart[ix * 48 + w.cy0], e = P.gstart[ix * 48 + w.cy1 + 1];
-            for (int j = s + sl; j < e; j += 16) {
+        for (int cx = w.cx0; cx <= w.cx1; cx += 8) {
+            int cs[8], ce[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int ix = min(cx + c, w.cx1);
+                cs[c] = P.gstart[ix * 48 + w.cy0];
+                ce[c] = P.gstart[ix * 48 + w.cy1 + 1];
+            }
+            int pre[9];
+            pre[0] = 0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) pre[c + 1] = pre[c] + ((cx + c <= w.cx1) ? ce[c] - cs[c] : 0);
+            const int tot = pre[8];
+            for (int t = sl; t < tot; t += 16) {
+                int j = cs[0] + t;  // column of the t-th candidate: the last c with pre[c] <= t
+#pragma unroll
+                for (int c = 1; c < 8; c++) j = (t >= pre[c]) ? cs[c] + (t - pre[c]) : j;
+                const int s = j - t;  // so that seq0 + (j - s) = seq0 + t below
                 const int i = P.gorder[j];
                 if (P.occupied0 && P.occupied0[i]) continue;
                 const orbx_keypoint kp = P.kps[i];
@@ -694,7 +712,7 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
                 push2(k1, k2, seq_key(d, seq0 + (j - s), i));
                 cnt++;
             }
-            seq0 += e - s;
+            seq0 += tot;
         }
     }
     // reductions inside the 16-lane group (xor masks 8,4,2,1 stay inside the group)
