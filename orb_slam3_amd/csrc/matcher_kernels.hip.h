@@ -38,8 +38,12 @@ constexpr int kTopK = 4;
 
 // keep the two smallest keys
 __device__ __forceinline__ void push2(u64 &k1, u64 &k2, u64 k) {
-    if (k < k1) { k2 = k1; k1 = k; }
-    else if (k < k2) k2 = k;
+    // branch-free on purpose: written as "if (k < k1) {k2 = k1; k1 = k;} else if (k < k2) k2 = k;" the compiler turns the two
+    // destinations into a selected ADDRESS and keeps (k1, k2) in scratch memory -- a global-memory round trip per candidate
+    const u64 lo = k < k1 ? k : k1;
+    const u64 other = k < k1 ? k1 : k;
+    k2 = other < k2 ? other : k2;
+    k1 = lo;
 }
 __device__ __forceinline__ void wave_min2(u64 &k1, u64 &k2) {
 #pragma unroll
@@ -948,16 +952,18 @@ __device__ __forceinline__ int dev_rot_bin(float a1, float a2) {  // e.g. ORBmat
 }
 // ComputeThreeMaxima (ORBmatcher.cc:2012-2053)
 __device__ __forceinline__ void dev_three_maxima(const int *hist, int &ind1, int &ind2, int &ind3) {
-    int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
-    for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {
+    int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+    for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {  // selects instead of branches: the state stays in registers
         const int s = hist[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
+        const bool a = s > max1, b = !a && s > max2, c = !a && !b && s > max3;
+        const int n3 = (a || b) ? max2 : (c ? s : max3), j3 = (a || b) ? i2 : (c ? i : i3);
+        const int n2 = a ? max1 : (b ? s : max2), j2 = a ? i1 : (b ? i : i2);
+        max1 = a ? s : max1; i1 = a ? i : i1;
+        max2 = n2; i2 = j2; max3 = n3; i3 = j3;
     }
-    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+    if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+    ind1 = i1; ind2 = i2; ind3 = i3;
 }
 
 struct InitProblem {  // ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763)
