@@ -318,11 +318,10 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
     int *ctl = (int *)p; p += 48;
     uint64_t *sa = (uint64_t *)p; p += (size_t)pool * 8;
     uint64_t *sb = (uint64_t *)p; p += (size_t)pool * 8;
-    OctBnd *bnd[2]; OctSeg *seg[2];
-    bnd[0] = (OctBnd *)p; p += (size_t)pool * 8;
-    bnd[1] = (OctBnd *)p; p += (size_t)pool * 8;
-    seg[0] = (OctSeg *)p; p += (size_t)pool * 8;
-    seg[1] = (OctSeg *)p; p += (size_t)pool * 8;
+    // the two generations of the node list: base + generation * pool (plain offset arithmetic keeps the accesses ds_* instead of
+    // flat_*, which an array of two pointers indexed at run time does not)
+    OctBnd *const bndb = (OctBnd *)p; p += (size_t)pool * 16;
+    OctSeg *const segb = (OctSeg *)p; p += (size_t)pool * 16;
     uint32_t *hist = (uint32_t *)p; p += (size_t)pool * 16;
     uint16_t *cpos = (uint16_t *)p; p += (size_t)pool * 8;
     uint16_t *npos = (uint16_t *)p; p += (size_t)pool * 2;   // new position of a node that is not divided; 0xffff = divided
@@ -377,8 +376,8 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
             rstart[r] = off; rpos[r] = size;
             if (r < L.nIni && cnt > 0) {
                 if (tid == 0) {
-                    bnd[0][size] = OctBnd{(int16_t)(int)(L.hX * (float)r), 0, (int16_t)(int)(L.hX * (float)(r + 1)), (int16_t)(L.h - 2 * kBorder)};
-                    seg[0][size] = OctSeg{off, cnt};
+                    bndb[size] = OctBnd{(int16_t)(int)(L.hX * (float)r), 0, (int16_t)(int)(L.hX * (float)(r + 1)), (int16_t)(L.h - 2 * kBorder)};
+                    segb[size] = OctSeg{off, cnt};
                 }
                 size++;
             }
@@ -421,8 +420,8 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
             const int cnt = wr - beg;
             if (cnt > 0) {
                 if (lane == 0) {
-                    bnd[0][size] = OctBnd{(int16_t)(int)(L.hX * (float)r), 0, (int16_t)(int)(L.hX * (float)(r + 1)), (int16_t)(L.h - 2 * kBorder)};
-                    seg[0][size] = OctSeg{beg, cnt};
+                    bndb[size] = OctBnd{(int16_t)(int)(L.hX * (float)r), 0, (int16_t)(int)(L.hX * (float)(r + 1)), (int16_t)(L.h - 2 * kBorder)};
+                    segb[size] = OctSeg{beg, cnt};
                 }
                 size++;
             }
@@ -437,8 +436,10 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
     //   sorted == true : size-ordered round (:690-750), processing order = eof[] (set from the sorted array), break at N
     auto pass = [&](bool sorted, int nB) {
         const int nxt = cur ^ 1;
-        const OctBnd *B0 = bnd[cur];
-        const OctSeg *S0 = seg[cur];
+        const OctBnd *B0 = bndb + cur * pool;
+        const OctSeg *S0 = segb + cur * pool;
+        OctBnd *B1 = bndb + nxt * pool;
+        OctSeg *S1 = segb + nxt * pool;
         const uint32_t *K0 = kb[cur];
         const uint16_t *O0 = nof[cur];
         // A. child key counts of every divisible node (and, 256-thread form, the rank of every key inside its child)
@@ -590,7 +591,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
                 const unsigned long long bk = __ballot(keepn);
                 if (keepn) {
                     const int pos = T + ubase + __popcll(bk & lt_mask);
-                    bnd[nxt][pos] = b; seg[nxt][pos] = sg;
+                    B1[pos] = b; S1[pos] = sg;
                     npos[j] = (uint16_t)pos;
                 }
                 ubase += __popcll(bk);
@@ -608,8 +609,8 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
                         if (cc[k] > 0) {
                             const int pos = T - 1 - ci;
                             ci++;
-                            bnd[nxt][pos] = OctBnd{(int16_t)cx0[k], (int16_t)cy0[k], (int16_t)cx1[k], (int16_t)cy1[k]};
-                            seg[nxt][pos] = OctSeg{off, cc[k]};
+                            B1[pos] = OctBnd{(int16_t)cx0[k], (int16_t)cy0[k], (int16_t)cx1[k], (int16_t)cy1[k]};
+                            S1[pos] = OctSeg{off, cc[k]};
                             cpos[4 * j + k] = (uint16_t)pos;
                             if (cc[k] > 1) {
                                 sa[ai] = ((uint64_t)(uint32_t)cc[k] << 32) | ((uint64_t)(uint16_t)cx0[k] << 16) | (uint64_t)pos;
