@@ -3,8 +3,10 @@
 // Stage -> reference function (all line numbers in /root/reference/src/ORBextractor.cc):
 //   k_pyr_base        copyMakeBorder of the input into level 0                 :1188-1191
 //   k_pyr_resize      cv::resize(INTER_LINEAR) level l-1 -> l + REFLECT_101    :1183-1186
-//   k_fast_cells      per-cell cv::FAST(ini) / fallback cv::FAST(min) + NMS    :805-870
-//   k_octree          DistributeOctTree / DivideNode / compareNodes            :480-779
+//   k_fast_wave       per-cell cv::FAST(ini) / fallback cv::FAST(min) + NMS    :805-870   (one wave per cell; k_fast_wave_list
+//                     for cells whose candidate queue overflows, k_fast_cells = generic workgroup-per-cell form)
+//   k_compact, k_octree_par (octree_par.hip.h)  DistributeOctTree / DivideNode / compareNodes   :480-779
+//                     (k_octree in octree.hip.h = sequential emulation, selectable reference)
 //   k_finalize        level concatenation + lapping split slots                :1117-1162
 //   k_blur            GaussianBlur 7x7 sigma 2 (fixed point)                   :1132-1133
 //   k_describe        IC_Angle + computeOrbDescriptor + keypoint record        :76-146, 1143-1162

@@ -308,7 +308,6 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         else if (tpb == 256) ORBX_FAST_LAUNCH(256);
         else if (tpb == 128) ORBX_FAST_LAUNCH(128);
         else ORBX_FAST_LAUNCH(64);
-        if (0) ORBX_FAST_LAUNCH(64);
     }
     {
         ProfScope ps(ex, K_OCTREE);
