@@ -4,7 +4,8 @@
  * Every function cites the reference lines (/root/reference/...) or the OpenCV / glibc routine it
  * restates.  "[OCV]" marks behaviour of OpenCV 4.x restated from its published algorithm; OpenCV is an
  * un-vendored dependency of the reference (CMakeLists.txt:33-36, "find_package(OpenCV 4.4)") and is
- * not available in this image, so those parts are **parity unpinned** (see header).
+ * not available in this image, so those parts are **parity unpinned**; everything that is the reference's own
+ * code in this file is pinned against the compiled reference source (see header, `make ref`).
  *
  * Build: g++ -O3 -march=x86-64-v3 -ffp-contract=off (see oracle/Makefile).  Contraction is OFF so that
  * every float expression rounds exactly as written; the one place where the reference's own build

@@ -12,10 +12,16 @@
  * plus restatements of the OpenCV 4.x primitives the reference calls (resize, copyMakeBorder,
  * FAST, GaussianBlur, fastAtan2, cvRound, BFMatcher) and of glibc 2.35 sinf/cosf.
  *
- * PARITY STATUS: **parity unpinned**.  The reference tree holds no golden vectors or tests for
- * this path and the reference itself cannot be built here (OpenCV/Eigen absent),
- * so the oracle is pinned only by (a) analytic known answers derived from the cited lines and
- * (b) an exhaustive check of the restated sinf/cosf against this image's glibc.
+ * PARITY STATUS.
+ *   Extractor, the reference's own code (T1 tables, pyramid composition, per-cell FAST with the threshold fallback,
+ *   DistributeOctTree, IC_Angle, computeOrbDescriptor incl. the FMA contraction of the reference's build flags, output
+ *   assembly / lapping split): PINNED against the reference itself -- /root/reference/src/ORBextractor.cc is compiled where
+ *   it lies (`make ref` -> oracle/_ref/liborb_ref.so) against oracle/ocv_shim and gives bit-identical keypoints, descriptors,
+ *   tables and pyramids (tests/test_oracle_vs_reference.py, committed goldens tests/golden/ref_*.npz).
+ *   OpenCV primitives (resize, copyMakeBorder, FAST, GaussianBlur, fastAtan2, cvRound, BFMatcher) and the matchers
+ *   (ORBmatcher.cc needs Eigen/Sophus/DBoW2 headers that are not in the image): **parity unpinned** -- the reference tree
+ *   holds no golden vectors or tests for this path; they are pinned only by analytic known answers
+ *   derived from the cited lines and an exhaustive check of the restated sinf/cosf against this image's glibc.
  */
 #ifndef ORB_ORACLE_H
 #define ORB_ORACLE_H
