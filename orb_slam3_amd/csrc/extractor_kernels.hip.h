@@ -507,15 +507,21 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
             const uint32_t aL = A[1 * D - 1], aC = A[1 * D], aR = A[1 * D + 1];    // centre row - 2
             const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];    // centre row
             const uint32_t bL = A[5 * D - 1], bC = A[5 * D], bR = A[5 * D + 1];    // centre row + 2
-            const uint32_t r4 = __builtin_amdgcn_alignbyte(cR, cC, 3), r12 = __builtin_amdgcn_alignbyte(cC, cL, 1);
-            const uint32_t r2 = __builtin_amdgcn_alignbyte(bR, bC, 2), r14 = __builtin_amdgcn_alignbyte(bC, bL, 2);
-            const uint32_t r6 = __builtin_amdgcn_alignbyte(aR, aC, 2), r10 = __builtin_amdgcn_alignbyte(aC, aL, 2);
-            const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), pk_even(r4), pk_even(r12), pk_even(r2), pk_even(r10),
-                                            pk_even(r6), pk_even(r14), t2);   // pixels 0 (low half) and 2
-            const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), pk_odd(r4), pk_odd(r12), pk_odd(r2), pk_odd(r10),
-                                            pk_odd(r6), pk_odd(r14), t2);     // pixels 1 and 3
-            const uint32_t one = 0x00010001u;
-            const uint32_t z = as_u32(pk_min(as_pk(fe), as_pk(one))) | (as_u32(pk_min(as_pk(fo), as_pk(one))) << 1);  // bits 0,1,16,17
+            // even / odd pixels of a neighbour dword that starts s bytes into the pair (hi, lo): ONE v_perm_b32 each
+            // (byte s, 0, byte s + 2, 0) / (byte s + 1, 0, byte s + 3, 0) instead of v_alignbyte + two unpacks
+#define FW_EVEN(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(s) | ((uint32_t)((s) + 2) << 16)))
+#define FW_ODD(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)((s) + 1) | ((uint32_t)((s) + 3) << 16)))
+            const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), FW_EVEN(cR, cC, 3), FW_EVEN(cC, cL, 1), FW_EVEN(bR, bC, 2),
+                                            FW_EVEN(aC, aL, 2), FW_EVEN(aR, aC, 2), FW_EVEN(bC, bL, 2), t2);   // pixels 0 (low half) and 2
+            const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), FW_ODD(cR, cC, 3), FW_ODD(cC, cL, 1), FW_ODD(bR, bC, 2),
+                                            FW_ODD(aC, aL, 2), FW_ODD(aR, aC, 2), FW_ODD(bC, bL, 2), t2);      // pixels 1 and 3
+#undef FW_EVEN
+#undef FW_ODD
+            // flags -> 4-bit mask: min(f, 1) per half (inline asm: the compiler expands the packed min into compares + selects)
+            uint32_t ze, zo;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(ze) : "v"(fe), "v"(0x00010001u));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(zo) : "v"(fo), "v"(0x00010001u));
+            const uint32_t z = ze | (zo << 1);  // bits 0, 1, 16, 17
             uint32_t m4 = (z | (z >> 14)) & 0xfu;
             m4 &= act ? vmask : 0u;
             const int c = __popc(m4);
