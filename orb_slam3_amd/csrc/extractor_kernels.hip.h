@@ -207,41 +207,44 @@ __device__ __forceinline__ int max3i(int a, int b, int c) {
 }
 
 __device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int pp) {
+    // [OCV] cornerScore<16>: with d[k] = v - p[k] the score is max(max_arcs min(d), -min_arcs max(d)) - 1 over the 16 arcs of 9.
+    // min over an arc of (v - p) = v - max over the arc of p, so the arcs are evaluated on the raw circle pixels and v enters
+    // twice at the end (sixteen subtractions fewer):   score = max(v - min_arcs max9(p), max_arcs min9(p) - v) - 1
     const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * pp];
-    d[1] = v - c[3 * pp + 1];
-    d[2] = v - c[2 * pp + 2];
-    d[3] = v - c[pp + 3];
-    d[4] = v - c[3];
-    d[5] = v - c[-pp + 3];
-    d[6] = v - c[-2 * pp + 2];
-    d[7] = v - c[-3 * pp + 1];
-    d[8] = v - c[-3 * pp];
-    d[9] = v - c[-3 * pp - 1];
-    d[10] = v - c[-2 * pp - 2];
-    d[11] = v - c[-pp - 3];
-    d[12] = v - c[-3];
-    d[13] = v - c[pp - 3];
-    d[14] = v - c[2 * pp - 2];
-    d[15] = v - c[3 * pp - 1];
+    int p[16];
+    p[0] = c[3 * pp];
+    p[1] = c[3 * pp + 1];
+    p[2] = c[2 * pp + 2];
+    p[3] = c[pp + 3];
+    p[4] = c[3];
+    p[5] = c[-pp + 3];
+    p[6] = c[-2 * pp + 2];
+    p[7] = c[-3 * pp + 1];
+    p[8] = c[-3 * pp];
+    p[9] = c[-3 * pp - 1];
+    p[10] = c[-2 * pp - 2];
+    p[11] = c[-pp - 3];
+    p[12] = c[-3];
+    p[13] = c[pp - 3];
+    p[14] = c[2 * pp - 2];
+    p[15] = c[3 * pp - 1];
     int lo3[16], hi3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        lo3[k] = min3i(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+        hi3[k] = max3i(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
     }
-    int A = -256, B = 256;
+    int maxmin = 0, minmax = 255;  // max over the arcs of min9(p), min over the arcs of max9(p)
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
-        const int a0 = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);          // min over d[k..k+8]
+        const int a0 = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);          // min over p[k..k+8]
         const int a1 = min3i(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]);
-        const int b0 = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);          // max over d[k..k+8]
+        const int b0 = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);          // max over p[k..k+8]
         const int b1 = max3i(hi3[k + 1], hi3[(k + 4) & 15], hi3[(k + 7) & 15]);
-        A = max3i(A, a0, a1);
-        B = min3i(B, b0, b1);
+        maxmin = max3i(maxmin, a0, a1);
+        minmax = min3i(minmax, b0, b1);
     }
-    return max(A, -B) - 1;
+    return max(v - minmax, maxmin - v) - 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------
