@@ -13,7 +13,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
+#include <iostream>
 #include <memory>
+#include <sstream>   // the real opencv2/core pulls these in; DBoW2's TemplatedVocabulary.h relies on it
+#include <string>
 #include <vector>
 
 #include "../../orb_oracle.h"
@@ -21,6 +25,7 @@
 typedef unsigned char uchar;
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_32F 5
 #define CV_PI 3.1415926535897932384626433832795
 #ifndef ORB_REF_BLUR_OCV440
 #define ORB_REF_BLUR_OCV440 0   /* Gaussian taps of OpenCV >= 4.5.1 (the oracle's default); 1 = OpenCV <= 4.5.0 */
@@ -82,16 +87,17 @@ public:
     int base_rows = 0, base_cols = 0;
 
     Mat() {}
-    Mat(int r, int c, int /*type*/) { alloc(r, c); }
-    Mat(Size s, int /*type*/) { alloc(s.height, s.width); }
+    Mat(int r, int c, int type) { alloc(r, c, type); }
+    Mat(Size s, int type) { alloc(s.height, s.width, type); }
     static Mat zeros(int r, int c, int type) { Mat m(r, c, type); if (m.data) memset(m.data, 0, (size_t)r * m.step.v); return m; }
+    bool isContinuous() const { return step.v == (size_t)cols * esz(); }
 
-    int type() const { return CV_8UC1; }
+    int type() const { return type_; }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     size_t step1() const { return step.v; }
     Mat getMat() const { return *this; }
     void release() { *this = Mat(); }
-    void create(int r, int c, int /*type*/) { if (r != rows || c != cols || !data) alloc(r, c); }
+    void create(int r, int c, int type) { if (r != rows || c != cols || type != type_ || !data) alloc(r, c, type); }
 
     Mat view(int x, int y, int w, int h) const {
         Mat m = *this;
@@ -104,28 +110,53 @@ public:
     Mat colRange(int a, int b) const { return view(a, 0, b - a, rows); }
     Mat row(int i) const { return view(0, i, cols, 1); }
     Mat clone() const {
-        Mat m(rows, cols, 0);
-        for (int r = 0; r < rows; r++) memcpy(m.data + (size_t)r * m.step.v, data + (size_t)r * step.v, cols);
+        Mat m(rows, cols, type_);
+        for (int r = 0; r < rows; r++) memcpy(m.data + (size_t)r * m.step.v, data + (size_t)r * step.v, (size_t)cols * esz());
         return m;
     }
     void copyTo(const Mat &dst) const {  // into an existing view of the same size (descriptor rows)
         assert(dst.rows == rows && dst.cols == cols);
-        for (int r = 0; r < rows; r++) memcpy(dst.data + (size_t)r * dst.step.v, data + (size_t)r * step.v, cols);
+        for (int r = 0; r < rows; r++) memcpy(dst.data + (size_t)r * dst.step.v, data + (size_t)r * step.v, (size_t)cols * esz());
     }
-    template <class T> T &at(int r, int c) { return *(T *)(data + (size_t)r * step.v + c); }
-    template <class T> const T &at(int r, int c) const { return *(const T *)(data + (size_t)r * step.v + c); }
+    template <class T> T &at(int r, int c) { return *(T *)(data + (size_t)r * step.v + (size_t)c * sizeof(T)); }
+    template <class T> const T &at(int r, int c) const { return *(const T *)(data + (size_t)r * step.v + (size_t)c * sizeof(T)); }
     uchar *ptr(int r = 0) { return data + (size_t)r * step.v; }
     const uchar *ptr(int r = 0) const { return data + (size_t)r * step.v; }
     template <class T> T *ptr(int r = 0) { return (T *)(data + (size_t)r * step.v); }
+    template <class T> const T *ptr(int r = 0) const { return (const T *)(data + (size_t)r * step.v); }
 
 private:
-    void alloc(int r, int c) {
-        rows = r; cols = c;
-        step.v = (size_t)c;
-        buf = std::shared_ptr<uchar>(new uchar[(size_t)std::max(r, 1) * std::max(c, 1) + 64], std::default_delete<uchar[]>());
+    int type_ = CV_8UC1;
+    size_t esz() const { return type_ == CV_32F ? 4 : 1; }
+    void alloc(int r, int c, int type) {
+        rows = r; cols = c; type_ = type;
+        step.v = (size_t)c * esz();
+        buf = std::shared_ptr<uchar>(new uchar[(size_t)std::max(r, 1) * std::max(c, 1) * esz() + 64], std::default_delete<uchar[]>());
         data = base = buf.get();
         base_rows = r; base_cols = c;
     }
+};
+
+// cv::FileStorage / cv::FileNode: only named by the virtual save() / load() of DBoW2's TemplatedVocabulary, which the
+// reference build never calls (the vocabulary is loaded with loadFromTextFile)
+struct FileNode {
+    enum { SEQ = 5 };
+    FileNode operator[](const char *) const { return FileNode(); }
+    FileNode operator[](const std::string &) const { return FileNode(); }
+    FileNode operator[](int) const { return FileNode(); }
+    size_t size() const { assert(!"cv::FileNode is outside the shim"); return 0; }
+    int type() const { return 0; }
+    template <class T> operator T() const { assert(!"cv::FileNode is outside the shim"); return T(); }
+};
+struct FileStorage {
+    enum { READ = 0, WRITE = 1 };
+    FileStorage() {}
+    template <class S> FileStorage(const S &, int) { assert(!"cv::FileStorage is outside the shim"); }
+    bool isOpened() const { return false; }
+    void release() {}
+    FileNode operator[](const char *) const { return FileNode(); }
+    FileNode operator[](const std::string &) const { return FileNode(); }
+    template <class T> FileStorage &operator<<(const T &) { return *this; }
 };
 
 typedef const Mat &InputArray;

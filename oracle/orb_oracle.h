@@ -18,6 +18,8 @@
  *   assembly / lapping split): PINNED against the reference itself -- /root/reference/src/ORBextractor.cc is compiled where
  *   it lies (`make ref` -> oracle/_ref/liborb_ref.so) against oracle/ocv_shim and gives bit-identical keypoints, descriptors,
  *   tables and pyramids (tests/test_oracle_vs_reference.py, committed goldens tests/golden/ref_*.npz).
+ *   DBoW2 transform (orbo_bow_transform): PINNED against the reference's vendored Thirdparty/DBoW2 built the same way
+ *   (oracle/_ref/libdbow2_ref.so).
  *   OpenCV primitives (resize, copyMakeBorder, FAST, GaussianBlur, fastAtan2, cvRound, BFMatcher) and the matchers
  *   (ORBmatcher.cc needs Eigen/Sophus/DBoW2 headers that are not in the image): **parity unpinned** -- the reference tree
  *   holds no golden vectors or tests for this path; they are pinned only by analytic known answers

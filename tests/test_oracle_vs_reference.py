@@ -80,3 +80,54 @@ def test_oracle_equals_reference_golden(name):
     mono, k, d = orc.extract(img, lap=(int(g["lap"][0]), int(g["lap"][1])))
     assert mono == int(g["mono"])
     assert np.array_equal(k, g["keypoints"].view(ob.KP_DTYPE).reshape(-1)) and np.array_equal(d, g["descriptors"])
+
+
+def _ordered_vocabulary(rng, k, L):
+    """Random k-ary vocabulary (2..k children per node, all leaves at depth L as in ORBvoc.txt -- for a leaf above the level
+    asked for the reference leaves *nid unassigned) numbered the way TemplatedVocabulary::loadFromTextFile numbers it: a
+    node's id is its line number, so children lists are ascending; word ids follow leaf id order.  Sibling descriptors are
+    duplicated in places so that distance ties occur (the first child must win)."""
+    children = [[]]
+    depth = [0]
+    q = [0]
+    while q:
+        i = q.pop(0)
+        if depth[i] == L:
+            continue
+        for _ in range(int(rng.integers(max(2, k - 3), k + 1))):
+            children.append([]); depth.append(depth[i] + 1)
+            children[i].append(len(children) - 1)
+            q.append(len(children) - 1)
+    n = len(children)
+    nd = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for ch in children:
+        if len(ch) >= 2 and rng.random() < 0.15:
+            nd[ch[1]] = nd[ch[0]]
+    cp, ci, wi, nw = [0], [], np.full(n, -1, np.int32), 0
+    for i in range(n):
+        ci.extend(children[i]); cp.append(len(ci))
+        if not children[i]:
+            wi[i] = nw; nw += 1
+    return np.array(cp, np.int32), np.array(ci, np.int32), nd, wi
+
+
+@pytest.mark.skipif(not rb.dbow_available(), reason="oracle/_ref/libdbow2_ref.so not built (needs /root/reference at build time)")
+def test_bow_transform_equals_vendored_dbow2(tmp_path):
+    """orbo_bow_transform (and through it orbx_bow_transform, tests/test_gpu_matcher.py::test_bow_transform) against the
+    reference's vendored DBoW2: TemplatedVocabulary<FORB::TDescriptor, FORB>::transform on a vocabulary loaded with
+    loadFromTextFile, per feature (word, node at levelsup) and the FeatureVector of the batch overload Frame::ComputeBoW calls."""
+    rng = np.random.default_rng(77)
+    for k, L in ((10, 4), (6, 6), (17, 3)):
+        cp, ci, nd, wi = _ordered_vocabulary(rng, k, L)
+        path = tmp_path / f"voc_{k}_{L}.txt"
+        rb.write_vocabulary_text(path, k, L, cp, ci, nd, wi)
+        voc = rb.RefVocabulary(path)
+        assert voc.words() == int((wi >= 0).sum())
+        feats = np.concatenate([rng.integers(0, 256, (700, 32), dtype=np.uint8), nd[rng.integers(1, len(nd), 300)]])
+        for levelsup in (4, 2, 0, 9):
+            rw, rn, fvn, fvf = voc.transform(feats, levelsup)
+            ow, on = ob.bow_transform(cp, ci, nd, wi, L, levelsup, feats)
+            assert np.array_equal(rw, ow) and np.array_equal(rn, on), (k, L, levelsup)
+            # FeatureVector = features grouped by node id (ascending), feature order kept inside a node
+            order = np.lexsort((np.arange(len(on)), on))
+            assert np.array_equal(fvn, on[order]) and np.array_equal(fvf, order)
