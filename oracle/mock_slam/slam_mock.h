@@ -1,0 +1,220 @@
+/* TEST INFRASTRUCTURE ONLY.  Stand-in SLAM types (Frame / KeyFrame / MapPoint / GeometricCamera) plus a minimal Eigen /
+ * Sophus vocabulary, just large enough that the reference's own src/ORBmatcher.cc compiles WHERE IT LIES (see
+ * oracle/Makefile, target _ref/libmatcher_ref.so).  Nothing here restates matcher logic: the matcher loops that run are
+ * the reference's; these types only carry the flattened test data into them.  Frame/KeyFrame::GetFeaturesInArea forward to
+ * the oracle's grid (orbo_grid_query), so the grid lookup itself stays a restatement (Frame.cc / KeyFrame.cc cannot be
+ * built here: they pull in g2o, Eigen, OpenCV calib3d ...).  The math types do plain float arithmetic; the parity tests
+ * drive the geometry with identity poses and a camera whose project() returns (x, y) unchanged, so every projected pixel
+ * is exactly the number the test chose. */
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstddef>
+#include <map>
+#include <set>
+#include <vector>
+#include <list>
+#include <utility>
+#include <tuple>
+#include <opencv2/core/core.hpp>
+#include "Thirdparty/DBoW2/DBoW2/BowVector.h"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+#include "../orb_oracle.h"
+
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+
+namespace Eigen {
+template <int N>
+struct Vec {
+    float v[N];
+    Vec() { for (int i = 0; i < N; i++) v[i] = 0.f; }
+    Vec(float a, float b) { static_assert(N == 2, ""); v[0] = a; v[1] = b; }
+    Vec(float a, float b, float c) { static_assert(N == 3, ""); v[0] = a; v[1] = b; v[2] = c; }
+    float &operator()(int i) { return v[i]; }
+    float operator()(int i) const { return v[i]; }
+    float &operator[](int i) { return v[i]; }
+    float operator[](int i) const { return v[i]; }
+    Vec operator-(const Vec &o) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] - o.v[i]; return r; }
+    Vec operator+(const Vec &o) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] + o.v[i]; return r; }
+    Vec operator-() const { Vec r; for (int i = 0; i < N; i++) r.v[i] = -v[i]; return r; }
+    Vec operator*(float s) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] * s; return r; }
+    Vec operator/(float s) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] / s; return r; }
+    float dot(const Vec &o) const { float s = 0.f; for (int i = 0; i < N; i++) s += v[i] * o.v[i]; return s; }
+    float squaredNorm() const { return dot(*this); }
+    float norm() const { return std::sqrt(dot(*this)); }
+    const Vec &transpose() const { return *this; }
+};
+template <int N> inline Vec<N> operator*(float s, const Vec<N> &a) { return a * s; }
+typedef Vec<2> Vector2f;
+typedef Vec<3> Vector3f;
+struct Matrix3f {
+    float m[3][3];
+    Matrix3f() { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = (i == j) ? 1.f : 0.f; }
+    static Matrix3f Identity() { return Matrix3f(); }
+    float &operator()(int i, int j) { return m[i][j]; }
+    float operator()(int i, int j) const { return m[i][j]; }
+    Vector3f operator*(const Vector3f &x) const {
+        Vector3f r;
+        for (int i = 0; i < 3; i++) r.v[i] = m[i][0] * x.v[0] + m[i][1] * x.v[1] + m[i][2] * x.v[2];
+        return r;
+    }
+    Matrix3f operator*(const Matrix3f &o) const {
+        Matrix3f r;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) r.m[i][j] = m[i][0] * o.m[0][j] + m[i][1] * o.m[1][j] + m[i][2] * o.m[2][j];
+        return r;
+    }
+    Matrix3f operator*(float s) const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[i][j] * s; return r; }
+    Matrix3f transpose() const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[j][i]; return r; }
+};
+}  // namespace Eigen
+
+namespace Sophus {
+struct SE3f {
+    Eigen::Matrix3f R;
+    Eigen::Vector3f t;
+    SE3f() {}
+    SE3f(const Eigen::Matrix3f &R_, const Eigen::Vector3f &t_) : R(R_), t(t_) {}
+    Eigen::Matrix3f rotationMatrix() const { return R; }
+    Eigen::Vector3f translation() const { return t; }
+    SE3f inverse() const { Eigen::Matrix3f Rt = R.transpose(); return SE3f(Rt, -(Rt * t)); }
+    Eigen::Vector3f operator*(const Eigen::Vector3f &x) const { return R * x + t; }
+    SE3f operator*(const SE3f &o) const { return SE3f(R * o.R, R * o.t + t); }
+};
+template <class T>
+struct Sim3 {
+    float s = 1.f;
+    Eigen::Matrix3f R;
+    Eigen::Vector3f t;
+    Sim3() {}
+    Sim3(float s_, const Eigen::Matrix3f &R_, const Eigen::Vector3f &t_) : s(s_), R(R_), t(t_) {}
+    Eigen::Matrix3f rotationMatrix() const { return R; }
+    Eigen::Vector3f translation() const { return t; }
+    float scale() const { return s; }
+    Sim3 inverse() const { Eigen::Matrix3f Rt = R.transpose(); return Sim3(1.f / s, Rt, -((Rt * t) * (1.f / s))); }
+    Eigen::Vector3f operator*(const Eigen::Vector3f &x) const { return (R * x) * s + t; }
+};
+typedef Sim3<float> Sim3f;
+}  // namespace Sophus
+
+namespace ORB_SLAM3 {
+
+class KeyFrame;
+class Frame;
+
+/* project() hands back (x, y) of the camera-frame point: the test stores the wanted pixel in the map point itself */
+class GeometricCamera {
+public:
+    virtual ~GeometricCamera() {}
+    virtual Eigen::Vector2f project(const Eigen::Vector3f &p) { return Eigen::Vector2f(p(0), p(1)); }
+    /* the verdicts of the epipolar test are test data: ok[idx1 * n2 + idx2], keyed by keypoint identity (class_id) */
+    const uint8_t *epi_ok = nullptr;
+    int epi_n2 = 0;
+    virtual bool epipolarConstrain(GeometricCamera *, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2,
+                                   const Eigen::Matrix3f &, const Eigen::Vector3f &, const float, const float) {
+        return epi_ok ? epi_ok[(size_t)kp1.class_id * epi_n2 + kp2.class_id] != 0 : true;
+    }
+};
+
+class MapPoint {
+public:
+    /* tracking fields the matchers read (MapPoint.h) */
+    float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackDepthR = 0, mTrackProjXR = 0, mTrackProjYR = 0;
+    bool mbTrackInView = false, mbTrackInViewR = false;
+    int mnTrackScaleLevel = 0, mnTrackScaleLevelR = -1;
+    float mTrackViewCos = 1.f, mTrackViewCosR = 1.f;
+    /* test data */
+    int id = -1;
+    bool bad = false;
+    int nobs = 1;
+    int pred_scale = 0;
+    Eigen::Vector3f pos, normal;
+    float min_dist = 0.f, max_dist = 3.0e38f;
+    cv::Mat desc; /* 1 x 32 */
+    std::map<KeyFrame *, int> in_kf;
+    std::vector<std::pair<KeyFrame *, int>> added_obs;
+    MapPoint *replaced_by = nullptr;
+
+    bool isBad() { return bad; }
+    int Observations() { return nobs; }
+    cv::Mat GetDescriptor() { return desc; }
+    Eigen::Vector3f GetWorldPos() { return pos; }
+    Eigen::Vector3f GetNormal() { return normal; }
+    float GetMinDistanceInvariance() { return min_dist; }
+    float GetMaxDistanceInvariance() { return max_dist; }
+    int PredictScale(const float &, KeyFrame *) { return pred_scale; }
+    int PredictScale(const float &, Frame *) { return pred_scale; }
+    bool IsInKeyFrame(KeyFrame *kf) { return in_kf.count(kf) != 0; }
+    std::tuple<int, int> GetIndexInKeyFrame(KeyFrame *kf) {
+        auto it = in_kf.find(kf);
+        return it == in_kf.end() ? std::tuple<int, int>(-1, -1) : std::tuple<int, int>(it->second, -1);
+    }
+    void AddObservation(KeyFrame *kf, int idx) { added_obs.push_back({kf, idx}); in_kf[kf] = idx; }
+    void Replace(MapPoint *p) { replaced_by = p; }
+};
+
+struct FeatureHolder {
+    int N = 0;
+    int Nleft = -1, NLeft = -1;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
+    std::vector<float> mvuRight, mvDepth;
+    cv::Mat mDescriptors;
+    DBoW2::BowVector mBowVec;
+    DBoW2::FeatureVector mFeatVec;
+    std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;
+    GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+    float fx = 1, fy = 1, cx = 0, cy = 0, mbf = 0, mb = 0;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
+    Sophus::SE3f Tcw, Trl;
+    /* grid over mvKeysUn held by the oracle; kps_un is the flattened copy it indexes */
+    std::vector<orbo_keypoint> kps_un;
+    orbo_grid *grid = nullptr;
+    ~FeatureHolder() { if (grid) orbo_grid_destroy(grid); }
+    std::vector<size_t> area(float x, float y, float r, int minLevel, int maxLevel) const {
+        std::vector<int32_t> tmp(N > 0 ? N : 1);
+        int n = orbo_grid_query(grid, x, y, r, minLevel, maxLevel, tmp.data(), (int)tmp.size());
+        return std::vector<size_t>(tmp.begin(), tmp.begin() + n);
+    }
+};
+
+class Frame : public FeatureHolder {
+public:
+    std::vector<MapPoint *> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1,
+                                          const int maxLevel = -1, const bool bRight = false) const {
+        return area(x, y, r, minLevel, maxLevel);
+    }
+    Sophus::SE3f GetPose() const { return Tcw; }
+    Sophus::SE3f GetRelativePoseTrl() const { return Trl; }
+};
+
+class KeyFrame : public FeatureHolder {
+public:
+    std::vector<MapPoint *> mvpMapPoints;
+    std::vector<std::pair<MapPoint *, int>> added;
+    std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+    std::set<MapPoint *> GetMapPoints() {
+        std::set<MapPoint *> s;
+        for (MapPoint *p : mvpMapPoints) if (p && !p->isBad()) s.insert(p);
+        return s;
+    }
+    /* probe: slots read as empty and stay empty, so Fuse reports every accepted query through AddObservation */
+    bool probe = false;
+    MapPoint *GetMapPoint(const size_t &idx) { return probe ? nullptr : mvpMapPoints[idx]; }
+    void AddMapPoint(MapPoint *p, const size_t &idx) { if (!probe) mvpMapPoints[idx] = p; added.push_back({p, (int)idx}); }
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const bool bRight = false) const {
+        return area(x, y, r, -1, -1);
+    }
+    bool IsInImage(const float &x, const float &y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
+    Sophus::SE3f GetPose() { return Tcw; }
+    Sophus::SE3f GetPoseInverse() { return Tcw.inverse(); }
+    Sophus::SE3f GetRightPose() { return Trl * Tcw; }
+    Sophus::SE3f GetRightPoseInverse() { return (Trl * Tcw).inverse(); }
+    Sophus::SE3f GetRelativePoseTrl() { return Trl; }
+    Eigen::Vector3f GetCameraCenter() { return Tcw.inverse().translation(); }
+    Eigen::Vector3f GetRightCameraCenter() { return (Trl * Tcw).inverse().translation(); }
+};
+
+}  // namespace ORB_SLAM3

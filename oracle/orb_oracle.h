@@ -20,10 +20,17 @@
  *   tables and pyramids (tests/test_oracle_vs_reference.py, committed goldens tests/golden/ref_*.npz).
  *   DBoW2 transform (orbo_bow_transform): PINNED against the reference's vendored Thirdparty/DBoW2 built the same way
  *   (oracle/_ref/libdbow2_ref.so).
- *   OpenCV primitives (resize, copyMakeBorder, FAST, GaussianBlur, fastAtan2, cvRound, BFMatcher) and the matchers
- *   (ORBmatcher.cc needs Eigen/Sophus/DBoW2 headers that are not in the image): **parity unpinned** -- the reference tree
- *   holds no golden vectors or tests for this path; they are pinned only by analytic known answers
- *   derived from the cited lines and an exhaustive check of the restated sinf/cosf against this image's glibc.
+ *   Matchers (orbo_search_*, orbo_fuse_search, orbo_three_maxima, orbo_descriptor_distance): PINNED against the reference's
+ *   own src/ORBmatcher.cc, compiled where it lies (oracle/_ref/libmatcher_ref.so) against oracle/mock_slam (stand-in Frame /
+ *   KeyFrame / MapPoint that only carry test data, minimal float Eigen/Sophus types, identity poses, project() = (x, y)):
+ *   identical match vectors on seeded inputs for all five SearchByProjection overloads, both SearchByBoW,
+ *   SearchForInitialization, SearchForTriangulation, both Fuse and SearchBySim3 (tests/test_oracle_matchers_vs_reference.py,
+ *   committed reference outputs tests/golden/matchers_ref.npz).
+ *   **parity unpinned**: the arithmetic inside the OpenCV primitives (resize, copyMakeBorder, FAST, GaussianBlur, fastAtan2,
+ *   cvRound, BFMatcher), Frame/KeyFrame::GetFeaturesInArea + grid assignment and Frame::ComputeStereoMatches (Frame.cc /
+ *   KeyFrame.cc need g2o, Eigen and OpenCV calib3d, absent from the image) -- the reference tree holds no golden vectors or
+ *   tests for them; they are pinned only by analytic known answers derived from the cited lines and
+ *   an exhaustive check of the restated sinf/cosf against this image's glibc.
  */
 #ifndef ORB_ORACLE_H
 #define ORB_ORACLE_H

@@ -135,3 +135,176 @@ class RefVocabulary:
         fvn, fvf = np.zeros(n, np.int32), np.zeros(n, np.int32)
         k = _dbow_lib().dbowref_transform(self.h, d.ctypes.data, n, levelsup, word.ctypes.data, node.ctypes.data, fvn.ctypes.data, fvf.ctypes.data)
         return word, node, fvn[:k], fvf[:k]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's ORBmatcher.cc compiled where it lies against oracle/mock_slam (stand-in Frame / KeyFrame / MapPoint) and
+# the OpenCV shim: oracle/_ref/libmatcher_ref.so.  The functions below take what the oracle_binding matchers take.
+# ---------------------------------------------------------------------------------------------------------------------
+_matcher = None
+
+
+def matcher_available() -> bool:
+    return (_DIR / "libmatcher_ref.so").exists()
+
+
+def _ml():
+    global _matcher
+    if _matcher is None:
+        C.CDLL(str(_DIR.parent / "liborb_oracle.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(str(_DIR / "libmatcher_ref.so"))
+        for name in ("matref_descriptor_distance", "matref_search_by_projection_mappoints", "matref_search_by_projection_frame",
+                     "matref_search_by_projection_keyframe", "matref_search_by_projection_sim3", "matref_search_by_bow_frame",
+                     "matref_search_by_bow_keyframes", "matref_search_for_initialization", "matref_search_for_triangulation",
+                     "matref_fuse", "matref_search_by_sim3"):
+            getattr(L, name).restype = C.c_int
+        _matcher = L
+    return _matcher
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _u8(a):
+    return None if a is None else np.ascontiguousarray(a, np.uint8)
+
+
+def _fv(fv):
+    from .oracle_binding import OFeatVec
+    return OFeatVec(fv.node_id.ctypes.data, fv.node_ptr.ctypes.data, fv.index.ctypes.data, len(fv.node_id))
+
+
+class RefFrame:
+    """The flattened Frame / KeyFrame data every projection matcher needs: undistorted keypoints, descriptors, image bounds."""
+
+    def __init__(self, kps_un, desc, minx, maxx, miny, maxy, scale_factors, u_right=None):
+        self.kps = np.ascontiguousarray(kps_un, KP_DTYPE)
+        self.desc = _u8(desc)
+        self.bounds = np.array([minx, maxx, miny, maxy], np.float32)
+        self.sf = _f32(scale_factors)
+        self.u_right = None if u_right is None else _f32(u_right)
+
+    def head(self):
+        return (_p(self.kps), _p(self.desc), len(self.kps), _p(self.bounds), _p(self.sf), len(self.sf))
+
+
+def ref_descriptor_distance(a, b):
+    a, b = _u8(a), _u8(b)
+    return _ml().matref_descriptor_distance(_p(a), _p(b))
+
+
+def ref_three_maxima(sizes):
+    s = _i32(sizes)
+    a, b, c = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    _ml().matref_three_maxima(_p(s), len(s), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def ref_search_by_projection_mappoints(F: RefFrame, mp, th, nnratio, occupied=None):
+    fm = np.full(len(F.kps), -1, np.int32)
+    occ = _u8(occupied)
+    a = {k: np.ascontiguousarray(v) for k, v in mp.items()}
+    arrs = [_f32(a["proj_x"]), _f32(a["proj_y"]), _f32(a["proj_xr"]), _i32(a["level"]), _f32(a["view_cos"]), _u8(a["desc"]),
+            _u8(a["in_view"]), _u8(a["has_obs"])]
+    n = _ml().matref_search_by_projection_mappoints(*F.head(), _p(F.u_right), _p(occ), len(arrs[0]), *[_p(x) for x in arrs],
+                                                   C.c_float(th), C.c_float(nnratio), _p(fm))
+    return n, fm
+
+
+def ref_search_by_projection_frame(F: RefFrame, q, th, mode=0, check_orientation=True, occupied=None):
+    """q: u, v, z (camera depth; ur = u - 1/z), octave, angle, desc, has_obs."""
+    cm = np.full(len(F.kps), -1, np.int32)
+    occ = _u8(occupied)
+    arrs = [_f32(q["u"]), _f32(q["v"]), _f32(q["z"]), _i32(q["octave"]), _f32(q["angle"]), _u8(q["desc"]), _u8(q["has_obs"])]
+    n = _ml().matref_search_by_projection_frame(*F.head(), _p(F.u_right), _p(occ), len(arrs[0]), *[_p(x) for x in arrs],
+                                               C.c_float(th), int(mode), int(check_orientation), _p(cm))
+    return n, cm
+
+
+def ref_search_by_projection_keyframe(F: RefFrame, q, th, orb_dist, check_orientation=True, occupied=None, skip=None):
+    """M3.  q: x, y, level, angle, desc; skip[i]: 0 query, 1 no map point, 2 bad, 3 in sAlreadyFound."""
+    m = np.full(len(F.kps), -1, np.int32)
+    occ, sk = _u8(occupied), _u8(skip)
+    arrs = [_f32(q["x"]), _f32(q["y"]), _i32(q["level"]), _f32(q["angle"]), _u8(q["desc"])]
+    n = _ml().matref_search_by_projection_keyframe(*F.head(), _p(occ), len(arrs[0]), *[_p(x) for x in arrs], _p(sk),
+                                                  C.c_float(th), int(orb_dist), int(check_orientation), _p(m))
+    return n, m
+
+
+def ref_search_by_projection_sim3(KF: RefFrame, q, th: int, ratio_hamming, variant=0, occupied=None):
+    m = np.full(len(KF.kps), -1, np.int32)
+    occ = _u8(occupied)
+    arrs = [_f32(q["x"]), _f32(q["y"]), _i32(q["level"]), _u8(q["desc"])]
+    n = _ml().matref_search_by_projection_sim3(*KF.head(), _p(occ), len(arrs[0]), *[_p(x) for x in arrs], int(th),
+                                              C.c_float(ratio_hamming), int(variant), _p(m))
+    return n, m
+
+
+def ref_search_by_bow_frame(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, nnratio, check_orientation):
+    kd, fd, ka, fa, kv = _u8(kf_desc), _u8(f_desc), _f32(kf_angle), _f32(f_angle), _u8(kf_valid)
+    a, b = _fv(kf_fv), _fv(f_fv)
+    fm = np.full(len(fd), -1, np.int32)
+    n = _ml().matref_search_by_bow_frame(_p(kd), _p(ka), _p(kv), len(kd), C.byref(a), _p(fd), _p(fa), len(fd), C.byref(b),
+                                        C.c_float(nnratio), int(check_orientation), _p(fm))
+    return n, fm
+
+
+def ref_search_by_bow_keyframes(d1, a1, v1, fv1, d2, a2, v2, fv2, nnratio, check_orientation):
+    d1, d2, a1, a2, v1, v2 = _u8(d1), _u8(d2), _f32(a1), _f32(a2), _u8(v1), _u8(v2)
+    a, b = _fv(fv1), _fv(fv2)
+    m12 = np.full(len(d1), -1, np.int32)
+    n = _ml().matref_search_by_bow_keyframes(_p(d1), _p(a1), _p(v1), len(d1), C.byref(a), _p(d2), _p(a2), _p(v2), len(d2),
+                                            C.byref(b), C.c_float(nnratio), int(check_orientation), _p(m12))
+    return n, m12
+
+
+def ref_search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_matched, window_size, nnratio, check_orientation):
+    k1, k2 = np.ascontiguousarray(kps1, KP_DTYPE), np.ascontiguousarray(kps2, KP_DTYPE)
+    d1, d2 = _u8(desc1), _u8(desc2)
+    b = _f32(bounds)
+    assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous
+    m12 = np.full(len(k1), -1, np.int32)
+    n = _ml().matref_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(b), _p(prev_matched),
+                                              int(window_size), C.c_float(nnratio), int(check_orientation), _p(m12))
+    return n, m12
+
+
+def ref_search_for_triangulation(d1, a1, s1, fv1, d2, a2, s2, fv2, check_orientation, pair_ok=None, coarse=False):
+    """pair_ok: (n1, n2) uint8 table of epipolarConstrain verdicts or None."""
+    d1, d2, a1, a2, s1, s2 = _u8(d1), _u8(d2), _f32(a1), _f32(a2), _u8(s1), _u8(s2)
+    a, b = _fv(fv1), _fv(fv2)
+    ok = _u8(pair_ok)
+    m12 = np.full(len(d1), -1, np.int32)
+    n = _ml().matref_search_for_triangulation(_p(d1), _p(a1), _p(s1), len(d1), C.byref(a), _p(d2), _p(a2), _p(s2), len(d2),
+                                             C.byref(b), int(check_orientation), _p(ok), int(coarse), _p(m12))
+    return n, m12
+
+
+def ref_fuse(KF: RefFrame, inv_sigma2, q, th, variant=0):
+    """q: u, v, z (camera depth; ur = u - 1/z), level, desc.  Returns (nFused, best_idx with -1 where nothing was fused)."""
+    isg = _f32(inv_sigma2)
+    arrs = [_f32(q["u"]), _f32(q["v"]), _f32(q["z"]), _i32(q["level"]), _u8(q["desc"])]
+    bi = np.full(len(arrs[0]), -1, np.int32)
+    kp, de, n, bo, sf, nl = KF.head()
+    r = _ml().matref_fuse(kp, de, n, bo, sf, _p(isg), nl, _p(KF.u_right), len(arrs[0]), *[_p(x) for x in arrs], C.c_float(th),
+                          int(variant), _p(bi))
+    return r, bi
+
+
+def ref_search_by_sim3(K1: RefFrame, K2: RefFrame, side1, side2, th):
+    """side: dict(valid, x, y, level, desc) per key frame feature (its map point projected into the OTHER key frame)."""
+    m12 = np.full(len(K1.kps), -1, np.int32)
+    s1 = [_u8(side1["valid"]), _f32(side1["x"]), _f32(side1["y"]), _i32(side1["level"]), _u8(side1["desc"])]
+    s2 = [_u8(side2["valid"]), _f32(side2["x"]), _f32(side2["y"]), _i32(side2["level"]), _u8(side2["desc"])]
+    n = _ml().matref_search_by_sim3(_p(K1.kps), _p(K1.desc), len(K1.kps), _p(K2.kps), _p(K2.desc), len(K2.kps), _p(K1.bounds),
+                                   _p(K1.sf), len(K1.sf), *[_p(x) for x in s1], *[_p(x) for x in s2], C.c_float(th), _p(m12))
+    return n, m12

@@ -1,0 +1,424 @@
+/* TEST INFRASTRUCTURE ONLY.  C entry points over the reference's own ORBmatcher (src/ORBmatcher.cc compiled where it lies
+ * against oracle/mock_slam + oracle/ocv_shim; see oracle/Makefile, _ref/libmatcher_ref.so).  Each function takes the same
+ * flattened arrays the oracle's orbo_* matcher takes, rebuilds the stand-in Frame / KeyFrame / MapPoint objects from them,
+ * runs the reference's member function and flattens its result back, so tests/test_oracle_vs_reference.py can compare the
+ * two on identical inputs.  Geometry is driven exactly: poses are identity (plus a z translation where the function reads
+ * the camera motion), the camera's project() is (x, y), so a map point at world (u, v, z) lands on pixel (u, v). */
+#include <cstring>
+#include <memory>
+#include <vector>
+#include "ORBmatcher.h"
+
+using namespace ORB_SLAM3;
+
+namespace {
+
+struct Bounds { float minx, maxx, miny, maxy; };
+
+void fill(FeatureHolder &h, const orbo_keypoint *kps, int n, const uint8_t *desc, const Bounds &b, const float *scale,
+          const float *sigma2, const float *inv_sigma2, int nlevels, const float *u_right, GeometricCamera *cam) {
+    h.N = n;
+    h.kps_un.assign(kps, kps + n);
+    h.mvKeysUn.resize(n);
+    for (int i = 0; i < n; i++) {
+        cv::KeyPoint k(kps[i].x, kps[i].y, kps[i].size, kps[i].angle, kps[i].response, kps[i].octave, i);
+        h.mvKeysUn[i] = k;
+    }
+    h.mvKeys = h.mvKeysUn;
+    h.mDescriptors = cv::Mat(n > 0 ? n : 1, 32, CV_8UC1);
+    if (n) std::memcpy(h.mDescriptors.data, desc, (size_t)n * 32);
+    h.mvuRight.assign(n, -1.f);
+    if (u_right) h.mvuRight.assign(u_right, u_right + n);
+    h.mvDepth.assign(n, -1.f);
+    h.mvScaleFactors.assign(scale, scale + nlevels);
+    h.mvLevelSigma2.assign(nlevels, 1.f);
+    h.mvInvLevelSigma2.assign(nlevels, 1.f);
+    if (sigma2) h.mvLevelSigma2.assign(sigma2, sigma2 + nlevels);
+    if (inv_sigma2) h.mvInvLevelSigma2.assign(inv_sigma2, inv_sigma2 + nlevels);
+    h.mnMinX = b.minx; h.mnMaxX = b.maxx; h.mnMinY = b.miny; h.mnMaxY = b.maxy;
+    h.mpCamera = cam;
+    h.grid = orbo_grid_create(h.kps_un.data(), n, b.minx, b.maxx, b.miny, b.maxy);
+}
+
+cv::Mat desc_row(const uint8_t *d) {
+    cv::Mat m(1, 32, CV_8UC1);
+    std::memcpy(m.data, d, 32);
+    return m;
+}
+
+void featvec(DBoW2::FeatureVector &fv, const orbo_featvec *f) {
+    for (int k = 0; k < f->n_nodes; k++)
+        for (int j = f->node_ptr[k]; j < f->node_ptr[k + 1]; j++) fv.addFeature(f->node_id[k], (unsigned)f->index[j]);
+}
+
+/* a map point that only marks "this feature slot is taken" */
+MapPoint *marker(std::vector<std::unique_ptr<MapPoint>> &pool, int nobs = 1, bool bad = false) {
+    pool.emplace_back(new MapPoint());
+    pool.back()->nobs = nobs;
+    pool.back()->bad = bad;
+    pool.back()->id = -2;
+    return pool.back().get();
+}
+
+const float kOnes[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+
+}  // namespace
+
+extern "C" {
+
+int matref_descriptor_distance(const uint8_t *a, const uint8_t *b) {
+    return ORBmatcher::DescriptorDistance(desc_row(a), desc_row(b));
+}
+
+void matref_three_maxima(const int *sizes, int L, int *i1, int *i2, int *i3) {
+    std::vector<std::vector<int>> h(L);
+    for (int i = 0; i < L; i++) h[i].assign(sizes[i], 0);
+    ORBmatcher m(0.6f, true);
+    int a = -1, b = -1, c = -1;
+    m.ComputeThreeMaxima(h.data(), L, a, b, c);
+    *i1 = a; *i2 = b; *i3 = c;
+}
+
+/* M1  ORBmatcher.cc:43-213, mono form */
+int matref_search_by_projection_mappoints(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *bounds,
+                                          const float *scale, int nlevels, const float *u_right,
+                                          const uint8_t *occupied, int n_mp, const float *proj_x, const float *proj_y,
+                                          const float *proj_xr, const int32_t *level, const float *view_cos,
+                                          const uint8_t *mp_desc, const uint8_t *in_view, const uint8_t *has_obs, float th,
+                                          float nnratio, int32_t *frame_match) {
+    GeometricCamera cam;
+    Frame F;
+    fill(F, kps, n, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, nullptr, nlevels, u_right, &cam);
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    F.mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; i++)
+        if (occupied && occupied[i]) F.mvpMapPoints[i] = marker(pool);
+    std::vector<MapPoint> mps(n_mp);
+    std::vector<MapPoint *> vp(n_mp);
+    for (int j = 0; j < n_mp; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.mbTrackInView = in_view[j] != 0;
+        p.mTrackProjX = proj_x[j]; p.mTrackProjY = proj_y[j]; p.mTrackProjXR = proj_xr[j];
+        p.mnTrackScaleLevel = level[j];
+        p.mTrackViewCos = view_cos[j];
+        p.nobs = has_obs[j] ? 1 : 0;
+        p.desc = desc_row(mp_desc + (size_t)j * 32);
+        vp[j] = &p;
+    }
+    ORBmatcher m(nnratio, true);
+    int r = m.SearchByProjection(F, vp, th, false, 50.0f);
+    for (int i = 0; i < n; i++) frame_match[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->id >= 0) ? F.mvpMapPoints[i]->id : -1;
+    return r;
+}
+
+/* M2  ORBmatcher.cc:1676-1885.  q_z = camera-frame depth of the projected point (the reference derives the stereo
+ * coordinate as u - mbf / z with mbf = 1 here).  mode 0 mono, 1 forward, 2 backward. */
+int matref_search_by_projection_frame(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *bounds,
+                                      const float *scale, int nlevels, const float *u_right, const uint8_t *occupied,
+                                      int n_q, const float *q_u, const float *q_v, const float *q_z,
+                                      const int32_t *q_octave, const float *q_angle, const uint8_t *q_desc,
+                                      const uint8_t *q_has_obs, float th, int mode, int check_orientation,
+                                      int32_t *cur_match) {
+    GeometricCamera cam;
+    Frame Cur, Last;
+    fill(Cur, kps, n, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, nullptr, nlevels, u_right, &cam);
+    Cur.mbf = 1.f;
+    Cur.mb = 0.5f;
+    const float tz = mode == 1 ? -1.f : mode == 2 ? 1.f : 0.f; /* camera centre at z = -tz in the last frame */
+    Cur.Tcw.t = Eigen::Vector3f(0.f, 0.f, tz);
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    Cur.mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; i++)
+        if (occupied && occupied[i]) Cur.mvpMapPoints[i] = marker(pool);
+    Last.N = n_q;
+    Last.mvKeys.resize(n_q);
+    Last.mvKeysUn.resize(n_q);
+    Last.mvbOutlier.assign(n_q, false);
+    std::vector<MapPoint> mps(n_q);
+    Last.mvpMapPoints.resize(n_q);
+    for (int j = 0; j < n_q; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.pos = Eigen::Vector3f(q_u[j], q_v[j], q_z[j] - tz);
+        p.nobs = q_has_obs[j] ? 1 : 0;
+        p.desc = desc_row(q_desc + (size_t)j * 32);
+        Last.mvpMapPoints[j] = &p;
+        Last.mvKeys[j].octave = q_octave[j];
+        Last.mvKeys[j].angle = q_angle[j];
+        Last.mvKeysUn[j] = Last.mvKeys[j];
+    }
+    ORBmatcher m(0.9f, check_orientation != 0);
+    int r = m.SearchByProjection(Cur, Last, th, mode == 0);
+    for (int i = 0; i < n; i++) cur_match[i] = (Cur.mvpMapPoints[i] && Cur.mvpMapPoints[i]->id >= 0) ? Cur.mvpMapPoints[i]->id : -1;
+    return r;
+}
+
+/* M3  ORBmatcher.cc:1887-2010 (relocalisation): query i = key frame feature i with its map point */
+int matref_search_by_projection_keyframe(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *bounds,
+                                         const float *scale, int nlevels, const uint8_t *occupied, int n_q,
+                                         const float *q_x, const float *q_y, const int32_t *q_level,
+                                         const float *q_angle, const uint8_t *q_desc, const uint8_t *q_skip, float th,
+                                         int orb_dist, int check_orientation, int32_t *match) {
+    GeometricCamera cam;
+    Frame Cur;
+    KeyFrame KF;
+    fill(Cur, kps, n, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, nullptr, nlevels, nullptr, &cam);
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    Cur.mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; i++)
+        if (occupied && occupied[i]) Cur.mvpMapPoints[i] = marker(pool, 0); /* any non-null pointer blocks the slot */
+    KF.N = n_q;
+    KF.mvKeysUn.resize(n_q);
+    KF.mvpMapPoints.resize(n_q);
+    std::vector<MapPoint> mps(n_q);
+    std::set<MapPoint *> found;
+    for (int j = 0; j < n_q; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.pos = Eigen::Vector3f(q_x[j], q_y[j], 1.f);
+        p.pred_scale = q_level[j];
+        p.desc = desc_row(q_desc + (size_t)j * 32);
+        KF.mvKeysUn[j].angle = q_angle[j];
+        KF.mvpMapPoints[j] = &p;
+        if (q_skip && q_skip[j] == 1) KF.mvpMapPoints[j] = nullptr;
+        if (q_skip && q_skip[j] == 2) p.bad = true;
+        if (q_skip && q_skip[j] == 3) found.insert(&p);
+    }
+    ORBmatcher m(0.9f, check_orientation != 0);
+    int r = m.SearchByProjection(Cur, &KF, found, th, orb_dist);
+    for (int i = 0; i < n; i++) match[i] = (Cur.mvpMapPoints[i] && Cur.mvpMapPoints[i]->id >= 0) ? Cur.mvpMapPoints[i]->id : -1;
+    return r;
+}
+
+/* M4  ORBmatcher.cc:427-535 (variant 0) and :537-646 (variant 1, with the parallel key frame vectors) */
+int matref_search_by_projection_sim3(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *bounds,
+                                     const float *scale, int nlevels, const uint8_t *occupied, int n_q, const float *q_x,
+                                     const float *q_y, const int32_t *q_level, const uint8_t *q_desc, int th,
+                                     float ratio_hamming, int variant, int32_t *match) {
+    GeometricCamera cam;
+    KeyFrame KF, other;
+    fill(KF, kps, n, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, nullptr, nlevels, nullptr, &cam);
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    std::vector<MapPoint *> matched(n, nullptr);
+    std::vector<KeyFrame *> matchedKF(n, nullptr);
+    for (int i = 0; i < n; i++)
+        if (occupied && occupied[i]) matched[i] = marker(pool);
+    std::vector<MapPoint> mps(n_q);
+    std::vector<MapPoint *> vp(n_q);
+    std::vector<KeyFrame *> vkf(n_q, &other);
+    for (int j = 0; j < n_q; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.pos = Eigen::Vector3f(q_x[j], q_y[j], 1.f);
+        p.normal = Eigen::Vector3f(0.f, 0.f, 1.0e30f); /* PO . n >> |PO| / 2 : the viewing-angle gate always passes */
+        p.pred_scale = q_level[j];
+        p.desc = desc_row(q_desc + (size_t)j * 32);
+        vp[j] = &p;
+    }
+    Sophus::Sim3f Scw;
+    ORBmatcher m(0.9f, true);
+    int r = variant == 0 ? m.SearchByProjection(&KF, Scw, vp, matched, th, ratio_hamming)
+                         : m.SearchByProjection(&KF, Scw, vp, vkf, matched, matchedKF, th, ratio_hamming);
+    for (int i = 0; i < n; i++) match[i] = (matched[i] && matched[i]->id >= 0) ? matched[i]->id : -1;
+    return r;
+}
+
+/* M5a  ORBmatcher.cc:223-425 (mono).  kf_valid: 0 = no / bad map point */
+int matref_search_by_bow_frame(const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                               const orbo_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f,
+                               const orbo_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match) {
+    KeyFrame KF;
+    Frame F;
+    KF.N = n_kf; F.N = n_f;
+    KF.mvKeysUn.resize(n_kf); F.mvKeys.resize(n_f);
+    KF.mDescriptors = cv::Mat(n_kf > 0 ? n_kf : 1, 32, CV_8UC1);
+    F.mDescriptors = cv::Mat(n_f > 0 ? n_f : 1, 32, CV_8UC1);
+    std::memcpy(KF.mDescriptors.data, kf_desc, (size_t)n_kf * 32);
+    std::memcpy(F.mDescriptors.data, f_desc, (size_t)n_f * 32);
+    std::vector<MapPoint> mps(n_kf);
+    KF.mvpMapPoints.assign(n_kf, nullptr);
+    for (int i = 0; i < n_kf; i++) {
+        KF.mvKeysUn[i].angle = kf_angle[i];
+        mps[i].id = i;
+        if (kf_valid[i]) KF.mvpMapPoints[i] = &mps[i];
+        else if (i & 1) { mps[i].bad = true; KF.mvpMapPoints[i] = &mps[i]; } /* both "absent" paths of :255-259 */
+    }
+    for (int i = 0; i < n_f; i++) F.mvKeys[i].angle = f_angle[i];
+    F.mvKeysUn = F.mvKeys;
+    featvec(KF.mFeatVec, kf_fv);
+    featvec(F.mFeatVec, f_fv);
+    std::vector<MapPoint *> out;
+    ORBmatcher m(nnratio, check_orientation != 0);
+    int r = m.SearchByBoW(&KF, F, out);
+    for (int i = 0; i < n_f; i++) f_match[i] = out[i] ? out[i]->id : -1;
+    return r;
+}
+
+/* M5b  ORBmatcher.cc:765-905 */
+int matref_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
+                                   const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                   const uint8_t *valid2, int n2, const orbo_featvec *fv2, float nnratio,
+                                   int check_orientation, int32_t *match12) {
+    KeyFrame K1, K2;
+    KeyFrame *K[2] = {&K1, &K2};
+    const uint8_t *D[2] = {desc1, desc2};
+    const float *A[2] = {angle1, angle2};
+    const uint8_t *V[2] = {valid1, valid2};
+    const int N[2] = {n1, n2};
+    std::vector<MapPoint> mps[2];
+    for (int s = 0; s < 2; s++) {
+        KeyFrame &k = *K[s];
+        k.N = N[s];
+        k.mvKeysUn.resize(N[s]);
+        k.mDescriptors = cv::Mat(N[s] > 0 ? N[s] : 1, 32, CV_8UC1);
+        std::memcpy(k.mDescriptors.data, D[s], (size_t)N[s] * 32);
+        mps[s].resize(N[s]);
+        k.mvpMapPoints.assign(N[s], nullptr);
+        for (int i = 0; i < N[s]; i++) {
+            k.mvKeysUn[i].angle = A[s][i];
+            mps[s][i].id = i;
+            if (V[s][i]) k.mvpMapPoints[i] = &mps[s][i];
+            else if (i & 1) { mps[s][i].bad = true; k.mvpMapPoints[i] = &mps[s][i]; }
+        }
+    }
+    featvec(K1.mFeatVec, fv1);
+    featvec(K2.mFeatVec, fv2);
+    std::vector<MapPoint *> out;
+    ORBmatcher m(nnratio, check_orientation != 0);
+    int r = m.SearchByBoW(&K1, &K2, out);
+    for (int i = 0; i < n1; i++) match12[i] = out[i] ? out[i]->id : -1;
+    return r;
+}
+
+/* M6  ORBmatcher.cc:648-763 */
+int matref_search_for_initialization(const orbo_keypoint *kps1, const uint8_t *desc1, int n1, const orbo_keypoint *kps2,
+                                     const uint8_t *desc2, int n2, const float *bounds, float *prev_matched,
+                                     int window_size, float nnratio, int check_orientation, int32_t *matches12) {
+    GeometricCamera cam;
+    Frame F1, F2;
+    const Bounds b{bounds[0], bounds[1], bounds[2], bounds[3]};
+    fill(F1, kps1, n1, desc1, b, kOnes, nullptr, nullptr, 16, nullptr, &cam);
+    fill(F2, kps2, n2, desc2, b, kOnes, nullptr, nullptr, 16, nullptr, &cam);
+    std::vector<cv::Point2f> prev(n1);
+    for (int i = 0; i < n1; i++) prev[i] = cv::Point2f(prev_matched[2 * i], prev_matched[2 * i + 1]);
+    std::vector<int> m12;
+    ORBmatcher m(nnratio, check_orientation != 0);
+    int r = m.SearchForInitialization(F1, F2, prev, m12, window_size);
+    for (int i = 0; i < n1; i++) {
+        matches12[i] = m12[i];
+        prev_matched[2 * i] = prev[i].x;
+        prev_matched[2 * i + 1] = prev[i].y;
+    }
+    return r;
+}
+
+/* M7  ORBmatcher.cc:907-1146, mono key frames.  pair_ok: n1 x n2 verdicts of GeometricCamera::epipolarConstrain (NULL = all
+ * pass).  The epipole is parked far outside the image so the :1026-1033 distance gate never fires; coarse = bCoarse. */
+int matref_search_for_triangulation(const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1,
+                                    const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                    const uint8_t *skip2, int n2, const orbo_featvec *fv2, int check_orientation,
+                                    const uint8_t *pair_ok, int coarse, int32_t *matches12) {
+    GeometricCamera cam;
+    cam.epi_ok = pair_ok;
+    cam.epi_n2 = n2;
+    KeyFrame K1, K2;
+    KeyFrame *K[2] = {&K1, &K2};
+    const uint8_t *D[2] = {desc1, desc2};
+    const float *A[2] = {angle1, angle2};
+    const uint8_t *S[2] = {skip1, skip2};
+    const int N[2] = {n1, n2};
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    for (int s = 0; s < 2; s++) {
+        KeyFrame &k = *K[s];
+        k.N = N[s];
+        k.mvKeysUn.resize(N[s]);
+        k.mDescriptors = cv::Mat(N[s] > 0 ? N[s] : 1, 32, CV_8UC1);
+        std::memcpy(k.mDescriptors.data, D[s], (size_t)N[s] * 32);
+        k.mvpMapPoints.assign(N[s], nullptr);
+        k.mvuRight.assign(N[s], -1.f);
+        k.mvScaleFactors.assign(16, 1.f);
+        k.mvLevelSigma2.assign(16, 1.f);
+        k.mpCamera = &cam;
+        for (int i = 0; i < N[s]; i++) {
+            k.mvKeysUn[i].angle = A[s][i];
+            k.mvKeysUn[i].class_id = i;
+            k.mvKeysUn[i].octave = 0;
+            if (S[s][i]) k.mvpMapPoints[i] = marker(pool);
+        }
+    }
+    K1.Tcw.t = Eigen::Vector3f(-1.0e6f, -1.0e6f, 0.f); /* camera centre, hence the epipole, at (1e6, 1e6) */
+    featvec(K1.mFeatVec, fv1);
+    featvec(K2.mFeatVec, fv2);
+    std::vector<std::pair<size_t, size_t>> pairs;
+    ORBmatcher m(0.6f, check_orientation != 0);
+    int r = m.SearchForTriangulation(&K1, &K2, pairs, false, coarse != 0);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (auto &p : pairs) matches12[p.first] = (int)p.second;
+    return r;
+}
+
+/* Fuse  ORBmatcher.cc:1148-1338 (variant 0; q_z = camera depth, ur = u - 1/z) and :1340-1455 (variant 1, Sim3 form, no
+ * chi2 gate).  Every key frame slot is empty, so each accepted query records AddObservation(pKF, bestIdx): best_idx[i]. */
+int matref_fuse(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *bounds, const float *scale,
+                const float *inv_sigma2, int nlevels, const float *u_right, int n_q, const float *q_u, const float *q_v,
+                const float *q_z, const int32_t *q_level, const uint8_t *q_desc, float th, int variant, int32_t *best_idx) {
+    GeometricCamera cam;
+    KeyFrame KF;
+    fill(KF, kps, n, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, inv_sigma2, nlevels, u_right, &cam);
+    KF.mbf = 1.f;
+    KF.mvpMapPoints.assign(n, nullptr);
+    KF.probe = true;
+    std::vector<MapPoint> mps(n_q);
+    std::vector<MapPoint *> vp(n_q), repl(n_q, nullptr);
+    for (int j = 0; j < n_q; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.pos = Eigen::Vector3f(q_u[j], q_v[j], q_z[j]);
+        p.normal = Eigen::Vector3f(0.f, 0.f, 1.0e30f);
+        p.pred_scale = q_level[j];
+        p.desc = desc_row(q_desc + (size_t)j * 32);
+        vp[j] = &p;
+    }
+    ORBmatcher m(0.6f, true);
+    Sophus::Sim3f Scw;
+    int r = variant == 0 ? m.Fuse(&KF, vp, th, false) : m.Fuse(&KF, Scw, vp, th, repl);
+    for (int j = 0; j < n_q; j++) best_idx[j] = mps[j].added_obs.empty() ? -1 : mps[j].added_obs[0].second;
+    return r;
+}
+
+/* SearchBySim3  ORBmatcher.cc:1457-1674: both key frames at identity, S12 = identity, fx = fy = 1, cx = cy = 0, points at
+ * z = 1: map point i of KF1 projects to (x1[i], y1[i]) in KF2 and vice versa.  valid: 0 none, 1 map point, 2 bad.
+ * match12[i1] = KF2 feature index or -1. */
+int matref_search_by_sim3(const orbo_keypoint *kps1, const uint8_t *desc1, int n1, const orbo_keypoint *kps2,
+                          const uint8_t *desc2, int n2, const float *bounds, const float *scale, int nlevels,
+                          const uint8_t *valid1, const float *x1, const float *y1, const int32_t *lvl1,
+                          const uint8_t *mpdesc1, const uint8_t *valid2, const float *x2, const float *y2,
+                          const int32_t *lvl2, const uint8_t *mpdesc2, float th, int32_t *match12) {
+    GeometricCamera cam;
+    KeyFrame K1, K2;
+    const Bounds b{bounds[0], bounds[1], bounds[2], bounds[3]};
+    fill(K1, kps1, n1, desc1, b, scale, nullptr, nullptr, nlevels, nullptr, &cam);
+    fill(K2, kps2, n2, desc2, b, scale, nullptr, nullptr, nlevels, nullptr, &cam);
+    std::vector<MapPoint> m1(n1), m2(n2);
+    K1.mvpMapPoints.assign(n1, nullptr);
+    K2.mvpMapPoints.assign(n2, nullptr);
+    for (int i = 0; i < n1; i++) {
+        m1[i].id = i; m1[i].pos = Eigen::Vector3f(x1[i], y1[i], 1.f); m1[i].pred_scale = lvl1[i];
+        m1[i].desc = desc_row(mpdesc1 + (size_t)i * 32); m1[i].bad = valid1[i] == 2;
+        if (valid1[i]) K1.mvpMapPoints[i] = &m1[i];
+    }
+    for (int i = 0; i < n2; i++) {
+        m2[i].id = i; m2[i].pos = Eigen::Vector3f(x2[i], y2[i], 1.f); m2[i].pred_scale = lvl2[i];
+        m2[i].desc = desc_row(mpdesc2 + (size_t)i * 32); m2[i].bad = valid2[i] == 2;
+        if (valid2[i]) K2.mvpMapPoints[i] = &m2[i];
+    }
+    std::vector<MapPoint *> out(n1, nullptr);
+    Sophus::Sim3f S12;
+    ORBmatcher m(0.75f, true);
+    int r = m.SearchBySim3(&K1, &K2, out, S12, th);
+    for (int i = 0; i < n1; i++) match12[i] = out[i] ? out[i]->id : -1;
+    return r;
+}
+
+}  // extern "C"

@@ -207,6 +207,28 @@ public:
         if (r < 0) throw std::runtime_error(std::string("orbx_fuse_search: ") + orbx_status_string(r));
     }
 
+    // SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (ORBmatcher.cc:1457-1674): the two projection searches are gate-less fuse searches
+    // (KeyFrame::GetFeaturesInArea, octave gate [l-1,l], first minimum wins, accept bestDist <= TH_HIGH :1569/:1656), followed by the
+    // mutual-agreement pass (:1662-1675).  q1 = KF1's map points transformed by S21 and projected into KF2 (one entry per KF1 feature,
+    // radius = th * pKF2->mvScaleFactors[level]); q2 = the converse.  use1[i] / use2[i] == 0 drops a slot (no / bad map point,
+    // vbAlreadyMatched, failed depth / image / distance gate :1495-1527).  vnMatch12[i1] = KF2 feature index or -1; returns nFound.
+    int SearchBySim3(const FrameView &KF1, const FrameView &KF2, const FuseQueries &q1, const std::vector<uint8_t> &use1,
+                     const FuseQueries &q2, const std::vector<uint8_t> &use2, std::vector<int32_t> &vnMatch12) {
+        std::vector<int32_t> bi1, bd1, bi2, bd2;
+        FuseSearch(KF2, nullptr, q1, bi1, bd1);
+        FuseSearch(KF1, nullptr, q2, bi2, bd2);
+        const int n1 = (int)bi1.size(), n2 = (int)bi2.size();
+        vnMatch12.assign(n1, -1);
+        int nFound = 0;
+        for (int i1 = 0; i1 < n1; i1++) {
+            if (!use1[i1] || bd1[i1] > TH_HIGH || bi1[i1] < 0) continue;
+            const int idx2 = bi1[i1];
+            if (idx2 >= n2 || !use2[idx2] || bd2[idx2] > TH_HIGH) continue;
+            if (bi2[idx2] == i1) { vnMatch12[i1] = idx2; nFound++; }
+        }
+        return nFound;
+    }
+
     // MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403) for a batch of map points: the observations' descriptors of map
     // point p are rows [setPtr[p], setPtr[p+1]) of `descriptors`; bestIdx[p] is the row offset (within the set) the reference keeps.
     void ComputeDistinctiveDescriptors(const std::vector<uint8_t> &descriptors, const std::vector<int32_t> &setPtr, std::vector<int32_t> &bestIdx) {

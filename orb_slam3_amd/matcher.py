@@ -279,3 +279,30 @@ class ORBmatcher:
         check(self._L.orbx_fuse_search(self._h, C.byref(fd), ptr(isg), nq, ptr(a["u"]), ptr(a["v"]), ptr(a["ur"]), ptr(a["r"]),
                                        ptr(a["lv"]), ptr(a["d"]), int(strict_fp), ptr(bi), ptr(bd)), "orbx_fuse_search")
         return bi, bd
+
+    # ---- SearchBySim3 (ORBmatcher.cc:1457-1674): two gate-less fuse searches + mutual agreement ----
+    def SearchBySim3(self, KF1: FrameView, KF2: FrameView, side1: dict, side2: dict, th: float, already_matched1=None,
+                     already_matched2=None, scale_factors1=None, scale_factors2=None):
+        """side1: for every feature of KF1, its map point transformed by S21 and projected into KF2 — dict(valid, u, v, level,
+        desc): valid[i] = the slot holds a good map point that survived the depth / image / distance gates of :1500-1527,
+        (u, v) the projection, level = PredictScale(dist3D, pKF2), desc = pMP->GetDescriptor().  side2: the same for KF2's
+        map points projected into KF1 (:1576-1645).  already_matched1/2 = vbAlreadyMatched1/2 (:1477-1490).  Search radius
+        th * mvScaleFactors[level] of the key frame searched in.  Returns (nFound, match12[n1]) with match12[i1] = KF2 feature
+        index (the reference stores vpMapPoints2[idx2]) or -1; slots the caller had matched already are left at -1."""
+        sf1 = _f32(KF1.scale_factors if scale_factors1 is None else scale_factors1)
+        sf2 = _f32(KF2.scale_factors if scale_factors2 is None else scale_factors2)
+
+        def one_way(side, target: FrameView, sf, done):
+            lv = _i32(side["level"])
+            ok = _u8(side["valid"]) == 1
+            if done is not None:
+                ok &= _u8(done) == 0
+            q = dict(u=side["u"], v=side["v"], ur=np.zeros(len(lv), np.float32), r=(np.float32(th) * sf[lv]).astype(np.float32),
+                     level=lv, desc=side["desc"])
+            bi, bd = self.FuseSearch(target, q, None)
+            return np.where(ok & (bd <= 100), bi, -1)          # bestDist <= TH_HIGH (:1569, :1656)
+        m1 = one_way(side1, KF2, sf2, already_matched1)
+        m2 = one_way(side2, KF1, sf1, already_matched2)
+        back = np.where(m1 >= 0, m2[np.maximum(m1, 0)], -2)
+        match12 = np.where(back == np.arange(len(m1)), m1, -1).astype(np.int32)   # :1662-1675 agreement check
+        return int((match12 >= 0).sum()), match12

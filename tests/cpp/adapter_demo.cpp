@@ -1,5 +1,6 @@
 // Exercises the C++ adapters (orb_slam3_amd/cpp/ORBextractor.h, ORBmatcher.h) exactly as ORB-SLAM3's host code would:
 // reads a binary PGM, extracts ORB features, matches the frame against itself shifted, prints counts and FNV hashes.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -60,6 +61,13 @@ int main(int argc, char **argv) {
     int fself = 0;
     for (size_t i = 0; i < bi.size(); i++) fself += (bd[i] == 0);
     std::printf("fuse zero-distance %d of %zu\n", fself, bi.size());
+    // SearchBySim3 of the frame against itself: every feature's map point projects onto the feature, mutual agreement everywhere
+    std::vector<uint8_t> use(kps.size(), 1);
+    std::vector<int32_t> m12;
+    const int nSim3 = matcher.SearchBySim3(F, F, fq, use, fq, use, m12);
+    int sself = 0;
+    for (size_t i = 0; i < m12.size(); i++) sself += (m12[i] >= 0 && std::equal(desc.begin() + 32 * i, desc.begin() + 32 * (i + 1), desc.begin() + 32 * m12[i]));
+    std::printf("sim3 found %d identical-descriptor %d\n", nSim3, sself);
     // ComputeDistinctiveDescriptors on sets of 5 consecutive descriptors
     std::vector<int32_t> setPtr, best;
     for (size_t i = 0; i + 5 <= kps.size(); i += 5) setPtr.push_back((int32_t)i);

@@ -238,7 +238,9 @@ def test_cpp_adapter_end_to_end(canvas1, tmp_path):
     assert line[3] == f"fuse zero-distance {len(kps)} of {len(kps)}"
     ptr = np.arange(0, len(kps) // 5 * 5 + 1, 5, dtype=np.int32)
     best = ob.distinctive_descriptors(desc, ptr)
-    assert line[4] == f"distinctive sets {len(best)} hash {fnv(best.astype(np.int32).tobytes()):016x}"
+    n_sim3, n_same = int(line[4].split()[2]), int(line[4].split()[4])
+    assert n_same == n_sim3 and n_sim3 > 0.95 * len(kps)   # SearchBySim3 of the frame against itself: mutual zero-distance matches
+    assert line[5] == f"distinctive sets {len(best)} hash {fnv(best.astype(np.int32).tobytes()):016x}"
 
 
 @pytest.mark.parametrize("w,h,nf,scale,nlevels,ini,mn", [

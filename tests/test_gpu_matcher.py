@@ -468,3 +468,34 @@ def test_fuse_search(oracle, canvas1):
         bi, bd = m.FuseSearch(F, q, sig, strict)
         assert np.array_equal(bi, obi) and np.array_equal(bd, obd), (ur is None, sig is None, strict)
         assert (bd <= 50).sum() > 100
+
+
+def test_search_by_sim3(oracle, canvas1):
+    """SearchBySim3 (ORBmatcher.cc:1457-1674) composed over orbx_fuse_search, against the same composition over the oracle (which
+    tests/test_oracle_matchers_vs_reference.py pins to the reference's own SearchBySim3)."""
+    import orb_slam3_amd as osa
+    ex, k0, d0, k1, d1 = _two_frames(canvas1)
+    sf = ex.GetScaleFactors()
+    rng = np.random.default_rng(61)
+    th = 7.5
+
+    def side(k, d, dx, dy):
+        n = len(k)
+        x = (k["x"] + dx + rng.normal(0, 1.0, n)).astype(np.float32)
+        valid = rng.choice([0, 1, 1, 1, 2], n).astype(np.uint8)
+        return dict(valid=valid, u=x, v=(k["y"] + dy).astype(np.float32), level=k["octave"], desc=_noisy_copy(rng, d, 0.03))
+    s0, s1 = side(k0, d0, -2.0, -1.0), side(k1, d1, 2.0, 1.0)
+    done0 = (rng.random(len(k0)) < 0.05).astype(np.uint8)
+
+    def one_way(s, grid, dtab, done):
+        q = dict(u=s["u"], v=s["v"], ur=np.zeros(len(s["u"]), np.float32), r=(np.float32(th) * sf[s["level"]]).astype(np.float32),
+                 level=s["level"], desc=s["desc"])
+        bi, bd = oracle.fuse_search(grid, dtab, None, None, q, fma=True)
+        ok = (s["valid"] == 1) & (bd <= 100)
+        return np.where(ok if done is None else ok & (done == 0), bi, -1)
+    g0, g1 = oracle.OracleGrid(k0, 0.0, 752.0, 0.0, 480.0), oracle.OracleGrid(k1, 0.0, 752.0, 0.0, 480.0)
+    m1, m2 = one_way(s0, g1, d1, done0), one_way(s1, g0, d0, None)
+    want = np.array([m1[i] if (m1[i] >= 0 and m2[m1[i]] == i) else -1 for i in range(len(k0))], np.int32)
+    n, m12 = osa.ORBmatcher(0.75, True).SearchBySim3(_frame_view(k0, d0, sf, 752, 480), _frame_view(k1, d1, sf, 752, 480), s0, s1, th, done0)
+    assert n == (want >= 0).sum() and np.array_equal(m12, want)
+    assert n > 100

@@ -1,0 +1,307 @@
+"""The oracle's matcher restatements against the REFERENCE ITSELF: /root/reference/src/ORBmatcher.cc compiled where it lies
+(oracle/Makefile, _ref/libmatcher_ref.so) against stand-in SLAM types (oracle/mock_slam: Frame / KeyFrame / MapPoint that only
+carry data, a camera whose project() is (x, y), identity poses) and the OpenCV shim.  Every loop that runs on the reference
+side is the reference's own code: candidate scans, best / second-best bookkeeping, ratio and threshold tests, occupancy
+read-after-write, rotation histogram + ComputeThreeMaxima, the BoW merge-walk, vMatchedDistance reassignment, the chi2 gates
+of Fuse with the FMA contraction GCC applies to the reference's build flags.  Frame/KeyFrame::GetFeaturesInArea are the
+one piece still restated (the mock forwards them to the oracle's grid).
+
+Two layers, like test_oracle_vs_reference.py: a live comparison when oracle/_ref/libmatcher_ref.so is present (it needs
+/root/reference at build time; it travels with gpurun), and the committed outputs of that library for the same seeded inputs
+(tests/golden/matchers_ref.npz; regenerate with ORBX_WRITE_GOLDEN=1 python -m pytest tests/test_oracle_matchers_vs_reference.py),
+which need nothing but the oracle."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle_binding as ob
+from oracle import ref_binding as rb
+from orb_slam3_amd import synth
+from orb_slam3_amd.matcher import FeatureVector
+
+W, H = 752, 480
+LIVE = rb.matcher_available()
+GOLD_PATH = Path(__file__).resolve().parent / "golden" / "matchers_ref.npz"
+_gold = dict(np.load(GOLD_PATH)) if GOLD_PATH.exists() else {}
+_fresh = {}
+
+
+def _flat(parts):
+    out = []
+    for x in parts:
+        a = np.atleast_1d(np.asarray(x))
+        out.append(a.view(np.int32).ravel() if a.dtype == np.float32 else a.astype(np.int32).ravel())
+    return np.concatenate(out)
+
+
+def _pin(name, oracle_out, ref_call):
+    """oracle_out must equal the reference's output: computed live when the compiled reference is here, else the committed one."""
+    o = _flat(oracle_out)
+    if LIVE:
+        r = _flat(ref_call())
+        assert np.array_equal(o, r), name
+        _fresh[name] = r
+        if name in _gold and not os.environ.get("ORBX_WRITE_GOLDEN"):
+            assert np.array_equal(_gold[name], r), f"stale golden {name}"
+    else:
+        assert name in _gold, f"no golden for {name} and no compiled reference"
+        assert np.array_equal(o, _gold[name]), name
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_golden():
+    yield
+    if LIVE and os.environ.get("ORBX_WRITE_GOLDEN"):
+        np.savez_compressed(GOLD_PATH, **_fresh)
+
+
+def _noisy_copy(rng, d, p):
+    flip = rng.random((len(d), 256)) < p
+    return d ^ np.packbits(flip, axis=1, bitorder="little")
+
+
+@pytest.fixture(scope="module")
+def frames():
+    """Two EuRoC-shaped frames of one canvas (frame t = canvas shifted by (2t, t)), extracted by the oracle."""
+    canvas = synth.make_canvas(1)
+    out = {}
+    for nf, t0, t1 in ((1000, 0, 1), (5000, 0, 4)):
+        ex = ob.OracleExtractor(nf, 1.2, 8, 20, 7)
+        _, k0, d0 = ex.extract(synth.frame_from_canvas(canvas, t0, W, H, 1000 + t0), lap=(0, 1000))
+        _, k1, d1 = ex.extract(synth.frame_from_canvas(canvas, t1, W, H, 1000 + t1), lap=(0, 1000))
+        out[nf] = (k0, d0, k1, d1, ex.tables())
+    return out
+
+
+def _views(k, d, sf, u_right=None):
+    return ob.OracleGrid(k, 0.0, float(W), 0.0, float(H)), rb.RefFrame(k, d, 0.0, float(W), 0.0, float(H), sf, u_right)
+
+
+def _depths(rng, n):
+    return (rng.integers(8, 320, n) / 8.0).astype(np.float32)   # few mantissa bits: z -+ 1 stays exact
+
+
+def test_descriptor_distance_and_three_maxima():
+    rng = np.random.default_rng(0)
+    z, f = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    pairs = [(rng.integers(0, 256, 32, dtype=np.uint8), rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(300)] + [(z, f), (f, f)]
+    _pin("distance", [ob.descriptor_distance(a, b) for a, b in pairs], lambda: [rb.ref_descriptor_distance(a, b) for a, b in pairs])
+    assert ob.descriptor_distance(z, f) == 256 and ob.descriptor_distance(f, f) == 0
+    hists = [rng.integers(0, 2 + t % 7, 30) for t in range(3000)] + [np.zeros(30, np.int64)]     # many ties and empty bins
+    _pin("three_maxima", [ob.three_maxima(s) for s in hists], lambda: [rb.ref_three_maxima(s) for s in hists])
+
+
+def test_search_by_projection_mappoints(frames):
+    """M1, ORBmatcher.cc:43-213 (mono form): ratio test within a level, stereo window, occupancy read-after-write."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf = tab["scale"]
+    rng = np.random.default_rng(9)
+    n_mp = 3 * len(k0)
+    src = rng.integers(0, len(k0), n_mp)
+    mp = dict(proj_x=k0["x"][src] - 2.0 + rng.normal(0, 2, n_mp).astype(np.float32),
+              proj_y=k0["y"][src] - 1.0 + rng.normal(0, 2, n_mp).astype(np.float32),
+              proj_xr=(k0["x"][src] - 2.0 - rng.uniform(0, 30, n_mp)).astype(np.float32), level=k0["octave"][src],
+              view_cos=rng.uniform(0.99, 1.0, n_mp).astype(np.float32), desc=_noisy_copy(rng, d0[src], 0.04),
+              in_view=(rng.random(n_mp) < 0.95).astype(np.uint8), has_obs=(rng.random(n_mp) < 0.9).astype(np.uint8))
+    occ = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    ur = np.where(rng.random(len(k1)) < 0.6, k1["x"] - rng.uniform(0, 30, len(k1)), -1.0).astype(np.float32)
+    for th, ratio, u_right in ((1.0, 0.8, None), (3.0, 0.8, None), (3.0, 0.6, ur), (15.0, 0.9, ur)):
+        grid, F = _views(k1, d1, sf, u_right)
+        on, ofm = ob.search_by_projection_mappoints(grid, d1, sf, mp, th, ratio, u_right, occ)
+        _pin(f"m1/{th}/{ratio}/{u_right is not None}", (on, ofm), lambda: rb.ref_search_by_projection_mappoints(F, mp, th, ratio, occ))
+        assert on > 100
+
+
+def test_search_by_projection_frame(frames):
+    """M2, ORBmatcher.cc:1676-1885: mono / forward / backward level windows, stereo gate u - bf/z, rotation filter."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf = tab["scale"]
+    rng = np.random.default_rng(5)
+    z = _depths(rng, len(k0))
+    u = (k0["x"] - 2.0).astype(np.float32)
+    q = dict(u=u, v=k0["y"] - 1.0, z=z, ur=(u - np.float32(1.0) / z).astype(np.float32), octave=k0["octave"], angle=k0["angle"],
+             desc=d0, has_obs=(rng.random(len(k0)) < 0.9).astype(np.uint8))
+    inside = (q["u"] >= 0) & (q["u"] <= W) & (q["v"] >= 0) & (q["v"] <= H)
+    q = {k: v[inside] for k, v in q.items()}
+    ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - rng.uniform(0, 20, len(k1)), -1.0).astype(np.float32)
+    for mode, ori, th, u_right in ((0, True, 15.0, None), (1, True, 7.0, None), (2, False, 15.0, None), (0, True, 30.0, None),
+                                   (1, True, 15.0, ur), (2, True, 15.0, ur)):
+        occ = (rng.random(len(k1)) < 0.05).astype(np.uint8)
+        grid, F = _views(k1, d1, sf, u_right)
+        on, ocm = ob.search_by_projection_frame(grid, d1, sf, q, th, mode, ori, u_right, occ)
+        _pin(f"m2/{mode}/{ori}/{th}/{u_right is not None}", (on, ocm), lambda: rb.ref_search_by_projection_frame(F, q, th, mode, ori, occ))
+        assert on > 50
+
+
+def test_search_by_projection_keyframe_and_sim3(frames):
+    """M3, ORBmatcher.cc:1887-2010 (Frame grid, levels [l-1,l+1], ORBdist, rotation filter) and M4, :427-646 both overloads
+    (KeyFrame grid + explicit octave gate [l-1,l], TH_LOW * ratioHamming)."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf = tab["scale"]
+    rng = np.random.default_rng(21)
+    lvl = k0["octave"]
+    x = (k0["x"] - 2.0 + rng.normal(0, 1.0, len(k0))).astype(np.float32)
+    y = (k0["y"] - 1.0).astype(np.float32)
+    inside = (x >= 0) & (x < W) & (y >= 0) & (y < H)
+    x, y, lvl, ang, dq = x[inside], y[inside], lvl[inside], k0["angle"][inside], _noisy_copy(rng, d0[inside], 0.03)
+    occ = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    grid, F = _views(k1, d1, sf)
+    for th, orbdist, ori in ((10.0, 100, True), (3.0, 64, True), (10.0, 100, False)):     # Tracking.cc:3726,3740
+        q = dict(x=x, y=y, r=(np.float32(th) * sf[lvl]).astype(np.float32), min_level=lvl - 1, max_level=lvl + 1, angle=ang, desc=dq)
+        on, om = ob.search_by_projection_window(grid, d1, q, float(orbdist), ori, False, occ)
+        _pin(f"m3/{th}/{orbdist}/{ori}", (on, om),
+             lambda: rb.ref_search_by_projection_keyframe(F, dict(x=x, y=y, level=lvl, angle=ang, desc=dq), th, orbdist, ori, occ))
+        assert on > 100
+    # key frame slots without / with bad / with already-found map points drop out of the query list
+    skip = rng.choice([0, 0, 0, 1, 2, 3], len(x)).astype(np.uint8)
+    keep = np.nonzero(skip == 0)[0]
+    q = dict(x=x[keep], y=y[keep], r=(np.float32(10.0) * sf[lvl[keep]]).astype(np.float32), min_level=lvl[keep] - 1,
+             max_level=lvl[keep] + 1, angle=ang[keep], desc=dq[keep])
+    on, om = ob.search_by_projection_window(grid, d1, q, 100.0, True, False, occ)
+    _pin("m3/skips", (on, np.where(om >= 0, keep[np.maximum(om, 0)], -1)),
+         lambda: rb.ref_search_by_projection_keyframe(F, dict(x=x, y=y, level=lvl, angle=ang, desc=dq), 10.0, 100, True, occ, skip))
+    for th, ratio in ((8, 1.5), (5, 1.0), (3, 1.5)):                                         # LoopClosing.cc:755,777,964
+        q = dict(x=x, y=y, r=(np.float32(th) * sf[lvl]).astype(np.float32), min_level=lvl - 1, max_level=lvl, desc=dq)
+        on, om = ob.search_by_projection_window(grid, d1, q, 50 * ratio, False, True, occ)
+        for variant in (0, 1):
+            _pin(f"m4/{th}/{ratio}/{variant}", (on, om),
+                 lambda: rb.ref_search_by_projection_sim3(F, dict(x=x, y=y, level=lvl, desc=dq), th, ratio, variant, occ))
+        assert on > 100
+
+
+def _bow_nodes(rng, k_a, k_b, n_nodes=100, noise=0.15):
+    def node(k):
+        return (np.floor(k["x"] / 60).astype(np.int64) * 7 + np.floor(k["y"] / 60).astype(np.int64) * 13 + k["octave"] * 31) % n_nodes
+    na, nb = node(k_a), node(k_b)
+    flip = rng.random(len(nb)) < noise
+    nb[flip] = rng.integers(0, n_nodes, flip.sum())
+    return na, nb
+
+
+def test_search_by_bow(frames):
+    """M5, ORBmatcher.cc:223-425 (KeyFrame -> Frame) and :765-905 (KeyFrame -> KeyFrame) over the reference's own
+    DBoW2::FeatureVector (std::map walk with lower_bound)."""
+    k0, d0, k1, d1, _ = frames[1000]
+    rng = np.random.default_rng(31)
+    for n_nodes in (100, 7):
+        na, nb = _bow_nodes(rng, k0, k1, n_nodes)
+        na[na == 3] = 4   # a node present on one side only: exercises the lower_bound skips
+        fva, fvb = FeatureVector.from_node_of_feature(na), FeatureVector.from_node_of_feature(nb)
+        valid0 = (rng.random(len(k0)) < 0.7).astype(np.uint8)
+        valid1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+        for ratio, ori in ((0.7, True), (0.9, True), (0.75, False)):
+            on, om = ob.search_by_bow_frame(d0, k0["angle"], valid0, fva, d1, k1["angle"], fvb, ratio, ori)
+            _pin(f"m5a/{n_nodes}/{ratio}/{ori}", (on, om),
+                 lambda: rb.ref_search_by_bow_frame(d0, k0["angle"], valid0, fva, d1, k1["angle"], fvb, ratio, ori))
+            assert on > 50
+            on, om = ob.search_by_bow_keyframes(d0, k0["angle"], valid0, fva, d1, k1["angle"], valid1, fvb, ratio, ori)
+            _pin(f"m5b/{n_nodes}/{ratio}/{ori}", (on, om),
+                 lambda: rb.ref_search_by_bow_keyframes(d0, k0["angle"], valid0, fva, d1, k1["angle"], valid1, fvb, ratio, ori))
+            assert on > 30
+
+
+def test_search_for_initialization(frames):
+    """M6, ORBmatcher.cc:648-763: level-0 keypoints, 100-px window, vMatchedDistance reassignment, vbPrevMatched update."""
+    k0, d0, k1, d1, tab = frames[5000]
+    bounds = np.array([0.0, W, 0.0, H], np.float32)
+    for ratio, ori, win in ((0.9, True, 100), (0.7, False, 100), (0.9, True, 30)):
+        prev_a = np.ascontiguousarray(np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32))
+        prev_b = prev_a.copy()
+        grid = ob.OracleGrid(k1, 0.0, float(W), 0.0, float(H))
+        on, om = ob.search_for_initialization(k0, d0, grid, d1, prev_a, win, ratio, ori)
+        _pin(f"m6/{ratio}/{ori}/{win}", (on, om, prev_a),
+             lambda: rb.ref_search_for_initialization(k0, d0, k1, d1, bounds, prev_b, win, ratio, ori) + (prev_b,))
+        assert on > 200
+
+
+def test_search_for_triangulation(frames):
+    """M7, ORBmatcher.cc:907-1146: later equal-distance candidate wins (dist > bestDist skips), vbMatched2 is never set in the
+    reference, the epipolar verdict is consulted lazily, rotation filter, bCoarse bypass."""
+    k0, d0, k1, d1, _ = frames[1000]
+    rng = np.random.default_rng(41)
+    na, nb = _bow_nodes(rng, k0, k1, 60)
+    fva, fvb = FeatureVector.from_node_of_feature(na), FeatureVector.from_node_of_feature(nb)
+    s0 = (rng.random(len(k0)) < 0.3).astype(np.uint8)
+    s1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    table = (rng.random((len(k0), len(k1))) < 0.7).astype(np.uint8)
+    d1b = d1.copy()
+    d1b[5] = d1b[9]    # exact duplicates inside KF2
+    for ori, tab, coarse in ((True, table, False), (False, table, False), (True, None, False), (True, table, True)):
+        pred = None if (tab is None or coarse) else (lambda i, j: tab[i, j])
+        on, om = ob.search_for_triangulation(d0, k0["angle"], s0, fva, d1b, k1["angle"], s1, fvb, ori, pred)
+        _pin(f"m7/{ori}/{tab is not None}/{coarse}", (on, om),
+             lambda: rb.ref_search_for_triangulation(d0, k0["angle"], s0, fva, d1b, k1["angle"], s1, fvb, ori, tab, coarse))
+        assert on > 50
+
+
+def _fuse_queries(rng, k0, d0, sf, th):
+    n = len(k0)
+    u = (k0["x"] - 2.0 + rng.normal(0, 1.5, n)).astype(np.float32)
+    v = (k0["y"] - 1.0 + rng.normal(0, 1.5, n)).astype(np.float32)
+    inside = (u >= 0) & (u < W) & (v >= 0) & (v < H)
+    u, v, lvl = u[inside], v[inside], k0["octave"][inside]
+    z = _depths(rng, len(u))
+    return dict(u=u, v=v, z=z, ur=(u - np.float32(1.0) / z).astype(np.float32), r=(np.float32(th) * sf[lvl]).astype(np.float32),
+                level=lvl, desc=_noisy_copy(rng, d0[inside], 0.03))
+
+
+def test_fuse(frames):
+    """Fuse, ORBmatcher.cc:1148-1338 (chi2 gates 5.99 mono / 7.8 stereo on e2 * invSigma2, TH_LOW) and :1340-1455 (Sim3 form)."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf, isg = tab["scale"], tab["inv_sigma2"]
+    rng = np.random.default_rng(51)
+    ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - rng.uniform(0, 3, len(k1)), -1.0).astype(np.float32)
+    for th, u_right in ((3.0, None), (4.0, ur), (2.5, ur)):     # LocalMapping.cc:738/760, LoopClosing.cc:2374
+        q = _fuse_queries(rng, k0, d0, sf, th)
+        grid, KF = _views(k1, d1, sf, u_right)
+        obi, obd = ob.fuse_search(grid, d1, u_right, isg, q, fma=True)
+        want = np.where(obd <= 50, obi, -1)
+        _pin(f"fuse0/{th}/{u_right is not None}", ((want >= 0).sum(), want), lambda: rb.ref_fuse(KF, isg, q, th, 0))
+        assert (want >= 0).sum() > 100
+        obi, obd = ob.fuse_search(grid, d1, None, None, q, fma=True)
+        want = np.where(obd <= 50, obi, -1)
+        _pin(f"fuse1/{th}/{u_right is not None}", ((want >= 0).sum(), want), lambda: rb.ref_fuse(KF, isg, q, th, 1))
+        assert (want >= 0).sum() > 100
+
+
+def test_search_by_sim3(frames):
+    """SearchBySim3, ORBmatcher.cc:1457-1674 = two gate-less fuse searches (best <= TH_HIGH, octave gate [l-1,l]) + mutual
+    agreement, composed here exactly as orb_slam3_amd composes it over orbx_fuse_search."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf = tab["scale"]
+    rng = np.random.default_rng(61)
+    th = 7.5
+    g0, K0 = _views(k0, d0, sf)
+    g1, K1 = _views(k1, d1, sf)
+
+    def side(k, d, dx, dy):
+        n = len(k)
+        x = (k["x"] + dx + rng.normal(0, 1.0, n)).astype(np.float32)
+        y = (k["y"] + dy).astype(np.float32)
+        valid = rng.choice([0, 1, 1, 1, 2], n).astype(np.uint8)
+        valid[(x < 0) | (x >= W) | (y < 0) | (y >= H)] = 0
+        return dict(valid=valid, x=x, y=y, level=k["octave"], desc=_noisy_copy(rng, d, 0.03))
+    s0, s1 = side(k0, d0, -2.0, -1.0), side(k1, d1, 2.0, 1.0)
+
+    def one_way(s, grid, dtab):
+        q = dict(u=s["x"], v=s["y"], ur=np.zeros(len(s["x"]), np.float32), r=(np.float32(th) * sf[s["level"]]).astype(np.float32),
+                 level=s["level"], desc=s["desc"])
+        bi, bd = ob.fuse_search(grid, dtab, None, None, q, fma=True)
+        return np.where((bd <= 100) & (s["valid"] == 1), bi, -1)
+    m1, m2 = one_way(s0, g1, d1), one_way(s1, g0, d0)
+    want = np.array([m1[i] if (m1[i] >= 0 and m2[m1[i]] == i) else -1 for i in range(len(k0))], np.int32)
+    _pin("sim3", ((want >= 0).sum(), want), lambda: rb.ref_search_by_sim3(K0, K1, s0, s1, th))
+    assert (want >= 0).sum() > 100
+
+    # the product's host-side composition (orb_slam3_amd.ORBmatcher.SearchBySim3) with its device search swapped for the oracle's:
+    # the agreement / validity logic above the C ABI must give the same answer (the device search itself is a -m gpu test)
+    from orb_slam3_amd.matcher import ORBmatcher, FrameView
+    host = object.__new__(ORBmatcher)
+    grids = {id(k0): g0, id(k1): g1}
+    host.FuseSearch = lambda KF, q, isg=None, strict_fp=False: ob.fuse_search(grids[id(KF.keypoints_un)], KF.descriptors, None, None, q)
+    fv0, fv1 = FrameView(k0, d0, 0.0, float(W), 0.0, float(H), sf), FrameView(k1, d1, 0.0, float(W), 0.0, float(H), sf)
+    p0, p1 = dict(s0, u=s0["x"], v=s0["y"]), dict(s1, u=s1["x"], v=s1["y"])
+    n, m12 = ORBmatcher.SearchBySim3(host, fv0, fv1, p0, p1, th)
+    assert n == (want >= 0).sum() and np.array_equal(m12, want)
