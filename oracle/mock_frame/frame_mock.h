@@ -1,0 +1,68 @@
+/* TEST INFRASTRUCTURE ONLY.  Class shells for the member functions of the reference's Frame.cc / KeyFrame.cc / MapPoint.cc that
+ * oracle/Makefile excerpts at build time (_ref/libframe_ref.so): just the data members those functions touch, with the
+ * reference's names.  The function BODIES compiled into the library are the reference's own text (see ref_frame_shim.cc);
+ * FRAME_GRID_ROWS / FRAME_GRID_COLS are taken from the reference's include/Frame.h by the same recipe. */
+#pragma once
+#include <climits>
+#include <cmath>
+#include <cstddef>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+#include <algorithm>
+#include <opencv2/opencv.hpp>
+#include "ORBextractor.h" /* the reference's own header (include/ORBextractor.h): mvImagePyramid */
+
+namespace ORB_SLAM3 {
+
+/* defined by the reference's ORBmatcher.cc inside _ref/libmatcher_ref.so */
+class ORBmatcher {
+public:
+    static const int TH_LOW, TH_HIGH, HISTO_LENGTH;
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
+};
+
+class Frame {
+public:
+    int N = 0, Nleft = -1;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
+    std::vector<float> mvuRight, mvDepth;
+    cv::Mat mDescriptors, mDescriptorsRight;
+    std::vector<float> mvScaleFactors, mvInvScaleFactors;
+    float mb = 0, mbf = 0;
+    ORBextractor *mpORBextractorLeft = nullptr, *mpORBextractorRight = nullptr;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+    std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    std::vector<std::size_t> mGridRight[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+
+    void AssignFeaturesToGrid();
+    bool PosInGrid(const cv::KeyPoint &kp, int &posX, int &posY);
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1,
+                                          const int maxLevel = -1, const bool bRight = false) const;
+    void ComputeStereoMatches();
+};
+
+class KeyFrame {
+public:
+    int N = 0, NLeft = -1;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
+    cv::Mat mDescriptors;
+    int mnGridCols = 0, mnGridRows = 0;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    std::vector<std::vector<std::vector<size_t>>> mGrid, mGridRight;
+    bool bad = false;
+    bool isBad() { return bad; }
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const bool bRight = false) const;
+};
+
+class MapPoint {
+public:
+    std::mutex mMutexFeatures;
+    bool mbBad = false;
+    std::map<KeyFrame *, std::tuple<int, int>> mObservations;
+    cv::Mat mDescriptor;
+    void ComputeDistinctiveDescriptors();
+};
+
+}  // namespace ORB_SLAM3

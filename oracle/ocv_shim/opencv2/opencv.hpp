@@ -202,4 +202,15 @@ struct KeyPointsFilter {
     static void retainBest(std::vector<KeyPoint> &, int) { assert(!"KeyPointsFilter::retainBest is outside the shim"); }
 };
 
+// cv::norm(a, b, NORM_L1) on 8-bit windows (Frame::ComputeStereoMatches' SAD): an exact integer sum, returned as double
+enum { NORM_L1 = 2, NORM_HAMMING = 6 };
+inline double norm(const Mat &a, const Mat &b, int normType) {
+    assert(normType == NORM_L1 && a.rows == b.rows && a.cols == b.cols);
+    long s = 0;
+    for (int r = 0; r < a.rows; r++) {
+        const uchar *pa = a.ptr(r), *pb = b.ptr(r);
+        for (int c = 0; c < a.cols; c++) s += pa[c] > pb[c] ? pa[c] - pb[c] : pb[c] - pa[c];
+    }
+    return (double)s;
+}
 }  // namespace cv

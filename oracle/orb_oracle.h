@@ -26,11 +26,16 @@
  *   identical match vectors on seeded inputs for all five SearchByProjection overloads, both SearchByBoW,
  *   SearchForInitialization, SearchForTriangulation, both Fuse and SearchBySim3 (tests/test_oracle_matchers_vs_reference.py,
  *   committed reference outputs tests/golden/matchers_ref.npz).
- *   **parity unpinned**: the arithmetic inside the OpenCV primitives (resize, copyMakeBorder, FAST, GaussianBlur, fastAtan2,
- *   cvRound, BFMatcher), Frame/KeyFrame::GetFeaturesInArea + grid assignment and Frame::ComputeStereoMatches (Frame.cc /
- *   KeyFrame.cc need g2o, Eigen and OpenCV calib3d, absent from the image) -- the reference tree holds no golden vectors or
- *   tests for them; they are pinned only by analytic known answers derived from the cited lines and
- *   an exhaustive check of the restated sinf/cosf against this image's glibc.
+ *   Grid, stereo, distinctive descriptors (orbo_grid_*, orbo_compute_stereo_matches, orbo_distinctive_descriptors): PINNED against
+ *   the reference's own text of Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / ComputeStereoMatches,
+ *   KeyFrame::GetFeaturesInArea and MapPoint::ComputeDistinctiveDescriptors (oracle/_ref/libframe_ref.so: the definitions reach the
+ *   compiler verbatim through a temporary file, inside class shells; tests/test_oracle_frame_vs_reference.py,
+ *   tests/golden/frame_ref.npz) -- float results of ComputeStereoMatches bit for bit.
+ *   **parity unpinned**: the arithmetic inside the OpenCV primitives the reference calls (resize, copyMakeBorder, FAST,
+ *   GaussianBlur, fastAtan2, cvRound, BFMatcher::knnMatch).  OpenCV is an external dependency absent from /root/reference and
+ *   from the image; the reference tree holds no golden vectors or tests for them; they are restated
+ *   from the published algorithms and pinned only by analytic known answers and an exhaustive check of the restated
+ *   sinf/cosf against this image's glibc.
  */
 #ifndef ORB_ORACLE_H
 #define ORB_ORACLE_H

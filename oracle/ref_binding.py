@@ -308,3 +308,82 @@ def ref_search_by_sim3(K1: RefFrame, K2: RefFrame, side1, side2, th):
     n = _ml().matref_search_by_sim3(_p(K1.kps), _p(K1.desc), len(K1.kps), _p(K2.kps), _p(K2.desc), len(K2.kps), _p(K1.bounds),
                                    _p(K1.sf), len(K1.sf), *[_p(x) for x in s1], *[_p(x) for x in s2], C.c_float(th), _p(m12))
     return n, m12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# oracle/_ref/libframe_ref.so: Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / ComputeStereoMatches,
+# KeyFrame::GetFeaturesInArea and MapPoint::ComputeDistinctiveDescriptors compiled from the reference's own text
+# ---------------------------------------------------------------------------------------------------------------------
+_frame = None
+
+
+def frame_available() -> bool:
+    return (_DIR / "libframe_ref.so").exists() and matcher_available()
+
+
+def _fl():
+    global _frame
+    if _frame is None:
+        C.CDLL(str(_DIR.parent / "liborb_oracle.so"), mode=C.RTLD_GLOBAL)
+        C.CDLL(str(_DIR / "libmatcher_ref.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(str(_DIR / "libframe_ref.so"))
+        L.frameref_grid_create.restype = C.c_void_p
+        L.frameref_grid_create.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4
+        L.frameref_grid_destroy.argtypes = [C.c_void_p]
+        L.frameref_grid_query.restype = C.c_int
+        L.frameref_grid_query.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.frameref_compute_stereo_matches.restype = C.c_int
+        L.frameref_distinctive_descriptor.restype = C.c_int
+        _frame = L
+    return _frame
+
+
+class RefGrid:
+    """Frame (and the KeyFrame copy of its) 64x48 feature grid, built and queried by the reference's own functions."""
+
+    def __init__(self, kps_un, minx, maxx, miny, maxy):
+        self.kps = np.ascontiguousarray(kps_un, KP_DTYPE)
+        self.b = (float(minx), float(maxx), float(miny), float(maxy))
+        self.L = _fl()
+        self.h = self.L.frameref_grid_create(self.kps.ctypes.data, len(self.kps), *self.b)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.frameref_grid_destroy(self.h)
+            self.h = None
+
+    def query(self, x, y, r, min_level=-1, max_level=-1, keyframe=False):
+        out = np.zeros(len(self.kps) + 1, np.int32)
+        n = self.L.frameref_grid_query(self.h, int(keyframe), *self.b, x, y, r, min_level, max_level, out.ctypes.data, len(out))
+        return out[:n].copy()
+
+
+def ref_grid_dims():
+    c, r = C.c_int(), C.c_int()
+    _fl().frameref_grid_dims(C.byref(c), C.byref(r))
+    return c.value, r.value
+
+
+def ref_compute_stereo_matches(kl, dl, kr, dr, scale, inv_scale, pyr_l, pyr_r, bf, b):
+    kl, kr = np.ascontiguousarray(kl, KP_DTYPE), np.ascontiguousarray(kr, KP_DTYPE)
+    dl, dr = _u8(dl), _u8(dr)
+    nl = len(pyr_l)
+    pl = (C.c_void_p * nl)(*[p.ctypes.data for p in pyr_l])
+    pr = (C.c_void_p * nl)(*[p.ctypes.data for p in pyr_r])
+    pw = np.array([p.shape[1] for p in pyr_l], np.int32)
+    ph = np.array([p.shape[0] for p in pyr_l], np.int32)
+    ps = np.array([p.strides[0] for p in pyr_l], np.uint64)
+    ur, depth = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32)
+    sc, isc = _f32(scale), _f32(inv_scale)
+    n = _fl().frameref_compute_stereo_matches(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(sc), _p(isc), nl,
+                                             C.cast(pl, C.c_void_p), C.cast(pr, C.c_void_p), _p(pw), _p(ph), _p(ps),
+                                             C.c_float(bf), C.c_float(b), _p(ur), _p(depth))
+    return n, ur, depth
+
+
+def ref_distinctive_descriptor(desc):
+    """The descriptor MapPoint::ComputeDistinctiveDescriptors keeps for one observation set, or None for an empty set."""
+    d = _u8(desc)
+    out = np.zeros(32, np.uint8)
+    r = _fl().frameref_distinctive_descriptor(_p(d), len(d), _p(out))
+    return None if r < 0 else out

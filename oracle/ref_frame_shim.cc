@@ -1,0 +1,131 @@
+/* TEST INFRASTRUCTURE ONLY.  oracle/_ref/libframe_ref.so: member functions of the reference's Frame.cc, KeyFrame.cc and MapPoint.cc
+ * that the hot path's restatements follow -- Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / ComputeStereoMatches,
+ * KeyFrame::GetFeaturesInArea, MapPoint::ComputeDistinctiveDescriptors -- compiled from the reference's own text.  Those files cannot
+ * be compiled whole in this image (g2o, Eigen, OpenCV calib3d ...), so oracle/Makefile writes the six function definitions, verbatim
+ * and untouched, into a temporary ref_excerpt.inc (ref_excerpt.awk; deleted after the build, never in the repo) which is included
+ * below inside class shells that declare only the members they touch (mock_frame/frame_mock.h).  ORBextractor (for mvImagePyramid)
+ * is the reference's own class; ORBmatcher::DescriptorDistance / TH_* come from the reference's ORBmatcher.cc in libmatcher_ref.so. */
+#include <cstring>
+#include <memory>
+#include "ref_excerpt_defs.inc" /* the two FRAME_GRID_* #define lines of the reference's include/Frame.h */
+#include "frame_mock.h"
+#include "../orb_oracle.h"
+
+using namespace std;
+
+namespace ORB_SLAM3 {
+float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
+#include "ref_excerpt.inc"
+}  // namespace ORB_SLAM3
+
+using namespace ORB_SLAM3;
+
+namespace {
+void keys(std::vector<cv::KeyPoint> &dst, const orbo_keypoint *k, int n) {
+    dst.resize(n);
+    for (int i = 0; i < n; i++) dst[i] = cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id);
+}
+cv::Mat rows32(const uint8_t *d, int n) {
+    cv::Mat m(n > 0 ? n : 1, 32, CV_8UC1);
+    if (n) std::memcpy(m.data, d, (size_t)n * 32);
+    return m;
+}
+void set_bounds(float minx, float maxx, float miny, float maxy) { /* Frame.cc:340-343 (first-frame initialisation) */
+    Frame::mnMinX = minx; Frame::mnMaxX = maxx; Frame::mnMinY = miny; Frame::mnMaxY = maxy;
+    Frame::mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(maxx - minx);
+    Frame::mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(maxy - miny);
+}
+struct GridHandle {
+    Frame F;
+    KeyFrame KF;
+};
+}  // namespace
+
+extern "C" {
+
+int frameref_grid_dims(int *cols, int *rows) { *cols = FRAME_GRID_COLS; *rows = FRAME_GRID_ROWS; return 0; }
+
+/* Frame with mono keypoints, grid assigned by the reference's AssignFeaturesToGrid; the KeyFrame copy holds the same grid the
+ * way KeyFrame's constructor copies it (KeyFrame.cc:60-78: mGrid[i][j] = F.mGrid[i][j]) */
+void *frameref_grid_create(const orbo_keypoint *kps_un, int n, float minx, float maxx, float miny, float maxy) {
+    GridHandle *h = new GridHandle();
+    set_bounds(minx, maxx, miny, maxy);
+    h->F.N = n;
+    keys(h->F.mvKeysUn, kps_un, n);
+    h->F.mvKeys = h->F.mvKeysUn;
+    h->F.AssignFeaturesToGrid();
+    KeyFrame &K = h->KF;
+    K.N = n; K.mvKeysUn = h->F.mvKeysUn; K.mvKeys = K.mvKeysUn;
+    K.mnGridCols = FRAME_GRID_COLS; K.mnGridRows = FRAME_GRID_ROWS;
+    K.mnMinX = minx; K.mnMaxX = maxx; K.mnMinY = miny; K.mnMaxY = maxy;
+    K.mfGridElementWidthInv = Frame::mfGridElementWidthInv; K.mfGridElementHeightInv = Frame::mfGridElementHeightInv;
+    K.mGrid.resize(K.mnGridCols);
+    for (int i = 0; i < K.mnGridCols; i++) {
+        K.mGrid[i].resize(K.mnGridRows);
+        for (int j = 0; j < K.mnGridRows; j++) K.mGrid[i][j] = h->F.mGrid[i][j];
+    }
+    return h;
+}
+void frameref_grid_destroy(void *h) { delete (GridHandle *)h; }
+
+/* which = 0: Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel); 1: KeyFrame::GetFeaturesInArea(x, y, r) */
+int frameref_grid_query(void *hv, int which, float minx, float maxx, float miny, float maxy, float x, float y, float r,
+                        int min_level, int max_level, int32_t *out, int cap) {
+    GridHandle *h = (GridHandle *)hv;
+    set_bounds(minx, maxx, miny, maxy); /* the Frame statics are process-wide: re-assert this handle's */
+    std::vector<size_t> v = which == 0 ? h->F.GetFeaturesInArea(x, y, r, min_level, max_level) : h->KF.GetFeaturesInArea(x, y, r);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
+    return (int)v.size();
+}
+
+/* Frame::ComputeStereoMatches on flattened inputs; pyramids: per level the ROI origin, size and stride */
+int frameref_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int nl, const orbo_keypoint *kr, const uint8_t *dr,
+                                    int nr, const float *scale, const float *inv_scale, int nlevels,
+                                    const uint8_t *const *pyr_left, const uint8_t *const *pyr_right, const int *pyr_w,
+                                    const int *pyr_h, const size_t *pyr_stride, float bf, float b, float *u_right, float *depth) {
+    ORBextractor exL(100, 1.2f, nlevels, 20, 7), exR(100, 1.2f, nlevels, 20, 7);
+    for (int l = 0; l < nlevels; l++) {
+        const uint8_t *src[2] = {pyr_left[l], pyr_right[l]};
+        ORBextractor *ex[2] = {&exL, &exR};
+        for (int s = 0; s < 2; s++) {
+            cv::Mat m(pyr_h[l], pyr_w[l], CV_8UC1);
+            for (int y = 0; y < pyr_h[l]; y++) std::memcpy(m.ptr(y), src[s] + (size_t)y * pyr_stride[l], pyr_w[l]);
+            ex[s]->mvImagePyramid[l] = m;
+        }
+    }
+    Frame F;
+    F.N = nl;
+    keys(F.mvKeys, kl, nl);
+    keys(F.mvKeysRight, kr, nr);
+    F.mDescriptors = rows32(dl, nl);
+    F.mDescriptorsRight = rows32(dr, nr);
+    F.mvScaleFactors.assign(scale, scale + nlevels);
+    F.mvInvScaleFactors.assign(inv_scale, inv_scale + nlevels);
+    F.mbf = bf; F.mb = b;
+    F.mpORBextractorLeft = &exL; F.mpORBextractorRight = &exR;
+    F.ComputeStereoMatches();
+    int n = 0;
+    for (int i = 0; i < nl; i++) {
+        u_right[i] = F.mvuRight[i];
+        depth[i] = F.mvDepth[i];
+        n += F.mvDepth[i] > 0;
+    }
+    return n;
+}
+
+/* MapPoint::ComputeDistinctiveDescriptors for one observation set (descriptors in observation order); writes the chosen
+ * descriptor, returns 0, or -1 when the reference returns early (empty set) */
+int frameref_distinctive_descriptor(const uint8_t *desc, int n, uint8_t *out32) {
+    std::vector<KeyFrame> kfs(n); /* contiguous: std::map<KeyFrame*> iterates in index order */
+    MapPoint mp;
+    for (int i = 0; i < n; i++) {
+        kfs[i].mDescriptors = rows32(desc + (size_t)i * 32, 1);
+        mp.mObservations[&kfs[i]] = std::tuple<int, int>(0, -1);
+    }
+    mp.ComputeDistinctiveDescriptors();
+    if (mp.mDescriptor.empty()) return -1;
+    std::memcpy(out32, mp.mDescriptor.data, 32);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+"""The oracle's restatements of Frame.cc / KeyFrame.cc / MapPoint.cc members against the REFERENCE'S OWN TEXT of those members:
+Frame::AssignFeaturesToGrid + PosInGrid + GetFeaturesInArea, KeyFrame::GetFeaturesInArea, Frame::ComputeStereoMatches (M8) and
+MapPoint::ComputeDistinctiveDescriptors, compiled into oracle/_ref/libframe_ref.so (oracle/Makefile: the six definitions reach the
+compiler verbatim through a temporary file, inside class shells that declare only the members they touch; ORBextractor and
+ORBmatcher::DescriptorDistance are the reference's own too).  Live when that library is here, else against its committed outputs
+(tests/golden/frame_ref.npz)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_binding as ob
+from oracle import ref_binding as rb
+from orb_slam3_amd import synth
+from _pin import Pinner
+
+_P = Pinner("frame_ref.npz", rb.frame_available())
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_golden():
+    yield
+    _P.finish()
+
+
+def test_feature_grid_assign_and_query():
+    """Frame.cc:385-416, 657-735 and KeyFrame.cc:704-748: cell assignment (incl. keypoints undistorted out of the image), cell
+    ranges, level filter, result order."""
+    rng = np.random.default_rng(0)
+    if rb.frame_available():
+        assert rb.ref_grid_dims() == (64, 48)
+    for case, (minx, maxx, miny, maxy) in enumerate(((0.0, 752.0, 0.0, 480.0), (-10.5, 760.25, -5.0, 485.0), (3.0, 1238.0, 2.0, 374.0))):
+        n = 1500
+        k = np.zeros(n, ob.KP_DTYPE)
+        k["x"] = rng.uniform(minx - 12, maxx + 12, n)
+        k["y"] = rng.uniform(miny - 12, maxy + 12, n)
+        k["octave"] = rng.integers(0, 8, n)
+        og = ob.OracleGrid(k, minx, maxx, miny, maxy)
+        rg = rb.RefGrid(k, minx, maxx, miny, maxy) if rb.frame_available() else None
+        qs = [(rng.uniform(minx - 60, maxx + 60), rng.uniform(miny - 60, maxy + 60), float(rng.choice([1.0, 5.0, 15.0, 40.0, 100.0, 700.0])),
+               int(rng.choice([-1, 0, 1, 3])), int(rng.choice([-1, 0, 2, 7]))) for _ in range(1500)]
+        qs += [(float(k["x"][i]), float(k["y"][i]), 2.5, -1, -1) for i in range(50)]     # |dx| < r is strict: the point itself, r tiny
+        o_frame = [np.concatenate([[-7], og.query(x, y, r, lo, hi)]) for x, y, r, lo, hi in qs]
+        o_kf = [np.concatenate([[-7], og.query(x, y, r)]) for x, y, r, lo, hi in qs]
+        _P.pin(f"grid/frame/{case}", o_frame, lambda: [np.concatenate([[-7], rg.query(x, y, r, lo, hi)]) for x, y, r, lo, hi in qs])
+        _P.pin(f"grid/keyframe/{case}", o_kf, lambda: [np.concatenate([[-7], rg.query(x, y, r, keyframe=True)]) for x, y, r, lo, hi in qs])
+        assert sum(len(a) for a in o_frame) > 5 * len(qs)
+
+
+@pytest.mark.parametrize("w,h,nf,seed", [(752, 480, 1000, 3), (1241, 376, 2000, 4)])
+def test_compute_stereo_matches(w, h, nf, seed):
+    """M8, Frame.cc:811-981: row table, disparity window, descriptor scan, 11x11 SAD slide, parabola fit, median cut -- float
+    results (mvuRight, mvDepth) bit for bit."""
+    canvas = synth.make_canvas(seed)
+    left, right = synth.make_stereo_pair(seed, 0, w, h, canvas)
+    exl, exr = ob.OracleExtractor(nf, 1.2, 8, 20, 7), ob.OracleExtractor(nf, 1.2, 8, 20, 7)
+    _, kl, dl = exl.extract(left)
+    _, kr, dr = exr.extract(right)
+    tab = exl.tables()
+    pyl = [np.ascontiguousarray(exl.level_padded(l)[19:-19, 19:-19]) for l in range(8)]
+    pyr = [np.ascontiguousarray(exr.level_padded(l)[19:-19, 19:-19]) for l in range(8)]
+    bf, b = 0.53716 * 718.856, 0.53716
+    on, our, od, _, _ = ob.compute_stereo_matches(kl, dl, kr, dr, tab["scale"], tab["inv_scale"], pyl, pyr, bf, b)
+    _P.pin(f"stereo/{w}x{h}", (on, our, od),
+           lambda: rb.ref_compute_stereo_matches(kl, dl, kr, dr, tab["scale"], tab["inv_scale"], pyl, pyr, bf, b))
+    assert on > 300
+
+
+def test_distinctive_descriptors():
+    """MapPoint.cc:329-403: distance matrix, per-row median at index 0.5*(N-1), first minimum wins."""
+    rng = np.random.default_rng(7)
+    sets = []
+    for n in (1, 2, 3, 4, 5, 8, 13, 30):
+        for t in range(60):
+            base = rng.integers(0, 256, 32, dtype=np.uint8)
+            d = np.stack([base ^ np.packbits(rng.random(256) < 0.1, bitorder="little") for _ in range(n)])
+            if n > 2 and t % 3 == 0:
+                d[1] = d[0]      # tied medians
+            sets.append(d)
+    ptr = np.concatenate([[0], np.cumsum([len(s) for s in sets])]).astype(np.int32)
+    best = ob.distinctive_descriptors(np.concatenate(sets), ptr)
+    chosen = [s[b] for s, b in zip(sets, best)]
+    _P.pin("distinctive", chosen, lambda: [rb.ref_distinctive_descriptor(s) for s in sets])

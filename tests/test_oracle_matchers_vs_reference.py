@@ -10,9 +10,6 @@ Two layers, like test_oracle_vs_reference.py: a live comparison when oracle/_ref
 /root/reference at build time; it travels with gpurun), and the committed outputs of that library for the same seeded inputs
 (tests/golden/matchers_ref.npz; regenerate with ORBX_WRITE_GOLDEN=1 python -m pytest tests/test_oracle_matchers_vs_reference.py),
 which need nothing but the oracle."""
-import os
-from pathlib import Path
-
 import numpy as np
 import pytest
 
@@ -20,41 +17,17 @@ from oracle import oracle_binding as ob
 from oracle import ref_binding as rb
 from orb_slam3_amd import synth
 from orb_slam3_amd.matcher import FeatureVector
+from _pin import Pinner
 
 W, H = 752, 480
-LIVE = rb.matcher_available()
-GOLD_PATH = Path(__file__).resolve().parent / "golden" / "matchers_ref.npz"
-_gold = dict(np.load(GOLD_PATH)) if GOLD_PATH.exists() else {}
-_fresh = {}
-
-
-def _flat(parts):
-    out = []
-    for x in parts:
-        a = np.atleast_1d(np.asarray(x))
-        out.append(a.view(np.int32).ravel() if a.dtype == np.float32 else a.astype(np.int32).ravel())
-    return np.concatenate(out)
-
-
-def _pin(name, oracle_out, ref_call):
-    """oracle_out must equal the reference's output: computed live when the compiled reference is here, else the committed one."""
-    o = _flat(oracle_out)
-    if LIVE:
-        r = _flat(ref_call())
-        assert np.array_equal(o, r), name
-        _fresh[name] = r
-        if name in _gold and not os.environ.get("ORBX_WRITE_GOLDEN"):
-            assert np.array_equal(_gold[name], r), f"stale golden {name}"
-    else:
-        assert name in _gold, f"no golden for {name} and no compiled reference"
-        assert np.array_equal(o, _gold[name]), name
+_P = Pinner("matchers_ref.npz", rb.matcher_available())
+_pin = _P.pin
 
 
 @pytest.fixture(scope="module", autouse=True)
 def _write_golden():
     yield
-    if LIVE and os.environ.get("ORBX_WRITE_GOLDEN"):
-        np.savez_compressed(GOLD_PATH, **_fresh)
+    _P.finish()
 
 
 def _noisy_copy(rng, d, p):
