@@ -284,6 +284,29 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
                                   int n2, const orbx_featvec *fv2, int check_orientation, orbx_pair_predicate pair_ok,
                                   void *user, int32_t *matches12);
 
+/* SearchForTriangulation for PINHOLE key frames with both geometric gates evaluated on the device -- no callback:
+ *  - epipole distance, src/ORBmatcher.cc:1026-1034 (pairs where neither feature is stereo): (ex-x2)^2 + (ey-y2)^2 <
+ *    100 * pKF2->mvScaleFactors[kp2.octave] rejects; (ep_x, ep_y) = pKF2->mpCamera->project(T2w * Cw) (:919-921);
+ *  - Pinhole::epipolarConstrain, src/CameraModels/Pinhole.cpp:107-129, on the caller's F12 = K1^-T [t12]x R12 K2^-1 (row-major;
+ *    the 3x3 algebra stays with the caller's Eigen): dsqr < 3.84 * pKF2->mvLevelSigma2[kp2.octave]; skipped when coarse (bCoarse).
+ * strict_fp = 0 applies the FMA contraction GCC -O3 -march=native gives the reference's text, 1 rounds
+ * every operation separately.  skip1/skip2, feature vectors, check_orientation, matches12 and the return value as in
+ * orbx_search_for_triangulation; rotation uses kps*_un[i].angle (:1086-1094). */
+typedef struct orbx_pinhole_gate {
+    const orbx_keypoint *kps1_un, *kps2_un; /* pKF1/pKF2->mvKeysUn */
+    const float *u_right1, *u_right2;       /* mvuRight, NULL = monocular (all < 0) */
+    const float *scale_factors2;            /* pKF2->mvScaleFactors [nlevels] */
+    const float *level_sigma2_2;            /* pKF2->mvLevelSigma2 [nlevels] */
+    int nlevels;
+    float F12[9];
+    float ep_x, ep_y;
+    int coarse;
+    int strict_fp;
+} orbx_pinhole_gate;
+int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbx_featvec *fv1,
+                                          const uint8_t *desc2, const uint8_t *skip2, int n2, const orbx_featvec *fv2,
+                                          int check_orientation, const orbx_pinhole_gate *gate, int32_t *matches12);
+
 /* Device-resident, batched frame-to-frame matcher used by the throughput path: for every frame f >= 1 of the
  * extractor's last batch, the keypoints of frame f-1 (queries, at their own position shifted by (du, dv)) are
  * matched against frame f exactly as orbx_search_by_projection_frame does with level_mode 0, all features free on

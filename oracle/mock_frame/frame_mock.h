@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <opencv2/opencv.hpp>
 #include "ORBextractor.h" /* the reference's own header (include/ORBextractor.h): mvImagePyramid */
+#include "../mock_slam/mini_eigen.h"
 
 namespace ORB_SLAM3 {
 
@@ -63,6 +64,26 @@ public:
     std::map<KeyFrame *, std::tuple<int, int>> mObservations;
     cv::Mat mDescriptor;
     void ComputeDistinctiveDescriptors();
+};
+
+/* shells for CameraModels/Pinhole.cpp's epipolarConstrain (the body is the reference's; toK_ is Pinhole.cpp:100-104 restated) */
+class GeometricCamera {
+public:
+    std::vector<float> mvParameters; /* fx, fy, cx, cy */
+    virtual ~GeometricCamera() {}
+    virtual Eigen::Matrix3f toK_() = 0;
+};
+class Pinhole : public GeometricCamera {
+public:
+    Eigen::Matrix3f toK_() override {
+        Eigen::Matrix3f K;
+        K(0, 0) = mvParameters[0]; K(0, 1) = 0.f; K(0, 2) = mvParameters[2];
+        K(1, 0) = 0.f; K(1, 1) = mvParameters[1]; K(1, 2) = mvParameters[3];
+        K(2, 0) = 0.f; K(2, 1) = 0.f; K(2, 2) = 1.f;
+        return K;
+    }
+    bool epipolarConstrain(GeometricCamera *pCamera2, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const Eigen::Matrix3f &R12,
+                           const Eigen::Vector3f &t12, const float sigmaLevel, const float unc);
 };
 
 }  // namespace ORB_SLAM3

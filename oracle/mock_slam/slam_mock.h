@@ -21,81 +21,7 @@
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 #include "../orb_oracle.h"
 
-#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
-
-namespace Eigen {
-template <int N>
-struct Vec {
-    float v[N];
-    Vec() { for (int i = 0; i < N; i++) v[i] = 0.f; }
-    Vec(float a, float b) { static_assert(N == 2, ""); v[0] = a; v[1] = b; }
-    Vec(float a, float b, float c) { static_assert(N == 3, ""); v[0] = a; v[1] = b; v[2] = c; }
-    float &operator()(int i) { return v[i]; }
-    float operator()(int i) const { return v[i]; }
-    float &operator[](int i) { return v[i]; }
-    float operator[](int i) const { return v[i]; }
-    Vec operator-(const Vec &o) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] - o.v[i]; return r; }
-    Vec operator+(const Vec &o) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] + o.v[i]; return r; }
-    Vec operator-() const { Vec r; for (int i = 0; i < N; i++) r.v[i] = -v[i]; return r; }
-    Vec operator*(float s) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] * s; return r; }
-    Vec operator/(float s) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] / s; return r; }
-    float dot(const Vec &o) const { float s = 0.f; for (int i = 0; i < N; i++) s += v[i] * o.v[i]; return s; }
-    float squaredNorm() const { return dot(*this); }
-    float norm() const { return std::sqrt(dot(*this)); }
-    const Vec &transpose() const { return *this; }
-};
-template <int N> inline Vec<N> operator*(float s, const Vec<N> &a) { return a * s; }
-typedef Vec<2> Vector2f;
-typedef Vec<3> Vector3f;
-struct Matrix3f {
-    float m[3][3];
-    Matrix3f() { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = (i == j) ? 1.f : 0.f; }
-    static Matrix3f Identity() { return Matrix3f(); }
-    float &operator()(int i, int j) { return m[i][j]; }
-    float operator()(int i, int j) const { return m[i][j]; }
-    Vector3f operator*(const Vector3f &x) const {
-        Vector3f r;
-        for (int i = 0; i < 3; i++) r.v[i] = m[i][0] * x.v[0] + m[i][1] * x.v[1] + m[i][2] * x.v[2];
-        return r;
-    }
-    Matrix3f operator*(const Matrix3f &o) const {
-        Matrix3f r;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) r.m[i][j] = m[i][0] * o.m[0][j] + m[i][1] * o.m[1][j] + m[i][2] * o.m[2][j];
-        return r;
-    }
-    Matrix3f operator*(float s) const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[i][j] * s; return r; }
-    Matrix3f transpose() const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[j][i]; return r; }
-};
-}  // namespace Eigen
-
-namespace Sophus {
-struct SE3f {
-    Eigen::Matrix3f R;
-    Eigen::Vector3f t;
-    SE3f() {}
-    SE3f(const Eigen::Matrix3f &R_, const Eigen::Vector3f &t_) : R(R_), t(t_) {}
-    Eigen::Matrix3f rotationMatrix() const { return R; }
-    Eigen::Vector3f translation() const { return t; }
-    SE3f inverse() const { Eigen::Matrix3f Rt = R.transpose(); return SE3f(Rt, -(Rt * t)); }
-    Eigen::Vector3f operator*(const Eigen::Vector3f &x) const { return R * x + t; }
-    SE3f operator*(const SE3f &o) const { return SE3f(R * o.R, R * o.t + t); }
-};
-template <class T>
-struct Sim3 {
-    float s = 1.f;
-    Eigen::Matrix3f R;
-    Eigen::Vector3f t;
-    Sim3() {}
-    Sim3(float s_, const Eigen::Matrix3f &R_, const Eigen::Vector3f &t_) : s(s_), R(R_), t(t_) {}
-    Eigen::Matrix3f rotationMatrix() const { return R; }
-    Eigen::Vector3f translation() const { return t; }
-    float scale() const { return s; }
-    Sim3 inverse() const { Eigen::Matrix3f Rt = R.transpose(); return Sim3(1.f / s, Rt, -((Rt * t) * (1.f / s))); }
-    Eigen::Vector3f operator*(const Eigen::Vector3f &x) const { return (R * x) * s + t; }
-};
-typedef Sim3<float> Sim3f;
-}  // namespace Sophus
+#include "mini_eigen.h"
 
 namespace ORB_SLAM3 {
 

@@ -457,3 +457,31 @@ def fuse_search(grid: OracleGrid, desc, u_right, inv_sigma2, q, fma=True):
                            _p(a["v"].astype(np.float32)), _p(a["ur"].astype(np.float32)), _p(a["r"].astype(np.float32)),
                            _p(a["level"].astype(np.int32)), _p(a["desc"].astype(np.uint8)), int(fma), _p(bi), _p(bd))
     return bi, bd
+
+
+def epipolar_pinhole(F12, x1, y1, x2, y2, unc, fma=True):
+    """Pinhole::epipolarConstrain on a given F12 for arrays of keypoint pairs -> uint8 verdicts."""
+    F = np.ascontiguousarray(F12, np.float32).ravel()
+    L = lib()
+    L.orbo_epipolar_pinhole.restype = C.c_int
+    f = C.c_float
+    return np.array([L.orbo_epipolar_pinhole(_p(F), f(a), f(b), f(c), f(d), f(u), int(fma)) for a, b, c, d, u in zip(x1, y1, x2, y2, unc)],
+                    np.uint8)
+
+
+def search_for_triangulation_pinhole(k1, d1, s1, ur1, fv1, k2, d2, s2, ur2, fv2, scale2, sigma2_2, F12, ep, coarse, check_orientation,
+                                     fma=True):
+    k1, k2 = np.ascontiguousarray(k1, KP_DTYPE), np.ascontiguousarray(k2, KP_DTYPE)
+    d1, d2 = np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)
+    s1, s2 = np.ascontiguousarray(s1, np.uint8), np.ascontiguousarray(s2, np.uint8)
+    ur1 = None if ur1 is None else np.ascontiguousarray(ur1, np.float32)
+    ur2 = None if ur2 is None else np.ascontiguousarray(ur2, np.float32)
+    sc, sg, F = (np.ascontiguousarray(x, np.float32) for x in (scale2, sigma2_2, np.asarray(F12).ravel()))
+    a, b = _fv(fv1), _fv(fv2)
+    m12 = np.full(len(k1), -1, np.int32)
+    L = lib()
+    L.orbo_search_for_triangulation_pinhole.restype = C.c_int
+    n = L.orbo_search_for_triangulation_pinhole(_p(k1), _p(d1), _p(s1), _p(ur1), len(k1), C.byref(a), _p(k2), _p(d2), _p(s2), _p(ur2),
+                                                len(k2), C.byref(b), _p(sc), _p(sg), _p(F), C.c_float(ep[0]), C.c_float(ep[1]),
+                                                int(coarse), int(check_orientation), int(fma), _p(m12))
+    return n, m12

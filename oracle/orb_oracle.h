@@ -190,6 +190,15 @@ int orbo_search_for_triangulation(const uint8_t *desc1, const float *angle1, con
                                   const uint8_t *skip2, int n2, const orbo_featvec *fv2, int check_orientation,
                                   orbo_pair_predicate pair_ok, void *user, int32_t *matches12);
 
+/* Pinhole::epipolarConstrain (CameraModels/Pinhole.cpp:107-129) on a caller-supplied F12 (row-major); see orb_oracle_match.cc */
+int orbo_epipolar_pinhole(const float *F12, float x1, float y1, float x2, float y2, float unc, int fma_mode);
+/* M7 with the epipole-distance gate (:1026-1034) and the pinhole epipolar gate evaluated inside (no callback) */
+int orbo_search_for_triangulation_pinhole(const orbo_keypoint *kps1, const uint8_t *desc1, const uint8_t *skip1, const float *u_right1,
+                                          int n1, const orbo_featvec *fv1, const orbo_keypoint *kps2, const uint8_t *desc2,
+                                          const uint8_t *skip2, const float *u_right2, int n2, const orbo_featvec *fv2,
+                                          const float *scale_factors2, const float *level_sigma2_2, const float *F12, float ep_x,
+                                          float ep_y, int coarse, int check_orientation, int fma_mode, int32_t *matches12);
+
 /* M8: Frame::ComputeStereoMatches (Frame.cc:811-981).  Fills u_right/depth (N_left), and the raw Hamming stage
  * result best_idx_r / best_dist (-1 / TH_HIGH when none) for kernel-level parity. */
 int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int nl, const orbo_keypoint *kr,

@@ -487,6 +487,77 @@ int orbo_search_for_triangulation(const uint8_t *desc1, const float *angle1, con
     return nmatches;
 }
 
+/* The two geometric gates of M7 for pinhole cameras, as the reference binary evaluates them.
+ * (1) epipole distance, ORBmatcher.cc:1026-1034 (only when neither feature is stereo): distex*distex + distey*distey <
+ *     100 * mvScaleFactors[kp2.octave] rejects.
+ * (2) Pinhole::epipolarConstrain, CameraModels/Pinhole.cpp:107-129, with F12 = K1^-T [t12]x R12 K2^-1 supplied by the caller:
+ *     a = x1 F00 + y1 F10 + F20 (b, c alike), num = a x2 + b y2 + c, den = a a + b b, dsqr = num num / den, pass iff den != 0 and
+ *     (double)dsqr < 3.84 * (double)unc, unc = pKF2->mvLevelSigma2[kp2.octave].
+ * fma_mode = 0: every operation rounds separately (the source as written).  fma_mode = 1: the contraction GCC 11 -O3 with FMA
+ * (-ffp-contract=fast, the reference's build flags) applies to THIS text -- read off the compiled reference
+ * (oracle/_ref/libframe_ref.so) and pinned against it on near-threshold pairs (tests/test_oracle_frame_vs_reference.py).  Which
+ * product of a sum gets fused is the compiler's choice, not the source's, and it is not uniform:
+ *   a = fma(x1, F00, y1*F10) + F20      b = fma(x1, F01, y1*F11) + F21      c = fma(y1, F12, x1*F02) + F22
+ *   num = fma(b, y2, a*x2) + c          den = fma(a, a, b*b)
+ * A build of the reference against real Eigen may fuse differently; callers that need the unfused semantics pass 0. */
+int orbo_epipolar_pinhole(const float *F, float x1, float y1, float x2, float y2, float unc, int fma_mode) {
+    float a, b, c, num, den;
+    if (fma_mode) {
+        a = std::fma(x1, F[0], y1 * F[3]) + F[6];
+        b = std::fma(x1, F[1], y1 * F[4]) + F[7];
+        c = std::fma(y1, F[5], x1 * F[2]) + F[8];
+        num = std::fma(b, y2, a * x2) + c;
+        den = std::fma(a, a, b * b);
+    } else {
+        a = (x1 * F[0] + y1 * F[3]) + F[6];
+        b = (x1 * F[1] + y1 * F[4]) + F[7];
+        c = (x1 * F[2] + y1 * F[5]) + F[8];
+        num = (a * x2 + b * y2) + c;
+        den = a * a + b * b;
+    }
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)unc;
+}
+
+namespace {
+struct PinholeGate {
+    const orbo_keypoint *k1, *k2;
+    const float *ur1, *ur2;           /* mvuRight or NULL (all < 0) */
+    const float *scale2, *sigma2_2;   /* pKF2->mvScaleFactors, pKF2->mvLevelSigma2 */
+    const float *F;
+    float ex, ey;
+    int fma_mode, coarse;
+};
+int pinhole_gate(void *user, int idx1, int idx2) {
+    const PinholeGate &g = *(const PinholeGate *)user;
+    const bool bStereo1 = g.ur1 && g.ur1[idx1] >= 0, bStereo2 = g.ur2 && g.ur2[idx2] >= 0;
+    const orbo_keypoint &kp1 = g.k1[idx1], &kp2 = g.k2[idx2];
+    if (!bStereo1 && !bStereo2) {
+        const float distex = g.ex - kp2.x, distey = g.ey - kp2.y;
+        const float d2 = g.fma_mode ? std::fma(distex, distex, distey * distey) : distex * distex + distey * distey;
+        if (d2 < 100 * g.scale2[kp2.octave]) return 0;
+    }
+    if (g.coarse) return 1;
+    return orbo_epipolar_pinhole(g.F, kp1.x, kp1.y, kp2.x, kp2.y, g.sigma2_2[kp2.octave], g.fma_mode);
+}
+}  // namespace
+
+/* M7 with both gates evaluated here (pinhole key frames): kps*: mvKeysUn, u_right*: mvuRight (NULL = monocular), ep = epipole of
+ * camera 1 in image 2 (:921), F12 row-major, coarse = bCoarse.  Everything else as orbo_search_for_triangulation. */
+int orbo_search_for_triangulation_pinhole(const orbo_keypoint *kps1, const uint8_t *desc1, const uint8_t *skip1, const float *u_right1,
+                                          int n1, const orbo_featvec *fv1, const orbo_keypoint *kps2, const uint8_t *desc2,
+                                          const uint8_t *skip2, const float *u_right2, int n2, const orbo_featvec *fv2,
+                                          const float *scale_factors2, const float *level_sigma2_2, const float *F12, float ep_x,
+                                          float ep_y, int coarse, int check_orientation, int fma_mode, int32_t *matches12) {
+    std::vector<float> a1(n1), a2(n2);
+    for (int i = 0; i < n1; i++) a1[i] = kps1[i].angle;
+    for (int i = 0; i < n2; i++) a2[i] = kps2[i].angle;
+    PinholeGate g{kps1, kps2, u_right1, u_right2, scale_factors2, level_sigma2_2, F12, ep_x, ep_y, fma_mode, coarse};
+    return orbo_search_for_triangulation(desc1, a1.data(), skip1, n1, fv1, desc2, a2.data(), skip2, n2, fv2, check_orientation,
+                                         pinhole_gate, &g, matches12);
+}
+
 /* M8, Frame.cc:811-981 */
 int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int N, const orbo_keypoint *kr,
                                 const uint8_t *dr, int Nr, const float *scale_factors, const float *inv_scale_factors,

@@ -387,3 +387,33 @@ def ref_distinctive_descriptor(desc):
     out = np.zeros(32, np.uint8)
     r = _fl().frameref_distinctive_descriptor(_p(d), len(d), _p(out))
     return None if r < 0 else out
+
+
+def ref_epipolar_pinhole(K1, K2, R12, t12, x1, y1, x2, y2, unc):
+    """The reference's Pinhole::epipolarConstrain for arrays of keypoint pairs.  Returns (verdicts uint8, F12 3x3 float32 as the
+    reference code computed it from K1, K2 (fx, fy, cx, cy), R12, t12 on the stand-in matrix type)."""
+    K1, K2, R, t = _f32(K1), _f32(K2), _f32(np.asarray(R12).ravel()), _f32(t12)
+    x1, y1, x2, y2, unc = (_f32(a) for a in (x1, y1, x2, y2, unc))
+    ok = np.zeros(len(x1), np.uint8)
+    F = np.zeros(9, np.float32)
+    _fl().frameref_epipolar_pinhole(_p(K1), _p(K2), _p(R), _p(t), len(x1), _p(x1), _p(y1), _p(x2), _p(y2), _p(unc), _p(ok), _p(F))
+    return ok, F.reshape(3, 3)
+
+
+def ref_search_for_triangulation_geo(k1, d1, s1, ur1, fv1, k2, d2, s2, ur2, fv2, scale2, ep, check_orientation, pair_ok=None, coarse=False):
+    """M7 with the reference's own epipole-distance gate on real keypoints; pair_ok = table of epipolarConstrain verdicts."""
+    k1, k2 = np.ascontiguousarray(k1, KP_DTYPE), np.ascontiguousarray(k2, KP_DTYPE)
+    d1, d2, s1, s2 = _u8(d1), _u8(d2), _u8(s1), _u8(s2)
+    a1, a2 = _f32(k1["angle"]), _f32(k2["angle"])
+    ur1 = None if ur1 is None else _f32(ur1)
+    ur2 = None if ur2 is None else _f32(ur2)
+    sc = _f32(scale2)
+    a, b = _fv(fv1), _fv(fv2)
+    ok = _u8(pair_ok)
+    m12 = np.full(len(k1), -1, np.int32)
+    L = _ml()
+    L.matref_search_for_triangulation_geo.restype = C.c_int
+    n = L.matref_search_for_triangulation_geo(_p(k1), _p(d1), _p(a1), _p(s1), _p(ur1), len(k1), C.byref(a), _p(k2), _p(d2), _p(a2), _p(s2),
+                                              _p(ur2), len(k2), C.byref(b), _p(sc), len(sc), C.c_float(ep[0]), C.c_float(ep[1]),
+                                              int(check_orientation), _p(ok), int(coarse), _p(m12))
+    return n, m12

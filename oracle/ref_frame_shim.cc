@@ -1,7 +1,7 @@
 /* TEST INFRASTRUCTURE ONLY.  oracle/_ref/libframe_ref.so: member functions of the reference's Frame.cc, KeyFrame.cc and MapPoint.cc
  * that the hot path's restatements follow -- Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / ComputeStereoMatches,
- * KeyFrame::GetFeaturesInArea, MapPoint::ComputeDistinctiveDescriptors -- compiled from the reference's own text.  Those files cannot
- * be compiled whole in this image (g2o, Eigen, OpenCV calib3d ...), so oracle/Makefile writes the six function definitions, verbatim
+ * KeyFrame::GetFeaturesInArea, MapPoint::ComputeDistinctiveDescriptors, Pinhole::epipolarConstrain -- compiled from the reference's own text.  Those files cannot
+ * be compiled whole in this image (g2o, Eigen, OpenCV calib3d ...), so oracle/Makefile writes the seven function definitions, verbatim
  * and untouched, into a temporary ref_excerpt.inc (ref_excerpt.awk; deleted after the build, never in the repo) which is included
  * below inside class shells that declare only the members they touch (mock_frame/frame_mock.h).  ORBextractor (for mvImagePyramid)
  * is the reference's own class; ORBmatcher::DescriptorDistance / TH_* come from the reference's ORBmatcher.cc in libmatcher_ref.so. */
@@ -126,6 +126,25 @@ int frameref_distinctive_descriptor(const uint8_t *desc, int n, uint8_t *out32) 
     if (mp.mDescriptor.empty()) return -1;
     std::memcpy(out32, mp.mDescriptor.data, 32);
     return 0;
+}
+
+/* Pinhole::epipolarConstrain (CameraModels/Pinhole.cpp:107-129) for n keypoint pairs.  K1, K2: fx, fy, cx, cy.  R12 row-major.
+ * F12_out receives the fundamental matrix the reference code used (the stand-in Matrix3f records its last product), so a test can
+ * hand exactly that matrix to the oracle / the device. */
+void frameref_epipolar_pinhole(const float *K1, const float *K2, const float *R12, const float *t12, int n, const float *x1,
+                               const float *y1, const float *x2, const float *y2, const float *unc, uint8_t *ok, float *F12_out) {
+    Pinhole c1, c2;
+    c1.mvParameters.assign(K1, K1 + 4);
+    c2.mvParameters.assign(K2, K2 + 4);
+    Eigen::Matrix3f R;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R(i, j) = R12[3 * i + j];
+    const Eigen::Vector3f t(t12[0], t12[1], t12[2]);
+    for (int i = 0; i < n; i++) {
+        cv::KeyPoint a(x1[i], y1[i], 31.f), b(x2[i], y2[i], 31.f);
+        ok[i] = c1.epipolarConstrain(&c2, a, b, R, t, 1.0f, unc[i]) ? 1 : 0;
+    }
+    const Eigen::Matrix3f &F = Eigen::last_product();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) F12_out[3 * i + j] = F(i, j);
 }
 
 }  // extern "C"

@@ -313,20 +313,26 @@ int matref_search_for_initialization(const orbo_keypoint *kps1, const uint8_t *d
     return r;
 }
 
-/* M7  ORBmatcher.cc:907-1146, mono key frames.  pair_ok: n1 x n2 verdicts of GeometricCamera::epipolarConstrain (NULL = all
- * pass).  The epipole is parked far outside the image so the :1026-1033 distance gate never fires; coarse = bCoarse. */
-int matref_search_for_triangulation(const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1,
-                                    const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
-                                    const uint8_t *skip2, int n2, const orbo_featvec *fv2, int check_orientation,
-                                    const uint8_t *pair_ok, int coarse, int32_t *matches12) {
+/* M7  ORBmatcher.cc:907-1146, pinhole key frames without a second camera.  pair_ok: n1 x n2 verdicts of
+ * GeometricCamera::epipolarConstrain (NULL = all pass), looked up by keypoint identity.  kps1 / kps2 (optional) give the keypoints
+ * their position and octave, u_right* the stereo flags, scale2 = pKF2->mvScaleFactors and (ep_x, ep_y) the epipole, so the
+ * reference's own epipole-distance gate (:1026-1034) runs on real data; without kps the epipole is parked far outside the image
+ * and the gate never fires.  coarse = bCoarse. */
+int matref_search_for_triangulation_geo(const orbo_keypoint *kps1, const uint8_t *desc1, const float *angle1, const uint8_t *skip1,
+                                        const float *u_right1, int n1, const orbo_featvec *fv1, const orbo_keypoint *kps2,
+                                        const uint8_t *desc2, const float *angle2, const uint8_t *skip2, const float *u_right2, int n2,
+                                        const orbo_featvec *fv2, const float *scale2, int nlevels, float ep_x, float ep_y,
+                                        int check_orientation, const uint8_t *pair_ok, int coarse, int32_t *matches12) {
     GeometricCamera cam;
     cam.epi_ok = pair_ok;
     cam.epi_n2 = n2;
     KeyFrame K1, K2;
     KeyFrame *K[2] = {&K1, &K2};
+    const orbo_keypoint *P[2] = {kps1, kps2};
     const uint8_t *D[2] = {desc1, desc2};
     const float *A[2] = {angle1, angle2};
     const uint8_t *S[2] = {skip1, skip2};
+    const float *U[2] = {u_right1, u_right2};
     const int N[2] = {n1, n2};
     std::vector<std::unique_ptr<MapPoint>> pool;
     for (int s = 0; s < 2; s++) {
@@ -337,17 +343,21 @@ int matref_search_for_triangulation(const uint8_t *desc1, const float *angle1, c
         std::memcpy(k.mDescriptors.data, D[s], (size_t)N[s] * 32);
         k.mvpMapPoints.assign(N[s], nullptr);
         k.mvuRight.assign(N[s], -1.f);
+        if (U[s]) k.mvuRight.assign(U[s], U[s] + N[s]);
         k.mvScaleFactors.assign(16, 1.f);
+        if (s == 1 && scale2) k.mvScaleFactors.assign(scale2, scale2 + nlevels);
         k.mvLevelSigma2.assign(16, 1.f);
         k.mpCamera = &cam;
         for (int i = 0; i < N[s]; i++) {
+            if (P[s]) k.mvKeysUn[i] = cv::KeyPoint(P[s][i].x, P[s][i].y, P[s][i].size, P[s][i].angle, P[s][i].response, P[s][i].octave, i);
+            else k.mvKeysUn[i].octave = 0;
             k.mvKeysUn[i].angle = A[s][i];
             k.mvKeysUn[i].class_id = i;
-            k.mvKeysUn[i].octave = 0;
             if (S[s][i]) k.mvpMapPoints[i] = marker(pool);
         }
     }
-    K1.Tcw.t = Eigen::Vector3f(-1.0e6f, -1.0e6f, 0.f); /* camera centre, hence the epipole, at (1e6, 1e6) */
+    /* camera centre of KF1 = -R^T t = (ep_x, ep_y, 0); KF2 at identity and project() = (x, y): the epipole is (ep_x, ep_y) */
+    K1.Tcw.t = kps1 ? Eigen::Vector3f(-ep_x, -ep_y, 0.f) : Eigen::Vector3f(-1.0e6f, -1.0e6f, 0.f);
     featvec(K1.mFeatVec, fv1);
     featvec(K2.mFeatVec, fv2);
     std::vector<std::pair<size_t, size_t>> pairs;
@@ -356,6 +366,14 @@ int matref_search_for_triangulation(const uint8_t *desc1, const float *angle1, c
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     for (auto &p : pairs) matches12[p.first] = (int)p.second;
     return r;
+}
+
+int matref_search_for_triangulation(const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1,
+                                    const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                    const uint8_t *skip2, int n2, const orbo_featvec *fv2, int check_orientation,
+                                    const uint8_t *pair_ok, int coarse, int32_t *matches12) {
+    return matref_search_for_triangulation_geo(nullptr, desc1, angle1, skip1, nullptr, n1, fv1, nullptr, desc2, angle2, skip2, nullptr,
+                                               n2, fv2, nullptr, 0, 0.f, 0.f, check_orientation, pair_ok, coarse, matches12);
 }
 
 /* Fuse  ORBmatcher.cc:1148-1338 (variant 0; q_z = camera depth, ur = u - 1/z) and :1340-1455 (variant 1, Sim3 form, no

@@ -51,6 +51,13 @@ class FrameDesc(C.Structure):
                 ("scale_factors", C.c_void_p), ("nlevels", C.c_int32), ("u_right", C.c_void_p)]
 
 
+class PinholeGate(C.Structure):
+    """orbx_pinhole_gate (include/orbx.h)."""
+    _fields_ = [("kps1_un", C.c_void_p), ("kps2_un", C.c_void_p), ("u_right1", C.c_void_p), ("u_right2", C.c_void_p),
+                ("scale_factors2", C.c_void_p), ("level_sigma2_2", C.c_void_p), ("nlevels", C.c_int), ("F12", C.c_float * 9),
+                ("ep_x", C.c_float), ("ep_y", C.c_float), ("coarse", C.c_int), ("strict_fp", C.c_int)]
+
+
 class FeatVec(C.Structure):
     """DBoW2::FeatureVector flattened: node ids ascending + CSR of feature indices."""
     _fields_ = [("node_id", C.c_void_p), ("node_ptr", C.c_void_p), ("index", C.c_void_p), ("n_nodes", C.c_int32)]
@@ -71,7 +78,7 @@ SYMBOLS = [
     "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
     "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
-    "orbx_search_for_triangulation", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_vocabulary_create",
+    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_vocabulary_create",
     "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors", "orbx_fuse_search",
 ]
 
@@ -142,6 +149,7 @@ def lib() -> C.CDLL:
     L.orbx_search_by_bow_frame.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, i32, fvp, f32, i32, vp]
     L.orbx_search_by_bow_keyframes.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, vp, i32, fvp, f32, i32, vp]
     L.orbx_search_for_triangulation.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, vp, i32, fvp, i32, PAIR_PREDICATE, vp, vp]
+    L.orbx_search_for_triangulation_pinhole.argtypes = [vp, vp, vp, i32, fvp, vp, vp, i32, fvp, i32, C.POINTER(PinholeGate), vp]
     _lib = L
     return L
 

@@ -186,6 +186,22 @@ public:
         return r;
     }
 
+    // The same for pinhole key frames with both gates on the device (no callback): `gate` carries mvKeysUn / mvuRight of both key frames,
+    // pKF2's mvScaleFactors / mvLevelSigma2, the epipole (:919-921) and F12 = K1^-T [t12]x R12 K2^-1 computed by the caller's Eigen as
+    // Pinhole::epipolarConstrain (CameraModels/Pinhole.cpp:107-112) does; bCoarse = gate.coarse.
+    int SearchForTriangulation(const uint8_t *desc1, const uint8_t *skip1, int n1, const FeatVec &fv1, const uint8_t *desc2,
+                               const uint8_t *skip2, int n2, const FeatVec &fv2, const orbx_pinhole_gate &gate,
+                               std::vector<std::pair<size_t, size_t>> &vMatchedPairs) {
+        std::vector<int32_t> m12(n1, -1);
+        orbx_featvec a = fv1.c(), b = fv2.c();
+        const int r = orbx_search_for_triangulation_pinhole(m_, desc1, skip1, n1, &a, desc2, skip2, n2, &b, mbCheckOrientation ? 1 : 0, &gate,
+                                                            m12.data());
+        if (r < 0) throw std::runtime_error(std::string("orbx_search_for_triangulation_pinhole: ") + orbx_status_string(r));
+        vMatchedPairs.clear();
+        for (int i = 0; i < n1; i++) if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);
+        return r;
+    }
+
     // Matching core of Fuse(KeyFrame*, vpMapPoints, th, bRight) (ORBmatcher.cc:1148-1337) and Fuse(KeyFrame*, Sim3f&, vpPoints, th,
     // vpReplacePoint) (:1339-1455).  The caller projects the map points exactly as :1186-1244 / :1376-1403 do (host float math), passes
     // the survivors, and afterwards runs the reference's own tail on (bestIdx[i], bestDist[i] <= TH_LOW): Replace / AddObservation /

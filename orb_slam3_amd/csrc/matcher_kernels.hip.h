@@ -1047,9 +1047,55 @@ __global__ __launch_bounds__(64) void k_replay_init(InitProblem P, GridParams g)
 
 struct FeatVecDev { const uint32_t *node_id; const int32_t *node_ptr; const int32_t *index; int n_nodes; };
 
+// The geometric gates of SearchForTriangulation for pinhole key frames (ORBmatcher.cc:1026-1034 epipole distance,
+// CameraModels/Pinhole.cpp:107-129 epipolarConstrain on a caller-supplied F12).  Both are pure functions of the pair, so the
+// reference's lazy evaluation order does not matter: they filter the candidates of the best-distance scan.
+struct TriGate {
+    int enabled;               // 0: no gate at all (table/callback-free bCoarse form without keypoints)
+    int coarse;                // bCoarse: skip epipolarConstrain (the epipole-distance test still applies)
+    int strict;                // 1: every float op rounds separately; 0: the FMA contraction of the reference's build flags
+    const orbx_keypoint *k1, *k2;
+    const float *ur1, *ur2;    // mvuRight (NULL: monocular)
+    const float *scale2;       // pKF2->mvScaleFactors
+    const float *sigma2_2;     // pKF2->mvLevelSigma2
+    float F[9];                // F12 row-major
+    float ex, ey;              // epipole of camera 1 in image 2 (:921)
+};
+
+__device__ __forceinline__ bool tri_gate(const TriGate &g, int i1, int i2) {
+    const bool st1 = g.ur1 && g.ur1[i1] >= 0.f, st2 = g.ur2 && g.ur2[i2] >= 0.f;
+    const float x2 = g.k2[i2].x, y2 = g.k2[i2].y;
+    const int oct2 = g.k2[i2].octave;
+    if (!st1 && !st2) {
+        const float dx = __fsub_rn(g.ex, x2), dy = __fsub_rn(g.ey, y2);
+        const float d2 = g.strict ? __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) : __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+        if (d2 < __fmul_rn(100.0f, g.scale2[oct2])) return false;
+    }
+    if (g.coarse) return true;
+    const float x1 = g.k1[i1].x, y1 = g.k1[i1].y;
+    float a, b, c, num, den;
+    if (g.strict) {
+        a = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F[0]), __fmul_rn(y1, g.F[3])), g.F[6]);
+        b = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F[1]), __fmul_rn(y1, g.F[4])), g.F[7]);
+        c = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F[2]), __fmul_rn(y1, g.F[5])), g.F[8]);
+        num = __fadd_rn(__fadd_rn(__fmul_rn(a, x2), __fmul_rn(b, y2)), c);
+        den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+    } else {  // which product GCC fuses is not uniform: read off the compiled reference text
+        a = __fadd_rn(__fmaf_rn(x1, g.F[0], __fmul_rn(y1, g.F[3])), g.F[6]);
+        b = __fadd_rn(__fmaf_rn(x1, g.F[1], __fmul_rn(y1, g.F[4])), g.F[7]);
+        c = __fadd_rn(__fmaf_rn(y1, g.F[5], __fmul_rn(x1, g.F[2])), g.F[8]);
+        num = __fadd_rn(__fmaf_rn(b, y2, __fmul_rn(a, x2)), c);
+        den = __fmaf_rn(a, a, __fmul_rn(b, b));
+    }
+    if (den == 0.f) return false;
+    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+    return (double)dsqr < __dmul_rn(3.84, (double)g.sigma2_2[oct2]);
+}
+
 struct BowProblem {
     int mode;   // 0: SearchByBoW(KeyFrame, Frame) :223-425   1: SearchByBoW(KeyFrame, KeyFrame) :765-905
-                // 2: SearchForTriangulation :907-1146 with the geometric gate always true (bCoarse)
+                // 2: SearchForTriangulation :907-1146; gate.enabled selects the pinhole gates, else every pair passes (bCoarse)
+    TriGate gate;
     FeatVecDev fa, fb;
     const uint8_t *desc_a; const float *angle_a; const uint8_t *skip_a; int na;   // skip_a[i] != 0: feature i of A is not a query
     const uint8_t *desc_b; const float *angle_b; const uint8_t *skip_b; int nb;   // skip_b[i] != 0: feature i of B is never a candidate
@@ -1089,6 +1135,7 @@ __global__ __launch_bounds__(64) void k_replay_bow(BowProblem P) {
                 const uint32_t pos = (uint32_t)(b - b0);
                 if (P.mode == 2) {
                     if (d > ORBX_TH_LOW) continue;               // :1017: '>' twice, so a later equal candidate wins
+                    if (P.gate.enabled && !tri_gate(P.gate, i, j)) continue;
                     push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)(0xffffffffu - pos));
                 } else {
                     push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)pos);

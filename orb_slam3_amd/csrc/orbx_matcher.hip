@@ -518,13 +518,15 @@ namespace {
 // k_replay_bow on host pointers: mode 0 SearchByBoW(KF, Frame), 1 SearchByBoW(KF, KF), 2 SearchForTriangulation without a gate
 int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float *angle_a, const uint8_t *skip_a, int na, const orbx_featvec *fa,
                    const uint8_t *desc_b, const float *angle_b, const uint8_t *skip_b, int nb, const orbx_featvec *fb, float nnratio,
-                   int check_orientation, int32_t *match_out, int n_out) {
+                   int check_orientation, int32_t *match_out, int n_out, const orbx_pinhole_gate *gate = nullptr) {
     if (na > 65535 || nb > 65535) return ORBX_E_TOO_LARGE;
     ORBX_HIP(hipSetDevice(m->device));
     const size_t ia = (size_t)fa->node_ptr[fa->n_nodes], ib = (size_t)fb->node_ptr[fb->n_nodes];
     const size_t need = Arena::pad(33 * (size_t)na) + Arena::pad(33 * (size_t)nb) + 2 * Arena::pad(4 * (size_t)std::max(na, nb)) * 2 +
                         Arena::pad(8 * (size_t)fa->n_nodes + 8) + Arena::pad(8 * (size_t)fb->n_nodes + 8) + Arena::pad(4 * ia) + Arena::pad(4 * ib) +
-                        Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 8192;
+                        Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 8192 +
+                        (gate ? Arena::pad(sizeof(orbx_keypoint) * (size_t)na) + Arena::pad(sizeof(orbx_keypoint) * (size_t)nb) +
+                                    Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 4 * Arena::pad(4 * 64) : 0);
     int r = m->arena.reserve(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
@@ -553,6 +555,19 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
     P.skip_a = up(skip_a, na); P.skip_b = up(skip_b, nb);
     if (!P.desc_a || !P.desc_b || (check_orientation && (!P.angle_a || !P.angle_b))) return ORBX_E_BAD_ARG;
     P.na = na; P.nb = nb; P.nnratio = nnratio; P.check_orientation = check_orientation ? 1 : 0;
+    if (gate) {  // the pinhole gates of SearchForTriangulation run inside the kernel (mode 2)
+        TriGate &G = P.gate;
+        G.enabled = 1; G.coarse = gate->coarse ? 1 : 0; G.strict = gate->strict_fp ? 1 : 0;
+        G.k1 = (const orbx_keypoint *)up(gate->kps1_un, sizeof(orbx_keypoint) * (size_t)na);
+        G.k2 = (const orbx_keypoint *)up(gate->kps2_un, sizeof(orbx_keypoint) * (size_t)nb);
+        G.ur1 = (const float *)up(gate->u_right1, 4 * (size_t)na);
+        G.ur2 = (const float *)up(gate->u_right2, 4 * (size_t)nb);
+        G.scale2 = (const float *)up(gate->scale_factors2, 4 * (size_t)gate->nlevels);
+        G.sigma2_2 = (const float *)up(gate->level_sigma2_2, 4 * (size_t)gate->nlevels);
+        if (!G.k1 || !G.k2 || !G.scale2 || !G.sigma2_2) return ORBX_E_BAD_ARG;
+        for (int i = 0; i < 9; i++) G.F[i] = gate->F12[i];
+        G.ex = gate->ep_x; G.ey = gate->ep_y;
+    }
     P.match = A.take<int32_t>(n_out); P.taken_b = A.take<uint8_t>(nb); P.entries = A.take<int32_t>(std::max(na, nb));
     P.nmatches = A.take<int32_t>(4);
     hipLaunchKernelGGL(k_replay_bow, dim3(1), dim3(64), 0, m->stream, P);
@@ -627,6 +642,23 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
     }
     if (check_orientation) hist.filter([&](int i1) { matches12[i1] = -1; nmatches--; });
     return nmatches;
+}
+
+// SearchForTriangulation for pinhole key frames with both geometric gates on the device (k_replay_bow mode 2 + tri_gate): the
+// epipole-distance test (ORBmatcher.cc:1026-1034) and Pinhole::epipolarConstrain (CameraModels/Pinhole.cpp:107-129) on the caller's
+// F12.  No callback, no host loop.
+int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbx_featvec *fv1,
+                                          const uint8_t *desc2, const uint8_t *skip2, int n2, const orbx_featvec *fv2,
+                                          int check_orientation, const orbx_pinhole_gate *gate, int32_t *matches12) {
+    if (!m || !fv1 || !fv2 || !matches12 || !gate || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
+    if (!gate->kps1_un || !gate->kps2_un || !gate->scale_factors2 || !gate->level_sigma2_2 || gate->nlevels <= 0 || gate->nlevels > 64)
+        return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return 0;
+    std::vector<float> a1(n1), a2(n2);  // kp.angle of mvKeysUn (:1086-1094)
+    for (int i = 0; i < n1; i++) a1[i] = gate->kps1_un[i].angle;
+    for (int i = 0; i < n2; i++) a2[i] = gate->kps2_un[i].angle;
+    return run_bow_replay(m, 2, desc1, a1.data(), skip1, n1, fv1, desc2, a2.data(), skip2, n2, fv2, 0.f, check_orientation, matches12, n1, gate);
 }
 
 }  // extern "C"

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import KP_DTYPE, FeatVec, FrameDesc, PAIR_PREDICATE, check, ptr
+from ._lib import KP_DTYPE, FeatVec, FrameDesc, PAIR_PREDICATE, PinholeGate, check, ptr
 
 
 @dataclass
@@ -249,6 +249,25 @@ class ORBmatcher:
         n = check(self._L.orbx_search_for_triangulation(self._h, ptr(d1), ptr(a1), ptr(s1), len(d1), C.byref(a), ptr(d2),
                                                         ptr(a2), ptr(s2), len(d2), C.byref(b), int(self.mbCheckOrientation),
                                                         cb, None, ptr(m12)), "orbx_search_for_triangulation")
+        return n, m12
+
+    def SearchForTriangulationPinhole(self, kps1_un, desc1, skip1, fv1: FeatureVector, kps2_un, desc2, skip2, fv2: FeatureVector,
+                                      scale_factors2, level_sigma2_2, F12, epipole, u_right1=None, u_right2=None, coarse=False,
+                                      strict_fp=False):
+        """SearchForTriangulation for pinhole key frames with the epipole-distance test (ORBmatcher.cc:1026-1034) and
+        Pinhole::epipolarConstrain (Pinhole.cpp:107-129, on the caller's F12) evaluated on the device: no callback."""
+        k1, k2 = np.ascontiguousarray(kps1_un, KP_DTYPE), np.ascontiguousarray(kps2_un, KP_DTYPE)
+        d1, s1, d2, s2 = _u8(desc1), _u8(skip1), _u8(desc2), _u8(skip2)
+        sf, sg = _f32(scale_factors2), _f32(level_sigma2_2)
+        ur1, ur2 = _f32(u_right1), _f32(u_right2)
+        g = PinholeGate(k1.ctypes.data, k2.ctypes.data, None if ur1 is None else ur1.ctypes.data, None if ur2 is None else ur2.ctypes.data,
+                        sf.ctypes.data, sg.ctypes.data, len(sf), (C.c_float * 9)(*[float(x) for x in np.asarray(F12, np.float32).ravel()]),
+                        float(epipole[0]), float(epipole[1]), int(coarse), int(strict_fp))
+        a, b = fv1.c_struct(), fv2.c_struct()
+        m12 = np.full(len(k1), -1, np.int32)
+        n = check(self._L.orbx_search_for_triangulation_pinhole(self._h, ptr(d1), ptr(s1), len(k1), C.byref(a), ptr(d2), ptr(s2), len(k2),
+                                                                C.byref(b), int(self.mbCheckOrientation), C.byref(g), ptr(m12)),
+                  "orbx_search_for_triangulation_pinhole")
         return n, m12
 
     # ---- DBoW2 transform (Frame::ComputeBoW, Frame.cc:738-745) ----

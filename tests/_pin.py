@@ -36,6 +36,15 @@ class Pinner:
             assert name in self.gold, f"no golden for {name} and no compiled reference"
             assert np.array_equal(o, self.gold[name]), name
 
+    def value(self, name, ref_call, dtype=np.float32):
+        """An INPUT that only the compiled reference can produce (e.g. the F12 it derived): live, or the committed copy."""
+        if self.live:
+            v = np.ascontiguousarray(ref_call(), dtype)
+            self.fresh[name] = flat([v])
+            return v
+        assert name in self.gold, f"no golden for {name} and no compiled reference"
+        return self.gold[name].view(dtype) if dtype == np.float32 else self.gold[name].astype(dtype)
+
     def finish(self):
         if self.live and os.environ.get("ORBX_WRITE_GOLDEN"):
             np.savez_compressed(self.path, **self.fresh)

@@ -499,3 +499,62 @@ def test_search_by_sim3(oracle, canvas1):
     n, m12 = osa.ORBmatcher(0.75, True).SearchBySim3(_frame_view(k0, d0, sf, 752, 480), _frame_view(k1, d1, sf, 752, 480), s0, s1, th, done0)
     assert n == (want >= 0).sum() and np.array_equal(m12, want)
     assert n > 100
+
+
+def test_search_for_triangulation_pinhole_device_gates(oracle, canvas1):
+    """orbx_search_for_triangulation_pinhole: epipole-distance test + Pinhole::epipolarConstrain evaluated inside k_replay_bow, against
+    the oracle (pinned to the reference's texts in tests/test_oracle_{matchers,frame}_vs_reference.py), FMA and strict float modes,
+    with near-threshold pairs made by placing KF2 keypoints a hair off the 1.96-sigma band of their KF1 partners."""
+    import orb_slam3_amd as osa
+    ex, k0, d0, k1, d1 = _two_frames(canvas1)
+    sf = ex.GetScaleFactors()
+    sg = (sf * sf).astype(np.float32)
+    rng = np.random.default_rng(43)
+    na, nb = _bow_nodes(rng, k0, k1, d0, d1, 60)
+    fva, fvb = osa.FeatureVector.from_node_of_feature(na), osa.FeatureVector.from_node_of_feature(nb)
+    s0 = (rng.random(len(k0)) < 0.3).astype(np.uint8)
+    s1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    ur0 = np.where(rng.random(len(k0)) < 0.2, k0["x"] - 5.0, -1.0).astype(np.float32)
+    ur1 = np.where(rng.random(len(k1)) < 0.2, k1["x"] - 5.0, -1.0).astype(np.float32)
+    K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]])
+    t = np.array([0.11, 0.004, 0.01])
+    th = 0.01
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    F = (np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)).astype(np.float32)
+    ep = (410.0, 236.0)
+    m = osa.ORBmatcher(0.6, True)
+    total = 0
+    for ori, coarse, u0, u1, strict in ((True, False, None, None, False), (True, False, ur0, ur1, True), (False, True, None, ur1, False),
+                                        (True, False, None, None, True)):
+        m.mbCheckOrientation = ori
+        on, om = oracle.search_for_triangulation_pinhole(k0, d0, s0, u0, fva, k1, d1, s1, u1, fvb, sf, sg, F, ep, coarse, ori, fma=not strict)
+        n, m12 = m.SearchForTriangulationPinhole(k0, d0, s0, fva, k1, d1, s1, fvb, sf, sg, F, ep, u0, u1, coarse, strict)
+        assert n == on and np.array_equal(m12, om), (ori, coarse, strict, n, on)
+        total += n
+    assert total > 100
+    # gate arithmetic alone, on pairs a few ulp from the threshold: two key frames of one feature each per pair would be slow, so
+    # use one query against many candidates sharing its vocabulary node and identical descriptors (distance 0 everywhere: the
+    # LAST passing candidate wins, :1017), sweeping the candidates' y across the band edge
+    nq = 64
+    kq = np.zeros(1, k0.dtype)
+    kq["x"], kq["y"], kq["octave"] = 300.0, 200.0, 0
+    dq = d0[:1]
+    F64 = F.astype(np.float64)
+    a = 300.0 * F64[0, 0] + 200.0 * F64[1, 0] + F64[2, 0]
+    b = 300.0 * F64[0, 1] + 200.0 * F64[1, 1] + F64[2, 1]
+    c = 300.0 * F64[0, 2] + 200.0 * F64[1, 2] + F64[2, 2]
+    for trial in range(20):
+        kc = np.zeros(nq, k0.dtype)
+        kc["octave"] = rng.integers(0, 8, nq)
+        x2 = rng.uniform(100, 700, nq)
+        d = np.sqrt(3.84 * sg[kc["octave"]].astype(np.float64)) * np.sqrt(a * a + b * b) * rng.choice([-1, 1], nq) * (1 + rng.normal(0, 2e-7, nq))
+        kc["x"], kc["y"] = x2.astype(np.float32), ((d - c - a * x2) / b).astype(np.float32)
+        dc = np.repeat(dq, nq, axis=0)
+        fq, fc = osa.FeatureVector.from_node_of_feature(np.zeros(1, np.int64)), osa.FeatureVector.from_node_of_feature(np.zeros(nq, np.int64))
+        z1, zq = np.zeros(1, np.uint8), np.zeros(nq, np.uint8)
+        for strict in (False, True):
+            on, om = oracle.search_for_triangulation_pinhole(kq, dq, z1, None, fq, kc, dc, zq, None, fc, sf, sg, F, (1e6, 1e6), False, False, fma=not strict)
+            m.mbCheckOrientation = False
+            n, m12 = m.SearchForTriangulationPinhole(kq, dq, z1, fq, kc, dc, zq, fc, sf, sg, F, (1e6, 1e6), None, None, False, strict)
+            assert n == on and np.array_equal(m12, om), (trial, strict, m12, om)

@@ -79,3 +79,33 @@ def test_distinctive_descriptors():
     best = ob.distinctive_descriptors(np.concatenate(sets), ptr)
     chosen = [s[b] for s, b in zip(sets, best)]
     _P.pin("distinctive", chosen, lambda: [rb.ref_distinctive_descriptor(s) for s in sets])
+
+
+def test_epipolar_constrain_pinhole_near_threshold():
+    """CameraModels/Pinhole.cpp:107-129.  F12 is whatever the reference text derived from (K1, K2, R12, t12) on the stand-in
+    matrix type; the pairs sit within a few ulp of dsqr = 3.84 * unc, where any difference in rounding or in which product the
+    compiler fused flips the verdict (the unfused evaluation disagrees on about a quarter of them)."""
+    rng = np.random.default_rng(1)
+    K = [458.654, 457.296, 367.215, 248.375]
+    th = 0.05
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+    t = np.array([0.11, 0.01, 0.02], np.float32)
+    n = 40000
+    x1, y1 = rng.uniform(0, 752, n).astype(np.float32), rng.uniform(0, 480, n).astype(np.float32)
+    unc = (1.44 ** rng.integers(0, 8, n)).astype(np.float32)
+    one = np.ones(1, np.float32)
+    F = _P.value("epi/F12", lambda: rb.ref_epipolar_pinhole(K, K, R, t, one, one, one, one, one)[1]).reshape(3, 3)
+    F64 = F.astype(np.float64)
+    a = x1 * F64[0, 0] + y1 * F64[1, 0] + F64[2, 0]
+    b = x1 * F64[0, 1] + y1 * F64[1, 1] + F64[2, 1]
+    c = x1 * F64[0, 2] + y1 * F64[1, 2] + F64[2, 2]
+    x2 = rng.uniform(0, 752, n)
+    d = np.sqrt(3.84 * unc.astype(np.float64)) * np.sqrt(a * a + b * b) * rng.choice([-1, 1], n) * (1 + rng.normal(0, 2e-7, n))
+    y2 = ((d - c - a * x2) / b).astype(np.float32)
+    x2 = x2.astype(np.float32)
+    far = rng.random(n) < 0.2            # and a share of ordinary pairs
+    y2[far] += rng.normal(0, 3, far.sum()).astype(np.float32)
+    got = ob.epipolar_pinhole(F, x1, y1, x2, y2, unc, fma=True)
+    _P.pin("epi/verdicts", [got], lambda: [rb.ref_epipolar_pinhole(K, K, R, t, x1, y1, x2, y2, unc)[0]])
+    assert 0.3 < got.mean() < 0.7
+    assert (ob.epipolar_pinhole(F, x1, y1, x2, y2, unc, fma=False) != got).mean() > 0.1    # the test does discriminate

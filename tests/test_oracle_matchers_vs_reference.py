@@ -209,6 +209,39 @@ def test_search_for_triangulation(frames):
         assert on > 50
 
 
+def test_search_for_triangulation_pinhole_gates(frames):
+    """M7 with the gates the way the device evaluates them (orbx_search_for_triangulation_pinhole): the reference's own
+    epipole-distance test (ORBmatcher.cc:1026-1034) runs on the real keypoints, and its epipolarConstrain verdicts come from the
+    reference's Pinhole.cpp text (identity intrinsics, R12 = I: F12 = [t12]x exactly)."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf, sg = tab["scale"], tab["sigma2"]
+    rng = np.random.default_rng(43)
+    na, nb = _bow_nodes(rng, k0, k1, 60)
+    fva, fvb = FeatureVector.from_node_of_feature(na), FeatureVector.from_node_of_feature(nb)
+    s0 = (rng.random(len(k0)) < 0.3).astype(np.uint8)
+    s1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    t12 = np.array([1.0, 0.02, 0.0005], np.float32)
+    F = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]], np.float32)
+    ep = (400.0, 240.0)
+    ur0 = np.where(rng.random(len(k0)) < 0.2, k0["x"] - 5.0, -1.0).astype(np.float32)
+    ur1 = np.where(rng.random(len(k1)) < 0.2, k1["x"] - 5.0, -1.0).astype(np.float32)
+    if rb.frame_available():   # verdict table of the reference's epipolarConstrain for every pair (unc = sigma2 of kp2's octave)
+        i0, i1 = np.meshgrid(np.arange(len(k0)), np.arange(len(k1)), indexing="ij")
+        ok, Fref = rb.ref_epipolar_pinhole([1, 1, 0, 0], [1, 1, 0, 0], np.eye(3, dtype=np.float32), t12, k0["x"][i0.ravel()], k0["y"][i0.ravel()],
+                                           k1["x"][i1.ravel()], k1["y"][i1.ravel()], sg[k1["octave"][i1.ravel()]])
+        assert np.array_equal(Fref, F)
+        table = ok.reshape(len(k0), len(k1))
+    for ori, coarse, u0, u1 in ((True, False, None, None), (False, False, ur0, ur1), (True, True, None, ur1)):
+        on, om = ob.search_for_triangulation_pinhole(k0, d0, s0, u0, fva, k1, d1, s1, u1, fvb, sf, sg, F, ep, coarse, ori, fma=True)
+        _pin(f"m7geo/{ori}/{coarse}/{u0 is not None}", (on, om),
+             lambda: rb.ref_search_for_triangulation_geo(k0, d0, s0, u0, fva, k1, d1, s1, u1, fvb, sf, ep, ori, table, coarse))
+        assert on > 50
+    # the gates do bite: without them more pairs survive
+    free, _ = ob.search_for_triangulation(d0, k0["angle"], s0, fva, d1, k1["angle"], s1, fvb, True, None)
+    gated, _ = ob.search_for_triangulation_pinhole(k0, d0, s0, None, fva, k1, d1, s1, None, fvb, sf, sg, F, ep, False, True)
+    assert gated < free
+
+
 def _fuse_queries(rng, k0, d0, sf, th):
     n = len(k0)
     u = (k0["x"] - 2.0 + rng.normal(0, 1.5, n)).astype(np.float32)
