@@ -75,3 +75,20 @@ def test_cpp_adapters_compile():
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", str(ROOT), "-x", "c++", "-"], input=src, text=True,
                        capture_output=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr
+
+
+def test_cpp_adapters_compile_and_link_against_the_c_abi(tmp_path):
+    """The header adapters with the reference's C++ class surface (orb_slam3_amd/cpp) and the C header itself (as plain C) compile,
+    and the demo links against liborbx.so -- no GPU needed for that."""
+    import subprocess
+    from orb_slam3_amd import _lib
+    c_src = tmp_path / "abi.c"
+    c_src.write_text('#include "orbx.h"\nint main(void) { return orbx_status_string(0) == 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", str(ROOT / "include"), "-c", str(c_src), "-o", str(tmp_path / "abi.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = tmp_path / "adapter_demo"
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-O1", str(ROOT / "tests/cpp/adapter_demo.cpp"), "-o", str(exe), str(_lib.LIB_PATH),
+                        "-Wl,-rpath," + str(_lib.LIB_PATH.parent), "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert exe.exists()
