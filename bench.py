@@ -74,9 +74,34 @@ def cpu_baseline(frames, n_sample):
             ob.search_by_projection_frame(grid, d, sf, q, 15.0, 0, True)
         prev = (k, d)
     dt = time.perf_counter() - t0
-    return {"value": round(feats / dt / 1e3, 3), "unit": "kfeatures/s", "cores": 1, "kind": "port",
-            "sample": f"{n_sample} frames of the same workload (extract + frame-to-frame match), {dt:.1f} s, "
-                      f"oracle/ C++ restatement -O3 x86-64-v3, host CPU {os.cpu_count()} logical cores available"}
+    out = {"value": round(feats / dt / 1e3, 3), "unit": "kfeatures/s", "cores": 1, "kind": "port",
+           "sample": f"{n_sample} frames of the same workload (extract + frame-to-frame match), {dt:.1f} s, "
+                     f"oracle/ C++ restatement -O3 x86-64-v3, host CPU {os.cpu_count()} logical cores available"}
+    # beside it, when oracle/_ref travelled here: the reference's OWN ORBextractor.cc + ORBmatcher.cc (compiled where they lie in the
+    # build container against the stand-in OpenCV / SLAM types, whose image primitives are the oracle's scalar ones) on a quarter of
+    # the sample -- shows the port is not slower than the code it restates; not a substitute for an OpenCV-backed build
+    try:
+        from oracle import ref_binding as rb
+        if rb.available() and rb.matcher_available():
+            rex = rb.RefExtractor(NFEATURES, 1.2, NLEVELS, 20, 7)
+            n_ref = max(2, n_sample // 4)
+            t0 = time.perf_counter()
+            rfeats, prev = 0, None
+            for t in range(n_ref):
+                _, k, d = rex.extract(frames[t % len(frames)], (0, 1000))
+                rfeats += len(k)
+                if prev is not None:
+                    k0, d0 = prev
+                    q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, z=np.ones(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
+                             desc=d0, has_obs=np.ones(len(k0), np.uint8))
+                    rb.ref_search_by_projection_frame(rb.RefFrame(k, d, 0.0, float(W), 0.0, float(H), sf), q, 15.0, 0, True)
+                prev = (k, d)
+            rdt = time.perf_counter() - t0
+            out["reference_build"] = {"value": round(rfeats / rdt / 1e3, 3), "unit": "kfeatures/s", "cores": 1,
+                                      "sample": f"{n_ref} frames, {rdt:.1f} s, reference ORBextractor.cc + ORBmatcher.cc over oracle/ocv_shim"}
+    except Exception as e:   # the baseline above stands on its own
+        out["reference_build"] = {"error": str(e)[:200]}
+    return out
 
 
 def bench_kitti(args, rank, local_rank, world, torch, dist, osa, synth):
