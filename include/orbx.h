@@ -28,7 +28,8 @@ enum {
     ORBX_OK = 0,
     ORBX_E_EMPTY = -1,
     ORBX_E_BAD_ARG = -2,
-    ORBX_E_TOO_SMALL = -3,   /* a pyramid level would have no 35-px FAST cell (the reference divides by zero) */
+    ORBX_E_TOO_SMALL = -3,   /* a pyramid level would have no 35-px FAST cell, or its detection window is narrower than half its
+                              * height (nIni = round(w/h) = 0, src/ORBextractor.cc:559-580): the reference divides by zero there */
     ORBX_E_CAPACITY = -4,    /* output capacity too small */
     ORBX_E_NO_DEVICE = -5,
     ORBX_E_HIP = -6,         /* a HIP runtime call failed; see orbx_last_error() */
