@@ -55,6 +55,29 @@ def algorithmic_bytes(sizes, n_frames, feats, cands):
     return per, extract_total
 
 
+def reference_build_child(td, n_ref):
+    """Child process of cpu_baseline: the compiled reference (oracle/_ref) on the frames saved in td; prints one JSON object."""
+    from oracle import oracle_binding as ob
+    from oracle import ref_binding as rb
+    frames = np.load(os.path.join(td, "frames.npy"))
+    sf = ob.OracleExtractor(NFEATURES, 1.2, NLEVELS, 20, 7).tables()["scale"]
+    rex = rb.RefExtractor(NFEATURES, 1.2, NLEVELS, 20, 7)
+    t0 = time.perf_counter()
+    feats, prev = 0, None
+    for t in range(n_ref):
+        _, k, d = rex.extract(frames[t % len(frames)], (0, 1000))
+        feats += len(k)
+        if prev is not None:
+            k0, d0 = prev
+            q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, z=np.ones(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
+                     desc=d0, has_obs=np.ones(len(k0), np.uint8))
+            rb.ref_search_by_projection_frame(rb.RefFrame(k, d, 0.0, float(W), 0.0, float(H), sf), q, 15.0, 0, True)
+        prev = (k, d)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"value": round(feats / dt / 1e3, 3), "unit": "kfeatures/s", "cores": 1,
+                      "sample": f"{n_ref} frames, {dt:.1f} s, reference ORBextractor.cc + ORBmatcher.cc over oracle/ocv_shim"}))
+
+
 def cpu_baseline(frames, n_sample):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores, 1 thread."""
     from oracle import oracle_binding as ob
@@ -79,26 +102,19 @@ def cpu_baseline(frames, n_sample):
                      f"oracle/ C++ restatement -O3 x86-64-v3, host CPU {os.cpu_count()} logical cores available"}
     # beside it, when oracle/_ref travelled here: the reference's OWN ORBextractor.cc + ORBmatcher.cc (compiled where they lie in the
     # build container against the stand-in OpenCV / SLAM types, whose image primitives are the oracle's scalar ones) on a quarter of
-    # the sample -- shows the port is not slower than the code it restates; not a substitute for an OpenCV-backed build
+    # the sample -- shows the port is not slower than the code it restates; not a substitute for an OpenCV-backed build.  Runs in
+    # a child process: nothing that library does can take the bench line down with it.
     try:
         from oracle import ref_binding as rb
         if rb.available() and rb.matcher_available():
-            rex = rb.RefExtractor(NFEATURES, 1.2, NLEVELS, 20, 7)
+            import subprocess
+            import tempfile
             n_ref = max(2, n_sample // 4)
-            t0 = time.perf_counter()
-            rfeats, prev = 0, None
-            for t in range(n_ref):
-                _, k, d = rex.extract(frames[t % len(frames)], (0, 1000))
-                rfeats += len(k)
-                if prev is not None:
-                    k0, d0 = prev
-                    q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, z=np.ones(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
-                             desc=d0, has_obs=np.ones(len(k0), np.uint8))
-                    rb.ref_search_by_projection_frame(rb.RefFrame(k, d, 0.0, float(W), 0.0, float(H), sf), q, 15.0, 0, True)
-                prev = (k, d)
-            rdt = time.perf_counter() - t0
-            out["reference_build"] = {"value": round(rfeats / rdt / 1e3, 3), "unit": "kfeatures/s", "cores": 1,
-                                      "sample": f"{n_ref} frames, {rdt:.1f} s, reference ORBextractor.cc + ORBmatcher.cc over oracle/ocv_shim"}
+            with tempfile.TemporaryDirectory() as td:
+                np.save(os.path.join(td, "frames.npy"), np.ascontiguousarray(frames[:min(n_ref, len(frames))]))
+                r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--reference-build-child", td, str(n_ref)],
+                                   capture_output=True, text=True, timeout=300)
+            out["reference_build"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": f"child exit {r.returncode}"}
     except Exception as e:   # the baseline above stands on its own
         out["reference_build"] = {"error": str(e)[:200]}
     return out
@@ -163,6 +179,8 @@ def bench_kitti(args, rank, local_rank, world, torch, dist, osa, synth):
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--reference-build-child":
+        return reference_build_child(sys.argv[2], int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
