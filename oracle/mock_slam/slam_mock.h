@@ -94,12 +94,12 @@ struct FeatureHolder {
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
     Sophus::SE3f Tcw, Trl;
     /* grid over mvKeysUn held by the oracle; kps_un is the flattened copy it indexes */
-    std::vector<orbo_keypoint> kps_un;
-    orbo_grid *grid = nullptr;
-    ~FeatureHolder() { if (grid) orbo_grid_destroy(grid); }
-    std::vector<size_t> area(float x, float y, float r, int minLevel, int maxLevel) const {
+    std::vector<orbo_keypoint> kps_un, kps_right;
+    orbo_grid *grid = nullptr, *grid_right = nullptr; /* fisheye stereo: mGridRight over mvKeysRight (Frame.cc:410-413) */
+    ~FeatureHolder() { if (grid) orbo_grid_destroy(grid); if (grid_right) orbo_grid_destroy(grid_right); }
+    std::vector<size_t> area(float x, float y, float r, int minLevel, int maxLevel, bool bRight = false) const {
         std::vector<int32_t> tmp(N > 0 ? N : 1);
-        int n = orbo_grid_query(grid, x, y, r, minLevel, maxLevel, tmp.data(), (int)tmp.size());
+        int n = orbo_grid_query(bRight ? grid_right : grid, x, y, r, minLevel, maxLevel, tmp.data(), (int)tmp.size());
         return std::vector<size_t>(tmp.begin(), tmp.begin() + n);
     }
 };
@@ -110,7 +110,7 @@ public:
     std::vector<bool> mvbOutlier;
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1,
                                           const int maxLevel = -1, const bool bRight = false) const {
-        return area(x, y, r, minLevel, maxLevel);
+        return area(x, y, r, minLevel, maxLevel, bRight);
     }
     Sophus::SE3f GetPose() const { return Tcw; }
     Sophus::SE3f GetRelativePoseTrl() const { return Trl; }

@@ -485,3 +485,24 @@ def search_for_triangulation_pinhole(k1, d1, s1, ur1, fv1, k2, d2, s2, ur2, fv2,
                                                 len(k2), C.byref(b), _p(sc), _p(sg), _p(F), C.c_float(ep[0]), C.c_float(ep[1]),
                                                 int(coarse), int(check_orientation), int(fma), _p(m12))
     return n, m12
+
+
+def search_by_projection_mappoints_fisheye(grid_left: OracleGrid, grid_right: OracleGrid, desc, scale_factors, l2r, r2l, mp, th, nnratio,
+                                           occupied=None):
+    """mp: in_view, proj_x, proj_y, level, view_cos, in_view_r, proj_xr, proj_yr, level_r, view_cos_r, desc, has_obs."""
+    nl, nr = len(grid_left.kps), len(grid_right.kps)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    l2r, r2l = np.ascontiguousarray(l2r, np.int32), np.ascontiguousarray(r2l, np.int32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    fm = np.full(nl + nr, -1, np.int32)
+    f32, i32, u8 = np.float32, np.int32, np.uint8
+    a = [np.ascontiguousarray(mp[k], t) for k, t in (("in_view", u8), ("proj_x", f32), ("proj_y", f32), ("level", i32), ("view_cos", f32),
+                                                     ("in_view_r", u8), ("proj_xr", f32), ("proj_yr", f32), ("level_r", i32),
+                                                     ("view_cos_r", f32), ("desc", u8), ("has_obs", u8))]
+    L = lib()
+    L.orbo_search_by_projection_mappoints_fisheye.restype = C.c_int
+    n = L.orbo_search_by_projection_mappoints_fisheye(C.c_void_p(grid_left.h), C.c_void_p(grid_right.h), _p(grid_left.kps), nl, _p(grid_right.kps), nr, _p(desc), _p(sf),
+                                                      _p(l2r), _p(r2l), _p(occ), len(a[0]), *[_p(x) for x in a], C.c_float(th),
+                                                      C.c_float(nnratio), _p(fm))
+    return n, fm

@@ -137,6 +137,18 @@ int orbo_search_by_projection_mappoints(const orbo_grid *grid, const orbo_keypoi
                                         const float *view_cos, const uint8_t *mp_desc, const uint8_t *mp_in_view,
                                         const uint8_t *mp_has_obs, float th, float nnratio, int32_t *frame_match);
 
+/* M1 in its fisheye-stereo form (F.Nleft != -1): left search + right-camera twin per map point (ORBmatcher.cc:43-213); features
+ * [0, n_left) left then [n_left, n_left + n_right) right; see orb_oracle_match.cc.  (Oracle only so far: liborbx implements the
+ * monocular / rectified form.) */
+int orbo_search_by_projection_mappoints_fisheye(const orbo_grid *grid_left, const orbo_grid *grid_right, const orbo_keypoint *kps_left,
+                                                int n_left, const orbo_keypoint *kps_right, int n_right, const uint8_t *desc,
+                                                const float *scale_factors, const int32_t *l2r, const int32_t *r2l,
+                                                const uint8_t *occupied, int n_mp, const uint8_t *in_view, const float *proj_x,
+                                                const float *proj_y, const int32_t *level, const float *view_cos,
+                                                const uint8_t *in_view_r, const float *proj_xr, const float *proj_yr,
+                                                const int32_t *level_r, const float *view_cos_r, const uint8_t *mp_desc,
+                                                const uint8_t *mp_has_obs, float th, float nnratio, int32_t *frame_match);
+
 /* M2: SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) after projection: one query per last-frame
  * map point that survived the projection gates; level window selected by mode (0: [o-1,o+1], 1 forward: [o,-1],
  * 2 backward: [0,o]).  Returns nmatches after the rotation-histogram filter. */

@@ -175,6 +175,92 @@ int orbo_search_by_projection_mappoints(const orbo_grid *grid, const orbo_keypoi
     return nmatches;
 }
 
+/* M1, the fisheye-stereo form (F.Nleft != -1), ORBmatcher.cc:43-213 whole: per map point the left search (:60-142) and then its
+ * right-camera twin (:144-210) in the same loop iteration.  Features are indexed as the reference indexes them: [0, n_left) left,
+ * [n_left, n_left + n_right) right; kps_left = F.mvKeys, kps_right = F.mvKeysRight, desc / occupied / frame_match cover all of them.
+ * l2r / r2l = F.mvLeftToRightMatch / F.mvRightToLeftMatch (-1 = no stereo partner): an accepted match is written to the partner
+ * slot as well and counts twice (:131-135, :197-201).  Differences from the left search that the twin really has: its radius is
+ * RadiusByViewingCos(mTrackViewCosR) WITHOUT the th factor (:147), it needs mnTrackScaleLevelR != -1 (:146), and the stereo
+ * coordinate gate (:92-97) exists only in the monocular form. */
+int orbo_search_by_projection_mappoints_fisheye(const orbo_grid *grid_left, const orbo_grid *grid_right, const orbo_keypoint *kps_left,
+                                                int n_left, const orbo_keypoint *kps_right, int n_right, const uint8_t *desc,
+                                                const float *scale_factors, const int32_t *l2r, const int32_t *r2l,
+                                                const uint8_t *occupied, int n_mp, const uint8_t *in_view, const float *proj_x,
+                                                const float *proj_y, const int32_t *level, const float *view_cos,
+                                                const uint8_t *in_view_r, const float *proj_xr, const float *proj_yr,
+                                                const int32_t *level_r, const float *view_cos_r, const uint8_t *mp_desc,
+                                                const uint8_t *mp_has_obs, float th, float nnratio, int32_t *frame_match) {
+    const int N = n_left + n_right;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    std::vector<uint8_t> occ(occupied ? std::vector<uint8_t>(occupied, occupied + N) : std::vector<uint8_t>(N, 0));
+    for (int i = 0; i < N; i++) frame_match[i] = -1;
+    std::vector<int32_t> vIndices;
+    auto assign = [&](int slot, int iMP) { frame_match[slot] = iMP; occ[slot] = mp_has_obs ? mp_has_obs[iMP] : 1; };
+    for (int iMP = 0; iMP < n_mp; iMP++) {
+        if (!in_view[iMP] && !in_view_r[iMP]) continue; /* :52-53 */
+        const uint8_t *MPdescriptor = mp_desc + (size_t)iMP * 32;
+        if (in_view[iMP]) {
+            const int nPredictedLevel = level[iMP];
+            float r = (view_cos[iMP] > 0.998) ? 2.5f : 4.0f;
+            if (bFactor) r *= th;
+            grid_query(grid_left, proj_x[iMP], proj_y[iMP], r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+            if (!vIndices.empty()) {
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (int32_t idx : vIndices) {
+                    if (occ[idx]) continue;
+                    const int dist = descriptor_distance(MPdescriptor, desc + (size_t)idx * 32);
+                    if (dist < bestDist) {
+                        bestDist2 = bestDist; bestDist = dist;
+                        bestLevel2 = bestLevel; bestLevel = kps_left[idx].octave; /* idx < Nleft: F.mvKeys[idx] */
+                        bestIdx = idx;
+                    } else if (dist < bestDist2) {
+                        bestLevel2 = kps_left[idx].octave;
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist <= TH_HIGH) {
+                    const bool rejected = bestLevel == bestLevel2 && bestDist > nnratio * bestDist2; /* :125-126: `continue` skips the twin too */
+                    if (rejected) continue;
+                    if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                        assign(bestIdx, iMP);
+                        if (l2r[bestIdx] != -1) { assign(l2r[bestIdx] + n_left, iMP); nmatches++; }
+                        nmatches++;
+                    }
+                }
+            }
+        }
+        if (in_view_r[iMP]) {
+            const int nPredictedLevel = level_r[iMP];
+            if (nPredictedLevel != -1) {
+                const float r = (view_cos_r[iMP] > 0.998) ? 2.5f : 4.0f;
+                grid_query(grid_right, proj_xr[iMP], proj_yr[iMP], r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+                if (vIndices.empty()) continue;
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (int32_t idx : vIndices) {
+                    if (occ[idx + n_left]) continue;
+                    const int dist = descriptor_distance(MPdescriptor, desc + (size_t)(idx + n_left) * 32);
+                    if (dist < bestDist) {
+                        bestDist2 = bestDist; bestDist = dist;
+                        bestLevel2 = bestLevel; bestLevel = kps_right[idx].octave;
+                        bestIdx = idx;
+                    } else if (dist < bestDist2) {
+                        bestLevel2 = kps_right[idx].octave;
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist <= TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                    if (r2l[bestIdx] != -1) { assign(r2l[bestIdx], iMP); nmatches++; }
+                    assign(bestIdx + n_left, iMP);
+                    nmatches++;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
 /* M2, ORBmatcher.cc:1676-1887 (mono form), queries = last-frame map points already projected */
 int orbo_search_by_projection_frame(const orbo_grid *grid, const orbo_keypoint *ckps, const uint8_t *cdesc, int nC,
                                     const float *scale_factors, const float *cur_u_right, const uint8_t *cur_occupied,

@@ -358,6 +358,31 @@ class RefGrid:
         return out[:n].copy()
 
 
+class RefGridStereo:
+    """Fisheye-stereo Frame (Nleft != -1): mGrid over mvKeys and mGridRight over mvKeysRight, by the reference's own functions."""
+
+    def __init__(self, kps_left, kps_right, minx, maxx, miny, maxy):
+        self.kl = np.ascontiguousarray(kps_left, KP_DTYPE)
+        self.kr = np.ascontiguousarray(kps_right, KP_DTYPE)
+        self.b = (float(minx), float(maxx), float(miny), float(maxy))
+        self.L = _fl()
+        self.L.frameref_grid_create_stereo.restype = C.c_void_p
+        self.L.frameref_grid_create_stereo.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_float] * 4
+        self.L.frameref_grid_query_stereo.restype = C.c_int
+        self.L.frameref_grid_query_stereo.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
+        self.h = self.L.frameref_grid_create_stereo(self.kl.ctypes.data, len(self.kl), self.kr.ctypes.data, len(self.kr), *self.b)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.frameref_grid_destroy(self.h)
+            self.h = None
+
+    def query(self, x, y, r, min_level=-1, max_level=-1, right=False):
+        out = np.zeros(len(self.kl) + len(self.kr) + 1, np.int32)
+        n = self.L.frameref_grid_query_stereo(self.h, int(right), *self.b, x, y, r, min_level, max_level, out.ctypes.data, len(out))
+        return out[:n].copy()
+
+
 def ref_grid_dims():
     c, r = C.c_int(), C.c_int()
     _fl().frameref_grid_dims(C.byref(c), C.byref(r))
@@ -417,3 +442,17 @@ def ref_search_for_triangulation_geo(k1, d1, s1, ur1, fv1, k2, d2, s2, ur2, fv2,
                                               _p(ur2), len(k2), C.byref(b), _p(sc), len(sc), C.c_float(ep[0]), C.c_float(ep[1]),
                                               int(check_orientation), _p(ok), int(coarse), _p(m12))
     return n, m12
+
+
+def ref_search_by_projection_mappoints_fisheye(kps_left, kps_right, desc, bounds, scale_factors, l2r, r2l, mp, th, nnratio, occupied=None):
+    kl, kr = np.ascontiguousarray(kps_left, KP_DTYPE), np.ascontiguousarray(kps_right, KP_DTYPE)
+    desc, b, sf = _u8(desc), _f32(bounds), _f32(scale_factors)
+    l2r, r2l, occ = _i32(l2r), _i32(r2l), _u8(occupied)
+    fm = np.full(len(kl) + len(kr), -1, np.int32)
+    a = [f(mp[k]) for k, f in (("in_view", _u8), ("proj_x", _f32), ("proj_y", _f32), ("level", _i32), ("view_cos", _f32), ("in_view_r", _u8),
+                               ("proj_xr", _f32), ("proj_yr", _f32), ("level_r", _i32), ("view_cos_r", _f32), ("desc", _u8), ("has_obs", _u8))]
+    L = _ml()
+    L.matref_search_by_projection_mappoints_fisheye.restype = C.c_int
+    n = L.matref_search_by_projection_mappoints_fisheye(_p(kl), len(kl), _p(kr), len(kr), _p(desc), _p(b), _p(sf), len(sf), _p(l2r), _p(r2l),
+                                                        _p(occ), len(a[0]), *[_p(x) for x in a], C.c_float(th), C.c_float(nnratio), _p(fm))
+    return n, fm

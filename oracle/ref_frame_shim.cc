@@ -67,6 +67,29 @@ void *frameref_grid_create(const orbo_keypoint *kps_un, int n, float minx, float
     return h;
 }
 void frameref_grid_destroy(void *h) { delete (GridHandle *)h; }
+/* the fisheye-stereo layout (Nleft != -1): features [0, n_left) are mvKeys, the rest mvKeysRight; AssignFeaturesToGrid fills mGrid
+ * and mGridRight (Frame.cc:395-413) */
+void *frameref_grid_create_stereo(const orbo_keypoint *kps_left, int n_left, const orbo_keypoint *kps_right, int n_right, float minx,
+                                  float maxx, float miny, float maxy) {
+    GridHandle *h = new GridHandle();
+    set_bounds(minx, maxx, miny, maxy);
+    h->F.N = n_left + n_right;
+    h->F.Nleft = n_left;
+    keys(h->F.mvKeys, kps_left, n_left);
+    keys(h->F.mvKeysRight, kps_right, n_right);
+    h->F.AssignFeaturesToGrid();
+    return h;
+}
+/* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel, bRight) of such a frame */
+int frameref_grid_query_stereo(void *hv, int right, float minx, float maxx, float miny, float maxy, float x, float y, float r,
+                               int min_level, int max_level, int32_t *out, int cap) {
+    GridHandle *h = (GridHandle *)hv;
+    set_bounds(minx, maxx, miny, maxy);
+    std::vector<size_t> v = h->F.GetFeaturesInArea(x, y, r, min_level, max_level, right != 0);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int32_t)v[i];
+    return (int)v.size();
+}
+
 
 /* which = 0: Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel); 1: KeyFrame::GetFeaturesInArea(x, y, r) */
 int frameref_grid_query(void *hv, int which, float minx, float maxx, float miny, float maxy, float x, float y, float r,

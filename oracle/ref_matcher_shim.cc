@@ -112,6 +112,54 @@ int matref_search_by_projection_mappoints(const orbo_keypoint *kps, const uint8_
     return r;
 }
 
+/* M1 in its fisheye-stereo form (F.Nleft != -1): ORBmatcher.cc:43-213 whole, left search + right-camera twin.  desc / occupied /
+ * frame_match cover the n_left + n_right features in the reference's order (left first). */
+int matref_search_by_projection_mappoints_fisheye(const orbo_keypoint *kps_left, int n_left, const orbo_keypoint *kps_right, int n_right,
+                                                  const uint8_t *desc, const float *bounds, const float *scale, int nlevels,
+                                                  const int32_t *l2r, const int32_t *r2l, const uint8_t *occupied, int n_mp,
+                                                  const uint8_t *in_view, const float *proj_x, const float *proj_y, const int32_t *level,
+                                                  const float *view_cos, const uint8_t *in_view_r, const float *proj_xr,
+                                                  const float *proj_yr, const int32_t *level_r, const float *view_cos_r,
+                                                  const uint8_t *mp_desc, const uint8_t *has_obs, float th, float nnratio,
+                                                  int32_t *frame_match) {
+    GeometricCamera cam;
+    Frame F;
+    const int N = n_left + n_right;
+    fill(F, kps_left, n_left, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, nullptr, nlevels, nullptr, &cam);
+    F.N = N; F.Nleft = n_left; F.NLeft = n_left;
+    F.mDescriptors = cv::Mat(N > 0 ? N : 1, 32, CV_8UC1);
+    if (N) std::memcpy(F.mDescriptors.data, desc, (size_t)N * 32);
+    F.kps_right.assign(kps_right, kps_right + n_right);
+    F.mvKeysRight.resize(n_right);
+    for (int i = 0; i < n_right; i++)
+        F.mvKeysRight[i] = cv::KeyPoint(kps_right[i].x, kps_right[i].y, kps_right[i].size, kps_right[i].angle, kps_right[i].response, kps_right[i].octave, i);
+    F.grid_right = orbo_grid_create(F.kps_right.data(), n_right, bounds[0], bounds[1], bounds[2], bounds[3]);
+    F.mvLeftToRightMatch.assign(l2r, l2r + n_left);
+    F.mvRightToLeftMatch.assign(r2l, r2l + n_right);
+    F.mvuRight.assign(N, -1.f);
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    F.mvpMapPoints.assign(N, nullptr);
+    for (int i = 0; i < N; i++)
+        if (occupied && occupied[i]) F.mvpMapPoints[i] = marker(pool);
+    std::vector<MapPoint> mps(n_mp);
+    std::vector<MapPoint *> vp(n_mp);
+    for (int j = 0; j < n_mp; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.mbTrackInView = in_view[j] != 0; p.mbTrackInViewR = in_view_r[j] != 0;
+        p.mTrackProjX = proj_x[j]; p.mTrackProjY = proj_y[j]; p.mTrackProjXR = proj_xr[j]; p.mTrackProjYR = proj_yr[j];
+        p.mnTrackScaleLevel = level[j]; p.mnTrackScaleLevelR = level_r[j];
+        p.mTrackViewCos = view_cos[j]; p.mTrackViewCosR = view_cos_r[j];
+        p.nobs = has_obs[j] ? 1 : 0;
+        p.desc = desc_row(mp_desc + (size_t)j * 32);
+        vp[j] = &p;
+    }
+    ORBmatcher m(nnratio, true);
+    int r = m.SearchByProjection(F, vp, th, false, 50.0f);
+    for (int i = 0; i < N; i++) frame_match[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->id >= 0) ? F.mvpMapPoints[i]->id : -1;
+    return r;
+}
+
 /* M2  ORBmatcher.cc:1676-1885.  q_z = camera-frame depth of the projected point (the reference derives the stereo
  * coordinate as u - mbf / z with mbf = 1 here).  mode 0 mono, 1 forward, 2 backward. */
 int matref_search_by_projection_frame(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *bounds,

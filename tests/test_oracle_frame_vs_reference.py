@@ -45,6 +45,22 @@ def test_feature_grid_assign_and_query():
         assert sum(len(a) for a in o_frame) > 5 * len(qs)
 
 
+def test_feature_grid_fisheye_stereo_layout():
+    """Frame.cc:395-413, 657-723 with Nleft != -1: the right camera's features live in mGridRight, indexed from 0; a query with
+    bRight reads that grid.  The oracle models it as two independent grids (what the matcher stand-ins use)."""
+    rng = np.random.default_rng(5)
+    b = (0.0, 512.0, 0.0, 512.0)
+    kl, kr = np.zeros(700, ob.KP_DTYPE), np.zeros(650, ob.KP_DTYPE)
+    for k in (kl, kr):
+        k["x"], k["y"], k["octave"] = rng.uniform(-5, 517, len(k)), rng.uniform(-5, 517, len(k)), rng.integers(0, 8, len(k))
+    gl, gr = ob.OracleGrid(kl, *b), ob.OracleGrid(kr, *b)
+    rg = rb.RefGridStereo(kl, kr, *b) if rb.frame_available() else None
+    qs = [(rng.uniform(-30, 540), rng.uniform(-30, 540), float(rng.choice([2.0, 10.0, 40.0])), int(rng.choice([-1, 0, 2])), int(rng.choice([-1, 1, 7])))
+          for _ in range(1000)]
+    o = [np.concatenate([[-7], gl.query(*q), [-8], gr.query(*q)]) for q in qs]
+    _P.pin("grid/fisheye", o, lambda: [np.concatenate([[-7], rg.query(*q), [-8], rg.query(*q, right=True)]) for q in qs])
+
+
 @pytest.mark.parametrize("w,h,nf,seed", [(752, 480, 1000, 3), (1241, 376, 2000, 4)])
 def test_compute_stereo_matches(w, h, nf, seed):
     """M8, Frame.cc:811-981: row table, disparity window, descriptor scan, 11x11 SAD slide, parabola fit, median cut -- float

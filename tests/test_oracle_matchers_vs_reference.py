@@ -87,6 +87,41 @@ def test_search_by_projection_mappoints(frames):
         assert on > 100
 
 
+def test_search_by_projection_mappoints_fisheye_twin(frames):
+    """M1 with F.Nleft != -1 (ORBmatcher.cc:43-213 whole): left search and right-camera twin interleaved per map point, partner
+    slots written through mvLeftToRightMatch / mvRightToLeftMatch, the twin's radius without the th factor.  Oracle only so far
+    (liborbx implements the Nleft == -1 form); this pins the semantics the device twin has to reproduce."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf = tab["scale"]
+    rng = np.random.default_rng(19)
+    kl, dl, kr, dr = k1, d1, k0, d0               # "left" = frame 1, "right" = frame 0 (the same scene shifted by (2, 1))
+    nl, nr = len(kl), len(kr)
+    desc = np.concatenate([dl, dr])
+    l2r = np.full(nl, -1, np.int32)
+    r2l = np.full(nr, -1, np.int32)
+    pairs = rng.permutation(min(nl, nr))[:300]     # some stereo partners (any injective pairing exercises the partner writes)
+    l2r[pairs] = pairs
+    r2l[pairs] = pairs
+    n_mp = 2500
+    src = rng.integers(0, nl, n_mp)
+    srcr = rng.integers(0, nr, n_mp)
+    mp = dict(in_view=(rng.random(n_mp) < 0.8).astype(np.uint8), proj_x=kl["x"][src] + rng.normal(0, 2, n_mp).astype(np.float32),
+              proj_y=kl["y"][src] + rng.normal(0, 2, n_mp).astype(np.float32), level=kl["octave"][src],
+              view_cos=rng.choice([0.99, 0.9995], n_mp).astype(np.float32), in_view_r=(rng.random(n_mp) < 0.7).astype(np.uint8),
+              proj_xr=kr["x"][srcr] + rng.normal(0, 2, n_mp).astype(np.float32), proj_yr=kr["y"][srcr] + rng.normal(0, 2, n_mp).astype(np.float32),
+              level_r=np.where(rng.random(n_mp) < 0.9, kr["octave"][srcr], -1).astype(np.int32),
+              view_cos_r=rng.choice([0.99, 0.9995], n_mp).astype(np.float32), desc=_noisy_copy(rng, dl[src], 0.05),
+              has_obs=(rng.random(n_mp) < 0.9).astype(np.uint8))
+    occ = (rng.random(nl + nr) < 0.1).astype(np.uint8)
+    gl, gr = ob.OracleGrid(kl, 0.0, float(W), 0.0, float(H)), ob.OracleGrid(kr, 0.0, float(W), 0.0, float(H))
+    bounds = np.array([0.0, W, 0.0, H], np.float32)
+    for th, ratio in ((1.0, 0.8), (3.0, 0.8), (5.0, 0.6)):
+        on, ofm = ob.search_by_projection_mappoints_fisheye(gl, gr, desc, sf, l2r, r2l, mp, th, ratio, occ)
+        _pin(f"m1fisheye/{th}/{ratio}", (on, ofm),
+             lambda: rb.ref_search_by_projection_mappoints_fisheye(kl, kr, desc, bounds, sf, l2r, r2l, mp, th, ratio, occ))
+        assert on > 200 and (ofm[nl:] >= 0).sum() > 50 and (ofm[:nl] >= 0).sum() > 50
+
+
 def test_search_by_projection_frame(frames):
     """M2, ORBmatcher.cc:1676-1885: mono / forward / backward level windows, stereo gate u - bf/z, rotation filter."""
     k0, d0, k1, d1, tab = frames[1000]
