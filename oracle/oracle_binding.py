@@ -506,3 +506,35 @@ def search_by_projection_mappoints_fisheye(grid_left: OracleGrid, grid_right: Or
                                                       _p(l2r), _p(r2l), _p(occ), len(a[0]), *[_p(x) for x in a], C.c_float(th),
                                                       C.c_float(nnratio), _p(fm))
     return n, fm
+
+
+def search_by_projection_frame_fisheye(grid_left: OracleGrid, grid_right: OracleGrid, desc, scale_factors, q, th, mode=0, check_orientation=True,
+                                       occupied=None):
+    """q: u, v, xr, yr (projection into the right camera), octave, angle, desc, has_obs."""
+    nl, nr = len(grid_left.kps), len(grid_right.kps)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    cm = np.full(nl + nr, -1, np.int32)
+    f32, i32, u8 = np.float32, np.int32, np.uint8
+    a = [np.ascontiguousarray(q[k], t) for k, t in (("u", f32), ("v", f32), ("xr", f32), ("yr", f32), ("octave", i32), ("angle", f32),
+                                                    ("desc", u8), ("has_obs", u8))]
+    L = lib()
+    L.orbo_search_by_projection_frame_fisheye.restype = C.c_int
+    n = L.orbo_search_by_projection_frame_fisheye(C.c_void_p(grid_left.h), C.c_void_p(grid_right.h), _p(grid_left.kps), nl, _p(grid_right.kps), nr,
+                                                  _p(desc), _p(sf), _p(occ), len(a[0]), *[_p(x) for x in a], C.c_float(th), int(mode),
+                                                  int(check_orientation), _p(cm))
+    return n, cm
+
+
+def search_by_bow_frame_fisheye(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, n_f_left, f_fv, nnratio, check_orientation):
+    kd, fd = np.ascontiguousarray(kf_desc, np.uint8), np.ascontiguousarray(f_desc, np.uint8)
+    ka, fa = np.ascontiguousarray(kf_angle, np.float32), np.ascontiguousarray(f_angle, np.float32)
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    a, b = _fv(kf_fv), _fv(f_fv)
+    fm = np.full(len(fd), -1, np.int32)
+    L = lib()
+    L.orbo_search_by_bow_frame_fisheye.restype = C.c_int
+    n = L.orbo_search_by_bow_frame_fisheye(_p(kd), _p(ka), _p(kv), len(kd), C.byref(a), _p(fd), _p(fa), len(fd), int(n_f_left), C.byref(b),
+                                           C.c_float(nnratio), int(check_orientation), _p(fm))
+    return n, fm

@@ -159,6 +159,15 @@ int orbo_search_by_projection_frame(const orbo_grid *grid, const orbo_keypoint *
                                     const uint8_t *q_desc, const uint8_t *q_has_obs, float th, int mode,
                                     int check_orientation, int32_t *cur_match);
 
+/* M2 in its fisheye-stereo form (CurrentFrame.Nleft != -1): left search + right-camera twin per last-frame map point
+ * (ORBmatcher.cc:1676-1885 whole); (q_xr, q_yr) = projection into the right camera.  Oracle only so far. */
+int orbo_search_by_projection_frame_fisheye(const orbo_grid *grid_left, const orbo_grid *grid_right, const orbo_keypoint *kps_left,
+                                            int n_left, const orbo_keypoint *kps_right, int n_right, const uint8_t *cdesc,
+                                            const float *scale_factors, const uint8_t *cur_occupied, int n_q, const float *q_u,
+                                            const float *q_v, const float *q_xr, const float *q_yr, const int32_t *q_octave,
+                                            const float *q_angle, const uint8_t *q_desc, const uint8_t *q_has_obs, float th, int mode,
+                                            int check_orientation, int32_t *cur_match);
+
 /* M3 / M4 (and M2 again) in their common form: one query per projected map point with an explicit window radius
  * and level range.  level_gate_in_loop = 0: Frame::GetFeaturesInArea(x,y,r,minLevel,maxLevel) as M3 (ORBmatcher.cc:
  * 1889-2010) does; = 1: KeyFrame::GetFeaturesInArea(x,y,r) (KeyFrame.cc:704-748, no level test) followed by the explicit
@@ -188,6 +197,11 @@ typedef struct orbo_featvec {
 int orbo_search_by_bow_frame(const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
                              const orbo_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f,
                              const orbo_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match);
+/* M5 (KeyFrame -> Frame) with F.Nleft != -1 (ORBmatcher.cc:283-392): per-camera best / second-best, right match nested in the left
+ * branch with its ratio test disabled (`|| true`, :359).  Frame features [0, n_f_left) left, the rest right.  Oracle only so far. */
+int orbo_search_by_bow_frame_fisheye(const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                                     const orbo_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f, int n_f_left,
+                                     const orbo_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match);
 /* M5: SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:765-905) -> match12[i1] = KF2 feature index or -1 */
 int orbo_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
                                  const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,

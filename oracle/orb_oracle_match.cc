@@ -317,6 +317,77 @@ int orbo_search_by_projection_frame(const orbo_grid *grid, const orbo_keypoint *
     return nmatches;
 }
 
+/* M2 in its fisheye-stereo form (CurrentFrame.Nleft != -1), ORBmatcher.cc:1676-1885 whole: per last-frame map point the left
+ * search and then the right-camera twin (:1794-1863) at the point's projection into the right camera (q_xr, q_yr), same radius
+ * and level window, occupancy and result slots offset by n_left, rotation entries pushed for both.  An EMPTY left window skips
+ * the twin as well (`continue`, :1738-1739); the stereo-coordinate gate (:1755-1761) exists only in the monocular form. */
+int orbo_search_by_projection_frame_fisheye(const orbo_grid *grid_left, const orbo_grid *grid_right, const orbo_keypoint *kps_left,
+                                            int n_left, const orbo_keypoint *kps_right, int n_right, const uint8_t *cdesc,
+                                            const float *scale_factors, const uint8_t *cur_occupied, int n_q, const float *q_u,
+                                            const float *q_v, const float *q_xr, const float *q_yr, const int32_t *q_octave,
+                                            const float *q_angle, const uint8_t *q_desc, const uint8_t *q_has_obs, float th, int mode,
+                                            int check_orientation, int32_t *cur_match) {
+    const int nC = n_left + n_right;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<uint8_t> occ(cur_occupied ? std::vector<uint8_t>(cur_occupied, cur_occupied + nC) : std::vector<uint8_t>(nC, 0));
+    for (int i = 0; i < nC; i++) cur_match[i] = -1;
+    std::vector<int32_t> vIndices2;
+    auto window = [&](const orbo_grid *g, float x, float y, float radius, int oct) {
+        if (mode == 1) grid_query(g, x, y, radius, oct, -1, vIndices2);
+        else if (mode == 2) grid_query(g, x, y, radius, 0, oct, vIndices2);
+        else grid_query(g, x, y, radius, oct - 1, oct + 1, vIndices2);
+    };
+    auto push = [&](float a_last, float a_cur, int slot) {
+        float rot = a_last - a_cur;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(slot);
+    };
+    for (int i = 0; i < n_q; i++) {
+        const int nLastOctave = q_octave[i];
+        const float radius = th * scale_factors[nLastOctave];
+        const uint8_t *dMP = q_desc + (size_t)i * 32;
+        const uint8_t obs = q_has_obs ? q_has_obs[i] : 1;
+        window(grid_left, q_u[i], q_v[i], radius, nLastOctave);
+        if (vIndices2.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int32_t i2 : vIndices2) {
+            if (occ[i2]) continue;
+            const int dist = descriptor_distance(dMP, cdesc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            cur_match[bestIdx2] = i; occ[bestIdx2] = obs;
+            nmatches++;
+            if (check_orientation) push(q_angle[i], kps_left[bestIdx2].angle, bestIdx2);
+        }
+        window(grid_right, q_xr[i], q_yr[i], radius, nLastOctave);
+        bestDist = 256; bestIdx2 = -1;
+        for (int32_t i2 : vIndices2) {
+            if (occ[i2 + n_left]) continue;
+            const int dist = descriptor_distance(dMP, cdesc + (size_t)(i2 + n_left) * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            cur_match[bestIdx2 + n_left] = i; occ[bestIdx2 + n_left] = obs;
+            nmatches++;
+            if (check_orientation) push(q_angle[i], kps_right[bestIdx2].angle, bestIdx2 + n_left);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { cur_match[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
 /* M3 (ORBmatcher.cc:1889-2010) / M4 (ORBmatcher.cc:427-646) common form */
 int orbo_search_by_projection_window(const orbo_grid *grid, const orbo_keypoint *kps, const uint8_t *desc, int n,
                                      const uint8_t *occupied, int n_q, const float *q_x, const float *q_y,
@@ -471,6 +542,57 @@ int orbo_search_by_bow_frame(const uint8_t *kf_desc, const float *kf_angle, cons
                 if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
                     f_match[bestIdxF] = realIdxKF;
                     if (check_orientation) rotHist[rot_bin(kf_angle[realIdxKF], f_angle[bestIdxF])].push_back(bestIdxF);
+                    nmatches++;
+                }
+            }
+        }
+    });
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { f_match[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+/* M5 (KeyFrame -> Frame) in its fisheye-stereo form (F.Nleft != -1), ORBmatcher.cc:283-392: the frame's features of a node are
+ * split by index into left (< n_f_left) and right; best / second-best are kept per camera; the right match is considered only
+ * INSIDE the branch of a left best <= TH_LOW, and its ratio test is disabled by `|| true` (:359). */
+int orbo_search_by_bow_frame_fisheye(const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                                     const orbo_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f, int n_f_left,
+                                     const orbo_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match) {
+    int nmatches = 0;
+    for (int i = 0; i < n_f; i++) f_match[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    join_nodes(kf_fv, f_fv, [&](int ik, int jf) {
+        for (int a = kf_fv->node_ptr[ik]; a < kf_fv->node_ptr[ik + 1]; a++) {
+            const int realIdxKF = kf_fv->index[a];
+            if (!kf_valid[realIdxKF]) continue;
+            const uint8_t *dKF = kf_desc + (size_t)realIdxKF * 32;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+            for (int b = f_fv->node_ptr[jf]; b < f_fv->node_ptr[jf + 1]; b++) {
+                const int realIdxF = f_fv->index[b];
+                if (f_match[realIdxF] >= 0) continue;
+                const int dist = descriptor_distance(dKF, f_desc + (size_t)realIdxF * 32);
+                if (realIdxF < n_f_left && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                else if (realIdxF < n_f_left && dist < bestDist2) bestDist2 = dist;
+                if (realIdxF >= n_f_left && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+                else if (realIdxF >= n_f_left && dist < bestDist2R) bestDist2R = dist;
+            }
+            if (bestDist1 <= TH_LOW) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    f_match[bestIdxF] = realIdxKF;
+                    if (check_orientation) rotHist[rot_bin(kf_angle[realIdxKF], f_angle[bestIdxF])].push_back(bestIdxF);
+                    nmatches++;
+                }
+                if (bestDist1R <= TH_LOW) { /* ratio test `|| true` */
+                    f_match[bestIdxFR] = realIdxKF;
+                    if (check_orientation) rotHist[rot_bin(kf_angle[realIdxKF], f_angle[bestIdxFR])].push_back(bestIdxFR);
                     nmatches++;
                 }
             }

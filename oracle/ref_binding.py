@@ -456,3 +456,27 @@ def ref_search_by_projection_mappoints_fisheye(kps_left, kps_right, desc, bounds
     n = L.matref_search_by_projection_mappoints_fisheye(_p(kl), len(kl), _p(kr), len(kr), _p(desc), _p(b), _p(sf), len(sf), _p(l2r), _p(r2l),
                                                         _p(occ), len(a[0]), *[_p(x) for x in a], C.c_float(th), C.c_float(nnratio), _p(fm))
     return n, fm
+
+
+def ref_search_by_projection_frame_fisheye(kps_left, kps_right, desc, bounds, scale_factors, q, th, mode=0, check_orientation=True, occupied=None):
+    """q: u, v, z (camera depth: the right-camera projection is (u + z, v)), octave, angle, desc, has_obs."""
+    kl, kr = np.ascontiguousarray(kps_left, KP_DTYPE), np.ascontiguousarray(kps_right, KP_DTYPE)
+    desc, b, sf, occ = _u8(desc), _f32(bounds), _f32(scale_factors), _u8(occupied)
+    cm = np.full(len(kl) + len(kr), -1, np.int32)
+    a = [_f32(q["u"]), _f32(q["v"]), _f32(q["z"]), _i32(q["octave"]), _f32(q["angle"]), _u8(q["desc"]), _u8(q["has_obs"])]
+    L = _ml()
+    L.matref_search_by_projection_frame_fisheye.restype = C.c_int
+    n = L.matref_search_by_projection_frame_fisheye(_p(kl), len(kl), _p(kr), len(kr), _p(desc), _p(b), _p(sf), len(sf), _p(occ), len(a[0]),
+                                                    *[_p(x) for x in a], C.c_float(th), int(mode), int(check_orientation), _p(cm))
+    return n, cm
+
+
+def ref_search_by_bow_frame_fisheye(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, n_f_left, f_fv, nnratio, check_orientation):
+    kd, fd, ka, fa, kv = _u8(kf_desc), _u8(f_desc), _f32(kf_angle), _f32(f_angle), _u8(kf_valid)
+    a, b = _fv(kf_fv), _fv(f_fv)
+    fm = np.full(len(fd), -1, np.int32)
+    L = _ml()
+    L.matref_search_by_bow_frame_fisheye.restype = C.c_int
+    n = L.matref_search_by_bow_frame_fisheye(_p(kd), _p(ka), _p(kv), len(kd), C.byref(a), _p(fd), _p(fa), len(fd), int(n_f_left), C.byref(b),
+                                             C.c_float(nnratio), int(check_orientation), _p(fm))
+    return n, fm

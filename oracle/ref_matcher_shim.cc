@@ -202,6 +202,58 @@ int matref_search_by_projection_frame(const orbo_keypoint *kps, const uint8_t *d
     return r;
 }
 
+/* M2 in its fisheye-stereo form: Trl = [[1,0,1],[0,1,0],[0,0,1] | 0] on the stand-in matrix type, so a point at camera depth z
+ * projects to (u + z, v) in the right camera -- the test picks z per query.  Features of the current frame: left then right. */
+int matref_search_by_projection_frame_fisheye(const orbo_keypoint *kps_left, int n_left, const orbo_keypoint *kps_right, int n_right,
+                                              const uint8_t *desc, const float *bounds, const float *scale, int nlevels,
+                                              const uint8_t *occupied, int n_q, const float *q_u, const float *q_v, const float *q_z,
+                                              const int32_t *q_octave, const float *q_angle, const uint8_t *q_desc,
+                                              const uint8_t *q_has_obs, float th, int mode, int check_orientation, int32_t *cur_match) {
+    GeometricCamera cam;
+    Frame Cur, Last;
+    const int N = n_left + n_right;
+    fill(Cur, kps_left, n_left, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, nullptr, nlevels, nullptr, &cam);
+    Cur.N = N; Cur.Nleft = n_left; Cur.NLeft = n_left;
+    Cur.mDescriptors = cv::Mat(N > 0 ? N : 1, 32, CV_8UC1);
+    if (N) std::memcpy(Cur.mDescriptors.data, desc, (size_t)N * 32);
+    Cur.kps_right.assign(kps_right, kps_right + n_right);
+    Cur.mvKeysRight.resize(n_right);
+    for (int i = 0; i < n_right; i++)
+        Cur.mvKeysRight[i] = cv::KeyPoint(kps_right[i].x, kps_right[i].y, kps_right[i].size, kps_right[i].angle, kps_right[i].response, kps_right[i].octave, i);
+    Cur.grid_right = orbo_grid_create(Cur.kps_right.data(), n_right, bounds[0], bounds[1], bounds[2], bounds[3]);
+    Cur.mvuRight.assign(N, -1.f);
+    Cur.mbf = 1.f;
+    Cur.mb = 0.5f;
+    const float tz = mode == 1 ? -1.f : mode == 2 ? 1.f : 0.f;
+    Cur.Tcw.t = Eigen::Vector3f(0.f, 0.f, tz);
+    Cur.Trl.R(0, 2) = 1.f;
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    Cur.mvpMapPoints.assign(N, nullptr);
+    for (int i = 0; i < N; i++)
+        if (occupied && occupied[i]) Cur.mvpMapPoints[i] = marker(pool);
+    Last.N = n_q;
+    Last.mvKeys.resize(n_q);
+    Last.mvKeysUn.resize(n_q);
+    Last.mvbOutlier.assign(n_q, false);
+    std::vector<MapPoint> mps(n_q);
+    Last.mvpMapPoints.resize(n_q);
+    for (int j = 0; j < n_q; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.pos = Eigen::Vector3f(q_u[j], q_v[j], q_z[j] - tz);
+        p.nobs = q_has_obs[j] ? 1 : 0;
+        p.desc = desc_row(q_desc + (size_t)j * 32);
+        Last.mvpMapPoints[j] = &p;
+        Last.mvKeys[j].octave = q_octave[j];
+        Last.mvKeys[j].angle = q_angle[j];
+        Last.mvKeysUn[j] = Last.mvKeys[j];
+    }
+    ORBmatcher m(0.9f, check_orientation != 0);
+    int r = m.SearchByProjection(Cur, Last, th, mode == 0);
+    for (int i = 0; i < N; i++) cur_match[i] = (Cur.mvpMapPoints[i] && Cur.mvpMapPoints[i]->id >= 0) ? Cur.mvpMapPoints[i]->id : -1;
+    return r;
+}
+
 /* M3  ORBmatcher.cc:1887-2010 (relocalisation): query i = key frame feature i with its map point */
 int matref_search_by_projection_keyframe(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *bounds,
                                          const float *scale, int nlevels, const uint8_t *occupied, int n_q,
@@ -294,6 +346,43 @@ int matref_search_by_bow_frame(const uint8_t *kf_desc, const float *kf_angle, co
     }
     for (int i = 0; i < n_f; i++) F.mvKeys[i].angle = f_angle[i];
     F.mvKeysUn = F.mvKeys;
+    featvec(KF.mFeatVec, kf_fv);
+    featvec(F.mFeatVec, f_fv);
+    std::vector<MapPoint *> out;
+    ORBmatcher m(nnratio, check_orientation != 0);
+    int r = m.SearchByBoW(&KF, F, out);
+    for (int i = 0; i < n_f; i++) f_match[i] = out[i] ? out[i]->id : -1;
+    return r;
+}
+
+/* M5a with F.Nleft != -1 (:283-392): both objects carry a second camera, the frame's features are left [0, n_f_left) then right */
+int matref_search_by_bow_frame_fisheye(const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                                       const orbo_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f, int n_f_left,
+                                       const orbo_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match) {
+    GeometricCamera cam;
+    KeyFrame KF;
+    Frame F;
+    KF.N = n_kf; F.N = n_f;
+    KF.mpCamera = KF.mpCamera2 = &cam; F.mpCamera = F.mpCamera2 = &cam;
+    KF.NLeft = KF.Nleft = n_kf;          /* every key frame feature is a left one: kp = pKF->mvKeys[realIdxKF] (:325-327) */
+    KF.mvKeys.resize(n_kf); KF.mvKeysUn.resize(n_kf);
+    F.Nleft = F.NLeft = n_f_left;
+    F.mvKeys.resize(n_f_left); F.mvKeysRight.resize(n_f - n_f_left);
+    KF.mDescriptors = cv::Mat(n_kf > 0 ? n_kf : 1, 32, CV_8UC1);
+    F.mDescriptors = cv::Mat(n_f > 0 ? n_f : 1, 32, CV_8UC1);
+    std::memcpy(KF.mDescriptors.data, kf_desc, (size_t)n_kf * 32);
+    std::memcpy(F.mDescriptors.data, f_desc, (size_t)n_f * 32);
+    std::vector<MapPoint> mps(n_kf);
+    KF.mvpMapPoints.assign(n_kf, nullptr);
+    for (int i = 0; i < n_kf; i++) {
+        KF.mvKeys[i].angle = kf_angle[i];
+        KF.mvKeysUn[i].angle = -1000.f;    /* must not be read in this configuration */
+        mps[i].id = i;
+        if (kf_valid[i]) KF.mvpMapPoints[i] = &mps[i];
+        else if (i & 1) { mps[i].bad = true; KF.mvpMapPoints[i] = &mps[i]; }
+    }
+    for (int i = 0; i < n_f_left; i++) F.mvKeys[i].angle = f_angle[i];
+    for (int i = n_f_left; i < n_f; i++) F.mvKeysRight[i - n_f_left].angle = f_angle[i];
     featvec(KF.mFeatVec, kf_fv);
     featvec(F.mFeatVec, f_fv);
     std::vector<MapPoint *> out;

@@ -143,6 +143,36 @@ def test_search_by_projection_frame(frames):
         assert on > 50
 
 
+def test_search_by_projection_frame_fisheye_twin(frames):
+    """M2 with CurrentFrame.Nleft != -1 (ORBmatcher.cc:1676-1885 whole): right-camera twin at the projection into the right camera,
+    skipped together with an empty left window, rotation entries from both cameras.  Oracle only so far."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf = tab["scale"]
+    rng = np.random.default_rng(23)
+    kl, dl = k1, d1                               # current left = frame 1
+    kr = k1.copy()                                # current right = the same features displaced by a per-feature disparity
+    disp = (rng.integers(8, 160, len(kr)) / 8.0).astype(np.float32)
+    kr["x"] = kl["x"] + disp
+    dr = _noisy_copy(rng, d1, 0.02)
+    nl, nr = len(kl), len(kr)
+    desc = np.concatenate([dl, dr])
+    u = (k0["x"] - 2.0).astype(np.float32)
+    v = (k0["y"] - 1.0).astype(np.float32)
+    z = (rng.integers(8, 160, len(k0)) / 8.0).astype(np.float32)
+    q = dict(u=u, v=v, z=z, xr=(u + z).astype(np.float32), yr=v, octave=k0["octave"], angle=k0["angle"], desc=d0,
+             has_obs=(rng.random(len(k0)) < 0.9).astype(np.uint8))
+    inside = (u >= 0) & (u <= W) & (v >= 0) & (v <= H)
+    q = {k: a[inside] for k, a in q.items()}
+    gl, gr = ob.OracleGrid(kl, 0.0, float(W), 0.0, float(H)), ob.OracleGrid(kr, 0.0, float(W), 0.0, float(H))
+    bounds = np.array([0.0, W, 0.0, H], np.float32)
+    for mode, ori, th in ((0, True, 15.0), (1, True, 7.0), (2, False, 15.0), (0, True, 40.0)):
+        occ = (rng.random(nl + nr) < 0.05).astype(np.uint8)
+        on, ocm = ob.search_by_projection_frame_fisheye(gl, gr, desc, sf, q, th, mode, ori, occ)
+        _pin(f"m2fisheye/{mode}/{ori}/{th}", (on, ocm),
+             lambda: rb.ref_search_by_projection_frame_fisheye(kl, kr, desc, bounds, sf, q, th, mode, ori, occ))
+        assert (ocm[:nl] >= 0).sum() > 50 and (ocm[nl:] >= 0).sum() > 20
+
+
 def test_search_by_projection_keyframe_and_sim3(frames):
     """M3, ORBmatcher.cc:1887-2010 (Frame grid, levels [l-1,l+1], ORBdist, rotation filter) and M4, :427-646 both overloads
     (KeyFrame grid + explicit octave gate [l-1,l], TH_LOW * ratioHamming)."""
@@ -208,6 +238,30 @@ def test_search_by_bow(frames):
             _pin(f"m5b/{n_nodes}/{ratio}/{ori}", (on, om),
                  lambda: rb.ref_search_by_bow_keyframes(d0, k0["angle"], valid0, fva, d1, k1["angle"], valid1, fvb, ratio, ori))
             assert on > 30
+
+
+def test_search_by_bow_frame_fisheye(frames):
+    """M5 (KeyFrame -> Frame) with F.Nleft != -1 (ORBmatcher.cc:283-392): per-camera best / second-best over one node list, the right
+    match nested inside the left branch with `|| true` for a ratio test.  Oracle only so far."""
+    k0, d0, k1, d1, _ = frames[1000]
+    rng = np.random.default_rng(37)
+    n_left = len(k1)
+    f_desc = np.concatenate([d1, _noisy_copy(rng, d1, 0.03)])       # right camera: noisy copies of the left features
+    f_angle = np.concatenate([k1["angle"], (k1["angle"] + rng.normal(0, 3, n_left)).astype(np.float32) % 360]).astype(np.float32)
+    for n_nodes in (100, 9):
+        na, nb = _bow_nodes(rng, k0, k1, n_nodes)
+        nbr = nb.copy()
+        flip = rng.random(n_left) < 0.1
+        nbr[flip] = rng.integers(0, n_nodes, flip.sum())
+        fva, fvb = FeatureVector.from_node_of_feature(na), FeatureVector.from_node_of_feature(np.concatenate([nb, nbr]))
+        valid0 = (rng.random(len(k0)) < 0.7).astype(np.uint8)
+        for ratio, ori in ((0.7, True), (0.9, True), (0.75, False)):
+            on, om = ob.search_by_bow_frame_fisheye(d0, k0["angle"], valid0, fva, f_desc, f_angle, n_left, fvb, ratio, ori)
+            _pin(f"m5afisheye/{n_nodes}/{ratio}/{ori}", (on, om),
+                 lambda: rb.ref_search_by_bow_frame_fisheye(d0, k0["angle"], valid0, fva, f_desc, f_angle, n_left, fvb, ratio, ori))
+            assert (om[:n_left] >= 0).sum() > 40 and (om[n_left:] >= 0).sum() > 40
+            mono_n, _ = ob.search_by_bow_frame(d0, k0["angle"], valid0, fva, d1, k1["angle"], FeatureVector.from_node_of_feature(nb), ratio, ori)
+            assert on > mono_n     # the twin adds right-camera matches
 
 
 def test_search_for_initialization(frames):
