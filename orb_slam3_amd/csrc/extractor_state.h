@@ -22,18 +22,61 @@ void set_error(const std::string &s);
         }                                                                                              \
     } while (0)
 
+// Device buffer.  Normal mode: hipMalloc + zero fill (every buffer has defined contents from its first use).
+// Guard mode (ORBX_GUARD=1|2, debugging aid, see tools/repro_fault.sh): the buffer is placed through the HIP virtual-memory
+// API so that its END (1) or its START (2) touches an unmapped address range, and it is filled with a poison byte: any kernel or copy
+// that runs past (before) the buffer, or indexes with a value it never wrote, faults deterministically instead of silently
+// touching a neighbouring allocation.
+int guard_mode();
+int guard_fill();   // ORBX_GUARD_FILL=<byte> (default 0xCB)
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    // guard-mode bookkeeping
+    void *va = nullptr; size_t va_bytes = 0, map_bytes = 0, gran = 0;
+    hipMemGenericAllocationHandle_t handle{};
+    bool guarded = false;
     int ensure(size_t need) {
         if (need <= bytes) return ORBX_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        ORBX_HIP(hipMalloc(&p, need));
+        release();
+        if (guard_mode() == 0) {
+            ORBX_HIP(hipMalloc(&p, need));
+            bytes = need;
+            ORBX_HIP(hipMemset(p, 0, need));
+            return ORBX_OK;
+        }
+        int dev = 0;
+        ORBX_HIP(hipGetDevice(&dev));
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        ORBX_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+        const size_t need16 = (need + 15) & ~(size_t)15;
+        map_bytes = (need16 + gran - 1) / gran * gran;
+        va_bytes = map_bytes + 2 * gran;
+        ORBX_HIP(hipMemAddressReserve(&va, va_bytes, gran, nullptr, 0));
+        ORBX_HIP(hipMemCreate(&handle, map_bytes, &prop, 0));
+        ORBX_HIP(hipMemMap((char *)va + gran, map_bytes, 0, handle, 0));
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ORBX_HIP(hipMemSetAccess((char *)va + gran, map_bytes, &acc, 1));
+        guarded = true;
+        ORBX_HIP(hipMemset((char *)va + gran, guard_fill(), map_bytes));
+        p = (char *)va + gran + (guard_mode() == 1 ? map_bytes - need16 : 0);
         bytes = need;
         return ORBX_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void release() {
+        if (guarded) {
+            // the address range stays reserved (debug mode; re-using freed ranges crashed hipMemMap in ROCm 7.0's runtime)
+            (void)hipMemUnmap((char *)va + gran, map_bytes);
+            (void)hipMemRelease(handle);
+            guarded = false; va = nullptr;
+        } else if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+    }
 };
 
 enum { K_PYR_BASE, K_PYR_RESIZE, K_FAST, K_OCTREE, K_FINALIZE, K_BLUR, K_DESCRIBE, K_MATCH_SCAN, K_MATCH_RESOLVE, K_COUNT };

@@ -28,6 +28,15 @@ thread_local std::string g_last_error;
 
 void set_error(const std::string &s) { g_last_error = s; }
 
+int guard_fill() {
+    static const int m = [] { const char *v = getenv("ORBX_GUARD_FILL"); return v ? (atoi(v) & 0xff) : 0xCB; }();
+    return m;
+}
+int guard_mode() {
+    static const int m = [] { const char *v = getenv("ORBX_GUARD"); return v ? atoi(v) : 0; }();
+    return m;
+}
+
 static const int8_t kPatternData[1024] = {
 #include "orb_pattern.inc"
 };
@@ -504,7 +513,7 @@ void orbx_destroy(orbx_extractor *ex) {
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
-                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg};
+                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg, &ex->d_xgtab};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);
