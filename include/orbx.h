@@ -205,7 +205,9 @@ int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kp_left, c
 
 /* Frame description for the projection matchers: undistorted keypoints (mvKeysUn), descriptors, image bounds
  * (mnMinX..mnMaxY) from which the 64x48 grid (Frame.h:44-45, Frame.cc:385-416) is built, per-level scale factors,
- * optional right coordinates (mvuRight, NULL for mono). */
+ * optional right coordinates (mvuRight, NULL for mono).  n <= ORBX_MAX_FRAME_FEATURES for the projection matchers
+ * (ORBX_E_TOO_LARGE otherwise, checked before any work is enqueued). */
+#define ORBX_MAX_FRAME_FEATURES 16000
 typedef struct orbx_frame_desc {
     const orbx_keypoint *keypoints_un;
     const uint8_t *descriptors;

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -43,6 +45,7 @@ struct DevBuf {
             ORBX_HIP(hipMalloc(&p, need));
             bytes = need;
             ORBX_HIP(hipMemset(p, 0, need));
+            if (getenv("ORBX_DEBUG_ALLOC")) fprintf(stderr, "[orbx alloc] %p .. %p  %zu bytes\n", p, (char *)p + need, need);
             return ORBX_OK;
         }
         int dev = 0;

@@ -288,7 +288,9 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     }
     {
         ProfScope ps(ex, K_FAST);
-        const int ini = std::min(std::max(ex->prm.ini_th_fast, 0), 255), mn = std::min(std::max(ex->prm.min_th_fast, 0), 255);
+        // one score map at min(ini, min) serves both passes of :830-846; for ini < min the reference's second pass FAST(min) is a
+        // subset of its first, so its result is FAST(ini) alone -- the same as running this stage with min := ini
+        const int ini = std::min(std::max(ex->prm.ini_th_fast, 0), 255), mn = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini);
         static const int tpb = [] { const char *v = getenv("ORBX_FAST_TPB"); return v ? atoi(v) : 0; }();
 #define ORBX_FAST_LAUNCH(T)                                                                                                  \
     hipLaunchKernelGGL(k_fast_cells<T>, dim3(ex->n_fast_tiles, n), dim3(T), ex->fast_lds, st, d_lv,                           \

@@ -18,7 +18,7 @@ using namespace orbx;
 
 namespace {
 
-constexpr int kMaxResolveFeatures = 16000;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
+constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
 
 struct Arena {  // bump allocator over one device buffer, reset per call
@@ -267,7 +267,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     const int n = F->n, nq = a.nq;
     for (int i = 0; i < n; i++) a.match_out[i] = -1;
     if (n == 0 || nq == 0) return 0;
-    if (n > 65535) return ORBX_E_TOO_LARGE;
+    if (n > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;  // before anything is enqueued: the resolve pass keeps 9 B per feature in LDS
     ORBX_HIP(hipSetDevice(m->device));
     size_t need = Arena::pad(28 * (size_t)n) + Arena::pad(32 * (size_t)n) + 3 * Arena::pad((size_t)n) + Arena::pad(4 * (size_t)n) * 2 +
                   Arena::pad(4 * (size_t)nq) * 7 + Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) * 2 + Arena::pad(8 * (size_t)nq) * 5 +
@@ -317,7 +317,6 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     g.inv_h = 48.0f / (F->max_y - F->min_y);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(64), 0, m->stream, dP, g);
     hipLaunchKernelGGL(k_window_best2, dim3((nq + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
-    if (n > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n);
