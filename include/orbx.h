@@ -94,6 +94,14 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
 int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int n_frames, int width, int height,
                               size_t row_stride, size_t frame_stride, int lap0, int lap1);
 
+/* The same over HOST-resident frames (what the reference hands to operator(): cv::Mat data in host memory, ORBextractor.cc:1086):
+ * the frames are copied to the device on the extractor's upload stream into one of two internal input slabs, so the upload
+ * of batch i+1 overlaps the kernels of batch i; everything else as orbx_extract_batch_device.  h_images should be pinned
+ * (hipHostMalloc / hipHostRegister) for the copy to be asynchronous; it may be reused by the caller as soon as the NEXT call
+ * to this function (or orbx_sync) has returned. */
+int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_frames, int width, int height,
+                            size_t row_stride, size_t frame_stride, int lap0, int lap1);
+
 /* Device-side view of the last batch (valid until the next extract call on this extractor). */
 typedef struct orbx_batch_view {
     int32_t n_frames;
@@ -319,6 +327,18 @@ int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1,
 int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                   int32_t *d_match, int32_t *d_nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, ...) (ORBmatcher.cc:39-141; called by
+ * Tracking::SearchLocalPoints, Tracking.cc:3390-3413) for EVERY frame of the extractor's last batch, device-resident: frame f is
+ * searched against n_mp map points whose per-frame projection data (what Frame::isInFrustum stores in the MapPoint: mTrackProjX/Y,
+ * mnTrackScaleLevel, mTrackViewCos, mbTrackInView) lie in device arrays [n_frames][n_mp]; d_mp_desc holds the map points'
+ * descriptors, frame f's at d_mp_desc + f*desc_frame_stride (0 = one shared set).  Monocular form (Nleft == -1, no mvuRight),
+ * all features free on entry, every map point "has observations".  d_match: device int32 [n_frames][cap] (map-point index
+ * per feature or -1), d_nmatches [n_frames]; NULL for both = internal buffers (orbx_batch_download_async).  Asynchronous. */
+int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, const float *d_proj_x, const float *d_proj_y,
+                                       const int32_t *d_level, const float *d_view_cos, const uint8_t *d_in_view,
+                                       const uint8_t *d_mp_desc, size_t desc_frame_stride, float th, float nnratio,
+                                       int32_t *d_match, int32_t *d_nmatches);
+
 /* The matching core of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th, bRight) (ORBmatcher.cc:1148-1337, candidate loop
  * :1246-1306) and Fuse(KeyFrame*, Sim3f&, vpPoints, th, vpReplacePoint) (:1339-1455, loop :1405-1433): for each projected
  * map point (u, v[, ur], radius = th*scale[lvl], predicted level) the best feature of the key frame among
@@ -358,6 +378,8 @@ int orbx_bow_transform(orbx_matcher *m, const orbx_vocabulary *voc, const uint8_
  * the left extractor's stream.  Results (mvuRight, mvDepth; -1 = no match) per frame via orbx_stereo_batch_download. */
 int orbx_stereo_batch_device(orbx_extractor *left, orbx_extractor *right, float bf, float b);
 int orbx_stereo_batch_download(orbx_extractor *left, int frame, float *u_right, float *depth, int *n_left, int *n_matches);
+/* all frames at once: u_right / depth [n_frames][cap] (entries beyond a frame's keypoint count unspecified), n_matches [n_frames] */
+int orbx_stereo_batch_download_all(orbx_extractor *left, float *u_right, float *depth, int32_t *n_matches);
 
 const char *orbx_last_error(void);
 const char *orbx_status_string(int status);

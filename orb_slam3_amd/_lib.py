@@ -69,7 +69,7 @@ _lib = None
 
 # every symbol include/orbx.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch_device", "orbx_batch_view_get", "orbx_sync",
+    "orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch_device", "orbx_extract_batch_host", "orbx_batch_view_get", "orbx_sync",
     "orbx_batch_download", "orbx_batch_download_all", "orbx_batch_download_async", "orbx_download_wait", "orbx_output_capacity", "orbx_get_level", "orbx_level_size",
     "orbx_get_level_device", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_scale_tables",
     "orbx_get_feature_tables", "orbx_debug_level_candidates", "orbx_debug_level_keypoints",
@@ -78,7 +78,7 @@ SYMBOLS = [
     "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
     "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
-    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_vocabulary_create",
+    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
     "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors", "orbx_fuse_search",
 ]
 
@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
     L.orbx_destroy.argtypes = [vp]
     L.orbx_extract.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, vp, i32, vp, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, sz, sz, i32, i32]
+    L.orbx_extract_batch_host.argtypes = [vp, vp, i32, i32, i32, sz, sz, i32, i32]
     L.orbx_batch_view_get.argtypes = [vp, C.POINTER(BatchView)]
     L.orbx_sync.argtypes = [vp]
     L.orbx_batch_download.argtypes = [vp, i32, vp, vp, i32, vp, vp]
@@ -142,6 +143,8 @@ def lib() -> C.CDLL:
     L.orbx_distinctive_descriptors.argtypes = [vp, vp, vp, i32, vp]
     L.orbx_fuse_search.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.orbx_stereo_batch_download.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.orbx_stereo_batch_download_all.argtypes = [vp, vp, vp, vp]
+    L.orbx_search_mappoints_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, sz, f32, f32, vp, vp]
     L.orbx_search_by_projection_window.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32,
                                                    i32, vp]
     L.orbx_search_for_initialization.argtypes = [vp, vp, vp, i32, C.POINTER(FrameDesc), vp, i32, f32, i32, vp]

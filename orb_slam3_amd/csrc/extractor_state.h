@@ -129,6 +129,13 @@ struct orbx_extractor {
     // concurrent branches of one batch: blur runs beside FAST/quad-tree (aux), the frame-to-frame matcher of batch i
     // runs beside the pyramid/FAST/quad-tree of batch i+1 (match)
     hipStream_t aux_stream = nullptr, match_stream = nullptr;
+    // host-resident input (orbx_extract_batch_host): upload stream + two input slabs; slot s may be overwritten once the
+    // k_pyr_base that read it has finished (ev_in_free), the extraction may start once the upload has landed (ev_in_ready)
+    hipStream_t in_stream = nullptr;
+    DevBuf d_in[2];
+    hipEvent_t ev_in_free[2] = {nullptr, nullptr}, ev_in_ready[2] = {nullptr, nullptr};
+    bool in_used[2] = {false, false};
+    unsigned in_issued = 0;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
     bool match_pending = false;
     bool blur_side = true;     // ORBX_BLUR_SIDE=0: k_blur stays on the main stream (after the pyramid)
@@ -142,6 +149,11 @@ struct orbx_extractor {
     DevBuf d_match, d_nmatch;  // internal frame-to-frame match outputs [B][cap], [B]
     // cached problem descriptors of orbx_match_consecutive_device
     struct MatchKey { int n = 0, cap = 0; const void *match = nullptr, *nm = nullptr; float th = 0, du = 0, dv = 0; int ori = 0; const void *kps = nullptr; } mkey;
+
+    // batched SearchByProjection(Frame, MapPoints) on the resident batch (orbx_search_mappoints_batch_device)
+    DevBuf d_mp_qr, d_mp_qmin, d_mp_qmax, d_mp_valid, d_mp_keys, d_mp_meta, d_mp_grid, d_mp_probs, d_mp_res, d_mp_misc, d_mp_entries;
+    struct MpKey { int n = 0, cap = 0, n_mp = 0; const void *px = nullptr, *py = nullptr, *lvl = nullptr, *vc = nullptr, *iv = nullptr, *desc = nullptr,
+                   *match = nullptr, *nm = nullptr, *kps = nullptr; size_t dstride = 0; float th = 0, ratio = 0; } mpkey;
 
     int ensure_stage(size_t bytes) {
         if (bytes <= h_stage_bytes) return ORBX_OK;

@@ -641,6 +641,27 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
     }
 }
 
+// Search windows of SearchByProjection(Frame, MapPoints) (ORBmatcher.cc:53-72) for every (frame, map point) of a batch:
+// r = RadiusByViewingCos(viewCos) [* th if th != 1] * mvScaleFactors[nPredictedLevel], levels [level-1, level]; a map point
+// that is not in view (mbTrackInView false) or whose predicted level is out of range is skipped.
+// grid (ceil(n_mp/256), n_frames), block 256
+__global__ __launch_bounds__(256) void k_mappoint_windows(int n_mp, const int32_t *__restrict__ level, const float *__restrict__ view_cos,
+                                                          const uint8_t *__restrict__ in_view, const float *__restrict__ scale, int nlevels,
+                                                          float th, float *__restrict__ qr, int32_t *__restrict__ qmin,
+                                                          int32_t *__restrict__ qmax, uint8_t *__restrict__ qvalid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_mp) return;
+    const size_t k = (size_t)blockIdx.y * n_mp + i;
+    const int lvl = level[k];
+    const bool ok = (!in_view || in_view[k]) && lvl >= 0 && lvl < nlevels;
+    float r = (view_cos[k] > 0.998f) ? 2.5f : 4.0f;   // :146 RadiusByViewingCos
+    if (th != 1.0f) r = __fmul_rn(r, th);
+    qr[k] = ok ? __fmul_rn(r, scale[lvl]) : 0.f;
+    qmin[k] = lvl - 1;
+    qmax[k] = lvl;
+    qvalid[k] = ok ? 1 : 0;
+}
+
 // candidate key of the grid scan: dist << 32 | seq << 16 | idx, seq = position in the reference's candidate enumeration
 __device__ __forceinline__ u64 seq_key(int dist, int seq, int idx) {
     return ((u64)(uint32_t)dist << 32) | ((u64)(uint32_t)seq << 16) | (u64)(uint32_t)idx;

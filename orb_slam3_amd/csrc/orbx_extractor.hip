@@ -180,9 +180,10 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
 
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
     ex->copy_pending = false; ex->match_pending = false; ex->copy_issued = ex->copy_waited = 0;
     ex->mkey = orbx_extractor::MatchKey();
+    ex->mpkey = orbx_extractor::MpKey();
     const int B = std::max(batch, ex->batch_cap);
     int r;
 #define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
@@ -252,7 +253,7 @@ struct ProfScope {
 
 // enqueue the whole extraction of `n` device-resident frames on ex->stream
 static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride,
-                           int lap0, int lap1) {
+                           int lap0, int lap1, hipEvent_t ev_input_consumed = nullptr) {
     const int nl = ex->prm.nlevels;
     const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
     uint8_t *pyr = (uint8_t *)ex->d_pyr.p;
@@ -264,6 +265,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, d_lv, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
                            (int32_t *)ex->d_fast_ovf.p);
     }
+    if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, st));  // k_pyr_base is the only reader of the input frames
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
@@ -468,6 +470,8 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 64) ex->fast_wave_qcap = atoi(v) & ~15; }  // test hook: force k_fast_overflow
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, use_prio == 2 ? prio_lo : prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
+    (void)hipStreamCreateWithPriority(&ex->in_stream, hipStreamNonBlocking, prio_hi);
+    for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[0], hipEventDisableTiming);
@@ -504,8 +508,10 @@ void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream})
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream})
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
+    ex->d_in[0].release(); ex->d_in[1].release();
     for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
     if (ex->ev_compute_done) (void)hipEventDestroy(ex->ev_compute_done);
     for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
@@ -515,7 +521,9 @@ void orbx_destroy(orbx_extractor *ex) {
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
-                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg, &ex->d_xgtab};
+                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg, &ex->d_xgtab,
+                      &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
+                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);
@@ -535,6 +543,40 @@ int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int n
     return enqueue_extract(ex, d_images, n_frames, row_stride, frame_stride, lap0, lap1);
 }
 
+int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_frames, int width, int height,
+                            size_t row_stride, size_t frame_stride, int lap0, int lap1) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    if (!h_images || width <= 0 || height <= 0 || n_frames <= 0) return ORBX_E_EMPTY;
+    if (row_stride < (size_t)width || frame_stride < row_stride * (size_t)height) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    int r = configure(ex, width, height, n_frames);
+    if (r != ORBX_OK) return r;
+    const unsigned slot = ex->in_issued & 1u;
+    orbx::DevBuf &din = ex->d_in[slot];
+    const size_t fbytes = (size_t)width * height, need = fbytes * n_frames;
+    if (need > din.bytes) {  // growing: nothing may still read the old slab
+        ORBX_HIP(hipStreamSynchronize(ex->stream));
+        ORBX_HIP(hipStreamSynchronize(ex->in_stream));
+        if ((r = din.ensure(need)) != ORBX_OK) return r;
+        ex->in_used[slot] = false;
+    }
+    hipStream_t is = ex->in_stream;
+    if (ex->in_used[slot]) ORBX_HIP(hipStreamWaitEvent(is, ex->ev_in_free[slot], 0));  // the batch that last used this slab
+    if (frame_stride == row_stride * (size_t)height) {  // rows of all frames equally spaced: one (2-D) copy into the packed slab
+        if (row_stride == (size_t)width) ORBX_HIP(hipMemcpyAsync(din.p, h_images, need, hipMemcpyHostToDevice, is));
+        else ORBX_HIP(hipMemcpy2DAsync(din.p, width, h_images, row_stride, width, (size_t)height * n_frames, hipMemcpyHostToDevice, is));
+    } else {
+        for (int f = 0; f < n_frames; f++)
+            ORBX_HIP(hipMemcpy2DAsync((uint8_t *)din.p + f * fbytes, width, h_images + f * frame_stride, row_stride, width, height,
+                                      hipMemcpyHostToDevice, is));
+    }
+    ORBX_HIP(hipEventRecord(ex->ev_in_ready[slot], is));
+    ORBX_HIP(hipStreamWaitEvent(ex->stream, ex->ev_in_ready[slot], 0));
+    ex->in_used[slot] = true;
+    ex->in_issued++;
+    return enqueue_extract(ex, (const uint8_t *)din.p, n_frames, width, fbytes, lap0, lap1, ex->ev_in_free[slot]);
+}
+
 int orbx_output_capacity(orbx_extractor *ex, int width, int height) {
     if (!ex) return ORBX_E_BAD_ARG;
     if (hipSetDevice(ex->device) != hipSuccess) return ORBX_E_HIP;
@@ -549,6 +591,7 @@ int orbx_sync(orbx_extractor *ex) {
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     ORBX_HIP(hipStreamSynchronize(ex->aux_stream));
     ORBX_HIP(hipStreamSynchronize(ex->match_stream));
+    ORBX_HIP(hipStreamSynchronize(ex->in_stream));
     return ORBX_OK;
 }
 

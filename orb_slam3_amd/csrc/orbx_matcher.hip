@@ -676,6 +676,10 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     const int np = n - 1, cap = ex->cap;
     int r;
     if (!d_match || !d_nmatches) {  // internal result buffers (downloaded by orbx_batch_download_async)
+        if (ex->d_match.bytes < 4 * (size_t)cap * ex->batch_cap || ex->d_nmatch.bytes < 4 * (size_t)ex->batch_cap) {
+            // growing frees the old buffers: an earlier matcher / download may still be using them
+            ORBX_HIP(hipStreamSynchronize(ex->match_stream)); ORBX_HIP(hipStreamSynchronize(ex->copy_stream));
+        }
         if ((r = ex->d_match.ensure(4 * (size_t)cap * ex->batch_cap)) != ORBX_OK) return r;
         if ((r = ex->d_nmatch.ensure(4 * (size_t)ex->batch_cap)) != ORBX_OK) return r;
         d_match = (int32_t *)ex->d_match.p;
@@ -689,6 +693,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     const bool cached = old.n == key.n && old.cap == key.cap && old.match == key.match && old.nm == key.nm && old.th == key.th &&
                         old.du == key.du && old.dv == key.dv && old.ori == key.ori && old.kps == key.kps;
     if (!cached) {  // (re)build the per-pair problem descriptors; steady-state batches reuse them without any host sync
+        ORBX_HIP(hipStreamSynchronize(ex->match_stream));   // the scratch below may be in use by the previous batch's matcher
 #define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
         ENS(ex->d_mkey1, 8 * (size_t)kTopK * cap * np);
         ENS(ex->d_mkey2, 4 * (size_t)cap * np);
@@ -752,6 +757,109 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
         ex->prof_ms[K_MATCH_RESOLVE] += t; ex->prof_n[K_MATCH_RESOLVE]++;
     }
+    ORBX_HIP(hipEventRecord(ex->ev_match, ms));
+    ex->match_pending = true;
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SearchByProjection(Frame&, vector<MapPoint*>&, th, bFarPoints, thFarPoints) (ORBmatcher.cc:39-141; Tracking::SearchLocalPoints,
+// Tracking.cc:3390-3413) for every frame of the resident batch against device-resident map-point data: per (frame, map point)
+// the projection (mTrackProjX/Y), predicted level and viewing cosine that Frame::isInFrustum left in the MapPoint, plus the
+// map points' descriptors.  Monocular / Nleft == -1 form with all features free on entry.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, const float *d_proj_x, const float *d_proj_y,
+                                                  const int32_t *d_level, const float *d_view_cos, const uint8_t *d_in_view,
+                                                  const uint8_t *d_mp_desc, size_t desc_frame_stride, float th, float nnratio,
+                                                  int32_t *d_match, int32_t *d_nmatches) {
+    if (!ex || n_mp < 0 || (n_mp > 0 && (!d_proj_x || !d_proj_y || !d_level || !d_view_cos || !d_mp_desc))) return ORBX_E_BAD_ARG;
+    const int n = ex->last_batch;
+    if (n < 1) return ORBX_E_BAD_ARG;
+    if (ex->cap > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;
+    ORBX_HIP(hipSetDevice(ex->device));
+    const int cap = ex->cap;
+    int r;
+    if (!d_match || !d_nmatches) {  // internal result buffers (downloaded by orbx_batch_download_async)
+        if (ex->d_match.bytes < 4 * (size_t)cap * ex->batch_cap || ex->d_nmatch.bytes < 4 * (size_t)ex->batch_cap) {
+            ORBX_HIP(hipStreamSynchronize(ex->match_stream)); ORBX_HIP(hipStreamSynchronize(ex->copy_stream));
+        }
+        if ((r = ex->d_match.ensure(4 * (size_t)cap * ex->batch_cap)) != ORBX_OK) return r;
+        if ((r = ex->d_nmatch.ensure(4 * (size_t)ex->batch_cap)) != ORBX_OK) return r;
+        d_match = (int32_t *)ex->d_match.p;
+        d_nmatches = (int32_t *)ex->d_nmatch.p;
+    }
+    const orbx_keypoint *kps = (const orbx_keypoint *)ex->d_kps.p;
+    orbx_extractor::MpKey key;
+    key.n = n; key.cap = cap; key.n_mp = n_mp; key.px = d_proj_x; key.py = d_proj_y; key.lvl = d_level; key.vc = d_view_cos; key.iv = d_in_view;
+    key.desc = d_mp_desc; key.match = d_match; key.nm = d_nmatches; key.kps = kps; key.dstride = desc_frame_stride; key.th = th; key.ratio = nnratio;
+    const orbx_extractor::MpKey &o = ex->mpkey;
+    const bool cached = o.n == key.n && o.cap == key.cap && o.n_mp == key.n_mp && o.px == key.px && o.py == key.py && o.lvl == key.lvl &&
+                        o.vc == key.vc && o.iv == key.iv && o.desc == key.desc && o.match == key.match && o.nm == key.nm && o.kps == key.kps &&
+                        o.dstride == key.dstride && o.th == key.th && o.ratio == key.ratio;
+    const size_t nq_all = (size_t)std::max(n_mp, 1) * n;
+    if (!cached) {  // (re)build the per-frame problem descriptors; steady-state batches reuse them without a host sync
+        ORBX_HIP(hipStreamSynchronize(ex->match_stream));   // the scratch below may be in use by the previous batch's matcher
+#define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
+        ENS(ex->d_mp_qr, 4 * nq_all); ENS(ex->d_mp_qmin, 4 * nq_all); ENS(ex->d_mp_qmax, 4 * nq_all); ENS(ex->d_mp_valid, nq_all);
+        ENS(ex->d_mp_keys, 8 * (size_t)kTopK * nq_all); ENS(ex->d_mp_meta, 4 * nq_all);
+        ENS(ex->d_mp_grid, 2 * ((size_t)kGridCells + 1 + 63 + cap) * n);
+        ENS(ex->d_mp_entries, 4 * nq_all);
+        ENS(ex->d_mp_probs, sizeof(WindowProblem) * (size_t)n);
+        ENS(ex->d_mp_res, sizeof(ResolveProblem) * (size_t)n);
+        ENS(ex->d_mp_misc, 256 + sizeof(float) * ex->prm.nlevels);
+#undef ENS
+        std::vector<WindowProblem> P(n);
+        std::vector<ResolveProblem> R(n);
+        const uint8_t *desc = (const uint8_t *)ex->d_desc.p;
+        const int32_t *count = (const int32_t *)ex->d_count.p;
+        int32_t *d_nq = (int32_t *)ex->d_mp_misc.p;
+        float *d_scale = (float *)((uint8_t *)ex->d_mp_misc.p + 256);
+        for (int f = 0; f < n; f++) {
+            WindowProblem &w = P[f];
+            memset(&w, 0, sizeof(w));
+            w.kps = kps + (size_t)f * cap; w.desc = desc + (size_t)f * cap * 32; w.n_ptr = count + f;
+            w.qx = d_proj_x + (size_t)f * n_mp; w.qy = d_proj_y + (size_t)f * n_mp;
+            w.qr = (const float *)ex->d_mp_qr.p + (size_t)f * n_mp;
+            w.qmin = (const int32_t *)ex->d_mp_qmin.p + (size_t)f * n_mp; w.qmax = (const int32_t *)ex->d_mp_qmax.p + (size_t)f * n_mp;
+            w.qdesc = d_mp_desc + (size_t)f * desc_frame_stride;
+            w.qvalid = (const uint8_t *)ex->d_mp_valid.p + (size_t)f * n_mp;
+            w.nq_ptr = d_nq;
+            w.gstart = (uint16_t *)ex->d_mp_grid.p + (size_t)f * (kGridCells + 64 + cap);
+            w.gorder = w.gstart + kGridCells + 64;
+            w.keys = (u64 *)ex->d_mp_keys.p + (size_t)f * n_mp * kTopK; w.meta = (int32_t *)ex->d_mp_meta.p + (size_t)f * n_mp;
+            ResolveProblem &q = R[f];
+            memset(&q, 0, sizeof(q));
+            q.mode = 1; q.nnratio = nnratio; q.max_dist = (float)ORBX_TH_HIGH;
+            q.match = d_match + (size_t)f * cap; q.nmatches = d_nmatches + f;
+            q.entries = (int32_t *)ex->d_mp_entries.p + (size_t)f * n_mp;
+        }
+        const int32_t nq_host = n_mp;
+        ORBX_HIP(hipMemcpyAsync(d_nq, &nq_host, 4, hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipMemcpyAsync(d_scale, ex->scale.data(), sizeof(float) * ex->prm.nlevels, hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipMemcpyAsync(ex->d_mp_probs.p, P.data(), sizeof(WindowProblem) * n, hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipMemcpyAsync(ex->d_mp_res.p, R.data(), sizeof(ResolveProblem) * n, hipMemcpyHostToDevice, ex->stream));
+        ORBX_HIP(hipStreamSynchronize(ex->stream));  // P/R are host temporaries
+        ex->mpkey = key;
+    }
+    GridParams g;
+    g.minx = 0.f; g.miny = 0.f;
+    g.inv_w = 64.0f / ((float)ex->width - 0.f);
+    g.inv_h = 48.0f / ((float)ex->height - 0.f);
+    const bool side = !ex->profile && ex->side_streams;
+    hipStream_t ms = side ? ex->match_stream : ex->stream;
+    if (side) ORBX_HIP(hipStreamWaitEvent(ms, ex->ev_describe, 0));
+    if (n_mp > 0)
+        hipLaunchKernelGGL(k_mappoint_windows, dim3((n_mp + 255) / 256, n), dim3(256), 0, ms, n_mp, d_level, d_view_cos, d_in_view,
+                           (const float *)((const uint8_t *)ex->d_mp_misc.p + 256), ex->prm.nlevels, th, (float *)ex->d_mp_qr.p,
+                           (int32_t *)ex->d_mp_qmin.p, (int32_t *)ex->d_mp_qmax.p, (uint8_t *)ex->d_mp_valid.p);
+    hipLaunchKernelGGL(k_grid_build, dim3(n), dim3(64), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
+    if (n_mp > 0)
+        hipLaunchKernelGGL(k_window_best2, dim3((n_mp + 15) / 16, n), dim3(256), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
+    if (resolve_lds_bytes(cap) > 64 * 1024)
+        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
+                       (const ResolveProblem *)ex->d_mp_res.p, g, cap);
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
     ex->match_pending = true;
     ORBX_HIP(hipGetLastError());
@@ -823,6 +931,19 @@ extern "C" int orbx_stereo_batch_download(orbx_extractor *L, int frame, float *u
         if (depth) ORBX_HIP(hipMemcpyAsync(depth, (float *)L->d_st_depth.p + (size_t)frame * L->cap, 4 * (size_t)nlv, hipMemcpyDeviceToHost, L->stream));
         ORBX_HIP(hipStreamSynchronize(L->stream));
     }
+    return ORBX_OK;
+}
+
+// all frames of the last stereo batch at once: u_right / depth [n_frames][cap] (-1 where unmatched; entries beyond a frame's
+// keypoint count are unspecified), n_matches [n_frames]; synchronous on the left extractor's stream
+extern "C" int orbx_stereo_batch_download_all(orbx_extractor *L, float *u_right, float *depth, int32_t *n_matches) {
+    if (!L || L->last_batch <= 0 || !L->d_st_ur.p) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(L->device));
+    const size_t n = (size_t)L->last_batch;
+    if (u_right) ORBX_HIP(hipMemcpyAsync(u_right, L->d_st_ur.p, 4 * n * L->cap, hipMemcpyDeviceToHost, L->stream));
+    if (depth) ORBX_HIP(hipMemcpyAsync(depth, L->d_st_depth.p, 4 * n * L->cap, hipMemcpyDeviceToHost, L->stream));
+    if (n_matches) ORBX_HIP(hipMemcpyAsync(n_matches, L->d_st_nm.p, 4 * n, hipMemcpyDeviceToHost, L->stream));
+    ORBX_HIP(hipStreamSynchronize(L->stream));
     return ORBX_OK;
 }
 

@@ -60,6 +60,14 @@ class ORBextractor:
               "orbx_extract_batch_device")
         self._last_shape = (width, height)
 
+    def extract_batch_host(self, h_ptr: int, n_frames: int, width: int, height: int, row_stride: int, frame_stride: int,
+                           vLappingArea=(0, 0)):
+        """Frames in (ideally pinned) host memory; the upload overlaps the previous batch's kernels."""
+        check(self._L.orbx_extract_batch_host(self._h, C.c_void_p(h_ptr), n_frames, width, height, row_stride,
+                                              frame_stride, int(vLappingArea[0]), int(vLappingArea[1])),
+              "orbx_extract_batch_host")
+        self._last_shape = (width, height)
+
     def sync(self):
         check(self._L.orbx_sync(self._h), "orbx_sync")
 
@@ -105,6 +113,20 @@ class ORBextractor:
                                                     C.c_void_p(d_match) if d_match else None,
                                                     C.c_void_p(d_nmatches) if d_nmatches else None),
               "orbx_match_consecutive_device")
+
+    def search_mappoints_batch_device(self, n_mp: int, d_proj_x: int, d_proj_y: int, d_level: int, d_view_cos: int, d_in_view: int,
+                                      d_mp_desc: int, desc_frame_stride=None, th=1.0, nnratio=0.8, d_match: int = 0, d_nmatches: int = 0):
+        """SearchByProjection(Frame, MapPoints) for every frame of the resident batch (device arrays [n_frames][n_mp])."""
+        stride = 32 * n_mp if desc_frame_stride is None else desc_frame_stride
+        vp = C.c_void_p
+        check(self._L.orbx_search_mappoints_batch_device(self._h, n_mp, vp(d_proj_x), vp(d_proj_y), vp(d_level), vp(d_view_cos),
+                                                         vp(d_in_view) if d_in_view else None, vp(d_mp_desc), stride, th, nnratio,
+                                                         vp(d_match) if d_match else None, vp(d_nmatches) if d_nmatches else None),
+              "orbx_search_mappoints_batch_device")
+
+    def stereo_download_all(self, h_ur: int, h_depth: int, h_nm: int):
+        check(self._L.orbx_stereo_batch_download_all(self._h, C.c_void_p(h_ur), C.c_void_p(h_depth), C.c_void_p(h_nm)),
+              "orbx_stereo_batch_download_all")
 
     # ---- Frame::ComputeStereoMatches on two resident batches (self = left extractor) ----
     def stereo_batch_device(self, right: "ORBextractor", bf: float, b: float):

@@ -1,0 +1,169 @@
+"""GPU tests at the bench's shape: B = 256 frames per batch, depth-2 pipeline over >= 20 steps, ALTERNATING inputs (so that
+nothing can pass by re-reading the previous batch's state), host-resident and device-resident input paths, sampled frames
+and match vectors of every step compared bit-for-bit with the CPU oracle.  Also: the batched map-point projection search
+(BASELINE config 4), the host-input entry point and the all-frames stereo download."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H, NF = 752, 480, 1000
+
+
+def _oracle_check_pair(ob, oex, sf, frames, hs, s):
+    """frames s, s+1 of a delivered batch + the match vector of the pair against the oracle."""
+    outs = []
+    for f in (s, s + 1):
+        mono, k, d = oex.extract(frames[f], lap=(0, 1000))
+        n = int(hs["cnt"][f])
+        assert n == len(k) and int(hs["mono"][f]) == mono, (f, n, len(k))
+        assert hs["kps"][f, :n].numpy().tobytes() == k.tobytes(), f
+        assert np.array_equal(hs["desc"][f, :n].numpy(), d), f
+        outs.append((k, d))
+    (k0, d0), (k1, d1) = outs
+    q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
+             desc=d0, has_obs=np.ones(len(k0), np.uint8))
+    grid = ob.OracleGrid(k1, 0.0, float(W), 0.0, float(H))
+    on, ocm = ob.search_by_projection_frame(grid, d1, sf, q, 15.0, 0, True, None, None)
+    assert int(hs["nm"][s + 1]) == on and np.array_equal(hs["match"][s + 1, :len(k1)].numpy(), ocm), s
+    assert on > 200
+
+
+def test_bench_shape_pipeline_alternating_inputs(oracle):
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    B, steps = 256, 24
+    canvases = [synth.make_canvas(10), synth.make_canvas(11)]
+    sets = [np.stack([synth.frame_from_canvas(c, t, W, H, 1000 * (10 + i) + t) for t in range(B)]) for i, c in enumerate(canvases)]
+    d_sets = [torch.from_numpy(x).cuda() for x in sets]
+    h_sets = [torch.from_numpy(x).pin_memory() for x in sets]
+    torch.cuda.synchronize()
+    ex = osa.ORBextractor(NF, 1.2, 8, 20, 7)
+    cap = ex.output_capacity(W, H)
+
+    def host_set():
+        return dict(kps=torch.zeros((B, cap, 28), dtype=torch.uint8).pin_memory(), desc=torch.zeros((B, cap, 32), dtype=torch.uint8).pin_memory(),
+                    cnt=torch.zeros(B, dtype=torch.int32).pin_memory(), mono=torch.zeros(B, dtype=torch.int32).pin_memory(),
+                    match=torch.zeros((B, cap), dtype=torch.int32).pin_memory(), nm=torch.zeros(B, dtype=torch.int32).pin_memory())
+    host = [host_set(), host_set()]
+    oex = oracle.OracleExtractor(NF, 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    rng = np.random.default_rng(3)
+
+    def enqueue(i):
+        k, hs = i % 2, host[i % 2]          # batch i uses input set i % 2 ...
+        if (i // 2) % 2:                     # ... and alternates between the host-input and the device-input entry point
+            ex.extract_batch_host(h_sets[k].data_ptr(), B, W, H, W, W * H, (0, 1000))
+        else:
+            ex.extract_batch_device(d_sets[k].data_ptr(), B, W, H, W, W * H, (0, 1000))
+        ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        ex.download_async(hs["kps"].data_ptr(), hs["desc"].data_ptr(), hs["cnt"].data_ptr(), hs["mono"].data_ptr(),
+                          hs["match"].data_ptr(), hs["nm"].data_ptr())
+
+    for i in range(steps + 1):
+        if i < steps:
+            enqueue(i)
+        if i >= 1:
+            ex.download_wait()
+            j = i - 1
+            # the batch in flight keeps the GPU busy while the oracle checks two random pairs of the delivered one
+            for s in sorted(set(int(x) for x in rng.integers(0, B - 1, 2))) + ([0, B - 2] if j in (0, steps - 1) else []):
+                _oracle_check_pair(oracle, oex, sf, sets[j % 2], host[j % 2], s)
+    ex.sync()
+
+
+def test_extract_batch_host_strided_input_equals_device_path():
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    n, w, h = 5, 640, 400
+    canvas = synth.make_canvas(21)
+    frames = np.stack([synth.frame_from_canvas(canvas, t, w, h, 2100 + t) for t in range(n)])
+    ex = osa.ORBextractor(800, 1.2, 8, 20, 7)
+    ex.extract_batch_device(torch.from_numpy(frames).cuda().data_ptr(), n, w, h, w, w * h, (0, 0))
+    want = [ex.download(f) for f in range(n)]
+    # (a) packed pinned frames; (b) rows padded to 704 bytes; (c) padded rows and a gap between frames
+    for row_stride, gap in ((w, 0), (704, 0), (704, 1000)):
+        fs = row_stride * h + gap
+        buf = torch.zeros(n * fs, dtype=torch.uint8).pin_memory()
+        view = buf.numpy()
+        for f in range(n):
+            view[f * fs:f * fs + row_stride * h].reshape(h, row_stride)[:, :w] = frames[f]
+        for _ in range(3):   # both input slabs get used and re-used
+            ex.extract_batch_host(buf.data_ptr(), n, w, h, row_stride, fs, (0, 0))
+        for f in range(n):
+            mono, k, d = ex.download(f)
+            assert mono == want[f][0] and k.tobytes() == want[f][1].tobytes() and np.array_equal(d, want[f][2]), (row_stride, gap, f)
+
+
+def _make_mappoints(rng, kps_list, desc_list, t, n_mp):
+    src = [s for s in range(max(0, t - 8), t)] or [t]
+    k = np.concatenate([kps_list[s] for s in src])
+    d = np.concatenate([desc_list[s] for s in src])
+    idx = rng.integers(0, len(k), n_mp)
+    k, d = k[idx], d[idx].copy()
+    d ^= np.packbits(rng.random((n_mp, 256)) < 0.04, axis=1, bitorder="little")
+    in_view = (rng.random(n_mp) < 0.95).astype(np.uint8)
+    level = k["octave"].astype(np.int32)
+    level[rng.random(n_mp) < 0.01] = 9        # out-of-range predicted level: skipped
+    vc = rng.uniform(0.9, 1.0, n_mp).astype(np.float32)
+    vc[::7] = 0.999                           # both RadiusByViewingCos branches
+    return dict(proj_x=(k["x"] + rng.normal(0, 2, n_mp)).astype(np.float32), proj_y=(k["y"] + rng.normal(0, 2, n_mp)).astype(np.float32),
+                proj_xr=np.zeros(n_mp, np.float32), level=level, view_cos=vc, desc=d, in_view=in_view, has_obs=np.ones(n_mp, np.uint8))
+
+
+@pytest.mark.parametrize("w,h,nf,n_mp,th", [(1024, 1024, 1500, 10000, 1.0), (752, 480, 1000, 3000, 3.0)])
+def test_search_mappoints_batch_device_equals_oracle(oracle, w, h, nf, n_mp, th):
+    """BASELINE config 4: SearchByProjection(Frame, MapPoints) of every frame of a resident batch against 10 k map points."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    B = 6
+    canvas = synth.make_canvas(4, size=2600, n_shapes=3000)
+    frames = np.stack([synth.frame_from_canvas(canvas, t, w, h, 5000 + t) for t in range(B)])
+    d_frames = torch.from_numpy(frames).cuda()
+    ex = osa.ORBextractor(nf, 1.2, 8, 20, 7)
+    ex.extract_batch_device(d_frames.data_ptr(), B, w, h, w, w * h, (0, 1000))
+    feats = [ex.download(f) for f in range(B)]
+    rng = np.random.default_rng(77)
+    mps = [_make_mappoints(rng, [x[1] for x in feats], [x[2] for x in feats], f, n_mp) for f in range(B)]
+    dev = {k: torch.from_numpy(np.stack([m[k] for m in mps])).cuda() for k in ("proj_x", "proj_y", "level", "view_cos", "desc", "in_view")}
+    cap = ex.batch_view().cap
+    d_match = torch.full((B, cap), -7, dtype=torch.int32, device="cuda")
+    d_nm = torch.full((B,), -7, dtype=torch.int32, device="cuda")
+    for _ in range(2):   # second call = cached problem descriptors
+        ex.search_mappoints_batch_device(n_mp, dev["proj_x"].data_ptr(), dev["proj_y"].data_ptr(), dev["level"].data_ptr(),
+                                         dev["view_cos"].data_ptr(), dev["in_view"].data_ptr(), dev["desc"].data_ptr(), th=th, nnratio=0.8,
+                                         d_match=d_match.data_ptr(), d_nmatches=d_nm.data_ptr())
+    ex.sync()
+    match, nm = d_match.cpu().numpy(), d_nm.cpu().numpy()
+    sf = ex.GetScaleFactors()
+    for f in range(B):
+        _, k, d = feats[f]
+        grid = oracle.OracleGrid(k, 0.0, float(w), 0.0, float(h))
+        on, ofm = oracle.search_by_projection_mappoints(grid, d, sf, mps[f], th, 0.8)
+        assert nm[f] == on and np.array_equal(match[f, :len(k)], ofm), f
+        assert on > 300
+
+
+def test_stereo_download_all_equals_per_frame_download():
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    B, w, h = 4, 1241, 376
+    canvas = synth.make_canvas(30, size=2600, n_shapes=3000)
+    pairs = [synth.make_stereo_pair(30, t, w, h, canvas) for t in range(B)]
+    dl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    dr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    exl, exr = osa.ORBextractor(2000, 1.2, 8, 20, 7), osa.ORBextractor(2000, 1.2, 8, 20, 7)
+    exl.extract_batch_device(dl.data_ptr(), B, w, h, w, w * h, (0, 0))
+    exr.extract_batch_device(dr.data_ptr(), B, w, h, w, w * h, (0, 0))
+    exl.stereo_batch_device(exr, 0.53716 * 718.856, 0.53716)
+    cap = exl.batch_view().cap
+    ur, depth, nm = np.zeros((B, cap), np.float32), np.zeros((B, cap), np.float32), np.zeros(B, np.int32)
+    exl.stereo_download_all(ur.ctypes.data, depth.ctypes.data, nm.ctypes.data)
+    for f in range(B):
+        n1, u1, d1 = exl.stereo_download(f)
+        assert nm[f] == n1 and n1 > 100
+        assert ur[f, :len(u1)].tobytes() == u1.tobytes() and depth[f, :len(d1)].tobytes() == d1.tobytes()

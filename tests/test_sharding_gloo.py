@@ -52,3 +52,43 @@ def test_single_rank_is_identity():
     from orb_slam3_amd import sharding
     assert sharding.sequences_for_rank(3, 1, 0) == [0, 1, 2]
     assert sharding.reduce_throughput(1.5, 42.0) == (1.5, 42.0)
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None) if k not in env_extra else None
+    return subprocess.run([sys.executable, str(root / "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` (no torchrun) starts 2 rank processes itself; dry mode: gloo, no device work."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"ORBX_BENCH_DRY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["config"]["sequences"] == 2 and out["attempts"] == 1
+    # rank r reports 1000 * steps * (r + 1) units: the sum over both ranks arrived on rank 0
+    assert abs(out["value"] * out["ms_per_step"] * 3 / 1e3 * 1e3 - 9000.0) < 9000.0 * 0.02
+
+
+def test_bench_refuses_a_mismatched_world_size():
+    """Under an external launcher --gpus must equal WORLD_SIZE: no silent single-GPU run."""
+    r = _run_bench(["--gpus", "8"], {"ORBX_BENCH_DRY": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_reports_failed_attempts(tmp_path):
+    """A rank that dies makes the launcher retry once and say so; two failures fail the run."""
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--retries", "0"], {"ORBX_BENCH_DRY": "1", "ORBX_BENCH_DRY_FAIL": "always"})
+    assert r.returncode != 0
+    flag = tmp_path / "failed_once"
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"ORBX_BENCH_DRY": "1", "ORBX_BENCH_DRY_FAIL": str(flag)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["attempts"] == 2 and len(out["failed_attempts"]) == 1
