@@ -242,7 +242,8 @@ int orbx_search_by_projection_mappoints(orbx_matcher *m, const orbx_frame_desc *
 /* ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (ORBmatcher.cc:1676-1887) after the
  * adapter has projected the last frame's map points (one query per point that passed the projection gates).
  * level_mode: 0 = [o-1, o+1], 1 = forward [o, inf), 2 = backward [0, o].  Rotation-histogram filter applied when
- * check_orientation != 0.  cur_match[i] = query index or -1.  Returns nmatches. */
+ * check_orientation != 0.  cur_match[i] = query index, -1 (never assigned: the slot keeps what it held), or -2 (assigned by the
+ * loop and then cleared by the rotation check: the reference leaves NULL there, ORBmatcher.cc:1871-1881).  Returns nmatches. */
 int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur, const uint8_t *cur_occupied, int n_q,
                                     const float *q_u, const float *q_v, const float *q_ur, const int32_t *q_octave,
                                     const float *q_angle, const uint8_t *q_desc, const uint8_t *q_has_obs, float th,

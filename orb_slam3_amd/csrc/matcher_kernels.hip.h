@@ -777,6 +777,8 @@ struct ResolveProblem {
     float nnratio;            // M1
     float max_dist;           // accept threshold on the best distance (TH_HIGH, ORBdist, TH_LOW*ratioHamming ...)
     int check_orientation;    // M2
+    int cleared_value;        // what match[i] becomes when the rotation check clears an assignment: -1, or -2 so that the caller can tell
+                              // "never assigned" (slot keeps its old content) from "assigned, then set to NULL" (ORBmatcher.cc:1871-1881)
     const float *q_angle;     // M2 (NULL with q_from_kps)
     const uint8_t *q_has_obs; // NULL = all true
     int32_t *match;           // [n] query index per feature or -1
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         // :1871-1881: every entry of a rejected bin clears its feature and decrements nmatches
         for (int e = lane; e < n_entries; e += 64) {
             const int v = R.entries[e], b = v >> 16;
-            if (b != ind1 && b != ind2 && b != ind3) R.match[v & 0xffff] = -1;
+            if (b != ind1 && b != ind2 && b != ind3) R.match[v & 0xffff] = R.cleared_value;
         }
         int dropped = 0;
         for (int i = 0; i < ORBX_HISTO_LENGTH; i++)

@@ -303,6 +303,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     P.keys = A.take<u64>((size_t)nq * kTopK); P.meta = A.take<int32_t>(nq);
     P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n);
     R.mode = a.mode; R.nnratio = a.nnratio; R.check_orientation = a.check_orientation; R.max_dist = a.max_dist;
+    R.cleared_value = -2;
     if (a.q_angle) { float *p = A.take<float>(nq); H2D(p, a.q_angle, 4 * (size_t)nq); R.q_angle = p; }
     if (a.q_has_obs) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.q_has_obs, (size_t)nq); R.q_has_obs = p; }
     R.match = A.take<int32_t>(n);
@@ -720,7 +721,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
             w.keys = (u64 *)ex->d_mkey1.p + (size_t)p * cap * kTopK; w.meta = (int32_t *)ex->d_mkey2.p + (size_t)p * cap;
             ResolveProblem &q = R[p];
             memset(&q, 0, sizeof(q));
-            q.mode = 2; q.check_orientation = check_orientation; q.max_dist = (float)ORBX_TH_HIGH;
+            q.mode = 2; q.check_orientation = check_orientation; q.max_dist = (float)ORBX_TH_HIGH; q.cleared_value = -1;
             q.match = d_match + (size_t)f * cap; q.nmatches = d_nmatches + f;
             q.entries = (int32_t *)ex->d_mentries.p + (size_t)p * cap;
         }
@@ -830,7 +831,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
             w.keys = (u64 *)ex->d_mp_keys.p + (size_t)f * n_mp * kTopK; w.meta = (int32_t *)ex->d_mp_meta.p + (size_t)f * n_mp;
             ResolveProblem &q = R[f];
             memset(&q, 0, sizeof(q));
-            q.mode = 1; q.nnratio = nnratio; q.max_dist = (float)ORBX_TH_HIGH;
+            q.mode = 1; q.nnratio = nnratio; q.max_dist = (float)ORBX_TH_HIGH; q.cleared_value = -1;
             q.match = d_match + (size_t)f * cap; q.nmatches = d_nmatches + f;
             q.entries = (int32_t *)ex->d_mp_entries.p + (size_t)f * n_mp;
         }

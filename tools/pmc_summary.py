@@ -7,7 +7,7 @@ calibrate on a known byte count in your own access pattern".  Calibration for th
 input exactly once with 4 B/lane loads (known: P = 1,117,367 px/frame x 128 frames = 143.0 MB) and reports
 FETCH_SIZE = 135,301 KiB = 138.5 MB, i.e. factor 0.97 -> our 4-B/lane kernels need NO doubling.  traffic =
 (FETCH_SIZE + WRITE_SIZE) x 1024; the doubled-fetch figure is kept in the CSV as an upper bound.
-Writes profiles/<tag>_pmc_traffic.csv and profiles/pmc_traffic.json (bytes per launch, read by bench.py).
+Writes profiles/<tag>_pmc_traffic.csv (bench.py --pmc measures the dominant kernel's traffic itself, in its own run).
 """
 import csv
 import re
@@ -45,5 +45,4 @@ with open(f"profiles/{tag}_pmc_traffic.csv", "w", newline="") as fh:
     wr = csv.writer(fh)
     wr.writerow(["kernel", "dispatches", "FETCH_SIZE_KiB_avg", "WRITE_SIZE_KiB_avg", "traffic_bytes_per_launch(fetch+write)", "upper_bound(2*fetch+write)"])
     wr.writerows(rows)
-json.dump(js, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(open(f"profiles/{tag}_pmc_traffic.csv").read())
