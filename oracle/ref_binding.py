@@ -144,15 +144,26 @@ class RefVocabulary:
 _matcher = None
 
 
+def _matcher_path():
+    """ORBX_MATCHER_BACKEND=adapter: the same matref_* entry points from libmatcher_adapter.so, i.e. the shim compiled against the
+    product's drop-in adapter (reference signatures -> C ABI -> HIP kernels) instead of the reference's ORBmatcher.cc: every test
+    written against the compiled reference then runs unchanged against the GPU path (tests/test_gpu_adapter_vs_reference.py)."""
+    import os
+    return _DIR / ("libmatcher_adapter.so" if os.environ.get("ORBX_MATCHER_BACKEND") == "adapter" else "libmatcher_ref.so")
+
+
 def matcher_available() -> bool:
-    return (_DIR / "libmatcher_ref.so").exists()
+    return _matcher_path().exists()
 
 
 def _ml():
     global _matcher
     if _matcher is None:
         C.CDLL(str(_DIR.parent / "liborb_oracle.so"), mode=C.RTLD_GLOBAL)
-        L = C.CDLL(str(_DIR / "libmatcher_ref.so"))
+        if _matcher_path().name == "libmatcher_adapter.so":
+            from orb_slam3_amd import _lib
+            _lib.lib()   # liborbx.so (and torch's HIP runtime) first: the adapter library's DT_NEEDED entry resolves to it
+        L = C.CDLL(str(_matcher_path()))
         for name in ("matref_descriptor_distance", "matref_search_by_projection_mappoints", "matref_search_by_projection_frame",
                      "matref_search_by_projection_keyframe", "matref_search_by_projection_sim3", "matref_search_by_bow_frame",
                      "matref_search_by_bow_keyframes", "matref_search_for_initialization", "matref_search_for_triangulation",

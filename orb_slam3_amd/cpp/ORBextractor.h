@@ -67,7 +67,7 @@ public:
                    cv::OutputArray _descriptors, std::vector<int> &vLappingArea) {
         if (_image.empty()) return -1;
         cv::Mat image = _image.getMat();
-        CV_Assert(image.type() == CV_8UC1);
+        if (image.type() != CV_8UC1) throw std::runtime_error("ORBextractor: CV_8UC1 image expected");   // assert(image.type() == CV_8UC1) :1094
         std::vector<orbx_keypoint> kps;
         std::vector<uint8_t> desc;
         const int mono = (*this)(image.data, image.cols, image.rows, image.step, kps, desc, vLappingArea);
@@ -78,18 +78,41 @@ public:
             _descriptors.create((int)kps.size(), 32, CV_8U);
             std::memcpy(_descriptors.getMat().data, desc.data(), desc.size());
         }
-        // keep the public pyramid valid for Frame::ComputeStereoMatches (Frame.cc:818,908,923)
-        mvImagePyramid.resize(nlevels_);
-        for (int l = 0; l < nlevels_; l++) {
-            int w, h;
-            orbx_level_size(ex_, image.cols, image.rows, l, &w, &h);
-            cv::Mat padded(h + 38, w + 38, CV_8UC1);
-            orbx_get_level(ex_, 0, l, padded.data, padded.step);
-            mvImagePyramid[l] = padded(cv::Rect(19, 19, w, h));
-        }
+        // the public pyramid (Frame::ComputeStereoMatches reads it, Frame.cc:818,908,923) is fetched lazily, level by level, on first use
+        mvImagePyramid.reset(this, image.cols, image.rows);
         return mono;
     }
-    std::vector<cv::Mat> mvImagePyramid;
+    // std::vector<cv::Mat> mvImagePyramid of the reference (ORBextractor.h:83), filled on demand: operator[] downloads the level the
+    // first time it is touched after an extraction (one D2H of the padded level, as the reference's parent buffer holds it)
+    class LazyPyramid {
+    public:
+        size_t size() const { return levels_.size(); }
+        int downloads() const { return downloads_; }   // levels fetched from the device so far (diagnostic)
+        cv::Mat &operator[](size_t l) {
+            if (!valid_.at(l)) {
+                int w, h;
+                orbx_level_size(ex_->ex_, width_, height_, (int)l, &w, &h);
+                cv::Mat padded(h + 38, w + 38, CV_8UC1);
+                const int st = orbx_get_level(ex_->ex_, 0, (int)l, padded.data, padded.step);
+                if (st != ORBX_OK) throw std::runtime_error(std::string("orbx_get_level: ") + orbx_status_string(st));
+                levels_[l] = padded(cv::Rect(19, 19, w, h));
+                valid_[l] = true;
+                downloads_++;
+            }
+            return levels_[l];
+        }
+        void reset(ORBextractor *ex, int width, int height) {
+            ex_ = ex; width_ = width; height_ = height;
+            levels_.assign(ex->nlevels_, cv::Mat());
+            valid_.assign(ex->nlevels_, false);
+        }
+    private:
+        ORBextractor *ex_ = nullptr;
+        int width_ = 0, height_ = 0, downloads_ = 0;
+        std::vector<cv::Mat> levels_;
+        std::vector<bool> valid_;
+    };
+    LazyPyramid mvImagePyramid;
 #else
     // mvImagePyramid[level] as a padded host copy: ROI origin = data() + 19*stride + 19
     struct Level { int w = 0, h = 0; size_t stride = 0; std::vector<uint8_t> padded; const uint8_t *roi() const { return padded.data() + 19 * stride + 19; } };

@@ -9,8 +9,11 @@
 #define ORBX_ADAPTER_ORBMATCHER_H
 
 #include <cstdint>
+#include <cstring>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -98,7 +101,7 @@ public:
             q.ur.empty() ? nullptr : q.ur.data(), q.octave.data(), q.angle.data(), q.descriptors.data(),
             q.hasObservations.empty() ? nullptr : q.hasObservations.data(), th, mode, mbCheckOrientation ? 1 : 0, vpMatch.data());
         if (r < 0) throw std::runtime_error(std::string("orbx_search_by_projection_frame: ") + orbx_status_string(r));
-        return r;
+        return r;   // vpMatch[i]: query index, -1 = untouched, -2 = assigned then cleared by the rotation check (slot becomes NULL)
     }
 
     // SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
@@ -268,6 +271,11 @@ public:
         if (r < 0) throw std::runtime_error(std::string("orbx_compute_stereo_matches: ") + orbx_status_string(r));
         return r;
     }
+
+#ifdef ORBX_WITH_SLAM_TYPES
+    // the reference's own signatures (Frame / KeyFrame / MapPoint graphs): see ORBmatcher_slam.inl
+#include "ORBmatcher_slam.inl"
+#endif
 
     orbx_matcher *handle() { return m_; }
 

@@ -1,0 +1,484 @@
+// ORBmatcher_slam.inl -- the REFERENCE signatures of ORBmatcher (/root/reference/include/ORBmatcher.h:47-87) over the C ABI.
+//
+// Included inside class ORB_SLAM3::ORBmatcher (ORBmatcher.h) when ORBX_WITH_SLAM_TYPES is defined, i.e. inside a tree that has
+// Frame / KeyFrame / MapPoint (ORB-SLAM3 itself, or the stand-in types of oracle/mock_slam in this repo's tests).  Each overload
+// does what the reference's member does around its candidate loop -- the same accessor calls, pose transforms, projection gates
+// and write-backs, in the same order -- and hands the candidate search / Hamming / best-second / taken-mask / rotation-histogram
+// part to the device.  Monocular / rectified-stereo forms (Nleft == -1); the fisheye-stereo twins throw until they are wired in.
+//
+// Requires before inclusion: Frame.h, KeyFrame.h, MapPoint.h (and with them cv::Mat, cv::KeyPoint, Sophus::SE3f, Eigen).
+
+private:
+    template <class Holder> static FrameView view_of(const Holder &h, const std::vector<cv::KeyPoint> &keysUn, bool withRight) {
+        static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint must be the 28-byte OpenCV layout");
+        FrameView v;
+        v.mvKeysUn = reinterpret_cast<const orbx_keypoint *>(keysUn.data());
+        v.mDescriptors = h.mDescriptors.data;
+        v.N = (int)keysUn.size();
+        v.mnMinX = h.mnMinX; v.mnMaxX = h.mnMaxX; v.mnMinY = h.mnMinY; v.mnMaxY = h.mnMaxY;
+        v.mvScaleFactors = h.mvScaleFactors.data();
+        v.nlevels = (int)h.mvScaleFactors.size();
+        v.mvuRight = (withRight && !h.mvuRight.empty()) ? h.mvuRight.data() : nullptr;
+        return v;
+    }
+    static void push_desc(std::vector<uint8_t> &dst, const cv::Mat &d) { dst.insert(dst.end(), d.data, d.data + 32); }
+    static void require_mono(const Frame &f, const char *what) {
+        if (f.Nleft != -1) throw std::runtime_error(std::string(what) + ": fisheye-stereo (Nleft != -1) form is not wired into this adapter");
+    }
+    static void require_mono(const KeyFrame &kf, const char *what) {
+        if (kf.NLeft != -1) throw std::runtime_error(std::string(what) + ": fisheye-stereo (NLeft != -1) form is not wired into this adapter");
+    }
+
+public:
+    // ORBmatcher.cc:43-213 (Tracking::SearchLocalPoints, Tracking.cc:3390-3413)
+    int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3, const bool bFarPoints = false,
+                           const float thFarPoints = 50.0f) {
+        require_mono(F, "SearchByProjection(Frame, MapPoints)");
+        MapPointBatch b;
+        const size_t n = vpMapPoints.size();
+        b.mTrackProjX.reserve(n); b.descriptors.reserve(32 * n);
+        for (MapPoint *pMP : vpMapPoints) {
+            // :52-59 -- the three skip rules, evaluated per point as the loop does
+            const bool in = pMP->mbTrackInView && !(bFarPoints && pMP->mTrackDepth > thFarPoints) && !pMP->isBad();
+            b.inView.push_back(in ? 1 : 0);
+            b.mTrackProjX.push_back(pMP->mTrackProjX); b.mTrackProjY.push_back(pMP->mTrackProjY);
+            b.mTrackProjXR.push_back(pMP->mTrackProjXR); b.mTrackViewCos.push_back(pMP->mTrackViewCos);
+            b.mnTrackScaleLevel.push_back(pMP->mnTrackScaleLevel);
+            b.hasObservations.push_back(pMP->Observations() > 0 ? 1 : 0);
+            if (in) push_desc(b.descriptors, pMP->GetDescriptor());   // copy under the MapPoint's own mutex
+            else b.descriptors.insert(b.descriptors.end(), 32, 0);
+        }
+        std::vector<uint8_t> occupied(F.N);
+        for (int i = 0; i < F.N; i++) occupied[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;   // :88-90
+        std::vector<int32_t> match;
+        const int nmatches = SearchByProjection(view_of(F, F.mvKeysUn, true), occupied, b, th, match);
+        for (int i = 0; i < F.N; i++)
+            if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];   // :129
+        return nmatches;
+    }
+
+    // ORBmatcher.cc:1676-1887 (Tracking::TrackWithMotionModel)
+    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono) {
+        require_mono(CurrentFrame, "SearchByProjection(Frame, Frame)");
+        require_mono(LastFrame, "SearchByProjection(Frame, Frame)");
+        const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+        const Eigen::Vector3f twc = Tcw.inverse().translation();
+        const Sophus::SE3f Tlw = LastFrame.GetPose();
+        const Eigen::Vector3f tlc = Tlw * twc;
+        const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;    // :1692-1693
+        const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
+        ProjectedQueries q;
+        std::vector<MapPoint *> live;
+        for (int i = 0; i < LastFrame.N; i++) {
+            MapPoint *pMP = LastFrame.mvpMapPoints[i];
+            if (!pMP || LastFrame.mvbOutlier[i]) continue;
+            Eigen::Vector3f x3Dw = pMP->GetWorldPos();
+            Eigen::Vector3f x3Dc = Tcw * x3Dw;
+            const float invzc = 1.0 / x3Dc(2);
+            if (invzc < 0) continue;
+            Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+            if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+            if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+            q.u.push_back(uv(0)); q.v.push_back(uv(1));
+            q.ur.push_back(uv(0) - CurrentFrame.mbf * invzc);             // :1751
+            q.octave.push_back(LastFrame.mvKeys[i].octave);               // :1719
+            q.angle.push_back(LastFrame.mvKeysUn[i].angle);               // :1776
+            q.hasObservations.push_back(pMP->Observations() > 0 ? 1 : 0);
+            push_desc(q.descriptors, pMP->GetDescriptor());
+            live.push_back(pMP);
+        }
+        std::vector<uint8_t> occupied(CurrentFrame.N);
+        for (int i = 0; i < CurrentFrame.N; i++)
+            occupied[i] = (CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;   // :1744-1746
+        std::vector<int32_t> match;
+        const int nmatches = SearchByProjection(view_of(CurrentFrame, CurrentFrame.mvKeysUn, true), occupied, q, th, bForward, bBackward, match);
+        for (int i = 0; i < CurrentFrame.N; i++) {
+            if (match[i] >= 0) CurrentFrame.mvpMapPoints[i] = live[match[i]];                // :1771
+            else if (match[i] == -2) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);   // :1876
+        }
+        return nmatches;
+    }
+
+    // ORBmatcher.cc:1889-2010 (Tracking::Relocalization)
+    int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist) {
+        require_mono(CurrentFrame, "SearchByProjection(Frame, KeyFrame)");
+        const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+        Eigen::Vector3f Ow = Tcw.inverse().translation();
+        const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
+        WindowQueries q;
+        std::vector<MapPoint *> live;
+        for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+            MapPoint *pMP = vpMPs[i];
+            if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+            Eigen::Vector3f x3Dw = pMP->GetWorldPos();
+            Eigen::Vector3f x3Dc = Tcw * x3Dw;
+            const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+            if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+            if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+            Eigen::Vector3f PO = x3Dw - Ow;
+            float dist3D = PO.norm();
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+            q.x.push_back(uv(0)); q.y.push_back(uv(1));
+            q.r.push_back(th * CurrentFrame.mvScaleFactors[nPredictedLevel]);        // :1940
+            q.minLevel.push_back(nPredictedLevel - 1); q.maxLevel.push_back(nPredictedLevel + 1);
+            q.angle.push_back(pKF->mvKeysUn[i].angle);                              // :1973
+            push_desc(q.descriptors, pMP->GetDescriptor());
+            live.push_back(pMP);
+        }
+        std::vector<uint8_t> occupied(CurrentFrame.N);
+        for (int i = 0; i < CurrentFrame.N; i++) occupied[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;   // :1955: any map point blocks the slot
+        std::vector<int32_t> match;
+        const int nmatches = SearchByProjectionWindow(view_of(CurrentFrame, CurrentFrame.mvKeysUn, false), occupied, q, (float)ORBdist,
+                                                      mbCheckOrientation, match);
+        for (int i = 0; i < CurrentFrame.N; i++) {
+            if (match[i] >= 0) CurrentFrame.mvpMapPoints[i] = live[match[i]];
+            else if (match[i] == -2) CurrentFrame.mvpMapPoints[i] = NULL;           // :2001
+        }
+        return nmatches;
+    }
+
+    // ORBmatcher.cc:648-763 (Tracking::MonocularInitialization)
+    int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10) {
+        static_assert(sizeof(cv::Point2f) == 8, "cv::Point2f layout");
+        const int N1 = (int)F1.mvKeysUn.size();
+        std::vector<float> prev(2 * (size_t)N1);
+        for (int i = 0; i < N1; i++) { prev[2 * i] = vbPrevMatched[i].x; prev[2 * i + 1] = vbPrevMatched[i].y; }
+        const int nmatches = SearchForInitialization(reinterpret_cast<const orbx_keypoint *>(F1.mvKeysUn.data()), F1.mDescriptors.data, N1,
+                                                     view_of(F2, F2.mvKeysUn, false), prev, vnMatches12, windowSize);
+        for (int i = 0; i < N1; i++) { vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1]; }   // :757-760
+        return nmatches;
+    }
+
+    // ORBmatcher.cc:223-425 (Tracking::TrackReferenceKeyFrame, Relocalization)
+    int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches) {
+        require_mono(F, "SearchByBoW(KeyFrame, Frame)");
+        const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
+        vpMapPointMatches = std::vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));
+        const int nKF = (int)vpMapPointsKF.size();
+        std::vector<uint8_t> valid(nKF);
+        std::vector<float> angKF(nKF), angF(F.N);
+        for (int i = 0; i < nKF; i++) {
+            MapPoint *pMP = vpMapPointsKF[i];
+            valid[i] = (pMP && !pMP->isBad()) ? 1 : 0;                              // :252-256
+            angKF[i] = pKF->mvKeysUn[i].angle;                                      // :335
+        }
+        for (int i = 0; i < F.N; i++) angF[i] = F.mvKeysUn[i].angle;
+        std::vector<int32_t> match;
+        const int nmatches = SearchByBoW(pKF->mDescriptors.data, angKF.data(), valid.data(), nKF, FeatVec::from(pKF->mFeatVec), F.mDescriptors.data,
+                                         angF.data(), F.N, FeatVec::from(F.mFeatVec), match);
+        for (int i = 0; i < F.N; i++)
+            if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];     // :329
+        return nmatches;
+    }
+
+    // ORBmatcher.cc:765-905 (LoopClosing / place recognition)
+    int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12) {
+        require_mono(*pKF1, "SearchByBoW(KeyFrame, KeyFrame)");
+        const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
+        const std::vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+        vpMatches12 = std::vector<MapPoint *>(n1, static_cast<MapPoint *>(NULL));
+        std::vector<uint8_t> v1(n1), v2(n2);
+        std::vector<float> a1(n1), a2(n2);
+        for (int i = 0; i < n1; i++) { MapPoint *p = vpMapPoints1[i]; v1[i] = (p && !p->isBad()) ? 1 : 0; a1[i] = pKF1->mvKeysUn[i].angle; }
+        for (int i = 0; i < n2; i++) { MapPoint *p = vpMapPoints2[i]; v2[i] = (p && !p->isBad()) ? 1 : 0; a2[i] = pKF2->mvKeysUn[i].angle; }
+        std::vector<int32_t> m12;
+        const int nmatches = SearchByBoW(pKF1->mDescriptors.data, a1.data(), v1.data(), n1, FeatVec::from(pKF1->mFeatVec), pKF2->mDescriptors.data,
+                                         a2.data(), v2.data(), n2, FeatVec::from(pKF2->mFeatVec), m12);
+        for (int i = 0; i < n1; i++)
+            if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];                 // :861
+        return nmatches;
+    }
+
+    // ORBmatcher.cc:2058-2074 on the reference's argument type
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) { return DescriptorDistance((const uint8_t *)a.data, (const uint8_t *)b.data); }
+
+    // ORBmatcher.cc:2012-2053 (kept for callers that build their own histograms)
+    void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3) {
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < L; i++) {
+            const int s = (int)histo[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    }
+
+private:
+    // the projection gates shared by the two Sim3 SearchByProjection overloads (:452-487 / :569-604); proj(p3Dc) -> (u, v)
+    template <class Proj>
+    int sim3_projection(KeyFrame *pKF, Sophus::Sim3f &Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th,
+                        float ratioHamming, Proj proj, std::vector<int32_t> &match, std::vector<int> &live) {
+        Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
+        Eigen::Vector3f Ow = Tcw.inverse().translation();
+        std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+        spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
+        WindowQueries q;
+        live.clear();
+        for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
+            MapPoint *pMP = vpPoints[iMP];
+            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+            Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+            Eigen::Vector3f p3Dc = Tcw * p3Dw;
+            if (p3Dc(2) < 0.0) continue;
+            const Eigen::Vector2f uv = proj(p3Dc);
+            if (!pKF->IsInImage(uv(0), uv(1))) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            Eigen::Vector3f PO = p3Dw - Ow;
+            const float dist = PO.norm();
+            if (dist < minDistance || dist > maxDistance) continue;
+            Eigen::Vector3f Pn = pMP->GetNormal();
+            if (PO.dot(Pn) < 0.5 * dist) continue;
+            int nPredictedLevel = pMP->PredictScale(dist, pKF);
+            q.x.push_back(uv(0)); q.y.push_back(uv(1));
+            q.r.push_back(th * pKF->mvScaleFactors[nPredictedLevel]);
+            q.minLevel.push_back(nPredictedLevel - 1); q.maxLevel.push_back(nPredictedLevel);   // :504-507
+            push_desc(q.descriptors, pMP->GetDescriptor());
+            live.push_back(iMP);
+        }
+        const int N = (int)pKF->mvKeysUn.size();
+        std::vector<uint8_t> occupied(N);
+        for (int i = 0; i < N; i++) occupied[i] = vpMatched[i] ? 1 : 0;   // :499
+        return SearchByProjectionWindow(view_of(*pKF, pKF->mvKeysUn, false), occupied, q, TH_LOW * ratioHamming, false, match);
+    }
+
+public:
+    // ORBmatcher.cc:427-538 (LoopClosing: projection of the loop key frame's covisible map points)
+    int SearchByProjection(KeyFrame *pKF, Sophus::Sim3f &Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th,
+                           float ratioHamming = 1.0) {
+        std::vector<int32_t> match;
+        std::vector<int> live;
+        const int nmatches = sim3_projection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming,
+                                             [&](const Eigen::Vector3f &p) { return pKF->mpCamera->project(p); }, match, live);
+        for (size_t i = 0; i < match.size(); i++)
+            if (match[i] >= 0) vpMatched[i] = vpPoints[live[match[i]]];   // :527
+        return nmatches;
+    }
+
+    // ORBmatcher.cc:540-646 (the variant that also records the key frame each point came from; pinhole projection written out, :573-578)
+    int SearchByProjection(KeyFrame *pKF, Sophus::Sim3<float> &Scw, const std::vector<MapPoint *> &vpPoints, const std::vector<KeyFrame *> &vpPointsKFs,
+                           std::vector<MapPoint *> &vpMatched, std::vector<KeyFrame *> &vpMatchedKF, int th, float ratioHamming = 1.0) {
+        const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+        std::vector<int32_t> match;
+        std::vector<int> live;
+        const int nmatches = sim3_projection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming, [&](const Eigen::Vector3f &p3Dc) {
+            const float invz = 1 / p3Dc(2);
+            const float x = p3Dc(0) * invz, y = p3Dc(1) * invz;
+            return Eigen::Vector2f(fx * x + cx, fy * y + cy);
+        }, match, live);
+        for (size_t i = 0; i < match.size(); i++)
+            if (match[i] >= 0) { vpMatched[i] = vpPoints[live[match[i]]]; vpMatchedKF[i] = vpPointsKFs[live[match[i]]]; }   // :638-639
+        return nmatches;
+    }
+
+    // ORBmatcher.cc:907-1146 (LocalMapping::CreateNewMapPoints).  The epipole-distance test and the camera model's epipolarConstrain
+    // are evaluated by the callback exactly where the reference evaluates them (any GeometricCamera; pinhole key frames may use the
+    // on-device gates through the orbx_pinhole_gate overload instead).
+    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo,
+                               const bool bCoarse = false) {
+        if (pKF1->NLeft != -1 || pKF2->NLeft != -1 || pKF1->mpCamera2 || pKF2->mpCamera2)
+            throw std::runtime_error("SearchForTriangulation: fisheye-stereo pairings are not wired into this adapter");
+        Sophus::SE3f T1w = pKF1->GetPose();
+        Sophus::SE3f T2w = pKF2->GetPose();
+        Sophus::SE3f Tw2 = pKF2->GetPoseInverse();
+        Eigen::Vector3f Cw = pKF1->GetCameraCenter();
+        Eigen::Vector3f C2 = T2w * Cw;
+        Eigen::Vector2f ep = pKF2->mpCamera->project(C2);
+        Sophus::SE3f T12 = T1w * Tw2;
+        Eigen::Matrix3f R12 = T12.rotationMatrix();
+        Eigen::Vector3f t12 = T12.translation();
+        GeometricCamera *pCamera1 = pKF1->mpCamera, *pCamera2 = pKF2->mpCamera;
+        const int n1 = pKF1->N, n2 = pKF2->N;
+        std::vector<uint8_t> skip1(n1), skip2(n2);
+        std::vector<float> a1(n1), a2(n2);
+        for (int i = 0; i < n1; i++) {
+            const bool bStereo1 = pKF1->mvuRight[i] >= 0;
+            skip1[i] = (pKF1->GetMapPoint(i) || (bOnlyStereo && !bStereo1)) ? 1 : 0;   // :971-983
+            a1[i] = pKF1->mvKeysUn[i].angle;
+        }
+        for (int i = 0; i < n2; i++) {
+            const bool bStereo2 = pKF2->mvuRight[i] >= 0;
+            skip2[i] = (pKF2->GetMapPoint(i) || (bOnlyStereo && !bStereo2)) ? 1 : 0;   // :1002-1012
+            a2[i] = pKF2->mvKeysUn[i].angle;
+        }
+        auto gate = [&](size_t idx1, size_t idx2) -> bool {
+            const cv::KeyPoint &kp1 = pKF1->mvKeysUn[idx1];
+            const cv::KeyPoint &kp2 = pKF2->mvKeysUn[idx2];
+            const bool bStereo1 = pKF1->mvuRight[idx1] >= 0, bStereo2 = pKF2->mvuRight[idx2] >= 0;
+            if (!bStereo1 && !bStereo2) {   // :1026-1034
+                const float distex = ep(0) - kp2.pt.x;
+                const float distey = ep(1) - kp2.pt.y;
+                if (distex * distex + distey * distey < 100 * pKF2->mvScaleFactors[kp2.octave]) return false;
+            }
+            return bCoarse || pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, pKF1->mvLevelSigma2[kp1.octave], pKF2->mvLevelSigma2[kp2.octave]);
+        };
+        return SearchForTriangulation(pKF1->mDescriptors.data, a1.data(), skip1.data(), n1, FeatVec::from(pKF1->mFeatVec), pKF2->mDescriptors.data,
+                                      a2.data(), skip2.data(), n2, FeatVec::from(pKF2->mFeatVec), gate, vMatchedPairs);
+    }
+
+    // ORBmatcher.cc:1148-1337 (LocalMapping::SearchInNeighbors)
+    int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th = 3.0, const bool bRight = false) {
+        if (bRight || pKF->NLeft != -1) throw std::runtime_error("Fuse: the right-camera / fisheye-stereo form is not wired into this adapter");
+        Sophus::SE3f Tcw = pKF->GetPose();
+        Eigen::Vector3f Ow = pKF->GetCameraCenter();
+        GeometricCamera *pCamera = pKF->mpCamera;
+        const float &bf = pKF->mbf;
+        FuseQueries q;
+        std::vector<int> live;
+        const int nMPs = (int)vpMapPoints.size();
+        for (int i = 0; i < nMPs; i++) {
+            MapPoint *pMP = vpMapPoints[i];
+            if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+            Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+            Eigen::Vector3f p3Dc = Tcw * p3Dw;
+            if (p3Dc(2) < 0.0f) continue;
+            const float invz = 1 / p3Dc(2);
+            const Eigen::Vector2f uv = pCamera->project(p3Dc);
+            if (!pKF->IsInImage(uv(0), uv(1))) continue;
+            const float ur = uv(0) - bf * invz;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            Eigen::Vector3f PO = p3Dw - Ow;
+            const float dist3D = PO.norm();
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            Eigen::Vector3f Pn = pMP->GetNormal();
+            if (PO.dot(Pn) < 0.5 * dist3D) continue;
+            int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+            q.u.push_back(uv(0)); q.v.push_back(uv(1)); q.ur.push_back(ur);
+            q.radius.push_back(th * pKF->mvScaleFactors[nPredictedLevel]);
+            q.nPredictedLevel.push_back(nPredictedLevel);
+            push_desc(q.descriptors, pMP->GetDescriptor());
+            live.push_back(i);
+        }
+        std::vector<int32_t> bestIdx, bestDist;
+        FuseSearch(view_of(*pKF, pKF->mvKeysUn, true), pKF->mvInvLevelSigma2.data(), q, bestIdx, bestDist);
+        int nFused = 0;
+        for (size_t k = 0; k < live.size(); k++) {   // the reference's tail, in its order, on the live graph (:1309-1330)
+            MapPoint *pMP = vpMapPoints[live[k]];
+            if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;   // an earlier iteration's Replace / AddObservation may have retired this query
+            if (bestIdx[k] < 0 || bestDist[k] > TH_LOW) continue;
+            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx[k]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx[k]);
+                pKF->AddMapPoint(pMP, bestIdx[k]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    // ORBmatcher.cc:1339-1455 (LoopClosing::SearchAndFuse)
+    int Fuse(KeyFrame *pKF, Sophus::Sim3f &Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint) {
+        Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
+        Eigen::Vector3f Ow = Tcw.inverse().translation();
+        const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();
+        FuseQueries q;
+        std::vector<int> live;
+        const int nPoints = (int)vpPoints.size();
+        for (int iMP = 0; iMP < nPoints; iMP++) {
+            MapPoint *pMP = vpPoints[iMP];
+            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+            Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+            Eigen::Vector3f p3Dc = Tcw * p3Dw;
+            if (p3Dc(2) < 0.0f) continue;
+            const Eigen::Vector2f uv = pKF->mpCamera->project(p3Dc);
+            if (!pKF->IsInImage(uv(0), uv(1))) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            Eigen::Vector3f PO = p3Dw - Ow;
+            const float dist3D = PO.norm();
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            Eigen::Vector3f Pn = pMP->GetNormal();
+            if (PO.dot(Pn) < 0.5 * dist3D) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+            q.u.push_back(uv(0)); q.v.push_back(uv(1));
+            q.radius.push_back(th * pKF->mvScaleFactors[nPredictedLevel]);
+            q.nPredictedLevel.push_back(nPredictedLevel);
+            push_desc(q.descriptors, pMP->GetDescriptor());
+            live.push_back(iMP);
+        }
+        std::vector<int32_t> bestIdx, bestDist;
+        FuseSearch(view_of(*pKF, pKF->mvKeysUn, false), nullptr, q, bestIdx, bestDist);
+        int nFused = 0;
+        for (size_t k = 0; k < live.size(); k++) {   // :1436-1449
+            if (bestIdx[k] < 0 || bestDist[k] > TH_LOW) continue;
+            MapPoint *pMP = vpPoints[live[k]];
+            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx[k]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[live[k]] = pMPinKF;
+            } else {
+                pMP->AddObservation(pKF, bestIdx[k]);
+                pKF->AddMapPoint(pMP, bestIdx[k]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
+    // ORBmatcher.cc:1457-1674 (LoopClosing: guided matching after the Sim3 estimate)
+    int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const Sophus::Sim3f &S12, const float th) {
+        const float &fx = pKF1->fx, &fy = pKF1->fy, &cx = pKF1->cx, &cy = pKF1->cy;
+        Sophus::SE3f T1w = pKF1->GetPose();
+        Sophus::SE3f T2w = pKF2->GetPose();
+        Sophus::Sim3f S21 = S12.inverse();
+        const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
+        const int N1 = (int)vpMapPoints1.size();
+        const std::vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int N2 = (int)vpMapPoints2.size();
+        std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+        for (int i = 0; i < N1; i++) {
+            MapPoint *pMP = vpMatches12[i];
+            if (pMP) {
+                vbAlreadyMatched1[i] = true;
+                int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
+                if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+            }
+        }
+        // one query slot per key-frame feature (use == 0: no / bad / already matched map point or a failed gate)
+        auto side = [&](const std::vector<MapPoint *> &mps, const std::vector<bool> &done, auto toOther, KeyFrame *pKFo, FuseQueries &q,
+                        std::vector<uint8_t> &use) {
+            const int N = (int)mps.size();
+            use.assign(N, 0);
+            q.u.assign(N, 0.f); q.v.assign(N, 0.f); q.radius.assign(N, 0.f); q.nPredictedLevel.assign(N, 0); q.descriptors.assign(32 * (size_t)N, 0);
+            for (int i = 0; i < N; i++) {
+                MapPoint *pMP = mps[i];
+                if (!pMP || done[i] || pMP->isBad()) continue;
+                Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+                Eigen::Vector3f p3Dc = toOther(p3Dw);
+                if (p3Dc(2) < 0.0) continue;
+                const float invz = 1.0 / p3Dc(2);
+                const float x = p3Dc(0) * invz, y = p3Dc(1) * invz;
+                const float u = fx * x + cx, v = fy * y + cy;
+                if (!pKFo->IsInImage(u, v)) continue;
+                const float maxDistance = pMP->GetMaxDistanceInvariance();
+                const float minDistance = pMP->GetMinDistanceInvariance();
+                const float dist3D = p3Dc.norm();
+                if (dist3D < minDistance || dist3D > maxDistance) continue;
+                const int nPredictedLevel = pMP->PredictScale(dist3D, pKFo);
+                q.u[i] = u; q.v[i] = v; q.radius[i] = th * pKFo->mvScaleFactors[nPredictedLevel]; q.nPredictedLevel[i] = nPredictedLevel;
+                const cv::Mat d = pMP->GetDescriptor();
+                std::memcpy(&q.descriptors[32 * (size_t)i], d.data, 32);
+                use[i] = 1;
+            }
+        };
+        FuseQueries q1, q2;
+        std::vector<uint8_t> use1, use2;
+        side(vpMapPoints1, vbAlreadyMatched1, [&](const Eigen::Vector3f &p) { Eigen::Vector3f c1 = T1w * p; Eigen::Vector3f c2 = S21 * c1; return c2; }, pKF2, q1, use1);
+        side(vpMapPoints2, vbAlreadyMatched2, [&](const Eigen::Vector3f &p) { Eigen::Vector3f c2 = T2w * p; Eigen::Vector3f c1 = S12 * c2; return c1; }, pKF1, q2, use2);
+        std::vector<int32_t> m12;
+        const int nFound = SearchBySim3(view_of(*pKF1, pKF1->mvKeysUn, false), view_of(*pKF2, pKF2->mvKeysUn, false), q1, use1, q2, use2, m12);
+        for (int i1 = 0; i1 < N1; i1++)
+            if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];   // :1668
+        return nFound;
+    }

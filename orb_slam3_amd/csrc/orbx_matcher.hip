@@ -337,7 +337,7 @@ int orbx_search_by_projection_mappoints(orbx_matcher *m, const orbx_frame_desc *
                                         const int32_t *pred_level, const float *view_cos, const uint8_t *mp_desc,
                                         const uint8_t *mp_in_view, const uint8_t *mp_has_obs, float th, float nnratio,
                                         int32_t *frame_match) {
-    if (!m || !frame || !frame_match || n_mp < 0) return ORBX_E_BAD_ARG;
+    if (!m || !frame || frame->n < 0 || (!frame_match && frame->n > 0) || n_mp < 0) return ORBX_E_BAD_ARG;   // empty frames / query sets are legal
     if (n_mp > 0 && (!proj_x || !proj_y || !pred_level || !view_cos || !mp_desc)) return ORBX_E_BAD_ARG;
     // per-query window: r = RadiusByViewingCos(viewCos) [* th] * scale[level], levels [lvl-1, lvl]  (ORBmatcher.cc:63-72)
     std::vector<float> qr(n_mp);
@@ -361,7 +361,7 @@ int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur,
                                     const float *q_u, const float *q_v, const float *q_ur, const int32_t *q_octave,
                                     const float *q_angle, const uint8_t *q_desc, const uint8_t *q_has_obs, float th, int level_mode,
                                     int check_orientation, int32_t *cur_match) {
-    if (!m || !cur || !cur_match || n_q < 0) return ORBX_E_BAD_ARG;
+    if (!m || !cur || cur->n < 0 || (!cur_match && cur->n > 0) || n_q < 0) return ORBX_E_BAD_ARG;
     if (n_q > 0 && (!q_u || !q_v || !q_octave || !q_desc || (check_orientation && !q_angle))) return ORBX_E_BAD_ARG;
     std::vector<float> qr(n_q);
     std::vector<int32_t> qmin(n_q), qmax(n_q);
@@ -385,7 +385,7 @@ extern "C" int orbx_search_by_projection_window(orbx_matcher *m, const orbx_fram
                                                 const float *q_x, const float *q_y, const float *q_r, const int32_t *q_min_level,
                                                 const int32_t *q_max_level, const float *q_angle, const uint8_t *q_desc,
                                                 const uint8_t *q_has_obs, float max_dist, int check_orientation, int32_t *match) {
-    if (!m || !frame || !match || n_q < 0) return ORBX_E_BAD_ARG;
+    if (!m || !frame || frame->n < 0 || (!match && frame->n > 0) || n_q < 0) return ORBX_E_BAD_ARG;
     if (n_q > 0 && (!q_x || !q_y || !q_r || !q_min_level || !q_max_level || !q_desc || (check_orientation && !q_angle))) return ORBX_E_BAD_ARG;
     ProjArgs a = {frame, occupied, n_q, q_x, q_y, q_r, nullptr, q_min_level, q_max_level, q_desc, nullptr, q_has_obs,
                   q_angle, 2, 0.f, check_orientation, match, max_dist};
@@ -474,7 +474,7 @@ extern "C" {
 // ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763): k_replay_init
 int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un, const uint8_t *desc1, int n1, const orbx_frame_desc *F2,
                                    float *prev_matched, int window_size, float nnratio, int check_orientation, int32_t *matches12) {
-    if (!m || !F2 || !matches12 || n1 < 0 || (n1 > 0 && (!kps1_un || !desc1 || !prev_matched))) return ORBX_E_BAD_ARG;
+    if (!m || !F2 || n1 < 0 || (n1 > 0 && (!matches12 || !kps1_un || !desc1 || !prev_matched))) return ORBX_E_BAD_ARG;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     const int n2 = F2->n;
     if (n1 == 0 || n2 == 0) return 0;
@@ -585,7 +585,7 @@ extern "C" {
 int orbx_search_by_bow_frame(orbx_matcher *m, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
                              const orbx_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f, const orbx_featvec *f_fv,
                              float nnratio, int check_orientation, int32_t *f_match) {
-    if (!m || !kf_fv || !f_fv || !f_match || n_kf < 0 || n_f < 0) return ORBX_E_BAD_ARG;
+    if (!m || !kf_fv || !f_fv || (!f_match && n_f > 0) || n_kf < 0 || n_f < 0) return ORBX_E_BAD_ARG;
     for (int i = 0; i < n_f; i++) f_match[i] = -1;
     if (n_kf == 0 || n_f == 0) return 0;
     std::vector<uint8_t> skip(n_kf);
@@ -598,7 +598,7 @@ int orbx_search_by_bow_frame(orbx_matcher *m, const uint8_t *kf_desc, const floa
 int orbx_search_by_bow_keyframes(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
                                  const orbx_featvec *fv1, const uint8_t *desc2, const float *angle2, const uint8_t *valid2, int n2,
                                  const orbx_featvec *fv2, float nnratio, int check_orientation, int32_t *match12) {
-    if (!m || !fv1 || !fv2 || !match12 || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
+    if (!m || !fv1 || !fv2 || (!match12 && n1 > 0) || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
     for (int i = 0; i < n1; i++) match12[i] = -1;
     if (n1 == 0 || n2 == 0) return 0;
     std::vector<uint8_t> skip1(n1), skip2(n2);
@@ -612,7 +612,7 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
                                   const orbx_featvec *fv1, const uint8_t *desc2, const float *angle2, const uint8_t *skip2, int n2,
                                   const orbx_featvec *fv2, int check_orientation, orbx_pair_predicate pair_ok, void *user,
                                   int32_t *matches12) {
-    if (!m || !fv1 || !fv2 || !matches12 || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
+    if (!m || !fv1 || !fv2 || (!matches12 && n1 > 0) || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return 0;
     // without a geometric gate (bCoarse) nothing but distances decides: the whole loop runs on the device (k_replay_bow mode 2).
@@ -650,7 +650,7 @@ int orbx_search_for_triangulation(orbx_matcher *m, const uint8_t *desc1, const f
 int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbx_featvec *fv1,
                                           const uint8_t *desc2, const uint8_t *skip2, int n2, const orbx_featvec *fv2,
                                           int check_orientation, const orbx_pinhole_gate *gate, int32_t *matches12) {
-    if (!m || !fv1 || !fv2 || !matches12 || !gate || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
+    if (!m || !fv1 || !fv2 || (!matches12 && n1 > 0) || !gate || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
     if (!gate->kps1_un || !gate->kps2_un || !gate->scale_factors2 || !gate->level_sigma2_2 || gate->nlevels <= 0 || gate->nlevels > 64)
         return ORBX_E_BAD_ARG;
     for (int i = 0; i < n1; i++) matches12[i] = -1;

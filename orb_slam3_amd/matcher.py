@@ -175,8 +175,9 @@ class ORBmatcher:
         return n, fm
 
     # ---- SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (ORBmatcher.cc:1676-1887) ----
-    def SearchByProjectionFrame(self, Cur: FrameView, q: dict, th: float, level_mode: int = 0, cur_occupied=None):
-        """q: u, v, ur, octave, angle, desc, has_obs (last-frame map points already projected into Cur)."""
+    def SearchByProjectionFrame(self, Cur: FrameView, q: dict, th: float, level_mode: int = 0, cur_occupied=None, raw=False):
+        """q: u, v, ur, octave, angle, desc, has_obs (last-frame map points already projected into Cur).
+        raw=True keeps the C ABI's -2 for "assigned, then cleared by the rotation check" (the slot becomes NULL in the reference)."""
         fd = Cur.c_struct()
         nq = len(q["u"])
         cm = np.full(fd.n, -1, np.int32)
@@ -187,12 +188,12 @@ class ORBmatcher:
             self._h, C.byref(fd), ptr(occ), nq, ptr(a["u"]), ptr(a["v"]), ptr(a["ur"]), ptr(a["o"]), ptr(a["ang"]),
             ptr(a["d"]), ptr(a["ho"]), th, level_mode, int(self.mbCheckOrientation), ptr(cm)),
             "orbx_search_by_projection_frame")
-        return n, cm
+        return n, (cm if raw else np.maximum(cm, -1))
 
     # ---- general window form: M3 = SearchByProjection(Frame&, KeyFrame*, ...) (ORBmatcher.cc:1889-2010) and
     #      M4 = SearchByProjection(KeyFrame*, Sim3f&, ...) (ORBmatcher.cc:427-646) ----
-    def SearchByProjectionWindow(self, F: FrameView, q: dict, max_dist: float, check_orientation: bool, occupied=None):
-        """q: x, y, r, min_level, max_level, angle, desc[, has_obs]."""
+    def SearchByProjectionWindow(self, F: FrameView, q: dict, max_dist: float, check_orientation: bool, occupied=None, raw=False):
+        """q: x, y, r, min_level, max_level, angle, desc[, has_obs].  raw: see SearchByProjectionFrame."""
         fd = F.c_struct()
         nq = len(q["x"])
         match = np.full(fd.n, -1, np.int32)
@@ -203,7 +204,7 @@ class ORBmatcher:
             self._h, C.byref(fd), ptr(occ), nq, ptr(a["x"]), ptr(a["y"]), ptr(a["r"]), ptr(a["lo"]), ptr(a["hi"]),
             ptr(a["ang"]), ptr(a["d"]), ptr(a["ho"]), max_dist, int(check_orientation), ptr(match)),
             "orbx_search_by_projection_window")
-        return n, match
+        return n, (match if raw else np.maximum(match, -1))
 
     # ---- SearchForInitialization (ORBmatcher.cc:648-763) ----
     def SearchForInitialization(self, kps1_un, desc1, F2: FrameView, vbPrevMatched, windowSize=100):
