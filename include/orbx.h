@@ -319,6 +319,35 @@ int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1,
                                           const uint8_t *desc2, const uint8_t *skip2, int n2, const orbx_featvec *fv2,
                                           int check_orientation, const orbx_pinhole_gate *gate, int32_t *matches12);
 
+/* ---- fisheye-stereo forms (F.Nleft != -1: KannalaBrandt8 stereo rigs, both cameras' features in one Frame) ----
+ * Feature indices follow the reference: [0, n_left) = left camera (F.mvKeys), [n_left, n_left + n_right) = right camera
+ * (F.mvKeysRight); `left` describes the left camera (keypoints_un = mvKeys, n = n_left, image bounds, scale factors) and its
+ * `descriptors` field points at ALL n_left + n_right rows of F.mDescriptors; occupied / match arrays cover all features.
+ *
+ * SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) ORBmatcher.cc:43-213 whole: per map point the left search and then
+ * the right-camera twin (:144-210) with mbTrackInViewR / mTrackProjXR,YR / mnTrackScaleLevelR / mTrackViewCosR; an accepted match
+ * is also written to the stereo partner's slot (mvLeftToRightMatch / mvRightToLeftMatch, -1 = none) and counts twice. */
+int orbx_search_by_projection_mappoints_fisheye(orbx_matcher *m, const orbx_frame_desc *left, const orbx_keypoint *kps_right, int n_right,
+                                                const int32_t *left_to_right, const int32_t *right_to_left, const uint8_t *frame_occupied,
+                                                int n_mp, const uint8_t *in_view, const float *proj_x, const float *proj_y,
+                                                const int32_t *pred_level, const float *view_cos, const uint8_t *in_view_r,
+                                                const float *proj_xr, const float *proj_yr, const int32_t *pred_level_r,
+                                                const float *view_cos_r, const uint8_t *mp_desc, const uint8_t *mp_has_obs, float th,
+                                                float nnratio, int32_t *frame_match);
+/* SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) ORBmatcher.cc:1676-1887 incl. the right-camera twin :1794-1863:
+ * (q_u, q_v) = projection into the left camera, (q_ur, q_vr) = projection of Trl * x3Dc into the right camera.  cur_match as in
+ * orbx_search_by_projection_frame (-2 = assigned, then cleared by the rotation check). */
+int orbx_search_by_projection_frame_fisheye(orbx_matcher *m, const orbx_frame_desc *left, const orbx_keypoint *kps_right, int n_right,
+                                            const uint8_t *cur_occupied, int n_q, const float *q_u, const float *q_v, const float *q_ur,
+                                            const float *q_vr, const int32_t *q_octave, const float *q_angle, const uint8_t *q_desc,
+                                            const uint8_t *q_has_obs, float th, int level_mode, int check_orientation, int32_t *cur_match);
+/* SearchByBoW(KeyFrame*, Frame&, ...) for a fisheye-stereo frame, ORBmatcher.cc:283-392: frame features >= n_f_left are the right
+ * camera's; best / second best are kept per camera, the right match is taken only inside the left `bestDist1 <= TH_LOW` branch and
+ * its ratio test is disabled by the reference's `|| true` (:359).  f_angle covers all n_f features (mvKeys then mvKeysRight). */
+int orbx_search_by_bow_frame_fisheye(orbx_matcher *m, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                                     const orbx_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f, int n_f_left,
+                                     const orbx_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match);
+
 /* Device-resident, batched frame-to-frame matcher used by the throughput path: for every frame f >= 1 of the
  * extractor's last batch, the keypoints of frame f-1 (queries, at their own position shifted by (du, dv)) are
  * matched against frame f exactly as orbx_search_by_projection_frame does with level_mode 0, all features free on

@@ -76,7 +76,8 @@ SYMBOLS = [
     "orbx_debug_level_blurred", "orbx_profile_enable", "orbx_profile_read", "orbx_matcher_create",
     "orbx_matcher_destroy", "orbx_hamming_csr", "orbx_hamming_best2_csr", "orbx_knn2", "orbx_stereo_rowband",
     "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
-    "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window",
+    "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window", "orbx_search_by_projection_mappoints_fisheye", "orbx_search_by_projection_frame_fisheye",
+    "orbx_search_by_bow_frame_fisheye",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
     "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
     "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors", "orbx_fuse_search",
@@ -135,6 +136,9 @@ def lib() -> C.CDLL:
                                                       vp, f32, f32, vp]
     L.orbx_search_by_projection_frame.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, vp, f32,
                                                   i32, i32, vp]
+    L.orbx_search_by_projection_mappoints_fisheye.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, i32] + [vp] * 12 + [f32, f32, vp]
+    L.orbx_search_by_projection_frame_fisheye.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, i32] + [vp] * 8 + [f32, i32, i32, vp]
+    L.orbx_search_by_bow_frame_fisheye.argtypes = [vp, vp, vp, vp, i32, C.POINTER(FeatVec), vp, vp, i32, i32, C.POINTER(FeatVec), f32, i32, vp]
     L.orbx_match_consecutive_device.argtypes = [vp, f32, f32, f32, i32, vp, vp]
     L.orbx_stereo_batch_device.argtypes = [vp, vp, f32, f32]
     L.orbx_vocabulary_create.argtypes = [i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]

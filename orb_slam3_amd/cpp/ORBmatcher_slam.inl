@@ -4,7 +4,7 @@
 // Frame / KeyFrame / MapPoint (ORB-SLAM3 itself, or the stand-in types of oracle/mock_slam in this repo's tests).  Each overload
 // does what the reference's member does around its candidate loop -- the same accessor calls, pose transforms, projection gates
 // and write-backs, in the same order -- and hands the candidate search / Hamming / best-second / taken-mask / rotation-histogram
-// part to the device.  Monocular / rectified-stereo forms (Nleft == -1); the fisheye-stereo twins throw until they are wired in.
+// part to the device.  Fisheye-stereo frames (Nleft != -1) take the twin entry points of the C ABI where the reference has a twin.
 //
 // Requires before inclusion: Frame.h, KeyFrame.h, MapPoint.h (and with them cv::Mat, cv::KeyPoint, Sophus::SE3f, Eigen).
 
@@ -33,7 +33,7 @@ public:
     // ORBmatcher.cc:43-213 (Tracking::SearchLocalPoints, Tracking.cc:3390-3413)
     int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3, const bool bFarPoints = false,
                            const float thFarPoints = 50.0f) {
-        require_mono(F, "SearchByProjection(Frame, MapPoints)");
+        if (F.Nleft != -1) return SearchByProjectionFisheye(F, vpMapPoints, th, bFarPoints, thFarPoints);
         MapPointBatch b;
         const size_t n = vpMapPoints.size();
         b.mTrackProjX.reserve(n); b.descriptors.reserve(32 * n);
@@ -57,10 +57,41 @@ public:
         return nmatches;
     }
 
+    // the same member for a fisheye-stereo frame (F.Nleft != -1): left search + right-camera twin per map point, ORBmatcher.cc:43-213 whole
+    int SearchByProjectionFisheye(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints) {
+        const size_t n = vpMapPoints.size();
+        std::vector<uint8_t> inL(n), inR(n), hasObs(n), desc(32 * n, 0);
+        std::vector<float> px(n), py(n), vc(n), pxr(n), pyr(n), vcr(n);
+        std::vector<int32_t> lv(n), lvr(n);
+        for (size_t k = 0; k < n; k++) {
+            MapPoint *pMP = vpMapPoints[k];
+            const bool ok = (pMP->mbTrackInView || pMP->mbTrackInViewR) && !(bFarPoints && pMP->mTrackDepth > thFarPoints) && !pMP->isBad();   // :52-59
+            inL[k] = (ok && pMP->mbTrackInView) ? 1 : 0;
+            inR[k] = (ok && pMP->mbTrackInViewR) ? 1 : 0;
+            px[k] = pMP->mTrackProjX; py[k] = pMP->mTrackProjY; lv[k] = pMP->mnTrackScaleLevel; vc[k] = pMP->mTrackViewCos;
+            pxr[k] = pMP->mTrackProjXR; pyr[k] = pMP->mTrackProjYR; lvr[k] = pMP->mnTrackScaleLevelR; vcr[k] = pMP->mTrackViewCosR;
+            hasObs[k] = pMP->Observations() > 0 ? 1 : 0;
+            if (ok) { const cv::Mat d = pMP->GetDescriptor(); std::memcpy(&desc[32 * k], d.data, 32); }
+        }
+        std::vector<uint8_t> occupied(F.N);
+        for (int i = 0; i < F.N; i++) occupied[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;
+        std::vector<int32_t> match(F.N, -1);
+        FrameView fv = view_of(F, F.mvKeys, false);
+        fv.N = F.Nleft;
+        orbx_frame_desc fd = fv.c();
+        const int nmatches = orbx_search_by_projection_mappoints_fisheye(
+            m_, &fd, reinterpret_cast<const orbx_keypoint *>(F.mvKeysRight.data()), F.N - F.Nleft, F.mvLeftToRightMatch.data(), F.mvRightToLeftMatch.data(),
+            occupied.data(), (int)n, inL.data(), px.data(), py.data(), lv.data(), vc.data(), inR.data(), pxr.data(), pyr.data(), lvr.data(), vcr.data(),
+            desc.data(), hasObs.data(), th, mfNNratio, match.data());
+        if (nmatches < 0) throw std::runtime_error(std::string("orbx_search_by_projection_mappoints_fisheye: ") + orbx_status_string(nmatches));
+        for (int i = 0; i < F.N; i++)
+            if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];
+        return nmatches;
+    }
+
     // ORBmatcher.cc:1676-1887 (Tracking::TrackWithMotionModel)
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono) {
-        require_mono(CurrentFrame, "SearchByProjection(Frame, Frame)");
-        require_mono(LastFrame, "SearchByProjection(Frame, Frame)");
+        const bool fisheye = CurrentFrame.Nleft != -1;
         const Sophus::SE3f Tcw = CurrentFrame.GetPose();
         const Eigen::Vector3f twc = Tcw.inverse().translation();
         const Sophus::SE3f Tlw = LastFrame.GetPose();
@@ -68,6 +99,7 @@ public:
         const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;    // :1692-1693
         const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
         ProjectedQueries q;
+        std::vector<float> vr;   // fisheye-stereo: v of the projection into the right camera (q.ur then holds its u)
         std::vector<MapPoint *> live;
         for (int i = 0; i < LastFrame.N; i++) {
             MapPoint *pMP = LastFrame.mvpMapPoints[i];
@@ -80,9 +112,16 @@ public:
             if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
             if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
             q.u.push_back(uv(0)); q.v.push_back(uv(1));
-            q.ur.push_back(uv(0) - CurrentFrame.mbf * invzc);             // :1751
-            q.octave.push_back(LastFrame.mvKeys[i].octave);               // :1719
-            q.angle.push_back(LastFrame.mvKeysUn[i].angle);               // :1776
+            const bool lastLeft = LastFrame.Nleft == -1 || i < LastFrame.Nleft;
+            q.octave.push_back(lastLeft ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave);   // :1719-1720
+            q.angle.push_back(LastFrame.Nleft == -1 ? LastFrame.mvKeysUn[i].angle                                           // :1776-1778
+                                                    : (lastLeft ? LastFrame.mvKeys[i].angle : LastFrame.mvKeysRight[i - LastFrame.Nleft].angle));
+            if (!fisheye) q.ur.push_back(uv(0) - CurrentFrame.mbf * invzc);   // :1751 (stereo-coordinate gate of the rectified form)
+            else {                                                            // :1795-1796: the point seen from the right camera
+                Eigen::Vector3f x3Dr = CurrentFrame.GetRelativePoseTrl() * x3Dc;
+                Eigen::Vector2f uvr = CurrentFrame.mpCamera->project(x3Dr);
+                q.ur.push_back(uvr(0)); vr.push_back(uvr(1));
+            }
             q.hasObservations.push_back(pMP->Observations() > 0 ? 1 : 0);
             push_desc(q.descriptors, pMP->GetDescriptor());
             live.push_back(pMP);
@@ -91,7 +130,19 @@ public:
         for (int i = 0; i < CurrentFrame.N; i++)
             occupied[i] = (CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;   // :1744-1746
         std::vector<int32_t> match;
-        const int nmatches = SearchByProjection(view_of(CurrentFrame, CurrentFrame.mvKeysUn, true), occupied, q, th, bForward, bBackward, match);
+        int nmatches;
+        if (!fisheye) nmatches = SearchByProjection(view_of(CurrentFrame, CurrentFrame.mvKeysUn, true), occupied, q, th, bForward, bBackward, match);
+        else {
+            match.assign(CurrentFrame.N, -1);
+            FrameView fv = view_of(CurrentFrame, CurrentFrame.mvKeys, false);   // left camera: mvKeys; descriptors: all N rows
+            fv.N = CurrentFrame.Nleft;
+            orbx_frame_desc fd = fv.c();
+            nmatches = orbx_search_by_projection_frame_fisheye(
+                m_, &fd, reinterpret_cast<const orbx_keypoint *>(CurrentFrame.mvKeysRight.data()), CurrentFrame.N - CurrentFrame.Nleft, occupied.data(),
+                (int)q.u.size(), q.u.data(), q.v.data(), q.ur.data(), vr.data(), q.octave.data(), q.angle.data(), q.descriptors.data(),
+                q.hasObservations.data(), th, bForward ? 1 : (bBackward ? 2 : 0), mbCheckOrientation ? 1 : 0, match.data());
+            if (nmatches < 0) throw std::runtime_error(std::string("orbx_search_by_projection_frame_fisheye: ") + orbx_status_string(nmatches));
+        }
         for (int i = 0; i < CurrentFrame.N; i++) {
             if (match[i] >= 0) CurrentFrame.mvpMapPoints[i] = live[match[i]];                // :1771
             else if (match[i] == -2) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);   // :1876
@@ -154,7 +205,6 @@ public:
 
     // ORBmatcher.cc:223-425 (Tracking::TrackReferenceKeyFrame, Relocalization)
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches) {
-        require_mono(F, "SearchByBoW(KeyFrame, Frame)");
         const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
         vpMapPointMatches = std::vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));
         const int nKF = (int)vpMapPointsKF.size();
@@ -165,10 +215,24 @@ public:
             valid[i] = (pMP && !pMP->isBad()) ? 1 : 0;                              // :252-256
             angKF[i] = pKF->mvKeysUn[i].angle;                                      // :335
         }
-        for (int i = 0; i < F.N; i++) angF[i] = F.mvKeysUn[i].angle;
         std::vector<int32_t> match;
-        const int nmatches = SearchByBoW(pKF->mDescriptors.data, angKF.data(), valid.data(), nKF, FeatVec::from(pKF->mFeatVec), F.mDescriptors.data,
-                                         angF.data(), F.N, FeatVec::from(F.mFeatVec), match);
+        int nmatches;
+        if (F.Nleft == -1) {
+            for (int i = 0; i < F.N; i++) angF[i] = F.mvKeysUn[i].angle;
+            nmatches = SearchByBoW(pKF->mDescriptors.data, angKF.data(), valid.data(), nKF, FeatVec::from(pKF->mFeatVec), F.mDescriptors.data,
+                                   angF.data(), F.N, FeatVec::from(F.mFeatVec), match);
+        } else {   // :283-392: the frame's features split into the two cameras; key-frame / frame angles from mvKeys / mvKeysRight (:331-343)
+            for (int i = 0; i < nKF; i++)
+                angKF[i] = (!pKF->mpCamera2) ? pKF->mvKeysUn[i].angle : (i >= pKF->NLeft ? pKF->mvKeysRight[i - pKF->NLeft].angle : pKF->mvKeys[i].angle);
+            for (int i = 0; i < F.N; i++)
+                angF[i] = (i >= F.Nleft) ? F.mvKeysRight[i - F.Nleft].angle : F.mvKeys[i].angle;   // :337-340, :367-370 wherever they are well defined
+            match.assign(F.N, -1);
+            FeatVec fa = FeatVec::from(pKF->mFeatVec), fb = FeatVec::from(F.mFeatVec);
+            orbx_featvec a = fa.c(), b = fb.c();
+            nmatches = orbx_search_by_bow_frame_fisheye(m_, pKF->mDescriptors.data, angKF.data(), valid.data(), nKF, &a, F.mDescriptors.data, angF.data(),
+                                                        F.N, F.Nleft, &b, mfNNratio, mbCheckOrientation ? 1 : 0, match.data());
+            if (nmatches < 0) throw std::runtime_error(std::string("orbx_search_by_bow_frame_fisheye: ") + orbx_status_string(nmatches));
+        }
         for (int i = 0; i < F.N; i++)
             if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];     // :329
         return nmatches;

@@ -494,7 +494,7 @@ struct WindowProblem {
     uint16_t *gorder;           // [n] feature indices
     // outputs
     u64 *keys;                  // per query: the kTopK smallest candidate keys, ascending (kNoKey = none)
-    int32_t *meta;              // per query: valid_len | exhaustive << 8  (see k_window_best2)
+    int32_t *meta;              // per query: valid_len | exhaustive << 8 | empty_window << 9  (see k_window_best2)
 };
 
 // candidate key: dist << 32 | cellx << 24 | celly << 16 | idx   (candidate order of GetFeaturesInArea: ix outer,
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
     if (qvalid && sl == 0) {
 #pragma unroll
         for (int r = 0; r < kTopK; r++) P.keys[(size_t)qi * kTopK + r] = out[r];
-        P.meta[qi] = valid_len | ((total <= valid_len) ? 256 : 0);
+        P.meta[qi] = valid_len | ((total <= valid_len) ? 256 : 0) | ((total == 0) ? 512 : 0);   // bit 9: GetFeaturesInArea returned nothing
     }
 }
 
@@ -989,6 +989,138 @@ __device__ __forceinline__ void dev_three_maxima(const int *hist, int &ind1, int
     ind1 = i1; ind2 = i2; ind3 = i3;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fisheye-stereo twins (F.Nleft != -1) of the two frame projection matchers: every query searches the LEFT camera's grid and
+// then, in the same loop iteration, the RIGHT camera's grid; both searches read and write ONE occupancy / result array over the
+// combined feature index space [0, n_left) left, [n_left, n_left + n_right) right.
+//   mode 1  SearchByProjection(Frame, MapPoints) ORBmatcher.cc:43-213: ratio test between the two best free candidates of one
+//           level (:123-139, :187-195); an accepted match is also written to the stereo partner's slot through
+//           mvLeftToRightMatch / mvRightToLeftMatch and counts twice (:131-135, :197-201); a LEFT ratio rejection `continue`s
+//           past the right twin (:125-126); the twin needs mbTrackInViewR and mnTrackScaleLevelR != -1 (:144-146: folded into
+//           the right problem's qvalid) and uses RadiusByViewingCos without the th factor (:147: folded into its qr)
+//   mode 2  SearchByProjection(Frame, Frame) :1676-1887 with the twin :1794-1863: best free candidate <= TH_HIGH on either side,
+//           rotation-histogram entries for both; an EMPTY left window `continue`s past the twin (:1738-1739)
+// probs[0] / probs[1] = left / right WindowProblem (own grid, own key lists from k_window_best2, occupied0 = NULL: the lists are
+// occupancy-free, occupancy lives here).  ONE wave replays the query loop in the reference's order; the (at most kTopK) listed
+// candidates of the current sub-query are examined by lanes 0..kTopK-1, a list that runs dry before the answer is known makes
+// the whole wave re-scan the window against the current occupancy -- exactly what the sequential loop sees at that point.
+// grid (1), block 64, dynamic LDS: occ[n_left + n_right] bytes
+// ---------------------------------------------------------------------------------------------------------
+struct TwinProblem {
+    int mode;
+    int n_left, n_right, nq;
+    float nnratio, max_dist;
+    int check_orientation, cleared_value;
+    const int32_t *l2r, *r2l;      // mode 1: stereo partners (-1 = none)
+    const uint8_t *occupied0;      // [n_left + n_right] taken on entry, or NULL
+    const uint8_t *q_has_obs;      // [nq] Observations() > 0 of the query's map point, NULL = all true
+    const float *q_angle;          // mode 2: angle of the last frame's keypoint
+    int32_t *match;                // out [n_left + n_right]: query index, -1, or cleared_value
+    int32_t *nmatches;             // out
+    int32_t *entries;              // scratch [2 * nq]: rotation histogram pushes bin << 16 | slot
+};
+
+__global__ __launch_bounds__(64) void k_replay_twin(const WindowProblem *__restrict__ probs, TwinProblem T, GridParams g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t occ[];
+    __shared__ int hist[ORBX_HISTO_LENGTH + 2];
+    const int lane = threadIdx.x;
+    const WindowProblem PL = probs[0], PR = probs[1];
+    const int N = T.n_left + T.n_right;
+    for (int i = lane; i < N; i += 64) {
+        occ[i] = T.occupied0 ? T.occupied0[i] : 0;
+        T.match[i] = -1;
+    }
+    if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0, n_entries = 0;
+    const bool two = (T.mode == 1), ori = (T.mode == 2 && T.check_orientation);
+    for (int iq = 0; iq < T.nq; iq++) {
+        const uint8_t obs = T.q_has_obs ? T.q_has_obs[iq] : (uint8_t)1;
+        bool skip_right = false;
+#pragma unroll 1
+        for (int side = 0; side < 2; side++) {
+            if (side == 1 && skip_right) break;
+            const WindowProblem &P = side ? PR : PL;
+            const int off = side ? T.n_left : 0, nside = side ? T.n_right : T.n_left;
+            if (P.qvalid && !P.qvalid[iq]) continue;
+            const int meta = P.meta[iq];
+            if (meta & 512) {                                   // vIndices.empty()
+                if (T.mode == 2 && side == 0) skip_right = true;
+                continue;
+            }
+            const int valid_len = meta & 0xff;
+            const bool exhaustive = (meta & 256) != 0;
+            u64 k = kNoKey;
+            if (lane < valid_len) k = P.keys[(size_t)iq * kTopK + lane];
+            const bool is_free = (k != kNoKey) && !occ[off + (int)(k & 0xffff)];
+            const u64 fb = __ballot(is_free);
+            u64 c1 = kNoKey, c2 = kNoKey;
+            if (fb) {
+                c1 = __shfl(k, __ffsll((long long)fb) - 1);
+                const u64 rest = fb & (fb - 1ull);
+                if (rest) c2 = __shfl(k, __ffsll((long long)rest) - 1);
+            }
+            const bool need_slow = !exhaustive && (c1 == kNoKey || (two && c2 == kNoKey && (float)(int)(c1 >> 32) <= T.max_dist));
+            if (need_slow) {   // the list ran dry: scan the window against the occupancy of this very moment
+                QueryWin w;
+                Desc dq;
+                u64 r1 = kNoKey, r2 = kNoKey;
+                if (load_query(P, iq, &w, g, &dq)) {
+                    scan_window(P, g, w, dq, nside, occ + off, lane, r1, r2);
+                    wave_min2(r1, r2);
+                }
+                c1 = r1; c2 = r2;
+            }
+            if (c1 == kNoKey) continue;
+            const int bestDist = (int)(c1 >> 32);
+            if ((float)bestDist > T.max_dist) continue;
+            const int t = (int)(c1 & 0xffff);
+            if (two) {
+                const int bestDist2 = (c2 == kNoKey) ? 256 : (int)(c2 >> 32);
+                const int bestLevel = P.kps[t].octave;
+                const int bestLevel2 = (c2 == kNoKey) ? -1 : P.kps[(int)(c2 & 0xffff)].octave;
+                if (bestLevel == bestLevel2 && (float)bestDist > T.nnratio * (float)bestDist2) {
+                    if (side == 0) skip_right = true;           // :125-126: `continue` leaves the whole iteration
+                    continue;
+                }
+            }
+            int np = 1;
+            int partner = -1;
+            if (two) {
+                const int p = side ? T.r2l[t] : T.l2r[t];
+                if (p != -1) { partner = side ? p : T.n_left + p; np = 2; }
+            }
+            if (lane == 0) {
+                T.match[off + t] = iq;
+                occ[off + t] = obs;
+                if (partner >= 0) { T.match[partner] = iq; occ[partner] = obs; }
+                if (ori) {
+                    const int b = dev_rot_bin(T.q_angle[iq], P.kps[t].angle);
+                    T.entries[n_entries] = (b << 16) | (off + t);
+                    hist[b]++;
+                }
+            }
+            nmatches += np;
+            if (ori) n_entries++;
+            __syncthreads();   // single wave: orders lane 0's LDS / global writes before the next sub-query's reads
+        }
+    }
+    __syncthreads();
+    if (ori) {
+        int ind1, ind2, ind3;
+        dev_three_maxima(hist, ind1, ind2, ind3);
+        int dropped = 0;
+        for (int e = lane; e < n_entries; e += 64) {
+            const int v = T.entries[e], b = v >> 16;
+            if (b != ind1 && b != ind2 && b != ind3) { T.match[v & 0xffff] = T.cleared_value; dropped++; }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) dropped += __shfl_xor(dropped, s);
+        nmatches -= dropped;
+    }
+    if (lane == 0) *T.nmatches = nmatches;
+}
+
 struct InitProblem {  // ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763)
     const orbx_keypoint *kps1; const uint8_t *desc1; int n1;
     const orbx_keypoint *kps2; const uint8_t *desc2; int n2;
@@ -1123,6 +1255,7 @@ struct BowProblem {
     const uint8_t *desc_a; const float *angle_a; const uint8_t *skip_a; int na;   // skip_a[i] != 0: feature i of A is not a query
     const uint8_t *desc_b; const float *angle_b; const uint8_t *skip_b; int nb;   // skip_b[i] != 0: feature i of B is never a candidate
     float nnratio; int check_orientation;
+    int nb_left;         // mode 3 = mode 0 for a fisheye-stereo frame (F.Nleft != -1, :283-392): B features >= nb_left are the right camera's
     int32_t *match;      // out: mode 0 [nb] (A index per B feature), modes 1, 2 [na] (B index per A feature)
     uint8_t *taken_b;    // scratch [nb] (mode 1: vbMatched2)
     int32_t *entries;    // scratch [max(na, nb)]
@@ -1132,7 +1265,8 @@ struct BowProblem {
 __global__ __launch_bounds__(64) void k_replay_bow(BowProblem P) {
     __shared__ int hist[ORBX_HISTO_LENGTH];
     const int lane = threadIdx.x;
-    const int nout = P.mode == 0 ? P.nb : P.na;
+    const bool toB = (P.mode == 0 || P.mode == 3);   // results are indexed by B's features
+    const int nout = toB ? P.nb : P.na;
     for (int i = lane; i < nout; i += 64) P.match[i] = -1;
     if (P.mode == 1) for (int i = lane; i < P.nb; i += 64) P.taken_b[i] = 0;
     if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
@@ -1148,11 +1282,11 @@ __global__ __launch_bounds__(64) void k_replay_bow(BowProblem P) {
             const int i = P.fa.index[a];
             if (P.skip_a && P.skip_a[i]) continue;
             const Desc dq = load_desc(P.desc_a + (size_t)i * 32);
-            u64 k1 = kNoKey, k2 = kNoKey;
+            u64 k1 = kNoKey, k2 = kNoKey, r1 = kNoKey, r2 = kNoKey;   // r*: right-camera candidates of mode 3
             for (int b = b0 + lane; b < b1; b += 64) {
                 const int j = P.fb.index[b];
                 if (P.skip_b && P.skip_b[j]) continue;
-                if (P.mode == 0 && P.match[j] >= 0) continue;   // vpMapPointMatches[realIdxF] already set (:281)
+                if (toB && P.match[j] >= 0) continue;           // vpMapPointMatches[realIdxF] already set (:281)
                 if (P.mode == 1 && P.taken_b[j]) continue;      // vbMatched2 (:826)
                 const int d = hamming(dq, load_desc(P.desc_b + (size_t)j * 32));
                 const uint32_t pos = (uint32_t)(b - b0);
@@ -1160,11 +1294,40 @@ __global__ __launch_bounds__(64) void k_replay_bow(BowProblem P) {
                     if (d > ORBX_TH_LOW) continue;               // :1017: '>' twice, so a later equal candidate wins
                     if (P.gate.enabled && !tri_gate(P.gate, i, j)) continue;
                     push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)(0xffffffffu - pos));
+                } else if (P.mode == 3 && j >= P.nb_left) {
+                    push2(r1, r2, ((u64)(uint32_t)d << 32) | (u64)pos);   // :302-315: best / second best kept per camera
                 } else {
                     push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)pos);
                 }
             }
             wave_min2(k1, k2);
+            if (P.mode == 3) {
+                // :318-377: the left match needs bestDist1 <= TH_LOW and the ratio test; the right one is looked at only INSIDE the
+                // bestDist1 <= TH_LOW branch and its ratio test is switched off by `|| true` (:359)
+                wave_min2(r1, r2);
+                if (k1 == kNoKey || (int)(k1 >> 32) > ORBX_TH_LOW) continue;
+                const int bestL = (int)(k1 >> 32);
+                const float secondL = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
+                const int jl = P.fb.index[b0 + (int)(uint32_t)(k1 & 0xffffffffu)];
+                const bool okL = (float)bestL < P.nnratio * secondL;
+                const bool okR = r1 != kNoKey && (int)(r1 >> 32) <= ORBX_TH_LOW;
+                const int jr = okR ? P.fb.index[b0 + (int)(uint32_t)(r1 & 0xffffffffu)] : -1;
+                if (lane == 0) {
+                    if (okL) {
+                        P.match[jl] = i;
+                        if (P.check_orientation) { const int bin = dev_rot_bin(P.angle_a[i], P.angle_b[jl]); hist[bin]++; P.entries[n_entries] = (bin << 16) | jl; }
+                    }
+                    if (okR) {
+                        P.match[jr] = i;
+                        if (P.check_orientation) { const int bin = dev_rot_bin(P.angle_a[i], P.angle_b[jr]); hist[bin]++; P.entries[n_entries + (okL ? 1 : 0)] = (bin << 16) | jr; }
+                    }
+                }
+                nmatches += (okL ? 1 : 0) + (okR ? 1 : 0);
+                if (P.check_orientation) n_entries += (okL ? 1 : 0) + (okR ? 1 : 0);
+                __threadfence_block();
+                __syncthreads();
+                continue;
+            }
             if (k1 == kNoKey) continue;
             const int best = (int)(k1 >> 32);
             const uint32_t pos = P.mode == 2 ? 0xffffffffu - (uint32_t)(k1 & 0xffffffffu) : (uint32_t)(k1 & 0xffffffffu);

@@ -381,6 +381,157 @@ int orbx_search_by_projection_frame(orbx_matcher *m, const orbx_frame_desc *cur,
 
 }  // extern "C"
 
+namespace {
+
+// shared driver of the fisheye-stereo twins of the two frame projection matchers (k_replay_twin)
+struct TwinArgs {
+    const orbx_frame_desc *left;          // left camera: mvKeys, n_left, image bounds, scale factors; descriptors of ALL n_left + n_right features
+    const orbx_keypoint *kps_right; int n_right;
+    const int32_t *l2r, *r2l;
+    const uint8_t *occupied;              // [n_left + n_right]
+    int nq;
+    const float *qx[2], *qy[2], *qr[2];   // per side: window centre and half size
+    const int32_t *qmin[2], *qmax[2];
+    const uint8_t *qvalid[2];
+    const uint8_t *qdesc, *q_has_obs;
+    const float *q_angle;
+    int mode; float nnratio; int check_orientation;
+    int32_t *match_out;
+};
+
+int run_projection_twin(orbx_matcher *m, const TwinArgs &a) {
+    const orbx_frame_desc *F = a.left;
+    const int nl = F->n, nr = a.n_right, N = nl + nr, nq = a.nq;
+    for (int i = 0; i < N; i++) a.match_out[i] = -1;
+    if (N == 0 || nq == 0) return 0;
+    if (N > 60000) return ORBX_E_TOO_LARGE;   // 16-bit feature indices in the candidate keys; occupancy bytes in LDS
+    ORBX_HIP(hipSetDevice(m->device));
+    const size_t need = Arena::pad(28 * (size_t)N) + Arena::pad(32 * (size_t)N) + Arena::pad((size_t)N) + 2 * Arena::pad(4 * (size_t)N) +
+                        2 * (5 * Arena::pad(4 * (size_t)nq) + Arena::pad((size_t)nq) + Arena::pad(8 * (size_t)kTopK * nq) + Arena::pad(4 * (size_t)nq) +
+                             Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)N)) +
+                        Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) + Arena::pad(4 * (size_t)nq) + Arena::pad(8 * (size_t)nq) +
+                        Arena::pad(2 * sizeof(WindowProblem)) + 64 * 256 + 4096;
+    int r = m->arena.reserve(need);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    A.reset();
+    WindowProblem P[2];
+    memset(P, 0, sizeof(P));
+    orbx_keypoint *dk = A.take<orbx_keypoint>(N);
+    uint8_t *dd = A.take<uint8_t>(32 * (size_t)N);
+    if (nl) H2D(dk, F->keypoints_un, 28 * (size_t)nl);
+    if (nr) H2D(dk + nl, a.kps_right, 28 * (size_t)nr);
+    H2D(dd, F->descriptors, 32 * (size_t)N);
+    int32_t *dcnt = A.take<int32_t>(4);
+    const int32_t cnts[3] = {nl, nr, nq};
+    H2D(dcnt, cnts, 12);
+    uint8_t *dqd = A.take<uint8_t>(32 * (size_t)nq);
+    H2D(dqd, a.qdesc, 32 * (size_t)nq);
+    for (int s = 0; s < 2; s++) {
+        WindowProblem &w = P[s];
+        w.kps = dk + (s ? nl : 0); w.desc = dd + (s ? (size_t)nl * 32 : 0); w.n_ptr = dcnt + s; w.nq_ptr = dcnt + 2;
+        float *f3[3]; const float *h3[3] = {a.qx[s], a.qy[s], a.qr[s]};
+        for (int k = 0; k < 3; k++) { f3[k] = A.take<float>(nq); H2D(f3[k], h3[k], 4 * (size_t)nq); }
+        w.qx = f3[0]; w.qy = f3[1]; w.qr = f3[2];
+        int32_t *i2[2]; const int32_t *hi2[2] = {a.qmin[s], a.qmax[s]};
+        for (int k = 0; k < 2; k++) { i2[k] = A.take<int32_t>(nq); H2D(i2[k], hi2[k], 4 * (size_t)nq); }
+        w.qmin = i2[0]; w.qmax = i2[1];
+        { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.qvalid[s], (size_t)nq); w.qvalid = p; }
+        w.qdesc = dqd;
+        w.keys = A.take<u64>((size_t)nq * kTopK); w.meta = A.take<int32_t>(nq);
+        w.gstart = A.take<uint16_t>(kGridCells + 1); w.gorder = A.take<uint16_t>(std::max(s ? nr : nl, 1));
+    }
+    TwinProblem T;
+    memset(&T, 0, sizeof(T));
+    T.mode = a.mode; T.n_left = nl; T.n_right = nr; T.nq = nq; T.nnratio = a.nnratio; T.max_dist = (float)ORBX_TH_HIGH;
+    T.check_orientation = a.check_orientation; T.cleared_value = -2;
+    if (a.l2r && nl) { int32_t *p = A.take<int32_t>(nl); H2D(p, a.l2r, 4 * (size_t)nl); T.l2r = p; }
+    if (a.r2l && nr) { int32_t *p = A.take<int32_t>(nr); H2D(p, a.r2l, 4 * (size_t)nr); T.r2l = p; }
+    if (a.occupied) { uint8_t *p = A.take<uint8_t>(N); H2D(p, a.occupied, (size_t)N); T.occupied0 = p; }
+    if (a.q_has_obs) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.q_has_obs, (size_t)nq); T.q_has_obs = p; }
+    if (a.q_angle) { float *p = A.take<float>(nq); H2D(p, a.q_angle, 4 * (size_t)nq); T.q_angle = p; }
+    T.match = A.take<int32_t>(N); T.nmatches = A.take<int32_t>(1); T.entries = A.take<int32_t>(2 * (size_t)nq);
+    WindowProblem *dP = A.take<WindowProblem>(2);
+    H2D(dP, P, sizeof(P));
+    GridParams g;
+    g.minx = F->min_x; g.miny = F->min_y;
+    g.inv_w = 64.0f / (F->max_x - F->min_x);
+    g.inv_h = 48.0f / (F->max_y - F->min_y);
+    hipLaunchKernelGGL(k_grid_build, dim3(2), dim3(64), 0, m->stream, dP, g);
+    hipLaunchKernelGGL(k_window_best2, dim3((nq + 15) / 16, 2), dim3(256), 0, m->stream, dP, g);
+    const size_t lds = ((size_t)N + 63) & ~(size_t)63;
+    hipLaunchKernelGGL(k_replay_twin, dim3(1), dim3(64), lds, m->stream, dP, T, g);
+    int32_t nm = 0;
+    D2H(a.match_out, T.match, 4 * (size_t)N);
+    D2H(&nm, T.nmatches, 4);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return nm;
+}
+
+}  // namespace
+
+// SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) for a fisheye-stereo frame (F.Nleft != -1), ORBmatcher.cc:43-213 whole
+extern "C" int orbx_search_by_projection_mappoints_fisheye(orbx_matcher *m, const orbx_frame_desc *left, const orbx_keypoint *kps_right, int n_right,
+                                                           const int32_t *left_to_right, const int32_t *right_to_left, const uint8_t *frame_occupied,
+                                                           int n_mp, const uint8_t *in_view, const float *proj_x, const float *proj_y,
+                                                           const int32_t *pred_level, const float *view_cos, const uint8_t *in_view_r,
+                                                           const float *proj_xr, const float *proj_yr, const int32_t *pred_level_r,
+                                                           const float *view_cos_r, const uint8_t *mp_desc, const uint8_t *mp_has_obs, float th,
+                                                           float nnratio, int32_t *frame_match) {
+    if (!m || !left || left->n < 0 || n_right < 0 || n_mp < 0 || (!frame_match && left->n + n_right > 0)) return ORBX_E_BAD_ARG;
+    if ((left->n > 0 && !left_to_right) || (n_right > 0 && (!right_to_left || !kps_right))) return ORBX_E_BAD_ARG;
+    if (n_mp > 0 && (!in_view || !proj_x || !proj_y || !pred_level || !view_cos || !in_view_r || !proj_xr || !proj_yr || !pred_level_r || !view_cos_r || !mp_desc))
+        return ORBX_E_BAD_ARG;
+    std::vector<float> qr[2];
+    std::vector<int32_t> qmin[2], qmax[2];
+    std::vector<uint8_t> valid[2];
+    const bool bFactor = th != 1.0;
+    for (int s = 0; s < 2; s++) { qr[s].resize(n_mp); qmin[s].resize(n_mp); qmax[s].resize(n_mp); valid[s].resize(n_mp); }
+    for (int i = 0; i < n_mp; i++) {
+        // left search :60-76
+        const int lvl = pred_level[i];
+        valid[0][i] = in_view[i] && lvl >= 0 && lvl < left->nlevels;
+        float r = (view_cos[i] > 0.998) ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        qr[0][i] = valid[0][i] ? r * left->scale_factors[lvl] : 0.f;
+        qmin[0][i] = lvl - 1; qmax[0][i] = lvl;
+        // right twin :144-152: needs mbTrackInViewR and mnTrackScaleLevelR != -1; RadiusByViewingCos(mTrackViewCosR) WITHOUT the th factor
+        const int lr = pred_level_r[i];
+        valid[1][i] = in_view_r[i] && lr >= 0 && lr < left->nlevels;
+        const float rr = (view_cos_r[i] > 0.998) ? 2.5f : 4.0f;
+        qr[1][i] = valid[1][i] ? rr * left->scale_factors[lr] : 0.f;
+        qmin[1][i] = lr - 1; qmax[1][i] = lr;
+    }
+    TwinArgs a = {left, kps_right, n_right, left_to_right, right_to_left, frame_occupied, n_mp, {proj_x, proj_xr}, {proj_y, proj_yr},
+                  {qr[0].data(), qr[1].data()}, {qmin[0].data(), qmin[1].data()}, {qmax[0].data(), qmax[1].data()}, {valid[0].data(), valid[1].data()},
+                  mp_desc, mp_has_obs, nullptr, 1, nnratio, 0, frame_match};
+    return run_projection_twin(m, a);
+}
+
+// SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) for a fisheye-stereo current frame, ORBmatcher.cc:1676-1887 with :1794-1863
+extern "C" int orbx_search_by_projection_frame_fisheye(orbx_matcher *m, const orbx_frame_desc *left, const orbx_keypoint *kps_right, int n_right,
+                                                       const uint8_t *cur_occupied, int n_q, const float *q_u, const float *q_v, const float *q_ur,
+                                                       const float *q_vr, const int32_t *q_octave, const float *q_angle, const uint8_t *q_desc,
+                                                       const uint8_t *q_has_obs, float th, int level_mode, int check_orientation, int32_t *cur_match) {
+    if (!m || !left || left->n < 0 || n_right < 0 || n_q < 0 || (!cur_match && left->n + n_right > 0) || (n_right > 0 && !kps_right)) return ORBX_E_BAD_ARG;
+    if (n_q > 0 && (!q_u || !q_v || !q_ur || !q_vr || !q_octave || !q_desc || (check_orientation && !q_angle))) return ORBX_E_BAD_ARG;
+    std::vector<float> qr(n_q);
+    std::vector<int32_t> qmin(n_q), qmax(n_q);
+    std::vector<uint8_t> valid(n_q);
+    for (int i = 0; i < n_q; i++) {
+        const int o = q_octave[i];
+        valid[i] = o >= 0 && o < left->nlevels;
+        qr[i] = valid[i] ? th * left->scale_factors[o] : 0.f;   // :1726, the twin uses the same radius (:1800)
+        if (level_mode == 1) { qmin[i] = o; qmax[i] = -1; }
+        else if (level_mode == 2) { qmin[i] = 0; qmax[i] = o; }
+        else { qmin[i] = o - 1; qmax[i] = o + 1; }
+    }
+    TwinArgs a = {left, kps_right, n_right, nullptr, nullptr, cur_occupied, n_q, {q_u, q_ur}, {q_v, q_vr}, {qr.data(), qr.data()},
+                  {qmin.data(), qmin.data()}, {qmax.data(), qmax.data()}, {valid.data(), valid.data()}, q_desc, q_has_obs, q_angle, 2, 0.f,
+                  check_orientation, cur_match};
+    return run_projection_twin(m, a);
+}
+
 extern "C" int orbx_search_by_projection_window(orbx_matcher *m, const orbx_frame_desc *frame, const uint8_t *occupied, int n_q,
                                                 const float *q_x, const float *q_y, const float *q_r, const int32_t *q_min_level,
                                                 const int32_t *q_max_level, const float *q_angle, const uint8_t *q_desc,
@@ -518,7 +669,7 @@ namespace {
 // k_replay_bow on host pointers: mode 0 SearchByBoW(KF, Frame), 1 SearchByBoW(KF, KF), 2 SearchForTriangulation without a gate
 int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float *angle_a, const uint8_t *skip_a, int na, const orbx_featvec *fa,
                    const uint8_t *desc_b, const float *angle_b, const uint8_t *skip_b, int nb, const orbx_featvec *fb, float nnratio,
-                   int check_orientation, int32_t *match_out, int n_out, const orbx_pinhole_gate *gate = nullptr) {
+                   int check_orientation, int32_t *match_out, int n_out, const orbx_pinhole_gate *gate = nullptr, int nb_left = 0) {
     if (na > 65535 || nb > 65535) return ORBX_E_TOO_LARGE;
     ORBX_HIP(hipSetDevice(m->device));
     const size_t ia = (size_t)fa->node_ptr[fa->n_nodes], ib = (size_t)fb->node_ptr[fb->n_nodes];
@@ -549,7 +700,7 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
         if (hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) return nullptr;
         return d;
     };
-    P.mode = mode;
+    P.mode = mode; P.nb_left = nb_left;
     P.desc_a = up(desc_a, 32 * (size_t)na); P.desc_b = up(desc_b, 32 * (size_t)nb);
     P.angle_a = (const float *)up(angle_a, 4 * (size_t)na); P.angle_b = (const float *)up(angle_b, 4 * (size_t)nb);
     P.skip_a = up(skip_a, na); P.skip_b = up(skip_b, nb);
@@ -592,6 +743,19 @@ int orbx_search_by_bow_frame(orbx_matcher *m, const uint8_t *kf_desc, const floa
     for (int i = 0; i < n_kf; i++) skip[i] = kf_valid ? !kf_valid[i] : 0;
     return run_bow_replay(m, 0, kf_desc, kf_angle, skip.data(), n_kf, kf_fv, f_desc, f_angle, nullptr, n_f, f_fv, nnratio, check_orientation,
                           f_match, n_f);
+}
+
+// the same for a fisheye-stereo frame (F.Nleft != -1, ORBmatcher.cc:283-392): features >= n_f_left belong to the right camera
+int orbx_search_by_bow_frame_fisheye(orbx_matcher *m, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid, int n_kf,
+                                     const orbx_featvec *kf_fv, const uint8_t *f_desc, const float *f_angle, int n_f, int n_f_left,
+                                     const orbx_featvec *f_fv, float nnratio, int check_orientation, int32_t *f_match) {
+    if (!m || !kf_fv || !f_fv || (!f_match && n_f > 0) || n_kf < 0 || n_f < 0 || n_f_left < 0 || n_f_left > n_f) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n_f; i++) f_match[i] = -1;
+    if (n_kf == 0 || n_f == 0) return 0;
+    std::vector<uint8_t> skip(n_kf);
+    for (int i = 0; i < n_kf; i++) skip[i] = kf_valid ? !kf_valid[i] : 0;
+    return run_bow_replay(m, 3, kf_desc, kf_angle, skip.data(), n_kf, kf_fv, f_desc, f_angle, nullptr, n_f, f_fv, nnratio, check_orientation,
+                          f_match, n_f, nullptr, n_f_left);
 }
 
 // ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (ORBmatcher.cc:765-905): k_replay_bow mode 1

@@ -190,6 +190,45 @@ class ORBmatcher:
             "orbx_search_by_projection_frame")
         return n, (cm if raw else np.maximum(cm, -1))
 
+    # ---- fisheye-stereo twins (F.Nleft != -1): features [0, n_left) left camera, [n_left, N) right camera ----
+    def SearchByProjectionFisheye(self, left: FrameView, kps_right, l2r, r2l, mp: dict, th: float = 3.0, frame_occupied=None):
+        """ORBmatcher.cc:43-213 whole.  left.descriptors holds ALL n_left + n_right rows; mp: in_view, proj_x, proj_y, level,
+        view_cos, in_view_r, proj_xr, proj_yr, level_r, view_cos_r, desc, has_obs."""
+        kr = np.ascontiguousarray(kps_right, KP_DTYPE)
+        left.keypoints_un = np.ascontiguousarray(left.keypoints_un, KP_DTYPE)
+        fd = left.c_struct()
+        N = fd.n + len(kr)
+        fm = np.full(N, -1, np.int32)
+        a = [_u8(mp["in_view"]), _f32(mp["proj_x"]), _f32(mp["proj_y"]), _i32(mp["level"]), _f32(mp["view_cos"]), _u8(mp["in_view_r"]),
+             _f32(mp["proj_xr"]), _f32(mp["proj_yr"]), _i32(mp["level_r"]), _f32(mp["view_cos_r"]), _u8(mp["desc"]), _u8(mp.get("has_obs"))]
+        l2r, r2l, occ = _i32(l2r), _i32(r2l), _u8(frame_occupied)
+        n = check(self._L.orbx_search_by_projection_mappoints_fisheye(self._h, C.byref(fd), ptr(kr), len(kr), ptr(l2r), ptr(r2l), ptr(occ), len(a[0]),
+                                                                      *[ptr(x) for x in a], th, self.mfNNratio, ptr(fm)),
+                  "orbx_search_by_projection_mappoints_fisheye")
+        return n, fm
+
+    def SearchByProjectionFrameFisheye(self, left: FrameView, kps_right, q: dict, th: float, level_mode: int = 0, cur_occupied=None, raw=False):
+        """ORBmatcher.cc:1676-1887 with the twin :1794-1863.  q: u, v, xr, yr, octave, angle, desc, has_obs."""
+        kr = np.ascontiguousarray(kps_right, KP_DTYPE)
+        fd = left.c_struct()
+        cm = np.full(fd.n + len(kr), -1, np.int32)
+        a = [_f32(q["u"]), _f32(q["v"]), _f32(q["xr"]), _f32(q["yr"]), _i32(q["octave"]), _f32(q["angle"]), _u8(q["desc"]), _u8(q.get("has_obs"))]
+        occ = _u8(cur_occupied)
+        n = check(self._L.orbx_search_by_projection_frame_fisheye(self._h, C.byref(fd), ptr(kr), len(kr), ptr(occ), len(a[0]), *[ptr(x) for x in a],
+                                                                  th, level_mode, int(self.mbCheckOrientation), ptr(cm)),
+                  "orbx_search_by_projection_frame_fisheye")
+        return n, (cm if raw else np.maximum(cm, -1))
+
+    def SearchByBoWFrameFisheye(self, kf_desc, kf_angle, kf_valid, kf_fv: "FeatureVector", f_desc, f_angle, n_f_left: int, f_fv: "FeatureVector"):
+        """ORBmatcher.cc:283-392 (frame features >= n_f_left are the right camera's; `|| true` on the right ratio test)."""
+        kd, ka, kv, fdsc, fa = _u8(kf_desc), _f32(kf_angle), _u8(kf_valid), _u8(f_desc), _f32(f_angle)
+        a, b = kf_fv.c_struct(), f_fv.c_struct()
+        fm = np.full(len(fdsc), -1, np.int32)
+        n = check(self._L.orbx_search_by_bow_frame_fisheye(self._h, ptr(kd), ptr(ka), ptr(kv), len(kd), C.byref(a), ptr(fdsc), ptr(fa), len(fdsc),
+                                                           int(n_f_left), C.byref(b), self.mfNNratio, int(self.mbCheckOrientation), ptr(fm)),
+                  "orbx_search_by_bow_frame_fisheye")
+        return n, fm
+
     # ---- general window form: M3 = SearchByProjection(Frame&, KeyFrame*, ...) (ORBmatcher.cc:1889-2010) and
     #      M4 = SearchByProjection(KeyFrame*, Sim3f&, ...) (ORBmatcher.cc:427-646) ----
     def SearchByProjectionWindow(self, F: FrameView, q: dict, max_dist: float, check_orientation: bool, occupied=None, raw=False):
