@@ -36,8 +36,18 @@ public:
     /* the verdicts of the epipolar test are test data: ok[idx1 * n2 + idx2], keyed by keypoint identity (class_id) */
     const uint8_t *epi_ok = nullptr;
     int epi_n2 = 0;
-    virtual bool epipolarConstrain(GeometricCamera *, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2,
-                                   const Eigen::Matrix3f &, const Eigen::Vector3f &, const float, const float) {
+    /* fisheye-stereo pairings (ORBmatcher.cc:1036-1069): when pair_left1 >= 0 the verdict also demands that the caller picked the
+     * camera objects and the relative translation of the pairing the two keypoints belong to (class_id >= n_left: right camera);
+     * t12x_expect[2 * right1 + right2] is the x component the test gave that pairing's t12 */
+    int cam_id = 0, pair_left1 = -1, pair_left2 = -1;
+    const float *t12x_expect = nullptr;
+    virtual bool epipolarConstrain(GeometricCamera *other, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2,
+                                   const Eigen::Matrix3f &, const Eigen::Vector3f &t12, const float, const float) {
+        if (pair_left1 >= 0) {
+            const int r1 = kp1.class_id >= pair_left1, r2 = kp2.class_id >= pair_left2;
+            if (cam_id != r1 || !other || other->cam_id != r2) return false;
+            if (t12x_expect && t12(0) != t12x_expect[2 * r1 + r2]) return false;
+        }
         return epi_ok ? epi_ok[(size_t)kp1.class_id * epi_n2 + kp2.class_id] != 0 : true;
     }
 };
@@ -131,7 +141,7 @@ public:
     MapPoint *GetMapPoint(const size_t &idx) { return probe ? nullptr : mvpMapPoints[idx]; }
     void AddMapPoint(MapPoint *p, const size_t &idx) { if (!probe) mvpMapPoints[idx] = p; added.push_back({p, (int)idx}); }
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const bool bRight = false) const {
-        return area(x, y, r, -1, -1);
+        return area(x, y, r, -1, -1, bRight);
     }
     bool IsInImage(const float &x, const float &y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
     Sophus::SE3f GetPose() { return Tcw; }

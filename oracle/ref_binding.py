@@ -167,7 +167,7 @@ def _ml():
         for name in ("matref_descriptor_distance", "matref_search_by_projection_mappoints", "matref_search_by_projection_frame",
                      "matref_search_by_projection_keyframe", "matref_search_by_projection_sim3", "matref_search_by_bow_frame",
                      "matref_search_by_bow_keyframes", "matref_search_for_initialization", "matref_search_for_triangulation",
-                     "matref_fuse", "matref_search_by_sim3"):
+                     "matref_fuse", "matref_search_by_sim3", "matref_fuse_right", "matref_search_for_triangulation_fisheye"):
             getattr(L, name).restype = C.c_int
         _matcher = L
     return _matcher
@@ -309,6 +309,28 @@ def ref_fuse(KF: RefFrame, inv_sigma2, q, th, variant=0):
     r = _ml().matref_fuse(kp, de, n, bo, sf, _p(isg), nl, _p(KF.u_right), len(arrs[0]), *[_p(x) for x in arrs], C.c_float(th),
                           int(variant), _p(bi))
     return r, bi
+
+
+def ref_fuse_right(kps_left, kps_right, desc, bounds, scale_factors, inv_sigma2, q, th):
+    """Fuse(pKF, vpMapPoints, th, bRight=True) on a fisheye-stereo key frame; best_idx holds GLOBAL feature indices (right: + n_left)."""
+    kl, kr = np.ascontiguousarray(kps_left, KP_DTYPE), np.ascontiguousarray(kps_right, KP_DTYPE)
+    d, b, sf, isg = _u8(desc), _f32(bounds), _f32(scale_factors), _f32(inv_sigma2)
+    arrs = [_f32(q["u"]), _f32(q["v"]), _f32(q["z"]), _i32(q["level"]), _u8(q["desc"])]
+    bi = np.full(len(arrs[0]), -1, np.int32)
+    r = _ml().matref_fuse_right(_p(kl), len(kl), _p(kr), len(kr), _p(d), _p(b), _p(sf), _p(isg), len(sf), len(arrs[0]), *[_p(x) for x in arrs],
+                                C.c_float(th), _p(bi))
+    return r, bi
+
+
+def ref_search_for_triangulation_fisheye(d1, a1, s1, n_left1, fv1, d2, a2, s2, n_left2, fv2, check_orientation, pair_ok=None, coarse=False):
+    """Both key frames fisheye-stereo (four camera pairings); arrays cover left then right features, pair_ok is (n1, n2) over them."""
+    d1, d2, a1, a2, s1, s2 = _u8(d1), _u8(d2), _f32(a1), _f32(a2), _u8(s1), _u8(s2)
+    a, b = _fv(fv1), _fv(fv2)
+    ok = _u8(pair_ok)
+    m12 = np.full(len(d1), -1, np.int32)
+    n = _ml().matref_search_for_triangulation_fisheye(_p(d1), _p(a1), _p(s1), len(d1), int(n_left1), C.byref(a), _p(d2), _p(a2), _p(s2), len(d2),
+                                                     int(n_left2), C.byref(b), int(check_orientation), _p(ok), int(coarse), _p(m12))
+    return n, m12
 
 
 def ref_search_by_sim3(K1: RefFrame, K2: RefFrame, side1, side2, th):

@@ -542,6 +542,98 @@ int matref_fuse(const orbo_keypoint *kps, const uint8_t *desc, int n, const floa
     return r;
 }
 
+/* Fuse(pKF, vpMapPoints, th, bRight = true)  ORBmatcher.cc:1148-1337 on a fisheye-stereo key frame: the map points are projected with
+ * the right camera's pose (Trl = identity here) and searched in the right camera's grid; a fused feature is reported with its
+ * global index idx + NLeft (:1296).  mvuRight holds -1 everywhere (Frame.cc:1137), so the monocular chi2 gate applies. */
+int matref_fuse_right(const orbo_keypoint *kps_left, int n_left, const orbo_keypoint *kps_right, int n_right, const uint8_t *desc,
+                      const float *bounds, const float *scale, const float *inv_sigma2, int nlevels, int n_q, const float *q_u,
+                      const float *q_v, const float *q_z, const int32_t *q_level, const uint8_t *q_desc, float th, int32_t *best_idx) {
+    GeometricCamera cam, cam2;
+    KeyFrame KF;
+    const int N = n_left + n_right;
+    fill(KF, kps_left, n_left, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, inv_sigma2, nlevels, nullptr, &cam);
+    KF.N = N; KF.Nleft = n_left; KF.NLeft = n_left;
+    KF.mpCamera2 = &cam2;
+    KF.mDescriptors = cv::Mat(N > 0 ? N : 1, 32, CV_8UC1);
+    if (N) std::memcpy(KF.mDescriptors.data, desc, (size_t)N * 32);
+    KF.kps_right.assign(kps_right, kps_right + n_right);
+    KF.mvKeysRight.resize(n_right);
+    for (int i = 0; i < n_right; i++)
+        KF.mvKeysRight[i] = cv::KeyPoint(kps_right[i].x, kps_right[i].y, kps_right[i].size, kps_right[i].angle, kps_right[i].response, kps_right[i].octave, i);
+    KF.grid_right = orbo_grid_create(KF.kps_right.data(), n_right, bounds[0], bounds[1], bounds[2], bounds[3]);
+    KF.mvuRight.assign(N, -1.f);
+    KF.mbf = 1.f;
+    KF.mvpMapPoints.assign(N, nullptr);
+    KF.probe = true;
+    std::vector<MapPoint> mps(n_q);
+    std::vector<MapPoint *> vp(n_q);
+    for (int j = 0; j < n_q; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.pos = Eigen::Vector3f(q_u[j], q_v[j], q_z[j]);
+        p.normal = Eigen::Vector3f(0.f, 0.f, 1.0e30f);
+        p.pred_scale = q_level[j];
+        p.desc = desc_row(q_desc + (size_t)j * 32);
+        vp[j] = &p;
+    }
+    ORBmatcher m(0.6f, true);
+    int r = m.Fuse(&KF, vp, th, true);
+    for (int j = 0; j < n_q; j++) best_idx[j] = mps[j].added_obs.empty() ? -1 : mps[j].added_obs[0].second;
+    return r;
+}
+
+/* SearchForTriangulation between two fisheye-stereo key frames (both have mpCamera2), ORBmatcher.cc:907-1146 with the four camera
+ * pairings of :1036-1069.  Features [0, n_left) are mvKeys, the rest mvKeysRight; angle* / skip* / the feature vectors cover all of
+ * them; pair_ok is indexed by the combined feature indices.  The four relative poses get distinct x translations (left KF1 at x = 0,
+ * its right camera at +1; left KF2 at 0, its right camera at +4: t12.x = 0 ll, +4 lr, -1 rl, +3 rr) and the stand-in cameras refuse a
+ * pair whose camera objects or t12 do not belong to the pairing of the two keypoints. */
+int matref_search_for_triangulation_fisheye(const uint8_t *desc1, const float *angle1, const uint8_t *skip1, int n1, int n_left1,
+                                            const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2, const uint8_t *skip2, int n2,
+                                            int n_left2, const orbo_featvec *fv2, int check_orientation, const uint8_t *pair_ok, int coarse,
+                                            int32_t *matches12) {
+    static const float t12x[4] = {0.f, 4.f, -1.f, 3.f};   /* [2 * right1 + right2] */
+    GeometricCamera cam[2][2];
+    KeyFrame K1, K2;
+    KeyFrame *K[2] = {&K1, &K2};
+    const uint8_t *D[2] = {desc1, desc2};
+    const float *A[2] = {angle1, angle2};
+    const uint8_t *S[2] = {skip1, skip2};
+    const int N[2] = {n1, n2}, NL[2] = {n_left1, n_left2};
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    for (int s = 0; s < 2; s++) {
+        KeyFrame &k = *K[s];
+        for (int c = 0; c < 2; c++) {
+            cam[s][c].cam_id = c; cam[s][c].epi_ok = pair_ok; cam[s][c].epi_n2 = n2;
+            cam[s][c].pair_left1 = n_left1; cam[s][c].pair_left2 = n_left2; cam[s][c].t12x_expect = t12x;
+        }
+        k.N = N[s]; k.Nleft = NL[s]; k.NLeft = NL[s];
+        k.mpCamera = &cam[s][0]; k.mpCamera2 = &cam[s][1];
+        k.mvKeys.resize(NL[s]); k.mvKeysUn.resize(NL[s]); k.mvKeysRight.resize(N[s] - NL[s]);
+        k.mDescriptors = cv::Mat(N[s] > 0 ? N[s] : 1, 32, CV_8UC1);
+        std::memcpy(k.mDescriptors.data, D[s], (size_t)N[s] * 32);
+        k.mvpMapPoints.assign(N[s], nullptr);
+        k.mvuRight.assign(N[s], -1.f);
+        k.mvScaleFactors.assign(16, 1.f);
+        k.mvLevelSigma2.assign(16, 1.f);
+        for (int i = 0; i < N[s]; i++) {
+            cv::KeyPoint &kp = i < NL[s] ? k.mvKeys[i] : k.mvKeysRight[i - NL[s]];
+            kp.octave = 0; kp.angle = A[s][i]; kp.class_id = i;   /* class_id = combined index: the verdict table's key */
+            if (S[s][i]) k.mvpMapPoints[i] = marker(pool);
+        }
+        k.mvKeysUn = k.mvKeys;
+    }
+    K1.Trl.t = Eigen::Vector3f(-1.f, 0.f, 0.f);   /* right camera of KF1 sits at x = +1 */
+    K2.Trl.t = Eigen::Vector3f(-4.f, 0.f, 0.f);   /* right camera of KF2 sits at x = +4 */
+    featvec(K1.mFeatVec, fv1);
+    featvec(K2.mFeatVec, fv2);
+    std::vector<std::pair<size_t, size_t>> pairs;
+    ORBmatcher m(0.6f, check_orientation != 0);
+    int r = m.SearchForTriangulation(&K1, &K2, pairs, false, coarse != 0);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (auto &p : pairs) matches12[p.first] = (int)p.second;
+    return r;
+}
+
 /* SearchBySim3  ORBmatcher.cc:1457-1674: both key frames at identity, S12 = identity, fx = fy = 1, cx = cy = 0, points at
  * z = 1: map point i of KF1 projects to (x1[i], y1[i]) in KF2 and vice versa.  valid: 0 none, 1 map point, 2 bad.
  * match12[i1] = KF2 feature index or -1. */

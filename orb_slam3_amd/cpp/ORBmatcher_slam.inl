@@ -346,8 +346,7 @@ public:
     // on-device gates through the orbx_pinhole_gate overload instead).
     int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo,
                                const bool bCoarse = false) {
-        if (pKF1->NLeft != -1 || pKF2->NLeft != -1 || pKF1->mpCamera2 || pKF2->mpCamera2)
-            throw std::runtime_error("SearchForTriangulation: fisheye-stereo pairings are not wired into this adapter");
+        if (pKF1->mpCamera2 || pKF2->mpCamera2) return SearchForTriangulationFisheye(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse);
         Sophus::SE3f T1w = pKF1->GetPose();
         Sophus::SE3f T2w = pKF2->GetPose();
         Sophus::SE3f Tw2 = pKF2->GetPoseInverse();
@@ -386,12 +385,47 @@ public:
                                       a2.data(), skip2.data(), n2, FeatVec::from(pKF2->mFeatVec), gate, vMatchedPairs);
     }
 
+    // the same member between fisheye-stereo key frames (both carry mpCamera2): the four camera pairings of ORBmatcher.cc:1036-1069.
+    // No feature is "stereo" (bStereo needs !mpCamera2, :980/:1008), so bOnlyStereo leaves no query, and the epipole test (:1026) is off.
+    int SearchForTriangulationFisheye(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo,
+                                      const bool bCoarse) {
+        if (!pKF1->mpCamera2 || !pKF2->mpCamera2) throw std::runtime_error("SearchForTriangulation: one key frame is fisheye-stereo and the other is not");
+        Sophus::SE3f T1w = pKF1->GetPose();
+        Sophus::SE3f Tw2 = pKF2->GetPoseInverse();
+        Sophus::SE3f Tr1w = pKF1->GetRightPose();
+        Sophus::SE3f Twr2 = pKF2->GetRightPoseInverse();
+        const Sophus::SE3f T[2][2] = {{T1w * Tw2, T1w * Twr2}, {Tr1w * Tw2, Tr1w * Twr2}};   // [right1][right2]: Tll, Tlr, Trl, Trr (:936-939)
+        Eigen::Matrix3f R[2][2];
+        Eigen::Vector3f t[2][2];
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { R[a][b] = T[a][b].rotationMatrix(); t[a][b] = T[a][b].translation(); }
+        GeometricCamera *cam1[2] = {pKF1->mpCamera, pKF1->mpCamera2}, *cam2[2] = {pKF2->mpCamera, pKF2->mpCamera2};
+        const int n1 = pKF1->N, n2 = pKF2->N;
+        auto key = [](KeyFrame *k, size_t idx) -> const cv::KeyPoint & {                       // :984-986, :1020-1022
+            return (k->NLeft == -1) ? k->mvKeysUn[idx] : ((int)idx < k->NLeft ? k->mvKeys[idx] : k->mvKeysRight[idx - k->NLeft]);
+        };
+        std::vector<uint8_t> skip1(n1), skip2(n2);
+        std::vector<float> a1(n1), a2(n2);
+        for (int i = 0; i < n1; i++) { skip1[i] = (pKF1->GetMapPoint(i) || bOnlyStereo) ? 1 : 0; a1[i] = key(pKF1, i).angle; }
+        for (int i = 0; i < n2; i++) { skip2[i] = (pKF2->GetMapPoint(i) || bOnlyStereo) ? 1 : 0; a2[i] = key(pKF2, i).angle; }
+        auto gate = [&](size_t idx1, size_t idx2) -> bool {
+            if (bCoarse) return true;
+            const cv::KeyPoint &kp1 = key(pKF1, idx1);
+            const cv::KeyPoint &kp2 = key(pKF2, idx2);
+            const int r1 = !(pKF1->NLeft == -1 || (int)idx1 < pKF1->NLeft), r2 = !(pKF2->NLeft == -1 || (int)idx2 < pKF2->NLeft);   // bRight1 / bRight2
+            return cam1[r1]->epipolarConstrain(cam2[r2], kp1, kp2, R[r1][r2], t[r1][r2], pKF1->mvLevelSigma2[kp1.octave], pKF2->mvLevelSigma2[kp2.octave]);
+        };
+        return SearchForTriangulation(pKF1->mDescriptors.data, a1.data(), skip1.data(), n1, FeatVec::from(pKF1->mFeatVec), pKF2->mDescriptors.data,
+                                      a2.data(), skip2.data(), n2, FeatVec::from(pKF2->mFeatVec), gate, vMatchedPairs);
+    }
+
     // ORBmatcher.cc:1148-1337 (LocalMapping::SearchInNeighbors)
     int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th = 3.0, const bool bRight = false) {
-        if (bRight || pKF->NLeft != -1) throw std::runtime_error("Fuse: the right-camera / fisheye-stereo form is not wired into this adapter");
-        Sophus::SE3f Tcw = pKF->GetPose();
-        Eigen::Vector3f Ow = pKF->GetCameraCenter();
-        GeometricCamera *pCamera = pKF->mpCamera;
+        // :1150-1163: the right camera of a fisheye-stereo key frame has its own pose, centre, camera model, grid and keypoints
+        Sophus::SE3f Tcw = bRight ? pKF->GetRightPose() : pKF->GetPose();
+        Eigen::Vector3f Ow = bRight ? pKF->GetRightCameraCenter() : pKF->GetCameraCenter();
+        GeometricCamera *pCamera = bRight ? pKF->mpCamera2 : pKF->mpCamera;
+        const int NLeft = pKF->NLeft;
+        const int idxOffset = bRight ? NLeft : 0;                                                       // :1296
         const float &bf = pKF->mbf;
         FuseQueries q;
         std::vector<int> live;
@@ -421,12 +455,16 @@ public:
             live.push_back(i);
         }
         std::vector<int32_t> bestIdx, bestDist;
-        FuseSearch(view_of(*pKF, pKF->mvKeysUn, true), pKF->mvInvLevelSigma2.data(), q, bestIdx, bestDist);
+        // :1260-1262: the candidates' keypoints are mvKeysUn (Nleft == -1), mvKeys (left of a fisheye rig) or mvKeysRight (bRight)
+        FrameView kfv = (NLeft == -1) ? view_of(*pKF, pKF->mvKeysUn, true) : view_of(*pKF, bRight ? pKF->mvKeysRight : pKF->mvKeys, false);
+        if (bRight) kfv.mDescriptors += (size_t)NLeft * 32;                                              // :1296-1298: row idx + NLeft
+        FuseSearch(kfv, pKF->mvInvLevelSigma2.data(), q, bestIdx, bestDist);
         int nFused = 0;
         for (size_t k = 0; k < live.size(); k++) {   // the reference's tail, in its order, on the live graph (:1309-1330)
             MapPoint *pMP = vpMapPoints[live[k]];
             if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;   // an earlier iteration's Replace / AddObservation may have retired this query
             if (bestIdx[k] < 0 || bestDist[k] > TH_LOW) continue;
+            bestIdx[k] += idxOffset;
             MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx[k]);
             if (pMPinKF) {
                 if (!pMPinKF->isBad()) {

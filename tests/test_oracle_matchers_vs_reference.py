@@ -361,6 +361,49 @@ def test_fuse(frames):
         assert (want >= 0).sum() > 100
 
 
+def test_fuse_right_camera_fisheye(frames):
+    """Fuse(pKF, vpMapPoints, th, bRight=True), ORBmatcher.cc:1148-1337 on a fisheye-stereo key frame: right camera's pose and grid,
+    mvKeysRight octaves, monocular chi2 gate (mvuRight is -1 throughout, Frame.cc:1137), fused index reported as idx + NLeft."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf, isg = tab["scale"], tab["inv_sigma2"]
+    rng = np.random.default_rng(71)
+    kl, dl, kr, dr = k1, d1, k0, d0            # left = frame 1, right = frame 0
+    desc = np.concatenate([dl, dr])
+    bounds = np.array([0.0, W, 0.0, H], np.float32)
+    gr = ob.OracleGrid(kr, 0.0, float(W), 0.0, float(H))
+    for th in (3.0, 4.0):
+        q = _fuse_queries(rng, kr, dr, sf, th)      # map points that project near the RIGHT camera's features
+        q["u"] = (q["u"] + 2.0).astype(np.float32); q["v"] = (q["v"] + 1.0).astype(np.float32)
+        q["ur"] = (q["u"] - np.float32(1.0) / q["z"]).astype(np.float32)
+        obi, obd = ob.fuse_search(gr, dr, None, isg, q, fma=True)
+        want = np.where(obd <= 50, obi + len(kl), -1)
+        _pin(f"fuse_right/{th}", ((want >= 0).sum(), want), lambda: rb.ref_fuse_right(kl, kr, desc, bounds, sf, isg, q, th))
+        assert (want >= 0).sum() > 100
+
+
+def test_search_for_triangulation_fisheye_pairings(frames):
+    """M7 between two fisheye-stereo key frames, ORBmatcher.cc:907-1146 with the four camera pairings of :1036-1069: no epipole test
+    (pKF1->mpCamera2), no stereo flags, per pair the camera objects and T12 of (left|right, left|right) -- the stand-in cameras
+    refuse a pair evaluated with the wrong objects or the wrong translation."""
+    k0, d0, k1, d1, _ = frames[1000]
+    rng = np.random.default_rng(73)
+    n1, n2 = len(k0), len(k1)
+    p0, p1 = rng.permutation(n1), rng.permutation(n2)   # shuffled, so that corresponding features fall into all four camera pairings
+    k0, d0, k1, d1 = k0[p0], d0[p0], k1[p1], d1[p1]
+    nl1, nl2 = int(0.6 * n1), int(0.55 * n2)       # features beyond n_left belong to the right cameras
+    na, nb = _bow_nodes(rng, k0, k1, 60)
+    fva, fvb = FeatureVector.from_node_of_feature(na), FeatureVector.from_node_of_feature(nb)
+    s0 = (rng.random(n1) < 0.3).astype(np.uint8)
+    s1 = (rng.random(n2) < 0.3).astype(np.uint8)
+    table = (rng.random((n1, n2)) < 0.7).astype(np.uint8)
+    for ori, coarse in ((True, False), (False, False), (True, True)):
+        pred = None if coarse else (lambda i, j: table[i, j])
+        on, om = ob.search_for_triangulation(d0, k0["angle"], s0, fva, d1, k1["angle"], s1, fvb, ori, pred)
+        _pin(f"m7fisheye/{ori}/{coarse}", (on, om),
+             lambda: rb.ref_search_for_triangulation_fisheye(d0, k0["angle"], s0, nl1, fva, d1, k1["angle"], s1, nl2, fvb, ori, table, coarse))
+        assert on > 50 and (om[nl1:] >= nl2).sum() > 5 and (om[:nl1] >= nl2).sum() > 5 and ((om[nl1:] >= 0) & (om[nl1:] < nl2)).sum() > 5
+
+
 def test_search_by_sim3(frames):
     """SearchBySim3, ORBmatcher.cc:1457-1674 = two gate-less fuse searches (best <= TH_HIGH, octave gate [l-1,l]) + mutual
     agreement, composed here exactly as orb_slam3_amd composes it over orbx_fuse_search."""
