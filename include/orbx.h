@@ -110,6 +110,7 @@ typedef struct orbx_batch_view {
     const uint8_t *d_descriptors;     /* [n_frames][cap][32] */
     const int32_t *d_count;           /* [n_frames] keypoints per frame */
     const int32_t *d_mono_index;      /* [n_frames] */
+    const orbx_keypoint *d_keypoints_un;  /* [n_frames][cap] mvKeysUn: == d_keypoints unless orbx_set_camera gave a distortion model */
 } orbx_batch_view;
 int orbx_batch_view_get(orbx_extractor *ex, orbx_batch_view *view);
 
@@ -368,6 +369,47 @@ int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, const float
                                        const int32_t *d_level, const float *d_view_cos, const uint8_t *d_in_view,
                                        const uint8_t *d_mp_desc, size_t desc_frame_stride, float th, float nnratio,
                                        int32_t *d_match, int32_t *d_nmatches);
+
+/* ---- candidate generation for the projection matchers: Frame::UndistortKeyPoints, ComputeImageBounds, isInFrustum ----
+ * Pinhole intrinsics (Frame::mK / fx, fy, cx, cy), radial-tangential distortion (Frame::mDistCoef: k1, k2, p1, p2[, k3]) and mbf. */
+typedef struct orbx_camera {
+    float fx, fy, cx, cy;
+    float k1, k2, p1, p2, k3;
+    float bf;
+} orbx_camera;
+/* Frame::mRcw (row-major), mtcw, mOw */
+typedef struct orbx_frame_pose {
+    float Rcw[9], tcw[3], Ow[3];
+} orbx_frame_pose;
+
+/* Frame::UndistortKeyPoints (Frame.cc:747-780): kps_un[i] = kps[i] with the point run through cv::undistortPoints(K, distCoef, R = I,
+ * P = K) (published algorithm: 5 fixed-point iterations of the radial-tangential model in double); a plain copy when k1 == 0. */
+int orbx_undistort_keypoints(orbx_matcher *m, const orbx_camera *cam, const orbx_keypoint *kps, int n, orbx_keypoint *kps_un);
+/* Frame::ComputeImageBounds (Frame.cc:782-810): bounds4 = {mnMinX, mnMaxX, mnMinY, mnMaxY} (host arithmetic, no device needed) */
+int orbx_image_bounds(const orbx_camera *cam, int width, int height, float *bounds4);
+/* Frame::isInFrustum(pMP, viewingCosLimit) (Frame.cc:512-575, Nleft == -1) for n_mp map points given flat: world position and normal
+ * (3 floats each), mfMinDistance / mfMaxDistance.  Outputs are the MapPoint fields the function writes: in_view (mbTrackInView),
+ * proj_x / proj_y (mTrackProjX/Y; -1 unless the projection lies inside the image bounds), and where in_view: proj_xr, depth
+ * (mTrackDepth), level (mnTrackScaleLevel = PredictScale, MapPoint.cc:531-546), view_cos.  Every float operation rounds as the
+ * reference text writes it. */
+int orbx_is_in_frustum(orbx_matcher *m, const orbx_camera *cam, const orbx_frame_pose *pose, const float *bounds4, float log_scale_factor,
+                       int nlevels, float viewing_cos_limit, int n_mp, const float *pos, const float *normal, const float *min_dist,
+                       const float *max_dist, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr, float *depth, int32_t *level,
+                       float *view_cos);
+/* The same for n_frames poses at once on device-resident map-point data (shared by all frames); outputs [n_frames][n_mp] in device
+ * memory -- exactly the arrays orbx_search_mappoints_batch_device consumes (Tracking::SearchLocalPoints, Tracking.cc:3339-3413: frustum
+ * test, then SearchByProjection).  bounds4 = NULL uses the extractor's camera (orbx_set_camera) or the plain image rectangle.
+ * Asynchronous, ordered before a following orbx_search_mappoints_batch_device on the same extractor. */
+int orbx_frustum_batch_device(orbx_extractor *ex, const orbx_camera *cam, const orbx_frame_pose *poses, int n_frames, const float *bounds4,
+                              float viewing_cos_limit, int n_mp, const float *d_pos, const float *d_normal, const float *d_min_dist,
+                              const float *d_max_dist, uint8_t *d_in_view, float *d_proj_x, float *d_proj_y, float *d_proj_xr, float *d_depth,
+                              int32_t *d_level, float *d_view_cos);
+/* Gives the extractor's batch path a camera: after every batched extraction the keypoints are undistorted on the device (mvKeysUn,
+ * orbx_batch_view.d_keypoints_un) and the batched matchers use them together with the undistorted image bounds.  cam = NULL removes
+ * it (mvKeysUn = mvKeys, bounds = image rectangle: the distortion-free default). */
+int orbx_set_camera(orbx_extractor *ex, const orbx_camera *cam);
+/* mvKeysUn of one frame of the last batch (equals the keypoints when no camera is set) */
+int orbx_batch_download_keypoints_un(orbx_extractor *ex, int frame, orbx_keypoint *kps_un, int cap, int *n_out);
 
 /* The matching core of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th, bRight) (ORBmatcher.cc:1148-1337, candidate loop
  * :1246-1306) and Fuse(KeyFrame*, Sim3f&, vpPoints, th, vpReplacePoint) (:1339-1455, loop :1405-1433): for each projected

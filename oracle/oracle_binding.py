@@ -26,7 +26,7 @@ FLAG_LIBM_SINCOS = 4
 
 def build(force: bool = False) -> Path:
     """Compile the oracle with g++ (seconds).  The GPU box uses the prebuilt .so if present."""
-    srcs = [_DIR / "orb_oracle.cc", _DIR / "orb_oracle_match.cc", _DIR / "orb_oracle.h", _DIR / "orb_pattern_data.inc"]
+    srcs = [_DIR / "orb_oracle.cc", _DIR / "orb_oracle_match.cc", _DIR / "orb_oracle_geom.cc", _DIR / "orb_oracle.h", _DIR / "orb_pattern_data.inc"]
     if force or not _SO.exists() or any(s.stat().st_mtime > _SO.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(_DIR), "-B", "liborb_oracle.so"], check=True, capture_output=True)
     return _SO
@@ -538,3 +538,41 @@ def search_by_bow_frame_fisheye(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_an
     n = L.orbo_search_by_bow_frame_fisheye(_p(kd), _p(ka), _p(kv), len(kd), C.byref(a), _p(fd), _p(fa), len(fd), int(n_f_left), C.byref(b),
                                            C.c_float(nnratio), int(check_orientation), _p(fm))
     return n, fm
+
+
+def is_in_frustum(Rcw, tcw, Ow, cam, bounds, log_scale_factor, nlevels, cos_limit, pos, normal, min_dist, max_dist):
+    """Frame::isInFrustum (Nleft == -1) for n map points.  cam = (fx, fy, cx, cy, mbf).  Returns dict(in_view, proj_x, proj_y, proj_xr,
+    depth, level, view_cos)."""
+    f32 = np.float32
+    R, t, O, b = [np.ascontiguousarray(x, f32).ravel() for x in (Rcw, tcw, Ow, bounds)]
+    P, Nn = np.ascontiguousarray(pos, f32).reshape(-1, 3), np.ascontiguousarray(normal, f32).reshape(-1, 3)
+    mn, mx = np.ascontiguousarray(min_dist, f32), np.ascontiguousarray(max_dist, f32)
+    n = len(P)
+    out = dict(in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, f32), proj_y=np.zeros(n, f32), proj_xr=np.zeros(n, f32),
+               depth=np.zeros(n, f32), level=np.zeros(n, np.int32), view_cos=np.zeros(n, f32))
+    L = lib()
+    L.orbo_is_in_frustum.restype = None
+    L.orbo_is_in_frustum(_p(R), _p(t), _p(O), C.c_float(cam[0]), C.c_float(cam[1]), C.c_float(cam[2]), C.c_float(cam[3]), C.c_float(cam[4]), _p(b),
+                         C.c_float(log_scale_factor), int(nlevels), C.c_float(cos_limit), n, _p(P), _p(Nn), _p(mn), _p(mx),
+                         *[_p(out[k]) for k in ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "level", "view_cos")])
+    return out
+
+
+def undistort_points(xy, cam, dist):
+    """cv::undistortPoints(xy, K, dist, R=I, P=K) [OCV-recalled].  cam = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])."""
+    a = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    o = np.zeros_like(a)
+    d = list(dist) + [0.0] * (5 - len(dist))
+    L = lib()
+    L.orbo_undistort_points.restype = None
+    L.orbo_undistort_points(len(a), _p(a), *[C.c_float(x) for x in cam[:4]], *[C.c_float(x) for x in d], _p(o))
+    return o
+
+
+def image_bounds(width, height, cam, dist):
+    b = np.zeros(4, np.float32)
+    d = list(dist) + [0.0] * (5 - len(dist))
+    L = lib()
+    L.orbo_image_bounds.restype = None
+    L.orbo_image_bounds(int(width), int(height), *[C.c_float(x) for x in cam[:4]], *[C.c_float(x) for x in d], _p(b))
+    return b

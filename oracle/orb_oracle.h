@@ -257,6 +257,17 @@ void orbo_fuse_search(const orbo_grid *grid, const orbo_keypoint *kps_un, const 
  * to the others (median = sorted row [0.5*(N-1)], first minimum wins); -1 for an empty set. */
 void orbo_distinctive_descriptors(const uint8_t *desc, const int32_t *set_ptr, int n_sets, int32_t *best_idx);
 
+/* Candidate-generation pre-passes (orb_oracle_geom.cc): Frame::isInFrustum (Frame.cc:512-575, Nleft == -1) with
+ * MapPoint::PredictScale and Pinhole::project; cv::undistortPoints as Frame::UndistortKeyPoints / ComputeImageBounds call it. */
+void orbo_is_in_frustum(const float *Rcw, const float *tcw, const float *Ow, float fx, float fy, float cx, float cy, float mbf,
+                        const float *bounds, float log_scale_factor, int nlevels, float viewing_cos_limit, int n, const float *pos,
+                        const float *normal, const float *min_dist, const float *max_dist, uint8_t *in_view, float *proj_x, float *proj_y,
+                        float *proj_xr, float *depth, int32_t *level, float *view_cos);
+void orbo_undistort_points(int n, const float *xy_in, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2,
+                           float k3, float *xy_out);
+void orbo_image_bounds(int width, int height, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2, float k3,
+                       float *bounds);
+
 /* M9: BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2): idx[2*i..], dist[2*i..]; -1 when fewer than k train rows */
 void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist);
 

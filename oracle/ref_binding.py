@@ -513,3 +513,28 @@ def ref_search_by_bow_frame_fisheye(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, 
     n = L.matref_search_by_bow_frame_fisheye(_p(kd), _p(ka), _p(kv), len(kd), C.byref(a), _p(fd), _p(fa), len(fd), int(n_f_left), C.byref(b),
                                              C.c_float(nnratio), int(check_orientation), _p(fm))
     return n, fm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# oracle/_ref/libfrustum_ref.so: Frame::isInFrustum + MapPoint::PredictScale + Pinhole::project from the reference's own text
+# ---------------------------------------------------------------------------------------------------------------------
+def frustum_available() -> bool:
+    return (_DIR / "libfrustum_ref.so").exists()
+
+
+def ref_is_in_frustum(Rcw, tcw, Ow, cam, bounds, log_scale_factor, nlevels, cos_limit, pos, normal, min_dist, max_dist):
+    f32 = np.float32
+    L = C.CDLL(str(_DIR / "libfrustum_ref.so"))
+    R, t, O, b = [np.ascontiguousarray(x, f32).ravel() for x in (Rcw, tcw, Ow, bounds)]
+    P, Nn = np.ascontiguousarray(pos, f32).reshape(-1, 3), np.ascontiguousarray(normal, f32).reshape(-1, 3)
+    mn, mx = _f32(min_dist), _f32(max_dist)
+    n = len(P)
+    out = dict(in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, f32), proj_y=np.zeros(n, f32), proj_xr=np.zeros(n, f32),
+               depth=np.zeros(n, f32), level=np.zeros(n, np.int32), view_cos=np.zeros(n, f32))
+    ret = np.zeros(n, np.uint8)
+    L.frustumref_is_in_frustum.restype = None
+    L.frustumref_is_in_frustum(_p(R), _p(t), _p(O), *[C.c_float(x) for x in cam[:5]], _p(b), C.c_float(log_scale_factor), int(nlevels),
+                               C.c_float(cos_limit), n, _p(P), _p(Nn), _p(mn), _p(mx),
+                               *[_p(out[k]) for k in ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "level", "view_cos")], _p(ret))
+    out["ret"] = ret
+    return out

@@ -42,7 +42,27 @@ class Params(C.Structure):
 
 class BatchView(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("cap", C.c_int32), ("d_keypoints", C.c_void_p),
-                ("d_descriptors", C.c_void_p), ("d_count", C.c_void_p), ("d_mono_index", C.c_void_p)]
+                ("d_descriptors", C.c_void_p), ("d_count", C.c_void_p), ("d_mono_index", C.c_void_p),
+                ("d_keypoints_un", C.c_void_p)]
+
+
+class Camera(C.Structure):
+    """orbx_camera: Pinhole intrinsics, radial-tangential distortion (k1, k2, p1, p2, k3), mbf."""
+    _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")]
+
+
+class FramePose(C.Structure):
+    """orbx_frame_pose: Frame::mRcw (row-major), mtcw, mOw."""
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3)]
+
+    @classmethod
+    def make(cls, Rcw, tcw, Ow):
+        import numpy as np
+        p = cls()
+        p.Rcw[:] = [float(x) for x in np.asarray(Rcw, np.float32).ravel()]
+        p.tcw[:] = [float(x) for x in np.asarray(tcw, np.float32).ravel()]
+        p.Ow[:] = [float(x) for x in np.asarray(Ow, np.float32).ravel()]
+        return p
 
 
 class FrameDesc(C.Structure):
@@ -77,7 +97,8 @@ SYMBOLS = [
     "orbx_matcher_destroy", "orbx_hamming_csr", "orbx_hamming_best2_csr", "orbx_knn2", "orbx_stereo_rowband",
     "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
     "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window", "orbx_search_by_projection_mappoints_fisheye", "orbx_search_by_projection_frame_fisheye",
-    "orbx_search_by_bow_frame_fisheye",
+    "orbx_search_by_bow_frame_fisheye", "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_is_in_frustum", "orbx_frustum_batch_device",
+    "orbx_set_camera", "orbx_batch_download_keypoints_un",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
     "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
     "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors", "orbx_fuse_search",
@@ -139,6 +160,12 @@ def lib() -> C.CDLL:
     L.orbx_search_by_projection_mappoints_fisheye.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, i32] + [vp] * 12 + [f32, f32, vp]
     L.orbx_search_by_projection_frame_fisheye.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, i32] + [vp] * 8 + [f32, i32, i32, vp]
     L.orbx_search_by_bow_frame_fisheye.argtypes = [vp, vp, vp, vp, i32, C.POINTER(FeatVec), vp, vp, i32, i32, C.POINTER(FeatVec), f32, i32, vp]
+    L.orbx_undistort_keypoints.argtypes = [vp, C.POINTER(Camera), vp, i32, vp]
+    L.orbx_image_bounds.argtypes = [C.POINTER(Camera), i32, i32, vp]
+    L.orbx_is_in_frustum.argtypes = [vp, C.POINTER(Camera), C.POINTER(FramePose), vp, f32, i32, f32, i32] + [vp] * 11
+    L.orbx_frustum_batch_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(FramePose), i32, vp, f32, i32] + [vp] * 11
+    L.orbx_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    L.orbx_batch_download_keypoints_un.argtypes = [vp, i32, vp, i32, vp]
     L.orbx_match_consecutive_device.argtypes = [vp, f32, f32, f32, i32, vp, vp]
     L.orbx_stereo_batch_device.argtypes = [vp, vp, f32, f32]
     L.orbx_vocabulary_create.argtypes = [i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]

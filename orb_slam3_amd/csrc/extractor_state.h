@@ -155,6 +155,14 @@ struct orbx_extractor {
     struct MpKey { int n = 0, cap = 0, n_mp = 0; const void *px = nullptr, *py = nullptr, *lvl = nullptr, *vc = nullptr, *iv = nullptr, *desc = nullptr,
                    *match = nullptr, *nm = nullptr, *kps = nullptr; size_t dstride = 0; float th = 0, ratio = 0; } mpkey;
 
+    // camera of the batch path (orbx_set_camera): undistorted keypoints + undistorted image bounds for the batched matchers
+    bool has_camera = false;
+    float cam_params[9] = {0};           // fx fy cx cy k1 k2 p1 p2 k3
+    float cam_bf = 0;
+    float bounds[4] = {0, 0, 0, 0};      // mnMinX, mnMaxX, mnMinY, mnMaxY of the current geometry
+    DevBuf d_kps_un, d_frustum_frames;
+    const void *match_kps() const { return has_camera ? d_kps_un.p : d_kps.p; }
+
     int ensure_stage(size_t bytes) {
         if (bytes <= h_stage_bytes) return ORBX_OK;
         if (h_stage) (void)hipHostFree(h_stage);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "extractor_kernels.hip.h"
+#include "geometry_kernels.hip.h"
 #include "extractor_state.h"
 
 namespace orbx {
@@ -208,6 +209,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_work, sizeof(WorkItem) * (size_t)cap * B);
     ENS(ex->d_kps, sizeof(orbx_keypoint) * (size_t)cap * B);
     ENS(ex->d_desc, (size_t)32 * cap * B);
+    if (ex->has_camera) { ENS(ex->d_kps_un, sizeof(orbx_keypoint) * (size_t)cap * B); }
     ENS(ex->d_count, sizeof(int32_t) * (size_t)B);
     ENS(ex->d_mono, sizeof(int32_t) * (size_t)B);
     ENS(ex->d_err, sizeof(int32_t));
@@ -230,6 +232,13 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size();
     ex->last_batch = 0;
+    if (ex->has_camera) {
+        CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],
+                         ex->cam_params[6], ex->cam_params[7], ex->cam_params[8]};
+        image_bounds(c, width, height, ex->bounds);
+    } else {
+        ex->bounds[0] = 0.f; ex->bounds[1] = (float)width; ex->bounds[2] = 0.f; ex->bounds[3] = (float)height;   // Frame.cc:804-807
+    }
     return ORBX_OK;
 }
 
@@ -365,6 +374,12 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
                            ex->pyr_frame, (const uint8_t *)ex->d_blur.p, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
                            (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0);
+    }
+    if (ex->has_camera) {   // Frame::UndistortKeyPoints for the whole batch (mvKeysUn for the batched matchers)
+        CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],
+                         ex->cam_params[6], ex->cam_params[7], ex->cam_params[8]};
+        hipLaunchKernelGGL(k_undistort, dim3((ex->cap + 255) / 256, n), dim3(256), 0, st, c, (const orbx_keypoint *)ex->d_kps.p,
+                           (const int32_t *)ex->d_count.p, ex->cap, (orbx_keypoint *)ex->d_kps_un.p);
     }
     ORBX_HIP(hipEventRecord(ex->ev_describe, st));
     ORBX_HIP(hipGetLastError());
@@ -523,7 +538,7 @@ void orbx_destroy(orbx_extractor *ex) {
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
-                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries};
+                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);
@@ -577,6 +592,41 @@ int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_f
     return enqueue_extract(ex, (const uint8_t *)din.p, n_frames, width, fbytes, lap0, lap1, ex->ev_in_free[slot]);
 }
 
+int orbx_set_camera(orbx_extractor *ex, const orbx_camera *cam) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
+    ex->has_camera = cam != nullptr;
+    if (cam) {
+        const float p[9] = {cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
+        memcpy(ex->cam_params, p, sizeof(p));
+        ex->cam_bf = cam->bf;
+    }
+    // re-derive the workspace (d_kps_un) and the image bounds for the current geometry
+    const int w = ex->width, h = ex->height, b = ex->batch_cap;
+    ex->width = 0; ex->height = 0;
+    ex->mkey = orbx_extractor::MatchKey(); ex->mpkey = orbx_extractor::MpKey();
+    if (w > 0 && h > 0) return configure(ex, w, h, std::max(b, 1));
+    return ORBX_OK;
+}
+
+int orbx_batch_download_keypoints_un(orbx_extractor *ex, int frame, orbx_keypoint *kps_un, int cap, int *n_out) {
+    if (!ex || frame < 0 || frame >= ex->last_batch) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    int32_t n = 0;
+    ORBX_HIP(hipMemcpyAsync(&n, (int32_t *)ex->d_count.p + frame, 4, hipMemcpyDeviceToHost, ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    if (n_out) *n_out = n;
+    if (n > cap) return ORBX_E_CAPACITY;
+    if (n > 0 && kps_un) {
+        ORBX_HIP(hipMemcpyAsync(kps_un, (const orbx_keypoint *)ex->match_kps() + (size_t)frame * ex->cap, sizeof(orbx_keypoint) * (size_t)n,
+                                hipMemcpyDeviceToHost, ex->stream));
+        ORBX_HIP(hipStreamSynchronize(ex->stream));
+    }
+    return ORBX_OK;
+}
+
 int orbx_output_capacity(orbx_extractor *ex, int width, int height) {
     if (!ex) return ORBX_E_BAD_ARG;
     if (hipSetDevice(ex->device) != hipSuccess) return ORBX_E_HIP;
@@ -603,6 +653,7 @@ int orbx_batch_view_get(orbx_extractor *ex, orbx_batch_view *v) {
     v->d_descriptors = (const uint8_t *)ex->d_desc.p;
     v->d_count = (const int32_t *)ex->d_count.p;
     v->d_mono_index = (const int32_t *)ex->d_mono.p;
+    v->d_keypoints_un = (const orbx_keypoint *)ex->match_kps();
     return ORBX_OK;
 }
 

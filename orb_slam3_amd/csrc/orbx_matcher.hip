@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "matcher_kernels.hip.h"
+#include "geometry_kernels.hip.h"
 #include "extractor_state.h"
 
 using namespace orbx;
@@ -850,7 +851,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         d_match = (int32_t *)ex->d_match.p;
         d_nmatches = (int32_t *)ex->d_nmatch.p;
     }
-    const orbx_keypoint *kps = (const orbx_keypoint *)ex->d_kps.p;
+    const orbx_keypoint *kps = (const orbx_keypoint *)ex->match_kps();   // mvKeysUn (== mvKeys without a distortion model)
     orbx_extractor::MatchKey key;
     key.n = n; key.cap = cap; key.match = d_match; key.nm = d_nmatches; key.th = th; key.du = du; key.dv = dv;
     key.ori = check_orientation; key.kps = kps;
@@ -896,9 +897,9 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         ex->mkey = key;
     }
     GridParams g;
-    g.minx = 0.f; g.miny = 0.f;  // undistorted bounds of a distortion-free camera: mnMinX = 0, mnMaxX = cols (Frame.cc:804-807)
-    g.inv_w = 64.0f / ((float)ex->width - 0.f);
-    g.inv_h = 48.0f / ((float)ex->height - 0.f);
+    g.minx = ex->bounds[0]; g.miny = ex->bounds[2];  // mnMinX.. of the extractor's camera (image rectangle without one, Frame.cc:804-807)
+    g.inv_w = 64.0f / (ex->bounds[1] - ex->bounds[0]);   // Frame.cc:342-343
+    g.inv_h = 48.0f / (ex->bounds[3] - ex->bounds[2]);
     // the matcher of batch i runs on its own stream beside the pyramid / FAST / quad-tree of batch i+1
     const bool side = !ex->profile && ex->side_streams;
     hipStream_t ms = side ? ex->match_stream : ex->stream;
@@ -954,7 +955,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
         d_match = (int32_t *)ex->d_match.p;
         d_nmatches = (int32_t *)ex->d_nmatch.p;
     }
-    const orbx_keypoint *kps = (const orbx_keypoint *)ex->d_kps.p;
+    const orbx_keypoint *kps = (const orbx_keypoint *)ex->match_kps();
     orbx_extractor::MpKey key;
     key.n = n; key.cap = cap; key.n_mp = n_mp; key.px = d_proj_x; key.py = d_proj_y; key.lvl = d_level; key.vc = d_view_cos; key.iv = d_in_view;
     key.desc = d_mp_desc; key.match = d_match; key.nm = d_nmatches; key.kps = kps; key.dstride = desc_frame_stride; key.th = th; key.ratio = nnratio;
@@ -1008,9 +1009,9 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
         ex->mpkey = key;
     }
     GridParams g;
-    g.minx = 0.f; g.miny = 0.f;
-    g.inv_w = 64.0f / ((float)ex->width - 0.f);
-    g.inv_h = 48.0f / ((float)ex->height - 0.f);
+    g.minx = ex->bounds[0]; g.miny = ex->bounds[2];  // mnMinX.. of the extractor's camera (image rectangle without one, Frame.cc:804-807)
+    g.inv_w = 64.0f / (ex->bounds[1] - ex->bounds[0]);   // Frame.cc:342-343
+    g.inv_h = 48.0f / (ex->bounds[3] - ex->bounds[2]);
     const bool side = !ex->profile && ex->side_streams;
     hipStream_t ms = side ? ex->match_stream : ex->stream;
     if (side) ORBX_HIP(hipStreamWaitEvent(ms, ex->ev_describe, 0));
@@ -1027,6 +1028,99 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
                        (const ResolveProblem *)ex->d_mp_res.p, g, cap);
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
     ex->match_pending = true;
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Candidate generation: Frame::UndistortKeyPoints, ComputeImageBounds, isInFrustum
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+inline CameraModel model_of(const orbx_camera *c) { return CameraModel{c->fx, c->fy, c->cx, c->cy, c->k1, c->k2, c->p1, c->p2, c->k3}; }
+inline FrustumFrame frustum_frame(const orbx_camera *cam, const orbx_frame_pose *pose, const float *b, float log_sf, int nlevels, float cos_limit) {
+    FrustumFrame F;
+    memcpy(F.Rcw, pose->Rcw, sizeof(F.Rcw)); memcpy(F.tcw, pose->tcw, sizeof(F.tcw)); memcpy(F.Ow, pose->Ow, sizeof(F.Ow));
+    F.fx = cam->fx; F.fy = cam->fy; F.cx = cam->cx; F.cy = cam->cy; F.mbf = cam->bf;
+    F.minx = b[0]; F.maxx = b[1]; F.miny = b[2]; F.maxy = b[3];
+    F.log_scale_factor = log_sf; F.nlevels = nlevels; F.cos_limit = cos_limit;
+    return F;
+}
+}  // namespace
+
+extern "C" int orbx_image_bounds(const orbx_camera *cam, int width, int height, float *bounds4) {
+    if (!cam || !bounds4 || width <= 0 || height <= 0) return ORBX_E_BAD_ARG;
+    image_bounds(model_of(cam), width, height, bounds4);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_undistort_keypoints(orbx_matcher *m, const orbx_camera *cam, const orbx_keypoint *kps, int n, orbx_keypoint *kps_un) {
+    if (!m || !cam || n < 0 || (n > 0 && (!kps || !kps_un))) return ORBX_E_BAD_ARG;
+    if (n == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(m->device));
+    int r = m->arena.reserve(2 * Arena::pad(sizeof(orbx_keypoint) * (size_t)n) + 4096);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    A.reset();
+    orbx_keypoint *di = A.take<orbx_keypoint>(n), *dou = A.take<orbx_keypoint>(n);
+    H2D(di, kps, sizeof(orbx_keypoint) * (size_t)n);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, m->stream, model_of(cam), (const orbx_keypoint *)di, (const int32_t *)nullptr, n, dou);
+    D2H(kps_un, dou, sizeof(orbx_keypoint) * (size_t)n);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_camera *cam, const orbx_frame_pose *pose, const float *bounds4, float log_scale_factor,
+                                  int nlevels, float viewing_cos_limit, int n_mp, const float *pos, const float *normal, const float *min_dist,
+                                  const float *max_dist, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr, float *depth, int32_t *level,
+                                  float *view_cos) {
+    if (!m || !cam || !pose || !bounds4 || nlevels < 1 || n_mp < 0) return ORBX_E_BAD_ARG;
+    if (n_mp > 0 && (!pos || !normal || !min_dist || !max_dist || !in_view || !proj_x || !proj_y || !proj_xr || !depth || !level || !view_cos)) return ORBX_E_BAD_ARG;
+    if (n_mp == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(m->device));
+    const size_t n = (size_t)n_mp;
+    int r = m->arena.reserve(2 * Arena::pad(12 * n) + 8 * Arena::pad(4 * n) + Arena::pad(n) + Arena::pad(sizeof(FrustumFrame)) + 8192);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    A.reset();
+    float *dp = A.take<float>(3 * n), *dn = A.take<float>(3 * n), *dmn = A.take<float>(n), *dmx = A.take<float>(n);
+    uint8_t *div = A.take<uint8_t>(n);
+    float *dx = A.take<float>(n), *dy = A.take<float>(n), *dxr = A.take<float>(n), *dd = A.take<float>(n), *dvc = A.take<float>(n);
+    int32_t *dl = A.take<int32_t>(n);
+    FrustumFrame *dF = A.take<FrustumFrame>(1);
+    const FrustumFrame F = frustum_frame(cam, pose, bounds4, log_scale_factor, nlevels, viewing_cos_limit);
+    H2D(dF, &F, sizeof(F));
+    H2D(dp, pos, 12 * n); H2D(dn, normal, 12 * n); H2D(dmn, min_dist, 4 * n); H2D(dmx, max_dist, 4 * n);
+    hipLaunchKernelGGL(k_in_frustum, dim3((n_mp + 255) / 256, 1), dim3(256), 0, m->stream, (const FrustumFrame *)dF, n_mp, (const float *)dp,
+                       (const float *)dn, (const float *)dmn, (const float *)dmx, div, dx, dy, dxr, dd, dl, dvc);
+    D2H(in_view, div, n); D2H(proj_x, dx, 4 * n); D2H(proj_y, dy, 4 * n); D2H(proj_xr, dxr, 4 * n); D2H(depth, dd, 4 * n);
+    D2H(level, dl, 4 * n); D2H(view_cos, dvc, 4 * n);
+    ORBX_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_frustum_batch_device(orbx_extractor *ex, const orbx_camera *cam, const orbx_frame_pose *poses, int n_frames, const float *bounds4,
+                                         float viewing_cos_limit, int n_mp, const float *d_pos, const float *d_normal, const float *d_min_dist,
+                                         const float *d_max_dist, uint8_t *d_in_view, float *d_proj_x, float *d_proj_y, float *d_proj_xr,
+                                         float *d_depth, int32_t *d_level, float *d_view_cos) {
+    if (!ex || !cam || !poses || n_frames < 1 || n_mp < 0) return ORBX_E_BAD_ARG;
+    if (n_mp > 0 && (!d_pos || !d_normal || !d_min_dist || !d_max_dist || !d_in_view || !d_proj_x || !d_proj_y || !d_proj_xr || !d_depth || !d_level || !d_view_cos))
+        return ORBX_E_BAD_ARG;
+    if (n_mp == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(ex->device));
+    const bool side = !ex->profile && ex->side_streams;
+    hipStream_t ms = side ? ex->match_stream : ex->stream;
+    if (ex->d_frustum_frames.bytes < sizeof(FrustumFrame) * (size_t)n_frames) ORBX_HIP(hipStreamSynchronize(ms));
+    int r = ex->d_frustum_frames.ensure(sizeof(FrustumFrame) * (size_t)n_frames);
+    if (r != ORBX_OK) return r;
+    const float *b = bounds4 ? bounds4 : ex->bounds;
+    if (!bounds4 && ex->width <= 0) return ORBX_E_BAD_ARG;
+    const float log_sf = logf((float)(double)ex->prm.scale_factor);   // Frame::mfLogScaleFactor = log(mfScaleFactor) (Frame.cc:120)
+    std::vector<FrustumFrame> F(n_frames);
+    for (int f = 0; f < n_frames; f++) F[f] = frustum_frame(cam, poses + f, b, log_sf, ex->prm.nlevels, viewing_cos_limit);
+    ORBX_HIP(hipMemcpyAsync(ex->d_frustum_frames.p, F.data(), sizeof(FrustumFrame) * (size_t)n_frames, hipMemcpyHostToDevice, ms));
+    ORBX_HIP(hipStreamSynchronize(ms));   // F is a host temporary (the poses change every frame: this copy is the per-batch upload)
+    hipLaunchKernelGGL(k_in_frustum, dim3((n_mp + 255) / 256, n_frames), dim3(256), 0, ms, (const FrustumFrame *)ex->d_frustum_frames.p, n_mp, d_pos,
+                       d_normal, d_min_dist, d_max_dist, d_in_view, d_proj_x, d_proj_y, d_proj_xr, d_depth, d_level, d_view_cos);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }

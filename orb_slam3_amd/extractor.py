@@ -88,6 +88,33 @@ class ORBextractor:
               "orbx_batch_download")
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
 
+    # ---- camera of the batch path: Frame::UndistortKeyPoints + ComputeImageBounds for the batched matchers ----
+    def set_camera(self, cam=None):
+        """cam: dict/tuple (fx, fy, cx, cy, k1, k2, p1, p2, k3, bf) or None (distortion-free default)."""
+        if cam is None:
+            check(self._L.orbx_set_camera(self._h, None), "orbx_set_camera")
+        else:
+            c = _lib.Camera(*[float(x) for x in cam])
+            check(self._L.orbx_set_camera(self._h, C.byref(c)), "orbx_set_camera")
+
+    def download_keypoints_un(self, frame: int) -> np.ndarray:
+        cap = self.batch_view().cap
+        k = np.zeros(cap, KP_DTYPE)
+        n = C.c_int(0)
+        check(self._L.orbx_batch_download_keypoints_un(self._h, frame, ptr(k), cap, C.byref(n)), "orbx_batch_download_keypoints_un")
+        return k[:n.value].copy()
+
+    def frustum_batch_device(self, cam, poses, cos_limit, n_mp, d_pos, d_normal, d_min, d_max, d_in_view, d_proj_x, d_proj_y, d_proj_xr,
+                             d_depth, d_level, d_view_cos, bounds=None):
+        """Frame::isInFrustum for every (pose, map point); poses: list of (Rcw, tcw, Ow); d_*: raw device pointers."""
+        c = _lib.Camera(*[float(x) for x in cam])
+        P = (_lib.FramePose * len(poses))(*[_lib.FramePose.make(*p) for p in poses])
+        b = None if bounds is None else np.ascontiguousarray(bounds, np.float32)
+        vp = C.c_void_p
+        check(self._L.orbx_frustum_batch_device(self._h, C.byref(c), P, len(poses), ptr(b), cos_limit, n_mp,
+                                                *[vp(x) for x in (d_pos, d_normal, d_min, d_max, d_in_view, d_proj_x, d_proj_y, d_proj_xr, d_depth,
+                                                                  d_level, d_view_cos)]), "orbx_frustum_batch_device")
+
     def download_all(self, kps=None, desc=None, counts=None, mono=None):
         v = self.batch_view()
         n, cap = v.n_frames, v.cap

@@ -190,6 +190,36 @@ class ORBmatcher:
             "orbx_search_by_projection_frame")
         return n, (cm if raw else np.maximum(cm, -1))
 
+    # ---- candidate generation: Frame::UndistortKeyPoints / ComputeImageBounds / isInFrustum ----
+    def UndistortKeyPoints(self, cam, kps):
+        from ._lib import Camera
+        k = np.ascontiguousarray(kps, KP_DTYPE)
+        out = np.zeros(len(k), KP_DTYPE)
+        c = Camera(*[float(x) for x in cam])
+        check(self._L.orbx_undistort_keypoints(self._h, C.byref(c), ptr(k), len(k), ptr(out)), "orbx_undistort_keypoints")
+        return out
+
+    def ComputeImageBounds(self, cam, width, height):
+        from ._lib import Camera
+        b = np.zeros(4, np.float32)
+        c = Camera(*[float(x) for x in cam])
+        check(self._L.orbx_image_bounds(C.byref(c), int(width), int(height), ptr(b)), "orbx_image_bounds")
+        return b
+
+    def isInFrustum(self, cam, pose, bounds, log_scale_factor, nlevels, cos_limit, pos, normal, min_dist, max_dist):
+        """Frame::isInFrustum for n map points (Nleft == -1).  pose = (Rcw, tcw, Ow).  Returns dict like the oracle's."""
+        from ._lib import Camera, FramePose
+        P, Nn = _f32(np.asarray(pos).reshape(-1, 3)), _f32(np.asarray(normal).reshape(-1, 3))
+        mn, mx, b = _f32(min_dist), _f32(max_dist), _f32(bounds)
+        n = len(P)
+        out = dict(in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, np.float32), proj_y=np.zeros(n, np.float32), proj_xr=np.zeros(n, np.float32),
+                   depth=np.zeros(n, np.float32), level=np.zeros(n, np.int32), view_cos=np.zeros(n, np.float32))
+        c, p = Camera(*[float(x) for x in cam]), FramePose.make(*pose)
+        check(self._L.orbx_is_in_frustum(self._h, C.byref(c), C.byref(p), ptr(b), float(log_scale_factor), int(nlevels), float(cos_limit), n, ptr(P),
+                                         ptr(Nn), ptr(mn), ptr(mx), *[ptr(out[k]) for k in ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "level", "view_cos")]),
+              "orbx_is_in_frustum")
+        return out
+
     # ---- fisheye-stereo twins (F.Nleft != -1): features [0, n_left) left camera, [n_left, N) right camera ----
     def SearchByProjectionFisheye(self, left: FrameView, kps_right, l2r, r2l, mp: dict, th: float = 3.0, frame_occupied=None):
         """ORBmatcher.cc:43-213 whole.  left.descriptors holds ALL n_left + n_right rows; mp: in_view, proj_x, proj_y, level,

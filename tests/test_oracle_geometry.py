@@ -1,0 +1,96 @@
+"""Oracle restatements of the candidate-generation pre-passes.
+
+* Frame::isInFrustum (+ MapPoint::PredictScale, Pinhole::project): the oracle against the reference's own text compiled where it
+  lies (oracle/_ref/libfrustum_ref.so: stand-in float Eigen, operations rounded as written), bit for bit, live or against the
+  committed outputs of that library (tests/golden/frustum_ref.npz).
+* cv::undistortPoints [OCV-recalled]: parity UNPINNED (no OpenCV here); checked against the defining property instead -- pushing the
+  undistorted point through the forward radial-tangential model the reference itself spells out (Frame::ProjectPointDistort,
+  Frame.cc:577-645) must give back the distorted pixel."""
+import numpy as np
+import pytest
+
+from oracle import oracle_binding as ob
+from oracle import ref_binding as rb
+from _pin import Pinner
+
+_P = Pinner("frustum_ref.npz", rb.frustum_available())
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_golden():
+    yield
+    _P.finish()
+
+
+def frustum_case(seed, n=4000):
+    rng = np.random.default_rng(seed)
+    a, b, c = rng.uniform(-0.3, 0.3, 3)       # a pose with a real rotation
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    Rcw = (Rz @ Ry @ Rx).astype(np.float32)
+    tcw = rng.uniform(-1, 1, 3).astype(np.float32)
+    Ow = (-(Rcw.astype(np.float64).T @ tcw.astype(np.float64))).astype(np.float32)
+    cam = (458.654, 457.296, 367.215, 248.375, 47.9)             # EuRoC cam0 intrinsics, bf
+    bounds = np.array([-10.5, 760.25, -8.0, 488.5], np.float32)  # undistorted image bounds stick out of the image
+    pos = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    pos[:, 2] = rng.uniform(-2, 12, n)                            # some behind the camera
+    normal = rng.normal(0, 1, (n, 3))
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    towards = (Ow[None, :] - pos)
+    towards /= np.linalg.norm(towards, axis=1, keepdims=True)
+    flip = rng.random(n) < 0.6                                    # most normals roughly face the camera
+    normal[flip] = -(towards[flip] + rng.normal(0, 0.3, (flip.sum(), 3))).astype(np.float32)
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    dist = np.linalg.norm(pos - Ow, axis=1)
+    max_d = (dist * rng.uniform(0.7, 4.0, n)).astype(np.float32)
+    min_d = (max_d / rng.uniform(1.5, 4.3, n)).astype(np.float32)
+    return Rcw, tcw, Ow, cam, bounds, np.float32(np.log(1.2)), 8, 0.5, pos, normal, min_d, max_d
+
+
+KEYS = ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "level", "view_cos")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_is_in_frustum_equals_reference_text(seed):
+    args = frustum_case(seed)
+    o = ob.is_in_frustum(*args)
+    # fields the reference leaves untouched on rejection are whatever the MapPoint held before: compare them only where in_view
+    def flat(d):
+        iv = d["in_view"].astype(bool)
+        return [d["in_view"], d["proj_x"], d["proj_y"]] + [np.where(iv, d[k], 0) for k in KEYS[3:]]
+    _P.pin(f"frustum/{seed}", flat(o), lambda: flat(rb.ref_is_in_frustum(*args)))
+    iv = o["in_view"].astype(bool)
+    assert 200 < iv.sum() < len(iv) - 200
+    assert len(np.unique(o["level"][iv])) >= 6 and (o["proj_x"][~iv] == -1).sum() > 100 and ((o["proj_x"] != -1) & ~iv).sum() > 100
+
+
+def _distort(xy_un, cam, dist):
+    """Frame::ProjectPointDistort's forward model (Frame.cc:612-636) in float64."""
+    fx, fy, cx, cy = cam
+    k1, k2, p1, p2, k3 = dist
+    x, y = (xy_un[:, 0] - cx) / fx, (xy_un[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2
+    xd = x * rad + (2 * p1 * x * y + p2 * (r2 + 2 * x * x))
+    yd = y * rad + (p1 * (r2 + 2 * y * y) + 2 * p2 * x * y)
+    return np.stack([xd * fx + cx, yd * fy + cy], axis=1)
+
+
+@pytest.mark.parametrize("cam,dist,size", [((458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0), (752, 480)),   # EuRoC cam0
+                                            ((517.3, 516.5, 318.6, 255.3), (0.2624, -0.9531, -0.0054, 0.0026, 1.1633), (640, 480))])                    # TUM1
+def test_undistort_points_inverts_the_forward_model(cam, dist, size):
+    rng = np.random.default_rng(5)
+    xy = np.stack([rng.uniform(0, size[0], 5000), rng.uniform(0, size[1], 5000)], axis=1).astype(np.float32)
+    un = ob.undistort_points(xy, cam, dist)
+    back = _distort(un.astype(np.float64), cam, dist)
+    err = np.abs(back - xy).max(axis=1)
+    # cv::undistortPoints stops after 5 fixed-point iterations: converged to thousandths of a pixel mid-image, tenths in the corners
+    assert np.percentile(err, 99) < 0.5 and np.median(err) < 2e-2 and np.percentile(err, 25) < 2e-3
+    assert np.abs(un - xy).max() > 3.0                               # and the distortion is not a no-op
+    size = (752, 480)
+    b = ob.image_bounds(752, 480, cam, dist)
+    corners = ob.undistort_points(np.array([[0, 0], [752, 0], [0, 480], [752, 480]], np.float32), cam, dist)
+    assert b[0] == min(corners[0, 0], corners[2, 0]) and b[1] == max(corners[1, 0], corners[3, 0])
+    assert b[2] == min(corners[0, 1], corners[1, 1]) and b[3] == max(corners[2, 1], corners[3, 1])
+    assert np.array_equal(ob.image_bounds(752, 480, cam, (0.0, 0, 0, 0, 0)), np.array([0, 752, 0, 480], np.float32))
