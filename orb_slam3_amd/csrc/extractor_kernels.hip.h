@@ -445,6 +445,30 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
+// phase 0 of the one-wave-per-cell FAST kernels: the cell's sub-image (+1 byte left, so that interior groups are dword aligned in LDS)
+// into the LDS tile.  16 lanes per row, 4 rows per step; the global loads of up to 12 steps (48 rows) are issued back to back and
+// only then stored -- ONE memory round trip per wave instead of one per step (the wave's lifetime, not VALU issue, bounds these
+// kernels once the per-pixel work is cheap: 175 waves per SIMD take turns, 8 at a time).
+template <int P>
+__device__ __forceinline__ void fast_tile_load(const uint8_t *__restrict__ src, int pitch, int rows, int cols, uint8_t *pix, int lane) {
+    const int c = lane & 15, nd = (cols + 4) >> 2, r0 = lane >> 4;
+    if (c >= nd) return;
+    for (int base = 0; base < rows; base += 48) {
+        uint32_t v[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int r = base + r0 + 4 * k;
+            v[k] = 0;
+            if (r < rows) __builtin_memcpy(&v[k], src + (size_t)r * pitch + 4 * c, 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int r = base + r0 + 4 * k;
+            if (r < rows) *reinterpret_cast<uint32_t *>(pix + r * P + 4 * c) = v[k];
+        }
+    }
+}
+
 // LDS of one wave (= one cell): pixel tile rows x P | queue[qcap] u16 | score per queue entry [qcap] u8.  After the scores are
 // known the pixel tile is dead and its memory becomes the zero-aproned score tile of the NMS; the survivors of the NMS
 // overwrite the head of the queue in place.  ~4.7 KB for EuRoC (P = 48, qcap = 768) -> 32 waves per CU: the kernel's time
@@ -477,18 +501,8 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
     uint16_t *queue = reinterpret_cast<uint16_t *>(smem + (((size_t)max_rows * P + 16 + 15) & ~(size_t)15));  // qcap entries
     uint8_t *scq = reinterpret_cast<uint8_t *>(queue + qcap);                             // qcap scores
 
-    {   // phase 0: P/4 lanes per row, (unaligned) dword loads starting one byte left of the sub-image
-        const uint8_t *src = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1;
-        const int c = lane & 15, nd = (cols + 4) >> 2;
-        if (c < nd) {
-            const uint8_t *p = src + (size_t)(lane >> 4) * L.pitch + 4 * c;
-            for (int r = lane >> 4; r < rows; r += 4, p += 4 * (size_t)L.pitch) {
-                uint32_t v;
-                __builtin_memcpy(&v, p, 4);
-                *reinterpret_cast<uint32_t *>(pix + r * P + 4 * c) = v;
-            }
-        }
-    }
+    // phase 0: (unaligned) dword loads starting one byte left of the sub-image
+    fast_tile_load<P>(pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1, L.pitch, rows, cols, pix, lane);
     __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
 
     // phase 1: antipodal-pair test at minTh, four pixels per lane; passing pixels are queued in row-major order
@@ -611,6 +625,161 @@ __global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ 
                       iniTh, minTh, max_rows, qcap, ovf_list, ovf_count);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_fast_ini: the first pass of the reference's per-cell detection, cv::FAST(cell, iniThFAST) (:826), for every cell -- and nothing
+// else.  A cell whose pass finds corners is finished (the reference never runs its second pass there); a cell whose pass finds none
+// (or whose queue overflows) goes to the list that k_fast_wave_list works through with the complete ini / min logic of
+// fast_wave_cell.  The score map at iniTh gives exactly the survivors the minTh map would give after the >= iniTh filter
+// (a pixel below iniTh cannot suppress one at or above it), so S20 is unchanged.
+// Why a separate pass: at iniTh most 4-pixel groups can be REJECTED before the antipodal-pair test.  A 9-arc contains one pixel
+// of every antipodal circle pair, so if BOTH pixels of some pair differ from the centre by at most t, there is no corner; for four
+// adjacent centres at once: v_sad_u8(centre dword, neighbour dword) <= t bounds all four |differences| by t.  Stage A tests the
+// vertical pair (rows y-3 / y+3: aligned dwords) and the horizontal pair (x-3 / x+3: v_alignbyte) -- 16 VALU for four pixels,
+// about 70 % of the groups of the EuRoC-like frames rejected at t = 20 (a few per cent at t = 7: noise) -- and queues the
+// surviving groups in row-major order; stage B runs the four-pair test of k_fast_wave on the queued groups only, all lanes busy.
+//   LDS: pixel tile | pixel queue u16[qcap] | scores u8[qcap] | group queue u16[gcap]
+// grid (total_cells, B), block 64
+// ---------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t fast_ini_lds_bytes(int P, int max_rows, int qcap, int gcap) {
+    return (((size_t)max_rows * P + 16 + 15) & ~(size_t)15) + (size_t)qcap * 3 + 16 + (size_t)gcap * 2;
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void k_fast_ini(const FastTile *__restrict__ ftiles, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                 int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
+                                                 size_t ent_frame_stride, int iniTh, int max_rows, int qcap, int gcap,
+                                                 uint32_t *__restrict__ list, int32_t *__restrict__ list_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const FastTile T = ftiles[blockIdx.x];
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x;
+    int32_t *cnt_out = cellcnt + (size_t)f * total_cells + T.cell;
+    const int cols = T.cols, rows = T.rows;
+    const int iw = cols - 6, ih = rows - 6;
+    if (cols <= 0) {  // :813 / :821 skip rules (decided on the host when the tile table is built)
+        if (lane == 0) *cnt_out = 0;
+        return;
+    }
+    uint8_t *pix = smem;
+    uint16_t *queue = reinterpret_cast<uint16_t *>(smem + (((size_t)max_rows * P + 16 + 15) & ~(size_t)15));
+    uint8_t *scq = reinterpret_cast<uint8_t *>(queue + qcap);
+    uint16_t *gq = reinterpret_cast<uint16_t *>(scq + qcap + 16 - (qcap & 1));   // 2-byte aligned
+
+    fast_tile_load<P>(pyr + (size_t)f * pyr_frame_stride + T.src_off, T.pitch, rows, cols, pix, lane);   // phase 0
+    __syncthreads();
+
+    constexpr int D = P / 4;
+    const int G = (iw + 3) >> 2, RPI = 64 / G;
+    const uint32_t ut = (uint32_t)iniTh;
+    int gn = 0;
+    {   // stage A: groups whose vertical AND horizontal antipodal pairs cannot both be rejected by the SAD bound
+        const uint32_t rcpG = ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G;
+        const int lrow = (int)(((uint32_t)lane * rcpG) >> 20), lg = lane - lrow * G;
+        const uint8_t *Abase = pix + lrow * P + 4 * lg + 4;
+        const uint32_t ebase = ((uint32_t)lrow << 8) | (uint32_t)(4 * lg);
+        for (int y0 = 0; y0 < ih; y0 += RPI) {
+            const bool act = lrow < RPI && y0 + lrow < ih;
+            const uint32_t *A = reinterpret_cast<const uint32_t *>(Abase + y0 * P);   // row y of the centre row y+3
+            const uint32_t r8 = A[0], r0 = A[6 * D];
+            const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];
+            const uint32_t sv = max(__builtin_amdgcn_sad_u8(cC, r0, 0u), __builtin_amdgcn_sad_u8(cC, r8, 0u));
+            const uint32_t p4 = __builtin_amdgcn_alignbyte(cR, cC, 3), p12 = __builtin_amdgcn_alignbyte(cC, cL, 1);
+            const uint32_t sh = max(__builtin_amdgcn_sad_u8(cC, p4, 0u), __builtin_amdgcn_sad_u8(cC, p12, 0u));
+            const bool keep = act && min(sv, sh) > ut;   // neither pair is "both within t for all four pixels"
+            const unsigned long long b = __ballot(keep);
+            if (keep) gq[gn + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)(ebase + ((uint32_t)y0 << 8));
+            gn += __popcll(b);
+        }
+    }
+    __syncthreads();
+
+    // stage B: the antipodal-pair test of k_fast_wave (at iniTh) on the queued groups, four pixels per lane, row-major queue order
+    int qn = 0;
+    {
+        const u16x2 t2 = as_pk(ut * 0x00010001u);
+        for (int g0 = 0; g0 < gn; g0 += 64) {
+            const int gi = g0 + lane;
+            const bool act = gi < gn;
+            const uint32_t e0 = act ? (uint32_t)gq[gi] : 0u;
+            const int y = (int)(e0 >> 8), x4 = (int)(e0 & 0xff);
+            const uint32_t vmask = 0xfu >> max(x4 + 3 - (iw - 1), 0);   // pixels of the last group beyond the interior
+            const uint32_t *A = reinterpret_cast<const uint32_t *>(pix + y * P + x4 + 4);
+            const uint32_t r8 = A[0], r0 = A[6 * D];
+            const uint32_t aL = A[1 * D - 1], aC = A[1 * D], aR = A[1 * D + 1];
+            const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];
+            const uint32_t bL = A[5 * D - 1], bC = A[5 * D], bR = A[5 * D + 1];
+#define FW_EVEN(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(s) | ((uint32_t)((s) + 2) << 16)))
+#define FW_ODD(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)((s) + 1) | ((uint32_t)((s) + 3) << 16)))
+            const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), FW_EVEN(cR, cC, 3), FW_EVEN(cC, cL, 1), FW_EVEN(bR, bC, 2),
+                                            FW_EVEN(aC, aL, 2), FW_EVEN(aR, aC, 2), FW_EVEN(bC, bL, 2), t2);
+            const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), FW_ODD(cR, cC, 3), FW_ODD(cC, cL, 1), FW_ODD(bR, bC, 2),
+                                            FW_ODD(aC, aL, 2), FW_ODD(aR, aC, 2), FW_ODD(bC, bL, 2), t2);
+#undef FW_EVEN
+#undef FW_ODD
+            uint32_t ze, zo;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(ze) : "v"(fe), "v"(0x00010001u));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(zo) : "v"(fo), "v"(0x00010001u));
+            const uint32_t z = ze | (zo << 1);
+            uint32_t m4 = (z | (z >> 14)) & 0xfu;
+            m4 &= act ? vmask : 0u;
+            const int c = __popc(m4);
+            const int incl = wave_incl_scan(c);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            if (qn + tot > qcap) {   // more candidates than the LDS queue holds: the list kernel takes this cell
+                if (lane == 0) list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | blockIdx.x;
+                return;
+            }
+            int pos = qn + incl - c;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (m4 & (1u << k)) { queue[pos] = (uint16_t)(e0 + k); pos++; }
+            }
+            qn += tot;
+        }
+    }
+    __syncthreads();
+
+    // phase 2: exact score of the queued pixels at iniTh
+    for (int e = lane; e < qn; e += 64) {
+        const int q = queue[e];
+        const int y = q >> 8, x = q & 0xff;
+        int s = fast_score16(pix + (y + 3) * P + x + 4, P);
+        scq[e] = (uint8_t)((s >= iniTh) ? s : 0);
+    }
+    __syncthreads();
+    uint8_t *sco = pix;   // the pixel tile is dead: score tile with a zero apron
+    for (int i = lane; i < (ih + 2) * (P / 4); i += 64) reinterpret_cast<uint32_t *>(sco)[i] = 0;
+    __syncthreads();
+    for (int e = lane; e < qn; e += 64) {
+        const int s = scq[e];
+        if (s) { const int q = queue[e]; sco[((q >> 8) + 1) * P + (q & 0xff) + 1] = (uint8_t)s; }
+    }
+    __syncthreads();
+
+    // phase 3 + 4: NMS, survivors emitted in row-major order (every survivor scores >= iniTh)
+    uint32_t *slot = cellent + (size_t)f * ent_frame_stride + T.slot;
+    int total = 0;
+    for (int e0 = 0; e0 < qn; e0 += 64) {
+        const int e = e0 + lane;
+        int keep = 0, s = 0, q = 0;
+        if (e < qn) {
+            q = queue[e];
+            s = scq[e];
+            const uint8_t *p = sco + ((q >> 8) + 1) * P + (q & 0xff) + 1;
+            keep = (s > 0) & (s > p[-1]) & (s > p[1]) & (s > p[-P - 1]) & (s > p[-P]) & (s > p[-P + 1]) & (s > p[P - 1]) & (s > p[P]) &
+                   (s > p[P + 1]);
+        }
+        const unsigned long long b = __ballot(keep != 0);
+        if (keep) slot[total + __popcll(b & ((1ull << lane) - 1ull))] = pack_key((q & 0xff) + T.ox, (q >> 8) + T.oy, s);
+        total += __popcll(b);
+    }
+    if (total == 0) {   // cv::FAST(cell, iniThFAST) found nothing: the second pass (:843-846) is the list kernel's
+        if (lane == 0) list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | blockIdx.x;
+        return;
+    }
+    if (lane == 0) *cnt_out = total;
+}
+
 // the cells k_fast_wave appended to its overflow list (more candidates than its LDS queue holds; about 0.5 % of the cells of
 // the EuRoC-like bench), with a queue that holds a whole cell.  grid (any), block 64, LDS for qcap = max interior pixels
 template <int P>
@@ -690,6 +859,8 @@ __global__ __launch_bounds__(256) void k_finalize(const LevelInfo *__restrict__ 
                 else pos = monoIdx + offm + __popcll(bm & lt);
                 WorkItem w;
                 w.key = key; w.level = l; w.pos = pos;
+                w.pitches = (uint32_t)L.pitch | ((uint32_t)L.bpitch << 16); w.off = (uint32_t)L.off; w.boff = (uint32_t)L.boff;
+                w.scale = L.scale; w.size = L.size;
                 work[(size_t)f * cap + g0 + i] = w;
             }
             monoIdx += totm;
@@ -893,7 +1064,12 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
     w.key = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.key);
     w.level = __builtin_amdgcn_readfirstlane(w.level);
     w.pos = __builtin_amdgcn_readfirstlane(w.pos);
-    const LevelInfo L = lv[w.level];
+    struct { int pitch, bpitch; uint32_t off, boff; float scale, size; } L;   // the level's constants travel with the work item
+    { const uint32_t pp = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.pitches); L.pitch = (int)(pp & 0xffffu); L.bpitch = (int)(pp >> 16); }
+    L.off = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.off);
+    L.boff = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.boff);
+    L.scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.scale)));
+    L.size = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.size)));
     const int kx = key_x(w.key), ky = key_y(w.key);
     // orientation disc column of this lane (loaded early: its latency hides behind the patch loads)
     const int du = (lane & 31) - kHalfPatch, dhalf = lane >> 5;

@@ -63,11 +63,12 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     std::vector<ResizeTap> xtab, ytab;
     std::vector<ResizeGroup> xgtab;
     std::vector<TileRef> fast_tiles, blur_tiles;
+    std::vector<FastTile> ftiles;
     size_t pyr_off = 0, blur_off = 0;
     uint32_t cand_off = 0, lvl_off = 0;
     int cell_base = 0, cap = 0, max_pool = 0;
     size_t fast_lds = 0;
-    int fast_wave_maxw = 0, fast_wave_rows = 0, fast_wave_qfull = 16;
+    int fast_wave_maxw = 0, fast_wave_rows = 0, fast_wave_qfull = 16, fast_ini_gcap = 16;
     bool fast_wave = true;
     for (int l = 0; l < nl; l++) {
         LevelInfo &L = lv[l];
@@ -163,7 +164,24 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
             }
         }
         for (int i = 0; i < L.nRows; i++)
-            for (int j = 0; j < L.nCols; j++) fast_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
+            for (int j = 0; j < L.nCols; j++) {
+                fast_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
+                // the same cell for k_fast_ini, geometry resolved here (ComputeKeyPointsOctTree :805-823)
+                const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+                const int iniX = kBorder + j * L.wCell, iniY = kBorder + i * L.hCell;
+                const int maxX = std::min(iniX + L.wCell + 6, maxBX), maxY = std::min(iniY + L.hCell + 6, maxBY);
+                const int cols = maxX - iniX, rows = maxY - iniY;
+                const bool skip = iniY >= maxBY - 3 || iniX >= maxBX - 6 || cols - 6 <= 0 || rows - 6 <= 0;
+                FastTile T;
+                memset(&T, 0, sizeof(T));
+                T.src_off = (uint32_t)(L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1);
+                T.pitch = L.pitch;
+                T.cols = (int16_t)(skip ? 0 : cols); T.rows = (int16_t)rows;
+                T.ox = (int16_t)(3 + j * L.wCell); T.oy = (int16_t)(3 + i * L.hCell);
+                T.cell = (uint32_t)(L.cell_base + i * L.nCols + j);
+                T.slot = L.cand_off + (uint32_t)(i * L.nCols + j) * (uint32_t)L.cell_cap;
+                ftiles.push_back(T);
+            }
         for (int i = 0; i < (L.h + kBlurTH - 1) / kBlurTH; i++)
             for (int j = 0; j < (L.w + kBlurTW - 1) / kBlurTW; j++)
                 blur_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
@@ -176,6 +194,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         fast_wave_maxw = std::max(fast_wave_maxw, L.wCell);
         fast_wave_rows = std::max(fast_wave_rows, rows);
         fast_wave_qfull = std::max(fast_wave_qfull, (L.wCell * L.hCell + 15) & ~15);
+        fast_ini_gcap = std::max(fast_ini_gcap, (((L.wCell + 3) / 4) * L.hCell + 15) & ~15);
     }
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
 
@@ -193,6 +212,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_ytab, sizeof(ResizeTap) * std::max<size_t>(ytab.size(), 1));
     ENS(ex->d_xgtab, sizeof(ResizeGroup) * std::max<size_t>(xgtab.size(), 1));
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
+    ENS(ex->d_ftiles, sizeof(FastTile) * ftiles.size());
     ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
     ENS(ex->d_pyr, pyr_off * B);
     ENS(ex->d_blur, blur_off * B);
@@ -219,6 +239,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (!ytab.empty()) ORBX_HIP(hipMemcpy(ex->d_ytab.p, ytab.data(), sizeof(ResizeTap) * ytab.size(), hipMemcpyHostToDevice));
     if (!xgtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xgtab.p, xgtab.data(), sizeof(ResizeGroup) * xgtab.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(ex->d_ftiles.p, ftiles.data(), sizeof(FastTile) * ftiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_tiles.p, blur_tiles.data(), sizeof(TileRef) * blur_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
     ex->lv = lv;
@@ -228,6 +249,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->fast_wave_pitch = (fast_wave_maxw + 7 <= 48) ? 48 : 64;
     ex->fast_wave_rows = fast_wave_rows;
     ex->fast_wave_qfull = fast_wave_qfull;
+    ex->fast_ini_gcap = fast_ini_gcap;
     ex->fast_wave_lds = fast_wave_lds_bytes(ex->fast_wave_pitch, fast_wave_rows, ex->fast_wave_qcap);
     { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size();
@@ -316,12 +338,24 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                        (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,         \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qcap, \
                        ovf_list, ovf_count)
-            if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE(48); else ORBX_FAST_WAVE(64);
+            static const bool ini_first = [] { const char *v = getenv("ORBX_FAST_INI"); return !(v && v[0] == '0'); }();
+            if (ini_first && ini > mn) {
+                // first pass of :826 for every cell (k_fast_ini); cells it leaves empty go to the list pass below
+                const size_t lds_ini = fast_ini_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_ini_qcap, ex->fast_ini_gcap);
+#define ORBX_FAST_INI(PITCH)                                                                                                        \
+    hipLaunchKernelGGL(k_fast_ini<PITCH>, dim3(ex->n_fast_tiles, n), dim3(64), lds_ini + ldspad, st,                                    \
+                       (const FastTile *)ex->d_ftiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,            \
+                       ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->fast_wave_rows, ex->fast_ini_qcap,     \
+                       ex->fast_ini_gcap, ovf_list, ovf_count)
+                if (ex->fast_wave_pitch == 48) ORBX_FAST_INI(48); else ORBX_FAST_INI(64);
+            } else {
+                if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE(48); else ORBX_FAST_WAVE(64);
+            }
             // cells with more candidates than k_fast_wave's LDS queue holds (about 0.5 % in the EuRoC-like bench): same kernel body,
             // queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
-    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(2048), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
+    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(16384), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
                        (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p, \
                        ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qfull, (const uint32_t *)ovf_list,                  \
                        (const int32_t *)ovf_count)
@@ -538,7 +572,7 @@ void orbx_destroy(orbx_extractor *ex) {
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
-                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames};
+                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_ftiles};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);

@@ -71,10 +71,27 @@ struct TileRef {  // blockIdx.x -> (level, tile) mapping for multi-level launche
     int16_t pad;
 };
 
-struct WorkItem {  // one selected keypoint of a frame, in level order
-    uint32_t key;   // level coords x,y + score
-    int32_t level;
-    int32_t pos;    // output slot (lapping split, ORBextractor.cc:1153-1162)
+struct FastTile {  // everything k_fast_ini needs of its cell, precomputed per geometry: one 32-byte scalar load, no LevelInfo
+    uint32_t src_off;   // byte offset inside a frame's pyramid slab of the tile's first byte (sub-image column -1)
+    int32_t pitch;      // bytes per padded row of the level
+    int16_t cols, rows; // sub-image size; cols <= 0 marks a cell the reference skips (:813 / :821)
+    int16_t ox, oy;     // level coordinates of interior pixel (0, 0): 3 + tj * wCell, 3 + ti * hCell
+    uint32_t cell;      // index of the cell inside a frame's cell-count array
+    uint32_t slot;      // entry offset of the cell's slot inside a frame's candidate slab
+    uint32_t pad[2];
 };
+static_assert(sizeof(FastTile) == 32, "FastTile layout");
+
+struct WorkItem {  // one selected keypoint of a frame, in level order, with the constants of its level (k_describe needs no LevelInfo load)
+    uint32_t key;     // level coords x,y + score
+    int32_t level;
+    int32_t pos;      // output slot (lapping split, ORBextractor.cc:1153-1162)
+    uint32_t pitches; // pitch | bpitch << 16 (bytes per padded / blurred row)
+    uint32_t off;     // byte offset of the level inside a frame's pyramid slab
+    uint32_t boff;    // ... inside a frame's blur slab
+    float scale;      // mvScaleFactor[level]
+    float size;       // keypoint size of the level
+};
+static_assert(sizeof(WorkItem) == 32, "WorkItem layout");
 
 }  // namespace orbx
