@@ -96,8 +96,8 @@ int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int n
 
 /* The same over HOST-resident frames (what the reference hands to operator(): cv::Mat data in host memory, ORBextractor.cc:1086):
  * the frames are copied to the device on the extractor's upload stream into one of two internal input slabs, so the upload
- * of batch i+1 overlaps the kernels of batch i; everything else as orbx_extract_batch_device.  h_images should be pinned
- * (hipHostMalloc / hipHostRegister) for the copy to be asynchronous; it may be reused by the caller as soon as the NEXT call
+ * of batch i+1 overlaps the kernels of batch i; everything else as orbx_extract_batch_device.  h_images MUST be pinned
+ * (hipHostMalloc / hipHostRegister; ORBX_E_BAD_ARG otherwise); it may be reused by the caller as soon as the NEXT call
  * to this function (or orbx_sync) has returned. */
 int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_frames, int width, int height,
                             size_t row_stride, size_t frame_stride, int lap0, int lap1);
@@ -126,7 +126,7 @@ int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *keypoints, uint8_
 int orbx_output_capacity(orbx_extractor *ex, int width, int height);
 /* Asynchronous form: the D2H copies run on the extractor's copy stream behind the kernels of the last batch and
  * overlap the kernels of the NEXT batch (which wait for the copy before overwriting the device outputs).
- * Host buffers should be pinned.  match / nmatches (optional) receive the internal results of
+ * Host buffers MUST be pinned (hipHostMalloc / hipHostRegister; ORBX_E_BAD_ARG otherwise).  match / nmatches (optional) receive the internal results of
  * orbx_match_consecutive_device(..., NULL, NULL): [n_frames][cap] / [n_frames].  Up to TWO downloads may be in flight
  * (enqueue batch i+1 before waiting for batch i, so that the matcher of batch i overlaps the pyramid / FAST of batch
  * i+1); orbx_download_wait blocks until the OLDEST one has landed and reports device-side errors. */

@@ -164,6 +164,16 @@ struct orbx_extractor {
     DevBuf d_kps_un, d_frustum_frames;
     const void *match_kps() const { return has_camera ? d_kps_un.p : d_kps.p; }
 
+    // Synchronous device -> caller copy through the pinned staging buffer (no caller pointer is ever handed to the HIP runtime: see
+    // PinnedArena in orbx_matcher.hip).  `off` = byte offset inside the staging buffer, so that several copies share one sync.
+    int d2h_staged_begin(size_t total_bytes) { return ensure_stage(total_bytes); }
+    int d2h_staged(size_t off, const void *d_src, size_t bytes) {
+        if (bytes == 0) return ORBX_OK;
+        ORBX_HIP(hipMemcpyAsync((uint8_t *)h_stage + off, d_src, bytes, hipMemcpyDeviceToHost, stream));
+        return ORBX_OK;
+    }
+    const uint8_t *staged(size_t off) const { return (const uint8_t *)h_stage + off; }
+
     int ensure_stage(size_t bytes) {
         if (bytes <= h_stage_bytes) return ORBX_OK;
         if (h_stage) (void)hipHostFree(h_stage);

@@ -304,21 +304,26 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, d_lv, l, (const ResizeTap *)ex->d_xtab.p,
                            (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame);
     }
+    auto launch_blur = [&]() -> int {
     {
-        // blur depends only on the pyramid and is needed only by k_describe: run it beside FAST / quad-tree
-        const bool side = !ex->profile && ex->side_streams && ex->blur_side;
-        hipStream_t bs = side ? ex->aux_stream : st;
-        if (side) {
-            ORBX_HIP(hipEventRecord(ex->ev_pyr, st));
-            ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
+            // blur depends only on the pyramid and is needed only by k_describe: run it beside FAST / quad-tree
+            const bool side = !ex->profile && ex->side_streams && ex->blur_side;
+            hipStream_t bs = side ? ex->aux_stream : st;
+            if (side) {
+                ORBX_HIP(hipEventRecord(ex->ev_pyr, st));
+                ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
+            }
+            ProfScope ps(ex, K_BLUR);
+            static const int kNew[4] = {18, 34, 48, 56}, kOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
+            const int *g = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kOld : kNew;
+            hipLaunchKernelGGL(k_blur, dim3(ex->n_blur_tiles, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p,
+                               (const uint8_t *)pyr, ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, g[0], g[1], g[2], g[3]);
+            if (side) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
         }
-        ProfScope ps(ex, K_BLUR);
-        static const int kNew[4] = {18, 34, 48, 56}, kOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
-        const int *g = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kOld : kNew;
-        hipLaunchKernelGGL(k_blur, dim3(ex->n_blur_tiles, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p,
-                           (const uint8_t *)pyr, ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, g[0], g[1], g[2], g[3]);
-        if (side) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
-    }
+        return ORBX_OK;
+    };
+    static const bool blur_after_fast = [] { const char *v = getenv("ORBX_BLUR_AFTER_FAST"); return v && v[0] == '1'; }();
+    if (!blur_after_fast) { int r = launch_blur(); if (r != ORBX_OK) return r; }
     {
         ProfScope ps(ex, K_FAST);
         // one score map at min(ini, min) serves both passes of :830-846; for ini < min the reference's second pass FAST(min) is a
@@ -365,6 +370,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         else if (tpb == 128) ORBX_FAST_LAUNCH(128);
         else ORBX_FAST_LAUNCH(64);
     }
+    if (blur_after_fast) { int r = launch_blur(); if (r != ORBX_OK) return r; }   // beside the latency-bound quad-tree stage instead of beside FAST
     {
         ProfScope ps(ex, K_OCTREE);
         if (ex->oct_par) {
@@ -421,10 +427,23 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     return ORBX_OK;
 }
 
+// The asynchronous entry points hand the caller's host pointers straight to the copy engine, so they insist on pinned memory
+// (hipHostMalloc / hipHostRegister, e.g. torch's pin_memory()): pageable memory would be pinned page by page by the runtime behind
+// the caller's back and the copy would not be asynchronous at all.
+static bool is_pinned_host(const void *p) {
+    if (!p) return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
 static int check_device_error(orbx_extractor *ex) {
-    int32_t e = 0;
-    ORBX_HIP(hipMemcpyAsync(&e, ex->d_err.p, sizeof(e), hipMemcpyDeviceToHost, ex->stream));
+    int r0 = ex->ensure_stage(64);
+    if (r0 != ORBX_OK) return r0;
+    ORBX_HIP(hipMemcpyAsync(ex->h_stage, ex->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, ex->stream));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
+    int32_t e = 0;
+    memcpy(&e, ex->h_stage, sizeof(e));
     if (e != 0) {
         set_error("device-side consistency check failed, code " + std::to_string(e));
         (void)hipMemsetAsync(ex->d_err.p, 0, sizeof(int32_t), ex->stream);
@@ -598,6 +617,7 @@ int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_f
     if (!h_images || width <= 0 || height <= 0 || n_frames <= 0) return ORBX_E_EMPTY;
     if (row_stride < (size_t)width || frame_stride < row_stride * (size_t)height) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
+    if (!is_pinned_host(h_images)) { set_error("orbx_extract_batch_host needs pinned frames (hipHostMalloc / hipHostRegister)"); return ORBX_E_BAD_ARG; }
     int r = configure(ex, width, height, n_frames);
     if (r != ORBX_OK) return r;
     const unsigned slot = ex->in_issued & 1u;
@@ -648,16 +668,16 @@ int orbx_set_camera(orbx_extractor *ex, const orbx_camera *cam) {
 int orbx_batch_download_keypoints_un(orbx_extractor *ex, int frame, orbx_keypoint *kps_un, int cap, int *n_out) {
     if (!ex || frame < 0 || frame >= ex->last_batch) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
-    int32_t n = 0;
-    ORBX_HIP(hipMemcpyAsync(&n, (int32_t *)ex->d_count.p + frame, 4, hipMemcpyDeviceToHost, ex->stream));
+    int r = ex->d2h_staged_begin(64 + sizeof(orbx_keypoint) * (size_t)ex->cap);
+    if (r != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, (int32_t *)ex->d_count.p + frame, 4)) != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(64, (const orbx_keypoint *)ex->match_kps() + (size_t)frame * ex->cap, sizeof(orbx_keypoint) * (size_t)ex->cap)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(ex->stream));
+    int32_t n = 0;
+    memcpy(&n, ex->staged(0), 4);
     if (n_out) *n_out = n;
     if (n > cap) return ORBX_E_CAPACITY;
-    if (n > 0 && kps_un) {
-        ORBX_HIP(hipMemcpyAsync(kps_un, (const orbx_keypoint *)ex->match_kps() + (size_t)frame * ex->cap, sizeof(orbx_keypoint) * (size_t)n,
-                                hipMemcpyDeviceToHost, ex->stream));
-        ORBX_HIP(hipStreamSynchronize(ex->stream));
-    }
+    if (n > 0 && kps_un) memcpy(kps_un, ex->staged(64), sizeof(orbx_keypoint) * (size_t)n);
     return ORBX_OK;
 }
 
@@ -696,17 +716,22 @@ int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8
     ORBX_HIP(hipSetDevice(ex->device));
     int r = check_device_error(ex);
     if (r != ORBX_OK) return r;
-    int32_t cm[2];
-    ORBX_HIP(hipMemcpyAsync(&cm[0], (int32_t *)ex->d_count.p + frame, 4, hipMemcpyDeviceToHost, ex->stream));
-    ORBX_HIP(hipMemcpyAsync(&cm[1], (int32_t *)ex->d_mono.p + frame, 4, hipMemcpyDeviceToHost, ex->stream));
+    if ((r = ex->d2h_staged_begin(64 + (size_t)ex->cap * (sizeof(orbx_keypoint) + 32))) != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, (int32_t *)ex->d_count.p + frame, 4)) != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(4, (int32_t *)ex->d_mono.p + frame, 4)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(ex->stream));
+    int32_t cm[2];
+    memcpy(cm, ex->staged(0), 8);
     if (n_out) *n_out = cm[0];
     if (mono) *mono = cm[1];
     if (cm[0] > cap) return ORBX_E_CAPACITY;
     if (cm[0] > 0) {
-        if (kps) ORBX_HIP(hipMemcpyAsync(kps, (orbx_keypoint *)ex->d_kps.p + (size_t)frame * ex->cap, sizeof(orbx_keypoint) * cm[0], hipMemcpyDeviceToHost, ex->stream));
-        if (desc) ORBX_HIP(hipMemcpyAsync(desc, (uint8_t *)ex->d_desc.p + (size_t)frame * ex->cap * 32, (size_t)32 * cm[0], hipMemcpyDeviceToHost, ex->stream));
+        const size_t kb = sizeof(orbx_keypoint) * (size_t)cm[0], db = (size_t)32 * cm[0], off_d = 64 + (size_t)ex->cap * sizeof(orbx_keypoint);
+        if (kps && (r = ex->d2h_staged(64, (orbx_keypoint *)ex->d_kps.p + (size_t)frame * ex->cap, kb)) != ORBX_OK) return r;
+        if (desc && (r = ex->d2h_staged(off_d, (uint8_t *)ex->d_desc.p + (size_t)frame * ex->cap * 32, db)) != ORBX_OK) return r;
         ORBX_HIP(hipStreamSynchronize(ex->stream));
+        if (kps) memcpy(kps, ex->staged(64), kb);
+        if (desc) memcpy(desc, ex->staged(off_d), db);
     }
     return ORBX_OK;
 }
@@ -714,18 +739,30 @@ int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *kps, uint8
 int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts, int32_t *mono) {
     if (!ex || ex->last_batch <= 0) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
-    const int n = ex->last_batch;
-    if (counts) ORBX_HIP(hipMemcpyAsync(counts, ex->d_count.p, 4 * (size_t)n, hipMemcpyDeviceToHost, ex->stream));
-    if (mono) ORBX_HIP(hipMemcpyAsync(mono, ex->d_mono.p, 4 * (size_t)n, hipMemcpyDeviceToHost, ex->stream));
-    if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, ex->stream));
-    if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, ex->stream));
-    return check_device_error(ex);
+    const size_t n = (size_t)ex->last_batch;
+    const size_t cb = 4 * n, kb = sizeof(orbx_keypoint) * (size_t)ex->cap * n, db = (size_t)32 * ex->cap * n;
+    const size_t o_m = (cb + 63) & ~(size_t)63, o_k = 2 * o_m, o_d = o_k + ((kb + 63) & ~(size_t)63);
+    int r = check_device_error(ex);
+    if (r != ORBX_OK) return r;
+    if ((r = ex->d2h_staged_begin(o_d + db)) != ORBX_OK) return r;
+    if (counts && (r = ex->d2h_staged(0, ex->d_count.p, cb)) != ORBX_OK) return r;
+    if (mono && (r = ex->d2h_staged(o_m, ex->d_mono.p, cb)) != ORBX_OK) return r;
+    if (kps && (r = ex->d2h_staged(o_k, ex->d_kps.p, kb)) != ORBX_OK) return r;
+    if (desc && (r = ex->d2h_staged(o_d, ex->d_desc.p, db)) != ORBX_OK) return r;
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    if (counts) memcpy(counts, ex->staged(0), cb);
+    if (mono) memcpy(mono, ex->staged(o_m), cb);
+    if (kps) memcpy(kps, ex->staged(o_k), kb);
+    if (desc) memcpy(desc, ex->staged(o_d), db);
+    return ORBX_OK;
 }
 
 int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts, int32_t *mono,
                               int32_t *match, int32_t *nmatches) {
     if (!ex || ex->last_batch <= 0) return ORBX_E_BAD_ARG;
     if (ex->copy_issued - ex->copy_waited >= 2) { set_error("two downloads already in flight: call orbx_download_wait first"); return ORBX_E_BAD_ARG; }
+    for (const void *p : {(const void *)kps, (const void *)desc, (const void *)counts, (const void *)mono, (const void *)match, (const void *)nmatches})
+        if (!is_pinned_host(p)) { set_error("orbx_batch_download_async needs pinned host buffers (hipHostMalloc / hipHostRegister)"); return ORBX_E_BAD_ARG; }
     ORBX_HIP(hipSetDevice(ex->device));
     const int n = ex->last_batch;
     hipStream_t cs = ex->copy_stream;
@@ -775,7 +812,10 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
     if (r != ORBX_OK) return r;
     const size_t dpitch = ((size_t)width + 63) & ~(size_t)63;
     if ((r = ex->d_img.ensure(dpitch * height)) != ORBX_OK) return r;
-    ORBX_HIP(hipMemcpy2DAsync(ex->d_img.p, dpitch, image, stride, width, height, hipMemcpyHostToDevice, ex->stream));
+    // the caller's image goes through the pinned staging buffer (rows packed to the device pitch), never to the runtime directly
+    if ((r = ex->ensure_stage(std::max(dpitch * height, 64 + (size_t)ex->cap * (sizeof(orbx_keypoint) + 32)))) != ORBX_OK) return r;
+    for (int y = 0; y < height; y++) memcpy((uint8_t *)ex->h_stage + (size_t)y * dpitch, image + (size_t)y * stride, (size_t)width);
+    ORBX_HIP(hipMemcpyAsync(ex->d_img.p, ex->h_stage, dpitch * height, hipMemcpyHostToDevice, ex->stream));
     r = enqueue_extract(ex, (const uint8_t *)ex->d_img.p, 1, dpitch, dpitch * height, lap0, lap1);
     if (r != ORBX_OK) return r;
     return orbx_batch_download(ex, 0, kps, desc, cap, n_out, mono_index);
@@ -793,9 +833,13 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
     const LevelInfo &L = ex->lv[level];
     if (dst_stride < (size_t)(L.w + 2 * kEdge)) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
-    const uint8_t *src = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off + kRingX;
-    ORBX_HIP(hipMemcpy2DAsync(dst, dst_stride, src, L.pitch, L.w + 2 * kEdge, L.h + 2 * kEdge, hipMemcpyDeviceToHost, ex->stream));
+    const uint8_t *src = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off;
+    const size_t bytes = (size_t)L.pitch * (L.h + 2 * kEdge);
+    int r = ex->d2h_staged_begin(bytes);
+    if (r != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, src, bytes)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(ex->stream));
+    for (int y = 0; y < L.h + 2 * kEdge; y++) memcpy(dst + (size_t)y * dst_stride, ex->staged((size_t)y * L.pitch + kRingX), (size_t)(L.w + 2 * kEdge));
     return ORBX_OK;
 }
 
@@ -831,10 +875,14 @@ int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, orbx_k
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     const LevelInfo &L = ex->lv[level];
     const int ncell = L.nCols * L.nRows;
-    std::vector<int32_t> cnt(ncell);
-    ORBX_HIP(hipMemcpy(cnt.data(), (int32_t *)ex->d_cellcnt.p + (size_t)frame * ex->total_cells + L.cell_base, 4 * (size_t)ncell, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> ent(L.cand_cap);
-    ORBX_HIP(hipMemcpy(ent.data(), (uint32_t *)ex->d_cellent.p + (size_t)frame * ex->cand_frame + L.cand_off, 4 * (size_t)L.cand_cap, hipMemcpyDeviceToHost));
+    const size_t cb = 4 * (size_t)ncell, eb = 4 * (size_t)L.cand_cap, eoff = (cb + 63) & ~(size_t)63;
+    int r = ex->d2h_staged_begin(eoff + eb);
+    if (r != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, (int32_t *)ex->d_cellcnt.p + (size_t)frame * ex->total_cells + L.cell_base, cb)) != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(eoff, (uint32_t *)ex->d_cellent.p + (size_t)frame * ex->cand_frame + L.cand_off, eb)) != ORBX_OK) return r;
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    const int32_t *cnt = (const int32_t *)ex->staged(0);
+    const uint32_t *ent = (const uint32_t *)ex->staged(eoff);
     int n = 0;
     for (int c = 0; c < ncell; c++)
         for (int k = 0; k < cnt[c]; k++) {
@@ -850,10 +898,15 @@ int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_ke
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     const LevelInfo &L = ex->lv[level];
+    int r = ex->d2h_staged_begin(64 + 4 * (size_t)L.lvl_cap);
+    if (r != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, (int32_t *)ex->d_lvlcnt.p + (size_t)frame * ex->prm.nlevels + level, 4)) != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(64, (uint32_t *)ex->d_lvlkp.p + (size_t)frame * ex->lvl_frame + L.lvl_off, 4 * (size_t)L.lvl_cap)) != ORBX_OK) return r;
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
     int32_t n = 0;
-    ORBX_HIP(hipMemcpy(&n, (int32_t *)ex->d_lvlcnt.p + (size_t)frame * ex->prm.nlevels + level, 4, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> keys(std::max(n, 1));
-    if (n > 0) ORBX_HIP(hipMemcpy(keys.data(), (uint32_t *)ex->d_lvlkp.p + (size_t)frame * ex->lvl_frame + L.lvl_off, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    memcpy(&n, ex->staged(0), 4);
+    n = std::min(std::max(n, 0), L.lvl_cap);
+    const uint32_t *keys = (const uint32_t *)ex->staged(64);
     for (int i = 0; i < n && i < cap && out; i++)
         out[i] = orbx_keypoint{(float)key_x(keys[i]), (float)key_y(keys[i]), L.size, -1.f, (float)key_s(keys[i]), level, -1};
     return n;
@@ -864,8 +917,12 @@ int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *
     const LevelInfo &L = ex->lv[level];
     if (dst_stride < (size_t)L.w) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
-    ORBX_HIP(hipMemcpy2DAsync(dst, dst_stride, (const uint8_t *)ex->d_blur.p + (size_t)frame * ex->blur_frame + L.boff, L.bpitch, L.w, L.h, hipMemcpyDeviceToHost, ex->stream));
+    const size_t bytes = (size_t)L.bpitch * L.h;
+    int r = ex->d2h_staged_begin(bytes);
+    if (r != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, (const uint8_t *)ex->d_blur.p + (size_t)frame * ex->blur_frame + L.boff, bytes)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(ex->stream));
+    for (int y = 0; y < L.h; y++) memcpy(dst + (size_t)y * dst_stride, ex->staged((size_t)y * L.bpitch), (size_t)L.w);
     return ORBX_OK;
 }
 

@@ -46,10 +46,51 @@ struct Arena {  // bump allocator over one device buffer, reset per call
 
 }  // namespace
 
+// Pinned host staging of a matcher context.  No entry point ever hands a CALLER'S (pageable) pointer to the HIP runtime: uploads are
+// memcpy'd into this arena first, downloads land here and are memcpy'd out after the stream synchronisation.  (The runtime's
+// alternative for pageable memory is to pin the caller's pages on the fly for the duration of the DMA; keeping that machinery out of
+// the hot path removes a whole class of lifetime hazards -- stack temporaries, vectors freed right after the call -- and is faster
+// for the small transfers these entry points make.)
+struct PinnedArena {
+    uint8_t *base = nullptr;
+    size_t cap = 0, used = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return ORBX_OK;
+        if (base) (void)hipHostFree(base);
+        base = nullptr; cap = 0;
+        bytes = (bytes * 3 / 2 + 4095) & ~(size_t)4095;
+        ORBX_HIP(hipHostMalloc((void **)&base, bytes, hipHostMallocDefault));
+        cap = bytes;
+        return ORBX_OK;
+    }
+    void reset() { used = 0; }
+    void *take(size_t bytes) {
+        used = (used + 63) & ~(size_t)63;
+        if (used + bytes > cap) return nullptr;
+        void *p = base + used;
+        used += bytes;
+        return p;
+    }
+};
+
 struct orbx_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
     Arena arena;
+    PinnedArena stage;
+    struct Pending { void *dst; const void *src; size_t bytes; };
+    std::vector<Pending> pending;   // downloads waiting in the staging arena for the stream synchronisation
+    // device scratch for one call + staging for everything that call can move in either direction
+    int reserve_all(size_t device_bytes) {
+        int r = arena.reserve(device_bytes);
+        if (r != ORBX_OK) return r;
+        return stage.reserve(2 * device_bytes + 65536);
+    }
+    void begin() { arena.reset(); stage.reset(); pending.clear(); }
+    void flush() {
+        for (const Pending &p : pending) memcpy(p.dst, p.src, p.bytes);
+        pending.clear();
+    }
 };
 
 // ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) resident on the device
@@ -83,11 +124,35 @@ void orbx_matcher_destroy(orbx_matcher *m) {
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->arena.base) (void)hipFree(m->arena.base);
+    if (m->stage.base) (void)hipHostFree(m->stage.base);
     delete m;
 }
 
-#define H2D(dst, src, bytes) ORBX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->stream))
-#define D2H(dst, src, bytes) ORBX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->stream))
+#define H2D(dst, src, bytes)                                                                                      \
+    do {                                                                                                          \
+        const size_t _b = (bytes);                                                                                \
+        if (_b > 0) {                                                                                             \
+            void *_s = m->stage.take(_b);                                                                         \
+            if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                            \
+            memcpy(_s, (src), _b);                                                                                \
+            ORBX_HIP(hipMemcpyAsync((dst), _s, _b, hipMemcpyHostToDevice, m->stream));                            \
+        }                                                                                                         \
+    } while (0)
+#define D2H(dst, src, bytes)                                                                                      \
+    do {                                                                                                          \
+        const size_t _b = (bytes);                                                                                \
+        if (_b > 0) {                                                                                             \
+            void *_s = m->stage.take(_b);                                                                         \
+            if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                            \
+            ORBX_HIP(hipMemcpyAsync(_s, (src), _b, hipMemcpyDeviceToHost, m->stream));                            \
+            m->pending.push_back(orbx_matcher::Pending{(void *)(dst), _s, _b});                                   \
+        }                                                                                                         \
+    } while (0)
+#define SYNC_AND_DELIVER()                                                                                        \
+    do {                                                                                                          \
+        ORBX_HIP(hipStreamSynchronize(m->stream));                                                                \
+        m->flush();                                                                                               \
+    } while (0)
 
 int orbx_hamming_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, const int32_t *row_ptr,
                      const int32_t *cand, uint16_t *dist_out) {
@@ -97,17 +162,17 @@ int orbx_hamming_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t
     if (nnz <= 0) return ORBX_OK;
     if (!t || !cand || !dist_out) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(m->device));
-    int r = m->arena.reserve(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32) + Arena::pad(4 * (size_t)(nq + 1)) +
+    int r = m->reserve_all(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32) + Arena::pad(4 * (size_t)(nq + 1)) +
                              Arena::pad(4 * (size_t)nnz) + Arena::pad(2 * (size_t)nnz) + 4096);
     if (r != ORBX_OK) return r;
-    m->arena.reset();
+    m->begin();
     uint8_t *dq = m->arena.take<uint8_t>((size_t)nq * 32), *dt = m->arena.take<uint8_t>((size_t)nt * 32);
     int32_t *drp = m->arena.take<int32_t>(nq + 1), *dc = m->arena.take<int32_t>(nnz);
     uint16_t *dd = m->arena.take<uint16_t>(nnz);
     H2D(dq, q, (size_t)nq * 32); H2D(dt, t, (size_t)nt * 32); H2D(drp, row_ptr, 4 * (size_t)(nq + 1)); H2D(dc, cand, 4 * (size_t)nnz);
     hipLaunchKernelGGL(k_hamming_csr, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, drp, dc, dd);
     D2H(dist_out, dd, 2 * (size_t)nnz);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return ORBX_OK;
 }
 
@@ -118,10 +183,10 @@ int orbx_hamming_best2_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint
     if (nq == 0) return ORBX_OK;
     const int nnz = row_ptr[nq];
     ORBX_HIP(hipSetDevice(m->device));
-    int r = m->arena.reserve(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32 + 32) + Arena::pad(4 * (size_t)(nq + 1)) +
+    int r = m->reserve_all(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32 + 32) + Arena::pad(4 * (size_t)(nq + 1)) +
                              Arena::pad(4 * (size_t)nnz + 4) + 4 * Arena::pad(4 * (size_t)nq) + 4096);
     if (r != ORBX_OK) return r;
-    m->arena.reset();
+    m->begin();
     uint8_t *dq = m->arena.take<uint8_t>((size_t)nq * 32), *dt = m->arena.take<uint8_t>((size_t)nt * 32 + 32);
     int32_t *drp = m->arena.take<int32_t>(nq + 1), *dc = m->arena.take<int32_t>(nnz + 1);
     int32_t *o[4];
@@ -133,7 +198,7 @@ int orbx_hamming_best2_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint
     hipLaunchKernelGGL(k_hamming_best2_csr, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, drp, dc, o[0], o[1], o[2], o[3]);
     int32_t *host[4] = {best_pos, best_dist, second_pos, second_dist};
     for (int k = 0; k < 4; k++) if (host[k]) D2H(host[k], o[k], 4 * (size_t)nq);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return ORBX_OK;
 }
 
@@ -141,16 +206,16 @@ int orbx_knn2(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int n
     if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist))) return ORBX_E_BAD_ARG;
     if (nq == 0) return ORBX_OK;
     ORBX_HIP(hipSetDevice(m->device));
-    int r = m->arena.reserve(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32 + 32) + 2 * Arena::pad(8 * (size_t)nq) + 4096);
+    int r = m->reserve_all(Arena::pad((size_t)nq * 32) + Arena::pad((size_t)nt * 32 + 32) + 2 * Arena::pad(8 * (size_t)nq) + 4096);
     if (r != ORBX_OK) return r;
-    m->arena.reset();
+    m->begin();
     uint8_t *dq = m->arena.take<uint8_t>((size_t)nq * 32), *dt = m->arena.take<uint8_t>((size_t)nt * 32 + 32);
     int32_t *di = m->arena.take<int32_t>(2 * (size_t)nq), *dd = m->arena.take<int32_t>(2 * (size_t)nq);
     H2D(dq, q, (size_t)nq * 32);
     if (nt > 0) H2D(dt, t, (size_t)nt * 32);
     hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, nt, di, dd);
     D2H(idx, di, 8 * (size_t)nq); D2H(dist, dd, 8 * (size_t)nq);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return ORBX_OK;
 }
 
@@ -161,10 +226,10 @@ int orbx_stereo_rowband(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t 
     if (nl == 0) return ORBX_OK;
     if (!kl || !dl || !best_idx_r || !best_dist) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(m->device));
-    int r = m->arena.reserve(Arena::pad(28 * (size_t)nl) + Arena::pad(32 * (size_t)nl) + Arena::pad(28 * (size_t)nr + 32) +
+    int r = m->reserve_all(Arena::pad(28 * (size_t)nl) + Arena::pad(32 * (size_t)nl) + Arena::pad(28 * (size_t)nr + 32) +
                              Arena::pad(32 * (size_t)nr + 32) + Arena::pad(4 * (size_t)nlevels) + 2 * Arena::pad(4 * (size_t)nl) + 4096);
     if (r != ORBX_OK) return r;
-    m->arena.reset();
+    m->begin();
     orbx_keypoint *dkl = m->arena.take<orbx_keypoint>(nl), *dkr = m->arena.take<orbx_keypoint>(nr + 1);
     uint8_t *ddl = m->arena.take<uint8_t>(32 * (size_t)nl), *ddr = m->arena.take<uint8_t>(32 * (size_t)nr + 32);
     float *dsc = m->arena.take<float>(nlevels);
@@ -175,7 +240,7 @@ int orbx_stereo_rowband(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t 
     hipLaunchKernelGGL(k_stereo_rowband, dim3((nl + 3) / 4), dim3(256), 0, m->stream, dkl, ddl, nl, dkr, ddr, nr, dsc, n_rows, min_d,
                        max_d, dbi, dbd);
     D2H(best_idx_r, dbi, 4 * (size_t)nl); D2H(best_dist, dbd, 4 * (size_t)nl);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return ORBX_OK;
 }
 
@@ -206,10 +271,10 @@ int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const 
     const size_t need = 2 * Arena::pad(slab) + Arena::pad(28 * (size_t)N) + Arena::pad(28 * (size_t)Nr) + Arena::pad(32 * (size_t)N) +
                         Arena::pad(32 * (size_t)Nr) + 5 * Arena::pad(4 * (size_t)N) + Arena::pad(sizeof(LevelInfo) * nlevels) +
                         Arena::pad(8 * (size_t)nlevels) + 8192;
-    int r = m->arena.reserve(need);
+    int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
-    A.reset();
+    m->begin();
     uint8_t *dL = A.take<uint8_t>(slab), *dR = A.take<uint8_t>(slab);
     for (int l = 0; l < nlevels; l++) {
         const size_t o = lv[l].off + (size_t)kEdge * pyr_stride[l] + kRoiX, bytes = pyr_stride[l] * (size_t)(pyr_h[l] - 1) + pyr_w[l];
@@ -239,7 +304,7 @@ int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const 
     ORBX_HIP(hipGetLastError());
     int32_t nm = 0;
     D2H(u_right, S.u_right, 4 * (size_t)N); D2H(depth, S.depth, 4 * (size_t)N); D2H(&nm, S.nmatches, 4);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return nm;
 }
 
@@ -274,10 +339,10 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
                   Arena::pad(4 * (size_t)nq) * 7 + Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) * 2 + Arena::pad(8 * (size_t)nq) * 5 +
                   Arena::pad(sizeof(WindowProblem)) + Arena::pad(sizeof(ResolveProblem)) + Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)n) +
                   16 * 256 + 4096;
-    int r = m->arena.reserve(need);
+    int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
-    A.reset();
+    m->begin();
     WindowProblem P;
     memset(&P, 0, sizeof(P));
     ResolveProblem R;
@@ -325,7 +390,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     int32_t nm = 0;
     D2H(a.match_out, R.match, 4 * (size_t)n);
     D2H(&nm, R.nmatches, 4);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return nm;
 }
 
@@ -412,10 +477,10 @@ int run_projection_twin(orbx_matcher *m, const TwinArgs &a) {
                              Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)N)) +
                         Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) + Arena::pad(4 * (size_t)nq) + Arena::pad(8 * (size_t)nq) +
                         Arena::pad(2 * sizeof(WindowProblem)) + 64 * 256 + 4096;
-    int r = m->arena.reserve(need);
+    int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
-    A.reset();
+    m->begin();
     WindowProblem P[2];
     memset(P, 0, sizeof(P));
     orbx_keypoint *dk = A.take<orbx_keypoint>(N);
@@ -465,7 +530,7 @@ int run_projection_twin(orbx_matcher *m, const TwinArgs &a) {
     int32_t nm = 0;
     D2H(a.match_out, T.match, 4 * (size_t)N);
     D2H(&nm, T.nmatches, 4);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return nm;
 }
 
@@ -634,10 +699,10 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un
     ORBX_HIP(hipSetDevice(m->device));
     const size_t need = Arena::pad(28 * (size_t)n1) + Arena::pad(32 * (size_t)n1) + Arena::pad(28 * (size_t)n2) + Arena::pad(32 * (size_t)n2) +
                         Arena::pad(8 * (size_t)n1) + 2 * Arena::pad(4 * (size_t)n1) + 2 * Arena::pad(4 * (size_t)n2) + 4096;
-    int r = m->arena.reserve(need);
+    int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
-    A.reset();
+    m->begin();
     InitProblem P;
     memset(&P, 0, sizeof(P));
     orbx_keypoint *dk1 = A.take<orbx_keypoint>(n1), *dk2 = A.take<orbx_keypoint>(n2);
@@ -660,7 +725,7 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un
     D2H(matches12, P.matches12, 4 * (size_t)n1);
     D2H(prev_matched, dprev, 8 * (size_t)n1);
     D2H(&nm, P.nmatches, 4);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return nm;
 }
 
@@ -679,10 +744,10 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
                         Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 8192 +
                         (gate ? Arena::pad(sizeof(orbx_keypoint) * (size_t)na) + Arena::pad(sizeof(orbx_keypoint) * (size_t)nb) +
                                     Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 4 * Arena::pad(4 * 64) : 0);
-    int r = m->arena.reserve(need);
+    int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
-    A.reset();
+    m->begin();
     BowProblem P;
     memset(&P, 0, sizeof(P));
     auto up_fv = [&](const orbx_featvec *f, FeatVecDev &d, size_t nidx) -> int {
@@ -698,7 +763,10 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
     auto up = [&](const void *src, size_t bytes) -> const uint8_t * {
         if (!src) return nullptr;
         uint8_t *d = A.take<uint8_t>(bytes);
-        if (hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) return nullptr;
+        void *st = m->stage.take(bytes);
+        if (!st) return nullptr;
+        memcpy(st, src, bytes);
+        if (hipMemcpyAsync(d, st, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) return nullptr;
         return d;
     };
     P.mode = mode; P.nb_left = nb_left;
@@ -726,7 +794,7 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
     int32_t nm = 0;
     D2H(match_out, P.match, 4 * (size_t)n_out);
     D2H(&nm, P.nmatches, 4);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return nm;
 }
 }  // namespace
@@ -1057,15 +1125,15 @@ extern "C" int orbx_undistort_keypoints(orbx_matcher *m, const orbx_camera *cam,
     if (!m || !cam || n < 0 || (n > 0 && (!kps || !kps_un))) return ORBX_E_BAD_ARG;
     if (n == 0) return ORBX_OK;
     ORBX_HIP(hipSetDevice(m->device));
-    int r = m->arena.reserve(2 * Arena::pad(sizeof(orbx_keypoint) * (size_t)n) + 4096);
+    int r = m->reserve_all(2 * Arena::pad(sizeof(orbx_keypoint) * (size_t)n) + 4096);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
-    A.reset();
+    m->begin();
     orbx_keypoint *di = A.take<orbx_keypoint>(n), *dou = A.take<orbx_keypoint>(n);
     H2D(di, kps, sizeof(orbx_keypoint) * (size_t)n);
     hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, m->stream, model_of(cam), (const orbx_keypoint *)di, (const int32_t *)nullptr, n, dou);
     D2H(kps_un, dou, sizeof(orbx_keypoint) * (size_t)n);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return ORBX_OK;
 }
 
@@ -1078,10 +1146,10 @@ extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_camera *cam, const
     if (n_mp == 0) return ORBX_OK;
     ORBX_HIP(hipSetDevice(m->device));
     const size_t n = (size_t)n_mp;
-    int r = m->arena.reserve(2 * Arena::pad(12 * n) + 8 * Arena::pad(4 * n) + Arena::pad(n) + Arena::pad(sizeof(FrustumFrame)) + 8192);
+    int r = m->reserve_all(2 * Arena::pad(12 * n) + 8 * Arena::pad(4 * n) + Arena::pad(n) + Arena::pad(sizeof(FrustumFrame)) + 8192);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
-    A.reset();
+    m->begin();
     float *dp = A.take<float>(3 * n), *dn = A.take<float>(3 * n), *dmn = A.take<float>(n), *dmx = A.take<float>(n);
     uint8_t *div = A.take<uint8_t>(n);
     float *dx = A.take<float>(n), *dy = A.take<float>(n), *dxr = A.take<float>(n), *dd = A.take<float>(n), *dvc = A.take<float>(n);
@@ -1094,7 +1162,7 @@ extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_camera *cam, const
                        (const float *)dn, (const float *)dmn, (const float *)dmx, div, dx, dy, dxr, dd, dl, dvc);
     D2H(in_view, div, n); D2H(proj_x, dx, 4 * n); D2H(proj_y, dy, 4 * n); D2H(proj_xr, dxr, 4 * n); D2H(depth, dd, 4 * n);
     D2H(level, dl, 4 * n); D2H(view_cos, dvc, 4 * n);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return ORBX_OK;
 }
 
@@ -1179,30 +1247,40 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
 extern "C" int orbx_stereo_batch_download(orbx_extractor *L, int frame, float *u_right, float *depth, int *n_left, int *n_matches) {
     if (!L || frame < 0 || frame >= L->last_batch || !L->d_st_ur.p) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(L->device));
-    int32_t nlv = 0, nm = 0;
-    ORBX_HIP(hipMemcpyAsync(&nlv, (int32_t *)L->d_count.p + frame, 4, hipMemcpyDeviceToHost, L->stream));
-    ORBX_HIP(hipMemcpyAsync(&nm, (int32_t *)L->d_st_nm.p + frame, 4, hipMemcpyDeviceToHost, L->stream));
+    const size_t fb = 4 * (size_t)L->cap, o_u = 64, o_d = o_u + ((fb + 63) & ~(size_t)63);
+    int r = L->d2h_staged_begin(o_d + fb);
+    if (r != ORBX_OK) return r;
+    if ((r = L->d2h_staged(0, (int32_t *)L->d_count.p + frame, 4)) != ORBX_OK) return r;
+    if ((r = L->d2h_staged(4, (int32_t *)L->d_st_nm.p + frame, 4)) != ORBX_OK) return r;
+    if ((r = L->d2h_staged(o_u, (float *)L->d_st_ur.p + (size_t)frame * L->cap, fb)) != ORBX_OK) return r;
+    if ((r = L->d2h_staged(o_d, (float *)L->d_st_depth.p + (size_t)frame * L->cap, fb)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(L->stream));
-    if (n_left) *n_left = nlv;
-    if (n_matches) *n_matches = nm;
-    if (nlv > 0) {
-        if (u_right) ORBX_HIP(hipMemcpyAsync(u_right, (float *)L->d_st_ur.p + (size_t)frame * L->cap, 4 * (size_t)nlv, hipMemcpyDeviceToHost, L->stream));
-        if (depth) ORBX_HIP(hipMemcpyAsync(depth, (float *)L->d_st_depth.p + (size_t)frame * L->cap, 4 * (size_t)nlv, hipMemcpyDeviceToHost, L->stream));
-        ORBX_HIP(hipStreamSynchronize(L->stream));
-    }
+    int32_t h[2];
+    memcpy(h, L->staged(0), 8);
+    if (n_left) *n_left = h[0];
+    if (n_matches) *n_matches = h[1];
+    const int nlv = std::min(std::max(h[0], 0), L->cap);
+    if (u_right) memcpy(u_right, L->staged(o_u), 4 * (size_t)nlv);
+    if (depth) memcpy(depth, L->staged(o_d), 4 * (size_t)nlv);
     return ORBX_OK;
 }
 
 // all frames of the last stereo batch at once: u_right / depth [n_frames][cap] (-1 where unmatched; entries beyond a frame's
-// keypoint count are unspecified), n_matches [n_frames]; synchronous on the left extractor's stream
+// keypoint count are unspecified), n_matches [n_frames]; synchronous on the left extractor's stream.  The destinations may be
+// pinned (copied directly would be possible) or pageable: they are always filled from the pinned staging buffer.
 extern "C" int orbx_stereo_batch_download_all(orbx_extractor *L, float *u_right, float *depth, int32_t *n_matches) {
     if (!L || L->last_batch <= 0 || !L->d_st_ur.p) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(L->device));
-    const size_t n = (size_t)L->last_batch;
-    if (u_right) ORBX_HIP(hipMemcpyAsync(u_right, L->d_st_ur.p, 4 * n * L->cap, hipMemcpyDeviceToHost, L->stream));
-    if (depth) ORBX_HIP(hipMemcpyAsync(depth, L->d_st_depth.p, 4 * n * L->cap, hipMemcpyDeviceToHost, L->stream));
-    if (n_matches) ORBX_HIP(hipMemcpyAsync(n_matches, L->d_st_nm.p, 4 * n, hipMemcpyDeviceToHost, L->stream));
+    const size_t n = (size_t)L->last_batch, fb = 4 * n * L->cap, o_d = (fb + 63) & ~(size_t)63, o_n = 2 * o_d;
+    int r = L->d2h_staged_begin(o_n + 4 * n);
+    if (r != ORBX_OK) return r;
+    if (u_right && (r = L->d2h_staged(0, L->d_st_ur.p, fb)) != ORBX_OK) return r;
+    if (depth && (r = L->d2h_staged(o_d, L->d_st_depth.p, fb)) != ORBX_OK) return r;
+    if (n_matches && (r = L->d2h_staged(o_n, L->d_st_nm.p, 4 * n)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(L->stream));
+    if (u_right) memcpy(u_right, L->staged(0), fb);
+    if (depth) memcpy(depth, L->staged(o_d), fb);
+    if (n_matches) memcpy(n_matches, L->staged(o_n), 4 * n);
     return ORBX_OK;
 }
 
@@ -1248,16 +1326,16 @@ extern "C" int orbx_bow_transform(orbx_matcher *m, const orbx_vocabulary *v, con
     if (!m || !v || n < 0 || (n > 0 && (!desc || !word_id || !node_id)) || m->device != v->device) return ORBX_E_BAD_ARG;
     if (n == 0) return ORBX_OK;
     ORBX_HIP(hipSetDevice(m->device));
-    int r = m->arena.reserve(Arena::pad(32 * (size_t)n) + 2 * Arena::pad(4 * (size_t)n) + 4096);
+    int r = m->reserve_all(Arena::pad(32 * (size_t)n) + 2 * Arena::pad(4 * (size_t)n) + 4096);
     if (r != ORBX_OK) return r;
-    m->arena.reset();
+    m->begin();
     uint8_t *dd = m->arena.take<uint8_t>(32 * (size_t)n);
     int32_t *dw = m->arena.take<int32_t>(n), *dn = m->arena.take<int32_t>(n);
     H2D(dd, desc, 32 * (size_t)n);
     hipLaunchKernelGGL(k_bow_transform, dim3((n + 15) / 16), dim3(256), 0, m->stream, v->child_ptr, v->child_idx, v->node_desc, v->word_id,
                        v->L, levelsup, dd, n, dw, dn);
     D2H(word_id, dw, 4 * (size_t)n); D2H(node_id, dn, 4 * (size_t)n);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return ORBX_OK;
 }
 
@@ -1268,16 +1346,16 @@ extern "C" int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *desc
     const int total = set_ptr[n_sets];
     if (total > 0 && !desc) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(m->device));
-    int r = m->arena.reserve(Arena::pad(32 * (size_t)total + 32) + Arena::pad(4 * (size_t)(n_sets + 1)) + Arena::pad(4 * (size_t)n_sets) + 4096);
+    int r = m->reserve_all(Arena::pad(32 * (size_t)total + 32) + Arena::pad(4 * (size_t)(n_sets + 1)) + Arena::pad(4 * (size_t)n_sets) + 4096);
     if (r != ORBX_OK) return r;
-    m->arena.reset();
+    m->begin();
     uint8_t *dd = m->arena.take<uint8_t>(32 * (size_t)total + 32);
     int32_t *dp = m->arena.take<int32_t>(n_sets + 1), *db = m->arena.take<int32_t>(n_sets);
     if (total > 0) H2D(dd, desc, 32 * (size_t)total);
     H2D(dp, set_ptr, 4 * (size_t)(n_sets + 1));
     hipLaunchKernelGGL(k_distinctive, dim3((n_sets + 3) / 4), dim3(256), 0, m->stream, dd, dp, n_sets, db);
     D2H(best_idx, db, 4 * (size_t)n_sets);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     return ORBX_OK;
 }
 
@@ -1298,10 +1376,10 @@ extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, cons
     size_t need = Arena::pad(28 * (size_t)n) + Arena::pad(32 * (size_t)n) + Arena::pad(4 * (size_t)n) + Arena::pad(4 * (size_t)nl) +
                   Arena::pad(4 * (size_t)n_q) * 6 + Arena::pad(32 * (size_t)n_q) + Arena::pad(8 * (size_t)n_q * kTopK) + Arena::pad(4 * (size_t)n_q) +
                   Arena::pad(sizeof(WindowProblem)) + Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)n) + 16 * 256 + 4096;
-    int r = m->arena.reserve(need);
+    int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
-    A.reset();
+    m->begin();
     WindowProblem P;
     memset(&P, 0, sizeof(P));
     orbx_keypoint *dk = A.take<orbx_keypoint>(n);
@@ -1337,7 +1415,7 @@ extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, cons
     hipLaunchKernelGGL(k_window_best2, dim3((n_q + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
     std::vector<u64> keys((size_t)n_q * kTopK);
     D2H(keys.data(), P.keys, 8 * (size_t)n_q * kTopK);
-    ORBX_HIP(hipStreamSynchronize(m->stream));
+    SYNC_AND_DELIVER();
     for (int i = 0; i < n_q; i++) {
         const u64 k = keys[(size_t)i * kTopK];
         if (k != kNoKey) { best_idx[i] = (int32_t)(k & 0xffff); best_dist[i] = (int32_t)(k >> 32); }

@@ -167,3 +167,24 @@ def test_stereo_download_all_equals_per_frame_download():
         n1, u1, d1 = exl.stereo_download(f)
         assert nm[f] == n1 and n1 > 100
         assert ur[f, :len(u1)].tobytes() == u1.tobytes() and depth[f, :len(d1)].tobytes() == d1.tobytes()
+
+
+def test_async_entry_points_refuse_pageable_host_memory():
+    """orbx_extract_batch_host / orbx_batch_download_async take the caller's pointers to the copy engine: pinned memory or an error."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    from orb_slam3_amd._lib import OrbxError
+    n, w, h = 2, 320, 240
+    frames = np.stack([synth.make_test_image(3 + t, w, h) for t in range(n)])
+    ex = osa.ORBextractor(500, 1.2, 8, 20, 7)
+    with pytest.raises(OrbxError):
+        ex.extract_batch_host(frames.ctypes.data, n, w, h, w, w * h, (0, 0))          # pageable numpy memory
+    pinned = torch.from_numpy(frames).pin_memory()
+    ex.extract_batch_host(pinned.data_ptr(), n, w, h, w, w * h, (0, 0))
+    cap = ex.batch_view().cap
+    kps = np.zeros((n, cap, 28), np.uint8)
+    with pytest.raises(OrbxError):
+        ex.download_async(kps.ctypes.data, 0, 0, 0)
+    ex.sync()
+    assert len(ex.download(0)[1]) > 50
