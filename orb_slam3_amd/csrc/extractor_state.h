@@ -31,6 +31,15 @@ void set_error(const std::string &s);
 // touching a neighbouring allocation.
 int guard_mode();
 int guard_fill();   // ORBX_GUARD_FILL=<byte> (default 0xCB)
+// Optional roctx ranges around the host-side phases (the reference instruments the same two spots with its REGISTER_TIMES timers:
+// ORB extraction and stereo / projection matching, Tracking.cc).  ORBX_ROCTX=1 resolves libroctx64.so / librocprofiler-sdk-roctx.so at
+// run time (no link dependency); rocprofv3 --marker-trace then shows orbx:extract / orbx:match / orbx:download ranges.
+struct RoctxRange {
+    explicit RoctxRange(const char *name);
+    ~RoctxRange();
+    bool on;
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;

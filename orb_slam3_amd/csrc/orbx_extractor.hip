@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -28,6 +29,28 @@ namespace orbx {
 thread_local std::string g_last_error;
 
 void set_error(const std::string &s) { g_last_error = s; }
+
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *v = getenv("ORBX_ROCTX");
+        if (!v || v[0] != '1') return;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+Roctx &roctx() { static Roctx r; return r; }
+}  // namespace
+RoctxRange::RoctxRange(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+RoctxRange::~RoctxRange() { if (on) roctx().pop(); }
 
 int guard_fill() {
     static const int m = [] { const char *v = getenv("ORBX_GUARD_FILL"); return v ? (atoi(v) & 0xff) : 0xCB; }();
@@ -285,6 +308,7 @@ struct ProfScope {
 // enqueue the whole extraction of `n` device-resident frames on ex->stream
 static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride,
                            int lap0, int lap1, hipEvent_t ev_input_consumed = nullptr) {
+    RoctxRange rr("orbx:extract");
     const int nl = ex->prm.nlevels;
     const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
     uint8_t *pyr = (uint8_t *)ex->d_pyr.p;
@@ -759,6 +783,7 @@ int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *des
 
 int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *desc, int32_t *counts, int32_t *mono,
                               int32_t *match, int32_t *nmatches) {
+    RoctxRange rr("orbx:download");
     if (!ex || ex->last_batch <= 0) return ORBX_E_BAD_ARG;
     if (ex->copy_issued - ex->copy_waited >= 2) { set_error("two downloads already in flight: call orbx_download_wait first"); return ORBX_E_BAD_ARG; }
     for (const void *p : {(const void *)kps, (const void *)desc, (const void *)counts, (const void *)mono, (const void *)match, (const void *)nmatches})

@@ -902,6 +902,7 @@ int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1,
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                              int32_t *d_match, int32_t *d_nmatches) {
+    RoctxRange rr("orbx:match_consecutive");
     if (!ex) return ORBX_E_BAD_ARG;
     const int n = ex->last_batch;
     if (n < 2) return ORBX_OK;
@@ -1007,6 +1008,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
                                                   const int32_t *d_level, const float *d_view_cos, const uint8_t *d_in_view,
                                                   const uint8_t *d_mp_desc, size_t desc_frame_stride, float th, float nnratio,
                                                   int32_t *d_match, int32_t *d_nmatches) {
+    RoctxRange rr("orbx:search_mappoints");
     if (!ex || n_mp < 0 || (n_mp > 0 && (!d_proj_x || !d_proj_y || !d_level || !d_view_cos || !d_mp_desc))) return ORBX_E_BAD_ARG;
     const int n = ex->last_batch;
     if (n < 1) return ORBX_E_BAD_ARG;
@@ -1199,6 +1201,7 @@ extern "C" int orbx_frustum_batch_device(orbx_extractor *ex, const orbx_camera *
 // the results are downloaded.  Runs on the left extractor's stream behind both extractions.
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, float bf, float b) {
+    RoctxRange rr("orbx:stereo");
     if (!L || !R || !(b > 0.f)) return ORBX_E_BAD_ARG;
     if (L->last_batch <= 0 || L->last_batch != R->last_batch || L->width != R->width || L->height != R->height ||
         L->prm.nlevels != R->prm.nlevels || L->device != R->device)
