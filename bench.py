@@ -353,8 +353,14 @@ def bench_euroc(R):
     W, H, NF, _, LAP = WORKLOADS["euroc"]
     B = a.batch or WORKLOADS["euroc"][3]
     seed = 10 + R.rank
-    canvas = synth.make_canvas(seed)
-    frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t) for t in range(B)])
+    from orb_slam3_amd import dataset
+    data = "synthetic"
+    if dataset.dataset_dir("euroc"):   # a real EuRoC sequence: rank r takes frames r*B .. (r+1)*B - 1
+        frames = dataset.load_mono("euroc", B, W, H, start=R.rank * B)
+        data = f"dataset: {dataset.dataset_dir('euroc')} (first {B} frames per rank)"
+    else:
+        canvas = synth.make_canvas(seed)
+        frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t) for t in range(B)])
     h_frames = torch.from_numpy(frames).pin_memory()          # the camera thread's buffers (pcie_inclusive leg)
     d_frames = torch.from_numpy(frames).cuda()                 # resident input of the contract's `value`
     torch.cuda.synchronize()
@@ -452,6 +458,7 @@ def bench_euroc(R):
                                  "SearchByProjection(th=15) + D2H of results; inputs resident in HBM",
                      "frames_per_step_per_gpu": B, "sequences": R.world, "features_per_frame": round(feats / a.steps / B, 1),
                      "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{R.world} independent sequences, one per GPU"})
+    out["data"] = data
     out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels})
     R.finish(out)
 
@@ -497,8 +504,14 @@ def bench_kitti(R):
     from orb_slam3_amd import synth
     W, H, NF, _, LAP = WORKLOADS["kitti"]
     B = a.batch or WORKLOADS["kitti"][3]
-    canvas = synth.make_canvas(30 + R.rank, size=2600, n_shapes=4000)
-    pairs = [synth.make_stereo_pair(30 + R.rank, t, W, H, canvas) for t in range(B)]
+    from orb_slam3_amd import dataset
+    data = "synthetic"
+    if dataset.dataset_dir("kitti"):
+        pairs = dataset.load_stereo("kitti", B, W, H)
+        data = f"dataset: {dataset.dataset_dir('kitti')} (first {B} pairs)"
+    else:
+        canvas = synth.make_canvas(30 + R.rank, size=2600, n_shapes=4000)
+        pairs = [synth.make_stereo_pair(30 + R.rank, t, W, H, canvas) for t in range(B)]
     dl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
     dr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
     torch.cuda.synchronize()
@@ -581,6 +594,7 @@ def bench_kitti(R):
                                  "(row-band Hamming, SAD sub-pixel, median rejection) on device + D2H; inputs resident in HBM",
                      "pairs_per_step_per_gpu": B, "sequences": R.world, "features_per_pair": round(feats / a.steps / B, 1),
                      "stereo_matches_per_pair": round(float(h_nm.sum()) / B, 1)})
+    out["data"] = data
     out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels})
     R.finish(out)
 
@@ -613,8 +627,14 @@ def bench_tumvi(R):
     canvas = synth.make_canvas(seed, size=2600, n_shapes=4000)
     yy, xx = np.mgrid[0:H, 0:W]
     vign = (1.0 - 0.45 * (((xx - W / 2) ** 2 + (yy - H / 2) ** 2) / (W * W / 2.0))).astype(np.float32)   # radial vignetting
-    frames = np.stack([np.clip(np.rint(synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t).astype(np.float32) * vign), 0, 255).astype(np.uint8)
-                       for t in range(B)])
+    from orb_slam3_amd import dataset
+    data = "synthetic"
+    if dataset.dataset_dir("tumvi"):
+        frames = dataset.load_mono("tumvi", B, W, H, start=R.rank * B)
+        data = f"dataset: {dataset.dataset_dir('tumvi')} (first {B} frames per rank)"
+    else:
+        frames = np.stack([np.clip(np.rint(synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t).astype(np.float32) * vign), 0, 255).astype(np.uint8)
+                           for t in range(B)])
     d_frames = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
     ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
@@ -697,6 +717,7 @@ def bench_tumvi(R):
                                  f"{N_MAPPOINTS} map points per frame (th=1, nnratio=0.8) + D2H; inputs resident in HBM",
                      "frames_per_step_per_gpu": B, "sequences": R.world, "features_per_frame": round(feats / a.steps / B, 1),
                      "map_point_matches_per_frame": round(float(last["nm"].sum()) / B, 1)})
+    out["data"] = data
     out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels})
     R.finish(out)
 

@@ -92,3 +92,33 @@ def test_cpp_adapters_compile_and_link_against_the_c_abi(tmp_path):
                         "-Wl,-rpath," + str(_lib.LIB_PATH.parent), "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert exe.exists()
+
+
+def test_dataset_loader_reads_euroc_and_kitti_layouts(tmp_path, monkeypatch):
+    """ORBX_EUROC_DIR / ORBX_KITTI_DIR: PNG sequences in the datasets' folder layouts replace the synthetic frames (bench.py)."""
+    from PIL import Image
+    from orb_slam3_amd import dataset, synth
+    rng = np.random.default_rng(0)
+    e = tmp_path / "MH_01_easy" / "mav0" / "cam0" / "data"
+    e.mkdir(parents=True)
+    frames = [synth.make_test_image(20 + t, 752, 480) for t in range(3)]
+    for t, f in enumerate(frames):
+        Image.fromarray(f).save(e / f"14036365{t:011d}.png")
+    monkeypatch.setenv("ORBX_EUROC_DIR", str(tmp_path / "MH_01_easy"))
+    got = dataset.load_mono("euroc", 5, 752, 480)           # cycles when the folder is short
+    assert got.shape == (5, 480, 752) and np.array_equal(got[1], frames[1]) and np.array_equal(got[3], frames[0])
+    k = tmp_path / "00"
+    (k / "image_0").mkdir(parents=True); (k / "image_1").mkdir()
+    big = rng.integers(0, 256, (380, 1250), dtype=np.uint8)   # slightly larger: centre-cropped to the workload's 1241x376
+    for t in range(2):
+        Image.fromarray(big).save(k / "image_0" / f"{t:06d}.png")
+        Image.fromarray(np.ascontiguousarray(big[:, ::-1])).save(k / "image_1" / f"{t:06d}.png")
+    monkeypatch.setenv("ORBX_KITTI_DIR", str(k))
+    pairs = dataset.load_stereo("kitti", 2, 1241, 376)
+    assert pairs[0][0].shape == (376, 1241) and np.array_equal(pairs[0][0], big[2:378, 4:1245])
+    t16 = tmp_path / "tumvi" / "mav0" / "cam0" / "data"
+    t16.mkdir(parents=True)
+    a16 = (rng.integers(0, 256, (1024, 1024)).astype(np.uint16) << 8)
+    Image.fromarray(a16).save(t16 / "0.png")
+    monkeypatch.setenv("ORBX_TUMVI_DIR", str(tmp_path / "tumvi"))
+    assert np.array_equal(dataset.load_mono("tumvi", 1, 1024, 1024)[0], (a16 >> 8).astype(np.uint8))
