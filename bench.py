@@ -62,7 +62,7 @@ def algorithmic_bytes(sizes, n_frames, feats, cands):
     per = {
         "k_pyr_base": 2 * px[0] * n_frames,                       # image read + level-0 write
         "k_pyr_resize": ((P - px[-1]) + (P - px[0])) * n_frames / (NLEVELS - 1),  # per launch (7 launches)
-        "k_fast_wave": P * n_frames + 4 * Cn,                     # pyramid read + packed candidates
+        "k_fast_ini": P * n_frames + 4 * Cn,                      # pyramid read + packed candidates (k_fast_ini + its list pass k_fast_wave_list)
         "k_blur": 2 * P * n_frames,
         "k_octree": 8 * Cn + 4 * N,                               # candidates read + gathered, keypoints out
         "k_finalize": 16 * N,
@@ -101,6 +101,11 @@ def roofline_from_profile(ex, prof, passes, sizes, n_frames, n_feat, n_cand, lau
 # PMC traffic of the dominant kernel, measured IN THIS RUN (opt-in, --pmc): two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE:
 # they do not fit one pass) over a short serialized child run of this same file, parsed from rocprofv3's database
 # ---------------------------------------------------------------------------------------------------------
+# a profile slot may cover more than one kernel: the FAST stage = first pass for every cell + the list pass over the cells it left
+STAGE_KERNELS = {"k_fast_ini": ("k_fast_ini", "k_fast_wave_list", "k_fast_wave"), "k_octree": ("k_compact", "k_octree_par", "k_octree_par1", "k_octree"),
+                 "k_window_best2": ("k_grid_build", "k_window_best2")}
+
+
 def pmc_traffic(kernel, workload, batch):
     import re
     import shutil
@@ -123,21 +128,22 @@ def pmc_traffic(kernel, workload, batch):
             shutil.rmtree(td, ignore_errors=True)
             return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
         c = sqlite3.connect(str(dbs[0]))
-        tot, n = 0.0, 0
+        group = STAGE_KERNELS.get(kernel, (kernel,))
+        per = {k: [0.0, 0] for k in group}
         tabs = [t[0] for t in c.execute("select name from sqlite_master where type in ('table','view')")]
         view = "counters_collection" if "counters_collection" in tabs else next((t for t in tabs if t.startswith("counters_collection")), None)
         if view is None:
             return None, "no counters_collection view in the rocprofv3 database"
         for name, val in c.execute(f"select kernel_name, value from {view} where counter_name=?", (counter,)):
             k = re.sub(r"<.*>", "", name.split("(")[0].replace("void ", "").replace("orbx::", ""))
-            if k == kernel:
-                tot += val
-                n += 1
+            if k in group:
+                per[k][0] += val
+                per[k][1] += 1
         c.close()
         shutil.rmtree(td, ignore_errors=True)
-        if n == 0:
+        if not any(v[1] for v in per.values()):
             return None, f"kernel {kernel} not in the {counter} pass"
-        out[counter] = tot / n * 1024.0   # KiB per dispatch -> bytes
+        out[counter] = sum(v[0] / v[1] for v in per.values() if v[1]) * 1024.0   # KiB per dispatch -> bytes, summed over the stage's kernels
     return out, None
 
 
@@ -269,6 +275,27 @@ def cpu_baseline_tumvi(frames, mp_sets, n_sample, w, h, nfeat):
 # ---------------------------------------------------------------------------------------------------------
 # rank process
 # ---------------------------------------------------------------------------------------------------------
+def bind_to_gpu_numa_node(torch, index):
+    """Run this rank (and first-touch its pinned buffers) on the CPU cores local to its GPU: the host-input leg moves 92 MB per step
+    over PCIe, and pinned memory on the other socket costs a third of the bandwidth.  Best effort; returns a short description."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        cpus = open(f"{base}/local_cpulist").read().strip()
+        node = open(f"{base}/numa_node").read().strip()
+        ids = set()
+        for part in cpus.split(","):
+            a, _, b = part.partition("-")
+            ids.update(range(int(a), int(b or a) + 1))
+        if ids:
+            os.sched_setaffinity(0, ids)
+            return f"gpu {bdf} numa {node} cpus {cpus}"
+    except Exception as e:   # no sysfs entry / no permission: keep the inherited affinity
+        return f"unbound ({type(e).__name__})"
+    return "unbound"
+
+
 class Rank:
     def __init__(self, args):
         self.args = args
@@ -285,6 +312,7 @@ class Rank:
             if torch.cuda.device_count() <= self.local_rank:
                 raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
             torch.cuda.set_device(self.local_rank)
+            self.numa = bind_to_gpu_numa_node(torch, self.local_rank)
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.dry:
@@ -423,7 +451,7 @@ def bench_euroc(R):
     if R.rank == 0 and a.verify > 0:
         verify_euroc(frames, host[(a.steps - 1) % 2], min(a.verify, 2), W, H, NF, ex)   # the host-input path delivers the same results
     pcie = {"value": round(feats_h_all / dt_h_max / 1e3, 2), "unit": "kfeatures/s", "ms_per_step": round(dt_h_max / a.steps * 1e3, 3),
-            "h2d_bytes_per_step": int(B * W * H), "h2d_GBs": round(B * W * H / (dt_h_max / a.steps) / 1e9, 1),
+            "h2d_bytes_per_step": int(B * W * H), "h2d_GBs": round(B * W * H / (dt_h_max / a.steps) / 1e9, 1), "host_affinity": R.numa,
             "note": "frames in pinned host memory; orbx_extract_batch_host uploads batch i+1 on its own stream while batch i computes"}
 
     # ---- per-kernel timing with HIP events on the extractor's stream (separate, untimed, serialized passes) ----

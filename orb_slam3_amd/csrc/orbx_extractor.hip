@@ -68,7 +68,7 @@ static const int8_t kPatternData[1024] = {
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
 static inline int cv_round_d(double v) { return (int)lrint(v); }
 
-static const char *kKernelNames[K_COUNT] = {"k_pyr_base", "k_pyr_resize", "k_fast_wave", "k_octree", "k_finalize",
+static const char *kKernelNames[K_COUNT] = {"k_pyr_base", "k_pyr_resize", "k_fast_ini", "k_octree", "k_finalize",
                                             "k_blur", "k_describe", "k_window_best2", "k_greedy_resolve"};
 
 }  // namespace orbx
