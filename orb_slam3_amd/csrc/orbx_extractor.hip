@@ -559,6 +559,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipStreamCreateWithPriority(&ex->copy_stream, hipStreamNonBlocking, prio_lo);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
     { const char *v = getenv("ORBX_BLUR_SIDE"); ex->blur_side = !(v && v[0] == '0'); }
+    { const char *v = getenv("ORBX_FAST_INI_QCAP"); if (v && atoi(v) >= 16) ex->fast_ini_qcap = atoi(v) & ~15; }  // test hook: force the list pass
     { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 64) ex->fast_wave_qcap = atoi(v) & ~15; }  // test hook: force k_fast_overflow
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, use_prio == 2 ? prio_lo : prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
