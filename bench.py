@@ -9,7 +9,7 @@ A "step" = one pass of the hot path over one batch of synthetic frames of ONE ca
         + D2H of keypoints, descriptors, counts and match indices into pinned host memory;
   kitti (BASELINE config 3): 64 rectified stereo pairs 1241x376, nFeatures=2000 -- left + right extraction +
         Frame::ComputeStereoMatches (row-band Hamming, SAD sub-pixel, median rejection) on the device + D2H;
-  tumvi (BASELINE config 4): 32 frames 1024x1024, nFeatures=1500 -- extract + SearchByProjection(Frame, MapPoints) against
+  tumvi (BASELINE config 4): 64 frames 1024x1024, nFeatures=1500 -- extract + SearchByProjection(Frame, MapPoints) against
         10,000 map-point descriptors per frame (Tracking.cc:3390-3413) + D2H.
 `value` follows the bench contract: inputs are resident in HBM when the timed region starts.  The same run also measures the
 host-input rate (`pcie_inclusive`: frames start in pinned host memory, orbx_extract_batch_host uploads batch i+1 while batch
@@ -45,7 +45,7 @@ WORKLOADS = {
     # name: (width, height, nfeatures, default frames per step, lapping area)
     "euroc": (752, 480, 1000, 256, (0, 1000)),
     "kitti": (1241, 376, 2000, 64, (0, 0)),
-    "tumvi": (1024, 1024, 1500, 32, (0, 1000)),
+    "tumvi": (1024, 1024, 1500, 64, (0, 1000)),
 }
 N_MAPPOINTS = 10000
 
@@ -107,6 +107,10 @@ STAGE_KERNELS = {"k_fast_ini": ("k_fast_ini", "k_fast_wave_list", "k_fast_wave")
 
 
 def pmc_traffic(kernel, workload, batch):
+    """HBM-side bytes per launch of a stage, measured in this run: two rocprofv3 --pmc child passes of this same file.
+    Reads: 32 * TCC_EA0_RDREQ_32B + 64 * TCC_EA0_RDREQ_64B + 128 * TCC_EA0_RDREQ_128B (the request-size classes; on gfx950 practically
+    every read request is a 128-byte one, which the derived FETCH_SIZE counter tallies at 64 bytes -- it under-reports every kernel of this
+    path by 2x).  Writes: WRITE_SIZE (32 / 64-byte write requests; agrees with known store volumes)."""
     import re
     import shutil
     import sqlite3
@@ -114,36 +118,39 @@ def pmc_traffic(kernel, workload, batch):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    out = {}
     env = dict(os.environ, ORBX_SIDE_STREAMS="0", TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    group = STAGE_KERNELS.get(kernel, (kernel,))
+    out = {}
+    passes = {"read": ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"], "write": ["WRITE_SIZE"]}
+    weight = {"TCC_EA0_RDREQ_32B_sum": 32.0, "TCC_EA0_RDREQ_64B_sum": 64.0, "TCC_EA0_RDREQ_128B_sum": 128.0, "WRITE_SIZE": 1024.0}
+    for name, counters in passes.items():
         td = tempfile.mkdtemp(prefix="orbx_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "-d", td, "-o", "p", "--", sys.executable, str(ROOT / "bench.py"), "--pmc-child", "--workload", workload,
+        cmd = [exe, "--pmc", *counters, "-d", td, "-o", "p", "--", sys.executable, str(ROOT / "bench.py"), "--pmc-child", "--workload", workload,
                "--batch", str(batch), "--steps", "2", "--warmup", "1"]
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
         dbs = list(Path(td).rglob("*.db"))
         if r.returncode != 0 or not dbs:
             shutil.rmtree(td, ignore_errors=True)
-            return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode})"
         c = sqlite3.connect(str(dbs[0]))
-        group = STAGE_KERNELS.get(kernel, (kernel,))
-        per = {k: [0.0, 0] for k in group}
         tabs = [t[0] for t in c.execute("select name from sqlite_master where type in ('table','view')")]
         view = "counters_collection" if "counters_collection" in tabs else next((t for t in tabs if t.startswith("counters_collection")), None)
         if view is None:
             return None, "no counters_collection view in the rocprofv3 database"
-        for name, val in c.execute(f"select kernel_name, value from {view} where counter_name=?", (counter,)):
-            k = re.sub(r"<.*>", "", name.split("(")[0].replace("void ", "").replace("orbx::", ""))
-            if k in group:
-                per[k][0] += val
-                per[k][1] += 1
+        per = {k: [0.0, 0] for k in group}   # bytes summed over counters, dispatches
+        seen = {k: set() for k in group}
+        for kname, cname, val, did in c.execute(f"select kernel_name, counter_name, value, dispatch_id from {view}"):
+            k = re.sub(r"<.*>", "", kname.split("(")[0].replace("void ", "").replace("orbx::", ""))
+            if k in per and cname in weight:
+                per[k][0] += val * weight[cname]
+                seen[k].add(did)
         c.close()
         shutil.rmtree(td, ignore_errors=True)
-        if not any(v[1] for v in per.values()):
-            return None, f"kernel {kernel} not in the {counter} pass"
-        out[counter] = sum(v[0] / v[1] for v in per.values() if v[1]) * 1024.0   # KiB per dispatch -> bytes, summed over the stage's kernels
+        if not any(seen.values()):
+            return None, f"kernel {kernel} not in the {name} pass"
+        out[name] = sum(per[k][0] / len(seen[k]) for k in group if seen[k])   # per launch, summed over the stage's kernels
     return out, None
 
 
@@ -471,9 +478,11 @@ def bench_euroc(R):
         if a.pmc:
             tr, err = pmc_traffic(roofline["kernel"], "euroc", B)
             if tr:
-                roofline["traffic"] = int(tr["FETCH_SIZE"] + tr["WRITE_SIZE"])
-                roofline["traffic_detail"] = {"FETCH_SIZE_bytes": int(tr["FETCH_SIZE"]), "WRITE_SIZE_bytes": int(tr["WRITE_SIZE"]),
-                                              "note": "rocprofv3 --pmc, separate passes of this run; 4-B/lane loads: FETCH_SIZE not doubled (calibration in DESIGN.md 6)"}
+                roofline["traffic"] = int(tr["read"] + tr["write"])
+                roofline["traffic_detail"] = {"read_bytes": int(tr["read"]), "write_bytes": int(tr["write"]),
+                                              "traffic_over_algorithmic": round((tr["read"] + tr["write"]) / roofline["alg_bytes_per_launch"], 2),
+                                              "note": "rocprofv3 --pmc child passes of this run; reads = 32/64/128-byte request classes "
+                                                      "(FETCH_SIZE tallies gfx950's 128-byte requests at 64 bytes), writes = WRITE_SIZE"}
             else:
                 roofline["traffic_error"] = err
 

@@ -372,10 +372,10 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                 // first pass of :826 for every cell (k_fast_ini); cells it leaves empty go to the list pass below
                 const size_t lds_ini = fast_ini_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_ini_qcap, ex->fast_ini_gcap);
 #define ORBX_FAST_INI(PITCH)                                                                                                        \
-    hipLaunchKernelGGL(k_fast_ini<PITCH>, dim3(ex->n_fast_tiles, n), dim3(64), lds_ini + ldspad, st,                                    \
+    hipLaunchKernelGGL(k_fast_ini<PITCH>, xcd_grid(ex->n_fast_tiles, n), dim3(64), lds_ini + ldspad, st,                                 \
                        (const FastTile *)ex->d_ftiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,            \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->fast_wave_rows, ex->fast_ini_qcap,     \
-                       ex->fast_ini_gcap, ovf_list, ovf_count)
+                       ex->fast_ini_gcap, ovf_list, ovf_count, n)
                 if (ex->fast_wave_pitch == 48) ORBX_FAST_INI(48); else ORBX_FAST_INI(64);
             } else {
                 if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE(48); else ORBX_FAST_WAVE(64);
@@ -434,10 +434,10 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     if (!ex->profile && ex->side_streams && ex->blur_side) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
     {
         ProfScope ps(ex, K_DESCRIBE);
-        hipLaunchKernelGGL(k_describe, dim3((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
+        hipLaunchKernelGGL(k_describe, xcd_grid((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
                            (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
                            ex->pyr_frame, (const uint8_t *)ex->d_blur.p, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
-                           (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0);
+                           (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0, n);
     }
     if (ex->has_camera) {   // Frame::UndistortKeyPoints for the whole batch (mvKeysUn for the batched matchers)
         CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],

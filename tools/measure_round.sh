@@ -16,7 +16,7 @@ python tools/rocprof_summary.py $(biggest_db $O/ov) profiles/${TAG}_overlapped_k
 # serialized (every kernel on the extractor's main stream): the per-kernel durations the roofline is computed from
 ORBX_SIDE_STREAMS=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/se -o se -- $CHILD --steps 12 --warmup 3 > /dev/null 2>&1
 python tools/rocprof_summary.py $(biggest_db $O/se) profiles/${TAG}_serialized_kernel_stats.csv
-ORBX_SIDE_STREAMS=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pf -o pf -- $CHILD --steps 3 --warmup 1 > /dev/null 2>&1
+ORBX_SIDE_STREAMS=0 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $O/pf -o pf -- $CHILD --steps 3 --warmup 1 > /dev/null 2>&1
 ORBX_SIDE_STREAMS=0 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/pw -o pw -- $CHILD --steps 3 --warmup 1 > /dev/null 2>&1
 python tools/pmc_summary.py $(biggest_db $O/pf) $(biggest_db $O/pw) $TAG
 ORBX_SIDE_STREAMS=0 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $O/sq -o sq -- $CHILD --steps 3 --warmup 1 > /dev/null 2>&1
