@@ -481,6 +481,31 @@ __device__ __forceinline__ void fast_tile_load(const uint8_t *__restrict__ src, 
     }
 }
 
+// the same through a buffer descriptor over the tile's byte range [src, src + (rows - 1) * pitch + 4 * nd): rows past the tile are
+// out of range for the hardware (they read as 0, no memory access), so the twelve loads need no per-row predicate and no 64-bit
+// address arithmetic -- one v_add per load instead of eight VALU instructions (a quarter of the cell's budget went into this phase:
+// 121 of 907 VALU instructions per wave, SQ_INSTS_VALU under ORBX_FAST_STOP=1).  The LDS slice must hold 48 rows (launch code).
+template <int P>
+__device__ __forceinline__ void fast_tile_load_srd(const uint8_t *src, int pitch, int rows, int cols, uint8_t *pix, int lane) {
+    const int c = lane & 15, nd = (cols + 4) >> 2, r0 = lane >> 4;
+    if (c >= nd) return;
+    // wave-uniform descriptor inputs, provably so for the compiler
+    const uint64_t a = (uint64_t)src;
+    const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)a), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const int spitch = __builtin_amdgcn_readfirstlane(pitch);
+    const int nbytes = __builtin_amdgcn_readfirstlane((rows - 1) * pitch + 4 * nd);
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)ahi << 32) | alo), 0, nbytes, 0x00020000);
+    const int voff = r0 * spitch + 4 * c;
+    uint32_t v[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, voff + 4 * k * spitch, 0, 0);
+    uint8_t *d = pix + r0 * P + 4 * c;
+#pragma unroll
+    for (int k = 0; k < 12; k++) *reinterpret_cast<uint32_t *>(d + 4 * k * P) = v[k];
+    for (int r = 48 + r0; r < rows; r += 4)   // tiles taller than 48 rows (cells above 42 px)
+        *reinterpret_cast<uint32_t *>(pix + r * P + 4 * c) = __builtin_amdgcn_raw_buffer_load_b32(srd, r * spitch + 4 * c, 0, 0);
+}
+
 // LDS of one wave (= one cell): pixel tile rows x P | queue[qcap] u16 | score per queue entry [qcap] u8.  After the scores are
 // known the pixel tile is dead and its memory becomes the zero-aproned score tile of the NMS; the survivors of the NMS
 // overwrite the head of the queue in place.  ~4.7 KB for EuRoC (P = 48, qcap = 768) -> 32 waves per CU: the kernel's time
@@ -656,16 +681,20 @@ __host__ __device__ inline size_t fast_ini_lds_bytes(int P, int max_rows, int qc
     return (((size_t)max_rows * P + 16 + 15) & ~(size_t)15) + (size_t)qcap * 3 + 16 + (size_t)gcap * 2;
 }
 
+// the waves of a k_fast_ini workgroup never talk to each other: LDS accesses of one wave execute in program order, so a wave-private
+// hand-over through LDS needs no s_barrier -- only the compiler must not move LDS accesses across the point
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one cell whose tile already sits in LDS
 template <int P>
-__global__ __launch_bounds__(64) void k_fast_ini(const FastTile *__restrict__ ftiles, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                 int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
-                                                 size_t ent_frame_stride, int iniTh, int max_rows, int qcap, int gcap,
-                                                 uint32_t *__restrict__ list, int32_t *__restrict__ list_count, int n_frames) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int tile, f;
-    if (!xcd_frame_map(n_frames, &tile, &f)) return;   // a frame's cells stay on one XCD (shared aprons hit its L2)
-    const FastTile T = ftiles[tile];
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void fast_ini_body(const FastTile T, const int f, const int tile, uint8_t *smem, int32_t *__restrict__ cellcnt,
+                                              int total_cells, uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh, int max_rows,
+                                              int qcap, uint32_t *__restrict__ list, int32_t *__restrict__ list_count, int dbg_stop) {
+    const int lane = threadIdx.x & 63;
     int32_t *cnt_out = cellcnt + (size_t)f * total_cells + T.cell;
     const int cols = T.cols, rows = T.rows;
     const int iw = cols - 6, ih = rows - 6;
@@ -677,9 +706,7 @@ __global__ __launch_bounds__(64) void k_fast_ini(const FastTile *__restrict__ ft
     uint16_t *queue = reinterpret_cast<uint16_t *>(smem + (((size_t)max_rows * P + 16 + 15) & ~(size_t)15));
     uint8_t *scq = reinterpret_cast<uint8_t *>(queue + qcap);
     uint16_t *gq = reinterpret_cast<uint16_t *>(scq + qcap + 16 - (qcap & 1));   // 2-byte aligned
-
-    fast_tile_load<P>(pyr + (size_t)f * pyr_frame_stride + T.src_off, T.pitch, rows, cols, pix, lane);   // phase 0
-    __syncthreads();
+    if (dbg_stop == 1) { if (lane == 0) *cnt_out = (int)pix[lane] > 255 ? 1 : 0; return; }   // ORBX_FAST_STOP: phase timing by truncation (diagnostic, wrong results)
 
     constexpr int D = P / 4;
     const int G = (iw + 3) >> 2, RPI = 64 / G;
@@ -704,7 +731,8 @@ __global__ __launch_bounds__(64) void k_fast_ini(const FastTile *__restrict__ ft
             gn += __popcll(b);
         }
     }
-    __syncthreads();
+    wave_lds_sync();
+    if (dbg_stop == 2) { if (lane == 0) *cnt_out = gn < 0 ? 1 : 0; return; }
 
     // stage B: the antipodal-pair test of k_fast_wave (at iniTh) on the queued groups, four pixels per lane, row-major queue order
     int qn = 0;
@@ -750,7 +778,8 @@ __global__ __launch_bounds__(64) void k_fast_ini(const FastTile *__restrict__ ft
             qn += tot;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
+    if (dbg_stop == 3) { if (lane == 0) *cnt_out = qn < 0 ? 1 : 0; return; }
 
     // phase 2: exact score of the queued pixels at iniTh
     for (int e = lane; e < qn; e += 64) {
@@ -759,15 +788,16 @@ __global__ __launch_bounds__(64) void k_fast_ini(const FastTile *__restrict__ ft
         int s = fast_score16(pix + (y + 3) * P + x + 4, P);
         scq[e] = (uint8_t)((s >= iniTh) ? s : 0);
     }
-    __syncthreads();
+    wave_lds_sync();
+    if (dbg_stop == 4) { if (lane == 0) *cnt_out = (int)scq[0] > 255 ? 1 : 0; return; }
     uint8_t *sco = pix;   // the pixel tile is dead: score tile with a zero apron
     for (int i = lane; i < (ih + 2) * (P / 4); i += 64) reinterpret_cast<uint32_t *>(sco)[i] = 0;
-    __syncthreads();
+    wave_lds_sync();
     for (int e = lane; e < qn; e += 64) {
         const int s = scq[e];
         if (s) { const int q = queue[e]; sco[((q >> 8) + 1) * P + (q & 0xff) + 1] = (uint8_t)s; }
     }
-    __syncthreads();
+    wave_lds_sync();
 
     // phase 3 + 4: NMS, survivors emitted in row-major order (every survivor scores >= iniTh)
     uint32_t *slot = cellent + (size_t)f * ent_frame_stride + T.slot;
@@ -791,6 +821,28 @@ __global__ __launch_bounds__(64) void k_fast_ini(const FastTile *__restrict__ ft
         return;
     }
     if (lane == 0) *cnt_out = total;
+}
+
+// W cells per workgroup, one per wave, each wave on its own LDS slice and never synchronising with the others: the work per cell
+// is so short (a few us) that with one-wave workgroups the kernel ran at the workgroup dispatch rate (truncation timing,
+// ORBX_FAST_STOP=1: tile loads alone 99 of 285 us for 665k workgroups)
+template <int P, int W>
+__global__ __launch_bounds__(64 * W) void k_fast_ini(const FastTile *__restrict__ ftiles, const uint8_t *__restrict__ pyr,
+                                                                 size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
+                                                                 uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh, int max_rows,
+                                                                 int qcap, int gcap, uint32_t *__restrict__ list, int32_t *__restrict__ list_count,
+                                                                 int n_frames, int n_tiles, int lds_per_wave, int dbg_stop) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+    int grp, f;
+    if (!xcd_frame_map(n_frames, &grp, &f)) return;   // a frame's cells stay on one XCD (shared aprons hit its L2)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = W * grp + wave;
+    if (tile >= n_tiles) return;
+    uint8_t *smem = smem_all + (size_t)wave * lds_per_wave;
+    const FastTile T = ftiles[tile];
+    if (T.cols > 0) fast_tile_load_srd<P>(pyr + (size_t)f * pyr_frame_stride + T.src_off, T.pitch, T.rows, T.cols, smem, lane);   // phase 0
+    wave_lds_sync();
+    fast_ini_body<P>(T, f, tile, smem, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, max_rows, qcap, list, list_count, dbg_stop);
 }
 
 // the cells k_fast_wave appended to its overflow list (more candidates than its LDS queue holds; about 0.5 % of the cells of

@@ -367,16 +367,22 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                        (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,         \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qcap, \
                        ovf_list, ovf_count)
+            static const int fast_stop = [] { const char *v = getenv("ORBX_FAST_STOP"); return v ? atoi(v) : 0; }();   // diagnostic: truncate k_fast_ini
             static const bool ini_first = [] { const char *v = getenv("ORBX_FAST_INI"); return !(v && v[0] == '0'); }();
             if (ini_first && ini > mn) {
                 // first pass of :826 for every cell (k_fast_ini); cells it leaves empty go to the list pass below
-                const size_t lds_ini = fast_ini_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_ini_qcap, ex->fast_ini_gcap);
-#define ORBX_FAST_INI(PITCH)                                                                                                        \
-    hipLaunchKernelGGL(k_fast_ini<PITCH>, xcd_grid(ex->n_fast_tiles, n), dim3(64), lds_ini + ldspad, st,                                 \
+                const size_t lds_wave = std::max<size_t>((fast_ini_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_ini_qcap, ex->fast_ini_gcap) + 15) & ~(size_t)15,
+                                                          (size_t)48 * ex->fast_wave_pitch);   // fast_tile_load_srd writes 48 rows
+#define ORBX_FAST_INI(PITCH, W)                                                                                                     \
+    hipLaunchKernelGGL((k_fast_ini<PITCH, W>), xcd_grid((ex->n_fast_tiles + W - 1) / W, n), dim3(64 * W), (lds_wave + ldspad) * W, st, \
                        (const FastTile *)ex->d_ftiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,            \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->fast_wave_rows, ex->fast_ini_qcap,     \
-                       ex->fast_ini_gcap, ovf_list, ovf_count, n)
-                if (ex->fast_wave_pitch == 48) ORBX_FAST_INI(48); else ORBX_FAST_INI(64);
+                       ex->fast_ini_gcap, ovf_list, ovf_count, n, ex->n_fast_tiles, (int)(lds_wave + ldspad), fast_stop)
+#define ORBX_FAST_INI_P(W) do { if (ex->fast_wave_pitch == 48) ORBX_FAST_INI(48, W); else ORBX_FAST_INI(64, W); } while (0)
+                // cells per workgroup (one wave each; the waves do not synchronise): 4 unless ORBX_FAST_INI_WAVES says otherwise
+                static const int ini_waves = [] { const char *v = getenv("ORBX_FAST_INI_WAVES"); return v ? atoi(v) : 4; }();
+                if (ini_waves == 1) ORBX_FAST_INI_P(1); else if (ini_waves == 2) ORBX_FAST_INI_P(2); else if (ini_waves == 8) ORBX_FAST_INI_P(8);
+                else ORBX_FAST_INI_P(4);
             } else {
                 if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE(48); else ORBX_FAST_WAVE(64);
             }
