@@ -44,15 +44,14 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // (row, chunk) so every lane is busy.
 // grid (ceil(words_per_frame/256), B)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo *__restrict__ lv, const uint8_t *__restrict__ img,
+__global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo L, const uint8_t *__restrict__ img,
                                                   size_t row_stride, size_t frame_stride, uint8_t *__restrict__ pyr,
-                                                  size_t pyr_frame_stride, int32_t *__restrict__ zero_word) {
+                                                  size_t pyr_frame_stride, int32_t *__restrict__ zero_word, uint32_t cpr_rcp) {
     if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0;  // k_fast_wave's overflow counter of this batch
-    const LevelInfo L = lv[0];
     const int cpr = L.pitch >> 4;  // 16-byte chunks per padded row (the pitch is a multiple of 64)
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
-    const int py = idx / cpr, ci = idx - py * cpr;
+    const int py = (int)__umulhi((uint32_t)idx, cpr_rcp), ci = idx - py * cpr;   // idx / cpr, cpr_rcp = ceil(2^32 / cpr)
     if (py >= L.h + 2 * kEdge) return;
     const uint8_t *src = img + (size_t)f * frame_stride;
     const int sy = reflect101(py - kEdge, L.h);
@@ -118,17 +117,18 @@ __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(
 
 constexpr int kResizeRows = 2;  // output rows per thread (measured: 1 -> 0.032, 2 -> 0.024, 4 -> 0.033 ms per level launch)
 
-__global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo *__restrict__ lv, int level,
+__global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo L, const LevelInfo P,   // levels l and l-1 travel as kernel arguments: no table round trip
+
                                                     const ResizeTap *__restrict__ xtab,
                                                     const ResizeTap *__restrict__ ytab,
                                                     const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr,
-                                                    size_t pyr_frame_stride) {
-    const LevelInfo L = lv[level];
-    const LevelInfo P = lv[level - 1];
+                                                    size_t pyr_frame_stride, uint32_t wpr_rcp) {
     const int wpr = L.pitch >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
-    const int pg = idx / wpr, wi = idx - pg * wpr;
+    // idx / wpr as one multiply-high by ceil(2^32 / wpr) (exact while idx * wpr < 2^32); the generic division is ~30 instructions,
+    // four of them quarter-rate -- a fifth of this kernel's VALU issue
+    const int pg = (int)__umulhi((uint32_t)idx, wpr_rcp), wi = idx - (int)__umul24((uint32_t)pg, (uint32_t)wpr);
     const int rows = L.h + 2 * kEdge;
     const int py0 = pg * kResizeRows;
     if (py0 >= rows) return;
@@ -709,11 +709,11 @@ __device__ __forceinline__ void fast_ini_body(const FastTile T, const int f, con
     if (dbg_stop == 1) { if (lane == 0) *cnt_out = (int)pix[lane] > 255 ? 1 : 0; return; }   // ORBX_FAST_STOP: phase timing by truncation (diagnostic, wrong results)
 
     constexpr int D = P / 4;
-    const int G = (iw + 3) >> 2, RPI = 64 / G;
+    const int G = (iw + 3) >> 2, RPI = (int)T.rows_per_iter;   // 64 / G, from the tile table: even a wave-uniform division runs on the VALU
     const uint32_t ut = (uint32_t)iniTh;
     int gn = 0;
     {   // stage A: groups whose vertical AND horizontal antipodal pairs cannot both be rejected by the SAD bound
-        const uint32_t rcpG = ((1u << 20) + (uint32_t)G - 1u) / (uint32_t)G;
+        const uint32_t rcpG = T.rcp_groups;   // ceil(2^20 / G)
         const int lrow = (int)(((uint32_t)lane * rcpG) >> 20), lg = lane - lrow * G;
         const uint8_t *Abase = pix + lrow * P + 4 * lg + 4;
         const uint32_t ebase = ((uint32_t)lrow << 8) | (uint32_t)(4 * lg);
@@ -1102,6 +1102,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 //   brief : lane i evaluates pattern pairs i, i+64, i+128, i+192; 4 ballots = 4 x u64 = the 32-byte descriptor
 // grid (ceil(cap/4), B), block 256
 // ---------------------------------------------------------------------------------------------------------
+// a pointer the program knows to be wave-uniform, made provably so for the compiler (buffer descriptors must live in SGPRs)
+__device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (const uint8_t *)(((uint64_t)hi << 32) | lo);
+}
+
 struct DescConst {
     int8_t vmax_of_u[16];              // orientation disc: largest |v| with umax[|v|] >= |u|
     int8_t pat[1024];                  // bit_pattern_31_ (x0,y0,x1,y1) x 256
@@ -1120,12 +1127,16 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
     __shared__ __attribute__((aligned(16))) uint8_t patches[4 * kDescWaveLds];
     int bx, f;
     if (!xcd_frame_map(n_frames, &bx, &f)) return;   // a frame's keypoints stay on one XCD (overlapping patches hit its L2)
-    const int g = bx * 4 + (threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the wave's keypoint is wave-uniform: scalar loads below
+    const int g = bx * 4 + wv;
     const int lane = threadIdx.x & 63;
-    if (g >= count[f]) return;  // wave-uniform; no block-level barrier below
-    uint8_t *A = patches + (threadIdx.x >> 6) * kDescWaveLds;
+    // the work item is fetched together with the frame's count, not after the test on it (one memory round trip less per wave)
+    const int cnt = count[f];
+    WorkItem w = work[(size_t)f * cap + min(g, cap - 1)];
+    asm volatile("" ::"s"(w.key), "s"(cnt));   // both loads in flight before the branch (the compiler would sink the second below it)
+    if (g >= cnt) return;  // wave-uniform; no block-level barrier below
+    uint8_t *A = patches + wv * kDescWaveLds;
     uint8_t *Bp = A + kDescAP * kDescAR;
-    WorkItem w = work[(size_t)f * cap + g];
     // the keypoint is the same for the whole wave: keep it (and every address derived from it) in scalar registers
     w.key = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.key);
     w.level = __builtin_amdgcn_readfirstlane(w.level);
@@ -1147,30 +1158,29 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
         const uint8_t *srcA = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + ky - kHalfPatch) * L.pitch + kRoiX +
                               (kx - kHalfPatch - axA);
         const uint8_t *srcB = blur + (size_t)f * blur_frame_stride + L.boff + (size_t)(ky - 18) * L.bpitch + (kx - 18 - axB);
-        uint32_t va[5], vb[6];
+        // 16 lanes per row, 4 rows per step, through one buffer descriptor per patch: rows past the patch are out of range for the
+        // hardware (no access, no predicate), the per-step address is one v_add, the LDS stores use immediate offsets -- the index
+        // arithmetic of a packed (idx / 9, idx % 9) mapping cost more VALU issue than the orientation sum
+        const int c = lane & 15, r0 = lane >> 4;
+        const auto srdA = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(srcA), 0, (kDescAR - 1) * L.pitch + 36, 0x00020000);
+        const auto srdB = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(srcB), 0, (kDescBR - 1) * L.bpitch + 40, 0x00020000);
+        const int offA = (c < 9 ? 0 : 0x40000000) + r0 * L.pitch + 4 * c;     // lanes beyond the patch width: out of range as well
+        const int offB = (c < 10 ? 0 : 0x40000000) + r0 * L.bpitch + 4 * c;
+        uint32_t va[8], vb[10];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int idx = lane + 64 * k;
-            const int r = (int)(__umul24((uint32_t)idx, 7282u) >> 16), c = idx - r * 9;  // idx / 9 for idx < 3640, full-rate multiply
-            va[k] = (idx < kDescAR * 9) ? *reinterpret_cast<const uint32_t *>(srcA + (uint32_t)(__umul24((uint32_t)r, (uint32_t)L.pitch) + 4 * c)) : 0u;
+        for (int k = 0; k < 8; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(srdA, offA + 4 * k * L.pitch, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 10; k++) vb[k] = __builtin_amdgcn_raw_buffer_load_b32(srdB, offB + 4 * k * L.bpitch, 0, 0);
+        if (c < 9) {   // row 31 (k = 7, r0 = 3) lands in the first row of the BRIEF patch, which is written afterwards
+            uint8_t *d = A + r0 * kDescAP + 4 * c;
+#pragma unroll
+            for (int k = 0; k < 8; k++) *reinterpret_cast<uint32_t *>(d + 4 * k * kDescAP) = va[k];
         }
+        if (c < 10) {
+            uint8_t *d = Bp + r0 * kDescBP + 4 * c;
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int idx = lane + 64 * k;
-            const int r = (int)(__umul24((uint32_t)idx, 6554u) >> 16), c = idx - r * 10;  // idx / 10 for idx < 1638
-            vb[k] = (idx < kDescBR * 10) ? *reinterpret_cast<const uint32_t *>(srcB + (uint32_t)(__umul24((uint32_t)r, (uint32_t)L.bpitch) + 4 * c)) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int idx = lane + 64 * k;
-            const int r = (int)(__umul24((uint32_t)idx, 7282u) >> 16), c = idx - r * 9;  // idx / 9 for idx < 3640, full-rate multiply
-            if (idx < kDescAR * 9) *reinterpret_cast<uint32_t *>(A + r * kDescAP + 4 * c) = va[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int idx = lane + 64 * k;
-            const int r = (int)(__umul24((uint32_t)idx, 6554u) >> 16), c = idx - r * 10;  // idx / 10 for idx < 1638
-            if (idx < kDescBR * 10) *reinterpret_cast<uint32_t *>(Bp + r * kDescBP + 4 * c) = vb[k];
+            for (int k = 0; k < 9; k++) *reinterpret_cast<uint32_t *>(d + 4 * k * kDescBP) = vb[k];
+            if (r0 == 0) *reinterpret_cast<uint32_t *>(d + 36 * kDescBP) = vb[9];   // row 36, the last one
         }
     }
     __builtin_amdgcn_wave_barrier();

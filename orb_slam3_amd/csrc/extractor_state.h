@@ -147,6 +147,9 @@ struct orbx_extractor {
     bool in_used[2] = {false, false};
     unsigned in_issued = 0;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
+    hipEvent_t ev_level[orbx::kMaxLevels] = {};   // level l of the pyramid written (k_blur follows the resize chain level by level)
+    int blur_tile_start[orbx::kMaxLevels + 1] = {};  // blur tiles of level l: [start[l], start[l + 1])
+    int blur_groups = 1;       // ORBX_BLUR_GROUPS (measured slower than one launch): levels 0 .. groups-2 get a k_blur launch of their own, the rest share the last one (1 = one launch after the pyramid)
     bool match_pending = false;
     bool blur_side = true;     // ORBX_BLUR_SIDE=0: k_blur stays on the main stream (after the pyramid)
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream

@@ -203,11 +203,15 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
                 T.ox = (int16_t)(3 + j * L.wCell); T.oy = (int16_t)(3 + i * L.hCell);
                 T.cell = (uint32_t)(L.cell_base + i * L.nCols + j);
                 T.slot = L.cand_off + (uint32_t)(i * L.nCols + j) * (uint32_t)L.cell_cap;
+                const uint32_t G = (uint32_t)std::max((cols - 6 + 3) >> 2, 1);
+                T.rcp_groups = ((1u << 20) + G - 1u) / G; T.rows_per_iter = 64u / G;
                 ftiles.push_back(T);
             }
+        ex->blur_tile_start[l] = (int)blur_tiles.size();
         for (int i = 0; i < (L.h + kBlurTH - 1) / kBlurTH; i++)
             for (int j = 0; j < (L.w + kBlurTW - 1) / kBlurTW; j++)
                 blur_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
+        ex->blur_tile_start[l + 1] = (int)blur_tiles.size();
         const int cols = L.wCell + 6, rows = L.hCell + 6;
         const size_t pp = (size_t)((cols + 3 + 3) & ~3);
         const size_t lds = 32 + ((rows * pp + 15) & ~(size_t)15) + ((((size_t)(L.hCell + 2) * (L.wCell + 2)) + 15) & ~(size_t)15) +
@@ -317,33 +321,55 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         ProfScope ps(ex, K_PYR_BASE);
         const LevelInfo &L = ex->lv[0];
         dim3 grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n);
-        hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, d_lv, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
-                           (int32_t *)ex->d_fast_ovf.p);
+        hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, L, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
+                           (int32_t *)ex->d_fast_ovf.p,
+                           (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)));
     }
     if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, st));  // k_pyr_base is the only reader of the input frames
+    // k_blur follows the resize chain on the aux stream, level group by level group: the chain is latency bound (three dependent memory
+    // round trips per wave, VALU mostly idle) and the blur VALU bound, so they share the machine well -- and FAST then runs without the
+    // blur beside it (both VALU bound: side by side they took as long as one after the other)
+    const bool blur_follow = !ex->profile && ex->side_streams && ex->blur_side && ex->blur_groups > 1;
+    const int n_groups = std::min(ex->blur_groups, nl);
+    static const int kBlurNew[4] = {18, 34, 48, 56}, kBlurOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
+    const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
+    auto blur_levels = [&](hipStream_t bs, int l0, int l1) {   // k_blur over the tiles of levels [l0, l1)
+        const int t0 = ex->blur_tile_start[l0], t1 = ex->blur_tile_start[l1];
+        if (t1 > t0)
+            hipLaunchKernelGGL(k_blur, dim3(t1 - t0, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p + t0, (const uint8_t *)pyr,
+                               ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, bg[0], bg[1], bg[2], bg[3]);
+    };
+    auto blur_after_level = [&](int l) -> int {   // level l has just been enqueued on st
+        if (!blur_follow) return ORBX_OK;
+        const bool last_group = l >= n_groups - 1;
+        if (last_group && l != nl - 1) return ORBX_OK;   // the last group waits for the top of the pyramid
+        ORBX_HIP(hipEventRecord(ex->ev_level[l], st));
+        ORBX_HIP(hipStreamWaitEvent(ex->aux_stream, ex->ev_level[l], 0));
+        if (last_group) { blur_levels(ex->aux_stream, n_groups - 1, nl); ORBX_HIP(hipEventRecord(ex->ev_blur, ex->aux_stream)); }
+        else blur_levels(ex->aux_stream, l, l + 1);
+        return ORBX_OK;
+    };
+    { int r = blur_after_level(0); if (r != ORBX_OK) return r; }
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
         dim3 grid(((L.pitch / 4) * ((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255) / 256, n);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, d_lv, l, (const ResizeTap *)ex->d_xtab.p,
-                           (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,
+                           (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,
+                           (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 4) - 1) / (uint64_t)(L.pitch / 4)));
+        { int r = blur_after_level(l); if (r != ORBX_OK) return r; }
     }
-    auto launch_blur = [&]() -> int {
-    {
-            // blur depends only on the pyramid and is needed only by k_describe: run it beside FAST / quad-tree
-            const bool side = !ex->profile && ex->side_streams && ex->blur_side;
-            hipStream_t bs = side ? ex->aux_stream : st;
-            if (side) {
-                ORBX_HIP(hipEventRecord(ex->ev_pyr, st));
-                ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
-            }
-            ProfScope ps(ex, K_BLUR);
-            static const int kNew[4] = {18, 34, 48, 56}, kOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
-            const int *g = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kOld : kNew;
-            hipLaunchKernelGGL(k_blur, dim3(ex->n_blur_tiles, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p,
-                               (const uint8_t *)pyr, ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, g[0], g[1], g[2], g[3]);
-            if (side) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
+    auto launch_blur = [&]() -> int {   // one launch over all levels: profile mode, ORBX_BLUR_SIDE=0, ORBX_BLUR_GROUPS=1, ORBX_SIDE_STREAMS=0
+        if (blur_follow) return ORBX_OK;
+        const bool side = !ex->profile && ex->side_streams && ex->blur_side;
+        hipStream_t bs = side ? ex->aux_stream : st;
+        if (side) {
+            ORBX_HIP(hipEventRecord(ex->ev_pyr, st));
+            ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
         }
+        ProfScope ps(ex, K_BLUR);
+        blur_levels(bs, 0, nl);
+        if (side) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
         return ORBX_OK;
     };
     static const bool blur_after_fast = [] { const char *v = getenv("ORBX_BLUR_AFTER_FAST"); return v && v[0] == '1'; }();
@@ -565,6 +591,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipStreamCreateWithPriority(&ex->copy_stream, hipStreamNonBlocking, prio_lo);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
     { const char *v = getenv("ORBX_BLUR_SIDE"); ex->blur_side = !(v && v[0] == '0'); }
+    { const char *v = getenv("ORBX_BLUR_GROUPS"); if (v && atoi(v) >= 1) ex->blur_groups = atoi(v); }
     { const char *v = getenv("ORBX_FAST_INI_QCAP"); if (v && atoi(v) >= 16) ex->fast_ini_qcap = atoi(v) & ~15; }  // test hook: force the list pass
     { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 64) ex->fast_wave_qcap = atoi(v) & ~15; }  // test hook: force k_fast_overflow
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, use_prio == 2 ? prio_lo : prio_hi);
@@ -572,6 +599,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipStreamCreateWithPriority(&ex->in_stream, hipStreamNonBlocking, prio_hi);
     for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    for (hipEvent_t &ev : ex->ev_level) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[0], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[1], hipEventDisableTiming);
@@ -612,6 +640,7 @@ void orbx_destroy(orbx_extractor *ex) {
     for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
     ex->d_in[0].release(); ex->d_in[1].release();
     for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ex->ev_level) if (ev) (void)hipEventDestroy(ev);
     if (ex->ev_compute_done) (void)hipEventDestroy(ex->ev_compute_done);
     for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
     if (ex->h_err) (void)hipHostFree(ex->h_err);

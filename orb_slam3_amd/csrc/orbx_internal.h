@@ -78,7 +78,8 @@ struct FastTile {  // everything k_fast_ini needs of its cell, precomputed per g
     int16_t ox, oy;     // level coordinates of interior pixel (0, 0): 3 + tj * wCell, 3 + ti * hCell
     uint32_t cell;      // index of the cell inside a frame's cell-count array
     uint32_t slot;      // entry offset of the cell's slot inside a frame's candidate slab
-    uint32_t pad[2];
+    uint32_t rcp_groups;  // ceil(2^20 / G), G = dword groups per interior row = (cols - 6 + 3) / 4: lane -> (row, group) without a division
+    uint32_t rows_per_iter;  // 64 / G
 };
 static_assert(sizeof(FastTile) == 32, "FastTile layout");
 
