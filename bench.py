@@ -98,7 +98,7 @@ def roofline_from_profile(ex, prof, passes, sizes, n_frames, n_feat, n_cand, lau
 
 
 # ---------------------------------------------------------------------------------------------------------
-# PMC traffic of the dominant kernel, measured IN THIS RUN (opt-in, --pmc): two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE:
+# PMC traffic of the dominant kernel, measured IN THIS RUN (default at --gpus 1; --no-pmc skips it): two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE:
 # they do not fit one pass) over a short serialized child run of this same file, parsed from rocprofv3's database
 # ---------------------------------------------------------------------------------------------------------
 # a profile slot may cover more than one kernel: the FAST stage = first pass for every cell + the list pass over the cells it left
@@ -129,7 +129,11 @@ def pmc_traffic(kernel, workload, batch):
         td = tempfile.mkdtemp(prefix="orbx_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", *counters, "-d", td, "-o", "p", "--", sys.executable, str(ROOT / "bench.py"), "--pmc-child", "--workload", workload,
                "--batch", str(batch), "--steps", "2", "--warmup", "1"]
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=240)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(td, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {' '.join(counters)} timed out"
         dbs = list(Path(td).rglob("*.db"))
         if r.returncode != 0 or not dbs:
             shutil.rmtree(td, ignore_errors=True)
@@ -475,7 +479,7 @@ def bench_euroc(R):
         n_cand = int(sum(len(ex.debug_candidates(l, f)) for f in samp for l in range(NLEVELS)) * B / len(samp))
         sizes = [ex.level_size(l, (W, H)) for l in range(NLEVELS)]
         roofline, kernels = roofline_from_profile(ex, prof, passes, sizes, B, n_feat, n_cand)
-        if a.pmc:
+        if a.pmc and R.world == 1:
             tr, err = pmc_traffic(roofline["kernel"], "euroc", B)
             if tr:
                 roofline["traffic"] = int(tr["read"] + tr["write"])
@@ -834,7 +838,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=384, help="frames in the CPU baseline sample (0 = skip); 384 = about 13 s of one core for euroc")
     ap.add_argument("--verify", type=int, default=4, help="frame pairs of the last timed step checked against the CPU oracle on rank 0 (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run: two extra rocprofv3 --pmc child passes (about 1 minute)")
+    ap.add_argument("--pmc", dest="pmc", action="store_true", default=True,
+                    help="measure roofline.traffic in this run: two extra rocprofv3 --pmc child passes of a few steps, about 40 s (default at --gpus 1)")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--retries", type=int, default=1, help="launcher: re-run the whole job this many times if a rank process dies (reported in the JSON)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="euroc",
                     help="euroc = BASELINE metric config; kitti = config 3 (stereo); tumvi = config 4 (map-point projection search)")

@@ -316,9 +316,11 @@ def test_alternative_kernel_paths(tmp_path):
     # ORBX_FAST_QCAP=96: most cells overflow k_fast_wave's queue; ORBX_OCTREE=seq: the sequential quad-tree emulation (k_octree);
     # ORBX_SIDE_STREAMS=0: every kernel on one stream
     # ORBX_FAST_INI=0: the round-1 single-pass FAST (k_fast_wave) instead of k_fast_ini + list pass; ORBX_FAST_INI_QCAP=48: most cells
-    # overflow k_fast_ini's pixel queue and take the list pass
+    # overflow k_fast_ini's pixel queue and take the list pass; ORBX_FAST_INI_WAVES: cells (waves) per k_fast_ini workgroup;
+    # ORBX_BLUR_GROUPS=3: k_blur follows the resize chain level by level on the aux stream
     for extra in ({"ORBX_FAST_TPB": "256"}, {"ORBX_FAST_TPB": "64"}, {"ORBX_FAST_INI": "0"}, {"ORBX_FAST_INI": "0", "ORBX_FAST_QCAP": "96"},
-                  {"ORBX_FAST_INI_QCAP": "48"}, {"ORBX_OCTREE": "seq"}, {"ORBX_SIDE_STREAMS": "0"}):
+                  {"ORBX_FAST_INI_QCAP": "48"}, {"ORBX_FAST_INI_WAVES": "1"}, {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_BLUR_GROUPS": "3"},
+                  {"ORBX_OCTREE": "seq"}, {"ORBX_SIDE_STREAMS": "0"}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]

@@ -22,6 +22,6 @@ python tools/pmc_summary.py $(biggest_db $O/pf) $(biggest_db $O/pw) $TAG
 ORBX_SIDE_STREAMS=0 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $O/sq -o sq -- $CHILD --steps 3 --warmup 1 > /dev/null 2>&1
 python tools/pmc_sq.py $TAG $(biggest_db $O/sq)
 # the bench line, with roofline.traffic measured by its own rocprofv3 --pmc child passes
-timeout 900 python bench.py --pmc 2> $O/bench.err | tail -1 > profiles/${TAG}_bench_euroc.json
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench.err | tail -1 > profiles/${TAG}_bench_euroc.json
 cut -c1-600 profiles/${TAG}_bench_euroc.json
 cp -r profiles $O/profiles_copy
