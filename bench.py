@@ -341,6 +341,23 @@ class Rank:
         if not self.dry:
             self.torch.cuda.synchronize()
 
+    # The timed region runs with Python's cyclic garbage collector off (and the heap collected just before): a generation-2 collection
+    # of a process that has imported torch takes 40-80 ms -- several times a whole 20-step timed region -- and landed inside it in
+    # about one run in twenty (seen as a single 82 ms stall: 5.5 instead of 1.35 ms per step).  Host-harness noise, not the path's.
+    def timed_begin(self, extractors=()):
+        import gc
+        gc.collect()
+        gc.disable()
+        self.barrier(extractors)
+        return time.perf_counter()
+
+    def timed_end(self, t0, extractors=()):
+        import gc
+        self.barrier(extractors)
+        dt = time.perf_counter() - t0
+        gc.enable()
+        return dt
+
     def reduce(self, dt, units):
         from orb_slam3_amd import sharding
         return sharding.reduce_throughput(dt, units, device=None if self.dry else "cuda")
@@ -372,12 +389,10 @@ def bench_dry(R):
             if fail != "always":
                 open(fail, "w").close()
             os._exit(134)
-    R.barrier()
-    t0 = time.perf_counter()
+    t0 = R.timed_begin()
     units = 1000.0 * a.steps * (R.rank + 1)
     time.sleep(0.01)
-    R.barrier()
-    dt_max, units_all = R.reduce(time.perf_counter() - t0, units)
+    dt_max, units_all = R.reduce(R.timed_end(t0), units)
     out = base_line(R, "dry run (ORBX_BENCH_DRY): launcher + sharding only", units_all / dt_max / 1e3, dt_max,
                     {"workload": "none", "sequences": R.world})
     out["roofline"] = None
@@ -432,21 +447,25 @@ def bench_euroc(R):
         feats = 0
         for i in range(nsteps + 1):
             if i < nsteps:
+                t = time.perf_counter()
                 enqueue(i, from_host)
+                host_enqueue[0] += time.perf_counter() - t
             if i >= 1:
                 ex.download_wait()
                 feats += int(host[(i - 1) % 2].cnt.sum())
         return feats
 
+    host_enqueue = [0.0]   # seconds the host thread spent issuing work (HIP API calls through the C ABI), per timed region
+
     def timed(from_host):
         run(max(a.warmup, 1), from_host)
-        R.barrier([ex])
-        t0 = time.perf_counter()
+        t0 = R.timed_begin([ex])
+        host_enqueue[0] = 0.0
         feats = run(a.steps, from_host)
-        R.barrier([ex])
-        return time.perf_counter() - t0, feats
+        return R.timed_end(t0, [ex]), feats
 
     dt, feats = timed(False)
+    enqueue_ms = host_enqueue[0] / a.steps * 1e3
     last = host[(a.steps - 1) % 2]
     nmatch = int(last.nm[1:].sum())
     dt_max, feats_all = R.reduce(dt, feats)
@@ -500,7 +519,8 @@ def bench_euroc(R):
                      "frames_per_step_per_gpu": B, "sequences": R.world, "features_per_frame": round(feats / a.steps / B, 1),
                      "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{R.world} independent sequences, one per GPU"})
     out["data"] = data
-    out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels})
+    out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels,
+                "host_enqueue_ms_per_step": round(enqueue_ms, 3)})
     R.finish(out)
 
 
@@ -578,13 +598,11 @@ def bench_kitti(R):
 
     for _ in range(max(a.warmup, 1)):
         step()
-    R.barrier([exl, exr])
-    t0 = time.perf_counter()
+    t0 = R.timed_begin([exl, exr])
     feats = 0
     for _ in range(a.steps):
         feats += step()
-    R.barrier([exl, exr])
-    dt = time.perf_counter() - t0
+    dt = R.timed_end(t0, [exl, exr])
     dt_max, feats_all = R.reduce(dt, feats)
 
     parity = None
@@ -702,18 +720,20 @@ def bench_tumvi(R):
         feats = 0
         for i in range(nsteps + 1):
             if i < nsteps:
+                t = time.perf_counter()
                 enqueue(i)
+                host_enqueue[0] += time.perf_counter() - t
             if i >= 1:
                 ex.download_wait()
                 feats += int(hs[(i - 1) % 2]["cnt"].sum())
         return feats
 
+    host_enqueue = [0.0]
     run(max(a.warmup, 1))
-    R.barrier([ex])
-    t0 = time.perf_counter()
+    t0 = R.timed_begin([ex])
+    host_enqueue[0] = 0.0
     feats = run(a.steps)
-    R.barrier([ex])
-    dt = time.perf_counter() - t0
+    dt = R.timed_end(t0, [ex])
     dt_max, feats_all = R.reduce(dt, feats)
     last = hs[(a.steps - 1) % 2]
 
@@ -759,7 +779,8 @@ def bench_tumvi(R):
                      "frames_per_step_per_gpu": B, "sequences": R.world, "features_per_frame": round(feats / a.steps / B, 1),
                      "map_point_matches_per_frame": round(float(last["nm"].sum()) / B, 1)})
     out["data"] = data
-    out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels})
+    out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels,
+                "host_enqueue_ms_per_step": round(host_enqueue[0] / a.steps * 1e3, 3)})
     R.finish(out)
 
 
