@@ -24,12 +24,17 @@ namespace orbx {
 // ceil(frames / 8)): x is the fastest dimension of the linear id, so blockIdx.x IS the XCD, and frame = 8 * blockIdx.z + blockIdx.x
 // keeps ALL workgroups of a frame on one XCD (frames f = 8k + x belong to XCD x).  Measured on the FAST stage: 1.25 GB -> 0.33 GB
 // of HBM reads per launch (request-size counters), the aprons and partial lines now hit the XCD's L2.
+// Batches of fewer than 8 frames (single-frame calls) use a grid (1, blocks per frame, frames) instead: a frame's workgroups then spread
+// over all XCDs -- one frame alone would otherwise run on an eighth of the machine.  The kernels read the multiplier from gridDim.x.
 __device__ __forceinline__ bool xcd_frame_map(int n_frames, int *bx, int *f) {
-    *f = (int)(blockIdx.z * 8u + blockIdx.x);
+    *f = (int)(blockIdx.z * gridDim.x + blockIdx.x);
     *bx = (int)blockIdx.y;
     return *f < n_frames;
 }
-inline dim3 xcd_grid(int blocks_per_frame, int n_frames) { return dim3(8, (unsigned)blocks_per_frame, (unsigned)((n_frames + 7) / 8)); }
+inline dim3 xcd_grid(int blocks_per_frame, int n_frames, bool local = true) {
+    if (n_frames < 8 || !local) return dim3(1, (unsigned)blocks_per_frame, (unsigned)n_frames);
+    return dim3(8, (unsigned)blocks_per_frame, (unsigned)((n_frames + 7) / 8));
+}
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     // [OCV] borderInterpolate(BORDER_REFLECT_101); |p| excursions here are < len
@@ -42,15 +47,16 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // Level 0: copy the input image into the padded level-0 slab, ring = REFLECT_101 of the image.
 // One thread writes 16 consecutive bytes of a padded row (aligned 16-byte store); threads are mapped flat over
 // (row, chunk) so every lane is busy.
-// grid (ceil(words_per_frame/256), B)
+// grid xcd_grid(ceil(words_per_frame/256), B)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo L, const uint8_t *__restrict__ img,
                                                   size_t row_stride, size_t frame_stride, uint8_t *__restrict__ pyr,
-                                                  size_t pyr_frame_stride, int32_t *__restrict__ zero_word, uint32_t cpr_rcp) {
-    if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0;  // k_fast_wave's overflow counter of this batch
+                                                  size_t pyr_frame_stride, int32_t *__restrict__ zero_word, uint32_t cpr_rcp, int n_frames) {
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;   // a frame's rows stay on one XCD: lines shared by neighbouring workgroups hit its L2
+    if (zero_word && bx == 0 && f == 0 && threadIdx.x == 0) *zero_word = 0;  // k_fast_wave's overflow counter of this batch
     const int cpr = L.pitch >> 4;  // 16-byte chunks per padded row (the pitch is a multiple of 64)
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.y;
+    const int idx = bx * 256 + threadIdx.x;
     const int py = (int)__umulhi((uint32_t)idx, cpr_rcp), ci = idx - py * cpr;   // idx / cpr, cpr_rcp = ceil(2^32 / cpr)
     if (py >= L.h + 2 * kEdge) return;
     const uint8_t *src = img + (size_t)f * frame_stride;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo L, const uint8
 // the REFLECT_101-mapped coordinate, so ROI and ring are written in one pass.  One thread = 4 consecutive bytes of
 // a padded row (aligned dword store), threads mapped flat over (row, dword).  (An LDS-staged tile variant was
 // measured 1.6x slower: the footprint set-up adds a third dependent memory round trip per small workgroup.)
-// grid (ceil(words_per_frame/256), B)
+// grid xcd_grid(ceil(words_per_frame/256), B)
 // ---------------------------------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -117,15 +123,20 @@ __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(
 
 constexpr int kResizeRows = 2;  // output rows per thread (measured: 1 -> 0.032, 2 -> 0.024, 4 -> 0.033 ms per level launch)
 
+// PK (round 2): the vertical pass without the two arithmetic shifts and the clamp per pixel.  With Q11 taps b0 + b1 = 2048 and
+// horizontal sums h <= 255 * 2048, both products b * (h >> 4) are non-negative and below 2^27, so "(p0 >> 16) + (p1 >> 16) + 2" is
+// ONE v_add_u32_sdwa of the two high words once the rounding constant rides in p0 (p0 = b0 * (h0 >> 4) + (2 << 16), a v_mad_u32_u24),
+// the result is at most 1022 (no clamp to 255 after the >> 2), and two pixels shift + pack in one v_ashr_pk_u8_i32 (gfx950).
+template <bool PK>
 __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo L, const LevelInfo P,   // levels l and l-1 travel as kernel arguments: no table round trip
-
                                                     const ResizeTap *__restrict__ xtab,
                                                     const ResizeTap *__restrict__ ytab,
                                                     const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr,
-                                                    size_t pyr_frame_stride, uint32_t wpr_rcp) {
+                                                    size_t pyr_frame_stride, uint32_t wpr_rcp, int n_frames) {
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;   // source rows shared by neighbouring workgroups hit the frame's XCD L2
     const int wpr = L.pitch >> 2;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.y;
+    const int idx = bx * 256 + threadIdx.x;
     // idx / wpr as one multiply-high by ceil(2^32 / wpr) (exact while idx * wpr < 2^32); the generic division is ~30 instructions,
     // four of them quarter-rate -- a fifth of this kernel's VALU issue
     const int pg = (int)__umulhi((uint32_t)idx, wpr_rcp), wi = idx - (int)__umul24((uint32_t)pg, (uint32_t)wpr);
@@ -164,14 +175,30 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo L, const Lev
             const uint32_t l1 = __builtin_amdgcn_perm(r1[r].y, r1[r].x, gh.y), q1 = __builtin_amdgcn_perm(r1[r].y, r1[r].x, selr);
             const int b0 = ty[r].c0, b1 = ty[r].c1;
             uint32_t out = 0;
+            if (PK) {   // the tables hold bilinear tap pairs: 0 <= b0, b1 <= 2048
+                int t[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // horizontal pass: S[sx] * alpha0 + S[sx+1] * alpha1 as one v_dot2_u32_u16 (cc[k] = alpha0 | alpha1 << 16)
-                const int h0 = (int)__builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
-                const int h1 = (int)__builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
-                int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
-                v = min(max(v, 0), 255);
-                out |= (uint32_t)v << (8 * k);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t h0 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
+                    const uint32_t h1 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
+                    const uint32_t p0 = __umul24(h0 >> 4, (uint32_t)b0) + 0x20000u, p1 = __umul24(h1 >> 4, (uint32_t)b1);
+                    t[k] = (int)((p0 >> 16) + (p1 >> 16));   // the SDWA peephole folds both shifts into the add's operand selects
+                }
+                // (t >> 2) saturated to a byte, two pixels per instruction (the saturation never acts: t <= 1022)
+                // v_ashr_pk_u8_i32: byte 0 = sat_u8(src0 >> 2), byte 1 = sat_u8(src1 >> 2)
+                const uint32_t lo = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 2);
+                const uint32_t hi = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 2);
+                out = lo | (hi << 16);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // horizontal pass: S[sx] * alpha0 + S[sx+1] * alpha1 as one v_dot2_u32_u16 (cc[k] = alpha0 | alpha1 << 16)
+                    const int h0 = (int)__builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
+                    const int h1 = (int)__builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
+                    int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+                    v = min(max(v, 0), 255);
+                    out |= (uint32_t)v << (8 * k);
+                }
             }
             if (py0 + r < rows) *reinterpret_cast<uint32_t *>(drow + (uint32_t)(r * L.pitch)) = out;
         }
@@ -1019,6 +1046,121 @@ __global__ __launch_bounds__(256) void k_blur(const LevelInfo *__restrict__ lv, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_blur_pk: the same filter with half the VALU work per row and L2-local tiles (round 2; k_blur is kept as ORBX_BLUR_KERNEL=0).
+//   * horizontal pass without byte alignment: the window of pixel x0+j is three (j = 1, 2) or two (j = 0, 3) v_dot4_u32_u8 of the
+//     ALIGNED dwords against tap dwords shifted instead of the data (10 instead of 6 v_alignbyte + 8 v_dot4);
+//   * vertical pass on PAIRS of consecutive rows of horizontal sums packed as 2 x u16 (a sum is at most 255 * 257): per output
+//     pixel three v_dot2_u32_u16 + one v_mad_u32_u24 with the rounding constant as the addend, instead of 3 adds + 4 multiplies +
+//     2 three-input adds; one v_lshl_or per pixel and row builds the pair (rows r-1, r), a ring of six pair slots serves
+//     rows r-5, r-3, r-1;
+//   * the result byte is bits 16..23 of the sum: with taps summing to 256 it cannot exceed 255 (SAT = false: no clamp), three
+//     v_perm_b32 / v_or gather the four bytes; taps summing to 257 (the OpenCV <= 4.5.0 table) clamp the sum first (SAT = true);
+//   * wave-uniform row pointers (the wave index through readfirstlane): row addresses are SALU work, loads and stores take the
+//     SGPR-base form; the next source row is requested before the current one is filtered;
+//   * grid (8, tiles, frames / 8): all tiles of a frame run on one XCD, so the 128-byte lines two neighbouring tiles share (tile
+//     rows start 4 bytes before a 256-byte boundary) and the six halo rows hit that XCD's L2.
+// 33 instead of 66 VALU instructions per row of four pixels.  grid xcd_grid(n_blur_tiles, B), block 256
+// ---------------------------------------------------------------------------------------------------------
+struct BlurRaw {
+    uint32_t m, c, p;  // pixels x0-4 .. x0-1, x0 .. x0+3, x0+4 .. x0+7
+};
+
+template <bool SAT>
+__global__ __launch_bounds__(256) void k_blur_pk(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
+                                                 const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                 uint8_t *__restrict__ blur, size_t blur_frame_stride, int g0, int g1,
+                                                 int g2, int g3, int n_frames) {
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;
+    const TileRef t = tiles[bx];
+    const LevelInfo L = lv[t.level];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0w = t.tj * kBlurTW;                 // first pixel of the wave's strip
+    const int y0 = (t.ti * 4 + wv) * kBlurRows;     // first output row of the wave's strip
+    if (y0 >= L.h) return;                          // wave-uniform
+    if (x0w + lane * 4 >= L.w) return;
+    // tap of the pixel at distance d from the window centre; taps of the three aligned dwords for window centre x0 + j
+    auto tapd = [&](int d) -> uint32_t {
+        d = d < 0 ? -d : d;
+        return d == 0 ? (uint32_t)g3 : d == 1 ? (uint32_t)g2 : d == 2 ? (uint32_t)g1 : d == 3 ? (uint32_t)g0 : 0u;
+    };
+    uint32_t ht[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v |= tapd(4 * k + b - (j + 4)) << (8 * b);
+            ht[j][k] = v;
+        }
+    const u16x2 vp0 = as_pk((uint32_t)g0 | ((uint32_t)g1 << 16));   // rows r-6, r-5
+    const u16x2 vp1 = as_pk((uint32_t)g2 | ((uint32_t)g3 << 16));   // rows r-4, r-3
+    const u16x2 vp2 = as_pk((uint32_t)g2 | ((uint32_t)g1 << 16));   // rows r-2, r-1
+    const uint8_t *roi = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)kEdge * L.pitch + kRoiX + x0w;   // wave-uniform
+    uint8_t *dst = blur + (size_t)f * blur_frame_stride + L.boff + x0w;                                         // wave-uniform
+    const uint32_t lofs = (uint32_t)lane * 4u;
+    const int ymax = L.h + kEdge - 1;  // last ring row that exists
+    const uint8_t *roi3 = roi - 3 * (ptrdiff_t)L.pitch;   // level row -3 (a ring row)
+    auto load_row = [&](int r) -> BlurRaw {  // r-th source row of the strip: level row y0 - 3 + r (>= -3: those ring rows exist)
+        const uint32_t y3 = (uint32_t)min(y0 + r, ymax + 3);                                    // row index counted from level row -3
+        const uint8_t *rowp = roi3 + (size_t)(y3 * (uint32_t)L.pitch);                          // wave-uniform: SALU
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(rowp + lofs);
+        BlurRaw v;
+        v.m = p[-1]; v.c = p[0]; v.p = p[1];
+        return v;
+    };
+    auto hsum = [&](const BlurRaw &v, uint32_t h[4]) {
+        h[0] = __builtin_amdgcn_udot4(v.c, ht[0][1], __builtin_amdgcn_udot4(v.m, ht[0][0], 0u, false), false);
+        h[1] = __builtin_amdgcn_udot4(v.p, ht[1][2], __builtin_amdgcn_udot4(v.c, ht[1][1], __builtin_amdgcn_udot4(v.m, ht[1][0], 0u, false), false), false);
+        h[2] = __builtin_amdgcn_udot4(v.p, ht[2][2], __builtin_amdgcn_udot4(v.c, ht[2][1], __builtin_amdgcn_udot4(v.m, ht[2][0], 0u, false), false), false);
+        h[3] = __builtin_amdgcn_udot4(v.p, ht[3][2], __builtin_amdgcn_udot4(v.c, ht[3][1], 0u, false), false);
+    };
+    uint32_t pr[6][4];   // pr[q % 6] = (sums of row q-1) | (sums of row q) << 16
+    uint32_t hprev[4];
+    BlurRaw cur = load_row(0);
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const BlurRaw nxt = load_row(r + 1);
+        uint32_t h[4];
+        hsum(cur, h);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (r > 0) pr[r][j] = hprev[j] | (h[j] << 16);
+            hprev[j] = h[j];
+        }
+        cur = nxt;
+    }
+    for (int gidx = 0; gidx < kBlurRows / 6; gidx++) {
+        const int rbase = 6 + gidx * 6;
+        if (y0 + rbase - 6 >= L.h) break;
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+            const int r = rbase + s, yo = y0 + r - 6;
+            const BlurRaw nxt = load_row(r + 1);   // one row beyond the strip at the very end: clamped to an existing row, unused
+            uint32_t h[4], sum[4];
+            hsum(cur, h);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                pr[s][j] = hprev[j] | (h[j] << 16);
+                hprev[j] = h[j];
+                uint32_t a = __umul24(h[j], (uint32_t)g0) + 32768u;                        // row r
+                a = __builtin_amdgcn_udot2(as_pk(pr[(s + 5) % 6][j]), vp2, a, false);      // rows r-2, r-1
+                a = __builtin_amdgcn_udot2(as_pk(pr[(s + 3) % 6][j]), vp1, a, false);      // rows r-4, r-3
+                a = __builtin_amdgcn_udot2(as_pk(pr[(s + 1) % 6][j]), vp0, a, false);      // rows r-6, r-5
+                sum[j] = SAT ? min(a, 0x00ffffffu) : a;
+            }
+            if (yo < L.h) {
+                const uint32_t lo = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u);    // byte 2 of sum[0], byte 2 of sum[1]
+                const uint32_t hi = __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);
+                *reinterpret_cast<uint32_t *>(dst + (size_t)((uint32_t)yo * (uint32_t)L.bpitch) + lofs) = lo | hi;
+            }
+            cur = nxt;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // glibc 2.35 sinf / cosf ("fma" ifunc variant: every multiply-add of the double polynomial fused), restated
 // for |x| < 120; bit-identical to the x86-64 libm the reference links against (validated exhaustively on the
 // CPU oracle, which uses the same formulation).  Tables: __sincosf_table.
@@ -1151,6 +1293,12 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
     // orientation disc column of this lane (loaded early: its latency hides behind the patch loads)
     const int du = (lane & 31) - kHalfPatch, dhalf = lane >> 5;
     const int dvmax = (lane & 31) <= 2 * kHalfPatch ? dc->vmax_of_u[du < 0 ? -du : du] : -1;
+    // this lane's four BRIEF pattern entries, requested together with the patches: fetched inside the BRIEF loop each of them was a
+    // dependent memory round trip of its own (the compiler hoists a load by one iteration at most), four per wave, in a kernel
+    // whose time is the waves' lifetime
+    uint32_t pat4[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) pat4[it] = reinterpret_cast<const uint32_t *>(dc->pat)[it * 64 + lane];
 
     // ---- stage both patches with aligned dword loads: one memory round trip for the whole keypoint ----
     const int axA = (kx - kHalfPatch) & 3, axB = (kx - 18) & 3;
@@ -1185,6 +1333,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (single-wave producer/consumer)
+    asm volatile("" ::"v"(pat4[0]), "v"(pat4[1]), "v"(pat4[2]), "v"(pat4[3]));   // the pattern loads stay up here
 
     // ---- IC_Angle on the unblurred patch (:76-103): m_10 = sum u*I, m_01 = sum v*I over the disc ----
     const uint8_t *c0 = A + kHalfPatch * kDescAP + kHalfPatch + axA + du;
@@ -1208,12 +1357,16 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     glibc_sincosf(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
-    const uint8_t *cb = Bp + 18 * kDescBP + 18 + axB;
+    // cvRound = round-half-even = adding 1.5 * 2^23 (|value| < 2^22: the sum's ulp is 1, its mantissa holds the rounded integer):
+    // ONE v_add_f32 instead of v_rndne + v_cvt.  The bit pattern is kMagicBits + n; the row product uses its low 24 bits
+    // (2^22 + n) and the constant part of the address goes into the base pointer (32-bit LDS address arithmetic wraps).
+    constexpr float kMagic = 12582912.f;
+    constexpr uint32_t kMagicBits = 0x4B400000u;
+    const uint32_t cbm = (uint32_t)(uintptr_t)(Bp + 18 * kDescBP + 18 + axB) - (0x400000u * (uint32_t)kDescBP + kMagicBits);
     unsigned long long bits[4];
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-        const int p = it * 64 + lane;
-        const char4 pt = reinterpret_cast<const char4 *>(dc->pat)[p];
+        const char4 pt = __builtin_bit_cast(char4, pat4[it]);
         const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
         float r0, q0, r1, q1;
         if (strict_mul_add) {
@@ -1227,8 +1380,10 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
             r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
             q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
         }
-        const int t0 = cb[__mul24(__float2int_rn(r0), kDescBP) + __float2int_rn(q0)];  // |row| <= 18: 24-bit multiply, full rate
-        const int t1 = cb[__mul24(__float2int_rn(r1), kDescBP) + __float2int_rn(q1)];
+        const uint32_t a0 = __umul24(__float_as_uint(__fadd_rn(r0, kMagic)), (uint32_t)kDescBP) + __float_as_uint(__fadd_rn(q0, kMagic)) + cbm;
+        const uint32_t a1 = __umul24(__float_as_uint(__fadd_rn(r1, kMagic)), (uint32_t)kDescBP) + __float_as_uint(__fadd_rn(q1, kMagic)) + cbm;
+        const int t0 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a0);
+        const int t1 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a1);
         bits[it] = __ballot(t0 < t1);
     }
     const size_t slot = (size_t)f * cap + w.pos;

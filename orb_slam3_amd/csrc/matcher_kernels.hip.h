@@ -571,6 +571,53 @@ __device__ __forceinline__ int scan_window(const WindowProblem &P, const GridPar
     return cnt;
 }
 
+// The same scan through the grid k_grid_build left in P.gstart / P.gorder (whole wave, one query): lane c fetches the slice bounds of
+// grid column cx0 + c, a wave prefix sum concatenates the slices, and the lanes walk the concatenated candidate sequence -- four
+// dependent memory round trips (bounds, index, keypoint, descriptor) instead of one per 64 features of the frame (scan_window reads
+// every keypoint of the frame: 16 serial round trips for 1000 features, and the re-scans were most of k_greedy_resolve's time).
+// The candidates are a superset (whole grid cells); in_window() applies GetFeaturesInArea's tests and supplies the cell for the key,
+// so keys -- and with them the tie-break order -- are those of scan_window.
+__device__ __forceinline__ int scan_window_grid(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
+                                                const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
+    const int ncol = w.cx1 - w.cx0 + 1;   // 1..64 (make_window clamps to the grid)
+    int cs = 0, len = 0;
+    if (lane < ncol) {
+        const int base = (w.cx0 + lane) * 48;
+        cs = P.gstart[base + w.cy0];
+        len = (int)P.gstart[base + w.cy1 + 1] - cs;
+    }
+    int incl = len;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int t = __shfl_up(incl, s);
+        if (lane >= s) incl += t;
+    }
+    const int pre = incl - len, total = __shfl(incl, 63);
+    int cnt = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        int j = -1;
+        for (int c = 0; c < ncol; c++) {   // column of the t-th candidate: the last c with pre[c] <= t
+            const int pc = __shfl(pre, c), sc = __shfl(cs, c);
+            if (t >= pc) j = sc + (t - pc);
+        }
+        if (t >= total || j < 0) continue;
+        const int i = P.gorder[j];
+        if (i >= n || (occ && occ[i])) continue;
+        const orbx_keypoint kp = P.kps[i];
+        int cx, cy;
+        if (!in_window(g, w, kp, &cx, &cy)) continue;
+        if (P.u_right && P.u_right[i] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
+            const float er = fabsf(w.xr - P.u_right[i]);
+            if (er > w.r) continue;
+        }
+        const int d = hamming(dq, load_desc(P.desc + (size_t)i * 32));
+        push2(k1, k2, cand_key(d, cx, cy, i));
+        cnt++;
+    }
+    return cnt;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Frame::AssignFeaturesToGrid (Frame.cc:385-416): one wave per frame builds the 64x48 grid as a counting sort of
 // the feature indices by cell id (x * 48 + y).  Inside a cell the indices stay ascending (= insertion order), and
@@ -796,7 +843,7 @@ struct ResolveProblem {
 // sequential loop would have seen.  Dynamic LDS: claim[n_alloc] (u32) + angle[n_alloc] (f32) + occ[n_alloc] (u8);
 // nothing inside the round loop touches global memory except fire-and-forget result stores.
 __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
-                                                       GridParams g, int n_alloc) {
+                                                       GridParams g, int n_alloc, int grid_rescan) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ int hist[ORBX_HISTO_LENGTH + 2];
     uint32_t *claim = reinterpret_cast<uint32_t *>(lds);
@@ -807,11 +854,25 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
     const int lane = threadIdx.x;
     const u64 lt_mask = (1ull << lane) - 1ull;
     const int n = min(*P.n_ptr, n_alloc), nq = *P.nq_ptr;
-    for (int i = lane; i < n; i += 64) {
-        occ[i] = P.occupied0 ? P.occupied0[i] : 0;
-        claim[i] = 0xffffffffu;
-        ang[i] = P.kps[i].angle;
-        R.match[i] = -1;
+    for (int i0 = 0; i0 < n; i0 += 8 * 64) {   // eight loads in flight per lane: two memory round trips for 1000 features, not sixteen
+        float a[8];
+        uint8_t o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + 64 * k + lane;
+            a[k] = i < n ? P.kps[i].angle : 0.f;
+            o[k] = (i < n && P.occupied0) ? P.occupied0[i] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + 64 * k + lane;
+            if (i < n) {
+                occ[i] = o[k];
+                claim[i] = 0xffffffffu;
+                ang[i] = a[k];
+                R.match[i] = -1;
+            }
+        }
     }
     if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
     __syncthreads();
@@ -842,21 +903,29 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         return b;
     };
 
+    // candidate lists of a chunk of 64 queries; the next chunk's are requested before the current chunk is replayed
+    struct Chunk { u64 L0, L1, L2, L3; int meta; float q_ang; };
+    auto fetch = [&](int q0) -> Chunk {
+        Chunk c = {kNoKey, kNoKey, kNoKey, kNoKey, 256, 0.f};   // inactive lane: empty exhaustive list
+        const int qi = q0 + lane;
+        if (qi < nq) {
+            const u64 *kp = P.keys + (size_t)qi * kTopK;
+            c.L0 = kp[0]; c.L1 = kp[1]; c.L2 = kp[2]; c.L3 = kp[3];
+            c.meta = P.meta[qi];
+            if (ori) c.q_ang = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
+        }
+        return c;
+    };
+    Chunk nxt = fetch(0);
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int qi = q0 + lane;
         const bool active = qi < nq;
-        u64 L0 = kNoKey, L1 = kNoKey, L2 = kNoKey, L3 = kNoKey;
-        int valid_len = 0;
-        bool exhaustive = true;
-        float q_ang = 0.f;
-        if (active) {
-            const u64 *kp = P.keys + (size_t)qi * kTopK;
-            L0 = kp[0]; L1 = kp[1]; L2 = kp[2]; L3 = kp[3];
-            const int m = P.meta[qi];
-            valid_len = m & 0xff;
-            exhaustive = (m & 256) != 0;
-            if (ori) q_ang = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
-        }
+        const Chunk C = nxt;
+        nxt = fetch(q0 + 64);
+        const u64 L0 = C.L0, L1 = C.L1, L2 = C.L2, L3 = C.L3;
+        const int valid_len = C.meta & 0xff;
+        const bool exhaustive = (C.meta & 256) != 0;
+        const float q_ang = C.q_ang;
         int pos = 0;
         while (pos < 64) {
             const bool live = active && lane >= pos;
@@ -912,7 +981,8 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                 Desc dq;
                 u64 r1 = kNoKey, r2 = kNoKey;
                 if (load_query(P, qc, &w, g, &dq)) {
-                    scan_window(P, g, w, dq, n, occ, lane, r1, r2);
+                    if (grid_rescan) scan_window_grid(P, g, w, dq, n, occ, lane, r1, r2);
+                    else scan_window(P, g, w, dq, n, occ, lane, r1, r2);
                     wave_min2(r1, r2);
                 }
                 if (accept(r1, r2)) {

@@ -317,13 +317,14 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
     uint8_t *pyr = (uint8_t *)ex->d_pyr.p;
     hipStream_t st = ex->stream;
+    static const bool pyr_local = [] { const char *v = getenv("ORBX_PYR_XCD"); return !(v && v[0] == '0'); }();   // 0 = round-robin workgroups
     {
         ProfScope ps(ex, K_PYR_BASE);
         const LevelInfo &L = ex->lv[0];
-        dim3 grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n);
+        const dim3 grid = xcd_grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n, pyr_local);
         hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, L, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
                            (int32_t *)ex->d_fast_ovf.p,
-                           (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)));
+                           (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)), n);
     }
     if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, st));  // k_pyr_base is the only reader of the input frames
     // k_blur follows the resize chain on the aux stream, level group by level group: the chain is latency bound (three dependent memory
@@ -335,9 +336,18 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
     auto blur_levels = [&](hipStream_t bs, int l0, int l1) {   // k_blur over the tiles of levels [l0, l1)
         const int t0 = ex->blur_tile_start[l0], t1 = ex->blur_tile_start[l1];
-        if (t1 > t0)
+        if (t1 <= t0) return;
+        static const bool packed = [] { const char *v = getenv("ORBX_BLUR_KERNEL"); return !(v && v[0] == '0'); }();   // 0 = round-1 k_blur
+        const bool sat = 2 * (bg[0] + bg[1] + bg[2]) + bg[3] > 256;   // taps summing to more than 1.0 (OpenCV <= 4.5.0) can exceed 255
+#define ORBX_BLUR_PK(SAT)                                                                                                              \
+    hipLaunchKernelGGL(k_blur_pk<SAT>, xcd_grid(t1 - t0, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p + t0,          \
+                       (const uint8_t *)pyr, ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n)
+        if (!packed)
             hipLaunchKernelGGL(k_blur, dim3(t1 - t0, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p + t0, (const uint8_t *)pyr,
                                ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, bg[0], bg[1], bg[2], bg[3]);
+        else if (sat) ORBX_BLUR_PK(true);
+        else ORBX_BLUR_PK(false);
+#undef ORBX_BLUR_PK
     };
     auto blur_after_level = [&](int l) -> int {   // level l has just been enqueued on st
         if (!blur_follow) return ORBX_OK;
@@ -353,10 +363,14 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
-        dim3 grid(((L.pitch / 4) * ((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255) / 256, n);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,
-                           (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,
-                           (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 4) - 1) / (uint64_t)(L.pitch / 4)));
+        const dim3 grid = xcd_grid(((L.pitch / 4) * ((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255) / 256, n, pyr_local);
+        static const bool resize_pk = [] { const char *v = getenv("ORBX_RESIZE_PK"); return !(v && v[0] == '0'); }();   // 0 = round-1 vertical pass
+#define ORBX_RESIZE(PK)                                                                                                         \
+    hipLaunchKernelGGL(k_pyr_resize<PK>, grid, dim3(256), 0, st, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,             \
+                       (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,                 \
+                       (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 4) - 1) / (uint64_t)(L.pitch / 4)), n)
+        if (resize_pk) ORBX_RESIZE(true); else ORBX_RESIZE(false);
+#undef ORBX_RESIZE
         { int r = blur_after_level(l); if (r != ORBX_OK) return r; }
     }
     auto launch_blur = [&]() -> int {   // one launch over all levels: profile mode, ORBX_BLUR_SIDE=0, ORBX_BLUR_GROUPS=1, ORBX_SIDE_STREAMS=0

@@ -21,6 +21,11 @@ namespace {
 
 constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
+// k_greedy_resolve re-scans a query's window through the frame's grid (ORBX_RESOLVE_RESCAN=full: over all features, the round-1 form)
+inline int resolve_grid_rescan() {
+    static const int v = [] { const char *e = getenv("ORBX_RESOLVE_RESCAN"); return (e && e[0] == 'f') ? 0 : 1; }();
+    return v;
+}
 
 struct Arena {  // bump allocator over one device buffer, reset per call
     uint8_t *base = nullptr;
@@ -386,7 +391,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     hipLaunchKernelGGL(k_window_best2, dim3((nq + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n);
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n, resolve_grid_rescan());
     int32_t nm = 0;
     D2H(a.match_out, R.match, 4 * (size_t)n);
     D2H(&nm, R.nmatches, 4);
@@ -986,7 +991,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     if (resolve_lds_bytes(cap) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mprobs.p,
-                       (const ResolveProblem *)ex->d_mres.p, g, cap);
+                       (const ResolveProblem *)ex->d_mres.p, g, cap, resolve_grid_rescan());
     if (ex->profile) {
         (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
         float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
@@ -1095,7 +1100,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
     if (resolve_lds_bytes(cap) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
-                       (const ResolveProblem *)ex->d_mp_res.p, g, cap);
+                       (const ResolveProblem *)ex->d_mp_res.p, g, cap, resolve_grid_rescan());
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
     ex->match_pending = true;
     ORBX_HIP(hipGetLastError());
