@@ -227,6 +227,98 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo L, const Lev
     }
 }
 
+// k_pyr_resize2: the same arithmetic, one thread = TWO adjacent dword columns (8 pixels) x 2 rows.  The resize chain is bound by the
+// waves' lifetime (table loads -> source rows -> store: two dependent memory round trips, 8 waves per SIMD at most), not by issue or
+// bandwidth (2 TB/s), so a wave that keeps twice the bytes in flight for the same two round trips doubles the rate until VALU issue
+// binds; the two columns share their row taps, source rows (adjacent 8-byte loads) and one 8-byte store per row.
+// grid xcd_grid(ceil((pitch / 8) * ceil(rows / 2) / 256), B)
+__global__ __launch_bounds__(256) void k_pyr_resize2(const LevelInfo L, const LevelInfo P, const ResizeTap *__restrict__ xtab,
+                                                     const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg,
+                                                     uint8_t *__restrict__ pyr, size_t pyr_frame_stride, uint32_t wpc_rcp, int n_frames) {
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;
+    const int wpc = L.pitch >> 3;   // column pairs per padded row (the pitch is a multiple of 64)
+    const int idx = bx * 256 + threadIdx.x;
+    const int pg = (int)__umulhi((uint32_t)idx, wpc_rcp), wg = idx - (int)__umul24((uint32_t)pg, (uint32_t)wpc);
+    const int rows = L.h + 2 * kEdge;
+    const int py0 = pg * kResizeRows;
+    if (py0 >= rows) return;
+    uint8_t *frame = pyr + (size_t)f * pyr_frame_stride;
+    const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX;  // previous level ROI origin
+    const uint4 *gp = reinterpret_cast<const uint4 *>(&xg[L.xg_off + 2 * wg]);   // two ResizeGroup entries = 64 contiguous bytes
+    uint4 gh[2], gc[2];
+    gh[0] = gp[0]; gc[0] = gp[1]; gh[1] = gp[2]; gc[1] = gp[3];
+    ResizeTap ty[kResizeRows];
+#pragma unroll
+    for (int r = 0; r < kResizeRows; r++) ty[r] = ytab[L.ytab_off + reflect101(min(py0 + r, rows - 1) - kEdge, L.h)];
+    uint32_t so0[kResizeRows], so1[kResizeRows];   // byte offsets of the two source rows of each output row
+#pragma unroll
+    for (int r = 0; r < kResizeRows; r++) {
+        const int sy0 = min(max(ty[r].ofs, 0), P.h - 1), sy1 = min(max(ty[r].ofs + 1, 0), P.h - 1);
+        so0[r] = __umul24((uint32_t)sy0, (uint32_t)P.pitch);
+        so1[r] = __umul24((uint32_t)sy1, (uint32_t)P.pitch);
+    }
+    // every source load of the thread before any arithmetic: one memory round trip
+    uint2 r0[2][kResizeRows], r1[2][kResizeRows];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int r = 0; r < kResizeRows; r++) {
+            // unconditional (a column without taps reads the row's first bytes and ignores them): loads inside divergent blocks make the
+            // compiler wait for ALL outstanding loads at every block boundary -- four round trips instead of one
+            const uint32_t gx = gh[c].z == 1 ? gh[c].x : 0u;
+            __builtin_memcpy(&r0[c][r], proi + (so0[r] + gx), 8);
+            __builtin_memcpy(&r1[c][r], proi + (so1[r] + gx), 8);
+        }
+    uint32_t out[2][kResizeRows];
+    constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint32_t selr = gh[c].y + 0x01010101u;
+        const uint32_t cc[4] = {gc[c].x, gc[c].y, gc[c].z, gc[c].w};
+#pragma unroll
+        for (int r = 0; r < kResizeRows; r++) {
+            uint32_t o = 0;   // gh.z == 2: pitch padding outside the ring, zeros
+            if (gh[c].z == 1) {
+                const uint32_t l0 = __builtin_amdgcn_perm(r0[c][r].y, r0[c][r].x, gh[c].y), q0 = __builtin_amdgcn_perm(r0[c][r].y, r0[c][r].x, selr);
+                const uint32_t l1 = __builtin_amdgcn_perm(r1[c][r].y, r1[c][r].x, gh[c].y), q1 = __builtin_amdgcn_perm(r1[c][r].y, r1[c][r].x, selr);
+                const int b0 = ty[r].c0, b1 = ty[r].c1;   // bilinear tap pair: 0 <= b0, b1 <= 2048
+                int t[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t h0 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
+                    const uint32_t h1 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
+                    const uint32_t p0 = __umul24(h0 >> 4, (uint32_t)b0) + 0x20000u, p1 = __umul24(h1 >> 4, (uint32_t)b1);
+                    t[k] = (int)((p0 >> 16) + (p1 >> 16));
+                }
+                const uint32_t lo = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 2);
+                const uint32_t hi = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 2);
+                o = lo | (hi << 16);
+            } else if (gh[c].z == 0) {   // taps further apart than 8 bytes (scale factor > 2): table form, as in k_pyr_resize
+                const uint8_t *S0 = proi + so0[r], *S1 = proi + so1[r];
+                const int b0 = ty[r].c0, b1 = ty[r].c1;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int x = (2 * wg + c) * 4 + k - kRoiX;
+                    if (x >= -kEdge && x < L.w + kEdge) {
+                        const ResizeTap tx = xtab[L.xtab_off + reflect101(x, L.w)];
+                        const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
+                        const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
+                        int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                        v = min(max(v, 0), 255);
+                        o |= (uint32_t)v << (8 * k);
+                    }
+                }
+            }
+            out[c][r] = o;
+        }
+    }
+    uint8_t *drow = frame + L.off + (size_t)py0 * L.pitch + wg * 8;
+#pragma unroll
+    for (int r = 0; r < kResizeRows; r++)
+        if (py0 + r < rows) *reinterpret_cast<uint2 *>(drow + (uint32_t)(r * L.pitch)) = make_uint2(out[0][r], out[1][r]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // FAST-9/16 corner score of one pixel.  [OCV] cornerScore<16>: with d[k] = v - p[k] on the Bresenham circle,
 //   score = max( max_arcs min(d over 9 contiguous), max_arcs min(-d over 9 contiguous) ) - 1

@@ -147,6 +147,21 @@ struct orbx_extractor {
     bool in_used[2] = {false, false};
     unsigned in_issued = 0;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
+    // The pyramid of batch i+1 is built AHEAD, on its own stream, while the main stream still runs k_finalize / k_describe of batch i
+    // (both latency bound): d_pyr and d_blur hold two slabs each, batch k uses slab k & 1, and the pyramid stream starts once the main
+    // stream has passed the FAST stage of the previous batch (ev_oct; ORBX_PYR_AHEAD=1: its quad-tree) -- by then every reader of the slab
+    // it overwrites (batch k-2) and every user of the FAST overflow counter k_pyr_base resets (batch k-1) is done.  OFF by default (ORBX_PYR_AHEAD=2 / 1 turn it
+    // on): with the streams on hardware queues of their own the concurrent kernels slowed each other by more than the overlap gained
+    // (1.31 / 1.40 vs 1.18 ms per step), with shared queues nothing overlapped.
+    hipStream_t pyr_stream = nullptr;
+    hipEvent_t ev_oct = nullptr;
+    bool pyr_ahead = false, have_oct = false;
+    int pyr_ahead_at = 2;   // where ev_oct is recorded: 2 = behind the FAST stage (default), 1 = behind the quad-tree
+    unsigned pyr_slot = 0;
+    size_t pyr_slab = 0, blur_slab = 0;   // bytes of one slab (batch_cap frames)
+    bool ahead() const { return pyr_ahead && side_streams && !profile && pyr_stream != nullptr; }
+    uint8_t *pyr_cur() const { return (uint8_t *)d_pyr.p + (size_t)pyr_slot * pyr_slab; }     // slab of the most recent batch
+    uint8_t *blur_cur() const { return (uint8_t *)d_blur.p + (size_t)pyr_slot * blur_slab; }
     hipEvent_t ev_level[orbx::kMaxLevels] = {};   // level l of the pyramid written (k_blur follows the resize chain level by level)
     int blur_tile_start[orbx::kMaxLevels + 1] = {};  // blur tiles of level l: [start[l], start[l + 1])
     int blur_groups = 1;       // ORBX_BLUR_GROUPS (measured slower than one launch): levels 0 .. groups-2 get a k_blur launch of their own, the rest share the last one (1 = one launch after the pyramid)

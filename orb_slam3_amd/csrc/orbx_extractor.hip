@@ -227,8 +227,9 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
 
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->pyr_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
     ex->copy_pending = false; ex->match_pending = false; ex->copy_issued = ex->copy_waited = 0;
+    ex->have_oct = false; ex->pyr_slot = 0;
     ex->mkey = orbx_extractor::MatchKey();
     ex->mpkey = orbx_extractor::MpKey();
     const int B = std::max(batch, ex->batch_cap);
@@ -241,8 +242,9 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_ftiles, sizeof(FastTile) * ftiles.size());
     ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
-    ENS(ex->d_pyr, pyr_off * B);
-    ENS(ex->d_blur, blur_off * B);
+    ENS(ex->d_pyr, 2 * pyr_off * B);     // two slabs: batch k uses slab k & 1 (extractor_state.h)
+    ENS(ex->d_blur, 2 * blur_off * B);
+    ex->pyr_slab = pyr_off * B; ex->blur_slab = blur_off * B;
     ENS(ex->d_cellcnt, sizeof(int32_t) * (size_t)cell_base * B);
     ENS(ex->d_cellent, sizeof(uint32_t) * (size_t)cand_off * B);
     ENS(ex->d_keys0, sizeof(uint32_t) * (size_t)cand_off * B);
@@ -315,18 +317,23 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     RoctxRange rr("orbx:extract");
     const int nl = ex->prm.nlevels;
     const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
-    uint8_t *pyr = (uint8_t *)ex->d_pyr.p;
+    ex->pyr_slot ^= 1u;
+    uint8_t *pyr = ex->pyr_cur();
+    uint8_t *blur_slab = ex->blur_cur();
     hipStream_t st = ex->stream;
+    const bool ahead = ex->ahead();
+    hipStream_t pst = ahead ? ex->pyr_stream : st;   // stream of the pyramid stage
+    if (ahead && ex->have_oct) ORBX_HIP(hipStreamWaitEvent(pst, ex->ev_oct, 0));   // not before the previous batch has left its quad-tree
     static const bool pyr_local = [] { const char *v = getenv("ORBX_PYR_XCD"); return !(v && v[0] == '0'); }();   // 0 = round-robin workgroups
     {
         ProfScope ps(ex, K_PYR_BASE);
         const LevelInfo &L = ex->lv[0];
         const dim3 grid = xcd_grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n, pyr_local);
-        hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, L, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
+        hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, pst, L, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
                            (int32_t *)ex->d_fast_ovf.p,
                            (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)), n);
     }
-    if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, st));  // k_pyr_base is the only reader of the input frames
+    if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));  // k_pyr_base is the only reader of the input frames
     // k_blur follows the resize chain on the aux stream, level group by level group: the chain is latency bound (three dependent memory
     // round trips per wave, VALU mostly idle) and the blur VALU bound, so they share the machine well -- and FAST then runs without the
     // blur beside it (both VALU bound: side by side they took as long as one after the other)
@@ -341,10 +348,10 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         const bool sat = 2 * (bg[0] + bg[1] + bg[2]) + bg[3] > 256;   // taps summing to more than 1.0 (OpenCV <= 4.5.0) can exceed 255
 #define ORBX_BLUR_PK(SAT)                                                                                                              \
     hipLaunchKernelGGL(k_blur_pk<SAT>, xcd_grid(t1 - t0, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p + t0,          \
-                       (const uint8_t *)pyr, ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n)
+                       (const uint8_t *)pyr, ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n)
         if (!packed)
             hipLaunchKernelGGL(k_blur, dim3(t1 - t0, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p + t0, (const uint8_t *)pyr,
-                               ex->pyr_frame, (uint8_t *)ex->d_blur.p, ex->blur_frame, bg[0], bg[1], bg[2], bg[3]);
+                               ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3]);
         else if (sat) ORBX_BLUR_PK(true);
         else ORBX_BLUR_PK(false);
 #undef ORBX_BLUR_PK
@@ -353,7 +360,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         if (!blur_follow) return ORBX_OK;
         const bool last_group = l >= n_groups - 1;
         if (last_group && l != nl - 1) return ORBX_OK;   // the last group waits for the top of the pyramid
-        ORBX_HIP(hipEventRecord(ex->ev_level[l], st));
+        ORBX_HIP(hipEventRecord(ex->ev_level[l], pst));
         ORBX_HIP(hipStreamWaitEvent(ex->aux_stream, ex->ev_level[l], 0));
         if (last_group) { blur_levels(ex->aux_stream, n_groups - 1, nl); ORBX_HIP(hipEventRecord(ex->ev_blur, ex->aux_stream)); }
         else blur_levels(ex->aux_stream, l, l + 1);
@@ -366,10 +373,18 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         const dim3 grid = xcd_grid(((L.pitch / 4) * ((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255) / 256, n, pyr_local);
         static const bool resize_pk = [] { const char *v = getenv("ORBX_RESIZE_PK"); return !(v && v[0] == '0'); }();   // 0 = round-1 vertical pass
 #define ORBX_RESIZE(PK)                                                                                                         \
-    hipLaunchKernelGGL(k_pyr_resize<PK>, grid, dim3(256), 0, st, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,             \
+    hipLaunchKernelGGL(k_pyr_resize<PK>, grid, dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,             \
                        (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,                 \
                        (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 4) - 1) / (uint64_t)(L.pitch / 4)), n)
-        if (resize_pk) ORBX_RESIZE(true); else ORBX_RESIZE(false);
+        static const bool resize_cols2 = [] { const char *v = getenv("ORBX_RESIZE_COLS"); return !(v && v[0] == '1'); }();   // 1 = one dword column per thread
+        if (resize_cols2 && resize_pk) {
+            const uint32_t wpc = (uint32_t)(L.pitch / 8);
+            const dim3 grid2 = xcd_grid((int)((wpc * (uint32_t)((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255u) / 256u), n, pyr_local);
+            hipLaunchKernelGGL(k_pyr_resize2, grid2, dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,
+                               (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,
+                               (uint32_t)((0x100000000ull + (uint64_t)wpc - 1) / (uint64_t)wpc), n);
+        }
+        else if (resize_pk) ORBX_RESIZE(true); else ORBX_RESIZE(false);
 #undef ORBX_RESIZE
         { int r = blur_after_level(l); if (r != ORBX_OK) return r; }
     }
@@ -377,15 +392,14 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         if (blur_follow) return ORBX_OK;
         const bool side = !ex->profile && ex->side_streams && ex->blur_side;
         hipStream_t bs = side ? ex->aux_stream : st;
-        if (side) {
-            ORBX_HIP(hipEventRecord(ex->ev_pyr, st));
-            ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
-        }
+        if (side) ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
         ProfScope ps(ex, K_BLUR);
         blur_levels(bs, 0, nl);
         if (side) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
         return ORBX_OK;
     };
+    ORBX_HIP(hipEventRecord(ex->ev_pyr, pst));                         // the pyramid of this batch is complete
+    if (ahead) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_pyr, 0));        // FAST and everything after it stay on the main stream
     static const bool blur_after_fast = [] { const char *v = getenv("ORBX_BLUR_AFTER_FAST"); return v && v[0] == '1'; }();
     if (!blur_after_fast) { int r = launch_blur(); if (r != ORBX_OK) return r; }
     {
@@ -440,6 +454,10 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         else if (tpb == 128) ORBX_FAST_LAUNCH(128);
         else ORBX_FAST_LAUNCH(64);
     }
+    // the next batch's pyramid may start (extractor_state.h): FAST and its list pass -- the users of the overflow counter k_pyr_base resets --
+    // are enqueued, every reader of the other pyramid slab finished a batch ago; it then runs beside the latency-bound quad-tree, k_finalize
+    // and k_describe of this batch
+    if (ex->ev_oct && ex->pyr_ahead_at == 2) { ORBX_HIP(hipEventRecord(ex->ev_oct, st)); ex->have_oct = true; }
     if (blur_after_fast) { int r = launch_blur(); if (r != ORBX_OK) return r; }   // beside the latency-bound quad-tree stage instead of beside FAST
     {
         ProfScope ps(ex, K_OCTREE);
@@ -465,6 +483,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                                (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p, ex->max_pool);
         }
     }
+    if (ex->ev_oct && ex->pyr_ahead_at != 2) { ORBX_HIP(hipEventRecord(ex->ev_oct, st)); ex->have_oct = true; }   // ORBX_PYR_AHEAD=1: the next pyramid starts after the quad-tree
     if (ex->copy_pending) {  // outputs of the previous batch may still be in flight to the host
         ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done[(ex->copy_issued - 1) & 1], 0));  // the most recent download
     }
@@ -482,7 +501,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         ProfScope ps(ex, K_DESCRIBE);
         hipLaunchKernelGGL(k_describe, xcd_grid((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
                            (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
-                           ex->pyr_frame, (const uint8_t *)ex->d_blur.p, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
+                           ex->pyr_frame, (const uint8_t *)blur_slab, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
                            (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0, n);
     }
     if (ex->has_camera) {   // Frame::UndistortKeyPoints for the whole batch (mvKeysUn for the batched matchers)
@@ -611,6 +630,10 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, use_prio == 2 ? prio_lo : prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
     (void)hipStreamCreateWithPriority(&ex->in_stream, hipStreamNonBlocking, prio_hi);
+    (void)hipStreamCreateWithPriority(&ex->pyr_stream, hipStreamNonBlocking, prio_hi);
+    (void)hipEventCreateWithFlags(&ex->ev_oct, hipEventDisableTiming);
+    // measured slower than the pyramid on the main stream: off unless ORBX_PYR_AHEAD=1 (behind the quad-tree) / 2 (behind FAST)
+    { const char *v = getenv("ORBX_PYR_AHEAD"); ex->pyr_ahead = v && (v[0] == '1' || v[0] == '2'); ex->pyr_ahead_at = (v && v[0] == '1') ? 1 : 2; }
     for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t &ev : ex->ev_level) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
@@ -649,8 +672,9 @@ void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream})
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->pyr_stream})
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (ex->ev_oct) (void)hipEventDestroy(ex->ev_oct);
     for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
     ex->d_in[0].release(); ex->d_in[1].release();
     for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
@@ -714,7 +738,7 @@ int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_f
                                       hipMemcpyHostToDevice, is));
     }
     ORBX_HIP(hipEventRecord(ex->ev_in_ready[slot], is));
-    ORBX_HIP(hipStreamWaitEvent(ex->stream, ex->ev_in_ready[slot], 0));
+    ORBX_HIP(hipStreamWaitEvent(ex->ahead() ? ex->pyr_stream : ex->stream, ex->ev_in_ready[slot], 0));   // the stream of k_pyr_base
     ex->in_used[slot] = true;
     ex->in_issued++;
     return enqueue_extract(ex, (const uint8_t *)din.p, n_frames, width, fbytes, lap0, lap1, ex->ev_in_free[slot]);
@@ -724,7 +748,7 @@ int orbx_set_camera(orbx_extractor *ex, const orbx_camera *cam) {
     if (!ex) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->pyr_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
     ex->has_camera = cam != nullptr;
     if (cam) {
         const float p[9] = {cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
@@ -770,6 +794,7 @@ int orbx_sync(orbx_extractor *ex) {
     ORBX_HIP(hipStreamSynchronize(ex->aux_stream));
     ORBX_HIP(hipStreamSynchronize(ex->match_stream));
     ORBX_HIP(hipStreamSynchronize(ex->in_stream));
+    if (ex->pyr_stream) ORBX_HIP(hipStreamSynchronize(ex->pyr_stream));
     return ORBX_OK;
 }
 
@@ -843,11 +868,16 @@ int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *d
     hipStream_t cs = ex->copy_stream;
     ORBX_HIP(hipEventRecord(ex->ev_compute_done, ex->stream));
     ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_compute_done, 0));
-    if (ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
+    // keypoints and descriptors leave as soon as the extraction is done, BESIDE the matcher (they are 94 % of the bytes and the matcher
+    // does not write them); only the match vectors wait for it.  With the wait in front of everything the next batch's k_finalize sat
+    // behind matcher + all copies in series (ORBX_COPY_AFTER_MATCH=1 restores that order).
+    static const bool copy_after_match = [] { const char *v = getenv("ORBX_COPY_AFTER_MATCH"); return v && v[0] == '1'; }();
+    if (copy_after_match && ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
     if (counts) ORBX_HIP(hipMemcpyAsync(counts, ex->d_count.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     if (mono) ORBX_HIP(hipMemcpyAsync(mono, ex->d_mono.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, cs));
+    if (!copy_after_match && ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
     if (match && ex->d_match.p) ORBX_HIP(hipMemcpyAsync(match, ex->d_match.p, 4 * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (nmatches && ex->d_nmatch.p) ORBX_HIP(hipMemcpyAsync(nmatches, ex->d_nmatch.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     const unsigned slot = ex->copy_issued & 1;
@@ -890,7 +920,8 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
     // the caller's image goes through the pinned staging buffer (rows packed to the device pitch), never to the runtime directly
     if ((r = ex->ensure_stage(std::max(dpitch * height, 64 + (size_t)ex->cap * (sizeof(orbx_keypoint) + 32)))) != ORBX_OK) return r;
     for (int y = 0; y < height; y++) memcpy((uint8_t *)ex->h_stage + (size_t)y * dpitch, image + (size_t)y * stride, (size_t)width);
-    ORBX_HIP(hipMemcpyAsync(ex->d_img.p, ex->h_stage, dpitch * height, hipMemcpyHostToDevice, ex->stream));
+    // on the stream that runs k_pyr_base (the pyramid stream when the pyramid is built ahead): the upload must be ordered before it
+    ORBX_HIP(hipMemcpyAsync(ex->d_img.p, ex->h_stage, dpitch * height, hipMemcpyHostToDevice, ex->ahead() ? ex->pyr_stream : ex->stream));
     r = enqueue_extract(ex, (const uint8_t *)ex->d_img.p, 1, dpitch, dpitch * height, lap0, lap1);
     if (r != ORBX_OK) return r;
     return orbx_batch_download(ex, 0, kps, desc, cap, n_out, mono_index);
@@ -908,7 +939,7 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
     const LevelInfo &L = ex->lv[level];
     if (dst_stride < (size_t)(L.w + 2 * kEdge)) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
-    const uint8_t *src = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off;
+    const uint8_t *src = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off;
     const size_t bytes = (size_t)L.pitch * (L.h + 2 * kEdge);
     int r = ex->d2h_staged_begin(bytes);
     if (r != ORBX_OK) return r;
@@ -921,7 +952,7 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
 int orbx_get_level_device(orbx_extractor *ex, int frame, int level, const uint8_t **d_padded, size_t *pitch) {
     if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
     const LevelInfo &L = ex->lv[level];
-    if (d_padded) *d_padded = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off + kRingX;
+    if (d_padded) *d_padded = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off + kRingX;
     if (pitch) *pitch = L.pitch;
     return ORBX_OK;
 }
@@ -995,7 +1026,7 @@ int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *
     const size_t bytes = (size_t)L.bpitch * L.h;
     int r = ex->d2h_staged_begin(bytes);
     if (r != ORBX_OK) return r;
-    if ((r = ex->d2h_staged(0, (const uint8_t *)ex->d_blur.p + (size_t)frame * ex->blur_frame + L.boff, bytes)) != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, (const uint8_t *)ex->blur_cur() + (size_t)frame * ex->blur_frame + L.boff, bytes)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     for (int y = 0; y < L.h; y++) memcpy(dst + (size_t)y * dst_stride, ex->staged((size_t)y * L.bpitch), (size_t)L.w);
     return ORBX_OK;

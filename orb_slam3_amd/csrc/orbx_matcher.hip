@@ -1232,7 +1232,7 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
     S.dl = (const uint8_t *)L->d_desc.p; S.dr = (const uint8_t *)R->d_desc.p;
     S.nl = (const int32_t *)L->d_count.p; S.nr = (const int32_t *)R->d_count.p;
     S.capL = capL; S.capR = R->cap;
-    S.pyrL = (const uint8_t *)L->d_pyr.p; S.pyrR = (const uint8_t *)R->d_pyr.p;
+    S.pyrL = (const uint8_t *)L->pyr_cur(); S.pyrR = (const uint8_t *)R->pyr_cur();
     S.pyr_frame_L = L->pyr_frame; S.pyr_frame_R = R->pyr_frame;
     S.lvL = (const LevelInfo *)L->d_lv.p; S.lvR = (const LevelInfo *)R->d_lv.p;
     S.scale = (const float *)L->d_st_scales.p; S.inv_scale = S.scale + nl;
