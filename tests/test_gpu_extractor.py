@@ -324,3 +324,21 @@ def test_alternative_kernel_paths(tmp_path):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.xfail(strict=False, reason="diagnostic sweep added at the end of round 2 (not yet run on hardware): see tests/test_gpu_pipeline.py "
+                                        "test_open_small_canvas_*; a failure message names the image and the first stage that differs")
+def test_open_random_image_sweep():
+    """Stage-wise GPU-vs-oracle comparison over canvases the other tests do not use (sizes, shape densities, seeds, noise): the first
+    image is the one behind the open 1007-vs-1008 keypoint difference.  Collects every mismatch instead of stopping at the first."""
+    from orb_slam3_amd import synth
+    ex, oex = _pair(1000)
+    cases = [(11, 1024, 700, 0)] + [(100 + k, (1024, 1536, 2048)[k % 3], (300, 700, 1500, 2400, 4000)[k % 5], k % 7) for k in range(40)]
+    failures = []
+    for seed, size, n_shapes, t in cases:
+        img = synth.frame_from_canvas(synth.make_canvas(seed, size=size, n_shapes=n_shapes), t, 752, 480, 1000 * seed + t)
+        try:
+            _check_frame(ex, oex, img, (0, 1000), stagewise=True)
+        except AssertionError as e:
+            failures.append(f"canvas(seed={seed}, size={size}, n_shapes={n_shapes}) frame {t}: {str(e)[:200]}")
+    assert not failures, "\n".join(failures)
