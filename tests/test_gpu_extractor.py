@@ -340,5 +340,16 @@ def test_open_random_image_sweep():
         try:
             _check_frame(ex, oex, img, (0, 1000), stagewise=True)
         except AssertionError as e:
-            failures.append(f"canvas(seed={seed}, size={size}, n_shapes={n_shapes}) frame {t}: {str(e)[:200]}")
+            msg = f"canvas(seed={seed}, size={size}, n_shapes={n_shapes}) frame {t}: {str(e)[:200]}"
+            # the same image through the sequential quad-tree emulation (k_octree; the switch is read when an extractor configures itself)
+            import os
+            os.environ["ORBX_OCTREE"] = "seq"
+            try:
+                _check_frame(_pair(1000)[0], oex, img, (0, 1000), stagewise=True)
+                msg += "  [passes with ORBX_OCTREE=seq: the difference is in k_octree_par]"
+            except AssertionError as e2:
+                msg += f"  [with ORBX_OCTREE=seq: {str(e2)[:120]}]"
+            finally:
+                del os.environ["ORBX_OCTREE"]
+            failures.append(msg)
     assert not failures, "\n".join(failures)
