@@ -10,6 +10,19 @@ sys.path.insert(0, str(ROOT))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # ORBX_TEST_EMULATOR=1: the `-m gpu` tests that only use the C ABI with host buffers run HERE, on the CPU, against liborbx's own
+    # host + device sources compiled for the SIMT emulator (tests/simt/: python tests/simt/build.py).  A way to exercise kernel LOGIC
+    # without a GPU -- it says nothing about timing, races between streams or the hardware; tests that need torch.cuda still fail.
+    if os.environ.get("ORBX_TEST_EMULATOR"):
+        import orb_slam3_amd._lib as _lib
+        emul = ROOT / "tests" / "simt" / "build" / "liborbx_emul.so"
+        if not emul.exists():
+            raise pytest.UsageError(f"{emul} is missing: run python tests/simt/build.py")
+        _lib.LIB_PATH = emul
+        import torch   # "device" memory is host memory under the emulator
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.Tensor.pin_memory = lambda self, *a, **k: self
+        torch.cuda.synchronize = lambda *a, **k: None
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,75 @@
+// stand-in for <hip/hip_runtime.h>: liborbx's host AND device code compiled for the CPU SIMT emulator (tests/simt/simt.h).
+// Streams and events are dummies -- every launch and copy completes before the call returns.  Test infrastructure only.
+#pragma once
+#include "../simt.h"
+#include <functional>
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotSupported = 801 };
+typedef struct simt_stream *hipStream_t;
+typedef struct simt_event *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostRegisterDefault = 0 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeUnregistered = 0 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void *devicePointer, *hostPointer; int isManaged; unsigned allocationFlags; };
+
+inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "simt: emulated HIP error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
+inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
+    for (size_t y = 0; y < h; y++) memmove((char *)d + y * dp, (const char *)s + y * sp, w);
+    return hipSuccess;
+}
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {   // every pointer counts as pinned host memory
+    memset(a, 0, sizeof(*a)); a->type = hipMemoryTypeHost; a->hostPointer = (void *)p; a->devicePointer = (void *)p; return hipSuccess;
+}
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+
+// the virtual-memory API of the guard allocator (ORBX_GUARD): not emulated
+typedef void *hipMemGenericAllocationHandle_t;
+enum { hipMemAllocationTypePinned = 1, hipMemLocationTypeDevice = 1, hipMemAccessFlagsProtReadWrite = 3, hipMemAllocationGranularityMinimum = 0 };
+struct hipMemLocation { int type, id; };
+struct hipMemAllocationProp { int type; hipMemLocation location; int requestedHandleType; void *win32HandleMetaData; };
+struct hipMemAccessDesc { hipMemLocation location; int flags; };
+inline hipError_t hipMemGetAllocationGranularity(size_t *g, const hipMemAllocationProp *, int) { *g = 4096; return hipErrorNotSupported; }
+inline hipError_t hipMemAddressReserve(void **, size_t, size_t, void *, unsigned long long) { return hipErrorNotSupported; }
+inline hipError_t hipMemAddressFree(void *, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *, size_t, const hipMemAllocationProp *, unsigned long long) { return hipErrorNotSupported; }
+inline hipError_t hipMemMap(void *, size_t, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return hipErrorNotSupported; }
+inline hipError_t hipMemUnmap(void *, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t) { return hipErrorNotSupported; }
+inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipErrorNotSupported; }
+
+// kernel launch: the blocks of the grid run one after the other, each under the fiber scheduler
+namespace simt {
+void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body);
+}
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    simt::launch(#kernel, dim3(grid), dim3(block), (size_t)(lds), [&] { kernel(__VA_ARGS__); })
