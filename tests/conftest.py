@@ -23,6 +23,14 @@ def pytest_configure(config):
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.Tensor.pin_memory = lambda self, *a, **k: self
         torch.cuda.synchronize = lambda *a, **k: None
+        for _name in ("zeros", "full", "empty", "ones"):   # device="cuda" -> host
+            def _wrap(fn):
+                def f(*a, **k):
+                    if str(k.get("device", "")).startswith("cuda"):
+                        k.pop("device")
+                    return fn(*a, **k)
+                return f
+            setattr(torch, _name, _wrap(getattr(torch, _name)))
 
 
 @pytest.fixture(scope="session")
