@@ -41,8 +41,8 @@ extern "C" {
 int simt_octree(int form, int w, int h, int quota, const uint32_t *keys, int C, uint32_t *out, int out_cap, int *err_out) {
     LevelInfo L = make_level(w, h, quota);
     if (L.lvl_cap > out_cap) return -2;
-    std::vector<uint32_t> k0(std::max(C, 1) + 64), k1(std::max(C, 1) + 64), res(L.lvl_cap + 64, 0);
-    std::vector<uint16_t> n0(std::max(C, 1) + 64), n1(std::max(C, 1) + 64);
+    std::vector<uint32_t> k0(std::max(C, 1) + 16384), k1(std::max(C, 1) + 16384), res(L.lvl_cap + 4096, 0);
+    std::vector<uint16_t> n0(std::max(C, 1) + 16384), n1(std::max(C, 1) + 16384);
     memcpy(k1.data(), keys, 4 * (size_t)C);
     int32_t cnt = -1, err = 0;
     const int max_pool = L.pool;
