@@ -23,6 +23,8 @@ REWRITES = [
     # k_describe stores row 31 of the orientation patch into what becomes row 0 of the BRIEF patch and relies on the wave's LDS
     # instructions executing in program order ACROSS lanes (lock step); the emulator's lanes are not in lock step: order the two phases
     (re.compile(r"(\n\s*)if \(c < 10\) \{(\s*)uint8_t \*d = Bp \+"), r"\1__builtin_amdgcn_wave_barrier();\1if (c < 10) {\2uint8_t *d = Bp +"),
+    # k_octree_par1's chunked scatter: all lanes read the running offset hist[slot], then all lanes bump it (lock step); see simt::defer_add
+    (re.compile(r"atomicAdd\(&hist\[slot\], 1u\);(\s*// LDS/memory operations of a wave are performed in order)"), r"simt::defer_add(&hist[slot], 1u);\1"),
     # k_describe's hand-made 32-bit LDS address
     (re.compile(r"\*reinterpret_cast<const __attribute__\(\(address_space\(3\)\)\) uint8_t \*>\((\w+)\)"), r"*simt::lds_ptr(\1)"),
 ]

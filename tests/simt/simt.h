@@ -62,6 +62,7 @@ struct Block {
     int alive_block = 0;
     int alive_wave[4] = {0, 0, 0, 0};
     Rendezvous wave_rv[4], block_rv;
+    std::vector<std::pair<uint32_t *, uint32_t>> deferred[4];   // per wave: additions that take effect at its next collective
     unsigned long long progress = 0;
     Dim3 block_idx, grid_dim;
     std::function<void()> body;
@@ -75,9 +76,11 @@ inline void yield_to_scheduler() {
     swapcontext(&b->fibers[b->cur].ctx, &b->sched);
 }
 
+inline void apply_deferred(Rendezvous &rv);
 // complete a rendezvous if every alive participant has arrived
 inline void try_complete(Rendezvous &rv, int alive) {
     if (rv.waiting > 0 && rv.waiting == alive) {
+        apply_deferred(rv);
         const int g = (int)(rv.generation & 1);
         memcpy(rv.result[g], rv.slot, sizeof(rv.slot));
         memcpy(rv.rpresent[g], rv.present, sizeof(rv.present));
@@ -88,6 +91,21 @@ inline void try_complete(Rendezvous &rv, int alive) {
     }
 }
 
+inline void apply_deferred(Rendezvous &rv) {
+    Block *b = blk();
+    for (int w = 0; w < 4; w++)
+        if (&rv == &b->wave_rv[w] || &rv == &b->block_rv) {
+            for (auto &d : b->deferred[w]) *d.first += d.second;
+            b->deferred[w].clear();
+        }
+}
+// An LDS update that the hardware's lock step orders AFTER every lane's earlier read of the same instruction sequence (all lanes
+// read a running offset, then all lanes bump it): the emulator's lanes run one after the other, so the update takes effect when the
+// wave reaches its next collective.  Used through a rewrite in build.py for the one place that needs it.
+inline void defer_add(uint32_t *p, uint32_t v) {
+    Block *b = blk();
+    b->deferred[b->cur >> 6].push_back({p, v});
+}
 // deposit `v` for lane index `idx` of the group; returns the generation slot holding everybody's values
 inline int rendezvous(Rendezvous &rv, int idx, uint64_t v, int *alive_counter) {
     rv.slot[idx] = v;

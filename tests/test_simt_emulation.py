@@ -100,8 +100,8 @@ print('emulation ok')
 
 
 def test_emulated_quadtree_under_wave_shuffle(emul_lib):
-    """k_octree_par's body alone (tests/simt/octree_emul.cc) on the oracle's FAST candidates of several frames, every level, with the
-    four waves of the workgroup resumed in a different random order every scheduler round: always the oracle's DistributeOctTree."""
+    """The quad-tree body alone (tests/simt/octree_emul.cc), both forms, on the oracle's FAST candidates of several frames, every level,
+    with the waves of the workgroup resumed in a different random order every scheduler round: always the oracle's DistributeOctTree."""
     code = """
 import ctypes as C
 L = C.CDLL(str(Path(%r)))
@@ -117,10 +117,10 @@ for seed, size, shapes in ((11, 1024, 700), (10, 2048, 2400), (33, 1536, 4000)):
         for l in range(8):
             w, h = oex.level_size(l)
             keys, want = pack(oex.level_candidates(l)), pack(oex.level_keypoints(l))
-            for rep in range(2):
+            for form in (0, 0, 1):   # the 256-thread form twice (different wave orders), then the single-wave chunked form (k_octree_par1)
                 out = np.zeros(4096, np.uint32); err = C.c_int(0)
-                n = L.simt_octree(0, w, h, quota[l], keys.ctypes.data_as(C.c_void_p), len(keys), out.ctypes.data_as(C.c_void_p), 4096, C.byref(err))
-                assert n == len(want) and np.array_equal(out[:n], want) and err.value == 0, (seed, t, l, n, len(want), err.value)
+                n = L.simt_octree(form, w, h, quota[l], keys.ctypes.data_as(C.c_void_p), len(keys), out.ctypes.data_as(C.c_void_p), 4096, C.byref(err))
+                assert n == len(want) and np.array_equal(out[:n], want) and err.value == 0, (seed, t, l, form, n, len(want), err.value)
                 runs += 1
 print('emulation ok', runs)
 """ % str(SIMT / "build" / "liboctree_emul.so")
