@@ -232,18 +232,13 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo L, const Lev
 // bandwidth (2 TB/s), so a wave that keeps twice the bytes in flight for the same two round trips doubles the rate until VALU issue
 // binds; the two columns share their row taps, source rows (adjacent 8-byte loads) and one 8-byte store per row.
 // grid xcd_grid(ceil((pitch / 8) * ceil(rows / 2) / 256), B)
-__global__ __launch_bounds__(256) void k_pyr_resize2(const LevelInfo L, const LevelInfo P, const ResizeTap *__restrict__ xtab,
-                                                     const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg,
-                                                     uint8_t *__restrict__ pyr, size_t pyr_frame_stride, uint32_t wpc_rcp, int n_frames) {
-    int bx, f;
-    if (!xcd_frame_map(n_frames, &bx, &f)) return;
-    const int wpc = L.pitch >> 3;   // column pairs per padded row (the pitch is a multiple of 64)
-    const int idx = bx * 256 + threadIdx.x;
-    const int pg = (int)__umulhi((uint32_t)idx, wpc_rcp), wg = idx - (int)__umul24((uint32_t)pg, (uint32_t)wpc);
+// one work item of the two-column form: row pair pg, column pair wg of level L of the frame whose pyramid slab starts at `frame`
+__device__ __forceinline__ void resize2_item(const LevelInfo &L, const LevelInfo &P, const ResizeTap *__restrict__ xtab,
+                                             const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg, uint8_t *frame,
+                                             const int pg, const int wg) {
     const int rows = L.h + 2 * kEdge;
     const int py0 = pg * kResizeRows;
     if (py0 >= rows) return;
-    uint8_t *frame = pyr + (size_t)f * pyr_frame_stride;
     const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX;  // previous level ROI origin
     const uint4 *gp = reinterpret_cast<const uint4 *>(&xg[L.xg_off + 2 * wg]);   // two ResizeGroup entries = 64 contiguous bytes
     uint4 gh[2], gc[2];
@@ -317,6 +312,40 @@ __global__ __launch_bounds__(256) void k_pyr_resize2(const LevelInfo L, const Le
 #pragma unroll
     for (int r = 0; r < kResizeRows; r++)
         if (py0 + r < rows) *reinterpret_cast<uint2 *>(drow + (uint32_t)(r * L.pitch)) = make_uint2(out[0][r], out[1][r]);
+}
+
+__global__ __launch_bounds__(256) void k_pyr_resize2(const LevelInfo L, const LevelInfo P, const ResizeTap *__restrict__ xtab,
+                                                     const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg,
+                                                     uint8_t *__restrict__ pyr, size_t pyr_frame_stride, uint32_t wpc_rcp, int n_frames) {
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;
+    const int wpc = L.pitch >> 3;   // column pairs per padded row (the pitch is a multiple of 64)
+    const int idx = bx * 256 + threadIdx.x;
+    const int pg = (int)__umulhi((uint32_t)idx, wpc_rcp), wg = idx - (int)__umul24((uint32_t)pg, (uint32_t)wpc);
+    resize2_item(L, P, xtab, ytab, xg, pyr + (size_t)f * pyr_frame_stride, pg, wg);
+}
+
+// k_pyr_chain (ORBX_PYR_CHAIN=1; written at the end of round 2, verified against the oracle under the CPU SIMT emulator, NOT yet
+// measured on the hardware): the whole resize chain of a frame in ONE workgroup of 1024 threads -- levels 1 .. n-1 one after the
+// other with a workgroup barrier in between -- instead of seven dependent launches.  A frame's levels are produced and consumed by
+// the same CU (its writes go through to the XCD's L2, where the next level's reads find them), the six kernel boundaries with their
+// cache write-backs / invalidations and launch gaps disappear; the price is one workgroup per CU (16 of 32 wave slots) for the 256
+// frames of a batch.  grid (B), block 1024
+__global__ __launch_bounds__(1024) void k_pyr_chain(const LevelInfo *__restrict__ lv, int nlevels, const ResizeTap *__restrict__ xtab,
+                                                    const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg,
+                                                    uint8_t *__restrict__ pyr, size_t pyr_frame_stride) {
+    uint8_t *frame = pyr + (size_t)blockIdx.x * pyr_frame_stride;
+    for (int l = 1; l < nlevels; l++) {
+        const LevelInfo L = lv[l], P = lv[l - 1];
+        const int wpc = L.pitch >> 3, npg = (L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows;
+        const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)wpc - 1u) / (uint32_t)wpc);   // wave-uniform: scalar unit
+        for (int it = threadIdx.x; it < wpc * npg; it += 1024) {
+            const int pg = (int)__umulhi((uint32_t)it, rcp), wg = it - (int)__umul24((uint32_t)pg, (uint32_t)wpc);
+            resize2_item(L, P, xtab, ytab, xg, frame, pg, wg);
+        }
+        __threadfence_block();   // this level's stores before the next level's loads (same workgroup, same CU)
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -688,6 +688,92 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
     }
 }
 
+// k_grid_build2 (ORBX_GRID_BUILD=2; written at the end of round 2, verified against the oracle through the matcher tests under the CPU
+// SIMT emulator, NOT yet measured on the hardware): the same grid with the wave's lifetime cut down -- k_grid_build spends its 51 us in
+// 32 dependent keypoint round trips (one per 64 features and pass) and in a 64-step shuffle loop per chunk for the rank inside a cell.
+// Here eight keypoints per lane are in flight at once (two round trips per 512 features and pass) and the lanes of a chunk that share
+// a cell are placed by claim rounds (LDS atomicMin of the lane id: the lowest lane wins, takes the cell's cursor and drops out;
+// as many rounds as the largest multiplicity inside the chunk, usually one or two), which keeps insertion order.
+// grid (n_problems), block 64
+__global__ __launch_bounds__(64) void k_grid_build2(const WindowProblem *__restrict__ probs, GridParams g) {
+    __shared__ uint16_t cnt[kGridCells];
+    __shared__ uint16_t start[kGridCells];
+    __shared__ uint32_t claim[kGridCells];
+    const WindowProblem P = probs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = *P.n_ptr;
+    for (int i = lane; i < kGridCells; i += 64) { cnt[i] = 0; claim[i] = 0xffffffffu; }
+    __syncthreads();
+    auto cell_of = [&](float x, float y) -> int {   // PosInGrid (Frame.cc:725-735); -1 = outside the grid
+        const int px = (int)roundf((x - g.minx) * g.inv_w), py = (int)roundf((y - g.miny) * g.inv_h);
+        return (px >= 0 && px < 64 && py >= 0 && py < 48) ? px * 48 + py : -1;
+    };
+    // pass 1: cell histogram (16-bit LDS counters packed in pairs: 32-bit atomics on the containing word)
+    uint32_t *cnt32 = reinterpret_cast<uint32_t *>(cnt);
+    for (int i0 = 0; i0 < n; i0 += 8 * 64) {
+        float2 xy[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + 64 * k + lane;
+            xy[k] = float2{-1e30f, -1e30f};
+            if (i < n) __builtin_memcpy(&xy[k], &P.kps[i].x, 8);   // x, y: the first two fields (4-byte aligned records)
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = cell_of(xy[k].x, xy[k].y);
+            if (c >= 0) atomicAdd(&cnt32[c >> 1], (c & 1) ? 0x10000u : 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the 3072 counters (48 per lane, then a wave scan of the lane totals)
+    int lane_tot = 0;
+    for (int k = 0; k < kGridCells / 64; k++) lane_tot += cnt[lane * (kGridCells / 64) + k];
+    int incl = lane_tot;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int t = __shfl_up(incl, s);
+        if (lane >= s) incl += t;
+    }
+    int run = incl - lane_tot;
+    for (int k = 0; k < kGridCells / 64; k++) {
+        const int c = lane * (kGridCells / 64) + k;
+        start[c] = (uint16_t)run;
+        P.gstart[c] = (uint16_t)run;
+        run += cnt[c];
+    }
+    if (lane == 63) P.gstart[kGridCells] = (uint16_t)run;
+    __syncthreads();
+    // pass 2: stable fill, 64 features at a time in index order (eight chunks loaded per round trip)
+    for (int i0 = 0; i0 < n; i0 += 8 * 64) {
+        float2 xy[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + 64 * k + lane;
+            xy[k] = float2{-1e30f, -1e30f};
+            if (i < n) __builtin_memcpy(&xy[k], &P.kps[i].x, 8);   // x, y: the first two fields (4-byte aligned records)
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + 64 * k + lane;
+            const int c = cell_of(xy[k].x, xy[k].y);
+            bool todo = c >= 0;
+            while (__ballot(todo)) {   // wave-uniform: one round per multiplicity of the most crowded cell of this chunk
+                if (todo) atomicMin(&claim[c], (uint32_t)lane);
+                __syncthreads();
+                const bool won = todo && claim[c] == (uint32_t)lane;
+                __syncthreads();
+                if (won) {
+                    P.gorder[start[c]] = (uint16_t)i;
+                    start[c] = (uint16_t)(start[c] + 1);
+                    claim[c] = 0xffffffffu;
+                    todo = false;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // Search windows of SearchByProjection(Frame, MapPoints) (ORBmatcher.cc:53-72) for every (frame, map point) of a batch:
 // r = RadiusByViewingCos(viewCos) [* th if th != 1] * mvScaleFactors[nPredictedLevel], levels [level-1, level]; a map point
 // that is not in view (mbTrackInView false) or whose predicted level is out of range is skipped.

@@ -367,7 +367,15 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         return ORBX_OK;
     };
     { int r = blur_after_level(0); if (r != ORBX_OK) return r; }
-    for (int l = 1; l < nl; l++) {
+    // ORBX_PYR_CHAIN=1: levels 1 .. n-1 of a frame by one 1024-thread workgroup in one launch (k_pyr_chain; unmeasured, off)
+    static const bool pyr_chain = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return v && v[0] == '1'; }();
+    const bool chain = pyr_chain && !blur_follow && nl > 1;
+    if (chain) {
+        ProfScope ps(ex, K_PYR_RESIZE);
+        hipLaunchKernelGGL(k_pyr_chain, dim3(n), dim3(1024), 0, pst, d_lv, nl, (const ResizeTap *)ex->d_xtab.p, (const ResizeTap *)ex->d_ytab.p,
+                           (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame);
+    }
+    for (int l = 1; l < nl && !chain; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
         const dim3 grid = xcd_grid(((L.pitch / 4) * ((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255) / 256, n, pyr_local);

@@ -21,6 +21,16 @@ namespace {
 
 constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
+// ORBX_GRID_BUILD=2: k_grid_build2 (batched loads, claim rounds; unmeasured) instead of k_grid_build
+inline bool grid_build2() {
+    static const bool v = [] { const char *e = getenv("ORBX_GRID_BUILD"); return e && e[0] == '2'; }();
+    return v;
+}
+#define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...)                                   \
+    do {                                                                                       \
+        if (grid_build2()) hipLaunchKernelGGL(k_grid_build2, grid, block, lds, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__);           \
+    } while (0)
 // k_greedy_resolve re-scans a query's window through the frame's grid (ORBX_RESOLVE_RESCAN=full: over all features, the round-1 form)
 inline int resolve_grid_rescan() {
     static const int v = [] { const char *e = getenv("ORBX_RESOLVE_RESCAN"); return (e && e[0] == 'f') ? 0 : 1; }();
@@ -387,7 +397,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     g.minx = F->min_x; g.miny = F->min_y;
     g.inv_w = 64.0f / (F->max_x - F->min_x);  // Frame.cc:342-343
     g.inv_h = 48.0f / (F->max_y - F->min_y);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(64), 0, m->stream, dP, g);
+    ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->stream, dP, g);
     hipLaunchKernelGGL(k_window_best2, dim3((nq + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
@@ -528,7 +538,7 @@ int run_projection_twin(orbx_matcher *m, const TwinArgs &a) {
     g.minx = F->min_x; g.miny = F->min_y;
     g.inv_w = 64.0f / (F->max_x - F->min_x);
     g.inv_h = 48.0f / (F->max_y - F->min_y);
-    hipLaunchKernelGGL(k_grid_build, dim3(2), dim3(64), 0, m->stream, dP, g);
+    ORBX_LAUNCH_GRID_BUILD( dim3(2), dim3(64), 0, m->stream, dP, g);
     hipLaunchKernelGGL(k_window_best2, dim3((nq + 15) / 16, 2), dim3(256), 0, m->stream, dP, g);
     const size_t lds = ((size_t)N + 63) & ~(size_t)63;
     hipLaunchKernelGGL(k_replay_twin, dim3(1), dim3(64), lds, m->stream, dP, T, g);
@@ -980,7 +990,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     if (side) ORBX_HIP(hipStreamWaitEvent(ms, ex->ev_describe, 0));
     hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
     if (ex->profile) (void)hipEventRecord(e0, ms);
-    hipLaunchKernelGGL(k_grid_build, dim3(np), dim3(64), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
+    ORBX_LAUNCH_GRID_BUILD( dim3(np), dim3(64), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
     hipLaunchKernelGGL(k_window_best2, dim3((cap + 15) / 16, np), dim3(256), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
     if (ex->profile) {
         (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
@@ -1094,7 +1104,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
         hipLaunchKernelGGL(k_mappoint_windows, dim3((n_mp + 255) / 256, n), dim3(256), 0, ms, n_mp, d_level, d_view_cos, d_in_view,
                            (const float *)((const uint8_t *)ex->d_mp_misc.p + 256), ex->prm.nlevels, th, (float *)ex->d_mp_qr.p,
                            (int32_t *)ex->d_mp_qmin.p, (int32_t *)ex->d_mp_qmax.p, (uint8_t *)ex->d_mp_valid.p);
-    hipLaunchKernelGGL(k_grid_build, dim3(n), dim3(64), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
+    ORBX_LAUNCH_GRID_BUILD( dim3(n), dim3(64), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (n_mp > 0)
         hipLaunchKernelGGL(k_window_best2, dim3((n_mp + 15) / 16, n), dim3(256), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (resolve_lds_bytes(cap) > 64 * 1024)
@@ -1419,7 +1429,7 @@ extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, cons
     g.minx = kf->min_x; g.miny = kf->min_y;
     g.inv_w = 64.0f / (kf->max_x - kf->min_x);
     g.inv_h = 48.0f / (kf->max_y - kf->min_y);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(64), 0, m->stream, dP, g);
+    ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->stream, dP, g);
     hipLaunchKernelGGL(k_window_best2, dim3((n_q + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
     std::vector<u64> keys((size_t)n_q * kTopK);
     D2H(keys.data(), P.keys, 8 * (size_t)n_q * kTopK);

@@ -13,7 +13,7 @@ void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std
     if (trace) fprintf(stderr, "simt: %s grid (%u, %u, %u) block %u lds %zu\n", name, grid.x, grid.y, grid.z, block.x, lds_bytes);
     if (lds_bytes > 200 * 1024) { fprintf(stderr, "simt: %zu bytes of dynamic LDS\n", lds_bytes); abort(); }
     const int nthreads = (int)(block.x * block.y * block.z);
-    if (nthreads > 256) { fprintf(stderr, "simt: %d threads per block\n", nthreads); abort(); }
+    if (nthreads > 1024) { fprintf(stderr, "simt: %d threads per block\n", nthreads); abort(); }
     Dim3 g; g.x = grid.x; g.y = grid.y; g.z = grid.z;
     for (unsigned z = 0; z < grid.z; z++)
         for (unsigned y = 0; y < grid.y; y++)

@@ -41,17 +41,18 @@ struct Fiber {
 };
 constexpr size_t kFiberStack = 192 * 1024;
 inline char *fiber_stack(int t) {   // stacks are reused by every block (not zeroed)
-    static char *pool = (char *)aligned_alloc(4096, 256 * kFiberStack);
+    static char *pool = (char *)aligned_alloc(4096, 1024 * kFiberStack);
     return pool + (size_t)t * kFiberStack;
 }
 
 struct Rendezvous {   // one per wave (64 lanes) and one per workgroup
+    int n = 64;           // slots in use (64 for a wave, the block size for the workgroup)
     int waiting = 0;
     unsigned long long generation = 0;
-    uint64_t slot[256];
-    uint8_t present[256];
-    uint64_t result[2][256];
-    uint8_t rpresent[2][256];
+    uint64_t slot[1024];
+    uint8_t present[1024];
+    uint64_t result[2][1024];
+    uint8_t rpresent[2][1024];
 };
 
 struct Block {
@@ -60,9 +61,9 @@ struct Block {
     ucontext_t sched;
     int cur = -1;
     int alive_block = 0;
-    int alive_wave[4] = {0, 0, 0, 0};
-    Rendezvous wave_rv[4], block_rv;
-    std::vector<std::pair<uint32_t *, uint32_t>> deferred[4];   // per wave: additions that take effect at its next collective
+    int alive_wave[16] = {0};
+    Rendezvous wave_rv[16], block_rv;
+    std::vector<std::pair<uint32_t *, uint32_t>> deferred[16];   // per wave: additions that take effect at its next collective
     unsigned long long progress = 0;
     Dim3 block_idx, grid_dim;
     std::function<void()> body;
@@ -82,9 +83,9 @@ inline void try_complete(Rendezvous &rv, int alive) {
     if (rv.waiting > 0 && rv.waiting == alive) {
         apply_deferred(rv);
         const int g = (int)(rv.generation & 1);
-        memcpy(rv.result[g], rv.slot, sizeof(rv.slot));
-        memcpy(rv.rpresent[g], rv.present, sizeof(rv.present));
-        memset(rv.present, 0, sizeof(rv.present));
+        memcpy(rv.result[g], rv.slot, sizeof(uint64_t) * (size_t)rv.n);
+        memcpy(rv.rpresent[g], rv.present, (size_t)rv.n);
+        memset(rv.present, 0, (size_t)rv.n);
         rv.waiting = 0;
         rv.generation++;
         blk()->progress++;
@@ -93,7 +94,7 @@ inline void try_complete(Rendezvous &rv, int alive) {
 
 inline void apply_deferred(Rendezvous &rv) {
     Block *b = blk();
-    for (int w = 0; w < 4; w++)
+    for (int w = 0; w < 16; w++)
         if (&rv == &b->wave_rv[w] || &rv == &b->block_rv) {
             for (auto &d : b->deferred[w]) *d.first += d.second;
             b->deferred[w].clear();
@@ -154,7 +155,9 @@ inline void run_block(Dim3 grid, Dim3 bidx, int nthreads, const std::function<vo
     b->fibers.resize(nthreads);
     b->alive_block = nthreads;
     for (int t = 0; t < nthreads; t++) b->alive_wave[t >> 6]++;
-    for (auto *rv : {&b->wave_rv[0], &b->wave_rv[1], &b->wave_rv[2], &b->wave_rv[3], &b->block_rv}) memset(rv->present, 0, sizeof(rv->present));
+    for (int w = 0; w < 16; w++) memset(b->wave_rv[w].present, 0, sizeof(b->wave_rv[w].present));
+    memset(b->block_rv.present, 0, sizeof(b->block_rv.present));
+    b->block_rv.n = nthreads;
     for (int t = 0; t < nthreads; t++) {
         Fiber &f = b->fibers[t];
         f.tid = t;
@@ -171,7 +174,8 @@ inline void run_block(Dim3 grid, Dim3 bidx, int nthreads, const std::function<vo
     const int nwaves = (nthreads + 63) / 64;
     while (b->alive_block > 0) {
         const unsigned long long before = b->progress;
-        int order[4] = {0, 1, 2, 3};
+        int order[16];
+        for (int i = 0; i < 16; i++) order[i] = i;
         if (shuffle_env)
             for (int i = nwaves - 1; i > 0; i--) {
                 rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;

@@ -48,10 +48,11 @@ print('emulation ok', n)
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"SIMT_SHUFFLE": "7"}, {"SIMT_LDS_RANDOM": "3"}])
+@pytest.mark.parametrize("env", [{}, {"SIMT_SHUFFLE": "7"}, {"SIMT_LDS_RANDOM": "3"}, {"ORBX_PYR_CHAIN": "1", "SIMT_SHUFFLE": "5"}])
 def test_emulated_extractor_small_image_stagewise(emul_lib, env):
     """Pyramid, blur, FAST candidates, quad-tree output, keypoints and descriptors of the emulated device code == oracle; also with the
-    waves of every workgroup resumed in random order and with random garbage in the dynamic LDS."""
+    waves of every workgroup resumed in random order, with random garbage in the dynamic LDS, and with the chained pyramid kernel
+    (k_pyr_chain: 16 waves per workgroup, levels separated by a workgroup barrier only)."""
     _child(STAGEWISE.replace("IMG", "synth.make_test_image(5, 320, 240)").replace("NF", "500"), env)
 
 
@@ -63,10 +64,12 @@ def test_emulated_extractor_open_issue_image(emul_lib):
     assert "emulation ok 1008" in out
 
 
-def test_emulated_batch_pipeline_with_matcher(emul_lib):
+@pytest.mark.parametrize("env", [{}, {"ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full"}])
+def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     """Two 8-frame batches (from 8 frames on a frame's workgroups are mapped to one XCD: grid (8, blocks, frames / 8)) through
     extract_batch_device / extract_batch_host, the batched frame-to-frame matcher (grid build, window scan, greedy replay with its
-    grid re-scan) and the asynchronous download: every frame and every match vector == oracle."""
+    grid re-scan) and the asynchronous download: every frame and every match vector == oracle.  Second run: k_grid_build2 and the
+    full-frame re-scan of k_greedy_resolve."""
     _child("""
 W, H, NF, B = 480, 360, 600, 8
 canvases = [synth.make_canvas(10, size=1024, n_shapes=700), synth.make_canvas(11, size=1024, n_shapes=700)]
@@ -96,7 +99,7 @@ for i in range(2):
             assert int(hs['nm'][f]) == on and np.array_equal(hs['match'][f, :len(k)], ocm) and on > 100, (i, f, on)
         prev = (k, d)
 print('emulation ok')
-""")
+""", env)
 
 
 def test_emulated_quadtree_under_wave_shuffle(emul_lib):
