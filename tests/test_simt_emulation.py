@@ -64,13 +64,7 @@ def test_emulated_extractor_open_issue_image(emul_lib):
     assert "emulation ok 1008" in out
 
 
-@pytest.mark.parametrize("env", [{}, {"ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full"}])
-def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
-    """Two 8-frame batches (from 8 frames on a frame's workgroups are mapped to one XCD: grid (8, blocks, frames / 8)) through
-    extract_batch_device / extract_batch_host, the batched frame-to-frame matcher (grid build, window scan, greedy replay with its
-    grid re-scan) and the asynchronous download: every frame and every match vector == oracle.  Second run: k_grid_build2 and the
-    full-frame re-scan of k_greedy_resolve."""
-    _child("""
+PIPELINE = """
 W, H, NF, B = 480, 360, 600, 8
 canvases = [synth.make_canvas(10, size=1024, n_shapes=700), synth.make_canvas(11, size=1024, n_shapes=700)]
 sets = [np.ascontiguousarray(np.stack([synth.frame_from_canvas(c, t, W, H, 1000 * (10 + i) + t) for t in range(B)])) for i, c in enumerate(canvases)]
@@ -99,7 +93,16 @@ for i in range(2):
             assert int(hs['nm'][f]) == on and np.array_equal(hs['match'][f, :len(k)], ocm) and on > 100, (i, f, on)
         prev = (k, d)
 print('emulation ok')
-""", env)
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full"}])
+def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
+    """Two 8-frame batches (from 8 frames on a frame's workgroups are mapped to one XCD: grid (8, blocks, frames / 8)) through
+    extract_batch_device / extract_batch_host, the batched frame-to-frame matcher (grid build, window scan, greedy replay with its
+    grid re-scan) and the asynchronous download: every frame and every match vector == oracle.  Second run: k_grid_build2 and the
+    full-frame re-scan of k_greedy_resolve."""
+    _child(PIPELINE, env)
 
 
 def test_emulated_quadtree_under_wave_shuffle(emul_lib):
@@ -128,3 +131,17 @@ for seed, size, shapes in ((11, 1024, 700), (10, 2048, 2400), (33, 1536, 4000)):
 print('emulation ok', runs)
 """ % str(SIMT / "build" / "liboctree_emul.so")
     _child(code, {"SIMT_SHUFFLE": "11"})
+
+
+SWITCHES = [{"ORBX_BLUR_KERNEL": "0"}, {"ORBX_RESIZE_COLS": "1"}, {"ORBX_RESIZE_COLS": "1", "ORBX_RESIZE_PK": "0"}, {"ORBX_PYR_XCD": "0"},
+            {"ORBX_PYR_AHEAD": "2"}, {"ORBX_PYR_AHEAD": "1"}, {"ORBX_COPY_AFTER_MATCH": "1"}, {"ORBX_SIDE_STREAMS": "0"}, {"ORBX_BLUR_SIDE": "0"},
+            {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_INI": "0"}, {"ORBX_FAST_TPB": "256"}, {"ORBX_BLUR_GROUPS": "3"}, {"ORBX_FAST_INI_QCAP": "48"},
+            {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_PYR_CHAIN": "1"}]
+
+
+@pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): about ten minutes")
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_emulated_switch_matrix(emul_lib, env):
+    """Every alternative kernel / scheduling switch of DESIGN.md section 6 through the two-batch pipeline under emulation (their LOGIC:
+    slab toggling, grids, the older kernels).  All sixteen passed at the end of round 2."""
+    _child(PIPELINE, env)
