@@ -19,32 +19,49 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+namespace simt { void sync_all(); }
+inline hipError_t hipDeviceSynchronize() { simt::sync_all(); return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
-inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)malloc(8); return hipSuccess; }
-inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
-inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
-inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
-inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+// ---- streams and events.  Default: every operation completes before the call returns.  SIMT_STREAM_FUZZ=<seed>: operations are
+// QUEUED per stream and executed, at synchronisation points, in a RANDOM order among all orders the recorded dependencies allow
+// (in-order per stream, hipStreamWaitEvent edges) -- a result that changes with the seed is a missing dependency between streams.
+namespace simt {
+struct Rt;
+Rt &rt();
+bool fuzz();
+void enqueue(hipStream_t s, std::function<void()> op);
+void record(hipEvent_t e, hipStream_t s);
+void wait_event(hipStream_t s, hipEvent_t e);
+void sync_stream(hipStream_t s);
+void sync_event(hipEvent_t e);
+void sync_all();
+hipStream_t new_stream();
+hipEvent_t new_event();
+}
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = simt::new_stream(); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = simt::new_stream(); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = simt::new_stream(); return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { simt::sync_stream(s); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t s) { simt::sync_stream(s); return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { simt::wait_event(s, e); return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = simt::new_event(); return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = simt::new_event(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { simt::sync_event(e); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { simt::record(e, s); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t e) { simt::sync_event(e); return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
-inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipFree(void *p) { simt::sync_all(); free(p); return hipSuccess; }   // hipFree synchronises the device
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s) { simt::enqueue(s, [=] { memset(p, v, n); }); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
-    for (size_t y = 0; y < h; y++) memmove((char *)d + y * dp, (const char *)s + y * sp, w);
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st) { simt::enqueue(st, [=] { memmove(d, s, n); }); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t st) {
+    simt::enqueue(st, [=] { for (size_t y = 0; y < h; y++) memmove((char *)d + y * dp, (const char *)s + y * sp, w); });
     return hipSuccess;
 }
 inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {   // every pointer counts as pinned host memory
@@ -71,5 +88,13 @@ inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size
 namespace simt {
 void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body);
 }
+#include <tuple>
+namespace simt {
+template <typename F, typename... A>
+inline void launch_on(hipStream_t st, const char *name, dim3 grid, dim3 block, size_t lds, F kernel, A... args) {
+    auto tup = std::make_tuple(args...);   // kernel arguments are evaluated and copied at the launch call, as on the real runtime
+    enqueue(st, [=] { launch(name, grid, block, lds, [&] { std::apply(kernel, tup); }); });
+}
+}
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-    simt::launch(#kernel, dim3(grid), dim3(block), (size_t)(lds), [&] { kernel(__VA_ARGS__); })
+    simt::launch_on(stream, #kernel, dim3(grid), dim3(block), (size_t)(lds), kernel, __VA_ARGS__)

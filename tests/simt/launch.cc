@@ -31,3 +31,81 @@ void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std
             }
 }
 }  // namespace simt
+
+// ---- stream / event runtime ------------------------------------------------------------------------------------------------------
+#include <deque>
+#include <map>
+struct simt_event { unsigned long long recorded = 0, done = 0; };   // tickets: number of records issued / executed
+struct simt_stream {
+    struct Op { std::function<void()> fn; simt_event *wait = nullptr; unsigned long long wait_ticket = 0; simt_event *rec = nullptr; unsigned long long rec_ticket = 0; };
+    std::deque<Op> q;
+};
+namespace simt {
+struct Rt {
+    std::vector<simt_stream *> streams;
+    bool fuzz = false;
+    int policy = 0;   // 0 random, 1 = the stream created first that can run (the main stream runs ahead, side streams starve), 2 = the last
+    unsigned long long rng = 0;
+    Rt() {
+        if (const char *e = getenv("SIMT_STREAM_FUZZ")) {
+            fuzz = true;
+            if (!strcmp(e, "first")) policy = 1;
+            else if (!strcmp(e, "last")) policy = 2;
+            else rng = strtoull(e, nullptr, 10) * 0x9E3779B97F4A7C15ull + 12345;
+        }
+    }
+    unsigned next() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (unsigned)(rng >> 11); }
+};
+Rt &rt() { static Rt r; return r; }
+bool fuzz() { return rt().fuzz; }
+hipStream_t new_stream() { auto *s = new simt_stream(); rt().streams.push_back(s); return s; }
+hipEvent_t new_event() { return new simt_event(); }
+static bool runnable(const simt_stream::Op &op) { return !op.wait || op.wait->done >= op.wait_ticket; }
+static void run_op(simt_stream *s) {
+    simt_stream::Op op = std::move(s->q.front());
+    s->q.pop_front();
+    if (op.fn) op.fn();
+    if (op.rec) op.rec->done = std::max(op.rec->done, op.rec_ticket);
+}
+// one scheduling step: a random stream whose head operation may run; false if nothing can
+static bool step() {
+    Rt &r = rt();
+    std::vector<simt_stream *> ready;
+    for (auto *s : r.streams) if (!s->q.empty() && runnable(s->q.front())) ready.push_back(s);
+    if (ready.empty()) return false;
+    run_op(r.policy == 1 ? ready.front() : r.policy == 2 ? ready.back() : ready[r.next() % ready.size()]);
+    return true;
+}
+static void stall() { fprintf(stderr, "simt: stream deadlock (an operation waits for an event record that is not queued)\n"); abort(); }
+void enqueue(hipStream_t s, std::function<void()> op) {
+    if (!rt().fuzz || !s) { op(); return; }   // default, and the legacy null stream: immediate
+    simt_stream::Op o; o.fn = std::move(op); s->q.push_back(std::move(o));
+}
+void record(hipEvent_t e, hipStream_t s) {
+    if (!e) return;
+    e->recorded++;
+    if (!rt().fuzz || !s) { e->done = e->recorded; return; }
+    simt_stream::Op o; o.rec = e; o.rec_ticket = e->recorded; s->q.push_back(std::move(o));
+}
+void wait_event(hipStream_t s, hipEvent_t e) {   // waits for the records issued so far (none recorded: no wait)
+    if (!rt().fuzz || !s || !e || e->recorded == 0) return;
+    simt_stream::Op o; o.wait = e; o.wait_ticket = e->recorded; s->q.push_back(std::move(o));
+}
+void sync_stream(hipStream_t s) {
+    if (!rt().fuzz || !s) return;
+    while (!s->q.empty()) if (!step()) stall();
+}
+void sync_event(hipEvent_t e) {
+    if (!rt().fuzz || !e) return;
+    while (e->done < e->recorded) if (!step()) stall();
+}
+void sync_all() {
+    if (!rt().fuzz) return;
+    for (;;) {
+        bool any = false;
+        for (auto *s : rt().streams) any = any || !s->q.empty();
+        if (!any) return;
+        if (!step()) stall();
+    }
+}
+}  // namespace simt

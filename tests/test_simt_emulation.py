@@ -48,7 +48,7 @@ print('emulation ok', n)
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"SIMT_SHUFFLE": "7"}, {"SIMT_LDS_RANDOM": "3"}, {"ORBX_PYR_CHAIN": "1", "SIMT_SHUFFLE": "5"}])
+@pytest.mark.parametrize("env", [{"SIMT_SHUFFLE": "7"}, {"SIMT_LDS_RANDOM": "3", "ORBX_PYR_CHAIN": "1", "SIMT_SHUFFLE": "5"}])
 def test_emulated_extractor_small_image_stagewise(emul_lib, env):
     """Pyramid, blur, FAST candidates, quad-tree output, keypoints and descriptors of the emulated device code == oracle; also with the
     waves of every workgroup resumed in random order, with random garbage in the dynamic LDS, and with the chained pyramid kernel
@@ -65,7 +65,8 @@ def test_emulated_extractor_open_issue_image(emul_lib):
 
 
 PIPELINE = """
-W, H, NF, B = 480, 360, 600, 8
+# the bench's loop shape: two batches in flight (enqueue i, then wait for i - 1), alternating inputs and entry points
+W, H, NF, B, STEPS = 480, 360, 600, 8, 3
 canvases = [synth.make_canvas(10, size=1024, n_shapes=700), synth.make_canvas(11, size=1024, n_shapes=700)]
 sets = [np.ascontiguousarray(np.stack([synth.frame_from_canvas(c, t, W, H, 1000 * (10 + i) + t) for t in range(B)])) for i, c in enumerate(canvases)]
 ex = osa.ORBextractor(NF, 1.2, 8, 20, 7)
@@ -73,64 +74,55 @@ oex = ob.OracleExtractor(NF, 1.2, 8, 20, 7)
 sf = oex.tables()["scale"]
 cap = ex.output_capacity(W, H)
 P = lambda a: a.ctypes.data
+host = [dict(kps=np.zeros((B, cap, 28), np.uint8), desc=np.zeros((B, cap, 32), np.uint8), cnt=np.zeros(B, np.int32), mono=np.zeros(B, np.int32),
+             match=np.zeros((B, cap), np.int32), nm=np.zeros(B, np.int32)) for _ in range(2)]
+want = []
 for i in range(2):
-    hs = dict(kps=np.zeros((B, cap, 28), np.uint8), desc=np.zeros((B, cap, 32), np.uint8), cnt=np.zeros(B, np.int32), mono=np.zeros(B, np.int32),
-              match=np.zeros((B, cap), np.int32), nm=np.zeros(B, np.int32))
-    (ex.extract_batch_host if i else ex.extract_batch_device)(P(sets[i]), B, W, H, W, W * H, (0, 1000))
-    ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
-    ex.download_async(P(hs['kps']), P(hs['desc']), P(hs['cnt']), P(hs['mono']), P(hs['match']), P(hs['nm']))
-    ex.download_wait()
-    prev = None
+    fr, prev = [], None
     for f in range(B):
         mono, k, d = oex.extract(sets[i][f], lap=(0, 1000))
-        n = int(hs['cnt'][f])
-        assert n == len(k) and int(hs['mono'][f]) == mono and hs['kps'][f, :n].tobytes() == k.tobytes() and np.array_equal(hs['desc'][f, :n], d), (i, f)
+        m = None
         if prev is not None:
             k0, d0 = prev
             q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"], desc=d0,
                      has_obs=np.ones(len(k0), np.uint8))
-            on, ocm = ob.search_by_projection_frame(ob.OracleGrid(k, 0.0, float(W), 0.0, float(H)), d, sf, q, 15.0, 0, True, None, None)
-            assert int(hs['nm'][f]) == on and np.array_equal(hs['match'][f, :len(k)], ocm) and on > 100, (i, f, on)
+            m = ob.search_by_projection_frame(ob.OracleGrid(k, 0.0, float(W), 0.0, float(H)), d, sf, q, 15.0, 0, True, None, None)
+            assert m[0] > 100
+        fr.append((mono, k, d, m))
         prev = (k, d)
+    want.append(fr)
+for i in range(STEPS + 1):
+    if i < STEPS:
+        hs = host[i % 2]
+        (ex.extract_batch_host if (i // 2) % 2 else ex.extract_batch_device)(P(sets[i % 2]), B, W, H, W, W * H, (0, 1000))
+        ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        ex.download_async(P(hs['kps']), P(hs['desc']), P(hs['cnt']), P(hs['mono']), P(hs['match']), P(hs['nm']))
+    if i >= 1:
+        ex.download_wait()
+        j = i - 1
+        hs = host[j % 2]
+        for f in range(B):
+            mono, k, d, m = want[j % 2][f]
+            n = int(hs['cnt'][f])
+            assert n == len(k) and int(hs['mono'][f]) == mono and hs['kps'][f, :n].tobytes() == k.tobytes() and np.array_equal(hs['desc'][f, :n], d), (j, f, n, len(k))
+            assert m is None or (int(hs['nm'][f]) == m[0] and np.array_equal(hs['match'][f, :len(k)], m[1])), (j, f)
+ex.sync()
 print('emulation ok')
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full"}])
+@pytest.mark.parametrize("env", [{"SIMT_STREAM_FUZZ": "first"}, {"SIMT_STREAM_FUZZ": "last", "ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full"},
+                                 {"SIMT_STREAM_FUZZ": "7", "ORBX_PYR_CHAIN": "1"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "in-order")
 def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
-    """Two 8-frame batches (from 8 frames on a frame's workgroups are mapped to one XCD: grid (8, blocks, frames / 8)) through
-    extract_batch_device / extract_batch_host, the batched frame-to-frame matcher (grid build, window scan, greedy replay with its
-    grid re-scan) and the asynchronous download: every frame and every match vector == oracle.  Second run: k_grid_build2 and the
-    full-frame re-scan of k_greedy_resolve."""
+    """Three 8-frame batches, two in flight, through extract_batch_device / extract_batch_host (from 8 frames on a frame's workgroups
+    are mapped to one XCD), the batched frame-to-frame matcher (grid build, window scan, greedy replay with its grid re-scan) and the
+    asynchronous download: every frame and every match vector == oracle.  SIMT_STREAM_FUZZ: the stand-in runtime queues the
+    operations per stream and executes them in another order the recorded dependencies allow -- `first`: the main stream runs ahead
+    and the side streams starve until something waits for them, `last`: the reverse, a number: random -- so that a missing event
+    dependency between streams shows up as a wrong result (checked: with the main stream's waits for the matcher / the download
+    removed, `first` fails).  Also: k_grid_build2 + the full-frame re-scan, and the chained pyramid kernel."""
     _child(PIPELINE, env)
-
-
-def test_emulated_quadtree_under_wave_shuffle(emul_lib):
-    """The quad-tree body alone (tests/simt/octree_emul.cc), both forms, on the oracle's FAST candidates of several frames, every level,
-    with the waves of the workgroup resumed in a different random order every scheduler round: always the oracle's DistributeOctTree."""
-    code = """
-import ctypes as C
-L = C.CDLL(str(Path(%r)))
-L.simt_octree.restype = C.c_int
-pack = lambda c: (c['x'].astype(np.uint32) | (c['y'].astype(np.uint32) << 12) | (c['response'].astype(np.uint32) << 24)).astype(np.uint32)
-oex = ob.OracleExtractor(1000, 1.2, 8, 20, 7)
-quota = [217, 181, 151, 126, 105, 87, 73, 60]
-runs = 0
-for seed, size, shapes in ((11, 1024, 700), (10, 2048, 2400), (33, 1536, 4000)):
-    c = synth.make_canvas(seed, size=size, n_shapes=shapes)
-    for t in range(3):
-        oex.extract(synth.frame_from_canvas(c, t, 752, 480, 1000 * seed + t), lap=(0, 1000))
-        for l in range(8):
-            w, h = oex.level_size(l)
-            keys, want = pack(oex.level_candidates(l)), pack(oex.level_keypoints(l))
-            for form in (0, 0, 1):   # the 256-thread form twice (different wave orders), then the single-wave chunked form (k_octree_par1)
-                out = np.zeros(4096, np.uint32); err = C.c_int(0)
-                n = L.simt_octree(form, w, h, quota[l], keys.ctypes.data_as(C.c_void_p), len(keys), out.ctypes.data_as(C.c_void_p), 4096, C.byref(err))
-                assert n == len(want) and np.array_equal(out[:n], want) and err.value == 0, (seed, t, l, form, n, len(want), err.value)
-                runs += 1
-print('emulation ok', runs)
-""" % str(SIMT / "build" / "liboctree_emul.so")
-    _child(code, {"SIMT_SHUFFLE": "11"})
 
 
 SWITCHES = [{"ORBX_BLUR_KERNEL": "0"}, {"ORBX_RESIZE_COLS": "1"}, {"ORBX_RESIZE_COLS": "1", "ORBX_RESIZE_PK": "0"}, {"ORBX_PYR_XCD": "0"},
