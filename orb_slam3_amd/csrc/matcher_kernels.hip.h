@@ -807,6 +807,27 @@ __device__ __forceinline__ u64 seq_key(int dist, int seq, int idx) {
 // If a lane that saw more than two candidates has both of its entries extracted, later rounds could miss that lane's
 // third candidate, so the list is cut there (valid_len); `exhaustive` says the list holds every candidate of the
 // query.  k_greedy_resolve falls back to a re-scan when it needs more than the valid part of a non-exhaustive list.
+// reductions over the 16 lanes of one query = one DPP row: rotate the row by 8, 4, 2, 1 (row_ror) and combine -- every lane ends
+// up with the result, no LDS crossbar traffic (`__shfl_xor` is a ds_bpermute: an LDS round trip per step and operand)
+template <int N>
+__device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }
+__device__ __forceinline__ u64 row16_min(u64 m) {
+#define ROW16_MIN_STEP(N)                                                                                                  \
+    {                                                                                                                      \
+        const u64 o = ((u64)(uint32_t)row_ror<N>((int)(m >> 32)) << 32) | (uint32_t)row_ror<N>((int)(uint32_t)m);          \
+        m = o < m ? o : m;                                                                                                 \
+    }
+    ROW16_MIN_STEP(8) ROW16_MIN_STEP(4) ROW16_MIN_STEP(2) ROW16_MIN_STEP(1)
+#undef ROW16_MIN_STEP
+    return m;
+}
+__device__ __forceinline__ int row16_add(int v) { v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v); return v; }
+__device__ __forceinline__ int row16_or(int v) { v |= row_ror<8>(v); v |= row_ror<4>(v); v |= row_ror<2>(v); v |= row_ror<1>(v); return v; }
+
+// DPP = true (ORBX_WINDOW_DPP=1; written at the end of round 2, verified through the matcher tests under the CPU SIMT emulator, NOT yet
+// measured on the hardware): the 16-lane reductions of the top-4 extraction by DPP row rotations instead of ds_bpermute shuffles --
+// 12 u64 / int reductions per wave, about 40 % of the kernel's VALU instructions and all of its LDS traffic
+template <bool DPP>
 __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__restrict__ probs, GridParams g) {
     const WindowProblem P = probs[blockIdx.y];
     const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
@@ -875,18 +896,24 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
     }
     // reductions inside the 16-lane group (xor masks 8,4,2,1 stay inside the group)
     int total = cnt;
+    if (DPP) total = row16_add(total);
+    else {
 #pragma unroll
-    for (int s = 8; s > 0; s >>= 1) total += __shfl_xor(total, s);
+        for (int s = 8; s > 0; s >>= 1) total += __shfl_xor(total, s);
+    }
     u64 out[kTopK];
     int valid_len = 0, npop = 0;
     bool cut = false;
 #pragma unroll
     for (int r = 0; r < kTopK; r++) {
         u64 m = k1;
+        if (DPP) m = row16_min(m);
+        else {
 #pragma unroll
-        for (int s = 8; s > 0; s >>= 1) {
-            const u64 o = __shfl_xor(m, s);
-            m = o < m ? o : m;
+            for (int s = 8; s > 0; s >>= 1) {
+                const u64 o = __shfl_xor(m, s);
+                m = o < m ? o : m;
+            }
         }
         out[r] = m;
         if (m != kNoKey && !cut) valid_len = r + 1;
@@ -894,8 +921,11 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
         if (mine) { k1 = k2; k2 = kNoKey; npop++; }
         // a lane that ran dry while it had seen more than two candidates invalidates everything after this round
         int dry = (mine && npop == 2 && cnt > 2) ? 1 : 0;
+        if (DPP) dry = row16_or(dry);
+        else {
 #pragma unroll
-        for (int s = 8; s > 0; s >>= 1) dry |= __shfl_xor(dry, s);
+            for (int s = 8; s > 0; s >>= 1) dry |= __shfl_xor(dry, s);
+        }
         cut = cut || (dry != 0);
     }
     if (qvalid && sl == 0) {

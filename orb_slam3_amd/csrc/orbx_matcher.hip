@@ -31,6 +31,16 @@ inline bool grid_build2() {
         if (grid_build2()) hipLaunchKernelGGL(k_grid_build2, grid, block, lds, stream, __VA_ARGS__); \
         else hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__);           \
     } while (0)
+// ORBX_WINDOW_DPP=1: k_window_best2<true> (DPP row reductions; unmeasured) instead of the shuffle form
+inline bool window_dpp() {
+    static const bool v = [] { const char *e = getenv("ORBX_WINDOW_DPP"); return e && e[0] == '1'; }();
+    return v;
+}
+#define ORBX_LAUNCH_WINDOW_BEST2(grid, block, lds, stream, ...)                                          \
+    do {                                                                                                \
+        if (window_dpp()) hipLaunchKernelGGL(k_window_best2<true>, grid, block, lds, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(k_window_best2<false>, grid, block, lds, stream, __VA_ARGS__);           \
+    } while (0)
 // k_greedy_resolve re-scans a query's window through the frame's grid (ORBX_RESOLVE_RESCAN=full: over all features, the round-1 form)
 inline int resolve_grid_rescan() {
     static const int v = [] { const char *e = getenv("ORBX_RESOLVE_RESCAN"); return (e && e[0] == 'f') ? 0 : 1; }();
@@ -398,7 +408,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     g.inv_w = 64.0f / (F->max_x - F->min_x);  // Frame.cc:342-343
     g.inv_h = 48.0f / (F->max_y - F->min_y);
     ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->stream, dP, g);
-    hipLaunchKernelGGL(k_window_best2, dim3((nq + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2( dim3((nq + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n, resolve_grid_rescan());
@@ -539,7 +549,7 @@ int run_projection_twin(orbx_matcher *m, const TwinArgs &a) {
     g.inv_w = 64.0f / (F->max_x - F->min_x);
     g.inv_h = 48.0f / (F->max_y - F->min_y);
     ORBX_LAUNCH_GRID_BUILD( dim3(2), dim3(64), 0, m->stream, dP, g);
-    hipLaunchKernelGGL(k_window_best2, dim3((nq + 15) / 16, 2), dim3(256), 0, m->stream, dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2( dim3((nq + 15) / 16, 2), dim3(256), 0, m->stream, dP, g);
     const size_t lds = ((size_t)N + 63) & ~(size_t)63;
     hipLaunchKernelGGL(k_replay_twin, dim3(1), dim3(64), lds, m->stream, dP, T, g);
     int32_t nm = 0;
@@ -991,7 +1001,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
     if (ex->profile) (void)hipEventRecord(e0, ms);
     ORBX_LAUNCH_GRID_BUILD( dim3(np), dim3(64), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
-    hipLaunchKernelGGL(k_window_best2, dim3((cap + 15) / 16, np), dim3(256), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
+    ORBX_LAUNCH_WINDOW_BEST2( dim3((cap + 15) / 16, np), dim3(256), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
     if (ex->profile) {
         (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
         float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
@@ -1106,7 +1116,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
                            (int32_t *)ex->d_mp_qmin.p, (int32_t *)ex->d_mp_qmax.p, (uint8_t *)ex->d_mp_valid.p);
     ORBX_LAUNCH_GRID_BUILD( dim3(n), dim3(64), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (n_mp > 0)
-        hipLaunchKernelGGL(k_window_best2, dim3((n_mp + 15) / 16, n), dim3(256), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
+        ORBX_LAUNCH_WINDOW_BEST2( dim3((n_mp + 15) / 16, n), dim3(256), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (resolve_lds_bytes(cap) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
@@ -1430,7 +1440,7 @@ extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, cons
     g.inv_w = 64.0f / (kf->max_x - kf->min_x);
     g.inv_h = 48.0f / (kf->max_y - kf->min_y);
     ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->stream, dP, g);
-    hipLaunchKernelGGL(k_window_best2, dim3((n_q + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2( dim3((n_q + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
     std::vector<u64> keys((size_t)n_q * kTopK);
     D2H(keys.data(), P.keys, 8 * (size_t)n_q * kTopK);
     SYNC_AND_DELIVER();
