@@ -131,9 +131,9 @@ SWITCHES = [{"ORBX_BLUR_KERNEL": "0"}, {"ORBX_RESIZE_COLS": "1"}, {"ORBX_RESIZE_
             {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_PYR_CHAIN": "1"}, {"ORBX_GRID_BUILD": "2"}, {"ORBX_WINDOW_DPP": "1"}]
 
 
-@pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): about ten minutes")
+@pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): about fifteen minutes")
 @pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_emulated_switch_matrix(emul_lib, env):
     """Every alternative kernel / scheduling switch of DESIGN.md section 6 through the two-batch pipeline under emulation (their LOGIC:
-    slab toggling, grids, the older kernels).  All sixteen passed at the end of round 2."""
+    slab toggling, grids, the older kernels, the three kernels prepared for round 3).  All eighteen passed at the end of round 2."""
     _child(PIPELINE, env)
