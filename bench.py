@@ -465,7 +465,10 @@ def bench_euroc(R):
         feats = run(a.steps, from_host)
         return R.timed_end(t0, [ex]), feats
 
+    t_settle = time.perf_counter()
     run(a.settle, False)
+    R.barrier([ex])
+    settle_ms = (time.perf_counter() - t_settle) / max(a.settle, 1) * 1e3   # the fresh process's first steps: start-up transient included
     dt, feats = timed(False)
     enqueue_ms = host_enqueue[0] / a.steps * 1e3
     last = host[(a.steps - 1) % 2]
@@ -522,7 +525,7 @@ def bench_euroc(R):
                      "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{R.world} independent sequences, one per GPU"})
     out["data"] = data
     out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels,
-                "host_enqueue_ms_per_step": round(enqueue_ms, 3)})
+                "host_enqueue_ms_per_step": round(enqueue_ms, 3), "settle_ms_per_step": round(settle_ms, 3)})
     R.finish(out)
 
 
