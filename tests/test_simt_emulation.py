@@ -137,3 +137,15 @@ def test_emulated_switch_matrix(emul_lib, env):
     """Every alternative kernel / scheduling switch of DESIGN.md section 6 through the two-batch pipeline under emulation (their LOGIC:
     slab toggling, grids, the older kernels, the three kernels prepared for round 3).  All eighteen passed at the end of round 2."""
     _child(PIPELINE, env)
+
+
+@pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): about three minutes")
+@pytest.mark.parametrize("workload", ["euroc", "kitti", "tumvi"])
+def test_emulated_bench_line(emul_lib, workload):
+    """bench.py itself on the emulator (4 frames per step): settle / warm-up / timed loop, the parity self-check against the oracle and
+    the JSON line of every workload."""
+    import json
+    r = subprocess.run([sys.executable, str(SIMT / "bench_emul.py"), "--workload", workload], capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["parity_checked"] and line["settle_steps"] == 1 and line["value"] > 0
