@@ -149,3 +149,21 @@ def test_emulated_bench_line(emul_lib, workload):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["parity_checked"] and line["settle_steps"] == 1 and line["value"] > 0
+
+
+def test_reference_matcher_modules_through_adapter_and_emulated_kernels(emul_lib):
+    """The drop-in boundary against the REFERENCE on the CPU: the test modules that pin the oracle to the compiled reference ORBmatcher.cc
+    run unchanged through the reference-signature C++ adapter (oracle/_ref/libmatcher_adapter.so, orb_slam3_amd/cpp/ORBmatcher.h) ->
+    C ABI -> the device kernels under the emulator (LD_PRELOAD puts the emulated library's orbx_* symbols in front of liborbx.so's).
+    The GPU form of this test is tests/test_gpu_adapter_vs_reference.py."""
+    import re
+    adapter = ROOT / "oracle" / "_ref" / "libmatcher_adapter.so"
+    if not adapter.exists():
+        pytest.skip("oracle/_ref/libmatcher_adapter.so not built (needs /root/reference at build time)")
+    env = dict(os.environ, ORBX_MATCHER_BACKEND="adapter", LD_PRELOAD=str(emul_lib))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_oracle_matchers_vs_reference.py", "tests/test_oracle_matchers_small_cases.py",
+                        "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 17, tail
