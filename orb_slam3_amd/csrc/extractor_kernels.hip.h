@@ -325,12 +325,113 @@ __global__ __launch_bounds__(256) void k_pyr_resize2(const LevelInfo L, const Le
     resize2_item(L, P, xtab, ytab, xg, pyr + (size_t)f * pyr_frame_stride, pg, wg);
 }
 
+// The same for N work items at once (k_pyr_chain only; resize2_item above stays as measured): the table loads of all items, then the
+// source loads of all items, then the arithmetic -- N = 2 keeps two items' round trips in flight per thread
+template <int N>
+__device__ __forceinline__ void resize2_items(const LevelInfo &L, const LevelInfo &P, const ResizeTap *__restrict__ xtab,
+                                              const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg, uint8_t *frame,
+                                              const int (&pg)[N], const int (&wg)[N]) {
+    const int rows = L.h + 2 * kEdge;
+    const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX;  // previous level ROI origin
+    int py0[N];
+    bool live[N];
+    uint4 gh[N][2], gc[N][2];
+    ResizeTap ty[N][kResizeRows];
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        py0[n] = pg[n] * kResizeRows;
+        live[n] = py0[n] < rows;
+        const int wgl = live[n] ? wg[n] : 0, pyl = live[n] ? py0[n] : 0;   // a dead item (past the last row pair) loads item (0, 0) and stores nothing
+        const uint4 *gp = reinterpret_cast<const uint4 *>(&xg[L.xg_off + 2 * wgl]);   // two ResizeGroup entries = 64 contiguous bytes
+        gh[n][0] = gp[0]; gc[n][0] = gp[1]; gh[n][1] = gp[2]; gc[n][1] = gp[3];
+#pragma unroll
+        for (int r = 0; r < kResizeRows; r++) ty[n][r] = ytab[L.ytab_off + reflect101(min(pyl + r, rows - 1) - kEdge, L.h)];
+    }
+    if (N == 1 && !live[0]) return;
+    uint32_t so0[N][kResizeRows], so1[N][kResizeRows];   // byte offsets of the two source rows of each output row
+    // every source load of the thread before any arithmetic: one memory round trip
+    uint2 r0[N][2][kResizeRows], r1[N][2][kResizeRows];
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+#pragma unroll
+        for (int r = 0; r < kResizeRows; r++) {
+            const int sy0 = min(max(ty[n][r].ofs, 0), P.h - 1), sy1 = min(max(ty[n][r].ofs + 1, 0), P.h - 1);
+            so0[n][r] = __umul24((uint32_t)sy0, (uint32_t)P.pitch);
+            so1[n][r] = __umul24((uint32_t)sy1, (uint32_t)P.pitch);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int r = 0; r < kResizeRows; r++) {
+                // unconditional (a column without taps reads the row's first bytes and ignores them): loads inside divergent blocks make
+                // the compiler wait for ALL outstanding loads at every block boundary -- four round trips instead of one
+                const uint32_t gx = gh[n][c].z == 1 ? gh[n][c].x : 0u;
+                __builtin_memcpy(&r0[n][c][r], proi + (so0[n][r] + gx), 8);
+                __builtin_memcpy(&r1[n][c][r], proi + (so1[n][r] + gx), 8);
+            }
+    }
+    constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        uint32_t out[2][kResizeRows];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t selr = gh[n][c].y + 0x01010101u;
+            const uint32_t cc[4] = {gc[n][c].x, gc[n][c].y, gc[n][c].z, gc[n][c].w};
+#pragma unroll
+            for (int r = 0; r < kResizeRows; r++) {
+                uint32_t o = 0;   // gh.z == 2: pitch padding outside the ring, zeros
+                if (gh[n][c].z == 1) {
+                    const uint32_t l0 = __builtin_amdgcn_perm(r0[n][c][r].y, r0[n][c][r].x, gh[n][c].y), q0 = __builtin_amdgcn_perm(r0[n][c][r].y, r0[n][c][r].x, selr);
+                    const uint32_t l1 = __builtin_amdgcn_perm(r1[n][c][r].y, r1[n][c][r].x, gh[n][c].y), q1 = __builtin_amdgcn_perm(r1[n][c][r].y, r1[n][c][r].x, selr);
+                    const int b0 = ty[n][r].c0, b1 = ty[n][r].c1;   // bilinear tap pair: 0 <= b0, b1 <= 2048
+                    int t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t h0 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
+                        const uint32_t h1 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
+                        const uint32_t p0 = __umul24(h0 >> 4, (uint32_t)b0) + 0x20000u, p1 = __umul24(h1 >> 4, (uint32_t)b1);
+                        t[k] = (int)((p0 >> 16) + (p1 >> 16));
+                    }
+                    const uint32_t lo = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 2);
+                    const uint32_t hi = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 2);
+                    o = lo | (hi << 16);
+                } else if (gh[n][c].z == 0) {   // taps further apart than 8 bytes (scale factor > 2): table form, as in k_pyr_resize
+                    const uint8_t *S0 = proi + so0[n][r], *S1 = proi + so1[n][r];
+                    const int b0 = ty[n][r].c0, b1 = ty[n][r].c1;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int x = (2 * wg[n] + c) * 4 + k - kRoiX;
+                        if (x >= -kEdge && x < L.w + kEdge) {
+                            const ResizeTap tx = xtab[L.xtab_off + reflect101(x, L.w)];
+                            const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
+                            const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
+                            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                            v = min(max(v, 0), 255);
+                            o |= (uint32_t)v << (8 * k);
+                        }
+                    }
+                }
+                out[c][r] = o;
+            }
+        }
+        if (live[n]) {
+            uint8_t *drow = frame + L.off + (size_t)py0[n] * L.pitch + wg[n] * 8;
+#pragma unroll
+            for (int r = 0; r < kResizeRows; r++)
+                if (py0[n] + r < rows) *reinterpret_cast<uint2 *>(drow + (uint32_t)(r * L.pitch)) = make_uint2(out[0][r], out[1][r]);
+        }
+    }
+}
+
 // k_pyr_chain (ORBX_PYR_CHAIN=1; written at the end of round 2, verified against the oracle under the CPU SIMT emulator, NOT yet
 // measured on the hardware): the whole resize chain of a frame in ONE workgroup of 1024 threads -- levels 1 .. n-1 one after the
 // other with a workgroup barrier in between -- instead of seven dependent launches.  A frame's levels are produced and consumed by
 // the same CU (its writes go through to the XCD's L2, where the next level's reads find them), the six kernel boundaries with their
 // cache write-backs / invalidations and launch gaps disappear; the price is one workgroup per CU (16 of 32 wave slots) for the 256
-// frames of a batch.  grid (B), block 1024
+// frames of a batch.  ILP = 2: two work items per thread and iteration, their table and source round trips in flight together (the
+// kernel's time is the waves' lifetime at 4 waves per SIMD).  grid (B), block 1024
+template <int ILP>   // work items per thread and loop iteration (ORBX_PYR_CHAIN=1 / 2)
 __global__ __launch_bounds__(1024) void k_pyr_chain(const LevelInfo *__restrict__ lv, int nlevels, const ResizeTap *__restrict__ xtab,
                                                     const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg,
                                                     uint8_t *__restrict__ pyr, size_t pyr_frame_stride) {
@@ -339,9 +440,15 @@ __global__ __launch_bounds__(1024) void k_pyr_chain(const LevelInfo *__restrict_
         const LevelInfo L = lv[l], P = lv[l - 1];
         const int wpc = L.pitch >> 3, npg = (L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows;
         const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)wpc - 1u) / (uint32_t)wpc);   // wave-uniform: scalar unit
-        for (int it = threadIdx.x; it < wpc * npg; it += 1024) {
-            const int pg = (int)__umulhi((uint32_t)it, rcp), wg = it - (int)__umul24((uint32_t)pg, (uint32_t)wpc);
-            resize2_item(L, P, xtab, ytab, xg, frame, pg, wg);
+        for (int it0 = threadIdx.x; it0 < wpc * npg; it0 += 1024 * ILP) {
+            int pg[ILP], wg[ILP];
+#pragma unroll
+            for (int n = 0; n < ILP; n++) {
+                const int it = it0 + 1024 * n;   // past the end: pg >= npg, a dead item
+                pg[n] = (int)__umulhi((uint32_t)it, rcp);
+                wg[n] = it - (int)__umul24((uint32_t)pg[n], (uint32_t)wpc);
+            }
+            resize2_items<ILP>(L, P, xtab, ytab, xg, frame, pg, wg);
         }
         __threadfence_block();   // this level's stores before the next level's loads (same workgroup, same CU)
         __syncthreads();

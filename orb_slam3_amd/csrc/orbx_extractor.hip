@@ -368,12 +368,15 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     };
     { int r = blur_after_level(0); if (r != ORBX_OK) return r; }
     // ORBX_PYR_CHAIN=1: levels 1 .. n-1 of a frame by one 1024-thread workgroup in one launch (k_pyr_chain; unmeasured, off)
-    static const bool pyr_chain = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return v && v[0] == '1'; }();
+    static const int pyr_chain = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return (v && (v[0] == '1' || v[0] == '2')) ? v[0] - '0' : 0; }();
     const bool chain = pyr_chain && !blur_follow && nl > 1;
     if (chain) {
         ProfScope ps(ex, K_PYR_RESIZE);
-        hipLaunchKernelGGL(k_pyr_chain, dim3(n), dim3(1024), 0, pst, d_lv, nl, (const ResizeTap *)ex->d_xtab.p, (const ResizeTap *)ex->d_ytab.p,
-                           (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame);
+#define ORBX_PYR_CHAIN(ILP)                                                                                                              \
+    hipLaunchKernelGGL(k_pyr_chain<ILP>, dim3(n), dim3(1024), 0, pst, d_lv, nl, (const ResizeTap *)ex->d_xtab.p, (const ResizeTap *)ex->d_ytab.p, \
+                       (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame)
+        if (pyr_chain == 2) ORBX_PYR_CHAIN(2); else ORBX_PYR_CHAIN(1);
+#undef ORBX_PYR_CHAIN
     }
     for (int l = 1; l < nl && !chain; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);

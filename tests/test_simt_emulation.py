@@ -48,7 +48,7 @@ print('emulation ok', n)
 """
 
 
-@pytest.mark.parametrize("env", [{"SIMT_SHUFFLE": "7"}, {"SIMT_LDS_RANDOM": "3", "ORBX_PYR_CHAIN": "1", "SIMT_SHUFFLE": "5"}])
+@pytest.mark.parametrize("env", [{"SIMT_SHUFFLE": "7"}, {"SIMT_LDS_RANDOM": "3", "ORBX_PYR_CHAIN": "2", "SIMT_SHUFFLE": "5"}])
 def test_emulated_extractor_small_image_stagewise(emul_lib, env):
     """Pyramid, blur, FAST candidates, quad-tree output, keypoints and descriptors of the emulated device code == oracle; also with the
     waves of every workgroup resumed in random order, with random garbage in the dynamic LDS, and with the chained pyramid kernel
@@ -128,7 +128,7 @@ def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
 SWITCHES = [{"ORBX_BLUR_KERNEL": "0"}, {"ORBX_RESIZE_COLS": "1"}, {"ORBX_RESIZE_COLS": "1", "ORBX_RESIZE_PK": "0"}, {"ORBX_PYR_XCD": "0"},
             {"ORBX_PYR_AHEAD": "2"}, {"ORBX_PYR_AHEAD": "1"}, {"ORBX_COPY_AFTER_MATCH": "1"}, {"ORBX_SIDE_STREAMS": "0"}, {"ORBX_BLUR_SIDE": "0"},
             {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_INI": "0"}, {"ORBX_FAST_TPB": "256"}, {"ORBX_BLUR_GROUPS": "3"}, {"ORBX_FAST_INI_QCAP": "48"},
-            {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_PYR_CHAIN": "1"}, {"ORBX_GRID_BUILD": "2"}, {"ORBX_WINDOW_DPP": "1"}]
+            {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_PYR_CHAIN": "1"}, {"ORBX_PYR_CHAIN": "2"}, {"ORBX_GRID_BUILD": "2"}, {"ORBX_WINDOW_DPP": "1"}]
 
 
 @pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): about fifteen minutes")

@@ -12,5 +12,5 @@ timeout 200 python3 -m pytest tests/test_gpu_pipeline.py tests/test_gpu_extracto
 echo "open items rc=$?"; tail -40 gpurun_out/r03a/open.log
 ORBX_TEST_SWITCHES=1 timeout 240 python3 -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -k alternative_switches > gpurun_out/r03a/switches.log 2>&1
 echo "switches rc=$?"; tail -12 gpurun_out/r03a/switches.log
-bash tools/ab.sh "ORBX_NONE=1" "ORBX_PYR_CHAIN=1" "ORBX_GRID_BUILD=2" "ORBX_WINDOW_DPP=1" "ORBX_PYR_CHAIN=1 ORBX_GRID_BUILD=2 ORBX_WINDOW_DPP=1" 2>&1 | tee gpurun_out/r03a/ab.log
+bash tools/ab.sh "ORBX_NONE=1" "ORBX_PYR_CHAIN=1" "ORBX_PYR_CHAIN=2" "ORBX_GRID_BUILD=2" "ORBX_WINDOW_DPP=1" "ORBX_PYR_CHAIN=1 ORBX_GRID_BUILD=2 ORBX_WINDOW_DPP=1" 2>&1 | tee gpurun_out/r03a/ab.log
 ORBX_PYR_CHAIN=1 ORBX_GRID_BUILD=2 ORBX_WINDOW_DPP=1 bash tools/quick_prof.sh > /dev/null 2>&1; head -14 gpurun_out/qp/stats.csv | tee gpurun_out/r03a/prof_chain.log
