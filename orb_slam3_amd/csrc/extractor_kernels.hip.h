@@ -1464,6 +1464,56 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// Branch-free forms of the two functions above for k_describe2, where the two halves of a wave work on different keypoints and a
+// data-dependent branch would run both sides: the same operations in the same order, the variant picked by selects (checked against
+// the branching forms on the CPU: tests/simt, every float angle in [0, 360) degrees at 1e-4 steps and 10^7 integer moment pairs).
+__device__ __forceinline__ void glibc_sincosf_sel(float y, float *sn, float *cs) {
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
+    const bool small = top < 0x3f4, tiny = top < 0x398;
+    const double x0 = (double)y;
+    const double r = __dmul_rn(x0, 0x1.45F306DC9C883p+23);
+    const int n = small ? 0 : (((int32_t)r + 0x800000) >> 24);
+    const double xr = small ? x0 : __fma_rn(-(double)n, 0x1.921FB54442D18p0, x0);
+    const double x2 = __dmul_rn(xr, xr);
+    const bool neg = (n & 2) != 0;                           // table T1: c0, c1, c2, c3, c4 negated; s1 .. s3 unchanged
+    const double sg = neg ? -1.0 : 1.0;
+    const double c0 = sg * 0x1p0, c1 = sg * -0x1.ffffffd0c621cp-2, c2 = sg * 0x1.55553e1068f19p-5, c3 = sg * -0x1.6c087e89a359dp-10,
+                 c4 = sg * 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    const double xs = small ? xr : __dmul_rn(xr, sgn);        // |y| < pi/4 uses x itself (no multiplication by 1.0: same value)
+    // sin polynomial of xs, cos polynomial of x2 (sc_sin_poly / sc_cos_poly, operation for operation)
+    const double x3 = __dmul_rn(xs, x2);
+    const double sp1 = __fma_rn(x2, s3, s2);
+    const double x7 = __dmul_rn(x3, x2);
+    const double sp = __fma_rn(x3, s1, xs);
+    const float fs = (float)__fma_rn(x7, sp1, sp);
+    const double x4 = __dmul_rn(x2, x2);
+    const double cq2 = __fma_rn(x2, c4, c3);
+    const double cq1 = __fma_rn(x2, c1, c0);
+    const double x6 = __dmul_rn(x4, x2);
+    const double cq = __fma_rn(x4, c2, cq1);
+    const float fc = (float)__fma_rn(x6, cq2, cq);
+    const bool swap = (n & 1) != 0;                          // odd quadrant: sin <- cos polynomial, cos <- sin polynomial
+    *sn = tiny ? y : (swap ? fc : fs);
+    *cs = tiny ? 1.0f : (swap ? fs : fc);
+}
+__device__ __forceinline__ float fast_atan2_deg_sel(float y, float x) {
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
+                p7 = -0.04432655554792128f * scale;
+    const float eps = 2.2204460492503131e-16f;  // (float)DBL_EPSILON
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool xbig = ax >= ay;
+    const float c = __fdiv_rn(xbig ? ay : ax, __fadd_rn(xbig ? ax : ay, eps));
+    const float c2 = __fmul_rn(c, c);
+    float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    a = xbig ? a : __fsub_rn(90.f, a);
+    a = x < 0 ? __fsub_rn(180.f, a) : a;
+    a = y < 0 ? __fsub_rn(360.f, a) : a;
+    return a;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // One wave per keypoint: IC_Angle on the UNBLURRED level (:76-103), steered 256-pair BRIEF on the BLURRED level
 // (:107-146), keypoint record + descriptor written to the final slot.
@@ -1624,6 +1674,131 @@ __global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ 
         float x = (float)kx, y = (float)ky;
         if (w.level != 0) { x = __fmul_rn(x, L.scale); y = __fmul_rn(y, L.scale); }
         kp.x = x; kp.y = y; kp.size = L.size; kp.angle = angle; kp.response = (float)key_s(w.key);
+        kp.octave = w.level; kp.class_id = -1;
+        kps[slot] = kp;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// k_describe2 (ORBX_DESCRIBE=2; written at the end of round 2, verified against the oracle under the CPU SIMT emulator, NOT yet measured
+// on the hardware): TWO keypoints per wave, one per half (32 lanes).  k_describe is VALU-issue bound (151 of 192 us) and about a third
+// of its instructions are wave-uniform work the vector unit executes for 64 identical lanes (work-item unpacking, fastAtan2, the FP64
+// sincos); with one keypoint per half that work serves two keypoints at once, everything else costs the same per keypoint:
+//   disc  : lane = column u of the orientation disc, 31 row steps; per-half totals from one wave prefix sum (lanes 31 and 63)
+//   brief : lane i of a half evaluates pattern pairs i, i + 32, ..., i + 224; each of the 8 ballots holds one dword of BOTH descriptors
+//   the two branches of fastAtan2 / sincosf become selects (glibc_sincosf_sel, fast_atan2_deg_sel: bit-identical, checked on the CPU)
+// Patches are staged by plain loads (a frame-uniform base + a 32-bit lane offset; every patch lies inside the padded level).
+// grid xcd_grid(ceil(cap / 8), B), block 256
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_describe2(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
+                                                   const int32_t *__restrict__ count, int cap, const uint8_t *__restrict__ pyr,
+                                                   size_t pyr_frame_stride, const uint8_t *__restrict__ blur, size_t blur_frame_stride,
+                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc, int strict_mul_add, int n_frames) {
+    __shared__ __attribute__((aligned(16))) uint8_t patches[4 * 2 * kDescWaveLds];
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, hw = lane >> 5, hl = lane & 31;
+    const int cnt = count[f];
+    const int g0 = (bx * 4 + wv) * 2;   // first keypoint of the wave
+    if (g0 >= cnt) return;              // wave-uniform
+    const bool live = g0 + hw < cnt;    // an odd count leaves the last wave's second half idle: it repeats the last keypoint and stores nothing
+    const WorkItem w = work[(size_t)f * cap + min(g0 + hw, cnt - 1)];
+    uint8_t *A = patches + (wv * 2 + hw) * kDescWaveLds;
+    uint8_t *Bp = A + kDescAP * kDescAR;
+    const int pitch = (int)(w.pitches & 0xffffu), bpitch = (int)(w.pitches >> 16);
+    const int kx = key_x(w.key), ky = key_y(w.key);
+    const int du = hl - kHalfPatch;
+    const int dvmax = hl <= 2 * kHalfPatch ? dc->vmax_of_u[du < 0 ? -du : du] : -1;
+    uint32_t pat8[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) pat8[it] = reinterpret_cast<const uint32_t *>(dc->pat)[it * 32 + hl];
+
+    // ---- both patches of both keypoints: 16 lanes per row, 2 rows per step and half, every load issued before the first LDS store ----
+    const int axA = (kx - kHalfPatch) & 3, axB = (kx - 18) & 3;
+    {
+        const uint8_t *fp = pyr + (size_t)f * pyr_frame_stride, *fb = blur + (size_t)f * blur_frame_stride;   // wave-uniform bases
+        const int c = hl & 15, r0 = hl >> 4;
+        const uint32_t offA = w.off + (uint32_t)((kEdge + ky - kHalfPatch + r0) * pitch + kRoiX + (kx - kHalfPatch - axA) + 4 * c);
+        const uint32_t offB = w.boff + (uint32_t)((ky - 18 + r0) * bpitch + (kx - 18 - axB) + 4 * c);
+        uint32_t va[16], vb[19];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            va[k] = 0;
+            if (c < 9 && r0 + 2 * k < kDescAR) va[k] = *reinterpret_cast<const uint32_t *>(fp + (offA + (uint32_t)(2 * k * pitch)));
+        }
+#pragma unroll
+        for (int k = 0; k < 19; k++) {
+            vb[k] = 0;
+            if (c < 10 && r0 + 2 * k < kDescBR) vb[k] = *reinterpret_cast<const uint32_t *>(fb + (offB + (uint32_t)(2 * k * bpitch)));
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (c < 9 && r0 + 2 * k < kDescAR) *reinterpret_cast<uint32_t *>(A + (r0 + 2 * k) * kDescAP + 4 * c) = va[k];
+#pragma unroll
+        for (int k = 0; k < 19; k++)
+            if (c < 10 && r0 + 2 * k < kDescBR) *reinterpret_cast<uint32_t *>(Bp + (r0 + 2 * k) * kDescBP + 4 * c) = vb[k];
+    }
+    wave_lds_sync();
+
+    // ---- IC_Angle (:76-103): lane = disc column, m_10 = u * sum I, m_01 = sum v * I ----
+    const uint8_t *c0 = A + kHalfPatch * kDescAP + kHalfPatch + axA + du;
+    int sumI = 0, m01 = 0;
+#pragma unroll
+    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
+        if ((v < 0 ? -v : v) <= dvmax) {
+            const int I = c0[v * kDescAP];
+            sumI += I;
+            m01 += v * I;
+        }
+    }
+    const int s10 = wave_incl_scan(du * sumI), s01 = wave_incl_scan(m01);
+    const int a10 = __builtin_amdgcn_readlane(s10, 31), b10 = __builtin_amdgcn_readlane(s10, 63);
+    const int a01 = __builtin_amdgcn_readlane(s01, 31), b01 = __builtin_amdgcn_readlane(s01, 63);
+    const int M10 = hw ? b10 - a10 : a10, M01 = hw ? b01 - a01 : a01;
+    const float angle = fast_atan2_deg_sel((float)M01, (float)M10);
+
+    // ---- steered BRIEF on the blurred patch ----
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    glibc_sincosf_sel(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
+    constexpr float kMagic = 12582912.f;           // cvRound by magic add, see k_describe
+    constexpr uint32_t kMagicBits = 0x4B400000u;
+    const uint32_t cbm = (uint32_t)(uintptr_t)(Bp + 18 * kDescBP + 18 + axB) - (0x400000u * (uint32_t)kDescBP + kMagicBits);
+    uint32_t mine = 0;   // lanes 0..7 of a half end up with descriptor dword hl of the half's keypoint
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const char4 pt = __builtin_bit_cast(char4, pat8[it]);
+        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
+        float r0, q0, r1, q1;
+        if (strict_mul_add) {
+            r0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
+            q0 = __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
+            r1 = __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
+            q1 = __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
+        } else {  // GCC -O3 -march=native: fma(x, b, y*a), fma(x, a, -(y*b))
+            r0 = __fmaf_rn(x0, b, __fmul_rn(y0, a));
+            q0 = __fmaf_rn(x0, a, -__fmul_rn(y0, b));
+            r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
+            q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
+        }
+        const uint32_t a0 = __umul24(__float_as_uint(__fadd_rn(r0, kMagic)), (uint32_t)kDescBP) + __float_as_uint(__fadd_rn(q0, kMagic)) + cbm;
+        const uint32_t a1 = __umul24(__float_as_uint(__fadd_rn(r1, kMagic)), (uint32_t)kDescBP) + __float_as_uint(__fadd_rn(q1, kMagic)) + cbm;
+        const int t0 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a0);
+        const int t1 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a1);
+        const unsigned long long bal = __ballot(t0 < t1);
+        const uint32_t half_bits = hw ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+        mine = hl == it ? half_bits : mine;
+    }
+    if (!live) return;
+    const size_t slot = (size_t)f * cap + w.pos;
+    if (hl < 8) reinterpret_cast<uint32_t *>(desc + slot * 32)[hl] = mine;
+    if (hl == 0) {
+        orbx_keypoint kp;
+        float x = (float)kx, y = (float)ky;
+        if (w.level != 0) { x = __fmul_rn(x, w.scale); y = __fmul_rn(y, w.scale); }
+        kp.x = x; kp.y = y; kp.size = w.size; kp.angle = angle; kp.response = (float)key_s(w.key);
         kp.octave = w.level; kp.class_id = -1;
         kps[slot] = kp;
     }

@@ -510,6 +510,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     if (!ex->profile && ex->side_streams && ex->blur_side) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
     {
         ProfScope ps(ex, K_DESCRIBE);
+        static const bool describe2 = [] { const char *v = getenv("ORBX_DESCRIBE"); return v && v[0] == '2'; }();   // two keypoints per wave (unmeasured, off)
+        if (describe2)
+            hipLaunchKernelGGL(k_describe2, xcd_grid((ex->cap + 7) / 8, n), dim3(256), 0, st, (const DescConst *)ex->d_dc.p,
+                               (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
+                               ex->pyr_frame, (const uint8_t *)blur_slab, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
+                               (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0, n);
+        else
         hipLaunchKernelGGL(k_describe, xcd_grid((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
                            (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
                            ex->pyr_frame, (const uint8_t *)blur_slab, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
