@@ -167,3 +167,14 @@ def test_reference_matcher_modules_through_adapter_and_emulated_kernels(emul_lib
     assert r.returncode == 0, tail
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 17, tail
+
+
+def test_branch_free_describe_math_equals_branching_forms(emul_lib, tmp_path):
+    """glibc_sincosf_sel / fast_atan2_deg_sel (k_describe2) are bit-identical to glibc_sincosf / fast_atan2_deg (k_describe, itself the port of
+    the libm the reference links and of cv::fastAtan2): 14.7 million arguments, device code compiled for the host."""
+    exe = tmp_path / "check_describe_math"
+    r = subprocess.run([str(CLANG), "-std=c++17", "-O1", "-ffp-contract=off", f"-I{SIMT}", f"-I{SIMT / 'build'}", "-Wno-ignored-attributes",
+                        "-Wno-unused-value", str(SIMT / "check_describe_math.cc"), str(SIMT / "launch.cc"), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:]
