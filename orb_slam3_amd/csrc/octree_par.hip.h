@@ -296,10 +296,12 @@ __device__ __forceinline__ uint64_t oct_blk_seg_excl(uint64_t v, bool fl, uint64
     return r;
 }
 
-template <bool BLK>
+// KEYS = capacity of the LDS key buffers of the 256-thread form (4096, or 2048 for k_octree_par_t's small tier); kE = key slots per thread
+template <bool BLK, int KEYS = kOctParLdsKeys>
 __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *smem, int max_pool, const int C, uint32_t *gk0, uint32_t *gk1,
                                                 uint16_t *gn0, uint16_t *gn1, uint32_t *__restrict__ out,
                                                 int32_t *__restrict__ lvlcnt_out, int32_t *__restrict__ err, long long *dbg) {
+    constexpr int kE = (KEYS >> 8) | 1;   // ceil(KEYS / 256) | 1 (odd: conflict-free LDS stride); 17 for 4096 keys
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // optional phase timing of one workgroup (ORBX_OCT_DBG): 100 MHz wall clock ticks per phase
     long long tmark = dbg ? (long long)wall_clock64() : 0;
@@ -338,14 +340,14 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
         uint8_t *lk = smem + oct_par_pool_bytes(max_pool);
         // every thread holds its keys in registers between the read and the write sweep of a pass: one buffer, updated in place
         kb[0] = kb[1] = (uint32_t *)lk;
-        nof[0] = nof[1] = (uint16_t *)(kb[0] + kOctParLdsKeys);
+        nof[0] = nof[1] = (uint16_t *)(kb[0] + KEYS);
     } else {
         kb[0] = gk0; kb[1] = gk1; nof[0] = gn0; nof[1] = gn1;
     }
-    const int E = ((C + 255) >> 8) | 1;  // BLK: keys per thread (<= kOctBlkE)
+    const int E = ((C + 255) >> 8) | 1;  // BLK: keys per thread (<= kE)
     // per-key registers of the 256-thread form: key; node (11 bits: pool <= 2047) | q << 11 | head << 14 | last << 15 |
-    // valid << 16 | rank inside the child << 17 (13 bits: <= kOctParLdsKeys)
-    uint32_t kv[kOctBlkE], r1[kOctBlkE];
+    // valid << 16 | rank inside the child << 17 (13 bits: <= KEYS)
+    uint32_t kv[kE], r1[kE];
     (void)kv; (void)r1;
 
     // ---- 2./3. roots (:559-602): key -> root (int)(x / hX), stable; empty roots are dropped.  vToDistributeKeys is in gk1
@@ -353,7 +355,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
     if (BLK) {
         uint64_t acc = 0;
 #pragma unroll
-        for (int e = 0; e < kOctBlkE; e++) {
+        for (int e = 0; e < kE; e++) {
             const int i = tid * E + e;
             r1[e] = 0;
             if (e < E && i < C) {
@@ -385,7 +387,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
         }
         acc = cin;
 #pragma unroll
-        for (int e = 0; e < kOctBlkE; e++) {
+        for (int e = 0; e < kE; e++) {
             if (r1[e] & (1u << 16)) {
                 const int q = (r1[e] >> 11) & 3;
                 const int pos = (q == 0 ? rstart[0] : q == 1 ? rstart[1] : q == 2 ? rstart[2] : rstart[3]) + (int)((acc >> (16 * q)) & 0xffff);
@@ -449,24 +451,24 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
             // groups of six keys: load round (key + node), load round (node record), arithmetic -- the LDS latencies of a
             // group overlap and the temporaries stay within the register budget of three workgroups per CU
 #pragma unroll
-            for (int g = 0; g < kOctBlkE; g += 6) {
+            for (int g = 0; g < kE; g += 6) {
                 if (g < E) {
                     OctSeg sgs[6];
                     OctBnd bns[6];
 #pragma unroll
                     for (int u = 0; u < 6; u++) {
                         const int e = g + u;
-                        if (e < kOctBlkE) { const int i = min(tid * E + e, C - 1); kv[e] = K0[i]; r1[e] = O0[i]; }
+                        if (e < kE) { const int i = min(tid * E + e, C - 1); kv[e] = K0[i]; r1[e] = O0[i]; }
                     }
 #pragma unroll
                     for (int u = 0; u < 6; u++) {
                         const int e = g + u;
-                        if (e < kOctBlkE) { sgs[u] = S0[r1[e]]; bns[u] = B0[r1[e]]; }
+                        if (e < kE) { sgs[u] = S0[r1[e]]; bns[u] = B0[r1[e]]; }
                     }
 #pragma unroll
                     for (int u = 0; u < 6; u++) {
                         const int e = g + u;
-                        if (e < kOctBlkE) {
+                        if (e < kE) {
                             const int i = tid * E + e;
                             if (e < E && i < C) {
                                 const uint32_t key = kv[e];
@@ -489,12 +491,12 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
                     }
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 6; u++) if (g + u < kOctBlkE) r1[g + u] = 0;
+                    for (int u = 0; u < 6; u++) if (g + u < kE) r1[g + u] = 0;
                 }
             }
             acc = oct_blk_seg_excl(acc, seen, wtot, wflag, lane, wave);
 #pragma unroll
-            for (int e = 0; e < kOctBlkE; e++) {
+            for (int e = 0; e < kE; e++) {
                 if (r1[e] & (1u << 16)) {
                     const int q = (r1[e] >> 11) & 7;
                     if (r1[e] & (1u << 14)) acc = 0;
@@ -632,7 +634,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
         uint16_t *O1 = nof[nxt];
         if (BLK) {
 #pragma unroll
-            for (int e = 0; e < kOctBlkE; e++) {
+            for (int e = 0; e < kE; e++) {
                 if (r1[e] & (1u << 16)) {
                     const int j = r1[e] & 0x7ff, q = (r1[e] >> 11) & 7;
                     const int np = npos[j];
@@ -760,6 +762,29 @@ __global__ __launch_bounds__(256, 3) void k_octree_par(const LevelInfo *__restri
     uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
     octree_par_body<true>(L, smem, max_pool, C, nullptr, gk1, nullptr, nullptr, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off,
                           lvlcnt + f * nlevels + level, err, dbg);
+}
+
+// k_octree_par_t (ORBX_OCTREE_KEYS=2048; written at the end of round 2, verified against the oracle under the CPU SIMT emulator, NOT yet
+// measured on the hardware): the 256-thread form in two tiers.  k_octree_par sizes its LDS key buffers and its per-thread key slots
+// for 4096 candidates on every level: 45 KB of LDS and 161 VGPRs keep it at three workgroups per CU, and a level with 1100 candidates
+// still walks 17 key slots per thread in every unrolled sweep.  The small tier (LO < C <= 2048: every level of the EuRoC-shaped bench)
+// has 9 slots, 118 VGPRs and 33 KB: four workgroups per CU (2048 workgroups = two dispatch rounds instead of three) and about 30 %
+// fewer instructions; levels with 2048 < C <= 4096 take the second launch, the rest k_octree_par1 as before.
+// grid (B, nlevels), block 256, dynamic LDS = oct_par_pool_bytes(max pool) + KEYS * 6
+template <int KEYS, int LO>
+__global__ __launch_bounds__(256, (KEYS <= 2048 ? 4 : 3)) void k_octree_par_t(const LevelInfo *__restrict__ lv, size_t ent_frame_stride,
+                                                                              uint32_t *__restrict__ keys1, uint32_t *__restrict__ lvlkp,
+                                                                              size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt, int nlevels,
+                                                                              const int32_t *__restrict__ cand_total, int32_t *__restrict__ err,
+                                                                              int max_pool) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int level = blockIdx.y, f = blockIdx.x;
+    const LevelInfo L = lv[level];
+    const int C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
+    if (!(C > LO && C <= KEYS && L.nIni <= 4 && L.pool <= 2047)) return;
+    uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
+    octree_par_body<true, KEYS>(L, smem, max_pool, C, nullptr, gk1, nullptr, nullptr, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off,
+                                lvlcnt + f * nlevels + level, err, nullptr);
 }
 
 // grid (B, nlevels), block 64, dynamic LDS = oct_par_pool_bytes(max pool)

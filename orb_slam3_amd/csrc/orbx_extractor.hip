@@ -478,6 +478,18 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             const size_t lds = oct_par_lds_bytes(ex->max_pool), lds1 = oct_par_pool_bytes(ex->max_pool);
             if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (lds1 > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            static const bool oct_tiers = [] { const char *v = getenv("ORBX_OCTREE_KEYS"); return v && atoi(v) == 2048; }();   // two-tier form (unmeasured, off)
+            if (oct_tiers) {
+                const size_t lds_s = oct_par_pool_bytes(ex->max_pool) + (size_t)2048 * 6;
+                if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<4096, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (lds_s > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<2048, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+                hipLaunchKernelGGL((k_octree_par_t<2048, -1>), dim3(n, nl), dim3(256), lds_s, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
+                                   (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
+                                   (int32_t *)ex->d_err.p, ex->max_pool);
+                hipLaunchKernelGGL((k_octree_par_t<4096, 2048>), dim3(n, nl), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
+                                   (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
+                                   (int32_t *)ex->d_err.p, ex->max_pool);
+            } else
             hipLaunchKernelGGL(k_octree_par, dim3(n, nl), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
                                (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
                                (int32_t *)ex->d_err.p, ex->max_pool, (long long *)ex->d_octdbg.p, ex->octdbg_level);

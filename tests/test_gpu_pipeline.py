@@ -110,7 +110,7 @@ def test_pipeline_under_alternative_switches():
     import sys
     for extra in ({"ORBX_BLUR_KERNEL": "0"}, {"ORBX_RESIZE_COLS": "1"}, {"ORBX_RESIZE_COLS": "1", "ORBX_RESIZE_PK": "0"}, {"ORBX_PYR_XCD": "0"},
                   {"ORBX_PYR_AHEAD": "2"}, {"ORBX_PYR_AHEAD": "1"}, {"ORBX_RESOLVE_RESCAN": "full", "ORBX_COPY_AFTER_MATCH": "1"},
-                  {"ORBX_PYR_CHAIN": "1"}, {"ORBX_PYR_CHAIN": "2"}, {"ORBX_DESCRIBE": "2"}, {"ORBX_GRID_BUILD": "2"}, {"ORBX_WINDOW_DPP": "1"}):
+                  {"ORBX_PYR_CHAIN": "1"}, {"ORBX_PYR_CHAIN": "2"}, {"ORBX_DESCRIBE": "2"}, {"ORBX_OCTREE_KEYS": "2048"}, {"ORBX_GRID_BUILD": "2"}, {"ORBX_WINDOW_DPP": "1"}):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "16", "4"], capture_output=True, text=True, env=dict(os.environ, **extra),
                            timeout=300)
         assert r.returncode == 0 and "pipeline ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-2000:])

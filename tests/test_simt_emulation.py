@@ -111,7 +111,7 @@ print('emulation ok')
 """
 
 
-@pytest.mark.parametrize("env", [{"SIMT_STREAM_FUZZ": "first"}, {"SIMT_STREAM_FUZZ": "last", "ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full", "ORBX_WINDOW_DPP": "1"},
+@pytest.mark.parametrize("env", [{"SIMT_STREAM_FUZZ": "first", "ORBX_OCTREE_KEYS": "2048"}, {"SIMT_STREAM_FUZZ": "last", "ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full", "ORBX_WINDOW_DPP": "1"},
                                  {"SIMT_STREAM_FUZZ": "7", "ORBX_PYR_CHAIN": "1", "ORBX_DESCRIBE": "2"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "in-order")
 def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
@@ -128,7 +128,7 @@ def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
 SWITCHES = [{"ORBX_BLUR_KERNEL": "0"}, {"ORBX_RESIZE_COLS": "1"}, {"ORBX_RESIZE_COLS": "1", "ORBX_RESIZE_PK": "0"}, {"ORBX_PYR_XCD": "0"},
             {"ORBX_PYR_AHEAD": "2"}, {"ORBX_PYR_AHEAD": "1"}, {"ORBX_COPY_AFTER_MATCH": "1"}, {"ORBX_SIDE_STREAMS": "0"}, {"ORBX_BLUR_SIDE": "0"},
             {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_INI": "0"}, {"ORBX_FAST_TPB": "256"}, {"ORBX_BLUR_GROUPS": "3"}, {"ORBX_FAST_INI_QCAP": "48"},
-            {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_PYR_CHAIN": "1"}, {"ORBX_PYR_CHAIN": "2"}, {"ORBX_DESCRIBE": "2"}, {"ORBX_GRID_BUILD": "2"}, {"ORBX_WINDOW_DPP": "1"}]
+            {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_PYR_CHAIN": "1"}, {"ORBX_PYR_CHAIN": "2"}, {"ORBX_DESCRIBE": "2"}, {"ORBX_OCTREE_KEYS": "2048"}, {"ORBX_GRID_BUILD": "2"}, {"ORBX_WINDOW_DPP": "1"}]
 
 
 @pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): about fifteen minutes")
