@@ -182,13 +182,22 @@ inline void run_block(Dim3 grid, Dim3 bidx, int nthreads, const std::function<vo
                 const int j = (int)(rng % (unsigned)(i + 1));
                 std::swap(order[i], order[j]);
             }
+        // ... and each wave takes part in a round with probability 1/2 (SIMT_SHUFFLE only), so that waves drift apart by any number of
+        // collectives, as they do on the hardware -- bounded only by the workgroup barriers
+        unsigned skip = 0;
+        if (shuffle_env) {
+            rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+            skip = (unsigned)(rng >> 20) & ((1u << nwaves) - 1u);
+            if (skip == (1u << nwaves) - 1u) skip = 0;
+        }
         for (int wi = 0; wi < nwaves; wi++)
             for (int t = order[wi] * 64; t < std::min(nthreads, order[wi] * 64 + 64); t++) {
+                if ((skip >> order[wi]) & 1u) break;
                 if (b->fibers[t].done) continue;
                 b->cur = t;
                 swapcontext(&b->sched, &b->fibers[t].ctx);
             }
-        if (b->progress == before && b->alive_block > 0) {
+        if (b->progress == before && b->alive_block > 0 && skip == 0) {
             fprintf(stderr, "simt: stall -- a collective was reached by only part of the live lanes (divergent control flow around it)\n");
             abort();
         }
