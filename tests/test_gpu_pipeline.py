@@ -233,11 +233,13 @@ def test_async_entry_points_refuse_pageable_host_memory():
     assert len(ex.download(0)[1]) > 50
 
 
-if __name__ == "__main__":   # child of test_pipeline_under_alternative_switches: python tests/test_gpu_pipeline.py <frames per batch> <steps>
+if __name__ == "__main__":   # child of test_pipeline_under_alternative_switches: python tests/test_gpu_pipeline.py <frames per batch> <steps> [small]
     import sys
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     from oracle import oracle_binding as _ob
     _ob.lib()
-    _run_pipeline(_ob, int(sys.argv[1]), int(sys.argv[2]), canvas_size=1024, n_shapes=700)
+    # standard canvases by default (the switch test is about the switches); "small" = the 1024^2 / 700-shape canvases of the open item
+    small = len(sys.argv) > 3 and sys.argv[3] == "small"
+    _run_pipeline(_ob, int(sys.argv[1]), int(sys.argv[2]), canvas_size=1024 if small else 2048, n_shapes=700 if small else 2400)
     print("pipeline ok")

@@ -6,7 +6,7 @@ N=${1:-6}
 for v in "ORBX_NONE=1" "ORBX_SIDE_STREAMS=0" "AMD_SERIALIZE_KERNEL=3" "HIP_LAUNCH_BLOCKING=1" "ORBX_OCTREE=seq" "ORBX_COPY_AFTER_MATCH=1" "GPU_MAX_HW_QUEUES=8"; do
   ok=0; bad=0; first=""
   for i in $(seq 1 $N); do
-    out=$(env $v timeout 120 python3 tests/test_gpu_pipeline.py 16 4 2>&1 | tail -3)
+    out=$(env $v timeout 120 python3 tests/test_gpu_pipeline.py 16 4 small 2>&1 | tail -3)
     if echo "$out" | grep -q "pipeline ok"; then ok=$((ok+1)); else bad=$((bad+1)); [ -z "$first" ] && first=$(echo "$out" | tr '\n' ' ' | cut -c1-200); fi
   done
   echo "$v : ok $ok failed $bad   $first"
