@@ -135,7 +135,7 @@ SWITCHES = [{"ORBX_BLUR_KERNEL": "0"}, {"ORBX_RESIZE_COLS": "1"}, {"ORBX_RESIZE_
 @pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_emulated_switch_matrix(emul_lib, env):
     """Every alternative kernel / scheduling switch of DESIGN.md section 6 through the two-batch pipeline under emulation (their LOGIC:
-    slab toggling, grids, the older kernels, the three kernels prepared for round 3).  All eighteen passed at the end of round 2."""
+    slab toggling, grids, the older kernels, the three kernels prepared for round 3).  All twenty-one passed at the end of round 2."""
     _child(PIPELINE, env)
 
 
