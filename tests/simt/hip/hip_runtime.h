@@ -50,7 +50,20 @@ inline hipError_t hipEventDestroy(hipEvent_t e) { simt::sync_event(e); return hi
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { simt::record(e, s); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t e) { simt::sync_event(e); return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
+// Device memory is not zero on allocation: SIMT_MALLOC_FILL=<byte value> fills it with that byte, SIMT_MALLOC_FILL=r<seed> with different
+// garbage per allocation -- a result that changes with it depends on device memory nothing wrote.
+inline hipError_t hipMalloc(void **p, size_t n) {
+    const size_t bytes = (n + 255) & ~(size_t)255;
+    *p = aligned_alloc(256, bytes);
+    if (!*p) return hipErrorInvalidValue;
+    static const char *fill = getenv("SIMT_MALLOC_FILL");
+    if (fill && fill[0] == 'r') {
+        static unsigned long long st = strtoull(fill + 1, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+        uint64_t *q = (uint64_t *)*p;
+        for (size_t i = 0; i < bytes / 8; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; q[i] = st; }
+    } else if (fill) memset(*p, (int)strtol(fill, nullptr, 0), bytes);
+    return hipSuccess;
+}
 inline hipError_t hipFree(void *p) { simt::sync_all(); free(p); return hipSuccess; }   // hipFree synchronises the device
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }

@@ -1,5 +1,8 @@
 // launch.cc -- grid loop + dynamic LDS of the SIMT emulator (one definition per emulated library)
 #include "hip/hip_runtime.h"
+#include <algorithm>
+#include <vector>
+#include <cstring>
 namespace simt {
 static uint8_t *g_lds = nullptr;
 static uint8_t g_anchor[16];
@@ -15,20 +18,34 @@ void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads > 1024) { fprintf(stderr, "simt: %d threads per block\n", nthreads); abort(); }
     Dim3 g; g.x = grid.x; g.y = grid.y; g.z = grid.z;
-    for (unsigned z = 0; z < grid.z; z++)
-        for (unsigned y = 0; y < grid.y; y++)
-            for (unsigned x = 0; x < grid.x; x++) {
-                Dim3 b; b.x = x; b.y = y; b.z = z;
-                // LDS is not zero on entry: a fixed pattern, or (SIMT_LDS_RANDOM=<seed>) different garbage for every block -- a result
-                // that changes with it depends on LDS the kernel never wrote
-                static const char *rnd = getenv("SIMT_LDS_RANDOM");
-                if (rnd) {
-                    static unsigned long long st = strtoull(rnd, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
-                    uint64_t *p = (uint64_t *)dyn_lds();
-                    for (size_t i = 0; i < (lds_bytes + 7) / 8; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; p[i] = st; }
-                } else memset(dyn_lds(), 0xcd, lds_bytes);
-                run_block(g, b, nthreads, body);
-            }
+    // Workgroups of a launch run one after another.  SIMT_BLOCK_ORDER=reverse runs them last to first, SIMT_BLOCK_ORDER=<seed> in a
+    // different random order for every launch: a result that changes with it depends on the order in which workgroups reach a
+    // global atomic (list appends, counters) -- which the hardware does not define.
+    static const char *order = getenv("SIMT_BLOCK_ORDER");
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    std::vector<uint32_t> perm;
+    if (order) {
+        perm.resize(nblocks);
+        for (size_t i = 0; i < nblocks; i++) perm[i] = (uint32_t)i;
+        if (!strcmp(order, "reverse")) std::reverse(perm.begin(), perm.end());
+        else {
+            static unsigned long long st = strtoull(order, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+            for (size_t i = nblocks; i > 1; i--) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; std::swap(perm[i - 1], perm[st % i]); }
+        }
+    }
+    for (size_t i = 0; i < nblocks; i++) {
+        const size_t id = order ? perm[i] : i;
+        Dim3 b; b.x = (unsigned)(id % grid.x); b.y = (unsigned)(id / grid.x % grid.y); b.z = (unsigned)(id / ((size_t)grid.x * grid.y));
+        // LDS is not zero on entry: a fixed pattern, or (SIMT_LDS_RANDOM=<seed>) different garbage for every block -- a result
+        // that changes with it depends on LDS the kernel never wrote
+        static const char *rnd = getenv("SIMT_LDS_RANDOM");
+        if (rnd) {
+            static unsigned long long st = strtoull(rnd, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+            uint64_t *p = (uint64_t *)dyn_lds();
+            for (size_t j = 0; j < (lds_bytes + 7) / 8; j++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; p[j] = st; }
+        } else memset(dyn_lds(), 0xcd, lds_bytes);
+        run_block(g, b, nthreads, body);
+    }
 }
 }  // namespace simt
 

@@ -250,23 +250,34 @@ inline long long wall_clock64() { return 0; }
 template <typename T> inline uint64_t simt_bits(T v) { uint64_t b = 0; static_assert(sizeof(T) <= 8, ""); memcpy(&b, &v, sizeof(T)); return b; }
 template <typename T> inline T simt_from(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
 
+// A shuffle / readlane whose source lane has left the kernel: the hardware returns 0 (ds_bpermute) or whatever the dead lane's
+// register holds (v_readlane, DPP-lowered shuffles) -- nothing a result may depend on.  The emulator returns 0 and counts the reads;
+// SIMT_STRICT_LANES=1 aborts at the first one.
+namespace simt {
+inline uint64_t lane_value(const WaveView &w, int src, const char *what) {
+    if (w.p[src & 63]) return w.v[src & 63];
+    static const bool strict = getenv("SIMT_STRICT_LANES") != nullptr;
+    if (strict) { fprintf(stderr, "simt: %s reads lane %d, which has left the kernel\n", what, src & 63); abort(); }
+    return 0;
+}
+}
 template <typename T> inline T __shfl(T v, int src) {
     const simt::WaveView w = simt::wave_collect(simt_bits(v));
-    return simt_from<T>(w.v[src & 63]);
+    return simt_from<T>(simt::lane_value(w, src, "__shfl"));
 }
 template <typename T> inline T __shfl_up(T v, unsigned d) {
     const int lane = simt::cur_tid() & 63;
     const simt::WaveView w = simt::wave_collect(simt_bits(v));
-    return lane >= (int)d ? simt_from<T>(w.v[lane - d]) : v;
+    return lane >= (int)d ? simt_from<T>(simt::lane_value(w, lane - (int)d, "__shfl_up")) : v;
 }
 template <typename T> inline T __shfl_xor(T v, int m) {
     const int lane = simt::cur_tid() & 63;
     const simt::WaveView w = simt::wave_collect(simt_bits(v));
-    return simt_from<T>(w.v[(lane ^ m) & 63]);
+    return simt_from<T>(simt::lane_value(w, lane ^ m, "__shfl_xor"));
 }
 inline int __builtin_amdgcn_readlane(int v, int l) {
     const simt::WaveView w = simt::wave_collect(simt_bits(v));
-    return simt_from<int>(w.v[l & 63]);
+    return simt_from<int>(simt::lane_value(w, l, "v_readlane"));
 }
 // v_readfirstlane_b32: the kernels use it on values that ARE wave-uniform (to tell the compiler so), also under partial EXEC masks
 // (inside helpers some lanes have left) -- a collective would not be reached by every live lane, and the value is the lane's own anyway
@@ -376,7 +387,7 @@ inline int __syncthreads_or(int pred) {
 template <typename T> inline T __shfl_down(T v, unsigned d) {
     const int lane = simt::cur_tid() & 63;
     const simt::WaveView w = simt::wave_collect(simt_bits(v));
-    return lane + (int)d < 64 ? simt_from<T>(w.v[lane + d]) : v;
+    return lane + (int)d < 64 ? simt_from<T>(simt::lane_value(w, lane + (int)d, "__shfl_down")) : v;
 }
 
 inline float __fmul_rn(float a, float b) { return a * b; }
