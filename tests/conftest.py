@@ -15,7 +15,9 @@ def pytest_configure(config):
     # without a GPU -- it says nothing about timing, races between streams or the hardware; tests that need torch.cuda still fail.
     if os.environ.get("ORBX_TEST_EMULATOR"):
         import orb_slam3_amd._lib as _lib
-        emul = ROOT / "tests" / "simt" / "build" / "liborbx_emul.so"
+        # ORBX_TEST_EMULATOR=ubsan / asan: the sanitizer builds (python tests/simt/build.py --ubsan / --asan)
+        kind = os.environ["ORBX_TEST_EMULATOR"]
+        emul = ROOT / "tests" / "simt" / "build" / ("liborbx_emul_%s.so" % kind if kind in ("ubsan", "asan") else "liborbx_emul.so")
         if not emul.exists():
             raise pytest.UsageError(f"{emul} is missing: run python tests/simt/build.py")
         _lib.LIB_PATH = emul

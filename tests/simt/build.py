@@ -45,16 +45,23 @@ def main():
         print("warning: inline assembly left in the copies", file=sys.stderr)
     asan = "--asan" in sys.argv[1:]   # AddressSanitizer build: device-side out-of-bounds accesses to "device" (heap) buffers are reported
     units = [a for a in sys.argv[1:] if not a.startswith("--")] or ["orbx_extractor.cc", "orbx_matcher.cc"]
-    out = BUILD / ("liborbx_emul_asan.so" if asan else "liborbx_emul.so")
+    # UBSan build: conversions of out-of-range floats to integers (x86 and gfx950 give DIFFERENT results for those), shifts by >= the
+    # width, signed overflow, out-of-bounds indices of fixed-size arrays; unaligned accesses are intended (the kernels rely on them)
+    ubsan = "--ubsan" in sys.argv[1:]
+    out = BUILD / ("liborbx_emul_asan.so" if asan else "liborbx_emul_ubsan.so" if ubsan else "liborbx_emul.so")
     cmd = [CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-unused-value",
            "-Wno-ignored-attributes", "-Wno-unknown-attributes", f"-I{HERE}", f"-I{BUILD}", "-o", str(out),
            str(HERE / "launch.cc")] + [str(BUILD / u) for u in units] + ["-ldl"]
     if asan:
         cmd[1:1] = ["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan"]
+    if ubsan:
+        rt = subprocess.run([CLANG, "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], capture_output=True, text=True).stdout.strip()
+        cmd[1:1] = ["-fsanitize=float-cast-overflow,shift,signed-integer-overflow,bounds,integer-divide-by-zero,float-divide-by-zero",
+                    "-fno-omit-frame-pointer", "-shared-libsan", f"-Wl,-rpath,{Path(rt).parent}"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     sys.stderr.write(r.stderr[-6000:])
     print("rewrites", n_rew, "rc", r.returncode)
-    if r.returncode == 0 and not asan:   # the quad-tree kernels alone (octree_emul.cc): 0.1 s per level, for sweeps
+    if r.returncode == 0 and not asan and not ubsan:   # the quad-tree kernels alone (octree_emul.cc): 0.1 s per level, for sweeps
         r = subprocess.run([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value", "-Wno-ignored-attributes",
                             f"-I{HERE}", f"-I{BUILD}", "-o", str(BUILD / "liboctree_emul.so"), str(HERE / "octree_emul.cc"), str(HERE / "launch.cc")],
                            capture_output=True, text=True)

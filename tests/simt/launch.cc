@@ -3,7 +3,9 @@
 #include <algorithm>
 #include <vector>
 #include <cstring>
+extern "C" char __start_simt_lds[], __stop_simt_lds[];   // the section of the kernels' static LDS arrays (simt.h)
 namespace simt {
+static __attribute__((section("simt_lds"), used)) char g_lds_section_anchor[16];   // the section exists even without a static array
 static uint8_t *g_lds = nullptr;
 static uint8_t g_anchor[16];
 uintptr_t bss_anchor() { return (uintptr_t)g_anchor; }   // static LDS arrays of the kernels live in this library's .bss too
@@ -43,7 +45,11 @@ void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std
             static unsigned long long st = strtoull(rnd, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
             uint64_t *p = (uint64_t *)dyn_lds();
             for (size_t j = 0; j < (lds_bytes + 7) / 8; j++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; p[j] = st; }
-        } else memset(dyn_lds(), 0xcd, lds_bytes);
+            for (char *q = __start_simt_lds; q < __stop_simt_lds; q++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; *q = (char)st; }
+        } else {
+            memset(dyn_lds(), 0xcd, lds_bytes);
+            memset(__start_simt_lds, 0xcd, (size_t)(__stop_simt_lds - __start_simt_lds));
+        }
         run_block(g, b, nthreads, body);
     }
 }

@@ -27,7 +27,9 @@
 #define __forceinline__ inline
 #define __restrict__
 #define __launch_bounds__(...)
-#define __shared__ static
+// static LDS arrays of the kernels land in one section of the emulated library, so that the launcher can fill them with garbage before
+// every workgroup (launch.cc): on the hardware they hold whatever the previous workgroup of that CU left there
+#define __shared__ static __attribute__((section("simt_lds")))
 #define __ATOMIC_SEQ_CST_SIMT 5
 
 namespace simt {
@@ -190,13 +192,26 @@ inline void run_block(Dim3 grid, Dim3 bidx, int nthreads, const std::function<vo
             skip = (unsigned)(rng >> 20) & ((1u << nwaves) - 1u);
             if (skip == (1u << nwaves) - 1u) skip = 0;
         }
-        for (int wi = 0; wi < nwaves; wi++)
-            for (int t = order[wi] * 64; t < std::min(nthreads, order[wi] * 64 + 64); t++) {
-                if ((skip >> order[wi]) & 1u) break;
+        // SIMT_LANE_ORDER=reverse|<seed>: the lanes of a wave run their stretch between two collectives last lane first / in a random order
+        // that changes every round.  The hardware executes them in lock step; what a wave's lanes do to the SAME location within one
+        // instruction (atomics handing out slots) has no defined order among the lanes, and a result that changes with this setting
+        // depends on one (or on a lower lane's plain store being visible to a higher lane within the stretch -- an emulator artefact).
+        static const char *lane_env = getenv("SIMT_LANE_ORDER");
+        static unsigned long long lrng = lane_env ? strtoull(lane_env, nullptr, 10) * 0x9E3779B97F4A7C15ull + 12345 : 0;
+        for (int wi = 0; wi < nwaves; wi++) {
+            if ((skip >> order[wi]) & 1u) continue;
+            const int t0 = order[wi] * 64, cnt = std::min(nthreads, t0 + 64) - t0;
+            int lanes[64];
+            for (int i = 0; i < cnt; i++) lanes[i] = lane_env && !strcmp(lane_env, "reverse") ? cnt - 1 - i : i;
+            if (lane_env && strcmp(lane_env, "reverse"))
+                for (int i = cnt - 1; i > 0; i--) { lrng ^= lrng << 13; lrng ^= lrng >> 7; lrng ^= lrng << 17; std::swap(lanes[i], lanes[lrng % (unsigned)(i + 1)]); }
+            for (int i = 0; i < cnt; i++) {
+                const int t = t0 + lanes[i];
                 if (b->fibers[t].done) continue;
                 b->cur = t;
                 swapcontext(&b->sched, &b->fibers[t].ctx);
             }
+        }
         if (b->progress == before && b->alive_block > 0 && skip == 0) {
             fprintf(stderr, "simt: stall -- a collective was reached by only part of the live lanes (divergent control flow around it)\n");
             abort();

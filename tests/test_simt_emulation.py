@@ -48,7 +48,7 @@ print('emulation ok', n)
 """
 
 
-@pytest.mark.parametrize("env", [{"SIMT_SHUFFLE": "7", "SIMT_BLOCK_ORDER": "reverse"},
+@pytest.mark.parametrize("env", [{"SIMT_SHUFFLE": "7", "SIMT_BLOCK_ORDER": "reverse", "SIMT_LANE_ORDER": "reverse", "SIMT_STRICT_LANES": "1"},
                                  {"SIMT_LDS_RANDOM": "3", "SIMT_MALLOC_FILL": "r9", "SIMT_BLOCK_ORDER": "4", "ORBX_PYR_CHAIN": "2", "SIMT_SHUFFLE": "5"}])
 def test_emulated_extractor_small_image_stagewise(emul_lib, env):
     """Pyramid, blur, FAST candidates, quad-tree output, keypoints and descriptors of the emulated device code == oracle; also with the
@@ -115,7 +115,7 @@ print('emulation ok')
 
 @pytest.mark.parametrize("env", [{"SIMT_STREAM_FUZZ": "first", "ORBX_OCTREE_KEYS": "2048", "SIMT_MALLOC_FILL": "255"},
                                  {"SIMT_STREAM_FUZZ": "last", "ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full", "ORBX_WINDOW_DPP": "1", "SIMT_BLOCK_ORDER": "reverse"},
-                                 {"SIMT_STREAM_FUZZ": "7", "ORBX_PYR_CHAIN": "1", "ORBX_DESCRIBE": "2", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11"}],
+                                 {"SIMT_STREAM_FUZZ": "7", "ORBX_PYR_CHAIN": "1", "ORBX_DESCRIBE": "2", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11", "SIMT_LANE_ORDER": "3", "SIMT_LDS_RANDOM": "8"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "in-order")
 def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     """Three 8-frame batches, two in flight, through extract_batch_device / extract_batch_host (from 8 frames on a frame's workgroups
