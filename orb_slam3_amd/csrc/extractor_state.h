@@ -53,7 +53,11 @@ struct DevBuf {
         if (guard_mode() == 0) {
             ORBX_HIP(hipMalloc(&p, need));
             bytes = need;
+            // the clear must have RUN before anybody uses the buffer: hipMemset may return before the fill executes (it is queued on the
+            // null stream), and the library's non-blocking streams do not wait for the null stream -- a copy or kernel enqueued right
+            // after ensure() could otherwise be overtaken by the zeros (seen once: the first host-input batch into a fresh slab)
             ORBX_HIP(hipMemset(p, 0, need));
+            ORBX_HIP(hipDeviceSynchronize());
             if (getenv("ORBX_DEBUG_ALLOC")) fprintf(stderr, "[orbx alloc] %p .. %p  %zu bytes\n", p, (char *)p + need, need);
             return ORBX_OK;
         }
@@ -76,6 +80,7 @@ struct DevBuf {
         ORBX_HIP(hipMemSetAccess((char *)va + gran, map_bytes, &acc, 1));
         guarded = true;
         ORBX_HIP(hipMemset((char *)va + gran, guard_fill(), map_bytes));
+        ORBX_HIP(hipDeviceSynchronize());   // as above
         p = (char *)va + gran + (guard_mode() == 1 ? map_bytes - need16 : 0);
         bytes = need;
         return ORBX_OK;

@@ -271,6 +271,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ORBX_HIP(hipMemcpy(ex->d_ftiles.p, ftiles.data(), sizeof(FastTile) * ftiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_tiles.p, blur_tiles.data(), sizeof(TileRef) * blur_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
+    ORBX_HIP(hipDeviceSynchronize());   // the fill has run (DevBuf::ensure, extractor_state.h)
     ex->lv = lv;
     ex->width = width; ex->height = height; ex->batch_cap = B;
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
@@ -1090,6 +1091,7 @@ int orbx_debug_octree_timing(orbx_extractor *ex, int level, int64_t *out16) {
         int r = ex->d_octdbg.ensure(16 * 8);
         if (r != ORBX_OK) return r;
         ORBX_HIP(hipMemset(ex->d_octdbg.p, 0, 16 * 8));
+        ORBX_HIP(hipDeviceSynchronize());
     } else {
         ex->d_octdbg.release();
     }

@@ -36,13 +36,14 @@ void sync_stream(hipStream_t s);
 void sync_event(hipEvent_t e);
 void sync_all();
 hipStream_t new_stream();
+hipStream_t null_stream();
 hipEvent_t new_event();
 }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = simt::new_stream(); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = simt::new_stream(); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = simt::new_stream(); return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { simt::sync_stream(s); return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t s) { simt::sync_stream(s); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t s) { simt::sync_stream(s ? s : simt::null_stream()); return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { simt::wait_event(s, e); return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = simt::new_event(); return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = simt::new_event(); return hipSuccess; }
@@ -69,9 +70,9 @@ inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
-inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemset(void *p, int v, size_t n) { simt::enqueue(simt::null_stream(), [=] { memset(p, v, n); }); return hipSuccess; }   // see null_stream()
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s) { simt::enqueue(s, [=] { memset(p, v, n); }); return hipSuccess; }
-inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { simt::sync_stream(simt::null_stream()); memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st) { simt::enqueue(st, [=] { memmove(d, s, n); }); return hipSuccess; }
 inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t st) {
     simt::enqueue(st, [=] { for (size_t y = 0; y < h; y++) memmove((char *)d + y * dp, (const char *)s + y * sp, w); });

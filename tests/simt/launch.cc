@@ -83,6 +83,15 @@ Rt &rt() { static Rt r; return r; }
 bool fuzz() { return rt().fuzz; }
 hipStream_t new_stream() { auto *s = new simt_stream(); rt().streams.push_back(s); return s; }
 hipEvent_t new_event() { return new simt_event(); }
+// SIMT_MEMSET_ASYNC=1 (with SIMT_STREAM_FUZZ): hipMemset(), like cudaMemset(), may return before the fill has run -- it is queued on the
+// null stream, which the (non-blocking) streams of the library do not wait for.  The null stream counts as the stream created first.
+hipStream_t null_stream() {
+    static hipStream_t ns = [] () -> hipStream_t {
+        if (!rt().fuzz || !getenv("SIMT_MEMSET_ASYNC")) return nullptr;
+        auto *s = new simt_stream(); rt().streams.insert(rt().streams.begin(), s); return s;
+    }();
+    return ns;
+}
 static bool runnable(const simt_stream::Op &op) { return !op.wait || op.wait->done >= op.wait_ticket; }
 static void run_op(simt_stream *s) {
     simt_stream::Op op = std::move(s->q.front());
