@@ -57,7 +57,8 @@ struct DevBuf {
             // null stream), and the library's non-blocking streams do not wait for the null stream -- a copy or kernel enqueued right
             // after ensure() could otherwise be overtaken by the zeros (seen once: the first host-input batch into a fresh slab)
             ORBX_HIP(hipMemset(p, 0, need));
-            ORBX_HIP(hipDeviceSynchronize());
+            static const bool nosync = getenv("ORBX_ENSURE_NOSYNC") != nullptr;   // diagnostic: the behaviour before the fix (tools/r03_first.sh)
+            if (!nosync) ORBX_HIP(hipDeviceSynchronize());
             if (getenv("ORBX_DEBUG_ALLOC")) fprintf(stderr, "[orbx alloc] %p .. %p  %zu bytes\n", p, (char *)p + need, need);
             return ORBX_OK;
         }

@@ -11,6 +11,10 @@ export TMPDIR=/tmp
 timeout 200 python3 -m pytest tests/test_gpu_pipeline.py tests/test_gpu_extractor.py -m gpu -q -rxX \
     -k "open_small_canvas or open_random_image_sweep or open_first_host_batch" > gpurun_out/r03a/open.log 2>&1
 echo "open items rc=$?"; tail -40 gpurun_out/r03a/open.log
+# the same sequence with the clear of DevBuf::ensure left unsynchronised (the code before the fix): expected to FAIL (xfail) if the
+# asynchronous hipMemset is the cause
+ORBX_ENSURE_NOSYNC=1 timeout 120 python3 -m pytest tests/test_gpu_pipeline.py -m gpu -q -rxX -k "open_first_host_batch" > gpurun_out/r03a/open_nosync.log 2>&1
+echo "unsynchronised clear rc=$?"; tail -15 gpurun_out/r03a/open_nosync.log
 bash tools/open_item_probe.sh 4 2>&1 | tee gpurun_out/r03a/probe.log
 ORBX_TEST_SWITCHES=1 timeout 240 python3 -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -k alternative_switches > gpurun_out/r03a/switches.log 2>&1
 echo "switches rc=$?"; tail -12 gpurun_out/r03a/switches.log
