@@ -179,6 +179,7 @@ def test_match_consecutive_device_equals_host_api(oracle, canvas1):
     cap = ex.batch_view().cap
     d_match = torch.full((nfr, cap), -7, dtype=torch.int32, device="cuda")
     d_nm = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on ITS stream; the library's non-blocking streams do not wait for it
     ex.match_consecutive_device(d_match.data_ptr(), d_nm.data_ptr(), th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
     ex.sync()
     match, nm = d_match.cpu().numpy(), d_nm.cpu().numpy()
@@ -225,6 +226,7 @@ def test_async_download_pipeline_equals_sync(canvas1):
         ex2.extract_batch_device(d_batches[b].data_ptr(), nfr, 752, 480, 752, 752 * 480, (0, 1000))
         d_match = torch.full((nfr, cap), -1, dtype=torch.int32, device="cuda")
         d_nm = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
         ex2.match_consecutive_device(d_match.data_ptr(), d_nm.data_ptr(), th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
         ex2.sync()
         hs = sets[b]

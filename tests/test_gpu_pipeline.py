@@ -201,6 +201,7 @@ def test_search_mappoints_batch_device_equals_oracle(oracle, w, h, nf, n_mp, th)
     cap = ex.batch_view().cap
     d_match = torch.full((B, cap), -7, dtype=torch.int32, device="cuda")
     d_nm = torch.full((B,), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on ITS stream; the library's non-blocking streams do not wait for it
     for _ in range(2):   # second call = cached problem descriptors
         ex.search_mappoints_batch_device(n_mp, dev["proj_x"].data_ptr(), dev["proj_y"].data_ptr(), dev["level"].data_ptr(),
                                          dev["view_cos"].data_ptr(), dev["in_view"].data_ptr(), dev["desc"].data_ptr(), th=th, nnratio=0.8,
