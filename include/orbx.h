@@ -90,7 +90,9 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
 
 /* Batched form over device-resident frames (one camera stream = one extractor = one HIP stream).
  * d_images: device pointer; frame f row y starts at d_images + f*frame_stride + y*row_stride.
- * Enqueues all kernels asynchronously on the extractor's stream; results stay in HBM until downloaded. */
+ * Enqueues all kernels asynchronously on the extractor's stream; results stay in HBM until downloaded.
+ * The extractor's streams are non-blocking: d_images (like every device buffer handed to an orbx_*_device call) must be complete
+ * when the call is made, and must stay untouched until orbx_sync / orbx_download_wait. */
 int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int n_frames, int width, int height,
                               size_t row_stride, size_t frame_stride, int lap0, int lap1);
 
