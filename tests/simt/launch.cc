@@ -13,30 +13,39 @@ uint8_t *dyn_lds() {
     if (!g_lds) g_lds = (uint8_t *)aligned_alloc(4096, 256 * 1024);
     return g_lds;
 }
-void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body) {
+// Workgroups of a launch run one after another.  SIMT_BLOCK_ORDER=reverse runs them last to first, SIMT_BLOCK_ORDER=<seed> in a
+// different random order for every launch: a result that changes with it depends on the order in which workgroups reach a
+// global atomic (list appends, counters) -- which the hardware does not define.
+std::vector<uint32_t> block_order(dim3 grid) {
+    static const char *order = getenv("SIMT_BLOCK_ORDER");
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    std::vector<uint32_t> perm(nblocks);
+    for (size_t i = 0; i < nblocks; i++) perm[i] = (uint32_t)i;
+    if (order && !strcmp(order, "reverse")) std::reverse(perm.begin(), perm.end());
+    else if (order) {
+        static unsigned long long st = strtoull(order, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+        for (size_t i = nblocks; i > 1; i--) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; std::swap(perm[i - 1], perm[st % i]); }
+    }
+    return perm;
+}
+// SIMT_KERNEL_SPLIT=<n> (with SIMT_STREAM_FUZZ): a launch is queued as up to n pieces (runs of workgroups), so that the scheduler
+// interleaves the workgroups of kernels that sit on different streams -- kernels overlapping in time, at workgroup granularity.
+int kernel_split() {
+    static const int n = [] { const char *e = getenv("SIMT_KERNEL_SPLIT"); return e ? atoi(e) : 0; }();
+    return n;
+}
+void launch_blocks(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body, const uint32_t *ids, size_t n,
+                   bool announce) {
     static const bool trace = getenv("SIMT_TRACE") != nullptr;
-    if (trace) fprintf(stderr, "simt: %s grid (%u, %u, %u) block %u lds %zu\n", name, grid.x, grid.y, grid.z, block.x, lds_bytes);
+    static const bool trace_pieces = trace && atoi(getenv("SIMT_TRACE")) >= 2;   // SIMT_TRACE=2: one line per piece of a split launch
+    if (trace && announce) fprintf(stderr, "simt: %s grid (%u, %u, %u) block %u lds %zu\n", name, grid.x, grid.y, grid.z, block.x, lds_bytes);
+    else if (trace_pieces) fprintf(stderr, "simt:   piece of %s from workgroup #%u (%zu)\n", name, n ? ids[0] : 0u, n);
     if (lds_bytes > 200 * 1024) { fprintf(stderr, "simt: %zu bytes of dynamic LDS\n", lds_bytes); abort(); }
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads > 1024) { fprintf(stderr, "simt: %d threads per block\n", nthreads); abort(); }
     Dim3 g; g.x = grid.x; g.y = grid.y; g.z = grid.z;
-    // Workgroups of a launch run one after another.  SIMT_BLOCK_ORDER=reverse runs them last to first, SIMT_BLOCK_ORDER=<seed> in a
-    // different random order for every launch: a result that changes with it depends on the order in which workgroups reach a
-    // global atomic (list appends, counters) -- which the hardware does not define.
-    static const char *order = getenv("SIMT_BLOCK_ORDER");
-    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
-    std::vector<uint32_t> perm;
-    if (order) {
-        perm.resize(nblocks);
-        for (size_t i = 0; i < nblocks; i++) perm[i] = (uint32_t)i;
-        if (!strcmp(order, "reverse")) std::reverse(perm.begin(), perm.end());
-        else {
-            static unsigned long long st = strtoull(order, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
-            for (size_t i = nblocks; i > 1; i--) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; std::swap(perm[i - 1], perm[st % i]); }
-        }
-    }
-    for (size_t i = 0; i < nblocks; i++) {
-        const size_t id = order ? perm[i] : i;
+    for (size_t i = 0; i < n; i++) {
+        const size_t id = ids[i];
         Dim3 b; b.x = (unsigned)(id % grid.x); b.y = (unsigned)(id / grid.x % grid.y); b.z = (unsigned)(id / ((size_t)grid.x * grid.y));
         // LDS is not zero on entry: a fixed pattern, or (SIMT_LDS_RANDOM=<seed>) different garbage for every block -- a result
         // that changes with it depends on LDS the kernel never wrote
@@ -52,6 +61,10 @@ void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std
         }
         run_block(g, b, nthreads, body);
     }
+}
+void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body) {
+    const std::vector<uint32_t> ids = block_order(grid);
+    launch_blocks(name, grid, block, lds_bytes, body, ids.data(), ids.size(), true);
 }
 }  // namespace simt
 

@@ -116,7 +116,7 @@ print('emulation ok')
 @pytest.mark.parametrize("env", [{"SIMT_STREAM_FUZZ": "first", "ORBX_OCTREE_KEYS": "2048", "SIMT_MALLOC_FILL": "255"},
                                  {"SIMT_STREAM_FUZZ": "last", "ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full", "ORBX_WINDOW_DPP": "1", "SIMT_BLOCK_ORDER": "reverse"},
                                  {"SIMT_STREAM_FUZZ": "7", "ORBX_PYR_CHAIN": "1", "ORBX_DESCRIBE": "2", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11", "SIMT_LANE_ORDER": "3", "SIMT_LDS_RANDOM": "8"},
-                                 {"SIMT_STREAM_FUZZ": "5", "SIMT_MEMSET_ASYNC": "1"}],
+                                 {"SIMT_STREAM_FUZZ": "5", "SIMT_MEMSET_ASYNC": "1", "SIMT_KERNEL_SPLIT": "6"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "in-order")
 def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     """Three 8-frame batches, two in flight, through extract_batch_device / extract_batch_host (from 8 frames on a frame's workgroups
@@ -126,6 +126,7 @@ def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     and the side streams starve until something waits for them, `last`: the reverse, a number: random -- so that a missing event
     dependency between streams shows up as a wrong result (checked: with the main stream's waits for the matcher / the download
     removed, `first` fails).  Also: k_grid_build2 + the full-frame re-scan, and the chained pyramid kernel.
+    SIMT_KERNEL_SPLIT: every launch is queued in pieces, so that kernels on different streams interleave at workgroup granularity.
     SIMT_MEMSET_ASYNC: hipMemset() returns before the fill has run (queued on the null stream, which the library's non-blocking streams
     do not wait for) -- with the clear of DevBuf::ensure left unsynchronised this schedule zeroes frame 0 of the first host-input batch
     AFTER its upload (the probable cause of the 1007-vs-1008 keypoints seen once on the hardware)."""
