@@ -76,14 +76,14 @@ def _run_pipeline(oracle, B, steps, canvas_size=2048, n_shapes=2400):
     ex.sync()
 
 
-_OPEN = ("seen once at the end of round 2 (GPU budget spent before it could be chased): a child of test_pipeline_under_alternative_switches "
-         "delivered 1007 keypoints where the oracle has 1008 -- frame 0 of batch 3, the first host-input batch into a freshly allocated input "
-         "slab (canvas 11, size 1024, 700 shapes).  Probable cause (DESIGN.md section 6): DevBuf::ensure cleared the slab with an "
-         "asynchronous hipMemset that nothing ordered against the upload; the oracle gives exactly 1007 for that frame with its first "
-         "16 KB zeroed.  Fixed (ensure waits for the fill); xfail until the fix has been seen green on the hardware")
+# History of the three tests below: at the end of round 2 a child of test_pipeline_under_alternative_switches delivered 1007 keypoints
+# where the oracle has 1008 -- frame 0 of batch 3, the first host-input batch into a freshly allocated input slab (canvas 11, size
+# 1024, 700 shapes).  Probable cause: DevBuf::ensure cleared the slab with an asynchronous hipMemset that
+# nothing ordered against the upload; the oracle gives exactly 1007 for that frame with its first 16 KB zeroed.  Fixed (ensure waits
+# for the fill).  With the fix all three passed on the MI355X (profiles/r02_k_open_item_after_fix.log, 24 fresh-slab trials in the
+# third test), so they are ordinary tests now; the control run with ORBX_ENSURE_NOSYNC=1 (tools/r03_first.sh) is still to be done.
 
 
-@pytest.mark.xfail(strict=False, reason=_OPEN)
 def test_open_small_canvas_single_image(oracle):
     import orb_slam3_amd as osa
     from orb_slam3_amd import synth
@@ -94,12 +94,10 @@ def test_open_small_canvas_single_image(oracle):
     assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
 
 
-@pytest.mark.xfail(strict=False, reason=_OPEN)
 def test_open_small_canvas_short_batches(oracle):
     _run_pipeline(oracle, 16, 4, canvas_size=1024, n_shapes=700)
 
 
-@pytest.mark.xfail(strict=False, reason=_OPEN)
 def test_open_first_host_batch_into_fresh_slab(oracle):
     """The suspected sequence itself, 12 times over: a NEW extractor, whose first call is a host-input batch (configure allocates and clears
     every buffer, the input slab is allocated, cleared and filled by the upload right away) -- first and last frame == oracle; then a

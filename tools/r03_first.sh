@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU visit of round 3 (prepared at the end of round 2, when the GPU budget was spent):
-#  1. the two discriminating reproductions of the open 1007-vs-1008 keypoint difference + the stage-wise image sweep (all xfail),
+#  1. the two discriminating reproductions of the open 1007-vs-1008 keypoint difference + the stage-wise image sweep (xfail in round 2; green with the fix at the end of round 2, ordinary tests now),
 #     with full output: which of them fails, and at which stage, says whether it is data or ordering
 #     + tools/open_item_probe.sh: failure rate of the short-batch loop with side streams off / serialized kernels / blocking launches
 #  2. the opt-in pipeline test of every round-2 switch (child processes)
