@@ -15,7 +15,7 @@ echo "open items rc=$?"; tail -40 gpurun_out/r03a/open.log
 # asynchronous hipMemset is the cause
 ORBX_ENSURE_NOSYNC=1 timeout 120 python3 -m pytest tests/test_gpu_pipeline.py -m gpu -q -rxX -k "open_first_host_batch" > gpurun_out/r03a/open_nosync.log 2>&1
 echo "unsynchronised clear rc=$?"; tail -15 gpurun_out/r03a/open_nosync.log
-bash tools/open_item_probe.sh 4 2>&1 | tee gpurun_out/r03a/probe.log
+ORBX_PROBE_SETTINGS="ORBX_NONE=1|ORBX_ENSURE_NOSYNC=1" bash tools/open_item_probe.sh 5 2>&1 | tee gpurun_out/r03a/probe.log
 ORBX_TEST_SWITCHES=1 timeout 240 python3 -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -k alternative_switches > gpurun_out/r03a/switches.log 2>&1
 echo "switches rc=$?"; tail -12 gpurun_out/r03a/switches.log
 bash tools/ab.sh "ORBX_NONE=1" "ORBX_PYR_CHAIN=1" "ORBX_PYR_CHAIN=2" "ORBX_GRID_BUILD=2" "ORBX_WINDOW_DPP=1" "ORBX_DESCRIBE=2" "ORBX_OCTREE_KEYS=2048" "ORBX_PYR_CHAIN=1 ORBX_GRID_BUILD=2 ORBX_WINDOW_DPP=1" 2>&1 | tee gpurun_out/r03a/ab.log
