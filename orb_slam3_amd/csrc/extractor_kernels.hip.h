@@ -2,13 +2,14 @@
 //
 // Stage -> reference function (all line numbers in /root/reference/src/ORBextractor.cc):
 //   k_pyr_base        copyMakeBorder of the input into level 0                 :1188-1191
-//   k_pyr_resize      cv::resize(INTER_LINEAR) level l-1 -> l + REFLECT_101    :1183-1186
-//   k_fast_wave       per-cell cv::FAST(ini) / fallback cv::FAST(min) + NMS    :805-870   (one wave per cell; k_fast_wave_list
-//                     for cells whose candidate queue overflows, k_fast_cells = generic workgroup-per-cell form)
-//   k_compact, k_octree_par (octree_par.hip.h)  DistributeOctTree / DivideNode / compareNodes   :480-779
-//                     (k_octree in octree.hip.h = sequential emulation, selectable reference)
+//   k_pyr_resize2     cv::resize(INTER_LINEAR) level l-1 -> l + REFLECT_101    :1183-1186
+//   k_fast_ini        per-cell cv::FAST(ini) + NMS                             :805-842   (one wave per cell)
+//   k_fast_wave_list  cells the first pass left empty: cv::FAST(ini) / fallback cv::FAST(min)   :843-870
+//                     (k_fast_cells = generic workgroup-per-cell form for cells wider than 57 px)
+//   k_compact, k_octree_par_t (octree_par.hip.h)  DistributeOctTree / DivideNode / compareNodes   :480-779
+//                     (k_octree in octree.hip.h = sequential emulation for node pools beyond the LDS budget)
 //   k_finalize        level concatenation + lapping split slots                :1117-1162
-//   k_blur            GaussianBlur 7x7 sigma 2 (fixed point)                   :1132-1133
+//   k_blur_pk         GaussianBlur 7x7 sigma 2 (fixed point)                   :1132-1133
 //   k_describe        IC_Angle + computeOrbDescriptor + keypoint record        :76-146, 1143-1162
 //
 // Integer pixel / bit work: no MFMA.  Built with -ffp-contract=off; the only fused float ops are the explicit
@@ -123,111 +124,11 @@ __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(
 
 constexpr int kResizeRows = 2;  // output rows per thread (measured: 1 -> 0.032, 2 -> 0.024, 4 -> 0.033 ms per level launch)
 
-// PK (round 2): the vertical pass without the two arithmetic shifts and the clamp per pixel.  With Q11 taps b0 + b1 = 2048 and
+// The vertical pass runs without the two arithmetic shifts and the clamp per pixel.  With Q11 taps b0 + b1 = 2048 and
 // horizontal sums h <= 255 * 2048, both products b * (h >> 4) are non-negative and below 2^27, so "(p0 >> 16) + (p1 >> 16) + 2" is
 // ONE v_add_u32_sdwa of the two high words once the rounding constant rides in p0 (p0 = b0 * (h0 >> 4) + (2 << 16), a v_mad_u32_u24),
 // the result is at most 1022 (no clamp to 255 after the >> 2), and two pixels shift + pack in one v_ashr_pk_u8_i32 (gfx950).
-template <bool PK>
-__global__ __launch_bounds__(256) void k_pyr_resize(const LevelInfo L, const LevelInfo P,   // levels l and l-1 travel as kernel arguments: no table round trip
-                                                    const ResizeTap *__restrict__ xtab,
-                                                    const ResizeTap *__restrict__ ytab,
-                                                    const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr,
-                                                    size_t pyr_frame_stride, uint32_t wpr_rcp, int n_frames) {
-    int bx, f;
-    if (!xcd_frame_map(n_frames, &bx, &f)) return;   // source rows shared by neighbouring workgroups hit the frame's XCD L2
-    const int wpr = L.pitch >> 2;
-    const int idx = bx * 256 + threadIdx.x;
-    // idx / wpr as one multiply-high by ceil(2^32 / wpr) (exact while idx * wpr < 2^32); the generic division is ~30 instructions,
-    // four of them quarter-rate -- a fifth of this kernel's VALU issue
-    const int pg = (int)__umulhi((uint32_t)idx, wpr_rcp), wi = idx - (int)__umul24((uint32_t)pg, (uint32_t)wpr);
-    const int rows = L.h + 2 * kEdge;
-    const int py0 = pg * kResizeRows;
-    if (py0 >= rows) return;
-    uint8_t *frame = pyr + (size_t)f * pyr_frame_stride;
-    const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX;  // previous level ROI origin
-    const uint4 gc = *reinterpret_cast<const uint4 *>(&xg[L.xg_off + wi].cc[0]);
-    const uint4 gh = *reinterpret_cast<const uint4 *>(&xg[L.xg_off + wi]);  // base, sel, valid
-    uint8_t *drow = frame + L.off + (size_t)py0 * L.pitch + wi * 4;
-    if (gh.z == 2) {  // pitch padding left / right of the ring (about one dword column in seven): nothing to compute
-#pragma unroll
-        for (int r = 0; r < kResizeRows; r++)
-            if (py0 + r < rows) *reinterpret_cast<uint32_t *>(drow + (size_t)r * L.pitch) = 0u;
-        return;
-    }
-    ResizeTap ty[kResizeRows];
-#pragma unroll
-    for (int r = 0; r < kResizeRows; r++) ty[r] = ytab[L.ytab_off + reflect101(min(py0 + r, rows - 1) - kEdge, L.h)];
-    if (gh.z) {
-        // all eight source bytes of a row in one unaligned 8-byte load; v_perm_b32 picks the left / right taps
-        uint2 r0[kResizeRows], r1[kResizeRows];
-#pragma unroll
-        for (int r = 0; r < kResizeRows; r++) {
-            const int sy0 = min(max(ty[r].ofs, 0), P.h - 1), sy1 = min(max(ty[r].ofs + 1, 0), P.h - 1);
-            __builtin_memcpy(&r0[r], proi + (uint32_t)(__umul24((uint32_t)sy0, (uint32_t)P.pitch) + gh.x), 8);
-            __builtin_memcpy(&r1[r], proi + (uint32_t)(__umul24((uint32_t)sy1, (uint32_t)P.pitch) + gh.x), 8);
-        }
-        const uint32_t selr = gh.y + 0x01010101u;
-        const uint32_t cc[4] = {gc.x, gc.y, gc.z, gc.w};
-        constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
-#pragma unroll
-        for (int r = 0; r < kResizeRows; r++) {
-            const uint32_t l0 = __builtin_amdgcn_perm(r0[r].y, r0[r].x, gh.y), q0 = __builtin_amdgcn_perm(r0[r].y, r0[r].x, selr);
-            const uint32_t l1 = __builtin_amdgcn_perm(r1[r].y, r1[r].x, gh.y), q1 = __builtin_amdgcn_perm(r1[r].y, r1[r].x, selr);
-            const int b0 = ty[r].c0, b1 = ty[r].c1;
-            uint32_t out = 0;
-            if (PK) {   // the tables hold bilinear tap pairs: 0 <= b0, b1 <= 2048
-                int t[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t h0 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
-                    const uint32_t h1 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
-                    const uint32_t p0 = __umul24(h0 >> 4, (uint32_t)b0) + 0x20000u, p1 = __umul24(h1 >> 4, (uint32_t)b1);
-                    t[k] = (int)((p0 >> 16) + (p1 >> 16));   // the SDWA peephole folds both shifts into the add's operand selects
-                }
-                // (t >> 2) saturated to a byte, two pixels per instruction (the saturation never acts: t <= 1022)
-                // v_ashr_pk_u8_i32: byte 0 = sat_u8(src0 >> 2), byte 1 = sat_u8(src1 >> 2)
-                const uint32_t lo = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 2);
-                const uint32_t hi = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 2);
-                out = lo | (hi << 16);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // horizontal pass: S[sx] * alpha0 + S[sx+1] * alpha1 as one v_dot2_u32_u16 (cc[k] = alpha0 | alpha1 << 16)
-                    const int h0 = (int)__builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
-                    const int h1 = (int)__builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
-                    int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
-                    v = min(max(v, 0), 255);
-                    out |= (uint32_t)v << (8 * k);
-                }
-            }
-            if (py0 + r < rows) *reinterpret_cast<uint32_t *>(drow + (uint32_t)(r * L.pitch)) = out;
-        }
-    } else {
-        for (int r = 0; r < kResizeRows && py0 + r < rows; r++) {
-            const int sy0 = min(max(ty[r].ofs, 0), P.h - 1), sy1 = min(max(ty[r].ofs + 1, 0), P.h - 1);
-            const uint8_t *S0 = proi + (size_t)sy0 * P.pitch;
-            const uint8_t *S1 = proi + (size_t)sy1 * P.pitch;
-            const int b0 = ty[r].c0, b1 = ty[r].c1;
-            uint32_t out = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int x = wi * 4 + k - kRoiX;
-                if (x >= -kEdge && x < L.w + kEdge) {
-                    const ResizeTap tx = xtab[L.xtab_off + reflect101(x, L.w)];
-                    // when ofs+1 == P.w the tap c1 is 0 and the byte read is the (valid) ring pixel
-                    const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
-                    const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
-                    int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                    v = min(max(v, 0), 255);
-                    out |= (uint32_t)v << (8 * k);
-                }
-            }
-            *reinterpret_cast<uint32_t *>(drow + (size_t)r * L.pitch) = out;
-        }
-    }
-}
-
-// k_pyr_resize2: the same arithmetic, one thread = TWO adjacent dword columns (8 pixels) x 2 rows.  The resize chain is bound by the
+// k_pyr_resize2: one thread = TWO adjacent dword columns (8 pixels) x 2 rows.  The resize chain is bound by the
 // waves' lifetime (table loads -> source rows -> store: two dependent memory round trips, 8 waves per SIMD at most), not by issue or
 // bandwidth (2 TB/s), so a wave that keeps twice the bytes in flight for the same two round trips doubles the rate until VALU issue
 // binds; the two columns share their row taps, source rows (adjacent 8-byte loads) and one 8-byte store per row.
@@ -323,136 +224,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize2(const LevelInfo L, const Le
     const int idx = bx * 256 + threadIdx.x;
     const int pg = (int)__umulhi((uint32_t)idx, wpc_rcp), wg = idx - (int)__umul24((uint32_t)pg, (uint32_t)wpc);
     resize2_item(L, P, xtab, ytab, xg, pyr + (size_t)f * pyr_frame_stride, pg, wg);
-}
-
-// The same for N work items at once (k_pyr_chain only; resize2_item above stays as measured): the table loads of all items, then the
-// source loads of all items, then the arithmetic -- N = 2 keeps two items' round trips in flight per thread
-template <int N>
-__device__ __forceinline__ void resize2_items(const LevelInfo &L, const LevelInfo &P, const ResizeTap *__restrict__ xtab,
-                                              const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg, uint8_t *frame,
-                                              const int (&pg)[N], const int (&wg)[N]) {
-    const int rows = L.h + 2 * kEdge;
-    const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX;  // previous level ROI origin
-    int py0[N];
-    bool live[N];
-    uint4 gh[N][2], gc[N][2];
-    ResizeTap ty[N][kResizeRows];
-#pragma unroll
-    for (int n = 0; n < N; n++) {
-        py0[n] = pg[n] * kResizeRows;
-        live[n] = py0[n] < rows;
-        const int wgl = live[n] ? wg[n] : 0, pyl = live[n] ? py0[n] : 0;   // a dead item (past the last row pair) loads item (0, 0) and stores nothing
-        const uint4 *gp = reinterpret_cast<const uint4 *>(&xg[L.xg_off + 2 * wgl]);   // two ResizeGroup entries = 64 contiguous bytes
-        gh[n][0] = gp[0]; gc[n][0] = gp[1]; gh[n][1] = gp[2]; gc[n][1] = gp[3];
-#pragma unroll
-        for (int r = 0; r < kResizeRows; r++) ty[n][r] = ytab[L.ytab_off + reflect101(min(pyl + r, rows - 1) - kEdge, L.h)];
-    }
-    if (N == 1 && !live[0]) return;
-    uint32_t so0[N][kResizeRows], so1[N][kResizeRows];   // byte offsets of the two source rows of each output row
-    // every source load of the thread before any arithmetic: one memory round trip
-    uint2 r0[N][2][kResizeRows], r1[N][2][kResizeRows];
-#pragma unroll
-    for (int n = 0; n < N; n++) {
-#pragma unroll
-        for (int r = 0; r < kResizeRows; r++) {
-            const int sy0 = min(max(ty[n][r].ofs, 0), P.h - 1), sy1 = min(max(ty[n][r].ofs + 1, 0), P.h - 1);
-            so0[n][r] = __umul24((uint32_t)sy0, (uint32_t)P.pitch);
-            so1[n][r] = __umul24((uint32_t)sy1, (uint32_t)P.pitch);
-        }
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int r = 0; r < kResizeRows; r++) {
-                // unconditional (a column without taps reads the row's first bytes and ignores them): loads inside divergent blocks make
-                // the compiler wait for ALL outstanding loads at every block boundary -- four round trips instead of one
-                const uint32_t gx = gh[n][c].z == 1 ? gh[n][c].x : 0u;
-                __builtin_memcpy(&r0[n][c][r], proi + (so0[n][r] + gx), 8);
-                __builtin_memcpy(&r1[n][c][r], proi + (so1[n][r] + gx), 8);
-            }
-    }
-    constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
-#pragma unroll
-    for (int n = 0; n < N; n++) {
-        uint32_t out[2][kResizeRows];
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const uint32_t selr = gh[n][c].y + 0x01010101u;
-            const uint32_t cc[4] = {gc[n][c].x, gc[n][c].y, gc[n][c].z, gc[n][c].w};
-#pragma unroll
-            for (int r = 0; r < kResizeRows; r++) {
-                uint32_t o = 0;   // gh.z == 2: pitch padding outside the ring, zeros
-                if (gh[n][c].z == 1) {
-                    const uint32_t l0 = __builtin_amdgcn_perm(r0[n][c][r].y, r0[n][c][r].x, gh[n][c].y), q0 = __builtin_amdgcn_perm(r0[n][c][r].y, r0[n][c][r].x, selr);
-                    const uint32_t l1 = __builtin_amdgcn_perm(r1[n][c][r].y, r1[n][c][r].x, gh[n][c].y), q1 = __builtin_amdgcn_perm(r1[n][c][r].y, r1[n][c][r].x, selr);
-                    const int b0 = ty[n][r].c0, b1 = ty[n][r].c1;   // bilinear tap pair: 0 <= b0, b1 <= 2048
-                    int t[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t h0 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q0, l0, kPair[k])), as_pk(cc[k]), 0u, false);
-                        const uint32_t h1 = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q1, l1, kPair[k])), as_pk(cc[k]), 0u, false);
-                        const uint32_t p0 = __umul24(h0 >> 4, (uint32_t)b0) + 0x20000u, p1 = __umul24(h1 >> 4, (uint32_t)b1);
-                        t[k] = (int)((p0 >> 16) + (p1 >> 16));
-                    }
-                    const uint32_t lo = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 2);
-                    const uint32_t hi = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 2);
-                    o = lo | (hi << 16);
-                } else if (gh[n][c].z == 0) {   // taps further apart than 8 bytes (scale factor > 2): table form, as in k_pyr_resize
-                    const uint8_t *S0 = proi + so0[n][r], *S1 = proi + so1[n][r];
-                    const int b0 = ty[n][r].c0, b1 = ty[n][r].c1;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int x = (2 * wg[n] + c) * 4 + k - kRoiX;
-                        if (x >= -kEdge && x < L.w + kEdge) {
-                            const ResizeTap tx = xtab[L.xtab_off + reflect101(x, L.w)];
-                            const int h0 = S0[tx.ofs] * tx.c0 + S0[tx.ofs + 1] * tx.c1;
-                            const int h1 = S1[tx.ofs] * tx.c0 + S1[tx.ofs + 1] * tx.c1;
-                            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                            v = min(max(v, 0), 255);
-                            o |= (uint32_t)v << (8 * k);
-                        }
-                    }
-                }
-                out[c][r] = o;
-            }
-        }
-        if (live[n]) {
-            uint8_t *drow = frame + L.off + (size_t)py0[n] * L.pitch + wg[n] * 8;
-#pragma unroll
-            for (int r = 0; r < kResizeRows; r++)
-                if (py0[n] + r < rows) *reinterpret_cast<uint2 *>(drow + (uint32_t)(r * L.pitch)) = make_uint2(out[0][r], out[1][r]);
-        }
-    }
-}
-
-// k_pyr_chain (ORBX_PYR_CHAIN=1; written at the end of round 2, verified against the oracle under the CPU SIMT emulator, NOT yet
-// measured on the hardware): the whole resize chain of a frame in ONE workgroup of 1024 threads -- levels 1 .. n-1 one after the
-// other with a workgroup barrier in between -- instead of seven dependent launches.  A frame's levels are produced and consumed by
-// the same CU (its writes go through to the XCD's L2, where the next level's reads find them), the six kernel boundaries with their
-// cache write-backs / invalidations and launch gaps disappear; the price is one workgroup per CU (16 of 32 wave slots) for the 256
-// frames of a batch.  ILP = 2: two work items per thread and iteration, their table and source round trips in flight together (the
-// kernel's time is the waves' lifetime at 4 waves per SIMD).  grid (B), block 1024
-template <int ILP>   // work items per thread and loop iteration (ORBX_PYR_CHAIN=1 / 2)
-__global__ __launch_bounds__(1024) void k_pyr_chain(const LevelInfo *__restrict__ lv, int nlevels, const ResizeTap *__restrict__ xtab,
-                                                    const ResizeTap *__restrict__ ytab, const ResizeGroup *__restrict__ xg,
-                                                    uint8_t *__restrict__ pyr, size_t pyr_frame_stride) {
-    uint8_t *frame = pyr + (size_t)blockIdx.x * pyr_frame_stride;
-    for (int l = 1; l < nlevels; l++) {
-        const LevelInfo L = lv[l], P = lv[l - 1];
-        const int wpc = L.pitch >> 3, npg = (L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows;
-        const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)wpc - 1u) / (uint32_t)wpc);   // wave-uniform: scalar unit
-        for (int it0 = threadIdx.x; it0 < wpc * npg; it0 += 1024 * ILP) {
-            int pg[ILP], wg[ILP];
-#pragma unroll
-            for (int n = 0; n < ILP; n++) {
-                const int it = it0 + 1024 * n;   // past the end: pg >= npg, a dead item
-                pg[n] = (int)__umulhi((uint32_t)it, rcp);
-                wg[n] = it - (int)__umul24((uint32_t)pg[n], (uint32_t)wpc);
-            }
-            resize2_items<ILP>(L, P, xtab, ytab, xg, frame, pg, wg);
-        }
-        __threadfence_block();   // this level's stores before the next level's loads (same workgroup, same CU)
-        __syncthreads();
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1208,73 +979,8 @@ constexpr int kBlurTW = 256;            // pixels per wave row
 constexpr int kBlurRows = 42;           // output rows per wave (6 prologue rows + 6 x 7 main-loop rows)
 constexpr int kBlurTH = 4 * kBlurRows;  // rows per workgroup
 
-__device__ __forceinline__ void blur_hrow(const uint8_t *__restrict__ rowp, uint32_t tap_lo, uint32_t tap_hi, uint32_t h[4]) {
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(rowp);
-    const uint32_t wm = p[-1], wc = p[0], wp = p[1];  // pixels x0-4 .. x0+7
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        // window of pixel x0+j: bytes (x0+j-3 .. x0+j) and (x0+j+1 .. x0+j+4)
-        // (v_alignbyte uses only 2 shift bits: the 4-byte shift of j == 3 is the next dword itself)
-        const uint32_t lo = (j == 3) ? wc : __builtin_amdgcn_alignbyte(wc, wm, 1 + j);
-        const uint32_t hi = (j == 3) ? wp : __builtin_amdgcn_alignbyte(wp, wc, 1 + j);
-        h[j] = __builtin_amdgcn_udot4(hi, tap_hi, __builtin_amdgcn_udot4(lo, tap_lo, 0u, false), false);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_blur(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
-                                              const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                              uint8_t *__restrict__ blur, size_t blur_frame_stride, int g0, int g1,
-                                              int g2, int g3) {
-    const TileRef t = tiles[blockIdx.x];
-    const int f = blockIdx.y;
-    const LevelInfo L = lv[t.level];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x0 = t.tj * kBlurTW + lane * 4;
-    const int y0 = (t.ti * 4 + wv) * kBlurRows;
-    if (x0 >= L.w || y0 >= L.h) return;
-    const uint32_t tap_lo = (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) | ((uint32_t)g3 << 24);  // x-3..x
-    const uint32_t tap_hi = (uint32_t)g2 | ((uint32_t)g1 << 8) | ((uint32_t)g0 << 16);                          // x+1..x+3
-    const uint8_t *roi = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)kEdge * L.pitch + kRoiX + x0;
-    uint8_t *dst = blur + (size_t)f * blur_frame_stride + L.boff + x0;
-    const int ymax = L.h + kEdge - 1;  // last ring row that exists
-    uint32_t hw[7][4];
-    auto src_row = [&](int r) -> const uint8_t * {  // r-th source row of this strip: level row y0 - 3 + r
-        const int y = min(y0 - 3 + r, ymax);   // >= -3: the ring rows above the ROI exist
-        return roi + (ptrdiff_t)__mul24(y, L.pitch);
-    };
-    auto emit = [&](int yo, int newest) {  // output row yo from the seven rows ending in slot `newest`
-        if (yo >= L.h) return;
-        uint32_t out = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            // row r-6+k sits in slot (newest + 1 + k) % 7
-            // 24-bit multiplies (taps < 2^8, sums of two horizontal results < 2^18): v_mad_u32_u24 issues at full rate,
-            // a 32-bit v_mul_lo_u32 at a quarter of it
-            const uint32_t s = __umul24((uint32_t)g0, hw[(newest + 1) % 7][j] + hw[newest][j]) +
-                               __umul24((uint32_t)g1, hw[(newest + 2) % 7][j] + hw[(newest + 6) % 7][j]) +
-                               __umul24((uint32_t)g2, hw[(newest + 3) % 7][j] + hw[(newest + 5) % 7][j]) +
-                               __umul24((uint32_t)g3, hw[(newest + 4) % 7][j]);
-            const uint32_t v = min((s + 32768u) >> 16, 255u);
-            out |= v << (8 * j);
-        }
-        *reinterpret_cast<uint32_t *>(dst + (uint32_t)__umul24((uint32_t)yo, (uint32_t)L.bpitch)) = out;
-    };
-#pragma unroll
-    for (int r = 0; r < 6; r++) blur_hrow(src_row(r), tap_lo, tap_hi, hw[r]);
-    for (int gidx = 0; gidx < kBlurRows / 7; gidx++) {
-        const int rbase = 6 + gidx * 7;
-        if (y0 + rbase - 6 >= L.h) break;
-#pragma unroll
-        for (int sidx = 0; sidx < 7; sidx++) {
-            const int slot = (6 + sidx) % 7;
-            blur_hrow(src_row(rbase + sidx), tap_lo, tap_hi, hw[slot]);
-            emit(y0 + rbase + sidx - 6, slot);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// k_blur_pk: the same filter with half the VALU work per row and L2-local tiles (round 2; k_blur is kept as ORBX_BLUR_KERNEL=0).
+// k_blur_pk: the same filter with half the VALU work per row and L2-local tiles (round 2; the round-1 form -- v_alignbyte windows, 66 VALU per row -- is gone).
 //   * horizontal pass without byte alignment: the window of pixel x0+j is three (j = 1, 2) or two (j = 0, 3) v_dot4_u32_u8 of the
 //     ALIGNED dwords against tap dwords shifted instead of the data (10 instead of 6 v_alignbyte + 8 v_dot4);
 //   * vertical pass on PAIRS of consecutive rows of horizontal sums packed as 2 x u16 (a sum is at most 255 * 257): per output
@@ -1393,81 +1099,10 @@ __global__ __launch_bounds__(256) void k_blur_pk(const LevelInfo *__restrict__ l
 // for |x| < 120; bit-identical to the x86-64 libm the reference links against (validated exhaustively on the
 // CPU oracle, which uses the same formulation).  Tables: __sincosf_table.
 // ---------------------------------------------------------------------------------------------------------
-struct SinCosTab {
-    double c0, c1, c2, c3, c4, s1, s2, s3;
-};
-__device__ __forceinline__ float sc_sin_poly(double x, double x2, const SinCosTab &p) {
-    const double x3 = __dmul_rn(x, x2);
-    const double s1 = __fma_rn(x2, p.s3, p.s2);
-    const double x7 = __dmul_rn(x3, x2);
-    const double s = __fma_rn(x3, p.s1, x);
-    return (float)__fma_rn(x7, s1, s);
-}
-__device__ __forceinline__ float sc_cos_poly(double x2, const SinCosTab &p) {
-    const double x4 = __dmul_rn(x2, x2);
-    const double c2 = __fma_rn(x2, p.c4, p.c3);
-    const double c1 = __fma_rn(x2, p.c1, p.c0);
-    const double x6 = __dmul_rn(x4, x2);
-    const double c = __fma_rn(x4, p.c2, c1);
-    return (float)__fma_rn(x6, c2, c);
-}
+// Branch-free form (the two halves of a k_describe wave work on different keypoints, a data-dependent branch would run both sides):
+// glibc's operations in glibc's order, the variant picked by selects (checked against the oracle's branching restatement on the CPU:
+// tests/simt, every float angle in [0, 360) degrees at 1e-4 steps and 10^7 integer moment pairs).
 __device__ __forceinline__ void glibc_sincosf(float y, float *sn, float *cs) {
-    const SinCosTab T0 = {0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10,
-                          0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
-    const SinCosTab T1 = {-0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10,
-                          -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
-    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
-    double x = (double)y;
-    if (top < 0x3f4) {  // |y| < pi/4
-        if (top < 0x398) { *sn = y; *cs = 1.0f; return; }
-        const double x2 = __dmul_rn(x, x);
-        *sn = sc_sin_poly(x, x2, T0);
-        *cs = sc_cos_poly(x2, T0);
-        return;
-    }
-    // |y| < 120: fast range reduction, hpi_inv pre-scaled by 2^24
-    const double r = __dmul_rn(x, 0x1.45F306DC9C883p+23);
-    const int n = ((int32_t)r + 0x800000) >> 24;
-    x = __fma_rn(-(double)n, 0x1.921FB54442D18p0, x);
-    const double x2 = __dmul_rn(x, x);
-    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;  // sign[n&3] = {1,-1,-1,1}
-    // sinf: p = table[(n&2)?1:0]; odd n -> cos poly, even n -> sin poly of x*sign
-    // cosf: same table choice; odd n -> sin poly of x*sign, even n -> cos poly
-    if (n & 2) {
-        if (n & 1) { *sn = sc_cos_poly(x2, T1); *cs = sc_sin_poly(__dmul_rn(x, sgn), x2, T1); }
-        else { *sn = sc_sin_poly(__dmul_rn(x, sgn), x2, T1); *cs = sc_cos_poly(x2, T1); }
-    } else {
-        if (n & 1) { *sn = sc_cos_poly(x2, T0); *cs = sc_sin_poly(__dmul_rn(x, sgn), x2, T0); }
-        else { *sn = sc_sin_poly(__dmul_rn(x, sgn), x2, T0); *cs = sc_cos_poly(x2, T0); }
-    }
-}
-
-// [OCV] cv::fastAtan2 (degrees), plain float ops
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
-    const float scale = (float)(180.0 / 3.14159265358979323846);
-    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
-                p7 = -0.04432655554792128f * scale;
-    const float eps = 2.2204460492503131e-16f;  // (float)DBL_EPSILON
-    const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-    }
-    if (x < 0) a = __fsub_rn(180.f, a);
-    if (y < 0) a = __fsub_rn(360.f, a);
-    return a;
-}
-
-// Branch-free forms of the two functions above for k_describe2, where the two halves of a wave work on different keypoints and a
-// data-dependent branch would run both sides: the same operations in the same order, the variant picked by selects (checked against
-// the branching forms on the CPU: tests/simt, every float angle in [0, 360) degrees at 1e-4 steps and 10^7 integer moment pairs).
-__device__ __forceinline__ void glibc_sincosf_sel(float y, float *sn, float *cs) {
     const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
     const bool small = top < 0x3f4, tiny = top < 0x398;
     const double x0 = (double)y;
@@ -1498,7 +1133,7 @@ __device__ __forceinline__ void glibc_sincosf_sel(float y, float *sn, float *cs)
     *sn = tiny ? y : (swap ? fc : fs);
     *cs = tiny ? 1.0f : (swap ? fs : fc);
 }
-__device__ __forceinline__ float fast_atan2_deg_sel(float y, float x) {
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float scale = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
                 p7 = -0.04432655554792128f * scale;
@@ -1514,21 +1149,6 @@ __device__ __forceinline__ float fast_atan2_deg_sel(float y, float x) {
     return a;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// One wave per keypoint: IC_Angle on the UNBLURRED level (:76-103), steered 256-pair BRIEF on the BLURRED level
-// (:107-146), keypoint record + descriptor written to the final slot.
-//   disc  : lane = column u of the orientation disc (upper / lower half of the wave = rows v >= 0 / v < 0), 16 row steps;
-//           the moments are integer sums, so the summation order is free; reduced with a DPP scan
-//   brief : lane i evaluates pattern pairs i, i+64, i+128, i+192; 4 ballots = 4 x u64 = the 32-byte descriptor
-// grid (ceil(cap/4), B), block 256
-// ---------------------------------------------------------------------------------------------------------
-// a pointer the program knows to be wave-uniform, made provably so for the compiler (buffer descriptors must live in SGPRs)
-__device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p) {
-    const uint64_t a = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    return (const uint8_t *)(((uint64_t)hi << 32) | lo);
-}
-
 struct DescConst {
     int8_t vmax_of_u[16];              // orientation disc: largest |v| with umax[|v|] >= |u|
     int8_t pat[1024];                  // bit_pattern_31_ (x0,y0,x1,y1) x 256
@@ -1538,160 +1158,19 @@ constexpr int kDescAP = 40, kDescAR = 31;   // orientation patch in LDS: 31 rows
 constexpr int kDescBP = 44, kDescBR = 37;   // BRIEF patch in LDS: 37 rows x 44 B (10 aligned dwords used)
 constexpr int kDescWaveLds = kDescAP * kDescAR + kDescBP * kDescBR + 12;  // 2880 B, multiple of 16
 
-__global__ __launch_bounds__(256) void k_describe(const LevelInfo *__restrict__ lv, const DescConst *__restrict__ dc,
-                                                  const WorkItem *__restrict__ work, const int32_t *__restrict__ count,
-                                                  int cap, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                  const uint8_t *__restrict__ blur, size_t blur_frame_stride,
-                                                  orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-                                                  int strict_mul_add, int n_frames) {
-    __shared__ __attribute__((aligned(16))) uint8_t patches[4 * kDescWaveLds];
-    int bx, f;
-    if (!xcd_frame_map(n_frames, &bx, &f)) return;   // a frame's keypoints stay on one XCD (overlapping patches hit its L2)
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the wave's keypoint is wave-uniform: scalar loads below
-    const int g = bx * 4 + wv;
-    const int lane = threadIdx.x & 63;
-    // the work item is fetched together with the frame's count, not after the test on it (one memory round trip less per wave)
-    const int cnt = count[f];
-    WorkItem w = work[(size_t)f * cap + min(g, cap - 1)];
-    asm volatile("" ::"s"(w.key), "s"(cnt));   // both loads in flight before the branch (the compiler would sink the second below it)
-    if (g >= cnt) return;  // wave-uniform; no block-level barrier below
-    uint8_t *A = patches + wv * kDescWaveLds;
-    uint8_t *Bp = A + kDescAP * kDescAR;
-    // the keypoint is the same for the whole wave: keep it (and every address derived from it) in scalar registers
-    w.key = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.key);
-    w.level = __builtin_amdgcn_readfirstlane(w.level);
-    w.pos = __builtin_amdgcn_readfirstlane(w.pos);
-    struct { int pitch, bpitch; uint32_t off, boff; float scale, size; } L;   // the level's constants travel with the work item
-    { const uint32_t pp = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.pitches); L.pitch = (int)(pp & 0xffffu); L.bpitch = (int)(pp >> 16); }
-    L.off = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.off);
-    L.boff = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.boff);
-    L.scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.scale)));
-    L.size = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.size)));
-    const int kx = key_x(w.key), ky = key_y(w.key);
-    // orientation disc column of this lane (loaded early: its latency hides behind the patch loads)
-    const int du = (lane & 31) - kHalfPatch, dhalf = lane >> 5;
-    const int dvmax = (lane & 31) <= 2 * kHalfPatch ? dc->vmax_of_u[du < 0 ? -du : du] : -1;
-    // this lane's four BRIEF pattern entries, requested together with the patches: fetched inside the BRIEF loop each of them was a
-    // dependent memory round trip of its own (the compiler hoists a load by one iteration at most), four per wave, in a kernel
-    // whose time is the waves' lifetime
-    uint32_t pat4[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) pat4[it] = reinterpret_cast<const uint32_t *>(dc->pat)[it * 64 + lane];
-
-    // ---- stage both patches with aligned dword loads: one memory round trip for the whole keypoint ----
-    const int axA = (kx - kHalfPatch) & 3, axB = (kx - 18) & 3;
-    {
-        const uint8_t *srcA = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + ky - kHalfPatch) * L.pitch + kRoiX +
-                              (kx - kHalfPatch - axA);
-        const uint8_t *srcB = blur + (size_t)f * blur_frame_stride + L.boff + (size_t)(ky - 18) * L.bpitch + (kx - 18 - axB);
-        // 16 lanes per row, 4 rows per step, through one buffer descriptor per patch: rows past the patch are out of range for the
-        // hardware (no access, no predicate), the per-step address is one v_add, the LDS stores use immediate offsets -- the index
-        // arithmetic of a packed (idx / 9, idx % 9) mapping cost more VALU issue than the orientation sum
-        const int c = lane & 15, r0 = lane >> 4;
-        const auto srdA = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(srcA), 0, (kDescAR - 1) * L.pitch + 36, 0x00020000);
-        const auto srdB = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(srcB), 0, (kDescBR - 1) * L.bpitch + 40, 0x00020000);
-        const int offA = (c < 9 ? 0 : 0x40000000) + r0 * L.pitch + 4 * c;     // lanes beyond the patch width: out of range as well
-        const int offB = (c < 10 ? 0 : 0x40000000) + r0 * L.bpitch + 4 * c;
-        uint32_t va[8], vb[10];
-#pragma unroll
-        for (int k = 0; k < 8; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(srdA, offA + 4 * k * L.pitch, 0, 0);
-#pragma unroll
-        for (int k = 0; k < 10; k++) vb[k] = __builtin_amdgcn_raw_buffer_load_b32(srdB, offB + 4 * k * L.bpitch, 0, 0);
-        if (c < 9) {   // row 31 (k = 7, r0 = 3) lands in the first row of the BRIEF patch, which is written afterwards
-            uint8_t *d = A + r0 * kDescAP + 4 * c;
-#pragma unroll
-            for (int k = 0; k < 8; k++) *reinterpret_cast<uint32_t *>(d + 4 * k * kDescAP) = va[k];
-        }
-        if (c < 10) {
-            uint8_t *d = Bp + r0 * kDescBP + 4 * c;
-#pragma unroll
-            for (int k = 0; k < 9; k++) *reinterpret_cast<uint32_t *>(d + 4 * k * kDescBP) = vb[k];
-            if (r0 == 0) *reinterpret_cast<uint32_t *>(d + 36 * kDescBP) = vb[9];   // row 36, the last one
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (single-wave producer/consumer)
-    asm volatile("" ::"v"(pat4[0]), "v"(pat4[1]), "v"(pat4[2]), "v"(pat4[3]));   // the pattern loads stay up here
-
-    // ---- IC_Angle on the unblurred patch (:76-103): m_10 = sum u*I, m_01 = sum v*I over the disc ----
-    const uint8_t *c0 = A + kHalfPatch * kDescAP + kHalfPatch + axA + du;
-    int sumI = 0, m01 = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int av = k + dhalf;            // |v|: rows 0..15 in the upper half, 1..15(16) in the lower half
-        const int v = dhalf ? -av : av;
-        if (av <= dvmax) {
-            const int I = c0[v * kDescAP];
-            sumI += I;
-            m01 += v * I;
-        }
-    }
-    int m10 = du * sumI;
-    m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);
-    m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // ---- steered BRIEF on the blurred patch ----
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    glibc_sincosf(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
-    // cvRound = round-half-even = adding 1.5 * 2^23 (|value| < 2^22: the sum's ulp is 1, its mantissa holds the rounded integer):
-    // ONE v_add_f32 instead of v_rndne + v_cvt.  The bit pattern is kMagicBits + n; the row product uses its low 24 bits
-    // (2^22 + n) and the constant part of the address goes into the base pointer (32-bit LDS address arithmetic wraps).
-    constexpr float kMagic = 12582912.f;
-    constexpr uint32_t kMagicBits = 0x4B400000u;
-    const uint32_t cbm = (uint32_t)(uintptr_t)(Bp + 18 * kDescBP + 18 + axB) - (0x400000u * (uint32_t)kDescBP + kMagicBits);
-    unsigned long long bits[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const char4 pt = __builtin_bit_cast(char4, pat4[it]);
-        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
-        float r0, q0, r1, q1;
-        if (strict_mul_add) {
-            r0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
-            q0 = __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
-            r1 = __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
-            q1 = __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
-        } else {  // GCC -O3 -march=native: fma(x, b, y*a), fma(x, a, -(y*b))
-            r0 = __fmaf_rn(x0, b, __fmul_rn(y0, a));
-            q0 = __fmaf_rn(x0, a, -__fmul_rn(y0, b));
-            r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
-            q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
-        }
-        const uint32_t a0 = __umul24(__float_as_uint(__fadd_rn(r0, kMagic)), (uint32_t)kDescBP) + __float_as_uint(__fadd_rn(q0, kMagic)) + cbm;
-        const uint32_t a1 = __umul24(__float_as_uint(__fadd_rn(r1, kMagic)), (uint32_t)kDescBP) + __float_as_uint(__fadd_rn(q1, kMagic)) + cbm;
-        const int t0 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a0);
-        const int t1 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a1);
-        bits[it] = __ballot(t0 < t1);
-    }
-    const size_t slot = (size_t)f * cap + w.pos;
-    if (lane < 4) {
-        const unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        reinterpret_cast<unsigned long long *>(desc + slot * 32)[lane] = v;
-    }
-    if (lane == 0) {
-        orbx_keypoint kp;
-        float x = (float)kx, y = (float)ky;
-        if (w.level != 0) { x = __fmul_rn(x, L.scale); y = __fmul_rn(y, L.scale); }
-        kp.x = x; kp.y = y; kp.size = L.size; kp.angle = angle; kp.response = (float)key_s(w.key);
-        kp.octave = w.level; kp.class_id = -1;
-        kps[slot] = kp;
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
-// k_describe2 (ORBX_DESCRIBE=2; written at the end of round 2, verified against the oracle under the CPU SIMT emulator, NOT yet measured
-// on the hardware): TWO keypoints per wave, one per half (32 lanes).  k_describe is VALU-issue bound (151 of 192 us) and about a third
-// of its instructions are wave-uniform work the vector unit executes for 64 identical lanes (work-item unpacking, fastAtan2, the FP64
-// sincos); with one keypoint per half that work serves two keypoints at once, everything else costs the same per keypoint:
+// k_describe: IC_Angle on the UNBLURRED level (:76-103), steered 256-pair BRIEF on the BLURRED level (:107-146), keypoint record +
+// descriptor written to the final slot.  TWO keypoints per wave, one per half (32 lanes): about a third of the one-keypoint-per-wave
+// form's instructions were wave-uniform work the vector unit executed for 64 identical lanes (work-item unpacking, fastAtan2, the FP64
+// sincos); with one keypoint per half that work serves two keypoints at once (round 3, profiles/r03_a_ab_prepared_kernels.log:
+// step 1.175 -> 1.160 ms; the one-keypoint form is gone):
 //   disc  : lane = column u of the orientation disc, 31 row steps; per-half totals from one wave prefix sum (lanes 31 and 63)
 //   brief : lane i of a half evaluates pattern pairs i, i + 32, ..., i + 224; each of the 8 ballots holds one dword of BOTH descriptors
-//   the two branches of fastAtan2 / sincosf become selects (glibc_sincosf_sel, fast_atan2_deg_sel: bit-identical, checked on the CPU)
+//   the two branches of fastAtan2 / sincosf become selects (glibc_sincosf, fast_atan2_deg: bit-identical, checked on the CPU)
 // Patches are staged by plain loads (a frame-uniform base + a 32-bit lane offset; every patch lies inside the padded level).
 // grid xcd_grid(ceil(cap / 8), B), block 256
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_describe2(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
+__global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
                                                    const int32_t *__restrict__ count, int cap, const uint8_t *__restrict__ pyr,
                                                    size_t pyr_frame_stride, const uint8_t *__restrict__ blur, size_t blur_frame_stride,
                                                    orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc, int strict_mul_add, int n_frames) {
@@ -1757,12 +1236,12 @@ __global__ __launch_bounds__(256) void k_describe2(const DescConst *__restrict__
     const int a10 = __builtin_amdgcn_readlane(s10, 31), b10 = __builtin_amdgcn_readlane(s10, 63);
     const int a01 = __builtin_amdgcn_readlane(s01, 31), b01 = __builtin_amdgcn_readlane(s01, 63);
     const int M10 = hw ? b10 - a10 : a10, M01 = hw ? b01 - a01 : a01;
-    const float angle = fast_atan2_deg_sel((float)M01, (float)M10);
+    const float angle = fast_atan2_deg((float)M01, (float)M10);
 
     // ---- steered BRIEF on the blurred patch ----
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
-    glibc_sincosf_sel(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
+    glibc_sincosf(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
     constexpr float kMagic = 12582912.f;           // cvRound by magic add, see k_describe
     constexpr uint32_t kMagicBits = 0x4B400000u;
     const uint32_t cbm = (uint32_t)(uintptr_t)(Bp + 18 * kDescBP + 18 + axB) - (0x400000u * (uint32_t)kDescBP + kMagicBits);

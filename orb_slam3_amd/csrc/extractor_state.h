@@ -57,8 +57,7 @@ struct DevBuf {
             // null stream), and the library's non-blocking streams do not wait for the null stream -- a copy or kernel enqueued right
             // after ensure() could otherwise be overtaken by the zeros (seen once: the first host-input batch into a fresh slab)
             ORBX_HIP(hipMemset(p, 0, need));
-            static const bool nosync = getenv("ORBX_ENSURE_NOSYNC") != nullptr;   // diagnostic: the behaviour before the fix (tools/r03_first.sh)
-            if (!nosync) ORBX_HIP(hipDeviceSynchronize());
+            ORBX_HIP(hipDeviceSynchronize());   // control run without this wait: 5 of 5 short-batch loops differ (profiles/r03_a_open_item_control.log)
             if (getenv("ORBX_DEBUG_ALLOC")) fprintf(stderr, "[orbx alloc] %p .. %p  %zu bytes\n", p, (char *)p + need, need);
             return ORBX_OK;
         }
@@ -122,8 +121,6 @@ struct orbx_extractor {
     int fast_ini_qcap = 640, fast_ini_gcap = 16;   // k_fast_ini: pixel queue / group queue capacities
     int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qcap = 768, fast_wave_qfull = 16;   // LDS tile pitch (48 / 64), max sub-image rows, queue capacity
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
-    DevBuf d_octdbg;            // optional phase timing of k_octree_par (orbx_debug_octree_timing)
-    int octdbg_level = -1;
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
     bool fast_wave = true;      // every level's cell fits k_fast_wave's fixed LDS pitch
     int n_fast_tiles = 0, n_blur_tiles = 0;
@@ -153,26 +150,8 @@ struct orbx_extractor {
     bool in_used[2] = {false, false};
     unsigned in_issued = 0;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
-    // The pyramid of batch i+1 is built AHEAD, on its own stream, while the main stream still runs k_finalize / k_describe of batch i
-    // (both latency bound): d_pyr and d_blur hold two slabs each, batch k uses slab k & 1, and the pyramid stream starts once the main
-    // stream has passed the FAST stage of the previous batch (ev_oct; ORBX_PYR_AHEAD=1: its quad-tree) -- by then every reader of the slab
-    // it overwrites (batch k-2) and every user of the FAST overflow counter k_pyr_base resets (batch k-1) is done.  OFF by default (ORBX_PYR_AHEAD=2 / 1 turn it
-    // on): with the streams on hardware queues of their own the concurrent kernels slowed each other by more than the overlap gained
-    // (1.31 / 1.40 vs 1.18 ms per step), with shared queues nothing overlapped.
-    hipStream_t pyr_stream = nullptr;
-    hipEvent_t ev_oct = nullptr;
-    bool pyr_ahead = false, have_oct = false;
-    int pyr_ahead_at = 2;   // where ev_oct is recorded: 2 = behind the FAST stage (default), 1 = behind the quad-tree
-    unsigned pyr_slot = 0;
-    size_t pyr_slab = 0, blur_slab = 0;   // bytes of one slab (batch_cap frames)
-    bool ahead() const { return pyr_ahead && side_streams && !profile && pyr_stream != nullptr; }
-    uint8_t *pyr_cur() const { return (uint8_t *)d_pyr.p + (size_t)pyr_slot * pyr_slab; }     // slab of the most recent batch
-    uint8_t *blur_cur() const { return (uint8_t *)d_blur.p + (size_t)pyr_slot * blur_slab; }
-    hipEvent_t ev_level[orbx::kMaxLevels] = {};   // level l of the pyramid written (k_blur follows the resize chain level by level)
     int blur_tile_start[orbx::kMaxLevels + 1] = {};  // blur tiles of level l: [start[l], start[l + 1])
-    int blur_groups = 1;       // ORBX_BLUR_GROUPS (measured slower than one launch): levels 0 .. groups-2 get a k_blur launch of their own, the rest share the last one (1 = one launch after the pyramid)
     bool match_pending = false;
-    bool blur_side = true;     // ORBX_BLUR_SIDE=0: k_blur stays on the main stream (after the pyramid)
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream
     hipEvent_t ev_compute_done = nullptr;
     hipEvent_t ev_copy_done[2] = {nullptr, nullptr};  // ring: up to two downloads in flight

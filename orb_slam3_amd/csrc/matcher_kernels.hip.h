@@ -627,75 +627,13 @@ __device__ __forceinline__ int scan_window_grid(const WindowProblem &P, const Gr
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kGridCells = 64 * 48;
 
-__global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restrict__ probs, GridParams g) {
-    __shared__ uint16_t cnt[kGridCells];
-    __shared__ uint16_t start[kGridCells];
-    const WindowProblem P = probs[blockIdx.x];
-    const int lane = threadIdx.x;
-    const int n = *P.n_ptr;
-    for (int i = lane; i < kGridCells; i += 64) cnt[i] = 0;
-    __syncthreads();
-    // pass 1: cell histogram (16-bit LDS counters packed in pairs: use 32-bit atomics on the containing word)
-    uint32_t *cnt32 = reinterpret_cast<uint32_t *>(cnt);
-    for (int i = lane; i < n; i += 64) {
-        const orbx_keypoint kp = P.kps[i];
-        const int px = (int)roundf((kp.x - g.minx) * g.inv_w), py = (int)roundf((kp.y - g.miny) * g.inv_h);  // PosInGrid
-        if (px >= 0 && px < 64 && py >= 0 && py < 48) {
-            const int c = px * 48 + py;
-            atomicAdd(&cnt32[c >> 1], (c & 1) ? 0x10000u : 1u);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the 3072 counters (48 per lane, then a wave scan of the lane totals)
-    int lane_tot = 0;
-    for (int k = 0; k < kGridCells / 64; k++) lane_tot += cnt[lane * (kGridCells / 64) + k];
-    int incl = lane_tot;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const int t = __shfl_up(incl, s);
-        if (lane >= s) incl += t;
-    }
-    int run = incl - lane_tot;
-    for (int k = 0; k < kGridCells / 64; k++) {
-        const int c = lane * (kGridCells / 64) + k;
-        start[c] = (uint16_t)run;
-        P.gstart[c] = (uint16_t)run;
-        run += cnt[c];
-    }
-    if (lane == 63) P.gstart[kGridCells] = (uint16_t)run;
-    __syncthreads();
-    // pass 2: stable fill, 64 features at a time in index order
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        int c = -1;
-        if (i < n) {
-            const orbx_keypoint kp = P.kps[i];
-            const int px = (int)roundf((kp.x - g.minx) * g.inv_w), py = (int)roundf((kp.y - g.miny) * g.inv_h);
-            if (px >= 0 && px < 64 && py >= 0 && py < 48) c = px * 48 + py;
-        }
-        int rank = 0, same = 0;  // lanes of this chunk with the same cell: before me / in total
-        for (int k = 0; k < 64; k++) {
-            const int ck = __shfl(c, k);
-            rank += (ck == c) & (k < lane);
-            same += (ck == c);
-        }
-        if (c >= 0) {
-            P.gorder[start[c] + rank] = (uint16_t)i;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (c >= 0 && rank == same - 1) start[c] += (uint16_t)same;  // the last lane of each cell group advances the cursor
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// k_grid_build2 (ORBX_GRID_BUILD=2; written at the end of round 2, verified against the oracle through the matcher tests under the CPU
-// SIMT emulator, NOT yet measured on the hardware): the same grid with the wave's lifetime cut down -- k_grid_build spends its 51 us in
-// 32 dependent keypoint round trips (one per 64 features and pass) and in a 64-step shuffle loop per chunk for the rank inside a cell.
-// Here eight keypoints per lane are in flight at once (two round trips per 512 features and pass) and the lanes of a chunk that share
+// Eight keypoints per lane are in flight at once (two round trips per 512 features and pass) and the lanes of a chunk that share
 // a cell are placed by claim rounds (LDS atomicMin of the lane id: the lowest lane wins, takes the cell's cursor and drops out;
-// as many rounds as the largest multiplicity inside the chunk, usually one or two), which keeps insertion order.
+// as many rounds as the largest multiplicity inside the chunk, usually one or two), which keeps insertion order.  The first form (one
+// round trip per 64 features and pass, a 64-step shuffle loop per chunk for the rank inside a cell) took 51 us per 256 frames, this one
+// 25 us (round 3, profiles/r03_a_chain_grid2_dpp_kernel_stats.csv).
 // grid (n_problems), block 64
-__global__ __launch_bounds__(64) void k_grid_build2(const WindowProblem *__restrict__ probs, GridParams g) {
+__global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restrict__ probs, GridParams g) {
     __shared__ uint16_t cnt[kGridCells];
     __shared__ uint16_t start[kGridCells];
     __shared__ uint32_t claim[kGridCells];
@@ -807,27 +745,6 @@ __device__ __forceinline__ u64 seq_key(int dist, int seq, int idx) {
 // If a lane that saw more than two candidates has both of its entries extracted, later rounds could miss that lane's
 // third candidate, so the list is cut there (valid_len); `exhaustive` says the list holds every candidate of the
 // query.  k_greedy_resolve falls back to a re-scan when it needs more than the valid part of a non-exhaustive list.
-// reductions over the 16 lanes of one query = one DPP row: rotate the row by 8, 4, 2, 1 (row_ror) and combine -- every lane ends
-// up with the result, no LDS crossbar traffic (`__shfl_xor` is a ds_bpermute: an LDS round trip per step and operand)
-template <int N>
-__device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }
-__device__ __forceinline__ u64 row16_min(u64 m) {
-#define ROW16_MIN_STEP(N)                                                                                                  \
-    {                                                                                                                      \
-        const u64 o = ((u64)(uint32_t)row_ror<N>((int)(m >> 32)) << 32) | (uint32_t)row_ror<N>((int)(uint32_t)m);          \
-        m = o < m ? o : m;                                                                                                 \
-    }
-    ROW16_MIN_STEP(8) ROW16_MIN_STEP(4) ROW16_MIN_STEP(2) ROW16_MIN_STEP(1)
-#undef ROW16_MIN_STEP
-    return m;
-}
-__device__ __forceinline__ int row16_add(int v) { v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v); return v; }
-__device__ __forceinline__ int row16_or(int v) { v |= row_ror<8>(v); v |= row_ror<4>(v); v |= row_ror<2>(v); v |= row_ror<1>(v); return v; }
-
-// DPP = true (ORBX_WINDOW_DPP=1; written at the end of round 2, verified through the matcher tests under the CPU SIMT emulator, NOT yet
-// measured on the hardware): the 16-lane reductions of the top-4 extraction by DPP row rotations instead of ds_bpermute shuffles --
-// 12 u64 / int reductions per wave, about 40 % of the kernel's VALU instructions and all of its LDS traffic
-template <bool DPP>
 __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__restrict__ probs, GridParams g) {
     const WindowProblem P = probs[blockIdx.y];
     const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
@@ -896,24 +813,18 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
     }
     // reductions inside the 16-lane group (xor masks 8,4,2,1 stay inside the group)
     int total = cnt;
-    if (DPP) total = row16_add(total);
-    else {
 #pragma unroll
-        for (int s = 8; s > 0; s >>= 1) total += __shfl_xor(total, s);
-    }
+    for (int s = 8; s > 0; s >>= 1) total += __shfl_xor(total, s);
     u64 out[kTopK];
     int valid_len = 0, npop = 0;
     bool cut = false;
 #pragma unroll
     for (int r = 0; r < kTopK; r++) {
         u64 m = k1;
-        if (DPP) m = row16_min(m);
-        else {
 #pragma unroll
-            for (int s = 8; s > 0; s >>= 1) {
-                const u64 o = __shfl_xor(m, s);
-                m = o < m ? o : m;
-            }
+        for (int s = 8; s > 0; s >>= 1) {
+            const u64 o = __shfl_xor(m, s);
+            m = o < m ? o : m;
         }
         out[r] = m;
         if (m != kNoKey && !cut) valid_len = r + 1;
@@ -921,11 +832,8 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
         if (mine) { k1 = k2; k2 = kNoKey; npop++; }
         // a lane that ran dry while it had seen more than two candidates invalidates everything after this round
         int dry = (mine && npop == 2 && cnt > 2) ? 1 : 0;
-        if (DPP) dry = row16_or(dry);
-        else {
 #pragma unroll
-            for (int s = 8; s > 0; s >>= 1) dry |= __shfl_xor(dry, s);
-        }
+        for (int s = 8; s > 0; s >>= 1) dry |= __shfl_xor(dry, s);
         cut = cut || (dry != 0);
     }
     if (qvalid && sl == 0) {
@@ -959,7 +867,7 @@ struct ResolveProblem {
 // sequential loop would have seen.  Dynamic LDS: claim[n_alloc] (u32) + angle[n_alloc] (f32) + occ[n_alloc] (u8);
 // nothing inside the round loop touches global memory except fire-and-forget result stores.
 __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
-                                                       GridParams g, int n_alloc, int grid_rescan) {
+                                                       GridParams g, int n_alloc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ int hist[ORBX_HISTO_LENGTH + 2];
     uint32_t *claim = reinterpret_cast<uint32_t *>(lds);
@@ -1097,8 +1005,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                 Desc dq;
                 u64 r1 = kNoKey, r2 = kNoKey;
                 if (load_query(P, qc, &w, g, &dq)) {
-                    if (grid_rescan) scan_window_grid(P, g, w, dq, n, occ, lane, r1, r2);
-                    else scan_window(P, g, w, dq, n, occ, lane, r1, r2);
+                    scan_window_grid(P, g, w, dq, n, occ, lane, r1, r2);
                     wave_min2(r1, r2);
                 }
                 if (accept(r1, r2)) {

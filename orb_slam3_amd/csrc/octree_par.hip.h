@@ -748,28 +748,12 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
 // launched over all (frame, level) pairs and each returns at once for the pairs that belong to the other.
 __device__ __forceinline__ bool oct_blk_form(const LevelInfo &L, int C) { return C <= kOctParLdsKeys && L.nIni <= 4 && L.pool <= 2047; }
 
-// grid (B, nlevels), block 256, dynamic LDS = oct_par_lds_bytes(max pool).  k_compact has run before.
-__global__ __launch_bounds__(256, 3) void k_octree_par(const LevelInfo *__restrict__ lv, size_t ent_frame_stride, uint32_t *__restrict__ keys1,
-                                                       uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt,
-                                                       int nlevels, const int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool,
-                                                       long long *dbg_all, int dbg_level) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int level = blockIdx.y, f = blockIdx.x;  // level-major: the long workgroups start first
-    const LevelInfo L = lv[level];
-    long long *dbg = (dbg_all && f == 0 && level == dbg_level) ? dbg_all : nullptr;
-    const int C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
-    if (!oct_blk_form(L, C)) return;
-    uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
-    octree_par_body<true>(L, smem, max_pool, C, nullptr, gk1, nullptr, nullptr, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off,
-                          lvlcnt + f * nlevels + level, err, dbg);
-}
-
-// k_octree_par_t (ORBX_OCTREE_KEYS=2048; written at the end of round 2, verified against the oracle under the CPU SIMT emulator, NOT yet
-// measured on the hardware): the 256-thread form in two tiers.  k_octree_par sizes its LDS key buffers and its per-thread key slots
-// for 4096 candidates on every level: 45 KB of LDS and 161 VGPRs keep it at three workgroups per CU, and a level with 1100 candidates
-// still walks 17 key slots per thread in every unrolled sweep.  The small tier (LO < C <= 2048: every level of the EuRoC-shaped bench)
-// has 9 slots, 118 VGPRs and 33 KB: four workgroups per CU (2048 workgroups = two dispatch rounds instead of three) and about 30 %
-// fewer instructions; levels with 2048 < C <= 4096 take the second launch, the rest k_octree_par1 as before.
+// k_octree_par_t: the 256-thread form in two tiers (k_compact has run before).  Sized for 4096 candidates on every level the form
+// needs 45 KB of LDS and 161 VGPRs (three workgroups per CU), and a level with 1100 candidates still walks 17 key slots per thread in
+// every unrolled sweep.  The small tier (LO < C <= 2048: every level of the EuRoC-shaped bench) has 9 slots, 118 VGPRs and 33 KB:
+// four workgroups per CU (2048 workgroups = two dispatch rounds instead of three) and about 30 % fewer instructions; levels with
+// 2048 < C <= 4096 take the second launch, the rest k_octree_par1.  Round 3, profiles/r03_a_ab_prepared_kernels.log: step 1.175 ->
+// 1.142 ms against the single-tier kernel, which is gone.
 // grid (B, nlevels), block 256, dynamic LDS = oct_par_pool_bytes(max pool) + KEYS * 6
 template <int KEYS, int LO>
 __global__ __launch_bounds__(256, (KEYS <= 2048 ? 4 : 3)) void k_octree_par_t(const LevelInfo *__restrict__ lv, size_t ent_frame_stride,

@@ -227,9 +227,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
 
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->pyr_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
     ex->copy_pending = false; ex->match_pending = false; ex->copy_issued = ex->copy_waited = 0;
-    ex->have_oct = false; ex->pyr_slot = 0;
     ex->mkey = orbx_extractor::MatchKey();
     ex->mpkey = orbx_extractor::MpKey();
     const int B = std::max(batch, ex->batch_cap);
@@ -242,9 +241,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_ftiles, sizeof(FastTile) * ftiles.size());
     ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
-    ENS(ex->d_pyr, 2 * pyr_off * B);     // two slabs: batch k uses slab k & 1 (extractor_state.h)
-    ENS(ex->d_blur, 2 * blur_off * B);
-    ex->pyr_slab = pyr_off * B; ex->blur_slab = blur_off * B;
+    ENS(ex->d_pyr, pyr_off * B);
+    ENS(ex->d_blur, blur_off * B);
     ENS(ex->d_cellcnt, sizeof(int32_t) * (size_t)cell_base * B);
     ENS(ex->d_cellent, sizeof(uint32_t) * (size_t)cand_off * B);
     ENS(ex->d_keys0, sizeof(uint32_t) * (size_t)cand_off * B);
@@ -318,14 +316,11 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     RoctxRange rr("orbx:extract");
     const int nl = ex->prm.nlevels;
     const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
-    ex->pyr_slot ^= 1u;
-    uint8_t *pyr = ex->pyr_cur();
-    uint8_t *blur_slab = ex->blur_cur();
+    uint8_t *pyr = (uint8_t *)ex->d_pyr.p;
+    uint8_t *blur_slab = (uint8_t *)ex->d_blur.p;
     hipStream_t st = ex->stream;
-    const bool ahead = ex->ahead();
-    hipStream_t pst = ahead ? ex->pyr_stream : st;   // stream of the pyramid stage
-    if (ahead && ex->have_oct) ORBX_HIP(hipStreamWaitEvent(pst, ex->ev_oct, 0));   // not before the previous batch has left its quad-tree
-    static const bool pyr_local = [] { const char *v = getenv("ORBX_PYR_XCD"); return !(v && v[0] == '0'); }();   // 0 = round-robin workgroups
+    hipStream_t pst = st;   // stream of the pyramid stage
+    const bool pyr_local = true;   // a frame's pyramid workgroups stay on one XCD
     {
         ProfScope ps(ex, K_PYR_BASE);
         const LevelInfo &L = ex->lv[0];
@@ -335,74 +330,30 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)), n);
     }
     if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));  // k_pyr_base is the only reader of the input frames
-    // k_blur follows the resize chain on the aux stream, level group by level group: the chain is latency bound (three dependent memory
-    // round trips per wave, VALU mostly idle) and the blur VALU bound, so they share the machine well -- and FAST then runs without the
-    // blur beside it (both VALU bound: side by side they took as long as one after the other)
-    const bool blur_follow = !ex->profile && ex->side_streams && ex->blur_side && ex->blur_groups > 1;
-    const int n_groups = std::min(ex->blur_groups, nl);
     static const int kBlurNew[4] = {18, 34, 48, 56}, kBlurOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
     const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
     auto blur_levels = [&](hipStream_t bs, int l0, int l1) {   // k_blur over the tiles of levels [l0, l1)
         const int t0 = ex->blur_tile_start[l0], t1 = ex->blur_tile_start[l1];
         if (t1 <= t0) return;
-        static const bool packed = [] { const char *v = getenv("ORBX_BLUR_KERNEL"); return !(v && v[0] == '0'); }();   // 0 = round-1 k_blur
         const bool sat = 2 * (bg[0] + bg[1] + bg[2]) + bg[3] > 256;   // taps summing to more than 1.0 (OpenCV <= 4.5.0) can exceed 255
 #define ORBX_BLUR_PK(SAT)                                                                                                              \
     hipLaunchKernelGGL(k_blur_pk<SAT>, xcd_grid(t1 - t0, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p + t0,          \
                        (const uint8_t *)pyr, ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n)
-        if (!packed)
-            hipLaunchKernelGGL(k_blur, dim3(t1 - t0, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p + t0, (const uint8_t *)pyr,
-                               ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3]);
-        else if (sat) ORBX_BLUR_PK(true);
+        if (sat) ORBX_BLUR_PK(true);
         else ORBX_BLUR_PK(false);
 #undef ORBX_BLUR_PK
     };
-    auto blur_after_level = [&](int l) -> int {   // level l has just been enqueued on st
-        if (!blur_follow) return ORBX_OK;
-        const bool last_group = l >= n_groups - 1;
-        if (last_group && l != nl - 1) return ORBX_OK;   // the last group waits for the top of the pyramid
-        ORBX_HIP(hipEventRecord(ex->ev_level[l], pst));
-        ORBX_HIP(hipStreamWaitEvent(ex->aux_stream, ex->ev_level[l], 0));
-        if (last_group) { blur_levels(ex->aux_stream, n_groups - 1, nl); ORBX_HIP(hipEventRecord(ex->ev_blur, ex->aux_stream)); }
-        else blur_levels(ex->aux_stream, l, l + 1);
-        return ORBX_OK;
-    };
-    { int r = blur_after_level(0); if (r != ORBX_OK) return r; }
-    // ORBX_PYR_CHAIN=1: levels 1 .. n-1 of a frame by one 1024-thread workgroup in one launch (k_pyr_chain; unmeasured, off)
-    static const int pyr_chain = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return (v && (v[0] == '1' || v[0] == '2')) ? v[0] - '0' : 0; }();
-    const bool chain = pyr_chain && !blur_follow && nl > 1;
-    if (chain) {
-        ProfScope ps(ex, K_PYR_RESIZE);
-#define ORBX_PYR_CHAIN(ILP)                                                                                                              \
-    hipLaunchKernelGGL(k_pyr_chain<ILP>, dim3(n), dim3(1024), 0, pst, d_lv, nl, (const ResizeTap *)ex->d_xtab.p, (const ResizeTap *)ex->d_ytab.p, \
-                       (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame)
-        if (pyr_chain == 2) ORBX_PYR_CHAIN(2); else ORBX_PYR_CHAIN(1);
-#undef ORBX_PYR_CHAIN
-    }
-    for (int l = 1; l < nl && !chain; l++) {
+    for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
-        const dim3 grid = xcd_grid(((L.pitch / 4) * ((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255) / 256, n, pyr_local);
-        static const bool resize_pk = [] { const char *v = getenv("ORBX_RESIZE_PK"); return !(v && v[0] == '0'); }();   // 0 = round-1 vertical pass
-#define ORBX_RESIZE(PK)                                                                                                         \
-    hipLaunchKernelGGL(k_pyr_resize<PK>, grid, dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,             \
-                       (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,                 \
-                       (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 4) - 1) / (uint64_t)(L.pitch / 4)), n)
-        static const bool resize_cols2 = [] { const char *v = getenv("ORBX_RESIZE_COLS"); return !(v && v[0] == '1'); }();   // 1 = one dword column per thread
-        if (resize_cols2 && resize_pk) {
-            const uint32_t wpc = (uint32_t)(L.pitch / 8);
-            const dim3 grid2 = xcd_grid((int)((wpc * (uint32_t)((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255u) / 256u), n, pyr_local);
-            hipLaunchKernelGGL(k_pyr_resize2, grid2, dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,
-                               (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,
-                               (uint32_t)((0x100000000ull + (uint64_t)wpc - 1) / (uint64_t)wpc), n);
-        }
-        else if (resize_pk) ORBX_RESIZE(true); else ORBX_RESIZE(false);
-#undef ORBX_RESIZE
-        { int r = blur_after_level(l); if (r != ORBX_OK) return r; }
+        const uint32_t wpc = (uint32_t)(L.pitch / 8);
+        const dim3 grid2 = xcd_grid((int)((wpc * (uint32_t)((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255u) / 256u), n, pyr_local);
+        hipLaunchKernelGGL(k_pyr_resize2, grid2, dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,
+                           (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,
+                           (uint32_t)((0x100000000ull + (uint64_t)wpc - 1) / (uint64_t)wpc), n);
     }
-    auto launch_blur = [&]() -> int {   // one launch over all levels: profile mode, ORBX_BLUR_SIDE=0, ORBX_BLUR_GROUPS=1, ORBX_SIDE_STREAMS=0
-        if (blur_follow) return ORBX_OK;
-        const bool side = !ex->profile && ex->side_streams && ex->blur_side;
+    auto launch_blur = [&]() -> int {   // one launch over all levels, beside FAST on the aux stream (ORBX_SIDE_STREAMS=0 / profile mode: main stream)
+        const bool side = !ex->profile && ex->side_streams;
         hipStream_t bs = side ? ex->aux_stream : st;
         if (side) ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
         ProfScope ps(ex, K_BLUR);
@@ -411,21 +362,18 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         return ORBX_OK;
     };
     ORBX_HIP(hipEventRecord(ex->ev_pyr, pst));                         // the pyramid of this batch is complete
-    if (ahead) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_pyr, 0));        // FAST and everything after it stay on the main stream
-    static const bool blur_after_fast = [] { const char *v = getenv("ORBX_BLUR_AFTER_FAST"); return v && v[0] == '1'; }();
-    if (!blur_after_fast) { int r = launch_blur(); if (r != ORBX_OK) return r; }
+    { int r = launch_blur(); if (r != ORBX_OK) return r; }
     {
         ProfScope ps(ex, K_FAST);
         // one score map at min(ini, min) serves both passes of :830-846; for ini < min the reference's second pass FAST(min) is a
         // subset of its first, so its result is FAST(ini) alone -- the same as running this stage with min := ini
         const int ini = std::min(std::max(ex->prm.ini_th_fast, 0), 255), mn = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini);
-        static const int tpb = [] { const char *v = getenv("ORBX_FAST_TPB"); return v ? atoi(v) : 0; }();
 #define ORBX_FAST_LAUNCH(T)                                                                                                  \
     hipLaunchKernelGGL(k_fast_cells<T>, dim3(ex->n_fast_tiles, n), dim3(T), ex->fast_lds, st, d_lv,                           \
                        (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn)
-        static const size_t ldspad = [] { const char *v = getenv("ORBX_FAST_LDSPAD"); return v ? (size_t)atoi(v) : (size_t)0; }();
-        if (ex->fast_wave && tpb == 0) {
+        const size_t ldspad = 0;
+        if (ex->fast_wave) {
             int32_t *ovf_count = (int32_t *)ex->d_fast_ovf.p;
             uint32_t *ovf_list = (uint32_t *)ex->d_fast_ovf.p + 16;
 #define ORBX_FAST_WAVE(PITCH)                                                                                                      \
@@ -433,9 +381,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                        (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,         \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qcap, \
                        ovf_list, ovf_count)
-            static const int fast_stop = [] { const char *v = getenv("ORBX_FAST_STOP"); return v ? atoi(v) : 0; }();   // diagnostic: truncate k_fast_ini
-            static const bool ini_first = [] { const char *v = getenv("ORBX_FAST_INI"); return !(v && v[0] == '0'); }();
-            if (ini_first && ini > mn) {
+            const int fast_stop = 0;
+            if (ini > mn) {
                 // first pass of :826 for every cell (k_fast_ini); cells it leaves empty go to the list pass below
                 const size_t lds_wave = std::max<size_t>((fast_ini_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_ini_qcap, ex->fast_ini_gcap) + 15) & ~(size_t)15,
                                                           (size_t)48 * ex->fast_wave_pitch);   // fast_tile_load_srd writes 48 rows
@@ -446,9 +393,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                        ex->fast_ini_gcap, ovf_list, ovf_count, n, ex->n_fast_tiles, (int)(lds_wave + ldspad), fast_stop)
 #define ORBX_FAST_INI_P(W) do { if (ex->fast_wave_pitch == 48) ORBX_FAST_INI(48, W); else ORBX_FAST_INI(64, W); } while (0)
                 // cells per workgroup (one wave each; the waves do not synchronise): 4 unless ORBX_FAST_INI_WAVES says otherwise
-                static const int ini_waves = [] { const char *v = getenv("ORBX_FAST_INI_WAVES"); return v ? atoi(v) : 4; }();
-                if (ini_waves == 1) ORBX_FAST_INI_P(1); else if (ini_waves == 2) ORBX_FAST_INI_P(2); else if (ini_waves == 8) ORBX_FAST_INI_P(8);
-                else ORBX_FAST_INI_P(4);
+                ORBX_FAST_INI_P(4);
             } else {
                 if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE(48); else ORBX_FAST_WAVE(64);
             }
@@ -462,38 +407,25 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                        (const int32_t *)ovf_count)
             if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE_LIST(48); else ORBX_FAST_WAVE_LIST(64);
         }
-        else if (tpb == 256) ORBX_FAST_LAUNCH(256);
-        else if (tpb == 128) ORBX_FAST_LAUNCH(128);
         else ORBX_FAST_LAUNCH(64);
     }
-    // the next batch's pyramid may start (extractor_state.h): FAST and its list pass -- the users of the overflow counter k_pyr_base resets --
-    // are enqueued, every reader of the other pyramid slab finished a batch ago; it then runs beside the latency-bound quad-tree, k_finalize
-    // and k_describe of this batch
-    if (ex->ev_oct && ex->pyr_ahead_at == 2) { ORBX_HIP(hipEventRecord(ex->ev_oct, st)); ex->have_oct = true; }
-    if (blur_after_fast) { int r = launch_blur(); if (r != ORBX_OK) return r; }   // beside the latency-bound quad-tree stage instead of beside FAST
     {
         ProfScope ps(ex, K_OCTREE);
         if (ex->oct_par) {
             hipLaunchKernelGGL(k_compact, dim3(nl, n), dim3(256), 0, st, d_lv, (const int32_t *)ex->d_cellcnt.p, ex->total_cells,
                                (const uint32_t *)ex->d_cellent.p, ex->cand_frame, (uint32_t *)ex->d_keys1.p, (int32_t *)ex->d_candtot.p, nl);
             const size_t lds = oct_par_lds_bytes(ex->max_pool), lds1 = oct_par_pool_bytes(ex->max_pool);
-            if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const size_t lds_s = oct_par_pool_bytes(ex->max_pool) + (size_t)2048 * 6;
             if (lds1 > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-            static const bool oct_tiers = [] { const char *v = getenv("ORBX_OCTREE_KEYS"); return v && atoi(v) == 2048; }();   // two-tier form (unmeasured, off)
-            if (oct_tiers) {
-                const size_t lds_s = oct_par_pool_bytes(ex->max_pool) + (size_t)2048 * 6;
-                if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<4096, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                if (lds_s > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<2048, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-                hipLaunchKernelGGL((k_octree_par_t<2048, -1>), dim3(n, nl), dim3(256), lds_s, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
-                                   (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
-                                   (int32_t *)ex->d_err.p, ex->max_pool);
-                hipLaunchKernelGGL((k_octree_par_t<4096, 2048>), dim3(n, nl), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
-                                   (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
-                                   (int32_t *)ex->d_err.p, ex->max_pool);
-            } else
-            hipLaunchKernelGGL(k_octree_par, dim3(n, nl), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
+            if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<4096, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (lds_s > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<2048, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            // two tiers of the 256-thread form: levels with at most 2048 candidates (every level of the EuRoC-shaped bench), then 2049 .. 4096
+            hipLaunchKernelGGL((k_octree_par_t<2048, -1>), dim3(n, nl), dim3(256), lds_s, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
                                (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
-                               (int32_t *)ex->d_err.p, ex->max_pool, (long long *)ex->d_octdbg.p, ex->octdbg_level);
+                               (int32_t *)ex->d_err.p, ex->max_pool);
+            hipLaunchKernelGGL((k_octree_par_t<4096, 2048>), dim3(n, nl), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
+                               (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
+                               (int32_t *)ex->d_err.p, ex->max_pool);
             hipLaunchKernelGGL(k_octree_par1, dim3(n, nl), dim3(64), lds1, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys0.p,
                                (uint32_t *)ex->d_keys1.p, (uint16_t *)ex->d_nof0.p, (uint16_t *)ex->d_nof1.p, (uint32_t *)ex->d_lvlkp.p,
                                ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p,
@@ -507,7 +439,6 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                                (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p, ex->max_pool);
         }
     }
-    if (ex->ev_oct && ex->pyr_ahead_at != 2) { ORBX_HIP(hipEventRecord(ex->ev_oct, st)); ex->have_oct = true; }   // ORBX_PYR_AHEAD=1: the next pyramid starts after the quad-tree
     if (ex->copy_pending) {  // outputs of the previous batch may still be in flight to the host
         ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done[(ex->copy_issued - 1) & 1], 0));  // the most recent download
     }
@@ -520,17 +451,10 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const int32_t *)ex->d_lvlcnt.p, (WorkItem *)ex->d_work.p, ex->cap, (int32_t *)ex->d_count.p,
                            (int32_t *)ex->d_mono.p, lap0, lap1, (int32_t *)ex->d_err.p);
     }
-    if (!ex->profile && ex->side_streams && ex->blur_side) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
+    if (!ex->profile && ex->side_streams) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
     {
         ProfScope ps(ex, K_DESCRIBE);
-        static const bool describe2 = [] { const char *v = getenv("ORBX_DESCRIBE"); return v && v[0] == '2'; }();   // two keypoints per wave (unmeasured, off)
-        if (describe2)
-            hipLaunchKernelGGL(k_describe2, xcd_grid((ex->cap + 7) / 8, n), dim3(256), 0, st, (const DescConst *)ex->d_dc.p,
-                               (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
-                               ex->pyr_frame, (const uint8_t *)blur_slab, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
-                               (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0, n);
-        else
-        hipLaunchKernelGGL(k_describe, xcd_grid((ex->cap + 3) / 4, n), dim3(256), 0, st, d_lv, (const DescConst *)ex->d_dc.p,
+        hipLaunchKernelGGL(k_describe, xcd_grid((ex->cap + 7) / 8, n), dim3(256), 0, st, (const DescConst *)ex->d_dc.p,
                            (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
                            ex->pyr_frame, (const uint8_t *)blur_slab, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
                            (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0, n);
@@ -642,32 +566,21 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
             ++v0;
         }
     }
-    // optional stream priorities (ORBX_STREAM_PRIO=1: matcher / copies low; 2: blur low as well).  Off by default: no gain for the
-    // single-extractor pipeline and a 20 % loss when two extractors (stereo) share the device
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // lo = numerically greatest = lowest priority
-    static const int use_prio = [] { const char *v = getenv("ORBX_STREAM_PRIO"); return v ? atoi(v) : 0; }();
-    if (!use_prio) prio_lo = prio_hi = 0;
+    // all streams at the default priority (priorities measured: no gain for one extractor, a 20 % loss when two share the device)
+    const int prio_lo = 0, prio_hi = 0;
     hipError_t e = hipStreamCreateWithPriority(&ex->stream, hipStreamNonBlocking, prio_hi);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); delete ex; return ORBX_E_HIP; }
     (void)hipEventCreate(&ex->ev0);
     (void)hipEventCreate(&ex->ev1);
     (void)hipStreamCreateWithPriority(&ex->copy_stream, hipStreamNonBlocking, prio_lo);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
-    { const char *v = getenv("ORBX_BLUR_SIDE"); ex->blur_side = !(v && v[0] == '0'); }
-    { const char *v = getenv("ORBX_BLUR_GROUPS"); if (v && atoi(v) >= 1) ex->blur_groups = atoi(v); }
     { const char *v = getenv("ORBX_FAST_INI_QCAP"); if (v && atoi(v) >= 16) ex->fast_ini_qcap = atoi(v) & ~15; }  // test hook: force the list pass
     { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 64) ex->fast_wave_qcap = atoi(v) & ~15; }  // test hook: force k_fast_overflow
-    (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, use_prio == 2 ? prio_lo : prio_hi);
+    (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
     (void)hipStreamCreateWithPriority(&ex->in_stream, hipStreamNonBlocking, prio_hi);
-    (void)hipStreamCreateWithPriority(&ex->pyr_stream, hipStreamNonBlocking, prio_hi);
-    (void)hipEventCreateWithFlags(&ex->ev_oct, hipEventDisableTiming);
-    // measured slower than the pyramid on the main stream: off unless ORBX_PYR_AHEAD=1 (behind the quad-tree) / 2 (behind FAST)
-    { const char *v = getenv("ORBX_PYR_AHEAD"); ex->pyr_ahead = v && (v[0] == '1' || v[0] == '2'); ex->pyr_ahead_at = (v && v[0] == '1') ? 1 : 2; }
     for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
-    for (hipEvent_t &ev : ex->ev_level) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[0], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[1], hipEventDisableTiming);
@@ -703,13 +616,11 @@ void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->pyr_stream})
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream})
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    if (ex->ev_oct) (void)hipEventDestroy(ex->ev_oct);
     for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
     ex->d_in[0].release(); ex->d_in[1].release();
     for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : ex->ev_level) if (ev) (void)hipEventDestroy(ev);
     if (ex->ev_compute_done) (void)hipEventDestroy(ex->ev_compute_done);
     for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
     if (ex->h_err) (void)hipHostFree(ex->h_err);
@@ -718,7 +629,7 @@ void orbx_destroy(orbx_extractor *ex) {
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
-                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_octdbg, &ex->d_xgtab,
+                      &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
                       &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_ftiles};
     for (DevBuf *b : bufs) b->release();
@@ -769,7 +680,7 @@ int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_f
                                       hipMemcpyHostToDevice, is));
     }
     ORBX_HIP(hipEventRecord(ex->ev_in_ready[slot], is));
-    ORBX_HIP(hipStreamWaitEvent(ex->ahead() ? ex->pyr_stream : ex->stream, ex->ev_in_ready[slot], 0));   // the stream of k_pyr_base
+    ORBX_HIP(hipStreamWaitEvent(ex->stream, ex->ev_in_ready[slot], 0));   // the stream of k_pyr_base
     ex->in_used[slot] = true;
     ex->in_issued++;
     return enqueue_extract(ex, (const uint8_t *)din.p, n_frames, width, fbytes, lap0, lap1, ex->ev_in_free[slot]);
@@ -779,7 +690,7 @@ int orbx_set_camera(orbx_extractor *ex, const orbx_camera *cam) {
     if (!ex) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->pyr_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
     ex->has_camera = cam != nullptr;
     if (cam) {
         const float p[9] = {cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
@@ -825,7 +736,6 @@ int orbx_sync(orbx_extractor *ex) {
     ORBX_HIP(hipStreamSynchronize(ex->aux_stream));
     ORBX_HIP(hipStreamSynchronize(ex->match_stream));
     ORBX_HIP(hipStreamSynchronize(ex->in_stream));
-    if (ex->pyr_stream) ORBX_HIP(hipStreamSynchronize(ex->pyr_stream));
     return ORBX_OK;
 }
 
@@ -902,13 +812,11 @@ int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *d
     // keypoints and descriptors leave as soon as the extraction is done, BESIDE the matcher (they are 94 % of the bytes and the matcher
     // does not write them); only the match vectors wait for it.  With the wait in front of everything the next batch's k_finalize sat
     // behind matcher + all copies in series (ORBX_COPY_AFTER_MATCH=1 restores that order).
-    static const bool copy_after_match = [] { const char *v = getenv("ORBX_COPY_AFTER_MATCH"); return v && v[0] == '1'; }();
-    if (copy_after_match && ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
     if (counts) ORBX_HIP(hipMemcpyAsync(counts, ex->d_count.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     if (mono) ORBX_HIP(hipMemcpyAsync(mono, ex->d_mono.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, cs));
-    if (!copy_after_match && ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
+    if (ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
     if (match && ex->d_match.p) ORBX_HIP(hipMemcpyAsync(match, ex->d_match.p, 4 * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (nmatches && ex->d_nmatch.p) ORBX_HIP(hipMemcpyAsync(nmatches, ex->d_nmatch.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     const unsigned slot = ex->copy_issued & 1;
@@ -952,7 +860,7 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
     if ((r = ex->ensure_stage(std::max(dpitch * height, 64 + (size_t)ex->cap * (sizeof(orbx_keypoint) + 32)))) != ORBX_OK) return r;
     for (int y = 0; y < height; y++) memcpy((uint8_t *)ex->h_stage + (size_t)y * dpitch, image + (size_t)y * stride, (size_t)width);
     // on the stream that runs k_pyr_base (the pyramid stream when the pyramid is built ahead): the upload must be ordered before it
-    ORBX_HIP(hipMemcpyAsync(ex->d_img.p, ex->h_stage, dpitch * height, hipMemcpyHostToDevice, ex->ahead() ? ex->pyr_stream : ex->stream));
+    ORBX_HIP(hipMemcpyAsync(ex->d_img.p, ex->h_stage, dpitch * height, hipMemcpyHostToDevice, ex->stream));
     r = enqueue_extract(ex, (const uint8_t *)ex->d_img.p, 1, dpitch, dpitch * height, lap0, lap1);
     if (r != ORBX_OK) return r;
     return orbx_batch_download(ex, 0, kps, desc, cap, n_out, mono_index);
@@ -970,7 +878,7 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
     const LevelInfo &L = ex->lv[level];
     if (dst_stride < (size_t)(L.w + 2 * kEdge)) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
-    const uint8_t *src = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off;
+    const uint8_t *src = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off;
     const size_t bytes = (size_t)L.pitch * (L.h + 2 * kEdge);
     int r = ex->d2h_staged_begin(bytes);
     if (r != ORBX_OK) return r;
@@ -983,7 +891,7 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
 int orbx_get_level_device(orbx_extractor *ex, int frame, int level, const uint8_t **d_padded, size_t *pitch) {
     if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
     const LevelInfo &L = ex->lv[level];
-    if (d_padded) *d_padded = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off + kRingX;
+    if (d_padded) *d_padded = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off + kRingX;
     if (pitch) *pitch = L.pitch;
     return ORBX_OK;
 }
@@ -1057,7 +965,7 @@ int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *
     const size_t bytes = (size_t)L.bpitch * L.h;
     int r = ex->d2h_staged_begin(bytes);
     if (r != ORBX_OK) return r;
-    if ((r = ex->d2h_staged(0, (const uint8_t *)ex->blur_cur() + (size_t)frame * ex->blur_frame + L.boff, bytes)) != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, (const uint8_t *)ex->d_blur.p + (size_t)frame * ex->blur_frame + L.boff, bytes)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     for (int y = 0; y < L.h; y++) memcpy(dst + (size_t)y * dst_stride, ex->staged((size_t)y * L.bpitch), (size_t)L.w);
     return ORBX_OK;
@@ -1081,23 +989,6 @@ int orbx_debug_sort_nodes(int device, const int32_t *count, const int32_t *ulx, 
     return ORBX_OK;
 }
 
-// phase timing of k_octree_par's workgroup (frame 0, level): 16 counters, see OCT_TICK in octree_par.hip.h; level < 0 disables
-int orbx_debug_octree_timing(orbx_extractor *ex, int level, int64_t *out16) {
-    if (!ex) return ORBX_E_BAD_ARG;
-    ORBX_HIP(hipSetDevice(ex->device));
-    ORBX_HIP(hipStreamSynchronize(ex->stream));
-    if (out16 && ex->d_octdbg.p) ORBX_HIP(hipMemcpy(out16, ex->d_octdbg.p, 16 * 8, hipMemcpyDeviceToHost));
-    if (level >= 0) {
-        int r = ex->d_octdbg.ensure(16 * 8);
-        if (r != ORBX_OK) return r;
-        ORBX_HIP(hipMemset(ex->d_octdbg.p, 0, 16 * 8));
-        ORBX_HIP(hipDeviceSynchronize());
-    } else {
-        ex->d_octdbg.release();
-    }
-    ex->octdbg_level = level;
-    return ORBX_OK;
-}
 
 int orbx_debug_sort_nodes_par(int device, const int32_t *count, const int32_t *ulx, int n, int32_t *perm, int32_t *fell_back) {
     if (n <= 0 || n > 65535) return ORBX_E_BAD_ARG;

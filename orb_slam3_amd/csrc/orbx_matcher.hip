@@ -21,32 +21,8 @@ namespace {
 
 constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
-// ORBX_GRID_BUILD=2: k_grid_build2 (batched loads, claim rounds; unmeasured) instead of k_grid_build
-inline bool grid_build2() {
-    static const bool v = [] { const char *e = getenv("ORBX_GRID_BUILD"); return e && e[0] == '2'; }();
-    return v;
-}
-#define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...)                                   \
-    do {                                                                                       \
-        if (grid_build2()) hipLaunchKernelGGL(k_grid_build2, grid, block, lds, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__);           \
-    } while (0)
-// ORBX_WINDOW_DPP=1: k_window_best2<true> (DPP row reductions; unmeasured) instead of the shuffle form
-inline bool window_dpp() {
-    static const bool v = [] { const char *e = getenv("ORBX_WINDOW_DPP"); return e && e[0] == '1'; }();
-    return v;
-}
-#define ORBX_LAUNCH_WINDOW_BEST2(grid, block, lds, stream, ...)                                          \
-    do {                                                                                                \
-        if (window_dpp()) hipLaunchKernelGGL(k_window_best2<true>, grid, block, lds, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL(k_window_best2<false>, grid, block, lds, stream, __VA_ARGS__);           \
-    } while (0)
-// k_greedy_resolve re-scans a query's window through the frame's grid (ORBX_RESOLVE_RESCAN=full: over all features, the round-1 form)
-inline int resolve_grid_rescan() {
-    static const int v = [] { const char *e = getenv("ORBX_RESOLVE_RESCAN"); return (e && e[0] == 'f') ? 0 : 1; }();
-    return v;
-}
-
+#define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__)
+#define ORBX_LAUNCH_WINDOW_BEST2(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_window_best2, grid, block, lds, stream, __VA_ARGS__)
 struct Arena {  // bump allocator over one device buffer, reset per call
     uint8_t *base = nullptr;
     size_t cap = 0, used = 0;
@@ -411,7 +387,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     ORBX_LAUNCH_WINDOW_BEST2( dim3((nq + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n, resolve_grid_rescan());
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n);
     int32_t nm = 0;
     D2H(a.match_out, R.match, 4 * (size_t)n);
     D2H(&nm, R.nmatches, 4);
@@ -1011,7 +987,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     if (resolve_lds_bytes(cap) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mprobs.p,
-                       (const ResolveProblem *)ex->d_mres.p, g, cap, resolve_grid_rescan());
+                       (const ResolveProblem *)ex->d_mres.p, g, cap);
     if (ex->profile) {
         (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
         float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
@@ -1120,7 +1096,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
     if (resolve_lds_bytes(cap) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
-                       (const ResolveProblem *)ex->d_mp_res.p, g, cap, resolve_grid_rescan());
+                       (const ResolveProblem *)ex->d_mp_res.p, g, cap);
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
     ex->match_pending = true;
     ORBX_HIP(hipGetLastError());
@@ -1252,7 +1228,7 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
     S.dl = (const uint8_t *)L->d_desc.p; S.dr = (const uint8_t *)R->d_desc.p;
     S.nl = (const int32_t *)L->d_count.p; S.nr = (const int32_t *)R->d_count.p;
     S.capL = capL; S.capR = R->cap;
-    S.pyrL = (const uint8_t *)L->pyr_cur(); S.pyrR = (const uint8_t *)R->pyr_cur();
+    S.pyrL = (const uint8_t *)L->d_pyr.p; S.pyrR = (const uint8_t *)R->d_pyr.p;
     S.pyr_frame_L = L->pyr_frame; S.pyr_frame_R = R->pyr_frame;
     S.lvL = (const LevelInfo *)L->d_lv.p; S.lvR = (const LevelInfo *)R->d_lv.p;
     S.scale = (const float *)L->d_st_scales.p; S.inv_scale = S.scale + nl;

@@ -49,12 +49,11 @@ print('emulation ok', n)
 
 
 @pytest.mark.parametrize("env", [{"SIMT_SHUFFLE": "7", "SIMT_BLOCK_ORDER": "reverse", "SIMT_LANE_ORDER": "reverse", "SIMT_STRICT_LANES": "1"},
-                                 {"SIMT_LDS_RANDOM": "3", "SIMT_MALLOC_FILL": "r9", "SIMT_BLOCK_ORDER": "4", "ORBX_PYR_CHAIN": "2", "SIMT_SHUFFLE": "5"}])
+                                 {"SIMT_LDS_RANDOM": "3", "SIMT_MALLOC_FILL": "r9", "SIMT_BLOCK_ORDER": "4", "SIMT_SHUFFLE": "5"}])
 def test_emulated_extractor_small_image_stagewise(emul_lib, env):
     """Pyramid, blur, FAST candidates, quad-tree output, keypoints and descriptors of the emulated device code == oracle; also with the
     waves of every workgroup resumed in random order, the workgroups of every launch run last to first / in random order (the order
-    of global-atomic list appends), with random garbage in the dynamic LDS and in every device allocation, and with the chained pyramid kernel
-    (k_pyr_chain: 16 waves per workgroup, levels separated by a workgroup barrier only)."""
+    of global-atomic list appends), with random garbage in the dynamic LDS and in every device allocation."""
     _child(STAGEWISE.replace("IMG", "synth.make_test_image(5, 320, 240)").replace("NF", "500"), env)
 
 
@@ -113,9 +112,9 @@ print('emulation ok')
 """
 
 
-@pytest.mark.parametrize("env", [{"SIMT_STREAM_FUZZ": "first", "ORBX_OCTREE_KEYS": "2048", "SIMT_MALLOC_FILL": "255"},
-                                 {"SIMT_STREAM_FUZZ": "last", "ORBX_GRID_BUILD": "2", "ORBX_RESOLVE_RESCAN": "full", "ORBX_WINDOW_DPP": "1", "SIMT_BLOCK_ORDER": "reverse"},
-                                 {"SIMT_STREAM_FUZZ": "7", "ORBX_PYR_CHAIN": "1", "ORBX_DESCRIBE": "2", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11", "SIMT_LANE_ORDER": "3", "SIMT_LDS_RANDOM": "8"},
+@pytest.mark.parametrize("env", [{"SIMT_STREAM_FUZZ": "first", "SIMT_MALLOC_FILL": "255"},
+                                 {"SIMT_STREAM_FUZZ": "last", "SIMT_BLOCK_ORDER": "reverse"},
+                                 {"SIMT_STREAM_FUZZ": "7", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11", "SIMT_LANE_ORDER": "3", "SIMT_LDS_RANDOM": "8"},
                                  {"SIMT_STREAM_FUZZ": "5", "SIMT_MEMSET_ASYNC": "1", "SIMT_KERNEL_SPLIT": "6"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "in-order")
 def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
@@ -125,7 +124,7 @@ def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     operations per stream and executes them in another order the recorded dependencies allow -- `first`: the main stream runs ahead
     and the side streams starve until something waits for them, `last`: the reverse, a number: random -- so that a missing event
     dependency between streams shows up as a wrong result (checked: with the main stream's waits for the matcher / the download
-    removed, `first` fails).  Also: k_grid_build2 + the full-frame re-scan, and the chained pyramid kernel.
+    removed, `first` fails).
     SIMT_KERNEL_SPLIT: every launch is queued in pieces, so that kernels on different streams interleave at workgroup granularity.
     SIMT_MEMSET_ASYNC: hipMemset() returns before the fill has run (queued on the null stream, which the library's non-blocking streams
     do not wait for) -- with the clear of DevBuf::ensure left unsynchronised this schedule zeroes frame 0 of the first host-input batch
@@ -133,17 +132,13 @@ def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     _child(PIPELINE, env)
 
 
-SWITCHES = [{"ORBX_BLUR_KERNEL": "0"}, {"ORBX_RESIZE_COLS": "1"}, {"ORBX_RESIZE_COLS": "1", "ORBX_RESIZE_PK": "0"}, {"ORBX_PYR_XCD": "0"},
-            {"ORBX_PYR_AHEAD": "2"}, {"ORBX_PYR_AHEAD": "1"}, {"ORBX_COPY_AFTER_MATCH": "1"}, {"ORBX_SIDE_STREAMS": "0"}, {"ORBX_BLUR_SIDE": "0"},
-            {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_INI": "0"}, {"ORBX_FAST_TPB": "256"}, {"ORBX_BLUR_GROUPS": "3"}, {"ORBX_FAST_INI_QCAP": "48"},
-            {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_PYR_CHAIN": "1"}, {"ORBX_PYR_CHAIN": "2"}, {"ORBX_DESCRIBE": "2"}, {"ORBX_OCTREE_KEYS": "2048"}, {"ORBX_GRID_BUILD": "2"}, {"ORBX_WINDOW_DPP": "1"}]
+SWITCHES = [{"ORBX_SIDE_STREAMS": "0"}, {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_INI_QCAP": "48"}]
 
 
-@pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): about fifteen minutes")
+@pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): a few minutes")
 @pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_emulated_switch_matrix(emul_lib, env):
-    """Every alternative kernel / scheduling switch of DESIGN.md section 6 through the two-batch pipeline under emulation (their LOGIC:
-    slab toggling, grids, the older kernels, the three kernels prepared for round 3).  All twenty-one passed at the end of round 2."""
+    """The library's remaining switches through the two-batch pipeline under emulation."""
     _child(PIPELINE, env)
 
 
@@ -177,12 +172,13 @@ def test_reference_matcher_modules_through_adapter_and_emulated_kernels(emul_lib
     assert m and int(m.group(1)) >= 17, tail
 
 
-def test_branch_free_describe_math_equals_branching_forms(emul_lib, tmp_path):
-    """glibc_sincosf_sel / fast_atan2_deg_sel (k_describe2) are bit-identical to glibc_sincosf / fast_atan2_deg (k_describe, itself the port of
-    the libm the reference links and of cv::fastAtan2): 14.7 million arguments, device code compiled for the host."""
+def test_branch_free_describe_math_equals_libm_and_oracle(emul_lib, tmp_path):
+    """k_describe's branch-free glibc_sincosf / fast_atan2_deg are bit-identical to the host libm's sinf / cosf (the libm the reference links;
+    the oracle's restatement was checked against it exhaustively) and to the oracle's cv::fastAtan2: 14.7 million arguments, device code compiled
+    for the host."""
     exe = tmp_path / "check_describe_math"
     r = subprocess.run([str(CLANG), "-std=c++17", "-O1", "-ffp-contract=off", f"-I{SIMT}", f"-I{SIMT / 'build'}", "-Wno-ignored-attributes",
-                        "-Wno-unused-value", str(SIMT / "check_describe_math.cc"), str(SIMT / "launch.cc"), "-o", str(exe)], capture_output=True, text=True)
+                        "-Wno-unused-value", str(SIMT / "check_describe_math.cc"), str(SIMT / "launch.cc"), f"-L{ROOT / 'oracle'}", "-lorb_oracle", f"-Wl,-rpath,{ROOT / 'oracle'}", "-lm", "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:]
