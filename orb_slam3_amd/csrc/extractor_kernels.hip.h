@@ -895,6 +895,7 @@ __global__ __launch_bounds__(64) void k_fast_wave_list(const LevelInfo *__restri
 // ---------------------------------------------------------------------------------------------------------
 }  // namespace orbx
 
+#include "fast_strip.hip.h"
 #include "octree.hip.h"
 #include "octree_par.hip.h"
 

@@ -1,0 +1,355 @@
+// fast_strip.hip.h -- k_fast_strip: the first pass of the reference's per-cell detection, cv::FAST(cell, iniThFAST, nonmax) for every
+// cell of a frame (/root/reference/src/ORBextractor.cc:805-842), one workgroup per STRIP of cells instead of one wave per cell.
+// Included by extractor_kernels.hip.h (uses fast_score16, quick_pairs, the DPP scan and the packed-u16 helpers defined there).
+//
+// A strip = up to floor(256 / wCell) horizontally adjacent cells of one cell row of one level.  The score of a pixel does not depend on
+// the cell it lies in ("corner at threshold t" <=> cornerScore >= t, and the cell interiors tile the detection window
+// exactly), so the detection stages run over the strip's interior as ONE image, 4 pixels per lane across its whole width:
+//   phase 0  the strip's sub-image rows (interior + 3-px apron, one extra byte left so that interior 4-pixel groups are dword aligned
+//            in LDS) -> LDS, rows interleaved over the 4 waves, every load of a wave in flight at once (buffer descriptor: no
+//            per-row predicates)                                                                                   | barrier
+//   stage A  per 4-pixel group: v_sad_u8 rejection on the vertical and horizontal antipodal pairs (if both pixels of a pair are
+//            within t of all four centres no 9-arc exists); lanes = groups of 64 / G whole rows (G = groups per row), every wave
+//            on its own band of rows; surviving groups queued row-major (ballot + mbcnt)
+//   stage B  the four-antipodal-pair test on the queued groups only (packed u16, both polarities); passing pixels queued row-major
+//   scores   exact cornerScore of the queued pixels; corners (score >= t) compacted in place                      | barrier
+//   NMS      the pixel tile is dead: each wave zeroes its band of the score tile and scatters its corners into it, with one ZERO
+//            COLUMN between adjacent cells -- cv::FAST runs per cell sub-image, so a neighbour in another cell scores 0 (the
+//            strip's rows belong to one cell row, the apron rows are zero)                                         | barrier
+//            strict '>' against the 8 neighbours; survivors compacted in place, counted per (wave, cell)           | barrier
+//   emit     a cell's survivors in row-major order = wave 0's, then wave 1's, ... (bands are row ranges): slot position = the
+//            earlier waves' counts of that cell + the rank inside the wave; cells without a survivor go to the list the second
+//            pass (k_fast_wave_list, :843-846) works through, cells of a strip whose queues overflowed as well.
+// What it removes against one wave per cell (k_fast_ini, rounds 1-2): the (wCell + 6)(hCell + 6) / (wCell hCell) apron re-read per
+// cell (now only the 6 apron rows per strip and 8 columns per 256), the per-cell set-up and the part-filled last iterations of every
+// stage (a strip's queues are 5-7 cells long), the lanes a 36-px cell row leaves idle (9 groups x 6-7 rows = 54-63 of 64).
+// grid xcd_grid(n_strips, B), block 256, dynamic LDS = fast_strip_lds_bytes(...)
+#pragma once
+
+namespace orbx {
+
+constexpr int kStripPitch = 272;   // LDS bytes per tile row: 4 + 256 interior + 4, rounded up to 16
+constexpr int kStripWaves = 4;
+constexpr int kStripMaxCells = 8;  // floor(256 / 35) = 7 cells at most
+
+struct StripTile {   // one strip, precomputed per geometry (48 bytes, scalar loads)
+    uint32_t src_off;      // byte offset inside a frame's pyramid slab of tile byte (row 0, col 0) = level pixel (X0 - 4, Y0 - 3)
+    int32_t pitch;         // bytes per padded row of the level
+    int16_t iw, ih;        // interior size: iw <= 256 pixels, ih <= 63 rows
+    int16_t ox, oy;        // candidate coordinates of interior pixel (0, 0): 3 + j0 * wCell, 3 + i * hCell
+    uint32_t cell0;        // index of the strip's first cell in a frame's cell-count array (= its TileRef index for the list pass)
+    uint32_t slot0;        // entry offset of that cell's slot inside a frame's candidate slab
+    uint32_t cell_cap;     // entries per cell slot
+    uint32_t rcp_wcell;    // ceil(2^16 / wCell): cell of interior column x = (x * rcp_wcell) >> 16  (exact for x < 256, wCell < 256)
+    uint32_t rcp_groups;   // ceil(2^20 / G), G = (iw + 3) / 4 dword groups per interior row: lane -> (row, group) without a division
+    uint16_t rows_per_iter, ncell;   // 64 / G rows per stage-A iteration; cells in the strip
+    uint32_t pad[2];
+};
+static_assert(sizeof(StripTile) == 48, "StripTile layout");
+
+__host__ __device__ inline size_t fast_strip_wave_bytes(int gcap, int qcap) { return ((size_t)gcap * 2 + (size_t)qcap * 3 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t fast_strip_lds_bytes(int max_rows, int gcap, int qcap) {
+    return (size_t)max_rows * kStripPitch + kStripWaves * fast_strip_wave_bytes(gcap, qcap) + (kStripWaves * kStripMaxCells + 4) * sizeof(int32_t);
+}
+
+// The four-pair test with the two polarities apart: *fb nonzero halves = pixels that can be BRIGHT corners at t (in every antipodal pair
+// one pixel is above centre + t), *fd = DARK.  A 9-arc of one polarity needs its pixel in every pair.
+__device__ __forceinline__ void quick_pairs_pol(u16x2 c, u16x2 p0, u16x2 p8, u16x2 p4, u16x2 p12, u16x2 p2, u16x2 p10, u16x2 p6, u16x2 p14, u16x2 t2,
+                                                uint32_t *fb, uint32_t *fd) {
+    const u16x2 mb = pk_min(pk_min(pk_max(p0, p8), pk_max(p4, p12)), pk_min(pk_max(p2, p10), pk_max(p6, p14)));
+    const u16x2 md = pk_max(pk_max(pk_min(p0, p8), pk_min(p4, p12)), pk_max(pk_min(p2, p10), pk_min(p6, p14)));
+    const u16x2 hi = c + t2;
+    const u16x2 lo = __builtin_elementwise_sub_sat(c, t2);
+    *fb = as_u32(__builtin_elementwise_sub_sat(mb, hi));
+    *fd = as_u32(__builtin_elementwise_sub_sat(lo, md));
+}
+
+// cornerScore of one polarity: m = 0 the bright side, max over the arcs of min9(p) - v - 1; m = 0xff the dark side, v - min over the arcs of
+// max9(p) - 1, evaluated as the bright side of the inverted pixels (255 - p = p ^ 0xff).  For a pixel whose quick test allows only this
+// polarity the other side of [OCV] cornerScore<16> is below the threshold, so "score >= t" and the score of every corner are unchanged
+// (40 instead of 80 three-input min / max per pixel).
+__device__ __forceinline__ int fast_score16_pol(const uint8_t *__restrict__ c, int pp, int m) {
+    const int v = c[0] ^ m;
+    int p[16];
+    p[0] = c[3 * pp]; p[1] = c[3 * pp + 1]; p[2] = c[2 * pp + 2]; p[3] = c[pp + 3]; p[4] = c[3]; p[5] = c[-pp + 3]; p[6] = c[-2 * pp + 2];
+    p[7] = c[-3 * pp + 1]; p[8] = c[-3 * pp]; p[9] = c[-3 * pp - 1]; p[10] = c[-2 * pp - 2]; p[11] = c[-pp - 3]; p[12] = c[-3];
+    p[13] = c[pp - 3]; p[14] = c[2 * pp - 2]; p[15] = c[3 * pp - 1];
+#pragma unroll
+    for (int k = 0; k < 16; k++) p[k] ^= m;
+    int lo3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) lo3[k] = min3i(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+    int maxmin = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        const int a0 = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);          // min over p[k..k+8]
+        const int a1 = min3i(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]);
+        maxmin = max3i(maxmin, a0, a1);
+    }
+    return maxmin - v - 1;
+}
+
+template <bool POL>   // polarity-split scores (one-sided arcs)
+__global__ __launch_bounds__(64 * kStripWaves) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
+                                                                 size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
+                                                                 uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
+                                                                 int max_rows, int gcap, int qcap, uint32_t *__restrict__ list,
+                                                                 int32_t *__restrict__ list_count, int second_pass, int n_frames) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int P = kStripPitch, D = P / 4, W = kStripWaves;
+    int tile, f;
+    if (!xcd_frame_map(n_frames, &tile, &f)) return;   // a frame's strips stay on one XCD (apron rows hit its L2)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const StripTile T = tiles[tile];
+    const int iw = T.iw, ih = T.ih, rows = ih + 6;
+    uint8_t *pix = smem;
+    uint8_t *wbase = smem + (size_t)max_rows * P + (size_t)wave * fast_strip_wave_bytes(gcap, qcap);
+    uint16_t *gq = reinterpret_cast<uint16_t *>(wbase);          // group queue
+    uint16_t *pq = gq + gcap;                                     // pixel queue -> corners -> survivors (compacted in place)
+    uint8_t *ps = reinterpret_cast<uint8_t *>(pq + qcap);         // score per pixel-queue entry
+    int32_t *cnt = reinterpret_cast<int32_t *>(smem + (size_t)max_rows * P + W * fast_strip_wave_bytes(gcap, qcap));   // [W][8] survivors per (wave, cell)
+    int32_t *ovf = cnt + W * kStripMaxCells;
+    if (threadIdx.x == 0) *ovf = 0;
+
+    // ---- phase 0: rows wave, wave + 4, ... ; lane = dword of the row (G + 2 <= 66 dwords: the two beyond lane 63 in a second sweep) ----
+    {
+        const int nd = ((iw + 3) >> 2) + 2;
+        const uint64_t a = (uint64_t)(pyr + (size_t)f * pyr_frame_stride + T.src_off);
+        const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)a), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        const int spitch = T.pitch;
+        const int nbytes = (rows - 1) * spitch + 4 * nd;
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)ahi << 32) | alo), 0, nbytes, 0x00020000);
+        const int oob = 0x40000000;
+        const int voff = (lane < nd ? 0 : oob) + wave * spitch + 4 * lane;
+        uint32_t v[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, voff + W * k * spitch, 0, 0);   // rows past the tile: out of range
+        // dwords 64, 65 of rows wave + 4 * (lane >> 1)
+        const int xr = wave + W * (lane >> 1), xd = 64 + (lane & 1);
+        const bool xlive = xd < nd && xr < rows;
+        const uint32_t xv = __builtin_amdgcn_raw_buffer_load_b32(srd, (xlive ? 0 : oob) + xr * spitch + 4 * xd, 0, 0);
+        uint8_t *d = pix + wave * P + 4 * lane;
+        if (lane < nd) {
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                if (wave + W * k < rows) *reinterpret_cast<uint32_t *>(d + W * k * P) = v[k];
+            for (int r = wave + 12 * W; r < rows; r += W)   // strips taller than 48 rows
+                *reinterpret_cast<uint32_t *>(pix + r * P + 4 * lane) = __builtin_amdgcn_raw_buffer_load_b32(srd, r * spitch + 4 * lane, 0, 0);
+        }
+        if (xlive) *reinterpret_cast<uint32_t *>(pix + xr * P + 4 * xd) = xv;
+    }
+    __syncthreads();
+
+    const int BH = (ih + W - 1) / W;                       // rows per wave band
+    const int yb0 = wave * BH, yb1 = min(ih, yb0 + BH);
+    const uint32_t ut = (uint32_t)iniTh;
+
+    // ---- stage A: groups whose vertical AND horizontal antipodal pairs cannot both be rejected by the SAD bound ----
+    // counters are wave-uniform (ballot popcounts: scalar unit); an entry past the queue's end is dropped and the count runs on,
+    // so that an overflow is seen after the loop (no data-dependent exit inside it)
+    int gn = 0;
+    {
+        const int G = (iw + 3) >> 2, RPI = (int)T.rows_per_iter;
+        const int lrow0 = (int)(((uint32_t)lane * T.rcp_groups) >> 20);
+        const bool lane_live = lrow0 < RPI;                 // the lanes past the last whole row of an iteration idle
+        const int lrow = lane_live ? lrow0 : 0, lg = lane_live ? lane - lrow0 * G : 0;
+        const uint8_t *Ap = pix + (yb0 + lrow) * P + 4 * lg + 4;
+        uint32_t ent = ((uint32_t)(yb0 + lrow) << 8) | (uint32_t)(4 * lg);
+        int left = lane_live ? yb1 - yb0 - lrow : 0;        // rows of the band at and below this lane's row
+#pragma unroll 2
+        for (int y0 = yb0; y0 < yb1; y0 += RPI) {
+            const uint32_t *A = reinterpret_cast<const uint32_t *>(Ap);   // tile row y = level row of the centre - 3
+            const uint32_t r8 = A[0], r0 = A[6 * D];
+            const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];
+            const uint32_t sv = max(__builtin_amdgcn_sad_u8(cC, r0, 0u), __builtin_amdgcn_sad_u8(cC, r8, 0u));
+            const uint32_t p4 = __builtin_amdgcn_alignbyte(cR, cC, 3), p12 = __builtin_amdgcn_alignbyte(cC, cL, 1);
+            const uint32_t sh = max(__builtin_amdgcn_sad_u8(cC, p4, 0u), __builtin_amdgcn_sad_u8(cC, p12, 0u));
+            const bool keep = left > 0 && min(sv, sh) > ut;
+            const unsigned long long b = __ballot(keep);
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, (uint32_t)gn));
+            if (keep && pos < gcap) gq[pos] = (uint16_t)ent;
+            gn += __popcll(b);
+            Ap += RPI * P; ent += (uint32_t)RPI << 8; left -= RPI;
+        }
+    }
+    bool over = gn > gcap;
+    wave_lds_sync();
+
+    // ---- stage B: the four-pair test on the queued groups, four pixels per lane, row-major queue order ----
+    int qn = 0;
+    if (!over) {
+        const u16x2 t2 = as_pk(ut * 0x00010001u);
+        for (int g0 = 0; g0 < gn; g0 += 64) {
+            const int gi = g0 + lane;
+            const bool act = gi < gn;
+            const uint32_t e0 = act ? (uint32_t)gq[gi] : 0u;
+            const int y = (int)(e0 >> 8), x4 = (int)(e0 & 0xff);
+            const uint32_t vmask = act ? 0xfu >> max(x4 + 3 - (iw - 1), 0) : 0u;   // pixels of the last group beyond the interior
+            const uint32_t *A = reinterpret_cast<const uint32_t *>(pix + y * P + x4 + 4);
+            const uint32_t r8 = A[0], r0 = A[6 * D];
+            const uint32_t aL = A[1 * D - 1], aC = A[1 * D], aR = A[1 * D + 1];
+            const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];
+            const uint32_t bL = A[5 * D - 1], bC = A[5 * D], bR = A[5 * D + 1];
+#define FS_EVEN(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(s) | ((uint32_t)((s) + 2) << 16)))
+#define FS_ODD(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)((s) + 1) | ((uint32_t)((s) + 3) << 16)))
+            if (!POL) {
+                const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), FS_EVEN(cR, cC, 3), FS_EVEN(cC, cL, 1), FS_EVEN(bR, bC, 2),
+                                                FS_EVEN(aC, aL, 2), FS_EVEN(aR, aC, 2), FS_EVEN(bC, bL, 2), t2);
+                const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), FS_ODD(cR, cC, 3), FS_ODD(cC, cL, 1), FS_ODD(bR, bC, 2),
+                                                FS_ODD(aC, aL, 2), FS_ODD(aR, aC, 2), FS_ODD(bC, bL, 2), t2);
+                uint32_t ze, zo;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(ze) : "v"(fe), "v"(0x00010001u));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zo) : "v"(fo), "v"(0x00010001u));
+                const uint32_t z = ze | (zo << 1);
+                const uint32_t m4 = (z | (z >> 14)) & vmask;
+                const int c = __popc(m4);
+                const int incl = wave_incl_scan(c);
+                int pos = qn + incl - c;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((m4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k);
+                    pos += (int)(m4 >> k & 1u);
+                }
+                qn += __builtin_amdgcn_readlane(incl, 63);
+            } else {
+                // the two polarities apart: a pixel that can only be a bright (dark) corner gets ONE queue entry with its polarity in bit
+                // 15, one that passes both tests (an edge through the centre, 9 % of the passing pixels) two, bright first
+                uint32_t fbe, fde, fbo, fdo;
+                quick_pairs_pol(pk_even(cC), pk_even(r0), pk_even(r8), FS_EVEN(cR, cC, 3), FS_EVEN(cC, cL, 1), FS_EVEN(bR, bC, 2),
+                                FS_EVEN(aC, aL, 2), FS_EVEN(aR, aC, 2), FS_EVEN(bC, bL, 2), t2, &fbe, &fde);
+                quick_pairs_pol(pk_odd(cC), pk_odd(r0), pk_odd(r8), FS_ODD(cR, cC, 3), FS_ODD(cC, cL, 1), FS_ODD(bR, bC, 2),
+                                FS_ODD(aC, aL, 2), FS_ODD(aR, aC, 2), FS_ODD(bC, bL, 2), t2, &fbo, &fdo);
+                uint32_t zbe, zbo, zde, zdo;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zbe) : "v"(fbe), "v"(0x00010001u));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zbo) : "v"(fbo), "v"(0x00010001u));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zde) : "v"(fde), "v"(0x00010001u));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zdo) : "v"(fdo), "v"(0x00010001u));
+                const uint32_t zb = zbe | (zbo << 1), zd = zde | (zdo << 1);
+                const uint32_t mb4 = (zb | (zb >> 14)) & vmask, md4 = (zd | (zd >> 14)) & vmask;
+                const int c = __popc(mb4) + __popc(md4);
+                const int incl = wave_incl_scan(c);
+                int pos = qn + incl - c;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((mb4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k);
+                    pos += (int)(mb4 >> k & 1u);
+                    if ((md4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k + 0x8000u);
+                    pos += (int)(md4 >> k & 1u);
+                }
+                qn += __builtin_amdgcn_readlane(incl, 63);
+            }
+#undef FS_EVEN
+#undef FS_ODD
+        }
+        over = qn > qcap;
+    }
+    wave_lds_sync();
+
+    // ---- exact scores of the queued pixels; corners (score >= iniTh) compacted in place, row-major order kept ----
+    int nc = 0;
+    if (!over) {
+        for (int e0 = 0; e0 < qn; e0 += 64) {
+            const int e = e0 + lane;
+            int s = -1, q = 0;
+            if (e < qn) {
+                q = pq[e];
+                if (!POL) s = fast_score16(pix + ((q >> 8) + 3) * P + (q & 0xff) + 4, P);
+                else s = fast_score16_pol(pix + (((q >> 8) & 0x3f) + 3) * P + (q & 0xff) + 4, P, (q >> 15) ? 0xff : 0);
+            }
+            const bool corner = s >= iniTh;
+            const unsigned long long b = __ballot(corner);
+            __builtin_amdgcn_wave_barrier();   // every lane has read its entry before any lane overwrites one (nc + rank <= e)
+            if (corner) {
+                const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, (uint32_t)nc));
+                pq[o] = (uint16_t)(q & 0x3fff);
+                ps[o] = (uint8_t)s;
+            }
+            nc += __popcll(b);
+        }
+    }
+    if (over && lane == 0) *ovf = 1;
+    __syncthreads();   // the pixel tile is dead from here on
+    if (*ovf) {        // a queue of some wave overflowed: the whole strip takes the second-pass kernel, cell by cell
+        if (threadIdx.x < T.ncell) list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + threadIdx.x);
+        return;
+    }
+
+    // ---- score tile (aliases the pixel tile): row y + 1, column 1 + x + cell(x); this wave's band + the apron row(s) next to it ----
+    uint8_t *sco = pix;
+    {
+        const int r0 = wave == 0 ? 0 : yb0 + 1, r1 = (wave == W - 1 || yb1 == ih) ? max(ih + 2, yb1 + 1) : yb1 + 1;   // rows [r0, r1)
+        uint4 *z = reinterpret_cast<uint4 *>(sco + r0 * P);
+        const int n16 = (r1 - r0) * (P / 16);
+        for (int i = lane; i < n16; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    wave_lds_sync();
+    for (int e = lane; e < nc; e += 64) {
+        const int q = pq[e], x = q & 0xff;
+        sco[((q >> 8) + 1) * P + 1 + x + (int)(((uint32_t)x * T.rcp_wcell) >> 16)] = ps[e];
+    }
+    __syncthreads();
+
+    // ---- NMS: strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); survivors compacted in place ----
+    int ns = 0;
+    for (int e0 = 0; e0 < nc; e0 += 64) {
+        const int e = e0 + lane;
+        int keep = 0, s = 0, q = 0;
+        if (e < nc) {
+            q = pq[e];
+            s = ps[e];
+            const int x = q & 0xff;
+            const uint8_t *p = sco + ((q >> 8) + 1) * P + 1 + x + (int)(((uint32_t)x * T.rcp_wcell) >> 16);
+            keep = (s > p[-1]) & (s > p[1]) & (s > p[-P - 1]) & (s > p[-P]) & (s > p[-P + 1]) & (s > p[P - 1]) & (s > p[P]) & (s > p[P + 1]);
+        }
+        const unsigned long long b = __ballot(keep != 0);
+        __builtin_amdgcn_wave_barrier();
+        if (keep) {
+            const int o = ns + __popcll(b & ((1ull << lane) - 1ull));
+            pq[o] = (uint16_t)q;
+            ps[o] = (uint8_t)s;
+        }
+        ns += __popcll(b);
+    }
+    wave_lds_sync();
+    // per-cell counts of this wave's survivors (lane c keeps the running count of cell c)
+    const int ncell = (int)T.ncell;
+    int mycnt = 0;
+    for (int e0 = 0; e0 < ns; e0 += 64) {
+        const int e = e0 + lane;
+        const int cellx = e < ns ? (int)(((uint32_t)(pq[e] & 0xff) * T.rcp_wcell) >> 16) : -1;
+        for (int c = 0; c < ncell; c++) {
+            const unsigned long long b = __ballot(cellx == c);
+            if (lane == c) mycnt += __popcll(b);
+        }
+    }
+    if (lane < kStripMaxCells) cnt[wave * kStripMaxCells + lane] = lane < ncell ? mycnt : 0;
+    __syncthreads();
+
+    // ---- emission: slot position = survivors of the cell in earlier waves (earlier rows) + rank inside this wave ----
+    uint32_t *slots = cellent + (size_t)f * ent_frame_stride + T.slot0;
+    int base = 0;   // lane c: survivors of cell c in the earlier waves, then also this wave's earlier chunks
+    if (lane < ncell)
+        for (int w = 0; w < wave; w++) base += cnt[w * kStripMaxCells + lane];
+    for (int e0 = 0; e0 < ns; e0 += 64) {
+        const int e = e0 + lane;
+        const int q = e < ns ? (int)pq[e] : 0;
+        const int cellx = e < ns ? (int)(((uint32_t)(q & 0xff) * T.rcp_wcell) >> 16) : -1;
+        int pos = 0;
+        for (int c = 0; c < ncell; c++) {
+            const unsigned long long b = __ballot(cellx == c);
+            const int before = __builtin_amdgcn_readlane(base, c);
+            if (cellx == c) pos = before + __popcll(b & ((1ull << lane) - 1ull));
+            if (lane == c) base += __popcll(b);
+        }
+        if (e < ns) slots[(size_t)cellx * T.cell_cap + pos] = pack_key((q & 0xff) + T.ox, (q >> 8) + T.oy, ps[e]);
+    }
+    if (wave == 0 && lane < ncell) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) total += cnt[w * kStripMaxCells + lane];
+        if (total > 0 || !second_pass) cellcnt[(size_t)f * total_cells + T.cell0 + lane] = total;
+        else list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + lane);   // cv::FAST(cell, iniThFAST) found nothing: second pass (:843-846)
+    }
+}
+
+}  // namespace orbx

@@ -87,6 +87,9 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     std::vector<ResizeGroup> xgtab;
     std::vector<TileRef> fast_tiles, blur_tiles;
     std::vector<FastTile> ftiles;
+    std::vector<StripTile> strips;
+    int strip_rows = 0;
+    bool fast_strip = true;
     size_t pyr_off = 0, blur_off = 0;
     uint32_t cand_off = 0, lvl_off = 0;
     int cell_base = 0, cap = 0, max_pool = 0;
@@ -207,6 +210,39 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
                 T.rcp_groups = ((1u << 20) + G - 1u) / G; T.rows_per_iter = 64u / G;
                 ftiles.push_back(T);
             }
+        // the same cells as strips of up to floor(256 / wCell) cells for k_fast_strip (fast_strip.hip.h)
+        {
+            const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+            const int kmax = std::max(1, std::min(256 / L.wCell, kStripMaxCells - 1));
+            const uint32_t rcpw = (65536u + (uint32_t)L.wCell - 1u) / (uint32_t)L.wCell;
+            for (int x = 0; x < 256; x++) if ((int)(((uint32_t)x * rcpw) >> 16) != x / L.wCell) fast_strip = false;
+            if (L.wCell > 256 || L.hCell > 63) fast_strip = false;
+            for (int i = 0; i < L.nRows && fast_strip; i++) {
+                const int Y0 = kBorder + 3 + i * L.hCell, IH = std::min(Y0 + L.hCell, maxBY - 3) - Y0;
+                if (IH <= 0) continue;   // :810 and sub-images with fewer than 7 rows
+                for (int j0 = 0; j0 < L.nCols; j0 += kmax) {
+                    const int j1 = std::min(j0 + kmax, L.nCols);
+                    const int X0 = kBorder + 3 + j0 * L.wCell, IW = std::min(kBorder + 3 + j1 * L.wCell, maxBX - 3) - X0;
+                    if (IW <= 0) continue;   // :819 and sub-images with fewer than 7 columns
+                    StripTile T;
+                    memset(&T, 0, sizeof(T));
+                    T.src_off = (uint32_t)(L.off + (size_t)(kEdge + Y0 - 3) * L.pitch + kRoiX + X0 - 4);
+                    T.pitch = L.pitch;
+                    T.iw = (int16_t)IW; T.ih = (int16_t)IH;
+                    T.ox = (int16_t)(3 + j0 * L.wCell); T.oy = (int16_t)(3 + i * L.hCell);
+                    T.cell0 = (uint32_t)(L.cell_base + i * L.nCols + j0);
+                    T.slot0 = L.cand_off + (uint32_t)(i * L.nCols + j0) * (uint32_t)L.cell_cap;
+                    T.cell_cap = (uint32_t)L.cell_cap;
+                    T.rcp_wcell = rcpw;
+                    const uint32_t G = (uint32_t)((IW + 3) >> 2);
+                    T.rcp_groups = ((1u << 20) + G - 1u) / G;
+                    T.rows_per_iter = (uint16_t)(64u / G);
+                    T.ncell = (uint16_t)((IW + L.wCell - 1) / L.wCell);
+                    strips.push_back(T);
+                    strip_rows = std::max(strip_rows, IH + 6);
+                }
+            }
+        }
         ex->blur_tile_start[l] = (int)blur_tiles.size();
         for (int i = 0; i < (L.h + kBlurTH - 1) / kBlurTH; i++)
             for (int j = 0; j < (L.w + kBlurTW - 1) / kBlurTW; j++)
@@ -240,6 +276,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_xgtab, sizeof(ResizeGroup) * std::max<size_t>(xgtab.size(), 1));
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_ftiles, sizeof(FastTile) * ftiles.size());
+    ENS(ex->d_strips, sizeof(StripTile) * std::max<size_t>(strips.size(), 1));
     ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
     ENS(ex->d_pyr, pyr_off * B);
     ENS(ex->d_blur, blur_off * B);
@@ -267,6 +304,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (!xgtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xgtab.p, xgtab.data(), sizeof(ResizeGroup) * xgtab.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_ftiles.p, ftiles.data(), sizeof(FastTile) * ftiles.size(), hipMemcpyHostToDevice));
+    if (!strips.empty()) ORBX_HIP(hipMemcpy(ex->d_strips.p, strips.data(), sizeof(StripTile) * strips.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_tiles.p, blur_tiles.data(), sizeof(TileRef) * blur_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
     ORBX_HIP(hipDeviceSynchronize());   // the fill has run (DevBuf::ensure, extractor_state.h)
@@ -274,6 +312,14 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->width = width; ex->height = height; ex->batch_cap = B;
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
     ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave = fast_wave && fast_tiles.size() < 65536 && batch < 65536;
+    ex->fast_strip = fast_strip && ex->fast_wave && !strips.empty();
+    { const char *v = getenv("ORBX_FAST_STRIP"); if (v && v[0] == '0') ex->fast_strip = false; }   // TEMPORARY (A/B visit): the per-cell k_fast_ini
+    { const char *v = getenv("ORBX_STRIP_GCAP"); if (v && atoi(v) >= 64) ex->strip_gcap = atoi(v) & ~7; }   // TEMPORARY (A/B visit)
+    { const char *v = getenv("ORBX_STRIP_QCAP"); if (v && atoi(v) >= 64) ex->strip_qcap = atoi(v) & ~15; }  // TEMPORARY (A/B visit)
+    ex->n_strips = (int)strips.size(); ex->strip_rows = strip_rows;
+    if (getenv("ORBX_DEBUG_ALLOC"))
+        fprintf(stderr, "[orbx fast] %s: %d strips of up to %d rows per frame, %zu cells, LDS %zu B per workgroup\n", ex->fast_strip ? "k_fast_strip" : "per-cell kernels",
+                ex->n_strips, strip_rows, fast_tiles.size(), fast_strip_lds_bytes(strip_rows, ex->strip_gcap, ex->strip_qcap));
     ex->fast_wave_pitch = (fast_wave_maxw + 7 <= 48) ? 48 : 64;
     ex->fast_wave_rows = fast_wave_rows;
     ex->fast_wave_qfull = fast_wave_qfull;
@@ -382,7 +428,18 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qcap, \
                        ovf_list, ovf_count)
             const int fast_stop = 0;
-            if (ini > mn) {
+            if (ex->fast_strip) {
+                // first pass of :826 for every cell, one workgroup per strip of cells; cells it leaves empty go to the list pass below
+                // (ini <= min: the second pass is a subset of the first, an empty cell stays empty)
+                const size_t lds = fast_strip_lds_bytes(ex->strip_rows, ex->strip_gcap, ex->strip_qcap);
+                static const bool pol = [] { const char *v = getenv("ORBX_FAST_POL"); return !(v && v[0] == '0'); }();   // TEMPORARY (A/B visit)
+#define ORBX_FAST_STRIP(POL)                                                                                                                  \
+    hipLaunchKernelGGL(k_fast_strip<POL>, xcd_grid(ex->n_strips, n), dim3(64 * kStripWaves), lds, st, (const StripTile *)ex->d_strips.p,         \
+                       (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p,          \
+                       ex->cand_frame, ini, ex->strip_rows, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count, ini > mn ? 1 : 0, n)
+                if (pol) ORBX_FAST_STRIP(true); else ORBX_FAST_STRIP(false);
+#undef ORBX_FAST_STRIP
+            } else if (ini > mn) {
                 // first pass of :826 for every cell (k_fast_ini); cells it leaves empty go to the list pass below
                 const size_t lds_wave = std::max<size_t>((fast_ini_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_ini_qcap, ex->fast_ini_gcap) + 15) & ~(size_t)15,
                                                           (size_t)48 * ex->fast_wave_pitch);   // fast_tile_load_srd writes 48 rows
@@ -574,7 +631,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipEventCreate(&ex->ev1);
     (void)hipStreamCreateWithPriority(&ex->copy_stream, hipStreamNonBlocking, prio_lo);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
-    { const char *v = getenv("ORBX_FAST_INI_QCAP"); if (v && atoi(v) >= 16) ex->fast_ini_qcap = atoi(v) & ~15; }  // test hook: force the list pass
+    { const char *v = getenv("ORBX_FAST_INI_QCAP"); if (v && atoi(v) >= 16) { ex->fast_ini_qcap = atoi(v) & ~15; ex->strip_qcap = atoi(v) & ~15; } }  // test hook: force the list pass
     { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 64) ex->fast_wave_qcap = atoi(v) & ~15; }  // test hook: force k_fast_overflow
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
@@ -631,7 +688,7 @@ void orbx_destroy(orbx_extractor *ex) {
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
-                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_ftiles};
+                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_ftiles, &ex->d_strips};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);

@@ -290,6 +290,15 @@ template <typename T> inline T __shfl_xor(T v, int m) {
     const simt::WaveView w = simt::wave_collect(simt_bits(v));
     return simt_from<T>(simt::lane_value(w, lane ^ m, "__shfl_xor"));
 }
+// v_mbcnt_lo / v_mbcnt_hi: bits of the mask below this lane
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned add) {
+    const int lane = simt::cur_tid() & 63;
+    return add + (unsigned)__builtin_popcount(mask & (lane >= 32 ? 0xffffffffu : ((1u << lane) - 1u)));
+}
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add) {
+    const int lane = simt::cur_tid() & 63;
+    return add + (lane > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (lane - 32)) - 1u)) : 0u);
+}
 inline int __builtin_amdgcn_readlane(int v, int l) {
     const simt::WaveView w = simt::wave_collect(simt_bits(v));
     return simt_from<int>(simt::lane_value(w, l, "v_readlane"));
