@@ -18,9 +18,12 @@ i computes) -- SURVEY.md 8d's "wall clock covering H2D ... D2H".
 Processes: with WORLD_SIZE unset this file is a LAUNCHER: it starts one rank process per GPU itself (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment) and relays rank 0's JSON line; under
 torch.distributed.run it is a rank directly (and --gpus must equal WORLD_SIZE).  Ranks shard independent camera sequences
-(seed = 10 + rank), no data-path collective; torch.distributed (RCCL) carries only the timing barrier and
-the max-over-ranks / sum-over-ranks reduction.  After the timed loop rank 0 checks sampled frames of the last step (keypoints,
-descriptors, match vectors) against the CPU oracle: "parity_checked" in the JSON line; a mismatch is a failed run.
+(seed = 10 + rank), no data-path collective; torch.distributed over GLOO (host tensors) carries only the timing
+barrier and the gather of every rank's (seconds, features) -- no RCCL communicator is created on the GPUs (north_star: "RCCL not
+required").  After the timed loop rank 0 checks EVERY frame and EVERY match vector of the last timed step (keypoints, descriptors, match
+indices) against the CPU oracle: "parity_checked" in the JSON line; a mismatch is a failed run.  The K timed steps are then repeated
+(`repeats`: median / min / max over the regions), the drop-in call is timed one frame at a time (`latency`), and at --gpus 1 the other two
+BASELINE configurations (KITTI stereo, TUM-VI map-point search) run as child processes of the same file (`other_workloads`).
 """
 from __future__ import annotations
 
@@ -324,12 +327,12 @@ class Rank:
                 raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
             torch.cuda.set_device(self.local_rank)
             self.numa = bind_to_gpu_numa_node(torch, self.local_rank)
+        self.group = None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if self.dry:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            else:
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            from orb_slam3_amd import sharding
+            sharding.init_host_group(self.rank, self.world)   # gloo: the barrier and the gather are host-side, nothing but HIP on the GPUs
+            self.group = "gloo"
 
     def barrier(self, extractors=()):
         if not self.dry:
@@ -360,7 +363,9 @@ class Rank:
 
     def reduce(self, dt, units):
         from orb_slam3_amd import sharding
-        return sharding.reduce_throughput(dt, units, device=None if self.dry else "cuda")
+        dt_max, units_all, per = sharding.gather_throughput(dt, units)
+        self.per_rank = [{"rank": r, "seconds": round(t, 6), "kfeatures_per_s": round(u / t / 1e3, 2) if t > 0 else None} for r, (t, u) in enumerate(per)]
+        return dt_max, units_all
 
     def finish(self, out):
         if self.rank == 0:
@@ -374,7 +379,7 @@ def base_line(R, metric, value, dt_max, extra_cfg):
     return {"metric": metric, "value": round(value, 2), "unit": "kfeatures/s", "n_gpus": R.world, "steps": a.steps, "warmup": a.warmup,
             "settle_steps": a.settle,
             "ms_per_step": round(dt_max / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic", "config": extra_cfg}
+            "dtype": "u8", "data": "synthetic", "config": extra_cfg, "process_group": R.group, "per_rank": getattr(R, "per_rank", None)}
 
 
 def pinned(torch, shape, dtype):
@@ -474,19 +479,35 @@ def bench_euroc(R):
     last = host[(a.steps - 1) % 2]
     nmatch = int(last.nm[1:].sum())
     dt_max, feats_all = R.reduce(dt, feats)
+    per_rank = R.per_rank
 
     # ---- parity of the delivered results (last timed step) against the CPU oracle, rank 0 ----
     parity = None
     if R.rank == 0 and a.verify > 0:
         parity = verify_euroc(frames, last, a.verify, W, H, NF, ex)
 
+    # ---- the K timed steps again, `repeat` regions in all (each between its own barriers): spread of the number above ----
+    regions = [(dt_max, feats_all)]
+    for _ in range(max(a.repeat, 1) - 1):
+        t0 = R.timed_begin([ex])
+        f_r = run(a.steps, False)
+        regions.append(R.reduce(R.timed_end(t0, [ex]), f_r))
+    R.per_rank = per_rank
+    ms = sorted(t / a.steps * 1e3 for t, _ in regions)
+    vals = sorted(f / t / 1e3 for t, f in regions)
+    repeats = {"regions": len(regions), "steps_per_region": a.steps,
+               "ms_per_step": {"median": round(float(np.median(ms)), 3), "min": round(ms[0], 3), "max": round(ms[-1], 3)},
+               "value": {"median": round(float(np.median(vals)), 2), "min": round(vals[0], 2), "max": round(vals[-1], 2)},
+               "note": "`value` / `ms_per_step` of the line are the FIRST region (exactly K steps after W warm-up steps); the others follow back to back"}
+
     # ---- the same loop with the frames starting in pinned host memory (upload inside the timed region) ----
     dt_h, feats_h = timed(True)
     dt_h_max, feats_h_all = R.reduce(dt_h, feats_h)
     if R.rank == 0 and a.verify > 0:
-        verify_euroc(frames, host[(a.steps - 1) % 2], min(a.verify, 2), W, H, NF, ex)   # the host-input path delivers the same results
+        pcie_parity = verify_euroc(frames, host[(a.steps - 1) % 2], a.verify, W, H, NF, ex)   # the host-input path delivers the same results
     pcie = {"value": round(feats_h_all / dt_h_max / 1e3, 2), "unit": "kfeatures/s", "ms_per_step": round(dt_h_max / a.steps * 1e3, 3),
             "h2d_bytes_per_step": int(B * W * H), "h2d_GBs": round(B * W * H / (dt_h_max / a.steps) / 1e9, 1), "host_affinity": R.numa,
+            "parity_checked": pcie_parity if (R.rank == 0 and a.verify > 0) else None,
             "note": "frames in pinned host memory; orbx_extract_batch_host uploads batch i+1 on its own stream while batch i computes"}
 
     # ---- per-kernel timing with HIP events on the extractor's stream (separate, untimed, serialized passes) ----
@@ -518,6 +539,16 @@ def bench_euroc(R):
     if R.rank == 0 and R.world == 1 and a.cpu_frames > 0:
         cpu = cpu_baseline_euroc(frames, a.cpu_frames, W, H, NF)
 
+    # ---- single-frame latency of the drop-in call (Tracking calls operator() once per frame: Frame.cc:418-425, ORBextractor.cc:1086) ----
+    latency = None
+    if R.rank == 0 and a.latency > 0:
+        latency = latency_euroc(osa, frames, a.latency, W, H, NF, LAP, R.local_rank, cpu)
+
+    # ---- BASELINE configs 3 and 4 in the same line (1 GPU): child processes of this file, own parity checks, no CPU / PMC legs ----
+    others = None
+    if R.rank == 0 and R.world == 1 and a.other_workloads:
+        others = {wl: other_workload_child(wl, a) for wl in ("kitti", "tumvi")}
+
     out = base_line(R, "ORB kfeatures/sec extract+match, EuRoC 752x480 nFeatures=1000", feats_all / dt_max / 1e3, dt_max,
                     {"workload": "EuRoC-shaped 752x480 mono, nFeatures=1000, 8 levels, scale 1.2, FAST 20/7: extract + frame-to-frame "
                                  "SearchByProjection(th=15) + D2H of results; inputs resident in HBM",
@@ -525,23 +556,79 @@ def bench_euroc(R):
                      "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{R.world} independent sequences, one per GPU"})
     out["data"] = data
     out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels,
-                "host_enqueue_ms_per_step": round(enqueue_ms, 3), "settle_ms_per_step": round(settle_ms, 3)})
+                "host_enqueue_ms_per_step": round(enqueue_ms, 3), "settle_ms_per_step": round(settle_ms, 3),
+                "repeats": repeats, "latency": latency, "other_workloads": others,
+                "value_pcie_inclusive": pcie["value"],
+                "metric_definition_note": "`value` = features delivered to pinned host memory per second with the input frames already resident in HBM "
+                                          "when the timed region starts (the bench contract); SURVEY.md 8(d)'s wall clock covering H2D of the images "
+                                          "... D2H of the results is `value_pcie_inclusive` (= pcie_inclusive.value: frames start in pinned host "
+                                          "memory, the upload of batch i+1 overlaps batch i; bound by the PCIe link, see pcie_inclusive.h2d_GBs)"})
     R.finish(out)
 
 
+def latency_euroc(osa, frames, n_calls, W, H, NF, LAP, device, cpu):
+    """orbx_extract one frame at a time on a fresh extractor: host image in, keypoints + descriptors out (synchronous: H2D, every kernel
+    of the extraction at batch size 1, D2H), the way Frame::ExtractORB calls the reference."""
+    ex1 = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=device)
+    for i in range(20):
+        ex1(frames[i % len(frames)], None, LAP)
+    ts = []
+    for i in range(n_calls):
+        t0 = time.perf_counter()
+        ex1(frames[i % len(frames)], None, LAP)
+        ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e3
+    out = {"call": "ORBextractor::operator() (orbx_extract), one 752x480 frame per call, host image in, host results out",
+           "calls": n_calls, "median_ms": round(float(np.median(ts)), 3), "p90_ms": round(float(np.percentile(ts, 90)), 3),
+           "min_ms": round(float(ts.min()), 3), "frames_per_s": round(1e3 / float(np.median(ts)), 1)}
+    if cpu and cpu.get("value"):
+        out["cpu_oracle_ms_per_frame"] = round(1000.0 / cpu["value"], 3)   # kfeatures/s at ~1000 features per frame (extract + match, 1 thread)
+    return out
+
+
+def other_workload_child(wl, a):
+    """`python bench.py --workload wl` (same K / W, parity check on, no CPU baseline, no PMC pass) as a child process; the fields a reader of
+    the euroc line needs."""
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", wl, "--steps", str(a.steps), "--warmup", str(a.warmup), "--cpu-frames", "0",
+           "--no-pmc", "--gpus", "1"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ORBX_BENCH_RANK_PROCESS"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=420)
+        line = next((l for l in reversed(r.stdout.strip().splitlines()) if l.startswith("{")), None)
+        if r.returncode != 0 or not line:
+            return {"error": f"child exit {r.returncode}: {r.stderr[-300:]}"}
+        d = json.loads(line)
+        rf = d.get("roofline") or {}
+        return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+                "config": d["config"], "parity_checked": d.get("parity_checked"),
+                "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "frac", "extract_all_kernels_frac")}, "data": d.get("data")}
+    except Exception as e:   # the euroc line stands on its own
+        return {"error": str(e)[:300]}
+
+
 def verify_euroc(frames, hs, n_check, W, H, NF, ex):
-    """Compare delivered keypoints / descriptors of sampled frames and the match vectors of sampled consecutive pairs with
-    the CPU oracle (bit-exact).  Raises on any difference."""
+    """Compare the delivered keypoints / descriptors of frames and the match vectors of consecutive pairs with the CPU oracle (bit-exact).
+    n_check >= 4 (the default): EVERY frame and EVERY pair of the step, the oracle frame-parallel on the host cores (ctypes releases the
+    GIL); smaller values sample.  Raises on any difference."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_binding as ob
     B = len(frames)
-    oex = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
-    sf = oex.tables()["scale"]
-    starts = sorted(set(int(x) for x in np.linspace(0, B - 2, n_check)))
-    checked = {"frames": 0, "match_pairs": 0}
-    for s in starts:
-        outs = []
-        for f in (s, s + 1):
-            mono, k, d = oex.extract(frames[f], lap=(0, 1000))
+    full = n_check >= 4
+    fset = list(range(B)) if full else sorted(set(f for s0 in np.linspace(0, B - 2, n_check) for f in (int(s0), int(s0) + 1)))
+    pairs = list(range(B - 1)) if full else sorted(set(int(s0) for s0 in np.linspace(0, B - 2, n_check)))
+    sf = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA).tables()["scale"]
+    nthreads = max(1, min(os.cpu_count() or 1, 64, len(fset)))
+
+    def extract_chunk(fs):
+        oex = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+        return [(f,) + tuple(oex.extract(frames[f], lap=(0, 1000))) for f in fs]
+
+    with ThreadPoolExecutor(nthreads) as pool:
+        res = {f: (mono, k, d) for chunk in pool.map(extract_chunk, [fset[i::nthreads] for i in range(nthreads)]) for f, mono, k, d in chunk}
+        for f in fset:
+            mono, k, d = res[f]
             n = int(hs.cnt[f])
             if n != len(k) or int(hs.mono[f]) != mono:
                 raise SystemExit(f"PARITY FAILURE: frame {f}: {n} keypoints / mono {int(hs.mono[f])}, oracle {len(k)} / {mono}")
@@ -549,17 +636,19 @@ def verify_euroc(frames, hs, n_check, W, H, NF, ex):
                 raise SystemExit(f"PARITY FAILURE: frame {f}: keypoints differ from the oracle")
             if not np.array_equal(hs.desc[f, :n].numpy(), d):
                 raise SystemExit(f"PARITY FAILURE: frame {f}: descriptors differ from the oracle")
-            outs.append((k, d))
-            checked["frames"] += 1
-        (k0, d0), (k1, d1) = outs
-        q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
-                 desc=d0, has_obs=np.ones(len(k0), np.uint8))
-        grid = ob.OracleGrid(k1, 0.0, float(W), 0.0, float(H))
-        on, ocm = ob.search_by_projection_frame(grid, d1, sf, q, 15.0, 0, True, None, None)
-        if int(hs.nm[s + 1]) != on or not np.array_equal(hs.match[s + 1, :len(k1)].numpy(), ocm):
-            raise SystemExit(f"PARITY FAILURE: match vector of frame pair ({s}, {s + 1}) differs from the oracle")
-        checked["match_pairs"] += 1
-    return checked
+
+        def match_pair(s0):
+            (_, k0, d0), (_, k1, d1) = res[s0], res[s0 + 1]
+            q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
+                     desc=d0, has_obs=np.ones(len(k0), np.uint8))
+            grid = ob.OracleGrid(k1, 0.0, float(W), 0.0, float(H))
+            on, ocm = ob.search_by_projection_frame(grid, d1, sf, q, 15.0, 0, True, None, None)
+            return s0, on, ocm, len(k1)
+
+        for s0, on, ocm, n1 in pool.map(match_pair, pairs):
+            if int(hs.nm[s0 + 1]) != on or not np.array_equal(hs.match[s0 + 1, :n1].numpy(), ocm):
+                raise SystemExit(f"PARITY FAILURE: match vector of frame pair ({s0}, {s0 + 1}) differs from the oracle")
+    return {"frames": len(fset), "match_pairs": len(pairs), "of_frames": B, "oracle_threads": nthreads}
 
 
 def bench_kitti(R):
@@ -867,8 +956,14 @@ def main():
                          "(TUM-VI workload, warm-up 3: 1.29-1.31 ms per step; warm-up 10: 1.07)")
     ap.add_argument("--batch", type=int, default=0, help="frames (stereo pairs) per step per GPU; 0 = the workload's default (256 / 64 / 32)")
     ap.add_argument("--cpu-frames", type=int, default=384, help="frames in the CPU baseline sample (0 = skip); 384 = about 13 s of one core for euroc")
-    ap.add_argument("--verify", type=int, default=4, help="frame pairs of the last timed step checked against the CPU oracle on rank 0 (0 = skip)")
+    ap.add_argument("--verify", type=int, default=4, help="parity of the last timed step against the CPU oracle on rank 0: >= 4 = every frame and every "
+                                                          "match vector of the step (euroc), 1-3 = that many sampled pairs, 0 = skip")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--repeat", type=int, default=5, help="timed regions of K steps each (the line's value is the first; `repeats` reports median / min / max)")
+    ap.add_argument("--latency", type=int, default=200, help="single-frame orbx_extract calls timed for the `latency` block (0 = skip)")
+    ap.add_argument("--other-workloads", dest="other_workloads", action="store_true", default=None,
+                    help="also run the kitti and tumvi workloads as child processes and embed their results (default for the euroc workload at --gpus 1)")
+    ap.add_argument("--no-other-workloads", dest="other_workloads", action="store_false")
     ap.add_argument("--pmc", dest="pmc", action="store_true", default=True,
                     help="measure roofline.traffic in this run: two extra rocprofv3 --pmc child passes of a few steps, about 40 s (default at --gpus 1)")
     ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
@@ -877,6 +972,8 @@ def main():
                     help="euroc = BASELINE metric config; kitti = config 3 (stereo); tumvi = config 4 (map-point projection search)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.other_workloads is None:
+        args.other_workloads = args.workload == "euroc" and args.cpu_frames > 0 and not args.no_profile   # the full default run only
     if args.pmc_child:
         return pmc_child(args)
 

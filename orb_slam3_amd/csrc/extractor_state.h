@@ -120,7 +120,7 @@ struct orbx_extractor {
     size_t fast_wave_lds = 0;   // k_fast_wave
     int fast_ini_qcap = 640, fast_ini_gcap = 16;   // k_fast_ini: pixel queue / group queue capacities
     bool fast_strip = false;    // k_fast_strip applies (cells at most 57 px wide, 63 px high)
-    int n_strips = 0, strip_rows = 0, strip_gcap = 384, strip_qcap = 512;   // k_fast_strip: strips per frame, tile rows, per-wave group / pixel queue capacities
+    int n_strips = 0, strip_rows = 0, n_strips_main = 0, strip_rows_main = 0, strip_gcap = 512, strip_qcap = 816;   // k_fast_strip: strips per frame, tile rows, per-wave group / pixel queue capacities
     int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qcap = 768, fast_wave_qfull = 16;   // LDS tile pitch (48 / 64), max sub-image rows, queue capacity
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)

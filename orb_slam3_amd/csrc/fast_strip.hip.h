@@ -47,7 +47,8 @@ struct StripTile {   // one strip, precomputed per geometry (48 bytes, scalar lo
 };
 static_assert(sizeof(StripTile) == 48, "StripTile layout");
 
-__host__ __device__ inline size_t fast_strip_wave_bytes(int gcap, int qcap) { return ((size_t)gcap * 2 + (size_t)qcap * 3 + 15) & ~(size_t)15; }
+// per wave: group queue u16[gcap] (dead after stage B: the scores u8[qcap] of the pixel queue reuse its bytes, qcap <= 2 gcap) | pixel queue u16[qcap]
+__host__ __device__ inline size_t fast_strip_wave_bytes(int gcap, int qcap) { return ((size_t)gcap * 2 + (size_t)qcap * 2 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t fast_strip_lds_bytes(int max_rows, int gcap, int qcap) {
     return (size_t)max_rows * kStripPitch + kStripWaves * fast_strip_wave_bytes(gcap, qcap) + (kStripWaves * kStripMaxCells + 4) * sizeof(int32_t);
 }
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_fast_strip(const StripTile
     uint8_t *wbase = smem + (size_t)max_rows * P + (size_t)wave * fast_strip_wave_bytes(gcap, qcap);
     uint16_t *gq = reinterpret_cast<uint16_t *>(wbase);          // group queue
     uint16_t *pq = gq + gcap;                                     // pixel queue -> corners -> survivors (compacted in place)
-    uint8_t *ps = reinterpret_cast<uint8_t *>(pq + qcap);         // score per pixel-queue entry
+    uint8_t *ps = reinterpret_cast<uint8_t *>(gq);                // score per pixel-queue entry, written when the group queue is dead
     int32_t *cnt = reinterpret_cast<int32_t *>(smem + (size_t)max_rows * P + W * fast_strip_wave_bytes(gcap, qcap));   // [W][8] survivors per (wave, cell)
     int32_t *ovf = cnt + W * kStripMaxCells;
     if (threadIdx.x == 0) *ovf = 0;

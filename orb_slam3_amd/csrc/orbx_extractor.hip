@@ -316,10 +316,23 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     { const char *v = getenv("ORBX_FAST_STRIP"); if (v && v[0] == '0') ex->fast_strip = false; }   // TEMPORARY (A/B visit): the per-cell k_fast_ini
     { const char *v = getenv("ORBX_STRIP_GCAP"); if (v && atoi(v) >= 64) ex->strip_gcap = atoi(v) & ~7; }   // TEMPORARY (A/B visit)
     { const char *v = getenv("ORBX_STRIP_QCAP"); if (v && atoi(v) >= 64) ex->strip_qcap = atoi(v) & ~15; }  // TEMPORARY (A/B visit)
+    // Two launches: the LDS of a workgroup is sized for the tallest strip of its launch, and the few tall strips of the small top levels
+    // (cells of up to 63 rows where a level has two or three cell rows) would cost every workgroup an occupancy step.  Main launch = the
+    // shortest row count that covers 85 % of the strips; the rest follow in a second launch.
+    {
+        std::stable_sort(strips.begin(), strips.end(), [](const StripTile &a, const StripTile &b) { return a.ih < b.ih; });
+        const size_t n85 = (strips.size() * 85 + 99) / 100;
+        const int ih_main = strips.empty() ? 0 : strips[std::min(n85, strips.size()) - 1].ih;
+        size_t n_main = 0;
+        while (n_main < strips.size() && strips[n_main].ih <= ih_main) n_main++;
+        ex->n_strips_main = (int)n_main; ex->strip_rows_main = ih_main + 6;
+        if (!strips.empty()) ORBX_HIP(hipMemcpy(ex->d_strips.p, strips.data(), sizeof(StripTile) * strips.size(), hipMemcpyHostToDevice));
+    }
     ex->n_strips = (int)strips.size(); ex->strip_rows = strip_rows;
+    if (ex->strip_qcap > 2 * ex->strip_gcap) ex->strip_gcap = (ex->strip_qcap / 2 + 7) & ~7;   // the scores reuse the group queue's bytes
     if (getenv("ORBX_DEBUG_ALLOC"))
-        fprintf(stderr, "[orbx fast] %s: %d strips of up to %d rows per frame, %zu cells, LDS %zu B per workgroup\n", ex->fast_strip ? "k_fast_strip" : "per-cell kernels",
-                ex->n_strips, strip_rows, fast_tiles.size(), fast_strip_lds_bytes(strip_rows, ex->strip_gcap, ex->strip_qcap));
+        fprintf(stderr, "[orbx fast] %s: %d strips of up to %d rows per frame (main launch: %d of up to %d rows), %zu cells, LDS %zu B per workgroup of the main launch\n", ex->fast_strip ? "k_fast_strip" : "per-cell kernels",
+                ex->n_strips, strip_rows, ex->n_strips_main, ex->strip_rows_main, fast_tiles.size(), fast_strip_lds_bytes(ex->strip_rows_main, ex->strip_gcap, ex->strip_qcap));
     ex->fast_wave_pitch = (fast_wave_maxw + 7 <= 48) ? 48 : 64;
     ex->fast_wave_rows = fast_wave_rows;
     ex->fast_wave_qfull = fast_wave_qfull;
@@ -433,11 +446,14 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                 // (ini <= min: the second pass is a subset of the first, an empty cell stays empty)
                 const size_t lds = fast_strip_lds_bytes(ex->strip_rows, ex->strip_gcap, ex->strip_qcap);
                 static const bool pol = [] { const char *v = getenv("ORBX_FAST_POL"); return !(v && v[0] == '0'); }();   // TEMPORARY (A/B visit)
-#define ORBX_FAST_STRIP(POL)                                                                                                                  \
-    hipLaunchKernelGGL(k_fast_strip<POL>, xcd_grid(ex->n_strips, n), dim3(64 * kStripWaves), lds, st, (const StripTile *)ex->d_strips.p,         \
-                       (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p,          \
-                       ex->cand_frame, ini, ex->strip_rows, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count, ini > mn ? 1 : 0, n)
-                if (pol) ORBX_FAST_STRIP(true); else ORBX_FAST_STRIP(false);
+#define ORBX_FAST_STRIP(POL, FIRST, COUNT, ROWS)                                                                                              \
+    hipLaunchKernelGGL(k_fast_strip<POL>, xcd_grid(COUNT, n), dim3(64 * kStripWaves), fast_strip_lds_bytes(ROWS, ex->strip_gcap, ex->strip_qcap), \
+                       st, (const StripTile *)ex->d_strips.p + (FIRST), (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,        \
+                       ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ROWS, ex->strip_gcap, ex->strip_qcap, ovf_list,       \
+                       ovf_count, ini > mn ? 1 : 0, n)
+                const int n_tall = ex->n_strips - ex->n_strips_main;
+                if (pol) ORBX_FAST_STRIP(true, 0, ex->n_strips_main, ex->strip_rows_main); else ORBX_FAST_STRIP(false, 0, ex->n_strips_main, ex->strip_rows_main);
+                if (n_tall > 0) { if (pol) ORBX_FAST_STRIP(true, ex->n_strips_main, n_tall, ex->strip_rows); else ORBX_FAST_STRIP(false, ex->n_strips_main, n_tall, ex->strip_rows); }
 #undef ORBX_FAST_STRIP
             } else if (ini > mn) {
                 // first pass of :826 for every cell (k_fast_ini); cells it leaves empty go to the list pass below

@@ -18,14 +18,17 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     from orb_slam3_amd import sharding
+    sharding.init_host_group(rank, world)   # what bench.py's Rank uses for the GPU run as well: gloo, no communicator on the devices
+    assert dist.get_backend() == "gloo"
     seqs = sharding.sequences_for_rank(8, world, rank)
     # pretend each sequence takes (1 + rank) seconds and yields 1000 features per frame over 10 frames
     local_t = float(len(seqs)) * (1 + rank)
     local_u = float(len(seqs)) * 10 * 1000
     dist.barrier()
     t, u = sharding.reduce_throughput(local_t, local_u)
+    t2, u2, per = sharding.gather_throughput(local_t, local_u)
+    assert (t2, u2) == (t, u) and per == [(4.0, 40000.0), (8.0, 40000.0)]   # every rank's (seconds, units): a straggler is visible
     q.put((rank, seqs, t, u))
     dist.destroy_process_group()
 
@@ -72,6 +75,7 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 2 and out["config"]["sequences"] == 2 and out["attempts"] == 1
+    assert out["process_group"] == "gloo" and [p["rank"] for p in out["per_rank"]] == [0, 1]
     # rank r reports 1000 * steps * (r + 1) units: the sum over both ranks arrived on rank 0
     assert abs(out["value"] * out["ms_per_step"] * 3 / 1e3 * 1e3 - 9000.0) < 9000.0 * 0.02
 
@@ -92,3 +96,16 @@ def test_bench_reports_failed_attempts(tmp_path):
     import json
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["attempts"] == 2 and len(out["failed_attempts"]) == 1
+
+
+def test_gpu_ranks_use_the_host_process_group_only():
+    """The non-dry rank path creates its process group through sharding.init_host_group (gloo) and nothing else: no "nccl" backend, no
+    device tensors in the barrier / reduction -- `bench.py --gpus 8` needs nothing but HIP on the GPUs."""
+    import re
+    from pathlib import Path
+    src = (Path(__file__).resolve().parent.parent / "bench.py").read_text()
+    rank_cls = src[src.index("class Rank:"):src.index("def base_line(")]
+    assert "init_host_group" in rank_cls and "init_process_group" not in rank_cls
+    assert not re.search(r"[\"']nccl[\"']", src)
+    sh = (Path(__file__).resolve().parent.parent / "orb_slam3_amd" / "sharding.py").read_text()
+    assert 'init_process_group("gloo"' in sh and "cuda" not in sh.split("def gather_throughput")[1].split("def reduce_throughput")[0]
