@@ -227,6 +227,95 @@ __global__ __launch_bounds__(256) void k_pyr_resize2(const LevelInfo L, const Le
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_pyr_resize_march (round 3): the same bilinear arithmetic, register-marching.  k_pyr_resize2 spends a table round trip (64 B of
+// ResizeGroup + row taps per 16 output bytes), then a source round trip, then the store, per thread, and moves 2.2 TB/s whatever is
+// done to its instruction count.  Here a lane owns one dword column (4 output pixels) of a block of RB output rows
+// and walks down it: the column's ResizeGroup is loaded ONCE, the row taps are wave-uniform scalar loads, the source rows of the block
+// are streamed in order (every source row is read once per block and its horizontal pass computed once -- an output row pair shares
+// it: 1.2 instead of 2 source rows per output row at scale 1.2), CH rows in flight while the previous CH are filtered, and a wave
+// stores 256 contiguous bytes per row.  The 19 ring rows above / below the ROI are REFLECT_101 copies of ROI rows 1..19 / h-2..h-20
+// (copyMakeBorder of the level itself, ORBextractor.cc:1185-1186): the wave that produces such a row stores it twice.
+// Needs every tap pair of a dword column within 8 source bytes (scale factor <= 2); k_pyr_resize2 stays for the other case.
+// grid xcd_grid(ceil(nstrips * ceil(h / RB) / 4), B), block 256 (four independent waves)
+// ---------------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256) void k_pyr_resize_march(const LevelInfo L, const LevelInfo P, const ResizeTap *__restrict__ ytab,
+                                                          const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                          int rb_rows, int nstrips, uint32_t nstrips_rcp, int n_items, int n_frames) {
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = bx * 4 + wave;
+    if (item >= n_items) return;
+    const int rb = nstrips == 1 ? item : __builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)item, nstrips_rcp)), cs = item - rb * nstrips;   // ceil(2^32 / 1) does not fit
+    const int ncol = L.pitch >> 2;
+    const int col = cs * 64 + lane;
+    const bool live = col < ncol;
+    const uint4 *gp = reinterpret_cast<const uint4 *>(&xg[L.xg_off + min(col, ncol - 1)]);
+    const uint4 gh = gp[0], gc = gp[1];   // base, sel, valid, pad | cc[4]
+    uint8_t *frame = pyr + (size_t)f * pyr_frame_stride;
+    const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX + (gh.z == 1 ? gh.x : 0u);   // this lane's first source byte of row 0
+    uint8_t *dcol = frame + L.off + 4 * (uint32_t)col;
+    const uint32_t sel = gh.y, selr = gh.y + 0x01010101u;
+    const uint32_t cc[4] = {gc.x, gc.y, gc.z, gc.w};
+    constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
+    const int y0 = rb * rb_rows, y1 = min(y0 + rb_rows, L.h);
+    const ResizeTap *yt = ytab + L.ytab_off;
+    int r = y0;
+    ResizeTap ty = yt[r], tyn = yt[min(r + 1, L.h - 1)];
+    int s = ty.ofs;                                   // next source row to fetch
+    const int s_last = yt[y1 - 1].ofs + 1;            // last source row the block needs
+    const int hmax = P.h - 1;
+    uint2 cur[CH], nxt[CH];
+    uint32_t Hp[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < CH; k++) __builtin_memcpy(&cur[k], proi + (size_t)(uint32_t)(min(s + k, hmax) * P.pitch), 8);
+    while (r < y1) {
+        if (s + CH <= s_last) {   // wave-uniform: the next CH rows are requested before these are filtered
+#pragma unroll
+            for (int k = 0; k < CH; k++) __builtin_memcpy(&nxt[k], proi + (size_t)(uint32_t)(min(s + CH + k, hmax) * P.pitch), 8);
+        }
+        uint32_t H[CH][4];   // horizontal pass of the chunk's rows, already >> 4 ([OCV] the vertical pass multiplies (sum >> 4))
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const uint32_t l = __builtin_amdgcn_perm(cur[k].y, cur[k].x, sel), q = __builtin_amdgcn_perm(cur[k].y, cur[k].x, selr);
+#pragma unroll
+            for (int j = 0; j < 4; j++) H[k][j] = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q, l, kPair[j])), as_pk(cc[j]), 0u, false) >> 4;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            // the output row whose source rows are (s + k - 1, s + k), if there is one (at most one: the scale factor is >= 1)
+            if (r < y1 && ty.ofs + 1 == s + k) {   // wave-uniform
+                const uint32_t *A = k == 0 ? Hp : H[k == 0 ? 0 : k - 1], *B = H[k];
+                const uint32_t b0 = (uint32_t)ty.c0, b1 = (uint32_t)ty.c1;
+                int t[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t p0 = __umul24(A[j], b0) + 0x20000u, p1 = __umul24(B[j], b1);
+                    t[j] = (int)((p0 >> 16) + (p1 >> 16));
+                }
+                uint32_t o = ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 2)) | ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 2) << 16);
+                if (gh.z != 1) o = 0u;   // pitch padding outside the ring
+                if (live) {
+                    *reinterpret_cast<uint32_t *>(dcol + (size_t)(uint32_t)((kEdge + r) * L.pitch)) = o;
+                    if (r >= 1 && r <= kEdge) *reinterpret_cast<uint32_t *>(dcol + (size_t)(uint32_t)((kEdge - r) * L.pitch)) = o;                              // ring above
+                    if (r <= L.h - 2 && r >= L.h - 1 - kEdge) *reinterpret_cast<uint32_t *>(dcol + (size_t)(uint32_t)((kEdge + 2 * (L.h - 1) - r) * L.pitch)) = o;   // ring below
+                }
+                r++;
+                ty = tyn;
+                tyn = yt[min(r + 1, L.h - 1)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) Hp[j] = H[CH - 1][j];
+#pragma unroll
+        for (int k = 0; k < CH; k++) cur[k] = nxt[k];
+        s += CH;
+        if (s > s_last + CH) break;   // cannot happen with monotone row taps; never spin on a bad table
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // FAST-9/16 corner score of one pixel.  [OCV] cornerScore<16>: with d[k] = v - p[k] on the Bresenham circle,
 //   score = max( max_arcs min(d over 9 contiguous), max_arcs min(-d over 9 contiguous) ) - 1
 // and "p is a corner at threshold t"  <=>  score >= t  (SURVEY.md 8c-R2).

@@ -119,6 +119,7 @@ struct orbx_extractor {
     size_t fast_lds = 0;
     size_t fast_wave_lds = 0;   // k_fast_wave
     int fast_ini_qcap = 640, fast_ini_gcap = 16;   // k_fast_ini: pixel queue / group queue capacities
+    bool resize_march_ok[orbx::kMaxLevels] = {};   // every tap pair of a dword column of level l within 8 source bytes (k_pyr_resize_march)
     bool fast_strip = false;    // k_fast_strip applies (cells at most 57 px wide, 63 px high)
     int n_strips = 0, strip_rows = 0, n_strips_main = 0, strip_rows_main = 0, strip_gcap = 512, strip_qcap = 816;   // k_fast_strip: strips per frame, tile rows, per-wave group / pixel queue capacities
     int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qcap = 768, fast_wave_qfull = 16;   // LDS tile pitch (48 / 64), max sub-image rows, queue capacity

@@ -29,7 +29,6 @@
 namespace orbx {
 
 constexpr int kStripPitch = 272;   // LDS bytes per tile row: 4 + 256 interior + 4, rounded up to 16
-constexpr int kStripWaves = 4;
 constexpr int kStripMaxCells = 8;  // floor(256 / 35) = 7 cells at most
 
 struct StripTile {   // one strip, precomputed per geometry (48 bytes, scalar loads)
@@ -49,55 +48,18 @@ static_assert(sizeof(StripTile) == 48, "StripTile layout");
 
 // per wave: group queue u16[gcap] (dead after stage B: the scores u8[qcap] of the pixel queue reuse its bytes, qcap <= 2 gcap) | pixel queue u16[qcap]
 __host__ __device__ inline size_t fast_strip_wave_bytes(int gcap, int qcap) { return ((size_t)gcap * 2 + (size_t)qcap * 2 + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t fast_strip_lds_bytes(int max_rows, int gcap, int qcap) {
-    return (size_t)max_rows * kStripPitch + kStripWaves * fast_strip_wave_bytes(gcap, qcap) + (kStripWaves * kStripMaxCells + 4) * sizeof(int32_t);
+__host__ __device__ inline size_t fast_strip_lds_bytes(int waves, int max_rows, int gcap, int qcap) {
+    return (size_t)max_rows * kStripPitch + waves * fast_strip_wave_bytes(gcap, qcap) + (waves * kStripMaxCells + 4) * sizeof(int32_t);
 }
 
-// The four-pair test with the two polarities apart: *fb nonzero halves = pixels that can be BRIGHT corners at t (in every antipodal pair
-// one pixel is above centre + t), *fd = DARK.  A 9-arc of one polarity needs its pixel in every pair.
-__device__ __forceinline__ void quick_pairs_pol(u16x2 c, u16x2 p0, u16x2 p8, u16x2 p4, u16x2 p12, u16x2 p2, u16x2 p10, u16x2 p6, u16x2 p14, u16x2 t2,
-                                                uint32_t *fb, uint32_t *fd) {
-    const u16x2 mb = pk_min(pk_min(pk_max(p0, p8), pk_max(p4, p12)), pk_min(pk_max(p2, p10), pk_max(p6, p14)));
-    const u16x2 md = pk_max(pk_max(pk_min(p0, p8), pk_min(p4, p12)), pk_max(pk_min(p2, p10), pk_min(p6, p14)));
-    const u16x2 hi = c + t2;
-    const u16x2 lo = __builtin_elementwise_sub_sat(c, t2);
-    *fb = as_u32(__builtin_elementwise_sub_sat(mb, hi));
-    *fd = as_u32(__builtin_elementwise_sub_sat(lo, md));
-}
-
-// cornerScore of one polarity: m = 0 the bright side, max over the arcs of min9(p) - v - 1; m = 0xff the dark side, v - min over the arcs of
-// max9(p) - 1, evaluated as the bright side of the inverted pixels (255 - p = p ^ 0xff).  For a pixel whose quick test allows only this
-// polarity the other side of [OCV] cornerScore<16> is below the threshold, so "score >= t" and the score of every corner are unchanged
-// (40 instead of 80 three-input min / max per pixel).
-__device__ __forceinline__ int fast_score16_pol(const uint8_t *__restrict__ c, int pp, int m) {
-    const int v = c[0] ^ m;
-    int p[16];
-    p[0] = c[3 * pp]; p[1] = c[3 * pp + 1]; p[2] = c[2 * pp + 2]; p[3] = c[pp + 3]; p[4] = c[3]; p[5] = c[-pp + 3]; p[6] = c[-2 * pp + 2];
-    p[7] = c[-3 * pp + 1]; p[8] = c[-3 * pp]; p[9] = c[-3 * pp - 1]; p[10] = c[-2 * pp - 2]; p[11] = c[-pp - 3]; p[12] = c[-3];
-    p[13] = c[pp - 3]; p[14] = c[2 * pp - 2]; p[15] = c[3 * pp - 1];
-#pragma unroll
-    for (int k = 0; k < 16; k++) p[k] ^= m;
-    int lo3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) lo3[k] = min3i(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
-    int maxmin = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-        const int a0 = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);          // min over p[k..k+8]
-        const int a1 = min3i(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]);
-        maxmin = max3i(maxmin, a0, a1);
-    }
-    return maxmin - v - 1;
-}
-
-template <bool POL>   // polarity-split scores (one-sided arcs)
-__global__ __launch_bounds__(64 * kStripWaves) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
+template <int W>   // waves per workgroup = row bands per strip
+__global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
                                                                  size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
                                                                  uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
                                                                  int max_rows, int gcap, int qcap, uint32_t *__restrict__ list,
                                                                  int32_t *__restrict__ list_count, int second_pass, int n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int P = kStripPitch, D = P / 4, W = kStripWaves;
+    constexpr int P = kStripPitch, D = P / 4;
     int tile, f;
     if (!xcd_frame_map(n_frames, &tile, &f)) return;   // a frame's strips stay on one XCD (apron rows hit its L2)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -121,23 +83,25 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_fast_strip(const StripTile
         const int nbytes = (rows - 1) * spitch + 4 * nd;
         const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)ahi << 32) | alo), 0, nbytes, 0x00020000);
         const int oob = 0x40000000;
-        const int voff = (lane < nd ? 0 : oob) + wave * spitch + 4 * lane;
-        uint32_t v[12];
+        const int voff = (lane < nd ? 0 : oob) + 4 * lane;
+        for (int rb = wave; rb < rows; rb += 16 * W) {   // 16 rows of this wave in flight at once (rows past the tile: out of range, no access)
+            uint32_t v[16];
 #pragma unroll
-        for (int k = 0; k < 12; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, voff + W * k * spitch, 0, 0);   // rows past the tile: out of range
-        // dwords 64, 65 of rows wave + 4 * (lane >> 1)
-        const int xr = wave + W * (lane >> 1), xd = 64 + (lane & 1);
-        const bool xlive = xd < nd && xr < rows;
-        const uint32_t xv = __builtin_amdgcn_raw_buffer_load_b32(srd, (xlive ? 0 : oob) + xr * spitch + 4 * xd, 0, 0);
-        uint8_t *d = pix + wave * P + 4 * lane;
-        if (lane < nd) {
+            for (int k = 0; k < 16; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, voff + (rb + W * k) * spitch, 0, 0);
+            if (lane < nd) {
+                uint8_t *d = pix + rb * P + 4 * lane;
 #pragma unroll
-            for (int k = 0; k < 12; k++)
-                if (wave + W * k < rows) *reinterpret_cast<uint32_t *>(d + W * k * P) = v[k];
-            for (int r = wave + 12 * W; r < rows; r += W)   // strips taller than 48 rows
-                *reinterpret_cast<uint32_t *>(pix + r * P + 4 * lane) = __builtin_amdgcn_raw_buffer_load_b32(srd, r * spitch + 4 * lane, 0, 0);
+                for (int k = 0; k < 16; k++)
+                    if (rb + W * k < rows) *reinterpret_cast<uint32_t *>(d + W * k * P) = v[k];
+            }
         }
-        if (xlive) *reinterpret_cast<uint32_t *>(pix + xr * P + 4 * xd) = xv;
+        if (nd > 64)   // dwords 64, 65 of rows wave + W * (lane >> 1) [+ 32 W, ...]
+            for (int xb = wave; xb < rows; xb += 32 * W) {
+                const int xr = xb + W * (lane >> 1), xd = 64 + (lane & 1);
+                const bool xlive = xd < nd && xr < rows;
+                const uint32_t xv = __builtin_amdgcn_raw_buffer_load_b32(srd, (xlive ? 0 : oob) + xr * spitch + 4 * xd, 0, 0);
+                if (xlive) *reinterpret_cast<uint32_t *>(pix + xr * P + 4 * xd) = xv;
+            }
     }
     __syncthreads();
 
@@ -193,52 +157,24 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_fast_strip(const StripTile
             const uint32_t bL = A[5 * D - 1], bC = A[5 * D], bR = A[5 * D + 1];
 #define FS_EVEN(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(s) | ((uint32_t)((s) + 2) << 16)))
 #define FS_ODD(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)((s) + 1) | ((uint32_t)((s) + 3) << 16)))
-            if (!POL) {
-                const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), FS_EVEN(cR, cC, 3), FS_EVEN(cC, cL, 1), FS_EVEN(bR, bC, 2),
-                                                FS_EVEN(aC, aL, 2), FS_EVEN(aR, aC, 2), FS_EVEN(bC, bL, 2), t2);
-                const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), FS_ODD(cR, cC, 3), FS_ODD(cC, cL, 1), FS_ODD(bR, bC, 2),
-                                                FS_ODD(aC, aL, 2), FS_ODD(aR, aC, 2), FS_ODD(bC, bL, 2), t2);
-                uint32_t ze, zo;
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(ze) : "v"(fe), "v"(0x00010001u));
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zo) : "v"(fo), "v"(0x00010001u));
-                const uint32_t z = ze | (zo << 1);
-                const uint32_t m4 = (z | (z >> 14)) & vmask;
-                const int c = __popc(m4);
-                const int incl = wave_incl_scan(c);
-                int pos = qn + incl - c;
+            const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), FS_EVEN(cR, cC, 3), FS_EVEN(cC, cL, 1), FS_EVEN(bR, bC, 2),
+                                            FS_EVEN(aC, aL, 2), FS_EVEN(aR, aC, 2), FS_EVEN(bC, bL, 2), t2);
+            const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), FS_ODD(cR, cC, 3), FS_ODD(cC, cL, 1), FS_ODD(bR, bC, 2),
+                                            FS_ODD(aC, aL, 2), FS_ODD(aR, aC, 2), FS_ODD(bC, bL, 2), t2);
+            uint32_t ze, zo;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(ze) : "v"(fe), "v"(0x00010001u));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(zo) : "v"(fo), "v"(0x00010001u));
+            const uint32_t z = ze | (zo << 1);
+            const uint32_t m4 = (z | (z >> 14)) & vmask;
+            const int c = __popc(m4);
+            const int incl = wave_incl_scan(c);
+            int pos = qn + incl - c;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if ((m4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k);
-                    pos += (int)(m4 >> k & 1u);
-                }
-                qn += __builtin_amdgcn_readlane(incl, 63);
-            } else {
-                // the two polarities apart: a pixel that can only be a bright (dark) corner gets ONE queue entry with its polarity in bit
-                // 15, one that passes both tests (an edge through the centre, 9 % of the passing pixels) two, bright first
-                uint32_t fbe, fde, fbo, fdo;
-                quick_pairs_pol(pk_even(cC), pk_even(r0), pk_even(r8), FS_EVEN(cR, cC, 3), FS_EVEN(cC, cL, 1), FS_EVEN(bR, bC, 2),
-                                FS_EVEN(aC, aL, 2), FS_EVEN(aR, aC, 2), FS_EVEN(bC, bL, 2), t2, &fbe, &fde);
-                quick_pairs_pol(pk_odd(cC), pk_odd(r0), pk_odd(r8), FS_ODD(cR, cC, 3), FS_ODD(cC, cL, 1), FS_ODD(bR, bC, 2),
-                                FS_ODD(aC, aL, 2), FS_ODD(aR, aC, 2), FS_ODD(bC, bL, 2), t2, &fbo, &fdo);
-                uint32_t zbe, zbo, zde, zdo;
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zbe) : "v"(fbe), "v"(0x00010001u));
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zbo) : "v"(fbo), "v"(0x00010001u));
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zde) : "v"(fde), "v"(0x00010001u));
-                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zdo) : "v"(fdo), "v"(0x00010001u));
-                const uint32_t zb = zbe | (zbo << 1), zd = zde | (zdo << 1);
-                const uint32_t mb4 = (zb | (zb >> 14)) & vmask, md4 = (zd | (zd >> 14)) & vmask;
-                const int c = __popc(mb4) + __popc(md4);
-                const int incl = wave_incl_scan(c);
-                int pos = qn + incl - c;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if ((mb4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k);
-                    pos += (int)(mb4 >> k & 1u);
-                    if ((md4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k + 0x8000u);
-                    pos += (int)(md4 >> k & 1u);
-                }
-                qn += __builtin_amdgcn_readlane(incl, 63);
+            for (int k = 0; k < 4; k++) {
+                if ((m4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k);
+                pos += (int)(m4 >> k & 1u);
             }
+            qn += __builtin_amdgcn_readlane(incl, 63);
 #undef FS_EVEN
 #undef FS_ODD
         }
@@ -254,15 +190,14 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_fast_strip(const StripTile
             int s = -1, q = 0;
             if (e < qn) {
                 q = pq[e];
-                if (!POL) s = fast_score16(pix + ((q >> 8) + 3) * P + (q & 0xff) + 4, P);
-                else s = fast_score16_pol(pix + (((q >> 8) & 0x3f) + 3) * P + (q & 0xff) + 4, P, (q >> 15) ? 0xff : 0);
+                s = fast_score16(pix + ((q >> 8) + 3) * P + (q & 0xff) + 4, P);
             }
             const bool corner = s >= iniTh;
             const unsigned long long b = __ballot(corner);
             __builtin_amdgcn_wave_barrier();   // every lane has read its entry before any lane overwrites one (nc + rank <= e)
             if (corner) {
                 const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, (uint32_t)nc));
-                pq[o] = (uint16_t)(q & 0x3fff);
+                pq[o] = (uint16_t)q;
                 ps[o] = (uint8_t)s;
             }
             nc += __popcll(b);

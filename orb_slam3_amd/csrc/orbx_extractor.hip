@@ -77,7 +77,29 @@ using namespace orbx;
 
 namespace orbx {
 
+static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride, int lap0, int lap1,
+                           hipEvent_t ev_input_consumed = nullptr);
+static int configure_geometry(orbx_extractor *ex, int width, int height, int batch);
+
+// (Re)configuration + a few untimed passes of the whole extraction over blank frames: the first launches of a process pay for code-object
+// loading and for the HIP runtime's signal / command pools growing (the first ~10 batches of a fresh process enqueued 5x slower and ran
+// 2.2x slower: `settle_ms_per_step` in bench.py); paying it here keeps it out of the caller's first frames.
 static int configure(orbx_extractor *ex, int width, int height, int batch) {
+    const bool fresh = !(width == ex->width && height == ex->height && batch <= ex->batch_cap);
+    int r = configure_geometry(ex, width, height, batch);
+    static const int prime_k = [] { const char *v = getenv("ORBX_PRIME"); return v ? atoi(v) : 0; }();   // TEMPORARY (A/B visit)
+    if (r != ORBX_OK || !fresh || prime_k <= 0) return r;
+    const int n = std::min(ex->batch_cap, 8);
+    if ((r = ex->d_img.ensure((size_t)width * height * n)) != ORBX_OK) return r;   // zero-filled: blank frames, no keypoints
+    for (int i = 0; i < prime_k; i++)
+        if ((r = enqueue_extract(ex, (const uint8_t *)ex->d_img.p, n, (size_t)width, (size_t)width * height, 0, 0, nullptr)) != ORBX_OK) return r;
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->aux_stream));
+    ex->last_batch = 0;
+    return ORBX_OK;
+}
+
+static int configure_geometry(orbx_extractor *ex, int width, int height, int batch) {
     if (width > kMaxDim || height > kMaxDim) return ORBX_E_TOO_LARGE;
     const bool same_geom = (width == ex->width && height == ex->height);
     if (same_geom && batch <= ex->batch_cap) return ORBX_OK;
@@ -140,6 +162,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         L.scale = ex->scale[l];
         L.size = (float)(int)(kPatch * ex->scale[l]);  // :880
         // resize tables ([OCV] resize INTER_LINEAR 8U), from level l-1
+        ex->resize_march_ok[l] = true;
         L.xtab_off = (uint32_t)xtab.size();
         L.ytab_off = (uint32_t)ytab.size();
         if (l > 0) {
@@ -184,6 +207,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
                 else {
                     g.base = lo;
                     g.valid = (hi + 1 - lo <= 7) ? 1 : 0;
+                    if (!g.valid) ex->resize_march_ok[l] = false;
                     for (int k = 0; k < 4; k++) g.sel |= (uint32_t)(in[k] ? (ofs[k] - lo) & 7 : 0) << (8 * k);
                 }
                 xgtab.push_back(g);
@@ -332,7 +356,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (ex->strip_qcap > 2 * ex->strip_gcap) ex->strip_gcap = (ex->strip_qcap / 2 + 7) & ~7;   // the scores reuse the group queue's bytes
     if (getenv("ORBX_DEBUG_ALLOC"))
         fprintf(stderr, "[orbx fast] %s: %d strips of up to %d rows per frame (main launch: %d of up to %d rows), %zu cells, LDS %zu B per workgroup of the main launch\n", ex->fast_strip ? "k_fast_strip" : "per-cell kernels",
-                ex->n_strips, strip_rows, ex->n_strips_main, ex->strip_rows_main, fast_tiles.size(), fast_strip_lds_bytes(ex->strip_rows_main, ex->strip_gcap, ex->strip_qcap));
+                ex->n_strips, strip_rows, ex->n_strips_main, ex->strip_rows_main, fast_tiles.size(), fast_strip_lds_bytes(4, ex->strip_rows_main, ex->strip_gcap, ex->strip_qcap));
     ex->fast_wave_pitch = (fast_wave_maxw + 7 <= 48) ? 48 : 64;
     ex->fast_wave_rows = fast_wave_rows;
     ex->fast_wave_qfull = fast_wave_qfull;
@@ -371,7 +395,7 @@ struct ProfScope {
 
 // enqueue the whole extraction of `n` device-resident frames on ex->stream
 static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride,
-                           int lap0, int lap1, hipEvent_t ev_input_consumed = nullptr) {
+                           int lap0, int lap1, hipEvent_t ev_input_consumed) {
     RoctxRange rr("orbx:extract");
     const int nl = ex->prm.nlevels;
     const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
@@ -405,6 +429,20 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
+        static const int march = [] { const char *v = getenv("ORBX_RESIZE_MARCH"); return v ? atoi(v) : 8; }();   // TEMPORARY (A/B visit): 0 = k_pyr_resize2, 4 / 8 = rows in flight
+        static const int march_rb = [] { const char *v = getenv("ORBX_RESIZE_RB"); return v ? atoi(v) : 0; }();    // TEMPORARY (A/B visit)
+        if (march && ex->resize_march_ok[l]) {
+            // register-marching form: one wave = 64 dword columns x rb output rows
+            const int nstrips = (L.pitch / 4 + 63) / 64, rb = march_rb ? march_rb : (L.h >= 256 ? 32 : 16), n_items = nstrips * ((L.h + rb - 1) / rb);
+            const uint32_t rcp = (uint32_t)((0x100000000ull + (uint64_t)nstrips - 1) / (uint64_t)nstrips);
+#define ORBX_RESIZE_MARCH(CH)                                                                                                                       \
+    hipLaunchKernelGGL(k_pyr_resize_march<CH>, xcd_grid((n_items + 3) / 4, n, pyr_local), dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_ytab.p, \
+                       (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame, rb, nstrips, rcp, n_items, n)
+            if (march == 4) ORBX_RESIZE_MARCH(4); else ORBX_RESIZE_MARCH(8);
+#undef ORBX_RESIZE_MARCH
+            continue;
+        }
+        // scale factors above 2 (a dword column's taps further apart than 8 source bytes): the table form
         const uint32_t wpc = (uint32_t)(L.pitch / 8);
         const dim3 grid2 = xcd_grid((int)((wpc * (uint32_t)((L.h + 2 * kEdge + kResizeRows - 1) / kResizeRows) + 255u) / 256u), n, pyr_local);
         hipLaunchKernelGGL(k_pyr_resize2, grid2, dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,
@@ -444,16 +482,17 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             if (ex->fast_strip) {
                 // first pass of :826 for every cell, one workgroup per strip of cells; cells it leaves empty go to the list pass below
                 // (ini <= min: the second pass is a subset of the first, an empty cell stays empty)
-                const size_t lds = fast_strip_lds_bytes(ex->strip_rows, ex->strip_gcap, ex->strip_qcap);
-                static const bool pol = [] { const char *v = getenv("ORBX_FAST_POL"); return !(v && v[0] == '0'); }();   // TEMPORARY (A/B visit)
-#define ORBX_FAST_STRIP(POL, FIRST, COUNT, ROWS)                                                                                              \
-    hipLaunchKernelGGL(k_fast_strip<POL>, xcd_grid(COUNT, n), dim3(64 * kStripWaves), fast_strip_lds_bytes(ROWS, ex->strip_gcap, ex->strip_qcap), \
+                static const int sw = [] { const char *v = getenv("ORBX_STRIP_WAVES"); return v ? atoi(v) : 4; }();   // TEMPORARY (A/B visit)
+#define ORBX_FAST_STRIP(WAVES, FIRST, COUNT, ROWS)                                                                                            \
+    hipLaunchKernelGGL(k_fast_strip<WAVES>, xcd_grid(COUNT, n), dim3(64 * WAVES), fast_strip_lds_bytes(WAVES, ROWS, ex->strip_gcap, ex->strip_qcap), \
                        st, (const StripTile *)ex->d_strips.p + (FIRST), (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,        \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ROWS, ex->strip_gcap, ex->strip_qcap, ovf_list,       \
                        ovf_count, ini > mn ? 1 : 0, n)
+#define ORBX_FAST_STRIP_W(FIRST, COUNT, ROWS) do { if (sw == 1) ORBX_FAST_STRIP(1, FIRST, COUNT, ROWS); else if (sw == 2) ORBX_FAST_STRIP(2, FIRST, COUNT, ROWS); else ORBX_FAST_STRIP(4, FIRST, COUNT, ROWS); } while (0)
                 const int n_tall = ex->n_strips - ex->n_strips_main;
-                if (pol) ORBX_FAST_STRIP(true, 0, ex->n_strips_main, ex->strip_rows_main); else ORBX_FAST_STRIP(false, 0, ex->n_strips_main, ex->strip_rows_main);
-                if (n_tall > 0) { if (pol) ORBX_FAST_STRIP(true, ex->n_strips_main, n_tall, ex->strip_rows); else ORBX_FAST_STRIP(false, ex->n_strips_main, n_tall, ex->strip_rows); }
+                ORBX_FAST_STRIP_W(0, ex->n_strips_main, ex->strip_rows_main);
+                if (n_tall > 0) ORBX_FAST_STRIP_W(ex->n_strips_main, n_tall, ex->strip_rows);
+#undef ORBX_FAST_STRIP_W
 #undef ORBX_FAST_STRIP
             } else if (ini > mn) {
                 // first pass of :826 for every cell (k_fast_ini); cells it leaves empty go to the list pass below
