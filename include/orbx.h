@@ -356,7 +356,9 @@ int orbx_search_by_bow_frame_fisheye(orbx_matcher *m, const uint8_t *kf_desc, co
  * matched against frame f exactly as orbx_search_by_projection_frame does with level_mode 0, all features free on
  * entry and every query "has observations".  d_match: device int32 [n_frames][cap] (query index in frame f-1 or -1),
  * d_nmatches: device int32 [n_frames]; pass NULL for both to use internal buffers (fetched with
- * orbx_batch_download_async).  Asynchronous on the extractor's stream. */
+ * orbx_batch_download_async).  There is ONE set of internal buffers per extractor: of the two batched matchers
+ * (this one and orbx_search_mappoints_batch_device) only the first to be called on a batch may use them, the other gets
+ * ORBX_E_BAD_ARG and has to be given result buffers of its own.  Asynchronous on the extractor's stream. */
 int orbx_match_consecutive_device(orbx_extractor *ex, float th, float du, float dv, int check_orientation,
                                   int32_t *d_match, int32_t *d_nmatches);
 

@@ -162,7 +162,8 @@ struct orbx_extractor {
     bool copy_pending = false;                         // a download was issued since the last (re)configuration
     int32_t *h_err = nullptr;  // pinned, 2 slots
     DevBuf d_st_bidx, d_st_bdist, d_st_ur, d_st_depth, d_st_sad, d_st_nm, d_st_scales;  // device stereo matcher (left extractor)
-    DevBuf d_match, d_nmatch;  // internal frame-to-frame match outputs [B][cap], [B]
+    DevBuf d_match, d_nmatch;  // internal match outputs [B][cap], [B] (one matcher per batch: orbx.h)
+    int internal_match_owner = 0;   // which batched matcher wrote them for the current batch: 0 none, 1 frame-to-frame, 2 map points
     // cached problem descriptors of orbx_match_consecutive_device
     struct MatchKey { int n = 0, cap = 0; const void *match = nullptr, *nm = nullptr; float th = 0, du = 0, dv = 0; int ori = 0; const void *kps = nullptr; } mkey;
 
@@ -177,6 +178,11 @@ struct orbx_extractor {
     float cam_bf = 0;
     float bounds[4] = {0, 0, 0, 0};      // mnMinX, mnMaxX, mnMinY, mnMaxY of the current geometry
     DevBuf d_kps_un, d_frustum_frames;
+    void *h_frustum[3] = {nullptr, nullptr, nullptr};   // pinned ring of orbx_frustum_batch_device's pose uploads
+    size_t h_frustum_bytes[3] = {0, 0, 0};
+    hipEvent_t ev_frustum[3] = {nullptr, nullptr, nullptr};
+    bool frustum_used[3] = {false, false, false};
+    unsigned frustum_issued = 0;
     const void *match_kps() const { return has_camera ? d_kps_un.p : d_kps.p; }
 
     // Synchronous device -> caller copy through the pinned staging buffer (no caller pointer is ever handed to the HIP runtime: see

@@ -77,29 +77,7 @@ using namespace orbx;
 
 namespace orbx {
 
-static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride, int lap0, int lap1,
-                           hipEvent_t ev_input_consumed = nullptr);
-static int configure_geometry(orbx_extractor *ex, int width, int height, int batch);
-
-// (Re)configuration + a few untimed passes of the whole extraction over blank frames: the first launches of a process pay for code-object
-// loading and for the HIP runtime's signal / command pools growing (the first ~10 batches of a fresh process enqueued 5x slower and ran
-// 2.2x slower: `settle_ms_per_step` in bench.py); paying it here keeps it out of the caller's first frames.
 static int configure(orbx_extractor *ex, int width, int height, int batch) {
-    const bool fresh = !(width == ex->width && height == ex->height && batch <= ex->batch_cap);
-    int r = configure_geometry(ex, width, height, batch);
-    static const int prime_k = [] { const char *v = getenv("ORBX_PRIME"); return v ? atoi(v) : 0; }();   // TEMPORARY (A/B visit)
-    if (r != ORBX_OK || !fresh || prime_k <= 0) return r;
-    const int n = std::min(ex->batch_cap, 8);
-    if ((r = ex->d_img.ensure((size_t)width * height * n)) != ORBX_OK) return r;   // zero-filled: blank frames, no keypoints
-    for (int i = 0; i < prime_k; i++)
-        if ((r = enqueue_extract(ex, (const uint8_t *)ex->d_img.p, n, (size_t)width, (size_t)width * height, 0, 0, nullptr)) != ORBX_OK) return r;
-    ORBX_HIP(hipStreamSynchronize(ex->stream));
-    ORBX_HIP(hipStreamSynchronize(ex->aux_stream));
-    ex->last_batch = 0;
-    return ORBX_OK;
-}
-
-static int configure_geometry(orbx_extractor *ex, int width, int height, int batch) {
     if (width > kMaxDim || height > kMaxDim) return ORBX_E_TOO_LARGE;
     const bool same_geom = (width == ex->width && height == ex->height);
     if (same_geom && batch <= ex->batch_cap) return ORBX_OK;
@@ -395,8 +373,9 @@ struct ProfScope {
 
 // enqueue the whole extraction of `n` device-resident frames on ex->stream
 static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride,
-                           int lap0, int lap1, hipEvent_t ev_input_consumed) {
+                           int lap0, int lap1, hipEvent_t ev_input_consumed = nullptr) {
     RoctxRange rr("orbx:extract");
+    ex->internal_match_owner = 0;   // a new batch: its first batched matcher owns the internal match buffers
     const int nl = ex->prm.nlevels;
     const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
     uint8_t *pyr = (uint8_t *)ex->d_pyr.p;
@@ -429,17 +408,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
-        static const int march = [] { const char *v = getenv("ORBX_RESIZE_MARCH"); return v ? atoi(v) : 8; }();   // TEMPORARY (A/B visit): 0 = k_pyr_resize2, 4 / 8 = rows in flight
-        static const int march_rb = [] { const char *v = getenv("ORBX_RESIZE_RB"); return v ? atoi(v) : 0; }();    // TEMPORARY (A/B visit)
-        if (march && ex->resize_march_ok[l]) {
-            // register-marching form: one wave = 64 dword columns x rb output rows
-            const int nstrips = (L.pitch / 4 + 63) / 64, rb = march_rb ? march_rb : (L.h >= 256 ? 32 : 16), n_items = nstrips * ((L.h + rb - 1) / rb);
+        if (ex->resize_march_ok[l]) {
+            // register-marching form: one wave = 64 dword columns x rb output rows (rb 16 / 32 and 4 / 8 source rows in flight measured
+            // alike, 64 rows per block 5 % slower: profiles/r03_c_ab_resize_march_strip_waves_prime.log)
+            const int nstrips = (L.pitch / 4 + 63) / 64, rb = L.h >= 256 ? 32 : 16, n_items = nstrips * ((L.h + rb - 1) / rb);
             const uint32_t rcp = (uint32_t)((0x100000000ull + (uint64_t)nstrips - 1) / (uint64_t)nstrips);
-#define ORBX_RESIZE_MARCH(CH)                                                                                                                       \
-    hipLaunchKernelGGL(k_pyr_resize_march<CH>, xcd_grid((n_items + 3) / 4, n, pyr_local), dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_ytab.p, \
-                       (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame, rb, nstrips, rcp, n_items, n)
-            if (march == 4) ORBX_RESIZE_MARCH(4); else ORBX_RESIZE_MARCH(8);
-#undef ORBX_RESIZE_MARCH
+            hipLaunchKernelGGL(k_pyr_resize_march<8>, xcd_grid((n_items + 3) / 4, n, pyr_local), dim3(256), 0, pst, L, ex->lv[l - 1],
+                               (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame, rb, nstrips, rcp, n_items, n);
             continue;
         }
         // scale factors above 2 (a dword column's taps further apart than 8 source bytes): the table form
@@ -736,6 +711,7 @@ void orbx_destroy(orbx_extractor *ex) {
     if (ex->ev_compute_done) (void)hipEventDestroy(ex->ev_compute_done);
     for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
     if (ex->h_err) (void)hipHostFree(ex->h_err);
+    for (int i = 0; i < 3; i++) { if (ex->h_frustum[i]) (void)hipHostFree(ex->h_frustum[i]); if (ex->ev_frustum[i]) (void)hipEventDestroy(ex->ev_frustum[i]); }
     ex->d_match.release(); ex->d_nmatch.release();
     for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales}) b->release();
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
@@ -773,6 +749,9 @@ int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_f
     int r = configure(ex, width, height, n_frames);
     if (r != ORBX_OK) return r;
     const unsigned slot = ex->in_issued & 1u;
+    // the contract of orbx.h: the PREVIOUS call's frames may be overwritten once this call has returned -- so its upload must have
+    // landed (it was queued behind ev_in_free of its slab and may still be pending)
+    if (ex->in_used[slot ^ 1u]) ORBX_HIP(hipEventSynchronize(ex->ev_in_ready[slot ^ 1u]));
     orbx::DevBuf &din = ex->d_in[slot];
     const size_t fbytes = (size_t)width * height, need = fbytes * n_frames;
     if (need > din.bytes) {  // growing: nothing may still read the old slab

@@ -912,6 +912,8 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     const int np = n - 1, cap = ex->cap;
     int r;
     if (!d_match || !d_nmatches) {  // internal result buffers (downloaded by orbx_batch_download_async)
+        if (ex->internal_match_owner == 2) { set_error("the internal match buffers hold the map-point search of this batch: download it first, or pass result buffers"); return ORBX_E_BAD_ARG; }
+        ex->internal_match_owner = 1;
         if (ex->d_match.bytes < 4 * (size_t)cap * ex->batch_cap || ex->d_nmatch.bytes < 4 * (size_t)ex->batch_cap) {
             // growing frees the old buffers: an earlier matcher / download may still be using them
             ORBX_HIP(hipStreamSynchronize(ex->match_stream)); ORBX_HIP(hipStreamSynchronize(ex->copy_stream));
@@ -1018,6 +1020,8 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
     const int cap = ex->cap;
     int r;
     if (!d_match || !d_nmatches) {  // internal result buffers (downloaded by orbx_batch_download_async)
+        if (ex->internal_match_owner == 1) { set_error("the internal match buffers hold the frame-to-frame matches of this batch: download them first, or pass result buffers"); return ORBX_E_BAD_ARG; }
+        ex->internal_match_owner = 2;
         if (ex->d_match.bytes < 4 * (size_t)cap * ex->batch_cap || ex->d_nmatch.bytes < 4 * (size_t)ex->batch_cap) {
             ORBX_HIP(hipStreamSynchronize(ex->match_stream)); ORBX_HIP(hipStreamSynchronize(ex->copy_stream));
         }
@@ -1186,10 +1190,24 @@ extern "C" int orbx_frustum_batch_device(orbx_extractor *ex, const orbx_camera *
     const float *b = bounds4 ? bounds4 : ex->bounds;
     if (!bounds4 && ex->width <= 0) return ORBX_E_BAD_ARG;
     const float log_sf = logf((float)(double)ex->prm.scale_factor);   // Frame::mfLogScaleFactor = log(mfScaleFactor) (Frame.cc:120)
-    std::vector<FrustumFrame> F(n_frames);
+    // the per-batch pose upload goes through a pinned ring of three slots owned by the library (no caller or pageable memory reaches the
+    // HIP runtime, and the host never waits for the matcher stream): a slot is reused once the copy out of it has run
+    const unsigned slot = ex->frustum_issued % 3u;
+    const size_t fbytes = sizeof(FrustumFrame) * (size_t)n_frames;
+    if (ex->frustum_used[slot]) ORBX_HIP(hipEventSynchronize(ex->ev_frustum[slot]));
+    if (ex->h_frustum_bytes[slot] < fbytes) {
+        if (ex->h_frustum[slot]) ORBX_HIP(hipHostFree(ex->h_frustum[slot]));
+        ex->h_frustum[slot] = nullptr; ex->h_frustum_bytes[slot] = 0;
+        ORBX_HIP(hipHostMalloc(&ex->h_frustum[slot], fbytes, hipHostMallocDefault));
+        ex->h_frustum_bytes[slot] = fbytes;
+    }
+    if (!ex->ev_frustum[slot]) ORBX_HIP(hipEventCreateWithFlags(&ex->ev_frustum[slot], hipEventDisableTiming));
+    FrustumFrame *F = (FrustumFrame *)ex->h_frustum[slot];
     for (int f = 0; f < n_frames; f++) F[f] = frustum_frame(cam, poses + f, b, log_sf, ex->prm.nlevels, viewing_cos_limit);
-    ORBX_HIP(hipMemcpyAsync(ex->d_frustum_frames.p, F.data(), sizeof(FrustumFrame) * (size_t)n_frames, hipMemcpyHostToDevice, ms));
-    ORBX_HIP(hipStreamSynchronize(ms));   // F is a host temporary (the poses change every frame: this copy is the per-batch upload)
+    ORBX_HIP(hipMemcpyAsync(ex->d_frustum_frames.p, F, fbytes, hipMemcpyHostToDevice, ms));
+    ORBX_HIP(hipEventRecord(ex->ev_frustum[slot], ms));
+    ex->frustum_used[slot] = true;
+    ex->frustum_issued++;
     hipLaunchKernelGGL(k_in_frustum, dim3((n_mp + 255) / 256, n_frames), dim3(256), 0, ms, (const FrustumFrame *)ex->d_frustum_frames.p, n_mp, d_pos,
                        d_normal, d_min_dist, d_max_dist, d_in_view, d_proj_x, d_proj_y, d_proj_xr, d_depth, d_level, d_view_cos);
     ORBX_HIP(hipGetLastError());

@@ -62,7 +62,8 @@ class ORBextractor:
 
     def extract_batch_host(self, h_ptr: int, n_frames: int, width: int, height: int, row_stride: int, frame_stride: int,
                            vLappingArea=(0, 0)):
-        """Frames in (ideally pinned) host memory; the upload overlaps the previous batch's kernels."""
+        """Frames in PINNED host memory (hipHostMalloc / hipHostRegister, e.g. torch's pin_memory(); pageable memory is refused with
+        ORBX_E_BAD_ARG); the upload overlaps the previous batch's kernels.  The frames may be overwritten once the NEXT call has returned."""
         check(self._L.orbx_extract_batch_host(self._h, C.c_void_p(h_ptr), n_frames, width, height, row_stride,
                                               frame_stride, int(vLappingArea[0]), int(vLappingArea[1])),
               "orbx_extract_batch_host")
@@ -90,10 +91,12 @@ class ORBextractor:
 
     # ---- camera of the batch path: Frame::UndistortKeyPoints + ComputeImageBounds for the batched matchers ----
     def set_camera(self, cam=None):
-        """cam: dict/tuple (fx, fy, cx, cy, k1, k2, p1, p2, k3, bf) or None (distortion-free default)."""
+        """cam: tuple (fx, fy, cx, cy, k1, k2, p1, p2, k3, bf) in that order, a dict with those keys, or None (distortion-free default)."""
         if cam is None:
             check(self._L.orbx_set_camera(self._h, None), "orbx_set_camera")
         else:
+            if isinstance(cam, dict):
+                cam = [cam[k] for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")]
             c = _lib.Camera(*[float(x) for x in cam])
             check(self._L.orbx_set_camera(self._h, C.byref(c)), "orbx_set_camera")
 
@@ -127,7 +130,7 @@ class ORBextractor:
         return kps, desc, counts, mono
 
     def download_async(self, kps, desc, counts, mono, match=None, nmatches=None):
-        """Enqueue the D2H of the last batch on the copy stream (arguments: raw host pointers, ideally pinned)."""
+        """Enqueue the D2H of the last batch on the copy stream (arguments: raw host pointers to PINNED memory; pageable memory is refused)."""
         check(self._L.orbx_batch_download_async(self._h, *[C.c_void_p(p) if p else None
                                                            for p in (kps, desc, counts, mono, match, nmatches)]),
               "orbx_batch_download_async")

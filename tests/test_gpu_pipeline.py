@@ -138,6 +138,41 @@ def test_pipeline_under_alternative_switches():
         assert r.returncode == 0 and "pipeline ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_host_frames_may_be_overwritten_after_the_next_call(oracle):
+    """include/orbx.h: the frames handed to orbx_extract_batch_host may be reused once the NEXT call has returned.  Two batches in flight
+    (nothing waits in between); the camera thread scribbles over batch i's frames the moment call i+1 has returned -- batch i's results
+    must still be those of its frames.  (Before the fix the upload of batch i could still be pending at that point.)"""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    B, steps = 48, 8
+    canvas = synth.make_canvas(12)
+    sets = [np.stack([synth.frame_from_canvas(canvas, 40 * i + t, W, H, 500 * i + t) for t in range(B)]) for i in range(steps)]
+    bufs = [torch.zeros((B, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    ex = osa.ORBextractor(NF, 1.2, 8, 20, 7)
+    cap = ex.output_capacity(W, H)
+    host = [dict(kps=torch.zeros((B, cap, 28), dtype=torch.uint8).pin_memory(), desc=torch.zeros((B, cap, 32), dtype=torch.uint8).pin_memory(),
+                 cnt=torch.zeros(B, dtype=torch.int32).pin_memory(), mono=torch.zeros(B, dtype=torch.int32).pin_memory()) for _ in range(2)]
+    oex = oracle.OracleExtractor(NF, 1.2, 8, 20, 7)
+    for i in range(steps + 1):
+        if i < steps:
+            bufs[i % 2].numpy()[:] = sets[i]
+            ex.extract_batch_host(bufs[i % 2].data_ptr(), B, W, H, W, W * H, (0, 1000))
+            hs = host[i % 2]
+            ex.download_async(hs["kps"].data_ptr(), hs["desc"].data_ptr(), hs["cnt"].data_ptr(), hs["mono"].data_ptr(), 0, 0)
+            if i >= 1:
+                bufs[(i - 1) % 2].numpy()[:] = 0x5a       # call i has returned: batch i-1's frames are the caller's again
+        if i >= 1:
+            ex.download_wait()
+            j, hs = i - 1, host[(i - 1) % 2]
+            for f in (0, B // 2, B - 1):
+                omono, ok, od = oex.extract(sets[j][f], lap=(0, 1000))
+                n = int(hs["cnt"][f])
+                assert n == len(ok) and int(hs["mono"][f]) == omono and hs["kps"][f, :n].numpy().tobytes() == ok.tobytes() and \
+                    np.array_equal(hs["desc"][f, :n].numpy(), od), (j, f, n, len(ok))
+    ex.sync()
+
+
 def test_extract_batch_host_strided_input_equals_device_path():
     import torch
     import orb_slam3_amd as osa
@@ -211,6 +246,12 @@ def test_search_mappoints_batch_device_equals_oracle(oracle, w, h, nf, n_mp, th)
         on, ofm = oracle.search_by_projection_mappoints(grid, d, sf, mps[f], th, 0.8)
         assert nm[f] == on and np.array_equal(match[f, :len(k)], ofm), f
         assert on > 300
+    # one set of internal result buffers per extractor (include/orbx.h): the second batched matcher of a batch that asks for them is refused
+    ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+    with pytest.raises(osa.OrbxError):
+        ex.search_mappoints_batch_device(n_mp, dev["proj_x"].data_ptr(), dev["proj_y"].data_ptr(), dev["level"].data_ptr(),
+                                         dev["view_cos"].data_ptr(), dev["in_view"].data_ptr(), dev["desc"].data_ptr(), th=th, nnratio=0.8)
+    ex.sync()
 
 
 def test_stereo_download_all_equals_per_frame_download():
