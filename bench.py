@@ -64,8 +64,8 @@ def algorithmic_bytes(sizes, n_frames, feats, cands):
     N, Cn = feats, cands
     per = {
         "k_pyr_base": 2 * px[0] * n_frames,                       # image read + level-0 write
-        "k_pyr_resize": ((P - px[-1]) + (P - px[0])) * n_frames / (NLEVELS - 1),  # per launch (7 launches)
-        "k_fast_ini": P * n_frames + 4 * Cn,                      # pyramid read + packed candidates (k_fast_ini + its list pass k_fast_wave_list)
+        "k_pyr_resize": ((P - px[-1]) + (P - px[0])) * n_frames,  # the whole chain; divided by its launches per step in roofline_from_profile
+        "k_fast_strip": P * n_frames + 4 * Cn,                      # FAST stage: pyramid read + packed candidates (k_fast_strip + its list pass k_fast_wave_list)
         "k_blur": 2 * P * n_frames,
         "k_octree": 8 * Cn + 4 * N,                               # candidates read + gathered, keypoints out
         "k_finalize": 16 * N,
@@ -85,6 +85,8 @@ def roofline_from_profile(ex, prof, passes, sizes, n_frames, n_feat, n_cand, lau
         if cnt == 0 or name not in per:
             continue
         lps = cnt / float(passes)
+        if name == "k_pyr_resize":
+            per[name] = per[name] / max(lps, 1.0)   # algorithmic bytes of an average launch of the chain
         kernels[name] = {"avg_ms": round(ms, 4), "launches_per_step": lps, "alg_GBs": round(per[name] / (ms * 1e-3) / 1e9, 1)}
         tot_ms += ms * lps
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
@@ -105,7 +107,7 @@ def roofline_from_profile(ex, prof, passes, sizes, n_frames, n_feat, n_cand, lau
 # they do not fit one pass) over a short serialized child run of this same file, parsed from rocprofv3's database
 # ---------------------------------------------------------------------------------------------------------
 # a profile slot may cover more than one kernel: the FAST stage = first pass for every cell + the list pass over the cells it left
-STAGE_KERNELS = {"k_fast_ini": ("k_fast_ini", "k_fast_wave_list", "k_fast_wave"), "k_octree": ("k_compact", "k_octree_par", "k_octree_par1", "k_octree"),
+STAGE_KERNELS = {"k_fast_strip": ("k_fast_strip", "k_fast_wave_list", "k_fast_cells"), "k_octree": ("k_compact", "k_octree_par_t", "k_octree_par1", "k_octree"),
                  "k_window_best2": ("k_grid_build", "k_window_best2")}
 
 

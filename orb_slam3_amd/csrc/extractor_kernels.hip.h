@@ -3,7 +3,7 @@
 // Stage -> reference function (all line numbers in /root/reference/src/ORBextractor.cc):
 //   k_pyr_base        copyMakeBorder of the input into level 0                 :1188-1191
 //   k_pyr_resize2     cv::resize(INTER_LINEAR) level l-1 -> l + REFLECT_101    :1183-1186
-//   k_fast_ini        per-cell cv::FAST(ini) + NMS                             :805-842   (one wave per cell)
+//   k_fast_strip      per-cell cv::FAST(ini) + NMS, a strip of cells per workgroup  :805-842   (fast_strip.hip.h)
 //   k_fast_wave_list  cells the first pass left empty: cv::FAST(ini) / fallback cv::FAST(min)   :843-870
 //                     (k_fast_cells = generic workgroup-per-cell form for cells wider than 57 px)
 //   k_compact, k_octree_par_t (octree_par.hip.h)  DistributeOctTree / DivideNode / compareNodes   :480-779
@@ -238,22 +238,17 @@ __global__ __launch_bounds__(256) void k_pyr_resize2(const LevelInfo L, const Le
 // Needs every tap pair of a dword column within 8 source bytes (scale factor <= 2); k_pyr_resize2 stays for the other case.
 // grid xcd_grid(ceil(nstrips * ceil(h / RB) / 4), B), block 256 (four independent waves)
 // ---------------------------------------------------------------------------------------------------------
+// one block of the marching resize: `item` = (row block, column strip) of level L of the frame whose pyramid slab starts at `frame`; one wave
 template <int CH>
-__global__ __launch_bounds__(256) void k_pyr_resize_march(const LevelInfo L, const LevelInfo P, const ResizeTap *__restrict__ ytab,
-                                                          const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                          int rb_rows, int nstrips, uint32_t nstrips_rcp, int n_items, int n_frames) {
-    int bx, f;
-    if (!xcd_frame_map(n_frames, &bx, &f)) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = bx * 4 + wave;
-    if (item >= n_items) return;
+__device__ __forceinline__ void resize_march_block(const LevelInfo &L, const LevelInfo &P, const ResizeTap *__restrict__ ytab,
+                                                   const ResizeGroup *__restrict__ xg, uint8_t *frame, int rb_rows, int nstrips,
+                                                   uint32_t nstrips_rcp, int item, int lane) {
     const int rb = nstrips == 1 ? item : __builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)item, nstrips_rcp)), cs = item - rb * nstrips;   // ceil(2^32 / 1) does not fit
     const int ncol = L.pitch >> 2;
     const int col = cs * 64 + lane;
     const bool live = col < ncol;
     const uint4 *gp = reinterpret_cast<const uint4 *>(&xg[L.xg_off + min(col, ncol - 1)]);
     const uint4 gh = gp[0], gc = gp[1];   // base, sel, valid, pad | cc[4]
-    uint8_t *frame = pyr + (size_t)f * pyr_frame_stride;
     const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX + (gh.z == 1 ? gh.x : 0u);   // this lane's first source byte of row 0
     uint8_t *dcol = frame + L.off + 4 * (uint32_t)col;
     const uint32_t sel = gh.y, selr = gh.y + 0x01010101u;
@@ -312,6 +307,40 @@ __global__ __launch_bounds__(256) void k_pyr_resize_march(const LevelInfo L, con
         for (int k = 0; k < CH; k++) cur[k] = nxt[k];
         s += CH;
         if (s > s_last + CH) break;   // cannot happen with monotone row taps; never spin on a bad table
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_pyr_resize_march(const LevelInfo L, const LevelInfo P, const ResizeTap *__restrict__ ytab,
+                                                          const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                          int rb_rows, int nstrips, uint32_t nstrips_rcp, int n_items, int n_frames) {
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = bx * 4 + wave;
+    if (item >= n_items) return;
+    resize_march_block<CH>(L, P, ytab, xg, pyr + (size_t)f * pyr_frame_stride, rb_rows, nstrips, nstrips_rcp, item, lane);
+}
+
+// k_pyr_chain_march: the SMALL levels of the chain (from the first level whose launch is bound by the lifetime of one wave, not by its
+// pixels: at EuRoC size levels 3 .. 7 hold 22 % of the chain's pixels and took 111 of its 204 us) in ONE launch: a 1024-thread
+// workgroup per frame walks the levels, its 16 waves share the blocks of a level, a workgroup barrier separates the levels (a frame's
+// levels are produced and consumed by the same CU; the stores are made visible with a workgroup-scope fence before the barrier).
+// grid (B), block 1024
+struct ChainLevel { int32_t rb_rows, nstrips, n_items; uint32_t nstrips_rcp; };
+struct ChainParams { int32_t first, count; ChainLevel lv[kMaxLevels]; };
+template <int CH>
+__global__ __launch_bounds__(1024) void k_pyr_chain_march(const LevelInfo *__restrict__ lv, const ChainParams cp, const ResizeTap *__restrict__ ytab,
+                                                          const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr, size_t pyr_frame_stride) {
+    uint8_t *frame = pyr + (size_t)blockIdx.x * pyr_frame_stride;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = 0; i < cp.count; i++) {
+        const int l = cp.first + i;
+        const LevelInfo L = lv[l], P = lv[l - 1];
+        const ChainLevel c = cp.lv[i];
+        for (int item = wave; item < c.n_items; item += 16) resize_march_block<CH>(L, P, ytab, xg, frame, c.rb_rows, c.nstrips, c.nstrips_rcp, item, lane);
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -596,31 +625,6 @@ __device__ __forceinline__ void fast_tile_load(const uint8_t *__restrict__ src, 
     }
 }
 
-// the same through a buffer descriptor over the tile's byte range [src, src + (rows - 1) * pitch + 4 * nd): rows past the tile are
-// out of range for the hardware (they read as 0, no memory access), so the twelve loads need no per-row predicate and no 64-bit
-// address arithmetic -- one v_add per load instead of eight VALU instructions (a quarter of the cell's budget went into this phase:
-// 121 of 907 VALU instructions per wave, SQ_INSTS_VALU under ORBX_FAST_STOP=1).  The LDS slice must hold 48 rows (launch code).
-template <int P>
-__device__ __forceinline__ void fast_tile_load_srd(const uint8_t *src, int pitch, int rows, int cols, uint8_t *pix, int lane) {
-    const int c = lane & 15, nd = (cols + 4) >> 2, r0 = lane >> 4;
-    if (c >= nd) return;
-    // wave-uniform descriptor inputs, provably so for the compiler
-    const uint64_t a = (uint64_t)src;
-    const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)a), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    const int spitch = __builtin_amdgcn_readfirstlane(pitch);
-    const int nbytes = __builtin_amdgcn_readfirstlane((rows - 1) * pitch + 4 * nd);
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)ahi << 32) | alo), 0, nbytes, 0x00020000);
-    const int voff = r0 * spitch + 4 * c;
-    uint32_t v[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, voff + 4 * k * spitch, 0, 0);
-    uint8_t *d = pix + r0 * P + 4 * c;
-#pragma unroll
-    for (int k = 0; k < 12; k++) *reinterpret_cast<uint32_t *>(d + 4 * k * P) = v[k];
-    for (int r = 48 + r0; r < rows; r += 4)   // tiles taller than 48 rows (cells above 42 px)
-        *reinterpret_cast<uint32_t *>(pix + r * P + 4 * c) = __builtin_amdgcn_raw_buffer_load_b32(srd, r * spitch + 4 * c, 0, 0);
-}
-
 // LDS of one wave (= one cell): pixel tile rows x P | queue[qcap] u16 | score per queue entry [qcap] u8.  After the scores are
 // known the pixel tile is dead and its memory becomes the zero-aproned score tile of the NMS; the survivors of the NMS
 // overwrite the head of the queue in place.  ~4.7 KB for EuRoC (P = 48, qcap = 768) -> 32 waves per CU: the kernel's time
@@ -766,202 +770,17 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
     if (lane == 0) *cnt_out = total;
 }
 
-template <int P>
-__global__ __launch_bounds__(64) void k_fast_wave(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
-                                                  const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                  int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
-                                                  size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
-                                                  uint32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    fast_wave_cell<P>(tiles[blockIdx.x], blockIdx.y, blockIdx.x, smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride,
-                      iniTh, minTh, max_rows, qcap, ovf_list, ovf_count);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_fast_ini: the first pass of the reference's per-cell detection, cv::FAST(cell, iniThFAST) (:826), for every cell -- and nothing
-// else.  A cell whose pass finds corners is finished (the reference never runs its second pass there); a cell whose pass finds none
-// (or whose queue overflows) goes to the list that k_fast_wave_list works through with the complete ini / min logic of
-// fast_wave_cell.  The score map at iniTh gives exactly the survivors the minTh map would give after the >= iniTh filter
-// (a pixel below iniTh cannot suppress one at or above it), so S20 is unchanged.
-// Why a separate pass: at iniTh most 4-pixel groups can be REJECTED before the antipodal-pair test.  A 9-arc contains one pixel
-// of every antipodal circle pair, so if BOTH pixels of some pair differ from the centre by at most t, there is no corner; for four
-// adjacent centres at once: v_sad_u8(centre dword, neighbour dword) <= t bounds all four |differences| by t.  Stage A tests the
-// vertical pair (rows y-3 / y+3: aligned dwords) and the horizontal pair (x-3 / x+3: v_alignbyte) -- 16 VALU for four pixels,
-// about 70 % of the groups of the EuRoC-like frames rejected at t = 20 (a few per cent at t = 7: noise) -- and queues the
-// surviving groups in row-major order; stage B runs the four-pair test of k_fast_wave on the queued groups only, all lanes busy.
-//   LDS: pixel tile | pixel queue u16[qcap] | scores u8[qcap] | group queue u16[gcap]
-// grid (total_cells, B), block 64
-// ---------------------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t fast_ini_lds_bytes(int P, int max_rows, int qcap, int gcap) {
-    return (((size_t)max_rows * P + 16 + 15) & ~(size_t)15) + (size_t)qcap * 3 + 16 + (size_t)gcap * 2;
-}
-
-// the waves of a k_fast_ini workgroup never talk to each other: LDS accesses of one wave execute in program order, so a wave-private
-// hand-over through LDS needs no s_barrier -- only the compiler must not move LDS accesses across the point
+// A wave hands data to itself through LDS: its LDS instructions execute in program order, so a wave-private hand-over needs no s_barrier --
+// only the compiler must not move LDS accesses across the point
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// one cell whose tile already sits in LDS
-template <int P>
-__device__ __forceinline__ void fast_ini_body(const FastTile T, const int f, const int tile, uint8_t *smem, int32_t *__restrict__ cellcnt,
-                                              int total_cells, uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh, int max_rows,
-                                              int qcap, uint32_t *__restrict__ list, int32_t *__restrict__ list_count, int dbg_stop) {
-    const int lane = threadIdx.x & 63;
-    int32_t *cnt_out = cellcnt + (size_t)f * total_cells + T.cell;
-    const int cols = T.cols, rows = T.rows;
-    const int iw = cols - 6, ih = rows - 6;
-    if (cols <= 0) {  // :813 / :821 skip rules (decided on the host when the tile table is built)
-        if (lane == 0) *cnt_out = 0;
-        return;
-    }
-    uint8_t *pix = smem;
-    uint16_t *queue = reinterpret_cast<uint16_t *>(smem + (((size_t)max_rows * P + 16 + 15) & ~(size_t)15));
-    uint8_t *scq = reinterpret_cast<uint8_t *>(queue + qcap);
-    uint16_t *gq = reinterpret_cast<uint16_t *>(scq + qcap + 16 - (qcap & 1));   // 2-byte aligned
-    if (dbg_stop == 1) { if (lane == 0) *cnt_out = (int)pix[lane] > 255 ? 1 : 0; return; }   // ORBX_FAST_STOP: phase timing by truncation (diagnostic, wrong results)
-
-    constexpr int D = P / 4;
-    const int G = (iw + 3) >> 2, RPI = (int)T.rows_per_iter;   // 64 / G, from the tile table: even a wave-uniform division runs on the VALU
-    const uint32_t ut = (uint32_t)iniTh;
-    int gn = 0;
-    {   // stage A: groups whose vertical AND horizontal antipodal pairs cannot both be rejected by the SAD bound
-        const uint32_t rcpG = T.rcp_groups;   // ceil(2^20 / G)
-        const int lrow = (int)(((uint32_t)lane * rcpG) >> 20), lg = lane - lrow * G;
-        const uint8_t *Abase = pix + lrow * P + 4 * lg + 4;
-        const uint32_t ebase = ((uint32_t)lrow << 8) | (uint32_t)(4 * lg);
-        for (int y0 = 0; y0 < ih; y0 += RPI) {
-            const bool act = lrow < RPI && y0 + lrow < ih;
-            const uint32_t *A = reinterpret_cast<const uint32_t *>(Abase + y0 * P);   // row y of the centre row y+3
-            const uint32_t r8 = A[0], r0 = A[6 * D];
-            const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];
-            const uint32_t sv = max(__builtin_amdgcn_sad_u8(cC, r0, 0u), __builtin_amdgcn_sad_u8(cC, r8, 0u));
-            const uint32_t p4 = __builtin_amdgcn_alignbyte(cR, cC, 3), p12 = __builtin_amdgcn_alignbyte(cC, cL, 1);
-            const uint32_t sh = max(__builtin_amdgcn_sad_u8(cC, p4, 0u), __builtin_amdgcn_sad_u8(cC, p12, 0u));
-            const bool keep = act && min(sv, sh) > ut;   // neither pair is "both within t for all four pixels"
-            const unsigned long long b = __ballot(keep);
-            if (keep) gq[gn + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)(ebase + ((uint32_t)y0 << 8));
-            gn += __popcll(b);
-        }
-    }
-    wave_lds_sync();
-    if (dbg_stop == 2) { if (lane == 0) *cnt_out = gn < 0 ? 1 : 0; return; }
-
-    // stage B: the antipodal-pair test of k_fast_wave (at iniTh) on the queued groups, four pixels per lane, row-major queue order
-    int qn = 0;
-    {
-        const u16x2 t2 = as_pk(ut * 0x00010001u);
-        for (int g0 = 0; g0 < gn; g0 += 64) {
-            const int gi = g0 + lane;
-            const bool act = gi < gn;
-            const uint32_t e0 = act ? (uint32_t)gq[gi] : 0u;
-            const int y = (int)(e0 >> 8), x4 = (int)(e0 & 0xff);
-            const uint32_t vmask = 0xfu >> max(x4 + 3 - (iw - 1), 0);   // pixels of the last group beyond the interior
-            const uint32_t *A = reinterpret_cast<const uint32_t *>(pix + y * P + x4 + 4);
-            const uint32_t r8 = A[0], r0 = A[6 * D];
-            const uint32_t aL = A[1 * D - 1], aC = A[1 * D], aR = A[1 * D + 1];
-            const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];
-            const uint32_t bL = A[5 * D - 1], bC = A[5 * D], bR = A[5 * D + 1];
-#define FW_EVEN(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(s) | ((uint32_t)((s) + 2) << 16)))
-#define FW_ODD(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)((s) + 1) | ((uint32_t)((s) + 3) << 16)))
-            const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), FW_EVEN(cR, cC, 3), FW_EVEN(cC, cL, 1), FW_EVEN(bR, bC, 2),
-                                            FW_EVEN(aC, aL, 2), FW_EVEN(aR, aC, 2), FW_EVEN(bC, bL, 2), t2);
-            const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), FW_ODD(cR, cC, 3), FW_ODD(cC, cL, 1), FW_ODD(bR, bC, 2),
-                                            FW_ODD(aC, aL, 2), FW_ODD(aR, aC, 2), FW_ODD(bC, bL, 2), t2);
-#undef FW_EVEN
-#undef FW_ODD
-            uint32_t ze, zo;
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(ze) : "v"(fe), "v"(0x00010001u));
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(zo) : "v"(fo), "v"(0x00010001u));
-            const uint32_t z = ze | (zo << 1);
-            uint32_t m4 = (z | (z >> 14)) & 0xfu;
-            m4 &= act ? vmask : 0u;
-            const int c = __popc(m4);
-            const int incl = wave_incl_scan(c);
-            const int tot = __builtin_amdgcn_readlane(incl, 63);
-            if (qn + tot > qcap) {   // more candidates than the LDS queue holds: the list kernel takes this cell
-                if (lane == 0) list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (uint32_t)tile;
-                return;
-            }
-            int pos = qn + incl - c;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (m4 & (1u << k)) { queue[pos] = (uint16_t)(e0 + k); pos++; }
-            }
-            qn += tot;
-        }
-    }
-    wave_lds_sync();
-    if (dbg_stop == 3) { if (lane == 0) *cnt_out = qn < 0 ? 1 : 0; return; }
-
-    // phase 2: exact score of the queued pixels at iniTh
-    for (int e = lane; e < qn; e += 64) {
-        const int q = queue[e];
-        const int y = q >> 8, x = q & 0xff;
-        int s = fast_score16(pix + (y + 3) * P + x + 4, P);
-        scq[e] = (uint8_t)((s >= iniTh) ? s : 0);
-    }
-    wave_lds_sync();
-    if (dbg_stop == 4) { if (lane == 0) *cnt_out = (int)scq[0] > 255 ? 1 : 0; return; }
-    uint8_t *sco = pix;   // the pixel tile is dead: score tile with a zero apron
-    for (int i = lane; i < (ih + 2) * (P / 4); i += 64) reinterpret_cast<uint32_t *>(sco)[i] = 0;
-    wave_lds_sync();
-    for (int e = lane; e < qn; e += 64) {
-        const int s = scq[e];
-        if (s) { const int q = queue[e]; sco[((q >> 8) + 1) * P + (q & 0xff) + 1] = (uint8_t)s; }
-    }
-    wave_lds_sync();
-
-    // phase 3 + 4: NMS, survivors emitted in row-major order (every survivor scores >= iniTh)
-    uint32_t *slot = cellent + (size_t)f * ent_frame_stride + T.slot;
-    int total = 0;
-    for (int e0 = 0; e0 < qn; e0 += 64) {
-        const int e = e0 + lane;
-        int keep = 0, s = 0, q = 0;
-        if (e < qn) {
-            q = queue[e];
-            s = scq[e];
-            const uint8_t *p = sco + ((q >> 8) + 1) * P + (q & 0xff) + 1;
-            keep = (s > 0) & (s > p[-1]) & (s > p[1]) & (s > p[-P - 1]) & (s > p[-P]) & (s > p[-P + 1]) & (s > p[P - 1]) & (s > p[P]) &
-                   (s > p[P + 1]);
-        }
-        const unsigned long long b = __ballot(keep != 0);
-        if (keep) slot[total + __popcll(b & ((1ull << lane) - 1ull))] = pack_key((q & 0xff) + T.ox, (q >> 8) + T.oy, s);
-        total += __popcll(b);
-    }
-    if (total == 0) {   // cv::FAST(cell, iniThFAST) found nothing: the second pass (:843-846) is the list kernel's
-        if (lane == 0) list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (uint32_t)tile;
-        return;
-    }
-    if (lane == 0) *cnt_out = total;
-}
-
-// W cells per workgroup, one per wave, each wave on its own LDS slice and never synchronising with the others: the work per cell
-// is so short (a few us) that with one-wave workgroups the kernel ran at the workgroup dispatch rate (truncation timing,
-// ORBX_FAST_STOP=1: tile loads alone 99 of 285 us for 665k workgroups)
-template <int P, int W>
-__global__ __launch_bounds__(64 * W) void k_fast_ini(const FastTile *__restrict__ ftiles, const uint8_t *__restrict__ pyr,
-                                                                 size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
-                                                                 uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh, int max_rows,
-                                                                 int qcap, int gcap, uint32_t *__restrict__ list, int32_t *__restrict__ list_count,
-                                                                 int n_frames, int n_tiles, int lds_per_wave, int dbg_stop) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
-    int grp, f;
-    if (!xcd_frame_map(n_frames, &grp, &f)) return;   // a frame's cells stay on one XCD (shared aprons hit its L2)
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = W * grp + wave;
-    if (tile >= n_tiles) return;
-    uint8_t *smem = smem_all + (size_t)wave * lds_per_wave;
-    const FastTile T = ftiles[tile];
-    if (T.cols > 0) fast_tile_load_srd<P>(pyr + (size_t)f * pyr_frame_stride + T.src_off, T.pitch, T.rows, T.cols, smem, lane);   // phase 0
-    wave_lds_sync();
-    fast_ini_body<P>(T, f, tile, smem, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, max_rows, qcap, list, list_count, dbg_stop);
-}
-
-// the cells k_fast_wave appended to its overflow list (more candidates than its LDS queue holds; about 0.5 % of the cells of
-// the EuRoC-like bench), with a queue that holds a whole cell.  grid (any), block 64, LDS for qcap = max interior pixels
+// k_fast_wave_list: the cells k_fast_strip put on its list -- no corner at iniTh (6 % of the cells of the EuRoC-like bench: the reference's
+// second pass, :843-846) or a strip whose queues overflowed -- one wave per cell with the complete ini / min logic of fast_wave_cell and a
+// queue that holds a whole cell.  grid (any), block 64, LDS for qcap = max interior pixels
 template <int P>
 __global__ __launch_bounds__(64) void k_fast_wave_list(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
                                                        const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,

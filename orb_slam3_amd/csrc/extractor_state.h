@@ -117,18 +117,16 @@ struct orbx_extractor {
     size_t pyr_frame = 0, blur_frame = 0, cand_frame = 0, lvl_frame = 0;
     int total_cells = 0, cap = 0, max_pool = 0;
     size_t fast_lds = 0;
-    size_t fast_wave_lds = 0;   // k_fast_wave
-    int fast_ini_qcap = 640, fast_ini_gcap = 16;   // k_fast_ini: pixel queue / group queue capacities
     bool resize_march_ok[orbx::kMaxLevels] = {};   // every tap pair of a dword column of level l within 8 source bytes (k_pyr_resize_march)
     bool fast_strip = false;    // k_fast_strip applies (cells at most 57 px wide, 63 px high)
     int n_strips = 0, strip_rows = 0, n_strips_main = 0, strip_rows_main = 0, strip_gcap = 512, strip_qcap = 816;   // k_fast_strip: strips per frame, tile rows, per-wave group / pixel queue capacities
-    int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qcap = 768, fast_wave_qfull = 16;   // LDS tile pitch (48 / 64), max sub-image rows, queue capacity
+    int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qfull = 16;   // list pass (fast_wave_cell): LDS tile pitch (48 / 64), max sub-image rows, whole-cell queue
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
     bool fast_wave = true;      // every level's cell fits k_fast_wave's fixed LDS pitch
     int n_fast_tiles = 0, n_blur_tiles = 0;
     // device memory
-    DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_ftiles, d_strips, d_blur_tiles, d_dc;
+    DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_tiles, d_dc;
     DevBuf d_pyr, d_blur, d_cellcnt, d_cellent, d_keys0, d_keys1, d_nof0, d_nof1, d_lvlkp, d_lvlcnt, d_candtot, d_work;
     DevBuf d_kps, d_desc, d_count, d_mono, d_err, d_img;
     DevBuf d_mkey1, d_mkey2, d_mocc, d_mentries, d_mprobs, d_mres, d_mscale, d_mgrid;  // batched frame-to-frame matcher scratch

@@ -52,7 +52,51 @@ __host__ __device__ inline size_t fast_strip_lds_bytes(int waves, int max_rows, 
     return (size_t)max_rows * kStripPitch + waves * fast_strip_wave_bytes(gcap, qcap) + (waves * kStripMaxCells + 4) * sizeof(int32_t);
 }
 
-template <int W>   // waves per workgroup = row bands per strip
+// cornerScore of TWO pixels per lane: the 16 circle pixels of both as packed u16 pairs (low half = pixel A, high half = pixel B), the arc
+// minima / maxima by v_pk_minimum3_f16 / v_pk_maximum3_f16 (gfx950) -- three-input, two pixels per instruction, 80 instructions for both
+// pixels where fast_score16 needs 80 for one.  The operands are INTEGERS 0 .. 255 in 16-bit lanes: as f16 bit patterns they are
+// non-negative (sub)normal numbers, whose order is the order of their bit patterns, and minimum / maximum return one of their inputs
+// unchanged (the kernels run with f16 denormals preserved, the AMDGPU default) -- so the result is the integer min / max.
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void fast_score16_x2(const uint8_t *__restrict__ ca, const uint8_t *__restrict__ cb, int pp, int *sa, int *sb) {
+    uint32_t p[16];
+#define FS_P2(k, off) p[k] = (uint32_t)ca[off] | ((uint32_t)cb[off] << 16)
+    FS_P2(0, 3 * pp); FS_P2(1, 3 * pp + 1); FS_P2(2, 2 * pp + 2); FS_P2(3, pp + 3); FS_P2(4, 3); FS_P2(5, -pp + 3); FS_P2(6, -2 * pp + 2);
+    FS_P2(7, -3 * pp + 1); FS_P2(8, -3 * pp); FS_P2(9, -3 * pp - 1); FS_P2(10, -2 * pp - 2); FS_P2(11, -pp - 3); FS_P2(12, -3);
+    FS_P2(13, pp - 3); FS_P2(14, 2 * pp - 2); FS_P2(15, 3 * pp - 1);
+#undef FS_P2
+    uint32_t lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = pk_min3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+        hi3[k] = pk_max3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+    }
+    uint32_t maxmin = 0u, minmax = 0x00ff00ffu;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        const uint32_t a0 = pk_min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+        const uint32_t a1 = pk_min3(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]);
+        const uint32_t b0 = pk_max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+        const uint32_t b1 = pk_max3(hi3[k + 1], hi3[(k + 4) & 15], hi3[(k + 7) & 15]);
+        maxmin = pk_max3(maxmin, a0, a1);
+        minmax = pk_min3(minmax, b0, b1);
+    }
+    const int va = ca[0], vb = cb[0];
+    const int mma = (int)(maxmin & 0xffffu), mmb = (int)(maxmin >> 16), mna = (int)(minmax & 0xffffu), mnb = (int)(minmax >> 16);
+    *sa = max(va - mna, mma - va) - 1;
+    *sb = max(vb - mnb, mmb - vb) - 1;
+}
+
+template <int W, bool X2>   // waves per workgroup = row bands per strip; two pixels per lane in the score stage
 __global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
                                                                  size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
                                                                  uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
@@ -184,7 +228,7 @@ __global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restri
 
     // ---- exact scores of the queued pixels; corners (score >= iniTh) compacted in place, row-major order kept ----
     int nc = 0;
-    if (!over) {
+    if (!over && !X2) {
         for (int e0 = 0; e0 < qn; e0 += 64) {
             const int e = e0 + lane;
             int s = -1, q = 0;
@@ -201,6 +245,29 @@ __global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restri
                 ps[o] = (uint8_t)s;
             }
             nc += __popcll(b);
+        }
+    }
+    if (!over && X2) {   // entries e0 + lane and e0 + 64 + lane of 128 per iteration
+        for (int e0 = 0; e0 < qn; e0 += 128) {
+            const int ea = e0 + lane, eb = e0 + 64 + lane;
+            const int qa = pq[min(ea, qn - 1)], qb = pq[min(eb, qn - 1)];
+            int sa, sb;
+            fast_score16_x2(pix + ((qa >> 8) + 3) * P + (qa & 0xff) + 4, pix + ((qb >> 8) + 3) * P + (qb & 0xff) + 4, P, &sa, &sb);
+            const bool ca = sa >= iniTh && ea < qn, cb = sb >= iniTh && eb < qn;
+            const unsigned long long ba = __ballot(ca), bb = __ballot(cb);
+            __builtin_amdgcn_wave_barrier();   // all 128 entries read before any is overwritten
+            const int na = __popcll(ba);
+            if (ca) {
+                const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba, (uint32_t)nc));
+                pq[o] = (uint16_t)qa;
+                ps[o] = (uint8_t)sa;
+            }
+            if (cb) {
+                const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, (uint32_t)(nc + na)));
+                pq[o] = (uint16_t)qb;
+                ps[o] = (uint8_t)sb;
+            }
+            nc += na + __popcll(bb);
         }
     }
     if (over && lane == 0) *ovf = 1;

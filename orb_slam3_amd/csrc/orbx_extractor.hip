@@ -68,7 +68,7 @@ static const int8_t kPatternData[1024] = {
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
 static inline int cv_round_d(double v) { return (int)lrint(v); }
 
-static const char *kKernelNames[K_COUNT] = {"k_pyr_base", "k_pyr_resize", "k_fast_ini", "k_octree", "k_finalize",
+static const char *kKernelNames[K_COUNT] = {"k_pyr_base", "k_pyr_resize", "k_fast_strip", "k_octree", "k_finalize",
                                             "k_blur", "k_describe", "k_window_best2", "k_greedy_resolve"};
 
 }  // namespace orbx
@@ -86,7 +86,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     std::vector<ResizeTap> xtab, ytab;
     std::vector<ResizeGroup> xgtab;
     std::vector<TileRef> fast_tiles, blur_tiles;
-    std::vector<FastTile> ftiles;
     std::vector<StripTile> strips;
     int strip_rows = 0;
     bool fast_strip = true;
@@ -94,7 +93,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     uint32_t cand_off = 0, lvl_off = 0;
     int cell_base = 0, cap = 0, max_pool = 0;
     size_t fast_lds = 0;
-    int fast_wave_maxw = 0, fast_wave_rows = 0, fast_wave_qfull = 16, fast_ini_gcap = 16;
+    int fast_wave_maxw = 0, fast_wave_rows = 0, fast_wave_qfull = 16;
     bool fast_wave = true;
     for (int l = 0; l < nl; l++) {
         LevelInfo &L = lv[l];
@@ -194,23 +193,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         for (int i = 0; i < L.nRows; i++)
             for (int j = 0; j < L.nCols; j++) {
                 fast_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
-                // the same cell for k_fast_ini, geometry resolved here (ComputeKeyPointsOctTree :805-823)
-                const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
-                const int iniX = kBorder + j * L.wCell, iniY = kBorder + i * L.hCell;
-                const int maxX = std::min(iniX + L.wCell + 6, maxBX), maxY = std::min(iniY + L.hCell + 6, maxBY);
-                const int cols = maxX - iniX, rows = maxY - iniY;
-                const bool skip = iniY >= maxBY - 3 || iniX >= maxBX - 6 || cols - 6 <= 0 || rows - 6 <= 0;
-                FastTile T;
-                memset(&T, 0, sizeof(T));
-                T.src_off = (uint32_t)(L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1);
-                T.pitch = L.pitch;
-                T.cols = (int16_t)(skip ? 0 : cols); T.rows = (int16_t)rows;
-                T.ox = (int16_t)(3 + j * L.wCell); T.oy = (int16_t)(3 + i * L.hCell);
-                T.cell = (uint32_t)(L.cell_base + i * L.nCols + j);
-                T.slot = L.cand_off + (uint32_t)(i * L.nCols + j) * (uint32_t)L.cell_cap;
-                const uint32_t G = (uint32_t)std::max((cols - 6 + 3) >> 2, 1);
-                T.rcp_groups = ((1u << 20) + G - 1u) / G; T.rows_per_iter = 64u / G;
-                ftiles.push_back(T);
             }
         // the same cells as strips of up to floor(256 / wCell) cells for k_fast_strip (fast_strip.hip.h)
         {
@@ -259,7 +241,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         fast_wave_maxw = std::max(fast_wave_maxw, L.wCell);
         fast_wave_rows = std::max(fast_wave_rows, rows);
         fast_wave_qfull = std::max(fast_wave_qfull, (L.wCell * L.hCell + 15) & ~15);
-        fast_ini_gcap = std::max(fast_ini_gcap, (((L.wCell + 3) / 4) * L.hCell + 15) & ~15);
     }
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
 
@@ -277,7 +258,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_ytab, sizeof(ResizeTap) * std::max<size_t>(ytab.size(), 1));
     ENS(ex->d_xgtab, sizeof(ResizeGroup) * std::max<size_t>(xgtab.size(), 1));
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
-    ENS(ex->d_ftiles, sizeof(FastTile) * ftiles.size());
     ENS(ex->d_strips, sizeof(StripTile) * std::max<size_t>(strips.size(), 1));
     ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
     ENS(ex->d_pyr, pyr_off * B);
@@ -305,7 +285,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (!ytab.empty()) ORBX_HIP(hipMemcpy(ex->d_ytab.p, ytab.data(), sizeof(ResizeTap) * ytab.size(), hipMemcpyHostToDevice));
     if (!xgtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xgtab.p, xgtab.data(), sizeof(ResizeGroup) * xgtab.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(ex->d_ftiles.p, ftiles.data(), sizeof(FastTile) * ftiles.size(), hipMemcpyHostToDevice));
     if (!strips.empty()) ORBX_HIP(hipMemcpy(ex->d_strips.p, strips.data(), sizeof(StripTile) * strips.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_tiles.p, blur_tiles.data(), sizeof(TileRef) * blur_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
@@ -315,9 +294,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
     ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave = fast_wave && fast_tiles.size() < 65536 && batch < 65536;
     ex->fast_strip = fast_strip && ex->fast_wave && !strips.empty();
-    { const char *v = getenv("ORBX_FAST_STRIP"); if (v && v[0] == '0') ex->fast_strip = false; }   // TEMPORARY (A/B visit): the per-cell k_fast_ini
-    { const char *v = getenv("ORBX_STRIP_GCAP"); if (v && atoi(v) >= 64) ex->strip_gcap = atoi(v) & ~7; }   // TEMPORARY (A/B visit)
-    { const char *v = getenv("ORBX_STRIP_QCAP"); if (v && atoi(v) >= 64) ex->strip_qcap = atoi(v) & ~15; }  // TEMPORARY (A/B visit)
     // Two launches: the LDS of a workgroup is sized for the tallest strip of its launch, and the few tall strips of the small top levels
     // (cells of up to 63 rows where a level has two or three cell rows) would cost every workgroup an occupancy step.  Main launch = the
     // shortest row count that covers 85 % of the strips; the rest follow in a second launch.
@@ -338,8 +314,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->fast_wave_pitch = (fast_wave_maxw + 7 <= 48) ? 48 : 64;
     ex->fast_wave_rows = fast_wave_rows;
     ex->fast_wave_qfull = fast_wave_qfull;
-    ex->fast_ini_gcap = fast_ini_gcap;
-    ex->fast_wave_lds = fast_wave_lds_bytes(ex->fast_wave_pitch, fast_wave_rows, ex->fast_wave_qcap);
     { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size();
     ex->last_batch = 0;
@@ -405,7 +379,16 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         else ORBX_BLUR_PK(false);
 #undef ORBX_BLUR_PK
     };
-    for (int l = 1; l < nl; l++) {
+    // The chain's small levels in one launch (k_pyr_chain_march): from the first level below 130 k pixels on, when every level from there
+    // on can march and the batch gives the 1024-thread workgroups (one per frame) enough of the machine.
+    int chain_first = nl;
+    static const bool chain_on = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return !(v && v[0] == '0'); }();   // TEMPORARY (A/B visit)
+    static const bool chain_force = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return v && v[0] == 'f'; }();   // TEMPORARY: also for small batches (emulator runs)
+    if (chain_on && (n >= 32 || chain_force)) {
+        for (int l = nl - 1; l >= 1 && ex->resize_march_ok[l] && ex->lv[l].w * ex->lv[l].h < 130000; l--) chain_first = l;
+        if (nl - chain_first < 2) chain_first = nl;
+    }
+    for (int l = 1; l < chain_first; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
         if (ex->resize_march_ok[l]) {
@@ -424,6 +407,23 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,
                            (uint32_t)((0x100000000ull + (uint64_t)wpc - 1) / (uint64_t)wpc), n);
     }
+    if (chain_first < nl) {
+        ProfScope ps(ex, K_PYR_RESIZE);
+        ChainParams cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.first = chain_first; cp.count = nl - chain_first;
+        for (int l = chain_first; l < nl; l++) {
+            const LevelInfo &L = ex->lv[l];
+            ChainLevel &c = cp.lv[l - chain_first];
+            c.nstrips = (L.pitch / 4 + 63) / 64;
+            const int blocks = std::max(1, 16 / c.nstrips);            // one round of the 16 waves where the level allows it
+            c.rb_rows = std::max(8, ((L.h + blocks - 1) / blocks + 3) & ~3);
+            c.n_items = c.nstrips * ((L.h + c.rb_rows - 1) / c.rb_rows);
+            c.nstrips_rcp = (uint32_t)((0x100000000ull + (uint64_t)c.nstrips - 1) / (uint64_t)c.nstrips);
+        }
+        hipLaunchKernelGGL(k_pyr_chain_march<8>, dim3(n), dim3(1024), 0, pst, d_lv, cp, (const ResizeTap *)ex->d_ytab.p,
+                           (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame);
+    }
     auto launch_blur = [&]() -> int {   // one launch over all levels, beside FAST on the aux stream (ORBX_SIDE_STREAMS=0 / profile mode: main stream)
         const bool side = !ex->profile && ex->side_streams;
         hipStream_t bs = side ? ex->aux_stream : st;
@@ -440,52 +440,22 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         // one score map at min(ini, min) serves both passes of :830-846; for ini < min the reference's second pass FAST(min) is a
         // subset of its first, so its result is FAST(ini) alone -- the same as running this stage with min := ini
         const int ini = std::min(std::max(ex->prm.ini_th_fast, 0), 255), mn = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini);
-#define ORBX_FAST_LAUNCH(T)                                                                                                  \
-    hipLaunchKernelGGL(k_fast_cells<T>, dim3(ex->n_fast_tiles, n), dim3(T), ex->fast_lds, st, d_lv,                           \
-                       (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, \
-                       ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn)
-        const size_t ldspad = 0;
-        if (ex->fast_wave) {
+        if (ex->fast_strip) {
             int32_t *ovf_count = (int32_t *)ex->d_fast_ovf.p;
             uint32_t *ovf_list = (uint32_t *)ex->d_fast_ovf.p + 16;
-#define ORBX_FAST_WAVE(PITCH)                                                                                                      \
-    hipLaunchKernelGGL(k_fast_wave<PITCH>, dim3(ex->n_fast_tiles, n), dim3(64), ex->fast_wave_lds + ldspad, st, d_lv,                 \
-                       (const TileRef *)ex->d_fast_tiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,         \
-                       ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qcap, \
-                       ovf_list, ovf_count)
-            const int fast_stop = 0;
-            if (ex->fast_strip) {
-                // first pass of :826 for every cell, one workgroup per strip of cells; cells it leaves empty go to the list pass below
-                // (ini <= min: the second pass is a subset of the first, an empty cell stays empty)
-                static const int sw = [] { const char *v = getenv("ORBX_STRIP_WAVES"); return v ? atoi(v) : 4; }();   // TEMPORARY (A/B visit)
-#define ORBX_FAST_STRIP(WAVES, FIRST, COUNT, ROWS)                                                                                            \
-    hipLaunchKernelGGL(k_fast_strip<WAVES>, xcd_grid(COUNT, n), dim3(64 * WAVES), fast_strip_lds_bytes(WAVES, ROWS, ex->strip_gcap, ex->strip_qcap), \
+            // first pass of :826 for every cell, one workgroup per strip of cells; cells it leaves empty go to the list pass below
+            // (ini <= min: the second pass is a subset of the first, an empty cell stays empty)
+            static const bool x2 = [] { const char *v = getenv("ORBX_FAST_X2"); return v && v[0] == '1'; }();   // TEMPORARY (A/B visit)
+#define ORBX_FAST_STRIP(X2, FIRST, COUNT, ROWS)                                                                                                   \
+    hipLaunchKernelGGL((k_fast_strip<4, X2>), xcd_grid(COUNT, n), dim3(256), fast_strip_lds_bytes(4, ROWS, ex->strip_gcap, ex->strip_qcap),      \
                        st, (const StripTile *)ex->d_strips.p + (FIRST), (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,        \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ROWS, ex->strip_gcap, ex->strip_qcap, ovf_list,       \
                        ovf_count, ini > mn ? 1 : 0, n)
-#define ORBX_FAST_STRIP_W(FIRST, COUNT, ROWS) do { if (sw == 1) ORBX_FAST_STRIP(1, FIRST, COUNT, ROWS); else if (sw == 2) ORBX_FAST_STRIP(2, FIRST, COUNT, ROWS); else ORBX_FAST_STRIP(4, FIRST, COUNT, ROWS); } while (0)
-                const int n_tall = ex->n_strips - ex->n_strips_main;
-                ORBX_FAST_STRIP_W(0, ex->n_strips_main, ex->strip_rows_main);
-                if (n_tall > 0) ORBX_FAST_STRIP_W(ex->n_strips_main, n_tall, ex->strip_rows);
-#undef ORBX_FAST_STRIP_W
+            const int n_tall = ex->n_strips - ex->n_strips_main;
+            if (x2) ORBX_FAST_STRIP(true, 0, ex->n_strips_main, ex->strip_rows_main); else ORBX_FAST_STRIP(false, 0, ex->n_strips_main, ex->strip_rows_main);
+            if (n_tall > 0) { if (x2) ORBX_FAST_STRIP(true, ex->n_strips_main, n_tall, ex->strip_rows); else ORBX_FAST_STRIP(false, ex->n_strips_main, n_tall, ex->strip_rows); }
 #undef ORBX_FAST_STRIP
-            } else if (ini > mn) {
-                // first pass of :826 for every cell (k_fast_ini); cells it leaves empty go to the list pass below
-                const size_t lds_wave = std::max<size_t>((fast_ini_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_ini_qcap, ex->fast_ini_gcap) + 15) & ~(size_t)15,
-                                                          (size_t)48 * ex->fast_wave_pitch);   // fast_tile_load_srd writes 48 rows
-#define ORBX_FAST_INI(PITCH, W)                                                                                                     \
-    hipLaunchKernelGGL((k_fast_ini<PITCH, W>), xcd_grid((ex->n_fast_tiles + W - 1) / W, n), dim3(64 * W), (lds_wave + ldspad) * W, st, \
-                       (const FastTile *)ex->d_ftiles.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,            \
-                       ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->fast_wave_rows, ex->fast_ini_qcap,     \
-                       ex->fast_ini_gcap, ovf_list, ovf_count, n, ex->n_fast_tiles, (int)(lds_wave + ldspad), fast_stop)
-#define ORBX_FAST_INI_P(W) do { if (ex->fast_wave_pitch == 48) ORBX_FAST_INI(48, W); else ORBX_FAST_INI(64, W); } while (0)
-                // cells per workgroup (one wave each; the waves do not synchronise): 4 unless ORBX_FAST_INI_WAVES says otherwise
-                ORBX_FAST_INI_P(4);
-            } else {
-                if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE(48); else ORBX_FAST_WAVE(64);
-            }
-            // cells with more candidates than k_fast_wave's LDS queue holds (about 0.5 % in the EuRoC-like bench): same kernel body,
-            // queue sized for a whole cell
+            // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
     hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(16384), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
@@ -493,8 +463,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                        ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qfull, (const uint32_t *)ovf_list,                  \
                        (const int32_t *)ovf_count)
             if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE_LIST(48); else ORBX_FAST_WAVE_LIST(64);
+#undef ORBX_FAST_WAVE_LIST
+        } else {
+            // a level with cells wider than 57 or higher than 63 pixels (levels under ~100 px): the generic workgroup-per-cell kernel for all
+            hipLaunchKernelGGL(k_fast_cells<64>, dim3(ex->n_fast_tiles, n), dim3(64), ex->fast_lds, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,
+                               (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p,
+                               ex->cand_frame, ini, mn);
         }
-        else ORBX_FAST_LAUNCH(64);
     }
     {
         ProfScope ps(ex, K_OCTREE);
@@ -661,8 +636,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipEventCreate(&ex->ev1);
     (void)hipStreamCreateWithPriority(&ex->copy_stream, hipStreamNonBlocking, prio_lo);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
-    { const char *v = getenv("ORBX_FAST_INI_QCAP"); if (v && atoi(v) >= 16) { ex->fast_ini_qcap = atoi(v) & ~15; ex->strip_qcap = atoi(v) & ~15; } }  // test hook: force the list pass
-    { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 64) ex->fast_wave_qcap = atoi(v) & ~15; }  // test hook: force k_fast_overflow
+    { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 16) ex->strip_qcap = atoi(v) & ~15; }  // test hook: k_fast_strip's pixel queues overflow, every cell takes the list pass
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
     (void)hipStreamCreateWithPriority(&ex->in_stream, hipStreamNonBlocking, prio_hi);
@@ -719,7 +693,7 @@ void orbx_destroy(orbx_extractor *ex) {
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
-                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_ftiles, &ex->d_strips};
+                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_strips};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);

@@ -71,17 +71,6 @@ struct TileRef {  // blockIdx.x -> (level, tile) mapping for multi-level launche
     int16_t pad;
 };
 
-struct FastTile {  // everything k_fast_ini needs of its cell, precomputed per geometry: one 32-byte scalar load, no LevelInfo
-    uint32_t src_off;   // byte offset inside a frame's pyramid slab of the tile's first byte (sub-image column -1)
-    int32_t pitch;      // bytes per padded row of the level
-    int16_t cols, rows; // sub-image size; cols <= 0 marks a cell the reference skips (:813 / :821)
-    int16_t ox, oy;     // level coordinates of interior pixel (0, 0): 3 + tj * wCell, 3 + ti * hCell
-    uint32_t cell;      // index of the cell inside a frame's cell-count array
-    uint32_t slot;      // entry offset of the cell's slot inside a frame's candidate slab
-    uint32_t rcp_groups;  // ceil(2^20 / G), G = dword groups per interior row = (cols - 6 + 3) / 4: lane -> (row, group) without a division
-    uint32_t rows_per_iter;  // 64 / G
-};
-static_assert(sizeof(FastTile) == 32, "FastTile layout");
 
 struct WorkItem {  // one selected keypoint of a frame, in level order, with the constants of its level (k_describe needs no LevelInfo load)
     uint32_t key;     // level coords x,y + score

@@ -19,6 +19,8 @@ REWRITES = [
     (re.compile(r'asm\("v_min3_i32 %0, %1, %2, %3"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);'), r"\1 = std::min(\2, std::min(\3, \4));"),
     (re.compile(r'asm\("v_max3_i32 %0, %1, %2, %3"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);'), r"\1 = std::max(\2, std::max(\3, \4));"),
     (re.compile(r'asm\("v_pk_min_u16 %0, %1, %2"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);'), r"\1 = simt_pk_min_u16(\2, \3);"),
+    (re.compile(r'asm\("v_pk_minimum3_f16 %0, %1, %2, %3"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);'), r"\1 = simt_pk_min3_u16(\2, \3, \4);"),
+    (re.compile(r'asm\("v_pk_maximum3_f16 %0, %1, %2, %3"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);'), r"\1 = simt_pk_max3_u16(\2, \3, \4);"),
     (re.compile(r'asm volatile\(""\s*::[^;]*\);'), ";"),
     # k_describe stores row 31 of the orientation patch into what becomes row 0 of the BRIEF patch and relies on the wave's LDS
     # instructions executing in program order ACROSS lanes (lock step); the emulator's lanes are not in lock step: order the two phases

@@ -392,6 +392,13 @@ inline uint32_t simt_pk_min_u16(uint32_t a, uint32_t b) {
     const uint32_t lo = std::min(a & 0xffffu, b & 0xffffu), hi = std::min(a >> 16, b >> 16);
     return lo | (hi << 16);
 }
+// v_pk_minimum3_f16 / v_pk_maximum3_f16 on the operands the kernels give them: integers 0 .. 255 per half (non-negative f16 bit patterns order like
+// the integers, and minimum / maximum return an input unchanged)
+inline uint32_t simt_pk_min3_u16(uint32_t a, uint32_t b, uint32_t c) { return simt_pk_min_u16(a, simt_pk_min_u16(b, c)); }
+inline uint32_t simt_pk_max3_u16(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t lo = std::max(a & 0xffffu, std::max(b & 0xffffu, c & 0xffffu)), hi = std::max(a >> 16, std::max(b >> 16, c >> 16));
+    return lo | (hi << 16);
+}
 // raw buffer descriptor: base + byte range; a dword load that is not fully inside the range returns 0 without touching memory
 struct simt_rsrc { const uint8_t *base; uint32_t num_records; };
 inline simt_rsrc __builtin_amdgcn_make_buffer_rsrc(void *p, short, int num_records, int) { return simt_rsrc{(const uint8_t *)p, (uint32_t)num_records}; }

@@ -57,6 +57,37 @@ def _check_frame(ex, oex, img, lap, stagewise=True):
     return len(kps)
 
 
+def test_ctor_tables_known_answers():
+    """T1 (ORBextractor.cc:409-469) through the library's own getters, against the analytic vectors of SURVEY.md 8(a) / 8(c): per-level quotas
+    for nFeatures 1000 / 2000 / 1500 / 5 x 1000, the umax disc half-widths, the float scale chain, int(31 * scale) keypoint sizes and the level
+    sizes of the three BASELINE geometries."""
+    import orb_slam3_amd as osa
+    quotas = {1000: [217, 181, 151, 126, 105, 87, 73, 60], 2000: [434, 362, 302, 251, 209, 175, 145, 122], 1500: [326, 271, 226, 189, 157, 131, 109, 91],
+              5000: [1086, 905, 754, 628, 524, 436, 364, 303]}
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    scales = [1.0, 1.2000000477, 1.4400000572, 1.7280001640, 2.0736002922, 2.4883203506, 2.9859845638, 3.5831816196]
+    for nf, want in quotas.items():
+        ex = osa.ORBextractor(nf, 1.2, 8, 20, 7)
+        q, u = ex.feature_tables()
+        assert list(q) == want and sum(want) == nf and list(u) == umax, (nf, list(q), list(u))
+        sf, inv, s2, inv2 = ex.GetScaleFactors(), ex.GetInverseScaleFactors(), ex.GetScaleSigmaSquares(), ex.GetInverseScaleSigmaSquares()
+        assert np.allclose(sf, scales, rtol=0, atol=5e-10 * 4) and sf.dtype == np.float32
+        chain = np.ones(8, np.float32)
+        for i in range(1, 8):
+            chain[i] = np.float32(np.float64(chain[i - 1]) * np.float64(np.float32(1.2)))   # :420: float x double scaleFactor -> float
+        assert sf.tobytes() == chain.tobytes()
+        assert inv.tobytes() == (np.float32(1.0) / chain).tobytes() and s2.tobytes() == (chain * chain).tobytes() and inv2.tobytes() == (np.float32(1.0) / (chain * chain)).tobytes()
+        assert [int(31 * float(x)) for x in sf] == [31, 37, 44, 53, 64, 77, 92, 111]
+        assert ex.GetLevels() == 8 and abs(ex.GetScaleFactor() - 1.2) < 1e-6
+    sizes = {(752, 480): [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)],
+             (1241, 376): [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)],
+             (1024, 1024): [(1024, 1024), (853, 853), (711, 711), (593, 593), (494, 494), (412, 412), (343, 343), (286, 286)]}
+    ex = osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    for shape, want in sizes.items():
+        ex.output_capacity(*shape)
+        assert [tuple(ex.level_size(l, shape)) for l in range(8)] == want, shape
+
+
 def test_small_image_stagewise():
     from orb_slam3_amd import synth
     ex, oex = _pair(500)
@@ -295,8 +326,10 @@ def test_reconfigure_between_shapes(canvas1):
 
 
 def test_alternative_kernel_paths(tmp_path):
-    """k_fast_cells (one 256-thread workgroup per cell, any cell size) is the fallback of the single-wave k_fast_wave, both as
-    a whole (ORBX_FAST_TPB) and per cell through the overflow list (k_fast_overflow, forced with a tiny queue capacity)."""
+    """The paths beside the default one, in child processes (the switches are read once per process): ORBX_FAST_QCAP=48 -- k_fast_strip's
+    pixel queues overflow, so every cell goes through the list pass (fast_wave_cell with the complete ini / min logic);
+    ORBX_OCTREE=seq -- the sequential quad-tree emulation k_octree; ORBX_SIDE_STREAMS=0 -- every kernel on one stream.  The generic
+    k_fast_cells (cells wider than 57 px) is what small images use: tests/test_gpu_extractor.py::test_parameter_sweep, test_small_image_stagewise."""
     import subprocess
     import sys
     from pathlib import Path
@@ -307,20 +340,13 @@ def test_alternative_kernel_paths(tmp_path):
         "import orb_slam3_amd as osa\n"
         "from orb_slam3_amd import synth\n"
         "from oracle import oracle_binding as ob\n"
-        "img = synth.make_test_image(21, 640, 400)\n"
+        "img = synth.make_test_image(21, 752, 480)\n"
         "m, k, d = osa.ORBextractor(800, 1.2, 8, 20, 7)(img, None, (0, 0))\n"
         "om, ok, od = ob.OracleExtractor(800, 1.2, 8, 20, 7).extract(img, lap=(0, 0))\n"
         "assert m == om and np.array_equal(k, ok) and np.array_equal(d, od), (len(k), len(ok))\n"
         "print('same', len(k))\n")
     import os
-    # ORBX_FAST_QCAP=96: most cells overflow k_fast_wave's queue; ORBX_OCTREE=seq: the sequential quad-tree emulation (k_octree);
-    # ORBX_SIDE_STREAMS=0: every kernel on one stream
-    # ORBX_FAST_INI=0: the round-1 single-pass FAST (k_fast_wave) instead of k_fast_ini + list pass; ORBX_FAST_INI_QCAP=48: most cells
-    # overflow k_fast_ini's pixel queue and take the list pass; ORBX_FAST_INI_WAVES: cells (waves) per k_fast_ini workgroup;
-    # ORBX_BLUR_GROUPS=3: k_blur follows the resize chain level by level on the aux stream
-    for extra in ({"ORBX_FAST_TPB": "256"}, {"ORBX_FAST_TPB": "64"}, {"ORBX_FAST_INI": "0"}, {"ORBX_FAST_INI": "0", "ORBX_FAST_QCAP": "96"},
-                  {"ORBX_FAST_INI_QCAP": "48"}, {"ORBX_FAST_INI_WAVES": "1"}, {"ORBX_FAST_INI_WAVES": "8"}, {"ORBX_BLUR_GROUPS": "3"},
-                  {"ORBX_OCTREE": "seq"}, {"ORBX_SIDE_STREAMS": "0"}):
+    for extra in ({"ORBX_FAST_QCAP": "48"}, {"ORBX_OCTREE": "seq"}, {"ORBX_SIDE_STREAMS": "0"}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]

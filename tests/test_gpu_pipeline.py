@@ -33,6 +33,58 @@ def test_bench_shape_pipeline_alternating_inputs(oracle):
     _run_pipeline(oracle, 256, 24)
 
 
+@pytest.mark.parametrize("B", [256, 9])
+def test_every_frame_and_match_vector_of_a_step(oracle, B):
+    """One delivered step compared WHOLE: all B frames (keypoints, descriptors, mono split) and all B - 1 match vectors against the oracle
+    (frame-parallel on the host cores).  The frame index drives the XCD mapping (frame = 8 * blockIdx.z + blockIdx.x for B >= 8), so sampled
+    frames do not cover it; B = 9 leaves the last XCD group with a single frame."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    canvas = synth.make_canvas(10)
+    frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 10000 + t) for t in range(B)])
+    d_frames = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ex = osa.ORBextractor(NF, 1.2, 8, 20, 7)
+    cap = ex.output_capacity(W, H)
+    hs = dict(kps=torch.zeros((B, cap, 28), dtype=torch.uint8).pin_memory(), desc=torch.zeros((B, cap, 32), dtype=torch.uint8).pin_memory(),
+              cnt=torch.zeros(B, dtype=torch.int32).pin_memory(), mono=torch.zeros(B, dtype=torch.int32).pin_memory(),
+              match=torch.zeros((B, cap), dtype=torch.int32).pin_memory(), nm=torch.zeros(B, dtype=torch.int32).pin_memory())
+    for _ in range(2):   # the second step overlaps the first one's matcher and download, as in the streaming loop
+        ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, (0, 1000))
+        ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        ex.download_async(hs["kps"].data_ptr(), hs["desc"].data_ptr(), hs["cnt"].data_ptr(), hs["mono"].data_ptr(), hs["match"].data_ptr(), hs["nm"].data_ptr())
+    ex.download_wait()
+    ex.download_wait()
+    ex.sync()
+    sf = oracle.OracleExtractor(NF, 1.2, 8, 20, 7).tables()["scale"]
+    nt = max(1, min(os.cpu_count() or 1, 64, B))
+
+    def extract_chunk(fs):
+        oex = oracle.OracleExtractor(NF, 1.2, 8, 20, 7)
+        return [(f,) + tuple(oex.extract(frames[f], lap=(0, 1000))) for f in fs]
+
+    with ThreadPoolExecutor(nt) as pool:
+        res = {f: (mono, k, d) for chunk in pool.map(extract_chunk, [list(range(B))[i::nt] for i in range(nt)]) for f, mono, k, d in chunk}
+        for f in range(B):
+            mono, k, d = res[f]
+            n = int(hs["cnt"][f])
+            assert n == len(k) and int(hs["mono"][f]) == mono, (f, n, len(k))
+            assert hs["kps"][f, :n].numpy().tobytes() == k.tobytes() and np.array_equal(hs["desc"][f, :n].numpy(), d), f
+
+        def match_pair(s0):
+            (_, k0, d0), (_, k1, d1) = res[s0], res[s0 + 1]
+            q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"], desc=d0,
+                     has_obs=np.ones(len(k0), np.uint8))
+            on, ocm = oracle.search_by_projection_frame(oracle.OracleGrid(k1, 0.0, float(W), 0.0, float(H)), d1, sf, q, 15.0, 0, True, None, None)
+            return s0, on, ocm, len(k1)
+
+        for s0, on, ocm, n1 in pool.map(match_pair, range(B - 1)):
+            assert int(hs["nm"][s0 + 1]) == on and np.array_equal(hs["match"][s0 + 1, :n1].numpy(), ocm), s0
+
+
 def _run_pipeline(oracle, B, steps, canvas_size=2048, n_shapes=2400):
     import torch
     import orb_slam3_amd as osa
@@ -132,7 +184,7 @@ def test_pipeline_under_alternative_switches():
     import os
     import subprocess
     import sys
-    for extra in ({"ORBX_SIDE_STREAMS": "0"}, {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_INI_QCAP": "48"}):
+    for extra in ({"ORBX_SIDE_STREAMS": "0"}, {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_QCAP": "48"}):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "16", "3"], capture_output=True, text=True, env=dict(os.environ, **extra),
                            timeout=300)
         assert r.returncode == 0 and "pipeline ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-2000:])
