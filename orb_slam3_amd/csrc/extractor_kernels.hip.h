@@ -255,11 +255,16 @@ __device__ __forceinline__ void resize_march_block(const LevelInfo &L, const Lev
     const uint32_t cc[4] = {gc.x, gc.y, gc.z, gc.w};
     constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
     const int y0 = rb * rb_rows, y1 = min(y0 + rb_rows, L.h);
-    const ResizeTap *yt = ytab + L.ytab_off;
+    // the row taps of the whole block in ONE vector load (lane i holds row y0 + i; rb_rows <= 64), read back with v_readlane: a scalar load
+    // per output row sat in the middle of the emit loop's dependence chain (16 - 32 exposed round trips per block)
+    const uint2 ytl = *reinterpret_cast<const uint2 *>(ytab + L.ytab_off + min(y0 + lane, L.h - 1));
+#define RM_TAP_OFS(i) __builtin_amdgcn_readlane((int)ytl.x, (i))
+#define RM_TAP_CC(i) ((uint32_t)__builtin_amdgcn_readlane((int)ytl.y, (i)))
     int r = y0;
-    ResizeTap ty = yt[r], tyn = yt[min(r + 1, L.h - 1)];
-    int s = ty.ofs;                                   // next source row to fetch
-    const int s_last = yt[y1 - 1].ofs + 1;            // last source row the block needs
+    int ty_ofs = RM_TAP_OFS(0);
+    uint32_t ty_cc = RM_TAP_CC(0);
+    int s = ty_ofs;                                   // next source row to fetch
+    const int s_last = RM_TAP_OFS(y1 - 1 - y0) + 1;   // last source row the block needs
     const int hmax = P.h - 1;
     uint2 cur[CH], nxt[CH];
     uint32_t Hp[4] = {0u, 0u, 0u, 0u};
@@ -280,9 +285,9 @@ __device__ __forceinline__ void resize_march_block(const LevelInfo &L, const Lev
 #pragma unroll
         for (int k = 0; k < CH; k++) {
             // the output row whose source rows are (s + k - 1, s + k), if there is one (at most one: the scale factor is >= 1)
-            if (r < y1 && ty.ofs + 1 == s + k) {   // wave-uniform
+            if (r < y1 && ty_ofs + 1 == s + k) {   // wave-uniform
                 const uint32_t *A = k == 0 ? Hp : H[k == 0 ? 0 : k - 1], *B = H[k];
-                const uint32_t b0 = (uint32_t)ty.c0, b1 = (uint32_t)ty.c1;
+                const uint32_t b0 = ty_cc & 0xffffu, b1 = ty_cc >> 16;   // c0 | c1 << 16: bilinear tap pair, 0 <= b <= 2048
                 int t[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -297,8 +302,8 @@ __device__ __forceinline__ void resize_march_block(const LevelInfo &L, const Lev
                     if (r <= L.h - 2 && r >= L.h - 1 - kEdge) *reinterpret_cast<uint32_t *>(dcol + (size_t)(uint32_t)((kEdge + 2 * (L.h - 1) - r) * L.pitch)) = o;   // ring below
                 }
                 r++;
-                ty = tyn;
-                tyn = yt[min(r + 1, L.h - 1)];
+                ty_ofs = RM_TAP_OFS(min(r, y1 - 1) - y0);
+                ty_cc = RM_TAP_CC(min(r, y1 - 1) - y0);
             }
         }
 #pragma unroll
@@ -308,6 +313,8 @@ __device__ __forceinline__ void resize_march_block(const LevelInfo &L, const Lev
         s += CH;
         if (s > s_last + CH) break;   // cannot happen with monotone row taps; never spin on a bad table
     }
+#undef RM_TAP_OFS
+#undef RM_TAP_CC
 }
 
 template <int CH>
@@ -320,28 +327,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize_march(const LevelInfo L, con
     const int item = bx * 4 + wave;
     if (item >= n_items) return;
     resize_march_block<CH>(L, P, ytab, xg, pyr + (size_t)f * pyr_frame_stride, rb_rows, nstrips, nstrips_rcp, item, lane);
-}
-
-// k_pyr_chain_march: the SMALL levels of the chain (from the first level whose launch is bound by the lifetime of one wave, not by its
-// pixels: at EuRoC size levels 3 .. 7 hold 22 % of the chain's pixels and took 111 of its 204 us) in ONE launch: a 1024-thread
-// workgroup per frame walks the levels, its 16 waves share the blocks of a level, a workgroup barrier separates the levels (a frame's
-// levels are produced and consumed by the same CU; the stores are made visible with a workgroup-scope fence before the barrier).
-// grid (B), block 1024
-struct ChainLevel { int32_t rb_rows, nstrips, n_items; uint32_t nstrips_rcp; };
-struct ChainParams { int32_t first, count; ChainLevel lv[kMaxLevels]; };
-template <int CH>
-__global__ __launch_bounds__(1024) void k_pyr_chain_march(const LevelInfo *__restrict__ lv, const ChainParams cp, const ResizeTap *__restrict__ ytab,
-                                                          const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr, size_t pyr_frame_stride) {
-    uint8_t *frame = pyr + (size_t)blockIdx.x * pyr_frame_stride;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = 0; i < cp.count; i++) {
-        const int l = cp.first + i;
-        const LevelInfo L = lv[l], P = lv[l - 1];
-        const ChainLevel c = cp.lv[i];
-        for (int item = wave; item < c.n_items; item += 16) resize_march_block<CH>(L, P, ytab, xg, frame, c.rb_rows, c.nstrips, c.nstrips_rcp, item, lane);
-        __threadfence_block();
-        __syncthreads();
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1058,6 +1043,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// a pointer the program knows to be wave-uniform, made provably so for the compiler (buffer descriptors must live in SGPRs)
+__device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (const uint8_t *)(((uint64_t)hi << 32) | lo);
+}
+
 struct DescConst {
     int8_t vmax_of_u[16];              // orientation disc: largest |v| with umax[|v|] >= |u|
     int8_t pat[1024];                  // bit_pattern_31_ (x0,y0,x1,y1) x 256
@@ -1076,7 +1068,6 @@ constexpr int kDescWaveLds = kDescAP * kDescAR + kDescBP * kDescBR + 12;  // 288
 //   disc  : lane = column u of the orientation disc, 31 row steps; per-half totals from one wave prefix sum (lanes 31 and 63)
 //   brief : lane i of a half evaluates pattern pairs i, i + 32, ..., i + 224; each of the 8 ballots holds one dword of BOTH descriptors
 //   the two branches of fastAtan2 / sincosf become selects (glibc_sincosf, fast_atan2_deg: bit-identical, checked on the CPU)
-// Patches are staged by plain loads (a frame-uniform base + a 32-bit lane offset; every patch lies inside the padded level).
 // grid xcd_grid(ceil(cap / 8), B), block 256
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
@@ -1106,27 +1097,33 @@ __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ 
     // ---- both patches of both keypoints: 16 lanes per row, 2 rows per step and half, every load issued before the first LDS store ----
     const int axA = (kx - kHalfPatch) & 3, axB = (kx - 18) & 3;
     {
-        const uint8_t *fp = pyr + (size_t)f * pyr_frame_stride, *fb = blur + (size_t)f * blur_frame_stride;   // wave-uniform bases
+        // through one buffer descriptor per slab of the FRAME (wave-uniform; the two halves address different levels through their 32-bit
+        // offsets): a lane that has nothing to fetch -- columns past the patch width, the odd half's row past the last one -- gets an offset
+        // outside the descriptor's range (no memory access, no per-load predicate, no zero-filled registers)
+        const auto srdA = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(pyr + (size_t)f * pyr_frame_stride), 0, (int)min(pyr_frame_stride, (size_t)0x7fffffff), 0x00020000);
+        const auto srdB = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(blur + (size_t)f * blur_frame_stride), 0, (int)min(blur_frame_stride, (size_t)0x7fffffff), 0x00020000);
         const int c = hl & 15, r0 = hl >> 4;
-        const uint32_t offA = w.off + (uint32_t)((kEdge + ky - kHalfPatch + r0) * pitch + kRoiX + (kx - kHalfPatch - axA) + 4 * c);
-        const uint32_t offB = w.boff + (uint32_t)((ky - 18 + r0) * bpitch + (kx - 18 - axB) + 4 * c);
+        constexpr uint32_t kOut = 0x80000000u;
+        const uint32_t offA = (c < 9 ? 0u : kOut) + w.off + (uint32_t)((kEdge + ky - kHalfPatch + r0) * pitch + kRoiX + (kx - kHalfPatch - axA) + 4 * c);
+        const uint32_t offB = (c < 10 ? 0u : kOut) + w.boff + (uint32_t)((ky - 18 + r0) * bpitch + (kx - 18 - axB) + 4 * c);
+        const uint32_t last = r0 == 0 ? 0u : kOut;   // rows 30 (A) and 36 (B) exist for the even half only
         uint32_t va[16], vb[19];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            va[k] = 0;
-            if (c < 9 && r0 + 2 * k < kDescAR) va[k] = *reinterpret_cast<const uint32_t *>(fp + (offA + (uint32_t)(2 * k * pitch)));
+        for (int k = 0; k < 16; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(srdA, (int)((offA + (uint32_t)(2 * k * pitch)) | (k == 15 ? last : 0u)), 0, 0);
+#pragma unroll
+        for (int k = 0; k < 19; k++) vb[k] = __builtin_amdgcn_raw_buffer_load_b32(srdB, (int)((offB + (uint32_t)(2 * k * bpitch)) | (k == 18 ? last : 0u)), 0, 0);
+        if (c < 9) {
+            uint8_t *d = A + r0 * kDescAP + 4 * c;
+#pragma unroll
+            for (int k = 0; k < 15; k++) *reinterpret_cast<uint32_t *>(d + 2 * k * kDescAP) = va[k];
+            if (r0 == 0) *reinterpret_cast<uint32_t *>(d + 30 * kDescAP) = va[15];
         }
+        if (c < 10) {
+            uint8_t *d = Bp + r0 * kDescBP + 4 * c;
 #pragma unroll
-        for (int k = 0; k < 19; k++) {
-            vb[k] = 0;
-            if (c < 10 && r0 + 2 * k < kDescBR) vb[k] = *reinterpret_cast<const uint32_t *>(fb + (offB + (uint32_t)(2 * k * bpitch)));
+            for (int k = 0; k < 18; k++) *reinterpret_cast<uint32_t *>(d + 2 * k * kDescBP) = vb[k];
+            if (r0 == 0) *reinterpret_cast<uint32_t *>(d + 36 * kDescBP) = vb[18];
         }
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (c < 9 && r0 + 2 * k < kDescAR) *reinterpret_cast<uint32_t *>(A + (r0 + 2 * k) * kDescAP + 4 * c) = va[k];
-#pragma unroll
-        for (int k = 0; k < 19; k++)
-            if (c < 10 && r0 + 2 * k < kDescBR) *reinterpret_cast<uint32_t *>(Bp + (r0 + 2 * k) * kDescBP + 4 * c) = vb[k];
     }
     wave_lds_sync();
 

@@ -12,7 +12,8 @@
 //            within t of all four centres no 9-arc exists); lanes = groups of 64 / G whole rows (G = groups per row), every wave
 //            on its own band of rows; surviving groups queued row-major (ballot + mbcnt)
 //   stage B  the four-antipodal-pair test on the queued groups only (packed u16, both polarities); passing pixels queued row-major
-//   scores   exact cornerScore of the queued pixels; corners (score >= t) compacted in place                      | barrier
+//   scores   exact cornerScore of the queued pixels, TWO per lane on packed u16 halves (v_pk_minimum3 / maximum3_f16, fast_score16_x2);
+//            corners (score >= t) compacted in place                                                             | barrier
 //   NMS      the pixel tile is dead: each wave zeroes its band of the score tile and scatters its corners into it, with one ZERO
 //            COLUMN between adjacent cells -- cv::FAST runs per cell sub-image, so a neighbour in another cell scores 0 (the
 //            strip's rows belong to one cell row, the apron rows are zero)                                         | barrier
@@ -96,7 +97,7 @@ __device__ __forceinline__ void fast_score16_x2(const uint8_t *__restrict__ ca, 
     *sb = max(vb - mnb, mmb - vb) - 1;
 }
 
-template <int W, bool X2>   // waves per workgroup = row bands per strip; two pixels per lane in the score stage
+template <int W>   // waves per workgroup = row bands per strip
 __global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
                                                                  size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
                                                                  uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
@@ -228,26 +229,7 @@ __global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restri
 
     // ---- exact scores of the queued pixels; corners (score >= iniTh) compacted in place, row-major order kept ----
     int nc = 0;
-    if (!over && !X2) {
-        for (int e0 = 0; e0 < qn; e0 += 64) {
-            const int e = e0 + lane;
-            int s = -1, q = 0;
-            if (e < qn) {
-                q = pq[e];
-                s = fast_score16(pix + ((q >> 8) + 3) * P + (q & 0xff) + 4, P);
-            }
-            const bool corner = s >= iniTh;
-            const unsigned long long b = __ballot(corner);
-            __builtin_amdgcn_wave_barrier();   // every lane has read its entry before any lane overwrites one (nc + rank <= e)
-            if (corner) {
-                const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, (uint32_t)nc));
-                pq[o] = (uint16_t)q;
-                ps[o] = (uint8_t)s;
-            }
-            nc += __popcll(b);
-        }
-    }
-    if (!over && X2) {   // entries e0 + lane and e0 + 64 + lane of 128 per iteration
+    if (!over) {   // exact scores, two queue entries per lane: e0 + lane and e0 + 64 + lane of 128 per iteration
         for (int e0 = 0; e0 < qn; e0 += 128) {
             const int ea = e0 + lane, eb = e0 + 64 + lane;
             const int qa = pq[min(ea, qn - 1)], qb = pq[min(eb, qn - 1)];

@@ -379,16 +379,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         else ORBX_BLUR_PK(false);
 #undef ORBX_BLUR_PK
     };
-    // The chain's small levels in one launch (k_pyr_chain_march): from the first level below 130 k pixels on, when every level from there
-    // on can march and the batch gives the 1024-thread workgroups (one per frame) enough of the machine.
-    int chain_first = nl;
-    static const bool chain_on = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return !(v && v[0] == '0'); }();   // TEMPORARY (A/B visit)
-    static const bool chain_force = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return v && v[0] == 'f'; }();   // TEMPORARY: also for small batches (emulator runs)
-    if (chain_on && (n >= 32 || chain_force)) {
-        for (int l = nl - 1; l >= 1 && ex->resize_march_ok[l] && ex->lv[l].w * ex->lv[l].h < 130000; l--) chain_first = l;
-        if (nl - chain_first < 2) chain_first = nl;
-    }
-    for (int l = 1; l < chain_first; l++) {
+    for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
         if (ex->resize_march_ok[l]) {
@@ -406,23 +397,6 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         hipLaunchKernelGGL(k_pyr_resize2, grid2, dim3(256), 0, pst, L, ex->lv[l - 1], (const ResizeTap *)ex->d_xtab.p,
                            (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame,
                            (uint32_t)((0x100000000ull + (uint64_t)wpc - 1) / (uint64_t)wpc), n);
-    }
-    if (chain_first < nl) {
-        ProfScope ps(ex, K_PYR_RESIZE);
-        ChainParams cp;
-        memset(&cp, 0, sizeof(cp));
-        cp.first = chain_first; cp.count = nl - chain_first;
-        for (int l = chain_first; l < nl; l++) {
-            const LevelInfo &L = ex->lv[l];
-            ChainLevel &c = cp.lv[l - chain_first];
-            c.nstrips = (L.pitch / 4 + 63) / 64;
-            const int blocks = std::max(1, 16 / c.nstrips);            // one round of the 16 waves where the level allows it
-            c.rb_rows = std::max(8, ((L.h + blocks - 1) / blocks + 3) & ~3);
-            c.n_items = c.nstrips * ((L.h + c.rb_rows - 1) / c.rb_rows);
-            c.nstrips_rcp = (uint32_t)((0x100000000ull + (uint64_t)c.nstrips - 1) / (uint64_t)c.nstrips);
-        }
-        hipLaunchKernelGGL(k_pyr_chain_march<8>, dim3(n), dim3(1024), 0, pst, d_lv, cp, (const ResizeTap *)ex->d_ytab.p,
-                           (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame);
     }
     auto launch_blur = [&]() -> int {   // one launch over all levels, beside FAST on the aux stream (ORBX_SIDE_STREAMS=0 / profile mode: main stream)
         const bool side = !ex->profile && ex->side_streams;
@@ -445,15 +419,14 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             uint32_t *ovf_list = (uint32_t *)ex->d_fast_ovf.p + 16;
             // first pass of :826 for every cell, one workgroup per strip of cells; cells it leaves empty go to the list pass below
             // (ini <= min: the second pass is a subset of the first, an empty cell stays empty)
-            static const bool x2 = [] { const char *v = getenv("ORBX_FAST_X2"); return v && v[0] == '1'; }();   // TEMPORARY (A/B visit)
-#define ORBX_FAST_STRIP(X2, FIRST, COUNT, ROWS)                                                                                                   \
-    hipLaunchKernelGGL((k_fast_strip<4, X2>), xcd_grid(COUNT, n), dim3(256), fast_strip_lds_bytes(4, ROWS, ex->strip_gcap, ex->strip_qcap),      \
-                       st, (const StripTile *)ex->d_strips.p + (FIRST), (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,        \
+#define ORBX_FAST_STRIP(FIRST, COUNT, ROWS)                                                                                                       \
+    hipLaunchKernelGGL(k_fast_strip<4>, xcd_grid(COUNT, n), dim3(256), fast_strip_lds_bytes(4, ROWS, ex->strip_gcap, ex->strip_qcap), st,        \
+                       (const StripTile *)ex->d_strips.p + (FIRST), (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p,            \
                        ex->total_cells, (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ROWS, ex->strip_gcap, ex->strip_qcap, ovf_list,       \
                        ovf_count, ini > mn ? 1 : 0, n)
             const int n_tall = ex->n_strips - ex->n_strips_main;
-            if (x2) ORBX_FAST_STRIP(true, 0, ex->n_strips_main, ex->strip_rows_main); else ORBX_FAST_STRIP(false, 0, ex->n_strips_main, ex->strip_rows_main);
-            if (n_tall > 0) { if (x2) ORBX_FAST_STRIP(true, ex->n_strips_main, n_tall, ex->strip_rows); else ORBX_FAST_STRIP(false, ex->n_strips_main, n_tall, ex->strip_rows); }
+            ORBX_FAST_STRIP(0, ex->n_strips_main, ex->strip_rows_main);
+            if (n_tall > 0) ORBX_FAST_STRIP(ex->n_strips_main, n_tall, ex->strip_rows);
 #undef ORBX_FAST_STRIP
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
