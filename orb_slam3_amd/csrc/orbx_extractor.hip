@@ -850,15 +850,35 @@ int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *d
     // keypoints and descriptors leave as soon as the extraction is done, BESIDE the matcher (they are 94 % of the bytes and the matcher
     // does not write them); only the match vectors wait for it.  With the wait in front of everything the next batch's k_finalize sat
     // behind matcher + all copies in series (ORBX_COPY_AFTER_MATCH=1 restores that order).
-    if (counts) ORBX_HIP(hipMemcpyAsync(counts, ex->d_count.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
-    if (mono) ORBX_HIP(hipMemcpyAsync(mono, ex->d_mono.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
-    if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
-    if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, cs));
-    if (ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
-    if (match && ex->d_match.p) ORBX_HIP(hipMemcpyAsync(match, ex->d_match.p, 4 * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
-    if (nmatches && ex->d_nmatch.p) ORBX_HIP(hipMemcpyAsync(nmatches, ex->d_nmatch.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
+    // k_copy_out instead of hipMemcpyAsync (which runs as a machine-filling blit kernel here, see the kernel's comment): two launches, the
+    // match vectors behind the matcher's event.  A host buffer without a device-visible address (hipHostRegister without the mapped flag)
+    // falls back to hipMemcpyAsync.
+    static const int copy_blocks = [] { const char *v = getenv("ORBX_COPY_BLOCKS"); return v ? atoi(v) : 16; }();   // TEMPORARY (A/B visit): 0 = hipMemcpyAsync
     const unsigned slot = ex->copy_issued & 1;
-    ORBX_HIP(hipMemcpyAsync(ex->h_err + slot, ex->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, cs));
+    auto put = [&](CopySegs &S, void *h_dst, const void *d_src, size_t bytes) -> int {
+        if (!h_dst || !d_src || bytes == 0) return ORBX_OK;
+        void *dv = nullptr;
+        if (copy_blocks > 0 && hipHostGetDevicePointer(&dv, h_dst, 0) == hipSuccess && dv) {
+            S.s[S.n].src = (const uint8_t *)d_src; S.s[S.n].dst = (uint8_t *)dv; S.s[S.n].bytes = bytes; S.n++;
+        } else {
+            (void)hipGetLastError();
+            ORBX_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, cs));
+        }
+        return ORBX_OK;
+    };
+    int rc;
+    CopySegs S1; S1.n = 0;
+    if ((rc = put(S1, counts, ex->d_count.p, 4 * (size_t)n)) != ORBX_OK) return rc;
+    if ((rc = put(S1, mono, ex->d_mono.p, 4 * (size_t)n)) != ORBX_OK) return rc;
+    if ((rc = put(S1, kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n)) != ORBX_OK) return rc;
+    if ((rc = put(S1, desc, ex->d_desc.p, (size_t)32 * ex->cap * n)) != ORBX_OK) return rc;
+    if (S1.n > 0) hipLaunchKernelGGL(k_copy_out, dim3(copy_blocks), dim3(256), 0, cs, S1);
+    if (ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
+    CopySegs S2; S2.n = 0;
+    if (ex->d_match.p && (rc = put(S2, match, ex->d_match.p, 4 * (size_t)ex->cap * n)) != ORBX_OK) return rc;
+    if (ex->d_nmatch.p && (rc = put(S2, nmatches, ex->d_nmatch.p, 4 * (size_t)n)) != ORBX_OK) return rc;
+    if ((rc = put(S2, ex->h_err + slot, ex->d_err.p, sizeof(int32_t))) != ORBX_OK) return rc;
+    if (S2.n > 0) hipLaunchKernelGGL(k_copy_out, dim3(copy_blocks), dim3(256), 0, cs, S2);
     ORBX_HIP(hipEventRecord(ex->ev_copy_done[slot], cs));
     ex->copy_issued++;
     ex->copy_pending = true;

@@ -69,6 +69,7 @@ inline hipError_t hipMalloc(void **p, size_t n) {
 }
 inline hipError_t hipFree(void *p) { simt::sync_all(); free(p); return hipSuccess; }   // hipFree synchronises the device
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }   // "device" memory is host memory here
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
