@@ -1043,38 +1043,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// k_copy_out: the results of a batch to pinned HOST memory, by a SMALL grid.  hipMemcpyAsync device -> host runs here as a blit kernel
-// (__amd_rocclr_copyBuffer) that fills the machine with waves stalled on PCIe writes: beside it k_window_best2 took 376 instead of 76 us
-// and the next batch's k_pyr_base 358 instead of 54 us (profiles/r03_g_timeline_before.txt).  The link needs little parallelism (53 GB/s,
-// a few hundred KB in flight); a few workgroups writing 16 bytes per lane and four stores per thread in flight move the same bytes in
-// the same time and leave the CUs to the kernels that run beside the copy.  Segments: device source, host destination (the pinned buffer's
-// device-visible address), bytes; 16-byte aligned pairs go by uint4, the rest by bytes.
-// grid (kCopyOutBlocks), block 256
-// ---------------------------------------------------------------------------------------------------------
-struct CopySeg { const uint8_t *src; uint8_t *dst; uint64_t bytes; };
-struct CopySegs { CopySeg s[8]; int32_t n; };
-__global__ __launch_bounds__(256) void k_copy_out(const CopySegs segs) {
-    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
-    for (int i = 0; i < segs.n; i++) {
-        const CopySeg g = segs.s[i];
-        if ((((uintptr_t)g.src | (uintptr_t)g.dst) & 15) == 0) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(g.src);
-            uint4 *dst = reinterpret_cast<uint4 *>(g.dst);
-            const size_t n16 = g.bytes >> 4;
-            size_t k = tid;
-            for (; k + 3 * nthr < n16; k += 4 * nthr) {   // four loads, then four stores
-                const uint4 a = src[k], b = src[k + nthr], c = src[k + 2 * nthr], d = src[k + 3 * nthr];
-                dst[k] = a; dst[k + nthr] = b; dst[k + 2 * nthr] = c; dst[k + 3 * nthr] = d;
-            }
-            for (; k < n16; k += nthr) dst[k] = src[k];
-            for (size_t t = (n16 << 4) + tid; t < g.bytes; t += nthr) g.dst[t] = g.src[t];
-        } else {
-            for (size_t t = tid; t < g.bytes; t += nthr) g.dst[t] = g.src[t];
-        }
-    }
-}
-
 // a pointer the program knows to be wave-uniform, made provably so for the compiler (buffer descriptors must live in SGPRs)
 __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p) {
     const uint64_t a = (uint64_t)p;

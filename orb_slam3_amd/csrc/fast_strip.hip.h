@@ -29,7 +29,12 @@
 
 namespace orbx {
 
-constexpr int kStripPitch = 272;   // LDS bytes per tile row: 4 + 256 interior + 4, rounded up to 16
+// LDS bytes per tile row: 4 + interior + 4, rounded up to 16.  Three tile shapes share one launch (and one LDS budget per workgroup): strips of
+// tall cells (the top pyramid levels: a level with two or three cell rows has cells of up to 63 px) are cut narrower, so that rows x pitch
+// stays inside the budget that the ordinary 44 - 46-row strips of 7 cells set -- a taller tile would cost EVERY workgroup an occupancy step
+constexpr int kStripPitch = 272;   // interior <= 256
+constexpr int kStripPitchMid = 208, kStripPitchLow = 144;   // interior <= 192 / <= 128
+__host__ __device__ inline int strip_max_interior(int pitch) { return pitch == kStripPitch ? 256 : pitch == kStripPitchMid ? 192 : 128; }
 constexpr int kStripMaxCells = 8;  // floor(256 / 35) = 7 cells at most
 
 struct StripTile {   // one strip, precomputed per geometry (48 bytes, scalar loads)
@@ -43,14 +48,15 @@ struct StripTile {   // one strip, precomputed per geometry (48 bytes, scalar lo
     uint32_t rcp_wcell;    // ceil(2^16 / wCell): cell of interior column x = (x * rcp_wcell) >> 16  (exact for x < 256, wCell < 256)
     uint32_t rcp_groups;   // ceil(2^20 / G), G = (iw + 3) / 4 dword groups per interior row: lane -> (row, group) without a division
     uint16_t rows_per_iter, ncell;   // 64 / G rows per stage-A iteration; cells in the strip
-    uint32_t pad[2];
+    uint32_t lds_pitch;    // kStripPitch / kStripPitchMid / kStripPitchLow
+    uint32_t pad;
 };
 static_assert(sizeof(StripTile) == 48, "StripTile layout");
 
 // per wave: group queue u16[gcap] (dead after stage B: the scores u8[qcap] of the pixel queue reuse its bytes, qcap <= 2 gcap) | pixel queue u16[qcap]
 __host__ __device__ inline size_t fast_strip_wave_bytes(int gcap, int qcap) { return ((size_t)gcap * 2 + (size_t)qcap * 2 + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t fast_strip_lds_bytes(int waves, int max_rows, int gcap, int qcap) {
-    return (size_t)max_rows * kStripPitch + waves * fast_strip_wave_bytes(gcap, qcap) + (waves * kStripMaxCells + 4) * sizeof(int32_t);
+__host__ __device__ inline size_t fast_strip_lds_bytes(int waves, int pix_bytes, int gcap, int qcap) {
+    return (size_t)pix_bytes + waves * fast_strip_wave_bytes(gcap, qcap) + (waves * kStripMaxCells + 4) * sizeof(int32_t);
 }
 
 // cornerScore of TWO pixels per lane: the 16 circle pixels of both as packed u16 pairs (low half = pixel A, high half = pixel B), the arc
@@ -97,25 +103,20 @@ __device__ __forceinline__ void fast_score16_x2(const uint8_t *__restrict__ ca, 
     *sb = max(vb - mnb, mmb - vb) - 1;
 }
 
-template <int W>   // waves per workgroup = row bands per strip
-__global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
-                                                                 size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
-                                                                 uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
-                                                                 int max_rows, int gcap, int qcap, uint32_t *__restrict__ list,
-                                                                 int32_t *__restrict__ list_count, int second_pass, int n_frames) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int P = kStripPitch, D = P / 4;
-    int tile, f;
-    if (!xcd_frame_map(n_frames, &tile, &f)) return;   // a frame's strips stay on one XCD (apron rows hit its L2)
+template <int W, int P>   // W waves per workgroup = row bands per strip; P = LDS pitch of the tile
+__device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f, uint8_t *smem, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent, size_t ent_frame_stride,
+                                                int iniTh, int pix_bytes, int gcap, int qcap, uint32_t *__restrict__ list, int32_t *__restrict__ list_count,
+                                                int second_pass) {
+    constexpr int D = P / 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const StripTile T = tiles[tile];
     const int iw = T.iw, ih = T.ih, rows = ih + 6;
     uint8_t *pix = smem;
-    uint8_t *wbase = smem + (size_t)max_rows * P + (size_t)wave * fast_strip_wave_bytes(gcap, qcap);
+    uint8_t *wbase = smem + (size_t)pix_bytes + (size_t)wave * fast_strip_wave_bytes(gcap, qcap);
     uint16_t *gq = reinterpret_cast<uint16_t *>(wbase);          // group queue
     uint16_t *pq = gq + gcap;                                     // pixel queue -> corners -> survivors (compacted in place)
     uint8_t *ps = reinterpret_cast<uint8_t *>(gq);                // score per pixel-queue entry, written when the group queue is dead
-    int32_t *cnt = reinterpret_cast<int32_t *>(smem + (size_t)max_rows * P + W * fast_strip_wave_bytes(gcap, qcap));   // [W][8] survivors per (wave, cell)
+    int32_t *cnt = reinterpret_cast<int32_t *>(smem + (size_t)pix_bytes + W * fast_strip_wave_bytes(gcap, qcap));   // [W][8] survivors per (wave, cell)
     int32_t *ovf = cnt + W * kStripMaxCells;
     if (threadIdx.x == 0) *ovf = 0;
 
@@ -335,6 +336,23 @@ __global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restri
         if (total > 0 || !second_pass) cellcnt[(size_t)f * total_cells + T.cell0 + lane] = total;
         else list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + lane);   // cv::FAST(cell, iniThFAST) found nothing: second pass (:843-846)
     }
+}
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
+                                                       size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
+                                                       uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
+                                                       int pix_bytes, int gcap, int qcap, uint32_t *__restrict__ list,
+                                                       int32_t *__restrict__ list_count, int second_pass, int n_frames) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int tile, f;
+    if (!xcd_frame_map(n_frames, &tile, &f)) return;   // a frame's strips stay on one XCD (apron rows hit its L2)
+    const StripTile T = tiles[tile];
+#define ORBX_STRIP_BODY(PITCH) fast_strip_body<W, PITCH>(T, f, smem, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, pix_bytes, gcap, qcap, list, list_count, second_pass)
+    if (T.lds_pitch == (uint32_t)kStripPitch) ORBX_STRIP_BODY(kStripPitch);          // wave-uniform
+    else if (T.lds_pitch == (uint32_t)kStripPitchMid) ORBX_STRIP_BODY(kStripPitchMid);
+    else ORBX_STRIP_BODY(kStripPitchLow);
+#undef ORBX_STRIP_BODY
 }
 
 }  // namespace orbx
