@@ -388,6 +388,50 @@ __device__ __forceinline__ int fast_score16(const uint8_t *__restrict__ c, int p
     return max(v - minmax, maxmin - v) - 1;
 }
 
+// cornerScore of TWO pixels per lane: the 16 circle pixels of both as packed u16 pairs (low half = pixel A, high half = pixel B), the arc
+// minima / maxima by v_pk_minimum3_f16 / v_pk_maximum3_f16 (gfx950) -- three-input, two pixels per instruction, 80 instructions for both
+// pixels where fast_score16 needs 80 for one.  The operands are INTEGERS 0 .. 255 in 16-bit lanes: as f16 bit patterns they are
+// non-negative (sub)normal numbers, whose order is the order of their bit patterns, and minimum / maximum return one of their inputs
+// unchanged (the kernels run with f16 denormals preserved, the AMDGPU default) -- so the result is the integer min / max.
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void fast_score16_x2(const uint8_t *__restrict__ ca, const uint8_t *__restrict__ cb, int pp, int *sa, int *sb) {
+    uint32_t p[16];
+#define FS_P2(k, off) p[k] = (uint32_t)ca[off] | ((uint32_t)cb[off] << 16)
+    FS_P2(0, 3 * pp); FS_P2(1, 3 * pp + 1); FS_P2(2, 2 * pp + 2); FS_P2(3, pp + 3); FS_P2(4, 3); FS_P2(5, -pp + 3); FS_P2(6, -2 * pp + 2);
+    FS_P2(7, -3 * pp + 1); FS_P2(8, -3 * pp); FS_P2(9, -3 * pp - 1); FS_P2(10, -2 * pp - 2); FS_P2(11, -pp - 3); FS_P2(12, -3);
+    FS_P2(13, pp - 3); FS_P2(14, 2 * pp - 2); FS_P2(15, 3 * pp - 1);
+#undef FS_P2
+    uint32_t lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = pk_min3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+        hi3[k] = pk_max3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+    }
+    uint32_t maxmin = 0u, minmax = 0x00ff00ffu;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        const uint32_t a0 = pk_min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+        const uint32_t a1 = pk_min3(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]);
+        const uint32_t b0 = pk_max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+        const uint32_t b1 = pk_max3(hi3[k + 1], hi3[(k + 4) & 15], hi3[(k + 7) & 15]);
+        maxmin = pk_max3(maxmin, a0, a1);
+        minmax = pk_min3(minmax, b0, b1);
+    }
+    const int va = ca[0], vb = cb[0];
+    const int mma = (int)(maxmin & 0xffffu), mmb = (int)(maxmin >> 16), mna = (int)(minmax & 0xffffu), mnb = (int)(minmax >> 16);
+    *sa = max(va - mna, mma - va) - 1;
+    *sb = max(vb - mnb, mmb - vb) - 1;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // One workgroup per FAST cell (ORBextractor.cc:805-870).  The cell sub-image [iniX, maxX) x [iniY, maxY) is
 // staged in LDS; scores are computed for its interior (3 px inside), NMS sees only same-cell neighbours (the
@@ -701,11 +745,13 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
     __syncthreads();
 
     // phase 2: exact score of the queued pixels, kept per queue entry while the pixel tile is still being read
-    for (int e = lane; e < qn; e += 64) {
-        const int q = queue[e];
-        const int y = q >> 8, x = q & 0xff;
-        int s = fast_score16(pix + (y + 3) * P + x + 4, P);
-        scq[e] = (uint8_t)((s >= minTh) ? s : 0);
+    for (int e0 = 0; e0 < qn; e0 += 128) {   // two queue entries per lane (fast_score16_x2)
+        const int ea = e0 + lane, eb = ea + 64;
+        const int qa = queue[min(ea, qn - 1)], qb = queue[min(eb, qn - 1)];
+        int sa, sb;
+        fast_score16_x2(pix + ((qa >> 8) + 3) * P + (qa & 0xff) + 4, pix + ((qb >> 8) + 3) * P + (qb & 0xff) + 4, P, &sa, &sb);
+        if (ea < qn) scq[ea] = (uint8_t)((sa >= minTh) ? sa : 0);
+        if (eb < qn) scq[eb] = (uint8_t)((sb >= minTh) ? sb : 0);
     }
     __syncthreads();
     // the pixel tile is dead: its memory becomes the score tile (pitch P, 1-px zero apron)

@@ -59,50 +59,6 @@ __host__ __device__ inline size_t fast_strip_lds_bytes(int waves, int pix_bytes,
     return (size_t)pix_bytes + waves * fast_strip_wave_bytes(gcap, qcap) + (waves * kStripMaxCells + 4) * sizeof(int32_t);
 }
 
-// cornerScore of TWO pixels per lane: the 16 circle pixels of both as packed u16 pairs (low half = pixel A, high half = pixel B), the arc
-// minima / maxima by v_pk_minimum3_f16 / v_pk_maximum3_f16 (gfx950) -- three-input, two pixels per instruction, 80 instructions for both
-// pixels where fast_score16 needs 80 for one.  The operands are INTEGERS 0 .. 255 in 16-bit lanes: as f16 bit patterns they are
-// non-negative (sub)normal numbers, whose order is the order of their bit patterns, and minimum / maximum return one of their inputs
-// unchanged (the kernels run with f16 denormals preserved, the AMDGPU default) -- so the result is the integer min / max.
-__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ void fast_score16_x2(const uint8_t *__restrict__ ca, const uint8_t *__restrict__ cb, int pp, int *sa, int *sb) {
-    uint32_t p[16];
-#define FS_P2(k, off) p[k] = (uint32_t)ca[off] | ((uint32_t)cb[off] << 16)
-    FS_P2(0, 3 * pp); FS_P2(1, 3 * pp + 1); FS_P2(2, 2 * pp + 2); FS_P2(3, pp + 3); FS_P2(4, 3); FS_P2(5, -pp + 3); FS_P2(6, -2 * pp + 2);
-    FS_P2(7, -3 * pp + 1); FS_P2(8, -3 * pp); FS_P2(9, -3 * pp - 1); FS_P2(10, -2 * pp - 2); FS_P2(11, -pp - 3); FS_P2(12, -3);
-    FS_P2(13, pp - 3); FS_P2(14, 2 * pp - 2); FS_P2(15, 3 * pp - 1);
-#undef FS_P2
-    uint32_t lo3[16], hi3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = pk_min3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
-        hi3[k] = pk_max3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
-    }
-    uint32_t maxmin = 0u, minmax = 0x00ff00ffu;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-        const uint32_t a0 = pk_min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-        const uint32_t a1 = pk_min3(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]);
-        const uint32_t b0 = pk_max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
-        const uint32_t b1 = pk_max3(hi3[k + 1], hi3[(k + 4) & 15], hi3[(k + 7) & 15]);
-        maxmin = pk_max3(maxmin, a0, a1);
-        minmax = pk_min3(minmax, b0, b1);
-    }
-    const int va = ca[0], vb = cb[0];
-    const int mma = (int)(maxmin & 0xffffu), mmb = (int)(maxmin >> 16), mna = (int)(minmax & 0xffffu), mnb = (int)(minmax >> 16);
-    *sa = max(va - mna, mma - va) - 1;
-    *sb = max(vb - mnb, mmb - vb) - 1;
-}
-
 template <int W, int P>   // W waves per workgroup = row bands per strip; P = LDS pitch of the tile
 __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f, uint8_t *smem, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
                                                 int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent, size_t ent_frame_stride,
