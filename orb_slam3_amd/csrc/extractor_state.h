@@ -119,7 +119,7 @@ struct orbx_extractor {
     size_t fast_lds = 0;
     bool resize_march_ok[orbx::kMaxLevels] = {};   // every tap pair of a dword column of level l within 8 source bytes (k_pyr_resize_march)
     bool fast_strip = false;    // k_fast_strip applies (cells at most 57 px wide, 63 px high)
-    int n_strips = 0, n_strips_l0 = 0, strip_pix_bytes = 0, strip_gcap = 512, strip_qcap = 816;   // k_fast_strip: strips per frame, tile rows, per-wave group / pixel queue capacities
+    int n_strips = 0, strip_pix_bytes = 0, strip_gcap = 512, strip_qcap = 816;   // k_fast_strip: strips per frame, tile rows, per-wave group / pixel queue capacities
     int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qfull = 16;   // list pass (fast_wave_cell): LDS tile pitch (48 / 64), max sub-image rows, whole-cell queue
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
@@ -150,7 +150,7 @@ struct orbx_extractor {
     hipEvent_t ev_in_free[2] = {nullptr, nullptr}, ev_in_ready[2] = {nullptr, nullptr};
     bool in_used[2] = {false, false};
     unsigned in_issued = 0;
-    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr, ev_base = nullptr, ev_fast0 = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
     int blur_tile_start[orbx::kMaxLevels + 1] = {};  // blur tiles of level l: [start[l], start[l + 1])
     bool match_pending = false;
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream

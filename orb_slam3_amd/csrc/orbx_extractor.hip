@@ -272,7 +272,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         const int budget = rows_main * kStripPitch;
         ex->strip_pix_bytes = budget;
         for (int l = 0; l < nl && fast_strip; l++) {
-            if (l == 1) ex->n_strips_l0 = (int)strips.size();
             const LevelInfo &L = lv[l];
             const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
             const uint32_t rcpw = (65536u + (uint32_t)L.wCell - 1u) / (uint32_t)L.wCell;
@@ -378,24 +377,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)), n);
     }
     if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));  // k_pyr_base is the only reader of the input frames
-    // FAST of level 0 needs nothing but level 0: its strips (43 % of the stage's pixels, VALU bound) start on the aux stream as soon as
-    // k_pyr_base is done and run beside the resize chain, whose launches are bound by the lifetime of their waves (VALU idle 57 % of the
-    // time).  The other levels' strips follow the chain on the main stream; the list pass waits for both.
     const int ini_th = std::min(std::max(ex->prm.ini_th_fast, 0), 255), min_th = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini_th);
-    static const bool split_on = [] { const char *v = getenv("ORBX_FAST_SPLIT"); return !(v && v[0] == '0'); }();   // TEMPORARY (A/B visit)
-    const bool fast_split = split_on && ex->fast_strip && !ex->profile && ex->side_streams && ex->n_strips_l0 > 0 && ex->n_strips_l0 < ex->n_strips && nl > 1;
-    auto launch_strips = [&](hipStream_t s, int first, int count) {
-        hipLaunchKernelGGL(k_fast_strip<4>, xcd_grid(count, n), dim3(256), fast_strip_lds_bytes(4, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap), s,
-                           (const StripTile *)ex->d_strips.p + first, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,
-                           (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini_th, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap,
-                           (uint32_t *)ex->d_fast_ovf.p + 16, (int32_t *)ex->d_fast_ovf.p, ini_th > min_th ? 1 : 0, n);
-    };
-    if (fast_split) {
-        ORBX_HIP(hipEventRecord(ex->ev_base, pst));
-        ORBX_HIP(hipStreamWaitEvent(ex->aux_stream, ex->ev_base, 0));
-        launch_strips(ex->aux_stream, 0, ex->n_strips_l0);
-        ORBX_HIP(hipEventRecord(ex->ev_fast0, ex->aux_stream));
-    }
     static const int kBlurNew[4] = {18, 34, 48, 56}, kBlurOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
     const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
     auto blur_levels = [&](hipStream_t bs, int l0, int l1) {   // k_blur over the tiles of levels [l0, l1)
@@ -449,10 +431,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             uint32_t *ovf_list = (uint32_t *)ex->d_fast_ovf.p + 16;
             // first pass of :826 for every cell, one workgroup per strip of cells; cells it leaves empty go to the list pass below
             // (ini <= min: the second pass is a subset of the first, an empty cell stays empty)
-            if (fast_split) {
-                launch_strips(st, ex->n_strips_l0, ex->n_strips - ex->n_strips_l0);
-                ORBX_HIP(hipStreamWaitEvent(st, ex->ev_fast0, 0));
-            } else launch_strips(st, 0, ex->n_strips);
+            // (Level 0's strips on the aux stream beside the latency-bound resize chain were measured: EuRoC 1.10 vs 1.11 ms, but TUM-VI 1.02 vs
+            // 0.84 ms -- with the default four hardware queues the aux stream shares one with the matcher, with eight everything else slows:
+            // profiles/r03_j_*, r03_k_*.  One launch on the main stream.)
+            hipLaunchKernelGGL(k_fast_strip<4>, xcd_grid(ex->n_strips, n), dim3(256), fast_strip_lds_bytes(4, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap), st,
+                               (const StripTile *)ex->d_strips.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,
+                               (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
+                               ini > mn ? 1 : 0, n);
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
@@ -639,7 +624,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
     (void)hipStreamCreateWithPriority(&ex->in_stream, hipStreamNonBlocking, prio_hi);
     for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
-    for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match, &ex->ev_base, &ex->ev_fast0}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[0], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[1], hipEventDisableTiming);
@@ -679,7 +664,7 @@ void orbx_destroy(orbx_extractor *ex) {
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
     ex->d_in[0].release(); ex->d_in[1].release();
-    for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match, ex->ev_base, ex->ev_fast0}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
     if (ex->ev_compute_done) (void)hipEventDestroy(ex->ev_compute_done);
     for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
     if (ex->h_err) (void)hipHostFree(ex->h_err);
