@@ -1,0 +1,895 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB kfeatures/sec, extract + match (BASELINE.json metric), on 1..N MI355X of one node.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload euroc|kitti|tumvi]
+
+A "step" = one pass of the hot path over one batch of synthetic frames of ONE camera sequence per GPU:
+  euroc (default, the metric's configuration): 256 frames 752x480, nFeatures=1000 -- extract (pyramid, FAST, quad-tree,
+        orientation, blur, rBRIEF) + frame-to-frame SearchByProjection (th=15, rotation check) between consecutive frames
+        + D2H of keypoints, descriptors, counts and match indices into pinned host memory;
+  kitti (BASELINE config 3): 64 rectified stereo pairs 1241x376, nFeatures=2000 -- left + right extraction +
+        Frame::ComputeStereoMatches (row-band Hamming, SAD sub-pixel, median rejection) on the device + D2H;
+  tumvi (BASELINE config 4): 64 frames 1024x1024, nFeatures=1500 -- extract + SearchByProjection(Frame, MapPoints) against
+        10,000 map-point descriptors per frame (Tracking.cc:3390-3413) + D2H.
+`value` follows the bench contract: inputs are resident in HBM when the timed region starts.  The same run also measures the
+host-input rate (`pcie_inclusive`: frames start in pinned host memory, orbx_extract_batch_host uploads batch i+1 while batch
+i computes) -- SURVEY.md 8d's "wall clock covering H2D ... D2H".
+
+Processes: with WORLD_SIZE unset this file is a LAUNCHER: it starts one rank process per GPU itself (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment) and relays rank 0's JSON line; under
+torch.distributed.run it is a rank directly (and --gpus must equal WORLD_SIZE).  Ranks shard independent camera sequences
+(seed = 10 + rank), no data-path collective; torch.distributed (RCCL) carries only the timing barrier and
+the max-over-ranks / sum-over-ranks reduction.  After the timed loop rank 0 checks sampled frames of the last step (keypoints,
+descriptors, match vectors) against the CPU oracle: "parity_checked" in the JSON line; a mismatch is a failed run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+NLEVELS = 8
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (width, height, nfeatures, default frames per step, lapping area)
+    "euroc": (752, 480, 1000, 256, (0, 1000)),
+    "kitti": (1241, 376, 2000, 64, (0, 0)),
+    "tumvi": (1024, 1024, 1500, 64, (0, 1000)),
+}
+N_MAPPOINTS = 10000
+
+
+# ---------------------------------------------------------------------------------------------------------
+# algorithmic bytes (SURVEY.md 8d / DESIGN.md 4): every stage reads its input once and writes its output once
+# ---------------------------------------------------------------------------------------------------------
+def algorithmic_bytes(sizes, n_frames, feats, cands):
+    """Per-kernel algorithmic bytes of ONE launch over n_frames frames.  P = sum of level pixels, N = keypoints out,
+    C = FAST candidates (both totals over the launch)."""
+    px = [a * b for a, b in sizes]
+    P = sum(px)
+    N, Cn = feats, cands
+    per = {
+        "k_pyr_base": 2 * px[0] * n_frames,                       # image read + level-0 write
+        "k_pyr_resize": ((P - px[-1]) + (P - px[0])) * n_frames / (NLEVELS - 1),  # per launch (7 launches)
+        "k_fast_ini": P * n_frames + 4 * Cn,                      # pyramid read + packed candidates (k_fast_ini + its list pass k_fast_wave_list)
+        "k_blur": 2 * P * n_frames,
+        "k_octree": 8 * Cn + 4 * N,                               # candidates read + gathered, keypoints out
+        "k_finalize": 16 * N,
+        "k_describe": N * (749 + 512 + 32 + 28),
+        "k_window_best2": (32 + 28) * 2 * N + 16 * N,
+        "k_greedy_resolve": 16 * N + 4 * N,
+    }
+    extract_total = (5 * P - px[0] - px[-1]) * n_frames + 12 * Cn + 1321 * N  # B_extract of SURVEY.md 8d
+    return per, extract_total
+
+
+def roofline_from_profile(ex, prof, passes, sizes, n_frames, n_feat, n_cand, launches_scale=1.0):
+    """roofline object for the kernel with the largest share of GPU time; prof = {kernel: (avg_ms, launches)}."""
+    per, extract_total = algorithmic_bytes(sizes, n_frames, n_feat, n_cand)
+    kernels, tot_ms = {}, 0.0
+    for name, (ms, cnt) in prof.items():
+        if cnt == 0 or name not in per:
+            continue
+        lps = cnt / float(passes)
+        kernels[name] = {"avg_ms": round(ms, 4), "launches_per_step": lps, "alg_GBs": round(per[name] / (ms * 1e-3) / 1e9, 1)}
+        tot_ms += ms * lps
+    dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
+    ach = per[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+    ext_ms = sum(v["avg_ms"] * v["launches_per_step"] for k, v in kernels.items() if not k.startswith(("k_window", "k_greedy")))
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": int(per[dom]), "avg_launch_ms": kernels[dom]["avg_ms"],
+                "timing": "HIP events on the extractor's own stream, serialized passes after the timed loop",
+                "kernel_time_share": round(kernels[dom]["avg_ms"] * kernels[dom]["launches_per_step"] / tot_ms, 3),
+                "extract_all_kernels_GBs": round(extract_total / (ext_ms * 1e-3) / 1e9, 1),
+                "extract_all_kernels_frac": round(extract_total / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return roofline, kernels
+
+
+# ---------------------------------------------------------------------------------------------------------
+# PMC traffic of the dominant kernel, measured IN THIS RUN (default at --gpus 1; --no-pmc skips it): two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE:
+# they do not fit one pass) over a short serialized child run of this same file, parsed from rocprofv3's database
+# ---------------------------------------------------------------------------------------------------------
+# a profile slot may cover more than one kernel: the FAST stage = first pass for every cell + the list pass over the cells it left
+STAGE_KERNELS = {"k_fast_ini": ("k_fast_ini", "k_fast_wave_list", "k_fast_wave"), "k_octree": ("k_compact", "k_octree_par", "k_octree_par1", "k_octree"),
+                 "k_window_best2": ("k_grid_build", "k_window_best2")}
+
+
+def pmc_traffic(kernel, workload, batch):
+    """HBM-side bytes per launch of a stage, measured in this run: two rocprofv3 --pmc child passes of this same file.
+    Reads: 32 * TCC_EA0_RDREQ_32B + 64 * TCC_EA0_RDREQ_64B + 128 * TCC_EA0_RDREQ_128B (the request-size classes; on gfx950 practically
+    every read request is a 128-byte one, which the derived FETCH_SIZE counter tallies at 64 bytes -- it under-reports every kernel of this
+    path by 2x).  Writes: WRITE_SIZE (32 / 64-byte write requests; agrees with known store volumes)."""
+    import re
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    env = dict(os.environ, ORBX_SIDE_STREAMS="0", TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    group = STAGE_KERNELS.get(kernel, (kernel,))
+    out = {}
+    passes = {"read": ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"], "write": ["WRITE_SIZE"]}
+    weight = {"TCC_EA0_RDREQ_32B_sum": 32.0, "TCC_EA0_RDREQ_64B_sum": 64.0, "TCC_EA0_RDREQ_128B_sum": 128.0, "WRITE_SIZE": 1024.0}
+    for name, counters in passes.items():
+        td = tempfile.mkdtemp(prefix="orbx_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", *counters, "-d", td, "-o", "p", "--", sys.executable, str(ROOT / "bench.py"), "--pmc-child", "--workload", workload,
+               "--batch", str(batch), "--steps", "2", "--warmup", "1"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=240)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(td, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {' '.join(counters)} timed out"
+        dbs = list(Path(td).rglob("*.db"))
+        if r.returncode != 0 or not dbs:
+            shutil.rmtree(td, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode})"
+        c = sqlite3.connect(str(dbs[0]))
+        tabs = [t[0] for t in c.execute("select name from sqlite_master where type in ('table','view')")]
+        view = "counters_collection" if "counters_collection" in tabs else next((t for t in tabs if t.startswith("counters_collection")), None)
+        if view is None:
+            return None, "no counters_collection view in the rocprofv3 database"
+        per = {k: [0.0, 0] for k in group}   # bytes summed over counters, dispatches
+        seen = {k: set() for k in group}
+        for kname, cname, val, did in c.execute(f"select kernel_name, counter_name, value, dispatch_id from {view}"):
+            k = re.sub(r"<.*>", "", kname.split("(")[0].replace("void ", "").replace("orbx::", ""))
+            if k in per and cname in weight:
+                per[k][0] += val * weight[cname]
+                seen[k].add(did)
+        c.close()
+        shutil.rmtree(td, ignore_errors=True)
+        if not any(seen.values()):
+            return None, f"kernel {kernel} not in the {name} pass"
+        out[name] = sum(per[k][0] / len(seen[k]) for k in group if seen[k])   # per launch, summed over the stage's kernels
+    return out, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (CPU restatement of the reference path) timed on this box's host cores, bounded sample
+# ---------------------------------------------------------------------------------------------------------
+def _oracle_euroc_sample(frames, idx, nfeat, w, h):
+    from oracle import oracle_binding as ob
+    oex = ob.OracleExtractor(nfeat, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+    sf = oex.tables()["scale"]
+    feats, prev = 0, None
+    for t in idx:
+        _, k, d = oex.extract(frames[t % len(frames)], lap=(0, 1000))
+        feats += len(k)
+        if prev is not None:
+            k0, d0 = prev
+            q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"],
+                     angle=k0["angle"], desc=d0, has_obs=np.ones(len(k0), np.uint8))
+            grid = ob.OracleGrid(k, 0.0, float(w), 0.0, float(h))
+            ob.search_by_projection_frame(grid, d, sf, q, 15.0, 0, True)
+        prev = (k, d)
+    return feats
+
+
+def reference_build_child(td, n_ref):
+    """Child process of cpu_baseline: the compiled reference (oracle/_ref) on the frames saved in td; prints one JSON object."""
+    from oracle import oracle_binding as ob
+    from oracle import ref_binding as rb
+    w, h, nf = WORKLOADS["euroc"][:3]
+    frames = np.load(os.path.join(td, "frames.npy"))
+    sf = ob.OracleExtractor(nf, 1.2, NLEVELS, 20, 7).tables()["scale"]
+    rex = rb.RefExtractor(nf, 1.2, NLEVELS, 20, 7)
+    t0 = time.perf_counter()
+    feats, prev = 0, None
+    for t in range(n_ref):
+        _, k, d = rex.extract(frames[t % len(frames)], (0, 1000))
+        feats += len(k)
+        if prev is not None:
+            k0, d0 = prev
+            q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, z=np.ones(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
+                     desc=d0, has_obs=np.ones(len(k0), np.uint8))
+            rb.ref_search_by_projection_frame(rb.RefFrame(k, d, 0.0, float(w), 0.0, float(h), sf), q, 15.0, 0, True)
+        prev = (k, d)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"value": round(feats / dt / 1e3, 3), "unit": "kfeatures/s", "cores": 1,
+                      "sample": f"{n_ref} frames, {dt:.1f} s, reference ORBextractor.cc + ORBmatcher.cc over oracle/ocv_shim"}))
+
+
+def cpu_baseline_euroc(frames, n_sample, w, h, nfeat):
+    t0 = time.perf_counter()
+    feats = _oracle_euroc_sample(frames, range(n_sample), nfeat, w, h)
+    dt = time.perf_counter() - t0
+    out = {"value": round(feats / dt / 1e3, 3), "unit": "kfeatures/s", "cores": 1, "kind": "port",
+           "sample": f"{n_sample} frames of the same workload (extract + frame-to-frame match), {dt:.1f} s, "
+                     f"oracle/ C++ restatement -O3 x86-64-v3, 1 thread; host has {os.cpu_count()} logical cores"}
+    # frame-parallel on all host cores: the same sample split over one thread per core (ctypes releases the GIL)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        nc = max(1, min(os.cpu_count() or 1, 64))
+        if nc > 1:
+            per = 12   # 12 frames (about 0.4 s) per thread
+            chunks = [range(c * per, (c + 1) * per) for c in range(nc)]
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(nc) as pool:
+                fs = list(pool.map(lambda r: _oracle_euroc_sample(frames, r, nfeat, w, h), chunks))
+            dt = time.perf_counter() - t0
+            out["all_cores"] = {"value": round(sum(fs) / dt / 1e3, 3), "unit": "kfeatures/s", "cores": nc,
+                                "sample": f"{nc} threads x {per} frames, {dt:.1f} s"}
+    except Exception as e:   # the 1-thread baseline stands on its own
+        out["all_cores"] = {"error": str(e)[:200]}
+    # beside it, when oracle/_ref travelled here: the reference's OWN ORBextractor.cc + ORBmatcher.cc (compiled where they lie in the
+    # build container against the stand-in OpenCV / SLAM types, whose image primitives are the oracle's scalar ones) on a quarter of
+    # the sample -- shows the port is not slower than the code it restates; not a substitute for an OpenCV-backed build.  Runs in
+    # a child process: nothing that library does can take the bench line down with it.
+    try:
+        from oracle import ref_binding as rb
+        if rb.available() and rb.matcher_available():
+            import tempfile
+            n_ref = max(2, n_sample // 4)
+            with tempfile.TemporaryDirectory() as td:
+                np.save(os.path.join(td, "frames.npy"), np.ascontiguousarray(frames[:min(n_ref, len(frames))]))
+                r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--reference-build-child", td, str(n_ref)],
+                                   capture_output=True, text=True, timeout=300)
+            out["reference_build"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": f"child exit {r.returncode}"}
+    except Exception as e:
+        out["reference_build"] = {"error": str(e)[:200]}
+    return out
+
+
+def cpu_baseline_kitti(pairs, n_sample, w, h, nfeat, bf, b):
+    from oracle import oracle_binding as ob
+    oel = ob.OracleExtractor(nfeat, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+    oer = ob.OracleExtractor(nfeat, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+    tb = oel.tables()
+    t0 = time.perf_counter()
+    feats = 0
+    for t in range(n_sample):
+        L, R = pairs[t % len(pairs)]
+        _, kl, dl = oel.extract(L, lap=(0, 0))
+        _, kr, dr = oer.extract(R, lap=(0, 0))
+        pl = [np.ascontiguousarray(oel.level_padded(l)[19:-19, 19:-19]) for l in range(NLEVELS)]
+        pr = [np.ascontiguousarray(oer.level_padded(l)[19:-19, 19:-19]) for l in range(NLEVELS)]
+        ob.compute_stereo_matches(kl, dl, kr, dr, tb["scale"], tb["inv_scale"], pl, pr, bf, b)
+        feats += len(kl) + len(kr)
+    dt = time.perf_counter() - t0
+    return {"value": round(feats / dt / 1e3, 3), "unit": "kfeatures/s", "cores": 1, "kind": "port",
+            "sample": f"{n_sample} stereo pairs of the same workload (2 x extract + ComputeStereoMatches), {dt:.1f} s, oracle/ C++ "
+                      f"restatement, 1 thread; host has {os.cpu_count()} logical cores"}
+
+
+def cpu_baseline_tumvi(frames, mp_sets, n_sample, w, h, nfeat):
+    from oracle import oracle_binding as ob
+    oex = ob.OracleExtractor(nfeat, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+    sf = oex.tables()["scale"]
+    t0 = time.perf_counter()
+    feats = 0
+    for t in range(n_sample):
+        f = t % len(frames)
+        _, k, d = oex.extract(frames[f], lap=(0, 1000))
+        grid = ob.OracleGrid(k, 0.0, float(w), 0.0, float(h))
+        ob.search_by_projection_mappoints(grid, d, sf, mp_sets(f), 1.0, 0.8)
+        feats += len(k)
+    dt = time.perf_counter() - t0
+    return {"value": round(feats / dt / 1e3, 3), "unit": "kfeatures/s", "cores": 1, "kind": "port",
+            "sample": f"{n_sample} frames of the same workload (extract + SearchByProjection vs {N_MAPPOINTS} map points), {dt:.1f} s, "
+                      f"oracle/ C++ restatement, 1 thread; host has {os.cpu_count()} logical cores"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rank process
+# ---------------------------------------------------------------------------------------------------------
+def bind_to_gpu_numa_node(torch, index):
+    """Run this rank (and first-touch its pinned buffers) on the CPU cores local to its GPU: the host-input leg moves 92 MB per step
+    over PCIe, and pinned memory on the other socket costs a third of the bandwidth.  Best effort; returns a short description."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        cpus = open(f"{base}/local_cpulist").read().strip()
+        node = open(f"{base}/numa_node").read().strip()
+        ids = set()
+        for part in cpus.split(","):
+            a, _, b = part.partition("-")
+            ids.update(range(int(a), int(b or a) + 1))
+        if ids:
+            os.sched_setaffinity(0, ids)
+            return f"gpu {bdf} numa {node} cpus {cpus}"
+    except Exception as e:   # no sysfs entry / no permission: keep the inherited affinity
+        return f"unbound ({type(e).__name__})"
+    return "unbound"
+
+
+class Rank:
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dry = bool(os.environ.get("ORBX_BENCH_DRY"))   # launcher / sharding test on a box without GPUs: no device work
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        if not self.dry:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU (liborbx has no CPU path)")
+            if torch.cuda.device_count() <= self.local_rank:
+                raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+            torch.cuda.set_device(self.local_rank)
+            self.numa = bind_to_gpu_numa_node(torch, self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.dry:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+
+    def barrier(self, extractors=()):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+            for e in extractors:
+                e.sync()
+        if self.world > 1:
+            self.dist.barrier()
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    # The timed region runs with Python's cyclic garbage collector off (and the heap collected just before): a generation-2 collection
+    # of a process that has imported torch takes 40-80 ms -- several times a whole 20-step timed region -- and landed inside it in
+    # about one run in twenty (seen as a single 82 ms stall: 5.5 instead of 1.35 ms per step).  Host-harness noise, not the path's.
+    def timed_begin(self, extractors=()):
+        import gc
+        gc.collect()
+        gc.disable()
+        self.barrier(extractors)
+        return time.perf_counter()
+
+    def timed_end(self, t0, extractors=()):
+        import gc
+        self.barrier(extractors)
+        dt = time.perf_counter() - t0
+        gc.enable()
+        return dt
+
+    def reduce(self, dt, units):
+        from orb_slam3_amd import sharding
+        return sharding.reduce_throughput(dt, units, device=None if self.dry else "cuda")
+
+    def finish(self, out):
+        if self.rank == 0:
+            print(json.dumps(out), flush=True)
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def base_line(R, metric, value, dt_max, extra_cfg):
+    a = R.args
+    return {"metric": metric, "value": round(value, 2), "unit": "kfeatures/s", "n_gpus": R.world, "steps": a.steps, "warmup": a.warmup,
+            "settle_steps": a.settle,
+            "ms_per_step": round(dt_max / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic", "config": extra_cfg}
+
+
+def pinned(torch, shape, dtype):
+    return torch.empty(shape, dtype=dtype).pin_memory()
+
+
+def bench_dry(R):
+    """No-GPU path of the launcher test: every rank 'processes' its own sequence and the reduction runs over gloo."""
+    a = R.args
+    fail = os.environ.get("ORBX_BENCH_DRY_FAIL")   # test hook of the launcher's retry path: rank 1 dies always / once
+    if fail and R.rank == R.world - 1:
+        if fail == "always" or not os.path.exists(fail):
+            if fail != "always":
+                open(fail, "w").close()
+            os._exit(134)
+    t0 = R.timed_begin()
+    units = 1000.0 * a.steps * (R.rank + 1)
+    time.sleep(0.01)
+    dt_max, units_all = R.reduce(R.timed_end(t0), units)
+    out = base_line(R, "dry run (ORBX_BENCH_DRY): launcher + sharding only", units_all / dt_max / 1e3, dt_max,
+                    {"workload": "none", "sequences": R.world})
+    out["roofline"] = None
+    out["cpu_baseline"] = None
+    R.finish(out)
+
+
+def bench_euroc(R):
+    a, torch = R.args, R.torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    W, H, NF, _, LAP = WORKLOADS["euroc"]
+    B = a.batch or WORKLOADS["euroc"][3]
+    seed = 10 + R.rank
+    from orb_slam3_amd import dataset
+    data = "synthetic"
+    if dataset.dataset_dir("euroc"):   # a real EuRoC sequence: rank r takes frames r*B .. (r+1)*B - 1
+        frames = dataset.load_mono("euroc", B, W, H, start=R.rank * B)
+        data = f"dataset: {dataset.dataset_dir('euroc')} (first {B} frames per rank)"
+    else:
+        canvas = synth.make_canvas(seed)
+        frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t) for t in range(B)])
+    h_frames = torch.from_numpy(frames).pin_memory()          # the camera thread's buffers (pcie_inclusive leg)
+    d_frames = torch.from_numpy(frames).cuda()                 # resident input of the contract's `value`
+    torch.cuda.synchronize()
+
+    ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
+    cap = ex.output_capacity(W, H)
+
+    class HostSet:   # pinned host destinations (the Tracking thread's buffers)
+        def __init__(self):
+            self.kps = pinned(torch, (B, cap, 28), torch.uint8)
+            self.desc = pinned(torch, (B, cap, 32), torch.uint8)
+            self.cnt = pinned(torch, (B,), torch.int32).zero_()
+            self.mono = pinned(torch, (B,), torch.int32).zero_()
+            self.match = pinned(torch, (B, cap), torch.int32)
+            self.nm = pinned(torch, (B,), torch.int32).zero_()
+    host = [HostSet(), HostSet()]   # double-buffered: the D2H of step i overlaps the kernels of step i+1
+
+    def enqueue(i, from_host):
+        hs = host[i % 2]
+        if from_host:
+            ex.extract_batch_host(h_frames.data_ptr(), B, W, H, W, W * H, LAP)
+        else:
+            ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, LAP)
+        ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        ex.download_async(hs.kps.data_ptr(), hs.desc.data_ptr(), hs.cnt.data_ptr(), hs.mono.data_ptr(),
+                          hs.match.data_ptr(), hs.nm.data_ptr())
+
+    def run(nsteps, from_host=False):
+        """nsteps pipelined steps, two batches in flight; returns the number of features delivered to the host."""
+        feats = 0
+        for i in range(nsteps + 1):
+            if i < nsteps:
+                t = time.perf_counter()
+                enqueue(i, from_host)
+                host_enqueue[0] += time.perf_counter() - t
+            if i >= 1:
+                ex.download_wait()
+                feats += int(host[(i - 1) % 2].cnt.sum())
+        return feats
+
+    host_enqueue = [0.0]   # seconds the host thread spent issuing work (HIP API calls through the C ABI), per timed region
+
+    def timed(from_host):
+        run(max(a.warmup, 1), from_host)
+        t0 = R.timed_begin([ex])
+        host_enqueue[0] = 0.0
+        feats = run(a.steps, from_host)
+        return R.timed_end(t0, [ex]), feats
+
+    t_settle = time.perf_counter()
+    run(a.settle, False)
+    R.barrier([ex])
+    settle_ms = (time.perf_counter() - t_settle) / max(a.settle, 1) * 1e3   # the fresh process's first steps: start-up transient included
+    dt, feats = timed(False)
+    enqueue_ms = host_enqueue[0] / a.steps * 1e3
+    last = host[(a.steps - 1) % 2]
+    nmatch = int(last.nm[1:].sum())
+    dt_max, feats_all = R.reduce(dt, feats)
+
+    # ---- parity of the delivered results (last timed step) against the CPU oracle, rank 0 ----
+    parity = None
+    if R.rank == 0 and a.verify > 0:
+        parity = verify_euroc(frames, last, a.verify, W, H, NF, ex)
+
+    # ---- the same loop with the frames starting in pinned host memory (upload inside the timed region) ----
+    dt_h, feats_h = timed(True)
+    dt_h_max, feats_h_all = R.reduce(dt_h, feats_h)
+    if R.rank == 0 and a.verify > 0:
+        verify_euroc(frames, host[(a.steps - 1) % 2], min(a.verify, 2), W, H, NF, ex)   # the host-input path delivers the same results
+    pcie = {"value": round(feats_h_all / dt_h_max / 1e3, 2), "unit": "kfeatures/s", "ms_per_step": round(dt_h_max / a.steps * 1e3, 3),
+            "h2d_bytes_per_step": int(B * W * H), "h2d_GBs": round(B * W * H / (dt_h_max / a.steps) / 1e9, 1), "host_affinity": R.numa,
+            "note": "frames in pinned host memory; orbx_extract_batch_host uploads batch i+1 on its own stream while batch i computes"}
+
+    # ---- per-kernel timing with HIP events on the extractor's stream (separate, untimed, serialized passes) ----
+    roofline, kernels = None, {}
+    if R.rank == 0 and not a.no_profile:
+        passes = 3
+        ex.profile_enable(True)
+        for _ in range(passes):
+            run(1)
+        prof = ex.profile_read()
+        ex.profile_enable(False)
+        n_feat = int(last.cnt.sum())
+        samp = list(range(0, B, max(1, B // 8)))   # candidate count sampled on a few frames
+        n_cand = int(sum(len(ex.debug_candidates(l, f)) for f in samp for l in range(NLEVELS)) * B / len(samp))
+        sizes = [ex.level_size(l, (W, H)) for l in range(NLEVELS)]
+        roofline, kernels = roofline_from_profile(ex, prof, passes, sizes, B, n_feat, n_cand)
+        if a.pmc and R.world == 1:
+            tr, err = pmc_traffic(roofline["kernel"], "euroc", B)
+            if tr:
+                roofline["traffic"] = int(tr["read"] + tr["write"])
+                roofline["traffic_detail"] = {"read_bytes": int(tr["read"]), "write_bytes": int(tr["write"]),
+                                              "traffic_over_algorithmic": round((tr["read"] + tr["write"]) / roofline["alg_bytes_per_launch"], 2),
+                                              "note": "rocprofv3 --pmc child passes of this run; reads = 32/64/128-byte request classes "
+                                                      "(FETCH_SIZE tallies gfx950's 128-byte requests at 64 bytes), writes = WRITE_SIZE"}
+            else:
+                roofline["traffic_error"] = err
+
+    cpu = None
+    if R.rank == 0 and R.world == 1 and a.cpu_frames > 0:
+        cpu = cpu_baseline_euroc(frames, a.cpu_frames, W, H, NF)
+
+    out = base_line(R, "ORB kfeatures/sec extract+match, EuRoC 752x480 nFeatures=1000", feats_all / dt_max / 1e3, dt_max,
+                    {"workload": "EuRoC-shaped 752x480 mono, nFeatures=1000, 8 levels, scale 1.2, FAST 20/7: extract + frame-to-frame "
+                                 "SearchByProjection(th=15) + D2H of results; inputs resident in HBM",
+                     "frames_per_step_per_gpu": B, "sequences": R.world, "features_per_frame": round(feats / a.steps / B, 1),
+                     "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{R.world} independent sequences, one per GPU"})
+    out["data"] = data
+    out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels,
+                "host_enqueue_ms_per_step": round(enqueue_ms, 3), "settle_ms_per_step": round(settle_ms, 3)})
+    R.finish(out)
+
+
+def verify_euroc(frames, hs, n_check, W, H, NF, ex):
+    """Compare delivered keypoints / descriptors of sampled frames and the match vectors of sampled consecutive pairs with
+    the CPU oracle (bit-exact).  Raises on any difference."""
+    from oracle import oracle_binding as ob
+    B = len(frames)
+    oex = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+    sf = oex.tables()["scale"]
+    starts = sorted(set(int(x) for x in np.linspace(0, B - 2, n_check)))
+    checked = {"frames": 0, "match_pairs": 0}
+    for s in starts:
+        outs = []
+        for f in (s, s + 1):
+            mono, k, d = oex.extract(frames[f], lap=(0, 1000))
+            n = int(hs.cnt[f])
+            if n != len(k) or int(hs.mono[f]) != mono:
+                raise SystemExit(f"PARITY FAILURE: frame {f}: {n} keypoints / mono {int(hs.mono[f])}, oracle {len(k)} / {mono}")
+            if hs.kps[f, :n].numpy().tobytes() != k.tobytes():
+                raise SystemExit(f"PARITY FAILURE: frame {f}: keypoints differ from the oracle")
+            if not np.array_equal(hs.desc[f, :n].numpy(), d):
+                raise SystemExit(f"PARITY FAILURE: frame {f}: descriptors differ from the oracle")
+            outs.append((k, d))
+            checked["frames"] += 1
+        (k0, d0), (k1, d1) = outs
+        q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"],
+                 desc=d0, has_obs=np.ones(len(k0), np.uint8))
+        grid = ob.OracleGrid(k1, 0.0, float(W), 0.0, float(H))
+        on, ocm = ob.search_by_projection_frame(grid, d1, sf, q, 15.0, 0, True, None, None)
+        if int(hs.nm[s + 1]) != on or not np.array_equal(hs.match[s + 1, :len(k1)].numpy(), ocm):
+            raise SystemExit(f"PARITY FAILURE: match vector of frame pair ({s}, {s + 1}) differs from the oracle")
+        checked["match_pairs"] += 1
+    return checked
+
+
+def bench_kitti(R):
+    """BASELINE config 3: KITTI-shaped 1241x376 rectified stereo, nFeatures=2000: left + right extraction and
+    Frame::ComputeStereoMatches (Hamming row band + SAD + median rejection) all on the device, results to the host."""
+    a, torch = R.args, R.torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    W, H, NF, _, LAP = WORKLOADS["kitti"]
+    B = a.batch or WORKLOADS["kitti"][3]
+    from orb_slam3_amd import dataset
+    data = "synthetic"
+    if dataset.dataset_dir("kitti"):
+        pairs = dataset.load_stereo("kitti", B, W, H)
+        data = f"dataset: {dataset.dataset_dir('kitti')} (first {B} pairs)"
+    else:
+        canvas = synth.make_canvas(30 + R.rank, size=2600, n_shapes=4000)
+        pairs = [synth.make_stereo_pair(30 + R.rank, t, W, H, canvas) for t in range(B)]
+    dl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    dr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    torch.cuda.synchronize()
+    exl = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
+    exr = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
+    cap = exl.output_capacity(W, H)
+    exr.output_capacity(W, H)
+    bf, b = 0.53716 * 718.856, 0.53716
+    host = {k: [pinned(torch, (B, cap, 28), torch.uint8), pinned(torch, (B, cap, 32), torch.uint8),
+                pinned(torch, (B,), torch.int32).zero_(), pinned(torch, (B,), torch.int32).zero_()] for k in "lr"}
+    h_ur, h_depth, h_nm = pinned(torch, (B, cap), torch.float32), pinned(torch, (B, cap), torch.float32), pinned(torch, (B,), torch.int32).zero_()
+
+    def step():
+        exl.extract_batch_device(dl.data_ptr(), B, W, H, W, W * H, LAP)
+        exr.extract_batch_device(dr.data_ptr(), B, W, H, W, W * H, LAP)
+        exl.stereo_batch_device(exr, bf, b)
+        for e, k in ((exl, "l"), (exr, "r")):
+            e.download_async(*[t.data_ptr() for t in host[k]])
+        exl.download_wait()
+        exr.download_wait()
+        exl.stereo_download_all(h_ur.data_ptr(), h_depth.data_ptr(), h_nm.data_ptr())   # synchronous on the left extractor's stream
+        return int(host["l"][2].sum()) + int(host["r"][2].sum())
+
+    for _ in range(a.settle + max(a.warmup, 1)):
+        step()
+    t0 = R.timed_begin([exl, exr])
+    feats = 0
+    for _ in range(a.steps):
+        feats += step()
+    dt = R.timed_end(t0, [exl, exr])
+    dt_max, feats_all = R.reduce(dt, feats)
+
+    parity = None
+    if R.rank == 0 and a.verify > 0:
+        from oracle import oracle_binding as ob
+        oel = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+        oer = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+        tb = oel.tables()
+        parity = {"pairs": 0}
+        for f in sorted(set(int(x) for x in np.linspace(0, B - 1, min(a.verify, 3)))):
+            res = []
+            for oe, img, k in ((oel, pairs[f][0], "l"), (oer, pairs[f][1], "r")):
+                _, kk, dd = oe.extract(img, lap=LAP)
+                n = int(host[k][2][f])
+                if n != len(kk) or host[k][0][f, :n].numpy().tobytes() != kk.tobytes() or not np.array_equal(host[k][1][f, :n].numpy(), dd):
+                    raise SystemExit(f"PARITY FAILURE: stereo pair {f} ({k}): extraction differs from the oracle")
+                res.append((kk, dd))
+            pl = [np.ascontiguousarray(oel.level_padded(l)[19:-19, 19:-19]) for l in range(NLEVELS)]
+            pr = [np.ascontiguousarray(oer.level_padded(l)[19:-19, 19:-19]) for l in range(NLEVELS)]
+            on, our, odepth, _, _ = ob.compute_stereo_matches(res[0][0], res[0][1], res[1][0], res[1][1], tb["scale"], tb["inv_scale"], pl, pr, bf, b)
+            n = len(res[0][0])
+            if int(h_nm[f]) != on or h_ur[f, :n].numpy().tobytes() != our.tobytes() or h_depth[f, :n].numpy().tobytes() != odepth.tobytes():
+                raise SystemExit(f"PARITY FAILURE: stereo pair {f}: mvuRight / mvDepth differ from the oracle")
+            parity["pairs"] += 1
+
+    roofline, kernels = None, {}
+    if R.rank == 0 and not a.no_profile:
+        passes = 3
+        exl.profile_enable(True)
+        for _ in range(passes):
+            exl.extract_batch_device(dl.data_ptr(), B, W, H, W, W * H, LAP)
+            exl.sync()
+        prof = exl.profile_read()
+        exl.profile_enable(False)
+        n_feat = int(host["l"][2].sum())
+        samp = list(range(0, B, max(1, B // 8)))
+        n_cand = int(sum(len(exl.debug_candidates(l, f)) for f in samp for l in range(NLEVELS)) * B / len(samp))
+        sizes = [exl.level_size(l, (W, H)) for l in range(NLEVELS)]
+        roofline, kernels = roofline_from_profile(exl, prof, passes, sizes, B, n_feat, n_cand)
+        roofline["note"] = "left extractor's launch (the right one is identical in shape); stereo kernels are not in this table"
+
+    cpu = None
+    if R.rank == 0 and R.world == 1 and a.cpu_frames > 0:
+        cpu = cpu_baseline_kitti(pairs, max(2, a.cpu_frames // 6), W, H, NF, bf, b)
+
+    out = base_line(R, "ORB kfeatures/sec extract+match, KITTI 1241x376 stereo nFeatures=2000", feats_all / dt_max / 1e3, dt_max,
+                    {"workload": "KITTI-shaped 1241x376 rectified stereo, nFeatures=2000: left+right extract + ComputeStereoMatches "
+                                 "(row-band Hamming, SAD sub-pixel, median rejection) on device + D2H; inputs resident in HBM",
+                     "pairs_per_step_per_gpu": B, "sequences": R.world, "features_per_pair": round(feats / a.steps / B, 1),
+                     "stereo_matches_per_pair": round(float(h_nm.sum()) / B, 1)})
+    out["data"] = data
+    out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels})
+    R.finish(out)
+
+
+def make_mappoints(rng, kps_list, desc_list, t, n_mp):
+    """map points = features of the up to 8 previous frames with each descriptor bit flipped w.p. 0.04,
+    projected at the source keypoint position + N(0, 2 px), predicted level = source octave, viewCos uniform [0.9, 1]."""
+    src = [s for s in range(max(0, t - 8), t)] or [t]
+    k = np.concatenate([kps_list[s] for s in src])
+    d = np.concatenate([desc_list[s] for s in src])
+    idx = rng.integers(0, len(k), n_mp)
+    k, d = k[idx], d[idx].copy()
+    flips = rng.random((n_mp, 256)) < 0.04
+    d ^= np.packbits(flips, axis=1, bitorder="little")
+    return dict(proj_x=(k["x"] + rng.normal(0, 2, n_mp)).astype(np.float32), proj_y=(k["y"] + rng.normal(0, 2, n_mp)).astype(np.float32),
+                proj_xr=np.zeros(n_mp, np.float32), level=k["octave"].astype(np.int32),
+                view_cos=rng.uniform(0.9, 1.0, n_mp).astype(np.float32), desc=d,
+                in_view=np.ones(n_mp, np.uint8), has_obs=np.ones(n_mp, np.uint8))
+
+
+def bench_tumvi(R):
+    """BASELINE config 4: TUM-VI-shaped 1024x1024, nFeatures=1500: extract + SearchByProjection(Frame, MapPoints) (M1,
+    ORBmatcher.cc:39-141 as called from Tracking.cc:3390-3413) against 10,000 map points per frame, all on the device."""
+    a, torch = R.args, R.torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    W, H, NF, _, LAP = WORKLOADS["tumvi"]
+    B = a.batch or WORKLOADS["tumvi"][3]
+    seed = 40 + R.rank
+    canvas = synth.make_canvas(seed, size=2600, n_shapes=4000)
+    yy, xx = np.mgrid[0:H, 0:W]
+    vign = (1.0 - 0.45 * (((xx - W / 2) ** 2 + (yy - H / 2) ** 2) / (W * W / 2.0))).astype(np.float32)   # radial vignetting
+    from orb_slam3_amd import dataset
+    data = "synthetic"
+    if dataset.dataset_dir("tumvi"):
+        frames = dataset.load_mono("tumvi", B, W, H, start=R.rank * B)
+        data = f"dataset: {dataset.dataset_dir('tumvi')} (first {B} frames per rank)"
+    else:
+        frames = np.stack([np.clip(np.rint(synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t).astype(np.float32) * vign), 0, 255).astype(np.uint8)
+                           for t in range(B)])
+    d_frames = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
+    cap = ex.output_capacity(W, H)
+    # map points from the frames' own features (one untimed extraction), resident on the device like the local map's descriptors
+    ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, LAP)
+    feats0 = [ex.download(f) for f in range(B)]
+    rng = np.random.default_rng(5000 + seed)
+    mps = [make_mappoints(rng, [x[1] for x in feats0], [x[2] for x in feats0], f, N_MAPPOINTS) for f in range(B)]
+    dev = {k: torch.from_numpy(np.stack([m[k] for m in mps])).cuda() for k in ("proj_x", "proj_y", "level", "view_cos", "desc", "in_view")}
+    torch.cuda.synchronize()
+    hs = [dict(kps=pinned(torch, (B, cap, 28), torch.uint8), desc=pinned(torch, (B, cap, 32), torch.uint8), cnt=pinned(torch, (B,), torch.int32).zero_(),
+               mono=pinned(torch, (B,), torch.int32).zero_(), match=pinned(torch, (B, cap), torch.int32), nm=pinned(torch, (B,), torch.int32).zero_())
+          for _ in range(2)]
+
+    def enqueue(i):
+        h = hs[i % 2]
+        ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, LAP)
+        ex.search_mappoints_batch_device(N_MAPPOINTS, dev["proj_x"].data_ptr(), dev["proj_y"].data_ptr(), dev["level"].data_ptr(),
+                                         dev["view_cos"].data_ptr(), dev["in_view"].data_ptr(), dev["desc"].data_ptr(), th=1.0, nnratio=0.8)
+        ex.download_async(h["kps"].data_ptr(), h["desc"].data_ptr(), h["cnt"].data_ptr(), h["mono"].data_ptr(), h["match"].data_ptr(), h["nm"].data_ptr())
+
+    def run(nsteps):
+        feats = 0
+        for i in range(nsteps + 1):
+            if i < nsteps:
+                t = time.perf_counter()
+                enqueue(i)
+                host_enqueue[0] += time.perf_counter() - t
+            if i >= 1:
+                ex.download_wait()
+                feats += int(hs[(i - 1) % 2]["cnt"].sum())
+        return feats
+
+    host_enqueue = [0.0]
+    run(a.settle + max(a.warmup, 1))
+    t0 = R.timed_begin([ex])
+    host_enqueue[0] = 0.0
+    feats = run(a.steps)
+    dt = R.timed_end(t0, [ex])
+    dt_max, feats_all = R.reduce(dt, feats)
+    last = hs[(a.steps - 1) % 2]
+
+    parity = None
+    if R.rank == 0 and a.verify > 0:
+        from oracle import oracle_binding as ob
+        oex = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+        sf = oex.tables()["scale"]
+        parity = {"frames": 0}
+        for f in sorted(set(int(x) for x in np.linspace(0, B - 1, min(a.verify, 3)))):
+            mono, k, d = oex.extract(frames[f], lap=LAP)
+            n = int(last["cnt"][f])
+            if n != len(k) or last["kps"][f, :n].numpy().tobytes() != k.tobytes() or not np.array_equal(last["desc"][f, :n].numpy(), d):
+                raise SystemExit(f"PARITY FAILURE: frame {f}: extraction differs from the oracle")
+            grid = ob.OracleGrid(k, 0.0, float(W), 0.0, float(H))
+            on, ofm = ob.search_by_projection_mappoints(grid, d, sf, mps[f], 1.0, 0.8)
+            if int(last["nm"][f]) != on or not np.array_equal(last["match"][f, :n].numpy(), ofm):
+                raise SystemExit(f"PARITY FAILURE: frame {f}: SearchByProjection(map points) differs from the oracle")
+            parity["frames"] += 1
+
+    roofline, kernels = None, {}
+    if R.rank == 0 and not a.no_profile:
+        passes = 3
+        ex.profile_enable(True)
+        for _ in range(passes):
+            ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, LAP)
+            ex.sync()
+        prof = ex.profile_read()
+        ex.profile_enable(False)
+        n_feat = int(last["cnt"].sum())
+        samp = list(range(0, B, max(1, B // 8)))
+        n_cand = int(sum(len(ex.debug_candidates(l, f)) for f in samp for l in range(NLEVELS)) * B / len(samp))
+        sizes = [ex.level_size(l, (W, H)) for l in range(NLEVELS)]
+        roofline, kernels = roofline_from_profile(ex, prof, passes, sizes, B, n_feat, n_cand)
+
+    cpu = None
+    if R.rank == 0 and R.world == 1 and a.cpu_frames > 0:
+        cpu = cpu_baseline_tumvi(frames, lambda f: mps[f], max(2, a.cpu_frames // 6), W, H, NF)
+
+    out = base_line(R, "ORB kfeatures/sec extract+match, TUM-VI 1024x1024 nFeatures=1500", feats_all / dt_max / 1e3, dt_max,
+                    {"workload": "TUM-VI-shaped 1024x1024 mono, nFeatures=1500: extract + SearchByProjection(Frame, MapPoints) against "
+                                 f"{N_MAPPOINTS} map points per frame (th=1, nnratio=0.8) + D2H; inputs resident in HBM",
+                     "frames_per_step_per_gpu": B, "sequences": R.world, "features_per_frame": round(feats / a.steps / B, 1),
+                     "map_point_matches_per_frame": round(float(last["nm"].sum()) / B, 1)})
+    out["data"] = data
+    out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels,
+                "host_enqueue_ms_per_step": round(host_enqueue[0] / a.steps * 1e3, 3)})
+    R.finish(out)
+
+
+def pmc_child(args):
+    """A few serialized steps of the workload's extraction + match for a rocprofv3 --pmc pass (no timing, no output)."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    W, H, NF, Bd, LAP = WORKLOADS[args.workload]
+    B = args.batch or Bd
+    canvas = synth.make_canvas(10)
+    frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 10000 + t) for t in range(B)])
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7)
+    for _ in range(args.warmup + args.steps):
+        ex.extract_batch_device(d.data_ptr(), B, W, H, W, W * H, LAP)
+        if args.workload == "euroc":
+            ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        ex.sync()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N starts the N rank processes itself
+# ---------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_once(argv, n):
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ORBX_BENCH_RANK_PROCESS="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py")] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    return rcs, out0 or ""
+
+
+def launcher(args, argv):
+    n = args.gpus
+    if n < 1:
+        raise SystemExit("--gpus must be >= 1")
+    attempts, history = 0, []
+    while True:
+        attempts += 1
+        rcs, out0 = launch_once(argv, n)
+        line = next((l for l in reversed(out0.strip().splitlines()) if l.startswith("{")), None)
+        if all(rc == 0 for rc in rcs) and line:
+            out = json.loads(line)
+            out["attempts"] = attempts
+            if history:
+                out["failed_attempts"] = history   # reported, never hidden: an attempt that died is a defect to chase
+            print(json.dumps(out), flush=True)
+            return 0
+        history.append({"rank_exit_codes": rcs})
+        sys.stderr.write(f"bench.py: attempt {attempts} failed (rank exit codes {rcs})\n")
+        if attempts >= 1 + args.retries:
+            return 1
+
+
+def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--reference-build-child":
+        return reference_build_child(sys.argv[2], int(sys.argv[3]))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle", type=int, default=8,
+                    help="untimed pipeline steps run once before the W warm-up steps (reported as settle_steps): in a fresh process the HIP "
+                         "runtime's first ~10 batches enqueue 5x slower (0.5 instead of 0.1 ms of host time per step, its signal and "
+                         "command pools still growing), and with a short warm-up that start-up transient landed in the timed region "
+                         "(TUM-VI workload, warm-up 3: 1.29-1.31 ms per step; warm-up 10: 1.07)")
+    ap.add_argument("--batch", type=int, default=0, help="frames (stereo pairs) per step per GPU; 0 = the workload's default (256 / 64 / 32)")
+    ap.add_argument("--cpu-frames", type=int, default=384, help="frames in the CPU baseline sample (0 = skip); 384 = about 13 s of one core for euroc")
+    ap.add_argument("--verify", type=int, default=4, help="frame pairs of the last timed step checked against the CPU oracle on rank 0 (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--pmc", dest="pmc", action="store_true", default=True,
+                    help="measure roofline.traffic in this run: two extra rocprofv3 --pmc child passes of a few steps, about 40 s (default at --gpus 1)")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--retries", type=int, default=1, help="launcher: re-run the whole job this many times if a rank process dies (reported in the JSON)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="euroc",
+                    help="euroc = BASELINE metric config; kitti = config 3 (stereo); tumvi = config 4 (map-point projection search)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
+
+    if "WORLD_SIZE" not in os.environ:
+        return launcher(args, sys.argv[1:])
+    if int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts the rank processes itself)")
+    R = Rank(args)
+    if R.dry:
+        return bench_dry(R)
+    return {"euroc": bench_euroc, "kitti": bench_kitti, "tumvi": bench_tumvi}[args.workload](R)
+
+
+if __name__ == "__main__":
+    sys.exit(main() or 0)

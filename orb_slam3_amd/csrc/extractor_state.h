@@ -146,6 +146,7 @@ struct orbx_extractor {
     // host-resident input (orbx_extract_batch_host): upload stream + two input slabs; slot s may be overwritten once the
     // k_pyr_base that read it has finished (ev_in_free), the extraction may start once the upload has landed (ev_in_ready)
     hipStream_t in_stream = nullptr;
+    hipStream_t spare_stream = nullptr;   // never used: spaces the hardware queues of a second extractor (orbx_create)
     DevBuf d_in[2];
     hipEvent_t ev_in_free[2] = {nullptr, nullptr}, ev_in_ready[2] = {nullptr, nullptr};
     bool in_used[2] = {false, false};

@@ -623,6 +623,12 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
     (void)hipStreamCreateWithPriority(&ex->in_stream, hipStreamNonBlocking, prio_hi);
+    // A sixth, unused stream.  The HIP runtime deals streams onto its GPU_MAX_HW_QUEUES (4) hardware queues round-robin in creation order, and
+    // streams that share a queue serialize.  With five streams per extractor the second extractor of a stereo rig starts one queue further on:
+    // its main stream shares a queue with the first one's copy stream, its aux stream with the first one's matcher -- KITTI stereo 1.85 ms per
+    // step; with six (the count the library had through round 2) the second extractor starts two queues on and the step is 1.675 ms (seven:
+    // 1.73, eight: 1.73; one extractor per process: no difference).  profiles/r03_l_kitti_stream_mapping.log
+    (void)hipStreamCreateWithFlags(&ex->spare_stream, hipStreamNonBlocking);
     for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
@@ -660,7 +666,7 @@ void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream})
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->spare_stream})
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
     ex->d_in[0].release(); ex->d_in[1].release();
