@@ -626,8 +626,8 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     // A sixth, unused stream.  The HIP runtime deals streams onto its GPU_MAX_HW_QUEUES (4) hardware queues round-robin in creation order, and
     // streams that share a queue serialize.  With five streams per extractor the second extractor of a stereo rig starts one queue further on:
     // its main stream shares a queue with the first one's copy stream, its aux stream with the first one's matcher -- KITTI stereo 1.85 ms per
-    // step; with six (the count the library had through round 2) the second extractor starts two queues on and the step is 1.675 ms (seven:
-    // 1.73, eight: 1.73; one extractor per process: no difference).  profiles/r03_l_kitti_stream_mapping.log
+    // step; with six (the count the library had through round 2) the second extractor starts two queues on and the step is 1.67 ms (seven:
+    // 1.71, eight: 1.70; one extractor per process: no difference).  profiles/r03_l_kitti_stream_mapping.log, r03_n_ab_spare_streams.log
     (void)hipStreamCreateWithFlags(&ex->spare_stream, hipStreamNonBlocking);
     for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
