@@ -384,6 +384,15 @@ def base_line(R, metric, value, dt_max, extra_cfg):
             "dtype": "u8", "data": "synthetic", "config": extra_cfg, "process_group": R.group, "per_rank": getattr(R, "per_rank", None)}
 
 
+def repeats_block(regions, steps):
+    ms = sorted(t / steps * 1e3 for t, _ in regions)
+    vals = sorted(f / t / 1e3 for t, f in regions)
+    return {"regions": len(regions), "steps_per_region": steps,
+            "ms_per_step": {"median": round(float(np.median(ms)), 3), "min": round(ms[0], 3), "max": round(ms[-1], 3)},
+            "value": {"median": round(float(np.median(vals)), 2), "min": round(vals[0], 2), "max": round(vals[-1], 2)},
+            "note": "`value` / `ms_per_step` of the line are the FIRST region (exactly K steps after W warm-up steps); the others follow back to back"}
+
+
 def pinned(torch, shape, dtype):
     return torch.empty(shape, dtype=dtype).pin_memory()
 
@@ -495,12 +504,7 @@ def bench_euroc(R):
         f_r = run(a.steps, False)
         regions.append(R.reduce(R.timed_end(t0, [ex]), f_r))
     R.per_rank = per_rank
-    ms = sorted(t / a.steps * 1e3 for t, _ in regions)
-    vals = sorted(f / t / 1e3 for t, f in regions)
-    repeats = {"regions": len(regions), "steps_per_region": a.steps,
-               "ms_per_step": {"median": round(float(np.median(ms)), 3), "min": round(ms[0], 3), "max": round(ms[-1], 3)},
-               "value": {"median": round(float(np.median(vals)), 2), "min": round(vals[0], 2), "max": round(vals[-1], 2)},
-               "note": "`value` / `ms_per_step` of the line are the FIRST region (exactly K steps after W warm-up steps); the others follow back to back"}
+    repeats = repeats_block(regions, a.steps)
 
     # ---- the same loop with the frames starting in pinned host memory (upload inside the timed region) ----
     dt_h, feats_h = timed(True)
@@ -604,7 +608,7 @@ def other_workload_child(wl, a):
         d = json.loads(line)
         rf = d.get("roofline") or {}
         return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
-                "config": d["config"], "parity_checked": d.get("parity_checked"),
+                "config": d["config"], "parity_checked": d.get("parity_checked"), "repeats": d.get("repeats"),
                 "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "frac", "extract_all_kernels_frac")}, "data": d.get("data")}
     except Exception as e:   # the euroc line stands on its own
         return {"error": str(e)[:300]}
@@ -694,12 +698,18 @@ def bench_kitti(R):
 
     for _ in range(a.settle + max(a.warmup, 1)):
         step()
-    t0 = R.timed_begin([exl, exr])
-    feats = 0
-    for _ in range(a.steps):
-        feats += step()
-    dt = R.timed_end(t0, [exl, exr])
-    dt_max, feats_all = R.reduce(dt, feats)
+
+    def region():
+        t0 = R.timed_begin([exl, exr])
+        f_r = 0
+        for _ in range(a.steps):
+            f_r += step()
+        return R.reduce(R.timed_end(t0, [exl, exr]), f_r), f_r
+
+    (dt_max, feats_all), feats = region()
+    per_rank = R.per_rank
+    regions = [(dt_max, feats_all)] + [region()[0] for _ in range(max(a.repeat, 1) - 1)]
+    R.per_rank = per_rank
 
     parity = None
     if R.rank == 0 and a.verify > 0:
@@ -750,7 +760,7 @@ def bench_kitti(R):
                      "pairs_per_step_per_gpu": B, "sequences": R.world, "features_per_pair": round(feats / a.steps / B, 1),
                      "stereo_matches_per_pair": round(float(h_nm.sum()) / B, 1)})
     out["data"] = data
-    out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels})
+    out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels, "repeats": repeats_block(regions, a.steps)})
     R.finish(out)
 
 
@@ -826,12 +836,22 @@ def bench_tumvi(R):
 
     host_enqueue = [0.0]
     run(a.settle + max(a.warmup, 1))
-    t0 = R.timed_begin([ex])
-    host_enqueue[0] = 0.0
-    feats = run(a.steps)
-    dt = R.timed_end(t0, [ex])
-    dt_max, feats_all = R.reduce(dt, feats)
+
+    def region():
+        t0 = R.timed_begin([ex])
+        host_enqueue[0] = 0.0
+        f_r = run(a.steps)
+        return R.reduce(R.timed_end(t0, [ex]), f_r), f_r
+
+    (dt_max, feats_all), feats = region()
+    per_rank = R.per_rank
+    enq = host_enqueue[0]
     last = hs[(a.steps - 1) % 2]
+    last_snapshot = {k: v.clone() for k, v in last.items()}   # the delivered step that the parity check reads (later regions reuse the buffers)
+    regions = [(dt_max, feats_all)] + [region()[0] for _ in range(max(a.repeat, 1) - 1)]
+    R.per_rank = per_rank
+    host_enqueue[0] = enq
+    last = last_snapshot
 
     parity = None
     if R.rank == 0 and a.verify > 0:
@@ -876,7 +896,7 @@ def bench_tumvi(R):
                      "map_point_matches_per_frame": round(float(last["nm"].sum()) / B, 1)})
     out["data"] = data
     out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels,
-                "host_enqueue_ms_per_step": round(host_enqueue[0] / a.steps * 1e3, 3)})
+                "host_enqueue_ms_per_step": round(host_enqueue[0] / a.steps * 1e3, 3), "repeats": repeats_block(regions, a.steps)})
     R.finish(out)
 
 
