@@ -167,7 +167,8 @@ def _ml():
         for name in ("matref_descriptor_distance", "matref_search_by_projection_mappoints", "matref_search_by_projection_frame",
                      "matref_search_by_projection_keyframe", "matref_search_by_projection_sim3", "matref_search_by_bow_frame",
                      "matref_search_by_bow_keyframes", "matref_search_for_initialization", "matref_search_for_triangulation",
-                     "matref_fuse", "matref_search_by_sim3", "matref_fuse_right", "matref_search_for_triangulation_fisheye"):
+                     "matref_fuse", "matref_search_by_sim3", "matref_fuse_right", "matref_search_for_triangulation_fisheye",
+                     "matref_search_by_bow_keyframes_fisheye"):
             getattr(L, name).restype = C.c_int
         _matcher = L
     return _matcher
@@ -275,6 +276,16 @@ def ref_search_by_bow_keyframes(d1, a1, v1, fv1, d2, a2, v2, fv2, nnratio, check
     m12 = np.full(len(d1), -1, np.int32)
     n = _ml().matref_search_by_bow_keyframes(_p(d1), _p(a1), _p(v1), len(d1), C.byref(a), _p(d2), _p(a2), _p(v2), len(d2),
                                             C.byref(b), C.c_float(nnratio), int(check_orientation), _p(m12))
+    return n, m12
+
+
+def ref_search_by_bow_keyframes_fisheye(d1, a1, v1, nleft1, fv1, d2, a2, v2, nleft2, fv2, nnratio, check_orientation):
+    """SearchByBoW(KF, KF) between fisheye-stereo key frames: features from nleft on are the right camera's (NLeft = nleft, mvKeysUn has nleft entries)."""
+    d1, d2, a1, a2, v1, v2 = _u8(d1), _u8(d2), _f32(a1), _f32(a2), _u8(v1), _u8(v2)
+    a, b = _fv(fv1), _fv(fv2)
+    m12 = np.full(len(d1), -1, np.int32)
+    n = _ml().matref_search_by_bow_keyframes_fisheye(_p(d1), _p(a1), _p(v1), len(d1), int(nleft1), C.byref(a), _p(d2), _p(a2), _p(v2), len(d2),
+                                                    int(nleft2), C.byref(b), C.c_float(nnratio), int(check_orientation), _p(m12))
     return n, m12
 
 

@@ -392,12 +392,14 @@ int matref_search_by_bow_frame_fisheye(const uint8_t *kf_desc, const float *kf_a
     return r;
 }
 
-/* M5b  ORBmatcher.cc:765-905 */
-int matref_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
-                                   const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
-                                   const uint8_t *valid2, int n2, const orbo_featvec *fv2, float nnratio,
-                                   int check_orientation, int32_t *match12) {
+/* M5b  ORBmatcher.cc:765-905; nleft >= 0: a fisheye-stereo key frame (NLeft = nleft, mvKeysUn holds the nleft left-camera keypoints only,
+ * the features from nleft on are the right camera's: :800-802 / :820-822 skip them) */
+static int bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1, int nleft1,
+                         const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                         const uint8_t *valid2, int n2, int nleft2, const orbo_featvec *fv2, float nnratio,
+                         int check_orientation, int32_t *match12) {
     KeyFrame K1, K2;
+    const int NL[2] = {nleft1, nleft2};
     KeyFrame *K[2] = {&K1, &K2};
     const uint8_t *D[2] = {desc1, desc2};
     const float *A[2] = {angle1, angle2};
@@ -407,13 +409,15 @@ int matref_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, co
     for (int s = 0; s < 2; s++) {
         KeyFrame &k = *K[s];
         k.N = N[s];
-        k.mvKeysUn.resize(N[s]);
+        const int nun = NL[s] >= 0 ? NL[s] : N[s];
+        if (NL[s] >= 0) { k.NLeft = NL[s]; k.Nleft = NL[s]; }
+        k.mvKeysUn.resize(nun);
         k.mDescriptors = cv::Mat(N[s] > 0 ? N[s] : 1, 32, CV_8UC1);
         std::memcpy(k.mDescriptors.data, D[s], (size_t)N[s] * 32);
         mps[s].resize(N[s]);
         k.mvpMapPoints.assign(N[s], nullptr);
         for (int i = 0; i < N[s]; i++) {
-            k.mvKeysUn[i].angle = A[s][i];
+            if (i < nun) k.mvKeysUn[i].angle = A[s][i];
             mps[s][i].id = i;
             if (V[s][i]) k.mvpMapPoints[i] = &mps[s][i];
             else if (i & 1) { mps[s][i].bad = true; k.mvpMapPoints[i] = &mps[s][i]; }
@@ -426,6 +430,18 @@ int matref_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, co
     int r = m.SearchByBoW(&K1, &K2, out);
     for (int i = 0; i < n1; i++) match12[i] = out[i] ? out[i]->id : -1;
     return r;
+}
+int matref_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
+                                   const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                   const uint8_t *valid2, int n2, const orbo_featvec *fv2, float nnratio,
+                                   int check_orientation, int32_t *match12) {
+    return bow_keyframes(desc1, angle1, valid1, n1, -1, fv1, desc2, angle2, valid2, n2, -1, fv2, nnratio, check_orientation, match12);
+}
+int matref_search_by_bow_keyframes_fisheye(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1, int nleft1,
+                                           const orbo_featvec *fv1, const uint8_t *desc2, const float *angle2,
+                                           const uint8_t *valid2, int n2, int nleft2, const orbo_featvec *fv2, float nnratio,
+                                           int check_orientation, int32_t *match12) {
+    return bow_keyframes(desc1, angle1, valid1, n1, nleft1, fv1, desc2, angle2, valid2, n2, nleft2, fv2, nnratio, check_orientation, match12);
 }
 
 /* M6  ORBmatcher.cc:648-763 */

@@ -240,15 +240,17 @@ public:
 
     // ORBmatcher.cc:765-905 (LoopClosing / place recognition)
     int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12) {
-        require_mono(*pKF1, "SearchByBoW(KeyFrame, KeyFrame)");
         const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
         const std::vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
         const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
         vpMatches12 = std::vector<MapPoint *>(n1, static_cast<MapPoint *>(NULL));
         std::vector<uint8_t> v1(n1), v2(n2);
-        std::vector<float> a1(n1), a2(n2);
-        for (int i = 0; i < n1; i++) { MapPoint *p = vpMapPoints1[i]; v1[i] = (p && !p->isBad()) ? 1 : 0; a1[i] = pKF1->mvKeysUn[i].angle; }
-        for (int i = 0; i < n2; i++) { MapPoint *p = vpMapPoints2[i]; v2[i] = (p && !p->isBad()) ? 1 : 0; a2[i] = pKF2->mvKeysUn[i].angle; }
+        std::vector<float> a1(n1, 0.f), a2(n2, 0.f);
+        // fisheye-stereo key frames (NLeft != -1): the features of the right camera (index >= mvKeysUn.size()) take no part, neither as
+        // queries (:800-802) nor as candidates (:820-822) -- the same as a feature without a map point
+        const int l1 = pKF1->NLeft != -1 ? std::min(n1, (int)pKF1->mvKeysUn.size()) : n1, l2 = pKF2->NLeft != -1 ? std::min(n2, (int)pKF2->mvKeysUn.size()) : n2;
+        for (int i = 0; i < n1; i++) { MapPoint *p = vpMapPoints1[i]; v1[i] = (i < l1 && p && !p->isBad()) ? 1 : 0; if (i < l1) a1[i] = pKF1->mvKeysUn[i].angle; }
+        for (int i = 0; i < n2; i++) { MapPoint *p = vpMapPoints2[i]; v2[i] = (i < l2 && p && !p->isBad()) ? 1 : 0; if (i < l2) a2[i] = pKF2->mvKeysUn[i].angle; }
         std::vector<int32_t> m12;
         const int nmatches = SearchByBoW(pKF1->mDescriptors.data, a1.data(), v1.data(), n1, FeatVec::from(pKF1->mFeatVec), pKF2->mDescriptors.data,
                                          a2.data(), v2.data(), n2, FeatVec::from(pKF2->mFeatVec), m12);

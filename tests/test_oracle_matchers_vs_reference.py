@@ -240,6 +240,28 @@ def test_search_by_bow(frames):
             assert on > 30
 
 
+def test_search_by_bow_keyframes_fisheye(frames):
+    """M5 (KeyFrame -> KeyFrame) between fisheye-stereo key frames (NLeft != -1, ORBmatcher.cc:800-802 / :820-822): the right camera's
+    features (index >= mvKeysUn.size()) are skipped as queries and as candidates -- the oracle's mono form with those features marked as
+    having no map point must give the reference's vector."""
+    k0, d0, k1, d1, _ = frames[1000]
+    rng = np.random.default_rng(41)
+    nl0, nl1 = len(k0), len(k1)
+    D0 = np.concatenate([d0, _noisy_copy(rng, d0, 0.03)]); D1 = np.concatenate([d1, _noisy_copy(rng, d1, 0.03)])   # right cameras: noisy copies
+    A0 = np.concatenate([k0["angle"], k0["angle"]]).astype(np.float32); A1 = np.concatenate([k1["angle"], k1["angle"]]).astype(np.float32)
+    for n_nodes in (100, 7):
+        na, nb = _bow_nodes(rng, k0, k1, n_nodes)
+        fva = FeatureVector.from_node_of_feature(np.concatenate([na, na])); fvb = FeatureVector.from_node_of_feature(np.concatenate([nb, nb]))
+        v0 = (rng.random(2 * nl0) < 0.8).astype(np.uint8); v1 = (rng.random(2 * nl1) < 0.8).astype(np.uint8)
+        m0 = v0.copy(); m0[nl0:] = 0
+        m1 = v1.copy(); m1[nl1:] = 0
+        for ratio, ori in ((0.7, True), (0.9, False)):
+            on, om = ob.search_by_bow_keyframes(D0, A0, m0, fva, D1, A1, m1, fvb, ratio, ori)
+            _pin(f"m5b_fisheye/{n_nodes}/{ratio}/{ori}", (on, om),
+                 lambda: rb.ref_search_by_bow_keyframes_fisheye(D0, A0, v0, nl0, fva, D1, A1, v1, nl1, fvb, ratio, ori))
+            assert on > 30 and (om[nl0:] == -1).all() and (om < nl1).all()
+
+
 def test_search_by_bow_frame_fisheye(frames):
     """M5 (KeyFrame -> Frame) with F.Nleft != -1 (ORBmatcher.cc:283-392): per-camera best / second-best over one node list, the right
     match nested inside the left branch with `|| true` for a ratio test.  Oracle only so far."""
