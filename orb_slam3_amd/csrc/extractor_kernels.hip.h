@@ -654,14 +654,6 @@ __device__ __forceinline__ void fast_tile_load(const uint8_t *__restrict__ src, 
     }
 }
 
-// A wave hands data to itself through LDS: its LDS instructions execute in program order, so a wave-private hand-over needs no s_barrier --
-// only the compiler must not move LDS accesses across the point
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // LDS of one wave (= one cell): pixel tile rows x P | queue[qcap] u16 | score per queue entry [qcap] u8.  After the scores are
 // known the pixel tile is dead and its memory becomes the zero-aproned score tile of the NMS; the survivors of the NMS
 // overwrite the head of the queue in place.  ~4.7 KB for EuRoC (P = 48, qcap = 768) -> 32 waves per CU: the kernel's time
@@ -677,7 +669,7 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
                                                size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
                                                uint32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
     const LevelInfo L = lv[t.level];
-    const int lane = threadIdx.x & 63;   // one wave per cell: alone in a 64-thread workgroup (k_fast_wave_list) or one of k_fast_strip's four
+    const int lane = threadIdx.x;
     const int cell = t.ti * L.nCols + t.tj;
     int32_t *cnt_out = cellcnt + (size_t)f * total_cells + L.cell_base + cell;
 
@@ -696,7 +688,7 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
 
     // phase 0: (unaligned) dword loads starting one byte left of the sub-image
     fast_tile_load<P>(pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1, L.pitch, rows, cols, pix, lane);
-    wave_lds_sync();  // a wave-private hand-over through LDS: an ordering point, no s_barrier
+    __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
 
     // phase 1: antipodal-pair test at minTh, four pixels per lane; passing pixels are queued in row-major order
     int qn = 0;
@@ -750,7 +742,7 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
             qn += tot;
         }
     }
-    wave_lds_sync();
+    __syncthreads();
 
     // phase 2: exact score of the queued pixels, kept per queue entry while the pixel tile is still being read
     for (int e0 = 0; e0 < qn; e0 += 128) {   // two queue entries per lane (fast_score16_x2)
@@ -761,16 +753,16 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
         if (ea < qn) scq[ea] = (uint8_t)((sa >= minTh) ? sa : 0);
         if (eb < qn) scq[eb] = (uint8_t)((sb >= minTh) ? sb : 0);
     }
-    wave_lds_sync();
+    __syncthreads();
     // the pixel tile is dead: its memory becomes the score tile (pitch P, 1-px zero apron)
     uint8_t *sco = pix;
     for (int i = lane; i < (ih + 2) * (P / 4); i += 64) reinterpret_cast<uint32_t *>(sco)[i] = 0;
-    wave_lds_sync();
+    __syncthreads();
     for (int e = lane; e < qn; e += 64) {
         const int s = scq[e];
         if (s) { const int q = queue[e]; sco[((q >> 8) + 1) * P + (q & 0xff) + 1] = (uint8_t)s; }
     }
-    wave_lds_sync();
+    __syncthreads();
 
     // phase 3: NMS over the queued pixels, strict '>' against all 8 neighbours ([OCV] FAST_t nonmax stage); the survivors
     // (row-major order kept) overwrite the head of the queue
@@ -791,7 +783,7 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
         if (keep) queue[ns + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)q;  // ns + rank <= e: never ahead of an unread entry
         ns += __popcll(b);
     }
-    wave_lds_sync();
+    __syncthreads();
 
     // phase 4: emission in row-major order of the survivors at the cell's threshold
     const int thr = any_ini ? iniTh : minTh;
@@ -809,6 +801,14 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
     if (lane == 0) *cnt_out = total;
 }
 
+// A wave hands data to itself through LDS: its LDS instructions execute in program order, so a wave-private hand-over needs no s_barrier --
+// only the compiler must not move LDS accesses across the point
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // k_fast_wave_list: the cells k_fast_strip put on its list -- no corner at iniTh (6 % of the cells of the EuRoC-like bench: the reference's
 // second pass, :843-846) or a strip whose queues overflowed -- one wave per cell with the complete ini / min logic of fast_wave_cell and a
 // queue that holds a whole cell.  grid (any), block 64, LDS for qcap = max interior pixels
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(64) void k_fast_wave_list(const LevelInfo *__restri
         const uint32_t e = list[k];
         fast_wave_cell<P>(tiles[e & 0xffffu], (int)(e >> 16), e & 0xffffu, smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent,
                           ent_frame_stride, iniTh, minTh, max_rows, qcap, nullptr, nullptr);
-        wave_lds_sync();
+        __syncthreads();
     }
 }
 

@@ -56,19 +56,14 @@ static_assert(sizeof(StripTile) == 48, "StripTile layout");
 // per wave: group queue u16[gcap] (dead after stage B: the scores u8[qcap] of the pixel queue reuse its bytes, qcap <= 2 gcap) | pixel queue u16[qcap]
 __host__ __device__ inline size_t fast_strip_wave_bytes(int gcap, int qcap) { return ((size_t)gcap * 2 + (size_t)qcap * 2 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t fast_strip_lds_bytes(int waves, int pix_bytes, int gcap, int qcap) {
-    return (size_t)pix_bytes + waves * fast_strip_wave_bytes(gcap, qcap) + (waves * kStripMaxCells + 4 + kStripMaxCells) * sizeof(int32_t);
+    return (size_t)pix_bytes + waves * fast_strip_wave_bytes(gcap, qcap) + (waves * kStripMaxCells + 4) * sizeof(int32_t);
 }
-struct StripSecondPass {   // the in-place second pass (fast_wave_cell): per-cell tile table, level table, LDS slice of a wave
-    const TileRef *cell_tiles;
-    const LevelInfo *lv;
-    int32_t min_th, cell_rows, cell_qcap, slice_bytes;   // cell_qcap <= 0: every empty cell goes to the list kernel
-};
 
 template <int W, int P>   // W waves per workgroup = row bands per strip; P = LDS pitch of the tile
 __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f, uint8_t *smem, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
                                                 int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent, size_t ent_frame_stride,
                                                 int iniTh, int pix_bytes, int gcap, int qcap, uint32_t *__restrict__ list, int32_t *__restrict__ list_count,
-                                                int second_pass, const StripSecondPass &sp) {
+                                                int second_pass) {
     constexpr int D = P / 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int iw = T.iw, ih = T.ih, rows = ih + 6;
@@ -78,7 +73,7 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
     uint16_t *pq = gq + gcap;                                     // pixel queue -> corners -> survivors (compacted in place)
     uint8_t *ps = reinterpret_cast<uint8_t *>(gq);                // score per pixel-queue entry, written when the group queue is dead
     int32_t *cnt = reinterpret_cast<int32_t *>(smem + (size_t)pix_bytes + W * fast_strip_wave_bytes(gcap, qcap));   // [W][8] survivors per (wave, cell)
-    int32_t *ovf = cnt + W * kStripMaxCells;   // [0] queue overflow flag, [1 .. 8] survivors per cell
+    int32_t *ovf = cnt + W * kStripMaxCells;
     if (threadIdx.x == 0) *ovf = 0;
 
     // ---- phase 0: rows wave, wave + 4, ... ; lane = dword of the row (G + 2 <= 66 dwords: the two beyond lane 63 in a second sweep) ----
@@ -295,31 +290,21 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
 #pragma unroll
         for (int w = 0; w < W; w++) total += cnt[w * kStripMaxCells + lane];
         if (total > 0 || !second_pass) cellcnt[(size_t)f * total_cells + T.cell0 + lane] = total;
-        else if (sp.cell_qcap <= 0) list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + lane);   // second pass by the list kernel
-        ovf[1 + lane] = total;
+        else list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + lane);   // cv::FAST(cell, iniThFAST) found nothing: second pass (:843-846)
     }
-    if (!second_pass || sp.cell_qcap <= 0) return;
-    // ---- second pass of the reference (:843-846) for the strip's cells without a corner at iniTh, in place: cv::FAST(cell, minThFAST) by
-    // fast_wave_cell, one wave per such cell on a quarter of the workgroup's LDS (the tile is re-read: it sits in this XCD's L2).  A cell whose
-    // candidates outgrow that slice goes to the list kernel.  Saves the list pass its scattered re-reads (91 MB per 256 frames for 6 % of the cells).
-    __syncthreads();
-    for (int c = wave; c < ncell; c += W)
-        if (ovf[1 + c] == 0)
-            fast_wave_cell<64>(sp.cell_tiles[T.cell0 + c], f, T.cell0 + c, smem + (size_t)wave * sp.slice_bytes, sp.lv, pyr, pyr_frame_stride, cellcnt, total_cells,
-                               cellent, ent_frame_stride, iniTh, sp.min_th, sp.cell_rows, sp.cell_qcap, list, list_count);
 }
 
 template <int W>
-__global__ __launch_bounds__(64 * W, 7) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
+__global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
                                                        size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
                                                        uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
                                                        int pix_bytes, int gcap, int qcap, uint32_t *__restrict__ list,
-                                                       int32_t *__restrict__ list_count, int second_pass, const StripSecondPass sp, int n_frames) {
+                                                       int32_t *__restrict__ list_count, int second_pass, int n_frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int tile, f;
     if (!xcd_frame_map(n_frames, &tile, &f)) return;   // a frame's strips stay on one XCD (apron rows hit its L2)
     const StripTile T = tiles[tile];
-#define ORBX_STRIP_BODY(PITCH) fast_strip_body<W, PITCH>(T, f, smem, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, pix_bytes, gcap, qcap, list, list_count, second_pass, sp)
+#define ORBX_STRIP_BODY(PITCH) fast_strip_body<W, PITCH>(T, f, smem, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, pix_bytes, gcap, qcap, list, list_count, second_pass)
     if (T.lds_pitch == (uint32_t)kStripPitch) ORBX_STRIP_BODY(kStripPitch);          // wave-uniform
     else if (T.lds_pitch == (uint32_t)kStripPitchMid) ORBX_STRIP_BODY(kStripPitchMid);
     else ORBX_STRIP_BODY(kStripPitchLow);

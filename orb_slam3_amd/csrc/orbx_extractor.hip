@@ -434,18 +434,11 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             // (Level 0's strips on the aux stream beside the latency-bound resize chain were measured: EuRoC 1.10 vs 1.11 ms, but TUM-VI 1.02 vs
             // 0.84 ms -- with the default four hardware queues the aux stream shares one with the matcher, with eight everything else slows:
             // profiles/r03_j_*, r03_k_*.  One launch on the main stream.)
-            StripSecondPass sp;
-            sp.cell_tiles = (const TileRef *)ex->d_fast_tiles.p; sp.lv = d_lv; sp.min_th = mn; sp.cell_rows = ex->fast_wave_rows;
-            sp.slice_bytes = (int)(((size_t)ex->strip_pix_bytes + 4 * fast_strip_wave_bytes(ex->strip_gcap, ex->strip_qcap)) / 4) & ~15;
-            sp.cell_qcap = ((sp.slice_bytes - (int)(((size_t)sp.cell_rows * 64 + 16 + 15) & ~(size_t)15) - 16) / 3) & ~15;
-            static const bool sp_list = [] { const char *v = getenv("ORBX_SECOND_PASS"); return v && v[0] == 'l'; }();   // TEMPORARY (A/B visit)
-            if (sp.cell_qcap < 64 || sp_list) sp.cell_qcap = 0;   // no room for a cell's queue in a quarter of the LDS: the list kernel takes every empty cell
             hipLaunchKernelGGL(k_fast_strip<4>, xcd_grid(ex->n_strips, n), dim3(256), fast_strip_lds_bytes(4, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap), st,
                                (const StripTile *)ex->d_strips.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,
                                (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
-                               ini > mn ? 1 : 0, sp, n);
-            // what is left on the list: strips whose queues overflowed, cells whose second pass outgrew its LDS slice: one wave per listed cell, queue
-            // sized for a whole cell
+                               ini > mn ? 1 : 0, n);
+            // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
     hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(16384), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
