@@ -168,7 +168,7 @@ def _ml():
                      "matref_search_by_projection_keyframe", "matref_search_by_projection_sim3", "matref_search_by_bow_frame",
                      "matref_search_by_bow_keyframes", "matref_search_for_initialization", "matref_search_for_triangulation",
                      "matref_fuse", "matref_search_by_sim3", "matref_fuse_right", "matref_search_for_triangulation_fisheye",
-                     "matref_search_by_bow_keyframes_fisheye"):
+                     "matref_search_by_bow_keyframes_fisheye", "matref_search_by_projection_keyframe_fisheye"):
             getattr(L, name).restype = C.c_int
         _matcher = L
     return _matcher
@@ -249,6 +249,19 @@ def ref_search_by_projection_keyframe(F: RefFrame, q, th, orb_dist, check_orient
     arrs = [_f32(q["x"]), _f32(q["y"]), _i32(q["level"]), _f32(q["angle"]), _u8(q["desc"])]
     n = _ml().matref_search_by_projection_keyframe(*F.head(), _p(occ), len(arrs[0]), *[_p(x) for x in arrs], _p(sk),
                                                   C.c_float(th), int(orb_dist), int(check_orientation), _p(m))
+    return n, m
+
+
+def ref_search_by_projection_keyframe_fisheye(kps_left, kps_right, desc, bounds, scale_factors, q, th, orb_dist, check_orientation=True,
+                                              occupied=None, skip=None):
+    """M3 on a fisheye-stereo current frame (Nleft != -1): features left then right, desc / occupied over all of them."""
+    kl, kr = np.ascontiguousarray(kps_left, KP_DTYPE), np.ascontiguousarray(kps_right, KP_DTYPE)
+    desc, b, sf, occ, sk = _u8(desc), _f32(bounds), _f32(scale_factors), _u8(occupied), _u8(skip)
+    m = np.full(len(kl) + len(kr), -1, np.int32)
+    arrs = [_f32(q["x"]), _f32(q["y"]), _i32(q["level"]), _f32(q["angle"]), _u8(q["desc"])]
+    n = _ml().matref_search_by_projection_keyframe_fisheye(_p(kl), len(kl), _p(kr), len(kr), _p(desc), _p(b), _p(sf), len(sf), _p(occ),
+                                                          len(arrs[0]), *[_p(x) for x in arrs], _p(sk), C.c_float(th), int(orb_dist),
+                                                          int(check_orientation), _p(m))
     return n, m
 
 

@@ -291,6 +291,55 @@ int matref_search_by_projection_keyframe(const orbo_keypoint *kps, const uint8_t
     return r;
 }
 
+/* M3 on a fisheye-stereo frame (CurrentFrame.Nleft != -1): the reference has no special case -- GetFeaturesInArea's default bRight = false
+ * searches the LEFT camera's grid (mvKeys), mvKeysUn == mvKeys (Frame.cc:751), so the right camera's features [n_left, N) are neither candidates
+ * nor written; desc / occupied cover all N features */
+int matref_search_by_projection_keyframe_fisheye(const orbo_keypoint *kps_left, int n_left, const orbo_keypoint *kps_right, int n_right,
+                                                 const uint8_t *desc, const float *bounds, const float *scale, int nlevels,
+                                                 const uint8_t *occupied, int n_q, const float *q_x, const float *q_y, const int32_t *q_level,
+                                                 const float *q_angle, const uint8_t *q_desc, const uint8_t *q_skip, float th, int orb_dist,
+                                                 int check_orientation, int32_t *match) {
+    GeometricCamera cam;
+    Frame Cur;
+    KeyFrame KF;
+    const int N = n_left + n_right;
+    fill(Cur, kps_left, n_left, desc, Bounds{bounds[0], bounds[1], bounds[2], bounds[3]}, scale, nullptr, nullptr, nlevels, nullptr, &cam);
+    Cur.N = N; Cur.Nleft = n_left; Cur.NLeft = n_left;
+    Cur.mDescriptors = cv::Mat(N > 0 ? N : 1, 32, CV_8UC1);
+    if (N) std::memcpy(Cur.mDescriptors.data, desc, (size_t)N * 32);
+    Cur.kps_right.assign(kps_right, kps_right + n_right);
+    Cur.mvKeysRight.resize(n_right);
+    for (int i = 0; i < n_right; i++)
+        Cur.mvKeysRight[i] = cv::KeyPoint(kps_right[i].x, kps_right[i].y, kps_right[i].size, kps_right[i].angle, kps_right[i].response, kps_right[i].octave, i);
+    Cur.grid_right = orbo_grid_create(Cur.kps_right.data(), n_right, bounds[0], bounds[1], bounds[2], bounds[3]);
+    Cur.mvuRight.assign(N, -1.f);
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    Cur.mvpMapPoints.assign(N, nullptr);
+    for (int i = 0; i < N; i++)
+        if (occupied && occupied[i]) Cur.mvpMapPoints[i] = marker(pool, 0);
+    KF.N = n_q;
+    KF.mvKeysUn.resize(n_q);
+    KF.mvpMapPoints.resize(n_q);
+    std::vector<MapPoint> mps(n_q);
+    std::set<MapPoint *> found;
+    for (int j = 0; j < n_q; j++) {
+        MapPoint &p = mps[j];
+        p.id = j;
+        p.pos = Eigen::Vector3f(q_x[j], q_y[j], 1.f);
+        p.pred_scale = q_level[j];
+        p.desc = desc_row(q_desc + (size_t)j * 32);
+        KF.mvKeysUn[j].angle = q_angle[j];
+        KF.mvpMapPoints[j] = &p;
+        if (q_skip && q_skip[j] == 1) KF.mvpMapPoints[j] = nullptr;
+        if (q_skip && q_skip[j] == 2) p.bad = true;
+        if (q_skip && q_skip[j] == 3) found.insert(&p);
+    }
+    ORBmatcher m(0.9f, check_orientation != 0);
+    int r = m.SearchByProjection(Cur, &KF, found, th, orb_dist);
+    for (int i = 0; i < N; i++) match[i] = (Cur.mvpMapPoints[i] && Cur.mvpMapPoints[i]->id >= 0) ? Cur.mvpMapPoints[i]->id : -1;
+    return r;
+}
+
 /* M4  ORBmatcher.cc:427-535 (variant 0) and :537-646 (variant 1, with the parallel key frame vectors) */
 int matref_search_by_projection_sim3(const orbo_keypoint *kps, const uint8_t *desc, int n, const float *bounds,
                                      const float *scale, int nlevels, const uint8_t *occupied, int n_q, const float *q_x,

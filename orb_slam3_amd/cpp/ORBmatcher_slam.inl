@@ -152,7 +152,10 @@ public:
 
     // ORBmatcher.cc:1889-2010 (Tracking::Relocalization)
     int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist) {
-        require_mono(CurrentFrame, "SearchByProjection(Frame, KeyFrame)");
+        // a fisheye-stereo frame (Nleft != -1) takes the same path over its LEFT camera: the reference's GetFeaturesInArea call has the default
+        // bRight = false, mvKeysUn == mvKeys there (Frame.cc:751); the right camera's features are neither candidates nor written
+        const bool fisheye = CurrentFrame.Nleft != -1;
+        const int NL = fisheye ? CurrentFrame.Nleft : CurrentFrame.N;
         const Sophus::SE3f Tcw = CurrentFrame.GetPose();
         Eigen::Vector3f Ow = Tcw.inverse().translation();
         const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
@@ -175,16 +178,17 @@ public:
             q.x.push_back(uv(0)); q.y.push_back(uv(1));
             q.r.push_back(th * CurrentFrame.mvScaleFactors[nPredictedLevel]);        // :1940
             q.minLevel.push_back(nPredictedLevel - 1); q.maxLevel.push_back(nPredictedLevel + 1);
-            q.angle.push_back(pKF->mvKeysUn[i].angle);                              // :1973
+            q.angle.push_back(i < pKF->mvKeysUn.size() ? pKF->mvKeysUn[i].angle : 0.f);   // :1973 (the reference reads past mvKeysUn for a right-camera feature of a fisheye key frame)
             push_desc(q.descriptors, pMP->GetDescriptor());
             live.push_back(pMP);
         }
-        std::vector<uint8_t> occupied(CurrentFrame.N);
-        for (int i = 0; i < CurrentFrame.N; i++) occupied[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;   // :1955: any map point blocks the slot
+        std::vector<uint8_t> occupied(NL);
+        for (int i = 0; i < NL; i++) occupied[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;   // :1955: any map point blocks the slot
         std::vector<int32_t> match;
-        const int nmatches = SearchByProjectionWindow(view_of(CurrentFrame, CurrentFrame.mvKeysUn, false), occupied, q, (float)ORBdist,
-                                                      mbCheckOrientation, match);
-        for (int i = 0; i < CurrentFrame.N; i++) {
+        FrameView fv = view_of(CurrentFrame, fisheye ? CurrentFrame.mvKeys : CurrentFrame.mvKeysUn, false);
+        fv.N = NL;
+        const int nmatches = SearchByProjectionWindow(fv, occupied, q, (float)ORBdist, mbCheckOrientation, match);
+        for (int i = 0; i < NL; i++) {
             if (match[i] >= 0) CurrentFrame.mvpMapPoints[i] = live[match[i]];
             else if (match[i] == -2) CurrentFrame.mvpMapPoints[i] = NULL;           // :2001
         }

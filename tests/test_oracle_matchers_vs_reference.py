@@ -209,6 +209,34 @@ def test_search_by_projection_keyframe_and_sim3(frames):
         assert on > 100
 
 
+def test_search_by_projection_keyframe_fisheye_frame(frames):
+    """M3 (ORBmatcher.cc:1887-2010) on a fisheye-stereo current frame (Nleft != -1): the reference takes no special path -- its
+    GetFeaturesInArea call searches the LEFT camera's grid (bRight defaults to false) and mvKeysUn == mvKeys there -- so the result is the
+    mono search over the left features; the right camera's features are neither candidates nor written."""
+    k0, d0, k1, d1, tab = frames[1000]
+    sf = tab["scale"]
+    rng = np.random.default_rng(23)
+    lvl = k0["octave"]
+    x = (k0["x"] - 2.0 + rng.normal(0, 1.0, len(k0))).astype(np.float32)
+    y = (k0["y"] - 1.0).astype(np.float32)
+    inside = (x >= 0) & (x < W) & (y >= 0) & (y < H)
+    x, y, lvl, ang, dq = x[inside], y[inside], lvl[inside], k0["angle"][inside], _noisy_copy(rng, d0[inside], 0.03)
+    nl = len(k1)
+    k_right = k1.copy(); k_right["x"] = np.clip(k1["x"] - 7.0, 0, W - 1).astype(np.float32)       # the right camera: shifted copies
+    desc_all = np.concatenate([d1, _noisy_copy(rng, d1, 0.01)])                                   # ... with BETTER descriptors than the left ones
+    occ_all = (rng.random(2 * nl) < 0.1).astype(np.uint8)
+    grid = ob.OracleGrid(k1, 0.0, float(W), 0.0, float(H))
+    bounds = np.array([0.0, W, 0.0, H], np.float32)
+    for th, orbdist, ori in ((10.0, 100, True), (3.0, 64, False)):
+        q = dict(x=x, y=y, r=(np.float32(th) * sf[lvl]).astype(np.float32), min_level=lvl - 1, max_level=lvl + 1, angle=ang, desc=dq)
+        on, om = ob.search_by_projection_window(grid, d1, q, float(orbdist), ori, False, occ_all[:nl])
+        full = np.concatenate([om, np.full(nl, -1, np.int32)])
+        _pin(f"m3_fisheye/{th}/{orbdist}/{ori}", (on, full),
+             lambda: rb.ref_search_by_projection_keyframe_fisheye(k1, k_right, desc_all, bounds, sf, dict(x=x, y=y, level=lvl, angle=ang, desc=dq),
+                                                                 th, orbdist, ori, occ_all))
+        assert on > 100
+
+
 def _bow_nodes(rng, k_a, k_b, n_nodes=100, noise=0.15):
     def node(k):
         return (np.floor(k["x"] / 60).astype(np.int64) * 7 + np.floor(k["y"] / 60).astype(np.int64) * 13 + k["octave"] * 31) % n_nodes
