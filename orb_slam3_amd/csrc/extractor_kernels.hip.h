@@ -1105,6 +1105,16 @@ constexpr int kDescAP = 40, kDescAR = 31;   // orientation patch in LDS: 31 rows
 constexpr int kDescBP = 44, kDescBR = 37;   // BRIEF patch in LDS: 37 rows x 44 B (10 aligned dwords used)
 constexpr int kDescWaveLds = kDescAP * kDescAR + kDescBP * kDescBR + 12;  // 2880 B, multiple of 16
 
+// orbx_extract (one frame per call, results wanted on the host at once): k_describe stores the frame's keypoints and descriptors a second time,
+// into a pinned host block, with the error word / count / monocular index in front -- the call then ends with ONE stream synchronisation
+// instead of three copy-and-wait round trips (85 of 256 us per call, tools/latency_timeline.sh).  hdr == nullptr: no mirror (every batched path).
+struct HostMirror {
+    int32_t *hdr;            // [0] device error word, [1] count, [2] monoIndex
+    orbx_keypoint *kps;      // [cap]
+    uint8_t *desc;           // [cap][32]
+    const int32_t *err, *mono;
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // k_describe: IC_Angle on the UNBLURRED level (:76-103), steered 256-pair BRIEF on the BLURRED level (:107-146), keypoint record +
 // descriptor written to the final slot.  TWO keypoints per wave, one per half (32 lanes): about a third of the one-keypoint-per-wave
@@ -1119,13 +1129,15 @@ constexpr int kDescWaveLds = kDescAP * kDescAR + kDescBP * kDescBR + 12;  // 288
 __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
                                                    const int32_t *__restrict__ count, int cap, const uint8_t *__restrict__ pyr,
                                                    size_t pyr_frame_stride, const uint8_t *__restrict__ blur, size_t blur_frame_stride,
-                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc, int strict_mul_add, int n_frames) {
+                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc, int strict_mul_add, int n_frames,
+                                                   const HostMirror hm) {
     __shared__ __attribute__((aligned(16))) uint8_t patches[4 * 2 * kDescWaveLds];
     int bx, f;
     if (!xcd_frame_map(n_frames, &bx, &f)) return;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, hw = lane >> 5, hl = lane & 31;
     const int cnt = count[f];
+    if (hm.hdr && bx == 0 && f == 0 && threadIdx.x == 0) { hm.hdr[0] = *hm.err; hm.hdr[1] = cnt; hm.hdr[2] = hm.mono[0]; }
     const int g0 = (bx * 4 + wv) * 2;   // first keypoint of the wave
     if (g0 >= cnt) return;              // wave-uniform
     const bool live = g0 + hw < cnt;    // an odd count leaves the last wave's second half idle: it repeats the last keypoint and stores nothing
@@ -1225,6 +1237,7 @@ __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ 
     if (!live) return;
     const size_t slot = (size_t)f * cap + w.pos;
     if (hl < 8) reinterpret_cast<uint32_t *>(desc + slot * 32)[hl] = mine;
+    if (hm.hdr && hl < 8) reinterpret_cast<uint32_t *>(hm.desc + (size_t)w.pos * 32)[hl] = mine;
     if (hl == 0) {
         orbx_keypoint kp;
         float x = (float)kx, y = (float)ky;
@@ -1232,6 +1245,7 @@ __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ 
         kp.x = x; kp.y = y; kp.size = w.size; kp.angle = angle; kp.response = (float)key_s(w.key);
         kp.octave = w.level; kp.class_id = -1;
         kps[slot] = kp;
+        if (hm.hdr) hm.kps[w.pos] = kp;
     }
 }
 

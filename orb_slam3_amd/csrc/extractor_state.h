@@ -128,7 +128,7 @@ struct orbx_extractor {
     // device memory
     DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_tiles, d_dc;
     DevBuf d_pyr, d_blur, d_cellcnt, d_cellent, d_keys0, d_keys1, d_nof0, d_nof1, d_lvlkp, d_lvlcnt, d_candtot, d_work;
-    DevBuf d_kps, d_desc, d_count, d_mono, d_err, d_img;
+    DevBuf d_kps, d_desc, d_count, d_mono, d_err;
     DevBuf d_mkey1, d_mkey2, d_mocc, d_mentries, d_mprobs, d_mres, d_mscale, d_mgrid;  // batched frame-to-frame matcher scratch
     // pinned host staging
     void *h_stage = nullptr;

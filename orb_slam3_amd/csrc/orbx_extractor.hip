@@ -358,7 +358,7 @@ struct ProfScope {
 
 // enqueue the whole extraction of `n` device-resident frames on ex->stream
 static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride,
-                           int lap0, int lap1, hipEvent_t ev_input_consumed = nullptr) {
+                           int lap0, int lap1, hipEvent_t ev_input_consumed = nullptr, const HostMirror *mirror = nullptr) {
     RoctxRange rr("orbx:extract");
     ex->internal_match_owner = 0;   // a new batch: its first batched matcher owns the internal match buffers
     const int nl = ex->prm.nlevels;
@@ -397,7 +397,9 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         if (ex->resize_march_ok[l]) {
             // register-marching form: one wave = 64 dword columns x rb output rows (rb 16 / 32 and 4 / 8 source rows in flight measured
             // alike, 64 rows per block 5 % slower: profiles/r03_c_ab_resize_march_strip_waves_prime.log)
-            const int nstrips = (L.pitch / 4 + 63) / 64, rb = L.h >= 256 ? 32 : 16, n_items = nstrips * ((L.h + rb - 1) / rb);
+            // A few frames cannot fill the machine and the launch lasts as long as ONE wave's march: short blocks then (single-frame call: 32 / 16 /
+            // 8 / 4 rows per block = 0.215 / 0.202 / 0.190 / 0.181 ms, profiles/r03_s_single_frame_latency.log)
+            const int nstrips = (L.pitch / 4 + 63) / 64, rb = n <= 8 ? 4 : L.h >= 256 ? 32 : 16, n_items = nstrips * ((L.h + rb - 1) / rb);
             const uint32_t rcp = (uint32_t)((0x100000000ull + (uint64_t)nstrips - 1) / (uint64_t)nstrips);
             hipLaunchKernelGGL(k_pyr_resize_march<8>, xcd_grid((n_items + 3) / 4, n, pyr_local), dim3(256), 0, pst, L, ex->lv[l - 1],
                                (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame, rb, nstrips, rcp, n_items, n);
@@ -502,7 +504,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         hipLaunchKernelGGL(k_describe, xcd_grid((ex->cap + 7) / 8, n), dim3(256), 0, st, (const DescConst *)ex->d_dc.p,
                            (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
                            ex->pyr_frame, (const uint8_t *)blur_slab, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
-                           (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0, n);
+                           (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0, n,
+                           mirror && n == 1 ? *mirror : HostMirror{nullptr, nullptr, nullptr, nullptr, nullptr});
     }
     if (ex->has_camera) {   // Frame::UndistortKeyPoints for the whole batch (mvKeysUn for the batched matchers)
         CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],
@@ -679,7 +682,7 @@ void orbx_destroy(orbx_extractor *ex) {
     for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales}) b->release();
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
-                      &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err, &ex->d_img,
+                      &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
                       &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_strips};
@@ -913,15 +916,32 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
     int r = configure(ex, width, height, 1);
     if (r != ORBX_OK) return r;
     const size_t dpitch = ((size_t)width + 63) & ~(size_t)63;
-    if ((r = ex->d_img.ensure(dpitch * height)) != ORBX_OK) return r;
-    // the caller's image goes through the pinned staging buffer (rows packed to the device pitch), never to the runtime directly
-    if ((r = ex->ensure_stage(std::max(dpitch * height, 64 + (size_t)ex->cap * (sizeof(orbx_keypoint) + 32)))) != ORBX_OK) return r;
+    // the caller's image goes into the pinned staging block (rows packed to the device pitch), never to the runtime directly, and k_pyr_base
+    // reads that block over the link itself (6.7 -> 13 us for the kernel, but no copy command and no wait for it: 0.190 -> 0.180 ms per call);
+    // the results come back into the same block, written by k_describe (HostMirror): ONE synchronisation ends the call
+    const size_t img_bytes = (dpitch * height + 255) & ~(size_t)255, kp_bytes = (sizeof(orbx_keypoint) * (size_t)ex->cap + 63) & ~(size_t)63;
+    if ((r = ex->ensure_stage(img_bytes + 64 + kp_bytes + (size_t)32 * ex->cap)) != ORBX_OK) return r;
     for (int y = 0; y < height; y++) memcpy((uint8_t *)ex->h_stage + (size_t)y * dpitch, image + (size_t)y * stride, (size_t)width);
-    // on the stream that runs k_pyr_base (the pyramid stream when the pyramid is built ahead): the upload must be ordered before it
-    ORBX_HIP(hipMemcpyAsync(ex->d_img.p, ex->h_stage, dpitch * height, hipMemcpyHostToDevice, ex->stream));
-    r = enqueue_extract(ex, (const uint8_t *)ex->d_img.p, 1, dpitch, dpitch * height, lap0, lap1);
+    uint8_t *hb = (uint8_t *)ex->h_stage + img_bytes;
+    const HostMirror hm = {(int32_t *)hb, (orbx_keypoint *)(hb + 64), hb + 64 + kp_bytes, (const int32_t *)ex->d_err.p, (const int32_t *)ex->d_mono.p};
+    r = enqueue_extract(ex, (const uint8_t *)ex->h_stage, 1, dpitch, dpitch * height, lap0, lap1, nullptr, &hm);
     if (r != ORBX_OK) return r;
-    return orbx_batch_download(ex, 0, kps, desc, cap, n_out, mono_index);
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    int32_t hdr[3];
+    memcpy(hdr, hm.hdr, sizeof(hdr));
+    if (hdr[0] != 0) {
+        set_error("device-side consistency check failed, code " + std::to_string(hdr[0]));
+        (void)hipMemsetAsync(ex->d_err.p, 0, sizeof(int32_t), ex->stream);
+        return ORBX_E_INTERNAL;
+    }
+    if (n_out) *n_out = hdr[1];
+    if (mono_index) *mono_index = hdr[2];
+    if (hdr[1] > cap) return ORBX_E_CAPACITY;
+    if (hdr[1] > 0) {
+        if (kps) memcpy(kps, hm.kps, sizeof(orbx_keypoint) * (size_t)hdr[1]);
+        if (desc) memcpy(desc, hm.desc, (size_t)32 * hdr[1]);
+    }
+    return ORBX_OK;
 }
 
 int orbx_level_size(orbx_extractor *ex, int width, int height, int level, int *w, int *h) {

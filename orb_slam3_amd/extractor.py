@@ -25,6 +25,7 @@ class ORBextractor:
         check(self._L.orbx_create(C.byref(prm), device, 0, 0, 0, C.byref(self._h)), "orbx_create")
         self.nfeatures, self.nlevels, self.device = nfeatures, nlevels, device
         self._last_shape = None
+        self._cap_of = {}   # (width, height) -> output capacity
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -40,9 +41,11 @@ class ORBextractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         h, w = image.shape
-        cap = check(self._L.orbx_output_capacity(self._h, w, h), "orbx_output_capacity")
-        kps = np.zeros(cap, KP_DTYPE)
-        desc = np.zeros((cap, 32), np.uint8)
+        cap = self._cap_of.get((w, h))
+        if cap is None:
+            cap = self._cap_of[(w, h)] = check(self._L.orbx_output_capacity(self._h, w, h), "orbx_output_capacity")
+        kps = np.empty(cap, KP_DTYPE)
+        desc = np.empty((cap, 32), np.uint8)
         n, mono = C.c_int(0), C.c_int(0)
         st = self._L.orbx_extract(self._h, ptr(image), w, h, image.strides[0], int(vLappingArea[0]),
                                   int(vLappingArea[1]), ptr(kps), ptr(desc), cap, C.byref(n), C.byref(mono))

@@ -195,6 +195,27 @@ def test_batch_device_matches_single(canvas1):
         assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), t
 
 
+def test_single_frame_call_host_block_equals_device_buffers(canvas1):
+    """orbx_extract hands its results over in a pinned host block the last kernel writes itself (one synchronisation per call); the device
+    buffers the batched matchers read hold the same keypoints and descriptors, and a frame with no keypoint at all comes back as count 0."""
+    from orb_slam3_amd import synth
+    ex, oex = _pair(1000)
+    for t in range(3):
+        img = synth.frame_from_canvas(canvas1, t, 752, 480, 1500 + t)
+        mono, kps, desc = ex(img, None, (0, 1000))
+        dmono, dkps, ddesc = ex.download(0)
+        omono, okps, odesc = oex.extract(img, lap=(0, 1000))
+        assert mono == dmono == omono
+        assert kps.tobytes() == dkps.tobytes() == okps.tobytes()
+        assert np.array_equal(desc, ddesc) and np.array_equal(desc, odesc)
+    mono, kps, desc = ex(np.full((480, 752), 77, np.uint8), None, (0, 0))
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    img = synth.frame_from_canvas(canvas1, 9, 752, 480, 1509)          # and the block is rewritten by the next call
+    mono, kps, desc = ex(img, None, (0, 0))
+    omono, okps, odesc = oex.extract(img, lap=(0, 0))
+    assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+
+
 def test_device_introsort_replica_matches_libstdcxx():
     """k_octree's std::sort replica vs libstdc++ on (count, UL.x) pairs with many ties, incl. sizes around the
     insertion-sort threshold and adversarial (heap-sort fallback) inputs."""
