@@ -24,9 +24,20 @@ public:
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
 };
 
+class GeometricCamera;
 class Frame {
 public:
     int N = 0, Nleft = -1;
+    /* fisheye stereo (Frame::ComputeStereoFishEyeMatches, Frame.cc:1126-1166) */
+    int Nright = -1, monoLeft = -1, monoRight = -1, mnCloseMPs = 0;
+    std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;
+    std::vector<Eigen::Vector3f> mvStereo3Dpoints;
+    std::vector<float> mvLevelSigma2;
+    GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+    Eigen::Matrix3f mRlr;
+    Eigen::Vector3f mtlr;
+    static cv::BFMatcher BFmatcher;   /* Frame.cc:43: cv::BFMatcher(cv::NORM_HAMMING) */
+    void ComputeStereoFishEyeMatches();
     std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
     std::vector<float> mvuRight, mvDepth;
     cv::Mat mDescriptors, mDescriptorsRight;
@@ -84,6 +95,24 @@ public:
     }
     bool epipolarConstrain(GeometricCamera *pCamera2, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const Eigen::Matrix3f &R12,
                            const Eigen::Vector3f &t12, const float sigmaLevel, const float unc);
+};
+
+/* stand-in for CameraModels/KannalaBrandt8 (host geometry of the caller's camera objects, outside the path): TriangulateMatches
+ * (KannalaBrandt8.cpp:306) hands the two keypoints' ABSOLUTE indices and the level sigmas to a callback the test supplies */
+typedef float (*frame_mock_triangulate_fn)(void *ctx, int i_left, int i_right, float sigma1, float sigma2, float *p3d);
+class KannalaBrandt8 : public GeometricCamera {
+public:
+    Frame *frame = nullptr;
+    frame_mock_triangulate_fn fn = nullptr;
+    void *ctx = nullptr;
+    Eigen::Matrix3f toK_() override { return Eigen::Matrix3f(); }
+    float TriangulateMatches(GeometricCamera *pCamera2, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const Eigen::Matrix3f &R12,
+                             const Eigen::Vector3f &t12, const float sigmaLevel, const float unc, Eigen::Vector3f &p3D) {
+        float p[3] = {0.f, 0.f, 0.f};
+        const float d = fn(ctx, (int)(&kp1 - frame->mvKeys.data()), (int)(&kp2 - frame->mvKeysRight.data()), sigmaLevel, unc, p);
+        p3D(0) = p[0]; p3D(1) = p[1]; p3D(2) = p[2];
+        return d;
+    }
 };
 
 }  // namespace ORB_SLAM3

@@ -213,4 +213,34 @@ inline double norm(const Mat &a, const Mat &b, int normType) {
     }
     return (double)s;
 }
+
+// cv::DMatch / cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, matches, 2) as Frame::ComputeStereoFishEyeMatches uses them (Frame.cc:43,
+// 1144) [OCV-recalled]: brute force, per query the min(k, train rows) nearest train rows in ascending distance, the lower train index
+// first among equals; the arithmetic is the oracle's orbo_knn2
+struct DMatch {
+    int queryIdx = -1, trainIdx = -1, imgIdx = -1;
+    float distance = 3.4028235e38f;
+};
+class BFMatcher {
+public:
+    BFMatcher(int normType = 4, bool crossCheck = false) : norm_(normType) { (void)crossCheck; }
+    void knnMatch(const Mat &q, const Mat &t, std::vector<std::vector<DMatch>> &matches, int k) const {
+        assert(norm_ == NORM_HAMMING && k == 2 && (q.rows == 0 || q.cols == 32) && (t.rows == 0 || t.cols == 32));
+        std::vector<uchar> qb((size_t)q.rows * 32 + 32), tb((size_t)t.rows * 32 + 32);
+        for (int r = 0; r < q.rows; r++) memcpy(qb.data() + (size_t)r * 32, q.ptr(r), 32);
+        for (int r = 0; r < t.rows; r++) memcpy(tb.data() + (size_t)r * 32, t.ptr(r), 32);
+        std::vector<int32_t> idx((size_t)2 * q.rows + 2), dist(idx.size());
+        orbo_knn2(qb.data(), q.rows, tb.data(), t.rows, idx.data(), dist.data());
+        matches.assign((size_t)q.rows, std::vector<DMatch>());
+        for (int i = 0; i < q.rows; i++)
+            for (int j = 0; j < 2; j++)
+                if (idx[2 * i + j] >= 0) {
+                    DMatch m;
+                    m.queryIdx = i; m.trainIdx = idx[2 * i + j]; m.imgIdx = 0; m.distance = (float)dist[2 * i + j];
+                    matches[i].push_back(m);
+                }
+    }
+private:
+    int norm_;
+};
 }  // namespace cv

@@ -330,6 +330,35 @@ def knn2(q: np.ndarray, t: np.ndarray):
     return idx, dist
 
 
+TRIANGULATE_FN = C.CFUNCTYPE(C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float))
+
+
+def triangulate_callback(fn):
+    """fn(i_left, i_right, sigma1, sigma2) -> (depth, (x, y, z)): the stand-in for KannalaBrandt8::TriangulateMatches as a C callback."""
+    def cb(_ctx, il, ir, s1, s2, p3d):
+        d, p = fn(il, ir, s1, s2)
+        p3d[0], p3d[1], p3d[2] = float(p[0]), float(p[1]), float(p[2])
+        return float(d)
+    return TRIANGULATE_FN(cb)
+
+
+def stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, level_sigma2, triangulate):
+    """Frame::ComputeStereoFishEyeMatches (Frame.cc:1126-1166).  Returns (nMatches, descMatches, l2r, r2l, depth, u_right, p3d[n_left, 3])."""
+    kl, kr = np.ascontiguousarray(kl, KP_DTYPE), np.ascontiguousarray(kr, KP_DTYPE)
+    dl, dr = np.ascontiguousarray(dl, np.uint8), np.ascontiguousarray(dr, np.uint8)
+    s2 = np.ascontiguousarray(level_sigma2, np.float32)
+    l2r, r2l = np.zeros(len(kl), np.int32), np.zeros(len(kr), np.int32)
+    depth, ur, p3d = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32), np.zeros((len(kl), 3), np.float32)
+    nd = C.c_int(0)
+    cb = triangulate_callback(triangulate)
+    f = lib().orbo_stereo_fisheye_matches
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, TRIANGULATE_FN, C.c_void_p] + [C.c_void_p] * 6
+    n = f(_p(kl), _p(dl), len(kl), int(mono_left), _p(kr), _p(dr), len(kr), int(mono_right), _p(s2), cb, None,
+          _p(l2r), _p(r2l), _p(depth), _p(ur), _p(p3d), C.cast(C.byref(nd), C.c_void_p))
+    return n, nd.value, l2r, r2l, depth, ur, p3d
+
+
 def compute_stereo_matches(kl, dl, kr, dr, scale, inv_scale, pyr_l, pyr_r, bf, b):
     """pyr_l / pyr_r: lists of contiguous uint8 level images (ROI, no ring)."""
     kl = np.ascontiguousarray(kl, KP_DTYPE)

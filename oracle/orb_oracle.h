@@ -271,6 +271,17 @@ void orbo_image_bounds(int width, int height, float fx, float fy, float cx, floa
 /* M9: BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2): idx[2*i..], dist[2*i..]; -1 when fewer than k train rows */
 void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist);
 
+/* Frame::ComputeStereoFishEyeMatches (Frame.cc:1126-1166): kNN-2 of the two lapping-area tails, Lowe's ratio (:1151), the camera's
+ * TriangulateMatches as a callback (KannalaBrandt8.cpp:306: host geometry of the caller's camera objects, outside the path; it gets
+ * the ABSOLUTE keypoint indices and the two level sigmas, returns the depth and fills p3D[3]), bookkeeping (:1157-1162).
+ * l2r[n_left], r2l[n_right], depth[n_left], u_right[n_left], p3d[3 * n_left] (written for accepted matches only, else 0);
+ * returns nMatches, *desc_matches = pairs that passed the ratio test. */
+typedef float (*orbo_triangulate_fn)(void *ctx, int i_left, int i_right, float sigma1, float sigma2, float *p3d);
+int orbo_stereo_fisheye_matches(const orbo_keypoint *kp_left, const uint8_t *desc_left, int n_left, int mono_left,
+                                const orbo_keypoint *kp_right, const uint8_t *desc_right, int n_right, int mono_right,
+                                const float *level_sigma2, orbo_triangulate_fn triangulate, void *ctx, int32_t *l2r, int32_t *r2l,
+                                float *depth, float *u_right, float *p3d, int *desc_matches);
+
 /* ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2012-2053) on bin sizes */
 void orbo_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3);
 

@@ -969,4 +969,34 @@ void orbo_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx,
     }
 }
 
+/* Frame::ComputeStereoFishEyeMatches, Frame.cc:1126-1166 */
+int orbo_stereo_fisheye_matches(const orbo_keypoint *kp_left, const uint8_t *desc_left, int n_left, int mono_left,
+                                const orbo_keypoint *kp_right, const uint8_t *desc_right, int n_right, int mono_right,
+                                const float *level_sigma2, orbo_triangulate_fn triangulate, void *ctx, int32_t *l2r, int32_t *r2l,
+                                float *depth, float *u_right, float *p3d, int *desc_matches) {
+    for (int i = 0; i < n_left; i++) { l2r[i] = -1; depth[i] = -1.0f; u_right[i] = -1.0f; p3d[3 * i] = p3d[3 * i + 1] = p3d[3 * i + 2] = 0.f; }  /* :1134-1138 */
+    for (int i = 0; i < n_right; i++) r2l[i] = -1;
+    const int nq = n_left - mono_left, nt = n_right - mono_right;   /* :1128-1132: the lapping-area tails */
+    std::vector<int32_t> idx((size_t)2 * (nq > 0 ? nq : 0) + 2), dist(idx.size());
+    if (nq > 0) orbo_knn2(desc_left + (size_t)mono_left * 32, nq, desc_right + (size_t)mono_right * 32, nt > 0 ? nt : 0, idx.data(), dist.data());  /* :1144 */
+    int n_matches = 0, n_desc = 0;
+    for (int q = 0; q < nq; q++) {
+        if (idx[2 * q + 1] < 0) continue;                                        /* (*it).size() >= 2 */
+        if (!((float)dist[2 * q] < (float)dist[2 * q + 1] * 0.7)) continue;        /* :1151, float < double */
+        n_desc++;
+        const int il = q + mono_left, ir = idx[2 * q] + mono_right;
+        const float s1 = level_sigma2[kp_left[il].octave], s2 = level_sigma2[kp_right[ir].octave];   /* :1155 */
+        float p[3] = {0.f, 0.f, 0.f};
+        const float d = triangulate(ctx, il, ir, s1, s2, p);
+        if (d > 0.0001f) {                                                       /* :1157 */
+            l2r[il] = ir; r2l[ir] = il;
+            p3d[3 * il] = p[0]; p3d[3 * il + 1] = p[1]; p3d[3 * il + 2] = p[2];
+            depth[il] = d;
+            n_matches++;
+        }
+    }
+    if (desc_matches) *desc_matches = n_desc;
+    return n_matches;
+}
+
 }  // extern "C"

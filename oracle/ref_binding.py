@@ -463,6 +463,48 @@ def ref_compute_stereo_matches(kl, dl, kr, dr, scale, inv_scale, pyr_l, pyr_r, b
     return n, ur, depth
 
 
+def ref_stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, level_sigma2, triangulate):
+    """The reference's Frame::ComputeStereoFishEyeMatches (its own text) with the stand-in camera of mock_frame/frame_mock.h.
+    Returns (nMatches, l2r, r2l, depth, u_right, p3d)."""
+    from . import oracle_binding as ob
+    kl, kr = np.ascontiguousarray(kl, KP_DTYPE), np.ascontiguousarray(kr, KP_DTYPE)
+    dl, dr = _u8(dl), _u8(dr)
+    s2 = _f32(level_sigma2)
+    l2r, r2l = np.zeros(len(kl), np.int32), np.zeros(len(kr), np.int32)
+    depth, ur, p3d = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32), np.zeros((len(kl), 3), np.float32)
+    cb = ob.triangulate_callback(triangulate)
+    f = _fl().frameref_stereo_fisheye_matches
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, ob.TRIANGULATE_FN,
+                  C.c_void_p] + [C.c_void_p] * 5
+    n = f(_p(kl), _p(dl), len(kl), int(mono_left), _p(kr), _p(dr), len(kr), int(mono_right), _p(s2), len(s2), cb, None,
+          _p(l2r), _p(r2l), _p(depth), _p(ur), _p(p3d))
+    return n, l2r, r2l, depth, ur, p3d
+
+
+def adapter_stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, level_sigma2, triangulate):
+    """The PRODUCT's C++ adapter (orb_slam3_amd/cpp/ORBmatcher.h: ComputeStereoFishEyeMatches, kNN-2 on the GPU) through
+    _ref/libmatcher_adapter.so; same arguments and result as ref_stereo_fisheye_matches."""
+    from . import oracle_binding as ob
+    from orb_slam3_amd import _lib
+    C.CDLL(str(_DIR.parent / "liborb_oracle.so"), mode=C.RTLD_GLOBAL)
+    _lib.lib()
+    L = C.CDLL(str(_DIR / "libmatcher_adapter.so"))
+    kl, kr = np.ascontiguousarray(kl, KP_DTYPE), np.ascontiguousarray(kr, KP_DTYPE)
+    dl, dr = _u8(dl), _u8(dr)
+    s2 = _f32(level_sigma2)
+    l2r, r2l = np.zeros(len(kl), np.int32), np.zeros(len(kr), np.int32)
+    depth, ur, p3d = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32), np.zeros((len(kl), 3), np.float32)
+    cb = ob.triangulate_callback(triangulate)
+    f = L.matref_adapter_stereo_fisheye_matches
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, ob.TRIANGULATE_FN,
+                  C.c_void_p] + [C.c_void_p] * 5
+    n = f(_p(kl), _p(dl), len(kl), int(mono_left), _p(kr), _p(dr), len(kr), int(mono_right), _p(s2), len(s2), cb, None,
+          _p(l2r), _p(r2l), _p(depth), _p(ur), _p(p3d))
+    return n, l2r, r2l, depth, ur, p3d
+
+
 def ref_distinctive_descriptor(desc):
     """The descriptor MapPoint::ComputeDistinctiveDescriptors keeps for one observation set, or None for an empty set."""
     d = _u8(desc)

@@ -14,6 +14,7 @@
 using namespace std;
 
 namespace ORB_SLAM3 {
+cv::BFMatcher Frame::BFmatcher = cv::BFMatcher(cv::NORM_HAMMING);   /* as Frame.cc:43 defines it */
 float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
 #include "ref_excerpt.inc"
 }  // namespace ORB_SLAM3
@@ -168,6 +169,35 @@ void frameref_epipolar_pinhole(const float *K1, const float *K2, const float *R1
     }
     const Eigen::Matrix3f &F = Eigen::last_product();
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) F12_out[3 * i + j] = F(i, j);
+}
+
+/* Frame::ComputeStereoFishEyeMatches (Frame.cc:1126-1166, the reference's text) on flattened inputs; the camera's TriangulateMatches is
+ * the stand-in of mock_frame/frame_mock.h.  p3d is reported for accepted matches only (the reference leaves the others unset). */
+int frameref_stereo_fisheye_matches(const orbo_keypoint *kl, const uint8_t *dl, int nl, int mono_left, const orbo_keypoint *kr,
+                                    const uint8_t *dr, int nr, int mono_right, const float *level_sigma2, int nlevels,
+                                    orbo_triangulate_fn tri, void *ctx, int32_t *l2r, int32_t *r2l, float *depth, float *u_right, float *p3d) {
+    Frame F;
+    KannalaBrandt8 cam, cam2;
+    keys(F.mvKeys, kl, nl);
+    keys(F.mvKeysRight, kr, nr);
+    F.mDescriptors = cv::Mat(nl, 32, CV_8UC1);
+    F.mDescriptorsRight = cv::Mat(nr, 32, CV_8UC1);
+    if (nl) std::memcpy(F.mDescriptors.data, dl, (size_t)nl * 32);
+    if (nr) std::memcpy(F.mDescriptorsRight.data, dr, (size_t)nr * 32);
+    F.Nleft = nl; F.Nright = nr; F.N = nl + nr; F.monoLeft = mono_left; F.monoRight = mono_right;
+    F.mvLevelSigma2.assign(level_sigma2, level_sigma2 + nlevels);
+    cam.frame = &F; cam.fn = tri; cam.ctx = ctx;
+    F.mpCamera = &cam; F.mpCamera2 = &cam2;
+    F.ComputeStereoFishEyeMatches();
+    int n = 0;
+    for (int i = 0; i < nl; i++) {
+        l2r[i] = F.mvLeftToRightMatch[i]; depth[i] = F.mvDepth[i]; u_right[i] = F.mvuRight[i];
+        const bool ok = l2r[i] >= 0;
+        for (int c = 0; c < 3; c++) p3d[3 * i + c] = ok ? F.mvStereo3Dpoints[i](c) : 0.f;
+        n += ok;
+    }
+    for (int i = 0; i < nr; i++) r2l[i] = F.mvRightToLeftMatch[i];
+    return n;
 }
 
 }  // extern "C"

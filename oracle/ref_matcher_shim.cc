@@ -733,4 +733,23 @@ int matref_search_by_sim3(const orbo_keypoint *kps1, const uint8_t *desc1, int n
     return r;
 }
 
+#ifdef ORBX_WITH_SLAM_TYPES
+/* adapter build only (libmatcher_adapter.so): the product's ORBmatcher::ComputeStereoFishEyeMatches (kNN-2 on the GPU) on the arrays
+ * frameref_stereo_fisheye_matches (ref_frame_shim.cc: the reference's own Frame::ComputeStereoFishEyeMatches) takes */
+int matref_adapter_stereo_fisheye_matches(const orbo_keypoint *kl, const uint8_t *dl, int nl, int mono_left, const orbo_keypoint *kr,
+                                          const uint8_t *dr, int nr, int mono_right, const float *level_sigma2, int nlevels,
+                                          orbo_triangulate_fn tri, void *ctx, int32_t *l2r, int32_t *r2l, float *depth, float *u_right, float *p3d) {
+    ORBmatcher m(0.75f, true);
+    std::vector<int> a, b;
+    std::vector<float> d, u;
+    std::vector<std::array<float, 3>> p;
+    (void)nlevels;
+    const int n = m.ComputeStereoFishEyeMatches((const orbx_keypoint *)kl, dl, nl, mono_left, (const orbx_keypoint *)kr, dr, nr, mono_right, level_sigma2,
+                                                [&](int il, int ir, float s1, float s2, float *p3) { return tri(ctx, il, ir, s1, s2, p3); }, a, b, d, u, p);
+    for (int i = 0; i < nl; i++) { l2r[i] = a[i]; depth[i] = d[i]; u_right[i] = u[i]; for (int c = 0; c < 3; c++) p3d[3 * i + c] = p[i][c]; }
+    for (int i = 0; i < nr; i++) r2l[i] = b[i];
+    return n;
+}
+#endif
+
 }  // extern "C"

@@ -15,6 +15,7 @@
 #include <string>
 #include <tuple>
 #include <utility>
+#include <array>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -256,6 +257,49 @@ public:
         if (n_sets <= 0) return;
         const int r = orbx_distinctive_descriptors(m_, descriptors.data(), setPtr.data(), n_sets, bestIdx.data());
         if (r < 0) throw std::runtime_error(std::string("orbx_distinctive_descriptors: ") + orbx_status_string(r));
+    }
+
+    // Frame::ComputeStereoFishEyeMatches (Frame.cc:1126-1166) on host vectors: the brute-force kNN-2 of the two lapping-area descriptor
+    // tails (BFmatcher.knnMatch, :1144) on the device, Lowe's ratio (:1151) and the bookkeeping (:1157-1162) here.  `triangulate(iLeft,
+    // iRight, sigma1, sigma2, p3D) -> depth` is the caller's own KannalaBrandt8::TriangulateMatches (host geometry of the camera objects,
+    // not part of the path) on mvKeys[iLeft] / mvKeysRight[iRight]; p3D is a float[3].  Returns nMatches; mvStereo3Dpoints[i] is written
+    // for accepted matches only, as in the reference.  The body that replaces the reference's member is in INTEGRATION.md.
+    template <class Triangulate>
+    int ComputeStereoFishEyeMatches(const orbx_keypoint *mvKeys, const uint8_t *mDescriptors, int Nleft, int monoLeft,
+                                    const orbx_keypoint *mvKeysRight, const uint8_t *mDescriptorsRight, int Nright, int monoRight,
+                                    const float *mvLevelSigma2, Triangulate &&triangulate, std::vector<int> &mvLeftToRightMatch,
+                                    std::vector<int> &mvRightToLeftMatch, std::vector<float> &mvDepth, std::vector<float> &mvuRight,
+                                    std::vector<std::array<float, 3>> &mvStereo3Dpoints, int *descMatches = nullptr) {
+        mvLeftToRightMatch.assign(Nleft > 0 ? Nleft : 0, -1);
+        mvRightToLeftMatch.assign(Nright > 0 ? Nright : 0, -1);
+        mvDepth.assign(Nleft > 0 ? Nleft : 0, -1.0f);
+        mvuRight.assign(Nleft > 0 ? Nleft : 0, -1.0f);
+        mvStereo3Dpoints.assign(Nleft > 0 ? Nleft : 0, std::array<float, 3>{0.f, 0.f, 0.f});
+        const int nq = Nleft - monoLeft, nt = Nright - monoRight;
+        int nMatches = 0, nDesc = 0;
+        if (nq > 0) {
+            std::vector<int32_t> idx(2 * (size_t)nq), dist(2 * (size_t)nq);
+            const int r = orbx_knn2(m_, mDescriptors + (size_t)monoLeft * 32, nq, mDescriptorsRight + (size_t)monoRight * 32, nt > 0 ? nt : 0,
+                                    idx.data(), dist.data());
+            if (r < 0) throw std::runtime_error(std::string("orbx_knn2: ") + orbx_status_string(r));
+            for (int q = 0; q < nq; q++) {
+                if (idx[2 * q + 1] < 0) continue;                                     // fewer than two neighbours
+                if (!((float)dist[2 * q] < (float)dist[2 * q + 1] * 0.7)) continue;     // :1151 (float against double)
+                nDesc++;
+                const int iL = q + monoLeft, iR = idx[2 * q] + monoRight;
+                float p3D[3] = {0.f, 0.f, 0.f};
+                const float depth = triangulate(iL, iR, mvLevelSigma2[mvKeys[iL].octave], mvLevelSigma2[mvKeysRight[iR].octave], p3D);
+                if (depth > 0.0001f) {
+                    mvLeftToRightMatch[iL] = iR;
+                    mvRightToLeftMatch[iR] = iL;
+                    mvStereo3Dpoints[iL] = {p3D[0], p3D[1], p3D[2]};
+                    mvDepth[iL] = depth;
+                    nMatches++;
+                }
+            }
+        }
+        if (descMatches) *descMatches = nDesc;
+        return nMatches;
     }
 
     // Frame::ComputeStereoMatches (Frame.cc:811-981) on host vectors: mvuRight / mvDepth out.  pyrLeft/pyrRight[l] are the level ROI

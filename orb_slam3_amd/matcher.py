@@ -128,6 +128,30 @@ class ORBmatcher:
         check(self._L.orbx_knn2(self._h, ptr(q), len(q), ptr(t), len(t), ptr(idx), ptr(dist)), "orbx_knn2")
         return idx, dist
 
+    def compute_stereo_fisheye_matches(self, kl, dl, mono_left, kr, dr, mono_right, level_sigma2, triangulate):
+        """Frame::ComputeStereoFishEyeMatches (Frame.cc:1126-1166): kNN-2 of the lapping-area tails on the device (:1144), Lowe's ratio
+        (:1151) and the bookkeeping (:1157-1162) on the host.  triangulate(i_left, i_right, sigma1, sigma2) -> (depth, (x, y, z)) is the
+        caller's KannalaBrandt8::TriangulateMatches.  Returns (nMatches, descMatches, l2r, r2l, depth, u_right, p3d)."""
+        kl, kr = np.ascontiguousarray(kl, KP_DTYPE), np.ascontiguousarray(kr, KP_DTYPE)
+        dl, dr, s2 = _u8(dl), _u8(dr), _f32(level_sigma2)
+        n_left, n_right = len(kl), len(kr)
+        l2r, r2l = np.full(n_left, -1, np.int32), np.full(n_right, -1, np.int32)
+        depth, ur, p3d = np.full(n_left, -1.0, np.float32), np.full(n_left, -1.0, np.float32), np.zeros((n_left, 3), np.float32)
+        n_matches = n_desc = 0
+        if n_left - mono_left > 0:
+            idx, dist = self.knn2(dl[mono_left:], dr[mono_right:])
+            for q in range(n_left - mono_left):
+                if idx[q, 1] < 0 or not (float(np.float32(dist[q, 0])) < float(np.float32(dist[q, 1])) * 0.7):
+                    continue
+                n_desc += 1
+                il, ir = q + mono_left, int(idx[q, 0]) + mono_right
+                d, p = triangulate(il, ir, float(s2[kl["octave"][il]]), float(s2[kr["octave"][ir]]))
+                d = np.float32(d)
+                if d > np.float32(0.0001):
+                    l2r[il], r2l[ir], depth[il], p3d[il] = ir, il, d, np.asarray(p, np.float32)
+                    n_matches += 1
+        return n_matches, n_desc, l2r, r2l, depth, ur, p3d
+
     def stereo_rowband(self, kl, dl, kr, dr, scale_factors, n_rows, min_d, max_d):
         kl = np.ascontiguousarray(kl, KP_DTYPE)
         kr = np.ascontiguousarray(kr, KP_DTYPE)

@@ -67,3 +67,33 @@ def test_reference_signature_extractor_with_opencv_types(tmp_path):
     lvl = ex.get_level(3)[19:-19, 19:-19]
     assert np.array_equal(raw[off:off + lvl.size].reshape(lvl.shape), lvl)   # mvImagePyramid[3] fetched lazily
     assert "levels touched 1" in r.stdout
+
+
+@pytest.mark.parametrize("case,n_left,n_right,mono_left,mono_right", [(0, 600, 580, 350, 330), (1, 300, 40, 0, 39), (2, 50, 60, 50, 10),
+                                                                      (3, 64, 64, 10, 64), (4, 200, 220, 199, 0), (5, 2500, 2400, 700, 650)])
+def test_compute_stereo_fisheye_matches(case, n_left, n_right, mono_left, mono_right):
+    """Frame::ComputeStereoFishEyeMatches (Frame.cc:1126-1166) through the product: the C++ adapter member (kNN-2 on the GPU, ratio test and
+    bookkeeping in the adapter, the camera's TriangulateMatches called back) and its Python mirror, against the oracle and against the
+    reference's own text (oracle/_ref/libframe_ref.so live, or its committed outputs in tests/golden/frame_ref.npz)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_oracle_frame_vs_reference import fisheye_case, fisheye_triangulate, _P
+    from oracle import oracle_binding as ob
+    from oracle import ref_binding as rb
+    import orb_slam3_amd as osa
+    kl, dl, kr, dr = fisheye_case(40 + case, n_left, n_right, mono_left, mono_right)
+    sigma2 = np.float32(1.2) ** (2 * np.arange(8, dtype=np.float32))
+    tri = fisheye_triangulate(kl, kr)
+    on, ond, *o = ob.stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, sigma2, tri)
+    pn, pnd, *pm = osa.ORBmatcher().compute_stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, sigma2, tri)
+    assert (pn, pnd) == (on, ond)
+    for a, b in zip(pm, o):
+        assert a.tobytes() == b.tobytes()
+    if case < 5:   # the pinned cases of tests/test_oracle_frame_vs_reference.py
+        _P.pin(f"fisheye_stereo/{case}", (pn, *pm), lambda: rb.ref_stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, sigma2, tri))
+    if (ROOT / "oracle" / "_ref" / "libmatcher_adapter.so").exists():
+        an, *am = rb.adapter_stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, sigma2, tri)
+        assert an == on
+        for a, b in zip(am, o):
+            assert a.tobytes() == b.tobytes()
+    if case in (0, 5):
+        assert on > 50

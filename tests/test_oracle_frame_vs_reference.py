@@ -80,6 +80,59 @@ def test_compute_stereo_matches(w, h, nf, seed):
     assert on > 300
 
 
+def fisheye_case(seed, n_left, n_right, mono_left, mono_right, flip=0.08, dup_every=9):
+    """Two fisheye cameras' keypoints + descriptors with a lapping-area tail: right tail rows are noisy copies of left tail rows (so that the
+    ratio test passes for many), some exact duplicates among the train rows (ties: the lower train index is the best AND the second
+    distance equals it, ratio fails), some unrelated rows.  Shared with tests/test_gpu_matcher.py."""
+    rng = np.random.default_rng(seed)
+    kl, kr = np.zeros(n_left, ob.KP_DTYPE), np.zeros(n_right, ob.KP_DTYPE)
+    for k in (kl, kr):
+        k["x"], k["y"] = rng.uniform(20, 492, len(k)), rng.uniform(20, 492, len(k))
+        k["octave"] = rng.integers(0, 8, len(k))
+        k["size"], k["angle"], k["class_id"] = 31.0, rng.uniform(0, 360, len(k)), -1
+    dl = rng.integers(0, 256, (n_left, 32), dtype=np.uint8)
+    dr = rng.integers(0, 256, (n_right, 32), dtype=np.uint8)
+    nq, nt = n_left - mono_left, n_right - mono_right
+    for j in range(nt):
+        if nq and j % 4 != 3:
+            src = mono_left + int(rng.integers(0, nq))
+            dr[mono_right + j] = dl[src] ^ np.packbits(rng.random(256) < flip, bitorder="little")
+        if dup_every and j and j % dup_every == 0:
+            dr[mono_right + j] = dr[mono_right + j - 1]
+    return kl, dl, kr, dr
+
+
+def fisheye_triangulate(kl, kr):
+    """Deterministic stand-in for KannalaBrandt8::TriangulateMatches: positive depths, rejections (-1) and values around the 0.0001 gate."""
+    def tri(il, ir, s1, s2):
+        dx = np.abs(np.float32(kl["x"][il]) - np.float32(kr["x"][ir]))
+        d = np.float32(dx * np.float32(0.01) + np.float32(s1) * np.float32(0.001) - np.float32(s2) * np.float32(0.0005))
+        if (il + ir) % 7 == 0:
+            d = np.float32(0.0001)            # exactly the gate: depth > 0.0001f fails
+        if (il + ir) % 11 == 0:
+            d = np.float32(-1.0)
+        return float(d), (float(kl["x"][il]) * 0.01, float(kr["y"][ir]) * 0.01, float(d))
+    return tri
+
+
+@pytest.mark.parametrize("case,n_left,n_right,mono_left,mono_right", [(0, 600, 580, 350, 330), (1, 300, 40, 0, 39), (2, 50, 60, 50, 10),
+                                                                      (3, 64, 64, 10, 64), (4, 200, 220, 199, 0)])
+def test_compute_stereo_fisheye_matches(case, n_left, n_right, mono_left, mono_right):
+    """Frame.cc:1126-1166: kNN-2 over the lapping-area tails, Lowe ratio 0.7 (float < double), TriangulateMatches as the camera's own
+    (stand-in) geometry, depth gate 0.0001f, the four output vectors.  Cases: ordinary; ONE train row (no second neighbour: nothing
+    passes); empty query tail; empty train tail; one query row."""
+    kl, dl, kr, dr = fisheye_case(40 + case, n_left, n_right, mono_left, mono_right)
+    sigma2 = np.float32(1.2) ** (2 * np.arange(8, dtype=np.float32))
+    tri = fisheye_triangulate(kl, kr)
+    n, nd, l2r, r2l, depth, ur, p3d = ob.stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, sigma2, tri)
+    _P.pin(f"fisheye_stereo/{case}", (n, l2r, r2l, depth, ur, p3d),
+           lambda: rb.ref_stereo_fisheye_matches(kl, dl, mono_left, kr, dr, mono_right, sigma2, tri))
+    if case == 0:
+        assert 50 < n < nd
+    if case in (1, 2, 3):
+        assert n == 0 and nd == 0
+
+
 def test_distinctive_descriptors():
     """MapPoint.cc:329-403: distance matrix, per-row median at index 0.5*(N-1), first minimum wins."""
     rng = np.random.default_rng(7)

@@ -67,7 +67,7 @@ def test_emulated_extractor_open_issue_image(emul_lib):
 
 PIPELINE = """
 # the bench's loop shape: two batches in flight (enqueue i, then wait for i - 1), alternating inputs and entry points
-W, H, NF, B, STEPS = 480, 360, 600, 8, 3
+W, H, NF, B, STEPS = 480, 360, 600, 9, 3   # 9 frames: the batch forms of the kernels (up to 8 frames take the short row blocks of the single-frame call)
 canvases = [synth.make_canvas(10, size=1024, n_shapes=700), synth.make_canvas(11, size=1024, n_shapes=700)]
 sets = [np.ascontiguousarray(np.stack([synth.frame_from_canvas(c, t, W, H, 1000 * (10 + i) + t) for t in range(B)])) for i, c in enumerate(canvases)]
 ex = osa.ORBextractor(NF, 1.2, 8, 20, 7)
@@ -112,13 +112,17 @@ print('emulation ok')
 """
 
 
+_FULL = pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): 45 s each")
+
+
 @pytest.mark.parametrize("env", [{"SIMT_STREAM_FUZZ": "first", "SIMT_MALLOC_FILL": "255"},
-                                 {"SIMT_STREAM_FUZZ": "last", "SIMT_BLOCK_ORDER": "reverse"},
-                                 {"SIMT_STREAM_FUZZ": "7", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11", "SIMT_LANE_ORDER": "3", "SIMT_LDS_RANDOM": "8"},
+                                 pytest.param({"SIMT_STREAM_FUZZ": "last", "SIMT_BLOCK_ORDER": "reverse"}, marks=_FULL),
+                                 pytest.param({"SIMT_STREAM_FUZZ": "7", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11", "SIMT_LANE_ORDER": "3",
+                                               "SIMT_LDS_RANDOM": "8"}, marks=_FULL),
                                  {"SIMT_STREAM_FUZZ": "5", "SIMT_MEMSET_ASYNC": "1", "SIMT_KERNEL_SPLIT": "6"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "in-order")
 def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
-    """Three 8-frame batches, two in flight, through extract_batch_device / extract_batch_host (from 8 frames on a frame's workgroups
+    """Three 9-frame batches, two in flight, through extract_batch_device / extract_batch_host (from 8 frames on a frame's workgroups
     are mapped to one XCD), the batched frame-to-frame matcher (grid build, window scan, greedy replay with its grid re-scan) and the
     asynchronous download: every frame and every match vector == oracle.  SIMT_STREAM_FUZZ: the stand-in runtime queues the
     operations per stream and executes them in another order the recorded dependencies allow -- `first`: the main stream runs ahead
