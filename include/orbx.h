@@ -456,6 +456,10 @@ int orbx_stereo_batch_device(orbx_extractor *left, orbx_extractor *right, float 
 int orbx_stereo_batch_download(orbx_extractor *left, int frame, float *u_right, float *depth, int *n_left, int *n_matches);
 /* all frames at once: u_right / depth [n_frames][cap] (entries beyond a frame's keypoint count unspecified), n_matches [n_frames] */
 int orbx_stereo_batch_download_all(orbx_extractor *left, float *u_right, float *depth, int32_t *n_matches);
+/* the same into PINNED host buffers, asynchronously behind the stereo kernels (at most two such downloads in flight): the next pair of batches
+ * can be extracted meanwhile; orbx_stereo_download_wait returns when the buffers of the OLDER one are complete */
+int orbx_stereo_batch_download_async(orbx_extractor *left, float *u_right, float *depth, int32_t *n_matches);
+int orbx_stereo_download_wait(orbx_extractor *left);
 
 const char *orbx_last_error(void);
 const char *orbx_status_string(int status);

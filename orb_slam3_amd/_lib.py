@@ -100,7 +100,7 @@ SYMBOLS = [
     "orbx_search_by_bow_frame_fisheye", "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_is_in_frustum", "orbx_frustum_batch_device",
     "orbx_set_camera", "orbx_batch_download_keypoints_un",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
-    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
+    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_stereo_batch_download_async", "orbx_stereo_download_wait", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
     "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors", "orbx_fuse_search",
 ]
 
@@ -175,6 +175,8 @@ def lib() -> C.CDLL:
     L.orbx_fuse_search.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.orbx_stereo_batch_download.argtypes = [vp, i32, vp, vp, vp, vp]
     L.orbx_stereo_batch_download_all.argtypes = [vp, vp, vp, vp]
+    L.orbx_stereo_batch_download_async.argtypes = [vp, vp, vp, vp]
+    L.orbx_stereo_download_wait.argtypes = [vp]
     L.orbx_search_mappoints_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, sz, f32, f32, vp, vp]
     L.orbx_search_by_projection_window.argtypes = [vp, C.POINTER(FrameDesc), vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32,
                                                    i32, vp]

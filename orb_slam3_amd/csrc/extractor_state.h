@@ -155,12 +155,13 @@ struct orbx_extractor {
     int blur_tile_start[orbx::kMaxLevels + 1] = {};  // blur tiles of level l: [start[l], start[l + 1])
     bool match_pending = false;
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream
-    hipEvent_t ev_compute_done = nullptr;
+    hipEvent_t ev_stereo_copy[2] = {nullptr, nullptr};   // ends of the last two orbx_stereo_batch_download_async
+    unsigned stereo_copy_issued = 0, stereo_copy_waited = 0;
     hipEvent_t ev_copy_done[2] = {nullptr, nullptr};  // ring: up to two downloads in flight
     unsigned copy_issued = 0, copy_waited = 0;         // copy_issued - copy_waited = downloads in flight
     bool copy_pending = false;                         // a download was issued since the last (re)configuration
     int32_t *h_err = nullptr;  // pinned, 2 slots
-    DevBuf d_st_bidx, d_st_bdist, d_st_ur, d_st_depth, d_st_sad, d_st_nm, d_st_scales;  // device stereo matcher (left extractor)
+    DevBuf d_st_bidx, d_st_bdist, d_st_ur, d_st_depth, d_st_sad, d_st_nm, d_st_scales, d_st_rowptr, d_st_rowidx;  // device stereo matcher (left extractor)
     DevBuf d_match, d_nmatch;  // internal match outputs [B][cap], [B] (one matcher per batch: orbx.h)
     int internal_match_owner = 0;   // which batched matcher wrote them for the current batch: 0 none, 1 frame-to-frame, 2 map points
     // cached problem descriptors of orbx_match_consecutive_device
@@ -198,7 +199,9 @@ struct orbx_extractor {
         if (bytes <= h_stage_bytes) return ORBX_OK;
         if (h_stage) (void)hipHostFree(h_stage);
         h_stage = nullptr; h_stage_bytes = 0;
-        ORBX_HIP(hipHostMalloc(&h_stage, bytes, hipHostMallocDefault));
+        // coherent (fine-grained) whatever HIP_HOST_COHERENT says: orbx_extract's kernels read the image from and write the results into this
+        // block themselves, and the host reads them right after the stream synchronisation
+        ORBX_HIP(hipHostMalloc(&h_stage, bytes, hipHostMallocCoherent));
         h_stage_bytes = bytes;
         return ORBX_OK;
     }

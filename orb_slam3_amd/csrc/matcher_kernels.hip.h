@@ -295,7 +295,45 @@ struct StereoBatch {
     float *u_right, *depth;            // [B][capL] outputs (-1 = none)
     int32_t *sad;                      // [B][capL] SAD distance of accepted matches, -1 otherwise
     int32_t *nmatches;                 // [B]
+    // right keypoints bucketed by floor(y) (k_stereo_row_index): row_ptr [B][n_rows + 1], row_idx [B][capR]; nullptr = no index, every
+    // right keypoint is tested.  band = ceil(2 * largest scale factor) + 1: a right keypoint whose row band (:828-838) contains row v
+    // has floor(y) in [v - band, v + band]
+    const int32_t *row_ptr, *row_idx;
+    int band;
 };
+
+// vRowIndices (Frame.cc:822-838) as an index instead of 2r + 1 registrations per keypoint: the right keypoints of a frame counted and
+// listed by floor(y); the exact band test stays in k_stereo_rowband_batch, which then looks at the ~5 % of the right keypoints whose
+// bucket lies within `band` rows of the left keypoint's row instead of at all of them (KITTI step: 394 -> .. us).  The order inside a
+// bucket is arbitrary (atomics): the search keeps the minimum of (distance, index), which does not depend on it.
+// grid (B), block 256, LDS 4 * (n_rows + 1) + 1024
+constexpr int kStereoIndexMaxRows = 8192;
+__global__ __launch_bounds__(256) void k_stereo_row_index(StereoBatch S, int32_t *row_ptr, int32_t *row_idx) {
+    extern __shared__ int32_t rows_lds[];   // [n_rows + 1] counts -> start offsets -> cursors, then 256 partial sums
+    const int f = blockIdx.x, tid = threadIdx.x, nrow = S.n_rows, nr = S.nr[f];
+    int32_t *part = rows_lds + nrow + 1;
+    const orbx_keypoint *kr = S.kr + (size_t)f * S.capR;
+    for (int i = tid; i <= nrow; i += 256) rows_lds[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) atomicAdd(&rows_lds[min(max((int)floorf(kr[i].y), 0), nrow - 1)], 1);
+    __syncthreads();
+    const int chunk = (nrow + 256) / 256, c0 = tid * chunk, c1 = min(c0 + chunk, nrow + 1);
+    int sum = 0;
+    for (int i = c0; i < c1; i++) sum += rows_lds[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[tid];
+    int32_t *gp = row_ptr + (size_t)f * (nrow + 1);
+    for (int i = c0; i < c1; i++) { const int v = rows_lds[i]; rows_lds[i] = run; gp[i] = run; run += v; }
+    __syncthreads();
+    int32_t *gi = row_idx + (size_t)f * S.capR;
+    for (int i = tid; i < nr; i += 256) gi[atomicAdd(&rows_lds[min(max((int)floorf(kr[i].y), 0), nrow - 1)], 1)] = i;
+}
 
 __global__ __launch_bounds__(256) void k_stereo_rowband_batch(StereoBatch S) {
     const int f = blockIdx.y;
@@ -311,7 +349,16 @@ __global__ __launch_bounds__(256) void k_stereo_rowband_batch(StereoBatch S) {
     u64 best = kNoKey;
     if (!(maxU < 0) && row >= 0 && row < S.n_rows) {
         const Desc dq = load_desc(S.dl + ((size_t)f * S.capL + iL) * 32);
-        for (int iR = lane; iR < nr; iR += 64) {
+        int j0 = 0, j1 = nr;
+        const int32_t *ridx = nullptr;
+        if (S.row_ptr) {
+            const int32_t *rp = S.row_ptr + (size_t)f * (S.n_rows + 1);
+            j0 = rp[max(row - S.band, 0)];
+            j1 = rp[min(row + S.band, S.n_rows - 1) + 1];
+            ridx = S.row_idx + (size_t)f * S.capR;
+        }
+        for (int j = j0 + lane; j < j1; j += 64) {
+            const int iR = ridx ? ridx[j] : j;
             const orbx_keypoint kpR = kr[iR];
             const float r = 2.0f * S.scale[kpR.octave];
             const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);

@@ -634,7 +634,6 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipStreamCreateWithFlags(&ex->spare_stream, hipStreamNonBlocking);
     for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&ex->ev_compute_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[0], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[1], hipEventDisableTiming);
     (void)hipHostMalloc((void **)&ex->h_err, 2 * sizeof(int32_t), hipHostMallocDefault);
@@ -674,12 +673,12 @@ void orbx_destroy(orbx_extractor *ex) {
     for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
     ex->d_in[0].release(); ex->d_in[1].release();
     for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
-    if (ex->ev_compute_done) (void)hipEventDestroy(ex->ev_compute_done);
+    for (hipEvent_t ev : ex->ev_stereo_copy) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
     if (ex->h_err) (void)hipHostFree(ex->h_err);
     for (int i = 0; i < 3; i++) { if (ex->h_frustum[i]) (void)hipHostFree(ex->h_frustum[i]); if (ex->ev_frustum[i]) (void)hipEventDestroy(ex->ev_frustum[i]); }
     ex->d_match.release(); ex->d_nmatch.release();
-    for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales}) b->release();
+    for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales, &ex->d_st_rowptr, &ex->d_st_rowidx}) b->release();
     DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err,
@@ -864,8 +863,9 @@ int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *d
     ORBX_HIP(hipSetDevice(ex->device));
     const int n = ex->last_batch;
     hipStream_t cs = ex->copy_stream;
-    ORBX_HIP(hipEventRecord(ex->ev_compute_done, ex->stream));
-    ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_compute_done, 0));
+    // behind the extraction itself (ev_describe), not behind whatever else the main stream has been given since: the stereo kernels of
+    // orbx_stereo_batch_device run there, and the keypoints / descriptors (94 % of the bytes) need not wait for them
+    ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_describe, 0));
     // keypoints and descriptors leave as soon as the extraction is done, BESIDE the matcher (they are 94 % of the bytes and the matcher
     // does not write them); only the match vectors wait for it.  With the wait in front of everything the next batch's k_finalize sat
     // behind matcher + all copies in series (ORBX_COPY_AFTER_MATCH=1 restores that order).

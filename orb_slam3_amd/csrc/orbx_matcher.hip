@@ -1236,11 +1236,17 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
     ENS(L->d_st_sad, 4 * (size_t)capL * L->batch_cap);
     ENS(L->d_st_nm, 4 * (size_t)L->batch_cap);
     ENS(L->d_st_scales, sizeof(float) * 2 * nl);
+    const bool row_index = L->height <= kStereoIndexMaxRows;
+    if (row_index) {
+        ENS(L->d_st_rowptr, 4 * ((size_t)L->height + 1) * L->batch_cap);
+        ENS(L->d_st_rowidx, 4 * (size_t)R->cap * L->batch_cap);
+    }
 #undef ENS
     hipStream_t st = L->stream;
     ORBX_HIP(hipMemcpyAsync(L->d_st_scales.p, L->scale.data(), sizeof(float) * nl, hipMemcpyHostToDevice, st));
     ORBX_HIP(hipMemcpyAsync((float *)L->d_st_scales.p + nl, L->inv_scale.data(), sizeof(float) * nl, hipMemcpyHostToDevice, st));
     ORBX_HIP(hipStreamWaitEvent(st, R->ev_describe, 0));  // the right extraction of this batch
+    if (L->stereo_copy_issued) ORBX_HIP(hipStreamWaitEvent(st, L->ev_stereo_copy[(L->stereo_copy_issued - 1) & 1], 0));  // the previous results may still be on their way to the host
     StereoBatch S;
     S.kl = (const orbx_keypoint *)L->d_kps.p; S.kr = (const orbx_keypoint *)R->d_kps.p;
     S.dl = (const uint8_t *)L->d_desc.p; S.dr = (const uint8_t *)R->d_desc.p;
@@ -1255,6 +1261,12 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
     S.best_idx = (int32_t *)L->d_st_bidx.p; S.best_dist = (int32_t *)L->d_st_bdist.p;
     S.u_right = (float *)L->d_st_ur.p; S.depth = (float *)L->d_st_depth.p;
     S.sad = (int32_t *)L->d_st_sad.p; S.nmatches = (int32_t *)L->d_st_nm.p;
+    S.row_ptr = S.row_idx = nullptr;
+    S.band = (int)ceilf(2.0f * *std::max_element(L->scale.begin(), L->scale.begin() + nl)) + 1;
+    if (row_index) {
+        hipLaunchKernelGGL(k_stereo_row_index, dim3(n), dim3(256), 4 * ((size_t)L->height + 1) + 1024, st, S, (int32_t *)L->d_st_rowptr.p, (int32_t *)L->d_st_rowidx.p);
+        S.row_ptr = (const int32_t *)L->d_st_rowptr.p; S.row_idx = (const int32_t *)L->d_st_rowidx.p;
+    }
     hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((capL + 3) / 4, n), dim3(256), 0, st, S);
     hipLaunchKernelGGL(k_stereo_sad, dim3((capL + 3) / 4, n), dim3(256), 0, st, S);
     hipLaunchKernelGGL(k_stereo_reject, dim3(n), dim3(256), 0, st, S);
@@ -1303,6 +1315,42 @@ extern "C" int orbx_stereo_batch_download_all(orbx_extractor *L, float *u_right,
     if (u_right) memcpy(u_right, L->staged(0), fb);
     if (depth) memcpy(depth, L->staged(o_d), fb);
     if (n_matches) memcpy(n_matches, L->staged(o_n), 4 * n);
+    return ORBX_OK;
+}
+
+// the same into PINNED host buffers, asynchronously on the left extractor's copy stream behind the stereo kernels: the pipelined form
+// (the next pair of batches is extracted while these results travel).  At most two such downloads in flight; orbx_stereo_download_wait ends the older, and
+// the next orbx_stereo_batch_device waits for it on the device before it overwrites the result buffers.
+extern "C" int orbx_stereo_batch_download_async(orbx_extractor *L, float *u_right, float *depth, int32_t *n_matches) {
+    if (!L || L->last_batch <= 0 || !L->d_st_ur.p) return ORBX_E_BAD_ARG;
+    if (L->stereo_copy_issued - L->stereo_copy_waited >= 2) { set_error("two stereo downloads already in flight: call orbx_stereo_download_wait first"); return ORBX_E_BAD_ARG; }
+    for (const void *p : {(const void *)u_right, (const void *)depth, (const void *)n_matches}) {
+        hipPointerAttribute_t a;
+        if (p && (hipPointerGetAttributes(&a, p) != hipSuccess || a.type != hipMemoryTypeHost)) {
+            (void)hipGetLastError();
+            set_error("orbx_stereo_batch_download_async needs pinned host buffers (hipHostMalloc / hipHostRegister)");
+            return ORBX_E_BAD_ARG;
+        }
+    }
+    ORBX_HIP(hipSetDevice(L->device));
+    for (hipEvent_t &ev : L->ev_stereo_copy) if (!ev) ORBX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const size_t n = (size_t)L->last_batch, fb = 4 * n * L->cap;
+    hipStream_t cs = L->copy_stream;
+    ORBX_HIP(hipStreamWaitEvent(cs, L->ev_match, 0));   // recorded behind k_stereo_reject
+    if (u_right) ORBX_HIP(hipMemcpyAsync(u_right, L->d_st_ur.p, fb, hipMemcpyDeviceToHost, cs));
+    if (depth) ORBX_HIP(hipMemcpyAsync(depth, L->d_st_depth.p, fb, hipMemcpyDeviceToHost, cs));
+    if (n_matches) ORBX_HIP(hipMemcpyAsync(n_matches, L->d_st_nm.p, 4 * n, hipMemcpyDeviceToHost, cs));
+    ORBX_HIP(hipEventRecord(L->ev_stereo_copy[L->stereo_copy_issued & 1], cs));
+    L->stereo_copy_issued++;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_download_wait(orbx_extractor *L) {
+    if (!L) return ORBX_E_BAD_ARG;
+    if (L->stereo_copy_issued == L->stereo_copy_waited) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(L->device));
+    ORBX_HIP(hipEventSynchronize(L->ev_stereo_copy[L->stereo_copy_waited & 1]));   // the OLDEST one in flight
+    L->stereo_copy_waited++;
     return ORBX_OK;
 }
 

@@ -162,6 +162,15 @@ class ORBextractor:
               "orbx_stereo_batch_download_all")
 
     # ---- Frame::ComputeStereoMatches on two resident batches (self = left extractor) ----
+    def stereo_download_async(self, h_ur: int, h_depth: int, h_nm: int):
+        """mvuRight / mvDepth [n_frames][cap] and the match counts into PINNED host buffers behind the stereo kernels; stereo_download_wait()
+        returns when they are complete.  The next pair of batches may be extracted meanwhile."""
+        check(self._L.orbx_stereo_batch_download_async(self._h, C.c_void_p(h_ur), C.c_void_p(h_depth), C.c_void_p(h_nm)),
+              "orbx_stereo_batch_download_async")
+
+    def stereo_download_wait(self):
+        check(self._L.orbx_stereo_download_wait(self._h), "orbx_stereo_download_wait")
+
     def stereo_batch_device(self, right: "ORBextractor", bf: float, b: float):
         check(self._L.orbx_stereo_batch_device(self._h, right._h, bf, b), "orbx_stereo_batch_device")
 

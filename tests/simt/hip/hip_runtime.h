@@ -11,7 +11,7 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotSupported = 801 };
 typedef struct simt_stream *hipStream_t;
 typedef struct simt_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostRegisterDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocCoherent = 0x40000000, hipHostRegisterDefault = 0 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeUnregistered = 0 };
 struct hipPointerAttribute_t { hipMemoryType type; int device; void *devicePointer, *hostPointer; int isManaged; unsigned allocationFlags; };

@@ -2,6 +2,8 @@
 nothing can pass by re-reading the previous batch's state), host-resident and device-resident input paths, sampled frames
 and match vectors of every step compared bit-for-bit with the CPU oracle.  Also: the batched map-point projection search
 (BASELINE config 4), the host-input entry point and the all-frames stereo download."""
+import os
+
 import numpy as np
 import pytest
 
@@ -326,6 +328,66 @@ def test_stereo_download_all_equals_per_frame_download():
         n1, u1, d1 = exl.stereo_download(f)
         assert nm[f] == n1 and n1 > 100
         assert ur[f, :len(u1)].tobytes() == u1.tobytes() and depth[f, :len(d1)].tobytes() == d1.tobytes()
+
+
+def test_stereo_pipelined_async_downloads_equal_synchronous_ones():
+    """The KITTI bench's loop shape: extraction of both cameras, orbx_stereo_batch_device, asynchronous downloads of the features and of the
+    stereo result into pinned buffers, the NEXT step enqueued before the previous one is waited for (two different sets of pairs
+    alternate, so that a result overwritten too early or delivered from the wrong step differs)."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    B, w, h = 3, 620, 240
+    canvas = synth.make_canvas(31, size=1400, n_shapes=1500)
+    data = []
+    for s0 in (0, 40):
+        pairs = [synth.make_stereo_pair(31, s0 + t, w, h, canvas) for t in range(B)]
+        data.append((torch.from_numpy(np.stack([p[0] for p in pairs])).cuda(), torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()))
+    exl, exr = osa.ORBextractor(800, 1.2, 8, 20, 7), osa.ORBextractor(800, 1.2, 8, 20, 7)
+    bf, b = 0.53716 * 718.856, 0.53716
+    cap = exl.output_capacity(w, h)
+    exr.output_capacity(w, h)
+    pin = lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory()
+    # synchronous reference results of both sets
+    want = []
+    for dl, dr in data:
+        exl.extract_batch_device(dl.data_ptr(), B, w, h, w, w * h, (0, 0))
+        exr.extract_batch_device(dr.data_ptr(), B, w, h, w, w * h, (0, 0))
+        exl.stereo_batch_device(exr, bf, b)
+        ur, depth, nm = np.zeros((B, cap), np.float32), np.zeros((B, cap), np.float32), np.zeros(B, np.int32)
+        exl.stereo_download_all(ur.ctypes.data, depth.ctypes.data, nm.ctypes.data)
+        feats = [(exl.download(f), exr.download(f)) for f in range(B)]
+        assert nm.min() > 30
+        want.append((ur, depth, nm, feats))
+    sets = [dict(l=[pin((B, cap, 28), torch.uint8), pin((B, cap, 32), torch.uint8), pin((B,), torch.int32), pin((B,), torch.int32)],
+                 r=[pin((B, cap, 28), torch.uint8), pin((B, cap, 32), torch.uint8), pin((B,), torch.int32), pin((B,), torch.int32)],
+                 ur=pin((B, cap), torch.float32), depth=pin((B, cap), torch.float32), nm=pin((B,), torch.int32)) for _ in range(2)]
+    steps = 5
+    for i in range(steps + 1):
+        if i < steps:
+            dl, dr = data[i % 2]
+            hs = sets[i % 2]
+            exl.extract_batch_device(dl.data_ptr(), B, w, h, w, w * h, (0, 0))
+            exr.extract_batch_device(dr.data_ptr(), B, w, h, w, w * h, (0, 0))
+            exl.stereo_batch_device(exr, bf, b)
+            exl.download_async(*[t.data_ptr() for t in hs["l"]])
+            exr.download_async(*[t.data_ptr() for t in hs["r"]])
+            exl.stereo_download_async(hs["ur"].data_ptr(), hs["depth"].data_ptr(), hs["nm"].data_ptr())
+        if i >= 1:
+            exl.download_wait(); exr.download_wait(); exl.stereo_download_wait()
+            hs = sets[(i - 1) % 2]
+            ur, depth, nm, feats = want[(i - 1) % 2]
+            assert np.array_equal(hs["nm"].numpy(), nm)
+            for f in range(B):
+                for k, (mono, kps, desc) in zip("lr", feats[f]):
+                    n = int(hs[k][2][f])
+                    assert n == len(kps) and hs[k][0][f, :n].numpy().tobytes() == kps.tobytes() and np.array_equal(hs[k][1][f, :n].numpy(), desc), (i, f, k)
+                n = int(hs["l"][2][f])
+                assert hs["ur"][f, :n].numpy().tobytes() == ur[f, :n].tobytes() and hs["depth"][f, :n].numpy().tobytes() == depth[f, :n].tobytes(), (i, f)
+    if not os.environ.get("ORBX_TEST_EMULATOR"):   # under the emulator every pointer is "host memory": nothing to refuse
+        pageable = np.zeros((B, cap), np.float32)
+        with pytest.raises(Exception):
+            exl.stereo_download_async(pageable.ctypes.data, 0, 0)   # pageable memory is refused
 
 
 def test_async_entry_points_refuse_pageable_host_memory():
