@@ -127,6 +127,12 @@ struct orbx_extractor {
     int n_fast_tiles = 0, n_blur_tiles = 0;
     // device memory
     DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_tiles, d_dc;
+    // Stereo rig (orbx_stereo_batch_device): the SAD stage reads both extractors' pyramids on the match stream while the NEXT pair of batches is
+    // extracted, so an extractor that has been part of a rig alternates between two pyramid slabs (allocated at the first stereo call)
+    DevBuf d_pyr2;
+    bool pyr_double = false;
+    int pyr_slot = 0;
+    uint8_t *pyr_cur() const { return (uint8_t *)(pyr_slot ? d_pyr2.p : d_pyr.p); }
     DevBuf d_pyr, d_blur, d_cellcnt, d_cellent, d_keys0, d_keys1, d_nof0, d_nof1, d_lvlkp, d_lvlcnt, d_candtot, d_work;
     DevBuf d_kps, d_desc, d_count, d_mono, d_err;
     DevBuf d_mkey1, d_mkey2, d_mocc, d_mentries, d_mprobs, d_mres, d_mscale, d_mgrid;  // batched frame-to-frame matcher scratch

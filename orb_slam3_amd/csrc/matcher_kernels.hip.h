@@ -295,29 +295,29 @@ struct StereoBatch {
     float *u_right, *depth;            // [B][capL] outputs (-1 = none)
     int32_t *sad;                      // [B][capL] SAD distance of accepted matches, -1 otherwise
     int32_t *nmatches;                 // [B]
-    // right keypoints bucketed by floor(y) (k_stereo_row_index): row_ptr [B][n_rows + 1], row_idx [B][capR]; nullptr = no index, every
-    // right keypoint is tested.  band = ceil(2 * largest scale factor) + 1: a right keypoint whose row band (:828-838) contains row v
-    // has floor(y) in [v - band, v + band]
-    const int32_t *row_ptr, *row_idx;
-    int band;
+    // right keypoints bucketed by floor(y) >> row_shift (k_stereo_row_index): row_ptr [B][n_buckets + 1], row_ent [B][capR] in bucket order.
+    // band = ceil(2 * largest scale factor) + 1: a right keypoint whose row band (:828-838) contains row v has floor(y) in [v - band, v + band]
+    const int32_t *row_ptr;
+    const uint4 *row_ent;              // x (float bits), minr, maxr, index << 8 | octave
+    int band, row_shift, n_buckets;
 };
 
 // vRowIndices (Frame.cc:822-838) as an index instead of 2r + 1 registrations per keypoint: the right keypoints of a frame counted and
-// listed by floor(y); the exact band test stays in k_stereo_rowband_batch, which then looks at the ~5 % of the right keypoints whose
-// bucket lies within `band` rows of the left keypoint's row instead of at all of them (KITTI step: 394 -> .. us).  The order inside a
-// bucket is arbitrary (atomics): the search keeps the minimum of (distance, index), which does not depend on it.
-// grid (B), block 256, LDS 4 * (n_rows + 1) + 1024
-constexpr int kStereoIndexMaxRows = 8192;
-__global__ __launch_bounds__(256) void k_stereo_row_index(StereoBatch S, int32_t *row_ptr, int32_t *row_idx) {
-    extern __shared__ int32_t rows_lds[];   // [n_rows + 1] counts -> start offsets -> cursors, then 256 partial sums
-    const int f = blockIdx.x, tid = threadIdx.x, nrow = S.n_rows, nr = S.nr[f];
-    int32_t *part = rows_lds + nrow + 1;
+// listed by the bucket of floor(y), each with its row band [minr, maxr] (:830-832) precomputed; k_stereo_rowband_batch then looks at the
+// ~5 % of the right keypoints whose bucket lies within `band` rows of the left keypoint's row instead of at all of them.  The order inside
+// a bucket is arbitrary (atomics): the search keeps the minimum of (distance, index), which does not depend on it.
+// grid (B), block 256, LDS 4 * (n_buckets + 1) + 1024
+constexpr int kStereoIndexMaxBuckets = 8192;
+__global__ __launch_bounds__(256) void k_stereo_row_index(StereoBatch S, int32_t *row_ptr, uint4 *row_ent) {
+    extern __shared__ int32_t rows_lds[];   // [n_buckets + 1] counts -> start offsets -> cursors, then 256 partial sums
+    const int f = blockIdx.x, tid = threadIdx.x, nb = S.n_buckets, nr = S.nr[f];
+    int32_t *part = rows_lds + nb + 1;
     const orbx_keypoint *kr = S.kr + (size_t)f * S.capR;
-    for (int i = tid; i <= nrow; i += 256) rows_lds[i] = 0;
+    for (int i = tid; i <= nb; i += 256) rows_lds[i] = 0;
     __syncthreads();
-    for (int i = tid; i < nr; i += 256) atomicAdd(&rows_lds[min(max((int)floorf(kr[i].y), 0), nrow - 1)], 1);
+    for (int i = tid; i < nr; i += 256) atomicAdd(&rows_lds[min(max((int)floorf(kr[i].y), 0) >> S.row_shift, nb - 1)], 1);
     __syncthreads();
-    const int chunk = (nrow + 256) / 256, c0 = tid * chunk, c1 = min(c0 + chunk, nrow + 1);
+    const int chunk = (nb + 256) / 256, c0 = tid * chunk, c1 = min(c0 + chunk, nb + 1);
     int sum = 0;
     for (int i = c0; i < c1; i++) sum += rows_lds[i];
     part[tid] = sum;
@@ -328,51 +328,60 @@ __global__ __launch_bounds__(256) void k_stereo_row_index(StereoBatch S, int32_t
     }
     __syncthreads();
     int run = part[tid];
-    int32_t *gp = row_ptr + (size_t)f * (nrow + 1);
+    int32_t *gp = row_ptr + (size_t)f * (nb + 1);
     for (int i = c0; i < c1; i++) { const int v = rows_lds[i]; rows_lds[i] = run; gp[i] = run; run += v; }
     __syncthreads();
-    int32_t *gi = row_idx + (size_t)f * S.capR;
-    for (int i = tid; i < nr; i += 256) gi[atomicAdd(&rows_lds[min(max((int)floorf(kr[i].y), 0), nrow - 1)], 1)] = i;
+    uint4 *ge = row_ent + (size_t)f * S.capR;
+    for (int i = tid; i < nr; i += 256) {
+        const orbx_keypoint kp = kr[i];
+        const float r = 2.0f * S.scale[kp.octave];                                   // :829
+        const int maxr = (int)ceilf(kp.y + r), minr = (int)floorf(kp.y - r);         // :830-831
+        const int slot = atomicAdd(&rows_lds[min(max((int)floorf(kp.y), 0) >> S.row_shift, nb - 1)], 1);
+        ge[slot] = make_uint4(__float_as_uint(kp.x), (uint32_t)minr, (uint32_t)maxr, ((uint32_t)i << 8) | (uint32_t)(kp.octave & 0xff));
+    }
 }
 
+// Hamming stage (:841-883): 16 lanes per left keypoint (4 keypoints per wave) stride the bucketed right keypoints near its row
+// grid (ceil(capL / 16), B), block 256
 __global__ __launch_bounds__(256) void k_stereo_rowband_batch(StereoBatch S) {
     const int f = blockIdx.y;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nl = S.nl[f], nr = S.nr[f];
-    if (iL >= nl) return;
-    const orbx_keypoint *kr = S.kr + (size_t)f * S.capR;
-    const uint8_t *dr = S.dr + (size_t)f * S.capR * 32;
-    const orbx_keypoint kpL = S.kl[(size_t)f * S.capL + iL];
-    const float minD = 0.f, maxD = S.bf / S.b;  // :841-843 (minZ = mb)
-    const int row = (int)kpL.y;
-    const float minU = kpL.x - maxD, maxU = kpL.x - minD;
+    const int iL = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+    const int nl = S.nl[f];
+    if (blockIdx.x * 16 >= nl) return;
+    const bool live = iL < nl;
     u64 best = kNoKey;
-    if (!(maxU < 0) && row >= 0 && row < S.n_rows) {
-        const Desc dq = load_desc(S.dl + ((size_t)f * S.capL + iL) * 32);
-        int j0 = 0, j1 = nr;
-        const int32_t *ridx = nullptr;
-        if (S.row_ptr) {
-            const int32_t *rp = S.row_ptr + (size_t)f * (S.n_rows + 1);
-            j0 = rp[max(row - S.band, 0)];
-            j1 = rp[min(row + S.band, S.n_rows - 1) + 1];
-            ridx = S.row_idx + (size_t)f * S.capR;
-        }
-        for (int j = j0 + lane; j < j1; j += 64) {
-            const int iR = ridx ? ridx[j] : j;
-            const orbx_keypoint kpR = kr[iR];
-            const float r = 2.0f * S.scale[kpR.octave];
-            const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
-            if (row < minr || row > maxr) continue;
-            if (kpR.octave < kpL.octave - 1 || kpR.octave > kpL.octave + 1) continue;
-            if (kpR.x >= minU && kpR.x <= maxU) {
-                const int d = hamming(dq, load_desc(dr + (size_t)iR * 32));
-                const u64 k = ((u64)d << 32) | (u64)(uint32_t)iR;
-                best = k < best ? k : best;
+    if (live) {
+        const uint8_t *dr = S.dr + (size_t)f * S.capR * 32;
+        const orbx_keypoint kpL = S.kl[(size_t)f * S.capL + iL];
+        const float minD = 0.f, maxD = S.bf / S.b;  // :841-843 (minZ = mb)
+        const int row = (int)kpL.y;
+        const float minU = kpL.x - maxD, maxU = kpL.x - minD;
+        if (!(maxU < 0) && row >= 0 && row < S.n_rows) {
+            const Desc dq = load_desc(S.dl + ((size_t)f * S.capL + iL) * 32);
+            const int32_t *rp = S.row_ptr + (size_t)f * (S.n_buckets + 1);
+            const int j0 = rp[max(row - S.band, 0) >> S.row_shift];
+            const int j1 = rp[(min(row + S.band, S.n_rows - 1) >> S.row_shift) + 1];
+            const uint4 *ent = S.row_ent + (size_t)f * S.capR;
+            for (int j = j0 + sl; j < j1; j += 16) {
+                const uint4 e = ent[j];
+                const int oct = (int)(e.w & 0xffu), iR = (int)(e.w >> 8);
+                const float xr = __uint_as_float(e.x);
+                if (row < (int)e.y || row > (int)e.z) continue;
+                if (oct < kpL.octave - 1 || oct > kpL.octave + 1) continue;
+                if (xr >= minU && xr <= maxU) {
+                    const int d = hamming(dq, load_desc(dr + (size_t)iR * 32));
+                    const u64 k = ((u64)d << 32) | (u64)(uint32_t)iR;
+                    best = k < best ? k : best;
+                }
             }
         }
     }
-    best = wave_min1(best);
-    if (lane == 0) {
+#pragma unroll
+    for (int s = 8; s > 0; s >>= 1) {   // minimum inside the 16-lane group
+        const u64 o = __shfl_xor(best, s);
+        best = o < best ? o : best;
+    }
+    if (live && sl == 0) {
         const int d = best == kNoKey ? 256 : (int)(best >> 32);
         const size_t o = (size_t)f * S.capL + iL;
         if (d < ORBX_TH_HIGH) { S.best_idx[o] = (int32_t)(best & 0xffffffffu); S.best_dist[o] = d; }
@@ -380,70 +389,85 @@ __global__ __launch_bounds__(256) void k_stereo_rowband_batch(StereoBatch S) {
     }
 }
 
+// SAD refinement + parabola (:885-964): 16 lanes per left keypoint, lane yy < 11 = one ROW of the 11 x 11 window: it fetches the row of the
+// left patch (12 bytes) and the 21 + 3 bytes of the right image that the eleven shifts incR = -5 .. 5 slide over with two loads, forms the
+// eleven row sums with v_alignbyte + v_sad_u8 and the group adds them up (xor butterflies: every lane ends with all eleven totals and
+// evaluates the same scalar tail).  Three load instructions per wave of four keypoints.
+// grid (ceil(capL / 16), B), block 256
 __global__ __launch_bounds__(256) void k_stereo_sad(StereoBatch S) {
     const int f = blockIdx.y;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (iL >= S.nl[f]) return;
-    const size_t o = (size_t)f * S.capL + iL;
+    const int iL = blockIdx.x * 16 + (threadIdx.x >> 4), sl = threadIdx.x & 15;
+    const int nl = S.nl[f];
+    if (blockIdx.x * 16 >= nl) return;
+    const bool live = iL < nl;
+    const size_t o = (size_t)f * S.capL + min(iL, nl - 1);
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
     const int bidx = S.best_idx[o];
     const int thOrbDist = (ORBX_TH_HIGH + ORBX_TH_LOW) / 2;
-    if (bidx >= 0 && S.best_dist[o] < thOrbDist) {  // wave-uniform
-        const orbx_keypoint kpL = S.kl[o];
-        const float uL = kpL.x;
-        const float uR0 = S.kr[(size_t)f * S.capR + bidx].x;
-        const int lvl = kpL.octave;
-        const float sf = S.inv_scale[lvl];
-        const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf)), scaleduR0 = roundf(__fmul_rn(uR0, sf));
-        const LevelInfo LL = S.lvL[lvl], LR = S.lvR[lvl];
-        const int w = 5, Lh = 5;
-        const float iniu = scaleduR0 + Lh - w, endu = scaleduR0 + Lh + w + 1;
-        if (!(iniu < 0 || endu >= (float)LR.w)) {
-            const uint8_t *IL = S.pyrL + (size_t)f * S.pyr_frame_L + LL.off + (size_t)(kEdge + (int)(scaledvL - w)) * LL.pitch + kRoiX + (int)(scaleduL - w);
-            const uint8_t *IR = S.pyrR + (size_t)f * S.pyr_frame_R + LR.off + (size_t)(kEdge + (int)(scaledvL - w)) * LR.pitch + kRoiX + (int)(scaleduR0 - w);
-            int sums[11];
+    const bool cand = live && bidx >= 0 && S.best_dist[o] < thOrbDist;   // uniform inside a 16-lane group
+    const orbx_keypoint kpL = S.kl[o];
+    const float uL = kpL.x;
+    const float uR0 = S.kr[(size_t)f * S.capR + max(bidx, 0)].x;
+    const int lvl = kpL.octave;
+    const float sf = S.inv_scale[lvl];
+    const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf)), scaleduR0 = roundf(__fmul_rn(uR0, sf));
+    const int w = 5, Lh = 5;
+    const int lw = S.lvR[lvl].w;
+    const float iniu = scaleduR0 + Lh - w, endu = scaleduR0 + Lh + w + 1;
+    const bool inside = cand && !(iniu < 0 || endu >= (float)lw);
+    int sums[11];
 #pragma unroll
-            for (int k = 0; k < 11; k++) sums[k] = 0;
-            for (int p = lane; p < 121; p += 64) {
-                const int yy = p / 11, xx = p - yy * 11;
-                const int a = IL[(size_t)yy * LL.pitch + xx];
-                const uint8_t *rr = IR + (size_t)yy * LR.pitch + xx;
+    for (int k = 0; k < 11; k++) sums[k] = 0;
+    if (inside && sl < 11) {
+        const int pitchL = S.lvL[lvl].pitch, pitchR = S.lvR[lvl].pitch;
+        const uint8_t *pl = S.pyrL + (size_t)f * S.pyr_frame_L + S.lvL[lvl].off + (size_t)(kEdge + (int)(scaledvL - w) + sl) * pitchL + kRoiX + (int)(scaleduL - w);
+        const uint8_t *pr = S.pyrR + (size_t)f * S.pyr_frame_R + S.lvR[lvl].off + (size_t)(kEdge + (int)(scaledvL - w) + sl) * pitchR + kRoiX + (int)(scaleduR0 - w) - 5;
+        uint32_t a[3], r[6];
+        __builtin_memcpy(a, pl, 12);   // 11 bytes of the row + one that is masked off
+        __builtin_memcpy(r, pr, 24);   // columns -10 .. +10 around scaleduR0 + three that are masked off
+        a[2] &= 0x00ffffffu;
 #pragma unroll
-                for (int k = 0; k < 11; k++) sums[k] += abs(a - (int)rr[k - 5]);
-            }
+        for (int k = 0; k < 11; k++) {
+            const int q = k >> 2, sh = k & 3;
+            const uint32_t w0 = sh ? __builtin_amdgcn_alignbyte(r[q + 1], r[q], sh) : r[q];
+            const uint32_t w1 = sh ? __builtin_amdgcn_alignbyte(r[q + 2], r[q + 1], sh) : r[q + 1];
+            const uint32_t w2 = (sh ? __builtin_amdgcn_alignbyte(r[q + 3], r[q + 2], sh) : r[q + 2]) & 0x00ffffffu;
+            sums[k] = (int)__builtin_amdgcn_sad_u8(a[0], w0, __builtin_amdgcn_sad_u8(a[1], w1, __builtin_amdgcn_sad_u8(a[2], w2, 0u)));
+        }
+    }
 #pragma unroll
-            for (int k = 0; k < 11; k++) {
+    for (int k = 0; k < 11; k++) {
 #pragma unroll
-                for (int s = 32; s > 0; s >>= 1) sums[k] += __shfl_xor(sums[k], s);
-            }
-            int bestDist = 0x7fffffff, bestinc = 0;
+        for (int x = 8; x > 0; x >>= 1) sums[k] += __shfl_xor(sums[k], x);
+    }
+    if (inside) {
+        int bestDist = 0x7fffffff, bestinc = 0;
 #pragma unroll
-            for (int k = 0; k < 11; k++)
-                if ((float)sums[k] < (float)bestDist) { bestDist = sums[k]; bestinc = k - 5; }  // :926 (float dist vs int best)
-            if (!(bestinc == -Lh || bestinc == Lh)) {
-                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+        for (int k = 0; k < 11; k++)
+            if ((float)sums[k] < (float)bestDist) { bestDist = sums[k]; bestinc = k - 5; }  // :926 (float dist vs int best)
+        if (!(bestinc == -Lh || bestinc == Lh)) {
+            float d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
-                for (int k = 1; k < 10; k++)
-                    if (k - 5 == bestinc) { d1 = (float)sums[k - 1]; d2 = (float)sums[k]; d3 = (float)sums[k + 1]; }
-                // :944  deltaR = (dist1-dist3)/(2.0f*(dist1+dist3-2.0f*dist2))
-                const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
-                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), den);
-                if (!(deltaR < -1 || deltaR > 1)) {
-                    float bestuR = __fmul_rn(S.scale[lvl], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));  // :950
-                    float disparity = __fsub_rn(uL, bestuR);
-                    const float minD = 0.f, maxD = S.bf / S.b;
-                    if (disparity >= minD && disparity < maxD) {
-                        if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }  // :956-959
-                        out_d = __fdiv_rn(S.bf, disparity);
-                        out_u = bestuR;
-                        out_sad = bestDist;
-                    }
+            for (int k = 1; k < 10; k++)
+                if (k - 5 == bestinc) { d1 = (float)sums[k - 1]; d2 = (float)sums[k]; d3 = (float)sums[k + 1]; }
+            // :944  deltaR = (dist1-dist3)/(2.0f*(dist1+dist3-2.0f*dist2))
+            const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
+            const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), den);
+            if (!(deltaR < -1 || deltaR > 1)) {
+                float bestuR = __fmul_rn(S.scale[lvl], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));  // :950
+                float disparity = __fsub_rn(uL, bestuR);
+                const float minD = 0.f, maxD = S.bf / S.b;
+                if (disparity >= minD && disparity < maxD) {
+                    if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }  // :956-959
+                    out_d = __fdiv_rn(S.bf, disparity);
+                    out_u = bestuR;
+                    out_sad = bestDist;
                 }
             }
         }
     }
-    if (lane == 0) { S.u_right[o] = out_u; S.depth[o] = out_d; S.sad[o] = out_sad; }
+    if (live && sl == 0) { S.u_right[o] = out_u; S.depth[o] = out_d; S.sad[o] = out_sad; }
 }
 
 // one workgroup per frame: median SAD distance (element size/2 of the ascending order, :967-968) via radix select,

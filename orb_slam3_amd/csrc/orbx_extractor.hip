@@ -228,6 +228,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
     ENS(ex->d_pyr, pyr_off * B);
+    if (ex->pyr_double) ENS(ex->d_pyr2, pyr_off * B);
     ENS(ex->d_blur, blur_off * B);
     ENS(ex->d_cellcnt, sizeof(int32_t) * (size_t)cell_base * B);
     ENS(ex->d_cellent, sizeof(uint32_t) * (size_t)cand_off * B);
@@ -363,7 +364,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     ex->internal_match_owner = 0;   // a new batch: its first batched matcher owns the internal match buffers
     const int nl = ex->prm.nlevels;
     const LevelInfo *d_lv = (const LevelInfo *)ex->d_lv.p;
-    uint8_t *pyr = (uint8_t *)ex->d_pyr.p;
+    if (ex->pyr_double) ex->pyr_slot ^= 1;   // the previous batch's pyramid may still be read by the rig's SAD stage (orbx_stereo_batch_device)
+    uint8_t *pyr = ex->pyr_cur();
     uint8_t *blur_slab = (uint8_t *)ex->d_blur.p;
     hipStream_t st = ex->stream;
     hipStream_t pst = st;   // stream of the pyramid stage
@@ -679,7 +681,7 @@ void orbx_destroy(orbx_extractor *ex) {
     for (int i = 0; i < 3; i++) { if (ex->h_frustum[i]) (void)hipHostFree(ex->h_frustum[i]); if (ex->ev_frustum[i]) (void)hipEventDestroy(ex->ev_frustum[i]); }
     ex->d_match.release(); ex->d_nmatch.release();
     for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales, &ex->d_st_rowptr, &ex->d_st_rowidx}) b->release();
-    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr,
+    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr, &ex->d_pyr2,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
@@ -956,7 +958,7 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
     const LevelInfo &L = ex->lv[level];
     if (dst_stride < (size_t)(L.w + 2 * kEdge)) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
-    const uint8_t *src = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off;
+    const uint8_t *src = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off;
     const size_t bytes = (size_t)L.pitch * (L.h + 2 * kEdge);
     int r = ex->d2h_staged_begin(bytes);
     if (r != ORBX_OK) return r;
@@ -969,7 +971,7 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
 int orbx_get_level_device(orbx_extractor *ex, int frame, int level, const uint8_t **d_padded, size_t *pitch) {
     if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
     const LevelInfo &L = ex->lv[level];
-    if (d_padded) *d_padded = (const uint8_t *)ex->d_pyr.p + (size_t)frame * ex->pyr_frame + L.off + kRingX;
+    if (d_padded) *d_padded = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off + kRingX;
     if (pitch) *pitch = L.pitch;
     return ORBX_OK;
 }

@@ -245,6 +245,14 @@ int orbx_stereo_rowband(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t 
     return ORBX_OK;
 }
 
+// StereoBatch's row index parameters for an image of n_rows rows and pyramid scale factors sc[0 .. nl)
+static void stereo_index_params(StereoBatch &S, int n_rows, const float *sc, int nl) {
+    S.band = (int)ceilf(2.0f * *std::max_element(sc, sc + nl)) + 1;
+    S.row_shift = 0;
+    while (((n_rows - 1) >> S.row_shift) + 1 > kStereoIndexMaxBuckets) S.row_shift++;
+    S.n_buckets = ((n_rows - 1) >> S.row_shift) + 1;
+}
+
 // Frame::ComputeStereoMatches (Frame.cc:811-981): device Hamming stage, host SAD refinement on the host-resident
 // pyramid (mvImagePyramid is host memory at this boundary), host median rejection.
 int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int N, const orbx_keypoint *kr,
@@ -271,7 +279,7 @@ int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const 
     }
     const size_t need = 2 * Arena::pad(slab) + Arena::pad(28 * (size_t)N) + Arena::pad(28 * (size_t)Nr) + Arena::pad(32 * (size_t)N) +
                         Arena::pad(32 * (size_t)Nr) + 5 * Arena::pad(4 * (size_t)N) + Arena::pad(sizeof(LevelInfo) * nlevels) +
-                        Arena::pad(8 * (size_t)nlevels) + 8192;
+                        Arena::pad(8 * (size_t)nlevels) + Arena::pad(4 * ((size_t)kStereoIndexMaxBuckets + 1)) + Arena::pad(16 * (size_t)Nr) + 8192;
     int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
@@ -299,8 +307,13 @@ int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const 
     S.scale = dsc; S.inv_scale = dsc + nlevels; S.n_rows = pyr_h[0]; S.bf = bf; S.b = b;
     S.best_idx = A.take<int32_t>(N); S.best_dist = A.take<int32_t>(N);
     S.u_right = A.take<float>(N); S.depth = A.take<float>(N); S.sad = A.take<int32_t>(N); S.nmatches = A.take<int32_t>(4);
-    hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((N + 3) / 4, 1), dim3(256), 0, m->stream, S);
-    hipLaunchKernelGGL(k_stereo_sad, dim3((N + 3) / 4, 1), dim3(256), 0, m->stream, S);
+    stereo_index_params(S, pyr_h[0], scale_factors, nlevels);
+    int32_t *drp = A.take<int32_t>((size_t)S.n_buckets + 1);
+    uint4 *den = A.take<uint4>(Nr);
+    S.row_ptr = drp; S.row_ent = den;
+    hipLaunchKernelGGL(k_stereo_row_index, dim3(1), dim3(256), 4 * ((size_t)S.n_buckets + 1) + 1024, m->stream, S, drp, den);
+    hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((N + 15) / 16, 1), dim3(256), 0, m->stream, S);
+    hipLaunchKernelGGL(k_stereo_sad, dim3((N + 15) / 16, 1), dim3(256), 0, m->stream, S);
     hipLaunchKernelGGL(k_stereo_reject, dim3(1), dim3(256), 0, m->stream, S);
     ORBX_HIP(hipGetLastError());
     int32_t nm = 0;
@@ -1236,23 +1249,32 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
     ENS(L->d_st_sad, 4 * (size_t)capL * L->batch_cap);
     ENS(L->d_st_nm, 4 * (size_t)L->batch_cap);
     ENS(L->d_st_scales, sizeof(float) * 2 * nl);
-    const bool row_index = L->height <= kStereoIndexMaxRows;
-    if (row_index) {
-        ENS(L->d_st_rowptr, 4 * ((size_t)L->height + 1) * L->batch_cap);
-        ENS(L->d_st_rowidx, 4 * (size_t)R->cap * L->batch_cap);
-    }
+    StereoBatch S;
+    stereo_index_params(S, L->height, L->scale.data(), nl);
+    ENS(L->d_st_rowptr, 4 * ((size_t)S.n_buckets + 1) * L->batch_cap);
+    ENS(L->d_st_rowidx, 16 * (size_t)R->cap * L->batch_cap);
 #undef ENS
-    hipStream_t st = L->stream;
+    // From now on both extractors alternate between two pyramid slabs: these kernels run on the left extractor's MATCH stream beside the next
+    // pair of extractions, and k_stereo_sad reads the pyramids of THIS pair.  (The slab written next is the one the stereo stage before this
+    // one read: every extraction waits for the rig's previous stereo stage before its k_finalize -- match_pending -- and the one after it
+    // follows on the same stream.)
+    for (orbx_extractor *e : {L, R})
+        if (!e->pyr_double) {
+            if ((r = e->d_pyr2.ensure(e->d_pyr.bytes)) != ORBX_OK) return r;
+            e->pyr_double = true;   // pyr_slot stays: the current batch lies in the slab it was extracted into
+        }
+    const bool side = !L->profile && L->side_streams;
+    hipStream_t st = side ? L->match_stream : L->stream;
     ORBX_HIP(hipMemcpyAsync(L->d_st_scales.p, L->scale.data(), sizeof(float) * nl, hipMemcpyHostToDevice, st));
     ORBX_HIP(hipMemcpyAsync((float *)L->d_st_scales.p + nl, L->inv_scale.data(), sizeof(float) * nl, hipMemcpyHostToDevice, st));
-    ORBX_HIP(hipStreamWaitEvent(st, R->ev_describe, 0));  // the right extraction of this batch
+    ORBX_HIP(hipStreamWaitEvent(st, L->ev_describe, 0));  // the two extractions of this batch
+    ORBX_HIP(hipStreamWaitEvent(st, R->ev_describe, 0));
     if (L->stereo_copy_issued) ORBX_HIP(hipStreamWaitEvent(st, L->ev_stereo_copy[(L->stereo_copy_issued - 1) & 1], 0));  // the previous results may still be on their way to the host
-    StereoBatch S;
     S.kl = (const orbx_keypoint *)L->d_kps.p; S.kr = (const orbx_keypoint *)R->d_kps.p;
     S.dl = (const uint8_t *)L->d_desc.p; S.dr = (const uint8_t *)R->d_desc.p;
     S.nl = (const int32_t *)L->d_count.p; S.nr = (const int32_t *)R->d_count.p;
     S.capL = capL; S.capR = R->cap;
-    S.pyrL = (const uint8_t *)L->d_pyr.p; S.pyrR = (const uint8_t *)R->d_pyr.p;
+    S.pyrL = L->pyr_cur(); S.pyrR = R->pyr_cur();
     S.pyr_frame_L = L->pyr_frame; S.pyr_frame_R = R->pyr_frame;
     S.lvL = (const LevelInfo *)L->d_lv.p; S.lvR = (const LevelInfo *)R->d_lv.p;
     S.scale = (const float *)L->d_st_scales.p; S.inv_scale = S.scale + nl;
@@ -1261,26 +1283,24 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
     S.best_idx = (int32_t *)L->d_st_bidx.p; S.best_dist = (int32_t *)L->d_st_bdist.p;
     S.u_right = (float *)L->d_st_ur.p; S.depth = (float *)L->d_st_depth.p;
     S.sad = (int32_t *)L->d_st_sad.p; S.nmatches = (int32_t *)L->d_st_nm.p;
-    S.row_ptr = S.row_idx = nullptr;
-    S.band = (int)ceilf(2.0f * *std::max_element(L->scale.begin(), L->scale.begin() + nl)) + 1;
-    if (row_index) {
-        hipLaunchKernelGGL(k_stereo_row_index, dim3(n), dim3(256), 4 * ((size_t)L->height + 1) + 1024, st, S, (int32_t *)L->d_st_rowptr.p, (int32_t *)L->d_st_rowidx.p);
-        S.row_ptr = (const int32_t *)L->d_st_rowptr.p; S.row_idx = (const int32_t *)L->d_st_rowidx.p;
-    }
-    hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((capL + 3) / 4, n), dim3(256), 0, st, S);
-    hipLaunchKernelGGL(k_stereo_sad, dim3((capL + 3) / 4, n), dim3(256), 0, st, S);
+    S.row_ptr = (const int32_t *)L->d_st_rowptr.p; S.row_ent = (const uint4 *)L->d_st_rowidx.p;
+    hipLaunchKernelGGL(k_stereo_row_index, dim3(n), dim3(256), 4 * ((size_t)S.n_buckets + 1) + 1024, st, S, (int32_t *)L->d_st_rowptr.p, (uint4 *)L->d_st_rowidx.p);
+    hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((capL + 15) / 16, n), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(k_stereo_sad, dim3((capL + 15) / 16, n), dim3(256), 0, st, S);
     hipLaunchKernelGGL(k_stereo_reject, dim3(n), dim3(256), 0, st, S);
     ORBX_HIP(hipGetLastError());
     // the extractors must not overwrite their outputs / pyramids before these kernels are done
     ORBX_HIP(hipEventRecord(L->ev_match, st));
     L->match_pending = true;
-    ORBX_HIP(hipStreamWaitEvent(R->stream, L->ev_match, 0));
+    ORBX_HIP(hipEventRecord(R->ev_match, st));   // the right extractor's next k_finalize waits for it as for a matcher of its own
+    R->match_pending = true;
     return ORBX_OK;
 }
 
 extern "C" int orbx_stereo_batch_download(orbx_extractor *L, int frame, float *u_right, float *depth, int *n_left, int *n_matches) {
     if (!L || frame < 0 || frame >= L->last_batch || !L->d_st_ur.p) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(L->device));
+    ORBX_HIP(hipStreamWaitEvent(L->stream, L->ev_match, 0));   // the stereo stage runs on the match stream
     const size_t fb = 4 * (size_t)L->cap, o_u = 64, o_d = o_u + ((fb + 63) & ~(size_t)63);
     int r = L->d2h_staged_begin(o_d + fb);
     if (r != ORBX_OK) return r;
@@ -1305,6 +1325,7 @@ extern "C" int orbx_stereo_batch_download(orbx_extractor *L, int frame, float *u
 extern "C" int orbx_stereo_batch_download_all(orbx_extractor *L, float *u_right, float *depth, int32_t *n_matches) {
     if (!L || L->last_batch <= 0 || !L->d_st_ur.p) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(L->device));
+    ORBX_HIP(hipStreamWaitEvent(L->stream, L->ev_match, 0));   // the stereo stage runs on the match stream
     const size_t n = (size_t)L->last_batch, fb = 4 * n * L->cap, o_d = (fb + 63) & ~(size_t)63, o_n = 2 * o_d;
     int r = L->d2h_staged_begin(o_n + 4 * n);
     if (r != ORBX_OK) return r;
