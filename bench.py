@@ -729,25 +729,36 @@ def bench_kitti(R):
     parity = None
     if R.rank == 0 and a.verify > 0:
         from oracle import oracle_binding as ob
-        oel = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
-        oer = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
-        tb = oel.tables()
-        parity = {"pairs": 0}
-        for f in sorted(set(int(x) for x in np.linspace(0, B - 1, min(a.verify, 3)))):
-            res = []
-            for oe, img, k in ((oel, pairs[f][0], "l"), (oer, pairs[f][1], "r")):
-                _, kk, dd = oe.extract(img, lap=LAP)
-                n = int(host[k][2][f])
-                if n != len(kk) or host[k][0][f, :n].numpy().tobytes() != kk.tobytes() or not np.array_equal(host[k][1][f, :n].numpy(), dd):
-                    raise SystemExit(f"PARITY FAILURE: stereo pair {f} ({k}): extraction differs from the oracle")
-                res.append((kk, dd))
-            pl = [np.ascontiguousarray(oel.level_padded(l)[19:-19, 19:-19]) for l in range(NLEVELS)]
-            pr = [np.ascontiguousarray(oer.level_padded(l)[19:-19, 19:-19]) for l in range(NLEVELS)]
-            on, our, odepth, _, _ = ob.compute_stereo_matches(res[0][0], res[0][1], res[1][0], res[1][1], tb["scale"], tb["inv_scale"], pl, pr, bf, b)
-            n = len(res[0][0])
-            if int(h_nm[f]) != on or h_ur[f, :n].numpy().tobytes() != our.tobytes() or h_depth[f, :n].numpy().tobytes() != odepth.tobytes():
-                raise SystemExit(f"PARITY FAILURE: stereo pair {f}: mvuRight / mvDepth differ from the oracle")
-            parity["pairs"] += 1
+        from concurrent.futures import ThreadPoolExecutor
+        tb = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA).tables()
+        # a.verify >= 4 (the default): EVERY pair of the delivered step, pair-parallel on the host cores (ctypes releases the GIL)
+        fset = list(range(B)) if a.verify >= 4 else sorted(set(int(x) for x in np.linspace(0, B - 1, a.verify)))
+        nthreads = max(1, min(os.cpu_count() or 1, 64, len(fset)))
+
+        def check_chunk(fs):
+            oel = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+            oer = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+            for f in fs:
+                res = []
+                for oe, img, k in ((oel, pairs[f][0], "l"), (oer, pairs[f][1], "r")):
+                    _, kk, dd = oe.extract(img, lap=LAP)
+                    n = int(host[k][2][f])
+                    if n != len(kk) or host[k][0][f, :n].numpy().tobytes() != kk.tobytes() or not np.array_equal(host[k][1][f, :n].numpy(), dd):
+                        return f"stereo pair {f} ({k}): extraction differs from the oracle"
+                    res.append((kk, dd))
+                pl = [np.ascontiguousarray(oel.level_padded(l)[19:-19, 19:-19]) for l in range(NLEVELS)]
+                pr = [np.ascontiguousarray(oer.level_padded(l)[19:-19, 19:-19]) for l in range(NLEVELS)]
+                on, our, odepth, _, _ = ob.compute_stereo_matches(res[0][0], res[0][1], res[1][0], res[1][1], tb["scale"], tb["inv_scale"], pl, pr, bf, b)
+                n = len(res[0][0])
+                if int(h_nm[f]) != on or h_ur[f, :n].numpy().tobytes() != our.tobytes() or h_depth[f, :n].numpy().tobytes() != odepth.tobytes():
+                    return f"stereo pair {f}: mvuRight / mvDepth differ from the oracle"
+            return None
+
+        with ThreadPoolExecutor(nthreads) as pool:
+            for err in pool.map(check_chunk, [fset[i::nthreads] for i in range(nthreads)]):
+                if err:
+                    raise SystemExit("PARITY FAILURE: " + err)
+        parity = {"pairs": len(fset), "of_pairs": B, "oracle_threads": nthreads}
 
     roofline, kernels = None, {}
     if R.rank == 0 and not a.no_profile:
@@ -871,19 +882,30 @@ def bench_tumvi(R):
     parity = None
     if R.rank == 0 and a.verify > 0:
         from oracle import oracle_binding as ob
-        oex = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
-        sf = oex.tables()["scale"]
-        parity = {"frames": 0}
-        for f in sorted(set(int(x) for x in np.linspace(0, B - 1, min(a.verify, 3)))):
-            mono, k, d = oex.extract(frames[f], lap=LAP)
-            n = int(last["cnt"][f])
-            if n != len(k) or last["kps"][f, :n].numpy().tobytes() != k.tobytes() or not np.array_equal(last["desc"][f, :n].numpy(), d):
-                raise SystemExit(f"PARITY FAILURE: frame {f}: extraction differs from the oracle")
-            grid = ob.OracleGrid(k, 0.0, float(W), 0.0, float(H))
-            on, ofm = ob.search_by_projection_mappoints(grid, d, sf, mps[f], 1.0, 0.8)
-            if int(last["nm"][f]) != on or not np.array_equal(last["match"][f, :n].numpy(), ofm):
-                raise SystemExit(f"PARITY FAILURE: frame {f}: SearchByProjection(map points) differs from the oracle")
-            parity["frames"] += 1
+        from concurrent.futures import ThreadPoolExecutor
+        sf = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA).tables()["scale"]
+        # a.verify >= 4 (the default): EVERY frame of the delivered step, frame-parallel on the host cores
+        fset = list(range(B)) if a.verify >= 4 else sorted(set(int(x) for x in np.linspace(0, B - 1, a.verify)))
+        nthreads = max(1, min(os.cpu_count() or 1, 64, len(fset)))
+
+        def check_chunk(fs):
+            oex = ob.OracleExtractor(NF, 1.2, NLEVELS, 20, 7, flags=ob.FLAG_DESC_FMA)
+            for f in fs:
+                mono, k, d = oex.extract(frames[f], lap=LAP)
+                n = int(last["cnt"][f])
+                if n != len(k) or last["kps"][f, :n].numpy().tobytes() != k.tobytes() or not np.array_equal(last["desc"][f, :n].numpy(), d):
+                    return f"frame {f}: extraction differs from the oracle"
+                grid = ob.OracleGrid(k, 0.0, float(W), 0.0, float(H))
+                on, ofm = ob.search_by_projection_mappoints(grid, d, sf, mps[f], 1.0, 0.8)
+                if int(last["nm"][f]) != on or not np.array_equal(last["match"][f, :n].numpy(), ofm):
+                    return f"frame {f}: SearchByProjection(map points) differs from the oracle"
+            return None
+
+        with ThreadPoolExecutor(nthreads) as pool:
+            for err in pool.map(check_chunk, [fset[i::nthreads] for i in range(nthreads)]):
+                if err:
+                    raise SystemExit("PARITY FAILURE: " + err)
+        parity = {"frames": len(fset), "of_frames": B, "oracle_threads": nthreads}
 
     roofline, kernels = None, {}
     if R.rank == 0 and not a.no_profile:

@@ -451,7 +451,9 @@ int orbx_bow_transform(orbx_matcher *m, const orbx_vocabulary *voc, const uint8_
 /* Frame::ComputeStereoMatches (Frame.cc:811-981) for every frame of two resident batches: `left` and `right` must have
  * extracted batches of the same size and image shape (rectified stereo, lapping {0,0}).  Row-band Hamming match, 11x11
  * SAD sub-pixel refinement on the device-resident pyramids and the median outlier rejection all run on the device, on
- * the left extractor's stream.  Results (mvuRight, mvDepth; -1 = no match) per frame via orbx_stereo_batch_download. */
+ * the left extractor's MATCH stream: the next pair of batches may be extracted meanwhile (from the first call on both
+ * extractors alternate between two pyramid slabs, and their next k_finalize waits for this stage as for a matcher of
+ * their own).  Results (mvuRight, mvDepth; -1 = no match) per frame via orbx_stereo_batch_download[_all | _async]. */
 int orbx_stereo_batch_device(orbx_extractor *left, orbx_extractor *right, float bf, float b);
 int orbx_stereo_batch_download(orbx_extractor *left, int frame, float *u_right, float *depth, int *n_left, int *n_matches);
 /* all frames at once: u_right / depth [n_frames][cap] (entries beyond a frame's keypoint count unspecified), n_matches [n_frames] */
