@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
         L.orbo_cosf.restype = f32
         L.orbo_cosf.argtypes = [f32]
         L.orbo_check_sincos_vs_libm.restype = u64
+        L.orbo_count_sincos_fma_vs_nofma.restype = u64
+        L.orbo_count_sincos_fma_vs_nofma.argtypes = [u32, u32, vp]
         L.orbo_check_sincos_vs_libm.argtypes = [u32, u32, vp]
         L.orbo_orb_descriptor.argtypes = [vp, sz, f32, i32, i32, vp]
         L.orbo_distribute_octree.restype = i32

@@ -785,6 +785,55 @@ float orbo_ic_angle(const uint8_t *center, size_t stride) {
     static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     return ic_angle(center, stride, umax);
 }
+/* The same two functions as the x86_64 "sse2" ifunc variant computes them (a libm on a CPU without FMA, or built without the multiarch
+ * variants): the identical source (sincosf.h) with every multiply-add rounded twice.  Used only to COUNT the arguments on which the two
+ * variants differ (orbo_count_sincos_fma_vs_nofma): the descriptor path's dependence on which libm variant the reference process runs. */
+static inline float sin_poly_nofma(double x, double x2, const SinCosTab &p) {
+    double x3 = x * x2;
+    double s1 = p.s2 + x2 * p.s3;
+    double x7 = x3 * x2;
+    double s = x + x3 * p.s1;
+    return (float)(s + x7 * s1);
+}
+static inline float cos_poly_nofma(double x2, const SinCosTab &p) {
+    double x4 = x2 * x2;
+    double c2 = p.c3 + x2 * p.c4;
+    double c1 = p.c0 + x2 * p.c1;
+    double x6 = x4 * x2;
+    double c = c1 + x4 * p.c2;
+    return (float)(c + x6 * c2);
+}
+static inline void sincos_nofma(float y, float *sn, float *cs) {
+    double x = y;
+    if (abstop12(y) < 0x3f4) {
+        if (abstop12(y) < 0x398) { *sn = y; *cs = 1.0f; return; }
+        *sn = sin_poly_nofma(x, x * x, kSC[0]); *cs = cos_poly_nofma(x * x, kSC[0]);
+        return;
+    }
+    double r = x * kSC[0].hpi_inv;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * kSC[0].hpi;
+    const SinCosTab &p = kSC[(n & 2) ? 1 : 0];
+    const float ps = sin_poly_nofma(x * kSC[0].sign[n & 3], x * x, p), pc = cos_poly_nofma(x * x, p);
+    *sn = (n & 1) ? pc : ps;
+    *cs = (n & 1) ? ps : pc;
+}
+/* number of float arguments with bit patterns in [lo, hi) (0 <= x < 120) for which sinf or cosf of the fma and the non-fma variant differ */
+uint64_t orbo_count_sincos_fma_vs_nofma(uint32_t lo, uint32_t hi, uint32_t *first_bad) {
+    uint64_t bad = 0;
+    for (uint64_t b = lo; b < hi; b++) {
+        uint32_t u = (uint32_t)b;
+        float x, s1, c1;
+        memcpy(&x, &u, 4);
+        const float s0 = ref_sinf(x), c0 = ref_cosf(x);
+        sincos_nofma(x, &s1, &c1);
+        if (memcmp(&s0, &s1, 4) || memcmp(&c0, &c1, 4)) {
+            if (!bad && first_bad) *first_bad = u;
+            bad++;
+        }
+    }
+    return bad;
+}
 float orbo_sinf(float x) { return ref_sinf(x); }
 float orbo_cosf(float x) { return ref_cosf(x); }
 uint64_t orbo_check_sincos_vs_libm(uint32_t lo, uint32_t hi, uint32_t *first_bad) {

@@ -108,6 +108,8 @@ float orbo_sinf(float x);
 float orbo_cosf(float x);
 /* exhaustive comparison of the restated sinf/cosf with the host libm over float bit patterns [lo,hi); returns #mismatches */
 uint64_t orbo_check_sincos_vs_libm(uint32_t lo_bits, uint32_t hi_bits, uint32_t *first_bad_bits);
+/* arguments in [lo, hi) on which the fma and the non-fma build of glibc's sinf / cosf differ (both restated in orb_oracle.cc) */
+uint64_t orbo_count_sincos_fma_vs_nofma(uint32_t lo_bits, uint32_t hi_bits, uint32_t *first_bad_bits);
 void orbo_orb_descriptor(const uint8_t *center, size_t stride, float angle_deg, int fma_mode, int libm, uint8_t *desc32);
 /* DistributeOctTree on explicit candidates.  Returns count. */
 int orbo_distribute_octree(const orbo_keypoint *in, int n_in, int minX, int maxX, int minY, int maxY, int N,

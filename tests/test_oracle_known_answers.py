@@ -4,6 +4,7 @@ The reference has no tests or golden vectors for this path ("parity unpinned"); 
 by hand from the cited lines, and tests/golden pins the oracle against regressions.
 """
 import ctypes as C
+import os
 import struct
 
 import numpy as np
@@ -180,6 +181,22 @@ def test_restated_sincos_matches_host_libm_sampled(oracle):
     for k in range(64):   # 64 windows of 200k consecutive floats each
         bad += L.orbo_check_sincos_vs_libm(lo + k * step, lo + k * step + 200000, C.byref(fb))
     assert bad == 0, hex(fb.value)
+
+
+def test_fma_and_non_fma_libm_variants_agree_on_the_descriptor_domain(oracle):
+    """glibc's sinf / cosf as the x86-64 "fma" ifunc computes them (the variant the reference runs here) and as the non-FMA build of the same
+    source computes them are bit-identical for EVERY float in [2^-12, 2 pi] -- the whole range of `angle * factorPI` (ORBextractor.cc:109-111);
+    below 2^-12 both return x and 1.  Exhaustive (122 M arguments, frame-parallel).  The counter does see differences elsewhere."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = oracle.lib()
+    f2b = lambda v: struct.unpack("<I", struct.pack("<f", v))[0]
+    lo, hi = f2b(2.0 ** -12), f2b(6.2831855) + 1
+    n = 64
+    edges = [lo + (hi - lo) * i // n for i in range(n + 1)]
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as pool:
+        counts = list(pool.map(lambda i: L.orbo_count_sincos_fma_vs_nofma(edges[i], edges[i + 1], None), range(n)))
+    assert sum(counts) == 0, counts
+    assert L.orbo_count_sincos_fma_vs_nofma(f2b(6.2831855) + 1, f2b(119.9), None) > 0   # not blind: the variants DO differ beyond 2 pi
 
 
 def test_three_maxima(oracle):
