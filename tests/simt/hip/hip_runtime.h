@@ -104,7 +104,7 @@ inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size
 // kernel launch: the blocks of the grid run one after the other, each under the fiber scheduler
 namespace simt {
 void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body);
-std::vector<uint32_t> block_order(dim3 grid);
+std::vector<uint32_t> block_order(dim3 grid, const char *name = nullptr);
 int kernel_split();
 bool fuzz();
 void launch_blocks(const char *name, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body, const uint32_t *ids, size_t n,
@@ -117,7 +117,7 @@ inline void launch_on(hipStream_t st, const char *name, dim3 grid, dim3 block, s
     auto tup = std::make_tuple(args...);   // kernel arguments are evaluated and copied at the launch call, as on the real runtime
     const int split = fuzz() && st ? kernel_split() : 0;
     if (split > 1) {   // SIMT_KERNEL_SPLIT: the launch as several queue entries (launch.cc)
-        auto ids = std::make_shared<std::vector<uint32_t>>(block_order(grid));
+        auto ids = std::make_shared<std::vector<uint32_t>>(block_order(grid, name));
         const size_t nb = ids->size(), pieces = std::min<size_t>(nb, (size_t)split), per = (nb + pieces - 1) / std::max<size_t>(pieces, 1);
         for (size_t c = 0; c * per < nb; c++)
             enqueue(st, [=] { launch_blocks(name, grid, block, lds, [&] { std::apply(kernel, tup); }, ids->data() + c * per, std::min(per, nb - c * per), c == 0); });

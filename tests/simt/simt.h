@@ -441,3 +441,8 @@ namespace simt { uint8_t *dyn_lds(); uintptr_t bss_anchor(); inline const uint8_
     return (const uint8_t *)((bss_anchor() & ~(uintptr_t)0xffffffffull) | a); } }
 inline void __threadfence_block() {}
 inline void __threadfence() {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline uint32_t __builtin_amdgcn_s_getreg(int) { return blockIdx.x & 7u; }   // XCC_ID of the probe: workgroups go to the XCDs round-robin
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
