@@ -25,6 +25,6 @@ for _name in ("tensor", "zeros", "full", "empty"):
         return lambda *a, **k: fn(*a, **{kk: vv for kk, vv in k.items() if not (kk == "device" and str(vv).startswith("cuda"))})
     setattr(torch, _name, _wrap(getattr(torch, _name)))
 os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
-sys.argv = ["bench.py", "--gpus", "1", "--batch", "4", "--steps", "2", "--warmup", "1", "--settle", "1", "--cpu-frames", "0", "--no-pmc",
+sys.argv = ["bench.py", "--gpus", "1", "--batch", "4", "--steps", "2", "--warmup", "1", "--settle", "1", "--settle-seconds", "0", "--cpu-frames", "0", "--no-pmc",
             "--no-profile", "--verify", "2"] + sys.argv[1:]
 runpy.run_path(str(ROOT / "bench.py"), run_name="__main__")
