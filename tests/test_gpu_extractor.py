@@ -195,6 +195,39 @@ def test_batch_device_matches_single(canvas1):
         assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), t
 
 
+@pytest.mark.parametrize("w,h,nf,B", [(424, 318, 500, 131), (752, 480, 1000, 136)])
+def test_one_launch_pyramid_chain_odd_batch(canvas1, w, h, nf, B):
+    """Batches of 128 frames and more build levels 1..7 in ONE launch whose workgroups wait for the row blocks of the level below
+    (k_pyr_resize_chain_ordered): a batch size that is not a multiple of 8 (the last frame group is part-filled) and a geometry other than the
+    bench's -- every pyramid level of sampled frames and every frame's keypoints / descriptors == oracle, twice in a row (the completion
+    counters are re-zeroed by k_pyr_base)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    ex = __import__("orb_slam3_amd").ORBextractor(nf, 1.2, 8, 20, 7)
+    frames = np.stack([synth.frame_from_canvas(canvas1, t, w, h, 3000 + t) for t in range(B)])
+    d = torch.from_numpy(frames).cuda()
+
+    def want(fs):
+        oex = ob.OracleExtractor(nf, 1.2, 8, 20, 7)
+        return [(f,) + tuple(oex.extract(frames[f], lap=(0, 0))) for f in fs]
+
+    with ThreadPoolExecutor(32) as pool:
+        ref = {r[0]: r[1:] for chunk in pool.map(want, [list(range(B))[i::32] for i in range(32)]) for r in chunk}
+    oex = ob.OracleExtractor(nf, 1.2, 8, 20, 7)
+    for rep in range(2):
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, (0, 0))
+        for f in range(B):
+            mono, kps, desc = ex.download(f)
+            omono, okps, odesc = ref[f]
+            assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (rep, f)
+        for f in (0, 7, B - 1):
+            oex.extract(frames[f], lap=(0, 0))
+            for l in range(8):
+                assert np.array_equal(ex.get_level(l, f), oex.level_padded(l)), (rep, f, l)
+
+
 def test_single_frame_call_host_block_equals_device_buffers(canvas1):
     """orbx_extract hands its results over in a pinned host block the last kernel writes itself (one synchronisation per call); the device
     buffers the batched matchers read hold the same keypoints and descriptors, and a frame with no keypoint at all comes back as count 0."""
