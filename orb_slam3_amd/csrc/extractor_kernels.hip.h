@@ -6,7 +6,7 @@
 //   k_fast_strip      per-cell cv::FAST(ini) + NMS, a strip of cells per workgroup  :805-842   (fast_strip.hip.h)
 //   k_fast_wave_list  cells the first pass left empty: cv::FAST(ini) / fallback cv::FAST(min)   :843-870
 //                     (k_fast_cells = generic workgroup-per-cell form for cells wider than 57 px)
-//   k_compact, k_octree_par_t (octree_par.hip.h)  DistributeOctTree / DivideNode / compareNodes   :480-779
+//   k_octree_par_t (octree_par.hip.h; its first tier gathers the keys: compact_level)  DistributeOctTree / DivideNode / compareNodes   :480-779
 //                     (k_octree in octree.hip.h = sequential emulation for node pools beyond the LDS budget)
 //   k_finalize        level concatenation + lapping split slots                :1117-1162
 //   k_blur_pk         GaussianBlur 7x7 sigma 2 (fixed point)                   :1132-1133

@@ -223,19 +223,14 @@ __global__ __launch_bounds__(64) void k_debug_sort_par(const int32_t *count, con
     for (int i = lane; i < n; i += 64) perm[i] = (int32_t)(scratch[i] & 0xffff);
 }
 
-// ---- k_compact: vToDistributeKeys of every (frame, level) (:805-870 pushes the cells' keypoints in cell row-major order):
+// ---- compact_level (k_compact until round 3): vToDistributeKeys of every (frame, level) (:805-870 pushes the cells' keypoints in cell row-major order):
 // exclusive scan of the per-cell counts + gather of the cell slots into one dense key array.  A separate, wide launch
 // (256 threads per (frame, level)) because the single quad-tree wave cannot hide the latency of these dependent global
-// loads.  grid (nlevels, B), block 256
-__global__ __launch_bounds__(256) void k_compact(const LevelInfo *__restrict__ lv, const int32_t *__restrict__ cellcnt, int total_cells,
-                                                 const uint32_t *__restrict__ cellent, size_t ent_frame_stride,
-                                                 uint32_t *__restrict__ keys, int32_t *__restrict__ cand_total, int nlevels) {
+// loads.  Since round 3 the first tier of k_octree_par_t calls it for its own (frame, level).
+// one (frame, level): returns the number of keys gathered (the same value in every thread); 256 threads, one barrier pair per 256 cells
+__device__ __forceinline__ int compact_level(const LevelInfo &L, const int32_t *__restrict__ ccnt, const uint32_t *__restrict__ ent,
+                                             uint32_t *__restrict__ dst) {
     __shared__ int wsum[4];
-    const int level = blockIdx.x, f = blockIdx.y;
-    const LevelInfo L = lv[level];
-    const int32_t *ccnt = cellcnt + (size_t)f * total_cells + L.cell_base;
-    const uint32_t *ent = cellent + (size_t)f * ent_frame_stride + L.cand_off;
-    uint32_t *dst = keys + (size_t)f * ent_frame_stride + L.cand_off;
     const int ncell = L.nCols * L.nRows;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int run = 0;
@@ -258,9 +253,8 @@ __global__ __launch_bounds__(256) void k_compact(const LevelInfo *__restrict__ l
         }
         run += s0 + s1 + s2 + s3;
     }
-    if (tid == 0) cand_total[f * nlevels + level] = run;
+    return run;
 }
-
 // ---- the kernel body ---------------------------------------------------------------------------------------------
 // exclusive SEGMENTED prefix sum over the 256 threads of the workgroup: the value accumulated since the last segment head
 // (fl = this thread contains a head; v = its accumulation after its last head, or over all its keys when it has none);
@@ -748,7 +742,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
 // launched over all (frame, level) pairs and each returns at once for the pairs that belong to the other.
 __device__ __forceinline__ bool oct_blk_form(const LevelInfo &L, int C) { return C <= kOctParLdsKeys && L.nIni <= 4 && L.pool <= 2047; }
 
-// k_octree_par_t: the 256-thread form in two tiers (k_compact has run before).  Sized for 4096 candidates on every level the form
+// k_octree_par_t: the 256-thread form in two tiers (the first tier gathers the keys itself: compact_level).  Sized for 4096 candidates on every level the form
 // needs 45 KB of LDS and 161 VGPRs (three workgroups per CU), and a level with 1100 candidates still walks 17 key slots per thread in
 // every unrolled sweep.  The small tier (LO < C <= 2048: every level of the EuRoC-shaped bench) has 9 slots, 118 VGPRs and 33 KB:
 // four workgroups per CU (2048 workgroups = two dispatch rounds instead of three) and about 30 % fewer instructions; levels with
@@ -759,14 +753,22 @@ template <int KEYS, int LO>
 __global__ __launch_bounds__(256, (KEYS <= 2048 ? 4 : 3)) void k_octree_par_t(const LevelInfo *__restrict__ lv, size_t ent_frame_stride,
                                                                               uint32_t *__restrict__ keys1, uint32_t *__restrict__ lvlkp,
                                                                               size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt, int nlevels,
-                                                                              const int32_t *__restrict__ cand_total, int32_t *__restrict__ err,
-                                                                              int max_pool) {
+                                                                              int32_t *__restrict__ cand_total, int32_t *__restrict__ err,
+                                                                              int max_pool, const int32_t *__restrict__ cellcnt, int total_cells,
+                                                                              const uint32_t *__restrict__ cellent) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int level = blockIdx.y, f = blockIdx.x;
     const LevelInfo L = lv[level];
-    const int C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
-    if (!(C > LO && C <= KEYS && L.nIni <= 4 && L.pool <= 2047)) return;
     uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
+    int C;
+    if (LO < 0 && cellcnt) {   // the first tier gathers vToDistributeKeys of EVERY (frame, level) itself (k_compact's work without its launch: the
+                               // later tiers and k_octree_par1 read the keys and the count it leaves behind)
+        C = __builtin_amdgcn_readfirstlane(compact_level(L, cellcnt + (size_t)f * total_cells + L.cell_base,
+                                                         cellent + (size_t)f * ent_frame_stride + L.cand_off, gk1));
+        if (threadIdx.x == 0) cand_total[f * nlevels + level] = C;
+        __syncthreads();   // the workgroup's own stores to gk1 are visible to its loads below
+    } else C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
+    if (!(C > LO && C <= KEYS && L.nIni <= 4 && L.pool <= 2047)) return;
     octree_par_body<true, KEYS>(L, smem, max_pool, C, nullptr, gk1, nullptr, nullptr, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off,
                                 lvlcnt + f * nlevels + level, err, nullptr);
 }

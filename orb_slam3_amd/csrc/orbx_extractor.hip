@@ -506,8 +506,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     {
         ProfScope ps(ex, K_OCTREE);
         if (ex->oct_par) {
-            hipLaunchKernelGGL(k_compact, dim3(nl, n), dim3(256), 0, st, d_lv, (const int32_t *)ex->d_cellcnt.p, ex->total_cells,
-                               (const uint32_t *)ex->d_cellent.p, ex->cand_frame, (uint32_t *)ex->d_keys1.p, (int32_t *)ex->d_candtot.p, nl);
+            // vToDistributeKeys of every (frame, level) is gathered by the first tier itself (compact_level): as a launch of its own (k_compact, rounds 1-3)
+            // it took 24 us + a launch boundary on the main stream's latency-bound stretch, inside the tier 13 us (profiles/r03_am)
             const size_t lds = oct_par_lds_bytes(ex->max_pool), lds1 = oct_par_pool_bytes(ex->max_pool);
             const size_t lds_s = oct_par_pool_bytes(ex->max_pool) + (size_t)2048 * 6;
             if (lds1 > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
@@ -515,11 +515,12 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             if (lds_s > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<2048, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
             // two tiers of the 256-thread form: levels with at most 2048 candidates (every level of the EuRoC-shaped bench), then 2049 .. 4096
             hipLaunchKernelGGL((k_octree_par_t<2048, -1>), dim3(n, nl), dim3(256), lds_s, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
-                               (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
-                               (int32_t *)ex->d_err.p, ex->max_pool);
+                               (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p,
+                               (int32_t *)ex->d_err.p, ex->max_pool, (const int32_t *)ex->d_cellcnt.p,
+                               ex->total_cells, (const uint32_t *)ex->d_cellent.p);
             hipLaunchKernelGGL((k_octree_par_t<4096, 2048>), dim3(n, nl), dim3(256), lds, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
-                               (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p,
-                               (int32_t *)ex->d_err.p, ex->max_pool);
+                               (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p,
+                               (int32_t *)ex->d_err.p, ex->max_pool, (const int32_t *)nullptr, ex->total_cells, (const uint32_t *)nullptr);
             hipLaunchKernelGGL(k_octree_par1, dim3(n, nl), dim3(64), lds1, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys0.p,
                                (uint32_t *)ex->d_keys1.p, (uint16_t *)ex->d_nof0.p, (uint16_t *)ex->d_nof1.p, (uint32_t *)ex->d_lvlkp.p,
                                ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p,
