@@ -163,6 +163,7 @@ struct orbx_extractor {
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
     int blur_tile_start[orbx::kMaxLevels + 1] = {};  // blur tiles of level l: [start[l], start[l + 1])
     bool match_pending = false;
+    bool copy_covers_match = false;   // the most recent download waited for ev_match on the copy stream: its ev_copy_done implies the matcher is done
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream
     hipEvent_t ev_stereo_copy[2] = {nullptr, nullptr};   // ends of the last two orbx_stereo_batch_download_async
     unsigned stereo_copy_issued = 0, stereo_copy_waited = 0;

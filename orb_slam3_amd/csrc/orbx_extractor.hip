@@ -215,7 +215,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream}) if (s) ORBX_HIP(hipStreamSynchronize(s));
-    ex->copy_pending = false; ex->match_pending = false; ex->copy_issued = ex->copy_waited = 0;
+    ex->copy_pending = false; ex->match_pending = false; ex->copy_covers_match = false; ex->copy_issued = ex->copy_waited = 0;
     ex->mkey = orbx_extractor::MatchKey();
     ex->mpkey = orbx_extractor::MpKey();
     const int B = std::max(batch, ex->batch_cap);
@@ -537,7 +537,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     if (ex->copy_pending) {  // outputs of the previous batch may still be in flight to the host
         ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done[(ex->copy_issued - 1) & 1], 0));  // the most recent download
     }
-    if (ex->match_pending) {  // the previous batch's matcher still reads its counts / keypoints / descriptors
+    if (ex->match_pending && !(ex->copy_pending && ex->copy_covers_match)) {  // the previous batch's matcher still reads its counts / keypoints / descriptors
+                                                                              // (a download issued behind it on the copy stream has waited for it already: one barrier less)
         ORBX_HIP(hipStreamWaitEvent(st, ex->ev_match, 0));
     }
     {
@@ -926,6 +927,7 @@ int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *d
     if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
+    ex->copy_covers_match = ex->match_pending;
     if (match && ex->d_match.p) ORBX_HIP(hipMemcpyAsync(match, ex->d_match.p, 4 * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (nmatches && ex->d_nmatch.p) ORBX_HIP(hipMemcpyAsync(nmatches, ex->d_nmatch.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     const unsigned slot = ex->copy_issued & 1;

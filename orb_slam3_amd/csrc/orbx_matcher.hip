@@ -1009,7 +1009,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         ex->prof_ms[K_MATCH_RESOLVE] += t; ex->prof_n[K_MATCH_RESOLVE]++;
     }
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
-    ex->match_pending = true;
+    ex->match_pending = true; ex->copy_covers_match = false;
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
@@ -1115,7 +1115,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
     hipLaunchKernelGGL(k_greedy_resolve, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
                        (const ResolveProblem *)ex->d_mp_res.p, g, cap);
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
-    ex->match_pending = true;
+    ex->match_pending = true; ex->copy_covers_match = false;
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
@@ -1291,9 +1291,9 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
     ORBX_HIP(hipGetLastError());
     // the extractors must not overwrite their outputs / pyramids before these kernels are done
     ORBX_HIP(hipEventRecord(L->ev_match, st));
-    L->match_pending = true;
+    L->match_pending = true; L->copy_covers_match = false;
     ORBX_HIP(hipEventRecord(R->ev_match, st));   // the right extractor's next k_finalize waits for it as for a matcher of its own
-    R->match_pending = true;
+    R->match_pending = true; R->copy_covers_match = false;
     return ORBX_OK;
 }
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+# visit ao: last library change of the round (one cross-stream wait less before k_finalize): GPU suite + the three workloads
+mkdir -p gpurun_out/r03ao
+run() { wl=$1; shift; env "$@" timeout 200 python bench.py --workload $wl --cpu-frames 0 --no-pmc --no-other-workloads --latency 0 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['repeats']['ms_per_step']; print('$wl $*', d['value'], d['ms_per_step'], r['median'], r['min'], r['max'], d.get('parity_checked'))"; }
+{
+timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+run euroc ORBX_NONE=1; run euroc ORBX_NONE=1; run kitti ORBX_NONE=1; run tumvi ORBX_NONE=1
+} > gpurun_out/r03ao/log.txt 2>&1
+cat gpurun_out/r03ao/log.txt
