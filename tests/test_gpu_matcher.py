@@ -102,6 +102,41 @@ def test_stereo_rowband_and_full_stereo(oracle):
     assert n > 100
 
 
+def test_stereo_matches_on_an_image_taller_than_the_row_index(oracle):
+    """orbx_compute_stereo_matches takes the caller's keypoints and pyramids: an image of more than 8192 rows (more than the row index has
+    buckets: two rows share a bucket, row_shift = 1) with synthetic keypoints -- Hamming stage, SAD stage and rejection == oracle."""
+    import orb_slam3_amd as osa
+    from orb_slam3_amd.extractor import KP_DTYPE
+    rng = np.random.default_rng(11)
+    w, h, n = 64, 9000, 600
+    sf = np.array([1.0, 1.2], np.float32)
+    isf = (1.0 / sf).astype(np.float32)
+    pyl = [rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (7500, 53), dtype=np.uint8)]
+    # the right images: the left ones shifted by the keypoints' disparity plus noise (a noise-free copy would give SAD 0 everywhere, median 0,
+    # and the reference's `dist < 1.5 * 1.4 * median` would reject every match)
+    noisy = lambda a: np.clip(a.astype(np.int32) + rng.integers(-12, 13, a.shape), 0, 255).astype(np.uint8)
+    pyr = [noisy(np.roll(pyl[0], -3, axis=1)), noisy(np.roll(pyl[1], -2, axis=1))]
+    kl = np.zeros(n, KP_DTYPE)
+    kl["x"] = rng.uniform(30, 44, n).astype(np.float32)
+    kl["y"] = rng.uniform(20, h - 20, n).astype(np.float32)
+    kl["octave"] = rng.integers(0, 2, n)
+    kl["size"] = 31.0
+    kl["class_id"] = -1
+    dl = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    kr = kl.copy()
+    kr["x"] = kl["x"] - np.where(kl["octave"] == 0, 3.0, 2.4).astype(np.float32) + rng.uniform(-0.3, 0.3, n).astype(np.float32)
+    kr["y"] = kl["y"] + rng.uniform(-1.5, 1.5, n).astype(np.float32)
+    dr = dl ^ np.packbits(rng.random((n, 256)) < 0.03, axis=1, bitorder="little")
+    perm = rng.permutation(n)
+    kr, dr = kr[perm], np.ascontiguousarray(dr[perm])
+    bf, b = 40.0, 1.0
+    on, our, odepth, _, _ = oracle.compute_stereo_matches(kl, dl, kr, dr, sf, isf, pyl, pyr, bf, b)
+    m = osa.ORBmatcher()
+    got_n, ur, depth = m.ComputeStereoMatches(kl, dl, kr, dr, sf, isf, pyl, pyr, bf, b)
+    assert got_n == on and ur.tobytes() == our.tobytes() and depth.tobytes() == odepth.tobytes()
+    assert on > 100
+
+
 def _frame_view(kps, desc, sf, w, h):
     import orb_slam3_amd as osa
     return osa.FrameView(kps, desc, 0.0, float(w), 0.0, float(h), sf)
