@@ -35,8 +35,7 @@ enum {
     ORBX_E_HIP = -6,         /* a HIP runtime call failed; see orbx_last_error() */
     ORBX_E_TOO_LARGE = -7,   /* image / batch exceeds the limits given at creation, or a dimension > 4095 px */
     ORBX_E_INTERNAL = -8     /* device-side consistency check failed; orbx_last_error() names the code: 1 more keypoints than the output
-                              * capacity, 2 / 3 quad-tree node pool / level list overflow, 77 a wave of the one-launch pyramid chain gave up
-                              * waiting for its source rows (the in-order dispatch it relies on did not hold) */
+                              * capacity, 2 / 3 quad-tree node pool / level list overflow */
 };
 
 /* 28-byte POD with the field layout of cv::KeyPoint {Point2f pt; float size, angle, response; int octave,

@@ -52,13 +52,10 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_base(const LevelInfo L, const uint8_t *__restrict__ img,
                                                   size_t row_stride, size_t frame_stride, uint8_t *__restrict__ pyr,
-                                                  size_t pyr_frame_stride, int32_t *__restrict__ zero_word, uint32_t cpr_rcp, int n_frames,
-                                                  int32_t *__restrict__ chain_flags, int flags_per_frame) {
+                                                  size_t pyr_frame_stride, int32_t *__restrict__ zero_word, uint32_t cpr_rcp, int n_frames) {
     int bx, f;
     if (!xcd_frame_map(n_frames, &bx, &f)) return;   // a frame's rows stay on one XCD: lines shared by neighbouring workgroups hit its L2
     if (zero_word && bx == 0 && f == 0 && threadIdx.x == 0) *zero_word = 0;  // k_fast_wave's overflow counter of this batch
-    if (chain_flags && bx == 0)   // row-block completion counters of k_pyr_resize_chain_ordered, this frame's
-        for (int i = threadIdx.x; i < flags_per_frame; i += 256) chain_flags[(size_t)f * flags_per_frame + i] = 0;
     const int cpr = L.pitch >> 4;  // 16-byte chunks per padded row (the pitch is a multiple of 64)
     const int idx = bx * 256 + threadIdx.x;
     const int py = (int)__umulhi((uint32_t)idx, cpr_rcp), ci = idx - py * cpr;   // idx / cpr, cpr_rcp = ceil(2^32 / cpr)
@@ -330,74 +327,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize_march(const LevelInfo L, con
     const int item = bx * 4 + wave;
     if (item >= n_items) return;
     resize_march_block<CH>(L, P, ytab, xg, pyr + (size_t)f * pyr_frame_stride, rb_rows, nstrips, nstrips_rcp, item, lane);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_pyr_resize_chain_ordered: levels 1 .. nlevels-1 in ONE launch.  The workgroups of level l follow those of level l-1 in the grid; a wave
-// about to march a block of level l >= 2 first waits until the row blocks of level l-1 that hold its source rows are complete: every wave
-// that finishes an item adds 1 to its row block's counter (release), a waiting wave polls the counters it needs (a device-scope atomic read at
-// the L2) and then acquires.  No deadlock: workgroups are DISPATCHED in the order of their linear id (per XCD; a frame's workgroups all lie on one
-// XCD, xcd_grid), so when a consumer is resident every producer it waits for is resident or finished, and producers wait only for smaller
-// ids.  What it buys: the drain of one level overlaps the start of the next instead of seven launch boundaries (each a machine-wide barrier).
-// A bounded spin turns a broken assumption into an error code instead of a hung GPU.  The counters are zeroed by k_pyr_base.
-// grid (8, ceil(B / 8), sum_l ceil(n_items_l / 4)) with B > 8 (a frame's workgroups on one XCD), block 256
-// ---------------------------------------------------------------------------------------------------------
-// Probe for the assumption above: every workgroup writes the id of the XCD it runs on (hardware register XCC_ID, gfx940+); the host checks that
-// all workgroups with the same blockIdx.x of a grid (8, y, z) report the same XCD (orbx_extractor::xcd_of_block_x_is_fixed).
-__global__ __launch_bounds__(64) void k_xcc_probe(uint32_t *__restrict__ out) {
-    const uint32_t id = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // hwreg(HW_REG_XCC_ID), all 32 bits
-    if (threadIdx.x == 0) out[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = id;
-}
-
-struct ChainLevels {
-    int32_t first_block[kMaxLevels + 1];   // workgroups of level l: [first_block[l], first_block[l + 1]); first_block[1] = 0
-    int32_t rb_shift[kMaxLevels];          // rows per block of level l = 1 << rb_shift[l]
-    int32_t nstrips[kMaxLevels], n_items[kMaxLevels];
-    int32_t flag_off[kMaxLevels];          // first counter of level l in a frame's counter array (one per row block)
-    uint32_t nstrips_rcp[kMaxLevels];
-    int32_t nlevels, flags_per_frame;
-};
-constexpr int kChainSpinLimit = 1 << 20;   // polls (x ~1 us) before a wave gives up and reports ORBX error 77
-template <int CH>
-__global__ __launch_bounds__(256) void k_pyr_resize_chain_ordered(const LevelInfo *__restrict__ lv, const ChainLevels C, const ResizeTap *__restrict__ ytab,
-                                                                  const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                                  int32_t *__restrict__ flags, int32_t *__restrict__ err, int n_frames) {
-    // LEVEL-major dispatch order inside an XCD: blockIdx.x = XCD = frame mod 8 (fastest), blockIdx.y = frame / 8, blockIdx.z = workgroup of the
-    // frame (slowest) -- the producers of a level-l block were dispatched a whole level of all the XCD's frames earlier, so a wait is rare and short
-    const int f = (int)(blockIdx.y * 8 + blockIdx.x), bx = (int)blockIdx.z;
-    if (f >= n_frames) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int l = 1;
-    while (l + 1 < C.nlevels && bx >= C.first_block[l + 1]) l++;   // wave-uniform
-    const int item = (bx - C.first_block[l]) * 4 + wave;
-    if (item >= C.n_items[l]) return;
-    const LevelInfo L = lv[l], P = lv[l - 1];
-    const int nstrips = C.nstrips[l], rb_rows = 1 << C.rb_shift[l];
-    const int rb = nstrips == 1 ? item : (int)__umulhi((uint32_t)item, C.nstrips_rcp[l]);
-    int32_t *fl = flags + (size_t)f * C.flags_per_frame;
-    if (l > 1) {   // the source rows of this block: rows ytab[y0].ofs .. ytab[y1 - 1].ofs + 1 of level l - 1
-        const int y0 = rb * rb_rows, y1 = min(y0 + rb_rows, L.h);
-        const int s0 = ytab[L.ytab_off + y0].ofs, s1 = min(ytab[L.ytab_off + y1 - 1].ofs + 1, P.h - 1);
-        const int need = C.nstrips[l - 1];
-        for (int p = s0 >> C.rb_shift[l - 1]; p <= (s1 >> C.rb_shift[l - 1]); p++) {
-            int32_t *c = fl + C.flag_off[l - 1] + p;
-            int spins = 0;
-            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {   // a load at the L2, not a read-modify-write
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > kChainSpinLimit) { if (lane == 0) atomicMax(err, 77); break; }
-            }
-        }
-        // No cache maintenance: producer and consumer run on the same XCD (blockIdx.x), whose L2 is the point of coherence of its CUs; the vector L1
-        // is write-through, and a line of source ROI bytes a consumer may hold was fetched after that row was complete (a 128-byte line holds ROI
-        // bytes of one row only: ROI rows start 64 bytes into a 64-byte-multiple pitch).  A device-scope fence here writes back / invalidates the
-        // whole L2 once per wave: measured 2.5 ms instead of 0.2 ms for the chain.
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    resize_march_block<CH>(L, P, ytab, xg, pyr + (size_t)f * pyr_frame_stride, rb_rows, nstrips, C.nstrips_rcp[l], item, lane);
-    if (l + 1 < C.nlevels) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): this wave's rows are in the L2 before its count
-        if (lane == 0) atomicAdd(fl + C.flag_off[l] + rb, 1);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

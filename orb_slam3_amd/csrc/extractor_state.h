@@ -130,9 +130,6 @@ struct orbx_extractor {
     // Stereo rig (orbx_stereo_batch_device): the SAD stage reads both extractors' pyramids on the match stream while the NEXT pair of batches is
     // extracted, so an extractor that has been part of a rig alternates between two pyramid slabs (allocated at the first stereo call)
     DevBuf d_pyr2;
-    int chain_min_frames = 128;   // smallest batch that takes the one-launch pyramid chain (measured: 256 EuRoC frames +3.5 %, 64 KITTI / TUM-VI frames -3 ... -5 %)
-    int chain_ok = -1;      // k_pyr_resize_chain_ordered usable: -1 not probed yet, 0 no, 1 yes (k_xcc_probe: blockIdx.x of a grid (8, y, z) fixes the XCD)
-    DevBuf d_chain_flags;   // row-block completion counters of k_pyr_resize_chain_ordered [B][sum_l row blocks]
     bool pyr_double = false;
     int pyr_slot = 0;
     uint8_t *pyr_cur() const { return (uint8_t *)(pyr_slot ? d_pyr2.p : d_pyr.p); }

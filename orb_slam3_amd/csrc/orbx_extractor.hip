@@ -255,6 +255,10 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_tiles.p, blur_tiles.data(), sizeof(TileRef) * blur_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
+    // Cells the reference skips (empty interior: iniX >= maxBorderX - 6 / iniY >= maxBorderY - 3, ORBextractor.cc:810,819 -- e.g. cell column 33 of
+    // level 0 of a 1226 x 370 image) belong to no strip and are never written by the FAST stage; compact_level reads every cell's count.  A
+    // buffer kept from another geometry holds that geometry's counts there: clear it whenever the cell layout changes.
+    if (!same_geom) ORBX_HIP(hipMemset(ex->d_cellcnt.p, 0, ex->d_cellcnt.bytes));
     ORBX_HIP(hipDeviceSynchronize());   // the fill has run (DevBuf::ensure, extractor_state.h)
     ex->lv = lv;
     ex->width = width; ex->height = height; ex->batch_cap = B;
@@ -370,54 +374,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     hipStream_t st = ex->stream;
     hipStream_t pst = st;   // stream of the pyramid stage
     const bool pyr_local = true;   // a frame's pyramid workgroups stay on one XCD
-    // levels 1 .. nl-1 in one launch (k_pyr_resize_chain_ordered) when every level takes the marching form and a frame's workgroups share an XCD
-    // (batches of chain_min_frames and more: the dependency waits need enough frames per XCD to stay rare); ORBX_PYR_CHAIN=0: one launch per
-    // level, ORBX_PYR_CHAIN=<n>: from n frames on (hardware A/B)
-    ChainLevels chain;
-    memset(&chain, 0, sizeof(chain));
-    static const int chain_env = [] { const char *v = getenv("ORBX_PYR_CHAIN"); return v ? atoi(v) : -1; }();
-    const bool chain_on = chain_env != 0;
-    if (chain_env > 8) ex->chain_min_frames = chain_env;
-    bool use_chain = chain_on && n >= ex->chain_min_frames && nl >= 3 && !ex->profile;
-    if (use_chain && ex->chain_ok < 0) {   // once per extractor: does blockIdx.x of a grid (8, y, z) fix the XCD a workgroup runs on?
-        constexpr int PY = 16, PZ = 8;
-        uint32_t *d_probe = nullptr, h_probe[8 * PY * PZ];
-        ex->chain_ok = 0;
-        if (hipMalloc((void **)&d_probe, sizeof(h_probe)) == hipSuccess) {
-            hipLaunchKernelGGL(k_xcc_probe, dim3(8, PY, PZ), dim3(64), 0, pst, d_probe);
-            if (hipMemcpyAsync(h_probe, d_probe, sizeof(h_probe), hipMemcpyDeviceToHost, pst) == hipSuccess && hipStreamSynchronize(pst) == hipSuccess) {
-                bool fixed = true;
-                for (int i = 0; i < 8 * PY * PZ; i++) fixed = fixed && h_probe[i] == h_probe[i % 8];
-                ex->chain_ok = fixed ? 1 : 0;
-            }
-            (void)hipFree(d_probe);
-        }
-        (void)hipGetLastError();
-    }
-    use_chain = use_chain && ex->chain_ok == 1;
-    for (int l = 1; l < nl && use_chain; l++) use_chain = ex->resize_march_ok[l];
-    if (use_chain) {
-        int blocks = 0, nflags = 0;
-        for (int l = 1; l < nl; l++) {
-            const LevelInfo &L = ex->lv[l];
-            const int shift = L.h >= 256 ? 5 : 4, rb = 1 << shift, nstrips = (L.pitch / 4 + 63) / 64, nrb = (L.h + rb - 1) / rb;
-            chain.first_block[l] = blocks; chain.rb_shift[l] = shift; chain.nstrips[l] = nstrips; chain.n_items[l] = nstrips * nrb;
-            chain.nstrips_rcp[l] = (uint32_t)((0x100000000ull + (uint64_t)nstrips - 1) / (uint64_t)nstrips);
-            chain.flag_off[l] = nflags;
-            blocks += (nstrips * nrb + 3) / 4; nflags += nrb;
-        }
-        chain.first_block[nl] = blocks; chain.nlevels = nl; chain.flags_per_frame = nflags;
-        int rr = ex->d_chain_flags.ensure(sizeof(int32_t) * (size_t)nflags * ex->batch_cap);
-        if (rr != ORBX_OK) return rr;
-    }
     {
         ProfScope ps(ex, K_PYR_BASE);
         const LevelInfo &L = ex->lv[0];
         const dim3 grid = xcd_grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n, pyr_local);
         hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, pst, L, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
                            (int32_t *)ex->d_fast_ovf.p,
-                           (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)), n,
-                           use_chain ? (int32_t *)ex->d_chain_flags.p : (int32_t *)nullptr, chain.flags_per_frame);
+                           (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)), n);
     }
     if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));  // k_pyr_base is the only reader of the input frames
     const int ini_th = std::min(std::max(ex->prm.ini_th_fast, 0), 255), min_th = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini_th);
@@ -434,11 +397,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         else ORBX_BLUR_PK(false);
 #undef ORBX_BLUR_PK
     };
-    if (use_chain)
-        hipLaunchKernelGGL(k_pyr_resize_chain_ordered<8>, dim3(8, (unsigned)((n + 7) / 8), (unsigned)chain.first_block[nl]), dim3(256), 0, pst, d_lv, chain,
-                           (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame, (int32_t *)ex->d_chain_flags.p,
-                           (int32_t *)ex->d_err.p, n);
-    for (int l = 1; l < nl && !use_chain; l++) {
+    for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
         if (ex->resize_march_ok[l]) {
@@ -487,6 +446,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                                (const StripTile *)ex->d_strips.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,
                                (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
                                ini > mn ? 1 : 0, n);
+            ORBX_HIP(hipGetLastError());   // e.g. an LDS budget the device refuses: fail here, not as silently missing candidates
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
@@ -728,7 +688,7 @@ void orbx_destroy(orbx_extractor *ex) {
     for (int i = 0; i < 3; i++) { if (ex->h_frustum[i]) (void)hipHostFree(ex->h_frustum[i]); if (ex->ev_frustum[i]) (void)hipEventDestroy(ex->ev_frustum[i]); }
     ex->d_match.release(); ex->d_nmatch.release();
     for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales, &ex->d_st_rowptr, &ex->d_st_rowidx}) b->release();
-    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr, &ex->d_pyr2, &ex->d_chain_flags,
+    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_dc, &ex->d_pyr, &ex->d_pyr2,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,

@@ -16,11 +16,10 @@ uint8_t *dyn_lds() {
 // Workgroups of a launch run one after another.  SIMT_BLOCK_ORDER=reverse runs them last to first, SIMT_BLOCK_ORDER=<seed> in a
 // different random order for every launch: a result that changes with it depends on the order in which workgroups reach a
 // global atomic (list appends, counters) -- which the hardware does not define.
-// A kernel whose name ends in _ordered relies on the hardware's in-order DISPATCH of workgroups (a later workgroup may wait for an earlier one):
-// its workgroups always run first to last.
+// (No kernel of the product may depend on it: HIP promises nothing about dispatch order.  Round 3's k_pyr_resize_chain_ordered did and was removed.)
 std::vector<uint32_t> block_order(dim3 grid, const char *name) {
     static const char *order_env = getenv("SIMT_BLOCK_ORDER");
-    const char *order = name && strstr(name, "_ordered") ? nullptr : order_env;
+    const char *order = order_env;
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     std::vector<uint32_t> perm(nblocks);
     for (size_t i = 0; i < nblocks; i++) perm[i] = (uint32_t)i;

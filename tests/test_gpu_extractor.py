@@ -196,11 +196,9 @@ def test_batch_device_matches_single(canvas1):
 
 
 @pytest.mark.parametrize("w,h,nf,B", [(424, 318, 500, 131), (752, 480, 1000, 136)])
-def test_one_launch_pyramid_chain_odd_batch(canvas1, w, h, nf, B):
-    """Batches of 128 frames and more build levels 1..7 in ONE launch whose workgroups wait for the row blocks of the level below
-    (k_pyr_resize_chain_ordered): a batch size that is not a multiple of 8 (the last frame group is part-filled) and a geometry other than the
-    bench's -- every pyramid level of sampled frames and every frame's keypoints / descriptors == oracle, twice in a row (the completion
-    counters are re-zeroed by k_pyr_base)."""
+def test_large_odd_batch_every_level(canvas1, w, h, nf, B):
+    """Batches of more than 128 frames whose size is not a multiple of 8 (the last XCD frame group of every launch is part-filled) and a geometry
+    other than the bench's -- every pyramid level of sampled frames and every frame's keypoints / descriptors == oracle, twice in a row."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
     from orb_slam3_amd import synth
@@ -377,6 +375,24 @@ def test_reconfigure_between_shapes(canvas1):
             mono, kps, desc = ex.download(t)
             omono, okps, odesc = oex.extract(frames[t], lap=(0, 0))
             assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (nb, t)
+
+
+def test_reconfigure_onto_a_geometry_with_skipped_cells(canvas1):
+    """ORBextractor.cc:810,819: a cell whose sub-image has no interior is skipped (`continue`) -- cell column 33 of level 0 of a 1226 x 370 image
+    (iniX = 16 + 33 * 36 = 1204 >= maxBorderX - 6).  Such a cell belongs to no strip of k_fast_strip and its count is never written; the
+    quad-tree's gather reads every cell's count.  An extractor that goes 1241 x 376 -> 1226 x 370 keeps its buffers (the smaller geometry fits),
+    so the counts of the old cell layout must not survive the reconfiguration (round 3 regression, found by the advisor)."""
+    from orb_slam3_amd import synth
+    ex, oex = _pair(2000)
+    for (w, h) in ((1241, 376), (1226, 370), (1241, 376), (1226, 370)):
+        img = synth.frame_from_canvas(canvas1, 9, w, h, 777)
+        mono, kps, desc = ex(img, None, (0, 0))
+        omono, okps, odesc = oex.extract(img, lap=(0, 0))
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (w, h)
+        for l in range(8):
+            got = ex.debug_candidates(l)
+            want = oex.level_candidates(l)
+            assert len(got) == len(want) and all(np.array_equal(got[fld], want[fld]) for fld in ("x", "y", "response")), (w, h, l)
 
 
 def test_alternative_kernel_paths(tmp_path):

@@ -120,8 +120,7 @@ _FULL = pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason
                                  pytest.param({"SIMT_STREAM_FUZZ": "7", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11", "SIMT_LANE_ORDER": "3",
                                                "SIMT_LDS_RANDOM": "8"}, marks=_FULL),
                                  {"SIMT_STREAM_FUZZ": "5", "SIMT_MEMSET_ASYNC": "1", "SIMT_KERNEL_SPLIT": "6"},
-                                 # the one-launch pyramid chain (default from 128 frames on) at 9 frames, its counters starting as garbage
-                                 {"ORBX_PYR_CHAIN": "9", "SIMT_STREAM_FUZZ": "3", "SIMT_KERNEL_SPLIT": "4", "SIMT_MALLOC_FILL": "r7", "SIMT_BLOCK_ORDER": "reverse"}],
+                                 {"SIMT_STREAM_FUZZ": "3", "SIMT_KERNEL_SPLIT": "4", "SIMT_MALLOC_FILL": "r7", "SIMT_BLOCK_ORDER": "reverse"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "in-order")
 def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     """Three 9-frame batches, two in flight, through extract_batch_device / extract_batch_host (from 8 frames on a frame's workgroups
