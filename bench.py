@@ -7,9 +7,9 @@ A "step" = one pass of the hot path over one batch of synthetic frames of ONE ca
   euroc (default, the metric's configuration): 256 frames 752x480, nFeatures=1000 -- extract (pyramid, FAST, quad-tree,
         orientation, blur, rBRIEF) + frame-to-frame SearchByProjection (th=15, rotation check) between consecutive frames
         + D2H of keypoints, descriptors, counts and match indices into pinned host memory;
-  kitti (BASELINE config 3): 64 rectified stereo pairs 1241x376, nFeatures=2000 -- left + right extraction +
+  kitti (BASELINE config 3): 128 rectified stereo pairs 1241x376, nFeatures=2000 -- left + right extraction +
         Frame::ComputeStereoMatches (row-band Hamming, SAD sub-pixel, median rejection) on the device + D2H;
-  tumvi (BASELINE config 4): 64 frames 1024x1024, nFeatures=1500 -- extract + SearchByProjection(Frame, MapPoints) against
+  tumvi (BASELINE config 4): 128 frames 1024x1024, nFeatures=1500 -- extract + SearchByProjection(Frame, MapPoints) against
         10,000 map-point descriptors per frame (Tracking.cc:3390-3413) + D2H.
 `value` follows the bench contract: inputs are resident in HBM when the timed region starts.  The same run also measures the
 host-input rate (`pcie_inclusive`: frames start in pinned host memory, orbx_extract_batch_host uploads batch i+1 while batch
@@ -47,8 +47,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOADS = {
     # name: (width, height, nfeatures, default frames per step, lapping area)
     "euroc": (752, 480, 1000, 256, (0, 1000)),
-    "kitti": (1241, 376, 2000, 64, (0, 0)),
-    "tumvi": (1024, 1024, 1500, 64, (0, 1000)),
+    "kitti": (1241, 376, 2000, 128, (0, 0)),      # 128 pairs
+    "tumvi": (1024, 1024, 1500, 128, (0, 1000)),  # 128 frames
 }
 N_MAPPOINTS = 10000
 
@@ -319,16 +319,20 @@ class Rank:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dry = bool(os.environ.get("ORBX_BENCH_DRY"))   # launcher / sharding test on a box without GPUs: no device work
+        self.device = self.local_rank
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         if not self.dry:
             if not torch.cuda.is_available():
                 raise SystemExit("bench.py needs a GPU (liborbx has no CPU path)")
-            if torch.cuda.device_count() <= self.local_rank:
+            # --share-gpus: ranks beyond the visible GPUs wrap around (rank r on GPU r mod count) -- the real multi-rank path (gloo group, one
+            # extractor + streams per rank, barrier, gather, parity on every rank) exercised on a single-GPU box; not a scaling number
+            self.device = self.local_rank % torch.cuda.device_count() if args.share_gpus else self.local_rank
+            if torch.cuda.device_count() <= self.device:
                 raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
-            torch.cuda.set_device(self.local_rank)
-            self.numa = bind_to_gpu_numa_node(torch, self.local_rank)
+            torch.cuda.set_device(self.device)
+            self.numa = bind_to_gpu_numa_node(torch, self.device)
         self.group = None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -368,6 +372,14 @@ class Rank:
         dt_max, units_all, per = sharding.gather_throughput(dt, units)
         self.per_rank = [{"rank": r, "seconds": round(t, 6), "kfeatures_per_s": round(u / t / 1e3, 2) if t > 0 else None} for r, (t, u) in enumerate(per)]
         return dt_max, units_all
+
+    def gather_objects(self, obj):
+        """every rank's small python object (a parity verdict) on every rank, over the host group"""
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def finish(self, out):
         if self.rank == 0:
@@ -449,7 +461,7 @@ def bench_euroc(R):
     d_frames = torch.from_numpy(frames).cuda()                 # resident input of the contract's `value`
     torch.cuda.synchronize()
 
-    ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
+    ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.device)
     cap = ex.output_capacity(W, H)
 
     class HostSet:   # pinned host destinations (the Tracking thread's buffers)
@@ -506,10 +518,13 @@ def bench_euroc(R):
     dt_max, feats_all = R.reduce(dt, feats)
     per_rank = R.per_rank
 
-    # ---- parity of the delivered results (last timed step) against the CPU oracle, rank 0 ----
+    # ---- parity of the delivered results (last timed step) against the CPU oracle: EVERY rank checks its own sequence ----
     parity = None
-    if R.rank == 0 and a.verify > 0:
+    if a.verify > 0:
         parity = verify_euroc(frames, last, a.verify, W, H, NF, ex)
+    parity_all = R.gather_objects(parity)
+    for pr, pc in zip(per_rank, parity_all):
+        pr["parity_checked"] = pc
 
     # ---- the K timed steps again, `repeat` regions in all (each between its own barriers): spread of the number above ----
     regions = [(dt_max, feats_all)]
@@ -523,11 +538,16 @@ def bench_euroc(R):
     # ---- the same loop with the frames starting in pinned host memory (upload inside the timed region) ----
     dt_h, feats_h = timed(True)
     dt_h_max, feats_h_all = R.reduce(dt_h, feats_h)
-    if R.rank == 0 and a.verify > 0:
+    per_rank_host = R.per_rank
+    R.per_rank = per_rank     # `per_rank` of the line belongs to `value` (resident inputs); the host-input leg carries its own list
+    pcie_parity = None
+    if a.verify > 0:
         pcie_parity = verify_euroc(frames, host[(a.steps - 1) % 2], a.verify, W, H, NF, ex)   # the host-input path delivers the same results
+    for pr, pc in zip(per_rank_host, R.gather_objects(pcie_parity)):
+        pr["parity_checked"] = pc
     pcie = {"value": round(feats_h_all / dt_h_max / 1e3, 2), "unit": "kfeatures/s", "ms_per_step": round(dt_h_max / a.steps * 1e3, 3),
             "h2d_bytes_per_step": int(B * W * H), "h2d_GBs": round(B * W * H / (dt_h_max / a.steps) / 1e9, 1), "host_affinity": R.numa,
-            "parity_checked": pcie_parity if (R.rank == 0 and a.verify > 0) else None,
+            "parity_checked": pcie_parity, "per_rank": per_rank_host,
             "note": "frames in pinned host memory; orbx_extract_batch_host uploads batch i+1 on its own stream while batch i computes"}
 
     # ---- per-kernel timing with HIP events on the extractor's stream (separate, untimed, serialized passes) ----
@@ -562,7 +582,7 @@ def bench_euroc(R):
     # ---- single-frame latency of the drop-in call (Tracking calls operator() once per frame: Frame.cc:418-425, ORBextractor.cc:1086) ----
     latency = None
     if R.rank == 0 and a.latency > 0:
-        latency = latency_euroc(osa, frames, a.latency, W, H, NF, LAP, R.local_rank, cpu)
+        latency = latency_euroc(osa, frames, a.latency, W, H, NF, LAP, R.device, cpu)
 
     # ---- BASELINE configs 3 and 4 in the same line (1 GPU): child processes of this file, own parity checks, no CPU / PMC legs ----
     others = None
@@ -578,11 +598,14 @@ def bench_euroc(R):
     out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels,
                 "host_enqueue_ms_per_step": round(enqueue_ms, 3), "settle_ms_per_step": round(settle_ms, 3),
                 "repeats": repeats, "latency": latency, "other_workloads": others,
-                "value_pcie_inclusive": pcie["value"],
-                "metric_definition_note": "`value` = features delivered to pinned host memory per second with the input frames already resident in HBM "
-                                          "when the timed region starts (the bench contract); SURVEY.md 8(d)'s wall clock covering H2D of the images "
-                                          "... D2H of the results is `value_pcie_inclusive` (= pcie_inclusive.value: frames start in pinned host "
-                                          "memory, the upload of batch i+1 overlaps batch i; bound by the PCIe link, see pcie_inclusive.h2d_GBs)"})
+                "value_device_resident": round(feats_all / dt_max / 1e3, 2), "value_pcie_inclusive": pcie["value"],
+                "metric_definition_note": "TWO clocks, both in this line.  `value` (= value_device_resident) = features delivered to pinned host memory "
+                                          "per second with the input frames already resident in HBM when the timed region starts: the bench contract "
+                                          "of this build ('inputs already resident in HBM ... the PCIe-inclusive rate is never value').  SURVEY.md "
+                                          "8(d)'s wall clock covering H2D of the images, all kernels, D2H of the results is `value_pcie_inclusive` "
+                                          "(= pcie_inclusive.value: frames start in pinned host memory, the upload of batch i+1 overlaps batch i); it "
+                                          "is bound by the host link, not by the device (pcie_inclusive.h2d_GBs against ~55 GB/s of PCIe 5 x16), and "
+                                          "has its own per_rank list and parity check"})
     R.finish(out)
 
 
@@ -690,8 +713,8 @@ def bench_kitti(R):
     dl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
     dr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
     torch.cuda.synchronize()
-    exl = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
-    exr = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
+    exl = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.device)
+    exr = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.device)
     cap = exl.output_capacity(W, H)
     exr.output_capacity(W, H)
     bf, b = 0.53716 * 718.856, 0.53716
@@ -843,7 +866,7 @@ def bench_tumvi(R):
                            for t in range(B)])
     d_frames = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
-    ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.local_rank)
+    ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.device)
     cap = ex.output_capacity(W, H)
     # map points from the frames' own features (one untimed extraction), resident on the device like the local map's descriptors
     ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, LAP)
@@ -1030,7 +1053,7 @@ def main():
                          "command pools still growing), and with a short warm-up that start-up transient landed in the timed region "
                          "(TUM-VI workload, warm-up 3: 1.29-1.31 ms per step; warm-up 10: 1.07)")
     ap.add_argument("--settle-seconds", dest="settle_seconds", type=float, default=0.25, help="... and at least this long (see settle())")
-    ap.add_argument("--batch", type=int, default=0, help="frames (stereo pairs) per step per GPU; 0 = the workload's default (256 / 64 / 32)")
+    ap.add_argument("--batch", type=int, default=0, help="frames (stereo pairs) per step per GPU; 0 = the workload's default (256 / 128 / 128, SURVEY.md 8d)")
     ap.add_argument("--cpu-frames", type=int, default=384, help="frames in the CPU baseline sample (0 = skip); 384 = about 13 s of one core for euroc")
     ap.add_argument("--verify", type=int, default=4, help="parity of the last timed step against the CPU oracle on rank 0: >= 4 = every frame and every "
                                                           "match vector of the step (euroc), 1-3 = that many sampled pairs, 0 = skip")
@@ -1046,6 +1069,8 @@ def main():
     ap.add_argument("--retries", type=int, default=1, help="launcher: re-run the whole job this many times if a rank process dies (reported in the JSON)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="euroc",
                     help="euroc = BASELINE metric config; kitti = config 3 (stereo); tumvi = config 4 (map-point projection search)")
+    ap.add_argument("--share-gpus", dest="share_gpus", action="store_true",
+                    help="ranks beyond the visible GPUs share them (rank r on GPU r mod count): exercises the N-rank path on a box with fewer GPUs")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.other_workloads is None:

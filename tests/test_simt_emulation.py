@@ -29,7 +29,11 @@ from oracle import oracle_binding as ob
 
 @pytest.fixture(scope="module")
 def emul_lib():
-    r = subprocess.run([sys.executable, str(SIMT / "build.py")], capture_output=True, text=True, timeout=900)
+    import fcntl
+    (SIMT / "build").mkdir(exist_ok=True)
+    with open(SIMT / "build" / ".lock", "w") as lock:   # pytest-xdist workers would otherwise rebuild the same files side by side
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run([sys.executable, str(SIMT / "build.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return SIMT / "build" / "liborbx_emul.so"
 
