@@ -473,6 +473,9 @@ def bench_euroc(R):
             self.match = pinned(torch, (B, cap), torch.int32)
             self.nm = pinned(torch, (B,), torch.int32).zero_()
     host = [HostSet(), HostSet()]   # double-buffered: the D2H of step i overlaps the kernels of step i+1
+    ablate = set(filter(None, (a.ablate or "").split(",")))   # DIAGNOSTIC (--ablate): parts of the step left out; the line says so and is not a result
+    if ablate:
+        a.verify = 0
 
     def enqueue(i, from_host):
         hs = host[i % 2]
@@ -480,9 +483,13 @@ def bench_euroc(R):
             ex.extract_batch_host(h_frames.data_ptr(), B, W, H, W, W * H, LAP)
         else:
             ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, LAP)
-        ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
-        ex.download_async(hs.kps.data_ptr(), hs.desc.data_ptr(), hs.cnt.data_ptr(), hs.mono.data_ptr(),
-                          hs.match.data_ptr(), hs.nm.data_ptr())
+        if "nomatch" not in ablate:
+            ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+        if "nodl" in ablate:     # DIAGNOSTIC: only the counts travel (4 B per frame) -- what the D2H of keypoints / descriptors costs the step
+            ex.download_async(0, 0, hs.cnt.data_ptr(), hs.mono.data_ptr(), 0, 0)
+        else:
+            ex.download_async(hs.kps.data_ptr(), hs.desc.data_ptr(), hs.cnt.data_ptr(), hs.mono.data_ptr(),
+                              hs.match.data_ptr() if "nomatch" not in ablate else 0, hs.nm.data_ptr() if "nomatch" not in ablate else 0)
 
     def run(nsteps, from_host=False):
         """nsteps pipelined steps, two batches in flight; returns the number of features delivered to the host."""
@@ -595,6 +602,9 @@ def bench_euroc(R):
                      "frames_per_step_per_gpu": B, "sequences": R.world, "features_per_frame": round(feats / a.steps / B, 1),
                      "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{R.world} independent sequences, one per GPU"})
     out["data"] = data
+    if ablate:
+        out["ablation"] = sorted(ablate)
+        out["metric"] = "DIAGNOSTIC, NOT A RESULT (parts of the step left out: " + ",".join(sorted(ablate)) + "): " + out["metric"]
     out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels,
                 "host_enqueue_ms_per_step": round(enqueue_ms, 3), "settle_ms_per_step": round(settle_ms, 3),
                 "repeats": repeats, "latency": latency, "other_workloads": others,
@@ -1071,6 +1081,8 @@ def main():
                     help="euroc = BASELINE metric config; kitti = config 3 (stereo); tumvi = config 4 (map-point projection search)")
     ap.add_argument("--share-gpus", dest="share_gpus", action="store_true",
                     help="ranks beyond the visible GPUs share them (rank r on GPU r mod count): exercises the N-rank path on a box with fewer GPUs")
+    ap.add_argument("--ablate", default="", help="DIAGNOSTIC for the euroc workload: comma list of nodl (no D2H of keypoints / descriptors / matches), nomatch "
+                                                 "(no frame-to-frame matcher); the line is marked and no parity check runs")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.other_workloads is None:

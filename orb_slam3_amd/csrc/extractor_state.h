@@ -1,6 +1,5 @@
 // extractor_state.h -- host-side state of an extractor (shared by orbx_extractor.hip and orbx_matcher.hip).
 #pragma once
-#include <functional>
 
 #include <hip/hip_runtime.h>
 
@@ -30,7 +29,6 @@ void set_error(const std::string &s);
 // API so that its END (1) or its START (2) touches an unmapped address range, and it is filled with a poison byte: any kernel or copy
 // that runs past (before) the buffer, or indexes with a value it never wrote, faults deterministically instead of silently
 // touching a neighbouring allocation.
-int match_defer_mode();   // ORBX_MATCH_DEFER (orbx_extractor::deferred_match)
 int guard_mode();
 int guard_fill();   // ORBX_GUARD_FILL=<byte> (default 0xCB)
 // Optional roctx ranges around the host-side phases (the reference instruments the same two spots with its REGISTER_TIMES timers:
@@ -162,21 +160,6 @@ struct orbx_extractor {
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
     int blur_tile_start[orbx::kMaxLevels + 1] = {};  // blur tiles of level l: [start[l], start[l + 1])
     bool match_pending = false;
-    // ORBX_MATCH_DEFER=1|2: the frame-to-frame matcher of batch i and the copy of its match vectors are not issued when they are called but inside
-    // the NEXT orbx_extract_batch_*, and the match stream waits for an event of THAT batch (defer_gate): 1 = its pyramid (the matcher runs beside
-    // its FAST strips instead of beside its pyramid: gather kernels beside streaming kernels stretch both several times),
-    // 2 = its FAST strips (beside the list pass / quad-tree, where the vector units idle).  The host-side deferral alone would not move anything:
-    // in the pipelined loop the host runs far ahead of the device, only a device-side dependency places a kernel.
-    std::function<int()> deferred_match, deferred_copy_tail;
-    hipEvent_t ev_fast = nullptr;
-    hipEvent_t defer_gate = nullptr;   // event of the NEXT batch the deferred matcher waits for (nullptr: flushed from elsewhere, no gate)
-    int flush_deferred(hipEvent_t gate = nullptr) {
-        int r = ORBX_OK;
-        defer_gate = gate;
-        if (deferred_match) { auto f = std::move(deferred_match); deferred_match = nullptr; r = f(); if (r != ORBX_OK) return r; }
-        if (deferred_copy_tail) { auto f = std::move(deferred_copy_tail); deferred_copy_tail = nullptr; r = f(); }
-        return r;
-    }
     bool copy_covers_match = false;   // the most recent download waited for ev_match on the copy stream: its ev_copy_done implies the matcher is done
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream
     hipEvent_t ev_stereo_copy[2] = {nullptr, nullptr};   // ends of the last two orbx_stereo_batch_download_async

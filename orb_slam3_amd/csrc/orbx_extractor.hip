@@ -56,10 +56,6 @@ int guard_fill() {
     static const int m = [] { const char *v = getenv("ORBX_GUARD_FILL"); return v ? (atoi(v) & 0xff) : 0xCB; }();
     return m;
 }
-int match_defer_mode() {
-    static const int m = [] { const char *v = getenv("ORBX_MATCH_DEFER"); return v ? atoi(v) : 0; }();
-    return m;
-}
 int guard_mode() {
     static const int m = [] { const char *v = getenv("ORBX_GUARD"); return v ? atoi(v) : 0; }();
     return m;
@@ -85,7 +81,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (width > kMaxDim || height > kMaxDim) return ORBX_E_TOO_LARGE;
     const bool same_geom = (width == ex->width && height == ex->height);
     if (same_geom && batch <= ex->batch_cap) return ORBX_OK;
-    { int rf = ex->flush_deferred(); if (rf != ORBX_OK) return rf; }
     const int nl = ex->prm.nlevels;
     std::vector<LevelInfo> lv(nl);
     std::vector<ResizeTap> xtab, ytab;
@@ -434,7 +429,6 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     };
     ORBX_HIP(hipEventRecord(ex->ev_pyr, pst));                         // the pyramid of this batch is complete
     { int r = launch_blur(); if (r != ORBX_OK) return r; }
-    if (match_defer_mode() == 1) { int rf = ex->flush_deferred(ex->ev_pyr); if (rf != ORBX_OK) return rf; }   // the previous batch's matcher + match-vector copy: behind this pyramid
     {
         ProfScope ps(ex, K_FAST);
         // one score map at min(ini, min) serves both passes of :830-846; for ini < min the reference's second pass FAST(min) is a
@@ -453,11 +447,6 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                                (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
                                ini > mn ? 1 : 0, n);
             ORBX_HIP(hipGetLastError());   // e.g. an LDS budget the device refuses: fail here, not as silently missing candidates
-            if (match_defer_mode() == 2 && (ex->deferred_match || ex->deferred_copy_tail)) {   // the previous batch's matcher: behind these strips
-                ORBX_HIP(hipEventRecord(ex->ev_fast, st));
-                int rf = ex->flush_deferred(ex->ev_fast);
-                if (rf != ORBX_OK) return rf;
-            }
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
@@ -505,7 +494,6 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                                (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p, ex->max_pool);
         }
     }
-    { int rf = ex->flush_deferred(); if (rf != ORBX_OK) return rf; }   // whatever is still deferred (a FAST path without the mode-2 gate): k_finalize waits for it
     if (ex->copy_pending) {  // outputs of the previous batch may still be in flight to the host
         ORBX_HIP(hipStreamWaitEvent(st, ex->ev_copy_done[(ex->copy_issued - 1) & 1], 0));  // the most recent download
     }
@@ -654,7 +642,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     // 1.71, eight: 1.70; one extractor per process: no difference).  profiles/r03_l_kitti_stream_mapping.log, r03_n_ab_spare_streams.log
     (void)hipStreamCreateWithFlags(&ex->spare_stream, hipStreamNonBlocking);
     for (hipEvent_t *ev : {&ex->ev_in_free[0], &ex->ev_in_free[1], &ex->ev_in_ready[0], &ex->ev_in_ready[1]}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
-    for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match, &ex->ev_fast}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    for (hipEvent_t *ev : {&ex->ev_pyr, &ex->ev_blur, &ex->ev_describe, &ex->ev_match}) (void)hipEventCreateWithFlags(ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[0], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ex->ev_copy_done[1], hipEventDisableTiming);
     (void)hipHostMalloc((void **)&ex->h_err, 2 * sizeof(int32_t), hipHostMallocDefault);
@@ -687,14 +675,13 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
 
 void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
-    (void)ex->flush_deferred();
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->spare_stream})
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
     ex->d_in[0].release(); ex->d_in[1].release();
-    for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match, ex->ev_fast}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ex->ev_stereo_copy) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ex->ev_copy_done) if (ev) (void)hipEventDestroy(ev);
     if (ex->h_err) (void)hipHostFree(ex->h_err);
@@ -810,7 +797,6 @@ int orbx_output_capacity(orbx_extractor *ex, int width, int height) {
 int orbx_sync(orbx_extractor *ex) {
     if (!ex) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
-    { int rf = ex->flush_deferred(); if (rf != ORBX_OK) return rf; }
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     ORBX_HIP(hipStreamSynchronize(ex->aux_stream));
     ORBX_HIP(hipStreamSynchronize(ex->match_stream));
@@ -900,21 +886,16 @@ int orbx_batch_download_async(orbx_extractor *ex, orbx_keypoint *kps, uint8_t *d
     if (mono) ORBX_HIP(hipMemcpyAsync(mono, ex->d_mono.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     if (kps) ORBX_HIP(hipMemcpyAsync(kps, ex->d_kps.p, sizeof(orbx_keypoint) * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
     if (desc) ORBX_HIP(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)32 * ex->cap * n, hipMemcpyDeviceToHost, cs));
+    if (ex->match_pending) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
     ex->copy_covers_match = ex->match_pending;
+    if (match && ex->d_match.p) ORBX_HIP(hipMemcpyAsync(match, ex->d_match.p, 4 * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
+    if (nmatches && ex->d_nmatch.p) ORBX_HIP(hipMemcpyAsync(nmatches, ex->d_nmatch.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
     const unsigned slot = ex->copy_issued & 1;
-    const bool mp = ex->match_pending;
-    auto tail = [ex, cs, mp, match, nmatches, n, slot]() -> int {   // what has to wait for the matcher, and the end of this download
-        if (mp) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_match, 0));
-        if (match && ex->d_match.p) ORBX_HIP(hipMemcpyAsync(match, ex->d_match.p, 4 * (size_t)ex->cap * n, hipMemcpyDeviceToHost, cs));
-        if (nmatches && ex->d_nmatch.p) ORBX_HIP(hipMemcpyAsync(nmatches, ex->d_nmatch.p, 4 * (size_t)n, hipMemcpyDeviceToHost, cs));
-        ORBX_HIP(hipMemcpyAsync(ex->h_err + slot, ex->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, cs));
-        ORBX_HIP(hipEventRecord(ex->ev_copy_done[slot], cs));
-        return ORBX_OK;
-    };
+    ORBX_HIP(hipMemcpyAsync(ex->h_err + slot, ex->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, cs));
+    ORBX_HIP(hipEventRecord(ex->ev_copy_done[slot], cs));
     ex->copy_issued++;
     ex->copy_pending = true;
-    if (ex->deferred_match) { ex->deferred_copy_tail = tail; return ORBX_OK; }   // ORBX_MATCH_DEFER: issued with the matcher (flush_deferred)
-    return tail();
+    return ORBX_OK;
 }
 
 // Waits for the OLDEST download still in flight (at most two are).
@@ -922,7 +903,6 @@ int orbx_download_wait(orbx_extractor *ex) {
     if (!ex) return ORBX_E_BAD_ARG;
     if (ex->copy_issued == ex->copy_waited) return ORBX_OK;
     ORBX_HIP(hipSetDevice(ex->device));
-    if (ex->copy_issued - ex->copy_waited == 1) { int rf = ex->flush_deferred(); if (rf != ORBX_OK) return rf; }   // the download waited for is the deferred one
     const unsigned slot = ex->copy_waited & 1;
     ORBX_HIP(hipEventSynchronize(ex->ev_copy_done[slot]));
     ex->copy_waited++;

@@ -985,44 +985,33 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     g.minx = ex->bounds[0]; g.miny = ex->bounds[2];  // mnMinX.. of the extractor's camera (image rectangle without one, Frame.cc:804-807)
     g.inv_w = 64.0f / (ex->bounds[1] - ex->bounds[0]);   // Frame.cc:342-343
     g.inv_h = 48.0f / (ex->bounds[3] - ex->bounds[2]);
-    const bool defer_on = match_defer_mode() != 0;
-    auto issue = [ex, np, cap, g]() -> int {
-        // the matcher of batch i runs on its own stream beside the pyramid / FAST / quad-tree of batch i+1
-        const bool side = !ex->profile && ex->side_streams;
-        hipStream_t ms = side ? ex->match_stream : ex->stream;
-        if (side) ORBX_HIP(hipStreamWaitEvent(ms, ex->ev_describe, 0));
-        if (side && ex->defer_gate) ORBX_HIP(hipStreamWaitEvent(ms, ex->defer_gate, 0));   // deferred issue: an event of the NEXT batch
-        hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
-        if (ex->profile) (void)hipEventRecord(e0, ms);
-        ORBX_LAUNCH_GRID_BUILD( dim3(np), dim3(64), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
-        ORBX_LAUNCH_WINDOW_BEST2( dim3((cap + 15) / 16, np), dim3(256), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
-        if (ex->profile) {
-            (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
-            float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
-            ex->prof_ms[K_MATCH_SCAN] += t; ex->prof_n[K_MATCH_SCAN]++;
-            (void)hipEventRecord(e0, ms);
-        }
-        if (resolve_lds_bytes(cap) > 64 * 1024)
-            ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
-        hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mprobs.p,
-                           (const ResolveProblem *)ex->d_mres.p, g, cap);
-        if (ex->profile) {
-            (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
-            float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
-            ex->prof_ms[K_MATCH_RESOLVE] += t; ex->prof_n[K_MATCH_RESOLVE]++;
-        }
-        ORBX_HIP(hipEventRecord(ex->ev_match, ms));
-        ORBX_HIP(hipGetLastError());
-        return ORBX_OK;
-    };
-    ex->match_pending = true; ex->copy_covers_match = false;
-    if (defer_on && !ex->profile && ex->side_streams) {
-        int r2 = ex->flush_deferred();   // an older one first
-        if (r2 != ORBX_OK) return r2;
-        ex->deferred_match = issue;
-        return ORBX_OK;
+    // the matcher of batch i runs on its own stream beside the pyramid / FAST / quad-tree of batch i+1
+    const bool side = !ex->profile && ex->side_streams;
+    hipStream_t ms = side ? ex->match_stream : ex->stream;
+    if (side) ORBX_HIP(hipStreamWaitEvent(ms, ex->ev_describe, 0));
+    hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
+    if (ex->profile) (void)hipEventRecord(e0, ms);
+    ORBX_LAUNCH_GRID_BUILD( dim3(np), dim3(64), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
+    ORBX_LAUNCH_WINDOW_BEST2( dim3((cap + 15) / 16, np), dim3(256), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
+    if (ex->profile) {
+        (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
+        float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+        ex->prof_ms[K_MATCH_SCAN] += t; ex->prof_n[K_MATCH_SCAN]++;
+        (void)hipEventRecord(e0, ms);
     }
-    return issue();
+    if (resolve_lds_bytes(cap) > 64 * 1024)
+        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mprobs.p,
+                       (const ResolveProblem *)ex->d_mres.p, g, cap);
+    if (ex->profile) {
+        (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
+        float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+        ex->prof_ms[K_MATCH_RESOLVE] += t; ex->prof_n[K_MATCH_RESOLVE]++;
+    }
+    ORBX_HIP(hipEventRecord(ex->ev_match, ms));
+    ex->match_pending = true; ex->copy_covers_match = false;
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -124,12 +124,7 @@ _FULL = pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason
                                  pytest.param({"SIMT_STREAM_FUZZ": "7", "SIMT_MALLOC_FILL": "r3", "SIMT_BLOCK_ORDER": "11", "SIMT_LANE_ORDER": "3",
                                                "SIMT_LDS_RANDOM": "8"}, marks=_FULL),
                                  {"SIMT_STREAM_FUZZ": "5", "SIMT_MEMSET_ASYNC": "1", "SIMT_KERNEL_SPLIT": "6"},
-                                 {"SIMT_STREAM_FUZZ": "3", "SIMT_KERNEL_SPLIT": "4", "SIMT_MALLOC_FILL": "r7", "SIMT_BLOCK_ORDER": "reverse"},
-                                 # the matcher of batch i issued inside the next extract call, gated on that batch's pyramid (1) / FAST strips (2)
-                                 {"ORBX_MATCH_DEFER": "1", "SIMT_STREAM_FUZZ": "first", "SIMT_KERNEL_SPLIT": "3"},
-                                 {"ORBX_MATCH_DEFER": "1", "SIMT_STREAM_FUZZ": "last"},
-                                 {"ORBX_MATCH_DEFER": "2", "SIMT_STREAM_FUZZ": "first"},
-                                 {"ORBX_MATCH_DEFER": "2", "SIMT_STREAM_FUZZ": "9", "SIMT_KERNEL_SPLIT": "5", "SIMT_MEMSET_ASYNC": "1"}],
+                                 {"SIMT_STREAM_FUZZ": "3", "SIMT_KERNEL_SPLIT": "4", "SIMT_MALLOC_FILL": "r7", "SIMT_BLOCK_ORDER": "reverse"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "in-order")
 def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     """Three 9-frame batches, two in flight, through extract_batch_device / extract_batch_host (from 8 frames on a frame's workgroups

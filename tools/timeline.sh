@@ -3,7 +3,7 @@
 # duration, the busy union and the idle gaps of the main queue.  usage: bash tools/timeline.sh [ENV=VALUE ...]
 export TMPDIR=/tmp
 O=gpurun_out/tl; rm -rf $O; mkdir -p $O
-env WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 "$@" timeout 120 rocprofv3 --kernel-trace ${TL_COPIES:+--memory-copy-trace} -d $O -o s -- python bench.py --steps 8 --warmup 3 --settle 4 --cpu-frames 0 --no-profile --verify 0 --repeat 1 --latency 0 --no-pmc > $O/bench.json 2> $O/bench.err
+env WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 "$@" timeout 120 rocprofv3 --kernel-trace ${TL_COPIES:+--memory-copy-trace} -d $O -o s -- python bench.py --steps 8 --warmup 3 --settle 4 --settle-seconds 0 --cpu-frames 0 --no-profile --verify 0 --repeat 1 --latency 0 --no-pmc --no-other-workloads ${TL_ARGS:-} > $O/bench.json 2> $O/bench.err
 python3 - <<'PY'
 import sqlite3,glob,re
 db=sorted(glob.glob('gpurun_out/tl/**/*.db',recursive=True))[-1]
