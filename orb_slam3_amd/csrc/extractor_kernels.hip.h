@@ -1035,6 +1035,184 @@ __global__ __launch_bounds__(256) void k_blur_pk(const LevelInfo *__restrict__ l
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_blur_stream (round 4): the same filter as k_blur_pk, arithmetic unchanged, as a THROTTLED STREAM that shares the machine with the FAST strips
+// instead of fighting them for it.  k_fast_strip keeps 7 workgroups = 28 of a CU's 32 wave slots busy and is bound by VALU issue; the blur is bound
+// by HBM traffic and needs few instructions.  k_blur_pk beside it (one 256-thread workgroup per tile, 35 x 256 of them) either floods the wave slots or
+// starves behind the strips: together they took 404 us where 229 + 84 us of VALU issue and 1 GB of traffic would allow ~320 (profiles/r04_a_*).
+// Here a fixed number of single-wave workgroups (4 per CU: the slots the strips leave free) each walk through many strips back to back, with SIX source
+// rows in flight per wave (4.6 KB; 1024 waves x 4.6 KB / 2 us = 2.3 TB/s) and no bubble between strips: the row stream of a wave is continuous,
+// the loads of the next strip's first rows are issued while the current strip's last rows are filtered.
+//   item  = one 256-pixel x 42-row strip of a level (BlurItem, precomputed per geometry): 48 source rows = 8 groups of 6; group 0 only fills the
+//           vertical window (no output), groups 1..7 emit 6 rows each
+//   wave  = blockIdx.x: group x = blockIdx.x % nx takes the frames f = x (mod nx) (nx = 8: a frame's strips stay on the XCD whose L2 the FAST strips
+//           of the same frame fill -- speed only, nothing depends on it), wave k of the group takes the items k, k + K, ... of the group's
+//           frame-major item sequence: all waves of a group work on the same one or two frames at a time
+// No LDS, no barriers, no inter-workgroup dependency.  grid (waves), block 64
+// ---------------------------------------------------------------------------------------------------------
+struct BlurItem {         // four dwords, fetched with one scalar load (sub-dword fields would become vector loads the row stream has to wait for)
+    uint32_t src_off;    // byte offset inside a frame's pyramid slab of (level row y0 - 3, ROI column x0w): a ring row for y0 = 0
+    uint32_t dst_off;    // byte offset inside a frame's blur slab of (row y0, column x0w)
+    uint32_t pitches;    // pitch | bpitch << 16
+    uint32_t misc;       // rmax | rows_out << 16 | nlanes << 24: rmax = last source row that exists, counted from level row y0 - 3 (rows past it are
+                         // clamped, their results never stored); rows_out = min(42, h - y0); nlanes = lanes with pixels, ceil(min(256, w - x0w) / 4)
+    __host__ __device__ uint32_t pitch() const { return pitches & 0xffffu; }
+    __host__ __device__ uint32_t bpitch() const { return pitches >> 16; }
+    __host__ __device__ uint32_t rmax() const { return misc & 0xffffu; }
+    __host__ __device__ int rows_out() const { return (int)((misc >> 16) & 0xffu); }
+    __host__ __device__ int nlanes() const { return (int)(misc >> 24); }
+};
+static_assert(sizeof(BlurItem) == 16, "BlurItem layout");
+
+template <bool SAT>
+__global__ __launch_bounds__(64) void k_blur_stream(const BlurItem *__restrict__ items, int nitems, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+                                                    uint8_t *__restrict__ blur, size_t blur_frame_stride, int g0, int g1, int g2, int g3, int n_frames,
+                                                    int nx) {
+    const int lane = threadIdx.x;
+    const int x = (int)(blockIdx.x % (unsigned)nx), k = (int)(blockIdx.x / (unsigned)nx), K = (int)(gridDim.x / (unsigned)nx);
+    const int nfx = (n_frames - x + nx - 1) / nx;            // frames of this group: f = x + nx * fi
+    const int total = nfx * nitems;
+    if (k >= total) return;                                   // wave-uniform
+    const int nmine = (total - k + K - 1) / K;
+    auto tapd = [&](int d) -> uint32_t {
+        d = d < 0 ? -d : d;
+        return d == 0 ? (uint32_t)g3 : d == 1 ? (uint32_t)g2 : d == 2 ? (uint32_t)g1 : d == 3 ? (uint32_t)g0 : 0u;
+    };
+    uint32_t ht[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v |= tapd(4 * q + b - (j + 4)) << (8 * b);
+            ht[j][q] = v;
+        }
+    const u16x2 vp0 = as_pk((uint32_t)g0 | ((uint32_t)g1 << 16));   // rows r-6, r-5
+    const u16x2 vp1 = as_pk((uint32_t)g2 | ((uint32_t)g3 << 16));   // rows r-4, r-3
+    const u16x2 vp2 = as_pk((uint32_t)g2 | ((uint32_t)g1 << 16));   // rows r-2, r-1
+    auto hsum = [&](const BlurRaw &v, uint32_t h[4]) {
+        h[0] = __builtin_amdgcn_udot4(v.c, ht[0][1], __builtin_amdgcn_udot4(v.m, ht[0][0], 0u, false), false);
+        h[1] = __builtin_amdgcn_udot4(v.p, ht[1][2], __builtin_amdgcn_udot4(v.c, ht[1][1], __builtin_amdgcn_udot4(v.m, ht[1][0], 0u, false), false), false);
+        h[2] = __builtin_amdgcn_udot4(v.p, ht[2][2], __builtin_amdgcn_udot4(v.c, ht[2][1], __builtin_amdgcn_udot4(v.m, ht[2][0], 0u, false), false), false);
+        h[3] = __builtin_amdgcn_udot4(v.p, ht[3][2], __builtin_amdgcn_udot4(v.c, ht[3][1], 0u, false), false);
+    };
+    // cursor over this wave's items: (fi, it) of item number j is k + j * K in the group's frame-major sequence
+    auto advance = [&](int &fi, int &it) {
+        it += K;
+        while (it >= nitems) { it -= nitems; fi++; }
+    };
+    // r-th source row of the strip: ONE dword per lane (its own four pixels) + one for the two dwords beyond the wave's ends (lane 0: the dword to
+    // its left, lane 63: the dword to its right; the lanes between repeat their own: an L1 hit).  The neighbours' dwords of the 12-pixel window come
+    // from the neighbouring lanes (DPP wave_shr / wave_shl) when the row is filtered: a third of k_blur_pk's bytes through the texture path, and the
+    // rows in flight are single registers the register allocator can keep in place across the loop's back edge (as dwordx3 tuples they were copied
+    // there, behind a wait for every outstanding load).
+    // The loads are inline assembly and the waits are counted by hand (s_waitcnt vmcnt): left to the compiler, the row stream was drained at every loop
+    // header (it cannot bound the number of outstanding operations across the conditional stores).  A row = 2 loads; when row slot s of a group is
+    // consumed, the operations issued after its own loads are: 2 loads (+ 1 store) for each of the 5 other slots and the 2 loads just issued for its
+    // own slot = 12 loads (+ up to 6 stores): vmcnt(12) is exact without stores and waits for at most two rows more than necessary with them.
+    struct RowRegs { uint32_t c, e; };
+    auto load_row = [&](const BlurItem &D, const uint8_t *src, int r, uint32_t lofs, uint32_t eofs) -> RowRegs {
+        const uint32_t rel = min((uint32_t)r, D.rmax());
+        const uint8_t *row = src + (size_t)(rel * D.pitch()) - 4;   // wave-uniform (SGPR base); the lane offsets below are >= 0
+        RowRegs v;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(v.c) : "v"(lofs), "s"(row) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(v.e) : "v"(eofs), "s"(row) : "memory");
+        return v;
+    };
+    auto wait_row = [&](RowRegs &v) { asm volatile("s_waitcnt vmcnt(12)" : "+v"(v.c), "+v"(v.e)); };
+    auto window = [&](const RowRegs &v) -> BlurRaw {
+        BlurRaw w;
+        w.c = v.c;
+        w.m = (uint32_t)__builtin_amdgcn_update_dpp((int)v.e, (int)v.c, 0x138, 0xf, 0xf, false);   // wave_shr:1: lane i <- lane i - 1, lane 0 keeps e
+        w.p = (uint32_t)__builtin_amdgcn_update_dpp((int)v.e, (int)v.c, 0x130, 0xf, 0xf, false);   // wave_shl:1: lane i <- lane i + 1, lane 63 keeps e
+        return w;
+    };
+    // a lane past the level's width loads the dword right of the last lane with pixels (ring bytes its neighbour's window needs), then repeats it
+    auto lane_ofs = [&](const BlurItem &D, uint32_t &lofs, uint32_t &eofs) {
+        lofs = (uint32_t)min(lane, D.nlanes()) * 4u + 4u;   // + 4: the row base points one dword left of the strip
+        eofs = lane == 0 ? 0u : lane == 63 ? 260u : lofs;
+    };
+    int fi = 0, it = k;
+    while (it >= nitems) { it -= nitems; fi++; }
+    BlurItem Dc = items[__builtin_amdgcn_readfirstlane(it)];   // wave-uniform index, dword fields: one scalar load
+    const uint8_t *srcc = pyr + (size_t)(x + nx * fi) * pyr_frame_stride + Dc.src_off;
+    uint8_t *dstc = blur + (size_t)(x + nx * fi) * blur_frame_stride + Dc.dst_off;
+    uint32_t lofc, eofc;
+    lane_ofs(Dc, lofc, eofc);
+    // Two sets of six row slots, used alternately (group g reads set g & 1 and requests the rows of group g + 1 into the other set): with ONE set
+    // the loop-carried copies at the back edge made the compiler wait for every outstanding load once per group -- no rows in flight across groups.
+    RowRegs rawA[6], rawB[6];
+#pragma unroll
+    for (int s = 0; s < 6; s++) rawA[s] = load_row(Dc, srcc, s, lofc, eofc);
+    uint32_t pr[6][4];   // pr[q % 6] = (sums of row q-1) | (sums of row q) << 16
+    uint32_t hprev[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int s = 0; s < 6; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) pr[s][j] = 0u;
+    for (int jm = 0; jm < nmine; jm++) {
+        // the item after this one (its descriptor is needed when group 7 prefetches): fetched now, a whole strip ahead of its use
+        int fin = fi, itn = it;
+        const bool have_next = jm + 1 < nmine;
+        if (have_next) advance(fin, itn);
+        const BlurItem Dn = items[__builtin_amdgcn_readfirstlane(itn)];
+        const uint8_t *srcn = pyr + (size_t)(x + nx * fin) * pyr_frame_stride + Dn.src_off;
+        uint32_t lofn, eofn;
+        lane_ofs(Dn, lofn, eofn);
+        const bool live = lane < Dc.nlanes();
+        // one group of six rows: filter the rows in `cons`, request the rows of the next group into `prod`
+        auto group = [&](RowRegs (&cons)[6], RowRegs (&prod)[6], const int ph) {
+            // rows of the NEXT group: group ph + 1 of this strip, or group 0 of the next strip (at the very end of the stream: six more rows of
+            // this strip, clamped to its last row and never used)
+            const bool wrap = ph == 7 && have_next;
+            const BlurItem &Dl = wrap ? Dn : Dc;
+            const uint8_t *srcl = wrap ? srcn : srcc;
+            const uint32_t lofl = wrap ? lofn : lofc, eofl = wrap ? eofn : eofc;
+            const int rl = wrap ? 0 : 6 * (ph + 1);
+#pragma unroll
+            for (int s = 0; s < 6; s++) {
+                prod[s] = load_row(Dl, srcl, rl + s, lofl, eofl);
+                wait_row(cons[s]);
+                uint32_t h[4];
+                hsum(window(cons[s]), h);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    pr[s][j] = hprev[j] | (h[j] << 16);
+                    hprev[j] = h[j];
+                }
+                if (ph > 0) {   // wave-uniform: group 0 only fills the window
+                    const int yo = 6 * ph + s - 6;
+                    uint32_t sum[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t a = __umul24(h[j], (uint32_t)g0) + 32768u;                        // row r
+                        a = __builtin_amdgcn_udot2(as_pk(pr[(s + 5) % 6][j]), vp2, a, false);      // rows r-2, r-1
+                        a = __builtin_amdgcn_udot2(as_pk(pr[(s + 3) % 6][j]), vp1, a, false);      // rows r-4, r-3
+                        a = __builtin_amdgcn_udot2(as_pk(pr[(s + 1) % 6][j]), vp0, a, false);      // rows r-6, r-5
+                        sum[j] = SAT ? min(a, 0x00ffffffu) : a;
+                    }
+                    if (live && yo < Dc.rows_out()) {
+                        const uint32_t lo = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u);    // byte 2 of sum[0], byte 2 of sum[1]
+                        const uint32_t hi = __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);
+                        *reinterpret_cast<uint32_t *>(dstc + (size_t)((uint32_t)yo * Dc.bpitch()) + 4u * (uint32_t)lane) = lo | hi;
+                    }
+                }
+            }
+        };
+#pragma unroll 1
+        for (int ph = 0; ph < 8; ph += 2) {
+            group(rawA, rawB, ph);
+            group(rawB, rawA, ph + 1);
+        }
+        // next strip
+        fi = fin; it = itn;
+        Dc = Dn; srcc = srcn; lofc = lofn; eofc = eofn;
+        dstc = blur + (size_t)(x + nx * fi) * blur_frame_stride + Dc.dst_off;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the six rows requested beyond the end of the stream
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // glibc 2.35 sinf / cosf ("fma" ifunc variant: every multiply-add of the double polynomial fused), restated
 // for |x| < 120; bit-identical to the x86-64 libm the reference links against (validated exhaustively on the
 // CPU oracle, which uses the same formulation).  Tables: __sincosf_table.

@@ -124,9 +124,9 @@ struct orbx_extractor {
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
     bool fast_wave = true;      // every level's cell fits k_fast_wave's fixed LDS pitch
-    int n_fast_tiles = 0, n_blur_tiles = 0;
+    int n_fast_tiles = 0, n_blur_tiles = 0, n_blur_items = 0;
     // device memory
-    DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_tiles, d_dc;
+    DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_tiles, d_blur_items, d_dc;
     // Stereo rig (orbx_stereo_batch_device): the SAD stage reads both extractors' pyramids on the match stream while the NEXT pair of batches is
     // extracted, so an extractor that has been part of a rig alternates between two pyramid slabs (allocated at the first stereo call)
     DevBuf d_pyr2;

@@ -22,6 +22,10 @@ REWRITES = [
     (re.compile(r'asm\("v_pk_minimum3_f16 %0, %1, %2, %3"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);'), r"\1 = simt_pk_min3_u16(\2, \3, \4);"),
     (re.compile(r'asm\("v_pk_maximum3_f16 %0, %1, %2, %3"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);'), r"\1 = simt_pk_max3_u16(\2, \3, \4);"),
     (re.compile(r'asm volatile\(""\s*::[^;]*\);'), ";"),
+    # k_blur_stream: hand-issued loads (SGPR base + 32-bit lane offset) and hand-counted waits
+    (re.compile(r'asm volatile\("global_load_dword %0, %1, %2"\s*:\s*"=v"\(([\w.]+)\)\s*:\s*"v"\((\w+)\),\s*"s"\((\w+)\)\s*:\s*"memory"\);'),
+     r"\1 = *reinterpret_cast<const uint32_t *>(\3 + \2);"),
+    (re.compile(r'asm volatile\("s_waitcnt vmcnt\(\d+\)"\s*:[^;]*\);'), ";"),
     # k_describe stores row 31 of the orientation patch into what becomes row 0 of the BRIEF patch and relies on the wave's LDS
     # instructions executing in program order ACROSS lanes (lock step); the emulator's lanes are not in lock step: order the two phases
     (re.compile(r"(\n\s*)if \(c < 10\) \{(\s*)uint8_t \*d = Bp \+"), r"\1__builtin_amdgcn_wave_barrier();\1if (c < 10) {\2uint8_t *d = Bp +"),

@@ -306,7 +306,7 @@ inline int __builtin_amdgcn_readlane(int v, int l) {
 // v_readfirstlane_b32: the kernels use it on values that ARE wave-uniform (to tell the compiler so), also under partial EXEC masks
 // (inside helpers some lanes have left) -- a collective would not be reached by every live lane, and the value is the lane's own anyway
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
-// v_mov_b32_dpp as used here: row_shr:n (0x111..0x11f), row_ror:n (0x121..0x12f), wave_shr:1 (0x138), row_bcast15 (0x142), row_bcast31 (0x143);
+// v_mov_b32_dpp as used here: row_shr:n (0x111..0x11f), row_ror:n (0x121..0x12f), wave_shr:1 (0x138), wave_shl:1 (0x130), row_bcast15 (0x142), row_bcast31 (0x143);
 // bank_mask 0xf, bound_ctrl off: a lane without a valid source, or in a row the row mask disables, keeps `old`
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     (void)bank_mask; (void)bound_ctrl;
@@ -317,6 +317,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (li >= n) from = lane - n; }
     else if (ctrl >= 0x121 && ctrl <= 0x12f) { const int n = ctrl - 0x120; from = 16 * row + ((li - n) & 15); }   // row_ror:n
     else if (ctrl == 0x138) { if (lane >= 1) from = lane - 1; }
+    else if (ctrl == 0x130) { if (lane <= 62) from = lane + 1; }   // wave_shl:1
     else if (ctrl == 0x142) { if (row >= 1) from = 16 * row - 1; }
     else if (ctrl == 0x143) { if (row >= 2) from = 31; }
     else { fprintf(stderr, "simt: DPP control 0x%x not emulated\n", ctrl); abort(); }
