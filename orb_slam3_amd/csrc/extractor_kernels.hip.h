@@ -9,7 +9,7 @@
 //   k_octree_par_t (octree_par.hip.h; its first tier gathers the keys: compact_level)  DistributeOctTree / DivideNode / compareNodes   :480-779
 //                     (k_octree in octree.hip.h = sequential emulation for node pools beyond the LDS budget)
 //   k_finalize        level concatenation + lapping split slots                :1117-1162
-//   k_blur_pk         GaussianBlur 7x7 sigma 2 (fixed point)                   :1132-1133
+//   k_blur_stream     GaussianBlur 7x7 sigma 2 (fixed point)                   :1132-1133
 //   k_describe        IC_Angle + computeOrbDescriptor + keypoint record        :76-146, 1143-1162
 //
 // Integer pixel / bit work: no MFMA.  Built with -ffp-contract=off; the only fused float ops are the explicit
@@ -908,147 +908,39 @@ __global__ __launch_bounds__(256) void k_finalize(const LevelInfo *__restrict__ 
 // The reference blurs a ring-less clone with BORDER_REFLECT_101 (:1132-1133); the padded pyramid level already
 // carries exactly that reflection in its 19-px ring, so the kernel reads the ring and needs no border logic.
 //
-// Register-marching separable filter, no LDS, no barriers: a lane owns a 4-pixel-wide column strip and walks down
-// kBlurRows output rows.  Per source row it loads three aligned dwords (12 px), forms the four horizontal sums with
-// v_alignbyte + v_dot4_u32_u8 (taps packed as bytes), keeps the last seven rows of sums in registers (rotation
-// resolved at compile time by unrolling 7x) and emits one packed dword of vertical results per row.
-// A wave covers 256 x kBlurRows pixels with fully coalesced 256-B row loads/stores; a workgroup = 4 row blocks.
-// grid (n_blur_tiles, B), block 256
+// k_blur_stream (round 4; replaces k_blur_pk, whose arithmetic it keeps): a register-marching separable filter, no LDS, no barriers.  A lane owns a
+// 4-pixel-wide column and walks down the rows of a strip (256 pixels x 42 rows):
+//   * horizontal pass without byte alignment: the window of pixel x0 + j is three (j = 1, 2) or two (j = 0, 3) v_dot4_u32_u8 of the ALIGNED dwords
+//     (left neighbour's, own, right neighbour's) against tap dwords shifted instead of the data;
+//   * vertical pass on PAIRS of consecutive rows of horizontal sums packed 2 x u16 (a sum is at most 255 * 257): per output pixel three
+//     v_dot2_u32_u16 + one v_mad_u32_u24 with the rounding constant as the addend; one v_lshl_or per pixel and row builds the pair (rows r-1, r), a
+//     ring of six pair slots (rotation resolved at compile time: the row loop is unrolled by six) serves rows r-5, r-3, r-1;
+//   * the result byte is bits 16..23 of the sum: with taps summing to 256 it cannot exceed 255 (SAT = false: no clamp); taps summing to 257 (the
+//     OpenCV <= 4.5.0 table) clamp the sum first (SAT = true).
+// What is new against k_blur_pk (one 256-thread workgroup per tile, one row requested ahead, three dwords per lane and row):
+//   * a fixed number of single-wave workgroups, each walking through MANY strips back to back as one continuous row stream: SIX source rows in
+//     flight per wave, the first rows of the next strip requested while the last rows of the current one are filtered (no bubble between strips).
+//     The loads are inline assembly and the waits counted by hand (see load_row): left to the compiler the stream was drained at every loop header;
+//   * ONE dword per lane and row (+ one for the two dwords beyond the wave's ends); the neighbours' dwords come from the neighbouring lanes
+//     (DPP wave_shr / wave_shl): a third of the bytes through the texture path;
+//   * item = strip (BlurItem, precomputed per geometry): 48 source rows = 8 groups of 6; group 0 only fills the vertical window, groups 1..7 emit;
+//   * wave = blockIdx.x: group x = blockIdx.x % nx takes the frames f = x (mod nx) (nx = 8: a frame's strips stay on the XCD whose L2 the FAST strips
+//     of the same frame fill -- speed only, nothing depends on it), wave k of the group takes the items k, k + K, ... of the group's frame-major
+//     item sequence: all waves of a group work on the same one or two frames at a time.
+// The idea was a blur THROTTLED to the four wave slots per CU that k_fast_strip (7 workgroups = 28 of 32 slots, VALU bound) leaves free, so that the
+// two overlap instead of fighting for slots.  Measured (profiles/r04_c_*): the strips take 404 us beside either form of the blur (272 us alone) --
+// what stretches them is the memory system under the blur's traffic, not the wave slots -- and 1024 waves (4 per CU) are too few for the blur itself
+// (300 us alone; 512: 454, 2048: 207, 4096: 175 = k_blur_pk).  What it does buy, at 2048 waves: EuRoC step 1.12 -> 1.09 ms, KITTI 1.51 -> 1.47,
+// TUM-VI 1.61 -> 1.62.
+// No inter-workgroup dependency.  grid (waves), block 64
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kBlurTW = 256;            // pixels per wave row
-constexpr int kBlurRows = 42;           // output rows per wave (6 prologue rows + 6 x 7 main-loop rows)
-constexpr int kBlurTH = 4 * kBlurRows;  // rows per workgroup
+constexpr int kBlurTW = 256;            // pixels per strip row
+constexpr int kBlurRows = 42;           // output rows per strip (6 rows that fill the window + 6 x 7 rows that emit)
 
-// ---------------------------------------------------------------------------------------------------------
-// k_blur_pk: the same filter with half the VALU work per row and L2-local tiles (round 2; the round-1 form -- v_alignbyte windows, 66 VALU per row -- is gone).
-//   * horizontal pass without byte alignment: the window of pixel x0+j is three (j = 1, 2) or two (j = 0, 3) v_dot4_u32_u8 of the
-//     ALIGNED dwords against tap dwords shifted instead of the data (10 instead of 6 v_alignbyte + 8 v_dot4);
-//   * vertical pass on PAIRS of consecutive rows of horizontal sums packed as 2 x u16 (a sum is at most 255 * 257): per output
-//     pixel three v_dot2_u32_u16 + one v_mad_u32_u24 with the rounding constant as the addend, instead of 3 adds + 4 multiplies +
-//     2 three-input adds; one v_lshl_or per pixel and row builds the pair (rows r-1, r), a ring of six pair slots serves
-//     rows r-5, r-3, r-1;
-//   * the result byte is bits 16..23 of the sum: with taps summing to 256 it cannot exceed 255 (SAT = false: no clamp), three
-//     v_perm_b32 / v_or gather the four bytes; taps summing to 257 (the OpenCV <= 4.5.0 table) clamp the sum first (SAT = true);
-//   * wave-uniform row pointers (the wave index through readfirstlane): row addresses are SALU work, loads and stores take the
-//     SGPR-base form; the next source row is requested before the current one is filtered;
-//   * grid (8, tiles, frames / 8): all tiles of a frame run on one XCD, so the 128-byte lines two neighbouring tiles share (tile
-//     rows start 4 bytes before a 256-byte boundary) and the six halo rows hit that XCD's L2.
-// 33 instead of 66 VALU instructions per row of four pixels.  grid xcd_grid(n_blur_tiles, B), block 256
-// ---------------------------------------------------------------------------------------------------------
 struct BlurRaw {
     uint32_t m, c, p;  // pixels x0-4 .. x0-1, x0 .. x0+3, x0+4 .. x0+7
 };
 
-template <bool SAT>
-__global__ __launch_bounds__(256) void k_blur_pk(const LevelInfo *__restrict__ lv, const TileRef *__restrict__ tiles,
-                                                 const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                 uint8_t *__restrict__ blur, size_t blur_frame_stride, int g0, int g1,
-                                                 int g2, int g3, int n_frames) {
-    int bx, f;
-    if (!xcd_frame_map(n_frames, &bx, &f)) return;
-    const TileRef t = tiles[bx];
-    const LevelInfo L = lv[t.level];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0w = t.tj * kBlurTW;                 // first pixel of the wave's strip
-    const int y0 = (t.ti * 4 + wv) * kBlurRows;     // first output row of the wave's strip
-    if (y0 >= L.h) return;                          // wave-uniform
-    if (x0w + lane * 4 >= L.w) return;
-    // tap of the pixel at distance d from the window centre; taps of the three aligned dwords for window centre x0 + j
-    auto tapd = [&](int d) -> uint32_t {
-        d = d < 0 ? -d : d;
-        return d == 0 ? (uint32_t)g3 : d == 1 ? (uint32_t)g2 : d == 2 ? (uint32_t)g1 : d == 3 ? (uint32_t)g0 : 0u;
-    };
-    uint32_t ht[4][3];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) v |= tapd(4 * k + b - (j + 4)) << (8 * b);
-            ht[j][k] = v;
-        }
-    const u16x2 vp0 = as_pk((uint32_t)g0 | ((uint32_t)g1 << 16));   // rows r-6, r-5
-    const u16x2 vp1 = as_pk((uint32_t)g2 | ((uint32_t)g3 << 16));   // rows r-4, r-3
-    const u16x2 vp2 = as_pk((uint32_t)g2 | ((uint32_t)g1 << 16));   // rows r-2, r-1
-    const uint8_t *roi = pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)kEdge * L.pitch + kRoiX + x0w;   // wave-uniform
-    uint8_t *dst = blur + (size_t)f * blur_frame_stride + L.boff + x0w;                                         // wave-uniform
-    const uint32_t lofs = (uint32_t)lane * 4u;
-    const int ymax = L.h + kEdge - 1;  // last ring row that exists
-    const uint8_t *roi3 = roi - 3 * (ptrdiff_t)L.pitch;   // level row -3 (a ring row)
-    auto load_row = [&](int r) -> BlurRaw {  // r-th source row of the strip: level row y0 - 3 + r (>= -3: those ring rows exist)
-        const uint32_t y3 = (uint32_t)min(y0 + r, ymax + 3);                                    // row index counted from level row -3
-        const uint8_t *rowp = roi3 + (size_t)(y3 * (uint32_t)L.pitch);                          // wave-uniform: SALU
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(rowp + lofs);
-        BlurRaw v;
-        v.m = p[-1]; v.c = p[0]; v.p = p[1];
-        return v;
-    };
-    auto hsum = [&](const BlurRaw &v, uint32_t h[4]) {
-        h[0] = __builtin_amdgcn_udot4(v.c, ht[0][1], __builtin_amdgcn_udot4(v.m, ht[0][0], 0u, false), false);
-        h[1] = __builtin_amdgcn_udot4(v.p, ht[1][2], __builtin_amdgcn_udot4(v.c, ht[1][1], __builtin_amdgcn_udot4(v.m, ht[1][0], 0u, false), false), false);
-        h[2] = __builtin_amdgcn_udot4(v.p, ht[2][2], __builtin_amdgcn_udot4(v.c, ht[2][1], __builtin_amdgcn_udot4(v.m, ht[2][0], 0u, false), false), false);
-        h[3] = __builtin_amdgcn_udot4(v.p, ht[3][2], __builtin_amdgcn_udot4(v.c, ht[3][1], 0u, false), false);
-    };
-    uint32_t pr[6][4];   // pr[q % 6] = (sums of row q-1) | (sums of row q) << 16
-    uint32_t hprev[4];
-    BlurRaw cur = load_row(0);
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-        const BlurRaw nxt = load_row(r + 1);
-        uint32_t h[4];
-        hsum(cur, h);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (r > 0) pr[r][j] = hprev[j] | (h[j] << 16);
-            hprev[j] = h[j];
-        }
-        cur = nxt;
-    }
-    for (int gidx = 0; gidx < kBlurRows / 6; gidx++) {
-        const int rbase = 6 + gidx * 6;
-        if (y0 + rbase - 6 >= L.h) break;
-#pragma unroll
-        for (int s = 0; s < 6; s++) {
-            const int r = rbase + s, yo = y0 + r - 6;
-            const BlurRaw nxt = load_row(r + 1);   // one row beyond the strip at the very end: clamped to an existing row, unused
-            uint32_t h[4], sum[4];
-            hsum(cur, h);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                pr[s][j] = hprev[j] | (h[j] << 16);
-                hprev[j] = h[j];
-                uint32_t a = __umul24(h[j], (uint32_t)g0) + 32768u;                        // row r
-                a = __builtin_amdgcn_udot2(as_pk(pr[(s + 5) % 6][j]), vp2, a, false);      // rows r-2, r-1
-                a = __builtin_amdgcn_udot2(as_pk(pr[(s + 3) % 6][j]), vp1, a, false);      // rows r-4, r-3
-                a = __builtin_amdgcn_udot2(as_pk(pr[(s + 1) % 6][j]), vp0, a, false);      // rows r-6, r-5
-                sum[j] = SAT ? min(a, 0x00ffffffu) : a;
-            }
-            if (yo < L.h) {
-                const uint32_t lo = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u);    // byte 2 of sum[0], byte 2 of sum[1]
-                const uint32_t hi = __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);
-                *reinterpret_cast<uint32_t *>(dst + (size_t)((uint32_t)yo * (uint32_t)L.bpitch) + lofs) = lo | hi;
-            }
-            cur = nxt;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_blur_stream (round 4): the same filter as k_blur_pk, arithmetic unchanged, as a THROTTLED STREAM that shares the machine with the FAST strips
-// instead of fighting them for it.  k_fast_strip keeps 7 workgroups = 28 of a CU's 32 wave slots busy and is bound by VALU issue; the blur is bound
-// by HBM traffic and needs few instructions.  k_blur_pk beside it (one 256-thread workgroup per tile, 35 x 256 of them) either floods the wave slots or
-// starves behind the strips: together they took 404 us where 229 + 84 us of VALU issue and 1 GB of traffic would allow ~320 (profiles/r04_a_*).
-// Here a fixed number of single-wave workgroups (4 per CU: the slots the strips leave free) each walk through many strips back to back, with SIX source
-// rows in flight per wave (4.6 KB; 1024 waves x 4.6 KB / 2 us = 2.3 TB/s) and no bubble between strips: the row stream of a wave is continuous,
-// the loads of the next strip's first rows are issued while the current strip's last rows are filtered.
-//   item  = one 256-pixel x 42-row strip of a level (BlurItem, precomputed per geometry): 48 source rows = 8 groups of 6; group 0 only fills the
-//           vertical window (no output), groups 1..7 emit 6 rows each
-//   wave  = blockIdx.x: group x = blockIdx.x % nx takes the frames f = x (mod nx) (nx = 8: a frame's strips stay on the XCD whose L2 the FAST strips
-//           of the same frame fill -- speed only, nothing depends on it), wave k of the group takes the items k, k + K, ... of the group's
-//           frame-major item sequence: all waves of a group work on the same one or two frames at a time
-// No LDS, no barriers, no inter-workgroup dependency.  grid (waves), block 64
-// ---------------------------------------------------------------------------------------------------------
 struct BlurItem {         // four dwords, fetched with one scalar load (sub-dword fields would become vector loads the row stream has to wait for)
     uint32_t src_off;    // byte offset inside a frame's pyramid slab of (level row y0 - 3, ROI column x0w): a ring row for y0 = 0
     uint32_t dst_off;    // byte offset inside a frame's blur slab of (row y0, column x0w)
@@ -1103,7 +995,7 @@ __global__ __launch_bounds__(64) void k_blur_stream(const BlurItem *__restrict__
     };
     // r-th source row of the strip: ONE dword per lane (its own four pixels) + one for the two dwords beyond the wave's ends (lane 0: the dword to
     // its left, lane 63: the dword to its right; the lanes between repeat their own: an L1 hit).  The neighbours' dwords of the 12-pixel window come
-    // from the neighbouring lanes (DPP wave_shr / wave_shl) when the row is filtered: a third of k_blur_pk's bytes through the texture path, and the
+    // from the neighbouring lanes (DPP wave_shr / wave_shl) when the row is filtered: a third of the bytes of three dwords per lane through the texture path, and the
     // rows in flight are single registers the register allocator can keep in place across the loop's back edge (as dwordx3 tuples they were copied
     // there, behind a wait for every outstanding load).
     // The loads are inline assembly and the waits are counted by hand (s_waitcnt vmcnt): left to the compiler, the row stream was drained at every loop

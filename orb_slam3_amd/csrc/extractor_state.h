@@ -124,9 +124,10 @@ struct orbx_extractor {
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
     bool fast_wave = true;      // every level's cell fits k_fast_wave's fixed LDS pitch
-    int n_fast_tiles = 0, n_blur_tiles = 0, n_blur_items = 0;
+    int n_fast_tiles = 0, n_blur_items = 0;
+    int blur_waves = 2048;      // single-wave workgroups of k_blur_stream (measured: 512 / 1024 / 2048 / 4096 -> EuRoC step 1.25 / 1.115 / 1.09 / 1.10 ms)
     // device memory
-    DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_tiles, d_blur_items, d_dc;
+    DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_items, d_dc;
     // Stereo rig (orbx_stereo_batch_device): the SAD stage reads both extractors' pyramids on the match stream while the NEXT pair of batches is
     // extracted, so an extractor that has been part of a rig alternates between two pyramid slabs (allocated at the first stereo call)
     DevBuf d_pyr2;
@@ -158,7 +159,6 @@ struct orbx_extractor {
     bool in_used[2] = {false, false};
     unsigned in_issued = 0;
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
-    int blur_tile_start[orbx::kMaxLevels + 1] = {};  // blur tiles of level l: [start[l], start[l + 1])
     bool match_pending = false;
     bool copy_covers_match = false;   // the most recent download waited for ev_match on the copy stream: its ev_copy_done implies the matcher is done
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream

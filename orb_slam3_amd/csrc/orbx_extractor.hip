@@ -85,7 +85,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     std::vector<LevelInfo> lv(nl);
     std::vector<ResizeTap> xtab, ytab;
     std::vector<ResizeGroup> xgtab;
-    std::vector<TileRef> fast_tiles, blur_tiles;
+    std::vector<TileRef> fast_tiles;
     std::vector<BlurItem> blur_items;
     std::vector<StripTile> strips;
     std::vector<int> strip_level_rows;
@@ -196,11 +196,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
                 fast_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
             }
         strip_level_rows.push_back(std::min(L.hCell, L.h - 2 * kBorder - 6) + 6);   // tile rows of this level's strips (fast_strip.hip.h)
-        ex->blur_tile_start[l] = (int)blur_tiles.size();
-        for (int i = 0; i < (L.h + kBlurTH - 1) / kBlurTH; i++)
-            for (int j = 0; j < (L.w + kBlurTW - 1) / kBlurTW; j++)
-                blur_tiles.push_back(TileRef{(int16_t)l, (int16_t)i, (int16_t)j, 0});
-        ex->blur_tile_start[l + 1] = (int)blur_tiles.size();
         for (int y0 = 0; y0 < L.h; y0 += kBlurRows)            // k_blur_stream: one item per 256-pixel x 42-row strip
             for (int x0 = 0; x0 < L.w; x0 += kBlurTW) {
                 BlurItem bi;
@@ -237,7 +232,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_ytab, sizeof(ResizeTap) * std::max<size_t>(ytab.size(), 1));
     ENS(ex->d_xgtab, sizeof(ResizeGroup) * std::max<size_t>(xgtab.size(), 1));
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
-    ENS(ex->d_blur_tiles, sizeof(TileRef) * blur_tiles.size());
     ENS(ex->d_blur_items, sizeof(BlurItem) * blur_items.size());
     ENS(ex->d_pyr, pyr_off * B);
     if (ex->pyr_double) ENS(ex->d_pyr2, pyr_off * B);
@@ -265,7 +259,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (!ytab.empty()) ORBX_HIP(hipMemcpy(ex->d_ytab.p, ytab.data(), sizeof(ResizeTap) * ytab.size(), hipMemcpyHostToDevice));
     if (!xgtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xgtab.p, xgtab.data(), sizeof(ResizeGroup) * xgtab.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(ex->d_blur_tiles.p, blur_tiles.data(), sizeof(TileRef) * blur_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_items.p, blur_items.data(), sizeof(BlurItem) * blur_items.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
     // Cells the reference skips (empty interior: iniX >= maxBorderX - 6 / iniY >= maxBorderY - 3, ORBextractor.cc:810,819 -- e.g. cell column 33 of
@@ -344,7 +337,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->fast_wave_rows = fast_wave_rows;
     ex->fast_wave_qfull = fast_wave_qfull;
     { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
-    ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_tiles = (int)blur_tiles.size(); ex->n_blur_items = (int)blur_items.size();
+    ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_items = (int)blur_items.size();
     ex->last_batch = 0;
     if (ex->has_camera) {
         CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],
@@ -399,27 +392,17 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const int ini_th = std::min(std::max(ex->prm.ini_th_fast, 0), 255), min_th = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini_th);
     static const int kBlurNew[4] = {18, 34, 48, 56}, kBlurOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
     const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
-    auto blur_levels = [&](hipStream_t bs, int l0, int l1) {   // k_blur over the tiles of levels [l0, l1)
-        const int t0 = ex->blur_tile_start[l0], t1 = ex->blur_tile_start[l1];
-        if (t1 <= t0) return;
+    auto blur_all_levels = [&](hipStream_t bs) {   // k_blur_stream over every strip of every level of every frame
         const bool sat = 2 * (bg[0] + bg[1] + bg[2]) + bg[3] > 256;   // taps summing to more than 1.0 (OpenCV <= 4.5.0) can exceed 255
-        static const int stream_waves = [] { const char *v = getenv("ORBX_BLUR_STREAM"); return v ? atoi(v) : 0; }();   // hardware A/B: 0 = k_blur_pk
-        if (stream_waves > 0 && l0 == 0 && l1 == nl) {
-            const int nx = n >= 8 ? 8 : 1;
-            const long items_per_group = (long)((n + nx - 1) / nx) * ex->n_blur_items;
-            const int K = (int)std::max<long>(1, std::min<long>(stream_waves / nx, items_per_group));
-            if (sat) hipLaunchKernelGGL(k_blur_stream<true>, dim3(K * nx), dim3(64), 0, bs, (const BlurItem *)ex->d_blur_items.p, ex->n_blur_items, (const uint8_t *)pyr,
-                                        ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n, nx);
-            else hipLaunchKernelGGL(k_blur_stream<false>, dim3(K * nx), dim3(64), 0, bs, (const BlurItem *)ex->d_blur_items.p, ex->n_blur_items, (const uint8_t *)pyr,
+        static const int waves_env = [] { const char *v = getenv("ORBX_BLUR_STREAM"); return v ? atoi(v) : 0; }();   // hardware A/B of the wave count
+        const int waves = waves_env > 0 ? waves_env : ex->blur_waves;
+        const int nx = n >= 8 ? 8 : 1;
+        const long items_per_group = (long)((n + nx - 1) / nx) * ex->n_blur_items;
+        const int K = (int)std::max<long>(1, std::min<long>(waves / nx, items_per_group));
+        if (sat) hipLaunchKernelGGL(k_blur_stream<true>, dim3(K * nx), dim3(64), 0, bs, (const BlurItem *)ex->d_blur_items.p, ex->n_blur_items, (const uint8_t *)pyr,
                                     ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n, nx);
-            return;
-        }
-#define ORBX_BLUR_PK(SAT)                                                                                                              \
-    hipLaunchKernelGGL(k_blur_pk<SAT>, xcd_grid(t1 - t0, n), dim3(256), 0, bs, d_lv, (const TileRef *)ex->d_blur_tiles.p + t0,          \
-                       (const uint8_t *)pyr, ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n)
-        if (sat) ORBX_BLUR_PK(true);
-        else ORBX_BLUR_PK(false);
-#undef ORBX_BLUR_PK
+        else hipLaunchKernelGGL(k_blur_stream<false>, dim3(K * nx), dim3(64), 0, bs, (const BlurItem *)ex->d_blur_items.p, ex->n_blur_items, (const uint8_t *)pyr,
+                                ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n, nx);
     };
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
@@ -447,7 +430,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         hipStream_t bs = side ? ex->aux_stream : st;
         if (side) ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
         ProfScope ps(ex, K_BLUR);
-        blur_levels(bs, 0, nl);
+        blur_all_levels(bs);
         if (side) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
         return ORBX_OK;
     };
@@ -712,7 +695,7 @@ void orbx_destroy(orbx_extractor *ex) {
     for (int i = 0; i < 3; i++) { if (ex->h_frustum[i]) (void)hipHostFree(ex->h_frustum[i]); if (ex->ev_frustum[i]) (void)hipEventDestroy(ex->ev_frustum[i]); }
     ex->d_match.release(); ex->d_nmatch.release();
     for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales, &ex->d_st_rowptr, &ex->d_st_rowidx}) b->release();
-    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_tiles, &ex->d_blur_items, &ex->d_dc, &ex->d_pyr, &ex->d_pyr2,
+    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_items, &ex->d_dc, &ex->d_pyr, &ex->d_pyr2,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
