@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(64) void k_blur_stream(const BlurItem *__restrict__
         lane_ofs(Dn, lofn, eofn);
         const bool live = lane < Dc.nlanes();
         // groups of this strip: one that fills the window + ceil(rows_out / 6) that emit, rounded up to an even number (the two sets of row slots
-        // alternate, and the next strip starts with set A again): 8 for a full strip, 2 for the 3-row strips beside k_pyr_resize_march_blur
+        // alternate, and the next strip starts with set A again): 8 for a full strip, fewer for the short last strip of a level
         const int ngroups = (1 + (Dc.rows_out() + 5) / 6 + 1) & ~1;
         // one group of six rows: filter the rows in `cons`, request the rows of the next group into `prod`
         auto group = [&](RowRegs (&cons)[6], RowRegs (&prod)[6], const int ph) {
@@ -1105,174 +1105,6 @@ __global__ __launch_bounds__(64) void k_blur_stream(const BlurItem *__restrict__
         dstc = blur + (size_t)(x + nx * fi) * blur_frame_stride + Dc.dst_off;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the six rows requested beyond the end of the stream
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_pyr_resize_march_blur (round 4): level l from level l-1 (resize_march_block's arithmetic) AND the blurred level l in one pass -- the rows a wave
-// produces are filtered while they are still in its registers, so the blur never reads the level back (P bytes per frame of HBM reads less, and the
-// seven-launch resize chain, bound by the lifetime of its waves rather than by instructions, absorbs the blur's instructions).
-//   * a lane's output dword (4 pixels of row r) is its `c` of k_blur_stream's horizontal pass; the neighbours' dwords come over DPP (wave_shr /
-//     wave_shl), so the column strips of a level OVERLAP by one dword on each side: 62 of the 64 lanes own a column (store the level dword, the ring
-//     copies and the blurred dword), lanes 0 and 63 recompute their neighbours' columns;
-//   * the vertical window needs rows r-6 .. r: a block of rb rows marches from row y0 - 3 to row y1 + 3 (rows outside [y0, y1) are computed for the
-//     window only: +6 rows per 32), and the output rows are emitted at wave-uniform but DATA-dependent places of the unrolled chunk loop -- the ring of
-//     row-pair sums can therefore not be rotated at compile time as in k_blur_stream: it lives in LDS (6 slots x 16 bytes per lane, lane-private:
-//     no synchronisation), the pair of the previous row stays in registers (one 16-byte write + two 16-byte reads per row);
-//   * rows 0..2 and h-3..h-1 of the blurred level need the REFLECT_101 rows above / below the level, which the march does not pass through in order:
-//     k_blur_stream filters them (3-row items, ExtractorGeometry::blur_items_fused) from the finished level -- as it does all of level 0 (whose
-//     source is the input image, not a resize) and every level whose scale factor is above 2 (k_pyr_resize2).
-// Batches of more than 8 frames only: the single-frame path marches blocks of 4 rows (latency), where 6 window rows per block would triple the work.
-// grid xcd_grid(ceil(nstrips * ceil(h / 32) / 4), B), block 256 (four independent waves); static LDS 24 KB
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kMarchBlurCols = 62;   // columns a wave owns (64 lanes, one recomputed column at each end)
-
-template <int CH, bool SAT>
-__device__ __forceinline__ void resize_march_blur_block(const LevelInfo &L, const LevelInfo &P, const ResizeTap *__restrict__ ytab,
-                                                        const ResizeGroup *__restrict__ xg, uint8_t *frame, uint8_t *bframe, int rb_rows, int nstrips,
-                                                        uint32_t nstrips_rcp, int item, int lane, uint4 *ring, int g0, int g1, int g2, int g3) {
-    const int rb = nstrips == 1 ? item : __builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)item, nstrips_rcp)), cs = item - rb * nstrips;
-    const int ncol = L.pitch >> 2;
-    const int col = cs * kMarchBlurCols - 1 + lane;
-    const bool own = lane >= 1 && lane <= kMarchBlurCols && col < ncol;          // this lane stores its column
-    const int colc = min(max(col, 0), ncol - 1);
-    const uint4 *gp = reinterpret_cast<const uint4 *>(&xg[L.xg_off + colc]);
-    const uint4 gh = gp[0], gc = gp[1];   // base, sel, valid, pad | cc[4]
-    const uint8_t *proi = frame + P.off + (size_t)kEdge * P.pitch + kRoiX + (gh.z == 1 ? gh.x : 0u);   // this lane's first source byte of row 0
-    uint8_t *dcol = frame + L.off + 4 * (uint32_t)colc;
-    const int bcol = colc - kRoiX / 4;                                            // dword column of the blurred level (no ring)
-    const bool bown = own && bcol >= 0 && bcol < ((L.w + 3) >> 2);
-    uint8_t *bdst = bframe + L.boff + 4 * (uint32_t)max(bcol, 0);
-    const uint32_t sel = gh.y, selr = gh.y + 0x01010101u;
-    const uint32_t cc[4] = {gc.x, gc.y, gc.z, gc.w};
-    constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
-    // blur taps (k_blur_stream)
-    auto tapd = [&](int d) -> uint32_t {
-        d = d < 0 ? -d : d;
-        return d == 0 ? (uint32_t)g3 : d == 1 ? (uint32_t)g2 : d == 2 ? (uint32_t)g1 : d == 3 ? (uint32_t)g0 : 0u;
-    };
-    uint32_t ht[4][3];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) v |= tapd(4 * q + b - (j + 4)) << (8 * b);
-            ht[j][q] = v;
-        }
-    const u16x2 vp0 = as_pk((uint32_t)g0 | ((uint32_t)g1 << 16));   // rows r-6, r-5
-    const u16x2 vp1 = as_pk((uint32_t)g2 | ((uint32_t)g3 << 16));   // rows r-4, r-3
-    const u16x2 vp2 = as_pk((uint32_t)g2 | ((uint32_t)g1 << 16));   // rows r-2, r-1
-    const int y0 = rb * rb_rows, y1 = min(y0 + rb_rows, L.h);
-    const int ya = max(y0 - 3, 0), yb = min(y1 + 3, L.h);          // rows the block marches through (at most rb_rows + 6 <= 64)
-    const uint2 ytl = *reinterpret_cast<const uint2 *>(ytab + L.ytab_off + min(ya + lane, L.h - 1));   // lane i holds the taps of row ya + i
-#define RM_TAP_OFS(i) __builtin_amdgcn_readlane((int)ytl.x, (i))
-#define RM_TAP_CC(i) ((uint32_t)__builtin_amdgcn_readlane((int)ytl.y, (i)))
-    int r = ya;
-    int ty_ofs = RM_TAP_OFS(0);
-    uint32_t ty_cc = RM_TAP_CC(0);
-    int s = ty_ofs;                                   // next source row to fetch
-    const int s_last = RM_TAP_OFS(yb - 1 - ya) + 1;   // last source row the block needs
-    const int hmax = P.h - 1;
-    uint2 cur[CH], nxt[CH];
-    uint32_t Hp[4] = {0u, 0u, 0u, 0u};
-    uint32_t hprev[4] = {0u, 0u, 0u, 0u};             // horizontal blur sums of the previous row
-    uint4 pprev = make_uint4(0u, 0u, 0u, 0u);         // pair (rows r-2, r-1), built when row r-1 was emitted
-    uint4 *myring = ring + lane;                      // slot q of this lane: myring[64 * q]
-    int slot = 0;                                     // (r - ya) % 6
-#pragma unroll
-    for (int k = 0; k < CH; k++) __builtin_memcpy(&cur[k], proi + (size_t)(uint32_t)(min(s + k, hmax) * P.pitch), 8);
-    while (r < yb) {
-        if (s + CH <= s_last) {   // wave-uniform: the next CH rows are requested before these are filtered
-#pragma unroll
-            for (int k = 0; k < CH; k++) __builtin_memcpy(&nxt[k], proi + (size_t)(uint32_t)(min(s + CH + k, hmax) * P.pitch), 8);
-        }
-        uint32_t H[CH][4];   // horizontal pass of the chunk's rows, already >> 4 ([OCV] the vertical pass multiplies (sum >> 4))
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const uint32_t l = __builtin_amdgcn_perm(cur[k].y, cur[k].x, sel), q = __builtin_amdgcn_perm(cur[k].y, cur[k].x, selr);
-#pragma unroll
-            for (int j = 0; j < 4; j++) H[k][j] = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q, l, kPair[j])), as_pk(cc[j]), 0u, false) >> 4;
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            if (r < yb && ty_ofs + 1 == s + k) {   // wave-uniform: the output row whose source rows are (s + k - 1, s + k)
-                const uint32_t *A = k == 0 ? Hp : H[k == 0 ? 0 : k - 1], *B = H[k];
-                const uint32_t b0 = ty_cc & 0xffffu, b1 = ty_cc >> 16;   // c0 | c1 << 16: bilinear tap pair, 0 <= b <= 2048
-                int t[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t p0 = __umul24(A[j], b0) + 0x20000u, p1 = __umul24(B[j], b1);
-                    t[j] = (int)((p0 >> 16) + (p1 >> 16));
-                }
-                uint32_t o = ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 2)) | ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 2) << 16);
-                if (gh.z != 1) o = 0u;   // pitch padding outside the ring
-                if (own && r >= y0 && r < y1) {   // rows outside [y0, y1) belong to the neighbouring blocks: computed for the blur window only
-                    *reinterpret_cast<uint32_t *>(dcol + (size_t)(uint32_t)((kEdge + r) * L.pitch)) = o;
-                    if (r >= 1 && r <= kEdge) *reinterpret_cast<uint32_t *>(dcol + (size_t)(uint32_t)((kEdge - r) * L.pitch)) = o;                              // ring above
-                    if (r <= L.h - 2 && r >= L.h - 1 - kEdge) *reinterpret_cast<uint32_t *>(dcol + (size_t)(uint32_t)((kEdge + 2 * (L.h - 1) - r) * L.pitch)) = o;   // ring below
-                }
-                // ---- the 7x7 blur of row r - 3 (window rows r-6 .. r; k_blur_stream's arithmetic) ----
-                {
-                    const uint32_t bm = (uint32_t)__builtin_amdgcn_update_dpp((int)o, (int)o, 0x138, 0xf, 0xf, false);   // left neighbour's dword (lane 0: unused)
-                    const uint32_t bp = (uint32_t)__builtin_amdgcn_update_dpp((int)o, (int)o, 0x130, 0xf, 0xf, false);   // right neighbour's dword (lane 63: unused)
-                    uint32_t h[4];
-                    h[0] = __builtin_amdgcn_udot4(o, ht[0][1], __builtin_amdgcn_udot4(bm, ht[0][0], 0u, false), false);
-                    h[1] = __builtin_amdgcn_udot4(bp, ht[1][2], __builtin_amdgcn_udot4(o, ht[1][1], __builtin_amdgcn_udot4(bm, ht[1][0], 0u, false), false), false);
-                    h[2] = __builtin_amdgcn_udot4(bp, ht[2][2], __builtin_amdgcn_udot4(o, ht[2][1], __builtin_amdgcn_udot4(bm, ht[2][0], 0u, false), false), false);
-                    h[3] = __builtin_amdgcn_udot4(bp, ht[3][2], __builtin_amdgcn_udot4(o, ht[3][1], 0u, false), false);
-                    const int s3 = slot >= 3 ? slot - 3 : slot + 3, s5 = slot >= 5 ? slot - 5 : slot + 1;   // slots of rows r-3 and r-5
-                    const uint4 p3 = myring[64 * s3], p5 = myring[64 * s5];     // pairs (r-4, r-3) and (r-6, r-5)
-                    const uint32_t pa[4] = {pprev.x, pprev.y, pprev.z, pprev.w}, pb[4] = {p3.x, p3.y, p3.z, p3.w}, pc[4] = {p5.x, p5.y, p5.z, p5.w};
-                    uint32_t sum[4], pn[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t a = __umul24(h[j], (uint32_t)g0) + 32768u;          // row r
-                        a = __builtin_amdgcn_udot2(as_pk(pa[j]), vp2, a, false);       // rows r-2, r-1
-                        a = __builtin_amdgcn_udot2(as_pk(pb[j]), vp1, a, false);       // rows r-4, r-3
-                        a = __builtin_amdgcn_udot2(as_pk(pc[j]), vp0, a, false);       // rows r-6, r-5
-                        sum[j] = SAT ? min(a, 0x00ffffffu) : a;
-                        pn[j] = hprev[j] | (h[j] << 16);                               // pair (r-1, r)
-                        hprev[j] = h[j];
-                    }
-                    pprev = make_uint4(pn[0], pn[1], pn[2], pn[3]);
-                    myring[64 * slot] = pprev;
-                    if (bown && r - ya >= 6) {   // the window is complete: rows ya .. r include r-6 (and row r-3 lies in [max(y0, 3), min(y1, h-3)))
-                        const uint32_t lo = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u);    // byte 2 of sum[0], byte 2 of sum[1]
-                        const uint32_t hi = __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);
-                        *reinterpret_cast<uint32_t *>(bdst + (size_t)((uint32_t)(r - 3) * (uint32_t)L.bpitch)) = lo | hi;
-                    }
-                    slot = slot == 5 ? 0 : slot + 1;
-                }
-                r++;
-                ty_ofs = RM_TAP_OFS(min(r, yb - 1) - ya);
-                ty_cc = RM_TAP_CC(min(r, yb - 1) - ya);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) Hp[j] = H[CH - 1][j];
-#pragma unroll
-        for (int k = 0; k < CH; k++) cur[k] = nxt[k];
-        s += CH;
-        if (s > s_last + CH) break;   // cannot happen with monotone row taps; never spin on a bad table
-    }
-#undef RM_TAP_OFS
-#undef RM_TAP_CC
-}
-
-template <int CH, bool SAT>
-__global__ __launch_bounds__(256) void k_pyr_resize_march_blur(const LevelInfo L, const LevelInfo P, const ResizeTap *__restrict__ ytab,
-                                                               const ResizeGroup *__restrict__ xg, uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
-                                                               uint8_t *__restrict__ blur, size_t blur_frame_stride, int rb_rows, int nstrips,
-                                                               uint32_t nstrips_rcp, int n_items, int g0, int g1, int g2, int g3, int n_frames) {
-    __shared__ uint4 ring[4][6 * 64];
-    int bx, f;
-    if (!xcd_frame_map(n_frames, &bx, &f)) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = bx * 4 + wave;
-    if (item >= n_items) return;
-    resize_march_blur_block<CH, SAT>(L, P, ytab, xg, pyr + (size_t)f * pyr_frame_stride, blur + (size_t)f * blur_frame_stride, rb_rows, nstrips, nstrips_rcp,
-                                     item, lane, ring[wave], g0, g1, g2, g3);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -124,10 +124,10 @@ struct orbx_extractor {
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
     bool fast_wave = true;      // every level's cell fits k_fast_wave's fixed LDS pitch
-    int n_fast_tiles = 0, n_blur_items = 0, n_blur_items_fused = 0;
+    int n_fast_tiles = 0, n_blur_items = 0;
     int blur_waves = 2048;      // single-wave workgroups of k_blur_stream (measured: 512 / 1024 / 2048 / 4096 -> EuRoC step 1.25 / 1.115 / 1.09 / 1.10 ms)
     // device memory
-    DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_items, d_blur_items_fused, d_dc;
+    DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_items, d_dc;
     // Stereo rig (orbx_stereo_batch_device): the SAD stage reads both extractors' pyramids on the match stream while the NEXT pair of batches is
     // extracted, so an extractor that has been part of a rig alternates between two pyramid slabs (allocated at the first stereo call)
     DevBuf d_pyr2;

@@ -86,7 +86,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     std::vector<ResizeTap> xtab, ytab;
     std::vector<ResizeGroup> xgtab;
     std::vector<TileRef> fast_tiles;
-    std::vector<BlurItem> blur_items, blur_items_fused;
+    std::vector<BlurItem> blur_items;
     std::vector<StripTile> strips;
     std::vector<int> strip_level_rows;
     bool fast_strip = true;
@@ -206,18 +206,9 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
                           | ((uint32_t)rows_out << 16) | ((uint32_t)((std::min(kBlurTW, L.w - x0) + 3) / 4) << 24);
                 return bi;
             };
-            // k_blur_stream: one item per 256-pixel x 42-row strip ...
+            // k_blur_stream: one item per 256-pixel x 42-row strip
             for (int y0 = 0; y0 < L.h; y0 += kBlurRows)
                 for (int x0 = 0; x0 < L.w; x0 += kBlurTW) blur_items.push_back(strip(y0, std::min(kBlurRows, L.h - y0), x0));
-            // ... and beside k_pyr_resize_march_blur (batches of more than 8 frames), which leaves it level 0, the levels the marching resize does not
-            // take, and the first / last three rows of the others
-            if (l == 0 || !ex->resize_march_ok[l] || L.h < 12) {
-                for (int y0 = 0; y0 < L.h; y0 += kBlurRows)
-                    for (int x0 = 0; x0 < L.w; x0 += kBlurTW) blur_items_fused.push_back(strip(y0, std::min(kBlurRows, L.h - y0), x0));
-            } else {
-                for (int y0 : {0, L.h - 3})
-                    for (int x0 = 0; x0 < L.w; x0 += kBlurTW) blur_items_fused.push_back(strip(y0, 3, x0));
-            }
         }
         const int cols = L.wCell + 6, rows = L.hCell + 6;
         const size_t pp = (size_t)((cols + 3 + 3) & ~3);
@@ -246,7 +237,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_xgtab, sizeof(ResizeGroup) * std::max<size_t>(xgtab.size(), 1));
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_blur_items, sizeof(BlurItem) * blur_items.size());
-    ENS(ex->d_blur_items_fused, sizeof(BlurItem) * blur_items_fused.size());
     ENS(ex->d_pyr, pyr_off * B);
     if (ex->pyr_double) ENS(ex->d_pyr2, pyr_off * B);
     ENS(ex->d_blur, blur_off * B);
@@ -274,7 +264,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (!xgtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xgtab.p, xgtab.data(), sizeof(ResizeGroup) * xgtab.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_items.p, blur_items.data(), sizeof(BlurItem) * blur_items.size(), hipMemcpyHostToDevice));
-    ORBX_HIP(hipMemcpy(ex->d_blur_items_fused.p, blur_items_fused.data(), sizeof(BlurItem) * blur_items_fused.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
     // Cells the reference skips (empty interior: iniX >= maxBorderX - 6 / iniY >= maxBorderY - 3, ORBextractor.cc:810,819 -- e.g. cell column 33 of
     // level 0 of a 1226 x 370 image) belong to no strip and are never written by the FAST stage; compact_level reads every cell's count.  A
@@ -352,7 +341,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->fast_wave_rows = fast_wave_rows;
     ex->fast_wave_qfull = fast_wave_qfull;
     { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
-    ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_items = (int)blur_items.size(); ex->n_blur_items_fused = (int)blur_items_fused.size();
+    ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_items = (int)blur_items.size();
     ex->last_batch = 0;
     if (ex->has_camera) {
         CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],
@@ -407,16 +396,12 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const int ini_th = std::min(std::max(ex->prm.ini_th_fast, 0), 255), min_th = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini_th);
     static const int kBlurNew[4] = {18, 34, 48, 56}, kBlurOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
     const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
-    // Batches of more than 8 frames: levels 1 .. nl-1 are resized AND blurred by k_pyr_resize_march_blur; k_blur_stream then only has level 0 and the
-    // first / last three rows of the others (blur_items_fused).  ORBX_BLUR_FUSED=0: the blur of every level by k_blur_stream (hardware A/B).
-    static const bool fused_env = [] { const char *v = getenv("ORBX_BLUR_FUSED"); return !(v && v[0] == '0'); }();
-    const bool fused = fused_env && n > 8;
     const bool sat = 2 * (bg[0] + bg[1] + bg[2]) + bg[3] > 256;   // taps summing to more than 1.0 (OpenCV <= 4.5.0) can exceed 255
-    auto blur_stream = [&](hipStream_t bs) {   // k_blur_stream over the strips the pyramid stage left
+    auto blur_stream = [&](hipStream_t bs) {   // k_blur_stream over every strip of every level of every frame
         static const int waves_env = [] { const char *v = getenv("ORBX_BLUR_STREAM"); return v ? atoi(v) : 0; }();   // hardware A/B of the wave count
         const int waves = waves_env > 0 ? waves_env : ex->blur_waves;
-        const BlurItem *items = (const BlurItem *)(fused ? ex->d_blur_items_fused.p : ex->d_blur_items.p);
-        const int nitems = fused ? ex->n_blur_items_fused : ex->n_blur_items;
+        const BlurItem *items = (const BlurItem *)ex->d_blur_items.p;
+        const int nitems = ex->n_blur_items;
         const int nx = n >= 8 ? 8 : 1;
         const long items_per_group = (long)((n + nx - 1) / nx) * nitems;
         const int K = (int)std::max<long>(1, std::min<long>(waves / nx, items_per_group));
@@ -428,19 +413,6 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
-        if (ex->resize_march_ok[l] && fused && L.h >= 12) {
-            // the marching form with the blur of the level in the same pass: 62 columns per wave (one recomputed on each side), blocks of 32 rows
-            // (+ 6 rows for the vertical window: shorter blocks would spend too much on them)
-            const int nstrips = (L.pitch / 4 + kMarchBlurCols - 1) / kMarchBlurCols, rb = 32, n_items = nstrips * ((L.h + rb - 1) / rb);
-            const uint32_t rcp = (uint32_t)((0x100000000ull + (uint64_t)nstrips - 1) / (uint64_t)nstrips);
-#define ORBX_MARCH_BLUR(SAT)                                                                                                                          \
-    hipLaunchKernelGGL((k_pyr_resize_march_blur<8, SAT>), xcd_grid((n_items + 3) / 4, n, pyr_local), dim3(256), 0, pst, L, ex->lv[l - 1],              \
-                       (const ResizeTap *)ex->d_ytab.p, (const ResizeGroup *)ex->d_xgtab.p, pyr, ex->pyr_frame, blur_slab, ex->blur_frame, rb, nstrips, \
-                       rcp, n_items, bg[0], bg[1], bg[2], bg[3], n)
-            if (sat) ORBX_MARCH_BLUR(true); else ORBX_MARCH_BLUR(false);
-#undef ORBX_MARCH_BLUR
-            continue;
-        }
         if (ex->resize_march_ok[l]) {
             // register-marching form: one wave = 64 dword columns x rb output rows (rb 16 / 32 and 4 / 8 source rows in flight measured
             // alike, 64 rows per block 5 % slower: profiles/r03_c_ab_resize_march_strip_waves_prime.log)
@@ -729,7 +701,7 @@ void orbx_destroy(orbx_extractor *ex) {
     for (int i = 0; i < 3; i++) { if (ex->h_frustum[i]) (void)hipHostFree(ex->h_frustum[i]); if (ex->ev_frustum[i]) (void)hipEventDestroy(ex->ev_frustum[i]); }
     ex->d_match.release(); ex->d_nmatch.release();
     for (DevBuf *b : {&ex->d_st_bidx, &ex->d_st_bdist, &ex->d_st_ur, &ex->d_st_depth, &ex->d_st_sad, &ex->d_st_nm, &ex->d_st_scales, &ex->d_st_rowptr, &ex->d_st_rowidx}) b->release();
-    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_items, &ex->d_blur_items_fused, &ex->d_dc, &ex->d_pyr, &ex->d_pyr2,
+    DevBuf *bufs[] = {&ex->d_lv, &ex->d_xtab, &ex->d_ytab, &ex->d_fast_tiles, &ex->d_blur_items, &ex->d_dc, &ex->d_pyr, &ex->d_pyr2,
                       &ex->d_blur, &ex->d_cellcnt, &ex->d_cellent, &ex->d_keys0, &ex->d_keys1, &ex->d_nof0, &ex->d_nof1, &ex->d_fast_ovf, &ex->d_lvlkp, &ex->d_lvlcnt,
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
