@@ -396,10 +396,22 @@ def base_line(R, metric, value, dt_max, extra_cfg):
             "dtype": "u8", "data": "synthetic", "config": extra_cfg, "process_group": R.group, "per_rank": getattr(R, "per_rank", None)}
 
 
-def repeats_block(regions, steps):
+STAMPS = []          # host time at which every step's results had arrived (appended by the run loops, cut per region by region_gaps)
+
+
+def region_gaps():
+    """Largest and median gap between consecutive step completions since the last call, in ms (then clears the list): a region that is slow because
+    of ONE long stall (host thread descheduled, a driver housekeeping pause) looks different from one whose every step is slow (clocks, contention)."""
+    g = np.diff(np.array(STAMPS)) * 1e3 if len(STAMPS) > 2 else np.zeros(1)
+    STAMPS.clear()
+    return {"max_gap_ms": round(float(g.max()), 3), "median_gap_ms": round(float(np.median(g)), 3), "argmax": int(g.argmax())}
+
+
+def repeats_block(regions, steps, gaps=None):
+    order = [round(t / steps * 1e3, 3) for t, _ in regions]
     ms = sorted(t / steps * 1e3 for t, _ in regions)
     vals = sorted(f / t / 1e3 for t, f in regions)
-    return {"regions": len(regions), "steps_per_region": steps,
+    return {"regions": len(regions), "steps_per_region": steps, "ms_per_step_in_order": order, "step_gaps": gaps,
             "ms_per_step": {"median": round(float(np.median(ms)), 3), "min": round(ms[0], 3), "max": round(ms[-1], 3)},
             "value": {"median": round(float(np.median(vals)), 2), "min": round(vals[0], 2), "max": round(vals[-1], 2)},
             "note": "`value` / `ms_per_step` of the line are the FIRST region (exactly K steps after W warm-up steps); the others follow back to back"}
@@ -501,6 +513,7 @@ def bench_euroc(R):
                 host_enqueue[0] += time.perf_counter() - t
             if i >= 1:
                 ex.download_wait()
+                STAMPS.append(time.perf_counter())
                 feats += int(host[(i - 1) % 2].cnt.sum())
         return feats
 
@@ -509,6 +522,7 @@ def bench_euroc(R):
     def timed(from_host):
         run(max(a.warmup, 1), from_host)
         t0 = R.timed_begin([ex])
+        STAMPS.clear()
         host_enqueue[0] = 0.0
         feats = run(a.steps, from_host)
         return R.timed_end(t0, [ex]), feats
@@ -518,7 +532,9 @@ def bench_euroc(R):
     R.barrier([ex])
     settle_ms = (time.perf_counter() - t_settle) / max(min(a.settle, 8), 1) * 1e3   # the fresh process's first steps: start-up transient included
     settle(lambda n: run(n, False), a, done=min(a.settle, 8))
+    STAMPS.clear()
     dt, feats = timed(False)
+    gaps = [region_gaps()]
     enqueue_ms = host_enqueue[0] / a.steps * 1e3
     last = host[(a.steps - 1) % 2]
     nmatch = int(last.nm[1:].sum())
@@ -539,8 +555,9 @@ def bench_euroc(R):
         t0 = R.timed_begin([ex])
         f_r = run(a.steps, False)
         regions.append(R.reduce(R.timed_end(t0, [ex]), f_r))
+        gaps.append(region_gaps())
     R.per_rank = per_rank
-    repeats = repeats_block(regions, a.steps)
+    repeats = repeats_block(regions, a.steps, gaps)
 
     # ---- the same loop with the frames starting in pinned host memory (upload inside the timed region) ----
     dt_h, feats_h = timed(True)
@@ -755,6 +772,7 @@ def bench_kitti(R):
                 exl.download_wait()
                 exr.download_wait()
                 exl.stereo_download_wait()
+                STAMPS.append(time.perf_counter())
                 hs = sets[(i - 1) % 2]
                 f += int(hs.cam["l"][2].sum()) + int(hs.cam["r"][2].sum())
         return f
@@ -762,10 +780,15 @@ def bench_kitti(R):
     settle(run, a)
     run(max(a.warmup, 1))
 
+    gaps = []
+
     def region():
         t0 = R.timed_begin([exl, exr])
+        STAMPS.clear()
         f_r = run(a.steps)
-        return R.reduce(R.timed_end(t0, [exl, exr]), f_r), f_r
+        out = R.reduce(R.timed_end(t0, [exl, exr]), f_r), f_r
+        gaps.append(region_gaps())
+        return out
 
     (dt_max, feats_all), feats = region()
     per_rank = R.per_rank
@@ -834,7 +857,7 @@ def bench_kitti(R):
                      "pairs_per_step_per_gpu": B, "sequences": R.world, "features_per_pair": round(feats / a.steps / B, 1),
                      "stereo_matches_per_pair": round(float(h_nm.sum()) / B, 1)})
     out["data"] = data
-    out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels, "repeats": repeats_block(regions, a.steps)})
+    out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels, "repeats": repeats_block(regions, a.steps, gaps)})
     R.finish(out)
 
 
@@ -905,6 +928,7 @@ def bench_tumvi(R):
                 host_enqueue[0] += time.perf_counter() - t
             if i >= 1:
                 ex.download_wait()
+                STAMPS.append(time.perf_counter())
                 feats += int(hs[(i - 1) % 2]["cnt"].sum())
         return feats
 
@@ -912,11 +936,16 @@ def bench_tumvi(R):
     settle(run, a)
     run(max(a.warmup, 1))
 
+    gaps = []
+
     def region():
         t0 = R.timed_begin([ex])
         host_enqueue[0] = 0.0
+        STAMPS.clear()
         f_r = run(a.steps)
-        return R.reduce(R.timed_end(t0, [ex]), f_r), f_r
+        out = R.reduce(R.timed_end(t0, [ex]), f_r), f_r
+        gaps.append(dict(region_gaps(), host_enqueue_ms_per_step=round(host_enqueue[0] / a.steps * 1e3, 3)))
+        return out
 
     (dt_max, feats_all), feats = region()
     per_rank = R.per_rank
@@ -982,7 +1011,7 @@ def bench_tumvi(R):
                      "map_point_matches_per_frame": round(float(last["nm"].sum()) / B, 1)})
     out["data"] = data
     out.update({"roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "kernels": kernels,
-                "host_enqueue_ms_per_step": round(host_enqueue[0] / a.steps * 1e3, 3), "repeats": repeats_block(regions, a.steps)})
+                "host_enqueue_ms_per_step": round(host_enqueue[0] / a.steps * 1e3, 3), "repeats": repeats_block(regions, a.steps, gaps)})
     R.finish(out)
 
 

@@ -398,8 +398,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
     const bool sat = 2 * (bg[0] + bg[1] + bg[2]) + bg[3] > 256;   // taps summing to more than 1.0 (OpenCV <= 4.5.0) can exceed 255
     auto blur_stream = [&](hipStream_t bs) {   // k_blur_stream over every strip of every level of every frame
-        static const int waves_env = [] { const char *v = getenv("ORBX_BLUR_STREAM"); return v ? atoi(v) : 0; }();   // hardware A/B of the wave count
-        const int waves = waves_env > 0 ? waves_env : ex->blur_waves;
+        const int waves = ex->blur_waves;
         const BlurItem *items = (const BlurItem *)ex->d_blur_items.p;
         const int nitems = ex->n_blur_items;
         const int nx = n >= 8 ? 8 : 1;
