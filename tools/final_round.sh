@@ -2,7 +2,7 @@
 # end-of-round evidence: GPU test-suite, the driver's bench line (with the KITTI / TUM-VI child runs embedded), serialized kernel stats, PMC traffic,
 # SQ counters, overlapped kernel stats, the pipelined timeline.  usage: bash tools/final_round.sh <tag>   -> gpurun_out/measure_<tag>/profiles_copy/
 set -u
-TAG=${1:-r03_z}
+TAG=${1:-r04_z}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/measure_$TAG
