@@ -447,6 +447,8 @@ def bench_dry(R):
     units = 1000.0 * a.steps * (R.rank + 1)
     time.sleep(0.01)
     dt_max, units_all = R.reduce(R.timed_end(t0), units)
+    for pr, pc in zip(R.per_rank, R.gather_objects({"checked_by_rank": R.rank})):   # the path the ranks' parity verdicts take to rank 0
+        pr["parity_checked"] = pc
     out = base_line(R, "dry run (ORBX_BENCH_DRY): launcher + sharding only", units_all / dt_max / 1e3, dt_max,
                     {"workload": "none", "sequences": R.world})
     out["roofline"] = None

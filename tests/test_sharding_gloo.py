@@ -76,8 +76,20 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 2 and out["config"]["sequences"] == 2 and out["attempts"] == 1
     assert out["process_group"] == "gloo" and [p["rank"] for p in out["per_rank"]] == [0, 1]
+    # every rank's parity verdict (here a stand-in object) reaches rank 0 over the host group, in rank order
+    assert [p["parity_checked"] for p in out["per_rank"]] == [{"checked_by_rank": 0}, {"checked_by_rank": 1}]
     # rank r reports 1000 * steps * (r + 1) units: the sum over both ranks arrived on rank 0
     assert abs(out["value"] * out["ms_per_step"] * 3 / 1e3 * 1e3 - 9000.0) < 9000.0 * 0.02
+
+
+def test_bench_share_gpus_flag_runs_more_ranks_than_gpus():
+    """--share-gpus (rank r on GPU r mod count: the N-rank path on a box with fewer GPUs, used for profiles/r04_two_ranks_one_gpu.json): accepted by
+    launcher and ranks; dry mode has no device, the mapping itself is a GPU-box matter."""
+    import json
+    r = _run_bench(["--gpus", "3", "--share-gpus", "--steps", "2", "--warmup", "1"], {"ORBX_BENCH_DRY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 3 and len(out["per_rank"]) == 3
 
 
 def test_bench_refuses_a_mismatched_world_size():
