@@ -1022,7 +1022,9 @@ __global__ __launch_bounds__(64) void k_blur_stream(const BlurItem *__restrict__
     // a lane past the level's width loads the dword right of the last lane with pixels (ring bytes its neighbour's window needs), then repeats it
     auto lane_ofs = [&](const BlurItem &D, uint32_t &lofs, uint32_t &eofs) {
         lofs = (uint32_t)min(lane, D.nlanes()) * 4u + 4u;   // + 4: the row base points one dword left of the strip
-        eofs = lane == 0 ? 0u : lane == 63 ? 260u : lofs;
+        // lane 63's right neighbour exists (and is needed) only when the strip is full: a part-filled strip of a narrow level may end within four
+        // bytes of the row's -- for the last ring row of the last level of the last frame: of the slab's -- end
+        eofs = lane == 0 ? 0u : (lane == 63 && D.nlanes() == 64) ? 260u : lofs;
     };
     int fi = 0, it = k;
     while (it >= nitems) { it -= nitems; fi++; }
