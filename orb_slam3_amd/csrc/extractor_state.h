@@ -153,11 +153,6 @@ struct orbx_extractor {
     // host-resident input (orbx_extract_batch_host): upload stream + two input slabs; slot s may be overwritten once the
     // k_pyr_base that read it has finished (ev_in_free), the extraction may start once the upload has landed (ev_in_ready)
     hipStream_t in_stream = nullptr;
-    // Three more upload streams, created by the first orbx_extract_batch_host (an extractor fed from device memory never has them: more streams per
-    // extractor move the hardware queues of a second extractor in the process, section 6 of DESIGN.md).  One H2D copy beside the D2H of the previous
-    // batch's results reaches 46.6 GB/s, the same bytes as four concurrent copies 55.3 (alone: 56.7; tools/microbench/h2d_streams.py).
-    hipStream_t in_extra[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_in_chunk[3] = {nullptr, nullptr, nullptr};
     hipStream_t spare_stream = nullptr;   // never used: spaces the hardware queues of a second extractor (orbx_create)
     DevBuf d_in[2];
     hipEvent_t ev_in_free[2] = {nullptr, nullptr}, ev_in_ready[2] = {nullptr, nullptr};

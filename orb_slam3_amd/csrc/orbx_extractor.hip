@@ -689,9 +689,8 @@ void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->spare_stream, ex->in_extra[0], ex->in_extra[1], ex->in_extra[2]})
+    for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->spare_stream})
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    for (hipEvent_t ev : ex->ev_in_chunk) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {ex->ev_in_free[0], ex->ev_in_free[1], ex->ev_in_ready[0], ex->ev_in_ready[1]}) if (ev) (void)hipEventDestroy(ev);
     ex->d_in[0].release(); ex->d_in[1].release();
     for (hipEvent_t ev : {ex->ev_pyr, ex->ev_blur, ex->ev_describe, ex->ev_match}) if (ev) (void)hipEventDestroy(ev);
@@ -750,27 +749,7 @@ int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *h_images, int n_f
     hipStream_t is = ex->in_stream;
     if (ex->in_used[slot]) ORBX_HIP(hipStreamWaitEvent(is, ex->ev_in_free[slot], 0));  // the batch that last used this slab
     if (frame_stride == row_stride * (size_t)height) {  // rows of all frames equally spaced: one (2-D) copy into the packed slab
-        if (row_stride == (size_t)width && need >= ((size_t)8 << 20)) {
-            // one contiguous block of at least 8 MB: four concurrent copies (in_stream + three more), each a quarter -- the link is shared with the
-            // D2H of the previous batch's results, and one copy alone gets 46.6 of the 56.7 GB/s, four get 55.3
-            if (!ex->in_extra[0])
-                for (int c = 0; c < 3; c++) {
-                    ORBX_HIP(hipStreamCreateWithFlags(&ex->in_extra[c], hipStreamNonBlocking));
-                    ORBX_HIP(hipEventCreateWithFlags(&ex->ev_in_chunk[c], hipEventDisableTiming));
-                }
-            const size_t q = ((need / 4) + 4095) & ~(size_t)4095;
-            for (int c = 0; c < 4; c++) {
-                const size_t o = q * c, b = o >= need ? 0 : std::min(q, need - o);
-                if (!b) continue;
-                hipStream_t cs = c == 0 ? is : ex->in_extra[c - 1];
-                if (c > 0 && ex->in_used[slot]) ORBX_HIP(hipStreamWaitEvent(cs, ex->ev_in_free[slot], 0));
-                ORBX_HIP(hipMemcpyAsync((uint8_t *)din.p + o, h_images + o, b, hipMemcpyHostToDevice, cs));
-                if (c > 0) {
-                    ORBX_HIP(hipEventRecord(ex->ev_in_chunk[c - 1], cs));
-                    ORBX_HIP(hipStreamWaitEvent(is, ex->ev_in_chunk[c - 1], 0));   // ev_in_ready below (recorded on `is`) then stands for all four
-                }
-            }
-        } else if (row_stride == (size_t)width) ORBX_HIP(hipMemcpyAsync(din.p, h_images, need, hipMemcpyHostToDevice, is));
+        if (row_stride == (size_t)width) ORBX_HIP(hipMemcpyAsync(din.p, h_images, need, hipMemcpyHostToDevice, is));
         else ORBX_HIP(hipMemcpy2DAsync(din.p, width, h_images, row_stride, width, (size_t)height * n_frames, hipMemcpyHostToDevice, is));
     } else {
         for (int f = 0; f < n_frames; f++)
