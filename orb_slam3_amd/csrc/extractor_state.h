@@ -153,18 +153,6 @@ struct orbx_extractor {
     // host-resident input (orbx_extract_batch_host): upload stream + two input slabs; slot s may be overwritten once the
     // k_pyr_base that read it has finished (ev_in_free), the extraction may start once the upload has landed (ev_in_ready)
     hipStream_t in_stream = nullptr;
-    // Single-frame calls (orbx_extract: ORBextractor::operator() as Tracking calls it, one frame per call) are launch bound: seventeen kernels of 4 - 30 us
-    // each, and the host cannot issue them as fast as the device finishes them (4 us gaps between the resize levels, 12 us where the blur's stream
-    // joins).  The launch sequence of a call is therefore captured ONCE per (geometry, lapping area, staging block) into a hipGraph and replayed:
-    // one hipGraphLaunch per frame.  Invalidated by anything that changes a kernel argument (configure(), a new staging block, other lapping area).
-    struct CallGraph {
-        hipGraphExec_t exec = nullptr;
-        unsigned long long generation = 0;   // config_generation it was captured under
-        const void *stage = nullptr;
-        int lap0 = 0, lap1 = 0, width = 0, height = 0;
-        bool failed = false;                 // capture not available (e.g. the emulator's stand-in runtime): direct launches from then on
-    } call_graph;
-    unsigned long long config_generation = 0;   // bumped by every (re)configuration
     hipStream_t spare_stream = nullptr;   // never used: spaces the hardware queues of a second extractor (orbx_create)
     DevBuf d_in[2];
     hipEvent_t ev_in_free[2] = {nullptr, nullptr}, ev_in_ready[2] = {nullptr, nullptr};

@@ -271,7 +271,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (!same_geom) ORBX_HIP(hipMemset(ex->d_cellcnt.p, 0, ex->d_cellcnt.bytes));
     ORBX_HIP(hipDeviceSynchronize());   // the fill has run (DevBuf::ensure, extractor_state.h)
     ex->lv = lv;
-    ex->config_generation++;   // every kernel argument derived from the workspace may have changed (orbx_extractor::call_graph)
     ex->width = width; ex->height = height; ex->batch_cap = B;
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
     ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave = fast_wave && fast_tiles.size() < 65536 && batch < 65536;
@@ -689,7 +688,6 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
 void orbx_destroy(orbx_extractor *ex) {
     if (!ex) return;
     (void)hipSetDevice(ex->device);
-    if (ex->call_graph.exec) { (void)hipGraphExecDestroy(ex->call_graph.exec); ex->call_graph.exec = nullptr; }
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     for (hipStream_t s : {ex->copy_stream, ex->aux_stream, ex->match_stream, ex->in_stream, ex->spare_stream})
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -948,38 +946,8 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
     for (int y = 0; y < height; y++) memcpy((uint8_t *)ex->h_stage + (size_t)y * dpitch, image + (size_t)y * stride, (size_t)width);
     uint8_t *hb = (uint8_t *)ex->h_stage + img_bytes;
     const HostMirror hm = {(int32_t *)hb, (orbx_keypoint *)(hb + 64), hb + 64 + kp_bytes, (const int32_t *)ex->d_err.p, (const int32_t *)ex->d_mono.p};
-    // the call's launch sequence as a graph replay (orbx_extractor::CallGraph); direct launches while profiling, for a stereo-rig extractor (its
-    // pyramid slab alternates), while an asynchronous download / matcher of an earlier batch is pending (their events are waited for inside the
-    // sequence), and where stream capture is not available
-    orbx_extractor::CallGraph &cg = ex->call_graph;
-    const bool graph_ok = !cg.failed && !ex->profile && !ex->pyr_double && !ex->copy_pending && !ex->match_pending && ex->side_streams;
-    if (graph_ok && cg.exec && (cg.generation != ex->config_generation || cg.stage != ex->h_stage || cg.lap0 != lap0 || cg.lap1 != lap1 || cg.width != width || cg.height != height)) {
-        (void)hipGraphExecDestroy(cg.exec);
-        cg.exec = nullptr;
-    }
-    if (graph_ok && !cg.exec) {
-        hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(ex->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            r = enqueue_extract(ex, (const uint8_t *)ex->h_stage, 1, dpitch, dpitch * height, lap0, lap1, nullptr, &hm);
-            const hipError_t ec = hipStreamEndCapture(ex->stream, &g);
-            if (r == ORBX_OK && ec == hipSuccess && g && hipGraphInstantiate(&cg.exec, g, nullptr, nullptr, 0) == hipSuccess) {
-                cg.generation = ex->config_generation; cg.stage = ex->h_stage; cg.lap0 = lap0; cg.lap1 = lap1; cg.width = width; cg.height = height;
-            } else {
-                cg.exec = nullptr; cg.failed = true;
-            }
-            if (g) (void)hipGraphDestroy(g);
-        } else cg.failed = true;
-        (void)hipGetLastError();
-    }
-    if (graph_ok && cg.exec) {
-        ORBX_HIP(hipGraphLaunch(cg.exec, ex->stream));
-        ORBX_HIP(hipEventRecord(ex->ev_describe, ex->stream));   // the captured record is a graph node, not the event later waiters look at
-        ex->internal_match_owner = 0;
-        ex->last_batch = 1;
-    } else {
-        r = enqueue_extract(ex, (const uint8_t *)ex->h_stage, 1, dpitch, dpitch * height, lap0, lap1, nullptr, &hm);
-        if (r != ORBX_OK) return r;
-    }
+    r = enqueue_extract(ex, (const uint8_t *)ex->h_stage, 1, dpitch, dpitch * height, lap0, lap1, nullptr, &hm);
+    if (r != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     int32_t hdr[3];
     memcpy(hdr, hm.hdr, sizeof(hdr));

@@ -47,16 +47,6 @@ inline hipError_t hipStreamCreate(hipStream_t *s) { *s = simt::new_stream(); ret
 inline hipError_t hipStreamDestroy(hipStream_t s) { simt::sync_stream(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t s) { simt::sync_stream(s ? s : simt::null_stream()); return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { simt::wait_event(s, e); return hipSuccess; }
-// stream capture / graphs: not emulated -- orbx_extract falls back to direct launches (orbx_extractor::CallGraph::failed)
-typedef struct simt_graph *hipGraph_t;
-typedef struct simt_graph_exec *hipGraphExec_t;
-enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
-inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
-inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = nullptr; return hipErrorNotSupported; }
-inline hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return hipErrorNotSupported; }
-inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
-inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
-inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = simt::new_event(); return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = simt::new_event(); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { simt::sync_event(e); return hipSuccess; }
