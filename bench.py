@@ -353,10 +353,15 @@ class Rank:
     # The timed region runs with Python's cyclic garbage collector off (and the heap collected just before): a generation-2 collection
     # of a process that has imported torch takes 40-80 ms -- several times a whole 20-step timed region -- and landed inside it in
     # about one run in twenty (seen as a single 82 ms stall: 5.5 instead of 1.35 ms per step).  Host-harness noise, not the path's.
-    def timed_begin(self, extractors=()):
+    # `warm` = the W untimed warm-up steps, run AFTER the collection: the timed region then follows them directly.  (Until round 4 the collection sat
+    # between warm-up and region -- tens of milliseconds of an idle device, long enough for it to leave its working clocks: every 20-step region
+    # started cold.)
+    def timed_begin(self, extractors=(), warm=None):
         import gc
         gc.collect()
         gc.disable()
+        if warm is not None:
+            warm()
         self.barrier(extractors)
         return time.perf_counter()
 
@@ -522,8 +527,7 @@ def bench_euroc(R):
     host_enqueue = [0.0]   # seconds the host thread spent issuing work (HIP API calls through the C ABI), per timed region
 
     def timed(from_host):
-        run(max(a.warmup, 1), from_host)
-        t0 = R.timed_begin([ex])
+        t0 = R.timed_begin([ex], warm=lambda: run(max(a.warmup, 1), from_host))
         STAMPS.clear()
         host_enqueue[0] = 0.0
         feats = run(a.steps, from_host)
@@ -554,7 +558,8 @@ def bench_euroc(R):
     # ---- the K timed steps again, `repeat` regions in all (each between its own barriers): spread of the number above ----
     regions = [(dt_max, feats_all)]
     for _ in range(max(a.repeat, 1) - 1):
-        t0 = R.timed_begin([ex])
+        t0 = R.timed_begin([ex], warm=lambda: run(max(a.warmup, 1), False))
+        STAMPS.clear()
         f_r = run(a.steps, False)
         regions.append(R.reduce(R.timed_end(t0, [ex]), f_r))
         gaps.append(region_gaps())
@@ -780,12 +785,11 @@ def bench_kitti(R):
         return f
 
     settle(run, a)
-    run(max(a.warmup, 1))
 
     gaps = []
 
     def region():
-        t0 = R.timed_begin([exl, exr])
+        t0 = R.timed_begin([exl, exr], warm=lambda: run(max(a.warmup, 1)))
         STAMPS.clear()
         f_r = run(a.steps)
         out = R.reduce(R.timed_end(t0, [exl, exr]), f_r), f_r
@@ -936,12 +940,11 @@ def bench_tumvi(R):
 
     host_enqueue = [0.0]
     settle(run, a)
-    run(max(a.warmup, 1))
 
     gaps = []
 
     def region():
-        t0 = R.timed_begin([ex])
+        t0 = R.timed_begin([ex], warm=lambda: run(max(a.warmup, 1)))
         host_enqueue[0] = 0.0
         STAMPS.clear()
         f_r = run(a.steps)
