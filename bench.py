@@ -956,11 +956,13 @@ def bench_tumvi(R):
     per_rank = R.per_rank
     enq = host_enqueue[0]
     last = hs[(a.steps - 1) % 2]
-    last_snapshot = {k: v.clone() for k, v in last.items()}   # the delivered step that the parity check reads (later regions reuse the buffers)
+    # Every region processes the same frames, so the last region's final step is what the parity check reads.  (Rounds 2-3 cloned the first region's
+    # delivered step here -- 15 MB of pinned result buffers into fresh pageable memory -- and THAT was TUM-VI's "slow mode": in two of three processes
+    # the device stalled once for 20 - 60 ms about 25 ms later, inside the second region; without the clone, never: profiles/r04_m_*.)
     regions = [(dt_max, feats_all)] + [region()[0] for _ in range(max(a.repeat, 1) - 1)]
     R.per_rank = per_rank
     host_enqueue[0] = enq
-    last = last_snapshot
+    last = hs[(a.steps - 1) % 2]
 
     parity = None
     if R.rank == 0 and a.verify > 0:
