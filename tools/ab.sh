@@ -1,7 +1,7 @@
 #!/bin/bash
 # Hardware A/B of environment switches on the bench's timed loop (one script instead of one per experiment).
 #   usage: bash tools/ab.sh [-t tag] [-w "euroc kitti tumvi"] [-r reps] [-p] [-v] VARIANT...
-#     VARIANT   environment assignments in one word list, e.g. "ORBX_MATCH_DEFER=1" or "ORBX_NONE=1" (the default build) or "A=1 B=2"
+#     VARIANT   environment assignments in one word list, e.g. "ORBX_SIDE_STREAMS=0" or "ORBX_NONE=1" (the default build) or "A=1 B=2"
 #     -r reps   interleaved repetitions of the whole variant list (default 2): box drift shows up as a difference between repetitions
 #     -p        also a serialized rocprofv3 --kernel-trace --stats pass per variant (euroc child, ORBX_SIDE_STREAMS=0) -> <tag>_<i>_kernel_stats.csv
 #     -v        keep the bench's full parity check on (default: --verify 4 stays on; -V turns it off for speed)

@@ -14,7 +14,7 @@ timeout 900 python3 -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest
 cut -c1-300 $O/profiles_copy/${TAG}_bench_euroc.json; echo
 ORBX_SIDE_STREAMS=0 timeout 60 rocprofv3 --kernel-trace --stats -d $O/se -o se -- $CHILD --steps 12 --warmup 3 > /dev/null 2>&1
 python tools/rocprof_summary.py $(biggest_db $O/se) $O/profiles_copy/${TAG}_serialized_kernel_stats.csv
-python3 tools/rocprof_dispatches.py $(biggest_db $O/se) | grep -i "march\|strip\|chain" > $O/profiles_copy/${TAG}_dispatches.txt
+python3 tools/rocprof_dispatches.py $(biggest_db $O/se) | grep -i "march\|strip\|blur" > $O/profiles_copy/${TAG}_dispatches.txt
 ORBX_SIDE_STREAMS=0 timeout 60 rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $O/pf -o pf -- $CHILD --steps 3 --warmup 1 > /dev/null 2>&1
 ORBX_SIDE_STREAMS=0 timeout 60 rocprofv3 --pmc WRITE_SIZE -d $O/pw -o pw -- $CHILD --steps 3 --warmup 1 > /dev/null 2>&1
 python tools/pmc_summary.py $(biggest_db $O/pf) $(biggest_db $O/pw) $TAG && cp profiles/${TAG}_pmc_traffic.csv $O/profiles_copy/
