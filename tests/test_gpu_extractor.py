@@ -334,6 +334,7 @@ def test_cpp_adapter_end_to_end(canvas1, tmp_path):
     (1280, 720, 3000, 1.3, 6, 20, 7),    # HD frame, > 2048 candidates on level 0 (quad-tree key buffers spill to global)
     (1226, 370, 2000, 1.2, 8, 12, 7),    # KITTI 04-12 shape
     (1600, 300, 1200, 1.2, 4, 20, 7),    # panorama: 6 quad-tree roots (single-wave form of k_octree_par)
+    (752, 480, 500, 2.5, 3, 20, 7),      # scale factor above 2: the table form of the resize (k_pyr_resize2; a dword column's taps more than 8 source bytes apart)
     (1920, 1080, 4000, 1.2, 8, 20, 7),   # full HD: a skipped cell at level 2 (ORBextractor.cc:819), > 4096 candidates on level 0, blur strips of 8 x 26 items per level 0
 ])
 def test_parameter_sweep(w, h, nf, scale, nlevels, ini, mn):
