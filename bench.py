@@ -107,7 +107,7 @@ def roofline_from_profile(ex, prof, passes, sizes, n_frames, n_feat, n_cand, lau
 # they do not fit one pass) over a short serialized child run of this same file, parsed from rocprofv3's database
 # ---------------------------------------------------------------------------------------------------------
 # a profile slot may cover more than one kernel: the FAST stage = first pass for every cell + the list pass over the cells it left
-STAGE_KERNELS = {"k_fast_strip": ("k_fast_strip", "k_fast_wave_list", "k_fast_cells"), "k_octree": ("k_compact", "k_octree_par_t", "k_octree_par1", "k_octree"),
+STAGE_KERNELS = {"k_fast_strip": ("k_fast_strip", "k_fast_wave_list", "k_fast_cells"), "k_octree": ("k_octree_par_t", "k_octree_rest", "k_octree"),
                  "k_window_best2": ("k_grid_build", "k_window_best2")}
 
 

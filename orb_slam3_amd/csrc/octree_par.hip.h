@@ -738,7 +738,7 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
 }
 
 // The 256-thread form handles a (frame, level) when its keys fit the LDS buffers, it has at most four roots and node indices
-// fit 11 bits; k_octree_par1 (one wave, chunked passes over global key buffers) handles the others.  Both kernels are
+// fit 11 bits; the single-wave chunked form (one wave, passes over global key buffers: k_octree_rest) handles the others.  Both kernels are
 // launched over all (frame, level) pairs and each returns at once for the pairs that belong to the other.
 __device__ __forceinline__ bool oct_blk_form(const LevelInfo &L, int C) { return C <= kOctParLdsKeys && L.nIni <= 4 && L.pool <= 2047; }
 
@@ -746,7 +746,7 @@ __device__ __forceinline__ bool oct_blk_form(const LevelInfo &L, int C) { return
 // needs 45 KB of LDS and 161 VGPRs (three workgroups per CU), and a level with 1100 candidates still walks 17 key slots per thread in
 // every unrolled sweep.  The small tier (LO < C <= 2048: every level of the EuRoC-shaped bench) has 9 slots, 118 VGPRs and 33 KB:
 // four workgroups per CU (2048 workgroups = two dispatch rounds instead of three) and about 30 % fewer instructions; levels with
-// 2048 < C <= 4096 take the second launch, the rest k_octree_par1.  Round 3, profiles/r03_a_ab_prepared_kernels.log: step 1.175 ->
+// 2048 < C <= 4096 and the rest take the second launch (k_octree_rest).  Round 3, profiles/r03_a_ab_prepared_kernels.log: step 1.175 ->
 // 1.142 ms against the single-tier kernel, which is gone.
 // grid (B, nlevels), block 256, dynamic LDS = oct_par_pool_bytes(max pool) + KEYS * 6
 template <int KEYS, int LO>
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256, (KEYS <= 2048 ? 4 : 3)) void k_octree_par_t(co
     uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
     int C;
     if (LO < 0 && cellcnt) {   // the first tier gathers vToDistributeKeys of EVERY (frame, level) itself (k_compact's work without its launch: the
-                               // later tiers and k_octree_par1 read the keys and the count it leaves behind)
+                               // second launch reads the keys and the count it leaves behind)
         C = __builtin_amdgcn_readfirstlane(compact_level(L, cellcnt + (size_t)f * total_cells + L.cell_base,
                                                          cellent + (size_t)f * ent_frame_stride + L.cand_off, gk1));
         if (threadIdx.x == 0) cand_total[f * nlevels + level] = C;
@@ -773,23 +773,34 @@ __global__ __launch_bounds__(256, (KEYS <= 2048 ? 4 : 3)) void k_octree_par_t(co
                                 lvlcnt + f * nlevels + level, err, nullptr);
 }
 
-// grid (B, nlevels), block 64, dynamic LDS = oct_par_pool_bytes(max pool)
-__global__ __launch_bounds__(64) void k_octree_par1(const LevelInfo *__restrict__ lv, size_t ent_frame_stride, uint32_t *__restrict__ keys0,
-                                                    uint32_t *__restrict__ keys1, uint16_t *__restrict__ nof0, uint16_t *__restrict__ nof1,
-                                                    uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt,
-                                                    int nlevels, const int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool) {
+// k_octree_rest (round 4): the second tier of the 256-thread form (2048 < C <= 4096) and the single-wave chunked form (levels the 256-thread form does not
+// take: more than 4096 candidates, more than four roots, a node pool beyond 2047) as ONE launch.  Both are near-empty launches for the bench's frames
+// (every level has at most 2048 candidates), 5 us each plus a launch boundary on the latency-bound stretch between the FAST strips and k_describe -- and
+// on every single-frame call.  A workgroup reads its level's candidate count (left by the first tier) and takes the form that applies; in the
+// single-wave form waves 1..3 leave at once.
+// grid (B, nlevels), block 256, dynamic LDS = max(oct_par_lds_bytes(max pool), oct_par_pool_bytes(max pool))
+__global__ __launch_bounds__(256, 3) void k_octree_rest(const LevelInfo *__restrict__ lv, size_t ent_frame_stride, uint32_t *__restrict__ keys0,
+                                                        uint32_t *__restrict__ keys1, uint16_t *__restrict__ nof0, uint16_t *__restrict__ nof1,
+                                                        uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt,
+                                                        int nlevels, const int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int level = blockIdx.y, f = blockIdx.x;
     const LevelInfo L = lv[level];
     int32_t *cnt_out = lvlcnt + f * nlevels + level;
     const int C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
-    if (oct_blk_form(L, C)) return;
+    uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
+    if (oct_blk_form(L, C)) {
+        if (C <= 2048) return;   // the first tier's (k_octree_par_t<2048, -1>)
+        octree_par_body<true, kOctParLdsKeys>(L, smem, max_pool, C, nullptr, gk1, nullptr, nullptr, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off, cnt_out,
+                                              err, nullptr);
+        return;
+    }
+    if (threadIdx.x >= 64) return;   // the chunked form is one wave's
     if (C >= 0xfffff) {  // the best-response pick packs the key position into 20 bits
         if (threadIdx.x == 0) { atomicExch(err, 2); *cnt_out = 0; }
         return;
     }
     uint32_t *gk0 = keys0 + (size_t)f * ent_frame_stride + L.cand_off;
-    uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
     uint16_t *gn0 = nof0 + (size_t)f * ent_frame_stride + L.cand_off;
     uint16_t *gn1 = nof1 + (size_t)f * ent_frame_stride + L.cand_off;
     octree_par_body<false>(L, smem, max_pool, C, gk0, gk1, gn0, gn1, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off, cnt_out, err, nullptr);
