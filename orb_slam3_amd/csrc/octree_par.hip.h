@@ -28,6 +28,7 @@
 namespace orbx {
 
 constexpr int kOctParLdsKeys = 4096;  // keys (and node-of-key entries) kept in LDS
+constexpr int kOctTier1Keys = 1792;   // first tier of the 256-thread form (k_octree_par_t<kOctTier1Keys, -1>): 7 key slots per thread
 constexpr int kOctBlkE = 17;          // keys per thread of the 256-thread form: ceil(C / 256) | 1 (odd: conflict-free LDS stride)
 
 // ordering point for code that only ONE wave executes (LDS operations of a wave are performed in issue order; the
@@ -746,11 +747,12 @@ __device__ __forceinline__ bool oct_blk_form(const LevelInfo &L, int C) { return
 // needs 45 KB of LDS and 161 VGPRs (three workgroups per CU), and a level with 1100 candidates still walks 17 key slots per thread in
 // every unrolled sweep.  The small tier (LO < C <= 2048: every level of the EuRoC-shaped bench) has 9 slots, 118 VGPRs and 33 KB:
 // four workgroups per CU (2048 workgroups = two dispatch rounds instead of three) and about 30 % fewer instructions; levels with
-// 2048 < C <= 4096 and the rest take the second launch (k_octree_rest).  Round 3, profiles/r03_a_ab_prepared_kernels.log: step 1.175 ->
+// 2048 < C <= 4096 and the rest take the second launch (k_octree_rest).  Round 4: the first tier at 1792 keys (7 slots per thread) and 96 VGPRs
+// (__launch_bounds__(256, 5): five spilled registers) fits FIVE workgroups per CU (31.7 KB of LDS each): 89 -> 85 us, TUM-VI step -1.8 %.  Round 3, profiles/r03_a_ab_prepared_kernels.log: step 1.175 ->
 // 1.142 ms against the single-tier kernel, which is gone.
 // grid (B, nlevels), block 256, dynamic LDS = oct_par_pool_bytes(max pool) + KEYS * 6
 template <int KEYS, int LO>
-__global__ __launch_bounds__(256, (KEYS <= 2048 ? 4 : 3)) void k_octree_par_t(const LevelInfo *__restrict__ lv, size_t ent_frame_stride,
+__global__ __launch_bounds__(256, (KEYS <= 2048 ? 5 : 3)) void k_octree_par_t(const LevelInfo *__restrict__ lv, size_t ent_frame_stride,
                                                                               uint32_t *__restrict__ keys1, uint32_t *__restrict__ lvlkp,
                                                                               size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt, int nlevels,
                                                                               int32_t *__restrict__ cand_total, int32_t *__restrict__ err,
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(256, 3) void k_octree_rest(const LevelInfo *__restr
     const int C = __builtin_amdgcn_readfirstlane(cand_total[f * nlevels + level]);
     uint32_t *gk1 = keys1 + (size_t)f * ent_frame_stride + L.cand_off;
     if (oct_blk_form(L, C)) {
-        if (C <= 2048) return;   // the first tier's (k_octree_par_t<2048, -1>)
+        if (C <= kOctTier1Keys) return;   // the first tier's (k_octree_par_t<kOctTier1Keys, -1>)
         octree_par_body<true, kOctParLdsKeys>(L, smem, max_pool, C, nullptr, gk1, nullptr, nullptr, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off, cnt_out,
                                               err, nullptr);
         return;

@@ -481,13 +481,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             // vToDistributeKeys of every (frame, level) is gathered by the first tier itself (compact_level): as a launch of its own (k_compact, rounds 1-3)
             // it took 24 us + a launch boundary on the main stream's latency-bound stretch, inside the tier 13 us (profiles/r03_am)
             const size_t lds = oct_par_lds_bytes(ex->max_pool), lds1 = oct_par_pool_bytes(ex->max_pool);
-            const size_t lds_s = oct_par_pool_bytes(ex->max_pool) + (size_t)2048 * 6;
+            const size_t lds_s = oct_par_pool_bytes(ex->max_pool) + (size_t)kOctTier1Keys * 6;
             const size_t lds_r = std::max(lds, lds1);
             if (lds_r > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_rest, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-            if (lds_s > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<2048, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            if (lds_s > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_par_t<kOctTier1Keys, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
             // the 256-thread form for levels with at most 2048 candidates (every level of the EuRoC-shaped bench), then ONE launch for everything else:
             // 2049 .. 4096 candidates in the 256-thread form with the larger key buffers, the rest in the single-wave chunked form (k_octree_rest)
-            hipLaunchKernelGGL((k_octree_par_t<2048, -1>), dim3(n, nl), dim3(256), lds_s, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
+            hipLaunchKernelGGL((k_octree_par_t<kOctTier1Keys, -1>), dim3(n, nl), dim3(256), lds_s, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys1.p,
                                (uint32_t *)ex->d_lvlkp.p, ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (int32_t *)ex->d_candtot.p,
                                (int32_t *)ex->d_err.p, ex->max_pool, (const int32_t *)ex->d_cellcnt.p,
                                ex->total_cells, (const uint32_t *)ex->d_cellent.p);
