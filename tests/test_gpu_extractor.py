@@ -148,6 +148,23 @@ def test_strict_and_ocv440_modes(canvas1):
         _check_frame(ex, oex, img, (0, 1000), stagewise=False)
 
 
+def test_ocv440_blur_taps_in_a_batch(canvas1):
+    """The <= 4.5.0 Gaussian tap table (sum 257: k_blur_stream<SAT = true> clamps before it takes the result byte) through the BATCHED path: nine frames,
+    wave-per-strip item streams that cross frame boundaries; blurred levels and descriptors == oracle."""
+    import torch
+    from orb_slam3_amd import synth
+    ex, oex = _pair(600, flags=2)
+    frames = np.stack([synth.frame_from_canvas(canvas1, t, 424, 318, 4100 + t) for t in range(9)])
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), 9, 424, 318, 424, 424 * 318, (0, 1000))
+    for f in (0, 4, 8):
+        mono, kps, desc = ex.download(f)
+        omono, okps, odesc = oex.extract(frames[f], lap=(0, 1000))
+        for l in range(8):
+            assert np.array_equal(ex.debug_blurred(l, f), oex.level_blurred(l)), (f, l)
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
+
+
 def test_flat_and_noise_images():
     """Edge cases: constant image (no corners at all -> 0 keypoints), pure noise (fallback threshold everywhere)."""
     ex, oex = _pair(1000)
