@@ -65,7 +65,8 @@ def algorithmic_bytes(sizes, n_frames, feats, cands):
     per = {
         "k_pyr_base": 2 * px[0] * n_frames,                       # image read + level-0 write
         "k_pyr_resize": ((P - px[-1]) + (P - px[0])) * n_frames,  # the whole chain; divided by its launches per step in roofline_from_profile
-        "k_fast_strip": P * n_frames + 4 * Cn,                      # FAST stage: pyramid read + packed candidates (k_fast_strip + its list pass k_fast_wave_list)
+        "k_fast_strip": P * n_frames + 12 * Cn,                     # FAST stage (k_fast_strip + its list pass k_fast_wave_list): pyramid read + candidates at SURVEY.md
+                                                                    # 8(d)'s 12 bytes (x, y, score) -- the kernels pack a candidate into 4 bytes; through round 3 the line used 4 * C
         "k_blur": 2 * P * n_frames,
         "k_octree": 8 * Cn + 4 * N,                               # candidates read + gathered, keypoints out
         "k_finalize": 16 * N,
