@@ -1192,6 +1192,76 @@ struct HostMirror {
     const int32_t *err, *mono;
 };
 
+// IC_Angle + steered BRIEF + keypoint record of the half's keypoint from its two patches in LDS (the tail k_describe and k_describe_fused share).
+// c0 = centre of the orientation patch (pitch AP) + this lane's disc column du; bc = centre of the blurred patch (pitch BP)
+template <int AP, int BP>
+__device__ __forceinline__ void describe_tail(const uint8_t *c0, const uint8_t *bc, const int dvmax, const int du, const int hw, const int hl,
+                                              const uint32_t (&pat8)[8], const int strict_mul_add, const bool live, const WorkItem &w, const int kx,
+                                              const int ky, const int f, const int cap, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                              const HostMirror &hm) {
+    // ---- IC_Angle (:76-103): lane = disc column, m_10 = u * sum I, m_01 = sum v * I ----
+    int sumI = 0, m01 = 0;
+#pragma unroll
+    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
+        if ((v < 0 ? -v : v) <= dvmax) {
+            const int I = c0[v * AP];
+            sumI += I;
+            m01 += v * I;
+        }
+    }
+    const int s10 = wave_incl_scan(du * sumI), s01 = wave_incl_scan(m01);
+    const int a10 = __builtin_amdgcn_readlane(s10, 31), b10 = __builtin_amdgcn_readlane(s10, 63);
+    const int a01 = __builtin_amdgcn_readlane(s01, 31), b01 = __builtin_amdgcn_readlane(s01, 63);
+    const int M10 = hw ? b10 - a10 : a10, M01 = hw ? b01 - a01 : a01;
+    const float angle = fast_atan2_deg((float)M01, (float)M10);
+
+    // ---- steered BRIEF on the blurred patch ----
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    glibc_sincosf(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
+    constexpr float kMagic = 12582912.f;           // cvRound by magic add, see k_describe
+    constexpr uint32_t kMagicBits = 0x4B400000u;
+    const uint32_t cbm = (uint32_t)(uintptr_t)bc - (0x400000u * (uint32_t)BP + kMagicBits);
+    uint32_t mine = 0;   // lanes 0..7 of a half end up with descriptor dword hl of the half's keypoint
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const char4 pt = __builtin_bit_cast(char4, pat8[it]);
+        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
+        float r0, q0, r1, q1;
+        if (strict_mul_add) {
+            r0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
+            q0 = __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
+            r1 = __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
+            q1 = __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
+        } else {  // GCC -O3 -march=native: fma(x, b, y*a), fma(x, a, -(y*b))
+            r0 = __fmaf_rn(x0, b, __fmul_rn(y0, a));
+            q0 = __fmaf_rn(x0, a, -__fmul_rn(y0, b));
+            r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
+            q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
+        }
+        const uint32_t a0 = __umul24(__float_as_uint(__fadd_rn(r0, kMagic)), (uint32_t)BP) + __float_as_uint(__fadd_rn(q0, kMagic)) + cbm;
+        const uint32_t a1 = __umul24(__float_as_uint(__fadd_rn(r1, kMagic)), (uint32_t)BP) + __float_as_uint(__fadd_rn(q1, kMagic)) + cbm;
+        const int t0 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a0);
+        const int t1 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a1);
+        const unsigned long long bal = __ballot(t0 < t1);
+        const uint32_t half_bits = hw ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+        mine = hl == it ? half_bits : mine;
+    }
+    if (!live) return;
+    const size_t slot = (size_t)f * cap + w.pos;
+    if (hl < 8) reinterpret_cast<uint32_t *>(desc + slot * 32)[hl] = mine;
+    if (hm.hdr && hl < 8) reinterpret_cast<uint32_t *>(hm.desc + (size_t)w.pos * 32)[hl] = mine;
+    if (hl == 0) {
+        orbx_keypoint kp;
+        float x = (float)kx, y = (float)ky;
+        if (w.level != 0) { x = __fmul_rn(x, w.scale); y = __fmul_rn(y, w.scale); }
+        kp.x = x; kp.y = y; kp.size = w.size; kp.angle = angle; kp.response = (float)key_s(w.key);
+        kp.octave = w.level; kp.class_id = -1;
+        kps[slot] = kp;
+        if (hm.hdr) hm.kps[w.pos] = kp;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_describe: IC_Angle on the UNBLURRED level (:76-103), steered 256-pair BRIEF on the BLURRED level (:107-146), keypoint record +
 // descriptor written to the final slot.  TWO keypoints per wave, one per half (32 lanes): about a third of the one-keypoint-per-wave
@@ -1262,68 +1332,131 @@ __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ 
     }
     wave_lds_sync();
 
-    // ---- IC_Angle (:76-103): lane = disc column, m_10 = u * sum I, m_01 = sum v * I ----
-    const uint8_t *c0 = A + kHalfPatch * kDescAP + kHalfPatch + axA + du;
-    int sumI = 0, m01 = 0;
-#pragma unroll
-    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
-        if ((v < 0 ? -v : v) <= dvmax) {
-            const int I = c0[v * kDescAP];
-            sumI += I;
-            m01 += v * I;
-        }
-    }
-    const int s10 = wave_incl_scan(du * sumI), s01 = wave_incl_scan(m01);
-    const int a10 = __builtin_amdgcn_readlane(s10, 31), b10 = __builtin_amdgcn_readlane(s10, 63);
-    const int a01 = __builtin_amdgcn_readlane(s01, 31), b01 = __builtin_amdgcn_readlane(s01, 63);
-    const int M10 = hw ? b10 - a10 : a10, M01 = hw ? b01 - a01 : a01;
-    const float angle = fast_atan2_deg((float)M01, (float)M10);
+    describe_tail<kDescAP, kDescBP>(A + kHalfPatch * kDescAP + kHalfPatch + axA + du, Bp + 18 * kDescBP + 18 + axB, dvmax, du, hw, hl, pat8, strict_mul_add, live, w,
+                                    kx, ky, f, cap, kps, desc, hm);
+}
 
-    // ---- steered BRIEF on the blurred patch ----
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    glibc_sincosf(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
-    constexpr float kMagic = 12582912.f;           // cvRound by magic add, see k_describe
-    constexpr uint32_t kMagicBits = 0x4B400000u;
-    const uint32_t cbm = (uint32_t)(uintptr_t)(Bp + 18 * kDescBP + 18 + axB) - (0x400000u * (uint32_t)kDescBP + kMagicBits);
-    uint32_t mine = 0;   // lanes 0..7 of a half end up with descriptor dword hl of the half's keypoint
+// ---------------------------------------------------------------------------------------------------------
+// k_describe_fused (round 4): k_describe with the GaussianBlur of :1132-1133 computed ON DEMAND -- the 37 x 37 blurred pixels the steered
+// pattern can reach (|rotated coordinate| <= 18), from the 43 x 43 raw pixels around the keypoint -- instead of read back from a blurred copy
+// of the whole pyramid.  The blur is linear up to its final rounding (k_blur_stream: sum of tap products + 32768, byte 2, saturated for the
+// <= 4.5.0 taps), and the ring of a level in the pyramid slab IS its BORDER_REFLECT_101 extension, so the values are the ones k_blur_stream
+// writes.  What it trades: no k_blur_stream launch (2 P bytes per frame read + written) and one 43-row patch read per keypoint instead of a
+// 31-row and a 37-row one, against 19 row filters per lane.
+//   lanes of a half (one keypoint): three segments of ten dword columns, lane = (segment, column c); columns 4 c .. 4 c + 3 from the aligned
+//     dword that holds pixel kx - 18; segment s filters raw rows R0 .. R0 + 18 (R0 = 0, 13, 25 counted from row ky - 21) into blurred rows
+//     R0 .. R0 + 12 (counted from ky - 18): 13 + 12 (+ 1 again) + 12 (+ 1 never read) rows, the same code in every segment
+//   a row = the lane's own dword + one load more for the dwords left of column 0 / right of column 9 (no memory access for the lanes between);
+//     the neighbours' dwords of the 12-pixel window come over DPP (wave_shr / wave_shl) like in k_blur_stream
+//   the raw rows go to LDS as they are (orientation patch: rows ky - 21 .. ky + 22, IC_Angle reads ky - 15 .. ky + 15), the blurred ones beside them;
+//     lanes 30 / 31 of a half run along as columns 10 / 11 of segment 2 (offsets outside the descriptor: zeros) and write the two pad dwords of a row
+// grid xcd_grid(ceil(cap / 8), B), block 256
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kDfP = 48;                  // pitch of both patches in LDS: 12 dwords per row, 10 used
+constexpr int kDfAR = 44, kDfBR = 38;     // raw rows ky - 21 .. ky + 22, blurred rows ky - 18 .. ky + 19
+constexpr int kDfRows = 19;               // raw rows per segment
+constexpr int kDfWaveLds = kDfP * (kDfAR + kDfBR);   // 3936 B per keypoint
+static_assert(kDfWaveLds % 16 == 0, "LDS carve");
+
+template <bool SAT>
+__global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
+                                                         const int32_t *__restrict__ count, int cap, const uint8_t *__restrict__ pyr,
+                                                         size_t pyr_frame_stride, int g0, int g1, int g2, int g3, orbx_keypoint *__restrict__ kps,
+                                                         uint8_t *__restrict__ desc, int strict_mul_add, int n_frames, const HostMirror hm) {
+    __shared__ __attribute__((aligned(16))) uint8_t patches[4 * 2 * kDfWaveLds];
+    int bx, f;
+    if (!xcd_frame_map(n_frames, &bx, &f)) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, hw = lane >> 5, hl = lane & 31;
+    const int cnt = count[f];
+    if (hm.hdr && bx == 0 && f == 0 && threadIdx.x == 0) { hm.hdr[0] = *hm.err; hm.hdr[1] = cnt; hm.hdr[2] = hm.mono[0]; }
+    const int g0i = (bx * 4 + wv) * 2;   // first keypoint of the wave
+    if (g0i >= cnt) return;              // wave-uniform
+    const bool live = g0i + hw < cnt;    // an odd count: the last wave's second half repeats the last keypoint and stores nothing
+    const WorkItem w = work[(size_t)f * cap + min(g0i + hw, cnt - 1)];
+    uint8_t *A = patches + (wv * 2 + hw) * kDfWaveLds;
+    uint8_t *Bp = A + kDfP * kDfAR;
+    const int pitch = (int)(w.pitches & 0xffffu);
+    const int kx = key_x(w.key), ky = key_y(w.key);
+    const int du = hl - kHalfPatch;
+    const int dvmax = hl <= 2 * kHalfPatch ? dc->vmax_of_u[du < 0 ? -du : du] : -1;
+    uint32_t pat8[8];
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const char4 pt = __builtin_bit_cast(char4, pat8[it]);
-        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
-        float r0, q0, r1, q1;
-        if (strict_mul_add) {
-            r0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
-            q0 = __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
-            r1 = __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
-            q1 = __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
-        } else {  // GCC -O3 -march=native: fma(x, b, y*a), fma(x, a, -(y*b))
-            r0 = __fmaf_rn(x0, b, __fmul_rn(y0, a));
-            q0 = __fmaf_rn(x0, a, -__fmul_rn(y0, b));
-            r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
-            q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
+    for (int it = 0; it < 8; it++) pat8[it] = reinterpret_cast<const uint32_t *>(dc->pat)[it * 32 + hl];
+
+    const int seg = hl < 10 ? 0 : hl < 20 ? 1 : 2, c = hl - 10 * seg, R0 = seg == 0 ? 0 : seg == 1 ? 13 : 25;
+    const int axB = (kx - 18) & 3;
+    uint32_t vc[kDfRows], ve[kDfRows];
+    {
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(pyr + (size_t)f * pyr_frame_stride), 0, (int)min(pyr_frame_stride, (size_t)0x7fffffff), 0x00020000);
+        constexpr uint32_t kOut = 0x80000000u;   // an offset outside the descriptor: no memory access, the load returns 0
+        const uint32_t own = w.off + (uint32_t)((kEdge + ky - 21 + R0) * pitch + kRoiX + (kx - 18 - axB) + 4 * c);
+        const uint32_t offC = c < 10 ? own : kOut, offE = c == 0 ? own - 4u : c == 9 ? own + 4u : kOut;
+#pragma unroll
+        for (int k = 0; k < kDfRows; k++) {
+            vc[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, (int)(offC + (uint32_t)(k * pitch)), 0, 0);
+            ve[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, (int)(offE + (uint32_t)(k * pitch)), 0, 0);
         }
-        const uint32_t a0 = __umul24(__float_as_uint(__fadd_rn(r0, kMagic)), (uint32_t)kDescBP) + __float_as_uint(__fadd_rn(q0, kMagic)) + cbm;
-        const uint32_t a1 = __umul24(__float_as_uint(__fadd_rn(r1, kMagic)), (uint32_t)kDescBP) + __float_as_uint(__fadd_rn(q1, kMagic)) + cbm;
-        const int t0 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a0);
-        const int t1 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a1);
-        const unsigned long long bal = __ballot(t0 < t1);
-        const uint32_t half_bits = hw ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-        mine = hl == it ? half_bits : mine;
     }
-    if (!live) return;
-    const size_t slot = (size_t)f * cap + w.pos;
-    if (hl < 8) reinterpret_cast<uint32_t *>(desc + slot * 32)[hl] = mine;
-    if (hm.hdr && hl < 8) reinterpret_cast<uint32_t *>(hm.desc + (size_t)w.pos * 32)[hl] = mine;
-    if (hl == 0) {
-        orbx_keypoint kp;
-        float x = (float)kx, y = (float)ky;
-        if (w.level != 0) { x = __fmul_rn(x, w.scale); y = __fmul_rn(y, w.scale); }
-        kp.x = x; kp.y = y; kp.size = w.size; kp.angle = angle; kp.response = (float)key_s(w.key);
-        kp.octave = w.level; kp.class_id = -1;
-        kps[slot] = kp;
-        if (hm.hdr) hm.kps[w.pos] = kp;
+    {
+        // horizontal taps of the four pixels of a dword over its 12-pixel window (m | c | p), as byte vectors for v_dot4 (k_blur_stream's)
+        auto tapd = [&](int d) -> uint32_t {
+            d = d < 0 ? -d : d;
+            return d == 0 ? (uint32_t)g3 : d == 1 ? (uint32_t)g2 : d == 2 ? (uint32_t)g1 : d == 3 ? (uint32_t)g0 : 0u;
+        };
+        uint32_t ht[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) v |= tapd(4 * q + b - (j + 4)) << (8 * b);
+                ht[j][q] = v;
+            }
+        const u16x2 vp0 = as_pk((uint32_t)g0 | ((uint32_t)g1 << 16));   // rows r-6, r-5
+        const u16x2 vp1 = as_pk((uint32_t)g2 | ((uint32_t)g3 << 16));   // rows r-4, r-3
+        const u16x2 vp2 = as_pk((uint32_t)g2 | ((uint32_t)g1 << 16));   // rows r-2, r-1
+        uint8_t *ad = A + R0 * kDfP + 4 * c, *bd = Bp + R0 * kDfP + 4 * c;
+        uint32_t pr[6][4];   // pr[q % 6] = (sums of row q-1) | (sums of row q) << 16
+        uint32_t hprev[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < kDfRows; k++) {
+            *reinterpret_cast<uint32_t *>(ad + k * kDfP) = vc[k];
+            uint32_t m = (uint32_t)__builtin_amdgcn_update_dpp((int)ve[k], (int)vc[k], 0x138, 0xf, 0xf, false);   // lane i <- lane i - 1
+            uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp((int)ve[k], (int)vc[k], 0x130, 0xf, 0xf, false);   // lane i <- lane i + 1
+            m = c == 0 ? ve[k] : m;   // the neighbour across a segment's end is another row's dword
+            p = c == 9 ? ve[k] : p;
+            uint32_t h[4];
+            h[0] = __builtin_amdgcn_udot4(vc[k], ht[0][1], __builtin_amdgcn_udot4(m, ht[0][0], 0u, false), false);
+            h[1] = __builtin_amdgcn_udot4(p, ht[1][2], __builtin_amdgcn_udot4(vc[k], ht[1][1], __builtin_amdgcn_udot4(m, ht[1][0], 0u, false), false), false);
+            h[2] = __builtin_amdgcn_udot4(p, ht[2][2], __builtin_amdgcn_udot4(vc[k], ht[2][1], __builtin_amdgcn_udot4(m, ht[2][0], 0u, false), false), false);
+            h[3] = __builtin_amdgcn_udot4(p, ht[3][2], __builtin_amdgcn_udot4(vc[k], ht[3][1], 0u, false), false);
+            const int s = k % 6;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                pr[s][j] = hprev[j] | (h[j] << 16);
+                hprev[j] = h[j];
+            }
+            if (k >= 6) {
+                uint32_t sum[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t a = __umul24(h[j], (uint32_t)g0) + 32768u;                        // row r
+                    a = __builtin_amdgcn_udot2(as_pk(pr[(s + 5) % 6][j]), vp2, a, false);      // rows r-2, r-1
+                    a = __builtin_amdgcn_udot2(as_pk(pr[(s + 3) % 6][j]), vp1, a, false);      // rows r-4, r-3
+                    a = __builtin_amdgcn_udot2(as_pk(pr[(s + 1) % 6][j]), vp0, a, false);      // rows r-6, r-5
+                    sum[j] = SAT ? min(a, 0x00ffffffu) : a;
+                }
+                const uint32_t lo = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u);    // byte 2 of sum[0], byte 2 of sum[1]
+                const uint32_t hi = __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);
+                *reinterpret_cast<uint32_t *>(bd + (k - 6) * kDfP) = lo | hi;
+            }
+        }
     }
+    wave_lds_sync();
+    describe_tail<kDfP, kDfP>(A + 21 * kDfP + 18 + axB + du, Bp + 18 * kDfP + 18 + axB, dvmax, du, hw, hl, pat8, strict_mul_add, live, w, kx, ky, f, cap,
+                              kps, desc, hm);
 }
 
 }  // namespace orbx

@@ -162,6 +162,8 @@ struct orbx_extractor {
     bool match_pending = false;
     bool copy_covers_match = false;   // the most recent download waited for ev_match on the copy stream: its ev_copy_done implies the matcher is done
     bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream
+    bool fused_blur = false;   // k_describe_fused (the blur on demand around the keypoints) instead of k_blur_stream + k_describe: chosen per geometry in
+                               // configure(), ORBX_FUSED_BLUR=0 / 1 forces
     hipEvent_t ev_stereo_copy[2] = {nullptr, nullptr};   // ends of the last two orbx_stereo_batch_download_async
     unsigned stereo_copy_issued = 0, stereo_copy_waited = 0;
     hipEvent_t ev_copy_done[2] = {nullptr, nullptr};  // ring: up to two downloads in flight

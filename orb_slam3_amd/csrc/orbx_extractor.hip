@@ -239,7 +239,17 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_blur_items, sizeof(BlurItem) * blur_items.size());
     ENS(ex->d_pyr, pyr_off * B);
     if (ex->pyr_double) ENS(ex->d_pyr2, pyr_off * B);
-    ENS(ex->d_blur, blur_off * B);
+    // The blur on demand (k_describe_fused) filters 43 x 43 pixels per keypoint, the blur pass (k_blur_stream) every pixel of the pyramid once and hides
+    // half of itself beside the FAST strips: measured (profiles/r04_s_ab_describe_fused_blur_*.log) the on-demand form wins while the keypoints'
+    // windows cover less than about 1.5 x the pyramid -- EuRoC 752x480 / 1000: 1.23 x, step -3.7 %; TUM-VI 1024x1024 / 1500: 0.64 x, -12 %;
+    // KITTI 1241x376 / 2000: 1.9 x, +3.8 %.  ORBX_FUSED_BLUR=0 / 1 forces either form.
+    {
+        size_t pyr_px = 0;
+        for (int l = 0; l < nl; l++) pyr_px += (size_t)lv[l].w * lv[l].h;
+        const char *v = getenv("ORBX_FUSED_BLUR");
+        ex->fused_blur = v && (v[0] == '0' || v[0] == '1') ? v[0] == '1' : (size_t)std::max(ex->prm.nfeatures, 0) * 1369 * 2 <= 3 * pyr_px;
+    }
+    if (!ex->fused_blur) ENS(ex->d_blur, blur_off * B);   // (orbx_debug_level_blurred allocates it when it is the only user)
     ENS(ex->d_cellcnt, sizeof(int32_t) * (size_t)cell_base * B);
     ENS(ex->d_cellent, sizeof(uint32_t) * (size_t)cand_off * B);
     ENS(ex->d_keys0, sizeof(uint32_t) * (size_t)cand_off * B);
@@ -371,6 +381,30 @@ struct ProfScope {
     }
 };
 
+// taps of GaussianBlur(7x7, sigma 2) in 8-bit fixed point: [OCV] >= 4.5.1 / <= 4.5.0 (ORBX_FLAG_BLUR_OCV440); the older ones sum to more than 1.0
+// and can exceed 255 (the saturating forms of the kernels)
+struct BlurTaps { int g[4]; bool sat; };
+static BlurTaps blur_taps(const orbx_extractor *ex) {
+    static const int kBlurNew[4] = {18, 34, 48, 56}, kBlurOld[4] = {18, 34, 49, 55};
+    const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
+    return BlurTaps{{bg[0], bg[1], bg[2], bg[3]}, 2 * (bg[0] + bg[1] + bg[2]) + bg[3] > 256};
+}
+// k_blur_stream over every strip of every level of the first n frames of the pyramid slab `pyr` into the blur slab
+static void launch_blur_stream(orbx_extractor *ex, int n, const uint8_t *pyr, hipStream_t bs) {
+    const BlurTaps bt = blur_taps(ex);
+    const int *bg = bt.g;
+    uint8_t *blur_slab = (uint8_t *)ex->d_blur.p;
+    const BlurItem *items = (const BlurItem *)ex->d_blur_items.p;
+    const int nitems = ex->n_blur_items;
+    const int nx = n >= 8 ? 8 : 1;
+    const long items_per_group = (long)((n + nx - 1) / nx) * nitems;
+    const int K = (int)std::max<long>(1, std::min<long>(ex->blur_waves / nx, items_per_group));
+    if (bt.sat) hipLaunchKernelGGL(k_blur_stream<true>, dim3(K * nx), dim3(64), 0, bs, items, nitems, pyr, ex->pyr_frame, blur_slab, ex->blur_frame,
+                                   bg[0], bg[1], bg[2], bg[3], n, nx);
+    else hipLaunchKernelGGL(k_blur_stream<false>, dim3(K * nx), dim3(64), 0, bs, items, nitems, pyr, ex->pyr_frame, blur_slab, ex->blur_frame,
+                            bg[0], bg[1], bg[2], bg[3], n, nx);
+}
+
 // enqueue the whole extraction of `n` device-resident frames on ex->stream
 static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride,
                            int lap0, int lap1, hipEvent_t ev_input_consumed = nullptr, const HostMirror *mirror = nullptr) {
@@ -394,21 +428,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     }
     if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));  // k_pyr_base is the only reader of the input frames
     const int ini_th = std::min(std::max(ex->prm.ini_th_fast, 0), 255), min_th = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini_th);
-    static const int kBlurNew[4] = {18, 34, 48, 56}, kBlurOld[4] = {18, 34, 49, 55};  // [OCV] >= 4.5.1 / <= 4.5.0 taps
-    const int *bg = (ex->prm.flags & ORBX_FLAG_BLUR_OCV440) ? kBlurOld : kBlurNew;
-    const bool sat = 2 * (bg[0] + bg[1] + bg[2]) + bg[3] > 256;   // taps summing to more than 1.0 (OpenCV <= 4.5.0) can exceed 255
-    auto blur_stream = [&](hipStream_t bs) {   // k_blur_stream over every strip of every level of every frame
-        const int waves = ex->blur_waves;
-        const BlurItem *items = (const BlurItem *)ex->d_blur_items.p;
-        const int nitems = ex->n_blur_items;
-        const int nx = n >= 8 ? 8 : 1;
-        const long items_per_group = (long)((n + nx - 1) / nx) * nitems;
-        const int K = (int)std::max<long>(1, std::min<long>(waves / nx, items_per_group));
-        if (sat) hipLaunchKernelGGL(k_blur_stream<true>, dim3(K * nx), dim3(64), 0, bs, items, nitems, (const uint8_t *)pyr,
-                                    ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n, nx);
-        else hipLaunchKernelGGL(k_blur_stream<false>, dim3(K * nx), dim3(64), 0, bs, items, nitems, (const uint8_t *)pyr,
-                                ex->pyr_frame, blur_slab, ex->blur_frame, bg[0], bg[1], bg[2], bg[3], n, nx);
-    };
+    const BlurTaps bt = blur_taps(ex);
     for (int l = 1; l < nl; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
@@ -435,12 +455,12 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         hipStream_t bs = side ? ex->aux_stream : st;
         if (side) ORBX_HIP(hipStreamWaitEvent(bs, ex->ev_pyr, 0));
         ProfScope ps(ex, K_BLUR);
-        blur_stream(bs);
+        launch_blur_stream(ex, n, pyr, bs);
         if (side) ORBX_HIP(hipEventRecord(ex->ev_blur, bs));
         return ORBX_OK;
     };
     ORBX_HIP(hipEventRecord(ex->ev_pyr, pst));                         // the pyramid of this batch is complete
-    { int r = launch_blur(); if (r != ORBX_OK) return r; }
+    if (!ex->fused_blur) { int r = launch_blur(); if (r != ORBX_OK) return r; }
     {
         ProfScope ps(ex, K_FAST);
         // one score map at min(ini, min) serves both passes of :830-846; for ini < min the reference's second pass FAST(min) is a
@@ -517,14 +537,24 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
                            (const int32_t *)ex->d_lvlcnt.p, (WorkItem *)ex->d_work.p, ex->cap, (int32_t *)ex->d_count.p,
                            (int32_t *)ex->d_mono.p, lap0, lap1, (int32_t *)ex->d_err.p);
     }
-    if (!ex->profile && ex->side_streams) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
+    if (!ex->fused_blur && !ex->profile && ex->side_streams) ORBX_HIP(hipStreamWaitEvent(st, ex->ev_blur, 0));
     {
         ProfScope ps(ex, K_DESCRIBE);
-        hipLaunchKernelGGL(k_describe, xcd_grid((ex->cap + 7) / 8, n), dim3(256), 0, st, (const DescConst *)ex->d_dc.p,
-                           (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr,
-                           ex->pyr_frame, (const uint8_t *)blur_slab, ex->blur_frame, (orbx_keypoint *)ex->d_kps.p,
-                           (uint8_t *)ex->d_desc.p, (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0, n,
-                           mirror && n == 1 ? *mirror : HostMirror{nullptr, nullptr, nullptr, nullptr, nullptr});
+        const HostMirror hm = mirror && n == 1 ? *mirror : HostMirror{nullptr, nullptr, nullptr, nullptr, nullptr};
+        const int strict = (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0;
+        const dim3 grid = xcd_grid((ex->cap + 7) / 8, n);
+        if (!ex->fused_blur)
+            hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p,
+                               (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr, ex->pyr_frame, (const uint8_t *)blur_slab,
+                               ex->blur_frame, (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm);
+        else if (bt.sat)   // the blur on demand, around the keypoints only (the blur slab is filled by orbx_debug_level_blurred alone)
+            hipLaunchKernelGGL(k_describe_fused<true>, grid, dim3(256), 0, st, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p,
+                               (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr, ex->pyr_frame, bt.g[0], bt.g[1], bt.g[2], bt.g[3],
+                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm);
+        else
+            hipLaunchKernelGGL(k_describe_fused<false>, grid, dim3(256), 0, st, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p,
+                               (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr, ex->pyr_frame, bt.g[0], bt.g[1], bt.g[2], bt.g[3],
+                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm);
     }
     if (ex->has_camera) {   // Frame::UndistortKeyPoints for the whole batch (mvKeysUn for the batched matchers)
         CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],
@@ -1063,6 +1093,11 @@ int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *
     const size_t bytes = (size_t)L.bpitch * L.h;
     int r = ex->d2h_staged_begin(bytes);
     if (r != ORBX_OK) return r;
+    if (ex->fused_blur) {   // k_describe_fused blurs around the keypoints only: fill the blur slab of the last batch now
+        if ((r = ex->d_blur.ensure(ex->blur_frame * (size_t)ex->batch_cap)) != ORBX_OK) return r;
+        launch_blur_stream(ex, ex->last_batch, ex->pyr_cur(), ex->stream);
+        ORBX_HIP(hipGetLastError());
+    }
     if ((r = ex->d2h_staged(0, (const uint8_t *)ex->d_blur.p + (size_t)frame * ex->blur_frame + L.boff, bytes)) != ORBX_OK) return r;
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     for (int y = 0; y < L.h; y++) memcpy(dst + (size_t)y * dst_stride, ex->staged((size_t)y * L.bpitch), (size_t)L.w);

@@ -165,6 +165,36 @@ def test_ocv440_blur_taps_in_a_batch(canvas1):
         assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_both_forms_of_the_blur(canvas1, monkeypatch, form):
+    """The descriptor stage has two forms, chosen per geometry (configure(), orbx_extractor.hip): k_blur_stream + k_describe (a blurred copy of the
+    pyramid) and k_describe_fused (the blur on demand, 43 x 43 raw pixels around each keypoint).  Both forced in turn (ORBX_FUSED_BLUR is read when a
+    geometry is configured) on: noise (keypoints at the smallest distance from every border, on every level), a KITTI-shaped and a small frame, the
+    <= 4.5.0 tap set (the saturating forms), a batch of nine frames; keypoints, descriptors and -- through orbx_debug_level_blurred, which fills the
+    blur slab on request in the fused form -- the blurred levels == oracle."""
+    import torch
+    from orb_slam3_amd import synth
+    monkeypatch.setenv("ORBX_FUSED_BLUR", form)
+    rng = np.random.default_rng(17)
+    noise = rng.integers(0, 256, (480, 752), dtype=np.uint8)
+    ex, oex = _pair(1000)
+    _check_frame(ex, oex, noise, (0, 1000), stagewise=True)
+    ex, oex = _pair(2000)
+    _check_frame(ex, oex, synth.frame_from_canvas(canvas1, 3, 1241, 376, 5100), (0, 0), stagewise=True)
+    ex, oex = _pair(300)
+    _check_frame(ex, oex, synth.make_test_image(8, 320, 240), (0, 1000), stagewise=True)
+    ex, oex = _pair(700, flags=2)   # ORBX_FLAG_BLUR_OCV440
+    frames = np.stack([noise[:318, :424]] + [synth.frame_from_canvas(canvas1, t, 424, 318, 4200 + t) for t in range(8)])
+    d = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+    ex.extract_batch_device(d.data_ptr(), 9, 424, 318, 424, 424 * 318, (0, 1000))
+    for f in (0, 5, 8):
+        mono, kps, desc = ex.download(f)
+        omono, okps, odesc = oex.extract(frames[f], lap=(0, 1000))
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
+        for l in (0, 7):
+            assert np.array_equal(ex.debug_blurred(l, f), oex.level_blurred(l)), (f, l)
+
+
 def test_flat_and_noise_images():
     """Edge cases: constant image (no corners at all -> 0 keypoints), pure noise (fallback threshold everywhere)."""
     ex, oex = _pair(1000)

@@ -52,12 +52,13 @@ print('emulation ok', n)
 """
 
 
-@pytest.mark.parametrize("env", [{"SIMT_SHUFFLE": "7", "SIMT_BLOCK_ORDER": "reverse", "SIMT_LANE_ORDER": "reverse", "SIMT_STRICT_LANES": "1"},
-                                 {"SIMT_LDS_RANDOM": "3", "SIMT_MALLOC_FILL": "r9", "SIMT_BLOCK_ORDER": "4", "SIMT_SHUFFLE": "5"}])
+@pytest.mark.parametrize("env", [{"SIMT_SHUFFLE": "7", "SIMT_BLOCK_ORDER": "reverse", "SIMT_LANE_ORDER": "reverse", "SIMT_STRICT_LANES": "1", "ORBX_FUSED_BLUR": "0"},
+                                 {"SIMT_LDS_RANDOM": "3", "SIMT_MALLOC_FILL": "r9", "SIMT_BLOCK_ORDER": "4", "SIMT_SHUFFLE": "5", "ORBX_FUSED_BLUR": "1"}])
 def test_emulated_extractor_small_image_stagewise(emul_lib, env):
     """Pyramid, blur, FAST candidates, quad-tree output, keypoints and descriptors of the emulated device code == oracle; also with the
     waves of every workgroup resumed in random order, the workgroups of every launch run last to first / in random order (the order
-    of global-atomic list appends), with random garbage in the dynamic LDS and in every device allocation."""
+    of global-atomic list appends), with random garbage in the dynamic LDS and in every device allocation; the first with the blurred copy of the
+    pyramid (k_blur_stream + k_describe), the second with the blur on demand (k_describe_fused)."""
     _child(STAGEWISE.replace("IMG", "synth.make_test_image(5, 320, 240)").replace("NF", "500"), env)
 
 
