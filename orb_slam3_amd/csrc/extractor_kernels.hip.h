@@ -1346,12 +1346,14 @@ __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ 
 //   lanes of a half (one keypoint): three segments of ten dword columns, lane = (segment, column c); columns 4 c .. 4 c + 3 from the aligned
 //     dword that holds pixel kx - 18; segment s filters raw rows R0 .. R0 + 18 (R0 = 0, 13, 25 counted from row ky - 21) into blurred rows
 //     R0 .. R0 + 12 (counted from ky - 18): 13 + 12 (+ 1 again) + 12 (+ 1 never read) rows, the same code in every segment
-//   a row = the lane's own dword + one load more for the dwords left of column 0 / right of column 9 (no memory access for the lanes between);
-//     the neighbours' dwords of the 12-pixel window come over DPP (wave_shr / wave_shl) like in k_blur_stream
+//   a row = ONE 12-byte load per lane: the dword left of its column, its own, the one right of it (the kernel is bound by VALU issue: with the
+//     neighbours' dwords over DPP as in k_blur_stream, a row costs two v_mov_dpp + two v_cndmask at the segment ends on top of its 15 filter
+//     instructions; the overlapping loads hit the L1)
 //   the raw rows go to LDS as they are (orientation patch: rows ky - 21 .. ky + 22, IC_Angle reads ky - 15 .. ky + 15), the blurred ones beside them;
 //     lanes 30 / 31 of a half run along as columns 10 / 11 of segment 2 (offsets outside the descriptor: zeros) and write the two pad dwords of a row
 // grid xcd_grid(ceil(cap / 8), B), block 256
 // ---------------------------------------------------------------------------------------------------------
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 constexpr int kDfP = 48;                  // pitch of both patches in LDS: 12 dwords per row, 10 used
 constexpr int kDfAR = 44, kDfBR = 38;     // raw rows ky - 21 .. ky + 22, blurred rows ky - 18 .. ky + 19
 constexpr int kDfRows = 19;               // raw rows per segment
@@ -1386,17 +1388,14 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
 
     const int seg = hl < 10 ? 0 : hl < 20 ? 1 : 2, c = hl - 10 * seg, R0 = seg == 0 ? 0 : seg == 1 ? 13 : 25;
     const int axB = (kx - 18) & 3;
-    uint32_t vc[kDfRows], ve[kDfRows];
+    u32x3 vw[kDfRows];   // a row's 12-pixel window of this lane: the dword left of its own, its own, the dword right of it
     {
         const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(pyr + (size_t)f * pyr_frame_stride), 0, (int)min(pyr_frame_stride, (size_t)0x7fffffff), 0x00020000);
         constexpr uint32_t kOut = 0x80000000u;   // an offset outside the descriptor: no memory access, the load returns 0
         const uint32_t own = w.off + (uint32_t)((kEdge + ky - 21 + R0) * pitch + kRoiX + (kx - 18 - axB) + 4 * c);
-        const uint32_t offC = c < 10 ? own : kOut, offE = c == 0 ? own - 4u : c == 9 ? own + 4u : kOut;
+        const uint32_t offW = c < 10 ? own - 4u : kOut;
 #pragma unroll
-        for (int k = 0; k < kDfRows; k++) {
-            vc[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, (int)(offC + (uint32_t)(k * pitch)), 0, 0);
-            ve[k] = __builtin_amdgcn_raw_buffer_load_b32(srd, (int)(offE + (uint32_t)(k * pitch)), 0, 0);
-        }
+        for (int k = 0; k < kDfRows; k++) vw[k] = __builtin_amdgcn_raw_buffer_load_b96(srd, (int)(offW + (uint32_t)(k * pitch)), 0, 0);
     }
     {
         // horizontal taps of the four pixels of a dword over its 12-pixel window (m | c | p), as byte vectors for v_dot4 (k_blur_stream's)
@@ -1414,38 +1413,47 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
                 for (int b = 0; b < 4; b++) v |= tapd(4 * q + b - (j + 4)) << (8 * b);
                 ht[j][q] = v;
             }
-        const u16x2 vp0 = as_pk((uint32_t)g0 | ((uint32_t)g1 << 16));   // rows r-6, r-5
-        const u16x2 vp1 = as_pk((uint32_t)g2 | ((uint32_t)g3 << 16));   // rows r-4, r-3
-        const u16x2 vp2 = as_pk((uint32_t)g2 | ((uint32_t)g1 << 16));   // rows r-2, r-1
+        // Vertical taps over PAIRS of rows (v_dot2).  Only the pairs that start at an even row are formed (one v_lshl_or per pixel and row pair): an
+        // output row whose window starts at an odd row takes that row from the high half of the pair before it (taps 0, g0) and its last two rows as a pair.
+        const u16x2 te0 = as_pk((uint32_t)g0 | ((uint32_t)g1 << 16)), te1 = as_pk((uint32_t)g2 | ((uint32_t)g3 << 16)), te2 = as_pk((uint32_t)g2 | ((uint32_t)g1 << 16));
+        const u16x2 to0 = as_pk((uint32_t)g0 << 16), to1 = as_pk((uint32_t)g1 | ((uint32_t)g2 << 16)), to2 = as_pk((uint32_t)g3 | ((uint32_t)g2 << 16)),
+                    to3 = as_pk((uint32_t)g1 | ((uint32_t)g0 << 16));
         uint8_t *ad = A + R0 * kDfP + 4 * c, *bd = Bp + R0 * kDfP + 4 * c;
-        uint32_t pr[6][4];   // pr[q % 6] = (sums of row q-1) | (sums of row q) << 16
-        uint32_t hprev[4] = {0u, 0u, 0u, 0u};
+        uint32_t pe[4][4];   // pe[(e / 2) % 4] = (sums of row e) | (sums of row e + 1) << 16 for the even rows e
+        uint32_t hev[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < kDfRows; k++) {
-            *reinterpret_cast<uint32_t *>(ad + k * kDfP) = vc[k];
-            uint32_t m = (uint32_t)__builtin_amdgcn_update_dpp((int)ve[k], (int)vc[k], 0x138, 0xf, 0xf, false);   // lane i <- lane i - 1
-            uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp((int)ve[k], (int)vc[k], 0x130, 0xf, 0xf, false);   // lane i <- lane i + 1
-            m = c == 0 ? ve[k] : m;   // the neighbour across a segment's end is another row's dword
-            p = c == 9 ? ve[k] : p;
+            const uint32_t m = vw[k].x, cc = vw[k].y, p = vw[k].z;
+            *reinterpret_cast<uint32_t *>(ad + k * kDfP) = cc;
             uint32_t h[4];
-            h[0] = __builtin_amdgcn_udot4(vc[k], ht[0][1], __builtin_amdgcn_udot4(m, ht[0][0], 0u, false), false);
-            h[1] = __builtin_amdgcn_udot4(p, ht[1][2], __builtin_amdgcn_udot4(vc[k], ht[1][1], __builtin_amdgcn_udot4(m, ht[1][0], 0u, false), false), false);
-            h[2] = __builtin_amdgcn_udot4(p, ht[2][2], __builtin_amdgcn_udot4(vc[k], ht[2][1], __builtin_amdgcn_udot4(m, ht[2][0], 0u, false), false), false);
-            h[3] = __builtin_amdgcn_udot4(p, ht[3][2], __builtin_amdgcn_udot4(vc[k], ht[3][1], 0u, false), false);
-            const int s = k % 6;
+            h[0] = __builtin_amdgcn_udot4(cc, ht[0][1], __builtin_amdgcn_udot4(m, ht[0][0], 0u, false), false);
+            h[1] = __builtin_amdgcn_udot4(p, ht[1][2], __builtin_amdgcn_udot4(cc, ht[1][1], __builtin_amdgcn_udot4(m, ht[1][0], 0u, false), false), false);
+            h[2] = __builtin_amdgcn_udot4(p, ht[2][2], __builtin_amdgcn_udot4(cc, ht[2][1], __builtin_amdgcn_udot4(m, ht[2][0], 0u, false), false), false);
+            h[3] = __builtin_amdgcn_udot4(p, ht[3][2], __builtin_amdgcn_udot4(cc, ht[3][1], 0u, false), false);
+            const int q = k >> 1;
+            if (k & 1) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                pr[s][j] = hprev[j] | (h[j] << 16);
-                hprev[j] = h[j];
+                for (int j = 0; j < 4; j++) pe[q & 3][j] = hev[j] | (h[j] << 16);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) hev[j] = h[j];
             }
             if (k >= 6) {
                 uint32_t sum[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    uint32_t a = __umul24(h[j], (uint32_t)g0) + 32768u;                        // row r
-                    a = __builtin_amdgcn_udot2(as_pk(pr[(s + 5) % 6][j]), vp2, a, false);      // rows r-2, r-1
-                    a = __builtin_amdgcn_udot2(as_pk(pr[(s + 3) % 6][j]), vp1, a, false);      // rows r-4, r-3
-                    a = __builtin_amdgcn_udot2(as_pk(pr[(s + 1) % 6][j]), vp0, a, false);      // rows r-6, r-5
+                    uint32_t a;
+                    if (k & 1) {
+                        a = __builtin_amdgcn_udot2(as_pk(pe[(q - 3) & 3][j]), to0, 32768u, false);   // row r-6
+                        a = __builtin_amdgcn_udot2(as_pk(pe[(q - 2) & 3][j]), to1, a, false);        // rows r-5, r-4
+                        a = __builtin_amdgcn_udot2(as_pk(pe[(q - 1) & 3][j]), to2, a, false);        // rows r-3, r-2
+                        a = __builtin_amdgcn_udot2(as_pk(pe[q & 3][j]), to3, a, false);              // rows r-1, r
+                    } else {
+                        a = __umul24(h[j], (uint32_t)g0) + 32768u;                                   // row r
+                        a = __builtin_amdgcn_udot2(as_pk(pe[(q - 1) & 3][j]), te2, a, false);        // rows r-2, r-1
+                        a = __builtin_amdgcn_udot2(as_pk(pe[(q - 2) & 3][j]), te1, a, false);        // rows r-4, r-3
+                        a = __builtin_amdgcn_udot2(as_pk(pe[(q - 3) & 3][j]), te0, a, false);        // rows r-6, r-5
+                    }
                     sum[j] = SAT ? min(a, 0x00ffffffu) : a;
                 }
                 const uint32_t lo = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u);    // byte 2 of sum[0], byte 2 of sum[1]

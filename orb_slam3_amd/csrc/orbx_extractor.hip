@@ -239,15 +239,16 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_blur_items, sizeof(BlurItem) * blur_items.size());
     ENS(ex->d_pyr, pyr_off * B);
     if (ex->pyr_double) ENS(ex->d_pyr2, pyr_off * B);
-    // The blur on demand (k_describe_fused) filters 43 x 43 pixels per keypoint, the blur pass (k_blur_stream) every pixel of the pyramid once and hides
-    // half of itself beside the FAST strips: measured (profiles/r04_s_ab_describe_fused_blur_*.log) the on-demand form wins while the keypoints'
-    // windows cover less than about 1.5 x the pyramid -- EuRoC 752x480 / 1000: 1.23 x, step -3.7 %; TUM-VI 1024x1024 / 1500: 0.64 x, -12 %;
-    // KITTI 1241x376 / 2000: 1.9 x, +3.8 %.  ORBX_FUSED_BLUR=0 / 1 forces either form.
+    // The blur on demand (k_describe_fused) filters 43 x 43 pixels per keypoint (VALU bound: +39 us per 256 k keypoints over k_describe), the blur pass
+    // (k_blur_stream) every pixel of the pyramid once (HBM bound, 200 us per 285 M pixels, about half of it hidden beside the FAST strips).  Measured
+    // (profiles/r04_s_ab_*, r04_t_ab_*): EuRoC 752x480 / 1000 (the keypoints' windows = 1.2 x the pyramid) step 1.053 -> 0.972 ms, TUM-VI 1024x1024 / 1500
+    // (0.6 x) 1.54 -> 1.33, KITTI 1241x376 / 2000 (1.9 x) 1.43 -> 1.34.  By those rates the blur pass wins beyond 3 - 6 x: on demand up to 4 x
+    // (e.g. not for the 5 x nFeatures extractor of the monocular initialisation).  ORBX_FUSED_BLUR=0 / 1 forces either form.
     {
         size_t pyr_px = 0;
         for (int l = 0; l < nl; l++) pyr_px += (size_t)lv[l].w * lv[l].h;
         const char *v = getenv("ORBX_FUSED_BLUR");
-        ex->fused_blur = v && (v[0] == '0' || v[0] == '1') ? v[0] == '1' : (size_t)std::max(ex->prm.nfeatures, 0) * 1369 * 2 <= 3 * pyr_px;
+        ex->fused_blur = v && (v[0] == '0' || v[0] == '1') ? v[0] == '1' : (size_t)std::max(ex->prm.nfeatures, 0) * 1369 <= 4 * pyr_px;
     }
     if (!ex->fused_blur) ENS(ex->d_blur, blur_off * B);   // (orbx_debug_level_blurred allocates it when it is the only user)
     ENS(ex->d_cellcnt, sizeof(int32_t) * (size_t)cell_base * B);

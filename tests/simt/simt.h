@@ -408,6 +408,14 @@ inline uint32_t __builtin_amdgcn_raw_buffer_load_b32(simt_rsrc r, int voffset, i
     if ((uint64_t)off + 4 > r.num_records) return 0;
     uint32_t v; memcpy(&v, r.base + off, 4); return v;
 }
+typedef uint32_t simt_u32x3 __attribute__((ext_vector_type(3)));
+inline simt_u32x3 __builtin_amdgcn_raw_buffer_load_b96(simt_rsrc r, int voffset, int soffset, int) {   // range check per dword
+    simt_u32x3 v;
+    v.x = __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0);
+    v.y = __builtin_amdgcn_raw_buffer_load_b32(r, voffset + 4, soffset, 0);
+    v.z = __builtin_amdgcn_raw_buffer_load_b32(r, voffset + 8, soffset, 0);
+    return v;
+}
 #undef __builtin_amdgcn_readfirstlane_collective
 inline int __syncthreads_or(int pred) {
     simt::Block *b = simt::blk();
