@@ -809,17 +809,22 @@ __device__ __forceinline__ u64 seq_key(int dist, int seq, int idx) {
     return ((u64)(uint32_t)dist << 32) | ((u64)(uint32_t)seq << 16) | (u64)(uint32_t)idx;
 }
 
-// grid (ceil(max_q/16), n_problems), block 256: 16 lanes per query (4 queries per wave).
-// For every grid column of the window the candidates are one contiguous slice of gorder; the 16 lanes stride it,
+// grid (ceil(max_q / (256 / LQ)), n_problems), block 256: LQ = 16 lanes per query (4 queries per wave) or 8 (8 queries per wave).
+// (Round 4: 8 is the default -- a window of the bench's matchers holds 1 - 10 candidates, most of 16 lanes idle through the scan and the
+// round-by-round extraction: kernel 74 -> 59 us alone, TUM-VI step 1.33 -> 1.26 ms, EuRoC level; 4 lanes measured like 8:
+// profiles/r04_u_*, r04_v_*.  ORBX_MATCH_LANES=16 / 8 / 4.)
+// For every grid column of the window the candidates are one contiguous slice of gorder; the LQ lanes stride it,
 // apply GetFeaturesInArea's level / distance tests (Frame.cc:697-716) and the callers' gates, and keep their two best
-// keys.  Output: the kTopK smallest candidate keys in ascending order, extracted round by round across the 16 lanes.
+// keys.  Output: the kTopK smallest candidate keys in ascending order, extracted round by round across the LQ lanes.
 // If a lane that saw more than two candidates has both of its entries extracted, later rounds could miss that lane's
 // third candidate, so the list is cut there (valid_len); `exhaustive` says the list holds every candidate of the
 // query.  k_greedy_resolve falls back to a re-scan when it needs more than the valid part of a non-exhaustive list.
-__global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__restrict__ probs, GridParams g) {
+template <int LQ>   // lanes per query: 16, 8 or 4
+__global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__restrict__ probs, GridParams g) {
+    static_assert(LQ == 16 || LQ == 8 || LQ == 4, "lanes per query");
     const WindowProblem P = probs[blockIdx.y];
-    const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
-    const int qi = blockIdx.x * 16 + sub;
+    const int sub = threadIdx.x / LQ, sl = threadIdx.x & (LQ - 1);
+    const int qi = blockIdx.x * (256 / LQ) + sub;
     const int nq = *P.nq_ptr;
     const bool qvalid = qi < nq;
     QueryWin w;
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
 #pragma unroll
             for (int c = 0; c < 8; c++) pre[c + 1] = pre[c] + ((cx + c <= w.cx1) ? ce[c] - cs[c] : 0);
             const int tot = pre[8];
-            for (int t = sl; t < tot; t += 16) {
+            for (int t = sl; t < tot; t += LQ) {
                 int j = cs[0] + t;  // column of the t-th candidate: the last c with pre[c] <= t
 #pragma unroll
                 for (int c = 1; c < 8; c++) j = (t >= pre[c]) ? cs[c] + (t - pre[c]) : j;
@@ -882,10 +887,10 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
             seq0 += tot;
         }
     }
-    // reductions inside the 16-lane group (xor masks 8,4,2,1 stay inside the group)
+    // reductions inside the LQ-lane group (xor masks LQ/2 .. 1 stay inside the group)
     int total = cnt;
 #pragma unroll
-    for (int s = 8; s > 0; s >>= 1) total += __shfl_xor(total, s);
+    for (int s = LQ / 2; s > 0; s >>= 1) total += __shfl_xor(total, s);
     u64 out[kTopK];
     int valid_len = 0, npop = 0;
     bool cut = false;
@@ -893,7 +898,7 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
     for (int r = 0; r < kTopK; r++) {
         u64 m = k1;
 #pragma unroll
-        for (int s = 8; s > 0; s >>= 1) {
+        for (int s = LQ / 2; s > 0; s >>= 1) {
             const u64 o = __shfl_xor(m, s);
             m = o < m ? o : m;
         }
@@ -904,7 +909,7 @@ __global__ __launch_bounds__(256) void k_window_best2(const WindowProblem *__res
         // a lane that ran dry while it had seen more than two candidates invalidates everything after this round
         int dry = (mine && npop == 2 && cnt > 2) ? 1 : 0;
 #pragma unroll
-        for (int s = 8; s > 0; s >>= 1) dry |= __shfl_xor(dry, s);
+        for (int s = LQ / 2; s > 0; s >>= 1) dry |= __shfl_xor(dry, s);
         cut = cut || (dry != 0);
     }
     if (qvalid && sl == 0) {

@@ -22,7 +22,15 @@ namespace {
 constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
 #define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__)
-#define ORBX_LAUNCH_WINDOW_BEST2(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_window_best2, grid, block, lds, stream, __VA_ARGS__)
+// k_window_best2 with 16, 8 or 4 lanes per query (ORBX_MATCH_LANES; default 8): nq = queries per problem, np = problems
+static int match_lanes() { static const int v = [] { const char *e = getenv("ORBX_MATCH_LANES"); const int n = e ? atoi(e) : 8; return n == 16 || n == 4 ? n : 8; }(); return v; }
+#define ORBX_LAUNCH_WINDOW_BEST2(nq, np, stream, ...)                                                                                          \
+    do {                                                                                                                                       \
+        const int lq_ = match_lanes();                                                                                                         \
+        if (lq_ == 4) hipLaunchKernelGGL(k_window_best2_t<4>, dim3(((nq) + 63) / 64, (np)), dim3(256), 0, stream, __VA_ARGS__);                 \
+        else if (lq_ == 8) hipLaunchKernelGGL(k_window_best2_t<8>, dim3(((nq) + 31) / 32, (np)), dim3(256), 0, stream, __VA_ARGS__);            \
+        else hipLaunchKernelGGL(k_window_best2_t<16>, dim3(((nq) + 15) / 16, (np)), dim3(256), 0, stream, __VA_ARGS__);                         \
+    } while (0)
 struct Arena {  // bump allocator over one device buffer, reset per call
     uint8_t *base = nullptr;
     size_t cap = 0, used = 0;
@@ -397,7 +405,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     g.inv_w = 64.0f / (F->max_x - F->min_x);  // Frame.cc:342-343
     g.inv_h = 48.0f / (F->max_y - F->min_y);
     ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->stream, dP, g);
-    ORBX_LAUNCH_WINDOW_BEST2( dim3((nq + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2(nq, 1, m->stream, dP, g);
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n);
@@ -538,7 +546,7 @@ int run_projection_twin(orbx_matcher *m, const TwinArgs &a) {
     g.inv_w = 64.0f / (F->max_x - F->min_x);
     g.inv_h = 48.0f / (F->max_y - F->min_y);
     ORBX_LAUNCH_GRID_BUILD( dim3(2), dim3(64), 0, m->stream, dP, g);
-    ORBX_LAUNCH_WINDOW_BEST2( dim3((nq + 15) / 16, 2), dim3(256), 0, m->stream, dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2(nq, 2, m->stream, dP, g);
     const size_t lds = ((size_t)N + 63) & ~(size_t)63;
     hipLaunchKernelGGL(k_replay_twin, dim3(1), dim3(64), lds, m->stream, dP, T, g);
     int32_t nm = 0;
@@ -992,7 +1000,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
     hipEvent_t e0 = ex->ev0, e1 = ex->ev1;
     if (ex->profile) (void)hipEventRecord(e0, ms);
     ORBX_LAUNCH_GRID_BUILD( dim3(np), dim3(64), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
-    ORBX_LAUNCH_WINDOW_BEST2( dim3((cap + 15) / 16, np), dim3(256), 0, ms, (const WindowProblem *)ex->d_mprobs.p, g);
+    ORBX_LAUNCH_WINDOW_BEST2(cap, np, ms, (const WindowProblem *)ex->d_mprobs.p, g);
     if (ex->profile) {
         (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
         float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
@@ -1109,7 +1117,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
                            (int32_t *)ex->d_mp_qmin.p, (int32_t *)ex->d_mp_qmax.p, (uint8_t *)ex->d_mp_valid.p);
     ORBX_LAUNCH_GRID_BUILD( dim3(n), dim3(64), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (n_mp > 0)
-        ORBX_LAUNCH_WINDOW_BEST2( dim3((n_mp + 15) / 16, n), dim3(256), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
+        ORBX_LAUNCH_WINDOW_BEST2(n_mp, n, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (resolve_lds_bytes(cap) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
@@ -1503,7 +1511,7 @@ extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, cons
     g.inv_w = 64.0f / (kf->max_x - kf->min_x);
     g.inv_h = 48.0f / (kf->max_y - kf->min_y);
     ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->stream, dP, g);
-    ORBX_LAUNCH_WINDOW_BEST2( dim3((n_q + 15) / 16, 1), dim3(256), 0, m->stream, dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2(n_q, 1, m->stream, dP, g);
     std::vector<u64> keys((size_t)n_q * kTopK);
     D2H(keys.data(), P.keys, 8 * (size_t)n_q * kTopK);
     SYNC_AND_DELIVER();
