@@ -1176,6 +1176,8 @@ __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p) {
 struct DescConst {
     int8_t vmax_of_u[16];              // orientation disc: largest |v| with umax[|v|] >= |u|
     int8_t pat[1024];                  // bit_pattern_31_ (x0,y0,x1,y1) x 256
+    uint32_t ic_mask[32][4][10];       // orientation disc, row form: row hl = v + 15 (row 31: empty), alignment axB = (kx - 18) & 3: byte t of the row is
+                                       // 0xff where |t - 18 - axB| <= umax[|v|] (k_describe_fused, ic_moments_rows)
 };
 
 constexpr int kDescAP = 40, kDescAR = 31;   // orientation patch in LDS: 31 rows x 40 B (9 aligned dwords used)
@@ -1192,14 +1194,10 @@ struct HostMirror {
     const int32_t *err, *mono;
 };
 
-// IC_Angle + steered BRIEF + keypoint record of the half's keypoint from its two patches in LDS (the tail k_describe and k_describe_fused share).
-// c0 = centre of the orientation patch (pitch AP) + this lane's disc column du; bc = centre of the blurred patch (pitch BP)
-template <int AP, int BP>
-__device__ __forceinline__ void describe_tail(const uint8_t *c0, const uint8_t *bc, const int dvmax, const int du, const int hw, const int hl,
-                                              const uint32_t (&pat8)[8], const int strict_mul_add, const bool live, const WorkItem &w, const int kx,
-                                              const int ky, const int f, const int cap, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-                                              const HostMirror &hm) {
-    // ---- IC_Angle (:76-103): lane = disc column, m_10 = u * sum I, m_01 = sum v * I ----
+// IC_Angle moments of the half's keypoint, COLUMN form (:76-103): lane = disc column, m_10 = u * sum I, m_01 = sum v * I; c0 = centre of the
+// orientation patch (pitch AP) + this lane's disc column du
+template <int AP>
+__device__ __forceinline__ void ic_moments_columns(const uint8_t *c0, const int dvmax, const int du, const int hw, int *M10, int *M01) {
     int sumI = 0, m01 = 0;
 #pragma unroll
     for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
@@ -1212,7 +1210,47 @@ __device__ __forceinline__ void describe_tail(const uint8_t *c0, const uint8_t *
     const int s10 = wave_incl_scan(du * sumI), s01 = wave_incl_scan(m01);
     const int a10 = __builtin_amdgcn_readlane(s10, 31), b10 = __builtin_amdgcn_readlane(s10, 63);
     const int a01 = __builtin_amdgcn_readlane(s01, 31), b01 = __builtin_amdgcn_readlane(s01, 63);
-    const int M10 = hw ? b10 - a10 : a10, M01 = hw ? b01 - a01 : a01;
+    *M10 = hw ? b10 - a10 : a10;
+    *M01 = hw ? b01 - a01 : a01;
+}
+
+// the same moments, ROW form (k_describe_fused, which is bound by VALU issue): lane = disc row v = hl - 15; the row's 40 bytes (ten aligned dwords of
+// the orientation patch, byte t = pixel x0 + t) are masked to the disc (DescConst::ic_mask: 0xff where |t - ctr| <= umax[|v|], ctr = byte of the
+// keypoint's column) and reduced with v_dot4: S = sum I, T = sum t * I (weights t = 0 .. 39 as literals), m_10 row = T - ctr * S, m_01 row = v * S.
+// 32 instead of 78 vector instructions per wave, three loads of the mask row instead of 31 dependent LDS byte reads.
+__device__ __forceinline__ void ic_moments_rows(const uint8_t *row, const uint32_t *__restrict__ mask_row, const int ctr, const int hw, const int hl,
+                                                int *M10, int *M01) {
+    uint32_t px[10], mk[10];
+    const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
+    const uint4 *m4 = reinterpret_cast<const uint4 *>(mask_row);
+    const uint4 pa = r4[0], pb = r4[1], ma = m4[0], mb = m4[1];
+    const uint2 pc = *reinterpret_cast<const uint2 *>(row + 32), mc = *reinterpret_cast<const uint2 *>(mask_row + 8);
+    px[0] = pa.x; px[1] = pa.y; px[2] = pa.z; px[3] = pa.w; px[4] = pb.x; px[5] = pb.y; px[6] = pb.z; px[7] = pb.w; px[8] = pc.x; px[9] = pc.y;
+    mk[0] = ma.x; mk[1] = ma.y; mk[2] = ma.z; mk[3] = ma.w; mk[4] = mb.x; mk[5] = mb.y; mk[6] = mb.z; mk[7] = mb.w; mk[8] = mc.x; mk[9] = mc.y;
+    uint32_t S = 0u, T = 0u;
+#pragma unroll
+    for (int d = 0; d < 10; d++) {
+        const uint32_t I = px[d] & mk[d];
+        S = __builtin_amdgcn_udot4(I, 0x01010101u, S, false);
+        T = __builtin_amdgcn_udot4(I, 0x03020100u + 0x04040404u * (uint32_t)d, T, false);
+    }
+    const int m10 = (int)T - ctr * (int)S, m01 = (hl - kHalfPatch) * (int)S;   // lane 31 of a half: an all-zero mask row
+    const int s10 = wave_incl_scan(m10), s01 = wave_incl_scan(m01);
+    const int a10 = __builtin_amdgcn_readlane(s10, 31), b10 = __builtin_amdgcn_readlane(s10, 63);
+    const int a01 = __builtin_amdgcn_readlane(s01, 31), b01 = __builtin_amdgcn_readlane(s01, 63);
+    *M10 = hw ? b10 - a10 : a10;
+    *M01 = hw ? b01 - a01 : a01;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// angle + steered BRIEF + keypoint record of the half's keypoint from its moments and its blurred patch in LDS (the tail k_describe and
+// k_describe_fused share).  bc = centre of the blurred patch (pitch BP)
+template <int BP>
+__device__ __forceinline__ void describe_tail(const int M10, const int M01, const uint8_t *bc, const int hw, const int hl,
+                                              const uint32_t (&pat8)[8], const int strict_mul_add, const bool live, const WorkItem &w, const int kx,
+                                              const int ky, const int f, const int cap, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                              const HostMirror &hm) {
     const float angle = fast_atan2_deg((float)M01, (float)M10);
 
     // ---- steered BRIEF on the blurred patch ----
@@ -1223,24 +1261,24 @@ __device__ __forceinline__ void describe_tail(const uint8_t *c0, const uint8_t *
     constexpr uint32_t kMagicBits = 0x4B400000u;
     const uint32_t cbm = (uint32_t)(uintptr_t)bc - (0x400000u * (uint32_t)BP + kMagicBits);
     uint32_t mine = 0;   // lanes 0..7 of a half end up with descriptor dword hl of the half's keypoint
+    // the two points of a pattern pair as ONE packed operation each (v_pk_mul / v_pk_fma / v_pk_add_f32 on (point 0, point 1)): the same multiplications,
+    // fused multiply-adds and additions per element as the scalar form of the reference binary
+    const f32x2 aa = {a, a}, bb = {b, b}, mg = {kMagic, kMagic};
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const char4 pt = __builtin_bit_cast(char4, pat8[it]);
-        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
-        float r0, q0, r1, q1;
+        const f32x2 X = {(float)pt.x, (float)pt.z}, Y = {(float)pt.y, (float)pt.w};
+        f32x2 R, Q;
         if (strict_mul_add) {
-            r0 = __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
-            q0 = __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
-            r1 = __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
-            q1 = __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
+            R = X * bb + Y * aa;      // -ffp-contract=off: products and sums round separately
+            Q = X * aa - Y * bb;
         } else {  // GCC -O3 -march=native: fma(x, b, y*a), fma(x, a, -(y*b))
-            r0 = __fmaf_rn(x0, b, __fmul_rn(y0, a));
-            q0 = __fmaf_rn(x0, a, -__fmul_rn(y0, b));
-            r1 = __fmaf_rn(x1, b, __fmul_rn(y1, a));
-            q1 = __fmaf_rn(x1, a, -__fmul_rn(y1, b));
+            R = __builtin_elementwise_fma(X, bb, Y * aa);
+            Q = __builtin_elementwise_fma(X, aa, -(Y * bb));
         }
-        const uint32_t a0 = __umul24(__float_as_uint(__fadd_rn(r0, kMagic)), (uint32_t)BP) + __float_as_uint(__fadd_rn(q0, kMagic)) + cbm;
-        const uint32_t a1 = __umul24(__float_as_uint(__fadd_rn(r1, kMagic)), (uint32_t)BP) + __float_as_uint(__fadd_rn(q1, kMagic)) + cbm;
+        const f32x2 Rm = R + mg, Qm = Q + mg;
+        const uint32_t a0 = __umul24(__float_as_uint(Rm.x), (uint32_t)BP) + __float_as_uint(Qm.x) + cbm;
+        const uint32_t a1 = __umul24(__float_as_uint(Rm.y), (uint32_t)BP) + __float_as_uint(Qm.y) + cbm;
         const int t0 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a0);
         const int t1 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a1);
         const unsigned long long bal = __ballot(t0 < t1);
@@ -1332,8 +1370,9 @@ __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ 
     }
     wave_lds_sync();
 
-    describe_tail<kDescAP, kDescBP>(A + kHalfPatch * kDescAP + kHalfPatch + axA + du, Bp + 18 * kDescBP + 18 + axB, dvmax, du, hw, hl, pat8, strict_mul_add, live, w,
-                                    kx, ky, f, cap, kps, desc, hm);
+    int M10, M01;
+    ic_moments_columns<kDescAP>(A + kHalfPatch * kDescAP + kHalfPatch + axA + du, dvmax, du, hw, &M10, &M01);
+    describe_tail<kDescBP>(M10, M01, Bp + 18 * kDescBP + 18 + axB, hw, hl, pat8, strict_mul_add, live, w, kx, ky, f, cap, kps, desc, hm);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1380,8 +1419,6 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
     uint8_t *Bp = A + kDfP * kDfAR;
     const int pitch = (int)(w.pitches & 0xffffu);
     const int kx = key_x(w.key), ky = key_y(w.key);
-    const int du = hl - kHalfPatch;
-    const int dvmax = hl <= 2 * kHalfPatch ? dc->vmax_of_u[du < 0 ? -du : du] : -1;
     uint32_t pat8[8];
 #pragma unroll
     for (int it = 0; it < 8; it++) pat8[it] = reinterpret_cast<const uint32_t *>(dc->pat)[it * 32 + hl];
@@ -1463,8 +1500,9 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
         }
     }
     wave_lds_sync();
-    describe_tail<kDfP, kDfP>(A + 21 * kDfP + 18 + axB + du, Bp + 18 * kDfP + 18 + axB, dvmax, du, hw, hl, pat8, strict_mul_add, live, w, kx, ky, f, cap,
-                              kps, desc, hm);
+    int M10, M01;
+    ic_moments_rows(A + (6 + min(hl, 30)) * kDfP, dc->ic_mask[min(hl, 31)][axB], 18 + axB, hw, hl, &M10, &M01);
+    describe_tail<kDfP>(M10, M01, Bp + 18 * kDfP + 18 + axB, hw, hl, pat8, strict_mul_add, live, w, kx, ky, f, cap, kps, desc, hm);
 }
 
 }  // namespace orbx

@@ -698,6 +698,12 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
         dc.vmax_of_u[u] = (int8_t)vm;
         if (vm >= 0) n += (u == 0 ? 1 : 2) * (2 * vm + 1);
     }
+    for (int r = 0; r < 31; r++)   // row form for k_describe_fused (row 31 stays empty)
+        for (int ax = 0; ax < 4; ax++)
+            for (int t = 0; t < 40; t++) {
+                const int v = r - kHalfPatch, u = t - 18 - ax;
+                if (std::abs(u) <= ex->umax[std::abs(v)]) dc.ic_mask[r][ax][t >> 2] |= 0xffu << (8 * (t & 3));
+            }
     // the column form equals the row form of :82-100 only for a monotone umax; 749 = pixel count of the reference's disc
     bool mono = true;
     for (int v = 0; v < kHalfPatch; v++) mono = mono && ex->umax[v] >= ex->umax[v + 1];
