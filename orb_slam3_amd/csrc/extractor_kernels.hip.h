@@ -11,9 +11,10 @@
 //   k_finalize        level concatenation + lapping split slots                :1117-1162
 //   k_blur_stream     GaussianBlur 7x7 sigma 2 (fixed point)                   :1132-1133
 //   k_describe        IC_Angle + computeOrbDescriptor + keypoint record        :76-146, 1143-1162
+//   k_describe_fused  the same with the GaussianBlur computed on demand around each keypoint (no k_blur_stream launch; chosen per geometry)
 //
 // Integer pixel / bit work: no MFMA.  Built with -ffp-contract=off; the only fused float ops are the explicit
-// __fmaf_rn / __fma_rn calls that reproduce the reference binary (see k_describe).
+// __fmaf_rn / __fma_rn calls (and __builtin_elementwise_fma on float pairs) that reproduce the reference binary (see describe_tail).
 #pragma once
 
 #include "orbx_internal.h"
