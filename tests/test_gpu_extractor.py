@@ -406,6 +406,28 @@ def test_parameter_sweep(w, h, nf, scale, nlevels, ini, mn):
     assert len(kps) > nf // 2
 
 
+def test_reconfigure_switches_the_descriptor_form(canvas1):
+    """One extractor whose geometry changes across the threshold of the descriptor stage's two forms (configure(): the blur on demand while
+    nFeatures x 37^2 <= 4 x the pyramid's pixels): 3000 features on 752x480 (3.7 x: k_describe_fused, no blur slab), then on 424x318 (9.9 x: the blur
+    slab is allocated now, k_blur_stream + k_describe), then back, with a batch in between; keypoints, descriptors and blurred levels == oracle."""
+    import torch
+    from orb_slam3_amd import synth
+    ex, oex = _pair(3000)
+    for (w, h) in ((752, 480), (424, 318), (752, 480)):
+        img = synth.frame_from_canvas(canvas1, 7, w, h, 777)
+        _check_frame(ex, oex, img, (0, 1000), stagewise=True)
+    frames = np.stack([synth.frame_from_canvas(canvas1, t, 424, 318, 880 + t) for t in range(9)])
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), 9, 424, 318, 424, 424 * 318, (0, 1000))
+    for f in (0, 8):
+        mono, kps, desc = ex.download(f)
+        omono, okps, odesc = oex.extract(frames[f], lap=(0, 1000))
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
+        assert np.array_equal(ex.debug_blurred(3, f), oex.level_blurred(3)), f
+    img = synth.frame_from_canvas(canvas1, 9, 752, 480, 999)
+    _check_frame(ex, oex, img, (0, 1000), stagewise=True)
+
+
 def test_reconfigure_between_shapes(canvas1):
     """One extractor instance used on changing image sizes / batch sizes (workspace reconfiguration)."""
     import torch
