@@ -1222,10 +1222,14 @@ __device__ __forceinline__ void ic_moments_columns(const uint8_t *c0, const int 
 __device__ __forceinline__ void ic_moments_rows(const uint8_t *row, const uint32_t *__restrict__ mask_row, const int ctr, const int hw, const int hl,
                                                 int *M10, int *M01) {
     uint32_t px[10], mk[10];
-    const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
-    const uint4 *m4 = reinterpret_cast<const uint4 *>(mask_row);
-    const uint4 pa = r4[0], pb = r4[1], ma = m4[0], mb = m4[1];
-    const uint2 pc = *reinterpret_cast<const uint2 *>(row + 32), mc = *reinterpret_cast<const uint2 *>(mask_row + 8);
+    const uint4 *r4 = reinterpret_cast<const uint4 *>(row);   // LDS rows are 16-byte aligned (pitch 48, patch base a multiple of 16)
+    const uint4 pa = r4[0], pb = r4[1];
+    const uint2 pc = *reinterpret_cast<const uint2 *>(row + 32);
+    uint4 ma, mb;   // a mask row is 40 bytes: 8-byte aligned only
+    uint2 mc;
+    __builtin_memcpy(&ma, mask_row, 16);
+    __builtin_memcpy(&mb, mask_row + 4, 16);
+    __builtin_memcpy(&mc, mask_row + 8, 8);
     px[0] = pa.x; px[1] = pa.y; px[2] = pa.z; px[3] = pa.w; px[4] = pb.x; px[5] = pb.y; px[6] = pb.z; px[7] = pb.w; px[8] = pc.x; px[9] = pc.y;
     mk[0] = ma.x; mk[1] = ma.y; mk[2] = ma.z; mk[3] = ma.w; mk[4] = mb.x; mk[5] = mb.y; mk[6] = mb.z; mk[7] = mb.w; mk[8] = mc.x; mk[9] = mc.y;
     uint32_t S = 0u, T = 0u;
