@@ -38,6 +38,12 @@ inline dim3 xcd_grid(int blocks_per_frame, int n_frames, bool local = true) {
     return dim3(8, (unsigned)blocks_per_frame, (unsigned)((n_frames + 7) / 8));
 }
 
+// Level 0 in place: the batch's frames as the caller holds them (no padded copy in the pyramid slab).  img == nullptr: level 0 lives in the slab.
+struct Level0Src {
+    const uint8_t *img;
+    size_t row_stride, frame_stride;
+};
+
 __device__ __forceinline__ int reflect101(int p, int len) {
     // [OCV] borderInterpolate(BORDER_REFLECT_101); |p| excursions here are < len
     if (p < 0) p = -p;
@@ -670,7 +676,7 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
                                                const LevelInfo *__restrict__ lv, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
                                                int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
                                                size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
-                                               uint32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
+                                               uint32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, const Level0Src src0) {
     const LevelInfo L = lv[t.level];
     const int lane = threadIdx.x;
     const int cell = t.ti * L.nCols + t.tj;
@@ -690,7 +696,10 @@ __device__ __forceinline__ void fast_wave_cell(const TileRef t, const int f, con
     uint8_t *scq = reinterpret_cast<uint8_t *>(queue + qcap);                             // qcap scores
 
     // phase 0: (unaligned) dword loads starting one byte left of the sub-image
-    fast_tile_load<P>(pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1, L.pitch, rows, cols, pix, lane);
+    const bool in_place = src0.img != nullptr && t.level == 0;   // level 0 in place: the caller's frame
+    fast_tile_load<P>(in_place ? src0.img + (size_t)f * src0.frame_stride + (size_t)iniY * src0.row_stride + iniX - 1
+                               : pyr + (size_t)f * pyr_frame_stride + L.off + (size_t)(kEdge + iniY) * L.pitch + kRoiX + iniX - 1,
+                      in_place ? (int)src0.row_stride : L.pitch, rows, cols, pix, lane);
     __syncthreads();  // single-wave workgroup: a compiler/LDS ordering point, no s_barrier
 
     // phase 1: antipodal-pair test at minTh, four pixels per lane; passing pixels are queued in row-major order
@@ -820,13 +829,13 @@ __global__ __launch_bounds__(64) void k_fast_wave_list(const LevelInfo *__restri
                                                        const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
                                                        int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent,
                                                        size_t ent_frame_stride, int iniTh, int minTh, int max_rows, int qcap,
-                                                       const uint32_t *__restrict__ list, const int32_t *__restrict__ list_count) {
+                                                       const uint32_t *__restrict__ list, const int32_t *__restrict__ list_count, const Level0Src src0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int count = *list_count;
     for (int k = blockIdx.x; k < count; k += gridDim.x) {
         const uint32_t e = list[k];
         fast_wave_cell<P>(tiles[e & 0xffffu], (int)(e >> 16), e & 0xffffu, smem, lv, pyr, pyr_frame_stride, cellcnt, total_cells, cellent,
-                          ent_frame_stride, iniTh, minTh, max_rows, qcap, nullptr, nullptr);
+                          ent_frame_stride, iniTh, minTh, max_rows, qcap, nullptr, nullptr, src0);
         __syncthreads();
     }
 }
@@ -837,6 +846,7 @@ __global__ __launch_bounds__(64) void k_fast_wave_list(const LevelInfo *__restri
 // ---------------------------------------------------------------------------------------------------------
 }  // namespace orbx
 
+#include "pyr_stream.hip.h"
 #include "fast_strip.hip.h"
 #include "octree.hip.h"
 #include "octree_par.hip.h"
@@ -1408,7 +1418,8 @@ template <bool SAT>
 __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
                                                          const int32_t *__restrict__ count, int cap, const uint8_t *__restrict__ pyr,
                                                          size_t pyr_frame_stride, int g0, int g1, int g2, int g3, orbx_keypoint *__restrict__ kps,
-                                                         uint8_t *__restrict__ desc, int strict_mul_add, int n_frames, const HostMirror hm) {
+                                                         uint8_t *__restrict__ desc, int strict_mul_add, int n_frames, const HostMirror hm,
+                                                         const Level0Src src0, int W0, int H0) {
     __shared__ __attribute__((aligned(16))) uint8_t patches[4 * 2 * kDfWaveLds];
     int bx, f;
     if (!xcd_frame_map(n_frames, &bx, &f)) return;
@@ -1431,13 +1442,65 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
     const int seg = hl < 10 ? 0 : hl < 20 ? 1 : 2, c = hl - 10 * seg, R0 = seg == 0 ? 0 : seg == 1 ? 13 : 25;
     const int axB = (kx - 18) & 3;
     u32x3 vw[kDfRows];   // a row's 12-pixel window of this lane: the dword left of its own, its own, the dword right of it
-    {
-        const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(pyr + (size_t)f * pyr_frame_stride), 0, (int)min(pyr_frame_stride, (size_t)0x7fffffff), 0x00020000);
-        constexpr uint32_t kOut = 0x80000000u;   // an offset outside the descriptor: no memory access, the load returns 0
-        const uint32_t own = w.off + (uint32_t)((kEdge + ky - 21 + R0) * pitch + kRoiX + (kx - 18 - axB) + 4 * c);
+    // Level 0 in place (src0.img != nullptr): a level-0 keypoint reads the caller's frame, which has no REFLECT_101 ring.  Its window (columns
+    // kx - 25 .. kx + 25, rows ky - 21 .. ky + 22 at most) lies inside the image unless the keypoint sits within 25 px of a side / 22 px of the top
+    // or bottom (keypoints start 16 px inside): those few take the staged form below, which applies the reflection itself.
+    const bool ip = src0.img != nullptr && w.level == 0;
+    const bool border = ip && (kx < 25 || kx > W0 - 27 || ky < 21 || ky > H0 - 23);
+    constexpr uint32_t kOut = 0x80000000u;   // an offset outside the descriptor: no memory access, the load returns 0
+    const unsigned long long bip = __ballot(ip);
+    if (__ballot(border) == 0ull && (bip == 0ull || bip == ~0ull)) {
+        // both keypoints of the wave in the slab, or both on the in-place level 0: one descriptor, one 12-byte load per row (wave-uniform choice)
+        const size_t img_bytes = (size_t)(H0 - 1) * src0.row_stride + (size_t)W0;
+        const uint8_t *base = bip ? src0.img + (size_t)f * src0.frame_stride : pyr + (size_t)f * pyr_frame_stride;
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(base), 0, (int)min(bip ? img_bytes : pyr_frame_stride, (size_t)0x7fffffff), 0x00020000);
+        const int lp = bip ? (int)src0.row_stride : pitch;
+        const uint32_t own = bip ? (uint32_t)((ky - 21 + R0) * lp + (kx - 18 - axB) + 4 * c)
+                                 : w.off + (uint32_t)((kEdge + ky - 21 + R0) * lp + kRoiX + (kx - 18 - axB) + 4 * c);
         const uint32_t offW = c < 10 ? own - 4u : kOut;
 #pragma unroll
-        for (int k = 0; k < kDfRows; k++) vw[k] = __builtin_amdgcn_raw_buffer_load_b96(srd, (int)(offW + (uint32_t)(k * pitch)), 0, 0);
+        for (int k = 0; k < kDfRows; k++) vw[k] = __builtin_amdgcn_raw_buffer_load_b96(srd, (int)(offW + (uint32_t)(k * lp)), 0, 0);
+    } else {
+        // staged form: the 44 x 48-byte window (columns X0 - 4 .. X0 + 43, X0 = kx - 18 - axB a multiple of 4) of each half's keypoint goes through the raw
+        // patch's LDS rows (byte 0 = column X0 - 4; the filter loop below rewrites them in their final layout), 528 dwords over 32 lanes.  A dword of the
+        // window is one dword of the image, possibly byte-reversed: columns x < 0 come from -x, columns x >= W from 2 W - 2 - x ([OCV] BORDER_REFLECT_101),
+        // rows likewise.  A slab level in the other half takes the same route with the identity mapping (its ring is in the slab), and so does the one
+        // wave of a frame whose halves straddle the in-place level 0 and level 1 (two base addresses: no common descriptor).
+        const uint8_t *roi = ip ? src0.img + (size_t)f * src0.frame_stride : pyr + (size_t)f * pyr_frame_stride + w.off + (size_t)(kEdge * pitch + kRoiX);
+        const int sp = ip ? (int)src0.row_stride : pitch;
+        const int X0m4 = kx - 18 - axB - 4;
+        uint32_t stage[17];
+#pragma unroll
+        for (int t = 0; t < 17; t++) {
+            const int i = min(hl + 32 * t, 527);
+            const int r = (i * 43691) >> 19, j = i - 12 * r;   // i / 12
+            int y = ky - 21 + r, x0 = X0m4 + 4 * j;
+            uint32_t sel = 0x03020100u;
+            if (ip) {
+                y = reflect101(y, H0);
+                const int d = W0 - x0;               // pixels of the dword inside the image
+                if (x0 < 0) { x0 = -x0 - 3; sel = 0x00010203u; }
+                else if (d <= 0) { x0 = 2 * W0 - 5 - x0; sel = 0x00010203u; }
+                else if (d < 4) { x0 = W0 - 4; sel = d == 1 ? 0x00010203u : d == 2 ? 0x01020302u : 0x02030201u; }   // the dword straddles the right edge
+            }
+            uint32_t v;
+            __builtin_memcpy(&v, roi + (ptrdiff_t)y * sp + x0, 4);
+            stage[t] = __builtin_amdgcn_perm(0u, v, sel);
+        }
+#pragma unroll
+        for (int t = 0; t < 17; t++) {
+            const int i = hl + 32 * t;
+            const int r = (i * 43691) >> 19, j = i - 12 * r;
+            if (i < 528) *reinterpret_cast<uint32_t *>(A + r * kDfP + 4 * j) = stage[t];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < kDfRows; k++) {
+            u32x3 v = {0u, 0u, 0u};
+            if (c < 10) __builtin_memcpy(&v, A + (R0 + k) * kDfP + 4 * c, 12);
+            vw[k] = v;
+        }
+        wave_lds_sync();
     }
     {
         // horizontal taps of the four pixels of a dword over its 12-pixel window (m | c | p), as byte vectors for v_dot4 (k_blur_stream's)

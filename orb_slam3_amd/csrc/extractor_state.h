@@ -100,6 +100,8 @@ enum { K_PYR_BASE, K_PYR_RESIZE, K_FAST, K_OCTREE, K_FINALIZE, K_BLUR, K_DESCRIB
 
 }  // namespace orbx
 
+extern "C" int orbx_materialize_level0(struct orbx_extractor *ex);   // orbx_extractor.hip (internal: not part of include/orbx.h)
+
 struct orbx_extractor {
     typedef orbx::DevBuf DevBuf;
     typedef orbx::LevelInfo LevelInfo;
@@ -128,6 +130,20 @@ struct orbx_extractor {
     int blur_waves = 2048;      // single-wave workgroups of k_blur_stream (measured: 512 / 1024 / 2048 / 4096 -> EuRoC step 1.25 / 1.115 / 1.09 / 1.10 ms)
     // device memory
     DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_items, d_dc;
+    // k_pyr_stream (levels 1 .. n-1 in one launch): per-geometry tables; ps_ok false = the geometry does not fit, the per-level launches run
+    DevBuf d_ps_levels, d_ps_cols, d_ps_steps, d_ps_tasks, d_ps_band0;
+    bool ps_ok = false;
+    orbx::PyrStreamGeom ps_geom;
+    int ps_bands = 0, ps_min_frames = 16;   // batches smaller than ps_min_frames keep the per-level launches (a band is one workgroup: too few to fill the device)
+    size_t ps_lds = 0;
+    // Level 0 in place: a batch extracted by k_pyr_stream + k_fast_strip + k_describe_fused reads level 0 from the caller's frames (which orbx.h
+    // keeps untouched until orbx_sync / orbx_download_wait) and leaves the slab's level 0 unwritten; the few readers of the padded level 0
+    // (orbx_get_level, the stereo rig's SAD stage, the blurred-level debug readout) materialise it first: materialize_level0()
+    bool lvl0_inplace = false;
+    bool inplace_allowed = true;   // ORBX_LEVEL0_COPY=1 keeps the padded copy (diagnostic)
+    const uint8_t *in0_images = nullptr;
+    size_t in0_row_stride = 0, in0_frame_stride = 0;
+    int n_strips0 = 0;          // level-0 strips of k_fast_strip (the first of a frame)
     // Stereo rig (orbx_stereo_batch_device): the SAD stage reads both extractors' pyramids on the match stream while the NEXT pair of batches is
     // extracted, so an extractor that has been part of a rig alternates between two pyramid slabs (allocated at the first stereo call)
     DevBuf d_pyr2;

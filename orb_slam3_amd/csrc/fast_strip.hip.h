@@ -14,13 +14,18 @@
 //   stage B  the four-antipodal-pair test on the queued groups only (packed u16, both polarities); passing pixels queued row-major
 //   scores   exact cornerScore of the queued pixels, TWO per lane on packed u16 halves (v_pk_minimum3 / maximum3_f16, fast_score16_x2);
 //            corners (score >= t) compacted in place                                                             | barrier
+//   2nd pass cells of the strip WITHOUT a corner at iniThFAST in any wave's band (known now, while the pixel tile is still alive): the reference
+//            runs cv::FAST(cell, minThFAST) for them (:843-846).  The four-pair test and the exact scores at minTh over those cells' columns
+//            only, appended to the same per-wave queues; the NMS below separates cells by a zero column, so the two thresholds never meet.
+//            (Rounds 3-4 sent these cells -- 6 % of the bench's -- to k_fast_wave_list, which re-read their sub-images from HBM: 92 MB per
+//            256 frames and a launch.)                                                                             | barrier (only if any)
 //   NMS      the pixel tile is dead: each wave zeroes its band of the score tile and scatters its corners into it, with one ZERO
 //            COLUMN between adjacent cells -- cv::FAST runs per cell sub-image, so a neighbour in another cell scores 0 (the
 //            strip's rows belong to one cell row, the apron rows are zero)                                         | barrier
 //            strict '>' against the 8 neighbours; survivors compacted in place, counted per (wave, cell)           | barrier
 //   emit     a cell's survivors in row-major order = wave 0's, then wave 1's, ... (bands are row ranges): slot position = the
-//            earlier waves' counts of that cell + the rank inside the wave; cells without a survivor go to the list the second
-//            pass (k_fast_wave_list, :843-846) works through, cells of a strip whose queues overflowed as well.
+//            earlier waves' counts of that cell + the rank inside the wave.  What is left for the list pass (k_fast_wave_list): cells whose
+//            corners at iniTh ALL lost the NMS (ties only: the reference then runs FAST(minTh) on them) and strips whose queues overflowed.
 // What it removes against one wave per cell (k_fast_ini, rounds 1-2): the (wCell + 6)(hCell + 6) / (wCell hCell) apron re-read per
 // cell (now only the 6 apron rows per strip and 8 columns per 256), the per-cell set-up and the part-filled last iterations of every
 // stage (a strip's queues are 5-7 cells long), the lanes a 36-px cell row leaves idle (9 groups x 6-7 rows = 54-63 of 64).
@@ -49,7 +54,7 @@ struct StripTile {   // one strip, precomputed per geometry (48 bytes, scalar lo
     uint32_t rcp_groups;   // ceil(2^20 / G), G = (iw + 3) / 4 dword groups per interior row: lane -> (row, group) without a division
     uint16_t rows_per_iter, ncell;   // 64 / G rows per stage-A iteration; cells in the strip
     uint32_t lds_pitch;    // kStripPitch / kStripPitchMid / kStripPitchLow
-    uint32_t pad;
+    uint32_t wcell;        // cell width (interior columns [c * wcell, min((c + 1) * wcell, iw)) belong to cell c of the strip)
 };
 static_assert(sizeof(StripTile) == 48, "StripTile layout");
 
@@ -60,10 +65,10 @@ __host__ __device__ inline size_t fast_strip_lds_bytes(int waves, int pix_bytes,
 }
 
 template <int W, int P>   // W waves per workgroup = row bands per strip; P = LDS pitch of the tile
-__device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f, uint8_t *smem, const uint8_t *__restrict__ pyr, size_t pyr_frame_stride,
+__device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f, uint8_t *smem, const uint8_t *__restrict__ tile_src, const int spitch,
                                                 int32_t *__restrict__ cellcnt, int total_cells, uint32_t *__restrict__ cellent, size_t ent_frame_stride,
-                                                int iniTh, int pix_bytes, int gcap, int qcap, uint32_t *__restrict__ list, int32_t *__restrict__ list_count,
-                                                int second_pass) {
+                                                int iniTh, int minTh, int pix_bytes, int gcap, int qcap, uint32_t *__restrict__ list,
+                                                int32_t *__restrict__ list_count, int second_pass) {
     constexpr int D = P / 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int iw = T.iw, ih = T.ih, rows = ih + 6;
@@ -73,15 +78,14 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
     uint16_t *pq = gq + gcap;                                     // pixel queue -> corners -> survivors (compacted in place)
     uint8_t *ps = reinterpret_cast<uint8_t *>(gq);                // score per pixel-queue entry, written when the group queue is dead
     int32_t *cnt = reinterpret_cast<int32_t *>(smem + (size_t)pix_bytes + W * fast_strip_wave_bytes(gcap, qcap));   // [W][8] survivors per (wave, cell)
-    int32_t *ovf = cnt + W * kStripMaxCells;
-    if (threadIdx.x == 0) *ovf = 0;
+    int32_t *ovf = cnt + W * kStripMaxCells;   // [0] a queue overflowed in the first pass, [1] cells with a corner at iniTh (bit per cell), [2] overflow in the second pass
+    if (threadIdx.x == 0) { ovf[0] = 0; ovf[1] = 0; ovf[2] = 0; }
 
     // ---- phase 0: rows wave, wave + 4, ... ; lane = dword of the row (G + 2 <= 66 dwords: the two beyond lane 63 in a second sweep) ----
     {
         const int nd = ((iw + 3) >> 2) + 2;
-        const uint64_t a = (uint64_t)(pyr + (size_t)f * pyr_frame_stride + T.src_off);
+        const uint64_t a = (uint64_t)tile_src;   // tile byte (row 0, col 0) = level pixel (X0 - 4, Y0 - 3)
         const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)a), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-        const int spitch = T.pitch;
         const int nbytes = (rows - 1) * spitch + 4 * nd;
         const auto srd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)ahi << 32) | alo), 0, nbytes, 0x00020000);
         const int oob = 0x40000000;
@@ -184,34 +188,99 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
     }
     wave_lds_sync();
 
-    // ---- exact scores of the queued pixels; corners (score >= iniTh) compacted in place, row-major order kept ----
-    int nc = 0;
-    if (!over) {   // exact scores, two queue entries per lane: e0 + lane and e0 + 64 + lane of 128 per iteration
-        for (int e0 = 0; e0 < qn; e0 += 128) {
+    // ---- exact scores of the queued pixels; corners (score >= th) compacted in place, row-major order kept ----
+    // entries [begin, end) of the pixel queue -> corners appended at `out` (out <= begin: the compaction never overtakes an unread entry)
+    auto score_compact = [&](const int begin, const int end, const int th, int out) -> int {
+        for (int e0 = begin; e0 < end; e0 += 128) {   // two queue entries per lane: e0 + lane and e0 + 64 + lane of 128 per iteration
             const int ea = e0 + lane, eb = e0 + 64 + lane;
-            const int qa = pq[min(ea, qn - 1)], qb = pq[min(eb, qn - 1)];
+            const int qa = pq[min(ea, end - 1)], qb = pq[min(eb, end - 1)];
             int sa, sb;
             fast_score16_x2(pix + ((qa >> 8) + 3) * P + (qa & 0xff) + 4, pix + ((qb >> 8) + 3) * P + (qb & 0xff) + 4, P, &sa, &sb);
-            const bool ca = sa >= iniTh && ea < qn, cb = sb >= iniTh && eb < qn;
+            const bool ca = sa >= th && ea < end, cb = sb >= th && eb < end;
             const unsigned long long ba = __ballot(ca), bb = __ballot(cb);
             __builtin_amdgcn_wave_barrier();   // all 128 entries read before any is overwritten
             const int na = __popcll(ba);
             if (ca) {
-                const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba, (uint32_t)nc));
+                const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba, (uint32_t)out));
                 pq[o] = (uint16_t)qa;
                 ps[o] = (uint8_t)sa;
             }
             if (cb) {
-                const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, (uint32_t)(nc + na)));
+                const int o = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, (uint32_t)(out + na)));
                 pq[o] = (uint16_t)qb;
                 ps[o] = (uint8_t)sb;
             }
-            nc += na + __popcll(bb);
+            out += na + __popcll(bb);
         }
+        return out;
+    };
+    int nc = 0;
+    if (!over) nc = score_compact(0, qn, iniTh, 0);
+    if (second_pass && !over) {   // which cells have a corner at iniTh in this wave's band
+        wave_lds_sync();
+        uint32_t m = 0u;
+        for (int e = lane; e < nc; e += 64) m |= 1u << (((uint32_t)(pq[e] & 0xff) * T.rcp_wcell) >> 16);
+        if (m) atomicOr(reinterpret_cast<uint32_t *>(ovf + 1), m);
     }
-    if (over && lane == 0) *ovf = 1;
-    __syncthreads();   // the pixel tile is dead from here on
-    if (*ovf) {        // a queue of some wave overflowed: the whole strip takes the second-pass kernel, cell by cell
+    if (over && lane == 0) ovf[0] = 1;
+    __syncthreads();   // without a second pass the pixel tile is dead from here on
+    bool ovf_any = ovf[0] != 0;
+    // ---- second pass (:843-846): cells without any corner at iniTh, at minTh, while their pixels are still in LDS ----
+    const uint32_t needy = (second_pass && !ovf_any) ? ~(uint32_t)ovf[1] & ((1u << T.ncell) - 1u) : 0u;   // the same value in every wave
+    if (needy) {
+        const u16x2 t2 = as_pk((uint32_t)minTh * 0x00010001u);
+        const int wcell = (int)T.wcell;
+        int qn2 = nc;   // the candidates of the second pass queue up behind the corners of the first
+        for (uint32_t rest = needy; rest; rest &= rest - 1u) {
+            const int c = __builtin_ctz(rest);                                    // wave-uniform
+            const int xa = c * wcell, xb = min(xa + wcell, iw);                   // the cell's interior columns [xa, xb)
+            const int g0 = xa >> 2, Gc = ((xb - 1) >> 2) - g0 + 1;                // its 4-pixel groups (the first and last may straddle a neighbour)
+            const uint32_t rcpG = (65536u + (uint32_t)Gc - 1u) / (uint32_t)Gc;    // lane / Gc for lane < 64
+            const int RPI = (int)((64u * rcpG) >> 16);                            // whole rows per iteration
+            const int lrow = (int)(((uint32_t)lane * rcpG) >> 16), lg = lane - lrow * Gc;
+            const int x4 = 4 * (g0 + lg);
+            // pixels of the group inside the cell (and so inside the interior: xb <= iw)
+            const uint32_t cmask = lrow < RPI ? ((0xfu << max(xa - x4, 0)) & 0xfu) & (0xfu >> max(x4 + 3 - (xb - 1), 0)) : 0u;
+            for (int y0 = yb0; y0 < yb1; y0 += RPI) {
+                const int y = y0 + lrow;
+                const bool act = cmask != 0u && y < yb1;
+                const uint32_t *A = reinterpret_cast<const uint32_t *>(pix + (act ? y : yb0) * P + (act ? x4 : 4 * g0) + 4);
+                const uint32_t r8 = A[0], r0 = A[6 * D];
+                const uint32_t aL = A[1 * D - 1], aC = A[1 * D], aR = A[1 * D + 1];
+                const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];
+                const uint32_t bL = A[5 * D - 1], bC = A[5 * D], bR = A[5 * D + 1];
+#define FS_EVEN(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(s) | ((uint32_t)((s) + 2) << 16)))
+#define FS_ODD(hi, lo, s) as_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)((s) + 1) | ((uint32_t)((s) + 3) << 16)))
+                const uint32_t fe = quick_pairs(pk_even(cC), pk_even(r0), pk_even(r8), FS_EVEN(cR, cC, 3), FS_EVEN(cC, cL, 1), FS_EVEN(bR, bC, 2),
+                                                FS_EVEN(aC, aL, 2), FS_EVEN(aR, aC, 2), FS_EVEN(bC, bL, 2), t2);
+                const uint32_t fo = quick_pairs(pk_odd(cC), pk_odd(r0), pk_odd(r8), FS_ODD(cR, cC, 3), FS_ODD(cC, cL, 1), FS_ODD(bR, bC, 2),
+                                                FS_ODD(aC, aL, 2), FS_ODD(aR, aC, 2), FS_ODD(bC, bL, 2), t2);
+#undef FS_EVEN
+#undef FS_ODD
+                uint32_t ze, zo;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(ze) : "v"(fe), "v"(0x00010001u));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(zo) : "v"(fo), "v"(0x00010001u));
+                const uint32_t z = ze | (zo << 1);
+                const uint32_t m4 = act ? (z | (z >> 14)) & cmask : 0u;
+                const int cn = __popc(m4);
+                const int incl = wave_incl_scan(cn);
+                int pos = qn2 + incl - cn;
+                const uint32_t e0 = ((uint32_t)y << 8) | (uint32_t)x4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((m4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k);
+                    pos += (int)(m4 >> k & 1u);
+                }
+                qn2 += __builtin_amdgcn_readlane(incl, 63);
+            }
+        }
+        wave_lds_sync();
+        if (qn2 > qcap) { if (lane == 0) ovf[2] = 1; }
+        else nc = score_compact(nc, qn2, minTh, nc);
+        __syncthreads();   // the pixel tile is dead from here on
+        ovf_any = ovf[2] != 0;
+    }
+    if (ovf_any) {     // a queue of some wave overflowed: the whole strip takes the second-pass kernel, cell by cell
         if (threadIdx.x < T.ncell) list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + threadIdx.x);
         return;
     }
@@ -289,22 +358,30 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
         int total = 0;
 #pragma unroll
         for (int w = 0; w < W; w++) total += cnt[w * kStripMaxCells + lane];
-        if (total > 0 || !second_pass) cellcnt[(size_t)f * total_cells + T.cell0 + lane] = total;
-        else list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + lane);   // cv::FAST(cell, iniThFAST) found nothing: second pass (:843-846)
+        // an empty cell is final when FAST(minTh) has been run on it above (or cannot find more: !second_pass); a cell whose corners at iniTh all
+        // lost the NMS (equal scores side by side) is empty for the reference as well, which then runs FAST(minTh) on it: the list pass (rare)
+        if (total > 0 || !second_pass || ((needy >> lane) & 1u)) cellcnt[(size_t)f * total_cells + T.cell0 + lane] = total;
+        else list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + lane);
     }
 }
 
 template <int W>
 __global__ __launch_bounds__(64 * W) void k_fast_strip(const StripTile *__restrict__ tiles, const uint8_t *__restrict__ pyr,
                                                        size_t pyr_frame_stride, int32_t *__restrict__ cellcnt, int total_cells,
-                                                       uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh,
+                                                       uint32_t *__restrict__ cellent, size_t ent_frame_stride, int iniTh, int minTh,
                                                        int pix_bytes, int gcap, int qcap, uint32_t *__restrict__ list,
-                                                       int32_t *__restrict__ list_count, int second_pass, int n_frames) {
+                                                       int32_t *__restrict__ list_count, int second_pass, int n_frames, const Level0Src src0, int n_strips0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int tile, f;
     if (!xcd_frame_map(n_frames, &tile, &f)) return;   // a frame's strips stay on one XCD (apron rows hit its L2)
     const StripTile T = tiles[tile];
-#define ORBX_STRIP_BODY(PITCH) fast_strip_body<W, PITCH>(T, f, smem, pyr, pyr_frame_stride, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, pix_bytes, gcap, qcap, list, list_count, second_pass)
+    // level 0 in place (src0.img != nullptr): its strips -- the first n_strips0 of a frame -- read the caller's frame; FAST never looks at the ring
+    // (the detection window starts 16 px inside the image, ORBextractor.cc:789-792)
+    const bool in_place = src0.img != nullptr && tile < n_strips0;   // workgroup-uniform
+    const uint8_t *tile_src = in_place ? src0.img + (size_t)f * src0.frame_stride + (size_t)(kBorder + T.oy - 3) * src0.row_stride + (kBorder + T.ox - 4)
+                                       : pyr + (size_t)f * pyr_frame_stride + T.src_off;
+    const int spitch = in_place ? (int)src0.row_stride : T.pitch;
+#define ORBX_STRIP_BODY(PITCH) fast_strip_body<W, PITCH>(T, f, smem, tile_src, spitch, cellcnt, total_cells, cellent, ent_frame_stride, iniTh, minTh, pix_bytes, gcap, qcap, list, list_count, second_pass)
     if (T.lds_pitch == (uint32_t)kStripPitch) ORBX_STRIP_BODY(kStripPitch);          // wave-uniform
     else if (T.lds_pitch == (uint32_t)kStripPitchMid) ORBX_STRIP_BODY(kStripPitchMid);
     else ORBX_STRIP_BODY(kStripPitchLow);

@@ -77,6 +77,181 @@ using namespace orbx;
 
 namespace orbx {
 
+// ---------------------------------------------------------------------------------------------------------
+// k_pyr_stream's per-geometry tables (pyr_stream.hip.h): the bands of a frame, the row schedule of every band (which rows of which level are
+// produced in which step), the LDS rings and the task list the waves of a workgroup work through.
+//   level 0 = the frame's rows, staged `rows0` per step;  level l rows become computable once both their source rows are complete;
+//   ring of level l = the largest distance, over the steps, between the newest row written and the oldest row its reader still needs.
+// Returns false when the geometry does not fit (a scale factor above 2, LDS budget, 16-bit table fields): the per-level launches stay.
+// ---------------------------------------------------------------------------------------------------------
+struct PyrStreamPlan {
+    PyrStreamGeom geom;
+    std::vector<PyrStreamLevel> levels;   // [nlevels], entry 0 unused
+    std::vector<PyrColumn> cols;
+    std::vector<PyrStep> steps;      // [bands][steps_per_band]
+    std::vector<PyrTask> tasks;      // all bands
+    std::vector<uint32_t> band_task0;
+    int bands = 0;
+    size_t lds_bytes = 0;
+};
+
+static bool build_pyr_stream(const std::vector<LevelInfo> &lv, const std::vector<ResizeTap> &ytab, const std::vector<ResizeGroup> &xg, const bool *march_ok,
+                             int bands, int rows0, size_t lds_budget, PyrStreamPlan &out) {
+    const int nl = (int)lv.size();
+    if (nl < 2 || nl > kMaxLevels || lv[0].w < 16) return false;
+    for (int l = 1; l < nl; l++) if (!march_ok[l]) return false;
+    PyrStreamPlan P;
+    memset(&P.geom, 0, sizeof(P.geom));
+    PyrStreamGeom &G = P.geom;
+    P.levels.assign(nl, PyrStreamLevel{0u, 0u, 0u, 0u, 0u, 0u, 0, 0u});
+    // ---- column tables ----
+    std::vector<int> nchunk(nl, 0);
+    uint32_t xg_bytes = 0;
+    for (int l = 1; l < nl; l++) {
+        const int nd = lv[l].pitch / 4;
+        int first = -1, last = -1;
+        for (int c = 0; c < nd; c++) if (xg[lv[l].xg_off + c].valid != 2) { if (first < 0) first = c; last = c; }
+        if (first < 0) return false;
+        PyrStreamLevel &S = P.levels[l];
+        S.xg_lds = xg_bytes; S.col0 = (uint32_t)first; S.ncol = (uint32_t)(last - first + 1);
+        S.pitch = (uint32_t)lv[l].pitch; S.off_lo = (uint32_t)lv[l].off; S.off_hi = (uint32_t)(lv[l].off >> 32);
+        S.h = lv[l].h; S.roi_dw = (uint32_t)((lv[l].w + 3) / 4);
+        nchunk[l] = (int)(S.ncol + 63) / 64;
+        if (nchunk[l] > 15) return false;
+        for (int c = first; c <= last; c++) {
+            const ResizeGroup &g = xg[lv[l].xg_off + c];
+            if (g.valid == 1 && (g.base < 0 || g.base > 0xffff)) return false;
+            PyrColumn pc;
+            pc.base_valid = (g.valid == 1 ? (uint32_t)g.base : 0u) | ((uint32_t)g.valid << 30);
+            pc.sel = g.sel;
+            for (int k = 0; k < 4; k++) pc.cc[k] = g.cc[k];
+            P.cols.push_back(pc);
+        }
+        xg_bytes += S.ncol * (uint32_t)sizeof(PyrColumn);
+    }
+    if (P.cols.size() & 1) P.cols.push_back(PyrColumn{0u, 0u, {0u, 0u, 0u, 0u}});   // the tables are staged into LDS sixteen bytes per thread
+    xg_bytes = (uint32_t)(P.cols.size() * sizeof(PyrColumn));
+    G.xg_bytes = xg_bytes;
+    // source rows of output row r of level l (clamped as k_pyr_resize_march clamps them)
+    auto src0 = [&](int l, int r) { return std::min(std::max(ytab[lv[l].ytab_off + r].ofs, 0), lv[l - 1].h - 1); };
+    auto src1 = [&](int l, int r) { return std::min(std::max(ytab[lv[l].ytab_off + r].ofs + 1, 0), lv[l - 1].h - 1); };
+    G.cpr0 = (uint32_t)((lv[0].w + 15) / 16);
+    G.cpr0_rcp = (uint32_t)((0x100000000ull + G.cpr0 - 1) / G.cpr0);
+    G.w0 = lv[0].w;
+    if ((uint32_t)rows0 * G.cpr0 > (uint32_t)(kPyrStreamStage * kPyrStreamThreads)) rows0 = (int)((kPyrStreamStage * kPyrStreamThreads) / G.cpr0);
+    if (rows0 < 2) return false;
+    // ---- per band: compute ranges, schedule, ring sizes ----
+    struct Band { std::vector<std::pair<int, int>> own, comp; std::vector<std::vector<std::pair<int, int>>> steps; std::vector<int> ring; };
+    std::vector<Band> B(bands);
+    std::vector<int> ring(nl, 0);
+    size_t max_steps = 0;
+    for (int k = 0; k < bands; k++) {
+        Band &b = B[k];
+        b.own.assign(nl, {0, 0}); b.comp.assign(nl, {0, 0});
+        for (int l = 1; l < nl; l++) b.own[l] = {(int)((long)k * lv[l].h / bands), (int)((long)(k + 1) * lv[l].h / bands)};
+        b.comp[nl - 1] = b.own[nl - 1];
+        for (int l = nl - 2; l >= 0; l--) {
+            int lo = src0(l + 1, b.comp[l + 1].first), hi = src1(l + 1, b.comp[l + 1].second - 1);
+            if (b.comp[l + 1].second <= b.comp[l + 1].first) { lo = b.own[l].first; hi = b.own[l].first - 1; }
+            if (l >= 1) { lo = std::min(lo, b.own[l].first); hi = std::max(hi, b.own[l].second - 1); }
+            b.comp[l] = {lo, hi + 1};
+        }
+        std::vector<int> rb(nl);
+        for (int l = 0; l < nl; l++) rb[l] = b.comp[l].first;
+        auto done = [&]() { for (int l = 0; l < nl; l++) if (rb[l] < b.comp[l].second) return false; return true; };
+        while (!done()) {
+            const std::vector<int> prev = rb;
+            rb[0] = std::min(b.comp[0].second, prev[0] + rows0);
+            for (int l = 1; l < nl; l++) {
+                int r = prev[l];
+                while (r < b.comp[l].second && src1(l, r) < prev[l - 1]) r++;
+                rb[l] = r;
+            }
+            std::vector<std::pair<int, int>> st(nl);
+            for (int l = 0; l < nl; l++) st[l] = {prev[l], rb[l]};
+            b.steps.push_back(st);
+            if (b.steps.size() > 4096) return false;
+        }
+        for (auto &st : b.steps)
+            for (int l = 0; l + 1 < nl; l++) {
+                const int a = st[l + 1].first;
+                const int lo = a < b.comp[l + 1].second ? src0(l + 1, a) : st[l].second;
+                ring[l] = std::max(ring[l], st[l].second - lo);
+            }
+        max_steps = std::max(max_steps, b.steps.size());
+    }
+    // ---- LDS layout ----
+    std::vector<uint32_t> ring_off(nl, 0), ring_pitch(nl, 0);
+    size_t lds = xg_bytes;
+    for (int l = 0; l + 1 < nl; l++) {
+        ring[l] = std::max(ring[l], 2);
+        ring_pitch[l] = (uint32_t)(((lv[l].w + 15) & ~15) + 16);
+        ring_off[l] = (uint32_t)lds;
+        lds += (size_t)ring[l] * ring_pitch[l];
+    }
+    lds += 16;
+    if (lds > lds_budget || lds / 16 >= 0xffff) return false;
+    G.ring0_off = ring_off[0]; G.ring0_pitch = ring_pitch[0]; G.ring0_rows = (uint32_t)ring[0];
+    G.steps_per_band = (uint32_t)max_steps;
+    // ---- steps and tasks ----
+    P.steps.assign((size_t)bands * max_steps, PyrStep{0u, 0u, 0u, 0u});
+    for (int k = 0; k < bands; k++) {
+        const Band &b = B[k];
+        P.band_task0.push_back((uint32_t)P.tasks.size());
+        const size_t t0 = P.tasks.size();
+        auto slot_off = [&](int l, int row) { return (uint16_t)((ring_off[l] + (uint32_t)((row - b.comp[l].first) % ring[l]) * ring_pitch[l]) / 16u); };
+        for (size_t s = 0; s < max_steps; s++) {
+            PyrStep &d = P.steps[(size_t)k * max_steps + s];
+            d.task_begin = d.task_end = (uint32_t)(P.tasks.size() - t0);
+            if (s >= b.steps.size()) continue;
+            const auto &st = b.steps[s];
+            const int y0 = st[0].first, ny = st[0].second - st[0].first;
+            if (y0 > 0xffff || ny > 0xffff) return false;
+            d.y0_rows = (uint32_t)y0 | ((uint32_t)ny << 16);
+            d.slot0 = (uint32_t)((y0 - b.comp[0].first) % ring[0]);
+            for (int l = 1; l < nl; l++) {
+                int r = st[l].first;
+                const int re = st[l].second;
+                while (r < re) {
+                    PyrTask T;
+                    memset(&T, 0, sizeof(T));
+                    const int a0 = src0(l, r), a1 = src1(l, r);
+                    int rows = 1, nsrc = 2;
+                    if (r + 1 < re && a1 == a0 + 1) {   // a pair: rows r, r + 1 from three (shared middle) or four consecutive source rows
+                        const int c0 = src0(l, r + 1), c1 = src1(l, r + 1);
+                        if (c0 == a1 && c1 == a1 + 1) { rows = 2; nsrc = 3; }
+                        else if (c0 == a1 + 1 && c1 == a1 + 2) { rows = 2; nsrc = 4; }
+                    }
+                    T.row = (uint32_t)r;
+                    T.src[0] = slot_off(l - 1, a0);
+                    T.src[1] = slot_off(l - 1, a1);
+                    T.src[2] = nsrc >= 3 ? slot_off(l - 1, a0 + 2) : T.src[1];
+                    T.src[3] = nsrc >= 4 ? slot_off(l - 1, a0 + 3) : T.src[2];
+                    uint32_t flags = 0;
+                    for (int q = 0; q < 2; q++) {
+                        const int rr = r + (q < rows ? q : 0);
+                        const ResizeTap &ty = ytab[lv[l].ytab_off + rr];
+                        T.b[q] = (uint32_t)(uint16_t)ty.c0 | ((uint32_t)(uint16_t)ty.c1 << 16);
+                        T.dst[q] = (l + 1 < nl && q < rows) ? slot_off(l, rr) : (uint16_t)0xffffu;
+                        if (q < rows && rr >= b.own[l].first && rr < b.own[l].second) flags |= 1u << (12 + q);
+                    }
+                    for (int c = 0; c < nchunk[l]; c++) {
+                        T.hdr = (uint32_t)l | ((uint32_t)c << 4) | ((uint32_t)(rows - 1) << 8) | ((uint32_t)nsrc << 9) | flags;
+                        P.tasks.push_back(T);
+                    }
+                    r += rows;
+                }
+            }
+            d.task_end = (uint32_t)(P.tasks.size() - t0);
+        }
+    }
+    if (P.tasks.empty()) return false;
+    P.bands = bands;
+    P.lds_bytes = lds;
+    out = std::move(P);
+    return true;
+}
+
 static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (width > kMaxDim || height > kMaxDim) return ORBX_E_TOO_LARGE;
     const bool same_geom = (width == ex->width && height == ex->height);
@@ -90,6 +265,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     std::vector<StripTile> strips;
     std::vector<int> strip_level_rows;
     bool fast_strip = true;
+    bool fused_blur = false;   // committed to ex together with the geometry, once every allocation and upload has succeeded
     size_t pyr_off = 0, blur_off = 0;
     uint32_t cand_off = 0, lvl_off = 0;
     int cell_base = 0, cap = 0, max_pool = 0;
@@ -221,6 +397,27 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         fast_wave_qfull = std::max(fast_wave_qfull, (L.wCell * L.hCell + 15) & ~15);
     }
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
+    // k_pyr_stream: two bands per frame and as many frame rows per step as keep two workgroups on a CU (LDS <= 80 KB); wider frames take more bands,
+    // then fewer rows per step
+    PyrStreamPlan plan;
+    bool ps_ok = false;
+    {
+        int want_bands = 0, want_rows = 0;
+        if (const char *v = getenv("ORBX_PYR_BANDS")) want_bands = atoi(v);
+        if (const char *v = getenv("ORBX_PYR_ROWS")) want_rows = atoi(v);
+        const char *off = getenv("ORBX_PYR_STREAM");
+        if (!(off && off[0] == '0')) {
+            if (want_bands > 0 && want_rows > 0) ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, want_bands, want_rows, 150 * 1024, plan);
+            else
+                for (int kb : {2, 4, 8}) {
+                    for (int r0 : {8, 6, 5, 4, 3}) {
+                        if (kb * 8 > height) continue;
+                        if ((ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, 80 * 1024, plan))) break;
+                    }
+                    if (ps_ok) break;
+                }
+        }
+    }
 
     ORBX_HIP(hipSetDevice(ex->device));
     ORBX_HIP(hipStreamSynchronize(ex->stream));
@@ -229,6 +426,9 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->mkey = orbx_extractor::MatchKey();
     ex->mpkey = orbx_extractor::MpKey();
     const int B = std::max(batch, ex->batch_cap);
+    // from here on device tables and buffers change: a failure below must not leave the extractor claiming its old geometry (the early return at
+    // the top would then launch on half-updated tables) -- the geometry is committed again at the end
+    ex->width = 0; ex->height = 0;
     int r;
 #define ENS(buf, bytes) if ((r = (buf).ensure(bytes)) != ORBX_OK) return r
     ENS(ex->d_lv, sizeof(LevelInfo) * nl);
@@ -237,6 +437,13 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_xgtab, sizeof(ResizeGroup) * std::max<size_t>(xgtab.size(), 1));
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_blur_items, sizeof(BlurItem) * blur_items.size());
+    if (ps_ok) {
+        ENS(ex->d_ps_levels, plan.levels.size() * sizeof(PyrStreamLevel));
+        ENS(ex->d_ps_cols, plan.cols.size() * sizeof(PyrColumn));
+        ENS(ex->d_ps_steps, plan.steps.size() * sizeof(PyrStep));
+        ENS(ex->d_ps_tasks, plan.tasks.size() * sizeof(PyrTask));
+        ENS(ex->d_ps_band0, plan.band_task0.size() * sizeof(uint32_t));
+    }
     ENS(ex->d_pyr, pyr_off * B);
     if (ex->pyr_double) ENS(ex->d_pyr2, pyr_off * B);
     // The blur on demand (k_describe_fused) filters 43 x 43 pixels per keypoint (VALU bound: +39 us per 256 k keypoints over k_describe), the blur pass
@@ -248,9 +455,9 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         size_t pyr_px = 0;
         for (int l = 0; l < nl; l++) pyr_px += (size_t)lv[l].w * lv[l].h;
         const char *v = getenv("ORBX_FUSED_BLUR");
-        ex->fused_blur = v && (v[0] == '0' || v[0] == '1') ? v[0] == '1' : (size_t)std::max(ex->prm.nfeatures, 0) * 1369 <= 4 * pyr_px;
+        fused_blur = v && (v[0] == '0' || v[0] == '1') ? v[0] == '1' : (size_t)std::max(ex->prm.nfeatures, 0) * 1369 <= 4 * pyr_px;
     }
-    if (!ex->fused_blur) ENS(ex->d_blur, blur_off * B);   // (orbx_debug_level_blurred allocates it when it is the only user)
+    if (!fused_blur) ENS(ex->d_blur, blur_off * B);   // (orbx_debug_level_blurred allocates it when it is the only user)
     ENS(ex->d_cellcnt, sizeof(int32_t) * (size_t)cell_base * B);
     ENS(ex->d_cellent, sizeof(uint32_t) * (size_t)cand_off * B);
     ENS(ex->d_keys0, sizeof(uint32_t) * (size_t)cand_off * B);
@@ -275,13 +482,30 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (!xgtab.empty()) ORBX_HIP(hipMemcpy(ex->d_xgtab.p, xgtab.data(), sizeof(ResizeGroup) * xgtab.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_items.p, blur_items.data(), sizeof(BlurItem) * blur_items.size(), hipMemcpyHostToDevice));
+    ex->ps_ok = false;
+    if (ps_ok) {
+        ORBX_HIP(hipMemcpy(ex->d_ps_levels.p, plan.levels.data(), plan.levels.size() * sizeof(PyrStreamLevel), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(ex->d_ps_cols.p, plan.cols.data(), plan.cols.size() * sizeof(PyrColumn), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(ex->d_ps_steps.p, plan.steps.data(), plan.steps.size() * sizeof(PyrStep), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(ex->d_ps_tasks.p, plan.tasks.data(), plan.tasks.size() * sizeof(PyrTask), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(ex->d_ps_band0.p, plan.band_task0.data(), plan.band_task0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (plan.lds_bytes > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_pyr_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes));
+    }
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
     // Cells the reference skips (empty interior: iniX >= maxBorderX - 6 / iniY >= maxBorderY - 3, ORBextractor.cc:810,819 -- e.g. cell column 33 of
     // level 0 of a 1226 x 370 image) belong to no strip and are never written by the FAST stage; compact_level reads every cell's count.  A
-    // buffer kept from another geometry holds that geometry's counts there: clear it whenever the cell layout changes.
-    if (!same_geom) ORBX_HIP(hipMemset(ex->d_cellcnt.p, 0, ex->d_cellcnt.bytes));
+    // buffer kept from another geometry holds that geometry's counts there, and a buffer re-allocated for a larger batch of the same geometry starts
+    // with the allocator's fill (poison bytes in guard mode): cleared at every (re)configuration -- this is a cold path.
+    ORBX_HIP(hipMemset(ex->d_cellcnt.p, 0, ex->d_cellcnt.bytes));
     ORBX_HIP(hipDeviceSynchronize());   // the fill has run (DevBuf::ensure, extractor_state.h)
     ex->lv = lv;
+    ex->ps_ok = ps_ok;
+    if (ps_ok) { ex->ps_geom = plan.geom; ex->ps_bands = plan.bands; ex->ps_lds = plan.lds_bytes; }
+    if (const char *v = getenv("ORBX_PYR_MIN_FRAMES")) ex->ps_min_frames = std::max(1, atoi(v));
+    if (getenv("ORBX_DEBUG_ALLOC") && ps_ok)
+        fprintf(stderr, "[orbx pyr] k_pyr_stream: %d bands, %u steps, %zu tasks, LDS %zu B (tables %u B)\n", plan.bands, plan.geom.steps_per_band, plan.tasks.size(),
+                plan.lds_bytes, plan.geom.xg_bytes);
+    ex->fused_blur = fused_blur;
     ex->width = width; ex->height = height; ex->batch_cap = B;
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
     ex->total_cells = cell_base; ex->cap = cap; ex->max_pool = max_pool; ex->fast_lds = fast_lds; ex->fast_wave = fast_wave && fast_tiles.size() < 65536 && batch < 65536;
@@ -331,6 +555,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
                     T.rows_per_iter = (uint16_t)(64u / G);
                     T.ncell = (uint16_t)((IW + L.wCell - 1) / L.wCell);
                     T.lds_pitch = (uint32_t)pitch;
+                    T.wcell = (uint32_t)L.wCell;
                     if ((IH + 6) * pitch > budget) fast_strip = false;
                     strips.push_back(T);
                 }
@@ -343,6 +568,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         }
     }
     ex->n_strips = (int)strips.size();
+    ex->n_strips0 = 0;
+    for (const StripTile &T : strips) if (T.src_off < lv[0].off + (size_t)lv[0].pitch * (lv[0].h + 2 * kEdge)) ex->n_strips0++;   // level 0 lies first in the slab
     ex->fast_strip = fast_strip && ex->fast_wave && !strips.empty();
     if (ex->strip_qcap > 2 * ex->strip_gcap) ex->strip_gcap = (ex->strip_qcap / 2 + 7) & ~7;   // the scores reuse the group queue's bytes
     if (getenv("ORBX_DEBUG_ALLOC"))
@@ -354,6 +581,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_items = (int)blur_items.size();
     ex->last_batch = 0;
+    ex->lvl0_inplace = false;
     if (ex->has_camera) {
         CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],
                          ex->cam_params[6], ex->cam_params[7], ex->cam_params[8]};
@@ -406,6 +634,35 @@ static void launch_blur_stream(orbx_extractor *ex, int n, const uint8_t *pyr, hi
                             bg[0], bg[1], bg[2], bg[3], n, nx);
 }
 
+// k_pyr_base: the frames into the padded level-0 slab of `pyr` (ring = REFLECT_101 of the image)
+static int launch_pyr_base(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride, uint8_t *pyr, hipStream_t st, bool zero_word) {
+    ProfScope ps(ex, K_PYR_BASE);
+    const LevelInfo &L = ex->lv[0];
+    const dim3 grid = xcd_grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n, true);   // a frame's workgroups stay on one XCD
+    hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, st, L, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
+                       zero_word ? (int32_t *)ex->d_fast_ovf.p : (int32_t *)nullptr,
+                       (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)), n);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+}  // namespace orbx
+
+// The padded level 0 of the last batch, if that batch was extracted in place (extractor_state.h): written now, on the extractor's stream, from the
+// frames the caller still holds; ev_describe is recorded again so that whoever waits for the extraction waits for this too.
+int orbx_materialize_level0(orbx_extractor *ex) {
+    if (!ex) return ORBX_E_BAD_ARG;
+    if (!ex->lvl0_inplace) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(ex->device));
+    int r = orbx::launch_pyr_base(ex, ex->in0_images, ex->last_batch, ex->in0_row_stride, ex->in0_frame_stride, ex->pyr_cur(), ex->stream, false);
+    if (r != ORBX_OK) return r;
+    ORBX_HIP(hipEventRecord(ex->ev_describe, ex->stream));
+    ex->lvl0_inplace = false;
+    return ORBX_OK;
+}
+
+namespace orbx {
+
 // enqueue the whole extraction of `n` device-resident frames on ex->stream
 static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, size_t row_stride, size_t frame_stride,
                            int lap0, int lap1, hipEvent_t ev_input_consumed = nullptr, const HostMirror *mirror = nullptr) {
@@ -419,18 +676,28 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     hipStream_t st = ex->stream;
     hipStream_t pst = st;   // stream of the pyramid stage
     const bool pyr_local = true;   // a frame's pyramid workgroups stay on one XCD
-    {
-        ProfScope ps(ex, K_PYR_BASE);
-        const LevelInfo &L = ex->lv[0];
-        const dim3 grid = xcd_grid(((L.pitch / 16) * (L.h + 2 * kEdge) + 255) / 256, n, pyr_local);
-        hipLaunchKernelGGL(k_pyr_base, grid, dim3(256), 0, pst, L, d_images, row_stride, frame_stride, pyr, ex->pyr_frame,
-                           (int32_t *)ex->d_fast_ovf.p,
-                           (uint32_t)((0x100000000ull + (uint64_t)(L.pitch / 16) - 1) / (uint64_t)(L.pitch / 16)), n);
+    const bool stream = ex->ps_ok && n >= ex->ps_min_frames;
+    // level 0 in place: every reader of level 0 in this call can take the caller's frames (the FAST strips never touch the ring, k_describe_fused
+    // reflects the few windows that cross the border itself, k_pyr_stream reads the frames anyway)
+    const bool inplace0 = stream && ex->fused_blur && ex->fast_strip && !ex->pyr_double && mirror == nullptr && ex->inplace_allowed;
+    const Level0Src src0 = inplace0 ? Level0Src{d_images, row_stride, frame_stride} : Level0Src{nullptr, 0, 0};
+    ex->lvl0_inplace = inplace0;
+    ex->in0_images = d_images; ex->in0_row_stride = row_stride; ex->in0_frame_stride = frame_stride;
+    if (!inplace0) {
+        int r = launch_pyr_base(ex, d_images, n, row_stride, frame_stride, pyr, pst, true);
+        if (r != ORBX_OK) return r;
     }
-    if (ev_input_consumed) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));  // k_pyr_base is the only reader of the input frames
+    if (ev_input_consumed && !stream) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));  // k_pyr_base is the only reader of the input frames
     const int ini_th = std::min(std::max(ex->prm.ini_th_fast, 0), 255), min_th = std::min(std::min(std::max(ex->prm.min_th_fast, 0), 255), ini_th);
     const BlurTaps bt = blur_taps(ex);
-    for (int l = 1; l < nl; l++) {
+    if (stream) {   // levels 1 .. nl-1 in one launch, straight from the caller's frames
+        ProfScope ps(ex, K_PYR_RESIZE);
+        hipLaunchKernelGGL(k_pyr_stream, xcd_grid(ex->ps_bands, n, pyr_local), dim3(kPyrStreamThreads), ex->ps_lds, pst, ex->ps_geom, (const PyrStreamLevel *)ex->d_ps_levels.p, (const uint4 *)ex->d_ps_cols.p,
+                           (const PyrStep *)ex->d_ps_steps.p, (const PyrTask *)ex->d_ps_tasks.p, (const uint32_t *)ex->d_ps_band0.p, d_images, row_stride,
+                           frame_stride, pyr, ex->pyr_frame, inplace0 ? (int32_t *)ex->d_fast_ovf.p : (int32_t *)nullptr, n);
+        if (ev_input_consumed && !inplace0) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));   // k_pyr_base and k_pyr_stream have read the frames
+    }
+    for (int l = 1; l < nl && !stream; l++) {
         ProfScope ps(ex, K_PYR_RESIZE);
         const LevelInfo &L = ex->lv[l];
         if (ex->resize_march_ok[l]) {
@@ -477,8 +744,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             // profiles/r03_j_*, r03_k_*.  One launch on the main stream.)
             hipLaunchKernelGGL(k_fast_strip<4>, xcd_grid(ex->n_strips, n), dim3(256), fast_strip_lds_bytes(4, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap), st,
                                (const StripTile *)ex->d_strips.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,
-                               (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
-                               ini > mn ? 1 : 0, n);
+                               (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
+                               ini > mn ? 1 : 0, n, src0, ex->n_strips0);
             ORBX_HIP(hipGetLastError());   // e.g. an LDS budget the device refuses: fail here, not as silently missing candidates
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
@@ -486,7 +753,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(16384), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
                        (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p, \
                        ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qfull, (const uint32_t *)ovf_list,                  \
-                       (const int32_t *)ovf_count)
+                       (const int32_t *)ovf_count, src0)
             if (ex->fast_wave_pitch == 48) ORBX_FAST_WAVE_LIST(48); else ORBX_FAST_WAVE_LIST(64);
 #undef ORBX_FAST_WAVE_LIST
         } else {
@@ -551,12 +818,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         else if (bt.sat)   // the blur on demand, around the keypoints only (the blur slab is filled by orbx_debug_level_blurred alone)
             hipLaunchKernelGGL(k_describe_fused<true>, grid, dim3(256), 0, st, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p,
                                (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr, ex->pyr_frame, bt.g[0], bt.g[1], bt.g[2], bt.g[3],
-                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm);
+                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm, src0, ex->width, ex->height);
         else
             hipLaunchKernelGGL(k_describe_fused<false>, grid, dim3(256), 0, st, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p,
                                (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr, ex->pyr_frame, bt.g[0], bt.g[1], bt.g[2], bt.g[3],
-                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm);
+                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm, src0, ex->width, ex->height);
     }
+    if (ev_input_consumed && inplace0) ORBX_HIP(hipEventRecord(ev_input_consumed, st));   // in place: the descriptor stage is the frames' last reader
     if (ex->has_camera) {   // Frame::UndistortKeyPoints for the whole batch (mvKeysUn for the batched matchers)
         CameraModel c = {ex->cam_params[0], ex->cam_params[1], ex->cam_params[2], ex->cam_params[3], ex->cam_params[4], ex->cam_params[5],
                          ex->cam_params[6], ex->cam_params[7], ex->cam_params[8]};
@@ -672,6 +940,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipEventCreate(&ex->ev1);
     (void)hipStreamCreateWithPriority(&ex->copy_stream, hipStreamNonBlocking, prio_lo);
     { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
+    { const char *v = getenv("ORBX_LEVEL0_COPY"); ex->inplace_allowed = !(v && v[0] == '1'); }
     { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 16) ex->strip_qcap = atoi(v) & ~15; }  // test hook: k_fast_strip's pixel queues overflow, every cell takes the list pass
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);
@@ -740,7 +1009,8 @@ void orbx_destroy(orbx_extractor *ex) {
                       &ex->d_candtot, &ex->d_work, &ex->d_kps, &ex->d_desc, &ex->d_count, &ex->d_mono, &ex->d_err,
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
-                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_strips};
+                      &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_strips,
+                      &ex->d_ps_levels, &ex->d_ps_cols, &ex->d_ps_steps, &ex->d_ps_tasks, &ex->d_ps_band0};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);
@@ -1013,6 +1283,7 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
     const LevelInfo &L = ex->lv[level];
     if (dst_stride < (size_t)(L.w + 2 * kEdge)) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(ex->device));
+    if (level == 0) { int r0 = orbx_materialize_level0(ex); if (r0 != ORBX_OK) return r0; }
     const uint8_t *src = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off;
     const size_t bytes = (size_t)L.pitch * (L.h + 2 * kEdge);
     int r = ex->d2h_staged_begin(bytes);
@@ -1026,6 +1297,7 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
 int orbx_get_level_device(orbx_extractor *ex, int frame, int level, const uint8_t **d_padded, size_t *pitch) {
     if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
     const LevelInfo &L = ex->lv[level];
+    if (level == 0) { int r0 = orbx_materialize_level0(ex); if (r0 != ORBX_OK) return r0; }
     if (d_padded) *d_padded = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off + kRingX;
     if (pitch) *pitch = L.pitch;
     return ORBX_OK;
@@ -1102,6 +1374,7 @@ int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *
     if (r != ORBX_OK) return r;
     if (ex->fused_blur) {   // k_describe_fused blurs around the keypoints only: fill the blur slab of the last batch now
         if ((r = ex->d_blur.ensure(ex->blur_frame * (size_t)ex->batch_cap)) != ORBX_OK) return r;
+        if ((r = orbx_materialize_level0(ex)) != ORBX_OK) return r;
         launch_blur_stream(ex, ex->last_batch, ex->pyr_cur(), ex->stream);
         ORBX_HIP(hipGetLastError());
     }

@@ -65,6 +65,50 @@ struct ResizeGroup {
     uint32_t cc[4];
 };
 
+// ---- k_pyr_stream (pyr_stream.hip.h): per-geometry tables built by build_pyr_stream (orbx_extractor.hip) ----
+constexpr int kPyrStreamThreads = 512;
+constexpr int kPyrStreamStage = 4;      // 16-byte chunks of frame rows a thread may have in flight per step
+
+struct PyrColumn {        // one dword column of a padded row (ResizeGroup without its padding: 24 bytes, LDS resident)
+    uint32_t base_valid;  // first source byte of the column's taps (ROI x of the level before) | valid << 30 (1: taps, otherwise zeros)
+    uint32_t sel;         // byte offset of each pixel's left tap inside the 8 source bytes (v_perm_b32 selector)
+    uint32_t cc[4];       // Q11 tap pairs c0 | c1 << 16
+};
+static_assert(sizeof(PyrColumn) == 24, "PyrColumn layout");
+
+struct PyrStreamLevel {
+    uint32_t xg_lds;      // byte offset of the level's PyrColumn table inside LDS
+    uint32_t col0, ncol;  // first dword column of a padded row that holds ring / ROI pixels, number of such columns
+    uint32_t pitch;       // bytes per padded row in the slab
+    uint32_t off_lo, off_hi;   // byte offset of the level inside a frame's pyramid slab
+    int32_t h;            // ROI rows
+    uint32_t roi_dw;      // dwords of an ROI row kept in the LDS ring: ceil(w / 4)
+};
+
+struct PyrStreamGeom {    // kernel argument (scalar loads)
+    uint32_t xg_bytes;        // bytes of the PyrColumn tables (multiple of 16)
+    uint32_t steps_per_band;
+    uint32_t cpr0, cpr0_rcp;  // 16-byte chunks per frame row, ceil(2^32 / cpr0)
+    uint32_t ring0_off, ring0_pitch, ring0_rows;   // LDS ring of frame rows
+    int32_t w0;
+};
+
+struct PyrStep {          // 16 bytes, one scalar load
+    uint32_t task_begin, task_end;   // indices into the band's task list
+    uint32_t y0_rows;         // first frame row to stage | number of rows << 16
+    uint32_t slot0;           // ring slot of that row (the following rows take the following slots, wrapping at ring0_rows)
+};
+
+struct PyrTask {          // 32 bytes, one scalar load
+    uint32_t hdr;         // level | chunk << 4 | (rows - 1) << 8 | source rows << 9 | store row 0 << 12 | store row 1 << 13
+    uint32_t row;         // first output row (ROI row of the level)
+    uint16_t src[4];      // LDS byte offsets / 16 of the source rows (ROI byte 0), consecutive rows of the level before
+    uint16_t dst[2];      // LDS byte offsets / 16 of the output rows in this level's ring; 0xffff: the last level keeps none
+    uint32_t b[2];        // vertical tap pair c0 | c1 << 16 of each output row
+    uint32_t pad;
+};
+static_assert(sizeof(PyrTask) == 32 && sizeof(PyrStep) == 16, "task table layout");
+
 struct TileRef {  // blockIdx.x -> (level, tile) mapping for multi-level launches
     int16_t level;
     int16_t ti, tj;

@@ -1266,11 +1266,14 @@ extern "C" int orbx_stereo_batch_device(orbx_extractor *L, orbx_extractor *R, fl
     // pair of extractions, and k_stereo_sad reads the pyramids of THIS pair.  (The slab written next is the one the stereo stage before this
     // one read: every extraction waits for the rig's previous stereo stage before its k_finalize -- match_pending -- and the one after it
     // follows on the same stream.)
-    for (orbx_extractor *e : {L, R})
+    for (orbx_extractor *e : {L, R}) {
+        // a pair extracted before the rig existed may have read its level 0 in place: the SAD stage needs the padded level in the slab
+        if ((r = orbx_materialize_level0(e)) != ORBX_OK) return r;
         if (!e->pyr_double) {
             if ((r = e->d_pyr2.ensure(e->d_pyr.bytes)) != ORBX_OK) return r;
             e->pyr_double = true;   // pyr_slot stays: the current batch lies in the slab it was extracted into
         }
+    }
     const bool side = !L->profile && L->side_streams;
     hipStream_t st = side ? L->match_stream : L->stream;
     ORBX_HIP(hipMemcpyAsync(L->d_st_scales.p, L->scale.data(), sizeof(float) * nl, hipMemcpyHostToDevice, st));

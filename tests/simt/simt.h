@@ -326,6 +326,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 }
 
 template <typename T> inline T atomicAdd(T *p, T v) { const T o = *p; *p = o + v; return o; }
+template <typename T> inline T atomicOr(T *p, T v) { const T o = *p; *p = o | v; return o; }
 template <typename T> inline T atomicExch(T *p, T v) { const T o = *p; *p = v; return o; }
 template <typename T> inline T atomicMax(T *p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 template <typename T> inline T atomicMin(T *p, T v) { const T o = *p; if (v < o) *p = v; return o; }
