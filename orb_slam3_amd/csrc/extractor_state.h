@@ -131,7 +131,7 @@ struct orbx_extractor {
     // device memory
     DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_items, d_dc;
     // k_pyr_stream (levels 1 .. n-1 in one launch): per-geometry tables; ps_ok false = the geometry does not fit, the per-level launches run
-    DevBuf d_ps_levels, d_ps_cols, d_ps_steps, d_ps_tasks, d_ps_band0;
+    DevBuf d_ps_cols, d_ps_steps, d_ps_tasks, d_ps_band0;
     bool ps_ok = false;
     orbx::PyrStreamGeom ps_geom;
     int ps_bands = 0, ps_min_frames = 16;   // batches smaller than ps_min_frames keep the per-level launches (a band is one workgroup: too few to fill the device)

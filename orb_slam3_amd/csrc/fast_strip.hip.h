@@ -16,7 +16,7 @@
 //            corners (score >= t) compacted in place                                                             | barrier
 //   2nd pass cells of the strip WITHOUT a corner at iniThFAST in any wave's band (known now, while the pixel tile is still alive): the reference
 //            runs cv::FAST(cell, minThFAST) for them (:843-846).  The four-pair test and the exact scores at minTh over those cells' columns
-//            only, appended to the same per-wave queues; the NMS below separates cells by a zero column, so the two thresholds never meet.
+//            only (one wave per such cell, all its rows), appended to that wave's queue; the NMS below separates cells by a zero column, so the two thresholds never meet.
 //            (Rounds 3-4 sent these cells -- 6 % of the bench's -- to k_fast_wave_list, which re-read their sub-images from HBM: 92 MB per
 //            256 frames and a launch.)                                                                             | barrier (only if any)
 //   NMS      the pixel tile is dead: each wave zeroes its band of the score tile and scatters its corners into it, with one ZERO
@@ -216,23 +216,29 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
     };
     int nc = 0;
     if (!over) nc = score_compact(0, qn, iniTh, 0);
-    if (second_pass && !over) {   // which cells have a corner at iniTh in this wave's band
+    if (second_pass == 1 && !over) {   // which cells have a corner at iniTh in this wave's band
         wave_lds_sync();
         uint32_t m = 0u;
         for (int e = lane; e < nc; e += 64) m |= 1u << (((uint32_t)(pq[e] & 0xff) * T.rcp_wcell) >> 16);
-        if (m) atomicOr(reinterpret_cast<uint32_t *>(ovf + 1), m);
+        uint32_t mw = 0u;   // OR over the wave: one ballot per cell (scalar unit), one LDS atomic per wave
+        for (int c = 0; c < (int)T.ncell; c++) mw |= __ballot((m >> c) & 1u) != 0ull ? 1u << c : 0u;
+        if (lane == 0 && mw) atomicOr(reinterpret_cast<uint32_t *>(ovf + 1), mw);
     }
     if (over && lane == 0) ovf[0] = 1;
     __syncthreads();   // without a second pass the pixel tile is dead from here on
     bool ovf_any = ovf[0] != 0;
     // ---- second pass (:843-846): cells without any corner at iniTh, at minTh, while their pixels are still in LDS ----
-    const uint32_t needy = (second_pass && !ovf_any) ? ~(uint32_t)ovf[1] & ((1u << T.ncell) - 1u) : 0u;   // the same value in every wave
+    const uint32_t needy = (second_pass == 1 && !ovf_any) ? ~(uint32_t)ovf[1] & ((1u << T.ncell) - 1u) : 0u;   // the same value in every wave
     if (needy) {
         const u16x2 t2 = as_pk((uint32_t)minTh * 0x00010001u);
         const int wcell = (int)T.wcell;
         int qn2 = nc;   // the candidates of the second pass queue up behind the corners of the first
-        for (uint32_t rest = needy; rest; rest &= rest - 1u) {
-            const int c = __builtin_ctz(rest);                                    // wave-uniform
+        // ONE wave takes a cell, all its rows (needy cell number i goes to wave i mod W): 64 / Gc rows per iteration fill the lanes (a wave's own band
+        // of ~10 rows would leave a fifth of them idle and cost every wave the set-up); the other waves wait at the barrier below
+        int turn = 0;
+        for (uint32_t rest = needy; rest; rest &= rest - 1u, turn++) {
+            if ((turn & (W - 1)) != wave) continue;                               // wave-uniform
+            const int c = __builtin_ctz(rest);
             const int xa = c * wcell, xb = min(xa + wcell, iw);                   // the cell's interior columns [xa, xb)
             const int g0 = xa >> 2, Gc = ((xb - 1) >> 2) - g0 + 1;                // its 4-pixel groups (the first and last may straddle a neighbour)
             const uint32_t rcpG = (65536u + (uint32_t)Gc - 1u) / (uint32_t)Gc;    // lane / Gc for lane < 64
@@ -241,10 +247,10 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
             const int x4 = 4 * (g0 + lg);
             // pixels of the group inside the cell (and so inside the interior: xb <= iw)
             const uint32_t cmask = lrow < RPI ? ((0xfu << max(xa - x4, 0)) & 0xfu) & (0xfu >> max(x4 + 3 - (xb - 1), 0)) : 0u;
-            for (int y0 = yb0; y0 < yb1; y0 += RPI) {
+            for (int y0 = 0; y0 < ih; y0 += RPI) {
                 const int y = y0 + lrow;
-                const bool act = cmask != 0u && y < yb1;
-                const uint32_t *A = reinterpret_cast<const uint32_t *>(pix + (act ? y : yb0) * P + (act ? x4 : 4 * g0) + 4);
+                const bool act = cmask != 0u && y < ih;
+                const uint32_t *A = reinterpret_cast<const uint32_t *>(pix + (act ? y : 0) * P + (act ? x4 : 4 * g0) + 4);
                 const uint32_t r8 = A[0], r0 = A[6 * D];
                 const uint32_t aL = A[1 * D - 1], aC = A[1 * D], aR = A[1 * D + 1];
                 const uint32_t cL = A[3 * D - 1], cC = A[3 * D], cR = A[3 * D + 1];
@@ -293,7 +299,8 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
         const int n16 = (r1 - r0) * (P / 16);
         for (int i = lane; i < n16; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    wave_lds_sync();
+    if (needy) __syncthreads();   // second-pass corners lie in any band: every band zeroed before any wave scatters (workgroup-uniform condition)
+    else wave_lds_sync();         // first-pass corners lie in the wave's own band
     for (int e = lane; e < nc; e += 64) {
         const int q = pq[e], x = q & 0xff;
         sco[((q >> 8) + 1) * P + 1 + x + (int)(((uint32_t)x * T.rcp_wcell) >> 16)] = ps[e];

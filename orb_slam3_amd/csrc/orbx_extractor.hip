@@ -138,7 +138,7 @@ static bool build_pyr_stream(const std::vector<LevelInfo> &lv, const std::vector
     G.cpr0 = (uint32_t)((lv[0].w + 15) / 16);
     G.cpr0_rcp = (uint32_t)((0x100000000ull + G.cpr0 - 1) / G.cpr0);
     G.w0 = lv[0].w;
-    if ((uint32_t)rows0 * G.cpr0 > (uint32_t)(kPyrStreamStage * kPyrStreamThreads)) rows0 = (int)((kPyrStreamStage * kPyrStreamThreads) / G.cpr0);
+    if ((uint32_t)rows0 * G.cpr0 > (uint32_t)(kPyrStreamStage * 64)) rows0 = (int)((kPyrStreamStage * 64) / G.cpr0);
     if (rows0 < 2) return false;
     // ---- per band: compute ranges, schedule, ring sizes ----
     struct Band { std::vector<std::pair<int, int>> own, comp; std::vector<std::vector<std::pair<int, int>>> steps; std::vector<int> ring; };
@@ -222,21 +222,37 @@ static bool build_pyr_stream(const std::vector<LevelInfo> &lv, const std::vector
                         if (c0 == a1 && c1 == a1 + 1) { rows = 2; nsrc = 3; }
                         else if (c0 == a1 + 1 && c1 == a1 + 2) { rows = 2; nsrc = 4; }
                     }
-                    T.row = (uint32_t)r;
-                    T.src[0] = slot_off(l - 1, a0);
-                    T.src[1] = slot_off(l - 1, a1);
-                    T.src[2] = nsrc >= 3 ? slot_off(l - 1, a0 + 2) : T.src[1];
-                    T.src[3] = nsrc >= 4 ? slot_off(l - 1, a0 + 3) : T.src[2];
-                    uint32_t flags = 0;
-                    for (int q = 0; q < 2; q++) {
-                        const int rr = r + (q < rows ? q : 0);
-                        const ResizeTap &ty = ytab[lv[l].ytab_off + rr];
-                        T.b[q] = (uint32_t)(uint16_t)ty.c0 | ((uint32_t)(uint16_t)ty.c1 << 16);
-                        T.dst[q] = (l + 1 < nl && q < rows) ? slot_off(l, rr) : (uint16_t)0xffffu;
-                        if (q < rows && rr >= b.own[l].first && rr < b.own[l].second) flags |= 1u << (12 + q);
-                    }
+                    const uint32_t s0 = slot_off(l - 1, a0), s1 = slot_off(l - 1, a1);
+                    const uint32_t s2 = nsrc >= 3 ? slot_off(l - 1, a0 + 2) : s1, s3 = nsrc >= 4 ? slot_off(l - 1, a0 + 3) : s2;
+                    T.src01 = s0 | (s1 << 16);
+                    T.src23 = s2 | (s3 << 16);
+                    const PyrStreamLevel &S = P.levels[l];
+                    const int h = lv[l].h;
+                    if (h < 2 * kEdge + 2) return false;   // a row with a copy in both rings: not handled (levels are at least 67 rows high)
                     for (int c = 0; c < nchunk[l]; c++) {
-                        T.hdr = (uint32_t)l | ((uint32_t)c << 4) | ((uint32_t)(rows - 1) << 8) | ((uint32_t)nsrc << 9) | flags;
+                        const uint32_t dcol0 = S.col0 + 64u * (uint32_t)c;                               // dword column of lane 0 inside the padded row
+                        const int nlive = std::min(64, (int)S.ncol - 64 * c);
+                        const int roi_first = std::max(0, kRoiX / 4 - (int)dcol0);                        // first lane whose dword lies in the ROI
+                        const int roi_n = std::max(0, std::min(nlive, kRoiX / 4 + (int)S.roi_dw - (int)dcol0) - roi_first);
+                        T.hdr = (uint32_t)(rows - 1) | ((uint32_t)nsrc << 1) | ((uint32_t)nlive << 4) | ((uint32_t)roi_first << 11) | ((uint32_t)roi_n << 18);
+                        T.xg = S.xg_lds + 64u * (uint32_t)c * (uint32_t)sizeof(PyrColumn);
+                        for (int q = 0; q < 2; q++) {
+                            const int rr = r + (q < rows ? q : 0);
+                            const ResizeTap &ty = ytab[lv[l].ytab_off + rr];
+                            T.b[q] = (uint32_t)(uint16_t)ty.c0 | ((uint32_t)(uint16_t)ty.c1 << 16);
+                            T.goff[q] = T.moff[q] = 0xffffffffu;
+                            if (q == 0) T.dlds = 0xffffffffu;
+                            if (q >= rows) continue;
+                            if (l + 1 < nl && roi_n > 0)
+                                T.dlds = (T.dlds & ~(0xffffu << (16 * q))) |
+                                         ((((uint32_t)slot_off(l, rr) * 16u + 4u * (dcol0 + (uint32_t)roi_first - (uint32_t)(kRoiX / 4))) / 4u) << (16 * q));
+                            if (rr >= b.own[l].first && rr < b.own[l].second) {
+                                const uint64_t row0 = lv[l].off + 4ull * dcol0;
+                                T.goff[q] = (uint32_t)(row0 + (uint64_t)(kEdge + rr) * lv[l].pitch);
+                                if (rr >= 1 && rr <= kEdge) T.moff[q] = (uint32_t)(row0 + (uint64_t)(kEdge - rr) * lv[l].pitch);
+                                if (rr <= h - 2 && rr >= h - 1 - kEdge) T.moff[q] = (uint32_t)(row0 + (uint64_t)(kEdge + 2 * (h - 1) - rr) * lv[l].pitch);
+                            }
+                        }
                         P.tasks.push_back(T);
                     }
                     r += rows;
@@ -438,7 +454,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_blur_items, sizeof(BlurItem) * blur_items.size());
     if (ps_ok) {
-        ENS(ex->d_ps_levels, plan.levels.size() * sizeof(PyrStreamLevel));
         ENS(ex->d_ps_cols, plan.cols.size() * sizeof(PyrColumn));
         ENS(ex->d_ps_steps, plan.steps.size() * sizeof(PyrStep));
         ENS(ex->d_ps_tasks, plan.tasks.size() * sizeof(PyrTask));
@@ -484,7 +499,6 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ORBX_HIP(hipMemcpy(ex->d_blur_items.p, blur_items.data(), sizeof(BlurItem) * blur_items.size(), hipMemcpyHostToDevice));
     ex->ps_ok = false;
     if (ps_ok) {
-        ORBX_HIP(hipMemcpy(ex->d_ps_levels.p, plan.levels.data(), plan.levels.size() * sizeof(PyrStreamLevel), hipMemcpyHostToDevice));
         ORBX_HIP(hipMemcpy(ex->d_ps_cols.p, plan.cols.data(), plan.cols.size() * sizeof(PyrColumn), hipMemcpyHostToDevice));
         ORBX_HIP(hipMemcpy(ex->d_ps_steps.p, plan.steps.data(), plan.steps.size() * sizeof(PyrStep), hipMemcpyHostToDevice));
         ORBX_HIP(hipMemcpy(ex->d_ps_tasks.p, plan.tasks.data(), plan.tasks.size() * sizeof(PyrTask), hipMemcpyHostToDevice));
@@ -692,7 +706,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const BlurTaps bt = blur_taps(ex);
     if (stream) {   // levels 1 .. nl-1 in one launch, straight from the caller's frames
         ProfScope ps(ex, K_PYR_RESIZE);
-        hipLaunchKernelGGL(k_pyr_stream, xcd_grid(ex->ps_bands, n, pyr_local), dim3(kPyrStreamThreads), ex->ps_lds, pst, ex->ps_geom, (const PyrStreamLevel *)ex->d_ps_levels.p, (const uint4 *)ex->d_ps_cols.p,
+        hipLaunchKernelGGL(k_pyr_stream, xcd_grid(ex->ps_bands, n, pyr_local), dim3(kPyrStreamThreads), ex->ps_lds, pst, ex->ps_geom, (const uint4 *)ex->d_ps_cols.p,
                            (const PyrStep *)ex->d_ps_steps.p, (const PyrTask *)ex->d_ps_tasks.p, (const uint32_t *)ex->d_ps_band0.p, d_images, row_stride,
                            frame_stride, pyr, ex->pyr_frame, inplace0 ? (int32_t *)ex->d_fast_ovf.p : (int32_t *)nullptr, n);
         if (ev_input_consumed && !inplace0) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));   // k_pyr_base and k_pyr_stream have read the frames
@@ -745,12 +759,12 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             hipLaunchKernelGGL(k_fast_strip<4>, xcd_grid(ex->n_strips, n), dim3(256), fast_strip_lds_bytes(4, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap), st,
                                (const StripTile *)ex->d_strips.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,
                                (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
-                               ini > mn ? 1 : 0, n, src0, ex->n_strips0);
+                               ini > mn ? (getenv("ORBX_FAST_FOLD") && getenv("ORBX_FAST_FOLD")[0] == '0' ? 2 : 1) : 0, n, src0, ex->n_strips0);
             ORBX_HIP(hipGetLastError());   // e.g. an LDS budget the device refuses: fail here, not as silently missing candidates
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
-    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(16384), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
+    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(n < 8 ? 256 : 2048), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
                        (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p, \
                        ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qfull, (const uint32_t *)ovf_list,                  \
                        (const int32_t *)ovf_count, src0)
@@ -1010,7 +1024,7 @@ void orbx_destroy(orbx_extractor *ex) {
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
                       &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_strips,
-                      &ex->d_ps_levels, &ex->d_ps_cols, &ex->d_ps_steps, &ex->d_ps_tasks, &ex->d_ps_band0};
+                      &ex->d_ps_cols, &ex->d_ps_steps, &ex->d_ps_tasks, &ex->d_ps_band0};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);

@@ -66,8 +66,9 @@ struct ResizeGroup {
 };
 
 // ---- k_pyr_stream (pyr_stream.hip.h): per-geometry tables built by build_pyr_stream (orbx_extractor.hip) ----
-constexpr int kPyrStreamThreads = 512;
-constexpr int kPyrStreamStage = 4;      // 16-byte chunks of frame rows a thread may have in flight per step
+constexpr int kPyrStreamWorkers = 8;     // waves that compute
+constexpr int kPyrStreamThreads = 64 * (kPyrStreamWorkers + 1);   // + the loader wave
+constexpr int kPyrStreamStage = 8;      // 16-byte chunks of frame rows a lane of the loader wave may have in flight per step
 
 struct PyrColumn {        // one dword column of a padded row (ResizeGroup without its padding: 24 bytes, LDS resident)
     uint32_t base_valid;  // first source byte of the column's taps (ROI x of the level before) | valid << 30 (1: taps, otherwise zeros)
@@ -99,15 +100,18 @@ struct PyrStep {          // 16 bytes, one scalar load
     uint32_t slot0;           // ring slot of that row (the following rows take the following slots, wrapping at ring0_rows)
 };
 
-struct PyrTask {          // 32 bytes, one scalar load
-    uint32_t hdr;         // level | chunk << 4 | (rows - 1) << 8 | source rows << 9 | store row 0 << 12 | store row 1 << 13
-    uint32_t row;         // first output row (ROI row of the level)
-    uint16_t src[4];      // LDS byte offsets / 16 of the source rows (ROI byte 0), consecutive rows of the level before
-    uint16_t dst[2];      // LDS byte offsets / 16 of the output rows in this level's ring; 0xffff: the last level keeps none
+struct PyrTask {          // 48 bytes, scalar loads; everything a wave needs to know about its 64 dword columns of one or two output rows
+    uint32_t hdr;         // (rows - 1) | source rows << 1 | live lanes (1 .. 64) << 4 | first lane with an ROI dword << 11 | lanes with an ROI dword << 18
+    uint32_t src01, src23;   // LDS byte offsets / 16 of the source rows (ROI byte 0), consecutive rows of the level before: row 0 | row 1 << 16, row 2 | row 3 << 16
+                          // (every field a whole dword: a 16-bit field would be fetched with a VECTOR load, whose wait also waits for the stores before it)
     uint32_t b[2];        // vertical tap pair c0 | c1 << 16 of each output row
+    uint32_t goff[2];     // byte offset inside a frame's pyramid slab of lane 0's dword of each output row; 0xffffffff: another band stores this row
+    uint32_t moff[2];     // ... of its REFLECT_101 copy in the 19-row ring above / below the level; 0xffffffff: none
+    uint32_t dlds;        // LDS byte offset / 4 of the first ROI dword of each output row in this level's ring (row 0 | row 1 << 16); 0xffff: the last level keeps none
+    uint32_t xg;          // LDS byte offset of lane 0's PyrColumn
     uint32_t pad;
 };
-static_assert(sizeof(PyrTask) == 32 && sizeof(PyrStep) == 16, "task table layout");
+static_assert(sizeof(PyrTask) == 48 && sizeof(PyrStep) == 16, "task table layout");
 
 struct TileRef {  // blockIdx.x -> (level, tile) mapping for multi-level launches
     int16_t level;
