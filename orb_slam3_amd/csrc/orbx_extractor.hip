@@ -96,7 +96,7 @@ struct PyrStreamPlan {
 };
 
 static bool build_pyr_stream(const std::vector<LevelInfo> &lv, const std::vector<ResizeTap> &ytab, const std::vector<ResizeGroup> &xg, const bool *march_ok,
-                             int bands, int rows0, size_t lds_budget, PyrStreamPlan &out) {
+                             int bands, int rows0, int workers, size_t lds_budget, PyrStreamPlan &out) {
     const int nl = (int)lv.size();
     if (nl < 2 || nl > kMaxLevels || lv[0].w < 16) return false;
     for (int l = 1; l < nl; l++) if (!march_ok[l]) return false;
@@ -135,6 +135,7 @@ static bool build_pyr_stream(const std::vector<LevelInfo> &lv, const std::vector
     // source rows of output row r of level l (clamped as k_pyr_resize_march clamps them)
     auto src0 = [&](int l, int r) { return std::min(std::max(ytab[lv[l].ytab_off + r].ofs, 0), lv[l - 1].h - 1); };
     auto src1 = [&](int l, int r) { return std::min(std::max(ytab[lv[l].ytab_off + r].ofs + 1, 0), lv[l - 1].h - 1); };
+    G.workers = (uint32_t)std::min(std::max(workers, 1), 15);
     G.cpr0 = (uint32_t)((lv[0].w + 15) / 16);
     G.cpr0_rcp = (uint32_t)((0x100000000ull + G.cpr0 - 1) / G.cpr0);
     G.w0 = lv[0].w;
@@ -259,6 +260,11 @@ static bool build_pyr_stream(const std::vector<LevelInfo> &lv, const std::vector
                 }
             }
             d.task_end = (uint32_t)(P.tasks.size() - t0);
+            // the costliest tasks first: with the waves taking tasks w, w + W, ... the step's last round holds the cheap ones
+            std::stable_sort(P.tasks.begin() + (ptrdiff_t)(t0 + d.task_begin), P.tasks.end(), [](const PyrTask &a, const PyrTask &b) {
+                auto cost = [](const PyrTask &t) { return (int)((t.hdr & 1u) * 2u + ((t.hdr >> 1) & 7u)); };
+                return cost(a) > cost(b);
+            });
         }
     }
     if (P.tasks.empty()) return false;
@@ -418,17 +424,18 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     PyrStreamPlan plan;
     bool ps_ok = false;
     {
-        int want_bands = 0, want_rows = 0;
+        int want_bands = 0, want_rows = 0, workers = 8;
         if (const char *v = getenv("ORBX_PYR_BANDS")) want_bands = atoi(v);
         if (const char *v = getenv("ORBX_PYR_ROWS")) want_rows = atoi(v);
+        if (const char *v = getenv("ORBX_PYR_WORKERS")) workers = atoi(v);
         const char *off = getenv("ORBX_PYR_STREAM");
         if (!(off && off[0] == '0')) {
-            if (want_bands > 0 && want_rows > 0) ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, want_bands, want_rows, 150 * 1024, plan);
+            if (want_bands > 0 && want_rows > 0) ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, want_bands, want_rows, workers, 150 * 1024, plan);
             else
                 for (int kb : {2, 4, 8}) {
                     for (int r0 : {8, 6, 5, 4, 3}) {
                         if (kb * 8 > height) continue;
-                        if ((ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, 80 * 1024, plan))) break;
+                        if ((ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, workers, 80 * 1024, plan))) break;
                     }
                     if (ps_ok) break;
                 }
@@ -706,7 +713,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const BlurTaps bt = blur_taps(ex);
     if (stream) {   // levels 1 .. nl-1 in one launch, straight from the caller's frames
         ProfScope ps(ex, K_PYR_RESIZE);
-        hipLaunchKernelGGL(k_pyr_stream, xcd_grid(ex->ps_bands, n, pyr_local), dim3(kPyrStreamThreads), ex->ps_lds, pst, ex->ps_geom, (const uint4 *)ex->d_ps_cols.p,
+        hipLaunchKernelGGL(k_pyr_stream, xcd_grid(ex->ps_bands, n, pyr_local), dim3(64 * (ex->ps_geom.workers + 1)), ex->ps_lds, pst, ex->ps_geom, (const uint4 *)ex->d_ps_cols.p,
                            (const PyrStep *)ex->d_ps_steps.p, (const PyrTask *)ex->d_ps_tasks.p, (const uint32_t *)ex->d_ps_band0.p, d_images, row_stride,
                            frame_stride, pyr, ex->pyr_frame, inplace0 ? (int32_t *)ex->d_fast_ovf.p : (int32_t *)nullptr, n);
         if (ev_input_consumed && !inplace0) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));   // k_pyr_base and k_pyr_stream have read the frames
@@ -764,7 +771,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
-    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(n < 8 ? 256 : 2048), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
+    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(256), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
                        (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p, \
                        ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qfull, (const uint32_t *)ovf_list,                  \
                        (const int32_t *)ovf_count, src0)

@@ -66,8 +66,6 @@ struct ResizeGroup {
 };
 
 // ---- k_pyr_stream (pyr_stream.hip.h): per-geometry tables built by build_pyr_stream (orbx_extractor.hip) ----
-constexpr int kPyrStreamWorkers = 8;     // waves that compute
-constexpr int kPyrStreamThreads = 64 * (kPyrStreamWorkers + 1);   // + the loader wave
 constexpr int kPyrStreamStage = 8;      // 16-byte chunks of frame rows a lane of the loader wave may have in flight per step
 
 struct PyrColumn {        // one dword column of a padded row (ResizeGroup without its padding: 24 bytes, LDS resident)
@@ -89,6 +87,7 @@ struct PyrStreamLevel {
 struct PyrStreamGeom {    // kernel argument (scalar loads)
     uint32_t xg_bytes;        // bytes of the PyrColumn tables (multiple of 16)
     uint32_t steps_per_band;
+    uint32_t workers;         // waves of a workgroup that compute (one more stages the frame rows)
     uint32_t cpr0, cpr0_rcp;  // 16-byte chunks per frame row, ceil(2^32 / cpr0)
     uint32_t ring0_off, ring0_pitch, ring0_rows;   // LDS ring of frame rows
     int32_t w0;

@@ -15,7 +15,7 @@
 // their common source row).  Bands of one frame overlap by the few rows the cascade needs (9 of 480 rows for two bands of a 752x480 frame);
 // rows in the overlap are computed by both bands and stored by the one that owns them.
 // Arithmetic = k_pyr_resize_march's ([OCV] resize INTER_LINEAR 8U: Q11 taps, horizontal sums >> 4, (b * H) >> 16 per source row, + 2 >> 2), bit for bit.
-// grid xcd_grid(bands per frame, B), block 576 (eight worker waves + the loader wave), dynamic LDS = PyrStreamGeom::lds_bytes
+// grid xcd_grid(bands per frame, B), block 64 x (worker waves + 1: the loader wave), dynamic LDS = PyrStreamGeom::lds_bytes
 #pragma once
 
 namespace orbx {
@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t pyr_vpass(const uint32_t (&A)[4], const uint
     return ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 2)) | ((uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 2) << 16);
 }
 
-__global__ __launch_bounds__(kPyrStreamThreads) void k_pyr_stream(const PyrStreamGeom G, const uint4 *__restrict__ xg24, const PyrStep *__restrict__ steps,
+__global__ __launch_bounds__(1024) void k_pyr_stream(const PyrStreamGeom G, const uint4 *__restrict__ xg24, const PyrStep *__restrict__ steps,
                                                                    const PyrTask *__restrict__ tasks, const uint32_t *__restrict__ band_task0,
                                                                    const uint8_t *__restrict__ img, size_t row_stride, size_t frame_stride,
                                                                    uint8_t *__restrict__ pyr, size_t pyr_frame_stride, int32_t *__restrict__ zero_word, int n_frames) {
@@ -49,9 +49,9 @@ __global__ __launch_bounds__(kPyrStreamThreads) void k_pyr_stream(const PyrStrea
     int band, f;
     if (!xcd_frame_map(n_frames, &band, &f)) return;   // the bands of a frame stay on one XCD (their overlap rows hit its L2)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NW = kPyrStreamWorkers;
+    const int NW = (int)G.workers;   // worker waves (the block has one wave more: the loader)
     if (zero_word && band == 0 && f == 0 && tid == 0) *zero_word = 0;   // the FAST stage's overflow counter of this batch (k_pyr_base's side job)
-    for (uint32_t i = (uint32_t)tid; i < G.xg_bytes / 16u; i += kPyrStreamThreads) reinterpret_cast<uint4 *>(smem)[i] = xg24[i];
+    for (uint32_t i = (uint32_t)tid; i < G.xg_bytes / 16u; i += 64u * (G.workers + 1u)) reinterpret_cast<uint4 *>(smem)[i] = xg24[i];
     const PyrStep *st = steps + (size_t)band * G.steps_per_band;
     __syncthreads();
     if (wave == NW) {
@@ -92,12 +92,16 @@ __global__ __launch_bounds__(kPyrStreamThreads) void k_pyr_stream(const PyrStrea
     // ---- the worker waves: the step's tasks, wave w takes tasks w, w + NW, ... ----
     uint8_t *slab = pyr + (size_t)f * pyr_frame_stride;
     const PyrTask *tk = tasks + band_task0[band];
+    PyrStep d = st[0];
+    PyrTask T = tk[min(d.task_begin + (uint32_t)wave, d.task_end - (d.task_end > d.task_begin ? 1u : 0u))];
     for (uint32_t s = 0; s < G.steps_per_band; s++) {
-        const PyrStep d = st[s];
-        PyrTask T = tk[min(d.task_begin + (uint32_t)wave, d.task_end - (d.task_end > d.task_begin ? 1u : 0u))];
+        // the next step's descriptor and this wave's first task of it are requested now and waited for after the barrier: a step does not start
+        // with two dependent scalar-memory round trips
+        const PyrStep dn = st[min(s + 1u, G.steps_per_band - 1u)];
         for (uint32_t t = d.task_begin + (uint32_t)wave; t < d.task_end; t += NW) {
             const PyrTask C = T;
-            T = tk[min(t + NW, d.task_end - 1u)];   // the next task's descriptor is on its way while this one is computed
+            // the next task's descriptor is on its way while this one is computed (after the step's last one: the first of the next step)
+            T = tk[t + NW < d.task_end ? t + NW : min(dn.task_begin + (uint32_t)wave, dn.task_end - (dn.task_end > dn.task_begin ? 1u : 0u))];
             const uint32_t two = C.hdr & 1u, nsrc = (C.hdr >> 1) & 7u, nlive = (C.hdr >> 4) & 127u, roi_lo = (C.hdr >> 11) & 127u, roi_n = (C.hdr >> 18) & 127u;
             const bool live = (uint32_t)lane < nlive;
             const uint8_t *e = smem + C.xg + (uint32_t)min(lane, (int)nlive - 1) * 24u;
@@ -134,6 +138,9 @@ __global__ __launch_bounds__(kPyrStreamThreads) void k_pyr_stream(const PyrStrea
                 if (in_roi && dl != 0xffffu) *reinterpret_cast<uint32_t *>(ll + dl * 4u) = o;
             }
         }
+        if (d.task_begin + (uint32_t)wave >= d.task_end)   // no task of this step for this wave: nothing has fetched the next step's first one
+            T = tk[min(dn.task_begin + (uint32_t)wave, dn.task_end - (dn.task_end > dn.task_begin ? 1u : 0u))];
+        d = dn;
         __syncthreads();
     }
 }
