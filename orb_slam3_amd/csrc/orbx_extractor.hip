@@ -433,7 +433,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
             if (want_bands > 0 && want_rows > 0) ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, want_bands, want_rows, workers, 150 * 1024, plan);
             else
                 for (int kb : {2, 4, 8}) {
-                    for (int r0 : {8, 6, 5, 4, 3}) {
+                    for (int r0 : {10, 8, 6, 5, 4, 3}) {
                         if (kb * 8 > height) continue;
                         if ((ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, workers, 80 * 1024, plan))) break;
                     }
@@ -771,7 +771,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
 #define ORBX_FAST_WAVE_LIST(PITCH)                                                                                                  \
-    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(256), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
+    hipLaunchKernelGGL(k_fast_wave_list<PITCH>, dim3(n < 8 ? 256 : 4096), dim3(64), lds_full, st, d_lv, (const TileRef *)ex->d_fast_tiles.p,         \
                        (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells, (uint32_t *)ex->d_cellent.p, \
                        ex->cand_frame, ini, mn, ex->fast_wave_rows, ex->fast_wave_qfull, (const uint32_t *)ovf_list,                  \
                        (const int32_t *)ovf_count, src0)

@@ -20,12 +20,15 @@
 
 namespace orbx {
 
-// horizontal pass of one source row for the four pixels of a dword column: sums >> 4 ([OCV] the vertical pass multiplies (sum >> 4))
-__device__ __forceinline__ void pyr_hpass(const uint8_t *row, const uint32_t sel, const uint32_t selr, const uint32_t (&cc)[4], uint32_t (&H)[4]) {
-    uint2 v;
-    __builtin_memcpy(&v, row, 8);   // unaligned 8-byte LDS read (ds_read_b64, unaligned access mode)
+// horizontal pass of one source row for the four pixels of a dword column: sums >> 4 ([OCV] the vertical pass multiplies (sum >> 4)).
+// The column's 8 source bytes start at any byte of the row: three ALIGNED dwords + two v_alignbyte (measured: an 8-byte LDS read at an odd address
+// costs the kernel 66 of 228 us -- the LDS serves it in pieces).
+__device__ __forceinline__ void pyr_hpass(const uint8_t *row4, const uint32_t osh, const uint32_t sel, const uint32_t selr, const uint32_t (&cc)[4], uint32_t (&H)[4]) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(row4);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const uint32_t vx = __builtin_amdgcn_alignbyte(d1, d0, osh), vy = __builtin_amdgcn_alignbyte(d2, d1, osh);
     constexpr uint32_t kPair[4] = {0x0c040c00u, 0x0c050c01u, 0x0c060c02u, 0x0c070c03u};  // (left tap k, right tap k) as two u16
-    const uint32_t l = __builtin_amdgcn_perm(v.y, v.x, sel), q = __builtin_amdgcn_perm(v.y, v.x, selr);
+    const uint32_t l = __builtin_amdgcn_perm(vy, vx, sel), q = __builtin_amdgcn_perm(vy, vx, selr);
 #pragma unroll
     for (int j = 0; j < 4; j++) H[j] = __builtin_amdgcn_udot2(as_pk(__builtin_amdgcn_perm(q, l, kPair[j])), as_pk(cc[j]), 0u, false) >> 4;
 }
@@ -108,15 +111,15 @@ __global__ __launch_bounds__(1024) void k_pyr_stream(const PyrStreamGeom G, cons
             const uint2 e0 = *reinterpret_cast<const uint2 *>(e);
             uint32_t cc[4];
             { uint2 a, b; a = *reinterpret_cast<const uint2 *>(e + 8); b = *reinterpret_cast<const uint2 *>(e + 16); cc[0] = a.x; cc[1] = a.y; cc[2] = b.x; cc[3] = b.y; }
-            const uint32_t base = e0.x & 0xffffu, valid = e0.x >> 30, sel = e0.y, selr = e0.y + 0x01010101u;
+            const uint32_t base = e0.x & 0xfffcu, osh = e0.x & 3u, valid = e0.x >> 30, sel = e0.y, selr = e0.y + 0x01010101u;
             uint32_t H0[4], H1[4], H2[4], H3[4];
-            pyr_hpass(smem + (C.src01 & 0xffffu) * 16u + base, sel, selr, cc, H0);
-            pyr_hpass(smem + (C.src01 >> 16) * 16u + base, sel, selr, cc, H1);
+            pyr_hpass(smem + (C.src01 & 0xffffu) * 16u + base, osh, sel, selr, cc, H0);
+            pyr_hpass(smem + (C.src01 >> 16) * 16u + base, osh, sel, selr, cc, H1);
             uint32_t o0 = pyr_vpass(H0, H1, C.b[0]), o1 = 0u;
             if (two) {   // wave-uniform: three source rows (the middle one shared) or four (two independent pairs)
-                pyr_hpass(smem + (C.src23 & 0xffffu) * 16u + base, sel, selr, cc, H2);
+                pyr_hpass(smem + (C.src23 & 0xffffu) * 16u + base, osh, sel, selr, cc, H2);
                 if (nsrc == 4u) {
-                    pyr_hpass(smem + (C.src23 >> 16) * 16u + base, sel, selr, cc, H3);
+                    pyr_hpass(smem + (C.src23 >> 16) * 16u + base, osh, sel, selr, cc, H3);
                     o1 = pyr_vpass(H2, H3, C.b[1]);
                 } else {
                     o1 = pyr_vpass(H1, H2, C.b[1]);

@@ -357,6 +357,7 @@ struct dim3 {
 
 inline int __builtin_amdgcn_s_waitcnt_dummy() { return 0; }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
 // V_PERM_B32: byte i of the result = byte sel[i] of {a (bytes 4..7), b (bytes 0..3)}; 0x0c -> 0x00, >= 0x0d -> 0xff
 inline uint32_t __builtin_amdgcn_perm(uint32_t a, uint32_t b, uint32_t sel) {
