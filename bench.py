@@ -78,6 +78,23 @@ def algorithmic_bytes(sizes, n_frames, feats, cands):
     return per, extract_total
 
 
+def as_executed_bytes(sizes, n_frames, feats, cands, ran):
+    """Algorithmic bytes of the extraction AS THE DEFAULT PATH EXECUTES IT (round 5), for the kernels in `ran`: SURVEY.md 8(d)'s B_extract charges
+    a blurred copy of the pyramid (2 P) and a resize chain that re-reads every level; k_describe_fused neither reads nor writes a blurred pyramid
+    (it reads the 43 x 43 raw window of a keypoint), k_pyr_stream reads the frame once and writes levels 1 .. 7 once, and with level 0 in place
+    there is no level-0 copy.  Candidates stay at SURVEY's 12 bytes."""
+    px = [a * b for a, b in sizes]
+    P = sum(px)
+    b = 0
+    if "k_pyr_base" in ran:
+        b += 2 * px[0] * n_frames
+    b += (px[0] + (P - px[0])) * n_frames if "k_pyr_resize" in ran else 0      # frame in, levels 1 .. 7 out
+    b += P * n_frames + 12 * cands                                              # FAST
+    b += 8 * cands + 4 * feats + 16 * feats                                     # quad-tree + finalize
+    b += (2 * P * n_frames + feats * 1321) if "k_blur" in ran else feats * (43 * 43 + 32 + 28)
+    return b
+
+
 def roofline_from_profile(ex, prof, passes, sizes, n_frames, n_feat, n_cand, launches_scale=1.0):
     """roofline object for the kernel with the largest share of GPU time; prof = {kernel: (avg_ms, launches)}."""
     per, extract_total = algorithmic_bytes(sizes, n_frames, n_feat, n_cand)
@@ -100,6 +117,13 @@ def roofline_from_profile(ex, prof, passes, sizes, n_frames, n_feat, n_cand, lau
                 "kernel_time_share": round(kernels[dom]["avg_ms"] * kernels[dom]["launches_per_step"] / tot_ms, 3),
                 "extract_all_kernels_GBs": round(extract_total / (ext_ms * 1e-3) / 1e9, 1),
                 "extract_all_kernels_frac": round(extract_total / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    exec_bytes = as_executed_bytes(sizes, n_frames, n_feat, n_cand, set(kernels))
+    roofline["extract_all_kernels_note"] = ("extract_all_kernels_* divide SURVEY.md 8(d)'s B_extract (which charges a blurred pyramid copy and a "
+                                            "level-by-level resize chain) by the serialized kernel time; extract_as_executed_* divide the bytes the "
+                                            "kernels that actually ran are asked to move (as_executed_bytes in bench.py)")
+    roofline["extract_as_executed_bytes"] = int(exec_bytes)
+    roofline["extract_as_executed_GBs"] = round(exec_bytes / (ext_ms * 1e-3) / 1e9, 1)
+    roofline["extract_as_executed_frac"] = round(exec_bytes / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return roofline, kernels
 
 
@@ -471,15 +495,24 @@ def bench_euroc(R):
     seed = 10 + R.rank
     from orb_slam3_amd import dataset
     data = "synthetic"
-    if dataset.dataset_dir("euroc"):   # a real EuRoC sequence: rank r takes frames r*B .. (r+1)*B - 1
-        frames = dataset.load_mono("euroc", B, W, H, start=R.rank * B)
-        data = f"dataset: {dataset.dataset_dir('euroc')} (first {B} frames per rank)"
+    # NS input sets of B frames each, used in rotation by the timed loop: one set of 256 frames is 92 MB, less than the 256 MB Infinity Cache, so a
+    # loop over ONE resident set could be served its frame reads from the cache; three sets (277 MB) cannot (`single_input_set` reports the
+    # difference).  Set k = frames k*B .. (k+1)*B - 1 of the rank's sequence.
+    NS = max(1, a.input_sets)
+    if dataset.dataset_dir("euroc"):   # a real EuRoC sequence: rank r takes frames r*NS*B .. (r+1)*NS*B - 1
+        allf = dataset.load_mono("euroc", NS * B, W, H, start=R.rank * NS * B)
+        data = f"dataset: {dataset.dataset_dir('euroc')} (first {NS * B} frames per rank)"
     else:
         canvas = synth.make_canvas(seed)
-        frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t) for t in range(B)])
-    h_frames = torch.from_numpy(frames).pin_memory()          # the camera thread's buffers (pcie_inclusive leg)
-    d_frames = torch.from_numpy(frames).cuda()                 # resident input of the contract's `value`
+        allf = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t) for t in range(NS * B)])
+    sets = [np.ascontiguousarray(allf[k * B:(k + 1) * B]) for k in range(NS)]
+    frames = sets[0]
+    h_sets = [torch.from_numpy(f).pin_memory() for f in sets]   # the camera thread's buffers (pcie_inclusive leg)
+    d_sets = [torch.from_numpy(f).cuda() for f in sets]         # resident inputs of the contract's `value`
     torch.cuda.synchronize()
+    rotate = [True]
+    step_no = [0]       # steps enqueued so far: step i reads set i mod NS
+    last_set = [0]
 
     ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=R.device)
     cap = ex.output_capacity(W, H)
@@ -499,10 +532,13 @@ def bench_euroc(R):
 
     def enqueue(i, from_host):
         hs = host[i % 2]
+        k = step_no[0] % NS if rotate[0] else 0
+        step_no[0] += 1
+        last_set[0] = k
         if from_host:
-            ex.extract_batch_host(h_frames.data_ptr(), B, W, H, W, W * H, LAP)
+            ex.extract_batch_host(h_sets[k].data_ptr(), B, W, H, W, W * H, LAP)
         else:
-            ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, LAP)
+            ex.extract_batch_device(d_sets[k].data_ptr(), B, W, H, W, W * H, LAP)
         if "nomatch" not in ablate:
             ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
         if "nodl" in ablate:     # DIAGNOSTIC: only the counts travel (4 B per frame) -- what the D2H of keypoints / descriptors costs the step
@@ -551,7 +587,7 @@ def bench_euroc(R):
     # ---- parity of the delivered results (last timed step) against the CPU oracle: EVERY rank checks its own sequence ----
     parity = None
     if a.verify > 0:
-        parity = verify_euroc(frames, last, a.verify, W, H, NF, ex)
+        parity = verify_euroc(sets[last_set[0]], last, a.verify, W, H, NF, ex)   # the set the last timed step read
     parity_all = R.gather_objects(parity)
     for pr, pc in zip(per_rank, parity_all):
         pr["parity_checked"] = pc
@@ -566,6 +602,18 @@ def bench_euroc(R):
         gaps.append(region_gaps())
     R.per_rank = per_rank
     repeats = repeats_block(regions, a.steps, gaps)
+    # ---- one more region over ONE resident set (what rounds 1-4 timed): does the Infinity Cache serve the frame reads then? ----
+    single = None
+    if NS > 1:
+        rotate[0] = False
+        t0 = R.timed_begin([ex], warm=lambda: run(max(a.warmup, 1), False))
+        STAMPS.clear()
+        f_r = run(a.steps, False)
+        dt_s, f_s = R.reduce(R.timed_end(t0, [ex]), f_r)
+        rotate[0] = True
+        single = {"ms_per_step": round(dt_s / a.steps * 1e3, 3), "value": round(f_s / dt_s / 1e3, 2),
+                  "note": f"the same loop re-reading ONE resident set of {B} frames ({B * W * H / 1e6:.0f} MB, inside the 256 MB Infinity Cache); `value` rotates {NS} sets"}
+    R.per_rank = per_rank
 
     # ---- the same loop with the frames starting in pinned host memory (upload inside the timed region) ----
     dt_h, feats_h = timed(True)
@@ -574,7 +622,7 @@ def bench_euroc(R):
     R.per_rank = per_rank     # `per_rank` of the line belongs to `value` (resident inputs); the host-input leg carries its own list
     pcie_parity = None
     if a.verify > 0:
-        pcie_parity = verify_euroc(frames, host[(a.steps - 1) % 2], a.verify, W, H, NF, ex)   # the host-input path delivers the same results
+        pcie_parity = verify_euroc(sets[last_set[0]], host[(a.steps - 1) % 2], a.verify, W, H, NF, ex)   # the host-input path delivers the same results
     for pr, pc in zip(per_rank_host, R.gather_objects(pcie_parity)):
         pr["parity_checked"] = pc
     pcie = {"value": round(feats_h_all / dt_h_max / 1e3, 2), "unit": "kfeatures/s", "ms_per_step": round(dt_h_max / a.steps * 1e3, 3),
@@ -615,6 +663,7 @@ def bench_euroc(R):
     latency = None
     if R.rank == 0 and a.latency > 0:
         latency = latency_euroc(osa, frames, a.latency, W, H, NF, LAP, R.device, cpu)
+        latency["calls_per_entry_point"] = latency_calls(osa, R.device, max(a.latency // 4, 10))
 
     # ---- BASELINE configs 3 and 4 in the same line (1 GPU): child processes of this file, own parity checks, no CPU / PMC legs ----
     others = None
@@ -632,7 +681,7 @@ def bench_euroc(R):
         out["metric"] = "DIAGNOSTIC, NOT A RESULT (parts of the step left out: " + ",".join(sorted(ablate)) + "): " + out["metric"]
     out.update({"roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_checked": parity, "kernels": kernels,
                 "host_enqueue_ms_per_step": round(enqueue_ms, 3), "settle_ms_per_step": round(settle_ms, 3),
-                "repeats": repeats, "latency": latency, "other_workloads": others,
+                "repeats": repeats, "latency": latency, "other_workloads": others, "input_sets": NS, "single_input_set": single,
                 "value_device_resident": round(feats_all / dt_max / 1e3, 2), "value_pcie_inclusive": pcie["value"],
                 "metric_definition_note": "TWO clocks, both in this line.  `value` (= value_device_resident) = features delivered to pinned host memory "
                                           "per second with the input frames already resident in HBM when the timed region starts: the bench contract "
@@ -661,6 +710,146 @@ def latency_euroc(osa, frames, n_calls, W, H, NF, LAP, device, cpu):
            "min_ms": round(float(ts.min()), 3), "frames_per_s": round(1e3 / float(np.median(ts)), 1)}
     if cpu and cpu.get("value"):
         out["cpu_oracle_ms_per_frame"] = round(1000.0 / cpu["value"], 3)   # kfeatures/s at ~1000 features per frame (extract + match, 1 thread)
+    return out
+
+
+def latency_calls(osa, device, n_calls, n_cpu=5):
+    """latency.calls: one matcher call at a time through the C ABI, host arrays in, host arrays out -- the way SLAM consumes the path
+    (Tracking.cc:3390-3413 calls SearchByProjection once per frame, LocalMapping.cc:412 SearchForTriangulation once per key-frame pair,
+    Frame.cc:811 ComputeStereoMatches once per stereo frame).  Each call beside the CPU oracle's time for the IDENTICAL call (1 thread, a few
+    repetitions), parity asserted on the timed inputs.  Untimed set-up: extraction of the frames the calls work on."""
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    rng = np.random.default_rng(77)
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e3
+        return r, {"median_ms": round(float(np.median(ts)), 4), "p90_ms": round(float(np.percentile(ts, 90)), 4), "min_ms": round(float(ts.min()), 4)}
+
+    def entry(name, ref, gpu_fn, cpu_fn, same, extra=None):
+        g, tg = timed(gpu_fn, n_calls)
+        c, tc = timed(cpu_fn, n_cpu)
+        ok = bool(same(g, c))
+        if not ok:
+            print(f"PARITY FAILURE in latency.calls: {name}", file=sys.stderr)
+        e = {"call": name, "reference": ref, **tg, "calls": n_calls, "cpu_oracle_median_ms": tc["median_ms"], "cpu_calls": n_cpu,
+             "speedup_vs_cpu_oracle": round(tc["median_ms"] / tg["median_ms"], 2), "parity_checked": ok}
+        if extra:
+            e.update(extra)
+        return e
+
+    def noisy(d, p):
+        flip = np.packbits(rng.random((len(d), 256)) < p, axis=1, bitorder="little")
+        return np.ascontiguousarray(d ^ flip)
+
+    out = []
+    # ---- M1: SearchByProjection(Frame, MapPoints): 1024 x 1024 frame, nFeatures 1500, 10 000 map points (BASELINE config 4) ----
+    canvas = synth.make_canvas(4)
+    ex = osa.ORBextractor(1500, 1.2, NLEVELS, 20, 7, device=device)
+    kk, dd = [], []
+    for t in range(1, 9):
+        _, k, d = ex(synth.frame_from_canvas(canvas, t, 1024, 1024, 5000 + t), None, (0, 1000))
+        k = k.copy(); k["x"] += 2.0 * t; k["y"] += 1.0 * t
+        kk.append(k); dd.append(d)
+    _, kf, df = ex(synth.frame_from_canvas(canvas, 0, 1024, 1024, 5000), None, (0, 1000))
+    sf = ex.GetScaleFactors()
+    src_k, src_d = np.concatenate(kk)[:N_MAPPOINTS], np.concatenate(dd)[:N_MAPPOINTS]
+    n_mp = len(src_k)
+    mp = dict(proj_x=src_k["x"] + rng.normal(0, 2, n_mp).astype(np.float32), proj_y=src_k["y"] + rng.normal(0, 2, n_mp).astype(np.float32),
+              proj_xr=np.zeros(n_mp, np.float32), level=src_k["octave"], view_cos=rng.uniform(0.9, 1.0, n_mp).astype(np.float32),
+              desc=noisy(src_d, 0.04), in_view=(rng.random(n_mp) < 0.95).astype(np.uint8), has_obs=(rng.random(n_mp) < 0.97).astype(np.uint8))
+    occ = (rng.random(len(kf)) < 0.1).astype(np.uint8)
+    m = osa.ORBmatcher(0.8, True, device=device)
+    F = osa.FrameView(kf, df, 0.0, 1024.0, 0.0, 1024.0, sf)
+    grid = ob.OracleGrid(kf, 0.0, 1024.0, 0.0, 1024.0)
+    out.append(entry("SearchByProjection(Frame, MapPoints) [orbx_search_by_projection_mappoints]: 10000 map points, 1024x1024 frame of %d keypoints, th=1" % len(kf),
+                     "ORBmatcher.cc:43-213, Tracking.cc:3390-3413",
+                     lambda: m.SearchByProjection(F, mp, 1.0, occ), lambda: ob.search_by_projection_mappoints(grid, df, sf, mp, 1.0, 0.8, None, occ),
+                     lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1]), {"note": "the oracle's time excludes its grid (Frame::AssignFeaturesToGrid runs at frame "
+                                                                                "construction in the reference); the device call builds its grid inside"}))
+    # ---- M2: SearchByProjection(CurrentFrame, LastFrame): consecutive 752 x 480 frames, th=15 ----
+    canvas1 = synth.make_canvas(1)
+    ex2 = osa.ORBextractor(1000, 1.2, NLEVELS, 20, 7, device=device)
+    _, k0, d0 = ex2(synth.frame_from_canvas(canvas1, 0, 752, 480, 1000), None, (0, 1000))
+    _, k1, d1 = ex2(synth.frame_from_canvas(canvas1, 1, 752, 480, 1001), None, (0, 1000))
+    sf2 = ex2.GetScaleFactors()
+    q = dict(u=k0["x"] - 2.0, v=k0["y"] - 1.0, ur=np.zeros(len(k0), np.float32), octave=k0["octave"], angle=k0["angle"], desc=d0,
+             has_obs=(rng.random(len(k0)) < 0.9).astype(np.uint8))
+    occ1 = (rng.random(len(k1)) < 0.05).astype(np.uint8)
+    m2 = osa.ORBmatcher(0.9, True, device=device)
+    F1 = osa.FrameView(k1, d1, 0.0, 752.0, 0.0, 480.0, sf2)
+    g1 = ob.OracleGrid(k1, 0.0, 752.0, 0.0, 480.0)
+    out.append(entry("SearchByProjection(CurrentFrame, LastFrame) [orbx_search_by_projection_frame]: %d points of the last frame, th=15" % len(k0),
+                     "ORBmatcher.cc:1676-1887, Tracking.cc:2886",
+                     lambda: m2.SearchByProjectionFrame(F1, q, 15.0, 0, occ1), lambda: ob.search_by_projection_frame(g1, d1, sf2, q, 15.0, 0, True, None, occ1),
+                     lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])))
+    # ---- M8: Frame::ComputeStereoMatches, 1241 x 376 pair, nFeatures 2000, Hamming row band + SAD refinement + median rejection ----
+    canvas3 = synth.make_canvas(3)
+    left, right = synth.make_stereo_pair(3, 0, 1241, 376, canvas3)
+    exl, exr = osa.ORBextractor(2000, 1.2, NLEVELS, 20, 7, device=device), osa.ORBextractor(2000, 1.2, NLEVELS, 20, 7, device=device)
+    _, kl, dl = exl(left, None, (0, 0))
+    _, kr, dr = exr(right, None, (0, 0))
+    sf3, isf3 = exl.GetScaleFactors(), exl.GetInverseScaleFactors()
+    pyl = [np.ascontiguousarray(pp) for pp in exl.mvImagePyramid]
+    pyr = [np.ascontiguousarray(pp) for pp in exr.mvImagePyramid]
+    bf, b = 0.53716 * 718.856, 0.53716
+    m3 = osa.ORBmatcher(device=device)
+    out.append(entry("Frame::ComputeStereoMatches [orbx_compute_stereo_matches]: 1241x376 pair, %d / %d keypoints, host pyramids in (as mvImagePyramid)" % (len(kl), len(kr)),
+                     "Frame.cc:811-981",
+                     lambda: m3.ComputeStereoMatches(kl, dl, kr, dr, sf3, isf3, pyl, pyr, bf, b),
+                     lambda: ob.compute_stereo_matches(kl, dl, kr, dr, sf3, isf3, pyl, pyr, bf, b)[:3],
+                     lambda g, c: g[0] == c[0] and g[1].tobytes() == c[1].tobytes() and g[2].tobytes() == c[2].tobytes(),
+                     {"note": "the call uploads both 8-level pyramids (the reference's mvImagePyramid is host memory at this boundary): %.1f MB per call"
+                              % (sum(pp.nbytes for pp in pyl + pyr) / 1e6)}))
+    # ---- M5 / M7 / Fuse on the 752 x 480 pair ----
+    def nodes(k, n_nodes):
+        return (np.floor(k["x"] / 60).astype(np.int64) * 7 + np.floor(k["y"] / 60).astype(np.int64) * 13 + k["octave"] * 31) % n_nodes
+    na, nb = nodes(k0, 100), nodes(k1, 100)
+    flip = rng.random(len(nb)) < 0.15
+    nb[flip] = rng.integers(0, 100, flip.sum())
+    fva, fvb = osa.FeatureVector.from_node_of_feature(na), osa.FeatureVector.from_node_of_feature(nb)
+    valid0 = (rng.random(len(k0)) < 0.7).astype(np.uint8)
+    m5 = osa.ORBmatcher(0.7, True, device=device)
+    out.append(entry("SearchByBoW(KeyFrame, Frame) [orbx_search_by_bow_frame]: %d x %d features, 100 vocabulary nodes" % (len(k0), len(k1)),
+                     "ORBmatcher.cc:223-425, Tracking.cc:2770",
+                     lambda: m5.SearchByBoWFrame(d0, k0["angle"], valid0, fva, d1, k1["angle"], fvb),
+                     lambda: ob.search_by_bow_frame(d0, k0["angle"], valid0, fva, d1, k1["angle"], fvb, 0.7, True),
+                     lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])))
+    sg = (sf2 * sf2).astype(np.float32)
+    na6, nb6 = nodes(k0, 60), nodes(k1, 60)
+    fva6, fvb6 = osa.FeatureVector.from_node_of_feature(na6), osa.FeatureVector.from_node_of_feature(nb6)
+    s0 = (rng.random(len(k0)) < 0.3).astype(np.uint8)
+    s1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]])
+    tt = np.array([0.11, 0.004, 0.01])
+    a_ = 0.01
+    Rm = np.array([[np.cos(a_), 0, np.sin(a_)], [0, 1, 0], [-np.sin(a_), 0, np.cos(a_)]])
+    tx = np.array([[0, -tt[2], tt[1]], [tt[2], 0, -tt[0]], [-tt[1], tt[0], 0]])
+    Fm = (np.linalg.inv(K).T @ tx @ Rm @ np.linalg.inv(K)).astype(np.float32)
+    ep = (410.0, 236.0)
+    m7 = osa.ORBmatcher(0.6, True, device=device)
+    out.append(entry("SearchForTriangulation(KF1, KF2), pinhole gates on the device [orbx_search_for_triangulation_pinhole]: %d x %d features" % (len(k0), len(k1)),
+                     "ORBmatcher.cc:907-1146, LocalMapping.cc:412",
+                     lambda: m7.SearchForTriangulationPinhole(k0, d0, s0, fva6, k1, d1, s1, fvb6, sf2, sg, Fm, ep, None, None, False, False),
+                     lambda: ob.search_for_triangulation_pinhole(k0, d0, s0, None, fva6, k1, d1, s1, None, fvb6, sf2, sg, Fm, ep, False, True, fma=True),
+                     lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])))
+    isg = ex2.GetInverseScaleSigmaSquares()
+    lvl = k0["octave"]
+    qf = dict(u=k0["x"] - 2.0 + rng.normal(0, 1.2, len(k0)).astype(np.float32), v=k0["y"] - 1.0 + rng.normal(0, 1.2, len(k0)).astype(np.float32),
+              ur=(k0["x"] - 20.0).astype(np.float32), r=(np.float32(3.0) * sf2[lvl]).astype(np.float32), level=lvl, desc=d0)
+    Ff = osa.FrameView(k1, d1, 0.0, 752.0, 0.0, 480.0, sf2, None)
+    mf = osa.ORBmatcher(device=device)
+    out.append(entry("Fuse(KeyFrame, MapPoints), candidate search [orbx_fuse_search]: %d map points into a key frame of %d features" % (len(k0), len(k1)),
+                     "ORBmatcher.cc:1148-1455, LocalMapping.cc:676",
+                     lambda: mf.FuseSearch(Ff, qf, isg, False), lambda: ob.fuse_search(g1, d1, None, isg, qf, fma=True),
+                     lambda g, c: np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1])))
     return out
 
 
@@ -1106,6 +1295,8 @@ def main():
                                                           "match vector of the step (euroc), 1-3 = that many sampled pairs, 0 = skip")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--repeat", type=int, default=5, help="timed regions of K steps each (the line's value is the first; `repeats` reports median / min / max)")
+    ap.add_argument("--input-sets", dest="input_sets", type=int, default=3,
+                    help="euroc workload: resident input sets of `batch` frames used in rotation by the timed loop (3 x 92 MB > the 256 MB Infinity Cache)")
     ap.add_argument("--latency", type=int, default=200, help="single-frame orbx_extract calls timed for the `latency` block (0 = skip)")
     ap.add_argument("--other-workloads", dest="other_workloads", action="store_true", default=None,
                     help="also run the kitti and tumvi workloads as child processes and embed their results (default for the euroc workload at --gpus 1)")
