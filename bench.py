@@ -464,6 +464,86 @@ def pinned(torch, shape, dtype):
     return torch.empty(shape, dtype=dtype).pin_memory()
 
 
+def bench_threads(args):
+    """`--threads`: SURVEY.md 8(e) as ONE process -- N host worker threads, thread s on GPU s mod G, each with its own extractor (its own HIP streams),
+    its own resident frames and its own pinned result ring; no process group, no collective.  The same extract + match + download loop as the
+    euroc workload's `value`; value = features of all threads / the slowest thread's time between a common start and its own last result.
+    Parity of every thread's last step against the oracle.  (tests/cpp/multi_gpu_demo.cpp is the same shape in C++.)"""
+    import threading
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    W, H, NF, _, LAP = WORKLOADS["euroc"]
+    B = args.batch or WORKLOADS["euroc"][3]
+    N = max(1, args.gpus)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py --threads: no GPU")
+    start = threading.Barrier(N + 1)
+    res = [None] * N
+
+    class HostSet:
+        def __init__(self, cap):
+            self.kps = pinned(torch, (B, cap, 28), torch.uint8)
+            self.desc = pinned(torch, (B, cap, 32), torch.uint8)
+            self.cnt = pinned(torch, (B,), torch.int32).zero_()
+            self.mono = pinned(torch, (B,), torch.int32).zero_()
+            self.match = pinned(torch, (B, cap), torch.int32)
+            self.nm = pinned(torch, (B,), torch.int32).zero_()
+
+    def work(i):
+        dev = i % ndev
+        canvas = synth.make_canvas(10 + i)
+        frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * (10 + i) + t) for t in range(B)])
+        d_frames = torch.from_numpy(frames).to(f"cuda:{dev}")
+        torch.cuda.synchronize(dev)
+        ex = osa.ORBextractor(NF, 1.2, NLEVELS, 20, 7, device=dev)
+        host = [HostSet(ex.output_capacity(W, H)) for _ in range(2)]
+
+        def run(nsteps):
+            feats = 0
+            for k in range(nsteps + 1):
+                if k < nsteps:
+                    hs = host[k % 2]
+                    ex.extract_batch_device(d_frames.data_ptr(), B, W, H, W, W * H, LAP)
+                    ex.match_consecutive_device(th=15.0, du=-2.0, dv=-1.0, check_orientation=True)
+                    ex.download_async(hs.kps.data_ptr(), hs.desc.data_ptr(), hs.cnt.data_ptr(), hs.mono.data_ptr(), hs.match.data_ptr(), hs.nm.data_ptr())
+                if k >= 1:
+                    ex.download_wait()
+                    feats += int(host[(k - 1) % 2].cnt.sum())
+            return feats
+        run(max(args.warmup, 1) + min(args.settle, 8))
+        ex.sync()
+        start.wait()
+        t0 = time.perf_counter()
+        feats = run(args.steps)
+        ex.sync()
+        dt = time.perf_counter() - t0
+        parity = verify_euroc(frames, host[(args.steps - 1) % 2], args.verify, W, H, NF, ex) if args.verify > 0 else None
+        res[i] = {"thread": i, "device": dev, "features": feats, "seconds": dt, "ms_per_step": round(dt / args.steps * 1e3, 3), "parity_checked": parity}
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(N)]
+    for t in threads:
+        t.start()
+    start.wait()
+    for t in threads:
+        t.join()
+    if any(r is None for r in res):
+        raise SystemExit("bench.py --threads: a worker thread died")
+    dt_max = max(r["seconds"] for r in res)
+    feats = sum(r["features"] for r in res)
+    out = {"metric": "ORB kfeatures/sec extract+match, EuRoC 752x480 nFeatures=1000", "value": round(feats / dt_max / 1e3, 2), "unit": "kfeatures/s",
+           "n_gpus": min(N, ndev), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "EuRoC-shaped 752x480 mono, nFeatures=1000: extract + frame-to-frame SearchByProjection(th=15) + D2H; inputs resident in HBM",
+                      "frames_per_step_per_thread": B, "sequences": N,
+                      "parallelism": f"ONE process, {N} host worker threads, thread s on GPU s mod {ndev}: one extractor + its HIP streams + one pinned result ring per thread; no collective"},
+           "host_mode": "threads", "threads": N, "visible_gpus": ndev, "per_thread": res,
+           "parity_checked": all(r["parity_checked"] is not None for r in res) if args.verify > 0 else None}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def bench_dry(R):
     """No-GPU path of the launcher test: every rank 'processes' its own sequence and the reduction runs over gloo."""
     a = R.args
@@ -503,7 +583,9 @@ def bench_euroc(R):
         allf = dataset.load_mono("euroc", NS * B, W, H, start=R.rank * NS * B)
         data = f"dataset: {dataset.dataset_dir('euroc')} (first {NS * B} frames per rank)"
     else:
-        canvas = synth.make_canvas(seed)
+        canvas = synth.make_texture_canvas(seed) if a.scene == "texture" else synth.make_canvas(seed)
+        if a.scene == "texture":
+            data = "synthetic, STRESS scene (synth.make_texture_canvas: 1/f noise + dense high-contrast texture); not the metric's scene"
         allf = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t) for t in range(NS * B)])
     sets = [np.ascontiguousarray(allf[k * B:(k + 1) * B]) for k in range(NS)]
     frames = sets[0]
@@ -676,6 +758,7 @@ def bench_euroc(R):
                      "frames_per_step_per_gpu": B, "sequences": R.world, "features_per_frame": round(feats / a.steps / B, 1),
                      "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{R.world} independent sequences, one per GPU"})
     out["data"] = data
+    out["stage_stats_last_step"] = ex.stage_stats()   # cells on the FAST list pass, quad-tree tiers, candidates: which paths the frames exercise
     if ablate:
         out["ablation"] = sorted(ablate)
         out["metric"] = "DIAGNOSTIC, NOT A RESULT (parts of the step left out: " + ",".join(sorted(ablate)) + "): " + out["metric"]
@@ -1311,12 +1394,20 @@ def main():
                     help="ranks beyond the visible GPUs share them (rank r on GPU r mod count): exercises the N-rank path on a box with fewer GPUs")
     ap.add_argument("--ablate", default="", help="DIAGNOSTIC for the euroc workload: comma list of nodl (no D2H of keypoints / descriptors / matches), nomatch "
                                                  "(no frame-to-frame matcher); the line is marked and no parity check runs")
+    ap.add_argument("--scene", choices=("quads", "texture"), default="quads",
+                    help="euroc workload, synthetic frames: quads = SURVEY.md 8(d)'s scene (the metric); texture = the stress scene with natural-image "
+                         "statistics and several times the FAST candidates (whole-step parity as usual; stage_stats_last_step says which paths it took)")
+    ap.add_argument("--threads", action="store_true",
+                    help="SURVEY.md 8(e) as ONE process: --gpus N host worker threads (thread s on GPU s mod the visible GPUs), each with its own extractor "
+                         "and pinned ring, instead of N rank processes; euroc workload, device-resident clock, parity of every thread's last step")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.other_workloads is None:
         args.other_workloads = args.workload == "euroc" and args.cpu_frames > 0 and not args.no_profile   # the full default run only
     if args.pmc_child:
         return pmc_child(args)
+    if args.threads:
+        return bench_threads(args)
 
     if "WORLD_SIZE" not in os.environ:
         return launcher(args, sys.argv[1:])

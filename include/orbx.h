@@ -159,6 +159,11 @@ int orbx_get_feature_tables(const orbx_extractor *ex, int32_t *features_per_leve
 int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, orbx_keypoint *out, int cap);
 int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_keypoint *out, int cap);
 int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_t dst_stride);
+/* Which paths the last batch took (bench / stress tests): out[0] = cells that went to the FAST list pass (k_fast_wave_list: corners at iniThFAST
+ * that all lost the NMS, or a strip / cell whose candidate queue overflowed), out[1] = cells of the batch, out[2..4] = (frame, level) quad-trees with
+ * <= 1792 / <= 4096 / more candidates (the two 256-thread tiers and the single-wave chunked form), out[5] = FAST candidates of the batch,
+ * out[6] = the largest candidate count of a level.  Returns the number of entries written (7), or < 0. */
+int orbx_debug_stage_stats(orbx_extractor *ex, int64_t *out, int cap);
 
 /* Average GPU time (ms) per launch of each extractor kernel over the calls since the last reset, measured with
  * HIP events on the extractor's stream when profiling is enabled.  names/ms arrays of `cap` entries; returns the

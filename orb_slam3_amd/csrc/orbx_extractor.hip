@@ -1405,6 +1405,30 @@ int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *
     return ORBX_OK;
 }
 
+int orbx_debug_stage_stats(orbx_extractor *ex, int64_t *out, int cap) {
+    if (!ex || !out || cap < 7 || ex->last_batch <= 0) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    const int nl = ex->prm.nlevels, B = ex->last_batch;
+    const size_t cb = sizeof(int32_t) * (size_t)nl * B;
+    int r = ex->d2h_staged_begin(64 + cb);
+    if (r != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(0, ex->d_fast_ovf.p, 4)) != ORBX_OK) return r;
+    if ((r = ex->d2h_staged(64, ex->d_candtot.p, cb)) != ORBX_OK) return r;
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    int32_t listed = 0;
+    memcpy(&listed, ex->staged(0), 4);
+    const int32_t *ct = (const int32_t *)ex->staged(64);
+    int64_t t1 = 0, t2 = 0, t3 = 0, total = 0, most = 0;
+    for (int i = 0; i < nl * B; i++) {
+        const int64_t c = ct[i];
+        total += c; most = std::max(most, c);
+        if (c <= kOctTier1Keys) t1++; else if (c <= kOctParLdsKeys) t2++; else t3++;
+    }
+    out[0] = ex->fast_strip ? listed : -1; out[1] = (int64_t)ex->total_cells * B; out[2] = t1; out[3] = t2; out[4] = t3; out[5] = total; out[6] = most;
+    return 7;
+}
+
 int orbx_debug_sort_nodes(int device, const int32_t *count, const int32_t *ulx, int n, int32_t *perm) {
     if (n <= 0 || n > 65535) return ORBX_E_BAD_ARG;
     ORBX_HIP(hipSetDevice(device));

@@ -252,6 +252,15 @@ class ORBextractor:
         check(self._L.orbx_debug_level_blurred(self._h, frame, level, ptr(out), out.strides[0]), "blurred")
         return out
 
+    def stage_stats(self) -> dict:
+        """Which paths the last batch took: orbx_debug_stage_stats."""
+        out = (C.c_int64 * 8)()
+        n = self._L.orbx_debug_stage_stats(self._h, out, 8)
+        if n < 7:
+            raise RuntimeError(f"orbx_debug_stage_stats: {n}")
+        return {"fast_list_cells": int(out[0]), "cells": int(out[1]), "quadtrees_le_1792": int(out[2]), "quadtrees_le_4096": int(out[3]),
+                "quadtrees_single_wave": int(out[4]), "fast_candidates": int(out[5]), "max_candidates_of_a_level": int(out[6])}
+
     def profile_enable(self, on=True):
         self._L.orbx_profile_enable(self._h, int(on))
 

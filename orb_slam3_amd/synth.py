@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["make_canvas", "frame_from_canvas", "make_frames", "make_stereo_pair", "make_test_image"]
+__all__ = ["make_canvas", "make_texture_canvas", "frame_from_canvas", "make_frames", "make_stereo_pair", "make_test_image"]
 
 
 def _bilinear_upsample(small: np.ndarray, size: int) -> np.ndarray:
@@ -51,6 +51,47 @@ def make_canvas(seed: int, size: int = 2048, n_shapes: int = 2400) -> np.ndarray
             bx, by = pts[(k + 1) % 4]
             inside &= ((bx - ax) * (yy - ay) - (by - ay) * (xx - ax)) >= 0
         canvas[y0:y1, x0:x1][inside] = grey
+    return canvas
+
+
+def make_texture_canvas(seed: int, size: int = 2048) -> np.ndarray:
+    """float32 canvas in [0,255] with NATURAL-IMAGE statistics instead of flat quads: 1/f ("pink") noise -- the amplitude spectrum of natural
+    scenes -- at high contrast, plus a dense layer of small high-contrast texture elements (speckles, short strokes, checker patches: foliage /
+    gravel / brick-like detail).  Several times the FAST candidates of make_canvas per frame, corners crowded next to each other (NMS ties,
+    full candidate queues), few flat cells.  The stress scene of the constants the kernels were tuned on the quad scene with (queue
+    capacities, quad-tree tier thresholds, the share of cells that take the minThFAST pass)."""
+    rng = np.random.default_rng(seed)
+    fy = np.fft.fftfreq(size)[:, None]
+    fx = np.fft.rfftfreq(size)[None, :]
+    f = np.sqrt(fx * fx + fy * fy)
+    f[0, 0] = 1.0
+    spec = (rng.normal(size=f.shape) + 1j * rng.normal(size=f.shape)) / f       # amplitude ~ 1 / f
+    spec[0, 0] = 0.0
+    pink = np.fft.irfft2(spec, s=(size, size)).astype(np.float32)
+    pink = (pink - pink.mean()) / (pink.std() + 1e-9)
+    canvas = np.clip(128.0 + 46.0 * pink, 0, 255).astype(np.float32)
+    # dense texture elements: ~1 per 12 x 12 px
+    n_el = (size // 12) ** 2
+    cx = rng.integers(2, size - 10, n_el)
+    cy = rng.integers(2, size - 10, n_el)
+    kind = rng.integers(0, 3, n_el)
+    grey = np.where(rng.random(n_el) < 0.5, rng.uniform(0, 70, n_el), rng.uniform(185, 255, n_el)).astype(np.float32)
+    ew = rng.integers(1, 6, n_el)
+    eh = rng.integers(1, 6, n_el)
+    for i in range(n_el):
+        x, y = int(cx[i]), int(cy[i])
+        if kind[i] == 0:      # speckle / blob
+            canvas[y:y + eh[i], x:x + ew[i]] = grey[i]
+        elif kind[i] == 1:    # short stroke
+            if ew[i] >= eh[i]:
+                canvas[y:y + 1 + (eh[i] > 3), x:x + 2 * ew[i]] = grey[i]
+            else:
+                canvas[y:y + 2 * eh[i], x:x + 1 + (ew[i] > 3)] = grey[i]
+        else:                 # 2 x 2 checker of cells ew x eh
+            canvas[y:y + eh[i], x:x + ew[i]] = grey[i]
+            canvas[y + eh[i]:y + 2 * eh[i], x + ew[i]:x + 2 * ew[i]] = grey[i]
+            canvas[y:y + eh[i], x + ew[i]:x + 2 * ew[i]] = 255.0 - grey[i]
+            canvas[y + eh[i]:y + 2 * eh[i], x:x + ew[i]] = 255.0 - grey[i]
     return canvas
 
 

@@ -518,3 +518,30 @@ def test_open_random_image_sweep():
                 del os.environ["ORBX_OCTREE"]
             failures.append(msg)
     assert not failures, "\n".join(failures)
+
+
+def test_texture_stress_scene_takes_the_rare_paths():
+    """synth.make_texture_canvas (1/f noise + dense high-contrast texture: an order of magnitude more FAST candidates than the quad scene the queue
+    capacities and tier thresholds were tuned on): a batch whose strips overflow their candidate queues (cells sent to the list pass), whose lower
+    levels exceed 4096 candidates (single-wave quad-tree form) -- keypoints, descriptors and every level's candidates == oracle."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    w, h, B = 752, 480, 9
+    canvas = synth.make_texture_canvas(11)
+    frames = np.stack([synth.frame_from_canvas(canvas, t, w, h, 3000 + t) for t in range(B)])
+    ex = osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    oex = ob.OracleExtractor(1000, 1.2, 8, 20, 7, flags=ob.FLAG_DESC_FMA)
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, (0, 1000))
+    st = ex.stage_stats()
+    assert st["fast_list_cells"] > 0 and st["quadtrees_single_wave"] > 0 and st["fast_candidates"] > 4 * 4500 * B, st
+    for f in range(B):
+        mono, kps, desc = ex.download(f)
+        omono, okps, odesc = oex.extract(frames[f], lap=(0, 1000))
+        if f in (0, B - 1):
+            for l in range(8):
+                got, want = ex.debug_candidates(l, f), oex.level_candidates(l)
+                assert len(got) == len(want) and np.array_equal(got["x"], want["x"]) and np.array_equal(got["y"], want["y"]) and np.array_equal(got["response"], want["response"]), (f, l)
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f

@@ -180,3 +180,55 @@ def test_left_and_right_extractors_on_two_std_threads(tmp_path):
             off += 28 * n
             assert np.array_equal(data[off:off + 32 * n].reshape(n, 32), desc)
             off += 32 * n
+
+
+def test_one_process_one_worker_thread_per_gpu(tmp_path):
+    """SURVEY.md 8(e)'s partitioning in the shape of a C++ SLAM process (tests/cpp/multi_gpu_demo.cpp): N std::threads, thread s on GPU s mod G with
+    its own extractor, streams and pinned staging ring, extract + frame-to-frame match + asynchronous download per step.  Two workers on the box's
+    one GPU, four steps each: every step of a worker equals its first, and the first equals the CPU oracle (keypoints, descriptors, match vectors)."""
+    from orb_slam3_amd import _lib, synth
+    from oracle import oracle_binding as ob
+    exe = tmp_path / "multi_gpu_demo"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(ROOT / "tests/cpp/multi_gpu_demo.cpp"), "-o", str(exe),
+                        str(_lib.LIB_PATH), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + str(_lib.LIB_PATH.parent), "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    w, h, nf, nt = 752, 480, 16, 2
+    seqs = []
+    for s in range(nt):
+        canvas = synth.make_canvas(10 + s)
+        seqs.append(np.stack([synth.frame_from_canvas(canvas, t, w, h, 1000 * (10 + s) + t) for t in range(nf)]))
+    raw = tmp_path / "frames.bin"
+    with open(raw, "wb") as f:
+        for q in seqs:
+            f.write(q.tobytes())
+    env = dict(os.environ)
+    import torch
+    env["LD_LIBRARY_PATH"] = str(Path(torch.__file__).parent / "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    out = tmp_path / "out.bin"
+    r = subprocess.run([str(exe), str(raw), str(w), str(h), str(nf), str(nt), "4", str(out)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches 0" in r.stdout, r.stdout
+    data = np.fromfile(out, np.uint8)
+    off = 0
+    oex = ob.OracleExtractor(1000, 1.2, 8, 20, 7, flags=ob.FLAG_DESC_FMA)
+    sf = oex.tables()["scale"]
+    for s in range(nt):
+        cap = int(data[off:off + 4].view(np.int32)[0]); off += 4
+        prev = None
+        for t in range(nf):
+            n, mono = (int(v) for v in data[off:off + 8].view(np.int32)); off += 8
+            omono, okps, odesc = oex.extract(seqs[s][t], lap=(0, 1000))
+            assert n == len(okps) and mono == omono, (s, t, n, len(okps))
+            assert data[off:off + 28 * n].tobytes() == okps.tobytes(), (s, t); off += 28 * n
+            assert np.array_equal(data[off:off + 32 * n].reshape(n, 32), odesc), (s, t); off += 32 * n
+            match = data[off:off + 4 * n].view(np.int32).copy(); off += 4 * n
+            if prev is not None:   # SearchByProjection(frame t, frame t - 1), th 15, the bench's constant-motion prediction (-2, -1)
+                pk, pd = prev
+                q = dict(u=pk["x"] - 2.0, v=pk["y"] - 1.0, ur=np.zeros(len(pk), np.float32), octave=pk["octave"], angle=pk["angle"], desc=pd,
+                         has_obs=np.ones(len(pk), np.uint8))
+                grid = ob.OracleGrid(okps, 0.0, float(w), 0.0, float(h))
+                on, ocm = ob.search_by_projection_frame(grid, odesc, sf, q, 15.0, 0, True, None, None)
+                assert np.array_equal(match, ocm), (s, t, int((match != ocm).sum()))
+            prev = (okps, odesc)
+    assert off == len(data)
