@@ -159,6 +159,11 @@ int orbx_get_feature_tables(const orbx_extractor *ex, int32_t *features_per_leve
 int orbx_debug_level_candidates(orbx_extractor *ex, int frame, int level, orbx_keypoint *out, int cap);
 int orbx_debug_level_keypoints(orbx_extractor *ex, int frame, int level, orbx_keypoint *out, int cap);
 int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_t dst_stride);
+/* The blur on demand of k_describe_fused (no blurred pyramid exists then): the 37 x 37 blurred pixels around keypoint k of `frame` of the last batch,
+ * dst[k][37][37] for the first min(count, cap_keypoints) keypoints in OUTPUT order, centre = the keypoint's level pixel; pixels outside the level are
+ * its BORDER_REFLECT_101 extension.  Re-runs the descriptor kernel of the last batch (its inputs must still be valid).  Returns the number of
+ * patches, or < 0 (ORBX_E_BAD_ARG when the extractor uses the blurred slab: orbx_debug_level_blurred). */
+int orbx_debug_fused_patches(orbx_extractor *ex, int frame, uint8_t *dst, int cap_keypoints);
 /* Which paths the last batch took (bench / stress tests): out[0] = cells that went to the FAST list pass (k_fast_wave_list: corners at iniThFAST
  * that all lost the NMS, or a strip / cell whose candidate queue overflowed), out[1] = cells of the batch, out[2..4] = (frame, level) quad-trees with
  * <= 1792 / <= 4096 / more candidates (the two 256-thread tiers and the single-wave chunked form), out[5] = FAST candidates of the batch,

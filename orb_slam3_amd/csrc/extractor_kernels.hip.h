@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
                                                          const int32_t *__restrict__ count, int cap, const uint8_t *__restrict__ pyr,
                                                          size_t pyr_frame_stride, int g0, int g1, int g2, int g3, orbx_keypoint *__restrict__ kps,
                                                          uint8_t *__restrict__ desc, int strict_mul_add, int n_frames, const HostMirror hm,
-                                                         const Level0Src src0, int W0, int H0) {
+                                                         const Level0Src src0, int W0, int H0, uint8_t *__restrict__ dbg_patch, int dbg_frame) {
     __shared__ __attribute__((aligned(16))) uint8_t patches[4 * 2 * kDfWaveLds];
     int bx, f;
     if (!xcd_frame_map(n_frames, &bx, &f)) return;
@@ -1568,6 +1568,11 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
         }
     }
     wave_lds_sync();
+    if (dbg_patch != nullptr && f == dbg_frame && live) {   // debug readout (orbx_debug_fused_patches): the 37 x 37 blurred pixels around the keypoint, as they lie in LDS
+        uint8_t *o = dbg_patch + (size_t)(g0i + hw) * (37 * 37);
+        for (int r = hl; r < 37; r += 32)
+            for (int j = 0; j < 37; j++) o[r * 37 + j] = Bp[r * kDfP + j + axB];
+    }
     int M10, M01;
     ic_moments_rows(A + (6 + min(hl, 30)) * kDfP, dc->ic_mask[min(hl, 31)][axB], 18 + axB, hw, hl, &M10, &M01);
     describe_tail<kDfP>(M10, M01, Bp + 18 * kDfP + 18 + axB, hw, hl, pat8, strict_mul_add, live, w, kx, ky, f, cap, kps, desc, hm);

@@ -839,11 +839,11 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
         else if (bt.sat)   // the blur on demand, around the keypoints only (the blur slab is filled by orbx_debug_level_blurred alone)
             hipLaunchKernelGGL(k_describe_fused<true>, grid, dim3(256), 0, st, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p,
                                (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr, ex->pyr_frame, bt.g[0], bt.g[1], bt.g[2], bt.g[3],
-                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm, src0, ex->width, ex->height);
+                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm, src0, ex->width, ex->height, (uint8_t *)nullptr, -1);
         else
             hipLaunchKernelGGL(k_describe_fused<false>, grid, dim3(256), 0, st, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p,
                                (const int32_t *)ex->d_count.p, ex->cap, (const uint8_t *)pyr, ex->pyr_frame, bt.g[0], bt.g[1], bt.g[2], bt.g[3],
-                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm, src0, ex->width, ex->height);
+                               (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p, strict, n, hm, src0, ex->width, ex->height, (uint8_t *)nullptr, -1);
     }
     if (ev_input_consumed && inplace0) ORBX_HIP(hipEventRecord(ev_input_consumed, st));   // in place: the descriptor stage is the frames' last reader
     if (ex->has_camera) {   // Frame::UndistortKeyPoints for the whole batch (mvKeysUn for the batched matchers)
@@ -1403,6 +1403,47 @@ int orbx_debug_level_blurred(orbx_extractor *ex, int frame, int level, uint8_t *
     ORBX_HIP(hipStreamSynchronize(ex->stream));
     for (int y = 0; y < L.h; y++) memcpy(dst + (size_t)y * dst_stride, ex->staged((size_t)y * L.bpitch), (size_t)L.w);
     return ORBX_OK;
+}
+
+int orbx_debug_fused_patches(orbx_extractor *ex, int frame, uint8_t *dst, int cap_keypoints) {
+    if (!ex || !dst || frame < 0 || frame >= ex->last_batch || cap_keypoints <= 0) return ORBX_E_BAD_ARG;
+    if (!ex->fused_blur) return ORBX_E_BAD_ARG;   // k_describe reads the blurred slab: orbx_debug_level_blurred
+    ORBX_HIP(hipSetDevice(ex->device));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    DevBuf scratch;
+    int r = scratch.ensure((size_t)ex->cap * 37 * 37);
+    if (r != ORBX_OK) return r;
+    // the descriptor kernel of the last batch once more, writing what it wrote before plus the blurred patches of `frame` (the frames the batch was
+    // extracted from must still be valid when level 0 was read in place)
+    const BlurTaps bt = blur_taps(ex);
+    const int n = ex->last_batch, strict = (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0;
+    const Level0Src src0 = ex->lvl0_inplace ? Level0Src{ex->in0_images, ex->in0_row_stride, ex->in0_frame_stride} : Level0Src{nullptr, 0, 0};
+    const HostMirror hm = HostMirror{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const dim3 grid = xcd_grid((ex->cap + 7) / 8, n);
+    if (bt.sat)
+        hipLaunchKernelGGL(k_describe_fused<true>, grid, dim3(256), 0, ex->stream, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p,
+                           ex->cap, (const uint8_t *)ex->pyr_cur(), ex->pyr_frame, bt.g[0], bt.g[1], bt.g[2], bt.g[3], (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p,
+                           strict, n, hm, src0, ex->width, ex->height, (uint8_t *)scratch.p, frame);
+    else
+        hipLaunchKernelGGL(k_describe_fused<false>, grid, dim3(256), 0, ex->stream, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p, (const int32_t *)ex->d_count.p,
+                           ex->cap, (const uint8_t *)ex->pyr_cur(), ex->pyr_frame, bt.g[0], bt.g[1], bt.g[2], bt.g[3], (orbx_keypoint *)ex->d_kps.p, (uint8_t *)ex->d_desc.p,
+                           strict, n, hm, src0, ex->width, ex->height, (uint8_t *)scratch.p, frame);
+    ORBX_HIP(hipGetLastError());
+    int32_t cnt = 0;
+    ORBX_HIP(hipMemcpyAsync(&cnt, (const int32_t *)ex->d_count.p + frame, 4, hipMemcpyDeviceToHost, ex->stream));
+    ORBX_HIP(hipStreamSynchronize(ex->stream));
+    const int m = std::min(cnt, cap_keypoints);
+    // patches are indexed by the keypoint's position in LEVEL order (the work list); the caller gets them by output slot
+    std::vector<WorkItem> work((size_t)std::max(cnt, 1));
+    std::vector<uint8_t> all((size_t)std::max(cnt, 1) * 37 * 37);
+    if (cnt > 0) {
+        ORBX_HIP(hipMemcpy(work.data(), (const WorkItem *)ex->d_work.p + (size_t)frame * ex->cap, sizeof(WorkItem) * (size_t)cnt, hipMemcpyDeviceToHost));
+        ORBX_HIP(hipMemcpy(all.data(), scratch.p, (size_t)cnt * 37 * 37, hipMemcpyDeviceToHost));
+        for (int i = 0; i < cnt; i++)
+            if (work[i].pos >= 0 && work[i].pos < m) memcpy(dst + (size_t)work[i].pos * 37 * 37, &all[(size_t)i * 37 * 37], 37 * 37);
+    }
+    scratch.release();
+    return m;
 }
 
 int orbx_debug_stage_stats(orbx_extractor *ex, int64_t *out, int cap) {

@@ -252,6 +252,14 @@ class ORBextractor:
         check(self._L.orbx_debug_level_blurred(self._h, frame, level, ptr(out), out.strides[0]), "blurred")
         return out
 
+    def debug_fused_patches(self, frame: int = 0, cap: int = 4096) -> np.ndarray:
+        """(n, 37, 37) blurred pixels around the keypoints of `frame` as k_describe_fused computed them in LDS (output order)."""
+        out = np.zeros((cap, 37, 37), np.uint8)
+        n = self._L.orbx_debug_fused_patches(self._h, frame, ptr(out), cap)
+        if n < 0:
+            raise RuntimeError(f"orbx_debug_fused_patches: {n}")
+        return out[:n]
+
     def stage_stats(self) -> dict:
         """Which paths the last batch took: orbx_debug_stage_stats."""
         out = (C.c_int64 * 8)()

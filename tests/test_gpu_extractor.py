@@ -545,3 +545,38 @@ def test_texture_stress_scene_takes_the_rare_paths():
                 got, want = ex.debug_candidates(l, f), oex.level_candidates(l)
                 assert len(got) == len(want) and np.array_equal(got["x"], want["x"]) and np.array_equal(got["y"], want["y"]) and np.array_equal(got["response"], want["response"]), (f, l)
         assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
+
+
+def test_fused_blur_patches_equal_the_blurred_level(canvas1):
+    """k_describe_fused never writes a blurred pyramid: what it filters into LDS around a keypoint is read back here (orbx_debug_fused_patches) and
+    compared, ALL 37 x 37 pixels of every keypoint of two frames of a batch, with the oracle's GaussianBlur of the keypoint's level (its
+    BORDER_REFLECT_101 extension where the patch leaves the level) -- a wrong blurred pixel that no BRIEF pair happens to sample would not show in the
+    descriptors.  Level 0 is read in place here (batch path), so the border keypoints' reflected windows are covered too."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    w, h, B = 752, 480, 16
+    frames = np.stack([synth.frame_from_canvas(canvas1, t, w, h, 7000 + t) for t in range(B)])
+    for flags, oflags in ((0, ob.FLAG_DESC_FMA), (2, ob.FLAG_DESC_FMA | ob.FLAG_BLUR_OCV440)):
+        ex = osa.ORBextractor(1000, 1.2, 8, 20, 7, flags=flags)
+        oex = ob.OracleExtractor(1000, 1.2, 8, 20, 7, flags=oflags)
+        d = torch.from_numpy(frames).cuda()
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, (0, 1000))
+        for f in (0, B - 1):
+            mono, kps, desc = ex.download(f)
+            omono, okps, odesc = oex.extract(frames[f], lap=(0, 1000))
+            assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+            patches = ex.debug_fused_patches(f)
+            assert len(patches) == len(kps) > 900
+            sf = oex.tables()["scale"]
+            blurred = [np.pad(oex.level_blurred(l), 18, mode="reflect") for l in range(8)]
+            n_border = 0
+            for k in range(len(kps)):
+                l = int(kps["octave"][k])
+                x, y = int(round(float(kps["x"][k]) / float(sf[l]))), int(round(float(kps["y"][k]) / float(sf[l])))
+                want = blurred[l][y:y + 37, x:x + 37]
+                assert np.array_equal(patches[k], want), (flags, f, k, l, x, y, int((patches[k] != want).sum()))
+                lw, lh = blurred[l].shape[1] - 36, blurred[l].shape[0] - 36
+                n_border += (x < 21 or y < 21 or x > lw - 22 or y > lh - 22)
+            assert n_border > 0   # keypoints whose raw 43 x 43 window leaves their level (the ring, or the in-kernel reflection on level 0) were among them
