@@ -78,7 +78,7 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
     uint16_t *pq = gq + gcap;                                     // pixel queue -> corners -> survivors (compacted in place)
     uint8_t *ps = reinterpret_cast<uint8_t *>(gq);                // score per pixel-queue entry, written when the group queue is dead
     int32_t *cnt = reinterpret_cast<int32_t *>(smem + (size_t)pix_bytes + W * fast_strip_wave_bytes(gcap, qcap));   // [W][8] survivors per (wave, cell)
-    int32_t *ovf = cnt + W * kStripMaxCells;   // [0] a queue overflowed in the first pass, [1] cells with a corner at iniTh (bit per cell), [2] overflow in the second pass
+    int32_t *ovf = cnt + W * kStripMaxCells;   // [0] a queue overflowed in the first pass, [1] cells with a corner at iniTh (bit per cell), [2] cells whose second pass overflowed (bit per cell)
     if (threadIdx.x == 0) { ovf[0] = 0; ovf[1] = 0; ovf[2] = 0; }
 
     // ---- phase 0: rows wave, wave + 4, ... ; lane = dword of the row (G + 2 <= 66 dwords: the two beyond lane 63 in a second sweep) ----
@@ -247,6 +247,7 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
             const int x4 = 4 * (g0 + lg);
             // pixels of the group inside the cell (and so inside the interior: xb <= iw)
             const uint32_t cmask = lrow < RPI ? ((0xfu << max(xa - x4, 0)) & 0xfu) & (0xfu >> max(x4 + 3 - (xb - 1), 0)) : 0u;
+            const int qstart = qn2;
             for (int y0 = 0; y0 < ih; y0 += RPI) {
                 const int y = y0 + lrow;
                 const bool act = cmask != 0u && y < ih;
@@ -279,13 +280,16 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
                 }
                 qn2 += __builtin_amdgcn_readlane(incl, 63);
             }
+            if (qn2 > qcap) {   // this cell's candidates do not fit behind the wave's corners: the cell alone takes the list pass, its entries are dropped
+                qn2 = qstart;
+                if (lane == 0) atomicOr(reinterpret_cast<uint32_t *>(ovf + 2), 1u << c);
+            }
         }
         wave_lds_sync();
-        if (qn2 > qcap) { if (lane == 0) ovf[2] = 1; }
-        else nc = score_compact(nc, qn2, minTh, nc);
+        nc = score_compact(nc, qn2, minTh, nc);
         __syncthreads();   // the pixel tile is dead from here on
-        ovf_any = ovf[2] != 0;
     }
+    const uint32_t listed = needy ? (uint32_t)ovf[2] : 0u;   // cells of the second pass handed to the list pass (bit per cell)
     if (ovf_any) {     // a queue of some wave overflowed: the whole strip takes the second-pass kernel, cell by cell
         if (threadIdx.x < T.ncell) list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + threadIdx.x);
         return;
@@ -367,7 +371,7 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
         for (int w = 0; w < W; w++) total += cnt[w * kStripMaxCells + lane];
         // an empty cell is final when FAST(minTh) has been run on it above (or cannot find more: !second_pass); a cell whose corners at iniTh all
         // lost the NMS (equal scores side by side) is empty for the reference as well, which then runs FAST(minTh) on it: the list pass (rare)
-        if (total > 0 || !second_pass || ((needy >> lane) & 1u)) cellcnt[(size_t)f * total_cells + T.cell0 + lane] = total;
+        if (!((listed >> lane) & 1u) && (total > 0 || !second_pass || ((needy >> lane) & 1u))) cellcnt[(size_t)f * total_cells + T.cell0 + lane] = total;
         else list[atomicAdd(list_count, 1)] = ((uint32_t)f << 16) | (T.cell0 + lane);
     }
 }
