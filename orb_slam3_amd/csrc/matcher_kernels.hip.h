@@ -1427,105 +1427,118 @@ struct BowProblem {
     int nb_left;         // mode 3 = mode 0 for a fisheye-stereo frame (F.Nleft != -1, :283-392): B features >= nb_left are the right camera's
     int32_t *match;      // out: mode 0 [nb] (A index per B feature), modes 1, 2 [na] (B index per A feature)
     uint8_t *taken_b;    // scratch [nb] (mode 1: vbMatched2)
-    int32_t *entries;    // scratch [max(na, nb)]
+    int32_t *entries;    // scratch [max(na, nb)] (+ 1 in mode 3's worst case per query: [2 max(na, nb)])
+    int32_t *hist;       // scratch [ORBX_HISTO_LENGTH], zeroed: rotation histogram over all nodes
+    int32_t *counters;   // scratch [2], zeroed: entries appended, matches accepted
     int32_t *nmatches;
 };
 
-__global__ __launch_bounds__(64) void k_replay_bow(BowProblem P) {
+// k_replay_bow: the query loops of SearchByBoW x 2 / SearchForTriangulation, ONE WAVE PER VOCABULARY NODE of A's feature vector.  The reference walks
+// the nodes the two feature vectors share in order and, inside a node, A's features in order, each against B's features of that node; what a query
+// may take depends only on earlier queries OF THE SAME NODE (a feature lies in exactly one node of its feature vector, so vpMapPointMatches[idxF] /
+// vbMatched2[idx2] of a candidate are only ever touched from its node) -- nodes are independent, their order is not observable.  Rounds 2-4 replayed
+// all nodes on one wave (1.3 ms for 1000 x 1000 features, a chain of dependent global loads per query; the CPU oracle takes 0.03 ms); a wave per
+// node overlaps those chains.  The rotation histogram and the match count are sums over the nodes (global atomics), the consistency filter
+// (ComputeThreeMaxima) runs in k_replay_bow_finish.
+// grid ceil(fa.n_nodes / 4), block 256; P.hist / P.counters zeroed, P.match = -1, P.taken_b = 0 by the host before the launch
+__global__ __launch_bounds__(256) void k_replay_bow(BowProblem P) {
+    const int lane = threadIdx.x & 63;
+    const int ia = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (ia >= P.fa.n_nodes) return;
+    const bool toB = (P.mode == 0 || P.mode == 3);   // results are indexed by B's features
+    // the node of B with the same id (:246-250, :800-805, :961-965 merge-join the two sorted maps): binary search
+    const uint32_t id = P.fa.node_id[ia];
+    int lo = 0, hi = P.fb.n_nodes - 1, ib = -1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t v = P.fb.node_id[mid];
+        if (v == id) { ib = mid; break; }
+        if (v < id) lo = mid + 1; else hi = mid - 1;
+    }
+    if (ib < 0) return;
+    int nmatches = 0;
+    const int a0 = P.fa.node_ptr[ia], a1 = P.fa.node_ptr[ia + 1], b0 = P.fb.node_ptr[ib], b1 = P.fb.node_ptr[ib + 1];
+    auto record = [&](int a_idx, int b_idx, int out_idx) {   // lane 0: the rotation bin of an accepted match
+        if (!P.check_orientation) return;
+        const int bin = dev_rot_bin(P.angle_a[a_idx], P.angle_b[b_idx]);
+        atomicAdd(&P.hist[bin], 1);
+        P.entries[atomicAdd(&P.counters[0], 1)] = (bin << 16) | out_idx;
+    };
+    for (int a = a0; a < a1; a++) {
+        const int i = P.fa.index[a];
+        if (P.skip_a && P.skip_a[i]) continue;
+        const Desc dq = load_desc(P.desc_a + (size_t)i * 32);
+        u64 k1 = kNoKey, k2 = kNoKey, r1 = kNoKey, r2 = kNoKey;   // r*: right-camera candidates of mode 3
+        for (int b = b0 + lane; b < b1; b += 64) {
+            const int j = P.fb.index[b];
+            if (P.skip_b && P.skip_b[j]) continue;
+            if (toB && P.match[j] >= 0) continue;           // vpMapPointMatches[realIdxF] already set (:281)
+            if (P.mode == 1 && P.taken_b[j]) continue;      // vbMatched2 (:826)
+            const int d = hamming(dq, load_desc(P.desc_b + (size_t)j * 32));
+            const uint32_t pos = (uint32_t)(b - b0);
+            if (P.mode == 2) {
+                if (d > ORBX_TH_LOW) continue;               // :1017: '>' twice, so a later equal candidate wins
+                if (P.gate.enabled && !tri_gate(P.gate, i, j)) continue;
+                push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)(0xffffffffu - pos));
+            } else if (P.mode == 3 && j >= P.nb_left) {
+                push2(r1, r2, ((u64)(uint32_t)d << 32) | (u64)pos);   // :302-315: best / second best kept per camera
+            } else {
+                push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)pos);
+            }
+        }
+        wave_min2(k1, k2);
+        if (P.mode == 3) {
+            // :318-377: the left match needs bestDist1 <= TH_LOW and the ratio test; the right one is looked at only INSIDE the
+            // bestDist1 <= TH_LOW branch and its ratio test is switched off by `|| true` (:359)
+            wave_min2(r1, r2);
+            if (k1 == kNoKey || (int)(k1 >> 32) > ORBX_TH_LOW) continue;
+            const int bestL = (int)(k1 >> 32);
+            const float secondL = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
+            const int jl = P.fb.index[b0 + (int)(uint32_t)(k1 & 0xffffffffu)];
+            const bool okL = (float)bestL < P.nnratio * secondL;
+            const bool okR = r1 != kNoKey && (int)(r1 >> 32) <= ORBX_TH_LOW;
+            const int jr = okR ? P.fb.index[b0 + (int)(uint32_t)(r1 & 0xffffffffu)] : -1;
+            if (lane == 0) {
+                if (okL) { P.match[jl] = i; record(i, jl, jl); }
+                if (okR) { P.match[jr] = i; record(i, jr, jr); }
+            }
+            nmatches += (okL ? 1 : 0) + (okR ? 1 : 0);
+            __threadfence_block();   // the wave's next query reads what lane 0 wrote
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        if (k1 == kNoKey) continue;
+        const int best = (int)(k1 >> 32);
+        const uint32_t pos = P.mode == 2 ? 0xffffffffu - (uint32_t)(k1 & 0xffffffffu) : (uint32_t)(k1 & 0xffffffffu);
+        const int j = P.fb.index[b0 + (int)pos];
+        const float second = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
+        bool ok;
+        if (P.mode == 0) ok = best <= ORBX_TH_LOW && (float)best < P.nnratio * second;      // :318-320
+        else if (P.mode == 1) ok = best < ORBX_TH_LOW && (float)best < P.nnratio * second;  // :848-850 (strict)
+        else ok = true;
+        if (!ok) continue;
+        const int out_idx = P.mode == 0 ? j : i, out_val = P.mode == 0 ? i : j;
+        nmatches++;
+        if (lane == 0) {
+            P.match[out_idx] = out_val;
+            if (P.mode == 1) P.taken_b[j] = 1;
+            record(i, j, out_idx);
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && nmatches) atomicAdd(&P.counters[1], nmatches);
+}
+
+// the rotation-consistency filter over the matches of all nodes (:401-416, :882-897, :1120-1137) and the match count
+__global__ __launch_bounds__(64) void k_replay_bow_finish(BowProblem P) {
     __shared__ int hist[ORBX_HISTO_LENGTH];
     const int lane = threadIdx.x;
-    const bool toB = (P.mode == 0 || P.mode == 3);   // results are indexed by B's features
-    const int nout = toB ? P.nb : P.na;
-    for (int i = lane; i < nout; i += 64) P.match[i] = -1;
-    if (P.mode == 1) for (int i = lane; i < P.nb; i += 64) P.taken_b[i] = 0;
-    if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
-    __syncthreads();
-    int nmatches = 0, n_entries = 0;
-    int ia = 0, ib = 0;
-    while (ia < P.fa.n_nodes && ib < P.fb.n_nodes) {  // merge-join of the two FeatureVector maps (:246-250, :800-805, :961-965)
-        const uint32_t na_id = P.fa.node_id[ia], nb_id = P.fb.node_id[ib];
-        if (na_id < nb_id) { ia++; continue; }
-        if (nb_id < na_id) { ib++; continue; }
-        const int a0 = P.fa.node_ptr[ia], a1 = P.fa.node_ptr[ia + 1], b0 = P.fb.node_ptr[ib], b1 = P.fb.node_ptr[ib + 1];
-        for (int a = a0; a < a1; a++) {
-            const int i = P.fa.index[a];
-            if (P.skip_a && P.skip_a[i]) continue;
-            const Desc dq = load_desc(P.desc_a + (size_t)i * 32);
-            u64 k1 = kNoKey, k2 = kNoKey, r1 = kNoKey, r2 = kNoKey;   // r*: right-camera candidates of mode 3
-            for (int b = b0 + lane; b < b1; b += 64) {
-                const int j = P.fb.index[b];
-                if (P.skip_b && P.skip_b[j]) continue;
-                if (toB && P.match[j] >= 0) continue;           // vpMapPointMatches[realIdxF] already set (:281)
-                if (P.mode == 1 && P.taken_b[j]) continue;      // vbMatched2 (:826)
-                const int d = hamming(dq, load_desc(P.desc_b + (size_t)j * 32));
-                const uint32_t pos = (uint32_t)(b - b0);
-                if (P.mode == 2) {
-                    if (d > ORBX_TH_LOW) continue;               // :1017: '>' twice, so a later equal candidate wins
-                    if (P.gate.enabled && !tri_gate(P.gate, i, j)) continue;
-                    push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)(0xffffffffu - pos));
-                } else if (P.mode == 3 && j >= P.nb_left) {
-                    push2(r1, r2, ((u64)(uint32_t)d << 32) | (u64)pos);   // :302-315: best / second best kept per camera
-                } else {
-                    push2(k1, k2, ((u64)(uint32_t)d << 32) | (u64)pos);
-                }
-            }
-            wave_min2(k1, k2);
-            if (P.mode == 3) {
-                // :318-377: the left match needs bestDist1 <= TH_LOW and the ratio test; the right one is looked at only INSIDE the
-                // bestDist1 <= TH_LOW branch and its ratio test is switched off by `|| true` (:359)
-                wave_min2(r1, r2);
-                if (k1 == kNoKey || (int)(k1 >> 32) > ORBX_TH_LOW) continue;
-                const int bestL = (int)(k1 >> 32);
-                const float secondL = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
-                const int jl = P.fb.index[b0 + (int)(uint32_t)(k1 & 0xffffffffu)];
-                const bool okL = (float)bestL < P.nnratio * secondL;
-                const bool okR = r1 != kNoKey && (int)(r1 >> 32) <= ORBX_TH_LOW;
-                const int jr = okR ? P.fb.index[b0 + (int)(uint32_t)(r1 & 0xffffffffu)] : -1;
-                if (lane == 0) {
-                    if (okL) {
-                        P.match[jl] = i;
-                        if (P.check_orientation) { const int bin = dev_rot_bin(P.angle_a[i], P.angle_b[jl]); hist[bin]++; P.entries[n_entries] = (bin << 16) | jl; }
-                    }
-                    if (okR) {
-                        P.match[jr] = i;
-                        if (P.check_orientation) { const int bin = dev_rot_bin(P.angle_a[i], P.angle_b[jr]); hist[bin]++; P.entries[n_entries + (okL ? 1 : 0)] = (bin << 16) | jr; }
-                    }
-                }
-                nmatches += (okL ? 1 : 0) + (okR ? 1 : 0);
-                if (P.check_orientation) n_entries += (okL ? 1 : 0) + (okR ? 1 : 0);
-                __threadfence_block();
-                __syncthreads();
-                continue;
-            }
-            if (k1 == kNoKey) continue;
-            const int best = (int)(k1 >> 32);
-            const uint32_t pos = P.mode == 2 ? 0xffffffffu - (uint32_t)(k1 & 0xffffffffu) : (uint32_t)(k1 & 0xffffffffu);
-            const int j = P.fb.index[b0 + (int)pos];
-            const float second = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
-            bool ok;
-            if (P.mode == 0) ok = best <= ORBX_TH_LOW && (float)best < P.nnratio * second;      // :318-320
-            else if (P.mode == 1) ok = best < ORBX_TH_LOW && (float)best < P.nnratio * second;  // :848-850 (strict)
-            else ok = true;
-            if (!ok) continue;
-            const int out_idx = P.mode == 0 ? j : i, out_val = P.mode == 0 ? i : j;
-            nmatches++;
-            if (lane == 0) {
-                P.match[out_idx] = out_val;
-                if (P.mode == 1) P.taken_b[j] = 1;
-                if (P.check_orientation) {
-                    const int bin = dev_rot_bin(P.angle_a[i], P.angle_b[j]);
-                    hist[bin]++;
-                    P.entries[n_entries] = (bin << 16) | out_idx;
-                }
-            }
-            if (P.check_orientation) n_entries++;
-            __threadfence_block();
-            __syncthreads();
-        }
-        ia++; ib++;
-    }
-    __syncthreads();
+    int nmatches = P.counters[1];
     if (P.check_orientation) {
+        if (lane < ORBX_HISTO_LENGTH) hist[lane] = P.hist[lane];
+        __syncthreads();
+        const int n_entries = P.counters[0];
         int ind1, ind2, ind3;
         dev_three_maxima(hist, ind1, ind2, ind3);
         int dropped = 0;

@@ -761,7 +761,7 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
     if (na > 65535 || nb > 65535) return ORBX_E_TOO_LARGE;
     ORBX_HIP(hipSetDevice(m->device));
     const size_t ia = (size_t)fa->node_ptr[fa->n_nodes], ib = (size_t)fb->node_ptr[fb->n_nodes];
-    const size_t need = Arena::pad(33 * (size_t)na) + Arena::pad(33 * (size_t)nb) + 2 * Arena::pad(4 * (size_t)std::max(na, nb)) * 2 +
+    const size_t need = Arena::pad(33 * (size_t)na) + Arena::pad(33 * (size_t)nb) + 3 * Arena::pad(4 * (size_t)std::max(na, nb)) * 2 +
                         Arena::pad(8 * (size_t)fa->n_nodes + 8) + Arena::pad(8 * (size_t)fb->n_nodes + 8) + Arena::pad(4 * ia) + Arena::pad(4 * ib) +
                         Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 8192 +
                         (gate ? Arena::pad(sizeof(orbx_keypoint) * (size_t)na) + Arena::pad(sizeof(orbx_keypoint) * (size_t)nb) +
@@ -810,9 +810,14 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
         for (int i = 0; i < 9; i++) G.F[i] = gate->F12[i];
         G.ex = gate->ep_x; G.ey = gate->ep_y;
     }
-    P.match = A.take<int32_t>(n_out); P.taken_b = A.take<uint8_t>(nb); P.entries = A.take<int32_t>(std::max(na, nb));
+    P.match = A.take<int32_t>(n_out); P.taken_b = A.take<uint8_t>(nb); P.entries = A.take<int32_t>(2 * (size_t)std::max(na, nb));
     P.nmatches = A.take<int32_t>(4);
-    hipLaunchKernelGGL(k_replay_bow, dim3(1), dim3(64), 0, m->stream, P);
+    P.hist = A.take<int32_t>(ORBX_HISTO_LENGTH + 2); P.counters = P.hist + ORBX_HISTO_LENGTH;
+    ORBX_HIP(hipMemsetAsync(P.match, 0xff, 4 * (size_t)n_out, m->stream));     // -1: no match
+    ORBX_HIP(hipMemsetAsync(P.taken_b, 0, (size_t)nb, m->stream));
+    ORBX_HIP(hipMemsetAsync(P.hist, 0, 4 * (size_t)(ORBX_HISTO_LENGTH + 2), m->stream));
+    if (fa->n_nodes > 0) hipLaunchKernelGGL(k_replay_bow, dim3((fa->n_nodes + 3) / 4), dim3(256), 0, m->stream, P);   // a wave per vocabulary node
+    hipLaunchKernelGGL(k_replay_bow_finish, dim3(1), dim3(64), 0, m->stream, P);
     int32_t nm = 0;
     D2H(match_out, P.match, 4 * (size_t)n_out);
     D2H(&nm, P.nmatches, 4);
