@@ -148,7 +148,7 @@ def pmc_traffic(kernel, workload, batch):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    env = dict(os.environ, ORBX_SIDE_STREAMS="0", TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     group = STAGE_KERNELS.get(kernel, (kernel,))

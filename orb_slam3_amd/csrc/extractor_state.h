@@ -140,7 +140,6 @@ struct orbx_extractor {
     // keeps untouched until orbx_sync / orbx_download_wait) and leaves the slab's level 0 unwritten; the few readers of the padded level 0
     // (orbx_get_level, the stereo rig's SAD stage, the blurred-level debug readout) materialise it first: materialize_level0()
     bool lvl0_inplace = false;
-    bool inplace_allowed = true;   // ORBX_LEVEL0_COPY=1 keeps the padded copy (diagnostic)
     const uint8_t *in0_images = nullptr;
     size_t in0_row_stride = 0, in0_frame_stride = 0;
     int n_strips0 = 0;          // level-0 strips of k_fast_strip (the first of a frame)
@@ -177,7 +176,7 @@ struct orbx_extractor {
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_describe = nullptr, ev_match = nullptr;
     bool match_pending = false;
     bool copy_covers_match = false;   // the most recent download waited for ev_match on the copy stream: its ev_copy_done implies the matcher is done
-    bool side_streams = true;  // ORBX_SIDE_STREAMS=0 keeps every kernel on the main stream
+    bool side_streams = true;  // the blur pass / the matcher / the downloads on their own streams (profile mode keeps every kernel on the main stream)
     bool fused_blur = false;   // k_describe_fused (the blur on demand around the keypoints) instead of k_blur_stream + k_describe: chosen per geometry in
                                // configure(), ORBX_FUSED_BLUR=0 / 1 forces
     hipEvent_t ev_stereo_copy[2] = {nullptr, nullptr};   // ends of the last two orbx_stereo_batch_download_async

@@ -424,21 +424,13 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     PyrStreamPlan plan;
     bool ps_ok = false;
     {
-        int want_bands = 0, want_rows = 0, workers = 8;
-        if (const char *v = getenv("ORBX_PYR_BANDS")) want_bands = atoi(v);
-        if (const char *v = getenv("ORBX_PYR_ROWS")) want_rows = atoi(v);
-        if (const char *v = getenv("ORBX_PYR_WORKERS")) workers = atoi(v);
-        const char *off = getenv("ORBX_PYR_STREAM");
-        if (!(off && off[0] == '0')) {
-            if (want_bands > 0 && want_rows > 0) ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, want_bands, want_rows, workers, 150 * 1024, plan);
-            else
-                for (int kb : {2, 4, 8}) {
-                    for (int r0 : {10, 8, 6, 5, 4, 3}) {
-                        if (kb * 8 > height) continue;
-                        if ((ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, workers, 80 * 1024, plan))) break;
-                    }
-                    if (ps_ok) break;
-                }
+        // (measured, profiles/r05_p3 / p4: eight workers, two bands, ten rows; more workers, more or fewer bands, 5 / 12 / 16 rows are all slower)
+        for (int kb : {2, 4, 8}) {
+            for (int r0 : {10, 8, 6, 5, 4, 3}) {
+                if (kb * 8 > height) continue;
+                if ((ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, 8, 80 * 1024, plan))) break;
+            }
+            if (ps_ok) break;
         }
     }
 
@@ -522,7 +514,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->lv = lv;
     ex->ps_ok = ps_ok;
     if (ps_ok) { ex->ps_geom = plan.geom; ex->ps_bands = plan.bands; ex->ps_lds = plan.lds_bytes; }
-    if (const char *v = getenv("ORBX_PYR_MIN_FRAMES")) ex->ps_min_frames = std::max(1, atoi(v));
+    if (const char *v = getenv("ORBX_PYR_STREAM_MIN")) ex->ps_min_frames = std::max(1, atoi(v));   // test hook: the smallest batch that takes k_pyr_stream
     if (getenv("ORBX_DEBUG_ALLOC") && ps_ok)
         fprintf(stderr, "[orbx pyr] k_pyr_stream: %d bands, %u steps, %zu tasks, LDS %zu B (tables %u B)\n", plan.bands, plan.geom.steps_per_band, plan.tasks.size(),
                 plan.lds_bytes, plan.geom.xg_bytes);
@@ -700,7 +692,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const bool stream = ex->ps_ok && n >= ex->ps_min_frames;
     // level 0 in place: every reader of level 0 in this call can take the caller's frames (the FAST strips never touch the ring, k_describe_fused
     // reflects the few windows that cross the border itself, k_pyr_stream reads the frames anyway)
-    const bool inplace0 = stream && ex->fused_blur && ex->fast_strip && !ex->pyr_double && mirror == nullptr && ex->inplace_allowed;
+    const bool inplace0 = stream && ex->fused_blur && ex->fast_strip && !ex->pyr_double && mirror == nullptr;
     const Level0Src src0 = inplace0 ? Level0Src{d_images, row_stride, frame_stride} : Level0Src{nullptr, 0, 0};
     ex->lvl0_inplace = inplace0;
     ex->in0_images = d_images; ex->in0_row_stride = row_stride; ex->in0_frame_stride = frame_stride;
@@ -766,7 +758,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             hipLaunchKernelGGL(k_fast_strip<4>, xcd_grid(ex->n_strips, n), dim3(256), fast_strip_lds_bytes(4, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap), st,
                                (const StripTile *)ex->d_strips.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,
                                (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
-                               ini > mn ? (getenv("ORBX_FAST_FOLD") && getenv("ORBX_FAST_FOLD")[0] == '0' ? 2 : 1) : 0, n, src0, ex->n_strips0);
+                               ini > mn ? 1 : 0, n, src0, ex->n_strips0);
             ORBX_HIP(hipGetLastError());   // e.g. an LDS budget the device refuses: fail here, not as silently missing candidates
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
@@ -960,8 +952,6 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     (void)hipEventCreate(&ex->ev0);
     (void)hipEventCreate(&ex->ev1);
     (void)hipStreamCreateWithPriority(&ex->copy_stream, hipStreamNonBlocking, prio_lo);
-    { const char *v = getenv("ORBX_SIDE_STREAMS"); ex->side_streams = !(v && v[0] == '0'); }
-    { const char *v = getenv("ORBX_LEVEL0_COPY"); ex->inplace_allowed = !(v && v[0] == '1'); }
     { const char *v = getenv("ORBX_FAST_QCAP"); if (v && atoi(v) >= 16) ex->strip_qcap = atoi(v) & ~15; }  // test hook: k_fast_strip's pixel queues overflow, every cell takes the list pass
     (void)hipStreamCreateWithPriority(&ex->aux_stream, hipStreamNonBlocking, prio_hi);
     (void)hipStreamCreateWithPriority(&ex->match_stream, hipStreamNonBlocking, prio_lo);

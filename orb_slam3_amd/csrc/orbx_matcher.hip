@@ -23,7 +23,7 @@ constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + a
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
 #define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__)
 // k_window_best2 with 16, 8 or 4 lanes per query (ORBX_MATCH_LANES; default 8): nq = queries per problem, np = problems
-static int match_lanes() { static const int v = [] { const char *e = getenv("ORBX_MATCH_LANES"); const int n = e ? atoi(e) : 8; return n == 16 || n == 4 ? n : 8; }(); return v; }
+static int match_lanes() { return 8; }   // lanes per query of k_window_best2_t (a window of the bench's matchers holds 1-10 candidates: 16 -> 8 lanes, 74 -> 59 us in round 4)
 #define ORBX_LAUNCH_WINDOW_BEST2(nq, np, stream, ...)                                                                                          \
     do {                                                                                                                                       \
         const int lq_ = match_lanes();                                                                                                         \

@@ -469,7 +469,7 @@ def test_reconfigure_onto_a_geometry_with_skipped_cells(canvas1):
 def test_alternative_kernel_paths(tmp_path):
     """The paths beside the default one, in child processes (the switches are read once per process): ORBX_FAST_QCAP=48 -- k_fast_strip's
     pixel queues overflow, so every cell goes through the list pass (fast_wave_cell with the complete ini / min logic);
-    ORBX_OCTREE=seq -- the sequential quad-tree emulation k_octree; ORBX_SIDE_STREAMS=0 -- every kernel on one stream.  The generic
+    ORBX_OCTREE=seq -- the sequential quad-tree emulation k_octree.  The generic
     k_fast_cells (cells wider than 57 px) is what small images use: tests/test_gpu_extractor.py::test_parameter_sweep, test_small_image_stagewise."""
     import subprocess
     import sys
@@ -487,7 +487,7 @@ def test_alternative_kernel_paths(tmp_path):
         "assert m == om and np.array_equal(k, ok) and np.array_equal(d, od), (len(k), len(ok))\n"
         "print('same', len(k))\n")
     import os
-    for extra in ({"ORBX_FAST_QCAP": "48"}, {"ORBX_OCTREE": "seq"}, {"ORBX_SIDE_STREAMS": "0"}):
+    for extra in ({"ORBX_FAST_QCAP": "48"}, {"ORBX_OCTREE": "seq"}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]

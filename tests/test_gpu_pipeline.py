@@ -186,7 +186,7 @@ def test_pipeline_under_alternative_switches():
     import os
     import subprocess
     import sys
-    for extra in ({"ORBX_SIDE_STREAMS": "0"}, {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_QCAP": "48"}):
+    for extra in ({"ORBX_OCTREE": "seq"}, {"ORBX_FAST_QCAP": "48"}):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "16", "3"], capture_output=True, text=True, env=dict(os.environ, **extra),
                            timeout=300)
         assert r.returncode == 0 and "pipeline ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-2000:])

@@ -98,6 +98,7 @@ BUDGETS = {
     "k_blur_streamILb0": (72, 7, 0, 0),
     "k_blur_streamILb1": (72, 7, 0, 0),
     "k_pyr_resize_marchILi8": (64, 8, 0, 0),
+    "k_pyr_stream": (72, 7, 0, 0),          # two 576-thread workgroups per CU (18 waves): <= 7 waves per SIMD are needed, no spill of the task registers
     "k_pyr_base": (32, 8, 0, 0),
     "k_window_best2_tILi8": (64, 8, 0, 0),
     "k_greedy_resolve": (96, 5, 128, 0),

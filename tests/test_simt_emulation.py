@@ -142,7 +142,7 @@ def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     _child(PIPELINE, env)
 
 
-SWITCHES = [{"ORBX_SIDE_STREAMS": "0"}, {"ORBX_OCTREE": "seq"}, {"ORBX_FAST_QCAP": "48"}]
+SWITCHES = [{"ORBX_OCTREE": "seq"}, {"ORBX_FAST_QCAP": "48"}]
 
 
 @pytest.mark.skipif(not os.environ.get("ORBX_TEST_EMULATOR_FULL"), reason="opt-in (ORBX_TEST_EMULATOR_FULL=1): a few minutes")

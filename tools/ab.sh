@@ -1,9 +1,9 @@
 #!/bin/bash
 # Hardware A/B of environment switches on the bench's timed loop (one script instead of one per experiment).
 #   usage: bash tools/ab.sh [-t tag] [-w "euroc kitti tumvi"] [-r reps] [-p] [-v] VARIANT...
-#     VARIANT   environment assignments in one word list, e.g. "ORBX_SIDE_STREAMS=0" or "ORBX_NONE=1" (the default build) or "A=1 B=2"
+#     VARIANT   environment assignments in one word list, e.g. "ORBX_FUSED_BLUR=0" or "ORBX_NONE=1" (the default build) or "A=1 B=2"
 #     -r reps   interleaved repetitions of the whole variant list (default 2): box drift shows up as a difference between repetitions
-#     -p        also a serialized rocprofv3 --kernel-trace --stats pass per variant (euroc child, ORBX_SIDE_STREAMS=0) -> <tag>_<i>_kernel_stats.csv
+#     -p        also a serialized rocprofv3 --kernel-trace --stats pass per variant (euroc child) -> <tag>_<i>_kernel_stats.csv
 #     -v        keep the bench's full parity check on (default: --verify 4 stays on; -V turns it off for speed)
 #   output: gpurun_out/<tag>/ab.log (one line per run: workload, variant, value, ms/step first region, median / min / max over the regions, parity)
 set -u
@@ -25,7 +25,7 @@ except Exception as e:
 {
 for rep in $(seq $REPS); do for wl in $WLS; do for v in "$@"; do run $wl $v; done; done; done
 if [ $PROF = 1 ]; then i=0; for v in "$@"; do i=$((i+1))
-  env $v ORBX_SIDE_STREAMS=0 timeout 90 rocprofv3 --kernel-trace --stats -d $O/se$i -o se -- python3 bench.py --pmc-child --workload euroc --steps 12 --warmup 3 > /dev/null 2>&1
+  env $v timeout 90 rocprofv3 --kernel-trace --stats -d $O/se$i -o se -- python3 bench.py --pmc-child --workload euroc --steps 12 --warmup 3 > /dev/null 2>&1
   db=$(find $O/se$i -name "*.db" -printf "%s %p\n" | sort -n | tail -1 | cut -d" " -f2)
   echo "--- serialized kernel stats: $v"; python3 tools/rocprof_summary.py $db $O/${TAG}_${i}_kernel_stats.csv | head -24; rm -rf $O/se$i
 done; fi

@@ -2,7 +2,7 @@
 # exact memory-side read bytes per kernel from the request-size classes: 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B (calibrates FETCH_SIZE)
 export TMPDIR=/tmp
 O=gpurun_out/exact; rm -rf $O; mkdir -p $O
-ORBX_SIDE_STREAMS=0 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum -d $O/p -o p -- python bench.py --pmc-child --workload euroc --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum -d $O/p -o p -- python bench.py --pmc-child --workload euroc --steps 2 --warmup 1 > /dev/null 2>&1
 python3 - <<'PY'
 import sqlite3,glob,re
 from collections import defaultdict

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/qt; rm -rf $O; mkdir -p $O
 bash tools/quick_prof.sh euroc
-ORBX_SIDE_STREAMS=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pf -o pf -- python bench.py --pmc-child --workload euroc --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pf -o pf -- python bench.py --pmc-child --workload euroc --steps 2 --warmup 1 > /dev/null 2>&1
 python3 - <<'PY'
 import sqlite3,glob,re
 from collections import defaultdict

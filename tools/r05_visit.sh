@@ -18,7 +18,7 @@ except Exception as e:
 {
 for v in "$@"; do run $v; done
 i=0; for v in "$@"; do i=$((i+1)); [ $i -gt $NPROF ] && break
-  env $v ORBX_SIDE_STREAMS=0 timeout 90 rocprofv3 --kernel-trace --stats -d $O/se$i -o se -- python3 bench.py --pmc-child --workload euroc --steps 12 --warmup 3 > /dev/null 2>&1
+  env $v timeout 90 rocprofv3 --kernel-trace --stats -d $O/se$i -o se -- python3 bench.py --pmc-child --workload euroc --steps 12 --warmup 3 > /dev/null 2>&1
   db=$(find $O/se$i -name "*.db" -printf "%s %p\n" | sort -n | tail -1 | cut -d" " -f2)
   echo "--- serialized kernel stats: $v"; python3 tools/rocprof_summary.py $db $O/${TAG}_${i}_kernel_stats.csv | head -22; rm -rf $O/se$i
 done

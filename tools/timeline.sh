@@ -15,7 +15,7 @@ if 'memory_copies' in tabs:
     cols=[r[1] for r in c.execute("pragma table_info(memory_copies)")]
     try: cp=[("copy:"+str(n),-1,s,e) for n,s,e in c.execute("select name,start,end from memory_copies order by start")]
     except Exception as ex: print("copies:",ex,cols)
-ib=[i for i,r in enumerate(rows) if 'k_pyr_base' in r[0]]
+ib=[i for i,r in enumerate(rows) if 'k_pyr_stream' in r[0] or 'k_pyr_base' in r[0]]
 # settle 4 + warm-up 3 + 8 timed steps with resident input, then warm-up 3 + 8 with host input: steps 10 and 11 are steady-state resident ones
 k=int(__import__('os').environ.get('TL_STEP','10'))
 i0,i1=ib[k],ib[k+2]
