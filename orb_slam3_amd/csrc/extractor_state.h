@@ -131,11 +131,12 @@ struct orbx_extractor {
     // device memory
     DevBuf d_lv, d_xtab, d_ytab, d_xgtab, d_fast_tiles, d_strips, d_blur_items, d_dc;
     // k_pyr_stream (levels 1 .. n-1 in one launch): per-geometry tables; ps_ok false = the geometry does not fit, the per-level launches run
-    DevBuf d_ps_cols, d_ps_steps, d_ps_tasks, d_ps_band0;
-    bool ps_ok = false;
-    orbx::PyrStreamGeom ps_geom;
-    int ps_bands = 0, ps_min_frames = 16;   // batches smaller than ps_min_frames keep the per-level launches (a band is one workgroup: too few to fill the device)
-    size_t ps_lds = 0;
+    // one plan per band count (1, 2, 4, 8 bands per frame): the launch takes the one that puts about two workgroups on every CU for the batch at hand
+    struct PyrPlanDev { DevBuf cols, steps, tasks, band0; orbx::PyrStreamGeom geom; int bands = 0; size_t lds = 0; bool ok = false; };
+    PyrPlanDev ps_plan[4];
+    bool ps_ok = false;         // at least one plan exists
+    int ps_wg_target = 512;     // workgroups a launch should have (2 per CU): 256 frames -> 2 bands, 128 -> 4 (KITTI 150 -> 104 us, TUM-VI 328 -> 222 us against 2 bands)
+    int ps_min_frames = 48;   // batches smaller than ps_min_frames keep the per-level launches (a band is one workgroup: too few to fill the device; measured equal at 16 frames, 3 % slower at 32, 5 % faster at 64, 14 % at 128)
     // Level 0 in place: a batch extracted by k_pyr_stream + k_fast_strip + k_describe_fused reads level 0 from the caller's frames (which orbx.h
     // keeps untouched until orbx_sync / orbx_download_wait) and leaves the slab's level 0 unwritten; the few readers of the padded level 0
     // (orbx_get_level, the stereo rig's SAD stage, the blurred-level debug readout) materialise it first: materialize_level0()

@@ -421,17 +421,16 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
     // k_pyr_stream: two bands per frame and as many frame rows per step as keep two workgroups on a CU (LDS <= 80 KB); wider frames take more bands,
     // then fewer rows per step
-    PyrStreamPlan plan;
+    PyrStreamPlan plans[4];
+    bool plan_ok[4] = {false, false, false, false};
     bool ps_ok = false;
-    {
-        // (measured, profiles/r05_p3 / p4: eight workers, two bands, ten rows; more workers, more or fewer bands, 5 / 12 / 16 rows are all slower)
-        for (int kb : {2, 4, 8}) {
-            for (int r0 : {10, 8, 6, 5, 4, 3}) {
-                if (kb * 8 > height) continue;
-                if ((ps_ok = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, 8, 80 * 1024, plan))) break;
-            }
-            if (ps_ok) break;
-        }
+    for (int k = 0; k < 3; k++) {   // 1, 2, 4 bands per frame (8 bands: slower than 4 at every batch size measured, profiles/r05_q2_*)
+        // (measured, profiles/r05_p3 / p4: eight workers, ten rows per step; more workers and 5 / 12 / 16 rows are slower)
+        const int kb = 1 << k;
+        if (kb * 16 > height) continue;
+        for (int r0 : {10, 8, 6, 5, 4, 3})
+            if ((plan_ok[k] = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, 8, 80 * 1024, plans[k]))) break;
+        ps_ok = ps_ok || plan_ok[k];
     }
 
     ORBX_HIP(hipSetDevice(ex->device));
@@ -452,12 +451,13 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ENS(ex->d_xgtab, sizeof(ResizeGroup) * std::max<size_t>(xgtab.size(), 1));
     ENS(ex->d_fast_tiles, sizeof(TileRef) * fast_tiles.size());
     ENS(ex->d_blur_items, sizeof(BlurItem) * blur_items.size());
-    if (ps_ok) {
-        ENS(ex->d_ps_cols, plan.cols.size() * sizeof(PyrColumn));
-        ENS(ex->d_ps_steps, plan.steps.size() * sizeof(PyrStep));
-        ENS(ex->d_ps_tasks, plan.tasks.size() * sizeof(PyrTask));
-        ENS(ex->d_ps_band0, plan.band_task0.size() * sizeof(uint32_t));
-    }
+    for (int k = 0; k < 4; k++)
+        if (plan_ok[k]) {
+            ENS(ex->ps_plan[k].cols, plans[k].cols.size() * sizeof(PyrColumn));
+            ENS(ex->ps_plan[k].steps, plans[k].steps.size() * sizeof(PyrStep));
+            ENS(ex->ps_plan[k].tasks, plans[k].tasks.size() * sizeof(PyrTask));
+            ENS(ex->ps_plan[k].band0, plans[k].band_task0.size() * sizeof(uint32_t));
+        }
     ENS(ex->d_pyr, pyr_off * B);
     if (ex->pyr_double) ENS(ex->d_pyr2, pyr_off * B);
     // The blur on demand (k_describe_fused) filters 43 x 43 pixels per keypoint (VALU bound: +39 us per 256 k keypoints over k_describe), the blur pass
@@ -497,12 +497,15 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ORBX_HIP(hipMemcpy(ex->d_fast_tiles.p, fast_tiles.data(), sizeof(TileRef) * fast_tiles.size(), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(ex->d_blur_items.p, blur_items.data(), sizeof(BlurItem) * blur_items.size(), hipMemcpyHostToDevice));
     ex->ps_ok = false;
-    if (ps_ok) {
-        ORBX_HIP(hipMemcpy(ex->d_ps_cols.p, plan.cols.data(), plan.cols.size() * sizeof(PyrColumn), hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(ex->d_ps_steps.p, plan.steps.data(), plan.steps.size() * sizeof(PyrStep), hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(ex->d_ps_tasks.p, plan.tasks.data(), plan.tasks.size() * sizeof(PyrTask), hipMemcpyHostToDevice));
-        ORBX_HIP(hipMemcpy(ex->d_ps_band0.p, plan.band_task0.data(), plan.band_task0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        if (plan.lds_bytes > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_pyr_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes));
+    for (int k = 0; k < 4; k++) {
+        ex->ps_plan[k].ok = false;
+        if (!plan_ok[k]) continue;
+        const PyrStreamPlan &pl = plans[k];
+        ORBX_HIP(hipMemcpy(ex->ps_plan[k].cols.p, pl.cols.data(), pl.cols.size() * sizeof(PyrColumn), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(ex->ps_plan[k].steps.p, pl.steps.data(), pl.steps.size() * sizeof(PyrStep), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(ex->ps_plan[k].tasks.p, pl.tasks.data(), pl.tasks.size() * sizeof(PyrTask), hipMemcpyHostToDevice));
+        ORBX_HIP(hipMemcpy(ex->ps_plan[k].band0.p, pl.band_task0.data(), pl.band_task0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (pl.lds_bytes > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_pyr_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
     }
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
     // Cells the reference skips (empty interior: iniX >= maxBorderX - 6 / iniY >= maxBorderY - 3, ORBextractor.cc:810,819 -- e.g. cell column 33 of
@@ -513,11 +516,17 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ORBX_HIP(hipDeviceSynchronize());   // the fill has run (DevBuf::ensure, extractor_state.h)
     ex->lv = lv;
     ex->ps_ok = ps_ok;
-    if (ps_ok) { ex->ps_geom = plan.geom; ex->ps_bands = plan.bands; ex->ps_lds = plan.lds_bytes; }
-    if (const char *v = getenv("ORBX_PYR_STREAM_MIN")) ex->ps_min_frames = std::max(1, atoi(v));   // test hook: the smallest batch that takes k_pyr_stream
-    if (getenv("ORBX_DEBUG_ALLOC") && ps_ok)
-        fprintf(stderr, "[orbx pyr] k_pyr_stream: %d bands, %u steps, %zu tasks, LDS %zu B (tables %u B)\n", plan.bands, plan.geom.steps_per_band, plan.tasks.size(),
-                plan.lds_bytes, plan.geom.xg_bytes);
+    for (int k = 0; k < 4; k++)
+        if (plan_ok[k]) {
+            ex->ps_plan[k].geom = plans[k].geom; ex->ps_plan[k].bands = plans[k].bands; ex->ps_plan[k].lds = plans[k].lds_bytes; ex->ps_plan[k].ok = true;
+            if (getenv("ORBX_DEBUG_ALLOC"))
+                fprintf(stderr, "[orbx pyr] k_pyr_stream plan: %d bands, %u steps, %zu tasks, LDS %zu B (tables %u B)\n", plans[k].bands, plans[k].geom.steps_per_band,
+                        plans[k].tasks.size(), plans[k].lds_bytes, plans[k].geom.xg_bytes);
+        }
+    if (const char *v = getenv("ORBX_PYR_STREAM_MIN")) {   // test hook "<frames>[,<workgroups>]": the smallest batch that takes k_pyr_stream, the launch size the band plan aims at
+        ex->ps_min_frames = std::max(1, atoi(v));
+        if (const char *c = strchr(v, ',')) ex->ps_wg_target = std::max(1, atoi(c + 1));
+    }
     ex->fused_blur = fused_blur;
     ex->width = width; ex->height = height; ex->batch_cap = B;
     ex->pyr_frame = pyr_off; ex->blur_frame = blur_off; ex->cand_frame = cand_off; ex->lvl_frame = lvl_off;
@@ -689,7 +698,17 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     hipStream_t st = ex->stream;
     hipStream_t pst = st;   // stream of the pyramid stage
     const bool pyr_local = true;   // a frame's pyramid workgroups stay on one XCD
-    const bool stream = ex->ps_ok && n >= ex->ps_min_frames;
+    // the plan whose band count brings the launch closest to ps_wg_target workgroups (two per CU); fewer bands win a tie (less overlap work)
+    const orbx_extractor::PyrPlanDev *pp = nullptr;
+    if (ex->ps_ok && n >= ex->ps_min_frames) {
+        long best = -1;
+        for (int k = 0; k < 4; k++) {
+            if (!ex->ps_plan[k].ok) continue;
+            const long wgs = (long)n * ex->ps_plan[k].bands, miss = wgs >= ex->ps_wg_target ? wgs - ex->ps_wg_target : 2 * (ex->ps_wg_target - wgs);
+            if (best < 0 || miss < best) { best = miss; pp = &ex->ps_plan[k]; }
+        }
+    }
+    const bool stream = pp != nullptr;
     // level 0 in place: every reader of level 0 in this call can take the caller's frames (the FAST strips never touch the ring, k_describe_fused
     // reflects the few windows that cross the border itself, k_pyr_stream reads the frames anyway)
     const bool inplace0 = stream && ex->fused_blur && ex->fast_strip && !ex->pyr_double && mirror == nullptr;
@@ -705,8 +724,8 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const BlurTaps bt = blur_taps(ex);
     if (stream) {   // levels 1 .. nl-1 in one launch, straight from the caller's frames
         ProfScope ps(ex, K_PYR_RESIZE);
-        hipLaunchKernelGGL(k_pyr_stream, xcd_grid(ex->ps_bands, n, pyr_local), dim3(64 * (ex->ps_geom.workers + 1)), ex->ps_lds, pst, ex->ps_geom, (const uint4 *)ex->d_ps_cols.p,
-                           (const PyrStep *)ex->d_ps_steps.p, (const PyrTask *)ex->d_ps_tasks.p, (const uint32_t *)ex->d_ps_band0.p, d_images, row_stride,
+        hipLaunchKernelGGL(k_pyr_stream, xcd_grid(pp->bands, n, pyr_local), dim3(64 * (pp->geom.workers + 1)), pp->lds, pst, pp->geom, (const uint4 *)pp->cols.p,
+                           (const PyrStep *)pp->steps.p, (const PyrTask *)pp->tasks.p, (const uint32_t *)pp->band0.p, d_images, row_stride,
                            frame_stride, pyr, ex->pyr_frame, inplace0 ? (int32_t *)ex->d_fast_ovf.p : (int32_t *)nullptr, n);
         if (ev_input_consumed && !inplace0) ORBX_HIP(hipEventRecord(ev_input_consumed, pst));   // k_pyr_base and k_pyr_stream have read the frames
     }
@@ -1021,7 +1040,9 @@ void orbx_destroy(orbx_extractor *ex) {
                       &ex->d_mkey1, &ex->d_mkey2, &ex->d_mocc, &ex->d_mentries, &ex->d_mprobs, &ex->d_mres, &ex->d_mscale, &ex->d_mgrid, &ex->d_xgtab,
                       &ex->d_mp_qr, &ex->d_mp_qmin, &ex->d_mp_qmax, &ex->d_mp_valid, &ex->d_mp_keys, &ex->d_mp_meta, &ex->d_mp_grid, &ex->d_mp_probs,
                       &ex->d_mp_res, &ex->d_mp_misc, &ex->d_mp_entries, &ex->d_kps_un, &ex->d_frustum_frames, &ex->d_strips,
-                      &ex->d_ps_cols, &ex->d_ps_steps, &ex->d_ps_tasks, &ex->d_ps_band0};
+                      &ex->ps_plan[0].cols, &ex->ps_plan[0].steps, &ex->ps_plan[0].tasks, &ex->ps_plan[0].band0, &ex->ps_plan[1].cols, &ex->ps_plan[1].steps,
+                      &ex->ps_plan[1].tasks, &ex->ps_plan[1].band0, &ex->ps_plan[2].cols, &ex->ps_plan[2].steps, &ex->ps_plan[2].tasks, &ex->ps_plan[2].band0,
+                      &ex->ps_plan[3].cols, &ex->ps_plan[3].steps, &ex->ps_plan[3].tasks, &ex->ps_plan[3].band0};
     for (DevBuf *b : bufs) b->release();
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->ev0) (void)hipEventDestroy(ex->ev0);

@@ -520,7 +520,7 @@ def test_open_random_image_sweep():
     assert not failures, "\n".join(failures)
 
 
-def test_texture_stress_scene_takes_the_rare_paths():
+def test_texture_stress_scene_takes_the_rare_paths(monkeypatch):
     """synth.make_texture_canvas (1/f noise + dense high-contrast texture: an order of magnitude more FAST candidates than the quad scene the queue
     capacities and tier thresholds were tuned on): a batch whose strips overflow their candidate queues (cells sent to the list pass), whose lower
     levels exceed 4096 candidates (single-wave quad-tree form) -- keypoints, descriptors and every level's candidates == oracle."""
@@ -528,6 +528,7 @@ def test_texture_stress_scene_takes_the_rare_paths():
     import orb_slam3_amd as osa
     from orb_slam3_amd import synth
     from oracle import oracle_binding as ob
+    monkeypatch.setenv("ORBX_PYR_STREAM_MIN", "1")   # the batch path of the bench (k_pyr_stream, level 0 in place) on a small batch
     w, h, B = 752, 480, 9
     canvas = synth.make_texture_canvas(11)
     frames = np.stack([synth.frame_from_canvas(canvas, t, w, h, 3000 + t) for t in range(B)])
@@ -547,7 +548,7 @@ def test_texture_stress_scene_takes_the_rare_paths():
         assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
 
 
-def test_fused_blur_patches_equal_the_blurred_level(canvas1):
+def test_fused_blur_patches_equal_the_blurred_level(canvas1, monkeypatch):
     """k_describe_fused never writes a blurred pyramid: what it filters into LDS around a keypoint is read back here (orbx_debug_fused_patches) and
     compared, ALL 37 x 37 pixels of every keypoint of two frames of a batch, with the oracle's GaussianBlur of the keypoint's level (its
     BORDER_REFLECT_101 extension where the patch leaves the level) -- a wrong blurred pixel that no BRIEF pair happens to sample would not show in the
@@ -556,6 +557,7 @@ def test_fused_blur_patches_equal_the_blurred_level(canvas1):
     import orb_slam3_amd as osa
     from orb_slam3_amd import synth
     from oracle import oracle_binding as ob
+    monkeypatch.setenv("ORBX_PYR_STREAM_MIN", "1")   # k_pyr_stream + level 0 in place on a small batch (the default takes them from 48 frames on)
     w, h, B = 752, 480, 16
     frames = np.stack([synth.frame_from_canvas(canvas1, t, w, h, 7000 + t) for t in range(B)])
     for flags, oflags in ((0, ob.FLAG_DESC_FMA), (2, ob.FLAG_DESC_FMA | ob.FLAG_BLUR_OCV440)):
@@ -580,3 +582,27 @@ def test_fused_blur_patches_equal_the_blurred_level(canvas1):
                 lw, lh = blurred[l].shape[1] - 36, blurred[l].shape[0] - 36
                 n_border += (x < 21 or y < 21 or x > lw - 22 or y > lh - 22)
             assert n_border > 0   # keypoints whose raw 43 x 43 window leaves their level (the ring, or the in-kernel reflection on level 0) were among them
+
+
+@pytest.mark.parametrize("w,h,nf,B,wgs", [(752, 480, 1000, 3, 3), (1241, 376, 2000, 2, 4), (517, 389, 700, 5, 20), (1024, 1024, 1500, 1, 2)])
+def test_stream_pyramid_and_level0_in_place_on_small_batches(monkeypatch, w, h, nf, B, wgs):
+    """k_pyr_stream (levels 1 .. 7 of a band of a frame in one workgroup) + level 0 read in place, forced onto small batches so that the band plans of
+    1 / 2 / 4 bands per frame all run (the plan is chosen by the batch size): every padded level incl. the materialised level 0, keypoints and
+    descriptors == oracle.  The border keypoints of level 0 go through k_describe_fused's reflecting staged form."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    monkeypatch.setenv("ORBX_PYR_STREAM_MIN", f"1,{wgs}")   # wgs / B = bands per frame the launch aims at: 1, 2, 4, 2
+    canvas = synth.make_canvas(1)
+    frames = np.stack([synth.frame_from_canvas(canvas, t, w, h, 3000 + t) for t in range(B)])
+    ex = osa.ORBextractor(nf, 1.2, 8, 20, 7)
+    oex = ob.OracleExtractor(nf, 1.2, 8, 20, 7, flags=ob.FLAG_DESC_FMA)
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, (0, 0))
+    for f in range(B):
+        mono, kps, desc = ex.download(f)
+        omono, okps, odesc = oex.extract(frames[f], lap=(0, 0))
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
+        for l in range(8):
+            assert np.array_equal(ex.get_level(l, f), oex.level_padded(l)), (f, l)
