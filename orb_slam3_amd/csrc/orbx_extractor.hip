@@ -700,7 +700,9 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const bool pyr_local = true;   // a frame's pyramid workgroups stay on one XCD
     // the plan whose band count brings the launch closest to ps_wg_target workgroups (two per CU); fewer bands win a tie (less overlap work)
     const orbx_extractor::PyrPlanDev *pp = nullptr;
-    if (ex->ps_ok && n >= ex->ps_min_frames) {
+    // (an extractor of a stereo rig keeps its padded level 0 for the SAD stage, so k_pyr_base runs anyway -- and beside the rig's second extractor the
+    // per-level chain is the faster form: KITTI 1.34 against 1.37 - 1.41 ms per 128 pairs, profiles/r05_ab_bands.log)
+    if (ex->ps_ok && n >= ex->ps_min_frames && !ex->pyr_double) {
         long best = -1;
         for (int k = 0; k < 4; k++) {
             if (!ex->ps_plan[k].ok) continue;
