@@ -268,6 +268,8 @@ static bool build_pyr_stream(const std::vector<LevelInfo> &lv, const std::vector
         }
     }
     if (P.tasks.empty()) return false;
+    P.band_task0.push_back((uint32_t)P.tasks.size());   // sentinel: band b's tasks are [band_task0[b], band_task0[b + 1])
+    for (int k = 0; k < bands; k++) if (P.band_task0[k + 1] == P.band_task0[k]) return false;   // a band without a task: not a geometry this form takes
     P.bands = bands;
     P.lds_bytes = lds;
     out = std::move(P);

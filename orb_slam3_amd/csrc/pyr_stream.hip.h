@@ -96,7 +96,8 @@ __global__ __launch_bounds__(1024) void k_pyr_stream(const PyrStreamGeom G, cons
     uint8_t *slab = pyr + (size_t)f * pyr_frame_stride;
     const PyrTask *tk = tasks + band_task0[band];
     PyrStep d = st[0];
-    PyrTask T = tk[min(d.task_begin + (uint32_t)wave, d.task_end - (d.task_end > d.task_begin ? 1u : 0u))];
+    const uint32_t last_task = band_task0[band + 1] - band_task0[band] - 1u;   // a step without tasks points one past its predecessor's: never fetch beyond the band's list
+    PyrTask T = tk[min(min(d.task_begin + (uint32_t)wave, d.task_end - (d.task_end > d.task_begin ? 1u : 0u)), last_task)];
     for (uint32_t s = 0; s < G.steps_per_band; s++) {
         // the next step's descriptor and this wave's first task of it are requested now and waited for after the barrier: a step does not start
         // with two dependent scalar-memory round trips
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(1024) void k_pyr_stream(const PyrStreamGeom G, cons
         for (uint32_t t = d.task_begin + (uint32_t)wave; t < d.task_end; t += NW) {
             const PyrTask C = T;
             // the next task's descriptor is on its way while this one is computed (after the step's last one: the first of the next step)
-            T = tk[t + NW < d.task_end ? t + NW : min(dn.task_begin + (uint32_t)wave, dn.task_end - (dn.task_end > dn.task_begin ? 1u : 0u))];
+            T = tk[t + NW < d.task_end ? t + NW : min(min(dn.task_begin + (uint32_t)wave, dn.task_end - (dn.task_end > dn.task_begin ? 1u : 0u)), last_task)];
             const uint32_t two = C.hdr & 1u, nsrc = (C.hdr >> 1) & 7u, nlive = (C.hdr >> 4) & 127u, roi_lo = (C.hdr >> 11) & 127u, roi_n = (C.hdr >> 18) & 127u;
             const bool live = (uint32_t)lane < nlive;
             const uint8_t *e = smem + C.xg + (uint32_t)min(lane, (int)nlive - 1) * 24u;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(1024) void k_pyr_stream(const PyrStreamGeom G, cons
             }
         }
         if (d.task_begin + (uint32_t)wave >= d.task_end)   // no task of this step for this wave: nothing has fetched the next step's first one
-            T = tk[min(dn.task_begin + (uint32_t)wave, dn.task_end - (dn.task_end > dn.task_begin ? 1u : 0u))];
+            T = tk[min(min(dn.task_begin + (uint32_t)wave, dn.task_end - (dn.task_end > dn.task_begin ? 1u : 0u)), last_task)];
         d = dn;
         __syncthreads();
     }
