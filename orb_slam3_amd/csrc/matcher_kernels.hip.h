@@ -809,7 +809,7 @@ __device__ __forceinline__ u64 seq_key(int dist, int seq, int idx) {
     return ((u64)(uint32_t)dist << 32) | ((u64)(uint32_t)seq << 16) | (u64)(uint32_t)idx;
 }
 
-// grid (ceil(max_q / (256 / LQ)), n_problems), block 256: LQ = 16 lanes per query (4 queries per wave) or 8 (8 queries per wave).
+// grid (8 | 1, ceil(max_q / (256 / LQ)), ceil(n_problems / 8) | n_problems), block 256: LQ = 16 lanes per query (4 queries per wave) or 8 (8 queries per wave).
 // (Round 4: 8 is the default -- a window of the bench's matchers holds 1 - 10 candidates, most of 16 lanes idle through the scan and the
 // round-by-round extraction: kernel 74 -> 59 us alone, TUM-VI step 1.33 -> 1.26 ms, EuRoC level; 4 lanes measured like 8:
 // profiles/r04_u_*, r04_v_*.  ORBX_MATCH_LANES=16 / 8 / 4.)
@@ -820,11 +820,13 @@ __device__ __forceinline__ u64 seq_key(int dist, int seq, int idx) {
 // third candidate, so the list is cut there (valid_len); `exhaustive` says the list holds every candidate of the
 // query.  k_greedy_resolve falls back to a re-scan when it needs more than the valid part of a non-exhaustive list.
 template <int LQ>   // lanes per query: 16, 8 or 4
-__global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__restrict__ probs, GridParams g) {
+__global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__restrict__ probs, GridParams g, int n_problems) {
     static_assert(LQ == 16 || LQ == 8 || LQ == 4, "lanes per query");
-    const WindowProblem P = probs[blockIdx.y];
+    const int prob = (int)(blockIdx.z * gridDim.x + blockIdx.x);   // grid (8, query blocks, problems / 8): x is the XCD, a problem's blocks share one L2
+    if (prob >= n_problems) return;
+    const WindowProblem P = probs[prob];
     const int sub = threadIdx.x / LQ, sl = threadIdx.x & (LQ - 1);
-    const int qi = blockIdx.x * (256 / LQ) + sub;
+    const int qi = blockIdx.y * (256 / LQ) + sub;
     const int nq = *P.nq_ptr;
     const bool qvalid = qi < nq;
     QueryWin w;

@@ -22,14 +22,15 @@ namespace {
 constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
 #define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__)
-// k_window_best2 with 16, 8 or 4 lanes per query (ORBX_MATCH_LANES; default 8): nq = queries per problem, np = problems
-static int match_lanes() { return 8; }   // lanes per query of k_window_best2_t (a window of the bench's matchers holds 1-10 candidates: 16 -> 8 lanes, 74 -> 59 us in round 4)
+// k_window_best2: 8 lanes per query (a window of the bench's matchers holds 1 - 10 candidates: 16 -> 8 lanes, 74 -> 59 us in round 4; 4 like 8).
+// nq = queries per problem, np = problems.  From 8 problems on the launch is XCD-aware like the extractor's (extractor_kernels.hip.h, xcd_grid): x = XCD,
+// problem = 8 z + x, so that ALL workgroups of a problem -- they share the frame's grid, keypoints and descriptors -- run on one XCD and fetch that frame
+// into ONE L2 (round 4 spread a problem's query blocks over the eight XCDs: 134 MB of HBM reads per launch for 35 MB of data).
 #define ORBX_LAUNCH_WINDOW_BEST2(nq, np, stream, ...)                                                                                          \
     do {                                                                                                                                       \
-        const int lq_ = match_lanes();                                                                                                         \
-        if (lq_ == 4) hipLaunchKernelGGL(k_window_best2_t<4>, dim3(((nq) + 63) / 64, (np)), dim3(256), 0, stream, __VA_ARGS__);                 \
-        else if (lq_ == 8) hipLaunchKernelGGL(k_window_best2_t<8>, dim3(((nq) + 31) / 32, (np)), dim3(256), 0, stream, __VA_ARGS__);            \
-        else hipLaunchKernelGGL(k_window_best2_t<16>, dim3(((nq) + 15) / 16, (np)), dim3(256), 0, stream, __VA_ARGS__);                         \
+        const int np_ = (np), nb_ = ((nq) + 31) / 32;                                                                                          \
+        const dim3 grid_ = np_ >= 8 ? dim3(8, (unsigned)nb_, (unsigned)((np_ + 7) / 8)) : dim3(1, (unsigned)nb_, (unsigned)np_);               \
+        hipLaunchKernelGGL(k_window_best2_t<8>, grid_, dim3(256), 0, stream, __VA_ARGS__, np_);                                                \
     } while (0)
 struct Arena {  // bump allocator over one device buffer, reset per call
     uint8_t *base = nullptr;
