@@ -423,6 +423,11 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     if (oct_lds_bytes(max_pool) > 150 * 1024) return ORBX_E_TOO_LARGE;
     // k_pyr_stream: two bands per frame and as many frame rows per step as keep two workgroups on a CU (LDS <= 80 KB); wider frames take more bands,
     // then fewer rows per step
+    // LDS budget of a workgroup: two of them AND a workgroup of the matcher's k_grid_build (24.5 KB static) fit a CU's 160 KB.  With 72 KB (ten frame
+    // rows per step) the kernel alone is 8 % faster (157 against 170 us) but the previous batch's matcher cannot start beside it -- k_grid_build waits for
+    // a CU with LDS to spare, the whole match stream slides behind the pyramid -- and the pipelined step is 2 % slower (0.880 against 0.861 ms,
+    // profiles/r05_ab_rows.log)
+    constexpr size_t kPyrStreamLdsBudget = 67 * 1024;
     PyrStreamPlan plans[4];
     bool plan_ok[4] = {false, false, false, false};
     bool ps_ok = false;
@@ -430,8 +435,10 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         // (measured, profiles/r05_p3 / p4: eight workers, ten rows per step; more workers and 5 / 12 / 16 rows are slower)
         const int kb = 1 << k;
         if (kb * 16 > height) continue;
-        for (int r0 : {10, 8, 6, 5, 4, 3})
-            if ((plan_ok[k] = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, 8, 80 * 1024, plans[k]))) break;
+        int r_first = 10;
+        if (const char *v = getenv("ORBX_PYR_STREAM_MIN")) { const char *c = strchr(v, ','); c = c ? strchr(c + 1, ',') : nullptr; if (c) r_first = std::max(2, atoi(c + 1)); }   // test hook, third field: rows per step
+        for (int r0 : {r_first, 8, 6, 5, 4, 3})
+            if ((plan_ok[k] = build_pyr_stream(lv, ytab, xgtab, ex->resize_march_ok, kb, r0, 8, kPyrStreamLdsBudget, plans[k]))) break;
         ps_ok = ps_ok || plan_ok[k];
     }
 
@@ -507,7 +514,7 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
         ORBX_HIP(hipMemcpy(ex->ps_plan[k].steps.p, pl.steps.data(), pl.steps.size() * sizeof(PyrStep), hipMemcpyHostToDevice));
         ORBX_HIP(hipMemcpy(ex->ps_plan[k].tasks.p, pl.tasks.data(), pl.tasks.size() * sizeof(PyrTask), hipMemcpyHostToDevice));
         ORBX_HIP(hipMemcpy(ex->ps_plan[k].band0.p, pl.band_task0.data(), pl.band_task0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        if (pl.lds_bytes > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_pyr_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
+        if (pl.lds_bytes > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_pyr_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     }
     ORBX_HIP(hipMemset(ex->d_err.p, 0, sizeof(int32_t)));
     // Cells the reference skips (empty interior: iniX >= maxBorderX - 6 / iniY >= maxBorderY - 3, ORBextractor.cc:810,819 -- e.g. cell column 33 of
