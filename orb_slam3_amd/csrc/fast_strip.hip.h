@@ -127,7 +127,7 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
         const uint8_t *Ap = pix + (yb0 + lrow) * P + 4 * lg + 4;
         uint32_t ent = ((uint32_t)(yb0 + lrow) << 8) | (uint32_t)(4 * lg);
         int left = lane_live ? yb1 - yb0 - lrow : 0;        // rows of the band at and below this lane's row
-#pragma unroll 2
+        // (no unroll request: the trip count is data dependent and the body holds a ballot -- hipcc refuses it with a warning, rounds 3-4)
         for (int y0 = yb0; y0 < yb1; y0 += RPI) {
             const uint32_t *A = reinterpret_cast<const uint32_t *>(Ap);   // tile row y = level row of the centre - 3
             const uint32_t r8 = A[0], r0 = A[6 * D];
