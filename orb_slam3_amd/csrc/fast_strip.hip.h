@@ -269,6 +269,7 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(zo) : "v"(fo), "v"(0x00010001u));
                 const uint32_t z = ze | (zo << 1);
                 const uint32_t m4 = act ? (z | (z >> 14)) & cmask : 0u;
+                if (__ballot(m4 != 0u) == 0ull) continue;   // nothing in these rows passes (the usual case in a cell without a corner at iniTh): no scan, no queue writes
                 const int cn = __popc(m4);
                 const int incl = wave_incl_scan(cn);
                 int pos = qn2 + incl - cn;
