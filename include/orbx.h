@@ -139,7 +139,10 @@ int orbx_download_wait(orbx_extractor *ex);
 
 /* mvImagePyramid[level] (public member read by Frame::ComputeStereoMatches, Frame.cc:818,908,923): copies the
  * padded level (19-px REFLECT_101 ring included) of `frame` of the last batch to host memory.
- * dst must hold (h+38) rows of dst_stride >= w+38 bytes; the ROI origin is dst + 19*dst_stride + 19. */
+ * dst must hold (h+38) rows of dst_stride >= w+38 bytes; the ROI origin is dst + 19*dst_stride + 19.
+ * LEVEL 0 of a batched extraction is not copied into the library's pyramid (its kernels read the caller's frames in place): the first
+ * orbx_get_level / orbx_get_level_device of level 0 after such a batch writes the padded level from those frames, which must therefore still
+ * hold the batch (the frames of orbx_extract_batch_host are kept by the library until the call after the next). */
 int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_t dst_stride);
 int orbx_level_size(orbx_extractor *ex, int width, int height, int level, int *w, int *h);
 /* Device pointer to the padded level (for device-resident consumers such as the stereo matcher). */
