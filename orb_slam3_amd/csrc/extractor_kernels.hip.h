@@ -1187,6 +1187,7 @@ __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p) {
 struct DescConst {
     int8_t vmax_of_u[16];              // orientation disc: largest |v| with umax[|v|] >= |u|
     int8_t pat[1024];                  // bit_pattern_31_ (x0,y0,x1,y1) x 256
+    float patf[256][4];                // the same pattern as floats (x0, y0, x1, y1): k_describe_fused takes it converted (four v_cvt per pair less)
     uint32_t ic_mask[32][4][10];       // orientation disc, row form: row hl = v + 15 (row 31: empty), alignment axB = (kx - 18) & 3: byte t of the row is
                                        // 0xff where |t - 18 - axB| <= umax[|v|] (k_describe_fused, ic_moments_rows)
 };
@@ -1259,30 +1260,43 @@ __device__ __forceinline__ void ic_moments_rows(const uint8_t *row, const uint32
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// angle + steered BRIEF + keypoint record of the half's keypoint from its moments and its blurred patch in LDS (the tail k_describe and
-// k_describe_fused share).  bc = centre of the blurred patch (pitch BP)
-template <int BP>
-__device__ __forceinline__ void describe_tail(const int M10, const int M01, const uint8_t *bc, const int hw, const int hl,
-                                              const uint32_t (&pat8)[8], const int strict_mul_add, const bool live, const WorkItem &w, const int kx,
-                                              const int ky, const int f, const int cap, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-                                              const HostMirror &hm) {
-    const float angle = fast_atan2_deg((float)M01, (float)M10);
-
-    // ---- steered BRIEF on the blurred patch ----
+// The tail of both descriptor kernels in three pieces (k_describe runs them back to back in every wave; k_describe_fused runs the middle one -- the same
+// for all 32 lanes of a half -- ONCE per workgroup, on eight lanes of wave 0, between two barriers):
+//   describe_rotation  the keypoint's angle (:76-103 fastAtan2) and the rotation (cos, sin) of the steered pattern (:112-113)
+//   describe_record    the keypoint record of slot w.pos
+//   describe_brief     the 256 comparisons on the blurred patch (bc = its centre, pitch BP); lanes 0..7 of a half end up with descriptor dword hl
+__device__ __forceinline__ void describe_rotation(const int M10, const int M01, float *angle, float *a, float *b) {
+    *angle = fast_atan2_deg((float)M01, (float)M10);
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    glibc_sincosf(__fmul_rn(angle, factorPI), &b, &a);  // a = cos, b = sin
+    glibc_sincosf(__fmul_rn(*angle, factorPI), b, a);  // a = cos, b = sin
+}
+
+__device__ __forceinline__ void describe_record(const uint32_t key, const int level, const int pos, const float scale, const float size, const float angle,
+                                                const int f, const int cap, orbx_keypoint *__restrict__ kps, const HostMirror &hm) {
+    orbx_keypoint kp;
+    float x = (float)key_x(key), y = (float)key_y(key);
+    if (level != 0) { x = __fmul_rn(x, scale); y = __fmul_rn(y, scale); }
+    kp.x = x; kp.y = y; kp.size = size; kp.angle = angle; kp.response = (float)key_s(key);
+    kp.octave = level; kp.class_id = -1;
+    kps[(size_t)f * cap + pos] = kp;
+    if (hm.hdr) hm.kps[pos] = kp;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// patf[it] = (x0, y0, x1, y1) of pattern pair it * 32 + hl.  Returns the eight ballots' halves: out[it] = dword `it` of the descriptor of this half's keypoint
+template <int BP>
+__device__ __forceinline__ void describe_brief(const float a, const float b, const uint8_t *bc, const int hw, const f32x4 (&patf)[8],
+                                               const int strict_mul_add, uint32_t (&out)[8]) {
     constexpr float kMagic = 12582912.f;           // cvRound by magic add, see k_describe
     constexpr uint32_t kMagicBits = 0x4B400000u;
     const uint32_t cbm = (uint32_t)(uintptr_t)bc - (0x400000u * (uint32_t)BP + kMagicBits);
-    uint32_t mine = 0;   // lanes 0..7 of a half end up with descriptor dword hl of the half's keypoint
     // the two points of a pattern pair as ONE packed operation each (v_pk_mul / v_pk_fma / v_pk_add_f32 on (point 0, point 1)): the same multiplications,
     // fused multiply-adds and additions per element as the scalar form of the reference binary
     const f32x2 aa = {a, a}, bb = {b, b}, mg = {kMagic, kMagic};
 #pragma unroll
     for (int it = 0; it < 8; it++) {
-        const char4 pt = __builtin_bit_cast(char4, pat8[it]);
-        const f32x2 X = {(float)pt.x, (float)pt.z}, Y = {(float)pt.y, (float)pt.w};
+        const f32x2 X = {patf[it].x, patf[it].z}, Y = {patf[it].y, patf[it].w};
         f32x2 R, Q;
         if (strict_mul_add) {
             R = X * bb + Y * aa;      // -ffp-contract=off: products and sums round separately
@@ -1297,22 +1311,33 @@ __device__ __forceinline__ void describe_tail(const int M10, const int M01, cons
         const int t0 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a0);
         const int t1 = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(a1);
         const unsigned long long bal = __ballot(t0 < t1);
-        const uint32_t half_bits = hw ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-        mine = hl == it ? half_bits : mine;
+        out[it] = hw ? (uint32_t)(bal >> 32) : (uint32_t)bal;
     }
+}
+
+template <int BP>
+__device__ __forceinline__ void describe_tail(const int M10, const int M01, const uint8_t *bc, const int hw, const int hl,
+                                              const uint32_t (&pat8)[8], const int strict_mul_add, const bool live, const WorkItem &w, const int kx,
+                                              const int ky, const int f, const int cap, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                              const HostMirror &hm) {
+    float angle, a, b;
+    describe_rotation(M10, M01, &angle, &a, &b);
+    f32x4 patf[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const char4 pt = __builtin_bit_cast(char4, pat8[it]);
+        patf[it] = f32x4{(float)pt.x, (float)pt.y, (float)pt.z, (float)pt.w};
+    }
+    uint32_t d8[8];
+    describe_brief<BP>(a, b, bc, hw, patf, strict_mul_add, d8);
+    uint32_t mine = 0;   // lanes 0..7 of a half: descriptor dword hl
+#pragma unroll
+    for (int it = 0; it < 8; it++) mine = hl == it ? d8[it] : mine;
     if (!live) return;
     const size_t slot = (size_t)f * cap + w.pos;
     if (hl < 8) reinterpret_cast<uint32_t *>(desc + slot * 32)[hl] = mine;
     if (hm.hdr && hl < 8) reinterpret_cast<uint32_t *>(hm.desc + (size_t)w.pos * 32)[hl] = mine;
-    if (hl == 0) {
-        orbx_keypoint kp;
-        float x = (float)kx, y = (float)ky;
-        if (w.level != 0) { x = __fmul_rn(x, w.scale); y = __fmul_rn(y, w.scale); }
-        kp.x = x; kp.y = y; kp.size = w.size; kp.angle = angle; kp.response = (float)key_s(w.key);
-        kp.octave = w.level; kp.class_id = -1;
-        kps[slot] = kp;
-        if (hm.hdr) hm.kps[w.pos] = kp;
-    }
+    if (hl == 0) describe_record(w.key, w.level, w.pos, w.scale, w.size, angle, f, cap, kps, hm);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1428,16 +1453,13 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
     const int cnt = count[f];
     if (hm.hdr && bx == 0 && f == 0 && threadIdx.x == 0) { hm.hdr[0] = *hm.err; hm.hdr[1] = cnt; hm.hdr[2] = hm.mono[0]; }
     const int g0i = (bx * 4 + wv) * 2;   // first keypoint of the wave
-    if (g0i >= cnt) return;              // wave-uniform
-    const bool live = g0i + hw < cnt;    // an odd count: the last wave's second half repeats the last keypoint and stores nothing
+    if (bx * 8 >= cnt) return;           // workgroup-uniform (the barriers below are for every wave of a workgroup that has a keypoint)
+    const bool live = g0i + hw < cnt;    // halves past the frame's last keypoint (the last workgroup only) repeat it and store nothing
     const WorkItem w = work[(size_t)f * cap + min(g0i + hw, cnt - 1)];
     uint8_t *A = patches + (wv * 2 + hw) * kDfWaveLds;
     uint8_t *Bp = A + kDfP * kDfAR;
     const int pitch = (int)(w.pitches & 0xffffu);
     const int kx = key_x(w.key), ky = key_y(w.key);
-    uint32_t pat8[8];
-#pragma unroll
-    for (int it = 0; it < 8; it++) pat8[it] = reinterpret_cast<const uint32_t *>(dc->pat)[it * 32 + hl];
 
     const int seg = hl < 10 ? 0 : hl < 20 ? 1 : 2, c = hl - 10 * seg, R0 = seg == 0 ? 0 : seg == 1 ? 13 : 25;
     const int axB = (kx - 18) & 3;
@@ -1573,9 +1595,45 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
         for (int r = hl; r < 37; r += 32)
             for (int j = 0; j < 37; j++) o[r * 37 + j] = Bp[r * kDfP + j + axB];
     }
+    // the lane's eight pattern pairs, as floats: issued here (the row windows' registers are free), in flight across the moments and the barriers below
+    f32x4 patf[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) patf[it] = reinterpret_cast<const f32x4 *>(dc->patf)[it * 32 + hl];
     int M10, M01;
     ic_moments_rows(A + (6 + min(hl, 30)) * kDfP, dc->ic_mask[min(hl, 31)][axB], 18 + axB, hw, hl, &M10, &M01);
-    describe_tail<kDfP>(M10, M01, Bp + 18 * kDfP + 18 + axB, hw, hl, pat8, strict_mul_add, live, w, kx, ky, f, cap, kps, desc, hm);
+    // fastAtan2, sincosf and the keypoint record are the same ~120 vector instructions in all 32 lanes of a half: they run ONCE per workgroup instead, its
+    // eight keypoints on lanes 0..7 of wave 0, while waves 1..3 wait (the kernel is bound by VALU issue: 844 -> ~760 instructions per wave)
+    __shared__ uint32_t kp_in[8][8];   // per keypoint: m_10, m_01, key, level, output slot, scale, size
+    __shared__ float rot[8][2];        // cos, sin of its angle
+    const int kq = wv * 2 + hw;
+    if (hl == 0) {
+        kp_in[kq][0] = (uint32_t)M10; kp_in[kq][1] = (uint32_t)M01; kp_in[kq][2] = w.key; kp_in[kq][3] = (uint32_t)w.level;
+        kp_in[kq][4] = (uint32_t)w.pos; kp_in[kq][5] = __float_as_uint(w.scale); kp_in[kq][6] = __float_as_uint(w.size);
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const int k = lane & 7;
+        float angle, ca, sb;
+        describe_rotation((int)kp_in[k][0], (int)kp_in[k][1], &angle, &ca, &sb);
+        if (lane < 8) {
+            rot[k][0] = ca; rot[k][1] = sb;
+            if (bx * 8 + k < cnt)
+                describe_record(kp_in[k][2], (int)kp_in[k][3], (int)kp_in[k][4], __uint_as_float(kp_in[k][5]), __uint_as_float(kp_in[k][6]), angle, f, cap, kps, hm);
+        }
+    }
+    __syncthreads();
+    uint32_t d8[8];
+    describe_brief<kDfP>(rot[kq][0], rot[kq][1], Bp + 18 * kDfP + 18 + axB, hw, patf, strict_mul_add, d8);
+    if (live && hl == 0) {   // the half's 32 descriptor bytes from one lane
+        uint4 *o = reinterpret_cast<uint4 *>(desc + ((size_t)f * cap + w.pos) * 32);
+        o[0] = make_uint4(d8[0], d8[1], d8[2], d8[3]);
+        o[1] = make_uint4(d8[4], d8[5], d8[6], d8[7]);
+        if (hm.hdr) {
+            uint4 *oh = reinterpret_cast<uint4 *>(hm.desc + (size_t)w.pos * 32);
+            oh[0] = make_uint4(d8[0], d8[1], d8[2], d8[3]);
+            oh[1] = make_uint4(d8[4], d8[5], d8[6], d8[7]);
+        }
+    }
 }
 
 }  // namespace orbx

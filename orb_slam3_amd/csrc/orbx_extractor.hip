@@ -785,10 +785,13 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             // (Level 0's strips on the aux stream beside the latency-bound resize chain were measured: EuRoC 1.10 vs 1.11 ms, but TUM-VI 1.02 vs
             // 0.84 ms -- with the default four hardware queues the aux stream shares one with the matcher, with eight everything else slows:
             // profiles/r03_j_*, r03_k_*.  One launch on the main stream.)
-            hipLaunchKernelGGL(k_fast_strip<4>, xcd_grid(ex->n_strips, n), dim3(256), fast_strip_lds_bytes(4, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap), st,
-                               (const StripTile *)ex->d_strips.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,
-                               (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,
-                               ini > mn ? 1 : 0, n, src0, ex->n_strips0);
+#define ORBX_FAST_STRIP(W)                                                                                                                                   \
+    hipLaunchKernelGGL(k_fast_strip<W>, xcd_grid(ex->n_strips, n), dim3(64 * W), fast_strip_lds_bytes(W, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap), st, \
+                       (const StripTile *)ex->d_strips.p, (const uint8_t *)pyr, ex->pyr_frame, (int32_t *)ex->d_cellcnt.p, ex->total_cells,                        \
+                       (uint32_t *)ex->d_cellent.p, ex->cand_frame, ini, mn, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap, ovf_list, ovf_count,             \
+                       ini > mn ? 1 : 0, n, src0, ex->n_strips0)
+            ORBX_FAST_STRIP(4);   // (two waves per strip, bands of twice the rows: fewer part-filled iterations, half the waves per CU -- 339 against 297 us, profiles/r05_q6)
+#undef ORBX_FAST_STRIP
             ORBX_HIP(hipGetLastError());   // e.g. an LDS budget the device refuses: fail here, not as silently missing candidates
             // second pass (:843-846) and strips whose queues overflowed: one wave per listed cell, queue sized for a whole cell
             const size_t lds_full = fast_wave_lds_bytes(ex->fast_wave_pitch, ex->fast_wave_rows, ex->fast_wave_qfull);
@@ -1019,6 +1022,7 @@ int orbx_create(const orbx_params *p, int device, int max_width, int max_height,
     for (int v = 0; v < kHalfPatch; v++) mono = mono && ex->umax[v] >= ex->umax[v + 1];
     if (n != 749 || !mono) { set_error("orientation disc has " + std::to_string(n) + " pixels"); orbx_destroy(ex); return ORBX_E_INTERNAL; }
     memcpy(dc.pat, kPatternData, 1024);
+    for (int i = 0; i < 1024; i++) dc.patf[i >> 2][i & 3] = (float)kPatternData[i];
     int r = ex->d_dc.ensure(sizeof(DescConst));
     if (r != ORBX_OK) { orbx_destroy(ex); return r; }
     if (hipMemcpy(ex->d_dc.p, &dc, sizeof(dc), hipMemcpyHostToDevice) != hipSuccess) { orbx_destroy(ex); return ORBX_E_HIP; }
