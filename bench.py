@@ -656,6 +656,15 @@ def bench_euroc(R):
     run(min(a.settle, 8), False)
     R.barrier([ex])
     settle_ms = (time.perf_counter() - t_settle) / max(min(a.settle, 8), 1) * 1e3   # the fresh process's first steps: start-up transient included
+    # the FAST stage's candidate queues follow the imagery (orbx_tune_fast_queues: results never depend on them): on the quad scene 1 % of the cells take the
+    # list pass and nothing changes, on --scene texture two thirds do and the queues grow in up to three steps -- all before the warm-up
+    fast_queues = []
+    for _ in range(3):
+        fast_queues.append(ex.tune_fast_queues(1))
+        if not fast_queues[-1]["changed"]:
+            break
+        run(2, False)
+        R.barrier([ex])
     settle(lambda n: run(n, False), a, done=min(a.settle, 8))
     STAMPS.clear()
     dt, feats = timed(False)
@@ -759,6 +768,8 @@ def bench_euroc(R):
                      "matches_per_frame": round(nmatch / max(B - 1, 1), 1), "parallelism": f"{R.world} independent sequences, one per GPU"})
     out["data"] = data
     out["stage_stats_last_step"] = ex.stage_stats()   # cells on the FAST list pass, quad-tree tiers, candidates: which paths the frames exercise
+    out["fast_queues"] = {"tuning_after_settle": fast_queues, "in_force": ex.tune_fast_queues(0),
+                          "note": "orbx_tune_fast_queues(mode 1) after the first settle steps; `changed` false = the default queues (512 groups / 816 pixels per wave)"}
     if ablate:
         out["ablation"] = sorted(ablate)
         out["metric"] = "DIAGNOSTIC, NOT A RESULT (parts of the step left out: " + ",".join(sorted(ablate)) + "): " + out["metric"]

@@ -173,6 +173,16 @@ int orbx_debug_fused_patches(orbx_extractor *ex, int frame, uint8_t *dst, int ca
  * out[6] = the largest candidate count of a level.  Returns the number of entries written (7), or < 0. */
 int orbx_debug_stage_stats(orbx_extractor *ex, int64_t *out, int cap);
 
+/* The FAST stage's candidate queues.  k_fast_strip keeps the pixels that pass its pre-tests in per-wave LDS queues sized for sparse scenes (the default
+ * leaves seven workgroups on a CU); a strip whose queue overflows is finished by the list pass (k_fast_wave_list) -- the RESULTS never depend on the
+ * queue size, only the time does (dense texture: two thirds of the cells take the list pass, the stage is 4 x slower).  This call looks at the LAST batch
+ * (it waits for it): mode 0 reports only; mode 1 doubles the queues (up to "every pixel of a wave's band") when more than a tenth of the batch's cells
+ * went to the list pass, and halves them again (never below the default) when fewer than 1 in 200 did while the queues are enlarged; mode 2 restores the
+ * default.  A caller with unknown imagery runs it after each of its first few batches (orb_slam3_amd.ORBextractor.tune_fast_queues, bench.py --scene
+ * texture).  info[0] = cells of the last batch that took the list pass, info[1] = cells of the batch, info[2] / info[3] = group / pixel queue entries per
+ * wave now in force.  Returns 1 if the sizes changed, 0 if not, < 0 on error. */
+int orbx_tune_fast_queues(orbx_extractor *ex, int mode, int32_t info[4]);
+
 /* Average GPU time (ms) per launch of each extractor kernel over the calls since the last reset, measured with
  * HIP events on the extractor's stream when profiling is enabled.  names/ms arrays of `cap` entries; returns the
  * number of kernels. */

@@ -93,7 +93,7 @@ SYMBOLS = [
     "orbx_batch_download", "orbx_batch_download_all", "orbx_batch_download_async", "orbx_download_wait", "orbx_output_capacity", "orbx_get_level", "orbx_level_size",
     "orbx_get_level_device", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_scale_tables",
     "orbx_get_feature_tables", "orbx_debug_level_candidates", "orbx_debug_level_keypoints",
-    "orbx_debug_level_blurred", "orbx_debug_stage_stats", "orbx_debug_fused_patches", "orbx_profile_enable", "orbx_profile_read", "orbx_matcher_create",
+    "orbx_debug_level_blurred", "orbx_debug_stage_stats", "orbx_tune_fast_queues", "orbx_debug_fused_patches", "orbx_profile_enable", "orbx_profile_read", "orbx_matcher_create",
     "orbx_matcher_destroy", "orbx_hamming_csr", "orbx_hamming_best2_csr", "orbx_knn2", "orbx_stereo_rowband",
     "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
     "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window", "orbx_search_by_projection_mappoints_fisheye", "orbx_search_by_projection_frame_fisheye",
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
     L.orbx_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32]
     L.orbx_debug_level_blurred.argtypes = [vp, i32, i32, vp, sz]
     L.orbx_debug_stage_stats.argtypes = [vp, vp, i32]
+    L.orbx_tune_fast_queues.argtypes = [vp, i32, vp]
     L.orbx_debug_fused_patches.argtypes = [vp, i32, vp, i32]
     L.orbx_debug_sort_nodes.argtypes = [i32, vp, vp, i32, vp]
     L.orbx_debug_sort_nodes_par.argtypes = [i32, vp, vp, i32, vp, vp]

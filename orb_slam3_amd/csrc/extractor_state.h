@@ -121,7 +121,9 @@ struct orbx_extractor {
     size_t fast_lds = 0;
     bool resize_march_ok[orbx::kMaxLevels] = {};   // every tap pair of a dword column of level l within 8 source bytes (k_pyr_resize_march)
     bool fast_strip = false;    // k_fast_strip applies (cells at most 57 px wide, 63 px high)
-    int n_strips = 0, strip_pix_bytes = 0, strip_gcap = 512, strip_qcap = 816;   // k_fast_strip: strips per frame, tile rows, per-wave group / pixel queue capacities
+    static constexpr int kStripGcap0 = 512, kStripQcap0 = 816;   // the default queue sizes (sparse scenes); orbx_tune_fast_queues
+    int strip_gmax = 1024, strip_qmax = 4096;                     // a wave's band in groups / pixels, over the geometry's strips (configure)
+    int n_strips = 0, strip_pix_bytes = 0, strip_gcap = kStripGcap0, strip_qcap = kStripQcap0;   // k_fast_strip: strips per frame, tile rows, per-wave group / pixel queue capacities
     int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qfull = 16;   // list pass (fast_wave_cell): LDS tile pitch (48 / 64), max sub-image rows, whole-cell queue
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)

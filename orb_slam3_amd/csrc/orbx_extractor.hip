@@ -600,6 +600,16 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     }
     ex->n_strips = (int)strips.size();
     ex->n_strips0 = 0;
+    {   // what a wave's queues would have to hold if every group / pixel of its band passed (the ceiling of orbx_tune_fast_queues)
+        int gmax = 64, qmax = 256;
+        for (const StripTile &T : strips) {
+            const int bh = (T.ih + 3) / 4, G = (T.iw + 3) >> 2;
+            gmax = std::max(gmax, bh * G); qmax = std::max(qmax, bh * 4 * G);
+        }
+        ex->strip_gmax = (gmax + 7) & ~7; ex->strip_qmax = (qmax + 15) & ~15;
+        ex->strip_gcap = std::min(ex->strip_gcap, std::max(ex->strip_gmax, orbx_extractor::kStripGcap0));   // a geometry with shorter bands than the one the queues were enlarged for
+        ex->strip_qcap = std::min(ex->strip_qcap, std::max(ex->strip_qmax, orbx_extractor::kStripQcap0));
+    }
     for (const StripTile &T : strips) if (T.src_off < lv[0].off + (size_t)lv[0].pitch * (lv[0].h + 2 * kEdge)) ex->n_strips0++;   // level 0 lies first in the slab
     ex->fast_strip = fast_strip && ex->fast_wave && !strips.empty();
     if (ex->strip_qcap > 2 * ex->strip_gcap) ex->strip_gcap = (ex->strip_qcap / 2 + 7) & ~7;   // the scores reuse the group queue's bytes
@@ -1494,6 +1504,38 @@ int orbx_debug_stage_stats(orbx_extractor *ex, int64_t *out, int cap) {
     }
     out[0] = ex->fast_strip ? listed : -1; out[1] = (int64_t)ex->total_cells * B; out[2] = t1; out[3] = t2; out[4] = t3; out[5] = total; out[6] = most;
     return 7;
+}
+
+int orbx_tune_fast_queues(orbx_extractor *ex, int mode, int32_t info[4]) {
+    if (!ex || mode < 0 || mode > 2) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(ex->device));
+    int32_t listed = 0;
+    const int64_t cells = (int64_t)ex->total_cells * std::max(ex->last_batch, 0);
+    if (ex->last_batch > 0 && ex->fast_strip) {
+        ORBX_HIP(hipStreamSynchronize(ex->stream));
+        int r = ex->d2h_staged_begin(64);
+        if (r != ORBX_OK) return r;
+        if ((r = ex->d2h_staged(0, ex->d_fast_ovf.p, 4)) != ORBX_OK) return r;
+        ORBX_HIP(hipStreamSynchronize(ex->stream));
+        memcpy(&listed, ex->staged(0), 4);
+    }
+    const int g0 = ex->strip_gcap, q0 = ex->strip_qcap;
+    const int gdef = orbx_extractor::kStripGcap0, qdef = orbx_extractor::kStripQcap0;
+    if (mode == 2) { ex->strip_gcap = gdef; ex->strip_qcap = qdef; }
+    else if (mode == 1 && ex->fast_strip && cells > 0) {
+        const int gmax = std::max(ex->strip_gmax, gdef), qmax = std::max(ex->strip_qmax, qdef);
+        if ((int64_t)listed * 10 > cells) {          // the queues overflow all over the batch
+            ex->strip_qcap = std::min(qmax, (2 * q0 + 15) & ~15);
+            ex->strip_gcap = gmax;                    // the group queue is the small one (2 bytes per 4 pixels): its ceiling at once
+        } else if ((int64_t)listed * 200 < cells && q0 > qdef) {
+            ex->strip_qcap = std::max(qdef, (q0 / 2 + 15) & ~15);
+            if (ex->strip_qcap == qdef) ex->strip_gcap = gdef;
+        }
+    }
+    if (ex->strip_qcap > 2 * ex->strip_gcap) ex->strip_gcap = (ex->strip_qcap / 2 + 7) & ~7;   // the scores reuse the group queue's bytes
+    if (fast_strip_lds_bytes(4, ex->strip_pix_bytes, ex->strip_gcap, ex->strip_qcap) > 64 * 1024) { ex->strip_gcap = g0; ex->strip_qcap = q0; }   // (cannot happen: 13 + 40 KB)
+    if (info) { info[0] = listed; info[1] = (int32_t)std::min<int64_t>(cells, INT32_MAX); info[2] = ex->strip_gcap; info[3] = ex->strip_qcap; }
+    return (ex->strip_gcap != g0 || ex->strip_qcap != q0) ? 1 : 0;
 }
 
 int orbx_debug_sort_nodes(int device, const int32_t *count, const int32_t *ulx, int n, int32_t *perm) {

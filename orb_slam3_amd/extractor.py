@@ -269,6 +269,15 @@ class ORBextractor:
         return {"fast_list_cells": int(out[0]), "cells": int(out[1]), "quadtrees_le_1792": int(out[2]), "quadtrees_le_4096": int(out[3]),
                 "quadtrees_single_wave": int(out[4]), "fast_candidates": int(out[5]), "max_candidates_of_a_level": int(out[6])}
 
+    def tune_fast_queues(self, mode: int = 1) -> dict:
+        """orbx_tune_fast_queues on the last batch: mode 0 report, 1 adapt (grow when > 10 % of the cells took the FAST list pass, shrink back when
+        < 0.5 %), 2 defaults.  Results never depend on the queue size; dense texture is ~2 x faster with the queues it ends up with."""
+        info = (C.c_int32 * 4)()
+        r = self._L.orbx_tune_fast_queues(self._h, int(mode), info)
+        if r < 0:
+            raise RuntimeError(f"orbx_tune_fast_queues: {r}")
+        return {"changed": bool(r), "fast_list_cells": int(info[0]), "cells": int(info[1]), "group_queue": int(info[2]), "pixel_queue": int(info[3])}
+
     def profile_enable(self, on=True):
         self._L.orbx_profile_enable(self._h, int(on))
 

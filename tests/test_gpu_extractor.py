@@ -548,6 +548,40 @@ def test_texture_stress_scene_takes_the_rare_paths(monkeypatch):
         assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
 
 
+def test_fast_queue_tuning_on_texture(monkeypatch):
+    """orbx_tune_fast_queues: on the texture scene the default queues send most cells to the list pass; after at most three calls fewer than a tenth do, and
+    the batch's keypoints / descriptors are byte-identical before and after (and == oracle for two frames)."""
+    import torch
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    monkeypatch.setenv("ORBX_PYR_STREAM_MIN", "1")
+    w, h, B = 752, 480, 12
+    canvas = synth.make_texture_canvas(12)
+    frames = np.stack([synth.frame_from_canvas(canvas, t, w, h, 4000 + t) for t in range(B)])
+    ex = osa.ORBextractor(1000, 1.2, 8, 20, 7)
+    d = torch.from_numpy(frames).cuda()
+
+    def run():
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, (0, 1000))
+        return [ex.download(f) for f in range(B)]
+    first = run()
+    t0 = ex.tune_fast_queues(0)
+    assert t0["fast_list_cells"] * 10 > t0["cells"] and t0["pixel_queue"] == 816, t0
+    for _ in range(3):
+        t = ex.tune_fast_queues(1)
+        again = run()
+        for (m0, k0, d0), (m1, k1, d1) in zip(first, again):
+            assert m0 == m1 and k0.tobytes() == k1.tobytes() and np.array_equal(d0, d1)
+    rep = ex.tune_fast_queues(0)
+    assert rep["fast_list_cells"] * 10 <= rep["cells"] and rep["pixel_queue"] > 816, rep
+    oex = ob.OracleExtractor(1000, 1.2, 8, 20, 7, flags=ob.FLAG_DESC_FMA)
+    for f in (0, B - 1):
+        omono, okps, odesc = oex.extract(frames[f], lap=(0, 1000))
+        assert again[f][0] == omono and again[f][1].tobytes() == okps.tobytes() and np.array_equal(again[f][2], odesc), f
+    assert ex.tune_fast_queues(2)["pixel_queue"] == 816
+
+
 def test_fused_blur_patches_equal_the_blurred_level(canvas1, monkeypatch):
     """k_describe_fused never writes a blurred pyramid: what it filters into LDS around a keypoint is read back here (orbx_debug_fused_patches) and
     compared, ALL 37 x 37 pixels of every keypoint of two frames of a batch, with the oracle's GaussianBlur of the keypoint's level (its

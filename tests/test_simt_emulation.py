@@ -62,6 +62,32 @@ def test_emulated_extractor_small_image_stagewise(emul_lib, env):
     _child(STAGEWISE.replace("IMG", "synth.make_test_image(5, 320, 240)").replace("NF", "500"), env)
 
 
+TUNE = """
+import test_gpu_extractor as tg
+img = synth.frame_from_canvas(synth.make_texture_canvas(11), 0, 752, 480, 3000)   # dense texture: the default candidate queues overflow (a geometry the strip kernel serves)
+ex, oex = osa.ORBextractor(500, 1.2, 8, 20, 7), ob.OracleExtractor(500, 1.2, 8, 20, 7)
+n0 = tg._check_frame(ex, oex, img, (0, 1000), stagewise=True)
+seen = []
+for i in range(3):
+    t = ex.tune_fast_queues(1)
+    seen.append(t)
+    n = tg._check_frame(ex, oex, img, (0, 1000), stagewise=(i == 2))
+    assert n == n0
+rep = ex.tune_fast_queues(0)
+assert seen[0]["changed"] and seen[0]["fast_list_cells"] * 10 > seen[0]["cells"], seen
+assert rep["fast_list_cells"] * 10 <= rep["cells"] and rep["pixel_queue"] > 816 and not rep["changed"], (seen, rep)
+assert ex.tune_fast_queues(2)["pixel_queue"] == 816
+assert tg._check_frame(ex, oex, img, (0, 1000), stagewise=False) == n0
+print('emulation ok', n0, [t["pixel_queue"] for t in seen])
+"""
+
+
+def test_emulated_fast_queue_tuning(emul_lib):
+    """orbx_tune_fast_queues on a dense-texture frame: the default queues overflow (more than a tenth of the cells go to the list pass), the call grows them
+    step by step until they do not; every stage of every run == oracle (the results never depend on the queue size), mode 2 restores the default."""
+    _child(TUNE)
+
+
 def test_emulated_extractor_open_issue_image(emul_lib):
     """The 752x480 frame behind the open 1007-vs-1008 difference seen on the hardware (tests/test_gpu_pipeline.py): the device code's
     logic yields the oracle's 1008 keypoints, stage by stage."""
