@@ -64,6 +64,15 @@ __device__ __forceinline__ u64 wave_min1(u64 k) {
     return k;
 }
 
+// Ordering point of a ONE-WAVE workgroup whose lanes hand data to each other through LDS only: the wave's LDS instructions execute in program order, so
+// the compiler must not move LDS accesses across it and nothing else is needed.  (__syncthreads() is also a fence for global memory: s_waitcnt vmcnt(0)
+// on gfx950, i.e. the wave waits for the acknowledgement of every store it has issued.)
+__device__ __forceinline__ void one_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // one wave per query; lanes stride the query's candidate list
 // ---------------------------------------------------------------------------------------------------------
@@ -622,6 +631,21 @@ __device__ __forceinline__ bool load_query(const WindowProblem &P, int qi, Query
     return !w->empty;
 }
 
+// load_query for ONE query of the whole wave (the re-scan of k_greedy_resolve, a latency chain): the validity flag, the query's record and its descriptor
+// are requested together -- two dependent round trips (record, scale of its octave) instead of three
+__device__ __forceinline__ bool load_query_eager(const WindowProblem &P, int qi, QueryWin *w, const GridParams &g, Desc *dq) {
+    const uint8_t valid = P.qvalid ? P.qvalid[qi] : (uint8_t)1;
+    *dq = load_desc(P.qdesc + (size_t)qi * 32);
+    if (P.q_from_kps) {
+        const orbx_keypoint k = P.q_from_kps[qi];
+        const float radius = P.th * P.scale[valid ? k.octave : 0];   // (the record of a query flagged invalid is not looked at)
+        *w = make_window(g, k.x + P.du, k.y + P.dv, radius, k.octave - 1, k.octave + 1, 0.f);
+    } else {
+        *w = make_window(g, P.qx[qi], P.qy[qi], P.qr[qi], P.qmin[qi], P.qmax[qi], P.qxr ? P.qxr[qi] : 0.f);
+    }
+    return valid && !w->empty;
+}
+
 // scan all features of the current frame for query window w; skip features flagged in `occ` (may be NULL)
 __device__ __forceinline__ int scan_window(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
                                            const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
@@ -672,17 +696,24 @@ __device__ __forceinline__ int scan_window_grid(const WindowProblem &P, const Gr
             const int pc = __shfl(pre, c), sc = __shfl(cs, c);
             if (t >= pc) j = sc + (t - pc);
         }
-        if (t >= total || j < 0) continue;
-        const int i = P.gorder[j];
-        if (i >= n || (occ && occ[i])) continue;
+        // the re-scan is a latency chain of the one wave: the keypoint, the descriptor and the right coordinate of a candidate are requested TOGETHER, before
+        // any of the window tests (a lane without a candidate reads feature 0: total > 0 implies n > 0) -- three dependent round trips (bounds, index,
+        // record) instead of four
+        const bool v0 = t < total && j >= 0;
+        const int i0 = v0 ? (int)P.gorder[j] : 0;
+        const bool v1 = v0 && i0 < n;
+        const int i = v1 ? i0 : 0;
         const orbx_keypoint kp = P.kps[i];
+        const Desc dc = load_desc(P.desc + (size_t)i * 32);
+        const float ur = P.u_right ? P.u_right[i] : 0.f;
+        if (!v1 || (occ && occ[i])) continue;
         int cx, cy;
         if (!in_window(g, w, kp, &cx, &cy)) continue;
-        if (P.u_right && P.u_right[i] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
-            const float er = fabsf(w.xr - P.u_right[i]);
+        if (P.u_right && ur > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
+            const float er = fabsf(w.xr - ur);
             if (er > w.r) continue;
         }
-        const int d = hamming(dq, load_desc(P.desc + (size_t)i * 32));
+        const int d = hamming(dq, dc);
         push2(k1, k2, cand_key(d, cx, cy, i));
         cnt++;
     }
@@ -768,16 +799,16 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
             bool todo = c >= 0;
             while (__ballot(todo)) {   // wave-uniform: one round per multiplicity of the most crowded cell of this chunk
                 if (todo) atomicMin(&claim[c], (uint32_t)lane);
-                __syncthreads();
+                one_wave_sync();   // LDS-only hand-overs of the one wave: a __syncthreads() here waits for the gorder stores' acknowledgement in every round
                 const bool won = todo && claim[c] == (uint32_t)lane;
-                __syncthreads();
+                one_wave_sync();
                 if (won) {
                     P.gorder[start[c]] = (uint16_t)i;
                     start[c] = (uint16_t)(start[c] + 1);
                     claim[c] = 0xffffffffu;
                     todo = false;
                 }
-                __syncthreads();
+                one_wave_sync();
             }
         }
     }
@@ -942,8 +973,11 @@ struct ResolveProblem {
 // first conflicting lane commit in parallel (their choices cannot influence each other); the conflicting lane simply
 // re-evaluates in the next round against the updated mask.  Only when a lane exhausts the valid part of a
 // non-exhaustive list does the whole wave re-scan that query's window against the current mask -- exactly what the
-// sequential loop would have seen.  Dynamic LDS: claim[n_alloc] (u32) + angle[n_alloc] (f32) + occ[n_alloc] (u8);
-// nothing inside the round loop touches global memory except fire-and-forget result stores.
+// sequential loop would have seen.  Dynamic LDS: claim[n_alloc] (u32) + angle[n_alloc] (f32) + occ[n_alloc] (u8) + octave[n_alloc] (u8);
+// nothing inside the round loop touches global memory except fire-and-forget result stores: the octaves of the ratio test (M1) are staged in
+// LDS with the angles, a query's has-observations flag arrives with its candidate list (one chunk ahead), and the hand-overs between the rounds
+// are LDS-only orderings of the ONE wave (one_wave_sync) -- a __syncthreads() there is s_waitcnt vmcnt(0): every round waited for the
+// acknowledgement of its result stores (round 5: ~45 rounds per 1000 queries of the bench's frame pairs, 170 per 10 000 map points).
 __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
                                                        GridParams g, int n_alloc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -951,6 +985,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
     uint32_t *claim = reinterpret_cast<uint32_t *>(lds);
     float *ang = reinterpret_cast<float *>(lds + (size_t)n_alloc * 4);
     uint8_t *occ = lds + (size_t)n_alloc * 8;
+    uint8_t *oct = occ + n_alloc;
     const WindowProblem P = probs[blockIdx.x];
     const ResolveProblem R = res[blockIdx.x];
     const int lane = threadIdx.x;
@@ -958,11 +993,13 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
     const int n = min(*P.n_ptr, n_alloc), nq = *P.nq_ptr;
     for (int i0 = 0; i0 < n; i0 += 8 * 64) {   // eight loads in flight per lane: two memory round trips for 1000 features, not sixteen
         float a[8];
+        int l[8];
         uint8_t o[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int i = i0 + 64 * k + lane;
             a[k] = i < n ? P.kps[i].angle : 0.f;
+            l[k] = i < n ? P.kps[i].octave : 0;
             o[k] = (i < n && P.occupied0) ? P.occupied0[i] : (uint8_t)0;
         }
 #pragma unroll
@@ -970,6 +1007,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
             const int i = i0 + 64 * k + lane;
             if (i < n) {
                 occ[i] = o[k];
+                oct[i] = (uint8_t)l[k];   // octaves are 0 .. nlevels - 1 < 256; compared for equality only
                 claim[i] = 0xffffffffu;
                 ang[i] = a[k];
                 R.match[i] = -1;
@@ -990,8 +1028,8 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         if ((float)bestDist > R.max_dist) return false;
         if (two) {
             const int bestDist2 = (k2 == kNoKey) ? 256 : (int)(k2 >> 32);
-            const int bestLevel = P.kps[(int)(k1 & 0xffff)].octave;
-            const int bestLevel2 = (k2 == kNoKey) ? -1 : P.kps[(int)(k2 & 0xffff)].octave;
+            const int bestLevel = oct[(int)(k1 & 0xffff)];
+            const int bestLevel2 = (k2 == kNoKey) ? -1 : (int)oct[(int)(k2 & 0xffff)];
             if (bestLevel == bestLevel2 && (float)bestDist > R.nnratio * (float)bestDist2) return false;
             if (!(bestLevel != bestLevel2 || (float)bestDist <= R.nnratio * (float)bestDist2)) return false;
         }
@@ -1006,15 +1044,16 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
     };
 
     // candidate lists of a chunk of 64 queries; the next chunk's are requested before the current chunk is replayed
-    struct Chunk { u64 L0, L1, L2, L3; int meta; float q_ang; };
+    struct Chunk { u64 L0, L1, L2, L3; int meta; float q_ang; uint8_t obs; };
     auto fetch = [&](int q0) -> Chunk {
-        Chunk c = {kNoKey, kNoKey, kNoKey, kNoKey, 256, 0.f};   // inactive lane: empty exhaustive list
+        Chunk c = {kNoKey, kNoKey, kNoKey, kNoKey, 256, 0.f, (uint8_t)1};   // inactive lane: empty exhaustive list
         const int qi = q0 + lane;
         if (qi < nq) {
             const u64 *kp = P.keys + (size_t)qi * kTopK;
             c.L0 = kp[0]; c.L1 = kp[1]; c.L2 = kp[2]; c.L3 = kp[3];
             c.meta = P.meta[qi];
             if (ori) c.q_ang = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
+            if (R.q_has_obs) c.obs = R.q_has_obs[qi];
         }
         return c;
     };
@@ -1028,6 +1067,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         const int valid_len = C.meta & 0xff;
         const bool exhaustive = (C.meta & 256) != 0;
         const float q_ang = C.q_ang;
+        const uint8_t q_obs = C.obs;
         int pos = 0;
         while (pos < 64) {
             const bool live = active && lane >= pos;
@@ -1052,9 +1092,9 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
             const int t1 = has ? (int)(c1 & 0xffff) : -1;
             const int t2 = (has && two && c2 != kNoKey) ? (int)(c2 & 0xffff) : -1;
             if (has) atomicMin(&claim[t1], (uint32_t)lane);
-            __syncthreads();
+            one_wave_sync();
             const bool conflict = need_slow || (has && (claim[t1] != (uint32_t)lane || (t2 >= 0 && claim[t2] < (uint32_t)lane)));
-            __syncthreads();
+            one_wave_sync();
             if (has) claim[t1] = 0xffffffffu;
             const u64 cb = __ballot(conflict);
             const int c = cb ? (__ffsll((long long)cb) - 1) : 64;
@@ -1063,7 +1103,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
             const u64 okb = __ballot(ok);
             if (ok) {
                 R.match[t1] = qi;
-                occ[t1] = R.q_has_obs ? R.q_has_obs[qi] : 1;
+                occ[t1] = q_obs;
                 if (ori) {
                     const int b = rot_bin(q_ang, t1);
                     R.entries[n_entries + __popcll(okb & lt_mask)] = (b << 16) | t1;  // rotHist[bin].push_back(bestIdx2)
@@ -1072,17 +1112,18 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
             }
             nmatches += __popcll(okb);
             if (ori) n_entries += __popcll(okb);
-            __syncthreads();
+            one_wave_sync();
             if (c >= 64) break;
             const bool slow = (__shfl((int)need_slow, c) != 0);
             if (!slow) { pos = c; continue; }  // claim conflict: lane c re-evaluates against the updated mask
             {   // list exhausted: re-scan query q0+c against the occupancy the sequential loop sees at this point
                 const int qc = q0 + c;
                 const float qa_c = __shfl(q_ang, c);  // all lanes participate in the shuffle
+                const int obs_c = __shfl((int)q_obs, c);
                 QueryWin w;
                 Desc dq;
                 u64 r1 = kNoKey, r2 = kNoKey;
-                if (load_query(P, qc, &w, g, &dq)) {
+                if (load_query_eager(P, qc, &w, g, &dq)) {
                     scan_window_grid(P, g, w, dq, n, occ, lane, r1, r2);
                     wave_min2(r1, r2);
                 }
@@ -1090,7 +1131,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                     const int idx = (int)(r1 & 0xffff);
                     if (lane == 0) {
                         R.match[idx] = qc;
-                        occ[idx] = R.q_has_obs ? R.q_has_obs[qc] : 1;
+                        occ[idx] = (uint8_t)obs_c;
                         if (ori) {
                             const int b = rot_bin(qa_c, idx);
                             R.entries[n_entries] = (b << 16) | idx;
@@ -1100,7 +1141,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                     nmatches++;
                     if (ori) n_entries++;
                 }
-                __syncthreads();
+                one_wave_sync();
             }
             pos = c + 1;
         }
@@ -1273,7 +1314,7 @@ __global__ __launch_bounds__(64) void k_replay_twin(const WindowProblem *__restr
             }
             nmatches += np;
             if (ori) n_entries++;
-            __syncthreads();   // single wave: orders lane 0's LDS / global writes before the next sub-query's reads
+            one_wave_sync();   // single wave: orders lane 0's LDS writes (occ, hist) before the next sub-query's reads; match / entries are read after the loop's __syncthreads()
         }
     }
     __syncthreads();

@@ -20,7 +20,7 @@ using namespace orbx;
 namespace {
 
 constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
-inline size_t resolve_lds_bytes(int n) { return (size_t)n * 9 + 64; }
+inline size_t resolve_lds_bytes(int n) { return (size_t)n * 10 + 64; }   // k_greedy_resolve: claim u32 + angle f32 + occ u8 + octave u8 per feature
 #define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__)
 // k_window_best2: 8 lanes per query (a window of the bench's matchers holds 1 - 10 candidates: 16 -> 8 lanes, 74 -> 59 us in round 4; 4 like 8).
 // nq = queries per problem, np = problems.  From 8 problems on the launch is XCD-aware like the extractor's (extractor_kernels.hip.h, xcd_grid): x = XCD,
@@ -88,18 +88,82 @@ struct orbx_matcher {
     hipStream_t stream = nullptr;
     Arena arena;
     PinnedArena stage;
+    // Round 5: transfers of ONE call are coalesced.  `mirror` is a pinned image of the device arena: an upload to arena offset o is staged at mirror offset o
+    // and only RECORDED; exec() -- the stream as every launch, memset and download of a call obtains it -- first issues the recorded uploads, ONE
+    // hipMemcpyAsync per run of arena-adjacent buffers (adjacent = nothing but take()'s alignment padding between them, which no buffer owns).  Downloads
+    // from the arena are recorded the same way and issued as runs by deliver().  A projection-matcher call made 14 uploads and 2 downloads of 4 B .. 32 KB,
+    // each a DMA submission of its own on the stream (~5 us): now 2 + 1.  Transfers whose device side is not in the arena take the direct path (stage).
+    PinnedArena mirror;
+    struct Span { size_t off, bytes; };
+    std::vector<Span> uploads;      // recorded, not yet issued (ascending offsets: the arena is a bump allocator)
+    std::vector<Span> issued;       // mirror ranges a DMA issued since the last synchronisation may still read: not staged over (such an upload goes direct)
     struct Pending { void *dst; const void *src; size_t bytes; };
-    std::vector<Pending> pending;   // downloads waiting in the staging arena for the stream synchronisation
+    std::vector<Pending> pending;   // downloads waiting in pinned memory for the stream synchronisation
+    struct Down { void *dst; size_t off, bytes; };
+    std::vector<Down> downloads;    // recorded downloads from the arena (issued by deliver())
+    hipError_t xfer_err = hipSuccess;
+    static constexpr size_t kPadGap = 255;   // Arena::take aligns to 256
     // device scratch for one call + staging for everything that call can move in either direction
     int reserve_all(size_t device_bytes) {
         int r = arena.reserve(device_bytes);
         if (r != ORBX_OK) return r;
+        r = mirror.reserve(arena.cap);
+        if (r != ORBX_OK) return r;
         return stage.reserve(2 * device_bytes + 65536);
     }
-    void begin() { arena.reset(); stage.reset(); pending.clear(); }
-    void flush() {
-        for (const Pending &p : pending) memcpy(p.dst, p.src, p.bytes);
+    // begin() follows a synchronisation of the previous call (every entry point ends in deliver(), or failed before anything was enqueued)
+    void begin() { arena.reset(); stage.reset(); pending.clear(); uploads.clear(); downloads.clear(); issued.clear(); xfer_err = hipSuccess; }
+    bool in_arena(const void *p, size_t bytes) const {
+        const uint8_t *q = static_cast<const uint8_t *>(p);
+        return arena.base && q >= arena.base && q + bytes <= arena.base + arena.cap && arena.cap <= mirror.cap;
+    }
+    bool stageable(const void *p, size_t bytes) const {   // an upload that may be staged in the mirror
+        if (!in_arena(p, bytes)) return false;
+        const size_t o = (size_t)(static_cast<const uint8_t *>(p) - arena.base);
+        for (const Span &q : issued)
+            if (o < q.off + q.bytes && q.off < o + bytes) return false;
+        return true;
+    }
+    void note(hipError_t e) { if (e != hipSuccess && xfer_err == hipSuccess) xfer_err = e; }
+    void flush_uploads() {
+        std::sort(uploads.begin(), uploads.end(), [](const Span &a, const Span &b) { return a.off < b.off; });   // (a record uploaded after its buffers were taken lies between them)
+        size_t i = 0;
+        while (i < uploads.size()) {
+            const size_t b = uploads[i].off;
+            size_t e = b + uploads[i].bytes, j = i + 1;
+            while (j < uploads.size() && uploads[j].off <= e + kPadGap) { e = std::max(e, uploads[j].off + uploads[j].bytes); j++; }
+            note(hipMemcpyAsync(arena.base + b, mirror.base + b, e - b, hipMemcpyHostToDevice, stream));
+            issued.push_back(Span{b, e - b});
+            i = j;
+        }
+        uploads.clear();
+    }
+    // the stream for anything that consumes the call's uploads (kernel launches, memsets, downloads, the synchronisation)
+    hipStream_t exec() {
+        if (!uploads.empty()) flush_uploads();
+        return stream;
+    }
+    // issue the recorded downloads (runs of arena-adjacent buffers), wait for the stream, hand the bytes to the caller's buffers
+    hipError_t deliver() {
+        (void)exec();
+        std::sort(downloads.begin(), downloads.end(), [](const Down &a, const Down &b) { return a.off < b.off; });
+        size_t i = 0;
+        while (i < downloads.size()) {
+            const size_t b = downloads[i].off;
+            size_t e = b + downloads[i].bytes, j = i + 1;
+            while (j < downloads.size() && downloads[j].off <= e + kPadGap) { e = std::max(e, downloads[j].off + downloads[j].bytes); j++; }
+            note(hipMemcpyAsync(mirror.base + b, arena.base + b, e - b, hipMemcpyDeviceToHost, stream));
+            i = j;
+        }
+        note(hipStreamSynchronize(stream));
+        if (xfer_err == hipSuccess) {
+            for (const Down &d : downloads) memcpy(d.dst, mirror.base + d.off, d.bytes);
+            for (const Pending &q : pending) memcpy(q.dst, q.src, q.bytes);
+        }
+        downloads.clear();
         pending.clear();
+        issued.clear();
+        return xfer_err;
     }
 };
 
@@ -135,6 +199,7 @@ void orbx_matcher_destroy(orbx_matcher *m) {
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->arena.base) (void)hipFree(m->arena.base);
     if (m->stage.base) (void)hipHostFree(m->stage.base);
+    if (m->mirror.base) (void)hipHostFree(m->mirror.base);
     delete m;
 }
 
@@ -142,26 +207,35 @@ void orbx_matcher_destroy(orbx_matcher *m) {
     do {                                                                                                          \
         const size_t _b = (bytes);                                                                                \
         if (_b > 0) {                                                                                             \
-            void *_s = m->stage.take(_b);                                                                         \
-            if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                            \
-            memcpy(_s, (src), _b);                                                                                \
-            ORBX_HIP(hipMemcpyAsync((dst), _s, _b, hipMemcpyHostToDevice, m->stream));                            \
+            if (m->stageable((dst), _b)) {  /* recorded; issued with its arena neighbours by exec() */             \
+                const size_t _o = (size_t)((const uint8_t *)(dst) - m->arena.base);                               \
+                memcpy(m->mirror.base + _o, (src), _b);                                                           \
+                m->uploads.push_back(orbx_matcher::Span{_o, _b});                                                 \
+            } else {                                                                                              \
+                void *_s = m->stage.take(_b);                                                                     \
+                if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                        \
+                memcpy(_s, (src), _b);                                                                            \
+                ORBX_HIP(hipMemcpyAsync((dst), _s, _b, hipMemcpyHostToDevice, m->stream));                        \
+            }                                                                                                     \
         }                                                                                                         \
     } while (0)
 #define D2H(dst, src, bytes)                                                                                      \
     do {                                                                                                          \
         const size_t _b = (bytes);                                                                                \
         if (_b > 0) {                                                                                             \
-            void *_s = m->stage.take(_b);                                                                         \
-            if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                            \
-            ORBX_HIP(hipMemcpyAsync(_s, (src), _b, hipMemcpyDeviceToHost, m->stream));                            \
-            m->pending.push_back(orbx_matcher::Pending{(void *)(dst), _s, _b});                                   \
+            if (m->in_arena((src), _b)) {   /* recorded; issued with its arena neighbours by deliver() */          \
+                m->downloads.push_back(orbx_matcher::Down{(void *)(dst), (size_t)((const uint8_t *)(src) - m->arena.base), _b}); \
+            } else {                                                                                              \
+                void *_s = m->stage.take(_b);                                                                     \
+                if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                        \
+                ORBX_HIP(hipMemcpyAsync(_s, (src), _b, hipMemcpyDeviceToHost, m->exec()));                        \
+                m->pending.push_back(orbx_matcher::Pending{(void *)(dst), _s, _b});                               \
+            }                                                                                                     \
         }                                                                                                         \
     } while (0)
 #define SYNC_AND_DELIVER()                                                                                        \
     do {                                                                                                          \
-        ORBX_HIP(hipStreamSynchronize(m->stream));                                                                \
-        m->flush();                                                                                               \
+        ORBX_HIP(m->deliver());                                                                                   \
     } while (0)
 
 int orbx_hamming_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, const int32_t *row_ptr,
@@ -180,7 +254,7 @@ int orbx_hamming_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t
     int32_t *drp = m->arena.take<int32_t>(nq + 1), *dc = m->arena.take<int32_t>(nnz);
     uint16_t *dd = m->arena.take<uint16_t>(nnz);
     H2D(dq, q, (size_t)nq * 32); H2D(dt, t, (size_t)nt * 32); H2D(drp, row_ptr, 4 * (size_t)(nq + 1)); H2D(dc, cand, 4 * (size_t)nnz);
-    hipLaunchKernelGGL(k_hamming_csr, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, drp, dc, dd);
+    hipLaunchKernelGGL(k_hamming_csr, dim3((nq + 3) / 4), dim3(256), 0, m->exec(), dq, nq, dt, drp, dc, dd);
     D2H(dist_out, dd, 2 * (size_t)nnz);
     SYNC_AND_DELIVER();
     return ORBX_OK;
@@ -205,7 +279,7 @@ int orbx_hamming_best2_csr(orbx_matcher *m, const uint8_t *q, int nq, const uint
     if (nt > 0) H2D(dt, t, (size_t)nt * 32);
     H2D(drp, row_ptr, 4 * (size_t)(nq + 1));
     if (nnz > 0) H2D(dc, cand, 4 * (size_t)nnz);
-    hipLaunchKernelGGL(k_hamming_best2_csr, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, drp, dc, o[0], o[1], o[2], o[3]);
+    hipLaunchKernelGGL(k_hamming_best2_csr, dim3((nq + 3) / 4), dim3(256), 0, m->exec(), dq, nq, dt, drp, dc, o[0], o[1], o[2], o[3]);
     int32_t *host[4] = {best_pos, best_dist, second_pos, second_dist};
     for (int k = 0; k < 4; k++) if (host[k]) D2H(host[k], o[k], 4 * (size_t)nq);
     SYNC_AND_DELIVER();
@@ -223,7 +297,7 @@ int orbx_knn2(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int n
     int32_t *di = m->arena.take<int32_t>(2 * (size_t)nq), *dd = m->arena.take<int32_t>(2 * (size_t)nq);
     H2D(dq, q, (size_t)nq * 32);
     if (nt > 0) H2D(dt, t, (size_t)nt * 32);
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dq, nq, dt, nt, di, dd);
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, m->exec(), dq, nq, dt, nt, di, dd);
     D2H(idx, di, 8 * (size_t)nq); D2H(dist, dd, 8 * (size_t)nq);
     SYNC_AND_DELIVER();
     return ORBX_OK;
@@ -247,7 +321,7 @@ int orbx_stereo_rowband(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t 
     H2D(dkl, kl, 28 * (size_t)nl); H2D(ddl, dl, 32 * (size_t)nl);
     if (nr > 0) { H2D(dkr, kr, 28 * (size_t)nr); H2D(ddr, dr, 32 * (size_t)nr); }
     H2D(dsc, scale, 4 * (size_t)nlevels);
-    hipLaunchKernelGGL(k_stereo_rowband, dim3((nl + 3) / 4), dim3(256), 0, m->stream, dkl, ddl, nl, dkr, ddr, nr, dsc, n_rows, min_d,
+    hipLaunchKernelGGL(k_stereo_rowband, dim3((nl + 3) / 4), dim3(256), 0, m->exec(), dkl, ddl, nl, dkr, ddr, nr, dsc, n_rows, min_d,
                        max_d, dbi, dbd);
     D2H(best_idx_r, dbi, 4 * (size_t)nl); D2H(best_dist, dbd, 4 * (size_t)nl);
     SYNC_AND_DELIVER();
@@ -320,10 +394,10 @@ int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const 
     int32_t *drp = A.take<int32_t>((size_t)S.n_buckets + 1);
     uint4 *den = A.take<uint4>(Nr);
     S.row_ptr = drp; S.row_ent = den;
-    hipLaunchKernelGGL(k_stereo_row_index, dim3(1), dim3(256), 4 * ((size_t)S.n_buckets + 1) + 1024, m->stream, S, drp, den);
-    hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((N + 15) / 16, 1), dim3(256), 0, m->stream, S);
-    hipLaunchKernelGGL(k_stereo_sad, dim3((N + 15) / 16, 1), dim3(256), 0, m->stream, S);
-    hipLaunchKernelGGL(k_stereo_reject, dim3(1), dim3(256), 0, m->stream, S);
+    hipLaunchKernelGGL(k_stereo_row_index, dim3(1), dim3(256), 4 * ((size_t)S.n_buckets + 1) + 1024, m->exec(), S, drp, den);
+    hipLaunchKernelGGL(k_stereo_rowband_batch, dim3((N + 15) / 16, 1), dim3(256), 0, m->exec(), S);
+    hipLaunchKernelGGL(k_stereo_sad, dim3((N + 15) / 16, 1), dim3(256), 0, m->exec(), S);
+    hipLaunchKernelGGL(k_stereo_reject, dim3(1), dim3(256), 0, m->exec(), S);
     ORBX_HIP(hipGetLastError());
     int32_t nm = 0;
     D2H(u_right, S.u_right, 4 * (size_t)N); D2H(depth, S.depth, 4 * (size_t)N); D2H(&nm, S.nmatches, 4);
@@ -389,27 +463,29 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     if (a.qxr && F->u_right) { float *p = A.take<float>(nq); H2D(p, a.qxr, 4 * (size_t)nq); P.qxr = p; }
     { uint8_t *p = A.take<uint8_t>(32 * (size_t)nq); H2D(p, a.qdesc, 32 * (size_t)nq); P.qdesc = p; }
     if (a.qvalid) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.qvalid, (size_t)nq); P.qvalid = p; }
-    P.keys = A.take<u64>((size_t)nq * kTopK); P.meta = A.take<int32_t>(nq);
-    P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n);
     R.mode = a.mode; R.nnratio = a.nnratio; R.check_orientation = a.check_orientation; R.max_dist = a.max_dist;
     R.cleared_value = -2;
     if (a.q_angle) { float *p = A.take<float>(nq); H2D(p, a.q_angle, 4 * (size_t)nq); R.q_angle = p; }
     if (a.q_has_obs) { uint8_t *p = A.take<uint8_t>(nq); H2D(p, a.q_has_obs, (size_t)nq); R.q_has_obs = p; }
-    R.match = A.take<int32_t>(n);
-    R.nmatches = A.take<int32_t>(1);
-    R.entries = A.take<int32_t>(nq);
+    // everything the call uploads lies in ONE run of the arena (one DMA, orbx_matcher::exec): the two problem records directly behind the inputs,
+    // the buffers only the device writes behind them; the downloads (match, nmatches) side by side as well
     WindowProblem *dP = A.take<WindowProblem>(1);
     ResolveProblem *dR = A.take<ResolveProblem>(1);
+    P.keys = A.take<u64>((size_t)nq * kTopK); P.meta = A.take<int32_t>(nq);
+    P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n);
+    R.entries = A.take<int32_t>(nq);
+    R.match = A.take<int32_t>(n);
+    R.nmatches = A.take<int32_t>(1);
     H2D(dP, &P, sizeof(P)); H2D(dR, &R, sizeof(R));
     GridParams g;
     g.minx = F->min_x; g.miny = F->min_y;
     g.inv_w = 64.0f / (F->max_x - F->min_x);  // Frame.cc:342-343
     g.inv_h = 48.0f / (F->max_y - F->min_y);
-    ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->stream, dP, g);
-    ORBX_LAUNCH_WINDOW_BEST2(nq, 1, m->stream, dP, g);
+    ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2(nq, 1, m->exec(), dP, g);
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->stream, dP, dR, g, n);
+    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->exec(), dP, dR, g, n);
     int32_t nm = 0;
     D2H(a.match_out, R.match, 4 * (size_t)n);
     D2H(&nm, R.nmatches, 4);
@@ -546,10 +622,10 @@ int run_projection_twin(orbx_matcher *m, const TwinArgs &a) {
     g.minx = F->min_x; g.miny = F->min_y;
     g.inv_w = 64.0f / (F->max_x - F->min_x);
     g.inv_h = 48.0f / (F->max_y - F->min_y);
-    ORBX_LAUNCH_GRID_BUILD( dim3(2), dim3(64), 0, m->stream, dP, g);
-    ORBX_LAUNCH_WINDOW_BEST2(nq, 2, m->stream, dP, g);
+    ORBX_LAUNCH_GRID_BUILD( dim3(2), dim3(64), 0, m->exec(), dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2(nq, 2, m->exec(), dP, g);
     const size_t lds = ((size_t)N + 63) & ~(size_t)63;
-    hipLaunchKernelGGL(k_replay_twin, dim3(1), dim3(64), lds, m->stream, dP, T, g);
+    hipLaunchKernelGGL(k_replay_twin, dim3(1), dim3(64), lds, m->exec(), dP, T, g);
     int32_t nm = 0;
     D2H(a.match_out, T.match, 4 * (size_t)N);
     D2H(&nm, T.nmatches, 4);
@@ -743,7 +819,7 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un
     g.minx = F2->min_x; g.miny = F2->min_y;
     g.inv_w = 64.0f / (F2->max_x - F2->min_x);
     g.inv_h = 48.0f / (F2->max_y - F2->min_y);
-    hipLaunchKernelGGL(k_replay_init, dim3(1), dim3(64), 0, m->stream, P, g);
+    hipLaunchKernelGGL(k_replay_init, dim3(1), dim3(64), 0, m->exec(), P, g);
     int32_t nm = 0;
     D2H(matches12, P.matches12, 4 * (size_t)n1);
     D2H(prev_matched, dprev, 8 * (size_t)n1);
@@ -786,10 +862,12 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
     auto up = [&](const void *src, size_t bytes) -> const uint8_t * {
         if (!src) return nullptr;
         uint8_t *d = A.take<uint8_t>(bytes);
-        void *st = m->stage.take(bytes);
-        if (!st) return nullptr;
-        memcpy(st, src, bytes);
-        if (hipMemcpyAsync(d, st, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) return nullptr;
+        if (bytes > 0) {   // recorded like H2D(): issued with its arena neighbours by exec()
+            if (!m->stageable(d, bytes)) return nullptr;
+            const size_t o = (size_t)(d - m->arena.base);
+            memcpy(m->mirror.base + o, src, bytes);
+            m->uploads.push_back(orbx_matcher::Span{o, bytes});
+        }
         return d;
     };
     P.mode = mode; P.nb_left = nb_left;
@@ -811,14 +889,15 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
         for (int i = 0; i < 9; i++) G.F[i] = gate->F12[i];
         G.ex = gate->ep_x; G.ey = gate->ep_y;
     }
-    P.match = A.take<int32_t>(n_out); P.taken_b = A.take<uint8_t>(nb); P.entries = A.take<int32_t>(2 * (size_t)std::max(na, nb));
-    P.nmatches = A.take<int32_t>(4);
+    // the two downloads side by side (one DMA), the two zero-filled buffers side by side (one fill)
+    P.match = A.take<int32_t>(n_out); P.nmatches = A.take<int32_t>(4);
+    P.taken_b = A.take<uint8_t>(nb);
     P.hist = A.take<int32_t>(ORBX_HISTO_LENGTH + 2); P.counters = P.hist + ORBX_HISTO_LENGTH;
-    ORBX_HIP(hipMemsetAsync(P.match, 0xff, 4 * (size_t)n_out, m->stream));     // -1: no match
-    ORBX_HIP(hipMemsetAsync(P.taken_b, 0, (size_t)nb, m->stream));
-    ORBX_HIP(hipMemsetAsync(P.hist, 0, 4 * (size_t)(ORBX_HISTO_LENGTH + 2), m->stream));
-    if (fa->n_nodes > 0) hipLaunchKernelGGL(k_replay_bow, dim3((fa->n_nodes + 3) / 4), dim3(256), 0, m->stream, P);   // a wave per vocabulary node
-    hipLaunchKernelGGL(k_replay_bow_finish, dim3(1), dim3(64), 0, m->stream, P);
+    P.entries = A.take<int32_t>(2 * (size_t)std::max(na, nb));
+    ORBX_HIP(hipMemsetAsync(P.match, 0xff, 4 * (size_t)n_out, m->exec()));     // -1: no match
+    ORBX_HIP(hipMemsetAsync(P.taken_b, 0, (size_t)((const uint8_t *)(P.hist + ORBX_HISTO_LENGTH + 2) - P.taken_b), m->exec()));   // taken_b, (padding,) hist + counters
+    if (fa->n_nodes > 0) hipLaunchKernelGGL(k_replay_bow, dim3((fa->n_nodes + 3) / 4), dim3(256), 0, m->exec(), P);   // a wave per vocabulary node
+    hipLaunchKernelGGL(k_replay_bow_finish, dim3(1), dim3(64), 0, m->exec(), P);
     int32_t nm = 0;
     D2H(match_out, P.match, 4 * (size_t)n_out);
     D2H(&nm, P.nmatches, 4);
@@ -1165,7 +1244,7 @@ extern "C" int orbx_undistort_keypoints(orbx_matcher *m, const orbx_camera *cam,
     m->begin();
     orbx_keypoint *di = A.take<orbx_keypoint>(n), *dou = A.take<orbx_keypoint>(n);
     H2D(di, kps, sizeof(orbx_keypoint) * (size_t)n);
-    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, m->stream, model_of(cam), (const orbx_keypoint *)di, (const int32_t *)nullptr, n, dou);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, 1), dim3(256), 0, m->exec(), model_of(cam), (const orbx_keypoint *)di, (const int32_t *)nullptr, n, dou);
     D2H(kps_un, dou, sizeof(orbx_keypoint) * (size_t)n);
     SYNC_AND_DELIVER();
     return ORBX_OK;
@@ -1192,7 +1271,7 @@ extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_camera *cam, const
     const FrustumFrame F = frustum_frame(cam, pose, bounds4, log_scale_factor, nlevels, viewing_cos_limit);
     H2D(dF, &F, sizeof(F));
     H2D(dp, pos, 12 * n); H2D(dn, normal, 12 * n); H2D(dmn, min_dist, 4 * n); H2D(dmx, max_dist, 4 * n);
-    hipLaunchKernelGGL(k_in_frustum, dim3((n_mp + 255) / 256, 1), dim3(256), 0, m->stream, (const FrustumFrame *)dF, n_mp, (const float *)dp,
+    hipLaunchKernelGGL(k_in_frustum, dim3((n_mp + 255) / 256, 1), dim3(256), 0, m->exec(), (const FrustumFrame *)dF, n_mp, (const float *)dp,
                        (const float *)dn, (const float *)dmn, (const float *)dmx, div, dx, dy, dxr, dd, dl, dvc);
     D2H(in_view, div, n); D2H(proj_x, dx, 4 * n); D2H(proj_y, dy, 4 * n); D2H(proj_xr, dxr, 4 * n); D2H(depth, dd, 4 * n);
     D2H(level, dl, 4 * n); D2H(view_cos, dvc, 4 * n);
@@ -1440,7 +1519,7 @@ extern "C" int orbx_bow_transform(orbx_matcher *m, const orbx_vocabulary *v, con
     uint8_t *dd = m->arena.take<uint8_t>(32 * (size_t)n);
     int32_t *dw = m->arena.take<int32_t>(n), *dn = m->arena.take<int32_t>(n);
     H2D(dd, desc, 32 * (size_t)n);
-    hipLaunchKernelGGL(k_bow_transform, dim3((n + 15) / 16), dim3(256), 0, m->stream, v->child_ptr, v->child_idx, v->node_desc, v->word_id,
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + 15) / 16), dim3(256), 0, m->exec(), v->child_ptr, v->child_idx, v->node_desc, v->word_id,
                        v->L, levelsup, dd, n, dw, dn);
     D2H(word_id, dw, 4 * (size_t)n); D2H(node_id, dn, 4 * (size_t)n);
     SYNC_AND_DELIVER();
@@ -1461,7 +1540,7 @@ extern "C" int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *desc
     int32_t *dp = m->arena.take<int32_t>(n_sets + 1), *db = m->arena.take<int32_t>(n_sets);
     if (total > 0) H2D(dd, desc, 32 * (size_t)total);
     H2D(dp, set_ptr, 4 * (size_t)(n_sets + 1));
-    hipLaunchKernelGGL(k_distinctive, dim3((n_sets + 3) / 4), dim3(256), 0, m->stream, dd, dp, n_sets, db);
+    hipLaunchKernelGGL(k_distinctive, dim3((n_sets + 3) / 4), dim3(256), 0, m->exec(), dd, dp, n_sets, db);
     D2H(best_idx, db, 4 * (size_t)n_sets);
     SYNC_AND_DELIVER();
     return ORBX_OK;
@@ -1511,16 +1590,16 @@ extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, cons
     P.qmin = dmin; P.qmax = dmax;
     if (q_ur && kf->u_right) { float *p = A.take<float>(n_q); H2D(p, q_ur, 4 * (size_t)n_q); P.qxr = p; }
     { uint8_t *p = A.take<uint8_t>(32 * (size_t)n_q); H2D(p, q_desc, 32 * (size_t)n_q); P.qdesc = p; }
+    WindowProblem *dP = A.take<WindowProblem>(1);   // directly behind the inputs: the call's uploads are one run of the arena (one DMA)
     P.keys = A.take<u64>((size_t)n_q * kTopK); P.meta = A.take<int32_t>(n_q);
     P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n);
-    WindowProblem *dP = A.take<WindowProblem>(1);
     H2D(dP, &P, sizeof(P));
     GridParams g;
     g.minx = kf->min_x; g.miny = kf->min_y;
     g.inv_w = 64.0f / (kf->max_x - kf->min_x);
     g.inv_h = 48.0f / (kf->max_y - kf->min_y);
-    ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->stream, dP, g);
-    ORBX_LAUNCH_WINDOW_BEST2(n_q, 1, m->stream, dP, g);
+    ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
+    ORBX_LAUNCH_WINDOW_BEST2(n_q, 1, m->exec(), dP, g);
     std::vector<u64> keys((size_t)n_q * kTopK);
     D2H(keys.data(), P.keys, 8 * (size_t)n_q * kTopK);
     SYNC_AND_DELIVER();
