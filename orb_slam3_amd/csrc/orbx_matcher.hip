@@ -102,6 +102,7 @@ struct orbx_matcher {
     struct Down { void *dst; size_t off, bytes; };
     std::vector<Down> downloads;    // recorded downloads from the arena (issued by deliver())
     hipError_t xfer_err = hipSuccess;
+    int64_t xfers[4] = {0, 0, 0, 0};   // DMA submissions up / down and their bytes since begin() (orbx_matcher_debug_transfers)
     static constexpr size_t kPadGap = 255;   // Arena::take aligns to 256
     // device scratch for one call + staging for everything that call can move in either direction
     int reserve_all(size_t device_bytes) {
@@ -112,7 +113,7 @@ struct orbx_matcher {
         return stage.reserve(2 * device_bytes + 65536);
     }
     // begin() follows a synchronisation of the previous call (every entry point ends in deliver(), or failed before anything was enqueued)
-    void begin() { arena.reset(); stage.reset(); pending.clear(); uploads.clear(); downloads.clear(); issued.clear(); xfer_err = hipSuccess; }
+    void begin() { arena.reset(); stage.reset(); pending.clear(); uploads.clear(); downloads.clear(); issued.clear(); xfer_err = hipSuccess; xfers[0] = xfers[1] = xfers[2] = xfers[3] = 0; }
     bool in_arena(const void *p, size_t bytes) const {
         const uint8_t *q = static_cast<const uint8_t *>(p);
         return arena.base && q >= arena.base && q + bytes <= arena.base + arena.cap && arena.cap <= mirror.cap;
@@ -133,6 +134,7 @@ struct orbx_matcher {
             size_t e = b + uploads[i].bytes, j = i + 1;
             while (j < uploads.size() && uploads[j].off <= e + kPadGap) { e = std::max(e, uploads[j].off + uploads[j].bytes); j++; }
             note(hipMemcpyAsync(arena.base + b, mirror.base + b, e - b, hipMemcpyHostToDevice, stream));
+            xfers[0]++; xfers[2] += (int64_t)(e - b);
             issued.push_back(Span{b, e - b});
             i = j;
         }
@@ -153,6 +155,7 @@ struct orbx_matcher {
             size_t e = b + downloads[i].bytes, j = i + 1;
             while (j < downloads.size() && downloads[j].off <= e + kPadGap) { e = std::max(e, downloads[j].off + downloads[j].bytes); j++; }
             note(hipMemcpyAsync(mirror.base + b, arena.base + b, e - b, hipMemcpyDeviceToHost, stream));
+            xfers[1]++; xfers[3] += (int64_t)(e - b);
             i = j;
         }
         note(hipStreamSynchronize(stream));
@@ -193,6 +196,12 @@ int orbx_matcher_create(int device, orbx_matcher **out) {
     return ORBX_OK;
 }
 
+int orbx_matcher_debug_transfers(const orbx_matcher *m, int64_t *out, int cap) {
+    if (!m || !out || cap < 4) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < 4; i++) out[i] = m->xfers[i];
+    return 4;
+}
+
 void orbx_matcher_destroy(orbx_matcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
@@ -216,6 +225,7 @@ void orbx_matcher_destroy(orbx_matcher *m) {
                 if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                        \
                 memcpy(_s, (src), _b);                                                                            \
                 ORBX_HIP(hipMemcpyAsync((dst), _s, _b, hipMemcpyHostToDevice, m->stream));                        \
+                m->xfers[0]++; m->xfers[2] += (int64_t)_b;                                                        \
             }                                                                                                     \
         }                                                                                                         \
     } while (0)
@@ -229,6 +239,7 @@ void orbx_matcher_destroy(orbx_matcher *m) {
                 void *_s = m->stage.take(_b);                                                                     \
                 if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                        \
                 ORBX_HIP(hipMemcpyAsync(_s, (src), _b, hipMemcpyDeviceToHost, m->exec()));                        \
+                m->xfers[1]++; m->xfers[3] += (int64_t)_b;                                                        \
                 m->pending.push_back(orbx_matcher::Pending{(void *)(dst), _s, _b});                               \
             }                                                                                                     \
         }                                                                                                         \

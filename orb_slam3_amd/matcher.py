@@ -105,6 +105,14 @@ class ORBmatcher:
             self._L.orbx_matcher_destroy(self._h)
             self._h = None
 
+    def last_transfers(self) -> dict:
+        """DMA submissions of the last call: orbx_matcher_debug_transfers."""
+        out = np.zeros(4, np.int64)
+        n = self._L.orbx_matcher_debug_transfers(self._h, ptr(out), 4)
+        if n < 0:
+            raise RuntimeError(f"orbx_matcher_debug_transfers: {n}")
+        return {"uploads": int(out[0]), "downloads": int(out[1]), "upload_bytes": int(out[2]), "download_bytes": int(out[3])}
+
     # ---- DescriptorDistance over candidate lists (ORBmatcher.cc:2058-2074) ----
     def hamming_csr(self, q_desc, t_desc, row_ptr, cand):
         q, t, rp, cd = _u8(q_desc), _u8(t_desc), _i32(row_ptr), _i32(cand)

@@ -163,6 +163,11 @@ def test_search_by_projection_frame(oracle, canvas1):
         n, cm = m.SearchByProjectionFrame(_frame_view(k1, d1, sf, 752, 480), q, th, mode, occ)
         assert n == on and np.array_equal(cm, ocm), (mode, n, on)
         assert n > 50
+        # the call's 15 input arrays travel as ONE run of its device arena (+ the two problem records behind them), match vector and count come back
+        # together: the DMA submissions of a call are part of its latency (round 5: 14 + 2 -> at most 2 + 1)
+        t = m.last_transfers()
+        assert 1 <= t["uploads"] <= 2 and t["downloads"] == 1, t
+        assert t["upload_bytes"] >= 60 * len(k1) + 60 * len(k0) and t["download_bytes"] >= 4 * len(k1) + 4, t
 
 
 def test_search_by_projection_mappoints(oracle):
