@@ -73,6 +73,25 @@ __device__ __forceinline__ void one_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A pointer a kernel finds INSIDE a problem record is a generic ("flat") pointer to the compiler: it emits flat_load / flat_store, which count on BOTH wait
+// counters.  In a latency chain that matters: a wait for an LDS result (lgkmcnt) then also waits for every flat load in flight -- the candidate lists
+// k_greedy_resolve requests one chunk ahead arrived synchronously, a memory round trip per 64 queries.  gld / gst state the address space (scalar types):
+// global_load / global_store, vmcnt alone.
+template <class T> __device__ __forceinline__ T gld(const T *p) { return *(const __attribute__((address_space(1))) T *)p; }
+template <class T> __device__ __forceinline__ void gst(T *p, T v) { *(__attribute__((address_space(1))) T *)p = v; }
+__device__ __forceinline__ Desc gld_desc(const uint8_t *p) {   // rows are 32-byte aligned
+    const u64 *q = reinterpret_cast<const u64 *>(p);
+    Desc d;
+    d.w[0] = gld(q); d.w[1] = gld(q + 1); d.w[2] = gld(q + 2); d.w[3] = gld(q + 3);
+    return d;
+}
+__device__ __forceinline__ orbx_keypoint gld_kp(const orbx_keypoint *p) {   // the fields the matchers look at (position, angle, octave)
+    orbx_keypoint k;
+    k.x = gld(&p->x); k.y = gld(&p->y); k.angle = gld(&p->angle); k.octave = gld(&p->octave);
+    k.size = 0.f; k.response = 0.f; k.class_id = -1;
+    return k;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // one wave per query; lanes stride the query's candidate list
 // ---------------------------------------------------------------------------------------------------------
@@ -619,29 +638,29 @@ __device__ __forceinline__ bool in_window(const GridParams &g, const QueryWin &w
 }
 
 __device__ __forceinline__ bool load_query(const WindowProblem &P, int qi, QueryWin *w, const GridParams &g, Desc *dq) {
-    if (P.qvalid && !P.qvalid[qi]) return false;
+    if (P.qvalid && !gld(P.qvalid + qi)) return false;
     if (P.q_from_kps) {
-        const orbx_keypoint k = P.q_from_kps[qi];
-        const float radius = P.th * P.scale[k.octave];
+        const orbx_keypoint k = gld_kp(P.q_from_kps + qi);
+        const float radius = P.th * gld(P.scale + k.octave);
         *w = make_window(g, k.x + P.du, k.y + P.dv, radius, k.octave - 1, k.octave + 1, 0.f);
     } else {
-        *w = make_window(g, P.qx[qi], P.qy[qi], P.qr[qi], P.qmin[qi], P.qmax[qi], P.qxr ? P.qxr[qi] : 0.f);
+        *w = make_window(g, gld(P.qx + qi), gld(P.qy + qi), gld(P.qr + qi), gld(P.qmin + qi), gld(P.qmax + qi), P.qxr ? gld(P.qxr + qi) : 0.f);
     }
-    *dq = load_desc(P.qdesc + (size_t)qi * 32);
+    *dq = gld_desc(P.qdesc + (size_t)qi * 32);
     return !w->empty;
 }
 
 // load_query for ONE query of the whole wave (the re-scan of k_greedy_resolve, a latency chain): the validity flag, the query's record and its descriptor
 // are requested together -- two dependent round trips (record, scale of its octave) instead of three
 __device__ __forceinline__ bool load_query_eager(const WindowProblem &P, int qi, QueryWin *w, const GridParams &g, Desc *dq) {
-    const uint8_t valid = P.qvalid ? P.qvalid[qi] : (uint8_t)1;
-    *dq = load_desc(P.qdesc + (size_t)qi * 32);
+    const uint8_t valid = P.qvalid ? gld(P.qvalid + qi) : (uint8_t)1;
+    *dq = gld_desc(P.qdesc + (size_t)qi * 32);
     if (P.q_from_kps) {
-        const orbx_keypoint k = P.q_from_kps[qi];
-        const float radius = P.th * P.scale[valid ? k.octave : 0];   // (the record of a query flagged invalid is not looked at)
+        const orbx_keypoint k = gld_kp(P.q_from_kps + qi);
+        const float radius = P.th * gld(P.scale + (valid ? k.octave : 0));   // (the record of a query flagged invalid is not looked at)
         *w = make_window(g, k.x + P.du, k.y + P.dv, radius, k.octave - 1, k.octave + 1, 0.f);
     } else {
-        *w = make_window(g, P.qx[qi], P.qy[qi], P.qr[qi], P.qmin[qi], P.qmax[qi], P.qxr ? P.qxr[qi] : 0.f);
+        *w = make_window(g, gld(P.qx + qi), gld(P.qy + qi), gld(P.qr + qi), gld(P.qmin + qi), gld(P.qmax + qi), P.qxr ? gld(P.qxr + qi) : 0.f);
     }
     return valid && !w->empty;
 }
@@ -678,8 +697,8 @@ __device__ __forceinline__ int scan_window_grid(const WindowProblem &P, const Gr
     int cs = 0, len = 0;
     if (lane < ncol) {
         const int base = (w.cx0 + lane) * 48;
-        cs = P.gstart[base + w.cy0];
-        len = (int)P.gstart[base + w.cy1 + 1] - cs;
+        cs = gld(P.gstart + base + w.cy0);
+        len = (int)gld(P.gstart + base + w.cy1 + 1) - cs;
     }
     int incl = len;
 #pragma unroll
@@ -700,12 +719,12 @@ __device__ __forceinline__ int scan_window_grid(const WindowProblem &P, const Gr
         // any of the window tests (a lane without a candidate reads feature 0: total > 0 implies n > 0) -- three dependent round trips (bounds, index,
         // record) instead of four
         const bool v0 = t < total && j >= 0;
-        const int i0 = v0 ? (int)P.gorder[j] : 0;
+        const int i0 = v0 ? (int)gld(P.gorder + j) : 0;
         const bool v1 = v0 && i0 < n;
         const int i = v1 ? i0 : 0;
-        const orbx_keypoint kp = P.kps[i];
-        const Desc dc = load_desc(P.desc + (size_t)i * 32);
-        const float ur = P.u_right ? P.u_right[i] : 0.f;
+        const orbx_keypoint kp = gld_kp(P.kps + i);
+        const Desc dc = gld_desc(P.desc + (size_t)i * 32);
+        const float ur = P.u_right ? gld(P.u_right + i) : 0.f;
         if (!v1 || (occ && occ[i])) continue;
         int cx, cy;
         if (!in_window(g, w, kp, &cx, &cy)) continue;
@@ -741,7 +760,7 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
     __shared__ uint32_t claim[kGridCells];
     const WindowProblem P = probs[blockIdx.x];
     const int lane = threadIdx.x;
-    const int n = *P.n_ptr;
+    const int n = gld(P.n_ptr);   // (gld / gst: the record's pointers are device memory, see above)
     for (int i = lane; i < kGridCells; i += 64) { cnt[i] = 0; claim[i] = 0xffffffffu; }
     __syncthreads();
     auto cell_of = [&](float x, float y) -> int {   // PosInGrid (Frame.cc:725-735); -1 = outside the grid
@@ -756,7 +775,7 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
         for (int k = 0; k < 8; k++) {
             const int i = i0 + 64 * k + lane;
             xy[k] = float2{-1e30f, -1e30f};
-            if (i < n) __builtin_memcpy(&xy[k], &P.kps[i].x, 8);   // x, y: the first two fields (4-byte aligned records)
+            if (i < n) { xy[k].x = gld(&P.kps[i].x); xy[k].y = gld(&P.kps[i].y); }
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -778,10 +797,10 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
     for (int k = 0; k < kGridCells / 64; k++) {
         const int c = lane * (kGridCells / 64) + k;
         start[c] = (uint16_t)run;
-        P.gstart[c] = (uint16_t)run;
+        gst(P.gstart + c, (uint16_t)run);
         run += cnt[c];
     }
-    if (lane == 63) P.gstart[kGridCells] = (uint16_t)run;
+    if (lane == 63) gst(P.gstart + kGridCells, (uint16_t)run);
     __syncthreads();
     // pass 2: stable fill, 64 features at a time in index order (eight chunks loaded per round trip)
     for (int i0 = 0; i0 < n; i0 += 8 * 64) {
@@ -790,7 +809,7 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
         for (int k = 0; k < 8; k++) {
             const int i = i0 + 64 * k + lane;
             xy[k] = float2{-1e30f, -1e30f};
-            if (i < n) __builtin_memcpy(&xy[k], &P.kps[i].x, 8);   // x, y: the first two fields (4-byte aligned records)
+            if (i < n) { xy[k].x = gld(&P.kps[i].x); xy[k].y = gld(&P.kps[i].y); }
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -803,7 +822,7 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
                 const bool won = todo && claim[c] == (uint32_t)lane;
                 one_wave_sync();
                 if (won) {
-                    P.gorder[start[c]] = (uint16_t)i;
+                    gst(P.gorder + start[c], (uint16_t)i);
                     start[c] = (uint16_t)(start[c] + 1);
                     claim[c] = 0xffffffffu;
                     todo = false;
@@ -858,7 +877,7 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
     const WindowProblem P = probs[prob];
     const int sub = threadIdx.x / LQ, sl = threadIdx.x & (LQ - 1);
     const int qi = blockIdx.y * (256 / LQ) + sub;
-    const int nq = *P.nq_ptr;
+    const int nq = gld(P.nq_ptr);
     const bool qvalid = qi < nq;
     QueryWin w;
     Desc dq;
@@ -876,8 +895,8 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const int ix = min(cx + c, w.cx1);
-                cs[c] = P.gstart[ix * 48 + w.cy0];
-                ce[c] = P.gstart[ix * 48 + w.cy1 + 1];
+                cs[c] = gld(P.gstart + ix * 48 + w.cy0);
+                ce[c] = gld(P.gstart + ix * 48 + w.cy1 + 1);
             }
             int pre[9];
             pre[0] = 0;
@@ -889,9 +908,9 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
 #pragma unroll
                 for (int c = 1; c < 8; c++) j = (t >= pre[c]) ? cs[c] + (t - pre[c]) : j;
                 const int s = j - t;  // so that seq0 + (j - s) = seq0 + t below
-                const int i = P.gorder[j];
-                if (P.occupied0 && P.occupied0[i]) continue;
-                const orbx_keypoint kp = P.kps[i];
+                const int i = gld(P.gorder + j);
+                if (P.occupied0 && gld(P.occupied0 + i)) continue;
+                const orbx_keypoint kp = gld_kp(P.kps + i);
                 if (w.check_levels) {
                     if (kp.octave < w.minL) continue;
                     if (w.maxL >= 0 && kp.octave > w.maxL) continue;
@@ -900,20 +919,20 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
                 if (!(fabsf(dx) < w.r && fabsf(dy) < w.r)) continue;
                 if (P.inv_sigma2) {  // Fuse: chi2 gate on the reprojection error
                     const float ex = __fsub_rn(w.x, kp.x), ey = __fsub_rn(w.y, kp.y);
-                    if (P.u_right && P.u_right[i] >= 0) {
-                        const float er = __fsub_rn(w.xr, P.u_right[i]);
+                    if (P.u_right && gld(P.u_right + i) >= 0) {
+                        const float er = __fsub_rn(w.xr, gld(P.u_right + i));
                         const float e2 = P.chi2_fma ? __fmaf_rn(er, er, __fmaf_rn(ex, ex, __fmul_rn(ey, ey)))
                                                     : __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
-                        if ((double)__fmul_rn(e2, P.inv_sigma2[kp.octave]) > 7.8) continue;
+                        if ((double)__fmul_rn(e2, gld(P.inv_sigma2 + kp.octave)) > 7.8) continue;
                     } else {
                         const float e2 = P.chi2_fma ? __fmaf_rn(ex, ex, __fmul_rn(ey, ey)) : __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
-                        if ((double)__fmul_rn(e2, P.inv_sigma2[kp.octave]) > 5.99) continue;
+                        if ((double)__fmul_rn(e2, gld(P.inv_sigma2 + kp.octave)) > 5.99) continue;
                     }
-                } else if (P.u_right && P.u_right[i] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
-                    const float er = fabsf(w.xr - P.u_right[i]);
+                } else if (P.u_right && gld(P.u_right + i) > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
+                    const float er = fabsf(w.xr - gld(P.u_right + i));
                     if (er > w.r) continue;
                 }
-                const int d = hamming(dq, load_desc(P.desc + (size_t)i * 32));
+                const int d = hamming(dq, gld_desc(P.desc + (size_t)i * 32));
                 push2(k1, k2, seq_key(d, seq0 + (j - s), i));
                 cnt++;
             }
@@ -947,8 +966,8 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
     }
     if (qvalid && sl == 0) {
 #pragma unroll
-        for (int r = 0; r < kTopK; r++) P.keys[(size_t)qi * kTopK + r] = out[r];
-        P.meta[qi] = valid_len | ((total <= valid_len) ? 256 : 0) | ((total == 0) ? 512 : 0);   // bit 9: GetFeaturesInArea returned nothing
+        for (int r = 0; r < kTopK; r++) gst(P.keys + (size_t)qi * kTopK + r, out[r]);
+        gst(P.meta + qi, valid_len | ((total <= valid_len) ? 256 : 0) | ((total == 0) ? 512 : 0));   // bit 9: GetFeaturesInArea returned nothing
     }
 }
 
@@ -990,7 +1009,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
     const ResolveProblem R = res[blockIdx.x];
     const int lane = threadIdx.x;
     const u64 lt_mask = (1ull << lane) - 1ull;
-    const int n = min(*P.n_ptr, n_alloc), nq = *P.nq_ptr;
+    const int n = min(gld(P.n_ptr), n_alloc), nq = gld(P.nq_ptr);
     for (int i0 = 0; i0 < n; i0 += 8 * 64) {   // eight loads in flight per lane: two memory round trips for 1000 features, not sixteen
         float a[8];
         int l[8];
@@ -998,9 +1017,9 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int i = i0 + 64 * k + lane;
-            a[k] = i < n ? P.kps[i].angle : 0.f;
-            l[k] = i < n ? P.kps[i].octave : 0;
-            o[k] = (i < n && P.occupied0) ? P.occupied0[i] : (uint8_t)0;
+            a[k] = i < n ? gld(&P.kps[i].angle) : 0.f;
+            l[k] = i < n ? gld(&P.kps[i].octave) : 0;
+            o[k] = (i < n && P.occupied0) ? gld(P.occupied0 + i) : (uint8_t)0;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1010,7 +1029,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                 oct[i] = (uint8_t)l[k];   // octaves are 0 .. nlevels - 1 < 256; compared for equality only
                 claim[i] = 0xffffffffu;
                 ang[i] = a[k];
-                R.match[i] = -1;
+                gst(R.match + i, -1);
             }
         }
     }
@@ -1050,10 +1069,10 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         const int qi = q0 + lane;
         if (qi < nq) {
             const u64 *kp = P.keys + (size_t)qi * kTopK;
-            c.L0 = kp[0]; c.L1 = kp[1]; c.L2 = kp[2]; c.L3 = kp[3];
-            c.meta = P.meta[qi];
-            if (ori) c.q_ang = P.q_from_kps ? P.q_from_kps[qi].angle : R.q_angle[qi];
-            if (R.q_has_obs) c.obs = R.q_has_obs[qi];
+            c.L0 = gld(kp); c.L1 = gld(kp + 1); c.L2 = gld(kp + 2); c.L3 = gld(kp + 3);
+            c.meta = gld(P.meta + qi);
+            if (ori) c.q_ang = P.q_from_kps ? gld(&P.q_from_kps[qi].angle) : gld(R.q_angle + qi);
+            if (R.q_has_obs) c.obs = gld(R.q_has_obs + qi);
         }
         return c;
     };
@@ -1062,6 +1081,9 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         const int qi = q0 + lane;
         const bool active = qi < nq;
         const Chunk C = nxt;
+        // the wait for this chunk's lists goes HERE, before the next chunk's are requested: placed at their first use further down it is a vmcnt(0) across the
+        // loop's back edge, which also waits for the requests just made -- the lists would arrive synchronously again
+        asm volatile("" :: "v"(C.L0), "v"(C.L1), "v"(C.L2), "v"(C.L3), "v"(C.meta), "v"(C.q_ang), "v"((int)C.obs) : "memory");
         nxt = fetch(q0 + 64);
         const u64 L0 = C.L0, L1 = C.L1, L2 = C.L2, L3 = C.L3;
         const int valid_len = C.meta & 0xff;
@@ -1102,11 +1124,11 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
             const bool ok = has && lane < c && accept(c1, c2);
             const u64 okb = __ballot(ok);
             if (ok) {
-                R.match[t1] = qi;
+                gst(R.match + t1, qi);
                 occ[t1] = q_obs;
                 if (ori) {
                     const int b = rot_bin(q_ang, t1);
-                    R.entries[n_entries + __popcll(okb & lt_mask)] = (b << 16) | t1;  // rotHist[bin].push_back(bestIdx2)
+                    gst(R.entries + n_entries + __popcll(okb & lt_mask), (b << 16) | t1);  // rotHist[bin].push_back(bestIdx2)
                     atomicAdd(&hist[b], 1);
                 }
             }
@@ -1130,11 +1152,11 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                 if (accept(r1, r2)) {
                     const int idx = (int)(r1 & 0xffff);
                     if (lane == 0) {
-                        R.match[idx] = qc;
+                        gst(R.match + idx, qc);
                         occ[idx] = (uint8_t)obs_c;
                         if (ori) {
                             const int b = rot_bin(qa_c, idx);
-                            R.entries[n_entries] = (b << 16) | idx;
+                            gst(R.entries + n_entries, (b << 16) | idx);
                             hist[b]++;
                         }
                     }
@@ -1160,15 +1182,15 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         // :1871-1881: every entry of a rejected bin clears its feature and decrements nmatches
         for (int e = lane; e < n_entries; e += 64) {
-            const int v = R.entries[e], b = v >> 16;
-            if (b != ind1 && b != ind2 && b != ind3) R.match[v & 0xffff] = R.cleared_value;
+            const int v = gld(R.entries + e), b = v >> 16;
+            if (b != ind1 && b != ind2 && b != ind3) gst(R.match + (v & 0xffff), R.cleared_value);
         }
         int dropped = 0;
         for (int i = 0; i < ORBX_HISTO_LENGTH; i++)
             if (i != ind1 && i != ind2 && i != ind3) dropped += hist[i];
         nmatches -= dropped;
     }
-    if (lane == 0) *R.nmatches = nmatches;
+    if (lane == 0) gst(R.nmatches, nmatches);
 }
 
 // ---------------------------------------------------------------------------------------------------------
