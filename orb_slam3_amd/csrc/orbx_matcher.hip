@@ -400,7 +400,7 @@ int orbx_compute_stereo_matches(orbx_matcher *m, const orbx_keypoint *kl, const 
     S.pyrL = dL; S.pyrR = dR; S.pyr_frame_L = 0; S.pyr_frame_R = 0; S.lvL = dlv; S.lvR = dlv;
     S.scale = dsc; S.inv_scale = dsc + nlevels; S.n_rows = pyr_h[0]; S.bf = bf; S.b = b;
     S.best_idx = A.take<int32_t>(N); S.best_dist = A.take<int32_t>(N);
-    S.u_right = A.take<float>(N); S.depth = A.take<float>(N); S.sad = A.take<int32_t>(N); S.nmatches = A.take<int32_t>(4);
+    S.u_right = A.take<float>(N); S.depth = A.take<float>(N); S.nmatches = A.take<int32_t>(4); S.sad = A.take<int32_t>(N);   // the three downloads side by side: one DMA
     stereo_index_params(S, pyr_h[0], scale_factors, nlevels);
     int32_t *drp = A.take<int32_t>((size_t)S.n_buckets + 1);
     uint4 *den = A.take<uint4>(Nr);
