@@ -43,5 +43,13 @@ ORBX_FUSED_BLUR=0 timeout 120 python bench.py --workload euroc --cpu-frames 0 --
 import sys, json
 d = json.loads(sys.stdin.read()); print('ORBX_FUSED_BLUR=0 euroc: ms_per_step', d['ms_per_step'], 'parity_checked', d['parity_checked'])" > $O/profiles_copy/${TAG}_blur_pass_forced_parity.txt 2>&1
 cat $O/profiles_copy/${TAG}_blur_pass_forced_parity.txt
+# steady state: one region of K = 4000 pipelined steps (the contract's K = 20 regions pay the pipeline's fill and drain); SOAK=0 skips it
+if [ "${SOAK:-1}" != "0" ]; then
+  timeout 150 python bench.py --gpus 1 --steps 4000 --warmup 5 --cpu-frames 0 --no-pmc --no-other-workloads --latency 0 --no-profile --repeat 2 2> /dev/null | tail -1 > $O/profiles_copy/${TAG}_soak_4000_step_regions.json
+  python3 -c "
+import sys, json
+d = json.load(open('$O/profiles_copy/${TAG}_soak_4000_step_regions.json')); print('K = 4000: ms_per_step', d['ms_per_step'], d['repeats']['ms_per_step_in_order'], 'value', d['value'], 'parity', d['parity_checked'], 'pcie-inclusive', d['pcie_inclusive']['ms_per_step'])"
+  lap soak
+fi
 rm -rf $O/se $O/pf $O/pw $O/sq $O/ov
 ls $O/profiles_copy
