@@ -168,6 +168,43 @@ def test_emulated_batch_pipeline_with_matcher(emul_lib, env):
     _child(PIPELINE, env)
 
 
+HOST_CALLS = """
+import test_gpu_matcher as tg
+W, H = 320, 240
+img0, img1 = synth.make_test_image(3, W, H), synth.make_test_image(3, W, H)
+img1 = np.roll(img1, (1, 2), (0, 1))
+ex = osa.ORBextractor(400, 1.2, 8, 20, 7)
+_, k0, d0 = ex(img0, None, (0, 1000)); _, k1, d1 = ex(img1, None, (0, 1000))
+sf = ex.GetScaleFactors()
+rng = np.random.default_rng(11)
+m = osa.ORBmatcher(0.9, True)
+for rep in range(3):   # the same context again and again: the mirror / arena of call n + 1 reuse the memory of call n
+    q = dict(u=k0['x'] + 2.0, v=k0['y'] + 1.0, ur=np.zeros(len(k0), np.float32), octave=k0['octave'], angle=k0['angle'], desc=d0,
+             has_obs=(rng.random(len(k0)) < 0.9).astype(np.uint8))
+    occ = (rng.random(len(k1)) < 0.05).astype(np.uint8)
+    on, ocm = ob.search_by_projection_frame(ob.OracleGrid(k1, 0.0, float(W), 0.0, float(H)), d1, sf, q, 15.0, 0, True, None, occ)
+    n, cm = m.SearchByProjectionFrame(tg._frame_view(k1, d1, sf, W, H), q, 15.0, 0, occ)
+    assert n == on and np.array_equal(cm, ocm) and n > 20, (rep, n, on)
+    t = m.last_transfers()
+    assert t['uploads'] == 1 and t['downloads'] == 1, t   # 15 input arrays + two problem records: one run of the arena; match vector + count: one
+    assert t['upload_bytes'] >= 60 * (len(k0) + len(k1)) and t['download_bytes'] >= 4 * len(k1) + 4, t
+    i, dist = m.knn2(d0, d1)   # another entry point on the same context in between (its own arena layout)
+    oi, od = ob.knn2(d0, d1)
+    assert np.array_equal(i, oi) and np.array_equal(dist, od)
+print('emulation ok')
+"""
+
+
+@pytest.mark.parametrize("env", [{"SIMT_MALLOC_FILL": "r5"}, {"SIMT_STREAM_FUZZ": "last", "SIMT_MALLOC_FILL": "255", "SIMT_KERNEL_SPLIT": "3"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_emulated_matcher_call_moves_its_data_in_one_dma_each_way(emul_lib, env):
+    """A host-pointer matcher call stages its inputs in a pinned mirror of its device arena and moves every run of adjacent buffers with ONE copy
+    (orbx_matcher::exec / deliver, DESIGN.md section 6): result == oracle, one upload and one download per SearchByProjection call
+    (orbx_matcher_debug_transfers), also with garbage in every allocation (the mirror's padding bytes travel with the run) and with the stand-in
+    runtime executing the stream's operations late and in pieces (a launch that did not flush the recorded uploads first would read stale memory)."""
+    _child(HOST_CALLS, env)
+
+
 SWITCHES = [{"ORBX_OCTREE": "seq"}, {"ORBX_FAST_QCAP": "48"}]
 
 
