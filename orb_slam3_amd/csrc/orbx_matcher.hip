@@ -19,7 +19,7 @@ using namespace orbx;
 
 namespace {
 
-constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) per feature must fit the 160 KB LDS
+constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) + octave (1 B) per feature must fit the 160 KB LDS (16000 x 10 + 200 B)
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 10 + 64; }   // k_greedy_resolve: claim u32 + angle f32 + occ u8 + octave u8 per feature
 #define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__)
 // k_window_best2: 8 lanes per query (a window of the bench's matchers holds 1 - 10 candidates: 16 -> 8 lanes, 74 -> 59 us in round 4; 4 like 8).
@@ -441,7 +441,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     const int n = F->n, nq = a.nq;
     for (int i = 0; i < n; i++) a.match_out[i] = -1;
     if (n == 0 || nq == 0) return 0;
-    if (n > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;  // before anything is enqueued: the resolve pass keeps 9 B per feature in LDS
+    if (n > kMaxResolveFeatures) return ORBX_E_TOO_LARGE;  // before anything is enqueued: the resolve pass keeps 10 B per feature in LDS
     ORBX_HIP(hipSetDevice(m->device));
     size_t need = Arena::pad(28 * (size_t)n) + Arena::pad(32 * (size_t)n) + 3 * Arena::pad((size_t)n) + Arena::pad(4 * (size_t)n) * 2 +
                   Arena::pad(4 * (size_t)nq) * 7 + Arena::pad(32 * (size_t)nq) + Arena::pad((size_t)nq) * 2 + Arena::pad(8 * (size_t)nq) * 5 +
