@@ -206,6 +206,50 @@ def test_search_by_projection_mappoints(oracle):
         assert n > 100
 
 
+def _synthetic_frame(rng, n, w, h):
+    import orb_slam3_amd as osa
+    k = np.zeros(n, osa.KP_DTYPE)
+    k["octave"] = rng.integers(0, 8, n)
+    sc = (1.2 ** k["octave"]).astype(np.float32)
+    k["x"] = (rng.uniform(20, w - 20, n) / sc).round().astype(np.float32) * sc   # level coordinates times the level's scale, as the extractor delivers them
+    k["y"] = (rng.uniform(20, h - 20, n) / sc).round().astype(np.float32) * sc
+    k["size"] = 31.0 * sc
+    k["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    k["response"] = rng.integers(7, 200, n).astype(np.float32)
+    k["class_id"] = -1
+    return k, _rand_desc(rng, n)
+
+
+def test_projection_matchers_at_the_largest_frame(oracle):
+    """ORBX_MAX_FRAME_FEATURES (16 000) features in the current frame: the replay of the query loop keeps 10 bytes per feature in LDS (160 KB: all of a
+    CU's), the grid's cells hold up to hundreds of features (candidate lists cut short, re-scans) -- M1 and M2 == oracle; one feature more is refused
+    before anything is enqueued."""
+    import orb_slam3_amd as osa
+    rng = np.random.default_rng(21)
+    W, H, N = 1024, 1024, 16000
+    kf, df = _synthetic_frame(rng, N, W, H)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    n_mp = 3000
+    src = rng.choice(N, n_mp, replace=False)
+    mp = dict(proj_x=kf["x"][src] + rng.normal(0, 1.5, n_mp).astype(np.float32), proj_y=kf["y"][src] + rng.normal(0, 1.5, n_mp).astype(np.float32),
+              proj_xr=np.zeros(n_mp, np.float32), level=kf["octave"][src], view_cos=rng.uniform(0.9, 1.0, n_mp).astype(np.float32),
+              desc=_noisy_copy(rng, df[src], 0.05), in_view=(rng.random(n_mp) < 0.95).astype(np.uint8), has_obs=(rng.random(n_mp) < 0.97).astype(np.uint8))
+    occ = (rng.random(N) < 0.1).astype(np.uint8)
+    grid = oracle.OracleGrid(kf, 0.0, float(W), 0.0, float(H))
+    m = osa.ORBmatcher(0.8, True)
+    on, ofm = oracle.search_by_projection_mappoints(grid, df, sf, mp, 3.0, 0.8, None, occ)
+    n, fm = m.SearchByProjection(_frame_view(kf, df, sf, W, H), mp, 3.0, occ)
+    assert n == on and np.array_equal(fm, ofm) and n > 500, (n, on)
+    q = dict(u=kf["x"][src] + 1.0, v=kf["y"][src] - 1.0, ur=np.zeros(n_mp, np.float32), octave=kf["octave"][src], angle=kf["angle"][src],
+             desc=_noisy_copy(rng, df[src], 0.05), has_obs=(rng.random(n_mp) < 0.9).astype(np.uint8))
+    on, ocm = oracle.search_by_projection_frame(grid, df, sf, q, 15.0, 0, True, None, occ)
+    n, cm = m.SearchByProjectionFrame(_frame_view(kf, df, sf, W, H), q, 15.0, 0, occ)
+    assert n == on and np.array_equal(cm, ocm) and n > 500, (n, on)
+    k1, d1 = _synthetic_frame(rng, N + 1, W, H)
+    with pytest.raises(osa.OrbxError):
+        m.SearchByProjectionFrame(_frame_view(k1, d1, sf, W, H), q, 15.0, 0, None)
+
+
 def test_match_consecutive_device_equals_host_api(oracle, canvas1):
     """The batched device-resident frame-to-frame matcher returns what M2 returns frame by frame."""
     import torch
