@@ -856,94 +856,64 @@ namespace orbx {
 // ---------------------------------------------------------------------------------------------------------
 // Output slots (ORBextractor.cc:1117-1162): keypoints of all levels in level order; a keypoint whose SCALED x
 // lies in [lap0, lap1] is written from the back (stereoIndex--), the others from the front (monoIndex++).
-// One workgroup per frame.  The frame's keypoints are ONE sequence g = 0 .. N - 1 (level order, list order inside a level) cut into chunks of 256:
-// pass 1 counts a chunk's lapping / other keypoints per wave (ballots) for ALL chunks, wave 0 turns the counts into running offsets, pass 2
-// writes the work items -- three barriers per frame.  (Rounds 1-4 walked the levels one after the other, two barriers and a dependent load
-// chain per level: 10 us per batch on the latency-bound stretch between the quad-tree and the descriptors.)
+// One workgroup per frame.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kFinChunks = 255;  // chunks of 256 keypoints (N <= 65 280: the packed counts stay below 2^16; beyond it the kernel reports err 1 like an overfull frame)
-
 __global__ __launch_bounds__(256) void k_finalize(const LevelInfo *__restrict__ lv, int nlevels,
                                                   const uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride,
                                                   const int32_t *__restrict__ lvlcnt, WorkItem *__restrict__ work,
                                                   int cap, int32_t *__restrict__ count, int32_t *__restrict__ mono,
                                                   int lap0, int lap1, int32_t *__restrict__ err) {
-    __shared__ int pre[kMaxLevels + 1];            // keypoints of the levels before l
-    __shared__ uint32_t l_off[kMaxLevels], l_pitches[kMaxLevels], l_poff[kMaxLevels], l_boff[kMaxLevels];
-    __shared__ float l_scale[kMaxLevels], l_size[kMaxLevels];
-    __shared__ int wsum[kFinChunks * 4];           // per (chunk, wave): lapping << 16 | others; after the scan: the running totals BEFORE it
-    __shared__ int wtot;                           // the frame's totals, packed alike
+    __shared__ int wsum[4];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < nlevels) {
-        const LevelInfo L = lv[tid];
-        pre[tid] = lvlcnt[f * nlevels + tid];
-        l_off[tid] = L.lvl_off; l_pitches[tid] = (uint32_t)L.pitch | ((uint32_t)L.bpitch << 16); l_poff[tid] = (uint32_t)L.off; l_boff[tid] = (uint32_t)L.boff;
-        l_scale[tid] = L.scale; l_size[tid] = L.size;
-    }
-    __syncthreads();
-    if (tid == 0) {   // exclusive prefix of at most sixteen counts
-        int run = 0;
-        for (int l = 0; l < nlevels; l++) { const int c = pre[l]; pre[l] = run; run += c; }
-        pre[nlevels] = run;
-    }
-    __syncthreads();
-    const int N = pre[nlevels];
-    const int nchunks = (N + 255) >> 8;
-    if (N > cap || nchunks > kFinChunks) {
+    int N = 0;
+    for (int l = 0; l < nlevels; l++) N += lvlcnt[f * nlevels + l];
+    if (N > cap) {
         if (tid == 0) { atomicExch(err, 1); count[f] = 0; mono[f] = 0; }
         return;
     }
+    int g0 = 0, monoIdx = 0, stereoIdx = N - 1;
     const float flap0 = (float)lap0, flap1 = (float)lap1;
-    const uint32_t *src = lvlkp + (size_t)f * lvlkp_frame_stride;
-    // keypoint g of the frame: its level (the last l with pre[l] <= g), key and side of the lapping split
-    auto fetch = [&](int g, int *level, uint32_t *key, bool *lap) {
-        int l = 0;
-        for (int k = 1; k < nlevels; k++) l = g >= pre[k] ? k : l;
-        *level = l;
-        *key = src[l_off[l] + (uint32_t)(g - pre[l])];
-        float x = (float)key_x(*key);
-        if (l != 0) x = x * l_scale[l];  // keypoint->pt *= scale (:1150)
-        *lap = (x >= flap0 && x <= flap1);
-    };
-    for (int c = 0; c < nchunks; c++) {
-        const int g = c * 256 + tid;
-        int l; uint32_t key; bool lap = false;
-        const bool valid = g < N;
-        if (valid) fetch(g, &l, &key, &lap);
-        const unsigned long long bl = __ballot(valid && lap), bm = __ballot(valid && !lap);
-        if (lane == 0) wsum[c * 4 + wv] = (__popcll(bl) << 16) | __popcll(bm);
-    }
-    __syncthreads();
-    if (wv == 0) {   // running totals over (chunk, wave) in sequence order: lapping and other counts travel together in one packed sum (N <= 65 280 < 65 536)
-        int carry = 0;
-        for (int e0 = 0; e0 < nchunks * 4; e0 += 64) {
-            const int e = e0 + lane;
-            const int v = e < nchunks * 4 ? wsum[e] : 0;
-            const int incl = wave_incl_scan(v);
-            if (e < nchunks * 4) wsum[e] = carry + incl - v;
-            carry += __builtin_amdgcn_readlane(incl, 63);
+    for (int l = 0; l < nlevels; l++) {
+        const LevelInfo L = lv[l];
+        const int nl = lvlcnt[f * nlevels + l];
+        const uint32_t *src = lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off;
+        for (int i0 = 0; i0 < nl; i0 += 256) {
+            const int i = i0 + tid;
+            uint32_t key = 0;
+            bool valid = i < nl, lap = false;
+            if (valid) {
+                key = src[i];
+                float x = (float)key_x(key);
+                if (l != 0) x = x * L.scale;  // keypoint->pt *= scale (:1150)
+                lap = (x >= flap0 && x <= flap1);
+            }
+            const unsigned long long bl = __ballot(valid && lap), bm = __ballot(valid && !lap);
+            if (lane == 0) wsum[wv] = (__popcll(bl) << 16) | __popcll(bm);
+            __syncthreads();
+            int offl = 0, offm = 0, totl = 0, totm = 0;
+            for (int k = 0; k < 4; k++) {
+                const int v = wsum[k];
+                if (k < wv) { offl += v >> 16; offm += v & 0xffff; }
+                totl += v >> 16; totm += v & 0xffff;
+            }
+            if (valid) {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                int pos;
+                if (lap) pos = stereoIdx - (offl + __popcll(bl & lt));
+                else pos = monoIdx + offm + __popcll(bm & lt);
+                WorkItem w;
+                w.key = key; w.level = l; w.pos = pos;
+                w.pitches = (uint32_t)L.pitch | ((uint32_t)L.bpitch << 16); w.off = (uint32_t)L.off; w.boff = (uint32_t)L.boff;
+                w.scale = L.scale; w.size = L.size;
+                work[(size_t)f * cap + g0 + i] = w;
+            }
+            monoIdx += totm;
+            stereoIdx -= totl;
+            __syncthreads();
         }
-        if (lane == 0) wtot = carry;
+        g0 += nl;
     }
-    __syncthreads();
-    for (int c = 0; c < nchunks; c++) {
-        const int g = c * 256 + tid;
-        int l = 0; uint32_t key = 0; bool lap = false;
-        const bool valid = g < N;
-        if (valid) fetch(g, &l, &key, &lap);
-        const unsigned long long bl = __ballot(valid && lap), bm = __ballot(valid && !lap);
-        if (valid) {
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const int before = wsum[c * 4 + wv];
-            WorkItem w;
-            w.key = key; w.level = l;
-            w.pos = lap ? (N - 1) - ((before >> 16) + __popcll(bl & lt)) : (before & 0xffff) + __popcll(bm & lt);
-            w.pitches = l_pitches[l]; w.off = l_poff[l]; w.boff = l_boff[l];
-            w.scale = l_scale[l]; w.size = l_size[l];
-            work[(size_t)f * cap + g] = w;
-        }
-    }
-    if (tid == 0) { count[f] = N; mono[f] = wtot & 0xffff; }   // monoIndex = the keypoints outside the lapping area
+    if (tid == 0) { count[f] = N; mono[f] = monoIdx; }
 }
 
 // ---------------------------------------------------------------------------------------------------------

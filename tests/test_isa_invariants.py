@@ -102,7 +102,7 @@ BUDGETS = {
     "k_pyr_base": (32, 8, 0, 0),
     "k_window_best2_tILi8": (64, 8, 0, 0),
     "k_greedy_resolve": (96, 5, 128, 0),
-    "k_finalize": (48, 8, 4608, 0),      # two-pass form: per-level constants and the per-(chunk, wave) counts of up to 255 chunks in LDS (4.5 KB)
+    "k_finalize": (32, 8, 64, 0),
 }
 
 
