@@ -57,7 +57,16 @@ enum {
     ORBX_FLAG_DESC_STRICT = 1u,
     /* 7x7 Gaussian taps of OpenCV <= 4.5.0 ([18,34,49,55,49,34,18]/256) instead of >= 4.5.1
      * ([18,34,48,56,48,34,18]/256). */
-    ORBX_FLAG_BLUR_OCV440 = 2u
+    ORBX_FLAG_BLUR_OCV440 = 2u,
+    /* cv::fastAtan2 (ORBextractor.cc:102) with its polynomial contracted to fused multiply-adds:
+     * fma(fma(fma(p7,c2,p5),c2,p3),c2,p1) * c, and 90 - q*c as ONE fnmadd.  That is what the scalar atan_f32 of
+     * OpenCV's core/src/mathfuncs.cpp compiles to where FMA is part of the library's BASELINE instruction set and the
+     * compiler contracts by default (GCC: -ffp-contract=fast): aarch64 builds (NEON FMA is baseline: Jetson, Apple),
+     * and x86 builds configured with CPU_BASELINE >= FMA3 / AVX2 or -march=native.  Default (flag clear): every
+     * operation rounded separately -- the stock x86-64 packages (baseline SSE3; FMA only in the dispatched array
+     * kernels, which the scalar cv::fastAtan2 does not go through).  The two differ by 1 ulp on a few percent of the
+     * angles (up to 3e-5 degrees near 360). */
+    ORBX_FLAG_ATAN_FMA = 4u
 };
 
 /* ORBextractor constructor arguments (ORBextractor.h:50-51; values from Settings.cc:443-451) */

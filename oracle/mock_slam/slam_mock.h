@@ -33,6 +33,13 @@ class GeometricCamera {
 public:
     virtual ~GeometricCamera() {}
     virtual Eigen::Vector2f project(const Eigen::Vector3f &p) { return Eigen::Vector2f(p(0), p(1)); }
+    /* include/CameraModels/GeometricCamera.h:77,93-96,105.  The table-driven stand-in below is "some camera model whose epipolarConstrain is
+     * opaque host code" (as KannalaBrandt8's is to the adapter): it reports CAM_FISHEYE; class Pinhole further down reports CAM_PINHOLE */
+    const static unsigned int CAM_PINHOLE = 0;
+    const static unsigned int CAM_FISHEYE = 1;
+    unsigned int mnType = CAM_FISHEYE;
+    unsigned int GetType() { return mnType; }
+    virtual Eigen::Matrix3f toK_() { return Eigen::Matrix3f(); }
     /* the verdicts of the epipolar test are test data: ok[idx1 * n2 + idx2], keyed by keypoint identity (class_id) */
     const uint8_t *epi_ok = nullptr;
     int epi_n2 = 0;
@@ -50,6 +57,25 @@ public:
         }
         return epi_ok ? epi_ok[(size_t)kp1.class_id * epi_n2 + kp2.class_id] != 0 : true;
     }
+};
+
+/* shell for CameraModels/Pinhole: project(Vector3f) and epipolarConstrain are the reference's own text in libmatcher_ref.so (excerpted by
+ * oracle/Makefile into a temporary include of ref_matcher_shim.cc); toK_ is Pinhole.cpp:100-104 restated.  In libmatcher_adapter.so
+ * epipolarConstrain aborts: the adapter must take pinhole key frames through the on-device gates and never call it. */
+class Pinhole : public GeometricCamera {
+public:
+    std::vector<float> mvParameters;
+    Pinhole(float fx, float fy, float cx, float cy) : mvParameters{fx, fy, cx, cy} { mnType = CAM_PINHOLE; }
+    Eigen::Vector2f project(const Eigen::Vector3f &v3D) override;
+    Eigen::Matrix3f toK_() override {
+        Eigen::Matrix3f K;
+        K(0, 0) = mvParameters[0]; K(0, 1) = 0.f; K(0, 2) = mvParameters[2];
+        K(1, 0) = 0.f; K(1, 1) = mvParameters[1]; K(1, 2) = mvParameters[3];
+        K(2, 0) = 0.f; K(2, 1) = 0.f; K(2, 2) = 1.f;
+        return K;
+    }
+    bool epipolarConstrain(GeometricCamera *pCamera2, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const Eigen::Matrix3f &R12,
+                           const Eigen::Vector3f &t12, const float sigmaLevel, const float unc) override;
 };
 
 class MapPoint {

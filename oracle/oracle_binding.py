@@ -22,6 +22,7 @@ assert KP_DTYPE.itemsize == 28
 FLAG_DESC_FMA = 1
 FLAG_BLUR_OCV440 = 2
 FLAG_LIBM_SINCOS = 4
+FLAG_ATAN_FMA = 8
 
 
 def build(force: bool = False) -> Path:
@@ -74,6 +75,8 @@ def lib() -> C.CDLL:
         L.orbo_gauss7_u8.argtypes = [vp, i32, i32, sz, vp, sz, i32]
         L.orbo_fast_atan2.restype = f32
         L.orbo_fast_atan2.argtypes = [f32, f32]
+        L.orbo_fast_atan2_fma.restype = f32
+        L.orbo_fast_atan2_fma.argtypes = [f32, f32]
         L.orbo_ic_angle.restype = f32
         L.orbo_ic_angle.argtypes = [vp, sz]
         L.orbo_sinf.restype = f32
@@ -236,8 +239,8 @@ def gauss7(img: np.ndarray, ocv440: bool = False) -> np.ndarray:
     return dst
 
 
-def fast_atan2(y: float, x: float) -> float:
-    return lib().orbo_fast_atan2(y, x)
+def fast_atan2(y: float, x: float, fma: bool = False) -> float:
+    return lib().orbo_fast_atan2_fma(y, x) if fma else lib().orbo_fast_atan2(y, x)
 
 
 def ic_angle(img: np.ndarray, x: int, y: int) -> float:

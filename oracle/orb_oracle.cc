@@ -264,10 +264,20 @@ const float kAtanP3 = -0.3258083974640975f * (float)(180 / M_PI);
 const float kAtanP5 = 0.1555786518463281f * (float)(180 / M_PI);
 const float kAtanP7 = -0.04432655554792128f * (float)(180 / M_PI);
 
-float fast_atan2(float y, float x) {
+float fast_atan2(float y, float x, bool fma_poly = false) {
     float ax = std::fabs(x), ay = std::fabs(y);
     float a, c, c2;
-    if (ax >= ay) {
+    if (fma_poly) {
+        /* ORBO_FLAG_ATAN_FMA: the same expression as a compiler that contracts a*b + c emits it (GCC -ffp-contract=fast with FMA in
+         * the baseline ISA: aarch64, or x86 with CPU_BASELINE >= FMA3): three fused Horner steps, and `90 - q*c` as one fnmadd.
+         * Written with explicit fmaf so that it does not depend on how THIS file is compiled; tests/test_oracle_known_answers.py
+         * checks it against the source expression compiled with -mfma -ffp-contract=fast. */
+        const bool xbig = ax >= ay;
+        c = xbig ? ay / (ax + (float)DBL_EPSILON) : ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        const float q = std::fmaf(std::fmaf(std::fmaf(kAtanP7, c2, kAtanP5), c2, kAtanP3), c2, kAtanP1);
+        a = xbig ? q * c : std::fmaf(-q, c, 90.f);
+    } else if (ax >= ay) {
         c = ay / (ax + (float)DBL_EPSILON);
         c2 = c * c;
         a = (((kAtanP7 * c2 + kAtanP5) * c2 + kAtanP3) * c2 + kAtanP1) * c;
@@ -367,7 +377,7 @@ struct Tables {
     int umax[16];
 };
 
-float ic_angle(const uint8_t *center, size_t stride, const int umax[16]) {
+float ic_angle(const uint8_t *center, size_t stride, const int umax[16], bool atan_fma = false) {
     int m_01 = 0, m_10 = 0;
     for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m_10 += u * center[u];
     const ptrdiff_t step = (ptrdiff_t)stride;
@@ -381,7 +391,7 @@ float ic_angle(const uint8_t *center, size_t stride, const int umax[16]) {
         }
         m_01 += v * v_sum;
     }
-    return fast_atan2((float)m_01, (float)m_10);
+    return fast_atan2((float)m_01, (float)m_10, atan_fma);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -701,7 +711,7 @@ int orbo_extract(orbo_extractor *ex, const uint8_t *img, int w, int h, size_t st
     for (int level = 0; level < t.nlevels; ++level) { /* :894-895 orientation on the UNBLURRED level */
         orbo_extractor::Level &L = ex->levels[level];
         for (orbo_keypoint &kp : L.keypoints)
-            kp.angle = ic_angle(L.roi() + (size_t)cv_round(kp.y) * L.stride + cv_round(kp.x), L.stride, t.umax);
+            kp.angle = ic_angle(L.roi() + (size_t)cv_round(kp.y) * L.stride + cv_round(kp.x), L.stride, t.umax, (t.flags & ORBO_FLAG_ATAN_FMA) != 0);
     }
 
     /* ---- operator() :1104-1167 ---- */
@@ -781,6 +791,10 @@ void orbo_gauss7_u8(const uint8_t *src, int w, int h, size_t sstride, uint8_t *d
     gauss7_u8(src, w, h, sstride, dst, dstride, ocv440 != 0);
 }
 float orbo_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+float orbo_fast_atan2_fma(float y, float x) { return fast_atan2(y, x, true); }
+void orbo_fast_atan2_n(const float *y, const float *x, float *out, int n, int fma_poly) {
+    for (int i = 0; i < n; i++) out[i] = fast_atan2(y[i], x[i], fma_poly != 0);
+}
 float orbo_ic_angle(const uint8_t *center, size_t stride) {
     static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     return ic_angle(center, stride, umax);

@@ -63,7 +63,9 @@ enum {
                                  for ORBextractor.cc:117-119 on an FMA CPU (the reference's own build flags) */
     ORBO_FLAG_BLUR_OCV440 = 2,/* Gaussian taps of OpenCV <= 4.5.0 ([18,34,49,55,49,34,18]) instead of the
                                  >= 4.5.1 error-diffused taps ([18,34,48,56,48,34,18]) */
-    ORBO_FLAG_LIBM_SINCOS = 4 /* call the host libm sinf/cosf instead of the restated glibc routines */
+    ORBO_FLAG_LIBM_SINCOS = 4,/* call the host libm sinf/cosf instead of the restated glibc routines */
+    ORBO_FLAG_ATAN_FMA = 8    /* cv::fastAtan2's polynomial contracted to FMAs (an OpenCV whose BASELINE has FMA: aarch64, or x86
+                                 CPU_BASELINE >= FMA3); default: every operation rounded separately (stock x86-64 packages) */
 };
 
 typedef struct orbo_extractor orbo_extractor;
@@ -103,6 +105,8 @@ int orbo_fast9_16(const uint8_t *img, int cols, int rows, size_t stride, int thr
 int orbo_fast_score(const uint8_t *center, size_t stride);
 void orbo_gauss7_u8(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride, int ocv440);
 float orbo_fast_atan2(float y, float x);
+float orbo_fast_atan2_fma(float y, float x); /* the ORBO_FLAG_ATAN_FMA form */
+void orbo_fast_atan2_n(const float *y, const float *x, float *out, int n, int fma_poly);
 float orbo_ic_angle(const uint8_t *center, size_t stride);
 float orbo_sinf(float x);
 float orbo_cosf(float x);

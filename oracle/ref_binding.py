@@ -543,6 +543,30 @@ def ref_search_for_triangulation_geo(k1, d1, s1, ur1, fv1, k2, d2, s2, ur2, fv2,
     return n, m12
 
 
+def ref_search_for_triangulation_pinhole_cams(k1, d1, s1, ur1, fv1, k2, d2, s2, ur2, fv2, scale2, sigma2_2, K1, K2, pose1, pose2, check_orientation,
+                                              only_stereo=False, coarse=False):
+    """M7 between key frames with real Pinhole cameras (K = fx, fy, cx, cy) and real poses (Tcw = (R 3x3, t 3)): every gate is the
+    reference's own text (ORBX_MATCHER_BACKEND=adapter: the adapter's CAM_PINHOLE route, gates on the device).  Returns
+    (nmatches, matches12, F12 3x3 -- the last 3x3 product of the run: the F12 the gates used)."""
+    k1, k2 = np.ascontiguousarray(k1, KP_DTYPE), np.ascontiguousarray(k2, KP_DTYPE)
+    d1, d2, s1, s2 = _u8(d1), _u8(d2), _u8(s1), _u8(s2)
+    ur1 = None if ur1 is None else _f32(ur1)
+    ur2 = None if ur2 is None else _f32(ur2)
+    sc, sg = _f32(scale2), _f32(sigma2_2)
+    a, b = _fv(fv1), _fv(fv2)
+    K1, K2 = _f32(K1), _f32(K2)
+    p1 = _f32(np.concatenate([np.asarray(pose1[0], np.float32).ravel(), np.asarray(pose1[1], np.float32).ravel()]))
+    p2 = _f32(np.concatenate([np.asarray(pose2[0], np.float32).ravel(), np.asarray(pose2[1], np.float32).ravel()]))
+    m12 = np.full(len(k1), -1, np.int32)
+    F = np.zeros(9, np.float32)
+    L = _ml()
+    L.matref_search_for_triangulation_pinhole_cams.restype = C.c_int
+    n = L.matref_search_for_triangulation_pinhole_cams(_p(k1), _p(d1), _p(s1), _p(ur1), len(k1), C.byref(a), _p(k2), _p(d2), _p(s2), _p(ur2), len(k2),
+                                                       C.byref(b), _p(sc), _p(sg), len(sc), _p(K1), _p(K2), _p(p1), _p(p2), int(check_orientation),
+                                                       int(only_stereo), int(coarse), _p(m12), _p(F))
+    return n, m12, F.reshape(3, 3)
+
+
 def ref_search_by_projection_mappoints_fisheye(kps_left, kps_right, desc, bounds, scale_factors, l2r, r2l, mp, th, nnratio, occupied=None):
     kl, kr = np.ascontiguousarray(kps_left, KP_DTYPE), np.ascontiguousarray(kps_right, KP_DTYPE)
     desc, b, sf = _u8(desc), _f32(bounds), _f32(scale_factors)

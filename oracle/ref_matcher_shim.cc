@@ -4,12 +4,27 @@
  * runs the reference's member function and flattens its result back, so tests/test_oracle_vs_reference.py can compare the
  * two on identical inputs.  Geometry is driven exactly: poses are identity (plus a z translation where the function reads
  * the camera motion), the camera's project() is (x, y), so a map point at world (u, v, z) lands on pixel (u, v). */
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
 #include "ORBmatcher.h"
 
 using namespace ORB_SLAM3;
+
+/* class Pinhole of mock_slam/slam_mock.h: member bodies from the reference's CameraModels/Pinhole.cpp, handed over by oracle/Makefile through a
+ * temporary include (ref_excerpt.awk; no reference text in the repo).  The adapter build gets project() only. */
+namespace ORB_SLAM3 {
+#include "ref_matcher_excerpt.inc"
+#ifdef MATREF_ADAPTER_BUILD
+bool Pinhole::epipolarConstrain(GeometricCamera *, const cv::KeyPoint &, const cv::KeyPoint &, const Eigen::Matrix3f &, const Eigen::Vector3f &, const float,
+                                const float) {
+    fprintf(stderr, "libmatcher_adapter: Pinhole::epipolarConstrain called on the host -- the adapter must route pinhole key frames to the device gates\n");
+    abort();
+}
+#endif
+}  // namespace ORB_SLAM3
 
 namespace {
 
@@ -567,6 +582,57 @@ int matref_search_for_triangulation_geo(const orbo_keypoint *kps1, const uint8_t
     int r = m.SearchForTriangulation(&K1, &K2, pairs, false, coarse != 0);
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     for (auto &p : pairs) matches12[p.first] = (int)p.second;
+    return r;
+}
+
+/* M7 between two key frames with REAL pinhole cameras and real poses (LocalMapping::CreateNewMapPoints' shape, LocalMapping.cc:466): K1 / K2 =
+ * fx, fy, cx, cy; pose1 / pose2 = Tcw as 9 floats of R (row-major) + 3 of t.  In libmatcher_ref.so every gate is the reference's own text:
+ * the epipole via Pinhole::project, the epipole-distance test of ORBmatcher.cc:1026-1034, and Pinhole::epipolarConstrain (which derives
+ * F12 from K1, K2, R12, t12 for every pair).  In libmatcher_adapter.so the same call must take the adapter's CAM_PINHOLE route (F12 built
+ * once by the adapter with the same expression, both gates inside k_replay_bow).  F12_out (optional, 9 floats): the last 3x3 product the
+ * run computed -- in the reference build the F12 of the last pair evaluated, in the adapter build the F12 the adapter built. */
+int matref_search_for_triangulation_pinhole_cams(const orbo_keypoint *kps1, const uint8_t *desc1, const uint8_t *skip1, const float *u_right1, int n1,
+                                                 const orbo_featvec *fv1, const orbo_keypoint *kps2, const uint8_t *desc2, const uint8_t *skip2,
+                                                 const float *u_right2, int n2, const orbo_featvec *fv2, const float *scale2, const float *sigma2_2,
+                                                 int nlevels, const float *K1, const float *K2, const float *pose1, const float *pose2,
+                                                 int check_orientation, int only_stereo, int coarse, int32_t *matches12, float *F12_out) {
+    Pinhole cam1(K1[0], K1[1], K1[2], K1[3]), cam2(K2[0], K2[1], K2[2], K2[3]);
+    KeyFrame KF1, KF2;
+    KeyFrame *K[2] = {&KF1, &KF2};
+    const orbo_keypoint *P[2] = {kps1, kps2};
+    const uint8_t *D[2] = {desc1, desc2};
+    const uint8_t *S[2] = {skip1, skip2};
+    const float *U[2] = {u_right1, u_right2};
+    const float *T[2] = {pose1, pose2};
+    const int N[2] = {n1, n2};
+    GeometricCamera *cams[2] = {&cam1, &cam2};
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    for (int s = 0; s < 2; s++) {
+        KeyFrame &k = *K[s];
+        k.N = N[s];
+        k.mvKeysUn.resize(N[s]);
+        k.mDescriptors = cv::Mat(N[s] > 0 ? N[s] : 1, 32, CV_8UC1);
+        std::memcpy(k.mDescriptors.data, D[s], (size_t)N[s] * 32);
+        k.mvpMapPoints.assign(N[s], nullptr);
+        k.mvuRight.assign(N[s], -1.f);
+        if (U[s]) k.mvuRight.assign(U[s], U[s] + N[s]);
+        k.mvScaleFactors.assign(scale2, scale2 + nlevels);
+        k.mvLevelSigma2.assign(sigma2_2, sigma2_2 + nlevels);
+        k.mpCamera = cams[s];
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) k.Tcw.R(i, j) = T[s][3 * i + j]; k.Tcw.t(i) = T[s][9 + i]; }
+        for (int i = 0; i < N[s]; i++) {
+            k.mvKeysUn[i] = cv::KeyPoint(P[s][i].x, P[s][i].y, P[s][i].size, P[s][i].angle, P[s][i].response, P[s][i].octave, i);
+            if (S[s][i]) k.mvpMapPoints[i] = marker(pool);
+        }
+    }
+    featvec(KF1.mFeatVec, fv1);
+    featvec(KF2.mFeatVec, fv2);
+    std::vector<std::pair<size_t, size_t>> pairs;
+    ORBmatcher m(0.6f, check_orientation != 0);
+    int r = m.SearchForTriangulation(&KF1, &KF2, pairs, only_stereo != 0, coarse != 0);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (auto &p : pairs) matches12[p.first] = (int)p.second;
+    if (F12_out) for (int i = 0; i < 9; i++) F12_out[i] = Eigen::last_product()(i / 3, i % 3);
     return r;
 }
 

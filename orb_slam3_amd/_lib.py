@@ -1,8 +1,9 @@
 """ctypes loader for liborbx.so (the C ABI declared in include/orbx.h).
 
 torch is imported first on purpose: PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's);
-loading liborbx after torch makes both share ONE HIP runtime in the process, which is what lets bench.py use
-torch.distributed (RCCL) for the cross-rank barrier next to our own HIP streams.  There is no CPU fallback:
+loading liborbx after torch makes both share ONE HIP runtime in the process (the tests and bench.py hold device
+buffers as torch tensors next to our own HIP streams; the cross-rank barrier of bench.py is a gloo host group,
+no RCCL communicator -- orb_slam3_amd/sharding.py).  There is no CPU fallback:
 a missing or unloadable library raises.
 """
 from __future__ import annotations
@@ -23,6 +24,7 @@ ORBX_OK = 0
 ORBX_E_EMPTY = -1
 FLAG_DESC_STRICT = 1
 FLAG_BLUR_OCV440 = 2
+FLAG_ATAN_FMA = 4
 TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
 
 

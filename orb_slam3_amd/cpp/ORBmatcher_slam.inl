@@ -22,12 +22,6 @@ private:
         return v;
     }
     static void push_desc(std::vector<uint8_t> &dst, const cv::Mat &d) { dst.insert(dst.end(), d.data, d.data + 32); }
-    static void require_mono(const Frame &f, const char *what) {
-        if (f.Nleft != -1) throw std::runtime_error(std::string(what) + ": fisheye-stereo (Nleft != -1) form is not wired into this adapter");
-    }
-    static void require_mono(const KeyFrame &kf, const char *what) {
-        if (kf.NLeft != -1) throw std::runtime_error(std::string(what) + ": fisheye-stereo (NLeft != -1) form is not wired into this adapter");
-    }
 
 public:
     // ORBmatcher.cc:43-213 (Tracking::SearchLocalPoints, Tracking.cc:3390-3413)
@@ -347,9 +341,13 @@ public:
         return nmatches;
     }
 
-    // ORBmatcher.cc:907-1146 (LocalMapping::CreateNewMapPoints).  The epipole-distance test and the camera model's epipolarConstrain
-    // are evaluated by the callback exactly where the reference evaluates them (any GeometricCamera; pinhole key frames may use the
-    // on-device gates through the orbx_pinhole_gate overload instead).
+    // ORBmatcher.cc:907-1146 (LocalMapping::CreateNewMapPoints, LocalMapping.cc:466: 10-30 calls per key frame).
+    // PINHOLE key frames (both cameras CAM_PINHOLE -- every monocular / stereo / RGB-D configuration of the reference): both geometric gates run
+    // on the device (orbx_search_for_triangulation_pinhole: one upload, one launch chain, one download of the matches; no candidate distance
+    // comes back to the host).  F12 is built HERE, once, with the very Eigen expression Pinhole::epipolarConstrain evaluates for every pair
+    // (CameraModels/Pinhole.cpp:109-112) -- same types, same operand order, hence the same floats as inside the reference.
+    // Any other GeometricCamera (KannalaBrandt8::epipolarConstrain triangulates): the epipole-distance test and the camera model's
+    // epipolarConstrain are evaluated by a callback exactly where the reference evaluates them.
     int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo,
                                const bool bCoarse = false) {
         if (pKF1->mpCamera2 || pKF2->mpCamera2) return SearchForTriangulationFisheye(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse);
@@ -375,6 +373,27 @@ public:
             const bool bStereo2 = pKF2->mvuRight[i] >= 0;
             skip2[i] = (pKF2->GetMapPoint(i) || (bOnlyStereo && !bStereo2)) ? 1 : 0;   // :1002-1012
             a2[i] = pKF2->mvKeysUn[i].angle;
+        }
+        if (pCamera1->GetType() == GeometricCamera::CAM_PINHOLE && pCamera2->GetType() == GeometricCamera::CAM_PINHOLE) {
+            static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint must be the 28-byte OpenCV layout");
+            Eigen::Matrix3f t12x = Sophus::SO3f::hat(t12);                                   // Pinhole.cpp:109
+            Eigen::Matrix3f K1 = pCamera1->toK_();                                           // :110
+            Eigen::Matrix3f K2 = pCamera2->toK_();                                           // :111
+            Eigen::Matrix3f F12 = K1.transpose().inverse() * t12x * R12 * K2.inverse();      // :112
+            orbx_pinhole_gate g;
+            std::memset(&g, 0, sizeof(g));
+            g.kps1_un = reinterpret_cast<const orbx_keypoint *>(pKF1->mvKeysUn.data());
+            g.kps2_un = reinterpret_cast<const orbx_keypoint *>(pKF2->mvKeysUn.data());
+            g.u_right1 = pKF1->mvuRight.data(); g.u_right2 = pKF2->mvuRight.data();          // bStereo1 / bStereo2 of :1024-1025
+            g.scale_factors2 = pKF2->mvScaleFactors.data();                                  // :1030
+            g.level_sigma2_2 = pKF2->mvLevelSigma2.data();                                   // `unc` of :1072
+            g.nlevels = (int)std::min(pKF2->mvScaleFactors.size(), pKF2->mvLevelSigma2.size());
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) g.F12[3 * r + c] = F12(r, c);
+            g.ep_x = ep(0); g.ep_y = ep(1);
+            g.coarse = bCoarse ? 1 : 0;
+            g.strict_fp = 0;
+            return SearchForTriangulation(pKF1->mDescriptors.data, skip1.data(), n1, FeatVec::from(pKF1->mFeatVec), pKF2->mDescriptors.data, skip2.data(), n2,
+                                          FeatVec::from(pKF2->mFeatVec), g, vMatchedPairs);
         }
         auto gate = [&](size_t idx1, size_t idx2) -> bool {
             const cv::KeyPoint &kp1 = pKF1->mvKeysUn[idx1];

@@ -1161,7 +1161,7 @@ __device__ __forceinline__ void glibc_sincosf(float y, float *sn, float *cs) {
     *sn = tiny ? y : (swap ? fc : fs);
     *cs = tiny ? 1.0f : (swap ? fs : fc);
 }
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+__device__ __forceinline__ float fast_atan2_deg(float y, float x, const bool fma_poly) {
     const float scale = (float)(180.0 / 3.14159265358979323846);
     const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
                 p7 = -0.04432655554792128f * scale;
@@ -1170,8 +1170,14 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const bool xbig = ax >= ay;
     const float c = __fdiv_rn(xbig ? ay : ax, __fadd_rn(xbig ? ax : ay, eps));
     const float c2 = __fmul_rn(c, c);
-    float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    a = xbig ? a : __fsub_rn(90.f, a);
+    float a;
+    if (fma_poly) {   // ORBX_FLAG_ATAN_FMA: the polynomial as a compiler that contracts a * b + c emits it (three fused steps; 90 - q * c is one fnmadd)
+        const float q = __fmaf_rn(__fmaf_rn(__fmaf_rn(p7, c2, p5), c2, p3), c2, p1);
+        a = xbig ? __fmul_rn(q, c) : __fmaf_rn(-q, c, 90.f);
+    } else {
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+        a = xbig ? a : __fsub_rn(90.f, a);
+    }
     a = x < 0 ? __fsub_rn(180.f, a) : a;
     a = y < 0 ? __fsub_rn(360.f, a) : a;
     return a;
@@ -1183,6 +1189,10 @@ __device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
     return (const uint8_t *)(((uint64_t)hi << 32) | lo);
 }
+
+// fp_mode bits of the descriptor kernels (their `fp_mode` argument): which of the float forms the reference BINARY executes
+constexpr int kFpDescStrict = 1;   // ORBX_FLAG_DESC_STRICT: x*b + y*a with separately rounded products (-ffp-contract=off build of ORBextractor.cc)
+constexpr int kFpAtanFma = 2;      // ORBX_FLAG_ATAN_FMA: cv::fastAtan2's polynomial contracted to FMAs (an OpenCV whose baseline has FMA3 / NEON)
 
 struct DescConst {
     int8_t vmax_of_u[16];              // orientation disc: largest |v| with umax[|v|] >= |u|
@@ -1265,8 +1275,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   describe_rotation  the keypoint's angle (:76-103 fastAtan2) and the rotation (cos, sin) of the steered pattern (:112-113)
 //   describe_record    the keypoint record of slot w.pos
 //   describe_brief     the 256 comparisons on the blurred patch (bc = its centre, pitch BP); lanes 0..7 of a half end up with descriptor dword hl
-__device__ __forceinline__ void describe_rotation(const int M10, const int M01, float *angle, float *a, float *b) {
-    *angle = fast_atan2_deg((float)M01, (float)M10);
+__device__ __forceinline__ void describe_rotation(const int M10, const int M01, const int fp_mode, float *angle, float *a, float *b) {
+    *angle = fast_atan2_deg((float)M01, (float)M10, (fp_mode & kFpAtanFma) != 0);
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     glibc_sincosf(__fmul_rn(*angle, factorPI), b, a);  // a = cos, b = sin
 }
@@ -1287,7 +1297,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // patf[it] = (x0, y0, x1, y1) of pattern pair it * 32 + hl.  Returns the eight ballots' halves: out[it] = dword `it` of the descriptor of this half's keypoint
 template <int BP>
 __device__ __forceinline__ void describe_brief(const float a, const float b, const uint8_t *bc, const int hw, const f32x4 (&patf)[8],
-                                               const int strict_mul_add, uint32_t (&out)[8]) {
+                                               const int fp_mode, uint32_t (&out)[8]) {
     constexpr float kMagic = 12582912.f;           // cvRound by magic add, see k_describe
     constexpr uint32_t kMagicBits = 0x4B400000u;
     const uint32_t cbm = (uint32_t)(uintptr_t)bc - (0x400000u * (uint32_t)BP + kMagicBits);
@@ -1298,7 +1308,7 @@ __device__ __forceinline__ void describe_brief(const float a, const float b, con
     for (int it = 0; it < 8; it++) {
         const f32x2 X = {patf[it].x, patf[it].z}, Y = {patf[it].y, patf[it].w};
         f32x2 R, Q;
-        if (strict_mul_add) {
+        if (fp_mode & kFpDescStrict) {
             R = X * bb + Y * aa;      // -ffp-contract=off: products and sums round separately
             Q = X * aa - Y * bb;
         } else {  // GCC -O3 -march=native: fma(x, b, y*a), fma(x, a, -(y*b))
@@ -1317,11 +1327,11 @@ __device__ __forceinline__ void describe_brief(const float a, const float b, con
 
 template <int BP>
 __device__ __forceinline__ void describe_tail(const int M10, const int M01, const uint8_t *bc, const int hw, const int hl,
-                                              const uint32_t (&pat8)[8], const int strict_mul_add, const bool live, const WorkItem &w, const int kx,
+                                              const uint32_t (&pat8)[8], const int fp_mode, const bool live, const WorkItem &w, const int kx,
                                               const int ky, const int f, const int cap, orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
                                               const HostMirror &hm) {
     float angle, a, b;
-    describe_rotation(M10, M01, &angle, &a, &b);
+    describe_rotation(M10, M01, fp_mode, &angle, &a, &b);
     f32x4 patf[8];
 #pragma unroll
     for (int it = 0; it < 8; it++) {
@@ -1329,7 +1339,7 @@ __device__ __forceinline__ void describe_tail(const int M10, const int M01, cons
         patf[it] = f32x4{(float)pt.x, (float)pt.y, (float)pt.z, (float)pt.w};
     }
     uint32_t d8[8];
-    describe_brief<BP>(a, b, bc, hw, patf, strict_mul_add, d8);
+    describe_brief<BP>(a, b, bc, hw, patf, fp_mode, d8);
     uint32_t mine = 0;   // lanes 0..7 of a half: descriptor dword hl
 #pragma unroll
     for (int it = 0; it < 8; it++) mine = hl == it ? d8[it] : mine;
@@ -1354,7 +1364,7 @@ __device__ __forceinline__ void describe_tail(const int M10, const int M01, cons
 __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
                                                    const int32_t *__restrict__ count, int cap, const uint8_t *__restrict__ pyr,
                                                    size_t pyr_frame_stride, const uint8_t *__restrict__ blur, size_t blur_frame_stride,
-                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc, int strict_mul_add, int n_frames,
+                                                   orbx_keypoint *__restrict__ kps, uint8_t *__restrict__ desc, int fp_mode, int n_frames,
                                                    const HostMirror hm) {
     __shared__ __attribute__((aligned(16))) uint8_t patches[4 * 2 * kDescWaveLds];
     int bx, f;
@@ -1412,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_describe(const DescConst *__restrict__ 
 
     int M10, M01;
     ic_moments_columns<kDescAP>(A + kHalfPatch * kDescAP + kHalfPatch + axA + du, dvmax, du, hw, &M10, &M01);
-    describe_tail<kDescBP>(M10, M01, Bp + 18 * kDescBP + 18 + axB, hw, hl, pat8, strict_mul_add, live, w, kx, ky, f, cap, kps, desc, hm);
+    describe_tail<kDescBP>(M10, M01, Bp + 18 * kDescBP + 18 + axB, hw, hl, pat8, fp_mode, live, w, kx, ky, f, cap, kps, desc, hm);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1443,7 +1453,7 @@ template <bool SAT>
 __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restrict__ dc, const WorkItem *__restrict__ work,
                                                          const int32_t *__restrict__ count, int cap, const uint8_t *__restrict__ pyr,
                                                          size_t pyr_frame_stride, int g0, int g1, int g2, int g3, orbx_keypoint *__restrict__ kps,
-                                                         uint8_t *__restrict__ desc, int strict_mul_add, int n_frames, const HostMirror hm,
+                                                         uint8_t *__restrict__ desc, int fp_mode, int n_frames, const HostMirror hm,
                                                          const Level0Src src0, int W0, int H0, uint8_t *__restrict__ dbg_patch, int dbg_frame) {
     __shared__ __attribute__((aligned(16))) uint8_t patches[4 * 2 * kDfWaveLds];
     int bx, f;
@@ -1614,7 +1624,7 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
     if (wv == 0) {
         const int k = lane & 7;
         float angle, ca, sb;
-        describe_rotation((int)kp_in[k][0], (int)kp_in[k][1], &angle, &ca, &sb);
+        describe_rotation((int)kp_in[k][0], (int)kp_in[k][1], fp_mode, &angle, &ca, &sb);
         if (lane < 8) {
             rot[k][0] = ca; rot[k][1] = sb;
             if (bx * 8 + k < cnt)
@@ -1623,7 +1633,7 @@ __global__ __launch_bounds__(256) void k_describe_fused(const DescConst *__restr
     }
     __syncthreads();
     uint32_t d8[8];
-    describe_brief<kDfP>(rot[kq][0], rot[kq][1], Bp + 18 * kDfP + 18 + axB, hw, patf, strict_mul_add, d8);
+    describe_brief<kDfP>(rot[kq][0], rot[kq][1], Bp + 18 * kDfP + 18 + axB, hw, patf, fp_mode, d8);
     if (live && hl == 0) {   // the half's 32 descriptor bytes from one lane
         uint4 *o = reinterpret_cast<uint4 *>(desc + ((size_t)f * cap + w.pos) * 32);
         o[0] = make_uint4(d8[0], d8[1], d8[2], d8[3]);

@@ -651,6 +651,9 @@ struct ProfScope {
     }
 };
 
+// the float forms the descriptor kernels evaluate (kFpDescStrict | kFpAtanFma) from orbx_params.flags
+static int fp_mode_of(uint32_t flags) { return ((flags & ORBX_FLAG_DESC_STRICT) ? kFpDescStrict : 0) | ((flags & ORBX_FLAG_ATAN_FMA) ? kFpAtanFma : 0); }
+
 // taps of GaussianBlur(7x7, sigma 2) in 8-bit fixed point: [OCV] >= 4.5.1 / <= 4.5.0 (ORBX_FLAG_BLUR_OCV440); the older ones sum to more than 1.0
 // and can exceed 255 (the saturating forms of the kernels)
 struct BlurTaps { int g[4]; bool sat; };
@@ -865,7 +868,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     {
         ProfScope ps(ex, K_DESCRIBE);
         const HostMirror hm = mirror && n == 1 ? *mirror : HostMirror{nullptr, nullptr, nullptr, nullptr, nullptr};
-        const int strict = (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0;
+        const int strict = fp_mode_of(ex->prm.flags);
         const dim3 grid = xcd_grid((ex->cap + 7) / 8, n);
         if (!ex->fused_blur)
             hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, (const DescConst *)ex->d_dc.p, (const WorkItem *)ex->d_work.p,
@@ -1452,7 +1455,7 @@ int orbx_debug_fused_patches(orbx_extractor *ex, int frame, uint8_t *dst, int ca
     // the descriptor kernel of the last batch once more, writing what it wrote before plus the blurred patches of `frame` (the frames the batch was
     // extracted from must still be valid when level 0 was read in place)
     const BlurTaps bt = blur_taps(ex);
-    const int n = ex->last_batch, strict = (ex->prm.flags & ORBX_FLAG_DESC_STRICT) ? 1 : 0;
+    const int n = ex->last_batch, strict = fp_mode_of(ex->prm.flags);
     const Level0Src src0 = ex->lvl0_inplace ? Level0Src{ex->in0_images, ex->in0_row_stride, ex->in0_frame_stride} : Level0Src{nullptr, 0, 0};
     const HostMirror hm = HostMirror{nullptr, nullptr, nullptr, nullptr, nullptr};
     const dim3 grid = xcd_grid((ex->cap + 7) / 8, n);

@@ -5,6 +5,7 @@
 #include "extractor_kernels.hip.h"
 #include <cmath>
 extern "C" float orbo_fast_atan2(float y, float x);
+extern "C" float orbo_fast_atan2_fma(float y, float x);   // the ORBX_FLAG_ATAN_FMA form
 static void libm_sincosf(float y, float *s, float *c) { *s = sinf(y); *c = cosf(y); }
 #include <random>
 int main() {
@@ -21,12 +22,16 @@ int main() {
     std::mt19937 rng(1);
     for (long i = 0; i < 10000000; i++) {
         const int m01 = (int)(rng() % 5800001) - 2900000, m10 = (int)(rng() % 5800001) - 2900000;
-        const float a = orbo_fast_atan2((float)m01, (float)m10), b = orbx::fast_atan2_deg((float)m01, (float)m10); n++;
+        const float a = orbo_fast_atan2((float)m01, (float)m10), b = orbx::fast_atan2_deg((float)m01, (float)m10, false); n++;
         if (memcmp(&a, &b, 4)) { if (bad < 15) printf("atan2 %d %d: %a vs %a\n", m01, m10, a, b); bad++; }
+        const float af = orbo_fast_atan2_fma((float)m01, (float)m10), bf = orbx::fast_atan2_deg((float)m01, (float)m10, true); n++;
+        if (memcmp(&af, &bf, 4)) { if (bad < 15) printf("atan2 (fma form) %d %d: %a vs %a\n", m01, m10, af, bf); bad++; }
     }
     for (int m01 = -40; m01 <= 40; m01++) for (int m10 = -40; m10 <= 40; m10++) {
-        const float a = orbo_fast_atan2((float)m01, (float)m10), b = orbx::fast_atan2_deg((float)m01, (float)m10); n++;
+        const float a = orbo_fast_atan2((float)m01, (float)m10), b = orbx::fast_atan2_deg((float)m01, (float)m10, false); n++;
         if (memcmp(&a, &b, 4)) { if (bad < 20) printf("atan2 %d %d: %a vs %a\n", m01, m10, a, b); bad++; }
+        const float af = orbo_fast_atan2_fma((float)m01, (float)m10), bf = orbx::fast_atan2_deg((float)m01, (float)m10, true); n++;
+        if (memcmp(&af, &bf, 4)) { if (bad < 20) printf("atan2 (fma form) %d %d: %a vs %a\n", m01, m10, af, bf); bad++; }
     }
     printf("checked %ld bad %ld\n", n, bad);
     return bad != 0;

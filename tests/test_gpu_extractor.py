@@ -19,6 +19,8 @@ def _pair(nfeatures=1000, flags=0, oflags=None):
             oflags |= ob.FLAG_DESC_FMA
         if flags & 2:
             oflags |= ob.FLAG_BLUR_OCV440
+        if flags & 4:
+            oflags |= ob.FLAG_ATAN_FMA
     return osa.ORBextractor(nfeatures, 1.2, 8, 20, 7, flags=flags), ob.OracleExtractor(nfeatures, 1.2, 8, 20, 7, flags=oflags)
 
 
@@ -146,6 +148,69 @@ def test_strict_and_ocv440_modes(canvas1):
     for flags in (1, 2, 3):
         ex, oex = _pair(1000, flags=flags)
         _check_frame(ex, oex, img, (0, 1000), stagewise=False)
+
+
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_atan_fma_flag(canvas1, monkeypatch, form):
+    """ORBX_FLAG_ATAN_FMA (VERDICT r5 'missing' 2): cv::fastAtan2's polynomial contracted to FMAs, as an OpenCV whose BASELINE has FMA
+    evaluates it.  Both descriptor kernels (blur on demand / blur pass), single frame and batch; angles and descriptors == the oracle's
+    ORBO_FLAG_ATAN_FMA form bit for bit, and the flag really changes some angles (else the test would be blind)."""
+    import torch
+    from orb_slam3_amd import synth
+    monkeypatch.setenv("ORBX_FUSED_BLUR", form)
+    img = synth.frame_from_canvas(canvas1, 9, 752, 480, 1009)
+    ex, oex = _pair(1000, flags=4)
+    _check_frame(ex, oex, img, (0, 1000), stagewise=False)
+    ex0, _ = _pair(1000, flags=0)
+    a0, a1 = ex0(img, None, (0, 1000))[1]["angle"], ex(img, None, (0, 1000))[1]["angle"]
+    assert 0 < np.count_nonzero(a0 != a1) < len(a0) // 2 and np.abs(a0 - a1).max() < 1e-4
+    ex, oex = _pair(1000, flags=5)   # + ORBX_FLAG_DESC_STRICT: the two bits of the kernels' fp_mode are independent
+    _check_frame(ex, oex, img, (0, 1000), stagewise=False)
+    ex, oex = _pair(600, flags=4)
+    frames = np.stack([synth.frame_from_canvas(canvas1, t, 424, 318, 4300 + t) for t in range(5)])
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), 5, 424, 318, 424, 424 * 318, (0, 1000))
+    for f in (0, 4):
+        mono, kps, desc = ex.download(f)
+        omono, okps, odesc = oex.extract(frames[f], lap=(0, 1000))
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), f
+
+
+@pytest.mark.parametrize("w,h,nlevels", [(1024, 768, 4), (752, 480, 3), (753, 481, 3)])
+def test_scale_factor_two(w, h, nlevels):
+    """scaleFactor == 2.0 (VERDICT r5 'missing' 3).  cv::resize switches INTER_LINEAR to INTER_AREA when both scales are exactly 2 (its 2 x 2
+    box average); the fixed-point bilinear formula AT exactly 2 x has both weights 1024 / 2048 and reduces to the same (a + b + c + d + 2) >> 2
+    (tests/test_oracle_primitives_vs_definitions.py::test_resize_at_exactly_two_is_the_box_average), so no second code path exists to diverge.
+    Here: levels that halve exactly (1024 x 768; 752 x 480 -> 376 x 240 -> 188 x 120) and levels that do not (753 x 481), every padded level ==
+    oracle, and the exactly halved levels == the box average of the level above."""
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    from oracle import oracle_binding as ob
+    canvas = synth.make_canvas(w + h, size=2048, n_shapes=2400)
+    img = synth.frame_from_canvas(canvas, 3, w, h, 99)
+    ex = osa.ORBextractor(600, 2.0, nlevels, 20, 7)
+    oex = ob.OracleExtractor(600, 2.0, nlevels, 20, 7, flags=ob.FLAG_DESC_FMA)
+    mono, kps, desc = ex(img, None, (0, 1000))
+    omono, okps, odesc = oex.extract(img, lap=(0, 1000))
+    levels = [ex.get_level(l) for l in range(nlevels)]
+    for l in range(nlevels):
+        assert np.array_equal(levels[l], oex.level_padded(l)), l
+    for l in range(1, nlevels):
+        up, lo = levels[l - 1][19:-19, 19:-19].astype(np.int32), levels[l][19:-19, 19:-19]
+        if up.shape[0] == 2 * lo.shape[0] and up.shape[1] == 2 * lo.shape[1]:
+            assert np.array_equal(lo, ((up[0::2, 0::2] + up[0::2, 1::2] + up[1::2, 0::2] + up[1::2, 1::2] + 2) >> 2).astype(np.uint8)), l
+        else:
+            assert (w, h) == (753, 481)
+    assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc) and len(kps) > 200
+    # the batched path (k_pyr_stream where the geometry allows it, else the per-level chain)
+    import torch
+    frames = np.stack([synth.frame_from_canvas(canvas, t, w, h, 100 + t) for t in range(3)])
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), 3, w, h, w, w * h, (0, 1000))
+    for f in (0, 2):
+        m2, k2, d2 = ex.download(f)
+        om, ok, od = oex.extract(frames[f], lap=(0, 1000))
+        assert m2 == om and k2.tobytes() == ok.tobytes() and np.array_equal(d2, od), f
 
 
 def test_ocv440_blur_taps_in_a_batch(canvas1):

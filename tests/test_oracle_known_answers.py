@@ -65,6 +65,64 @@ def test_fast_atan2_axes_and_accuracy(oracle):
         assert abs((got - want + 180) % 360 - 180) < 0.31
 
 
+_ATAN_SRC = r"""
+#include <math.h>
+#include <float.h>
+/* the expression of OpenCV's scalar atan_f32 (core/src/mathfuncs.cpp), as SURVEY.md 8c-R4 restates it; which machine
+   operations it becomes is the COMPILER'S choice -- that choice is what this test pins */
+static const float p1 = 0.9997878412794807f * (float)(180 / M_PI), p3 = -0.3258083974640975f * (float)(180 / M_PI),
+                   p5 = 0.1555786518463281f * (float)(180 / M_PI), p7 = -0.04432655554792128f * (float)(180 / M_PI);
+float atan_src(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+void atan_src_n(const float *y, const float *x, float *out, int n) { for (int i = 0; i < n; i++) out[i] = atan_src(y[i], x[i]); }
+"""
+
+
+def test_fast_atan2_fma_fork_equals_the_source_expression_under_both_compilations(oracle, tmp_path):
+    """VERDICT r5 'missing' 2: cv::fastAtan2's polynomial is contracted to FMAs where OpenCV's baseline ISA has FMA (aarch64; x86
+    CPU_BASELINE >= FMA3).  The oracle writes both forms with explicit operations; here the SOURCE expression is compiled twice by
+    the image's gcc -- `-ffp-contract=off` and `-mfma -ffp-contract=fast` -- and each build must equal the oracle's form bit for bit
+    (the default and ORBO_FLAG_ATAN_FMA / ORBX_FLAG_ATAN_FMA).  The two forms must also really differ somewhere."""
+    import subprocess
+    src = tmp_path / "atan_src.c"
+    src.write_text(_ATAN_SRC)
+    libs = {}
+    for tag, flags in (("strict", ["-ffp-contract=off"]), ("fma", ["-mfma", "-ffp-contract=fast"])):
+        so = tmp_path / f"atan_{tag}.so"
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", *flags, "-o", str(so), str(src), "-lm"], check=True)
+        L = C.CDLL(str(so))
+        L.atan_src_n.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        libs[tag] = L
+    rng = np.random.default_rng(11)
+    n = 400000
+    # the moments IC_Angle feeds it (integers of magnitude < 2.9e6), plus axes / diagonals / zeros
+    y = rng.integers(-2900000, 2900000, n).astype(np.float32)
+    x = rng.integers(-2900000, 2900000, n).astype(np.float32)
+    y[:8] = [0, 1, 0, -1, 5, -5, 0, 7]
+    x[:8] = [1, 0, -1, 0, 5, 5, 0, -7]
+    out = {}
+    for tag, L in libs.items():
+        o = np.zeros(n, np.float32)
+        L.atan_src_n(y.ctypes.data, x.ctypes.data, o.ctypes.data, n)
+        out[tag] = o
+    lib = oracle.lib()
+    f = lib.orbo_fast_atan2_n
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    for tag, fma in (("strict", 0), ("fma", 1)):
+        got = np.zeros(n, np.float32)
+        f(y.ctypes.data, x.ctypes.data, got.ctypes.data, n, fma)
+        assert got.tobytes() == out[tag].tobytes(), f"{tag}: {np.count_nonzero(got != out[tag])} of {n} differ"
+    ndiff = np.count_nonzero(out["strict"] != out["fma"])
+    assert 0 < ndiff < n // 2, ndiff
+    assert np.max(np.abs(out["strict"].astype(np.float64) - out["fma"])) < 1e-4   # an ulp of a float below 360
+
+
 def test_blur_constant_is_identity_and_impulse(oracle):
     img = np.full((40, 50), 93, np.uint8)
     assert np.array_equal(oracle.gauss7(img), img)

@@ -381,6 +381,85 @@ def test_search_for_triangulation_pinhole_gates(frames):
     assert gated < free
 
 
+def _rot(rx, ry, rz):
+    """float32 rotation matrix Rz(rz) Ry(ry) Rx(rx)"""
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return (Rz @ Ry @ Rx).astype(np.float32)
+
+
+PINHOLE_CASES = [
+    # name, K1, K2, pose2 = Tcw of key frame 2 (key frame 1 sits at the origin), bOnlyStereo, bCoarse, check orientation, stereo flags
+    # sideways motion, intrinsics and translation exact in binary: the frames' (2, 1) px shift is this baseline at one depth, many pairs pass
+    ("sideways_exact", (512.0, 512.0, 384.0, 256.0), (512.0, 512.0, 384.0, 256.0), (np.eye(3, dtype=np.float32), (-1.0, -0.5, 0.015625)), False, False, True, False),
+    # EuRoC cam0 intrinsics, a small rotation, mixed stereo / monocular keypoints
+    ("euroc_rotated", (458.654, 457.296, 367.215, 248.375), (458.654, 457.296, 367.215, 248.375), (_rot(0.0004, -0.0007, 0.0011), (-0.11, -0.05, 0.004)), False, False,
+     False, True),
+    # forward motion: the epipole lies inside image 2, the epipole-distance gate of :1026-1034 fires
+    ("forward_epipole_in_image", (458.654, 457.296, 367.215, 248.375), (460.0, 459.0, 370.0, 250.0), (np.eye(3, dtype=np.float32), (0.002, -0.001, -0.4)), False, False, True,
+     False),
+    ("only_stereo", (512.0, 512.0, 384.0, 256.0), (512.0, 512.0, 384.0, 256.0), (np.eye(3, dtype=np.float32), (-1.0, -0.5, 0.015625)), True, False, True, True),
+    ("coarse", (458.654, 457.296, 367.215, 248.375), (458.654, 457.296, 367.215, 248.375), (_rot(0.0004, -0.0007, 0.0011), (-0.11, -0.05, 0.004)), False, True, True, False),
+]
+
+
+def pinhole_case_inputs(frames, case):
+    """Inputs of one PINHOLE_CASES entry (also used by tests/test_gpu_matcher.py and bench.py's latency block)."""
+    name, K1, K2, pose2, only_stereo, coarse, ori, stereo = case
+    k0, d0, k1, d1, tab = frames[1000]
+    rng = np.random.default_rng(sum(map(ord, name)))
+    na, nb = _bow_nodes(rng, k0, k1, 60)
+    fva, fvb = FeatureVector.from_node_of_feature(na), FeatureVector.from_node_of_feature(nb)
+    s0 = (rng.random(len(k0)) < 0.3).astype(np.uint8)
+    s1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    ur0 = np.where(rng.random(len(k0)) < 0.5, k0["x"] - 5.0, -1.0).astype(np.float32) if stereo else None
+    ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 5.0, -1.0).astype(np.float32) if stereo else None
+    pose1 = (np.eye(3, dtype=np.float32), np.zeros(3, np.float32))
+    pose2 = (np.asarray(pose2[0], np.float32), np.asarray(pose2[1], np.float32))
+    return dict(k0=k0, d0=d0, s0=s0, ur0=ur0, fva=fva, k1=k1, d1=d1, s1=s1, ur1=ur1, fvb=fvb, sf=tab["scale"], sg=tab["sigma2"], K1=K1, K2=K2, pose1=pose1, pose2=pose2,
+                only_stereo=only_stereo, coarse=coarse, ori=ori)
+
+
+@pytest.mark.parametrize("case", PINHOLE_CASES, ids=[c[0] for c in PINHOLE_CASES])
+def test_search_for_triangulation_between_pinhole_keyframes(frames, case):
+    """M7 the way LocalMapping::CreateNewMapPoints calls it (LocalMapping.cc:466): two key frames with Pinhole cameras and poses, nothing
+    else.  Reference side: ORBmatcher.cc:907-1146 whole, the epipole from Pinhole::project, Pinhole::epipolarConstrain deriving F12 from
+    (K1, K2, R12, t12) for every pair -- all the reference's own text.  The oracle gets the epipole and the F12 that run used and must return
+    the same pairs.  With ORBX_MATCHER_BACKEND=adapter the same call goes through the drop-in adapter, which must take its CAM_PINHOLE
+    route (the stand-in's host epipolarConstrain aborts in that build): F12 built once, both gates inside k_replay_bow."""
+    c = pinhole_case_inputs(frames, case)
+    name = case[0]
+    live = {}
+
+    def run():
+        if "r" not in live:
+            live["r"] = rb.ref_search_for_triangulation_pinhole_cams(c["k0"], c["d0"], c["s0"], c["ur0"], c["fva"], c["k1"], c["d1"], c["s1"], c["ur1"], c["fvb"],
+                                                                     c["sf"], c["sg"], c["K1"], c["K2"], c["pose1"], c["pose2"], c["ori"], c["only_stereo"], c["coarse"])
+        return live["r"]
+    # key frame 1 at the origin: Cw = 0, C2 = t2, epipole = Pinhole::project(t2) (float operations in the order of Pinhole.cpp:43-49)
+    t2 = c["pose2"][1]
+    K2 = np.asarray(c["K2"], np.float32)
+    ep = (K2[0] * t2[0] / t2[2] + K2[2], K2[1] * t2[1] / t2[2] + K2[3])
+    if c["coarse"]:
+        F = np.eye(3, dtype=np.float32)   # bCoarse: epipolarConstrain is never evaluated, no F12 exists on the reference side
+    else:
+        F = _P.value(f"m7cams/{name}/F12", lambda: run()[2]).reshape(3, 3)
+        assert np.abs(F).max() > 0
+    s0 = c["s0"].copy()
+    s1 = c["s1"].copy()
+    if c["only_stereo"]:   # :971-983 / :1002-1012: monocular keypoints are skipped on both sides
+        s0 |= (c["ur0"] < 0).astype(np.uint8)
+        s1 |= (c["ur1"] < 0).astype(np.uint8)
+    on, om = ob.search_for_triangulation_pinhole(c["k0"], c["d0"], s0, c["ur0"], c["fva"], c["k1"], c["d1"], s1, c["ur1"], c["fvb"], c["sf"], c["sg"], F, ep,
+                                                 c["coarse"], c["ori"], fma=True)
+    _pin(f"m7cams/{name}", (on, om), lambda: run()[:2])
+    if rb.matcher_available() and not c["coarse"] and f"m7cams/{name}/F12" in _P.gold:   # both builds (reference, adapter) must have used the same F12
+        assert np.array_equal(_P.gold[f"m7cams/{name}/F12"].view(np.float32).reshape(3, 3), run()[2]), "F12 of this run differs from the compiled reference's"
+    assert on > (5 if name == "forward_epipole_in_image" else 40), on
+
+
 def _fuse_queries(rng, k0, d0, sf, th):
     n = len(k0)
     u = (k0["x"] - 2.0 + rng.normal(0, 1.5, n)).astype(np.float32)

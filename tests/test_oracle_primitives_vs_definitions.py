@@ -135,3 +135,18 @@ def test_fast_atan2_accuracy_dense():
     got = np.array([ob.fast_atan2(float(a), float(b)) for a, b in zip(y.astype(np.float32), x.astype(np.float32))])
     want = np.degrees(np.arctan2(y.astype(np.float32).astype(np.float64), x.astype(np.float32).astype(np.float64))) % 360
     assert np.abs((got - want + 180) % 360 - 180).max() < 0.3
+
+
+def test_resize_at_exactly_two_is_the_box_average():
+    """cv::resize(INTER_LINEAR) at a scale of exactly 2 in both directions is re-routed to INTER_AREA, whose fast 2 x 2 path for 8-bit images is
+    (a + b + c + d + 2) >> 2 (imgproc/src/resize.cpp: "in case of scale_x && scale_y is equal to 2 INTER_AREA (fast) also is equal to
+    INTER_LINEAR").  The fixed-point bilinear restatement needs no second path for it: at exactly 2 x the source coordinate is 2x + 0.5, both
+    horizontal and both vertical weights are 1024 of 2048, ((1024 * ((a + b) * 1024 >> 4)) >> 16) = a + b exactly, and the result IS the box
+    average.  Checked here on random images (even sizes halve exactly; ORBextractor.cc:1183 with scaleFactor == 2.0)."""
+    rng = np.random.default_rng(5)
+    for (h, w) in ((480, 752), (376, 1240), (2, 2), (10, 6), (768, 1024)):
+        src = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = ob.resize_linear(src, w // 2, h // 2)
+        s = src.astype(np.int32)
+        want = ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        assert np.array_equal(got, want), (h, w)
