@@ -807,7 +807,7 @@ def latency_euroc(osa, frames, n_calls, W, H, NF, LAP, device, cpu):
     return out
 
 
-def latency_calls(osa, device, n_calls, n_cpu=5):
+def latency_calls(osa, device, n_calls, n_cpu=5, small=False):
     """latency.calls: one matcher call at a time through the C ABI, host arrays in, host arrays out -- the way SLAM consumes the path
     (Tracking.cc:3390-3413 calls SearchByProjection once per frame, LocalMapping.cc:412 SearchForTriangulation once per key-frame pair,
     Frame.cc:811 ComputeStereoMatches once per stereo frame).  Each call beside the CPU oracle's time for the IDENTICAL call (1 thread, a few
@@ -944,6 +944,101 @@ def latency_calls(osa, device, n_calls, n_cpu=5):
                      "ORBmatcher.cc:1148-1455, LocalMapping.cc:676",
                      lambda: mf.FuseSearch(Ff, qf, isg, False), lambda: ob.fuse_search(g1, d1, None, isg, qf, fma=True),
                      lambda g, c: np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1])))
+    # ---- round 6: the six entry points that had parity but no clock (VERDICT r5 'missing' 6) ----
+    # M9: cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) -- the brute-force "__popcll + wave-reduce" kernel of north_star (Frame.cc:1144)
+    mk = osa.ORBmatcher(device=device)
+    for nq_, nt_ in (((200, 150),) if small else ((1000, 1000), (5000, 5000))):
+        qd_ = rng.integers(0, 256, (nq_, 32), dtype=np.uint8)
+        td_ = noisy(np.ascontiguousarray(qd_[rng.permutation(nq_)[:nt_]]), 0.08)
+        td_[7] = td_[3]   # an exact distance tie: the lower train index must win
+        out.append(entry("BFMatcher::knnMatch(k=2), brute force [orbx_knn2]: %d x %d descriptors" % (nq_, nt_), "Frame.cc:1126-1166 (:1144)",
+                         lambda qd_=qd_, td_=td_: mk.knn2(qd_, td_), lambda qd_=qd_, td_=td_: ob.knn2(qd_, td_),
+                         lambda g, c: np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1]),
+                         {"algorithmic_bytes": 32 * (nq_ + nt_) + 16 * nq_, "hamming_distances": nq_ * nt_}))
+    # M3 / M4: SearchByProjection window forms (relocalisation: levels [l-1, l+1], ORBdist 100, rotation check; Sim3: [l-1, l], TH_LOW * ratio)
+    lv0 = k0["octave"]
+    base_q = dict(x=k0["x"] - 2.0 + rng.normal(0, 1.0, len(k0)).astype(np.float32), y=k0["y"] - 1.0, angle=k0["angle"], desc=d0)
+    occw = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    q3 = dict(base_q, r=(np.float32(10.0) * sf2[lv0]).astype(np.float32), min_level=lv0 - 1, max_level=lv0 + 1)
+    mw = osa.ORBmatcher(0.9, True, device=device)
+    out.append(entry("SearchByProjection(Frame, KeyFrame, sAlreadyFound, th=10, ORBdist=100) [orbx_search_by_projection_window]: %d queries into %d features" % (len(k0), len(k1)),
+                     "ORBmatcher.cc:1889-2010, Tracking.cc:3726",
+                     lambda: mw.SearchByProjectionWindow(F1, q3, 100.0, True, occw), lambda: ob.search_by_projection_window(g1, d1, q3, 100.0, True, False, occw),
+                     lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])))
+    q4 = dict(base_q, r=(np.float32(8.0) * sf2[lv0]).astype(np.float32), min_level=lv0 - 1, max_level=lv0)
+    out.append(entry("SearchByProjection(KeyFrame, Sim3, MapPoints, th=8, ratioHamming=1.5) [orbx_search_by_projection_window]: %d queries into %d features" % (len(k0), len(k1)),
+                     "ORBmatcher.cc:427-646, LoopClosing.cc:755",
+                     lambda: mw.SearchByProjectionWindow(F1, q4, 75.0, False, occw), lambda: ob.search_by_projection_window(g1, d1, q4, 75.0, False, True, occw),
+                     lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])))
+    # M6: SearchForInitialization with the 5 x nFeatures extractor of the monocular initialisation (Tracking.cc:601, 2491): level-0 keypoints only
+    exi = osa.ORBextractor(1500 if small else 5000, 1.2, NLEVELS, 20, 7, device=device)
+    _, ki0, di0 = exi(synth.frame_from_canvas(canvas1, 0, 752, 480, 1000), None, (0, 1000))
+    _, ki1, di1 = exi(synth.frame_from_canvas(canvas1, 4, 752, 480, 1004), None, (0, 1000))
+    Fi = osa.FrameView(ki1, di1, 0.0, 752.0, 0.0, 480.0, sf2)
+    gi = ob.OracleGrid(ki1, 0.0, 752.0, 0.0, 480.0)
+    prev0 = np.ascontiguousarray(np.stack([ki0["x"], ki0["y"]], axis=1).astype(np.float32))
+    mi = osa.ORBmatcher(0.9, True, device=device)
+    out.append(entry("SearchForInitialization(F1, F2, windowSize=100) [orbx_search_for_initialization]: %d x %d keypoints of the 5 x nFeatures extractor (%d on level 0)"
+                     % (len(ki0), len(ki1), int((ki0["octave"] == 0).sum())), "ORBmatcher.cc:648-763, Tracking.cc:2491",
+                     lambda: mi.SearchForInitialization(ki0, di0, Fi, prev0.copy(), 100), lambda: ob.search_for_initialization(ki0, di0, gi, di1, prev0.copy(), 100, 0.9, True),
+                     lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])))
+    # (f)2: DBoW2 transform of one frame's descriptors through a k = 10, L = 5 vocabulary (ORBvoc is k = 10, L = 6; levelsup = 4 as Frame::ComputeBoW)
+    kv, Lv = 10, (3 if small else 5)
+    n_nodes = (kv ** (Lv + 1) - 1) // (kv - 1)
+    ids = np.arange(n_nodes, dtype=np.int64)
+    first_child = ids * kv + 1
+    is_leaf = first_child >= n_nodes
+    cp = np.concatenate([[0], np.cumsum(np.where(is_leaf, 0, kv))]).astype(np.int32)
+    ci = np.arange(1, n_nodes, dtype=np.int32)
+    nd_desc = rng.integers(0, 256, (n_nodes, 32), dtype=np.uint8)
+    wi = np.where(is_leaf, np.cumsum(is_leaf) - 1, -1).astype(np.int32)
+    voc = osa.ORBVocabulary(Lv, cp, ci, nd_desc, wi, device=device)
+    mb = osa.ORBmatcher(device=device)
+    out.append(entry("Frame::ComputeBoW = TemplatedVocabulary::transform(levelsup=4) [orbx_bow_transform]: %d descriptors, k=%d L=%d vocabulary (%d nodes resident)"
+                     % (len(d0), kv, Lv, n_nodes), "Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1262, Frame.cc:738-745",
+                     lambda: mb.BowTransform(voc, d0, 4), lambda: ob.bow_transform(cp, ci, nd_desc, wi, Lv, 4, d0),
+                     lambda g, c: np.array_equal(g[0], c[0]) and np.array_equal(g[1], c[1])))
+    # (f)4: MapPoint::ComputeDistinctiveDescriptors for the map points a new key frame touches (LocalMapping.cc:290: one call per map point in the reference)
+    sizes = rng.integers(2, 25, 500)
+    set_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    based = rng.integers(0, 256, (len(sizes), 32), dtype=np.uint8)
+    dset = noisy(np.repeat(based, sizes, axis=0), 0.08)
+    out.append(entry("MapPoint::ComputeDistinctiveDescriptors x %d map points [orbx_distinctive_descriptors]: %d observations" % (len(sizes), len(dset)),
+                     "MapPoint.cc:329-403, LocalMapping.cc:290",
+                     lambda: mb.DistinctiveDescriptors(dset, set_ptr), lambda: ob.distinctive_descriptors(dset, set_ptr), lambda g, c: np.array_equal(g, c)))
+    # (f)3: Frame::isInFrustum for the local map (Tracking::SearchLocalPoints, Tracking.cc:3360-3380): 10 000 map points against one pose
+    a_, b_, c_ = 0.11, -0.07, 0.05
+    Rx = np.array([[1, 0, 0], [0, np.cos(a_), -np.sin(a_)], [0, np.sin(a_), np.cos(a_)]])
+    Ry = np.array([[np.cos(b_), 0, np.sin(b_)], [0, 1, 0], [-np.sin(b_), 0, np.cos(b_)]])
+    Rz = np.array([[np.cos(c_), -np.sin(c_), 0], [np.sin(c_), np.cos(c_), 0], [0, 0, 1]])
+    Rcw = (Rz @ Ry @ Rx).astype(np.float32)
+    tcw = np.array([0.3, -0.2, 0.1], np.float32)
+    Ow = (-(Rcw.astype(np.float64).T @ tcw.astype(np.float64))).astype(np.float32)
+    camf = (458.654, 457.296, 367.215, 248.375, 47.9)
+    bnd = np.array([-10.5, 760.25, -8.0, 488.5], np.float32)
+    nfp = 1000 if small else N_MAPPOINTS
+    posf = rng.uniform(-6, 6, (nfp, 3)).astype(np.float32)
+    posf[:, 2] = rng.uniform(-2, 12, nfp)
+    towards = Ow[None, :] - posf
+    towards /= np.linalg.norm(towards, axis=1, keepdims=True)
+    nrm = (towards + rng.normal(0, 0.4, (nfp, 3))).astype(np.float32)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    dist = np.linalg.norm(posf - Ow, axis=1)
+    mxd = (dist * rng.uniform(0.7, 4.0, nfp)).astype(np.float32)
+    mnd = (mxd / rng.uniform(1.5, 4.3, nfp)).astype(np.float32)
+    lsf = np.float32(np.log(1.2))
+    keysf = ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "level", "view_cos")
+
+    def same_frustum(g, c):
+        iv = c["in_view"].astype(bool)
+        ok = np.array_equal(g["in_view"], c["in_view"]) and g["proj_x"].tobytes() == c["proj_x"].tobytes() and g["proj_y"].tobytes() == c["proj_y"].tobytes()
+        for k in ("proj_xr", "depth", "view_cos"):
+            ok = ok and g[k][iv].tobytes() == c[k][iv].tobytes()
+        lv_d = np.nonzero(g["level"][iv] != c["level"][iv])[0]   # PredictScale goes through logf: may differ only at an integer boundary
+        return bool(ok and len(lv_d) <= 2)
+    out.append(entry("Frame::isInFrustum x %d map points [orbx_is_in_frustum]: one pose, pinhole" % nfp, "Frame.cc:512-586, Tracking.cc:3360-3380",
+                     lambda: mb.isInFrustum(camf[:4] + (0, 0, 0, 0, 0, camf[4]), (Rcw, tcw, Ow), bnd, lsf, 8, 0.5, posf, nrm, mnd, mxd),
+                     lambda: ob.is_in_frustum(Rcw, tcw, Ow, camf, bnd, lsf, 8, 0.5, posf, nrm, mnd, mxd), same_frustum))
     return out
 
 

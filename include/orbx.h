@@ -205,9 +205,11 @@ int orbx_profile_read(orbx_extractor *ex, const char **names, double *avg_ms, in
 typedef struct orbx_matcher orbx_matcher;
 int orbx_matcher_create(int device, orbx_matcher **out);
 void orbx_matcher_destroy(orbx_matcher *m);
-/* Transfers of the context's LAST call (test hook; host-pointer entry points): out[0] = host-to-device DMA submissions, out[1] = device-to-host ones,
- * out[2] / out[3] = their bytes.  A call stages its inputs in a pinned mirror of its device arena and moves each run of adjacent buffers with one
- * submission (a projection-matcher call: 2 up, 1 down).  Returns the number of entries written (4), or < 0. */
+/* Transfers of the context's LAST call (test hook; host-pointer entry points): out[0] = host-to-device transfers submitted (one per run of adjacent
+ * buffers), out[1] = device-to-host ones, out[2] / out[3] = their bytes; with cap >= 6 also out[4] = how many of them a DMA engine carried
+ * (hipMemcpyAsync) and out[5] = k_xfer launches.  A call stages its inputs in a pinned, device-visible mirror of its device arena; runs up to 1 MiB are
+ * moved by the lanes of a k_xfer launch in the call's own queue (a projection-matcher call: 1 run up, 1 down, 2 launches, no DMA submission), larger
+ * ones by the DMA engine; ORBX_MATCHER_DMA=1 sends everything through the DMA engine (round 5's transport).  Returns the entries written, or < 0. */
 int orbx_matcher_debug_transfers(const orbx_matcher *m, int64_t *out, int cap);
 
 /* ORBmatcher::TH_LOW / TH_HIGH / HISTO_LENGTH (ORBmatcher.cc:35-37) */

@@ -95,6 +95,35 @@ __device__ __forceinline__ orbx_keypoint gld_kp(const orbx_keypoint *p) {   // t
 // ---------------------------------------------------------------------------------------------------------
 // one wave per query; lanes stride the query's candidate list
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// k_xfer: the transfers and fills of ONE host-pointer matcher call as a launch in the call's own queue (round 6).  A call's inputs are staged in a
+// pinned, device-visible mirror of its arena (orbx_matcher); until round 5 every run of adjacent buffers went up with a hipMemcpyAsync and the
+// results came back with one -- each a hand-over between the compute queue and a DMA engine (~ 8-10 us apiece on the critical path of a call that
+// computes for 10-20 us), plus a launch per hipMemsetAsync.  Here the lanes read the mirror (host memory) / write it themselves, 16 bytes each, and the
+// fills ride in the same launch: a call is kernel launches only, in ONE in-order queue, and ends with one stream synchronisation.  Runs above
+// kKernelXferMax (the stereo matcher's 4.4 MB of pyramids) stay with the DMA engine.
+// op: dst / src device-visible addresses, 16-byte aligned; units = 16-byte units; src == nullptr: fill with the byte `fill`.
+// grid: ceil(largest op / 256) capped at 1024, block 256
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxXferOps = 12;
+struct XferOp { uint8_t *dst; const uint8_t *src; uint32_t units; uint32_t fill; };
+struct XferOps { XferOp op[kMaxXferOps]; int n; };
+__global__ __launch_bounds__(256) void k_xfer(const XferOps X) {
+    const uint32_t gtid = blockIdx.x * 256 + threadIdx.x, gstride = gridDim.x * 256;
+    for (int k = 0; k < X.n; k++) {
+        uint4 *d = reinterpret_cast<uint4 *>(X.op[k].dst);
+        const uint4 *s = reinterpret_cast<const uint4 *>(X.op[k].src);
+        const uint32_t units = X.op[k].units;
+        if (s) {
+            for (uint32_t u = gtid; u < units; u += gstride) d[u] = s[u];
+        } else {
+            const uint32_t f = X.op[k].fill * 0x01010101u;
+            const uint4 v = make_uint4(f, f, f, f);
+            for (uint32_t u = gtid; u < units; u += gstride) d[u] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_hamming_csr(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
                                                      const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ cand,
                                                      uint16_t *__restrict__ dist) {

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -69,7 +70,9 @@ struct PinnedArena {
         if (base) (void)hipHostFree(base);
         base = nullptr; cap = 0;
         bytes = (bytes * 3 / 2 + 4095) & ~(size_t)4095;
-        ORBX_HIP(hipHostMalloc((void **)&base, bytes, hipHostMallocDefault));
+        // coherent (fine-grained) whatever HIP_HOST_COHERENT says: k_xfer's lanes read the staged inputs from and write the results into this block
+        // themselves, and the host reads them right after the stream synchronisation (as the extractor's h_stage, extractor_state.h)
+        ORBX_HIP(hipHostMalloc((void **)&base, bytes, hipHostMallocCoherent));
         cap = bytes;
         return ORBX_OK;
     }
@@ -88,32 +91,45 @@ struct orbx_matcher {
     hipStream_t stream = nullptr;
     Arena arena;
     PinnedArena stage;
-    // Round 5: transfers of ONE call are coalesced.  `mirror` is a pinned image of the device arena: an upload to arena offset o is staged at mirror offset o
-    // and only RECORDED; exec() -- the stream as every launch, memset and download of a call obtains it -- first issues the recorded uploads, ONE
-    // hipMemcpyAsync per run of arena-adjacent buffers (adjacent = nothing but take()'s alignment padding between them, which no buffer owns).  Downloads
-    // from the arena are recorded the same way and issued as runs by deliver().  A projection-matcher call made 14 uploads and 2 downloads of 4 B .. 32 KB,
-    // each a DMA submission of its own on the stream (~5 us): now 2 + 1.  Transfers whose device side is not in the arena take the direct path (stage).
+    // Transfers of ONE call are coalesced (round 5) and issued as KERNEL work (round 6).  `mirror` is a pinned, device-visible image of the device arena: an
+    // upload to arena offset o is staged at mirror offset o and only RECORDED; exec() -- the stream as every launch, fill and download of a call obtains it --
+    // first issues the recorded uploads and fills: every run of arena-adjacent buffers (adjacent = nothing but take()'s alignment padding between them, which
+    // no buffer owns) is one op of a k_xfer launch whose lanes read the mirror themselves (runs above kKernelXferMax: one hipMemcpyAsync).  Downloads from the
+    // arena are recorded the same way and issued as runs by deliver(): a k_xfer launch that writes the mirror.  Round 4: 14 uploads and 2 downloads of
+    // 4 B .. 32 KB per projection-matcher call, each a DMA submission (~5 us); round 5: 1 + 1 DMA submissions; now none -- the call's work is one in-order
+    // chain of launches in the compute queue, no hand-over to a DMA engine and back.  Transfers whose device side is not in the arena take the direct path.
     PinnedArena mirror;
     struct Span { size_t off, bytes; };
     std::vector<Span> uploads;      // recorded, not yet issued (ascending offsets: the arena is a bump allocator)
-    std::vector<Span> issued;       // mirror ranges a DMA issued since the last synchronisation may still read: not staged over (such an upload goes direct)
+    std::vector<Span> issued;       // mirror ranges a transfer issued since the last synchronisation may still read: not staged over (such an upload goes direct)
+    struct Fill { size_t off, bytes; uint32_t value; };
+    std::vector<Fill> fills;        // recorded fills of arena ranges, issued with the uploads
     struct Pending { void *dst; const void *src; size_t bytes; };
     std::vector<Pending> pending;   // downloads waiting in pinned memory for the stream synchronisation
     struct Down { void *dst; size_t off, bytes; };
     std::vector<Down> downloads;    // recorded downloads from the arena (issued by deliver())
     hipError_t xfer_err = hipSuccess;
-    int64_t xfers[4] = {0, 0, 0, 0};   // DMA submissions up / down and their bytes since begin() (orbx_matcher_debug_transfers)
+    int64_t xfers[6] = {0, 0, 0, 0, 0, 0};   // transfer submissions (runs) up / down and their bytes since begin(); [4] of them by a DMA engine, [5] k_xfer launches
+    bool kernel_xfer = true;                 // ORBX_MATCHER_DMA=1: every run by hipMemcpyAsync, fills by hipMemsetAsync (round 5's transport, for A/B)
+    bool dirty = false;                      // something was enqueued since the last synchronisation
     static constexpr size_t kPadGap = 255;   // Arena::take aligns to 256
+    static constexpr size_t kKernelXferMax = (size_t)1 << 20;
     // device scratch for one call + staging for everything that call can move in either direction
     int reserve_all(size_t device_bytes) {
+        if (dirty) { (void)hipStreamSynchronize(stream); dirty = false; }   // a call that failed between exec() and deliver(): nothing of it may still read what is re-allocated here
         int r = arena.reserve(device_bytes);
         if (r != ORBX_OK) return r;
         r = mirror.reserve(arena.cap);
         if (r != ORBX_OK) return r;
         return stage.reserve(2 * device_bytes + 65536);
     }
-    // begin() follows a synchronisation of the previous call (every entry point ends in deliver(), or failed before anything was enqueued)
-    void begin() { arena.reset(); stage.reset(); pending.clear(); uploads.clear(); downloads.clear(); issued.clear(); xfer_err = hipSuccess; xfers[0] = xfers[1] = xfers[2] = xfers[3] = 0; }
+    // begin() follows a synchronisation of the previous call: every entry point ends in deliver(); one that returned between exec() and deliver() (a failed
+    // launch, an exhausted staging arena) left `dirty` set and is waited for here, before its mirror ranges are staged over
+    void begin() {
+        if (dirty) { (void)hipStreamSynchronize(stream); dirty = false; }
+        arena.reset(); stage.reset(); pending.clear(); uploads.clear(); downloads.clear(); issued.clear(); fills.clear(); xfer_err = hipSuccess;
+        for (int64_t &x : xfers) x = 0;
+    }
     bool in_arena(const void *p, size_t bytes) const {
         const uint8_t *q = static_cast<const uint8_t *>(p);
         return arena.base && q >= arena.base && q + bytes <= arena.base + arena.cap && arena.cap <= mirror.cap;
@@ -126,39 +142,95 @@ struct orbx_matcher {
         return true;
     }
     void note(hipError_t e) { if (e != hipSuccess && xfer_err == hipSuccess) xfer_err = e; }
+    void record_upload(size_t o, size_t bytes) {   // staged in the mirror at offset o by the caller
+        for (const Fill &f : fills)
+            if (o < f.off + f.bytes + 16 && f.off < o + bytes + 16) { flush_uploads(); break; }   // never reorder an upload and a fill of one range
+        uploads.push_back(Span{o, bytes});
+    }
+    void launch_xfer(const XferOps &X, uint32_t max_units) {
+        const uint32_t grid = std::min<uint32_t>(1024u, (max_units + 255u) / 256u);
+        hipLaunchKernelGGL(k_xfer, dim3(grid ? grid : 1), dim3(256), 0, stream, X);
+        note(hipGetLastError());
+        xfers[5]++;
+    }
+    // a fill of an arena range, issued with the call's uploads (the device side of the range must not be the target of a recorded upload)
+    hipError_t fill(void *dst, int value, size_t bytes) {
+        if (bytes == 0) return hipSuccess;
+        const size_t o = (size_t)(static_cast<const uint8_t *>(dst) - arena.base);
+        if (kernel_xfer && in_arena(dst, bytes) && (o & 15) == 0) {
+            for (const Span &u : uploads)
+                if (o < u.off + u.bytes + 16 && u.off < o + bytes + 16) { flush_uploads(); break; }   // never reorder a fill and an upload of one range
+            fills.push_back(Fill{o, bytes, (uint32_t)(value & 0xff)});
+            return hipSuccess;
+        }
+        dirty = true;
+        return hipMemsetAsync(dst, value, bytes, exec());
+    }
     void flush_uploads() {
         std::sort(uploads.begin(), uploads.end(), [](const Span &a, const Span &b) { return a.off < b.off; });   // (a record uploaded after its buffers were taken lies between them)
+        XferOps X;
+        X.n = 0;
+        uint32_t max_units = 0;
+        auto add = [&](uint8_t *dst, const uint8_t *src, size_t bytes, uint32_t value) {
+            if (X.n == kMaxXferOps) { launch_xfer(X, max_units); X.n = 0; max_units = 0; }
+            const uint32_t units = (uint32_t)((bytes + 15) / 16);
+            X.op[X.n++] = XferOp{dst, src, units, value};
+            max_units = std::max(max_units, units);
+        };
         size_t i = 0;
         while (i < uploads.size()) {
             const size_t b = uploads[i].off;
             size_t e = b + uploads[i].bytes, j = i + 1;
             while (j < uploads.size() && uploads[j].off <= e + kPadGap) { e = std::max(e, uploads[j].off + uploads[j].bytes); j++; }
-            note(hipMemcpyAsync(arena.base + b, mirror.base + b, e - b, hipMemcpyHostToDevice, stream));
+            if (kernel_xfer && e - b <= kKernelXferMax && (b & 15) == 0) {
+                add(arena.base + b, mirror.base + b, e - b, 0);   // (rounded up to 16 bytes: alignment padding at most, the next buffer starts on a multiple of 256)
+            } else {
+                note(hipMemcpyAsync(arena.base + b, mirror.base + b, e - b, hipMemcpyHostToDevice, stream));
+                xfers[4]++;
+            }
             xfers[0]++; xfers[2] += (int64_t)(e - b);
             issued.push_back(Span{b, e - b});
             i = j;
         }
         uploads.clear();
+        for (const Fill &f : fills) add(arena.base + f.off, nullptr, f.bytes, f.value);
+        fills.clear();
+        if (X.n) launch_xfer(X, max_units);
+        dirty = true;
     }
     // the stream for anything that consumes the call's uploads (kernel launches, memsets, downloads, the synchronisation)
     hipStream_t exec() {
-        if (!uploads.empty()) flush_uploads();
+        if (!uploads.empty() || !fills.empty()) flush_uploads();
+        dirty = true;
         return stream;
     }
     // issue the recorded downloads (runs of arena-adjacent buffers), wait for the stream, hand the bytes to the caller's buffers
     hipError_t deliver() {
         (void)exec();
         std::sort(downloads.begin(), downloads.end(), [](const Down &a, const Down &b) { return a.off < b.off; });
+        XferOps X;
+        X.n = 0;
+        uint32_t max_units = 0;
         size_t i = 0;
         while (i < downloads.size()) {
             const size_t b = downloads[i].off;
             size_t e = b + downloads[i].bytes, j = i + 1;
             while (j < downloads.size() && downloads[j].off <= e + kPadGap) { e = std::max(e, downloads[j].off + downloads[j].bytes); j++; }
-            note(hipMemcpyAsync(mirror.base + b, arena.base + b, e - b, hipMemcpyDeviceToHost, stream));
+            if (kernel_xfer && e - b <= kKernelXferMax && (b & 15) == 0) {
+                if (X.n == kMaxXferOps) { launch_xfer(X, max_units); X.n = 0; max_units = 0; }
+                const uint32_t units = (uint32_t)((e - b + 15) / 16);
+                X.op[X.n++] = XferOp{mirror.base + b, arena.base + b, units, 0};
+                max_units = std::max(max_units, units);
+            } else {
+                note(hipMemcpyAsync(mirror.base + b, arena.base + b, e - b, hipMemcpyDeviceToHost, stream));
+                xfers[4]++;
+            }
             xfers[1]++; xfers[3] += (int64_t)(e - b);
             i = j;
         }
+        if (X.n) launch_xfer(X, max_units);
         note(hipStreamSynchronize(stream));
+        dirty = false;
         if (xfer_err == hipSuccess) {
             for (const Down &d : downloads) memcpy(d.dst, mirror.base + d.off, d.bytes);
             for (const Pending &q : pending) memcpy(q.dst, q.src, q.bytes);
@@ -192,14 +264,17 @@ int orbx_matcher_create(int device, orbx_matcher **out) {
     m->device = device;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); delete m; return ORBX_E_HIP; }
+    const char *dma = getenv("ORBX_MATCHER_DMA");
+    m->kernel_xfer = !(dma && dma[0] == '1');
     *out = m;
     return ORBX_OK;
 }
 
 int orbx_matcher_debug_transfers(const orbx_matcher *m, int64_t *out, int cap) {
     if (!m || !out || cap < 4) return ORBX_E_BAD_ARG;
-    for (int i = 0; i < 4; i++) out[i] = m->xfers[i];
-    return 4;
+    const int n = cap >= 6 ? 6 : 4;
+    for (int i = 0; i < n; i++) out[i] = m->xfers[i];
+    return n;
 }
 
 void orbx_matcher_destroy(orbx_matcher *m) {
@@ -219,13 +294,14 @@ void orbx_matcher_destroy(orbx_matcher *m) {
             if (m->stageable((dst), _b)) {  /* recorded; issued with its arena neighbours by exec() */             \
                 const size_t _o = (size_t)((const uint8_t *)(dst) - m->arena.base);                               \
                 memcpy(m->mirror.base + _o, (src), _b);                                                           \
-                m->uploads.push_back(orbx_matcher::Span{_o, _b});                                                 \
+                m->record_upload(_o, _b);                                                                         \
             } else {                                                                                              \
                 void *_s = m->stage.take(_b);                                                                     \
                 if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                        \
                 memcpy(_s, (src), _b);                                                                            \
+                m->dirty = true;                                                                                  \
                 ORBX_HIP(hipMemcpyAsync((dst), _s, _b, hipMemcpyHostToDevice, m->stream));                        \
-                m->xfers[0]++; m->xfers[2] += (int64_t)_b;                                                        \
+                m->xfers[0]++; m->xfers[2] += (int64_t)_b; m->xfers[4]++;                                         \
             }                                                                                                     \
         }                                                                                                         \
     } while (0)
@@ -239,7 +315,7 @@ void orbx_matcher_destroy(orbx_matcher *m) {
                 void *_s = m->stage.take(_b);                                                                     \
                 if (!_s) { set_error("staging arena exhausted"); return ORBX_E_INTERNAL; }                        \
                 ORBX_HIP(hipMemcpyAsync(_s, (src), _b, hipMemcpyDeviceToHost, m->exec()));                        \
-                m->xfers[1]++; m->xfers[3] += (int64_t)_b;                                                        \
+                m->xfers[1]++; m->xfers[3] += (int64_t)_b; m->xfers[4]++;                                         \
                 m->pending.push_back(orbx_matcher::Pending{(void *)(dst), _s, _b});                               \
             }                                                                                                     \
         }                                                                                                         \
@@ -877,7 +953,7 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
             if (!m->stageable(d, bytes)) return nullptr;
             const size_t o = (size_t)(d - m->arena.base);
             memcpy(m->mirror.base + o, src, bytes);
-            m->uploads.push_back(orbx_matcher::Span{o, bytes});
+            m->record_upload(o, bytes);
         }
         return d;
     };
@@ -905,8 +981,8 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
     P.taken_b = A.take<uint8_t>(nb);
     P.hist = A.take<int32_t>(ORBX_HISTO_LENGTH + 2); P.counters = P.hist + ORBX_HISTO_LENGTH;
     P.entries = A.take<int32_t>(2 * (size_t)std::max(na, nb));
-    ORBX_HIP(hipMemsetAsync(P.match, 0xff, 4 * (size_t)n_out, m->exec()));     // -1: no match
-    ORBX_HIP(hipMemsetAsync(P.taken_b, 0, (size_t)((const uint8_t *)(P.hist + ORBX_HISTO_LENGTH + 2) - P.taken_b), m->exec()));   // taken_b, (padding,) hist + counters
+    ORBX_HIP(m->fill(P.match, 0xff, 4 * (size_t)n_out));     // -1: no match.  Both fills ride in the launch that brings the inputs (orbx_matcher::fill)
+    ORBX_HIP(m->fill(P.taken_b, 0, (size_t)((const uint8_t *)(P.hist + ORBX_HISTO_LENGTH + 2) - P.taken_b)));   // taken_b, (padding,) hist + counters
     if (fa->n_nodes > 0) hipLaunchKernelGGL(k_replay_bow, dim3((fa->n_nodes + 3) / 4), dim3(256), 0, m->exec(), P);   // a wave per vocabulary node
     hipLaunchKernelGGL(k_replay_bow_finish, dim3(1), dim3(64), 0, m->exec(), P);
     int32_t nm = 0;

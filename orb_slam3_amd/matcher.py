@@ -106,12 +106,13 @@ class ORBmatcher:
             self._h = None
 
     def last_transfers(self) -> dict:
-        """DMA submissions of the last call: orbx_matcher_debug_transfers."""
-        out = np.zeros(4, np.int64)
-        n = self._L.orbx_matcher_debug_transfers(self._h, ptr(out), 4)
+        """Transfers of the last call: orbx_matcher_debug_transfers (runs up / down, their bytes, how many went through a DMA engine, k_xfer launches)."""
+        out = np.zeros(6, np.int64)
+        n = self._L.orbx_matcher_debug_transfers(self._h, ptr(out), 6)
         if n < 0:
             raise RuntimeError(f"orbx_matcher_debug_transfers: {n}")
-        return {"uploads": int(out[0]), "downloads": int(out[1]), "upload_bytes": int(out[2]), "download_bytes": int(out[3])}
+        return {"uploads": int(out[0]), "downloads": int(out[1]), "upload_bytes": int(out[2]), "download_bytes": int(out[3]),
+                "dma_submissions": int(out[4]), "xfer_launches": int(out[5])}
 
     # ---- DescriptorDistance over candidate lists (ORBmatcher.cc:2058-2074) ----
     def hamming_csr(self, q_desc, t_desc, row_ptr, cand):
