@@ -188,6 +188,127 @@ def pmc_traffic(kernel, workload, batch):
     return out, None
 
 
+SQ_CLOCK_GHZ = 2.4        # MI355X peak engine clock (MI355X_MICROARCH.md); the measured clock of the pass is reported beside it
+N_SIMDS = 1024            # 256 CUs x 4 SIMDs
+VALU_ISSUE_CYCLES = 4     # a wave64 VALU instruction of these integer / packed kernels occupies its SIMD's vector issue for one quad-cycle:
+                          # SQ_ACTIVE_INST_VALU (quad-cycles) == SQ_INSTS_VALU to 1 % on every kernel of the path (profiles/r05_g_pmc_sq_counters.csv)
+
+
+def pmc_sq(workload, batch):
+    """VALU-issue side of the roofline, measured in this run (round 6): ONE rocprofv3 --pmc child pass with SQ counters (+ --kernel-trace for the
+    dispatch durations of the same pass, + GRBM_GUI_ACTIVE for the clock the pass ran at, when the counter exists).  Per kernel, averaged per launch:
+    SQ_INSTS_VALU (wave-instructions), SQ_WAVES, SQ_ACTIVE_INST_VALU, the launch duration under the counters, and the issue time
+    SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / clock -- the floor of a kernel whose every SIMD issues a vector instruction whenever it can."""
+    import re
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    base = ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY"]
+    err = None
+    for counters in (base + ["GRBM_GUI_ACTIVE"], base):
+        td = tempfile.mkdtemp(prefix="orbx_sq_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", *counters, "-d", td, "-o", "p", "--", sys.executable, str(ROOT / "bench.py"), "--pmc-child", "--workload", workload,
+               "--batch", str(batch), "--steps", "2", "--warmup", "1"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=240)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(td, ignore_errors=True)
+            err = "rocprofv3 SQ pass timed out"
+            continue
+        dbs = list(Path(td).rglob("*.db"))
+        if r.returncode != 0 or not dbs:
+            shutil.rmtree(td, ignore_errors=True)
+            err = f"rocprofv3 SQ pass failed (rc {r.returncode})"
+            continue
+        try:
+            c = sqlite3.connect(str(dbs[0]))
+            tabs = [t[0] for t in c.execute("select name from sqlite_master where type in ('table','view')")]
+            view = "counters_collection" if "counters_collection" in tabs else next((t for t in tabs if t.startswith("counters_collection")), None)
+            if view is None:
+                raise RuntimeError("no counters_collection view in the rocprofv3 database")
+
+            def short(kname):
+                return re.sub(r"<.*>", "", kname.split("(")[0].replace("void ", "").replace("orbx::", ""))
+            acc = {}   # kernel -> counter -> [sum, set(dispatches)]
+            for kname, cname, val, did in c.execute(f"select kernel_name, counter_name, value, dispatch_id from {view}"):
+                k = short(kname)
+                if not k.startswith("k_"):
+                    continue
+                a_ = acc.setdefault(k, {}).setdefault(cname, [0.0, set()])
+                a_[0] += val
+                a_[1].add(did)
+            dur = {}
+            kview = "kernels" if "kernels" in tabs else next((t for t in tabs if t.startswith("kernels")), None)
+            if kview:
+                for kname, st, en in c.execute(f"select name, start, end from {kview}"):
+                    d_ = dur.setdefault(short(kname), [0.0, 0])
+                    d_[0] += (en - st) * 1e-3
+                    d_[1] += 1
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            shutil.rmtree(td, ignore_errors=True)
+            err = f"rocprofv3 SQ pass: {e}"
+            continue
+        shutil.rmtree(td, ignore_errors=True)
+        out = {}
+        for k, cs in acc.items():
+            avg = {cn: v[0] / max(len(v[1]), 1) for cn, v in cs.items()}
+            if "SQ_INSTS_VALU" not in avg:
+                continue
+            e = {"valu_insts": int(avg["SQ_INSTS_VALU"]), "waves": int(avg.get("SQ_WAVES", 0)), "launches_in_pass": len(cs["SQ_INSTS_VALU"][1]),
+                 "valu_per_wave": round(avg["SQ_INSTS_VALU"] / max(avg.get("SQ_WAVES", 1), 1), 1),
+                 "salu_per_wave": round(avg.get("SQ_INSTS_SALU", 0) / max(avg.get("SQ_WAVES", 1), 1), 1),
+                 "lds_per_wave": round(avg.get("SQ_INSTS_LDS", 0) / max(avg.get("SQ_WAVES", 1), 1), 1),
+                 "active_inst_valu_quadcycles": int(avg.get("SQ_ACTIVE_INST_VALU", 0)),
+                 "issue_us_at_peak_clock": round(avg["SQ_INSTS_VALU"] * VALU_ISSUE_CYCLES / N_SIMDS / (SQ_CLOCK_GHZ * 1e3), 2)}
+            if k in dur and dur[k][1]:
+                e["launch_us_under_counters"] = round(dur[k][0] / dur[k][1], 2)
+                if "GRBM_GUI_ACTIVE" in avg and e["launch_us_under_counters"] > 0:
+                    e["clock_ghz_under_counters"] = round(avg["GRBM_GUI_ACTIVE"] / e["launch_us_under_counters"] / 1e3, 3)
+            out[k] = e
+        if out:
+            return out, None
+        err = "no SQ counters in the pass"
+    return None, err
+
+
+def valu_issue_block(sq, roofline, kernels, ms_per_step):
+    """roofline.valu_issue: the ceiling that binds this path.  For the dominant kernel and for the step: vector issue time against
+    the kernel / step time.  frac = issue time at the PEAK clock / measured time (a lower bound of the true fraction: under a VALU-dense kernel the
+    part clocks below its peak -- clock_ghz_under_counters is what the counter pass saw)."""
+    dom = roofline["kernel"]
+    group = STAGE_KERNELS.get(dom, (dom,))
+    rows = {k: v for k, v in sq.items()}
+    dom_issue = sum(rows[k]["issue_us_at_peak_clock"] for k in group if k in rows)
+    dom_us = roofline["avg_launch_ms"] * 1e3
+    blk = {"model": f"SQ_INSTS_VALU x {VALU_ISSUE_CYCLES} cycles / {N_SIMDS} SIMDs / {SQ_CLOCK_GHZ} GHz per launch (in-run rocprofv3 --pmc pass); frac = issue time / measured time",
+           "kernel": dom, "issue_us": round(dom_issue, 1), "launch_us": round(dom_us, 1), "frac": round(dom_issue / dom_us, 3) if dom_us > 0 else None,
+           "valu_per_wave": rows.get(dom, {}).get("valu_per_wave"), "waves": rows.get(dom, {}).get("waves")}
+    clk = rows.get(dom, {}).get("clock_ghz_under_counters")
+    if clk:
+        blk["clock_ghz_under_counters"] = clk
+        blk["frac_at_that_clock"] = round(dom_issue * SQ_CLOCK_GHZ / clk / (rows[dom].get("launch_us_under_counters") or dom_us), 3)
+    # the step: every kernel of the pass x its launches per step (the child pass runs the same step as the timed loop)
+    lps = {}
+    for name, v in kernels.items():
+        for k in STAGE_KERNELS.get(name, (name,)):
+            lps[k] = v["launches_per_step"]
+    step_issue = 0.0
+    for k, v in rows.items():
+        n = next((l for kk, l in lps.items() if k.startswith(kk) or kk.startswith(k)), 1.0)
+        step_issue += v["issue_us_at_peak_clock"] * n
+    blk["step_issue_us"] = round(step_issue, 1)
+    blk["step_frac"] = round(step_issue / (ms_per_step * 1e3), 3)
+    blk["per_kernel"] = rows
+    return blk
+
+
 # ---------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (CPU restatement of the reference path) timed on this box's host cores, bounded sample
 # ---------------------------------------------------------------------------------------------------------
@@ -253,6 +374,8 @@ def cpu_baseline_euroc(frames, n_sample, w, h, nfeat):
             dt = time.perf_counter() - t0
             out["all_cores"] = {"value": round(sum(fs) / dt / 1e3, 3), "unit": "kfeatures/s", "cores": nc,
                                 "sample": f"{nc} threads x {per} frames, {dt:.1f} s"}
+            out["value_all_cores"] = out["all_cores"]["value"]   # flat copies: a reader that keeps only cpu_baseline's scalars sees both figures
+            out["cores_all"] = nc
     except Exception as e:   # the 1-thread baseline stands on its own
         out["all_cores"] = {"error": str(e)[:200]}
     # beside it, when oracle/_ref travelled here: the reference's OWN ORBextractor.cc + ORBmatcher.cc (compiled where they lie in the
@@ -745,6 +868,11 @@ def bench_euroc(R):
                                                       "(FETCH_SIZE tallies gfx950's 128-byte requests at 64 bytes), writes = WRITE_SIZE"}
             else:
                 roofline["traffic_error"] = err
+            sq, err = pmc_sq("euroc", B)
+            if sq:
+                roofline["valu_issue"] = valu_issue_block(sq, roofline, kernels, dt_max / a.steps * 1e3)
+            else:
+                roofline["valu_issue_error"] = err
 
     cpu = None
     if R.rank == 0 and R.world == 1 and a.cpu_frames > 0:

@@ -34,8 +34,10 @@ enum {
     ORBX_E_NO_DEVICE = -5,
     ORBX_E_HIP = -6,         /* a HIP runtime call failed; see orbx_last_error() */
     ORBX_E_TOO_LARGE = -7,   /* image / batch exceeds the limits given at creation, or a dimension > 4095 px */
-    ORBX_E_INTERNAL = -8     /* device-side consistency check failed; orbx_last_error() names the code: 1 more keypoints than the output
+    ORBX_E_INTERNAL = -8,    /* device-side consistency check failed; orbx_last_error() names the code: 1 more keypoints than the output
                               * capacity, 2 / 3 quad-tree node pool / level list overflow */
+    ORBX_E_STALE = -9        /* level 0 of a batch that was extracted in place was requested after orbx_sync / orbx_download_wait released the
+                              * caller's frames (see orbx_get_level) */
 };
 
 /* 28-byte POD with the field layout of cv::KeyPoint {Point2f pt; float size, angle, response; int octave,
@@ -149,9 +151,12 @@ int orbx_download_wait(orbx_extractor *ex);
 /* mvImagePyramid[level] (public member read by Frame::ComputeStereoMatches, Frame.cc:818,908,923): copies the
  * padded level (19-px REFLECT_101 ring included) of `frame` of the last batch to host memory.
  * dst must hold (h+38) rows of dst_stride >= w+38 bytes; the ROI origin is dst + 19*dst_stride + 19.
- * LEVEL 0 of a batched extraction is not copied into the library's pyramid (its kernels read the caller's frames in place): the first
- * orbx_get_level / orbx_get_level_device of level 0 after such a batch writes the padded level from those frames, which must therefore still
- * hold the batch (the frames of orbx_extract_batch_host are kept by the library until the call after the next). */
+ * LEVEL 0 of a batched extraction of ps_min_frames (48) frames or more is not copied into the library's pyramid (its kernels read the caller's
+ * frames in place): the first orbx_get_level / orbx_get_level_device of level 0 after such a batch writes the padded level from those frames.
+ * That is only possible while the frames are still the library's to read, i.e. BEFORE the orbx_sync / orbx_download_wait that hands them back to
+ * the caller: afterwards the request fails with ORBX_E_STALE rather than return a level built from whatever the buffer holds by then.  (The frames
+ * of orbx_extract_batch_host live in the library's upload slab, which is kept until the call after the next.)  orbx_get_level_device(0) of such a
+ * batch synchronises the extractor's stream before it returns the pointer; for every other level and batch it is a pure getter. */
 int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_t dst_stride);
 int orbx_level_size(orbx_extractor *ex, int width, int height, int level, int *w, int *h);
 /* Device pointer to the padded level (for device-resident consumers such as the stereo matcher). */
@@ -211,6 +216,9 @@ void orbx_matcher_destroy(orbx_matcher *m);
  * moved by the lanes of a k_xfer launch in the call's own queue (a projection-matcher call: 1 run up, 1 down, 2 launches, no DMA submission), larger
  * ones by the DMA engine; ORBX_MATCHER_DMA=1 sends everything through the DMA engine (round 5's transport).  Returns the entries written, or < 0. */
 int orbx_matcher_debug_transfers(const orbx_matcher *m, int64_t *out, int cap);
+/* Test hook: the replay of the context's last orbx_search_for_initialization (k_replay_init_lists): out3[0] = rounds of its chunk loop, out3[1] = queries whose
+ * candidate list ran dry and were re-scanned by the whole wave, out3[2] = queries (level-0 keypoints of F1).  Returns 3, or < 0. */
+int orbx_matcher_debug_replay_stats(const orbx_matcher *m, int32_t *out3);
 
 /* ORBmatcher::TH_LOW / TH_HIGH / HISTO_LENGTH (ORBmatcher.cc:35-37) */
 #define ORBX_TH_LOW 50

@@ -22,6 +22,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 ORBX_OK = 0
 ORBX_E_EMPTY = -1
+ORBX_E_STALE = -9
 FLAG_DESC_STRICT = 1
 FLAG_BLUR_OCV440 = 2
 FLAG_ATAN_FMA = 4
@@ -96,7 +97,7 @@ SYMBOLS = [
     "orbx_get_level_device", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_scale_tables",
     "orbx_get_feature_tables", "orbx_debug_level_candidates", "orbx_debug_level_keypoints",
     "orbx_debug_level_blurred", "orbx_debug_stage_stats", "orbx_tune_fast_queues", "orbx_debug_fused_patches", "orbx_profile_enable", "orbx_profile_read", "orbx_matcher_create",
-    "orbx_matcher_destroy", "orbx_matcher_debug_transfers", "orbx_hamming_csr", "orbx_hamming_best2_csr", "orbx_knn2", "orbx_stereo_rowband",
+    "orbx_matcher_destroy", "orbx_matcher_debug_transfers", "orbx_matcher_debug_replay_stats", "orbx_hamming_csr", "orbx_hamming_best2_csr", "orbx_knn2", "orbx_stereo_rowband",
     "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
     "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window", "orbx_search_by_projection_mappoints_fisheye", "orbx_search_by_projection_frame_fisheye",
     "orbx_search_by_bow_frame_fisheye", "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_is_in_frustum", "orbx_frustum_batch_device",
@@ -153,6 +154,7 @@ def lib() -> C.CDLL:
     L.orbx_matcher_create.argtypes = [i32, C.POINTER(vp)]
     L.orbx_matcher_destroy.argtypes = [vp]
     L.orbx_matcher_debug_transfers.argtypes = [vp, vp, i32]
+    L.orbx_matcher_debug_replay_stats.argtypes = [vp, vp]
     L.orbx_hamming_csr.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     L.orbx_hamming_best2_csr.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     L.orbx_knn2.argtypes = [vp, vp, i32, vp, i32, vp, vp]

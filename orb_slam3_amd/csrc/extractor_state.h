@@ -143,6 +143,12 @@ struct orbx_extractor {
     // keeps untouched until orbx_sync / orbx_download_wait) and leaves the slab's level 0 unwritten; the few readers of the padded level 0
     // (orbx_get_level, the stereo rig's SAD stage, the blurred-level debug readout) materialise it first: materialize_level0()
     bool lvl0_inplace = false;
+    // level 0 of an in-place batch is written on REQUEST from the caller's frames -- which include/orbx.h lets the caller overwrite after orbx_sync /
+    // orbx_download_wait.  Those two calls therefore mark the frames released; a request for level 0 after that is refused (ORBX_E_STALE) instead of
+    // answered from whatever the buffer holds by then.  in0_copy_seq = downloads issued when the batch was enqueued (a download issued later covers it).
+    bool in0_released = false;
+    unsigned in0_copy_seq = 0;
+    hipEvent_t in0_event = nullptr;   // "input consumed" event of the in-place batch (upload slab of orbx_extract_batch_host): re-recorded behind the materialisation
     const uint8_t *in0_images = nullptr;
     size_t in0_row_stride = 0, in0_frame_stride = 0;
     int n_strips0 = 0;          // level-0 strips of k_fast_strip (the first of a frame)

@@ -900,7 +900,7 @@ __device__ __forceinline__ u64 seq_key(int dist, int seq, int idx) {
 // query.  k_greedy_resolve falls back to a re-scan when it needs more than the valid part of a non-exhaustive list.
 template <int LQ>   // lanes per query: 16, 8 or 4
 __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__restrict__ probs, GridParams g, int n_problems) {
-    static_assert(LQ == 16 || LQ == 8 || LQ == 4, "lanes per query");
+    static_assert(LQ == 64 || LQ == 16 || LQ == 8 || LQ == 4, "lanes per query");
     const int prob = (int)(blockIdx.z * gridDim.x + blockIdx.x);   // grid (8, query blocks, problems / 8): x is the XCD, a problem's blocks share one L2
     if (prob >= n_problems) return;
     const WindowProblem P = probs[prob];
@@ -1463,6 +1463,237 @@ __global__ __launch_bounds__(64) void k_replay_init(InitProblem P, GridParams g)
     if (lane == 0) *P.nmatches = nmatches;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// SearchForInitialization, round 6.  k_replay_init above scans ALL of F2 per query on one wave: 27.6 ms for the 5 x nFeatures extractor of the
+// monocular initialisation (4993 x 4993 keypoints, 1086 level-0 queries, 100-px windows) against 2.0 ms on one CPU core.  Here the work that does not
+// depend on the loop's state runs wide, and only the state-dependent decisions are replayed:
+//   k_grid_build + k_window_best2_t<64>   F2's grid; per query (= level-0 keypoint of F1, index order) the kTopK smallest candidate keys of its window in
+//                                         the reference's (distance, enumeration order) order -- no state involved
+//   k_replay_init_lists (one wave)        the loop of :661-730 over chunks of 64 queries.  What a query may take depends on earlier queries only through
+//                                         vMatchedDistance (:687 skips a candidate already matched at a distance <= its own): every lane picks the first two
+//                                         entries of its list that the CURRENT vMatchedDistance does not skip, lanes that would change a vMatchedDistance a
+//                                         later lane has looked at make that lane wait (LDS claims, as k_greedy_resolve), the conflict-free prefix commits in
+//                                         parallel (vnMatches12 / vnMatches21 / vMatchedDistance in LDS), and a query whose list runs dry before two
+//                                         unskipped entries are known is re-scanned by the whole wave against the state of that moment -- exactly what the
+//                                         sequential loop sees.  The rotation histogram is a sum (bins computed after the loop from the accepted pairs).
+// dynamic LDS: claim u32[n2] | vMatchedDistance u16[n2] | vnMatches21 u16[n2] | vnMatches12 u16[n1]   (0xffff = INT_MAX / -1; n1, n2 <= kMaxResolveFeatures)
+// ---------------------------------------------------------------------------------------------------------
+struct InitReplay {
+    const int32_t *q_index;         // [nq] F1 feature index of query q
+    const orbx_keypoint *kps1;      // F1.mvKeysUn
+    int n1, n2, nq;
+    float nnratio; int check_orientation;
+    float *prev_matched;            // [n1][2], updated at the end (:757-760)
+    int32_t *matches12;             // out [n1]
+    int32_t *entries;               // scratch [nq]: accepted pairs i1 << 16 | i2 in query order (rotHist pushes, :716-727)
+    int32_t *nmatches;              // out
+};
+
+// the window of ONE query scanned by the whole wave against the current vMatchedDistance (scan_window_grid with the skip rule of :687-688)
+__device__ __forceinline__ void scan_window_grid_md(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n, const uint16_t *md,
+                                                    int lane, u64 &k1, u64 &k2) {
+    const int ncol = w.cx1 - w.cx0 + 1;
+    int cs = 0, len = 0;
+    if (lane < ncol) {
+        const int base = (w.cx0 + lane) * 48;
+        cs = gld(P.gstart + base + w.cy0);
+        len = (int)gld(P.gstart + base + w.cy1 + 1) - cs;
+    }
+    int incl = len;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int t = __shfl_up(incl, s);
+        if (lane >= s) incl += t;
+    }
+    const int pre = incl - len, total = __shfl(incl, 63);
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        int j = -1;
+        for (int c = 0; c < ncol; c++) {
+            const int pc = __shfl(pre, c), sc = __shfl(cs, c);
+            if (t >= pc) j = sc + (t - pc);
+        }
+        const bool v0 = t < total && j >= 0;
+        const int i0 = v0 ? (int)gld(P.gorder + j) : 0;
+        const bool v1 = v0 && i0 < n;
+        const int i = v1 ? i0 : 0;
+        const orbx_keypoint kp = gld_kp(P.kps + i);
+        const Desc dc = gld_desc(P.desc + (size_t)i * 32);
+        if (!v1) continue;
+        int cx, cy;
+        if (!in_window(g, w, kp, &cx, &cy)) continue;
+        const int d = hamming(dq, dc);
+        if ((int)md[i] <= d) continue;   // :687-688 (0xffff = INT_MAX: never)
+        push2(k1, k2, cand_key(d, cx, cy, i));
+    }
+}
+
+__global__ __launch_bounds__(64) void k_replay_init_lists(const WindowProblem *__restrict__ prob, InitReplay R, GridParams g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ int hist[ORBX_HISTO_LENGTH + 2];
+    const WindowProblem P = prob[0];
+    const int lane = threadIdx.x, n1 = R.n1, n2 = R.n2, nq = R.nq;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    uint32_t *claim = reinterpret_cast<uint32_t *>(lds);
+    uint16_t *md = reinterpret_cast<uint16_t *>(lds + (size_t)n2 * 4);
+    uint16_t *m21 = md + n2;
+    uint16_t *m12 = m21 + n2;
+    for (int i = lane; i < n2; i += 64) { claim[i] = 0xffffffffu; md[i] = 0xffffu; m21[i] = 0xffffu; }
+    for (int i = lane; i < n1; i += 64) m12[i] = 0xffffu;
+    if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0, n_entries = 0, n_rounds = 0, n_rescans = 0;
+    struct Chunk { u64 L0, L1, L2, L3; int meta, i1; };
+    auto fetch = [&](int q0) -> Chunk {
+        Chunk c = {kNoKey, kNoKey, kNoKey, kNoKey, 256, 0};   // inactive lane: empty exhaustive list
+        const int qi = q0 + lane;
+        if (qi < nq) {
+            const u64 *kp = P.keys + (size_t)qi * kTopK;
+            c.L0 = gld(kp); c.L1 = gld(kp + 1); c.L2 = gld(kp + 2); c.L3 = gld(kp + 3);
+            c.meta = gld(P.meta + qi);
+            c.i1 = gld(R.q_index + qi);
+        }
+        return c;
+    };
+    // best / second best of a lane's list under the current vMatchedDistance; *slow: the list cannot answer (ran dry before what decides the query is known)
+    auto pick = [&](const u64 (&L)[kTopK], int valid_len, bool exhaustive, u64 *c1, u64 *c2, bool *slow) {
+        u64 a = kNoKey, b = kNoKey;
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) {
+            const u64 k = L[e];
+            if (e < valid_len && !((int)md[(int)(k & 0xffff)] <= (int)(k >> 32))) {
+                if (a == kNoKey) a = k;
+                else if (b == kNoKey) b = k;
+            }
+        }
+        *c1 = a; *c2 = b;
+        // what the list has not seen sorts behind its last valid entry: with that entry's distance above TH_LOW nothing unseen can become the best match
+        const int floor_d = valid_len > 0 ? (int)(L[valid_len - 1] >> 32) : 0;
+        bool s = false;
+        if (!exhaustive) {
+            if (a == kNoKey) s = floor_d <= ORBX_TH_LOW;                                 // best unknown
+            else if (b == kNoKey && (int)(a >> 32) <= ORBX_TH_LOW) s = true;             // second best unknown, and the ratio test will ask for it
+        }
+        *slow = s;
+    };
+    auto accept = [&](u64 c1, u64 c2) -> bool {   // :707-711
+        if (c1 == kNoKey) return false;
+        const int best = (int)(c1 >> 32);
+        const float second = (c2 == kNoKey) ? (float)INT_MAX : (float)(int)(c2 >> 32);
+        return best <= ORBX_TH_LOW && (float)best < second * R.nnratio;
+    };
+    Chunk nxt = fetch(0);
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int qi = q0 + lane;
+        const bool active = qi < nq;
+        const Chunk C = nxt;
+        asm volatile("" :: "v"(C.L0), "v"(C.L1), "v"(C.L2), "v"(C.L3), "v"(C.meta), "v"(C.i1) : "memory");   // this chunk's lists have arrived before the next chunk's are requested
+        nxt = fetch(q0 + 64);
+        const u64 L[kTopK] = {C.L0, C.L1, C.L2, C.L3};
+        const int valid_len = C.meta & 0xff, i1 = C.i1;
+        const bool exhaustive = (C.meta & 256) != 0;
+        int pos = 0;
+        while (pos < 64) {
+            const bool live = active && lane >= pos;
+            u64 c1 = kNoKey, c2 = kNoKey;
+            bool need_slow = false;
+            n_rounds++;
+            if (live) pick(L, valid_len, exhaustive, &c1, &c2, &need_slow);
+            const bool has = live && !need_slow && accept(c1, c2);
+            const int t1 = has ? (int)(c1 & 0xffff) : -1;
+            if (has) atomicMin(&claim[t1], (uint32_t)lane);
+            one_wave_sync();
+            // a lane must wait for every earlier lane of this round that is about to change a vMatchedDistance it has looked at (all valid entries of its list)
+            bool conflict = need_slow;
+            if (live && !need_slow) {
+#pragma unroll
+                for (int e = 0; e < kTopK; e++)
+                    if (e < valid_len && claim[(int)(L[e] & 0xffff)] < (uint32_t)lane) conflict = true;
+            }
+            one_wave_sync();
+            if (has) claim[t1] = 0xffffffffu;
+            const u64 cb = __ballot(conflict);
+            const int c = cb ? (__ffsll((long long)cb) - 1) : 64;
+            const bool ok = has && lane < c;
+            const u64 okb = __ballot(ok);
+            bool unmatched = false;
+            if (ok) {   // :713-727; the targets of one round's commits are distinct (two lanes with one target: the later one conflicts), and so are their former owners
+                const int old = m21[t1];
+                if (old != 0xffff) { m12[old] = 0xffffu; unmatched = true; }
+                m12[i1] = (uint16_t)t1;
+                m21[t1] = (uint16_t)i1;
+                md[t1] = (uint16_t)(c1 >> 32);
+                gst(R.entries + n_entries + __popcll(okb & lt_mask), (i1 << 16) | t1);
+            }
+            nmatches += __popcll(okb) - __popcll(__ballot(unmatched));
+            n_entries += __popcll(okb);
+            one_wave_sync();
+            if (c >= 64) break;
+            const bool slow = (__shfl((int)need_slow, c) != 0);
+            if (!slow) { pos = c; continue; }   // lane c re-evaluates against the updated state
+            {   // query q0 + c: its window scanned by the whole wave against the state the sequential loop has at this point
+                const int qc = q0 + c;
+                const int i1c = __shfl(i1, c);
+                n_rescans++;
+                QueryWin w;
+                Desc dq;
+                u64 r1 = kNoKey, r2 = kNoKey;
+                if (load_query_eager(P, qc, &w, g, &dq)) {
+                    scan_window_grid_md(P, g, w, dq, n2, md, lane, r1, r2);
+                    wave_min2(r1, r2);
+                }
+                if (accept(r1, r2)) {
+                    const int t = (int)(r1 & 0xffff);
+                    const int old = m21[t];
+                    one_wave_sync();
+                    if (lane == 0) {
+                        if (old != 0xffff) m12[old] = 0xffffu;
+                        m12[i1c] = (uint16_t)t;
+                        m21[t] = (uint16_t)i1c;
+                        md[t] = (uint16_t)(r1 >> 32);
+                        gst(R.entries + n_entries, (i1c << 16) | t);
+                    }
+                    nmatches += 1 - (old != 0xffff ? 1 : 0);
+                    n_entries++;
+                }
+                one_wave_sync();
+            }
+            pos = c + 1;
+        }
+    }
+    __syncthreads();   // the entries are in memory (and visible to the wave's own loads) from here on
+    if (R.check_orientation) {   // :733-755: bins of the accepted pairs, ComputeThreeMaxima, pairs of the losing bins dropped if they still stand
+        for (int e = lane; e < n_entries; e += 64) {
+            const int v = gld(R.entries + e), a = (int)((uint32_t)v >> 16), b = v & 0xffff;
+            atomicAdd(&hist[dev_rot_bin(gld(&R.kps1[a].angle), gld(&P.kps[b].angle))], 1);
+        }
+        __syncthreads();
+        int ind1, ind2, ind3;
+        dev_three_maxima(hist, ind1, ind2, ind3);
+        int dropped = 0;
+        for (int e = lane; e < n_entries; e += 64) {
+            const int v = gld(R.entries + e), a = (int)((uint32_t)v >> 16), b = v & 0xffff;
+            const int bin = dev_rot_bin(gld(&R.kps1[a].angle), gld(&P.kps[b].angle));
+            // an index may sit in the histogram after it was unmatched (:746): only pairs that still stand are dropped and counted
+            if (bin != ind1 && bin != ind2 && bin != ind3 && m12[a] != 0xffff) { m12[a] = 0xffffu; dropped++; }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) dropped += __shfl_xor(dropped, s);
+        nmatches -= dropped;
+        __syncthreads();
+    }
+    for (int i = lane; i < n1; i += 64) {   // vnMatches12 out; :757-760 vbPrevMatched
+        const int m = m12[i];
+        gst(R.matches12 + i, m == 0xffff ? -1 : m);
+        if (m != 0xffff) {
+            const orbx_keypoint kp = gld_kp(P.kps + m);
+            gst(R.prev_matched + 2 * i, kp.x);
+            gst(R.prev_matched + 2 * i + 1, kp.y);
+        }
+    }
+    if (lane == 0) { gst(R.nmatches, nmatches); gst(R.nmatches + 1, n_rounds); gst(R.nmatches + 2, n_rescans); gst(R.nmatches + 3, nq); }   // [1..3]: orbx_matcher_debug_replay_stats
+}
+
 struct FeatVecDev { const uint32_t *node_id; const int32_t *node_ptr; const int32_t *index; int n_nodes; };
 
 // The geometric gates of SearchForTriangulation for pinhole key frames (ORBmatcher.cc:1026-1034 epipole distance,
@@ -1525,6 +1756,7 @@ struct BowProblem {
     int32_t *hist;       // scratch [ORBX_HISTO_LENGTH], zeroed: rotation histogram over all nodes
     int32_t *counters;   // scratch [2], zeroed: entries appended, matches accepted
     int32_t *nmatches;
+    const int32_t *pair_b;   // [fa.n_nodes] index of the node with the same id in fb, or -1 (merge-join of the two sorted node-id lists, done by the host)
 };
 
 // k_replay_bow: the query loops of SearchByBoW x 2 / SearchForTriangulation, ONE WAVE PER VOCABULARY NODE of A's feature vector.  The reference walks
@@ -1535,21 +1767,16 @@ struct BowProblem {
 // node overlaps those chains.  The rotation histogram and the match count are sums over the nodes (global atomics), the consistency filter
 // (ComputeThreeMaxima) runs in k_replay_bow_finish.
 // grid ceil(fa.n_nodes / 4), block 256; P.hist / P.counters zeroed, P.match = -1, P.taken_b = 0 by the host before the launch
-__global__ __launch_bounds__(256) void k_replay_bow(BowProblem P) {
-    const int lane = threadIdx.x & 63;
-    const int ia = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (ia >= P.fa.n_nodes) return;
+// Round 6: (a) the node pairing (the merge-join of the two sorted maps) comes from the host as pair_b[ia] -- the binary search it replaces was seven
+// dependent global loads per wave; (b) a node whose B list has at most 64 features runs REGISTER-RESIDENT (replay_bow_node64): lane l holds candidate l --
+// its index, descriptor, skip flag, angle, and for the triangulation gates its keypoint and level constants -- and the taken-state of the candidate
+// (vpMapPointMatches[idx] != NULL / vbMatched2[idx], which only this wave ever changes: a feature lies in exactly one node) in a register; the queries of the
+// node are preloaded the same way, 64 at a time, and broadcast one by one.  The query loop then touches no memory at all except fire-and-forget result
+// stores: 44 -> 9 us for 1000 x 1000 features in 100 nodes (every query of the first form walked index -> flags -> descriptor -> state, each a
+// dependent round trip).  Larger B lists keep the first form (replay_bow_big_node).
+// grid ceil(fa.n_nodes / 4), block 256; P.hist / P.counters zeroed, P.match = -1, P.taken_b = 0 before the launch (orbx_matcher::fill)
+__device__ __attribute__((noinline)) void replay_bow_big_node(const BowProblem &P, const int ia, const int ib, const int lane) {
     const bool toB = (P.mode == 0 || P.mode == 3);   // results are indexed by B's features
-    // the node of B with the same id (:246-250, :800-805, :961-965 merge-join the two sorted maps): binary search
-    const uint32_t id = P.fa.node_id[ia];
-    int lo = 0, hi = P.fb.n_nodes - 1, ib = -1;
-    while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        const uint32_t v = P.fb.node_id[mid];
-        if (v == id) { ib = mid; break; }
-        if (v < id) lo = mid + 1; else hi = mid - 1;
-    }
-    if (ib < 0) return;
     int nmatches = 0;
     const int a0 = P.fa.node_ptr[ia], a1 = P.fa.node_ptr[ia + 1], b0 = P.fb.node_ptr[ib], b1 = P.fb.node_ptr[ib + 1];
     auto record = [&](int a_idx, int b_idx, int out_idx) {   // lane 0: the rotation bin of an accepted match
@@ -1622,6 +1849,163 @@ __global__ __launch_bounds__(256) void k_replay_bow(BowProblem P) {
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && nmatches) atomicAdd(&P.counters[1], nmatches);
+}
+
+
+__device__ __forceinline__ Desc shfl_desc(const Desc &d, int src) {
+    Desc r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.w[k] = __shfl(d.w[k], src);
+    return r;
+}
+
+// tri_gate with both keypoints' fields in registers (the same operations in the same order)
+__device__ __forceinline__ bool tri_gate_regs(const TriGate &g, float x1, float y1, bool st1, float x2, float y2, bool st2, float scale2_o, float sigma2_o) {
+    if (!st1 && !st2) {
+        const float dx = __fsub_rn(g.ex, x2), dy = __fsub_rn(g.ey, y2);
+        const float d2 = g.strict ? __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) : __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+        if (d2 < __fmul_rn(100.0f, scale2_o)) return false;
+    }
+    if (g.coarse) return true;
+    float a, b, c, num, den;
+    if (g.strict) {
+        a = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F[0]), __fmul_rn(y1, g.F[3])), g.F[6]);
+        b = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F[1]), __fmul_rn(y1, g.F[4])), g.F[7]);
+        c = __fadd_rn(__fadd_rn(__fmul_rn(x1, g.F[2]), __fmul_rn(y1, g.F[5])), g.F[8]);
+        num = __fadd_rn(__fadd_rn(__fmul_rn(a, x2), __fmul_rn(b, y2)), c);
+        den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+    } else {
+        a = __fadd_rn(__fmaf_rn(x1, g.F[0], __fmul_rn(y1, g.F[3])), g.F[6]);
+        b = __fadd_rn(__fmaf_rn(x1, g.F[1], __fmul_rn(y1, g.F[4])), g.F[7]);
+        c = __fadd_rn(__fmaf_rn(y1, g.F[5], __fmul_rn(x1, g.F[2])), g.F[8]);
+        num = __fadd_rn(__fmaf_rn(b, y2, __fmul_rn(a, x2)), c);
+        den = __fmaf_rn(a, a, __fmul_rn(b, b));
+    }
+    if (den == 0.f) return false;
+    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+    return (double)dsqr < __dmul_rn(3.84, (double)sigma2_o);
+}
+
+__device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int a0, const int a1, const int b0, const int nbn, const int lane) {
+    const int mode = P.mode;
+    const bool gated = mode == 2 && P.gate.enabled;
+    // ---- candidate `lane` of B's list ----
+    const bool cv = lane < nbn;
+    const int j = cv ? P.fb.index[b0 + lane] : 0;
+    const bool cskip = cv && P.skip_b && P.skip_b[j];
+    const Desc dc = load_desc(P.desc_b + (size_t)j * 32);
+    const float ang_b = (P.check_orientation && cv) ? P.angle_b[j] : 0.f;
+    float x2 = 0.f, y2 = 0.f, sc2 = 0.f, sg2 = 0.f;
+    bool st2 = false;
+    if (gated && cv) {
+        x2 = P.gate.k2[j].x; y2 = P.gate.k2[j].y;
+        const int o2 = P.gate.k2[j].octave;
+        sc2 = P.gate.scale2[o2]; sg2 = P.gate.sigma2_2[o2];
+        st2 = P.gate.ur2 && P.gate.ur2[j] >= 0.f;
+    }
+    const bool right = mode == 3 && j >= P.nb_left;
+    bool taken = false;   // vpMapPointMatches[realIdxF] != NULL (:281) / vbMatched2[idx2] (:826): nothing but this wave's own matches sets them
+    int nmatches = 0;
+    for (int q0 = a0; q0 < a1; q0 += 64) {
+        // ---- query `lane` of this chunk of A's list ----
+        const bool qv = q0 + lane < a1;
+        const int i = qv ? P.fa.index[q0 + lane] : 0;
+        const bool qskip = !qv || (P.skip_a && P.skip_a[i]);
+        const Desc dqa = load_desc(P.desc_a + (size_t)i * 32);
+        const float ang_a = (P.check_orientation && qv) ? P.angle_a[i] : 0.f;
+        float x1 = 0.f, y1 = 0.f;
+        bool st1 = false;
+        if (gated && qv) { x1 = P.gate.k1[i].x; y1 = P.gate.k1[i].y; st1 = P.gate.ur1 && P.gate.ur1[i] >= 0.f; }
+        int e0 = -1, e1 = -1;   // this lane's QUERY produced these histogram entries (bin << 16 | out index); mode 3 can produce two
+        const int nqc = min(64, a1 - q0);
+        for (int q = 0; q < nqc; q++) {
+            if (__shfl((int)qskip, q)) continue;   // wave-uniform
+            const int iq = __shfl(i, q);
+            const Desc dq = shfl_desc(dqa, q);
+            const float aq = __shfl(ang_a, q);
+            float xq = 0.f, yq = 0.f;
+            bool stq = false;
+            if (gated) { xq = __shfl(x1, q); yq = __shfl(y1, q); stq = __shfl((int)st1, q) != 0; }   // (wave-uniform branch: every lane takes part)
+            u64 k1 = kNoKey, k2 = kNoKey, r1 = kNoKey, r2 = kNoKey;
+            if (cv && !cskip && !(taken && mode != 2)) {
+                const int d = hamming(dq, dc);
+                if (mode == 2) {
+                    bool ok = d <= ORBX_TH_LOW;   // :1017
+                    if (ok && gated) ok = tri_gate_regs(P.gate, xq, yq, stq, x2, y2, st2, sc2, sg2);
+                    if (ok) k1 = ((u64)(uint32_t)d << 32) | (u64)(0xffffffffu - (uint32_t)lane);   // a later equal candidate wins
+                } else if (right) {
+                    r1 = ((u64)(uint32_t)d << 32) | (u64)(uint32_t)lane;
+                } else {
+                    k1 = ((u64)(uint32_t)d << 32) | (u64)(uint32_t)lane;
+                }
+            }
+            wave_min2(k1, k2);
+            if (mode == 3) {
+                wave_min2(r1, r2);
+                if (k1 == kNoKey || (int)(k1 >> 32) > ORBX_TH_LOW) continue;
+                const int bestL = (int)(k1 >> 32);
+                const float secondL = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
+                const int pl = (int)(uint32_t)(k1 & 0xffffffffu);
+                const bool okL = (float)bestL < P.nnratio * secondL;
+                const bool okR = r1 != kNoKey && (int)(r1 >> 32) <= ORBX_TH_LOW;
+                const int pr = okR ? (int)(uint32_t)(r1 & 0xffffffffu) : -1;
+                if (okL && lane == pl) { taken = true; P.match[j] = iq; if (P.check_orientation) atomicAdd(&P.hist[dev_rot_bin(aq, ang_b)], 1); }
+                if (okR && lane == pr) { taken = true; P.match[j] = iq; if (P.check_orientation) atomicAdd(&P.hist[dev_rot_bin(aq, ang_b)], 1); }
+                if (P.check_orientation) {
+                    const int jl = __shfl(j, pl), binl = dev_rot_bin(aq, __shfl(ang_b, pl));
+                    const int jr = __shfl(j, okR ? pr : 0), binr = dev_rot_bin(aq, __shfl(ang_b, okR ? pr : 0));
+                    if (lane == q) { if (okL) e0 = (binl << 16) | jl; if (okR) e1 = (binr << 16) | jr; }
+                }
+                nmatches += (okL ? 1 : 0) + (okR ? 1 : 0);
+                continue;
+            }
+            if (k1 == kNoKey) continue;
+            const int best = (int)(k1 >> 32);
+            const int pos = mode == 2 ? (int)(0xffffffffu - (uint32_t)(k1 & 0xffffffffu)) : (int)(uint32_t)(k1 & 0xffffffffu);
+            const float second = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
+            bool ok;
+            if (mode == 0) ok = best <= ORBX_TH_LOW && (float)best < P.nnratio * second;      // :318-320
+            else if (mode == 1) ok = best < ORBX_TH_LOW && (float)best < P.nnratio * second;  // :848-850 (strict)
+            else ok = true;
+            if (!ok) continue;
+            nmatches++;
+            const int jw = __shfl(j, pos);
+            const int out_idx = mode == 0 ? jw : iq, out_val = mode == 0 ? iq : jw;
+            if (lane == pos) {
+                if (mode != 2) taken = true;
+                P.match[out_idx] = out_val;
+                if (P.check_orientation) atomicAdd(&P.hist[dev_rot_bin(aq, ang_b)], 1);
+            }
+            if (P.check_orientation) {
+                const int bin = dev_rot_bin(aq, __shfl(ang_b, pos));
+                if (lane == q) e0 = (bin << 16) | out_idx;
+            }
+        }
+        if (P.check_orientation) {   // the chunk's histogram entries: one returned atomic for all of them (order is not observable: the finish kernel drops by bin)
+            const u64 b0m = __ballot(e0 >= 0), b1m = __ballot(e1 >= 0);
+            const int tot = __popcll(b0m) + __popcll(b1m);
+            if (tot) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&P.counters[0], tot);
+                base = __shfl(base, 0);
+                const u64 lt = (1ull << lane) - 1ull;
+                if (e0 >= 0) P.entries[base + __popcll(b0m & lt)] = e0;
+                if (e1 >= 0) P.entries[base + __popcll(b0m) + __popcll(b1m & lt)] = e1;
+            }
+        }
+    }
+    if (lane == 0 && nmatches) atomicAdd(&P.counters[1], nmatches);
+}
+
+__global__ __launch_bounds__(256) void k_replay_bow(BowProblem P) {
+    const int lane = threadIdx.x & 63;
+    const int ia = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (ia >= P.fa.n_nodes) return;
+    const int ib = P.pair_b[ia];   // the node of B with the same id (:246-250, :800-805, :961-965 merge-join the two sorted maps), -1: none
+    if (ib < 0) return;
+    const int a0 = P.fa.node_ptr[ia], a1 = P.fa.node_ptr[ia + 1], b0 = P.fb.node_ptr[ib], b1 = P.fb.node_ptr[ib + 1];
+    if (b1 - b0 <= 64) replay_bow_node64(P, a0, a1, b0, b1 - b0, lane);
+    else replay_bow_big_node(P, ia, ib, lane);
 }
 
 // the rotation-consistency filter over the matches of all nodes (:401-416, :882-897, :1120-1137) and the match count

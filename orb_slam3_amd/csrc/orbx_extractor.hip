@@ -697,10 +697,16 @@ static int launch_pyr_base(orbx_extractor *ex, const uint8_t *d_images, int n, s
 int orbx_materialize_level0(orbx_extractor *ex) {
     if (!ex) return ORBX_E_BAD_ARG;
     if (!ex->lvl0_inplace) return ORBX_OK;
+    if (ex->in0_released) {
+        set_error("level 0 of the last batch was read in place from the caller's frames and never copied; orbx_sync / orbx_download_wait have since released "
+                  "those frames to the caller -- ask for level 0 (orbx_get_level / orbx_get_level_device) before that call");
+        return ORBX_E_STALE;
+    }
     ORBX_HIP(hipSetDevice(ex->device));
     int r = orbx::launch_pyr_base(ex, ex->in0_images, ex->last_batch, ex->in0_row_stride, ex->in0_frame_stride, ex->pyr_cur(), ex->stream, false);
     if (r != ORBX_OK) return r;
     ORBX_HIP(hipEventRecord(ex->ev_describe, ex->stream));
+    if (ex->in0_event) ORBX_HIP(hipEventRecord(ex->in0_event, ex->stream));   // the upload slab the frames lie in stays busy until k_pyr_base has read it
     ex->lvl0_inplace = false;
     return ORBX_OK;
 }
@@ -739,6 +745,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
     const Level0Src src0 = inplace0 ? Level0Src{d_images, row_stride, frame_stride} : Level0Src{nullptr, 0, 0};
     ex->lvl0_inplace = inplace0;
     ex->in0_images = d_images; ex->in0_row_stride = row_stride; ex->in0_frame_stride = frame_stride;
+    ex->in0_released = false; ex->in0_copy_seq = ex->copy_issued; ex->in0_event = inplace0 ? ev_input_consumed : nullptr;
     if (!inplace0) {
         int r = launch_pyr_base(ex, d_images, n, row_stride, frame_stride, pyr, pst, true);
         if (r != ORBX_OK) return r;
@@ -938,6 +945,7 @@ const char *orbx_status_string(int s) {
         case ORBX_E_HIP: return "HIP runtime error";
         case ORBX_E_TOO_LARGE: return "image or batch too large";
         case ORBX_E_INTERNAL: return "internal device-side check failed";
+        case ORBX_E_STALE: return "level 0 requested after the caller's frames were released";
         default: return s > 0 ? "ok" : "unknown error";
     }
 }
@@ -1178,6 +1186,7 @@ int orbx_sync(orbx_extractor *ex) {
     ORBX_HIP(hipStreamSynchronize(ex->aux_stream));
     ORBX_HIP(hipStreamSynchronize(ex->match_stream));
     ORBX_HIP(hipStreamSynchronize(ex->in_stream));
+    if (ex->lvl0_inplace) ex->in0_released = true;   // the caller may overwrite the frames from here on (include/orbx.h)
     return ORBX_OK;
 }
 
@@ -1283,6 +1292,7 @@ int orbx_download_wait(orbx_extractor *ex) {
     const unsigned slot = ex->copy_waited & 1;
     ORBX_HIP(hipEventSynchronize(ex->ev_copy_done[slot]));
     ex->copy_waited++;
+    if (ex->lvl0_inplace && ex->copy_waited > ex->in0_copy_seq) ex->in0_released = true;   // a download issued after the in-place batch has completed: its frames are the caller's again
     if (ex->h_err[slot] != 0) {
         set_error("device-side consistency check failed, code " + std::to_string(ex->h_err[slot]));
         ex->h_err[slot] = 0;
@@ -1357,7 +1367,11 @@ int orbx_get_level(orbx_extractor *ex, int frame, int level, uint8_t *dst, size_
 int orbx_get_level_device(orbx_extractor *ex, int frame, int level, const uint8_t **d_padded, size_t *pitch) {
     if (!ex || frame < 0 || frame >= ex->last_batch || level < 0 || level >= ex->prm.nlevels) return ORBX_E_BAD_ARG;
     const LevelInfo &L = ex->lv[level];
-    if (level == 0) { int r0 = orbx_materialize_level0(ex); if (r0 != ORBX_OK) return r0; }
+    if (level == 0 && ex->lvl0_inplace) {   // not a pure getter then: the level is written now -- complete before the pointer is handed out
+        int r0 = orbx_materialize_level0(ex);
+        if (r0 != ORBX_OK) return r0;
+        ORBX_HIP(hipStreamSynchronize(ex->stream));
+    }
     if (d_padded) *d_padded = (const uint8_t *)ex->pyr_cur() + (size_t)frame * ex->pyr_frame + L.off + kRingX;
     if (pitch) *pitch = L.pitch;
     return ORBX_OK;

@@ -112,6 +112,7 @@ struct orbx_matcher {
     int64_t xfers[6] = {0, 0, 0, 0, 0, 0};   // transfer submissions (runs) up / down and their bytes since begin(); [4] of them by a DMA engine, [5] k_xfer launches
     bool kernel_xfer = true;                 // ORBX_MATCHER_DMA=1: every run by hipMemcpyAsync, fills by hipMemsetAsync (round 5's transport, for A/B)
     bool dirty = false;                      // something was enqueued since the last synchronisation
+    int32_t replay_stats[3] = {0, 0, 0};     // k_replay_init_lists of the last orbx_search_for_initialization: rounds, whole-wave re-scans, queries
     static constexpr size_t kPadGap = 255;   // Arena::take aligns to 256
     static constexpr size_t kKernelXferMax = (size_t)1 << 20;
     // device scratch for one call + staging for everything that call can move in either direction
@@ -275,6 +276,12 @@ int orbx_matcher_debug_transfers(const orbx_matcher *m, int64_t *out, int cap) {
     const int n = cap >= 6 ? 6 : 4;
     for (int i = 0; i < n; i++) out[i] = m->xfers[i];
     return n;
+}
+
+int orbx_matcher_debug_replay_stats(const orbx_matcher *m, int32_t *out3) {
+    if (!m || !out3) return ORBX_E_BAD_ARG;
+    for (int k = 0; k < 3; k++) out3[k] = m->replay_stats[k];
+    return 3;
 }
 
 void orbx_matcher_destroy(orbx_matcher *m) {
@@ -874,7 +881,9 @@ int bow_distances(orbx_matcher *m, const uint8_t *descA, const uint8_t *skipA, c
 
 extern "C" {
 
-// ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763): k_replay_init
+// ORBmatcher::SearchForInitialization (ORBmatcher.cc:648-763).  Round 6: F2's grid, the candidate lists of every level-0 keypoint of F1 (k_window_best2_t<64>:
+// a wave per query, the lists do not depend on the loop's state) and a one-wave replay of the loop over those lists (k_replay_init_lists);
+// frames beyond kMaxResolveFeatures keep the single-wave scan k_replay_init (the replay's state no longer fits the LDS).
 int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un, const uint8_t *desc1, int n1, const orbx_frame_desc *F2,
                                    float *prev_matched, int window_size, float nnratio, int check_orientation, int32_t *matches12) {
     if (!m || !F2 || n1 < 0 || (n1 > 0 && (!matches12 || !kps1_un || !desc1 || !prev_matched))) return ORBX_E_BAD_ARG;
@@ -883,36 +892,102 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un
     if (n1 == 0 || n2 == 0) return 0;
     if (n1 > 65535 || n2 > 65535) return ORBX_E_TOO_LARGE;
     ORBX_HIP(hipSetDevice(m->device));
-    const size_t need = Arena::pad(28 * (size_t)n1) + Arena::pad(32 * (size_t)n1) + Arena::pad(28 * (size_t)n2) + Arena::pad(32 * (size_t)n2) +
-                        Arena::pad(8 * (size_t)n1) + 2 * Arena::pad(4 * (size_t)n1) + 2 * Arena::pad(4 * (size_t)n2) + 4096;
-    int r = m->reserve_all(need);
-    if (r != ORBX_OK) return r;
-    Arena &A = m->arena;
-    m->begin();
-    InitProblem P;
-    memset(&P, 0, sizeof(P));
-    orbx_keypoint *dk1 = A.take<orbx_keypoint>(n1), *dk2 = A.take<orbx_keypoint>(n2);
-    uint8_t *dd1 = A.take<uint8_t>(32 * (size_t)n1), *dd2 = A.take<uint8_t>(32 * (size_t)n2);
-    float *dprev = A.take<float>(2 * (size_t)n1);
-    H2D(dk1, kps1_un, 28 * (size_t)n1); H2D(dd1, desc1, 32 * (size_t)n1);
-    H2D(dk2, F2->keypoints_un, 28 * (size_t)n2); H2D(dd2, F2->descriptors, 32 * (size_t)n2);
-    H2D(dprev, prev_matched, 8 * (size_t)n1);
-    P.kps1 = dk1; P.desc1 = dd1; P.n1 = n1; P.kps2 = dk2; P.desc2 = dd2; P.n2 = n2; P.prev_matched = dprev;
-    P.window = (float)window_size; P.nnratio = nnratio; P.check_orientation = check_orientation ? 1 : 0;
-    P.matches12 = A.take<int32_t>(n1); P.entries = A.take<int32_t>(n1);
-    P.matches21 = A.take<int32_t>(n2); P.matched_dist = A.take<int32_t>(n2);
-    P.nmatches = A.take<int32_t>(4);
     GridParams g;
     g.minx = F2->min_x; g.miny = F2->min_y;
     g.inv_w = 64.0f / (F2->max_x - F2->min_x);
     g.inv_h = 48.0f / (F2->max_y - F2->min_y);
-    hipLaunchKernelGGL(k_replay_init, dim3(1), dim3(64), 0, m->exec(), P, g);
-    int32_t nm = 0;
-    D2H(matches12, P.matches12, 4 * (size_t)n1);
-    D2H(prev_matched, dprev, 8 * (size_t)n1);
-    D2H(&nm, P.nmatches, 4);
+    if (n1 > kMaxResolveFeatures || n2 > kMaxResolveFeatures) {
+        const size_t need = Arena::pad(28 * (size_t)n1) + Arena::pad(32 * (size_t)n1) + Arena::pad(28 * (size_t)n2) + Arena::pad(32 * (size_t)n2) +
+                            Arena::pad(8 * (size_t)n1) + 2 * Arena::pad(4 * (size_t)n1) + 2 * Arena::pad(4 * (size_t)n2) + 4096;
+        int r = m->reserve_all(need);
+        if (r != ORBX_OK) return r;
+        Arena &A = m->arena;
+        m->begin();
+        InitProblem P;
+        memset(&P, 0, sizeof(P));
+        orbx_keypoint *dk1 = A.take<orbx_keypoint>(n1), *dk2 = A.take<orbx_keypoint>(n2);
+        uint8_t *dd1 = A.take<uint8_t>(32 * (size_t)n1), *dd2 = A.take<uint8_t>(32 * (size_t)n2);
+        float *dprev = A.take<float>(2 * (size_t)n1);
+        H2D(dk1, kps1_un, 28 * (size_t)n1); H2D(dd1, desc1, 32 * (size_t)n1);
+        H2D(dk2, F2->keypoints_un, 28 * (size_t)n2); H2D(dd2, F2->descriptors, 32 * (size_t)n2);
+        H2D(dprev, prev_matched, 8 * (size_t)n1);
+        P.kps1 = dk1; P.desc1 = dd1; P.n1 = n1; P.kps2 = dk2; P.desc2 = dd2; P.n2 = n2; P.prev_matched = dprev;
+        P.window = (float)window_size; P.nnratio = nnratio; P.check_orientation = check_orientation ? 1 : 0;
+        P.matches12 = A.take<int32_t>(n1); P.entries = A.take<int32_t>(n1);
+        P.matches21 = A.take<int32_t>(n2); P.matched_dist = A.take<int32_t>(n2);
+        P.nmatches = A.take<int32_t>(4);
+        hipLaunchKernelGGL(k_replay_init, dim3(1), dim3(64), 0, m->exec(), P, g);
+        int32_t nm = 0;
+        D2H(matches12, P.matches12, 4 * (size_t)n1);
+        D2H(prev_matched, dprev, 8 * (size_t)n1);
+        D2H(&nm, P.nmatches, 4);
+        SYNC_AND_DELIVER();
+        return nm;
+    }
+    // the queries: keypoints of F1 on level 0, in index order (:661-666); window = vbPrevMatched[i1] +- windowSize on level [level1, level1] (:668)
+    std::vector<int32_t> qidx;
+    qidx.reserve(n1);
+    for (int i = 0; i < n1; i++)
+        if (kps1_un[i].octave <= 0) qidx.push_back(i);
+    const int nq = (int)qidx.size();
+    if (nq == 0) return 0;
+    std::vector<float> qx(nq), qy(nq), qr(nq, (float)window_size);
+    std::vector<int32_t> qlv(nq);
+    std::vector<uint8_t> qd(32 * (size_t)nq);
+    for (int k = 0; k < nq; k++) {
+        const int i = qidx[k];
+        qx[k] = prev_matched[2 * i]; qy[k] = prev_matched[2 * i + 1]; qlv[k] = kps1_un[i].octave;
+        memcpy(&qd[32 * (size_t)k], desc1 + 32 * (size_t)i, 32);
+    }
+    const size_t lds = 4 * (size_t)n2 + 2 * (size_t)n2 * 2 + 2 * (size_t)n1 + 64;
+    const size_t need = Arena::pad(28 * (size_t)n1) + Arena::pad(28 * (size_t)n2) + Arena::pad(32 * (size_t)n2) + Arena::pad(8 * (size_t)n1) +
+                        Arena::pad(4 * (size_t)nq) * 6 + Arena::pad(32 * (size_t)nq) + Arena::pad(8 * (size_t)nq * kTopK) + Arena::pad(4 * (size_t)nq) * 2 +
+                        Arena::pad(sizeof(WindowProblem)) + Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)n2) + Arena::pad(4 * (size_t)n1) + 16 * 256 + 4096;
+    int r = m->reserve_all(need);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    m->begin();
+    WindowProblem P;
+    memset(&P, 0, sizeof(P));
+    InitReplay R;
+    memset(&R, 0, sizeof(R));
+    // every upload in one run of the arena, the problem record directly behind the inputs; device-only buffers behind it; the three downloads side by side
+    orbx_keypoint *dk1 = A.take<orbx_keypoint>(n1), *dk2 = A.take<orbx_keypoint>(n2);
+    uint8_t *dd2 = A.take<uint8_t>(32 * (size_t)n2);
+    H2D(dk1, kps1_un, 28 * (size_t)n1); H2D(dk2, F2->keypoints_un, 28 * (size_t)n2); H2D(dd2, F2->descriptors, 32 * (size_t)n2);
+    P.kps = dk2; P.desc = dd2;
+    int32_t *dcnt = A.take<int32_t>(4);
+    const int32_t cnts[2] = {n2, nq};
+    H2D(dcnt, cnts, 8);
+    P.n_ptr = dcnt; P.nq_ptr = dcnt + 1;
+    float *dqx = A.take<float>(nq), *dqy = A.take<float>(nq), *dqr = A.take<float>(nq);
+    int32_t *dql = A.take<int32_t>(nq), *dqi = A.take<int32_t>(nq);
+    uint8_t *dqd = A.take<uint8_t>(32 * (size_t)nq);
+    H2D(dqx, qx.data(), 4 * (size_t)nq); H2D(dqy, qy.data(), 4 * (size_t)nq); H2D(dqr, qr.data(), 4 * (size_t)nq);
+    H2D(dql, qlv.data(), 4 * (size_t)nq); H2D(dqi, qidx.data(), 4 * (size_t)nq); H2D(dqd, qd.data(), 32 * (size_t)nq);
+    P.qx = dqx; P.qy = dqy; P.qr = dqr; P.qmin = dql; P.qmax = dql; P.qdesc = dqd;
+    WindowProblem *dP = A.take<WindowProblem>(1);
+    P.keys = A.take<u64>((size_t)nq * kTopK); P.meta = A.take<int32_t>(nq);
+    P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n2);
+    R.q_index = dqi; R.kps1 = dk1; R.n1 = n1; R.n2 = n2; R.nq = nq; R.nnratio = nnratio; R.check_orientation = check_orientation ? 1 : 0;
+    R.entries = A.take<int32_t>(nq);
+    R.matches12 = A.take<int32_t>(n1);
+    R.prev_matched = A.take<float>(2 * (size_t)n1);
+    R.nmatches = A.take<int32_t>(4);
+    H2D(R.prev_matched, prev_matched, 8 * (size_t)n1);
+    H2D(dP, &P, sizeof(P));
+    ORBX_LAUNCH_GRID_BUILD(dim3(1), dim3(64), 0, m->exec(), dP, g);
+    hipLaunchKernelGGL(k_window_best2_t<64>, dim3(1, (unsigned)((nq + 3) / 4), 1), dim3(256), 0, m->exec(), dP, g, 1);   // a wave per query (100-px windows: hundreds of candidates)
+    if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_replay_init_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_replay_init_lists, dim3(1), dim3(64), lds, m->exec(), dP, R, g);
+    ORBX_HIP(hipGetLastError());
+    int32_t nm[4] = {0, 0, 0, 0};
+    D2H(matches12, R.matches12, 4 * (size_t)n1);
+    D2H(prev_matched, R.prev_matched, 8 * (size_t)n1);
+    D2H(nm, R.nmatches, 16);
     SYNC_AND_DELIVER();
-    return nm;
+    for (int k = 0; k < 3; k++) m->replay_stats[k] = nm[k + 1];
+    return nm[0];
 }
 
 }  // extern "C"
@@ -927,6 +1002,7 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
     const size_t ia = (size_t)fa->node_ptr[fa->n_nodes], ib = (size_t)fb->node_ptr[fb->n_nodes];
     const size_t need = Arena::pad(33 * (size_t)na) + Arena::pad(33 * (size_t)nb) + 3 * Arena::pad(4 * (size_t)std::max(na, nb)) * 2 +
                         Arena::pad(8 * (size_t)fa->n_nodes + 8) + Arena::pad(8 * (size_t)fb->n_nodes + 8) + Arena::pad(4 * ia) + Arena::pad(4 * ib) +
+                        Arena::pad(4 * (size_t)fa->n_nodes + 4) + 1024 +
                         Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 8192 +
                         (gate ? Arena::pad(sizeof(orbx_keypoint) * (size_t)na) + Arena::pad(sizeof(orbx_keypoint) * (size_t)nb) +
                                     Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 4 * Arena::pad(4 * 64) : 0);
@@ -946,6 +1022,13 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
         return ORBX_OK;
     };
     if ((r = up_fv(fa, P.fa, ia)) != ORBX_OK || (r = up_fv(fb, P.fb, ib)) != ORBX_OK) return r;
+    {   // the merge-join of the two sorted node-id lists (:246-250, :800-805, :961-965) on the host: node ia of A pairs with node pair_b[ia] of B
+        std::vector<int32_t> pair((size_t)fa->n_nodes + 1, -1);
+        for_common_nodes(fa, fb, [&](int a_, int b_) { pair[a_] = b_; });
+        int32_t *dpair = A.take<int32_t>(fa->n_nodes + 1);
+        H2D(dpair, pair.data(), 4 * ((size_t)fa->n_nodes + 1));
+        P.pair_b = dpair;
+    }
     auto up = [&](const void *src, size_t bytes) -> const uint8_t * {
         if (!src) return nullptr;
         uint8_t *d = A.take<uint8_t>(bytes);

@@ -114,6 +114,13 @@ class ORBmatcher:
         return {"uploads": int(out[0]), "downloads": int(out[1]), "upload_bytes": int(out[2]), "download_bytes": int(out[3]),
                 "dma_submissions": int(out[4]), "xfer_launches": int(out[5])}
 
+    def last_replay_stats(self) -> dict:
+        """k_replay_init_lists of the last SearchForInitialization: orbx_matcher_debug_replay_stats."""
+        out = np.zeros(3, np.int32)
+        if self._L.orbx_matcher_debug_replay_stats(self._h, ptr(out)) < 0:
+            raise RuntimeError("orbx_matcher_debug_replay_stats")
+        return {"rounds": int(out[0]), "rescans": int(out[1]), "queries": int(out[2])}
+
     # ---- DescriptorDistance over candidate lists (ORBmatcher.cc:2058-2074) ----
     def hamming_csr(self, q_desc, t_desc, row_ptr, cand):
         q, t, rp, cd = _u8(q_desc), _u8(t_desc), _i32(row_ptr), _i32(cand)

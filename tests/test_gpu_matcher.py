@@ -378,6 +378,31 @@ def test_search_for_initialization(oracle, canvas1):
         assert n > 200 and (m12[k0["octave"] > 0] == -1).all()
 
 
+def test_search_for_initialization_under_contention(oracle, canvas1):
+    """M6 where the loop's state matters: descriptors drawn from 40 prototypes (tests/test_oracle_matchers_vs_reference.py::contended_init_case, pinned
+    against the compiled reference there) -- dozens of candidates within TH_LOW per query, matches taken over again and again, vMatchedDistance
+    skips, distance ties, candidate lists that run dry (the whole-wave re-scan of k_replay_init_lists)."""
+    import orb_slam3_amd as osa
+    from test_oracle_matchers_vs_reference import contended_init_case
+    ex, k0, d0, k1, d1 = _two_frames(canvas1, nf=5000, t0=0, t1=4)
+    sf = ex.GetScaleFactors()
+    k0, d0c, k1, d1c = contended_init_case({5000: (k0, d0, k1, d1, None)})
+    rescans = []
+    for ratio, ori, win in ((0.9, True, 100), (1.0, False, 60), (0.95, True, 25), (0.9, True, 400)):
+        prev_a = np.ascontiguousarray(np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32))
+        prev_b = prev_a.copy()
+        grid = oracle.OracleGrid(k1, 0.0, 752.0, 0.0, 480.0)
+        on, om = oracle.search_for_initialization(k0, d0c, grid, d1c, prev_a, win, ratio, ori)
+        mm = osa.ORBmatcher(ratio, ori)
+        n, m12 = mm.SearchForInitialization(k0, d0c, _frame_view(k1, d1c, sf, 752, 480), prev_b, win)
+        assert n == on and np.array_equal(m12, om) and prev_a.tobytes() == prev_b.tobytes(), (ratio, ori, win, n, on)
+        assert n > 20
+        st = mm.last_replay_stats()
+        rescans.append(st["rescans"])
+        assert st["queries"] == int((k0["octave"] == 0).sum()) and st["rounds"] >= (st["queries"] + 63) // 64
+    assert max(rescans) > 10, rescans   # the case does drive lists dry (the re-scan path is exercised, not just present)
+
+
 def _bow_nodes(rng, k_a, k_b, d_a, d_b, n_nodes=100, noise=0.15):
     """Synthetic vocabulary nodes: a feature's node is a hash of its position cell, so that true correspondences
     (frame b is frame a shifted by a few pixels) mostly share a node; `noise` of them are scrambled."""

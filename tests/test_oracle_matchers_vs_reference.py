@@ -328,6 +328,36 @@ def test_search_for_initialization(frames):
         assert on > 200
 
 
+def contended_init_case(frames):
+    """SearchForInitialization inputs with heavy contention for F2's features: level-0 descriptors of BOTH frames are drawn from 40 prototypes with a few
+    bits flipped, so that every query sees dozens of candidates within TH_LOW, matches are taken over again and again (vnMatches21 reassignment,
+    :713-716), vMatchedDistance skips are frequent and distance ties abound.  Also used by tests/test_gpu_matcher.py."""
+    k0, d0, k1, d1, _ = frames[5000]
+    rng = np.random.default_rng(88)
+    d0c, d1c = d0.copy(), d1.copy()
+    proto = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    for k, d in ((k0, d0c), (k1, d1c)):
+        lv0 = np.nonzero(k["octave"] == 0)[0]
+        pick = rng.integers(0, len(proto), len(lv0))
+        flips = (rng.random((len(lv0), 256)) < 0.03)
+        d[lv0] = proto[pick] ^ np.packbits(flips, axis=1, bitorder="little")
+    return k0, d0c, k1, d1c
+
+
+def test_search_for_initialization_under_contention(frames):
+    """M6 where the loop's state matters (round 6: the device replays the loop over precomputed candidate lists; a list that runs dry is re-scanned)."""
+    k0, d0, k1, d1 = contended_init_case(frames)
+    bounds = np.array([0.0, W, 0.0, H], np.float32)
+    for ratio, ori, win in ((0.9, True, 100), (1.0, False, 60), (0.95, True, 25)):
+        prev_a = np.ascontiguousarray(np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32))
+        prev_b = prev_a.copy()
+        grid = ob.OracleGrid(k1, 0.0, float(W), 0.0, float(H))
+        on, om = ob.search_for_initialization(k0, d0, grid, d1, prev_a, win, ratio, ori)
+        _pin(f"m6c/{ratio}/{ori}/{win}", (on, om, prev_a),
+             lambda: rb.ref_search_for_initialization(k0, d0, k1, d1, bounds, prev_b, win, ratio, ori) + (prev_b,))
+        assert on > 20, on
+
+
 def test_search_for_triangulation(frames):
     """M7, ORBmatcher.cc:907-1146: later equal-distance candidate wins (dist > bestDist skips), vbMatched2 is never set in the
     reference, the epipolar verdict is consulted lazily, rotation filter, bCoarse bypass."""
