@@ -803,7 +803,7 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int i = i0 + 64 * k + lane;
-            xy[k] = float2{-1e30f, -1e30f};
+            xy[k] = float2{-1e8f, -1e8f};   // (outside every grid; small enough that the float -> int conversion of its cell is defined)
             if (i < n) { xy[k].x = gld(&P.kps[i].x); xy[k].y = gld(&P.kps[i].y); }
         }
 #pragma unroll
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(64) void k_grid_build(const WindowProblem *__restri
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int i = i0 + 64 * k + lane;
-            xy[k] = float2{-1e30f, -1e30f};
+            xy[k] = float2{-1e8f, -1e8f};   // (outside every grid; small enough that the float -> int conversion of its cell is defined)
             if (i < n) { xy[k].x = gld(&P.kps[i].x); xy[k].y = gld(&P.kps[i].y); }
         }
 #pragma unroll
