@@ -190,6 +190,7 @@ def pmc_traffic(kernel, workload, batch):
 
 SQ_CLOCK_GHZ = 2.4        # MI355X peak engine clock (MI355X_MICROARCH.md); the measured clock of the pass is reported beside it
 N_SIMDS = 1024            # 256 CUs x 4 SIMDs
+N_XCD = 8
 VALU_ISSUE_CYCLES = 4     # a wave64 VALU instruction of these integer / packed kernels occupies its SIMD's vector issue for one quad-cycle:
                           # SQ_ACTIVE_INST_VALU (quad-cycles) == SQ_INSTS_VALU to 1 % on every kernel of the path (profiles/r05_g_pmc_sq_counters.csv)
 
@@ -269,8 +270,8 @@ def pmc_sq(workload, batch):
                  "issue_us_at_peak_clock": round(avg["SQ_INSTS_VALU"] * VALU_ISSUE_CYCLES / N_SIMDS / (SQ_CLOCK_GHZ * 1e3), 2)}
             if k in dur and dur[k][1]:
                 e["launch_us_under_counters"] = round(dur[k][0] / dur[k][1], 2)
-                if "GRBM_GUI_ACTIVE" in avg and e["launch_us_under_counters"] > 0:
-                    e["clock_ghz_under_counters"] = round(avg["GRBM_GUI_ACTIVE"] / e["launch_us_under_counters"] / 1e3, 3)
+                if "GRBM_GUI_ACTIVE" in avg and e["launch_us_under_counters"] > 0:   # the counter is the sum over the part's 8 XCDs (r06_c: 17.8 "GHz" raw)
+                    e["clock_ghz_under_counters"] = round(avg["GRBM_GUI_ACTIVE"] / N_XCD / e["launch_us_under_counters"] / 1e3, 3)
             out[k] = e
         if out:
             return out, None
