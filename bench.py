@@ -707,9 +707,9 @@ def bench_euroc(R):
         allf = dataset.load_mono("euroc", NS * B, W, H, start=R.rank * NS * B)
         data = f"dataset: {dataset.dataset_dir('euroc')} (first {NS * B} frames per rank)"
     else:
-        canvas = synth.make_texture_canvas(seed) if a.scene == "texture" else synth.make_canvas(seed)
-        if a.scene == "texture":
-            data = "synthetic, STRESS scene (synth.make_texture_canvas: 1/f noise + dense high-contrast texture); not the metric's scene"
+        canvas = synth.make_scene_canvas(a.scene, seed)
+        if a.scene != "quads":
+            data = f"synthetic, STRESS scene {a.scene} (synth.make_texture_canvas: 1/f noise + dense high-contrast texture; blend:<a> mixes it into the quad scene); not the metric's scene"
         allf = np.stack([synth.frame_from_canvas(canvas, t, W, H, 1000 * seed + t) for t in range(NS * B)])
     sets = [np.ascontiguousarray(allf[k * B:(k + 1) * B]) for k in range(NS)]
     frames = sets[0]
@@ -1537,7 +1537,7 @@ def pmc_child(args):
     from orb_slam3_amd import synth
     W, H, NF, Bd, LAP = WORKLOADS[args.workload]
     B = args.batch or Bd
-    canvas = synth.make_texture_canvas(10) if args.scene == "texture" else synth.make_canvas(10)
+    canvas = synth.make_scene_canvas(args.scene, 10)
     frames = np.stack([synth.frame_from_canvas(canvas, t, W, H, 10000 + t) for t in range(B)])
     d = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
@@ -1633,9 +1633,10 @@ def main():
                     help="ranks beyond the visible GPUs share them (rank r on GPU r mod count): exercises the N-rank path on a box with fewer GPUs")
     ap.add_argument("--ablate", default="", help="DIAGNOSTIC for the euroc workload: comma list of nodl (no D2H of keypoints / descriptors / matches), nomatch "
                                                  "(no frame-to-frame matcher); the line is marked and no parity check runs")
-    ap.add_argument("--scene", choices=("quads", "texture"), default="quads",
+    ap.add_argument("--scene", default="quads",
                     help="euroc workload, synthetic frames: quads = SURVEY.md 8(d)'s scene (the metric); texture = the stress scene with natural-image "
-                         "statistics and several times the FAST candidates (whole-step parity as usual; stage_stats_last_step says which paths it took)")
+                         "statistics and 13 x the FAST candidates; blend:<a> (0..1) = (1 - a) quads + a texture, densities in between "
+                         "(whole-step parity as usual; stage_stats_last_step says which paths it took; tools/density_sweep.sh)")
     ap.add_argument("--threads", action="store_true",
                     help="SURVEY.md 8(e) as ONE process: --gpus N host worker threads (thread s on GPU s mod the visible GPUs), each with its own extractor "
                          "and pinned ring, instead of N rank processes; euroc workload, device-resident clock, parity of every thread's last step")

@@ -127,6 +127,7 @@ struct orbx_extractor {
     int fast_wave_pitch = 64, fast_wave_rows = 0, fast_wave_qfull = 16;   // list pass (fast_wave_cell): LDS tile pitch (48 / 64), max sub-image rows, whole-cell queue
     DevBuf d_fast_ovf;          // [1 + n_fast_tiles * batch] overflow counter + list of k_fast_wave
     bool oct_par = true;        // wave-parallel quad-tree kernel (k_octree_par); false: sequential emulation (k_octree)
+    bool oct_single_wave = false;   // diagnostic: levels beyond the LDS tiers on one wave (round 5) instead of the whole workgroup
     bool fast_wave = true;      // every level's cell fits k_fast_wave's fixed LDS pitch
     int n_fast_tiles = 0, n_blur_items = 0;
     int blur_waves = 2048;      // single-wave workgroups of k_blur_stream (measured: 512 / 1024 / 2048 / 4096 -> EuRoC step 1.25 / 1.115 / 1.09 / 1.10 ms)

@@ -292,7 +292,15 @@ __device__ __forceinline__ uint64_t oct_blk_seg_excl(uint64_t v, bool fl, uint64
 }
 
 // KEYS = capacity of the LDS key buffers of the 256-thread form (4096, or 2048 for k_octree_par_t's small tier); kE = key slots per thread
-template <bool BLK, int KEYS = kOctParLdsKeys>
+// WIDE (round 6; only with BLK == false): the global-memory form on all 256 threads of the workgroup.  The single-wave chunked form walks every key of a level in
+// chunks of 64, twice per pass (child histogram, stable scatter), and its scatter hands a running offset from chunk to chunk -- one wave, 2 ms for a level
+// of 22 900 candidates (the texture scene: 2.2 of 3.3 ms per step).  Here the chunks are independent: a table in LDS (the key area the LDS form would use)
+// holds, per chunk, how many keys of the chunk's LAST node go to each child; its prefix sum P gives the number of a node's keys in earlier chunks as
+// P[chunk] - P[chunk where the node starts] (a node's keys are contiguous, so every chunk in between belongs to it entirely), and a key's place is
+// child offset + that + its rank inside the chunk.  No atomics on the offsets, no order between chunks: the four waves stride the chunks.  C <= 65535
+// (16-bit fields); larger levels keep the single-wave form.
+constexpr int kOctWideMaxKeys = 65535;
+template <bool BLK, int KEYS = kOctParLdsKeys, bool WIDE = false>
 __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *smem, int max_pool, const int C, uint32_t *gk0, uint32_t *gk1,
                                                 uint16_t *gn0, uint16_t *gn1, uint32_t *__restrict__ out,
                                                 int32_t *__restrict__ lvlcnt_out, int32_t *__restrict__ err, long long *dbg) {
@@ -302,10 +310,31 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
     long long tmark = dbg ? (long long)wall_clock64() : 0;
     const long long tstart = tmark;
 #define OCT_TICK(k) do { if (dbg) { const long long tn = (long long)wall_clock64(); if (tid == 0) dbg[k] += tn - tmark; tmark = tn; } } while (0)
-    constexpr int NT = BLK ? 256 : 64;
+    static_assert(!(BLK && WIDE), "WIDE is a form of the global-memory body");
+    constexpr int NT = (BLK || WIDE) ? 256 : 64;
+    constexpr int NW = NT / 64;
     const int pool = L.pool;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#define OCT_SYNC_ALL() do { if (BLK) __syncthreads(); else OCT_WAVE_SYNC(); } while (0)
+#define OCT_SYNC_ALL() do { if (BLK || WIDE) __syncthreads(); else OCT_WAVE_SYNC(); } while (0)
+    // WIDE: per-chunk tables in the LDS key area: ctab[c] = four 16-bit counters (then their exclusive prefix sums), one per child
+    uint64_t *const ctab = reinterpret_cast<uint64_t *>(smem + oct_par_pool_bytes(max_pool));
+    const int nch = (C + 63) >> 6;
+    // exclusive prefix sum of ctab[0 .. nch) in place, by wave 0 (the fields never carry into each other: they count disjoint keys, C <= 65535); total -> ctl[2], ctl[3]
+    auto chunk_scan = [&](int *ctl_) {
+        if (wave == 0) {
+            uint32_t rlo = 0, rhi = 0;
+            for (int c0 = 0; c0 < nch; c0 += 64) {
+                const int c = c0 + lane;
+                const uint64_t v = c < nch ? ctab[c] : 0ull;
+                const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+                const uint32_t ilo = (uint32_t)wave_incl_scan((int)lo), ihi = (uint32_t)wave_incl_scan((int)hi);
+                if (c < nch) ctab[c] = ((uint64_t)(rhi + ihi - hi) << 32) | (uint64_t)(rlo + ilo - lo);
+                rlo += (uint32_t)__builtin_amdgcn_readlane((int)ilo, 63);
+                rhi += (uint32_t)__builtin_amdgcn_readlane((int)ihi, 63);
+            }
+            if (lane == 0) { ctl_[2] = (int)rlo; ctl_[3] = (int)rhi; }
+        }
+    };
 
     // carve (8-byte arrays first)
     uint8_t *p = smem;
@@ -392,6 +421,42 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
             }
         }
         __syncthreads();
+    } else if (WIDE) {
+        int wr = 0;
+        for (int r = 0; r < L.nIni; r++) {
+            auto root_of = [&](uint32_t key) { return min((int)((float)key_x(key) / L.hX), L.nIni - 1); };
+            for (int c = wave; c < nch; c += NW) {   // keys of root r per chunk
+                const int i = c * 64 + lane;
+                const bool mine = i < C && root_of(kb[1][i]) == r;
+                const unsigned long long b = __ballot(mine);
+                if (lane == 0) ctab[c] = (uint64_t)__popcll(b);
+            }
+            __syncthreads();
+            chunk_scan(ctl);
+            __syncthreads();
+            const int cnt = ctl[2];
+            for (int c = wave; c < nch; c += NW) {
+                const int i = c * 64 + lane;
+                uint32_t key = 0;
+                bool mine = false;
+                if (i < C) { key = kb[1][i]; mine = root_of(key) == r; }
+                const unsigned long long b = __ballot(mine);
+                if (mine) {
+                    const int pos = wr + (int)(uint32_t)ctab[c] + __popcll(b & lt_mask);
+                    kb[0][pos] = key;
+                    nof[0][pos] = (uint16_t)size;
+                }
+            }
+            if (cnt > 0) {
+                if (tid == 0) {
+                    bndb[size] = OctBnd{(int16_t)(int)(L.hX * (float)r), 0, (int16_t)(int)(L.hX * (float)(r + 1)), (int16_t)(L.h - 2 * kBorder)};
+                    segb[size] = OctSeg{wr, cnt};
+                }
+                size++;
+            }
+            wr += cnt;
+            __syncthreads();   // ctab is reused by the next root; the keys written here are read by the first pass
+        }
     } else {
         int wr = 0;
         for (int r = 0; r < L.nIni; r++) {
@@ -504,6 +569,31 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
                     }
                 }
             }
+        } else if (WIDE) {
+            for (int i = tid; i < size * 4; i += NT) hist[i] = 0;
+            __syncthreads();
+            for (int c = wave; c < nch; c += NW) {
+                const int i0 = c * 64, i = i0 + lane;
+                int j = -1, q = 4;
+                if (i < C) {
+                    const uint32_t key = K0[i];
+                    j = O0[i];
+                    if (S0[j].cnt > 1) {
+                        const OctBnd b = B0[j];
+                        const int sx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), sy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);
+                        q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
+                        atomicAdd(&hist[4 * j + q], 1u);
+                    }
+                }
+                // the chunk's contribution to the node it ends in: keys of that node per child (what a later chunk of the same node finds before it)
+                const int jl = __shfl(j, min(63, C - 1 - i0));
+                const bool same = i < C && j == jl;
+                const unsigned long long t0 = __ballot(same && q == 0), t1 = __ballot(same && q == 1), t2 = __ballot(same && q == 2), t3 = __ballot(same && q == 3);
+                if (lane == 0)
+                    ctab[c] = (uint64_t)__popcll(t0) | ((uint64_t)__popcll(t1) << 16) | ((uint64_t)__popcll(t2) << 32) | ((uint64_t)__popcll(t3) << 48);
+            }
+            __syncthreads();
+            chunk_scan(ctl);   // (the barrier that follows publishes it)
         } else {
             for (int i = lane; i < size * 4; i += 64) hist[i] = 0;
             OCT_WAVE_SYNC();
@@ -641,6 +731,40 @@ __device__ __forceinline__ void octree_par_body(const LevelInfo &L, uint8_t *sme
                     } else {
                         const int i = tid * E + e;
                         K1[i] = kv[e];
+                        O1[i] = (uint16_t)np;
+                    }
+                }
+            }
+        } else if (WIDE) {
+            for (int c = wave; c < nch; c += NW) {
+                const int i0 = c * 64, i = i0 + lane;
+                uint32_t key = 0;
+                int j = 0, q = 4, np = 0, s0 = 0, beg = 0;
+                if (i < C) {
+                    key = K0[i];
+                    j = O0[i];
+                    np = npos[j];
+                    if (np == 0xffff) {
+                        const OctBnd b = B0[j];
+                        const int sx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), sy = b.y0 + ((b.y1 - b.y0 + 1) >> 1);
+                        q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
+                        beg = S0[j].beg;
+                        s0 = max(beg - i0, 0);  // first lane of this node's run inside the chunk
+                    }
+                }
+                const unsigned long long b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+                if (i < C) {
+                    if (q < 4) {
+                        const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+                        const int rank = __popcll(bq & lt_mask & ~((1ull << s0) - 1ull));
+                        int earlier = 0;   // keys of this node and child in earlier chunks: every chunk from the node's first one up to this one ends in the node
+                        if (beg < i0) earlier = (int)(((ctab[c] >> (16 * q)) - (ctab[beg >> 6] >> (16 * q))) & 0xffff);
+                        const int slot = 4 * j + q;
+                        const int pos = (int)hist[slot] + earlier + rank;
+                        K1[pos] = key;
+                        O1[pos] = cpos[slot];
+                    } else {
+                        K1[i] = key;
                         O1[i] = (uint16_t)np;
                     }
                 }
@@ -784,7 +908,7 @@ __global__ __launch_bounds__(256, (KEYS <= 2048 ? 5 : 3)) void k_octree_par_t(co
 __global__ __launch_bounds__(256, 3) void k_octree_rest(const LevelInfo *__restrict__ lv, size_t ent_frame_stride, uint32_t *__restrict__ keys0,
                                                         uint32_t *__restrict__ keys1, uint16_t *__restrict__ nof0, uint16_t *__restrict__ nof1,
                                                         uint32_t *__restrict__ lvlkp, size_t lvlkp_frame_stride, int32_t *__restrict__ lvlcnt,
-                                                        int nlevels, const int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool) {
+                                                        int nlevels, const int32_t *__restrict__ cand_total, int32_t *__restrict__ err, int max_pool, int single_wave) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int level = blockIdx.y, f = blockIdx.x;
     const LevelInfo L = lv[level];
@@ -797,14 +921,18 @@ __global__ __launch_bounds__(256, 3) void k_octree_rest(const LevelInfo *__restr
                                               err, nullptr);
         return;
     }
-    if (threadIdx.x >= 64) return;   // the chunked form is one wave's
+    uint32_t *gk0 = keys0 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint16_t *gn0 = nof0 + (size_t)f * ent_frame_stride + L.cand_off;
+    uint16_t *gn1 = nof1 + (size_t)f * ent_frame_stride + L.cand_off;
+    if (C <= kOctWideMaxKeys && !single_wave) {   // the global-memory form on the whole workgroup (round 6)
+        octree_par_body<false, kOctParLdsKeys, true>(L, smem, max_pool, C, gk0, gk1, gn0, gn1, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off, cnt_out, err, nullptr);
+        return;
+    }
+    if (threadIdx.x >= 64) return;   // the chunked single-wave form (levels beyond 65535 candidates; ORBX_OCTREE=w1)
     if (C >= 0xfffff) {  // the best-response pick packs the key position into 20 bits
         if (threadIdx.x == 0) { atomicExch(err, 2); *cnt_out = 0; }
         return;
     }
-    uint32_t *gk0 = keys0 + (size_t)f * ent_frame_stride + L.cand_off;
-    uint16_t *gn0 = nof0 + (size_t)f * ent_frame_stride + L.cand_off;
-    uint16_t *gn1 = nof1 + (size_t)f * ent_frame_stride + L.cand_off;
     octree_par_body<false>(L, smem, max_pool, C, gk0, gk1, gn0, gn1, lvlkp + (size_t)f * lvlkp_frame_stride + L.lvl_off, cnt_out, err, nullptr);
 }
 

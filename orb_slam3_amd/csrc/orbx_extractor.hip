@@ -619,7 +619,8 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
     ex->fast_wave_pitch = (fast_wave_maxw + 7 <= 48) ? 48 : 64;
     ex->fast_wave_rows = fast_wave_rows;
     ex->fast_wave_qfull = fast_wave_qfull;
-    { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024; }
+    { const char *v = getenv("ORBX_OCTREE"); ex->oct_par = !(v && v[0] == 's') && oct_par_lds_bytes(max_pool) <= 150 * 1024;
+      ex->oct_single_wave = v && v[0] == 'w'; }   // ORBX_OCTREE=w1: the global-memory form on ONE wave (round 5's; the whole workgroup since round 6)
     ex->n_fast_tiles = (int)fast_tiles.size(); ex->n_blur_items = (int)blur_items.size();
     ex->last_batch = 0;
     ex->lvl0_inplace = false;
@@ -848,7 +849,7 @@ static int enqueue_extract(orbx_extractor *ex, const uint8_t *d_images, int n, s
             hipLaunchKernelGGL(k_octree_rest, dim3(n, nl), dim3(256), lds_r, st, d_lv, ex->cand_frame, (uint32_t *)ex->d_keys0.p,
                                (uint32_t *)ex->d_keys1.p, (uint16_t *)ex->d_nof0.p, (uint16_t *)ex->d_nof1.p, (uint32_t *)ex->d_lvlkp.p,
                                ex->lvl_frame, (int32_t *)ex->d_lvlcnt.p, nl, (const int32_t *)ex->d_candtot.p, (int32_t *)ex->d_err.p,
-                               ex->max_pool);
+                               ex->max_pool, ex->oct_single_wave ? 1 : 0);
         } else {
             if (oct_lds_bytes(ex->max_pool) > 64 * 1024)
                 ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds_bytes(ex->max_pool)));

@@ -132,3 +132,20 @@ def make_test_image(seed: int, w: int, h: int) -> np.ndarray:
     """Small structured + noisy image for unit tests (fast to build)."""
     canvas = make_canvas(seed, size=max(512, 2 * max(w, h)), n_shapes=150)
     return frame_from_canvas(canvas, 0, w, h, seed + 77)
+
+
+def make_scene_canvas(scene: str, seed: int, size: int = 2048) -> np.ndarray:
+    """Canvas by scene name: "quads" (make_canvas: SURVEY.md 8(d)'s scene, the metric), "texture" (make_texture_canvas: 13 x the FAST candidates), or
+    "blend:<a>" with 0 <= a <= 1: (1 - a) * quads + a * texture, pixel by pixel -- candidate densities in between (bench.py --scene, tools/density_sweep.sh)."""
+    if scene == "quads":
+        return make_canvas(seed, size=size) if size != 2048 else make_canvas(seed)
+    if scene == "texture":
+        return make_texture_canvas(seed, size)
+    if scene.startswith("blend:"):
+        a = float(scene.split(":", 1)[1])
+        if not 0.0 <= a <= 1.0:
+            raise ValueError("blend factor must lie in [0, 1]")
+        q = make_canvas(seed, size=size) if size != 2048 else make_canvas(seed)
+        t = make_texture_canvas(seed, size)
+        return ((1.0 - a) * q.astype(np.float32) + a * t.astype(np.float32)).astype(np.float32)
+    raise ValueError(f"unknown scene {scene!r}")
