@@ -440,22 +440,46 @@ def cpu_baseline_tumvi(frames, mp_sets, n_sample, w, h, nfeat):
 # ---------------------------------------------------------------------------------------------------------
 # rank process
 # ---------------------------------------------------------------------------------------------------------
+def parse_cpulist(text):
+    ids = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        ids.update(range(int(a), int(b or a) + 1))
+    return ids
+
+
+def rank_core_set(index, bdfs, sysfs="/sys/bus/pci/devices"):
+    """CPU cores for the rank that drives GPU `index` of the node's GPUs `bdfs` (PCI addresses in device order): the cores local to the GPU
+    (sysfs local_cpulist), and -- where several GPUs hang off the same cores, e.g. four per socket on an 8-GPU node -- an equal, DISJOINT share of
+    them per GPU, so that eight ranks do not all run (and first-touch their pinned rings) on the first cores of a socket.  Returns (core set, numa node,
+    cpulist text); raises when sysfs has no entry.  Pure function of the sysfs tree: tests/test_sharding_gloo.py runs it on a fake 8-GPU topology."""
+    lists = []
+    for b in bdfs:
+        lists.append(open(f"{sysfs}/{b}/local_cpulist").read().strip())
+    mine = lists[index]
+    node = open(f"{sysfs}/{bdfs[index]}/numa_node").read().strip()
+    cores = sorted(parse_cpulist(mine))
+    peers = [i for i, l in enumerate(lists) if l == mine]
+    k, n = peers.index(index), len(peers)
+    share = cores[k * len(cores) // n:(k + 1) * len(cores) // n] if len(cores) >= n else cores
+    return set(share), node, mine
+
+
 def bind_to_gpu_numa_node(torch, index):
     """Run this rank (and first-touch its pinned buffers) on the CPU cores local to its GPU: the host-input leg moves 92 MB per step
-    over PCIe, and pinned memory on the other socket costs a third of the bandwidth.  Best effort; returns a short description."""
+    over PCIe, and pinned memory on the other socket costs a third of the bandwidth.  GPUs that share a set of local cores split it
+    (rank_core_set).  Best effort; returns a short description."""
     try:
-        p = torch.cuda.get_device_properties(index)
-        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
-        base = f"/sys/bus/pci/devices/{bdf}"
-        cpus = open(f"{base}/local_cpulist").read().strip()
-        node = open(f"{base}/numa_node").read().strip()
-        ids = set()
-        for part in cpus.split(","):
-            a, _, b = part.partition("-")
-            ids.update(range(int(a), int(b or a) + 1))
+        bdfs = []
+        for d in range(torch.cuda.device_count()):
+            p = torch.cuda.get_device_properties(d)
+            bdfs.append(f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0")
+        ids, node, cpus = rank_core_set(index, bdfs)
         if ids:
             os.sched_setaffinity(0, ids)
-            return f"gpu {bdf} numa {node} cpus {cpus}"
+            return f"gpu {bdfs[index]} numa {node} cpus {cpus} -> {len(ids)} cores from {min(ids)}"
     except Exception as e:   # no sysfs entry / no permission: keep the inherited affinity
         return f"unbound ({type(e).__name__})"
     return "unbound"

@@ -121,3 +121,33 @@ def test_gpu_ranks_use_the_host_process_group_only():
     assert not re.search(r"[\"']nccl[\"']", src)
     sh = (Path(__file__).resolve().parent.parent / "orb_slam3_amd" / "sharding.py").read_text()
     assert 'init_process_group("gloo"' in sh and "cuda" not in sh.split("def gather_throughput")[1].split("def reduce_throughput")[0]
+
+
+def test_rank_core_sets_on_a_fake_eight_gpu_node(tmp_path):
+    """bench.py binds a rank to the cores local to its GPU before it allocates pinned memory (never run on an 8-GPU node by the
+    builder).  rank_core_set is a pure function of the sysfs tree: on a fake node with two sockets x four GPUs every local rank must get a non-empty
+    core set inside its GPU's local_cpulist, the eight sets must be pairwise disjoint, and together they must cover every core; a GPU alone on its
+    cores gets all of them; a missing sysfs entry raises (bind_to_gpu_numa_node then reports `unbound`)."""
+    import sys
+    from pathlib import Path
+    import pytest
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    sysfs = tmp_path / "devices"
+    lists = ["0-63,128-191"] * 4 + ["64-127,192-255"] * 4
+    bdfs = [f"0000:{0x10 + 0x10 * i:02x}:00.0" for i in range(8)]
+    for b, l, node in zip(bdfs, lists, [0] * 4 + [1] * 4):
+        (sysfs / b).mkdir(parents=True)
+        (sysfs / b / "local_cpulist").write_text(l + "\n")
+        (sysfs / b / "numa_node").write_text(f"{node}\n")
+    sets = [bench.rank_core_set(i, bdfs, str(sysfs)) for i in range(8)]
+    for i, (cores, node, text) in enumerate(sets):
+        assert len(cores) == 32 and cores <= bench.parse_cpulist(lists[i]) and node == str(i // 4) and text == lists[i]
+    for i in range(8):
+        for j in range(i + 1, 8):
+            assert not (sets[i][0] & sets[j][0]), (i, j)
+    assert set().union(*[c for c, _, _ in sets]) == set(range(256))
+    alone = bench.rank_core_set(0, bdfs[:1], str(sysfs))[0]
+    assert alone == bench.parse_cpulist(lists[0])
+    with pytest.raises(OSError):
+        bench.rank_core_set(0, ["0000:ff:00.0"], str(sysfs))

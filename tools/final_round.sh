@@ -4,7 +4,7 @@
 # forced -- in THIS order: most important first, every step under its own timeout, so that a visit cut short keeps what it has.
 # usage: bash tools/final_round.sh <tag>   -> gpurun_out/measure_<tag>/profiles_copy/
 set -u
-TAG=${1:-r05_a}
+TAG=${1:-r06_a}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/measure_$TAG
@@ -43,6 +43,21 @@ ORBX_FUSED_BLUR=0 timeout 120 python bench.py --workload euroc --cpu-frames 0 --
 import sys, json
 d = json.loads(sys.stdin.read()); print('ORBX_FUSED_BLUR=0 euroc: ms_per_step', d['ms_per_step'], 'parity_checked', d['parity_checked'])" > $O/profiles_copy/${TAG}_blur_pass_forced_parity.txt 2>&1
 cat $O/profiles_copy/${TAG}_blur_pass_forced_parity.txt
+# round 6: every host-pointer matcher entry point one call at a time (both transports), the kernel timeline of one call of each, the candidate-density sweep,
+# and the N-rank path with two ranks on the one GPU (both clocks, parity on both ranks: VERDICT r5 item 9)
+timeout 300 python tools/latency_calls.py 100 > $O/profiles_copy/${TAG}_latency_calls_kernel_xfer.txt 2>&1
+ORBX_MATCHER_DMA=1 timeout 300 python tools/latency_calls.py 100 > $O/profiles_copy/${TAG}_latency_calls_dma_engine.txt 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python tools/latency_calls.py 30 > /dev/null 2>&1
+python tools/call_timeline.py $(biggest_db $O/kt) > $O/profiles_copy/${TAG}_call_timelines.txt 2>&1
+lap calls
+bash tools/density_sweep.sh $TAG > /dev/null 2>&1; cp gpurun_out/density_$TAG/density_sweep.txt $O/profiles_copy/${TAG}_density_sweep.txt; cp gpurun_out/density_$TAG/density_sweep.json $O/profiles_copy/${TAG}_density_sweep.json
+tail -7 $O/profiles_copy/${TAG}_density_sweep.txt | cut -c1-120
+lap density
+timeout 300 python bench.py --gpus 2 --share-gpus --steps 20 --warmup 5 --cpu-frames 0 --no-pmc --no-other-workloads --latency 0 --no-profile 2> $O/two_ranks.err | tail -1 > $O/profiles_copy/${TAG}_two_ranks_one_gpu.json
+python3 -c "
+import json
+d = json.load(open('$O/profiles_copy/${TAG}_two_ranks_one_gpu.json')); print('2 ranks on one GPU: n_gpus', d['n_gpus'], 'value', d['value'], 'per_rank', [(r.get('rank'), r.get('parity_checked') is not None) for r in d.get('per_rank', [])], 'pcie', d['pcie_inclusive']['value'])"
+lap two-ranks
 # steady state: one region of K = 4000 pipelined steps (the contract's K = 20 regions pay the pipeline's fill and drain); SOAK=0 skips it
 if [ "${SOAK:-1}" != "0" ]; then
   timeout 150 python bench.py --gpus 1 --steps 4000 --warmup 5 --cpu-frames 0 --no-pmc --no-other-workloads --latency 0 --no-profile --repeat 2 2> /dev/null | tail -1 > $O/profiles_copy/${TAG}_soak_4000_step_regions.json
@@ -51,5 +66,5 @@ import sys, json
 d = json.load(open('$O/profiles_copy/${TAG}_soak_4000_step_regions.json')); print('K = 4000: ms_per_step', d['ms_per_step'], d['repeats']['ms_per_step_in_order'], 'value', d['value'], 'parity', d['parity_checked'], 'pcie-inclusive', d['pcie_inclusive']['ms_per_step'])"
   lap soak
 fi
-rm -rf $O/se $O/pf $O/pw $O/sq $O/ov
+rm -rf $O/se $O/pf $O/pw $O/sq $O/ov $O/kt
 ls $O/profiles_copy
