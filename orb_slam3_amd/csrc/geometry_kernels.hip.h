@@ -36,6 +36,9 @@ static __global__ __launch_bounds__(256) void k_in_frustum(const FrustumFrame *_
     float px = -1.f, py = -1.f, pxr = 0.f, dep = 0.f, vc = 0.f;   // :515-516: mTrackProjX/Y = -1 until the bounds test passes
     int lvl = 0;
     const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
+    // every input of the map point requested at once (the tests below read them conditionally: each would be a dependent round trip -- over the host
+    // link when the call runs in the matcher context's direct mode)
+    const float mn_in = min_dist[i], mx = max_dist[i], N0 = normal[3 * i], N1 = normal[3 * i + 1], N2 = normal[3 * i + 2];
     float Pc[3];
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -48,11 +51,9 @@ static __global__ __launch_bounds__(256) void k_in_frustum(const FrustumFrame *_
             px = u; py = v;
             const float PO0 = __fsub_rn(P0, F.Ow[0]), PO1 = __fsub_rn(P1, F.Ow[1]), PO2 = __fsub_rn(P2, F.Ow[2]);
             const float dist = sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(PO0, PO0)), __fmul_rn(PO1, PO1)), __fmul_rn(PO2, PO2)));
-            const float mx = max_dist[i];
-            const float maxDistance = __fmul_rn(1.2f, mx), minDistance = __fmul_rn(0.8f, min_dist[i]);
+            const float maxDistance = __fmul_rn(1.2f, mx), minDistance = __fmul_rn(0.8f, mn_in);
             if (!(dist < minDistance || dist > maxDistance)) {
-                const float viewCos = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(PO0, normal[3 * i])), __fmul_rn(PO1, normal[3 * i + 1])),
-                                                          __fmul_rn(PO2, normal[3 * i + 2])), dist);
+                const float viewCos = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(PO0, N0)), __fmul_rn(PO1, N1)), __fmul_rn(PO2, N2)), dist);
                 if (!(viewCos < F.cos_limit)) {
                     const float ratio = __fdiv_rn(mx, dist);
                     // logf through the double logarithm: correctly rounded to float but for double-rounding cases (libm's logf is

@@ -1000,6 +1000,74 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
     }
 }
 
+// k_window_brute (round 6): the same lists as k_window_best2_t WITHOUT the frame's grid, for ONE small problem (a single host-pointer call with a
+// thousand queries into a thousand features): a wave per query walks every feature of the frame, applies PosInGrid + GetFeaturesInArea's tests itself
+// (in_window: the candidate's grid cell comes out of that, so the key orders candidates exactly as the grid enumeration does: cell x, cell y, index) and
+// the caller's gates, and extracts the kTopK smallest keys.  It replaces k_grid_build (one wave, 12 us: a counting sort the call then uses once) +
+// k_window_best2_t (7 - 9 us) by one launch of ~5 us; k_greedy_resolve's re-scan takes the grid-less scan_window when the record has no grid.
+// grid (ceil(nq / 4)), block 256
+__global__ __launch_bounds__(256) void k_window_brute(const WindowProblem *__restrict__ probs, GridParams g) {
+    const WindowProblem P = probs[0];
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = gld(P.nq_ptr), n = gld(P.n_ptr);
+    if (qi >= nq) return;   // wave-uniform
+    QueryWin w;
+    Desc dq;
+    u64 k1 = kNoKey, k2 = kNoKey;
+    int cnt = 0;
+    if (load_query(P, qi, &w, g, &dq)) {
+        for (int i = lane; i < n; i += 64) {
+            if (P.occupied0 && gld(P.occupied0 + i)) continue;
+            const orbx_keypoint kp = gld_kp(P.kps + i);
+            int cx, cy;
+            if (!in_window(g, w, kp, &cx, &cy)) continue;
+            if (P.inv_sigma2) {  // Fuse: chi2 gate on the reprojection error (as k_window_best2_t)
+                const float ex = __fsub_rn(w.x, kp.x), ey = __fsub_rn(w.y, kp.y);
+                if (P.u_right && gld(P.u_right + i) >= 0) {
+                    const float er = __fsub_rn(w.xr, gld(P.u_right + i));
+                    const float e2 = P.chi2_fma ? __fmaf_rn(er, er, __fmaf_rn(ex, ex, __fmul_rn(ey, ey)))
+                                                : __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                    if ((double)__fmul_rn(e2, gld(P.inv_sigma2 + kp.octave)) > 7.8) continue;
+                } else {
+                    const float e2 = P.chi2_fma ? __fmaf_rn(ex, ex, __fmul_rn(ey, ey)) : __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                    if ((double)__fmul_rn(e2, gld(P.inv_sigma2 + kp.octave)) > 5.99) continue;
+                }
+            } else if (P.u_right && gld(P.u_right + i) > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
+                const float er = fabsf(w.xr - gld(P.u_right + i));
+                if (er > w.r) continue;
+            }
+            const int d = hamming(dq, gld_desc(P.desc + (size_t)i * 32));
+            push2(k1, k2, cand_key(d, cx, cy, i));
+            cnt++;
+        }
+    }
+    int total = cnt;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) total += __shfl_xor(total, s);
+    u64 out[kTopK];
+    int valid_len = 0, npop = 0;
+    bool cut = false;
+#pragma unroll
+    for (int r = 0; r < kTopK; r++) {
+        const u64 m = wave_min1(k1);
+        out[r] = m;
+        if (m != kNoKey && !cut) valid_len = r + 1;
+        const bool mine = (m != kNoKey) && (k1 == m);
+        if (mine) { k1 = k2; k2 = kNoKey; npop++; }
+        // a lane that ran dry while it had seen more than two candidates invalidates everything after this round (as k_window_best2_t)
+        const bool dry = mine && npop == 2 && cnt > 2;
+        cut = cut || (__ballot(dry) != 0ull);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < kTopK; r++) gst(P.keys + (size_t)qi * kTopK + r, out[r]);
+        gst(P.meta + qi, valid_len | ((total <= valid_len) ? 256 : 0) | ((total == 0) ? 512 : 0));
+    }
+}
+// the largest (queries x features) a single call hands to k_window_brute (beyond it the grid pays for itself)
+constexpr size_t kBruteMaxPairs = (size_t)5 << 19;   // 2.6 M
+
 struct ResolveProblem {
     int mode;                 // 1 = SearchByProjection(Frame, MapPoints) (M1), 2 = SearchByProjection(Cur, Last) (M2)
     float nnratio;            // M1
@@ -1175,7 +1243,8 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                 Desc dq;
                 u64 r1 = kNoKey, r2 = kNoKey;
                 if (load_query_eager(P, qc, &w, g, &dq)) {
-                    scan_window_grid(P, g, w, dq, n, occ, lane, r1, r2);
+                    if (P.gstart) scan_window_grid(P, g, w, dq, n, occ, lane, r1, r2);
+                    else scan_window(P, g, w, dq, n, occ, lane, r1, r2);   // a record without a grid (k_window_brute made its lists): wave-uniform
                     wave_min2(r1, r2);
                 }
                 if (accept(r1, r2)) {
@@ -1757,6 +1826,7 @@ struct BowProblem {
     int32_t *counters;   // scratch [2], zeroed: entries appended, matches accepted
     int32_t *nmatches;
     const int32_t *pair_b;   // [fa.n_nodes] index of the node with the same id in fb, or -1 (merge-join of the two sorted node-id lists, done by the host)
+    int debug_stop;          // diagnostic (ORBX_BOW_DEBUG): 1 return after the node's ranges, 2 after the candidates' loads, 3 after the first chunk's query loads, 4 skip the loop body's reductions
 };
 
 // k_replay_bow: the query loops of SearchByBoW x 2 / SearchForTriangulation, ONE WAVE PER VOCABULARY NODE of A's feature vector.  The reference walks
@@ -1886,12 +1956,32 @@ __device__ __forceinline__ bool tri_gate_regs(const TriGate &g, float x1, float 
     return (double)dsqr < __dmul_rn(3.84, (double)sigma2_o);
 }
 
+// minimum of a 32-bit key over the wave: DPP scan (row_shr 1 / 2 / 4 / 8, row_bcast15, row_bcast31), the result read from lane 63 -- a dozen vector
+// instructions; the 64-bit wave_min2 above goes through ds_bpermute (twelve LDS round trips, dependent)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, CTRL, ROWS, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_min_u32<0x111, 0xf>(v);
+    v = dpp_min_u32<0x112, 0xf>(v);
+    v = dpp_min_u32<0x114, 0xf>(v);
+    v = dpp_min_u32<0x118, 0xf>(v);
+    v = dpp_min_u32<0x142, 0xa>(v);
+    v = dpp_min_u32<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+constexpr uint32_t kNoKey32 = 0xffffffffu;
+
 __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int a0, const int a1, const int b0, const int nbn, const int lane) {
     const int mode = P.mode;
     const bool gated = mode == 2 && P.gate.enabled;
-    // ---- candidate `lane` of B's list ----
+    // ---- the index lists first (both requests in flight together), then everything that hangs off them ----
     const bool cv = lane < nbn;
     const int j = cv ? P.fb.index[b0 + lane] : 0;
+    int i_next = a0 + lane < a1 ? P.fa.index[a0 + lane] : 0;
+    // ---- candidate `lane` of B's list ----
     const bool cskip = cv && P.skip_b && P.skip_b[j];
     const Desc dc = load_desc(P.desc_b + (size_t)j * 32);
     const float ang_b = (P.check_orientation && cv) ? P.angle_b[j] : 0.f;
@@ -1904,12 +1994,16 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
         st2 = P.gate.ur2 && P.gate.ur2[j] >= 0.f;
     }
     const bool right = mode == 3 && j >= P.nb_left;
+    if (P.debug_stop == 2) { if (dc.w[0] == 0x1234567ull && ang_b == 1.5f && cskip && x2 == 3.f) P.match[0] = 7; return; }
     bool taken = false;   // vpMapPointMatches[realIdxF] != NULL (:281) / vbMatched2[idx2] (:826): nothing but this wave's own matches sets them
     int nmatches = 0;
+    // candidate key: distance (<= 256) << 6 | lane -- the first minimum in list order wins; SearchForTriangulation (:1017) lets a later equal one win: 63 - lane
+    const uint32_t ktie = mode == 2 ? (uint32_t)(63 - lane) : (uint32_t)lane;
     for (int q0 = a0; q0 < a1; q0 += 64) {
         // ---- query `lane` of this chunk of A's list ----
         const bool qv = q0 + lane < a1;
-        const int i = qv ? P.fa.index[q0 + lane] : 0;
+        const int i = i_next;
+        if (q0 + 64 < a1) i_next = q0 + 64 + lane < a1 ? P.fa.index[q0 + 64 + lane] : 0;
         const bool qskip = !qv || (P.skip_a && P.skip_a[i]);
         const Desc dqa = load_desc(P.desc_a + (size_t)i * 32);
         const float ang_a = (P.check_orientation && qv) ? P.angle_a[i] : 0.f;
@@ -1917,59 +2011,74 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
         bool st1 = false;
         if (gated && qv) { x1 = P.gate.k1[i].x; y1 = P.gate.k1[i].y; st1 = P.gate.ur1 && P.gate.ur1[i] >= 0.f; }
         int e0 = -1, e1 = -1;   // this lane's QUERY produced these histogram entries (bin << 16 | out index); mode 3 can produce two
+        if (P.debug_stop == 3) { if (dqa.w[0] == 0x1234567ull && ang_a == 1.5f && qskip && x1 == 3.f && dc.w[0] == 0x1234567ull && ang_b == 1.5f && cskip) P.match[0] = 7; return; }
         const int nqc = min(64, a1 - q0);
-        for (int q = 0; q < nqc; q++) {
-            if (__shfl((int)qskip, q)) continue;   // wave-uniform
-            const int iq = __shfl(i, q);
-            const Desc dq = shfl_desc(dqa, q);
-            const float aq = __shfl(ang_a, q);
+        const u64 skipmask = __ballot(qskip);
+        for (int qq = 0; qq < nqc; qq++) {
+            const int q = __builtin_amdgcn_readfirstlane(qq);   // wave-uniform: the query's fields come by v_readlane (scalar operands from here on)
+            if ((skipmask >> q) & 1ull) continue;
+            const int iq = __builtin_amdgcn_readlane(i, q);
+            Desc dq;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                dq.w[k] = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(dqa.w[k] >> 32), q) << 32) | (u64)(uint32_t)__builtin_amdgcn_readlane((int)dqa.w[k], q);
+            const float aq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_a), q));
             float xq = 0.f, yq = 0.f;
             bool stq = false;
-            if (gated) { xq = __shfl(x1, q); yq = __shfl(y1, q); stq = __shfl((int)st1, q) != 0; }   // (wave-uniform branch: every lane takes part)
-            u64 k1 = kNoKey, k2 = kNoKey, r1 = kNoKey, r2 = kNoKey;
+            if (gated) {
+                xq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), q));
+                yq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1), q));
+                stq = __builtin_amdgcn_readlane((int)st1, q) != 0;
+            }
+            uint32_t k = kNoKey32, kr = kNoKey32;   // kr: right-camera candidates of mode 3 (:302-315: best / second best kept per camera)
             if (cv && !cskip && !(taken && mode != 2)) {
                 const int d = hamming(dq, dc);
+                const uint32_t key = ((uint32_t)d << 6) | ktie;
                 if (mode == 2) {
                     bool ok = d <= ORBX_TH_LOW;   // :1017
                     if (ok && gated) ok = tri_gate_regs(P.gate, xq, yq, stq, x2, y2, st2, sc2, sg2);
-                    if (ok) k1 = ((u64)(uint32_t)d << 32) | (u64)(0xffffffffu - (uint32_t)lane);   // a later equal candidate wins
+                    if (ok) k = key;
                 } else if (right) {
-                    r1 = ((u64)(uint32_t)d << 32) | (u64)(uint32_t)lane;
+                    kr = key;
                 } else {
-                    k1 = ((u64)(uint32_t)d << 32) | (u64)(uint32_t)lane;
+                    k = key;
                 }
             }
-            wave_min2(k1, k2);
+            const uint32_t m1 = wave_min_u32(k);
             if (mode == 3) {
-                wave_min2(r1, r2);
-                if (k1 == kNoKey || (int)(k1 >> 32) > ORBX_TH_LOW) continue;
-                const int bestL = (int)(k1 >> 32);
-                const float secondL = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
-                const int pl = (int)(uint32_t)(k1 & 0xffffffffu);
+                if (m1 == kNoKey32 || (int)(m1 >> 6) > ORBX_TH_LOW) continue;   // :318-377: the right match is looked at only inside the bestDist1 <= TH_LOW branch
+                const uint32_t m2 = wave_min_u32(k == m1 ? kNoKey32 : k);
+                const uint32_t mr = wave_min_u32(kr);
+                const int bestL = (int)(m1 >> 6);
+                const float secondL = (m2 == kNoKey32) ? 256.0f : (float)(int)(m2 >> 6);
+                const int pl = (int)(m1 & 63u);
                 const bool okL = (float)bestL < P.nnratio * secondL;
-                const bool okR = r1 != kNoKey && (int)(r1 >> 32) <= ORBX_TH_LOW;
-                const int pr = okR ? (int)(uint32_t)(r1 & 0xffffffffu) : -1;
+                const bool okR = mr != kNoKey32 && (int)(mr >> 6) <= ORBX_TH_LOW;   // its ratio test is switched off by `|| true` (:359)
+                const int pr = okR ? (int)(mr & 63u) : 0;
                 if (okL && lane == pl) { taken = true; P.match[j] = iq; if (P.check_orientation) atomicAdd(&P.hist[dev_rot_bin(aq, ang_b)], 1); }
                 if (okR && lane == pr) { taken = true; P.match[j] = iq; if (P.check_orientation) atomicAdd(&P.hist[dev_rot_bin(aq, ang_b)], 1); }
                 if (P.check_orientation) {
-                    const int jl = __shfl(j, pl), binl = dev_rot_bin(aq, __shfl(ang_b, pl));
-                    const int jr = __shfl(j, okR ? pr : 0), binr = dev_rot_bin(aq, __shfl(ang_b, okR ? pr : 0));
+                    const int jl = __builtin_amdgcn_readlane(j, pl), jr = __builtin_amdgcn_readlane(j, pr);
+                    const int binl = dev_rot_bin(aq, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_b), pl)));
+                    const int binr = dev_rot_bin(aq, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_b), pr)));
                     if (lane == q) { if (okL) e0 = (binl << 16) | jl; if (okR) e1 = (binr << 16) | jr; }
                 }
                 nmatches += (okL ? 1 : 0) + (okR ? 1 : 0);
                 continue;
             }
-            if (k1 == kNoKey) continue;
-            const int best = (int)(k1 >> 32);
-            const int pos = mode == 2 ? (int)(0xffffffffu - (uint32_t)(k1 & 0xffffffffu)) : (int)(uint32_t)(k1 & 0xffffffffu);
-            const float second = (k2 == kNoKey) ? 256.0f : (float)(int)(k2 >> 32);
-            bool ok;
-            if (mode == 0) ok = best <= ORBX_TH_LOW && (float)best < P.nnratio * second;      // :318-320
-            else if (mode == 1) ok = best < ORBX_TH_LOW && (float)best < P.nnratio * second;  // :848-850 (strict)
-            else ok = true;
+            if (m1 == kNoKey32) continue;
+            const int best = (int)(m1 >> 6);
+            const int pos = mode == 2 ? 63 - (int)(m1 & 63u) : (int)(m1 & 63u);
+            bool ok = true;
+            if (mode != 2) {   // the ratio test needs the second-best distance
+                const uint32_t m2 = wave_min_u32(k == m1 ? kNoKey32 : k);
+                const float second = (m2 == kNoKey32) ? 256.0f : (float)(int)(m2 >> 6);
+                if (mode == 0) ok = best <= ORBX_TH_LOW && (float)best < P.nnratio * second;      // :318-320
+                else ok = best < ORBX_TH_LOW && (float)best < P.nnratio * second;                 // :848-850 (strict)
+            }
             if (!ok) continue;
             nmatches++;
-            const int jw = __shfl(j, pos);
+            const int jw = __builtin_amdgcn_readlane(j, pos);
             const int out_idx = mode == 0 ? jw : iq, out_val = mode == 0 ? iq : jw;
             if (lane == pos) {
                 if (mode != 2) taken = true;
@@ -1977,7 +2086,7 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
                 if (P.check_orientation) atomicAdd(&P.hist[dev_rot_bin(aq, ang_b)], 1);
             }
             if (P.check_orientation) {
-                const int bin = dev_rot_bin(aq, __shfl(ang_b, pos));
+                const int bin = dev_rot_bin(aq, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_b), pos)));
                 if (lane == q) e0 = (bin << 16) | out_idx;
             }
         }
@@ -1987,7 +2096,7 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
             if (tot) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&P.counters[0], tot);
-                base = __shfl(base, 0);
+                base = __builtin_amdgcn_readlane(base, 0);
                 const u64 lt = (1ull << lane) - 1ull;
                 if (e0 >= 0) P.entries[base + __popcll(b0m & lt)] = e0;
                 if (e1 >= 0) P.entries[base + __popcll(b0m) + __popcll(b1m & lt)] = e1;
@@ -2004,6 +2113,7 @@ __global__ __launch_bounds__(256) void k_replay_bow(BowProblem P) {
     const int ib = P.pair_b[ia];   // the node of B with the same id (:246-250, :800-805, :961-965 merge-join the two sorted maps), -1: none
     if (ib < 0) return;
     const int a0 = P.fa.node_ptr[ia], a1 = P.fa.node_ptr[ia + 1], b0 = P.fb.node_ptr[ib], b1 = P.fb.node_ptr[ib + 1];
+    if (P.debug_stop == 1) { if (a0 + a1 + b0 + b1 == -12345) P.match[0] = 7; return; }
     if (b1 - b0 <= 64) replay_bow_node64(P, a0, a1, b0, b1 - b0, lane);
     else replay_bow_big_node(P, ia, ib, lane);
 }

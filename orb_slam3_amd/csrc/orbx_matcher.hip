@@ -108,9 +108,11 @@ struct orbx_matcher {
     std::vector<Pending> pending;   // downloads waiting in pinned memory for the stream synchronisation
     struct Down { void *dst; size_t off, bytes; };
     std::vector<Down> downloads;    // recorded downloads from the arena (issued by deliver())
+    std::vector<Down> direct;       // results a kernel wrote straight into the mirror (host_view): handed out after the synchronisation, no transfer
     hipError_t xfer_err = hipSuccess;
     int64_t xfers[6] = {0, 0, 0, 0, 0, 0};   // transfer submissions (runs) up / down and their bytes since begin(); [4] of them by a DMA engine, [5] k_xfer launches
     bool kernel_xfer = true;                 // ORBX_MATCHER_DMA=1: every run by hipMemcpyAsync, fills by hipMemsetAsync (round 5's transport, for A/B)
+    bool brute_windows = true;               // ORBX_MATCHER_BRUTE=0: small single calls build the grid as large ones do (A/B)
     bool dirty = false;                      // something was enqueued since the last synchronisation
     int32_t replay_stats[3] = {0, 0, 0};     // k_replay_init_lists of the last orbx_search_for_initialization: rounds, whole-wave re-scans, queries
     static constexpr size_t kPadGap = 255;   // Arena::take aligns to 256
@@ -128,7 +130,7 @@ struct orbx_matcher {
     // launch, an exhausted staging arena) left `dirty` set and is waited for here, before its mirror ranges are staged over
     void begin() {
         if (dirty) { (void)hipStreamSynchronize(stream); dirty = false; }
-        arena.reset(); stage.reset(); pending.clear(); uploads.clear(); downloads.clear(); issued.clear(); fills.clear(); xfer_err = hipSuccess;
+        arena.reset(); stage.reset(); pending.clear(); uploads.clear(); downloads.clear(); direct.clear(); issued.clear(); fills.clear(); xfer_err = hipSuccess;
         for (int64_t &x : xfers) x = 0;
     }
     bool in_arena(const void *p, size_t bytes) const {
@@ -143,6 +145,16 @@ struct orbx_matcher {
         return true;
     }
     void note(hipError_t e) { if (e != hipSuccess && xfer_err == hipSuccess) xfer_err = e; }
+    // DIRECT access (round 6): a purely streaming kernel (every input read once, every output written once: k_in_frustum) is handed the MIRROR's addresses
+    // of its arena buffers -- its lanes read the staged inputs over the host link and write the results into host memory themselves: one launch per call
+    // instead of three (k_xfer, kernel, k_xfer).  host_view(p) = the mirror address of arena buffer p; stage_direct copies an input there without recording an
+    // upload; result_direct registers an output for deliver().
+    template <class T> T *host_view(T *p) const { return reinterpret_cast<T *>(mirror.base + (reinterpret_cast<const uint8_t *>(p) - arena.base)); }
+    bool direct_ok(size_t total_bytes) const { return kernel_xfer && total_bytes <= kKernelXferMax * 2; }
+    void stage_direct(void *arena_dst, const void *src, size_t bytes) { memcpy(host_view(static_cast<uint8_t *>(arena_dst)), src, bytes); }
+    void result_direct(void *dst, const void *arena_src, size_t bytes) {
+        direct.push_back(Down{dst, (size_t)(static_cast<const uint8_t *>(arena_src) - arena.base), bytes});
+    }
     void record_upload(size_t o, size_t bytes) {   // staged in the mirror at offset o by the caller
         for (const Fill &f : fills)
             if (o < f.off + f.bytes + 16 && f.off < o + bytes + 16) { flush_uploads(); break; }   // never reorder an upload and a fill of one range
@@ -234,9 +246,11 @@ struct orbx_matcher {
         dirty = false;
         if (xfer_err == hipSuccess) {
             for (const Down &d : downloads) memcpy(d.dst, mirror.base + d.off, d.bytes);
+            for (const Down &d : direct) memcpy(d.dst, mirror.base + d.off, d.bytes);
             for (const Pending &q : pending) memcpy(q.dst, q.src, q.bytes);
         }
         downloads.clear();
+        direct.clear();
         pending.clear();
         issued.clear();
         return xfer_err;
@@ -267,6 +281,8 @@ int orbx_matcher_create(int device, orbx_matcher **out) {
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); delete m; return ORBX_E_HIP; }
     const char *dma = getenv("ORBX_MATCHER_DMA");
     m->kernel_xfer = !(dma && dma[0] == '1');
+    const char *br = getenv("ORBX_MATCHER_BRUTE");
+    m->brute_windows = !(br && br[0] == '0');
     *out = m;
     return ORBX_OK;
 }
@@ -570,13 +586,20 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
     R.entries = A.take<int32_t>(nq);
     R.match = A.take<int32_t>(n);
     R.nmatches = A.take<int32_t>(1);
+    // a small problem skips the grid: k_window_brute walks all features per query (no k_grid_build launch, whose counting sort this one call would use once)
+    const bool brute = m->brute_windows && (size_t)nq * (size_t)n <= kBruteMaxPairs;
+    if (brute) { P.gstart = nullptr; P.gorder = nullptr; }
     H2D(dP, &P, sizeof(P)); H2D(dR, &R, sizeof(R));
     GridParams g;
     g.minx = F->min_x; g.miny = F->min_y;
     g.inv_w = 64.0f / (F->max_x - F->min_x);  // Frame.cc:342-343
     g.inv_h = 48.0f / (F->max_y - F->min_y);
-    ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
-    ORBX_LAUNCH_WINDOW_BEST2(nq, 1, m->exec(), dP, g);
+    if (brute) {
+        hipLaunchKernelGGL(k_window_brute, dim3((nq + 3) / 4), dim3(256), 0, m->exec(), dP, g);
+    } else {
+        ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
+        ORBX_LAUNCH_WINDOW_BEST2(nq, 1, m->exec(), dP, g);
+    }
     if (resolve_lds_bytes(n) > 64 * 1024)
         ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
     hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->exec(), dP, dR, g, n);
@@ -1041,6 +1064,7 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
         return d;
     };
     P.mode = mode; P.nb_left = nb_left;
+    { const char *dbg = getenv("ORBX_BOW_DEBUG"); P.debug_stop = dbg ? atoi(dbg) : 0; }
     P.desc_a = up(desc_a, 32 * (size_t)na); P.desc_b = up(desc_b, 32 * (size_t)nb);
     P.angle_a = (const float *)up(angle_a, 4 * (size_t)na); P.angle_b = (const float *)up(angle_b, 4 * (size_t)nb);
     P.skip_a = up(skip_a, na); P.skip_b = up(skip_b, nb);
@@ -1439,6 +1463,17 @@ extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_camera *cam, const
     int32_t *dl = A.take<int32_t>(n);
     FrustumFrame *dF = A.take<FrustumFrame>(1);
     const FrustumFrame F = frustum_frame(cam, pose, bounds4, log_scale_factor, nlevels, viewing_cos_limit);
+    if (m->direct_ok(57 * n)) {   // streaming kernel, small call: its lanes read the staged inputs from and write the results into the pinned mirror (one launch)
+        m->stage_direct(dF, &F, sizeof(F));
+        m->stage_direct(dp, pos, 12 * n); m->stage_direct(dn, normal, 12 * n); m->stage_direct(dmn, min_dist, 4 * n); m->stage_direct(dmx, max_dist, 4 * n);
+        hipLaunchKernelGGL(k_in_frustum, dim3((n_mp + 255) / 256, 1), dim3(256), 0, m->exec(), (const FrustumFrame *)m->host_view(dF), n_mp,
+                           (const float *)m->host_view(dp), (const float *)m->host_view(dn), (const float *)m->host_view(dmn), (const float *)m->host_view(dmx),
+                           m->host_view(div), m->host_view(dx), m->host_view(dy), m->host_view(dxr), m->host_view(dd), m->host_view(dl), m->host_view(dvc));
+        m->result_direct(in_view, div, n); m->result_direct(proj_x, dx, 4 * n); m->result_direct(proj_y, dy, 4 * n); m->result_direct(proj_xr, dxr, 4 * n);
+        m->result_direct(depth, dd, 4 * n); m->result_direct(level, dl, 4 * n); m->result_direct(view_cos, dvc, 4 * n);
+        SYNC_AND_DELIVER();
+        return ORBX_OK;
+    }
     H2D(dF, &F, sizeof(F));
     H2D(dp, pos, 12 * n); H2D(dn, normal, 12 * n); H2D(dmn, min_dist, 4 * n); H2D(dmx, max_dist, 4 * n);
     hipLaunchKernelGGL(k_in_frustum, dim3((n_mp + 255) / 256, 1), dim3(256), 0, m->exec(), (const FrustumFrame *)dF, n_mp, (const float *)dp,
@@ -1763,13 +1798,19 @@ extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_frame_desc *kf, cons
     WindowProblem *dP = A.take<WindowProblem>(1);   // directly behind the inputs: the call's uploads are one run of the arena (one DMA)
     P.keys = A.take<u64>((size_t)n_q * kTopK); P.meta = A.take<int32_t>(n_q);
     P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n);
+    const bool brute = m->brute_windows && (size_t)n_q * (size_t)n <= kBruteMaxPairs;
+    if (brute) { P.gstart = nullptr; P.gorder = nullptr; }
     H2D(dP, &P, sizeof(P));
     GridParams g;
     g.minx = kf->min_x; g.miny = kf->min_y;
     g.inv_w = 64.0f / (kf->max_x - kf->min_x);
     g.inv_h = 48.0f / (kf->max_y - kf->min_y);
-    ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
-    ORBX_LAUNCH_WINDOW_BEST2(n_q, 1, m->exec(), dP, g);
+    if (brute) {
+        hipLaunchKernelGGL(k_window_brute, dim3((n_q + 3) / 4), dim3(256), 0, m->exec(), dP, g);
+    } else {
+        ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
+        ORBX_LAUNCH_WINDOW_BEST2(n_q, 1, m->exec(), dP, g);
+    }
     std::vector<u64> keys((size_t)n_q * kTopK);
     D2H(keys.data(), P.keys, 8 * (size_t)n_q * kTopK);
     SYNC_AND_DELIVER();
