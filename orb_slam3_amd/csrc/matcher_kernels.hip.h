@@ -623,6 +623,12 @@ struct WindowProblem {
     // outputs
     u64 *keys;                  // per query: the kTopK smallest candidate keys, ascending (kNoKey = none)
     int32_t *meta;              // per query: valid_len | exhaustive << 8 | empty_window << 9  (see k_window_best2)
+    // k_window_best2_t<64> only (SearchForInitialization): EVERY candidate key of a query, unordered, up to all_cap per query (NULL: not wanted); all_cnt[q] = how
+    // many the query has (> all_cap: the list is incomplete).  k_replay_init_lists re-evaluates a query whose short list ran dry from this one -- a coalesced read
+    // and LDS look-ups instead of a walk through the grid (bounds -> indices -> keypoints -> descriptors, ten times over for a 100-px window)
+    u64 *all_keys;
+    int32_t *all_cnt;
+    int32_t all_cap;
 };
 
 // candidate key: dist << 32 | cellx << 24 | celly << 16 | idx   (candidate order of GetFeaturesInArea: ix outer,
@@ -694,22 +700,37 @@ __device__ __forceinline__ bool load_query_eager(const WindowProblem &P, int qi,
     return valid && !w->empty;
 }
 
-// scan all features of the current frame for query window w; skip features flagged in `occ` (may be NULL)
+// scan all features of the current frame for query window w; skip features flagged in `occ` (may be NULL).  Eight features per lane are in flight at once
+// (keypoint, right coordinate and descriptor requested together before any test: the scan is a latency chain of ONE wave -- round 6: the re-scan of
+// k_greedy_resolve when k_window_brute made the lists, 16 dependent round trips for 1000 features in the one-at-a-time form, now two)
 __device__ __forceinline__ int scan_window(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
                                            const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
     int cnt = 0;
-    for (int i = lane; i < n; i += 64) {
-        if (occ && occ[i]) continue;
-        const orbx_keypoint kp = P.kps[i];
-        int cx, cy;
-        if (!in_window(g, w, kp, &cx, &cy)) continue;
-        if (P.u_right && P.u_right[i] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
-            const float er = fabsf(w.xr - P.u_right[i]);
-            if (er > w.r) continue;
+    for (int i0 = 0; i0 < n; i0 += 8 * 64) {
+        orbx_keypoint kp[8];
+        Desc dc[8];
+        float ur[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = min(i0 + 64 * u + lane, n - 1);
+            kp[u] = gld_kp(P.kps + i);
+            dc[u] = gld_desc(P.desc + (size_t)i * 32);
+            ur[u] = P.u_right ? gld(P.u_right + i) : 0.f;
         }
-        const int d = hamming(dq, load_desc(P.desc + (size_t)i * 32));
-        push2(k1, k2, cand_key(d, cx, cy, i));
-        cnt++;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 64 * u + lane;
+            if (i >= n || (occ && occ[i])) continue;
+            int cx, cy;
+            if (!in_window(g, w, kp[u], &cx, &cy)) continue;
+            if (P.u_right && ur[u] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
+                const float er = fabsf(w.xr - ur[u]);
+                if (er > w.r) continue;
+            }
+            const int d = hamming(dq, dc[u]);
+            push2(k1, k2, cand_key(d, cx, cy, i));
+            cnt++;
+        }
     }
     return cnt;
 }
@@ -906,6 +927,11 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
     const WindowProblem P = probs[prob];
     const int sub = threadIdx.x / LQ, sl = threadIdx.x & (LQ - 1);
     const int qi = blockIdx.y * (256 / LQ) + sub;
+    __shared__ int all_n[LQ == 64 ? 4 : 1];
+    if (LQ == 64 && P.all_keys) {   // workgroup-uniform
+        if (threadIdx.x < 4) all_n[threadIdx.x] = 0;
+        __syncthreads();
+    }
     const int nq = gld(P.nq_ptr);
     const bool qvalid = qi < nq;
     QueryWin w;
@@ -962,7 +988,12 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
                     if (er > w.r) continue;
                 }
                 const int d = hamming(dq, gld_desc(P.desc + (size_t)i * 32));
-                push2(k1, k2, seq_key(d, seq0 + (j - s), i));
+                const u64 key = seq_key(d, seq0 + (j - s), i);
+                push2(k1, k2, key);
+                if (LQ == 64 && P.all_keys) {   // (compile-time false for the hot forms)
+                    const int slot = atomicAdd(&all_n[sub], 1);
+                    if (slot < P.all_cap) gst(P.all_keys + (size_t)qi * P.all_cap + slot, key);
+                }
                 cnt++;
             }
             seq0 += tot;
@@ -997,6 +1028,7 @@ __global__ __launch_bounds__(256) void k_window_best2_t(const WindowProblem *__r
 #pragma unroll
         for (int r = 0; r < kTopK; r++) gst(P.keys + (size_t)qi * kTopK + r, out[r]);
         gst(P.meta + qi, valid_len | ((total <= valid_len) ? 256 : 0) | ((total == 0) ? 512 : 0));   // bit 9: GetFeaturesInArea returned nothing
+        if (LQ == 64 && P.all_keys) gst(P.all_cnt + qi, total);
     }
 }
 
@@ -1707,7 +1739,19 @@ __global__ __launch_bounds__(64) void k_replay_init_lists(const WindowProblem *_
                 QueryWin w;
                 Desc dq;
                 u64 r1 = kNoKey, r2 = kNoKey;
-                if (load_query_eager(P, qc, &w, g, &dq)) {
+                const int call = P.all_keys ? gld(P.all_cnt + qc) : 0x7fffffff;
+                if (call <= P.all_cap) {   // the query's complete candidate list: the skip rule of :687-688 on every entry, the two smallest survivors
+                    const u64 *lk = P.all_keys + (size_t)qc * P.all_cap;
+                    for (int t0 = 0; t0 < call; t0 += 4 * 64) {
+                        u64 kk[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) kk[u] = t0 + 64 * u + lane < call ? gld(lk + t0 + 64 * u + lane) : kNoKey;
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (kk[u] != kNoKey && !((int)md[(int)(kk[u] & 0xffff)] <= (int)(kk[u] >> 32))) push2(r1, r2, kk[u]);
+                    }
+                    wave_min2(r1, r2);
+                } else if (load_query_eager(P, qc, &w, g, &dq)) {
                     scan_window_grid_md(P, g, w, dq, n2, md, lane, r1, r2);
                     wave_min2(r1, r2);
                 }

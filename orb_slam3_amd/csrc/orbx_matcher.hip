@@ -963,9 +963,12 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un
         memcpy(&qd[32 * (size_t)k], desc1 + 32 * (size_t)i, 32);
     }
     const size_t lds = 4 * (size_t)n2 + 2 * (size_t)n2 * 2 + 2 * (size_t)n1 + 64;
+    // every candidate key of every query for the replay's re-evaluations (WindowProblem::all_keys): up to 512 per query within 8 MB
+    const int all_cap = (int)std::min<size_t>(512, std::max<size_t>(64, ((size_t)8 << 20) / (8 * (size_t)nq)));
     const size_t need = Arena::pad(28 * (size_t)n1) + Arena::pad(28 * (size_t)n2) + Arena::pad(32 * (size_t)n2) + Arena::pad(8 * (size_t)n1) +
                         Arena::pad(4 * (size_t)nq) * 6 + Arena::pad(32 * (size_t)nq) + Arena::pad(8 * (size_t)nq * kTopK) + Arena::pad(4 * (size_t)nq) * 2 +
-                        Arena::pad(sizeof(WindowProblem)) + Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)n2) + Arena::pad(4 * (size_t)n1) + 16 * 256 + 4096;
+                        Arena::pad(sizeof(WindowProblem)) + Arena::pad(2 * (kGridCells + 1)) + Arena::pad(2 * (size_t)n2) + Arena::pad(4 * (size_t)n1) + 16 * 256 + 4096 +
+                        Arena::pad(4 * (size_t)nq) + Arena::pad(8 * (size_t)nq * all_cap);
     int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
@@ -992,6 +995,7 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *kps1_un
     WindowProblem *dP = A.take<WindowProblem>(1);
     P.keys = A.take<u64>((size_t)nq * kTopK); P.meta = A.take<int32_t>(nq);
     P.gstart = A.take<uint16_t>(kGridCells + 1); P.gorder = A.take<uint16_t>(n2);
+    P.all_cap = all_cap; P.all_cnt = A.take<int32_t>(nq); P.all_keys = A.take<u64>((size_t)nq * all_cap);
     R.q_index = dqi; R.kps1 = dk1; R.n1 = n1; R.n2 = n2; R.nq = nq; R.nnratio = nnratio; R.check_orientation = check_orientation ? 1 : 0;
     R.entries = A.take<int32_t>(nq);
     R.matches12 = A.take<int32_t>(n1);
