@@ -252,8 +252,9 @@ class ORBmatcher:
         P, Nn = _f32(np.asarray(pos).reshape(-1, 3)), _f32(np.asarray(normal).reshape(-1, 3))
         mn, mx, b = _f32(min_dist), _f32(max_dist), _f32(bounds)
         n = len(P)
-        out = dict(in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, np.float32), proj_y=np.zeros(n, np.float32), proj_xr=np.zeros(n, np.float32),
-                   depth=np.zeros(n, np.float32), level=np.zeros(n, np.int32), view_cos=np.zeros(n, np.float32))
+        # (np.empty: the call writes every entry of every array)
+        out = dict(in_view=np.empty(n, np.uint8), proj_x=np.empty(n, np.float32), proj_y=np.empty(n, np.float32), proj_xr=np.empty(n, np.float32),
+                   depth=np.empty(n, np.float32), level=np.empty(n, np.int32), view_cos=np.empty(n, np.float32))
         c, p = Camera(*[float(x) for x in cam]), FramePose.make(*pose)
         check(self._L.orbx_is_in_frustum(self._h, C.byref(c), C.byref(p), ptr(b), float(log_scale_factor), int(nlevels), float(cos_limit), n, ptr(P),
                                          ptr(Nn), ptr(mn), ptr(mx), *[ptr(out[k]) for k in ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "level", "view_cos")]),
