@@ -700,25 +700,25 @@ __device__ __forceinline__ bool load_query_eager(const WindowProblem &P, int qi,
     return valid && !w->empty;
 }
 
-// scan all features of the current frame for query window w; skip features flagged in `occ` (may be NULL).  Eight features per lane are in flight at once
+// scan all features of the current frame for query window w; skip features flagged in `occ` (may be NULL).  Four features per lane are in flight at once
 // (keypoint, right coordinate and descriptor requested together before any test: the scan is a latency chain of ONE wave -- round 6: the re-scan of
-// k_greedy_resolve when k_window_brute made the lists, 16 dependent round trips for 1000 features in the one-at-a-time form, now two)
+// k_greedy_resolve when k_window_brute made the lists, 16 dependent round trips for 1000 features in the one-at-a-time form, now four; eight in flight cost the kernel 80 more VGPRs)
 __device__ __forceinline__ int scan_window(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
                                            const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
     int cnt = 0;
-    for (int i0 = 0; i0 < n; i0 += 8 * 64) {
-        orbx_keypoint kp[8];
-        Desc dc[8];
-        float ur[8];
+    for (int i0 = 0; i0 < n; i0 += 4 * 64) {
+        orbx_keypoint kp[4];
+        Desc dc[4];
+        float ur[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < 4; u++) {
             const int i = min(i0 + 64 * u + lane, n - 1);
             kp[u] = gld_kp(P.kps + i);
             dc[u] = gld_desc(P.desc + (size_t)i * 32);
             ur[u] = P.u_right ? gld(P.u_right + i) : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < 4; u++) {
             const int i = i0 + 64 * u + lane;
             if (i >= n || (occ && occ[i])) continue;
             int cx, cy;
@@ -1126,7 +1126,11 @@ struct ResolveProblem {
 // LDS with the angles, a query's has-observations flag arrives with its candidate list (one chunk ahead), and the hand-overs between the rounds
 // are LDS-only orderings of the ONE wave (one_wave_sync) -- a __syncthreads() there is s_waitcnt vmcnt(0): every round waited for the
 // acknowledgement of its result stores (round 5: ~45 rounds per 1000 queries of the bench's frame pairs, 170 per 10 000 map points).
-__global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
+// BRUTE: the problems may come without a grid (k_window_brute made the lists: single small host-pointer calls) -- the re-scan then walks all features
+// (scan_window).  An instantiation of its own because that scan keeps four features per lane in flight: 31 more VGPRs than the batched pipeline's form,
+// which shares the machine with the next batch's extraction, has to carry.
+template <bool BRUTE>
+__global__ __launch_bounds__(64) void k_greedy_resolve_t(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
                                                        GridParams g, int n_alloc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ int hist[ORBX_HISTO_LENGTH + 2];
@@ -1275,7 +1279,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve(const WindowProblem *__re
                 Desc dq;
                 u64 r1 = kNoKey, r2 = kNoKey;
                 if (load_query_eager(P, qc, &w, g, &dq)) {
-                    if (P.gstart) scan_window_grid(P, g, w, dq, n, occ, lane, r1, r2);
+                    if (!BRUTE || P.gstart) scan_window_grid(P, g, w, dq, n, occ, lane, r1, r2);
                     else scan_window(P, g, w, dq, n, occ, lane, r1, r2);   // a record without a grid (k_window_brute made its lists): wave-uniform
                     wave_min2(r1, r2);
                 }

@@ -600,9 +600,15 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
         ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
         ORBX_LAUNCH_WINDOW_BEST2(nq, 1, m->exec(), dP, g);
     }
-    if (resolve_lds_bytes(n) > 64 * 1024)
-        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(1), dim3(64), resolve_lds_bytes(n), m->exec(), dP, dR, g, n);
+    if (brute) {
+        if (resolve_lds_bytes(n) > 64 * 1024)
+            ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
+        hipLaunchKernelGGL(k_greedy_resolve_t<true>, dim3(1), dim3(64), resolve_lds_bytes(n), m->exec(), dP, dR, g, n);
+    } else {
+        if (resolve_lds_bytes(n) > 64 * 1024)
+            ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
+        hipLaunchKernelGGL(k_greedy_resolve_t<false>, dim3(1), dim3(64), resolve_lds_bytes(n), m->exec(), dP, dR, g, n);
+    }
     int32_t nm = 0;
     D2H(a.match_out, R.match, 4 * (size_t)n);
     D2H(&nm, R.nmatches, 4);
@@ -1291,8 +1297,8 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         (void)hipEventRecord(e0, ms);
     }
     if (resolve_lds_bytes(cap) > 64 * 1024)
-        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(np), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mprobs.p,
+        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
+    hipLaunchKernelGGL(k_greedy_resolve_t<false>, dim3(np), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mprobs.p,
                        (const ResolveProblem *)ex->d_mres.p, g, cap);
     if (ex->profile) {
         (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
@@ -1402,8 +1408,8 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
     if (n_mp > 0)
         ORBX_LAUNCH_WINDOW_BEST2(n_mp, n, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (resolve_lds_bytes(cap) > 64 * 1024)
-        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
-    hipLaunchKernelGGL(k_greedy_resolve, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
+        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
+    hipLaunchKernelGGL(k_greedy_resolve_t<false>, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
                        (const ResolveProblem *)ex->d_mp_res.p, g, cap);
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
     ex->match_pending = true; ex->copy_covers_match = false;

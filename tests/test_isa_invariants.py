@@ -101,7 +101,8 @@ BUDGETS = {
     "k_pyr_stream": (72, 7, 0, 0),          # two 576-thread workgroups per CU (18 waves): <= 7 waves per SIMD are needed, no spill of the task registers
     "k_pyr_base": (32, 8, 0, 0),
     "k_window_best2_tILi8": (64, 8, 0, 0),
-    "k_greedy_resolve": (96, 5, 128, 0),
+    "k_greedy_resolve_tILb0": (96, 5, 128, 0),   # the batched pipeline's form (beside the next batch's extraction)
+    "k_greedy_resolve_tILb1": (128, 4, 128, 0),  # single small calls: + the grid-less re-scan with four features per lane in flight
     "k_finalize": (32, 8, 64, 0),
 }
 
@@ -117,5 +118,5 @@ def test_resource_budgets(isa):
             assert m["ScratchSize"] <= scratch, (name, m)
     # no kernel spills: scratch only where a cold non-inlined call needs a frame
     for name, (_, _, m) in kernels.items():
-        if not re.search(r"k_octree|k_debug_sort", name):
+        if not re.search(r"k_octree|k_debug_sort|k_replay_bowE", name):   # k_replay_bow: the cold big-node path is a non-inlined call
             assert m["ScratchSize"] == 0, (name, m)
