@@ -1327,6 +1327,268 @@ __global__ __launch_bounds__(64) void k_greedy_resolve_t(const WindowProblem *__
     if (lane == 0) gst(R.nmatches, nmatches);
 }
 
+// Workgroup barrier that orders LDS accesses ONLY (the address-space form of the fence: s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads() is also a
+// release of global memory -- s_waitcnt vmcnt(0) -- so a round of the replay below would wait for the acknowledgement of its result stores.
+__device__ __forceinline__ void wg_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// k_resolve_wide_t (round 6): the same replay of SearchByProjection's sequential query loop (ORBmatcher.cc:88-139, 1745-1800) as k_greedy_resolve_t, by a
+// WORKGROUP of WAVES waves per problem, 64 * WAVES queries of a chunk in flight, ONE query per thread -- and without the restriction to a conflict-free PREFIX:
+// the one-wave form commits the lanes before the first conflicting lane and starts a new round for every conflict (~45 rounds + 6 wave-wide re-scans, one
+// after the other, per 1000 queries of the bench's frame pairs: 99 us of one wave's dependent instructions).  Here a round is
+//   claim    every unresolved query q marks EVERY still-free entry of its candidate list with atomicMin(claim[feature], q)                       | barrier
+//   judge    q's decision depends on its first (M1: first two) free entries f1 (, f2).  It is FINAL when no earlier unresolved query can take them:
+//            claim[f1] == q (and claim[f2] == q) -- an earlier unresolved query e only ever commits to an entry of its own list, all of which it has
+//            claimed -- PROVIDED every earlier unresolved e is "self-contained": its list is exhaustive, or it owns (claim == e) as many free entries
+//            as its decision reads (1, M1: 2), so that what it finally picks lies inside the list.  The lowest query that is not (its whole list
+//            occupied / contested and more candidates in its window than the list holds) is a fence for this round: bar_q                         | barrier
+//   commit   all final queries below bar_q at once: ratio test, match[], the taken-mask, the rotation histogram; claims cleared                    | barrier
+//   re-scan  queries whose non-exhaustive list ran dry are re-scanned against the CURRENT mask, one per wave, all waves at once; the result is a fresh
+//            list of the kTopK best FREE candidates (the mask only grows, so it stays a valid list: the entries that get taken are skipped like any
+//            other).  The lowest unresolved query sees the mask the sequential loop sees, so every round resolves at least that one.              | barrier
+// A chunk of the bench's frame pairs takes 2 - 3 rounds.  "No match" outcomes that cannot change (exhaustive list all taken; best free distance above the
+// threshold -- later states only have worse bests) resolve at once.  Barriers order LDS only (wg_lds_sync); result stores are fire-and-forget.
+// The rotation-histogram entries are written in commit order of the round, not query order: their consumer (the losing bins' features are cleared, :1871-1881)
+// does not depend on the order.
+// grid (n_problems), block 64 * WAVES, dynamic LDS as k_greedy_resolve_t (claim u32 + angle f32 + occ u8 + octave u8 per feature)
+template <int WAVES, bool BRUTE>
+__global__ __launch_bounds__(64 * WAVES) void k_resolve_wide_t(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
+                                                               GridParams g, int n_alloc) {
+    constexpr int T = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ int hist[ORBX_HISTO_LENGTH + 2];
+    // static LDS stays small: with the largest frame (kMaxResolveFeatures) the dynamic part is 160 064 of the 163 840 bytes of a workgroup
+    constexpr int kPool = 64;          // re-scans per round (slot 0 is kept for the LOWEST query that needs one: that one always makes progress)
+    __shared__ u64 rl[kPool * kTopK];  // refreshed lists of the re-scanned queries
+    __shared__ int rl_meta[kPool];
+    __shared__ uint16_t rq[kPool];     // queries (thread ids) to re-scan this round
+    // two sets of round counters, used by alternate rounds (a set is cleared in the round after the one that read it):
+    //   0 bar_q | 1 unresolved after the round | 2 re-scan requests besides the lowest | 3 lowest query that needs a re-scan;  [16] nmatches, [17] histogram entries
+    __shared__ int ctl[18];
+    uint32_t *claim = reinterpret_cast<uint32_t *>(lds);
+    float *ang = reinterpret_cast<float *>(lds + (size_t)n_alloc * 4);
+    uint8_t *occ = lds + (size_t)n_alloc * 8;
+    uint8_t *oct = occ + n_alloc;
+    const WindowProblem P = probs[blockIdx.x];
+    const ResolveProblem R = res[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = min(gld(P.n_ptr), n_alloc), nq = gld(P.nq_ptr);
+    for (int i0 = 0; i0 < n; i0 += 4 * T) {   // four loads in flight per thread
+        float a[4];
+        int l[4];
+        uint8_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + T * k + tid;
+            a[k] = i < n ? gld(&P.kps[i].angle) : 0.f;
+            l[k] = i < n ? gld(&P.kps[i].octave) : 0;
+            o[k] = (i < n && P.occupied0) ? gld(P.occupied0 + i) : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + T * k + tid;
+            if (i < n) {
+                occ[i] = o[k];
+                oct[i] = (uint8_t)l[k];
+                claim[i] = 0xffffffffu;
+                ang[i] = a[k];
+                gst(R.match + i, -1);
+            }
+        }
+    }
+    if (tid < ORBX_HISTO_LENGTH) hist[tid] = 0;
+    if (tid < 18) ctl[tid] = ((tid & 7) == 0 || (tid & 7) == 3) && tid < 16 ? 0x7fffffff : 0;
+    __syncthreads();   // (also: the -1 fills are acknowledged before any wave stores a match into the same array)
+    const float factor = 1.0f / ORBX_HISTO_LENGTH;
+    const bool ori = (R.mode == 2 && R.check_orientation);
+    const bool two = (R.mode == 1);
+
+    auto accept = [&](u64 k1, u64 k2) -> bool {   // ORBmatcher.cc:123-139 (as k_greedy_resolve_t)
+        if (k1 == kNoKey) return false;
+        const int bestDist = (int)(k1 >> 32);
+        if ((float)bestDist > R.max_dist) return false;
+        if (two) {
+            const int bestDist2 = (k2 == kNoKey) ? 256 : (int)(k2 >> 32);
+            const int bestLevel = oct[(int)(k1 & 0xffff)];
+            const int bestLevel2 = (k2 == kNoKey) ? -1 : (int)oct[(int)(k2 & 0xffff)];
+            if (bestLevel == bestLevel2 && (float)bestDist > R.nnratio * (float)bestDist2) return false;
+            if (!(bestLevel != bestLevel2 || (float)bestDist <= R.nnratio * (float)bestDist2)) return false;
+        }
+        return true;
+    };
+    // the whole wave re-scans the window of query q0 + tq against the current mask: kTopK best free candidates -> rl / rl_meta (as k_window_brute extracts them)
+    auto rescan = [&](int qc, int slot) {
+        QueryWin w;
+        Desc dq;
+        u64 k1 = kNoKey, k2 = kNoKey;
+        int cnt = 0;
+        if (load_query_eager(P, qc, &w, g, &dq)) {
+            if (!BRUTE || P.gstart) cnt = scan_window_grid(P, g, w, dq, n, occ, lane, k1, k2);
+            else cnt = scan_window(P, g, w, dq, n, occ, lane, k1, k2);   // a record without a grid: wave-uniform
+        }
+        int total = cnt;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) total += __shfl_xor(total, s);
+        int valid_len = 0, npop = 0;
+        bool cut = false;
+#pragma unroll
+        for (int r = 0; r < kTopK; r++) {
+            const u64 m = wave_min1(k1);
+            if (lane == 0) rl[slot * kTopK + r] = m;
+            if (m != kNoKey && !cut) valid_len = r + 1;
+            const bool mine = (m != kNoKey) && (k1 == m);
+            if (mine) { k1 = k2; k2 = kNoKey; npop++; }
+            const bool dry = mine && npop == 2 && cnt > 2;   // a lane that ran dry while it had seen more: everything after this round is unknown
+            cut = cut || (__ballot(dry) != 0ull);
+        }
+        if (lane == 0) rl_meta[slot] = valid_len | ((total <= valid_len) ? 256 : 0);
+    };
+
+    struct Chunk { u64 L0, L1, L2, L3; int meta; float q_ang; uint8_t obs; };
+    auto fetch = [&](int q0) -> Chunk {
+        Chunk c = {kNoKey, kNoKey, kNoKey, kNoKey, 256, 0.f, (uint8_t)1};
+        const int qi = q0 + tid;
+        if (qi < nq) {
+            const u64 *kp = P.keys + (size_t)qi * kTopK;
+            c.L0 = gld(kp); c.L1 = gld(kp + 1); c.L2 = gld(kp + 2); c.L3 = gld(kp + 3);
+            c.meta = gld(P.meta + qi);
+            if (ori) c.q_ang = P.q_from_kps ? gld(&P.q_from_kps[qi].angle) : gld(R.q_angle + qi);
+            if (R.q_has_obs) c.obs = gld(R.q_has_obs + qi);
+        }
+        return c;
+    };
+    Chunk nxt = fetch(0);
+    int par = 0;   // parity of the round
+    for (int q0 = 0; q0 < nq; q0 += T) {
+        const int qi = q0 + tid;
+        const Chunk C = nxt;
+        asm volatile("" :: "v"(C.L0), "v"(C.L1), "v"(C.L2), "v"(C.L3), "v"(C.meta), "v"(C.q_ang), "v"((int)C.obs) : "memory");   // wait here, not across the next request
+        nxt = fetch(q0 + T);
+        u64 L0 = C.L0, L1 = C.L1, L2 = C.L2, L3 = C.L3;
+        int valid_len = C.meta & 0xff;
+        bool exhaustive = (C.meta & 256) != 0;
+        bool resolved = qi >= nq;
+        for (;; par ^= 8) {
+            int *ct = ctl + par;
+            // ---- claim ----
+            u64 f1 = kNoKey, f2 = kNoKey;
+            uint32_t fm = 0u;   // bit e: list entry e is valid and free
+            if (!resolved) {
+#pragma unroll
+                for (int e = 0; e < kTopK; e++) {
+                    const u64 k = e == 0 ? L0 : e == 1 ? L1 : e == 2 ? L2 : L3;
+                    if (e < valid_len && !occ[(int)(k & 0xffff)]) {
+                        atomicMin(&claim[(int)(k & 0xffff)], (uint32_t)tid);
+                        if (f1 == kNoKey) f1 = k;
+                        else if (f2 == kNoKey) f2 = k;
+                        fm |= 1u << e;
+                    }
+                }
+            }
+            wg_lds_sync();
+            if (tid == 0) { int *o = ctl + (par ^ 8); o[0] = 0x7fffffff; o[1] = 0; o[2] = 0; o[3] = 0x7fffffff; }   // the other set: last read before this barrier, next written after the round's last
+            // ---- judge ----
+            bool decided_no = false, need_rescan = false, can_commit = false;
+            if (!resolved) {
+                if (f1 == kNoKey) { if (exhaustive) decided_no = true; else need_rescan = true; }
+                else if ((float)(int)(f1 >> 32) > R.max_dist) decided_no = true;   // the best free distance only grows
+                else if (two && f2 == kNoKey && !exhaustive) need_rescan = true;    // second best unknown
+                int own = 0;
+#pragma unroll
+                for (int e = 0; e < kTopK; e++) {
+                    const u64 k = e == 0 ? L0 : e == 1 ? L1 : e == 2 ? L2 : L3;
+                    if ((fm >> e) & 1u) own += claim[(int)(k & 0xffff)] == (uint32_t)tid ? 1 : 0;
+                }
+                const bool self_contained = decided_no || (!need_rescan && (exhaustive || own >= (two ? 2 : 1)));
+                if (!self_contained) atomicMin(&ct[0], tid);
+                if (need_rescan) atomicMin(&ct[3], tid);
+                if (!decided_no && !need_rescan)
+                    can_commit = claim[(int)(f1 & 0xffff)] == (uint32_t)tid && (!two || f2 == kNoKey || claim[(int)(f2 & 0xffff)] == (uint32_t)tid);
+            }
+            wg_lds_sync();
+            // ---- commit ----
+            const int bar_q = ct[0];
+            int my_slot = -1;
+            if (!resolved) {
+                bool done = decided_no;
+                if (can_commit && tid < bar_q) {
+                    done = true;
+                    if (accept(f1, two ? f2 : kNoKey)) {
+                        const int t1 = (int)(f1 & 0xffff);
+                        gst(R.match + t1, qi);
+                        occ[t1] = C.obs;
+                        atomicAdd(&ctl[16], 1);
+                        if (ori) {   // :1775-1792
+                            float rot = C.q_ang - ang[t1];
+                            if (rot < 0.0f) rot += 360.0f;
+                            int b = (int)roundf(rot * factor);
+                            if (b == ORBX_HISTO_LENGTH) b = 0;
+                            gst(R.entries + atomicAdd(&ctl[17], 1), (b << 16) | t1);   // rotHist[bin].push_back(bestIdx2)
+                            atomicAdd(&hist[b], 1);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < kTopK; e++) {
+                    const u64 k = e == 0 ? L0 : e == 1 ? L1 : e == 2 ? L2 : L3;
+                    if ((fm >> e) & 1u) claim[(int)(k & 0xffff)] = 0xffffffffu;
+                }
+                if (!done) {
+                    atomicAdd(&ct[1], 1);
+                    if (need_rescan) {
+                        my_slot = tid == ct[3] ? 0 : 1 + atomicAdd(&ct[2], 1);
+                        if (my_slot < kPool) rq[my_slot] = (uint16_t)tid;
+                    }
+                }
+                resolved = done;
+            }
+            wg_lds_sync();
+            const int n_unres = ct[1], rq_n = ct[3] == 0x7fffffff ? 0 : min(1 + ct[2], kPool);
+            if (n_unres == 0) { par ^= 8; break; }   // workgroup-uniform
+            if (rq_n > 0) {
+                for (int i = wave; i < rq_n; i += WAVES) {
+                    rescan(q0 + (int)rq[i], i);
+                }
+                wg_lds_sync();
+                if (my_slot >= 0 && my_slot < kPool) {   // (a request beyond the pool keeps its list: it asks again next round)
+                    L0 = rl[my_slot * kTopK]; L1 = rl[my_slot * kTopK + 1]; L2 = rl[my_slot * kTopK + 2]; L3 = rl[my_slot * kTopK + 3];
+                    const int mt = rl_meta[my_slot];
+                    valid_len = mt & 0xff;
+                    exhaustive = (mt & 256) != 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int nmatches = ctl[16];
+    const int n_entries = ctl[17];
+    if (ori) {
+        // ComputeThreeMaxima :2012-2053
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        // :1871-1881: every entry of a rejected bin clears its feature and decrements nmatches
+        for (int e = tid; e < n_entries; e += T) {
+            const int v = gld(R.entries + e), b = v >> 16;
+            if (b != ind1 && b != ind2 && b != ind3) gst(R.match + (v & 0xffff), R.cleared_value);
+        }
+        int dropped = 0;
+        for (int i = 0; i < ORBX_HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3) dropped += hist[i];
+        nmatches -= dropped;
+    }
+    if (tid == 0) gst(R.nmatches, nmatches);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Matchers whose inner loop carries more state than the candidate lists of k_window_best2 can encode
 // (SearchForInitialization's vMatchedDistance, the BoW merge-joins): ONE WAVE replays the reference's query loop in its

@@ -22,6 +22,25 @@ namespace {
 
 constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) + octave (1 B) per feature must fit the 160 KB LDS (16000 x 10 + 200 B)
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 10 + 64; }   // k_greedy_resolve: claim u32 + angle f32 + occ u8 + octave u8 per feature
+// The replay of SearchByProjection's query loop: k_resolve_wide_t (a workgroup of 4 waves per problem; ORBX_RESOLVE_WAVES=2 / 8 for A/B, =1: the one-wave
+// k_greedy_resolve_t of rounds 1-5)
+template <int WAVES, bool BRUTE>
+inline int launch_resolve_wide(int np, size_t lds, hipStream_t st, const WindowProblem *dP, const ResolveProblem *dR, const GridParams &g, int cap) {
+    if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_resolve_wide_t<WAVES, BRUTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_resolve_wide_t<WAVES, BRUTE>), dim3(np), dim3(64 * WAVES), lds, st, dP, dR, g, cap);
+    return ORBX_OK;
+}
+template <bool BRUTE>
+inline int launch_resolve(int np, hipStream_t st, const WindowProblem *dP, const ResolveProblem *dR, const GridParams &g, int cap) {
+    static const int waves = [] { const char *v = getenv("ORBX_RESOLVE_WAVES"); return v ? atoi(v) : 4; }();
+    const size_t lds = resolve_lds_bytes(cap);
+    if (waves == 2) return launch_resolve_wide<2, BRUTE>(np, lds, st, dP, dR, g, cap);
+    if (waves == 8) return launch_resolve_wide<8, BRUTE>(np, lds, st, dP, dR, g, cap);
+    if (waves != 1) return launch_resolve_wide<4, BRUTE>(np, lds, st, dP, dR, g, cap);
+    if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<BRUTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_greedy_resolve_t<BRUTE>, dim3(np), dim3(64), lds, st, dP, dR, g, cap);
+    return ORBX_OK;
+}
 #define ORBX_LAUNCH_GRID_BUILD(grid, block, lds, stream, ...) hipLaunchKernelGGL(k_grid_build, grid, block, lds, stream, __VA_ARGS__)
 // k_window_best2: 8 lanes per query (a window of the bench's matchers holds 1 - 10 candidates: 16 -> 8 lanes, 74 -> 59 us in round 4; 4 like 8).
 // nq = queries per problem, np = problems.  From 8 problems on the launch is XCD-aware like the extractor's (extractor_kernels.hip.h, xcd_grid): x = XCD,
@@ -600,15 +619,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
         ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
         ORBX_LAUNCH_WINDOW_BEST2(nq, 1, m->exec(), dP, g);
     }
-    if (brute) {
-        if (resolve_lds_bytes(n) > 64 * 1024)
-            ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
-        hipLaunchKernelGGL(k_greedy_resolve_t<true>, dim3(1), dim3(64), resolve_lds_bytes(n), m->exec(), dP, dR, g, n);
-    } else {
-        if (resolve_lds_bytes(n) > 64 * 1024)
-            ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(n)));
-        hipLaunchKernelGGL(k_greedy_resolve_t<false>, dim3(1), dim3(64), resolve_lds_bytes(n), m->exec(), dP, dR, g, n);
-    }
+    { const int rr = brute ? launch_resolve<true>(1, m->exec(), dP, dR, g, n) : launch_resolve<false>(1, m->exec(), dP, dR, g, n); if (rr != ORBX_OK) return rr; }
     int32_t nm = 0;
     D2H(a.match_out, R.match, 4 * (size_t)n);
     D2H(&nm, R.nmatches, 4);
@@ -1296,10 +1307,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         ex->prof_ms[K_MATCH_SCAN] += t; ex->prof_n[K_MATCH_SCAN]++;
         (void)hipEventRecord(e0, ms);
     }
-    if (resolve_lds_bytes(cap) > 64 * 1024)
-        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
-    hipLaunchKernelGGL(k_greedy_resolve_t<false>, dim3(np), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mprobs.p,
-                       (const ResolveProblem *)ex->d_mres.p, g, cap);
+    { const int rr = launch_resolve<false>(np, ms, (const WindowProblem *)ex->d_mprobs.p, (const ResolveProblem *)ex->d_mres.p, g, cap); if (rr != ORBX_OK) return rr; }
     if (ex->profile) {
         (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
         float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
@@ -1407,10 +1415,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
     ORBX_LAUNCH_GRID_BUILD( dim3(n), dim3(64), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (n_mp > 0)
         ORBX_LAUNCH_WINDOW_BEST2(n_mp, n, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
-    if (resolve_lds_bytes(cap) > 64 * 1024)
-        ORBX_HIP(hipFuncSetAttribute((const void *)k_greedy_resolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds_bytes(cap)));
-    hipLaunchKernelGGL(k_greedy_resolve_t<false>, dim3(n), dim3(64), resolve_lds_bytes(cap), ms, (const WindowProblem *)ex->d_mp_probs.p,
-                       (const ResolveProblem *)ex->d_mp_res.p, g, cap);
+    { const int rr = launch_resolve<false>(n, ms, (const WindowProblem *)ex->d_mp_probs.p, (const ResolveProblem *)ex->d_mp_res.p, g, cap); if (rr != ORBX_OK) return rr; }
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
     ex->match_pending = true; ex->copy_covers_match = false;
     ORBX_HIP(hipGetLastError());

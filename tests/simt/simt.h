@@ -245,7 +245,8 @@ static simt_gdim3 gridDim;
 
 inline void __syncthreads() { simt::block_barrier(); }
 inline void __builtin_amdgcn_wave_barrier() { simt::wave_collect(0); }
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
+inline void __builtin_amdgcn_s_barrier() { simt::block_barrier(); }
 
 inline unsigned long long __ballot(bool pred) {
     const simt::WaveView w = simt::wave_collect(pred ? 1 : 0);

@@ -250,6 +250,43 @@ def test_projection_matchers_at_the_largest_frame(oracle):
         m.SearchByProjectionFrame(_frame_view(k1, d1, sf, W, H), q, 15.0, 0, None)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_projection_matchers_under_heavy_contention(oracle, seed):
+    """The replay of the sequential query loop (k_resolve_wide_t) where it is hardest: thousands of queries compete for a few hundred features packed into a
+    small region, windows hold tens of candidates (lists cut short -> re-scans, several per round), the queries are noisy copies of FEW descriptors (long
+    chains of queries that want the same features in the same order), some queries leave the taken-mask untouched (has_obs = 0).  M1 and M2 == oracle."""
+    import orb_slam3_amd as osa
+    rng = np.random.default_rng(100 + seed)
+    W, H, N = 752, 480, 300 + 100 * seed
+    kf, _ = _synthetic_frame(rng, N, W, H)
+    kf["x"] = rng.uniform(300, 380, N).astype(np.float32)
+    kf["y"] = rng.uniform(200, 260, N).astype(np.float32)
+    kf["octave"] = rng.integers(0, 3, N)
+    protos = _rand_desc(rng, 6)
+    df = _noisy_copy(rng, protos[rng.integers(0, 6, N)], 0.08)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    n_mp = 2500
+    src = rng.integers(0, N, n_mp)
+    mp = dict(proj_x=kf["x"][src] + rng.normal(0, 3, n_mp).astype(np.float32), proj_y=kf["y"][src] + rng.normal(0, 3, n_mp).astype(np.float32),
+              proj_xr=np.zeros(n_mp, np.float32), level=kf["octave"][src], view_cos=rng.uniform(0.9, 1.0, n_mp).astype(np.float32),
+              desc=_noisy_copy(rng, df[src], 0.05), in_view=(rng.random(n_mp) < 0.97).astype(np.uint8), has_obs=(rng.random(n_mp) < 0.8).astype(np.uint8))
+    occ = (rng.random(N) < 0.05).astype(np.uint8)
+    grid = oracle.OracleGrid(kf, 0.0, float(W), 0.0, float(H))
+    m = osa.ORBmatcher(0.9, True)
+    for th in (3.0, 8.0):
+        on, ofm = oracle.search_by_projection_mappoints(grid, df, sf, mp, th, 0.9, None, occ)
+        n, fm = m.SearchByProjection(_frame_view(kf, df, sf, W, H), mp, th, occ)
+        assert n == on and np.array_equal(fm, ofm), (th, n, on)
+    assert n > N // 4
+    q = dict(u=kf["x"][src] + 1.0, v=kf["y"][src] - 1.0, ur=np.zeros(n_mp, np.float32), octave=kf["octave"][src], angle=kf["angle"][src],
+             desc=_noisy_copy(rng, df[src], 0.05), has_obs=(rng.random(n_mp) < 0.8).astype(np.uint8))
+    for th, mode in ((15.0, 0), (7.0, 1)):
+        on, ocm = oracle.search_by_projection_frame(grid, df, sf, q, th, mode, True, None, occ)
+        n, cm = m.SearchByProjectionFrame(_frame_view(kf, df, sf, W, H), q, th, mode, occ)
+        assert n == on and np.array_equal(cm, ocm), (th, mode, n, on)
+    assert n > N // 8
+
+
 def test_match_consecutive_device_equals_host_api(oracle, canvas1):
     """The batched device-resident frame-to-frame matcher returns what M2 returns frame by frame."""
     import torch
