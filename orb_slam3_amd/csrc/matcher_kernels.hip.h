@@ -34,7 +34,10 @@ __device__ __forceinline__ int hamming(const Desc &a, const Desc &b) {
 }
 
 constexpr u64 kNoKey = ~0ull;
-constexpr int kTopK = 4;
+// candidates a query's list holds.  Round 6: 4 -> 6.  A list that runs dry (every entry taken, more candidates in the window) costs the replay a wave-wide
+// re-scan of the window, ~3.5 us each on its critical path: 6 per 1000 queries of the bench's frame pairs with 4 entries, under 1 with 6 (k_greedy_resolve_t
+// 100 -> 75 us per 255 pairs, k_window_best2_t 53 -> 57; 8 entries: 78 / 59 -- the replay's rounds read every entry)
+constexpr int kTopK = 6;
 
 // keep the two smallest keys
 __device__ __forceinline__ void push2(u64 &k1, u64 &k2, u64 k) {
@@ -703,6 +706,7 @@ __device__ __forceinline__ bool load_query_eager(const WindowProblem &P, int qi,
 // scan all features of the current frame for query window w; skip features flagged in `occ` (may be NULL).  Four features per lane are in flight at once
 // (keypoint, right coordinate and descriptor requested together before any test: the scan is a latency chain of ONE wave -- round 6: the re-scan of
 // k_greedy_resolve when k_window_brute made the lists, 16 dependent round trips for 1000 features in the one-at-a-time form, now four; eight in flight cost the kernel 80 more VGPRs)
+template <int OS = 1>   // byte stride of the taken flags (k_resolve_wide_t keeps them in the low bytes of 16-bit words)
 __device__ __forceinline__ int scan_window(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
                                            const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
     int cnt = 0;
@@ -720,7 +724,7 @@ __device__ __forceinline__ int scan_window(const WindowProblem &P, const GridPar
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + 64 * u + lane;
-            if (i >= n || (occ && occ[i])) continue;
+            if (i >= n || (occ && occ[i * OS])) continue;
             int cx, cy;
             if (!in_window(g, w, kp[u], &cx, &cy)) continue;
             if (P.u_right && ur[u] > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
@@ -741,6 +745,7 @@ __device__ __forceinline__ int scan_window(const WindowProblem &P, const GridPar
 // every keypoint of the frame: 16 serial round trips for 1000 features, and the re-scans were most of k_greedy_resolve's time).
 // The candidates are a superset (whole grid cells); in_window() applies GetFeaturesInArea's tests and supplies the cell for the key,
 // so keys -- and with them the tie-break order -- are those of scan_window.
+template <int OS = 1>
 __device__ __forceinline__ int scan_window_grid(const WindowProblem &P, const GridParams &g, const QueryWin &w, const Desc &dq, int n,
                                                 const uint8_t *occ, int lane, u64 &k1, u64 &k2) {
     const int ncol = w.cx1 - w.cx0 + 1;   // 1..64 (make_window clamps to the grid)
@@ -775,7 +780,7 @@ __device__ __forceinline__ int scan_window_grid(const WindowProblem &P, const Gr
         const orbx_keypoint kp = gld_kp(P.kps + i);
         const Desc dc = gld_desc(P.desc + (size_t)i * 32);
         const float ur = P.u_right ? gld(P.u_right + i) : 0.f;
-        if (!v1 || (occ && occ[i])) continue;
+        if (!v1 || (occ && occ[i * OS])) continue;
         int cx, cy;
         if (!in_window(g, w, kp, &cx, &cy)) continue;
         if (P.u_right && ur > 0) {  // ORBmatcher.cc:92-97 / 1751-1757
@@ -1196,13 +1201,17 @@ __global__ __launch_bounds__(64) void k_greedy_resolve_t(const WindowProblem *__
     };
 
     // candidate lists of a chunk of 64 queries; the next chunk's are requested before the current chunk is replayed
-    struct Chunk { u64 L0, L1, L2, L3; int meta; float q_ang; uint8_t obs; };
+    struct Chunk { u64 L[kTopK]; int meta; float q_ang; uint8_t obs; };
     auto fetch = [&](int q0) -> Chunk {
-        Chunk c = {kNoKey, kNoKey, kNoKey, kNoKey, 256, 0.f, (uint8_t)1};   // inactive lane: empty exhaustive list
+        Chunk c;   // inactive lane: empty exhaustive list
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) c.L[e] = kNoKey;
+        c.meta = 256; c.q_ang = 0.f; c.obs = 1;
         const int qi = q0 + lane;
         if (qi < nq) {
             const u64 *kp = P.keys + (size_t)qi * kTopK;
-            c.L0 = gld(kp); c.L1 = gld(kp + 1); c.L2 = gld(kp + 2); c.L3 = gld(kp + 3);
+#pragma unroll
+            for (int e = 0; e < kTopK; e++) c.L[e] = gld(kp + e);
             c.meta = gld(P.meta + qi);
             if (ori) c.q_ang = P.q_from_kps ? gld(&P.q_from_kps[qi].angle) : gld(R.q_angle + qi);
             if (R.q_has_obs) c.obs = gld(R.q_has_obs + qi);
@@ -1216,9 +1225,10 @@ __global__ __launch_bounds__(64) void k_greedy_resolve_t(const WindowProblem *__
         const Chunk C = nxt;
         // the wait for this chunk's lists goes HERE, before the next chunk's are requested: placed at their first use further down it is a vmcnt(0) across the
         // loop's back edge, which also waits for the requests just made -- the lists would arrive synchronously again
-        asm volatile("" :: "v"(C.L0), "v"(C.L1), "v"(C.L2), "v"(C.L3), "v"(C.meta), "v"(C.q_ang), "v"((int)C.obs) : "memory");
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) asm volatile("" :: "v"(C.L[e]) : "memory");
+        asm volatile("" :: "v"(C.meta), "v"(C.q_ang), "v"((int)C.obs) : "memory");
         nxt = fetch(q0 + 64);
-        const u64 L0 = C.L0, L1 = C.L1, L2 = C.L2, L3 = C.L3;
         const int valid_len = C.meta & 0xff;
         const bool exhaustive = (C.meta & 256) != 0;
         const float q_ang = C.q_ang;
@@ -1232,7 +1242,7 @@ __global__ __launch_bounds__(64) void k_greedy_resolve_t(const WindowProblem *__
             if (live) {
 #pragma unroll
                 for (int e = 0; e < kTopK; e++) {
-                    const u64 k = e == 0 ? L0 : e == 1 ? L1 : e == 2 ? L2 : L3;
+                    const u64 k = C.L[e];
                     if (e < valid_len && !occ[(int)(k & 0xffff)]) {
                         if (c1 == kNoKey) c1 = k;
                         else if (c2 == kNoKey) c2 = k;
@@ -1336,54 +1346,58 @@ __device__ __forceinline__ void wg_lds_sync() {
 }
 
 // k_resolve_wide_t (round 6): the same replay of SearchByProjection's sequential query loop (ORBmatcher.cc:88-139, 1745-1800) as k_greedy_resolve_t, by a
-// WORKGROUP of WAVES waves per problem, 64 * WAVES queries of a chunk in flight, ONE query per thread -- and without the restriction to a conflict-free PREFIX:
-// the one-wave form commits the lanes before the first conflicting lane and starts a new round for every conflict (~45 rounds + 6 wave-wide re-scans, one
-// after the other, per 1000 queries of the bench's frame pairs: 99 us of one wave's dependent instructions).  Here a round is
-//   claim    every unresolved query q marks EVERY still-free entry of its candidate list with atomicMin(claim[feature], q)                       | barrier
-//   judge    q's decision depends on its first (M1: first two) free entries f1 (, f2).  It is FINAL when no earlier unresolved query can take them:
-//            claim[f1] == q (and claim[f2] == q) -- an earlier unresolved query e only ever commits to an entry of its own list, all of which it has
-//            claimed -- PROVIDED every earlier unresolved e is "self-contained": its list is exhaustive, or it owns (claim == e) as many free entries
-//            as its decision reads (1, M1: 2), so that what it finally picks lies inside the list.  The lowest query that is not (its whole list
-//            occupied / contested and more candidates in its window than the list holds) is a fence for this round: bar_q                         | barrier
-//   commit   all final queries below bar_q at once: ratio test, match[], the taken-mask, the rotation histogram; claims cleared                    | barrier
-//   re-scan  queries whose non-exhaustive list ran dry are re-scanned against the CURRENT mask, one per wave, all waves at once; the result is a fresh
-//            list of the kTopK best FREE candidates (the mask only grows, so it stays a valid list: the entries that get taken are skipped like any
-//            other).  The lowest unresolved query sees the mask the sequential loop sees, so every round resolves at least that one.              | barrier
-// A chunk of the bench's frame pairs takes 2 - 3 rounds.  "No match" outcomes that cannot change (exhaustive list all taken; best free distance above the
-// threshold -- later states only have worse bests) resolve at once.  Barriers order LDS only (wg_lds_sync); result stores are fire-and-forget.
-// The rotation-histogram entries are written in commit order of the round, not query order: their consumer (the losing bins' features are cleared, :1871-1881)
-// does not depend on the order.
-// grid (n_problems), block 64 * WAVES, dynamic LDS as k_greedy_resolve_t (claim u32 + angle f32 + occ u8 + octave u8 per feature)
+// WORKGROUP of WAVES waves per problem: 64 * WAVES queries of a chunk in flight, one query per thread, and no restriction to a conflict-free PREFIX (the
+// one-wave form commits the lanes before the first conflicting lane and starts a new round for every conflict: ~45 rounds + 6 wave-wide re-scans, one after
+// the other, per 1000 queries of the bench's frame pairs -- 99 us of one wave's dependent instructions).  A query's decision reads the first (M1: first two)
+// still-free entries of its candidate list, its PICKS p1 (, p2); it commits to p1.  A round:
+//   claim     every unresolved query q with a decision to make: atomicMin(claim1[p1], q)                                                          | barrier
+//   unstable  q is CLEAN when no earlier query picks its picks (claim1[p1] == q, claim1[p2] >= q).  A query that is not clean will move to another entry
+//             of its list once the earlier one has committed: it is UNSTABLE and publishes every free entry of its list, atomicMin(claim2[entry], q) | barrier
+//   closure   a clean query one of whose picks an EARLIER unstable query lists (claim2[pick] < q) may lose that pick: it becomes unstable too and publishes
+//             its list; repeated until a pass adds nobody (one pass, rarely two)                                                                    | barrier per pass
+//   fence     an unstable query must also be certain to stay INSIDE its list: its list is exhaustive, or it has as many free entries as its decision reads
+//             that nobody earlier picks or lists.  The lowest unstable query that is not -- and the lowest query whose non-exhaustive list ran dry --
+//             stops every later query for this round.
+//   commit    all clean, never-threatened queries below the fence at once (what earlier queries commit to in the same round are their picks, which are
+//             not this query's): ratio test, match[], the taken-mask, the rotation entries; claims cleared                                          | barrier
+//   re-scan   queries whose non-exhaustive list ran dry are re-scanned against the CURRENT mask, one per wave, all waves at once: a fresh list of the kTopK
+//             best FREE candidates (the mask only grows, so it stays a valid list).  The lowest unresolved query sees the mask the sequential loop sees
+//             and is always served, so every round resolves at least that one.                                                                      | barrier
+// "No match" outcomes that cannot change (exhaustive list all taken; best free distance above the threshold -- later states only have worse bests) resolve at
+// once.  A round is bound by the issue rate of ONE wave's instruction stream (every wave runs the same code): the phases are branch-free, the list entries
+// packed (distance << 16 | feature), taken flag and octave of a feature share a 16-bit LDS word.  Barriers order LDS only (wg_lds_sync); result stores are
+// fire-and-forget.  The rotation histogram (:1775-1792) is built after the rounds from the committed (query, feature) pairs -- the angles never enter LDS.
+// grid (n_problems), block 64 * WAVES, dynamic LDS resolve_lds_bytes(n_alloc): claim1 u32 + claim2 u32 + (taken | octave << 8) u16 per feature.
+// With check_orientation the query index travels in 16 bits of an entry: nq <= 65535 (the host falls back to k_greedy_resolve_t beyond).
 template <int WAVES, bool BRUTE>
 __global__ __launch_bounds__(64 * WAVES) void k_resolve_wide_t(const WindowProblem *__restrict__ probs, const ResolveProblem *__restrict__ res,
                                                                GridParams g, int n_alloc) {
     constexpr int T = 64 * WAVES;
+    constexpr uint32_t kNone = 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    __shared__ int hist[ORBX_HISTO_LENGTH + 2];
     // static LDS stays small: with the largest frame (kMaxResolveFeatures) the dynamic part is 160 064 of the 163 840 bytes of a workgroup
-    constexpr int kPool = 64;          // re-scans per round (slot 0 is kept for the LOWEST query that needs one: that one always makes progress)
-    __shared__ u64 rl[kPool * kTopK];  // refreshed lists of the re-scanned queries
-    __shared__ int rl_meta[kPool];
-    __shared__ uint16_t rq[kPool];     // queries (thread ids) to re-scan this round
+    constexpr int kPool = 64;              // re-scans per round (slot 0 is kept for the LOWEST query that needs one)
+    __shared__ int hist[ORBX_HISTO_LENGTH + 2];
+    __shared__ uint32_t rl[kPool * kTopK]; // refreshed lists of the re-scanned queries (packed entries)
+    __shared__ int rl_exh[kPool];
+    __shared__ uint16_t rq[kPool];         // queries (thread ids) to re-scan this round
     // two sets of round counters, used by alternate rounds (a set is cleared in the round after the one that read it):
-    //   0 bar_q | 1 unresolved after the round | 2 re-scan requests besides the lowest | 3 lowest query that needs a re-scan;  [16] nmatches, [17] histogram entries
+    //   0 fence | 1 unresolved after the round | 2 re-scan requests besides the lowest | 3 lowest query that needs a re-scan | 4 any unstable query
+    //   5..7 "a closure pass added somebody" (pass i uses 5 + i % 3);  [16] nmatches, [17] rotation entries
     __shared__ int ctl[18];
-    uint32_t *claim = reinterpret_cast<uint32_t *>(lds);
-    float *ang = reinterpret_cast<float *>(lds + (size_t)n_alloc * 4);
-    uint8_t *occ = lds + (size_t)n_alloc * 8;
-    uint8_t *oct = occ + n_alloc;
+    uint32_t *claim1 = reinterpret_cast<uint32_t *>(lds);
+    uint32_t *claim2 = claim1 + n_alloc;
+    uint16_t *oo = reinterpret_cast<uint16_t *>(lds + (size_t)n_alloc * 8);   // low byte: taken, high byte: octave
     const WindowProblem P = probs[blockIdx.x];
     const ResolveProblem R = res[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = min(gld(P.n_ptr), n_alloc), nq = gld(P.nq_ptr);
     for (int i0 = 0; i0 < n; i0 += 4 * T) {   // four loads in flight per thread
-        float a[4];
         int l[4];
         uint8_t o[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = i0 + T * k + tid;
-            a[k] = i < n ? gld(&P.kps[i].angle) : 0.f;
             l[k] = i < n ? gld(&P.kps[i].octave) : 0;
             o[k] = (i < n && P.occupied0) ? gld(P.occupied0 + i) : (uint8_t)0;
         }
@@ -1391,10 +1405,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_resolve_wide_t(const WindowProbl
         for (int k = 0; k < 4; k++) {
             const int i = i0 + T * k + tid;
             if (i < n) {
-                occ[i] = o[k];
-                oct[i] = (uint8_t)l[k];
-                claim[i] = 0xffffffffu;
-                ang[i] = a[k];
+                oo[i] = (uint16_t)((o[k] ? 1u : 0u) | ((uint32_t)(l[k] & 0xff) << 8));   // octaves are 0 .. nlevels - 1 < 256; compared for equality only
+                claim1[i] = kNone;
+                claim2[i] = kNone;
                 gst(R.match + i, -1);
             }
         }
@@ -1402,32 +1415,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_resolve_wide_t(const WindowProbl
     if (tid < ORBX_HISTO_LENGTH) hist[tid] = 0;
     if (tid < 18) ctl[tid] = ((tid & 7) == 0 || (tid & 7) == 3) && tid < 16 ? 0x7fffffff : 0;
     __syncthreads();   // (also: the -1 fills are acknowledged before any wave stores a match into the same array)
-    const float factor = 1.0f / ORBX_HISTO_LENGTH;
     const bool ori = (R.mode == 2 && R.check_orientation);
     const bool two = (R.mode == 1);
+    const int need_own = two ? 2 : 1;
 
-    auto accept = [&](u64 k1, u64 k2) -> bool {   // ORBmatcher.cc:123-139 (as k_greedy_resolve_t)
-        if (k1 == kNoKey) return false;
-        const int bestDist = (int)(k1 >> 32);
-        if ((float)bestDist > R.max_dist) return false;
-        if (two) {
-            const int bestDist2 = (k2 == kNoKey) ? 256 : (int)(k2 >> 32);
-            const int bestLevel = oct[(int)(k1 & 0xffff)];
-            const int bestLevel2 = (k2 == kNoKey) ? -1 : (int)oct[(int)(k2 & 0xffff)];
-            if (bestLevel == bestLevel2 && (float)bestDist > R.nnratio * (float)bestDist2) return false;
-            if (!(bestLevel != bestLevel2 || (float)bestDist <= R.nnratio * (float)bestDist2)) return false;
-        }
-        return true;
-    };
-    // the whole wave re-scans the window of query q0 + tq against the current mask: kTopK best free candidates -> rl / rl_meta (as k_window_brute extracts them)
+    // the whole wave re-scans the window of query qc against the current mask: kTopK best free candidates -> pool slot (as k_window_brute extracts them)
     auto rescan = [&](int qc, int slot) {
         QueryWin w;
         Desc dq;
         u64 k1 = kNoKey, k2 = kNoKey;
         int cnt = 0;
+        const uint8_t *occ8 = reinterpret_cast<const uint8_t *>(oo);   // the scans look at occ[i]: byte 2 i of the shared words
         if (load_query_eager(P, qc, &w, g, &dq)) {
-            if (!BRUTE || P.gstart) cnt = scan_window_grid(P, g, w, dq, n, occ, lane, k1, k2);
-            else cnt = scan_window(P, g, w, dq, n, occ, lane, k1, k2);   // a record without a grid: wave-uniform
+            if (!BRUTE || P.gstart) cnt = scan_window_grid<2>(P, g, w, dq, n, occ8, lane, k1, k2);
+            else cnt = scan_window<2>(P, g, w, dq, n, occ8, lane, k1, k2);   // a record without a grid: wave-uniform
         }
         int total = cnt;
 #pragma unroll
@@ -1437,108 +1438,156 @@ __global__ __launch_bounds__(64 * WAVES) void k_resolve_wide_t(const WindowProbl
 #pragma unroll
         for (int r = 0; r < kTopK; r++) {
             const u64 m = wave_min1(k1);
-            if (lane == 0) rl[slot * kTopK + r] = m;
-            if (m != kNoKey && !cut) valid_len = r + 1;
+            const bool keep = m != kNoKey && !cut;
+            if (lane == 0) rl[slot * kTopK + r] = keep ? ((uint32_t)(m >> 32) << 16) | (uint32_t)(m & 0xffff) : kNone;
+            if (keep) valid_len = r + 1;
             const bool mine = (m != kNoKey) && (k1 == m);
             if (mine) { k1 = k2; k2 = kNoKey; npop++; }
             const bool dry = mine && npop == 2 && cnt > 2;   // a lane that ran dry while it had seen more: everything after this round is unknown
             cut = cut || (__ballot(dry) != 0ull);
         }
-        if (lane == 0) rl_meta[slot] = valid_len | ((total <= valid_len) ? 256 : 0);
+        if (lane == 0) rl_exh[slot] = total <= valid_len ? 1 : 0;
     };
 
-    struct Chunk { u64 L0, L1, L2, L3; int meta; float q_ang; uint8_t obs; };
+    struct Chunk { u64 L[kTopK]; int meta; uint8_t obs; };
     auto fetch = [&](int q0) -> Chunk {
-        Chunk c = {kNoKey, kNoKey, kNoKey, kNoKey, 256, 0.f, (uint8_t)1};
+        Chunk c;
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) c.L[e] = kNoKey;
+        c.meta = 256; c.obs = 1;
         const int qi = q0 + tid;
         if (qi < nq) {
             const u64 *kp = P.keys + (size_t)qi * kTopK;
-            c.L0 = gld(kp); c.L1 = gld(kp + 1); c.L2 = gld(kp + 2); c.L3 = gld(kp + 3);
+#pragma unroll
+            for (int e = 0; e < kTopK; e++) c.L[e] = gld(kp + e);
             c.meta = gld(P.meta + qi);
-            if (ori) c.q_ang = P.q_from_kps ? gld(&P.q_from_kps[qi].angle) : gld(R.q_angle + qi);
             if (R.q_has_obs) c.obs = gld(R.q_has_obs + qi);
         }
         return c;
     };
+    auto pack = [&](u64 k, bool valid) -> uint32_t { return (valid && k != kNoKey) ? ((uint32_t)(k >> 32) << 16) | (uint32_t)(k & 0xffff) : kNone; };
     Chunk nxt = fetch(0);
-    int par = 0;   // parity of the round
+    int par = 0;   // counter set of the round
     for (int q0 = 0; q0 < nq; q0 += T) {
         const int qi = q0 + tid;
         const Chunk C = nxt;
-        asm volatile("" :: "v"(C.L0), "v"(C.L1), "v"(C.L2), "v"(C.L3), "v"(C.meta), "v"(C.q_ang), "v"((int)C.obs) : "memory");   // wait here, not across the next request
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) asm volatile("" :: "v"(C.L[e]) : "memory");   // wait here, not across the next request
+        asm volatile("" :: "v"(C.meta), "v"((int)C.obs) : "memory");
         nxt = fetch(q0 + T);
-        u64 L0 = C.L0, L1 = C.L1, L2 = C.L2, L3 = C.L3;
-        int valid_len = C.meta & 0xff;
+        const int vl = C.meta & 0xff;
+        uint32_t E[kTopK];   // the list: distance << 16 | feature, kNone = no entry
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) E[e] = pack(C.L[e], vl > e);
         bool exhaustive = (C.meta & 256) != 0;
         bool resolved = qi >= nq;
         for (;; par ^= 8) {
             int *ct = ctl + par;
-            // ---- claim ----
-            u64 f1 = kNoKey, f2 = kNoKey;
-            uint32_t fm = 0u;   // bit e: list entry e is valid and free
-            if (!resolved) {
+            // ---- claim: the picks under the current mask ----
+            int I[kTopK];
+            uint32_t O[kTopK];
 #pragma unroll
-                for (int e = 0; e < kTopK; e++) {
-                    const u64 k = e == 0 ? L0 : e == 1 ? L1 : e == 2 ? L2 : L3;
-                    if (e < valid_len && !occ[(int)(k & 0xffff)]) {
-                        atomicMin(&claim[(int)(k & 0xffff)], (uint32_t)tid);
-                        if (f1 == kNoKey) f1 = k;
-                        else if (f2 == kNoKey) f2 = k;
-                        fm |= 1u << e;
+            for (int e = 0; e < kTopK; e++) I[e] = E[e] != kNone ? (int)(E[e] & 0xffff) : 0;
+#pragma unroll
+            for (int e = 0; e < kTopK; e++) O[e] = oo[I[e]];
+            uint32_t fm = 0u;   // bit e: entry e is free
+#pragma unroll
+            for (int e = 0; e < kTopK; e++) fm |= (E[e] != kNone && !(O[e] & 0xff)) ? 1u << e : 0u;
+            if (resolved) fm = 0u;
+            const uint32_t fm2 = fm & (fm - 1u);
+            const int k1 = fm ? __builtin_ctz(fm) : kTopK, k2 = fm2 ? __builtin_ctz(fm2) : kTopK;
+            uint32_t p1 = kNone, p2 = kNone, op1 = 0u, op2 = 0u;
+#pragma unroll
+            for (int e = 0; e < kTopK; e++) {
+                p1 = k1 == e ? E[e] : p1; op1 = k1 == e ? O[e] : op1;
+                p2 = k2 == e ? E[e] : p2; op2 = k2 == e ? O[e] : op2;
+            }
+            const bool best_ok = p1 != kNone && (float)(int)(p1 >> 16) <= R.max_dist;
+            const bool decided_no = !resolved && (p1 == kNone ? exhaustive : !best_ok);   // cannot change: the best free distance only grows
+            const bool dry = !resolved && !exhaustive && (p1 == kNone || (two && p2 == kNone && best_ok));   // best / second best unknown
+            const bool has = !resolved && !decided_no && !dry;
+            const int t1 = (int)(p1 & 0xffff), t2 = (two && p2 != kNone) ? (int)(p2 & 0xffff) : -1;
+            if (has) atomicMin(&claim1[t1], (uint32_t)tid);
+            if (dry) { atomicMin(&ct[0], tid); atomicMin(&ct[3], tid); }
+            wg_lds_sync();
+            if (tid == 0) {   // the other set: last read before this barrier, next written after the round's last
+                int *o = ctl + (par ^ 8);
+                o[0] = 0x7fffffff; o[1] = 0; o[2] = 0; o[3] = 0x7fffffff; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0;
+            }
+            // ---- unstable: a pick that an earlier query picks ----
+            uint32_t C1[kTopK];
+#pragma unroll
+            for (int e = 0; e < kTopK; e++) C1[e] = claim1[I[e]];
+            uint32_t cp1 = 0u, cp2 = 0u, own1 = 0u;   // own1: free entries that no earlier query picks (for the fence)
+#pragma unroll
+            for (int e = 0; e < kTopK; e++) {
+                cp1 = k1 == e ? C1[e] : cp1;
+                cp2 = k2 == e ? C1[e] : cp2;
+                own1 |= C1[e] >= (uint32_t)tid ? 1u << e : 0u;
+            }
+            own1 &= fm;
+            bool unstable = has && !(cp1 == (uint32_t)tid && (t2 < 0 || cp2 >= (uint32_t)tid));
+            bool published = false;
+            auto publish = [&]() {
+#pragma unroll
+                for (int e = 0; e < kTopK; e++)
+                    if ((fm >> e) & 1u) atomicMin(&claim2[I[e]], (uint32_t)tid);
+                published = true;
+            };
+            if (unstable) { publish(); ct[4] = 1; }
+            wg_lds_sync();
+            if (ct[4]) {   // workgroup-uniform
+                // ---- closure: clean queries whose picks an earlier unstable query lists; fence ----
+                for (int pass = 0;; pass++) {
+                    const int fl = 5 + pass % 3;
+                    uint32_t C2[kTopK];
+#pragma unroll
+                    for (int e = 0; e < kTopK; e++) C2[e] = claim2[I[e]];
+                    uint32_t d1 = kNone, d2 = kNone, own = 0u;
+#pragma unroll
+                    for (int e = 0; e < kTopK; e++) {
+                        d1 = k1 == e ? C2[e] : d1;
+                        d2 = k2 == e ? C2[e] : d2;
+                        own |= C2[e] >= (uint32_t)tid ? 1u << e : 0u;
                     }
+                    if (has && !unstable && (d1 < (uint32_t)tid || (t2 >= 0 && d2 < (uint32_t)tid))) { unstable = true; publish(); ct[fl] = 1; }
+                    if (unstable && !exhaustive && __popc(own & own1) < need_own) atomicMin(&ct[0], tid);   // may leave its list: nothing later commits this round
+                    if (tid == 0) ct[5 + (pass + 1) % 3] = 0;
+                    wg_lds_sync();
+                    if (!ct[fl]) break;   // nobody was added in this pass: every test above saw every published list
                 }
             }
-            wg_lds_sync();
-            if (tid == 0) { int *o = ctl + (par ^ 8); o[0] = 0x7fffffff; o[1] = 0; o[2] = 0; o[3] = 0x7fffffff; }   // the other set: last read before this barrier, next written after the round's last
-            // ---- judge ----
-            bool decided_no = false, need_rescan = false, can_commit = false;
-            if (!resolved) {
-                if (f1 == kNoKey) { if (exhaustive) decided_no = true; else need_rescan = true; }
-                else if ((float)(int)(f1 >> 32) > R.max_dist) decided_no = true;   // the best free distance only grows
-                else if (two && f2 == kNoKey && !exhaustive) need_rescan = true;    // second best unknown
-                int own = 0;
-#pragma unroll
-                for (int e = 0; e < kTopK; e++) {
-                    const u64 k = e == 0 ? L0 : e == 1 ? L1 : e == 2 ? L2 : L3;
-                    if ((fm >> e) & 1u) own += claim[(int)(k & 0xffff)] == (uint32_t)tid ? 1 : 0;
-                }
-                const bool self_contained = decided_no || (!need_rescan && (exhaustive || own >= (two ? 2 : 1)));
-                if (!self_contained) atomicMin(&ct[0], tid);
-                if (need_rescan) atomicMin(&ct[3], tid);
-                if (!decided_no && !need_rescan)
-                    can_commit = claim[(int)(f1 & 0xffff)] == (uint32_t)tid && (!two || f2 == kNoKey || claim[(int)(f2 & 0xffff)] == (uint32_t)tid);
-            }
-            wg_lds_sync();
             // ---- commit ----
-            const int bar_q = ct[0];
+            const int fence = ct[0];
             int my_slot = -1;
             if (!resolved) {
                 bool done = decided_no;
-                if (can_commit && tid < bar_q) {
+                if (has && !unstable && tid < fence) {
                     done = true;
-                    if (accept(f1, two ? f2 : kNoKey)) {
-                        const int t1 = (int)(f1 & 0xffff);
+                    const int bestDist = (int)(p1 >> 16);
+                    bool ok = true;
+                    if (two) {   // ORBmatcher.cc:123-139
+                        const int bestDist2 = p2 == kNone ? 256 : (int)(p2 >> 16);
+                        const int bestLevel = (int)(op1 >> 8), bestLevel2 = p2 == kNone ? -1 : (int)(op2 >> 8);
+                        if (bestLevel == bestLevel2 && (float)bestDist > R.nnratio * (float)bestDist2) ok = false;
+                        if (!(bestLevel != bestLevel2 || (float)bestDist <= R.nnratio * (float)bestDist2)) ok = false;
+                    }
+                    if (ok) {
                         gst(R.match + t1, qi);
-                        occ[t1] = C.obs;
+                        reinterpret_cast<uint8_t *>(oo)[2 * t1] = C.obs;
                         atomicAdd(&ctl[16], 1);
-                        if (ori) {   // :1775-1792
-                            float rot = C.q_ang - ang[t1];
-                            if (rot < 0.0f) rot += 360.0f;
-                            int b = (int)roundf(rot * factor);
-                            if (b == ORBX_HISTO_LENGTH) b = 0;
-                            gst(R.entries + atomicAdd(&ctl[17], 1), (b << 16) | t1);   // rotHist[bin].push_back(bestIdx2)
-                            atomicAdd(&hist[b], 1);
-                        }
+                        if (ori) gst(R.entries + atomicAdd(&ctl[17], 1), (int32_t)(((uint32_t)qi << 16) | (uint32_t)t1));
                     }
                 }
+                if (has) claim1[t1] = kNone;
+                if (published) {
 #pragma unroll
-                for (int e = 0; e < kTopK; e++) {
-                    const u64 k = e == 0 ? L0 : e == 1 ? L1 : e == 2 ? L2 : L3;
-                    if ((fm >> e) & 1u) claim[(int)(k & 0xffff)] = 0xffffffffu;
+                    for (int e = 0; e < kTopK; e++)
+                        if ((fm >> e) & 1u) claim2[I[e]] = kNone;
                 }
                 if (!done) {
                     atomicAdd(&ct[1], 1);
-                    if (need_rescan) {
+                    if (dry) {
                         my_slot = tid == ct[3] ? 0 : 1 + atomicAdd(&ct[2], 1);
                         if (my_slot < kPool) rq[my_slot] = (uint16_t)tid;
                     }
@@ -1549,23 +1598,34 @@ __global__ __launch_bounds__(64 * WAVES) void k_resolve_wide_t(const WindowProbl
             const int n_unres = ct[1], rq_n = ct[3] == 0x7fffffff ? 0 : min(1 + ct[2], kPool);
             if (n_unres == 0) { par ^= 8; break; }   // workgroup-uniform
             if (rq_n > 0) {
-                for (int i = wave; i < rq_n; i += WAVES) {
-                    rescan(q0 + (int)rq[i], i);
-                }
+                for (int i = wave; i < rq_n; i += WAVES) rescan(q0 + (int)rq[i], i);
                 wg_lds_sync();
                 if (my_slot >= 0 && my_slot < kPool) {   // (a request beyond the pool keeps its list: it asks again next round)
-                    L0 = rl[my_slot * kTopK]; L1 = rl[my_slot * kTopK + 1]; L2 = rl[my_slot * kTopK + 2]; L3 = rl[my_slot * kTopK + 3];
-                    const int mt = rl_meta[my_slot];
-                    valid_len = mt & 0xff;
-                    exhaustive = (mt & 256) != 0;
+#pragma unroll
+                    for (int e = 0; e < kTopK; e++) E[e] = rl[my_slot * kTopK + e];
+                    exhaustive = rl_exh[my_slot] != 0;
                 }
             }
         }
     }
     __syncthreads();
     int nmatches = ctl[16];
-    const int n_entries = ctl[17];
     if (ori) {
+        // rotation histogram :1775-1792 from the committed pairs; entries become (bin, feature)
+        const int n_entries = ctl[17];
+        const float factor = 1.0f / ORBX_HISTO_LENGTH;
+        for (int e = tid; e < n_entries; e += T) {
+            const uint32_t v = (uint32_t)gld(R.entries + e);
+            const int q = (int)(v >> 16), t1 = (int)(v & 0xffff);
+            const float qa = P.q_from_kps ? gld(&P.q_from_kps[q].angle) : gld(R.q_angle + q);
+            float rot = qa - gld(&P.kps[t1].angle);
+            if (rot < 0.0f) rot += 360.0f;
+            int b = (int)roundf(rot * factor);
+            if (b == ORBX_HISTO_LENGTH) b = 0;
+            atomicAdd(&hist[b], 1);
+            gst(R.entries + e, (b << 16) | t1);
+        }
+        __syncthreads();
         // ComputeThreeMaxima :2012-2053
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
         for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {
@@ -1576,7 +1636,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_resolve_wide_t(const WindowProbl
         }
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
-        // :1871-1881: every entry of a rejected bin clears its feature and decrements nmatches
+        // :1871-1881: every entry of a rejected bin clears its feature and decrements nmatches (a thread re-reads the entries it wrote itself)
         for (int e = tid; e < n_entries; e += T) {
             const int v = gld(R.entries + e), b = v >> 16;
             if (b != ind1 && b != ind2 && b != ind3) gst(R.match + (v & 0xffff), R.cleared_value);
@@ -1910,13 +1970,17 @@ __global__ __launch_bounds__(64) void k_replay_init_lists(const WindowProblem *_
     if (lane < ORBX_HISTO_LENGTH) hist[lane] = 0;
     __syncthreads();
     int nmatches = 0, n_entries = 0, n_rounds = 0, n_rescans = 0;
-    struct Chunk { u64 L0, L1, L2, L3; int meta, i1; };
+    struct Chunk { u64 L[kTopK]; int meta, i1; };
     auto fetch = [&](int q0) -> Chunk {
-        Chunk c = {kNoKey, kNoKey, kNoKey, kNoKey, 256, 0};   // inactive lane: empty exhaustive list
+        Chunk c;   // inactive lane: empty exhaustive list
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) c.L[e] = kNoKey;
+        c.meta = 256; c.i1 = 0;
         const int qi = q0 + lane;
         if (qi < nq) {
             const u64 *kp = P.keys + (size_t)qi * kTopK;
-            c.L0 = gld(kp); c.L1 = gld(kp + 1); c.L2 = gld(kp + 2); c.L3 = gld(kp + 3);
+#pragma unroll
+            for (int e = 0; e < kTopK; e++) c.L[e] = gld(kp + e);
             c.meta = gld(P.meta + qi);
             c.i1 = gld(R.q_index + qi);
         }
@@ -1954,9 +2018,13 @@ __global__ __launch_bounds__(64) void k_replay_init_lists(const WindowProblem *_
         const int qi = q0 + lane;
         const bool active = qi < nq;
         const Chunk C = nxt;
-        asm volatile("" :: "v"(C.L0), "v"(C.L1), "v"(C.L2), "v"(C.L3), "v"(C.meta), "v"(C.i1) : "memory");   // this chunk's lists have arrived before the next chunk's are requested
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) asm volatile("" :: "v"(C.L[e]) : "memory");   // this chunk's lists have arrived before the next chunk's are requested
+        asm volatile("" :: "v"(C.meta), "v"(C.i1) : "memory");
         nxt = fetch(q0 + 64);
-        const u64 L[kTopK] = {C.L0, C.L1, C.L2, C.L3};
+        u64 L[kTopK];
+#pragma unroll
+        for (int e = 0; e < kTopK; e++) L[e] = C.L[e];
         const int valid_len = C.meta & 0xff, i1 = C.i1;
         const bool exhaustive = (C.meta & 256) != 0;
         int pos = 0;

@@ -22,8 +22,10 @@ namespace {
 
 constexpr int kMaxResolveFeatures = ORBX_MAX_FRAME_FEATURES;  // claim (4 B) + angle (4 B) + occ (1 B) + octave (1 B) per feature must fit the 160 KB LDS (16000 x 10 + 200 B)
 inline size_t resolve_lds_bytes(int n) { return (size_t)n * 10 + 64; }   // k_greedy_resolve: claim u32 + angle f32 + occ u8 + octave u8 per feature
-// The replay of SearchByProjection's query loop: k_resolve_wide_t (a workgroup of 4 waves per problem; ORBX_RESOLVE_WAVES=2 / 8 for A/B, =1: the one-wave
-// k_greedy_resolve_t of rounds 1-5)
+// The replay of SearchByProjection's query loop.  Single calls and the batched map-point search: k_resolve_wide_t, a workgroup of 4 waves per problem
+// (M1 10 000 points 241 -> 197 us per call, M2 132 -> 94, M3 111 -> 85: profiles/r06_h_resolve_ab.txt).  The frame-to-frame matcher of a BATCH keeps the
+// one-wave k_greedy_resolve_t: 255 problems side by side, 75 against 83 us serialized, and a quarter of the wave slots beside the next batch's extraction.
+// ORBX_RESOLVE_WAVES = 1 / 2 / 4 / 8 forces one form everywhere (A/B).
 template <int WAVES, bool BRUTE>
 inline int launch_resolve_wide(int np, size_t lds, hipStream_t st, const WindowProblem *dP, const ResolveProblem *dR, const GridParams &g, int cap) {
     if (lds > 64 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_resolve_wide_t<WAVES, BRUTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -31,8 +33,9 @@ inline int launch_resolve_wide(int np, size_t lds, hipStream_t st, const WindowP
     return ORBX_OK;
 }
 template <bool BRUTE>
-inline int launch_resolve(int np, hipStream_t st, const WindowProblem *dP, const ResolveProblem *dR, const GridParams &g, int cap) {
-    static const int waves = [] { const char *v = getenv("ORBX_RESOLVE_WAVES"); return v ? atoi(v) : 4; }();
+inline int launch_resolve(int np, hipStream_t st, const WindowProblem *dP, const ResolveProblem *dR, const GridParams &g, int cap, int nq_max, int default_waves) {
+    static const int waves_env = [] { const char *v = getenv("ORBX_RESOLVE_WAVES"); return v ? atoi(v) : 0; }();
+    const int waves = nq_max > 65535 ? 1 : waves_env > 0 ? waves_env : default_waves;   // the wide form carries the query index of a rotation entry in 16 bits
     const size_t lds = resolve_lds_bytes(cap);
     if (waves == 2) return launch_resolve_wide<2, BRUTE>(np, lds, st, dP, dR, g, cap);
     if (waves == 8) return launch_resolve_wide<8, BRUTE>(np, lds, st, dP, dR, g, cap);
@@ -619,7 +622,7 @@ int run_projection(orbx_matcher *m, const ProjArgs &a) {
         ORBX_LAUNCH_GRID_BUILD( dim3(1), dim3(64), 0, m->exec(), dP, g);
         ORBX_LAUNCH_WINDOW_BEST2(nq, 1, m->exec(), dP, g);
     }
-    { const int rr = brute ? launch_resolve<true>(1, m->exec(), dP, dR, g, n) : launch_resolve<false>(1, m->exec(), dP, dR, g, n); if (rr != ORBX_OK) return rr; }
+    { const int rr = brute ? launch_resolve<true>(1, m->exec(), dP, dR, g, n, nq, 4) : launch_resolve<false>(1, m->exec(), dP, dR, g, n, nq, 4); if (rr != ORBX_OK) return rr; }
     int32_t nm = 0;
     D2H(a.match_out, R.match, 4 * (size_t)n);
     D2H(&nm, R.nmatches, 4);
@@ -1307,7 +1310,7 @@ extern "C" int orbx_match_consecutive_device(orbx_extractor *ex, float th, float
         ex->prof_ms[K_MATCH_SCAN] += t; ex->prof_n[K_MATCH_SCAN]++;
         (void)hipEventRecord(e0, ms);
     }
-    { const int rr = launch_resolve<false>(np, ms, (const WindowProblem *)ex->d_mprobs.p, (const ResolveProblem *)ex->d_mres.p, g, cap); if (rr != ORBX_OK) return rr; }
+    { const int rr = launch_resolve<false>(np, ms, (const WindowProblem *)ex->d_mprobs.p, (const ResolveProblem *)ex->d_mres.p, g, cap, cap, 1); if (rr != ORBX_OK) return rr; }
     if (ex->profile) {
         (void)hipEventRecord(e1, ms); (void)hipEventSynchronize(e1);
         float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
@@ -1415,7 +1418,7 @@ extern "C" int orbx_search_mappoints_batch_device(orbx_extractor *ex, int n_mp, 
     ORBX_LAUNCH_GRID_BUILD( dim3(n), dim3(64), 0, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
     if (n_mp > 0)
         ORBX_LAUNCH_WINDOW_BEST2(n_mp, n, ms, (const WindowProblem *)ex->d_mp_probs.p, g);
-    { const int rr = launch_resolve<false>(n, ms, (const WindowProblem *)ex->d_mp_probs.p, (const ResolveProblem *)ex->d_mp_res.p, g, cap); if (rr != ORBX_OK) return rr; }
+    { const int rr = launch_resolve<false>(n, ms, (const WindowProblem *)ex->d_mp_probs.p, (const ResolveProblem *)ex->d_mp_res.p, g, cap, 0, 4); if (rr != ORBX_OK) return rr; }
     ORBX_HIP(hipEventRecord(ex->ev_match, ms));
     ex->match_pending = true; ex->copy_covers_match = false;
     ORBX_HIP(hipGetLastError());
