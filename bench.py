@@ -1192,6 +1192,27 @@ def latency_calls(osa, device, n_calls, n_cpu=5, small=False):
     out.append(entry("Frame::isInFrustum x %d map points [orbx_is_in_frustum]: one pose, pinhole" % nfp, "Frame.cc:512-586, Tracking.cc:3360-3380",
                      lambda: mb.isInFrustum(camf[:4] + (0, 0, 0, 0, 0, camf[4]), (Rcw, tcw, Ow), bnd, lsf, 8, 0.5, posf, nrm, mnd, mxd),
                      lambda: ob.is_in_frustum(Rcw, tcw, Ow, camf, bnd, lsf, 8, 0.5, posf, nrm, mnd, mxd), same_frustum))
+    # the fisheye rig's form (TUM-VI): both cameras, KannalaBrandt8::project
+    kbl = np.array((190.978477, 190.973307, 254.931706, 256.897442, 0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367), np.float32)
+    kbr = np.array((190.442369, 190.434438, 252.598164, 254.917230, 0.0034003171, 0.0017669271, -0.0026631290, 0.0003299517), np.float32)
+    Rrl = np.eye(3, dtype=np.float32)
+    trl = np.array([-0.101, 0.002, 0.001], np.float32)
+    views = [(Rcw, tcw, Ow, kbl), ((Rrl @ Rcw).astype(np.float32), (Rrl @ tcw + trl).astype(np.float32), (Rcw.T @ (-trl) + Ow).astype(np.float32), kbr)]
+    bndf = np.array([0.0, 512.0, 0.0, 512.0], np.float32)
+
+    def same_checks(g, c):
+        ok = True
+        for r in (0, 1):
+            both = (g["in_view"][r] & c[r]["in_view"]).astype(bool)
+            ok = ok and int((g["in_view"][r] != c[r]["in_view"]).sum()) <= 2
+            for k in ("proj_x", "proj_y"):   # the azimuth's cos / sin are double: one float ulp allowed (orbx.h)
+                ok = ok and int(np.abs(g[k][r][both].view(np.int32).astype(np.int64) - c[r][k][both].view(np.int32).astype(np.int64)).max(initial=0)) <= 1
+            ok = ok and g["depth"][r][both].tobytes() == c[r]["depth"][both].tobytes() and g["view_cos"][r][both].tobytes() == c[r]["view_cos"][both].tobytes()
+        return bool(ok)
+    out.append(entry("Frame::isInFrustumChecks x %d map points x 2 cameras [orbx_is_in_frustum_checks]: fisheye rig, KannalaBrandt8::project" % nfp,
+                     "Frame.cc:577-590, 1168-1240, KannalaBrandt8.cpp:67-85",
+                     lambda: mb.isInFrustumChecks(views, bndf, lsf, 8, 0.5, posf, nrm, mnd, mxd),
+                     lambda: [ob.is_in_frustum_checks(v, bndf, lsf, 8, 0.5, posf, nrm, mnd, mxd) for v in views], same_checks))
     return out
 
 

@@ -447,6 +447,22 @@ int orbx_is_in_frustum(orbx_matcher *m, const orbx_camera *cam, const orbx_frame
                        int nlevels, float viewing_cos_limit, int n_mp, const float *pos, const float *normal, const float *min_dist,
                        const float *max_dist, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr, float *depth, int32_t *level,
                        float *view_cos);
+/* One camera of a fisheye rig as Frame::isInFrustumChecks (Frame.cc:1168-1240) sees it.  The caller evaluates the reference's expressions (:1172-1186):
+ * left camera R = mRcw, t = mtcw, twc = mOw; right camera (bRight) R = Rrl * mRcw, t = Rrl * mtcw + trl, twc = mRwc * mTlr.translation() + mOw.
+ * params = KannalaBrandt8::mvParameters (fx, fy, cx, cy, k0 .. k3). */
+typedef struct orbx_fisheye_view {
+    float R[9], t[3], twc[3];
+    float params[8];
+} orbx_fisheye_view;
+/* Frame::isInFrustumChecks(pMP, viewingCosLimit, bRight) (Frame.cc:1168-1240, called from Frame::isInFrustum :577-590 when Nleft != -1) with
+ * KannalaBrandt8::project (CameraModels/KannalaBrandt8.cpp:67-85) for n_mp map points and n_views (1 or 2: left, right) cameras of the rig.
+ * Outputs [n_views][n_mp]: in_view (mbTrackInView / mbTrackInViewR) and, where in_view, proj_x / proj_y (mTrackProjX/Y[R]), depth (mTrackDepth[R]),
+ * level (mnTrackScaleLevel[R]), view_cos (mTrackViewCos[R]); elsewhere level = -1 (:579-580) and zeros (the reference leaves those fields untouched).
+ * atan2f is glibc's, restated bit for bit; cos / sin of the azimuth are evaluated in double as the reference's translation unit does (no float overload
+ * in scope): proj_x / proj_y may differ from an x86-64 glibc build in the last float ulp where the double result lies on a rounding boundary. */
+int orbx_is_in_frustum_checks(orbx_matcher *m, const orbx_fisheye_view *views, int n_views, const float *bounds4, float log_scale_factor, int nlevels,
+                              float viewing_cos_limit, int n_mp, const float *pos, const float *normal, const float *min_dist, const float *max_dist,
+                              uint8_t *in_view, float *proj_x, float *proj_y, float *depth, int32_t *level, float *view_cos);
 /* The same for n_frames poses at once on device-resident map-point data (shared by all frames); outputs [n_frames][n_mp] in device
  * memory -- exactly the arrays orbx_search_mappoints_batch_device consumes (Tracking::SearchLocalPoints, Tracking.cc:3339-3413: frustum
  * test, then SearchByProjection).  bounds4 = NULL uses the extractor's camera (orbx_set_camera) or the plain image rectangle.

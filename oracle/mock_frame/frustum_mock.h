@@ -30,6 +30,10 @@ class Pinhole : public GeometricCamera {
 public:
     Eigen::Vector2f project(const Eigen::Vector3f &v3D) override;
 };
+class KannalaBrandt8 : public GeometricCamera {   /* mvParameters: fx, fy, cx, cy, k0 .. k3; body: ref_kb8_shim.cc (a translation unit WITHOUT `using namespace std`, as the reference's) */
+public:
+    Eigen::Vector2f project(const Eigen::Vector3f &v3D) override;
+};
 
 class MapPoint {
 public:
@@ -55,13 +59,15 @@ public:
     Eigen::Matrix<float, 3, 1> mOw;
     Eigen::Matrix<float, 3, 3> mRcw;
     Eigen::Matrix<float, 3, 1> mtcw;
-    GeometricCamera *mpCamera = nullptr;
+    GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+    Eigen::Matrix<float, 3, 3> mRwc;
+    Sophus::SE3f mTrl, mTlr;   /* Frame.h: Sophus::SE3<float> mTlr, mTrl */
     float mbf = 0;
     int mnScaleLevels = 0;
     float mfLogScaleFactor = 0;
     static float mnMinX, mnMaxX, mnMinY, mnMaxY;
     bool isInFrustum(MapPoint *pMP, float viewingCosLimit);
-    bool isInFrustumChecks(MapPoint *, float, bool = false) { return false; }   /* fisheye branch: not exercised */
+    bool isInFrustumChecks(MapPoint *pMP, float viewingCosLimit, bool bRight = false);
 };
 
 }  // namespace ORB_SLAM3

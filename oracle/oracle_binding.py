@@ -592,6 +592,24 @@ def is_in_frustum(Rcw, tcw, Ow, cam, bounds, log_scale_factor, nlevels, cos_limi
     return out
 
 
+def is_in_frustum_checks(view, bounds, log_scale_factor, nlevels, cos_limit, pos, normal, min_dist, max_dist):
+    """Frame::isInFrustumChecks for one camera of a fisheye rig.  view = (R, t, twc, params8) as Frame.cc:1172-1186 compute them.
+    Returns dict(in_view, proj_x, proj_y, depth, level, view_cos)."""
+    f32 = np.float32
+    R, t, w, prm = [np.ascontiguousarray(x, f32).ravel() for x in view]
+    b = np.ascontiguousarray(bounds, f32).ravel()
+    P, Nn = np.ascontiguousarray(pos, f32).reshape(-1, 3), np.ascontiguousarray(normal, f32).reshape(-1, 3)
+    mn, mx = np.ascontiguousarray(min_dist, f32), np.ascontiguousarray(max_dist, f32)
+    n = len(P)
+    out = dict(in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, f32), proj_y=np.zeros(n, f32), depth=np.zeros(n, f32),
+               level=np.zeros(n, np.int32), view_cos=np.zeros(n, f32))
+    L = lib()
+    L.orbo_is_in_frustum_checks.restype = None
+    L.orbo_is_in_frustum_checks(_p(R), _p(t), _p(w), _p(prm), _p(b), C.c_float(log_scale_factor), int(nlevels), C.c_float(cos_limit), n, _p(P), _p(Nn),
+                                _p(mn), _p(mx), *[_p(out[k]) for k in ("in_view", "proj_x", "proj_y", "depth", "level", "view_cos")])
+    return out
+
+
 def undistort_points(xy, cam, dist):
     """cv::undistortPoints(xy, K, dist, R=I, P=K) [OCV-recalled].  cam = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])."""
     a = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)

@@ -265,6 +265,10 @@ void orbo_distinctive_descriptors(const uint8_t *desc, const int32_t *set_ptr, i
 
 /* Candidate-generation pre-passes (orb_oracle_geom.cc): Frame::isInFrustum (Frame.cc:512-575, Nleft == -1) with
  * MapPoint::PredictScale and Pinhole::project; cv::undistortPoints as Frame::UndistortKeyPoints / ComputeImageBounds call it. */
+void orbo_kb8_project(const float *params8, float X, float Y, float Z, float *u, float *v);
+void orbo_is_in_frustum_checks(const float *R, const float *t, const float *twc, const float *params8, const float *bounds, float log_scale_factor,
+                               int nlevels, float viewing_cos_limit, int n, const float *pos, const float *normal, const float *min_dist,
+                               const float *max_dist, uint8_t *in_view, float *proj_x, float *proj_y, float *depth, int32_t *level, float *view_cos);
 void orbo_is_in_frustum(const float *Rcw, const float *tcw, const float *Ow, float fx, float fy, float cx, float cy, float mbf,
                         const float *bounds, float log_scale_factor, int nlevels, float viewing_cos_limit, int n, const float *pos,
                         const float *normal, const float *min_dist, const float *max_dist, uint8_t *in_view, float *proj_x, float *proj_y,

@@ -55,6 +55,50 @@ void orbo_is_in_frustum(const float *Rcw, const float *tcw, const float *Ow, flo
     }
 }
 
+/* KannalaBrandt8::project(const Eigen::Vector3f &) (CameraModels/KannalaBrandt8.cpp:67-85).  The reference's translation unit has no `using namespace std`:
+ * its cos(psi) / sin(psi) are the C library's double functions, the sums are double and round to float once (pinned by compiling that text in a
+ * translation unit of the same kind: oracle/ref_kb8_shim.cc). */
+void orbo_kb8_project(const float *p, float X, float Y, float Z, float *u, float *v) {
+    const float x2_plus_y2 = X * X + Y * Y;
+    const float theta = atan2f(sqrtf(x2_plus_y2), Z);
+    const float psi = atan2f(Y, X);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
+    *u = (float)(p[0] * r * ::cos((double)psi) + p[2]);
+    *v = (float)(p[1] * r * ::sin((double)psi) + p[3]);
+}
+
+/* Frame::isInFrustumChecks(pMP, viewingCosLimit, bRight) (Frame.cc:1168-1240) for n map points and one camera of the rig: R, t, twc are what lines
+ * 1172-1186 compute (the caller does; the tests take them from the reference text itself).  Outputs as orbx_is_in_frustum_checks documents. */
+void orbo_is_in_frustum_checks(const float *R, const float *t, const float *twc, const float *params8, const float *bounds, float log_scale_factor,
+                               int nlevels, float viewing_cos_limit, int n, const float *pos, const float *normal, const float *min_dist,
+                               const float *max_dist, uint8_t *in_view, float *proj_x, float *proj_y, float *depth, int32_t *level, float *view_cos) {
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    for (int i = 0; i < n; i++) {
+        in_view[i] = 0; proj_x[i] = 0; proj_y[i] = 0; depth[i] = 0; level[i] = -1; view_cos[i] = 0;
+        const float P[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+        float Pc[3];
+        for (int r = 0; r < 3; r++) Pc[r] = (R[3 * r] * P[0] + R[3 * r + 1] * P[1] + R[3 * r + 2] * P[2]) + t[r];   /* mR * P + mt */
+        const float Pc_dist = std::sqrt((0.f + Pc[0] * Pc[0]) + Pc[1] * Pc[1] + Pc[2] * Pc[2]);
+        if (Pc[2] < 0.0f) continue;
+        float u, v;
+        orbo_kb8_project(params8, Pc[0], Pc[1], Pc[2], &u, &v);
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+        const float PO[3] = {P[0] - twc[0], P[1] - twc[1], P[2] - twc[2]};
+        const float dist = std::sqrt((0.f + PO[0] * PO[0]) + PO[1] * PO[1] + PO[2] * PO[2]);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float viewCos = ((0.f + PO[0] * normal[3 * i]) + PO[1] * normal[3 * i + 1] + PO[2] * normal[3 * i + 2]) / dist;
+        if (viewCos < viewing_cos_limit) continue;
+        const float ratio = max_dist[i] / dist;   /* MapPoint::PredictScale */
+        int nScale = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= nlevels) nScale = nlevels - 1;
+        in_view[i] = 1; proj_x[i] = u; proj_y[i] = v; depth[i] = Pc_dist; level[i] = nScale; view_cos[i] = viewCos;
+    }
+}
+
 /* [OCV-recalled] cv::undistortPoints(src, dst, K, distCoeffs, R = I, P = K) as Frame::UndistortKeyPoints (Frame.cc:747-780) and
  * ComputeImageBounds (:782-810) call it: double arithmetic, default criteria (COUNT = 5 fixed-point iterations), radial-tangential
  * model k1, k2, p1, p2, k3 (mDistCoef with 4 or 5 entries: k3 = 0 for 4).  xy: n interleaved (x, y) float pairs, in and out. */

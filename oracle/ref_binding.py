@@ -628,3 +628,23 @@ def ref_is_in_frustum(Rcw, tcw, Ow, cam, bounds, log_scale_factor, nlevels, cos_
                                *[_p(out[k]) for k in ("in_view", "proj_x", "proj_y", "proj_xr", "depth", "level", "view_cos")], _p(ret))
     out["ret"] = ret
     return out
+
+
+def ref_is_in_frustum_checks(Rcw, tcw, Ow, Rwc, Rrl, trl, tlr, params_l, params_r, b_right, bounds, log_scale_factor, nlevels, cos_limit, pos, normal,
+                             min_dist, max_dist):
+    """The reference's Frame::isInFrustumChecks + KannalaBrandt8::project text.  Returns (dict of outputs, view15 = mR | mt | twc of lines 1172-1186)."""
+    f32 = np.float32
+    L = C.CDLL(str(_DIR / "libfrustum_ref.so"))
+    a = [np.ascontiguousarray(x, f32).ravel() for x in (Rcw, tcw, Ow, Rwc, Rrl, trl, tlr, params_l, params_r)]
+    b = np.ascontiguousarray(bounds, f32).ravel()
+    P, Nn = np.ascontiguousarray(pos, f32).reshape(-1, 3), np.ascontiguousarray(normal, f32).reshape(-1, 3)
+    mn, mx = _f32(min_dist), _f32(max_dist)
+    n = len(P)
+    out = dict(in_view=np.zeros(n, np.uint8), proj_x=np.zeros(n, f32), proj_y=np.zeros(n, f32), depth=np.zeros(n, f32),
+               level=np.zeros(n, np.int32), view_cos=np.zeros(n, f32))
+    view = np.zeros(15, f32)
+    L.frustumref_is_in_frustum_checks.restype = None
+    L.frustumref_is_in_frustum_checks(*[_p(x) for x in a], int(b_right), _p(b), C.c_float(log_scale_factor), int(nlevels), C.c_float(cos_limit), n,
+                                      _p(P), _p(Nn), _p(mn), _p(mx), *[_p(out[k]) for k in ("in_view", "proj_x", "proj_y", "depth", "level", "view_cos")],
+                                      _p(view))
+    return out, view

@@ -100,7 +100,7 @@ SYMBOLS = [
     "orbx_matcher_destroy", "orbx_matcher_debug_transfers", "orbx_matcher_debug_replay_stats", "orbx_hamming_csr", "orbx_hamming_best2_csr", "orbx_knn2", "orbx_stereo_rowband",
     "orbx_compute_stereo_matches", "orbx_search_by_projection_mappoints", "orbx_search_by_projection_frame",
     "orbx_match_consecutive_device", "orbx_last_error", "orbx_status_string", "orbx_search_by_projection_window", "orbx_search_by_projection_mappoints_fisheye", "orbx_search_by_projection_frame_fisheye",
-    "orbx_search_by_bow_frame_fisheye", "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_is_in_frustum", "orbx_frustum_batch_device",
+    "orbx_search_by_bow_frame_fisheye", "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_is_in_frustum", "orbx_is_in_frustum_checks", "orbx_frustum_batch_device",
     "orbx_set_camera", "orbx_batch_download_keypoints_un",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
     "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_stereo_batch_download_async", "orbx_stereo_download_wait", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
@@ -171,6 +171,7 @@ def lib() -> C.CDLL:
     L.orbx_undistort_keypoints.argtypes = [vp, C.POINTER(Camera), vp, i32, vp]
     L.orbx_image_bounds.argtypes = [C.POINTER(Camera), i32, i32, vp]
     L.orbx_is_in_frustum.argtypes = [vp, C.POINTER(Camera), C.POINTER(FramePose), vp, f32, i32, f32, i32] + [vp] * 11
+    L.orbx_is_in_frustum_checks.argtypes = [vp, vp, i32, vp, f32, i32, f32, i32] + [vp] * 10
     L.orbx_frustum_batch_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(FramePose), i32, vp, f32, i32] + [vp] * 11
     L.orbx_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.orbx_batch_download_keypoints_un.argtypes = [vp, i32, vp, i32, vp]

@@ -1,6 +1,8 @@
 // geometry_kernels.hip.h -- candidate-generation pre-passes of the projection matchers, gfx950.
 //   k_in_frustum   Frame::isInFrustum (Frame.cc:512-575, Nleft == -1) + MapPoint::PredictScale (MapPoint.cc:531-546) + Pinhole::project
 //                  (CameraModels/Pinhole.cpp:43-49) for every (frame, map point): fills the arrays SearchByProjection reads
+//   k_in_frustum_checks  Frame::isInFrustumChecks (Frame.cc:1168-1240: the fisheye rig's form, left and right camera) + KannalaBrandt8::project
+//                  (CameraModels/KannalaBrandt8.cpp:67-85), with glibc's atan2f restated for the device
 //   k_undistort    cv::undistortPoints as Frame::UndistortKeyPoints (Frame.cc:747-780) calls it [OCV-recalled]: 5 fixed-point
 //                  iterations of the radial-tangential model in double, P = K
 // Built with -ffp-contract=off: every operation rounds as the reference text writes it (a reference built against the real Eigen may
@@ -8,6 +10,7 @@
 #pragma once
 
 #include <cmath>
+#include <cstring>
 
 #include "orbx_internal.h"
 
@@ -69,6 +72,143 @@ static __global__ __launch_bounds__(256) void k_in_frustum(const FrustumFrame *_
         }
     }
     in_view[o] = iv; proj_x[o] = px; proj_y[o] = py; proj_xr[o] = pxr; depth[o] = dep; level[o] = lvl; view_cos[o] = vc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// glibc 2.35 atanf / atan2f (sysdeps/ieee754/flt-32/s_atanf.c, e_atan2f.c: the fdlibm forms, plain float operations -- no FMA variant exists for them),
+// restated operation for operation.  tests/simt/check_geometry_math.cc compares them on the CPU with the host libm: atanf on EVERY float, atan2f on
+// 4 * 10^8 pairs -- bit-identical.
+// ---------------------------------------------------------------------------------------------------------
+__host__ __device__ inline float glibc_atanf(float x) {
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                          6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    uint32_t ux;
+    memcpy(&ux, &x, 4);
+    const int32_t hx = (int32_t)ux, ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {   // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {    // |x| < 0.4375
+        if (ix < 0x31000000) return x;   // |x| < 2^-29 (raises inexact in the original)
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {           // |x| < 1.1875
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return hx < 0 ? -r : r;
+}
+__host__ __device__ inline float glibc_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    uint32_t ux, uy;
+    memcpy(&ux, &x, 4);
+    memcpy(&uy, &y, 4);
+    const int32_t hx = (int32_t)ux, ix = hx & 0x7fffffff, hy = (int32_t)uy, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return glibc_atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return m < 2 ? y : m == 2 ? pi + tiny : -pi - tiny;
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = glibc_atanf(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return -z;
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
+// One camera of a fisheye rig as Frame::isInFrustumChecks sees it (Frame.cc:1172-1186): the caller evaluates the reference's Eigen expressions
+// (bRight: mR = Rrl * mRcw, mt = Rrl * mtcw + trl, twc = mRwc * mTlr.translation() + mOw; left: mRcw, mtcw, mOw)
+struct FisheyeView {
+    float R[9], t[3], twc[3];
+    float p[8];   // KannalaBrandt8::mvParameters: fx, fy, cx, cy, k0 .. k3
+};
+struct FrustumChecks {
+    FisheyeView view[2];
+    float minx, maxx, miny, maxy;
+    float log_scale_factor;
+    int nlevels;
+    float cos_limit;
+};
+
+// KannalaBrandt8::project(const Eigen::Vector3f &) (KannalaBrandt8.cpp:67-85).  The translation unit has no `using namespace std`, so its
+// `cos(psi)` / `sin(psi)` are ::cos(double) / ::sin(double): the products fx * r * cos(psi) + cx are evaluated in double and rounded to float once.
+// The device's double cos / sin are within 1-2 ulp (double) of glibc's: the float results agree except where the double value lies that close to a
+// float rounding boundary (the same situation as logf in k_in_frustum; the tests allow one float ulp and count the differences: none seen).
+__host__ __device__ inline void kb8_project(const float *p, float X, float Y, float Z, float *u, float *v) {
+    const float x2_plus_y2 = X * X + Y * Y;
+    const float theta = glibc_atan2f(sqrtf(x2_plus_y2), Z);
+    const float psi = glibc_atan2f(Y, X);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
+    *u = (float)((double)(p[0] * r) * cos((double)psi) + (double)p[2]);
+    *v = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
+}
+
+// grid (ceil(n_mp / 256), n_views), block 256.  Outputs [n_views][n_mp]: the MapPoint fields the function writes when every test passes
+// (mTrackProjX/Y[R], mnTrackScaleLevel[R], mTrackViewCos[R], mTrackDepth[R]); otherwise in_view = 0, level = -1 (Frame.cc:579-580) and zeros.
+static __global__ __launch_bounds__(256) void k_in_frustum_checks(const FrustumChecks *__restrict__ fc, int n_mp, const float *__restrict__ pos,
+                                                           const float *__restrict__ normal, const float *__restrict__ min_dist,
+                                                           const float *__restrict__ max_dist, uint8_t *__restrict__ in_view,
+                                                           float *__restrict__ proj_x, float *__restrict__ proj_y, float *__restrict__ depth,
+                                                           int32_t *__restrict__ level, float *__restrict__ view_cos) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_mp) return;
+    const FrustumChecks F = *fc;
+    const FisheyeView &V = F.view[blockIdx.y];
+    const size_t o = (size_t)blockIdx.y * n_mp + i;
+    const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
+    const float mn_in = min_dist[i], mx = max_dist[i], N0 = normal[3 * i], N1 = normal[3 * i + 1], N2 = normal[3 * i + 2];
+    uint8_t iv = 0;
+    float px = 0.f, py = 0.f, dep = 0.f, vc = 0.f;
+    int lvl = -1;
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        Pc[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(V.R[3 * r], P0), __fmul_rn(V.R[3 * r + 1], P1)), __fmul_rn(V.R[3 * r + 2], P2)), V.t[r]);
+    const float Pc_dist = sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(Pc[0], Pc[0])), __fmul_rn(Pc[1], Pc[1])), __fmul_rn(Pc[2], Pc[2])));
+    if (!(Pc[2] < 0.0f)) {
+        float u, v;
+        kb8_project(V.p, Pc[0], Pc[1], Pc[2], &u, &v);
+        if (!(u < F.minx || u > F.maxx) && !(v < F.miny || v > F.maxy)) {
+            const float PO0 = __fsub_rn(P0, V.twc[0]), PO1 = __fsub_rn(P1, V.twc[1]), PO2 = __fsub_rn(P2, V.twc[2]);
+            const float dist = sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(PO0, PO0)), __fmul_rn(PO1, PO1)), __fmul_rn(PO2, PO2)));
+            const float maxDistance = __fmul_rn(1.2f, mx), minDistance = __fmul_rn(0.8f, mn_in);
+            if (!(dist < minDistance || dist > maxDistance)) {
+                const float viewCos = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(PO0, N0)), __fmul_rn(PO1, N1)), __fmul_rn(PO2, N2)), dist);
+                if (!(viewCos < F.cos_limit)) {
+                    const float ratio = __fdiv_rn(mx, dist);
+                    int nScale = (int)ceilf(__fdiv_rn((float)log((double)ratio), F.log_scale_factor));   // as k_in_frustum
+                    if (nScale < 0) nScale = 0;
+                    else if (nScale >= F.nlevels) nScale = F.nlevels - 1;
+                    iv = 1; px = u; py = v; dep = Pc_dist; lvl = nScale; vc = viewCos;
+                }
+            }
+        }
+    }
+    in_view[o] = iv; proj_x[o] = px; proj_y[o] = py; depth[o] = dep; level[o] = lvl; view_cos[o] = vc;
 }
 
 struct CameraModel {   // Pinhole intrinsics (Frame::mK) + radial-tangential distortion (Frame::mDistCoef)

@@ -1502,6 +1502,39 @@ extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_camera *cam, const
     return ORBX_OK;
 }
 
+extern "C" int orbx_is_in_frustum_checks(orbx_matcher *m, const orbx_fisheye_view *views, int n_views, const float *bounds4, float log_scale_factor,
+                                         int nlevels, float viewing_cos_limit, int n_mp, const float *pos, const float *normal, const float *min_dist,
+                                         const float *max_dist, uint8_t *in_view, float *proj_x, float *proj_y, float *depth, int32_t *level,
+                                         float *view_cos) {
+    if (!m || !views || n_views < 1 || n_views > 2 || !bounds4 || nlevels < 1 || n_mp < 0) return ORBX_E_BAD_ARG;
+    if (n_mp > 0 && (!pos || !normal || !min_dist || !max_dist || !in_view || !proj_x || !proj_y || !depth || !level || !view_cos)) return ORBX_E_BAD_ARG;
+    if (n_mp == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(m->device));
+    const size_t n = (size_t)n_mp, no = n * (size_t)n_views;
+    int r = m->reserve_all(2 * Arena::pad(12 * n) + 2 * Arena::pad(4 * n) + 5 * Arena::pad(4 * no) + Arena::pad(no) + Arena::pad(sizeof(FrustumChecks)) + 8192);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    m->begin();
+    float *dp = A.take<float>(3 * n), *dn = A.take<float>(3 * n), *dmn = A.take<float>(n), *dmx = A.take<float>(n);
+    uint8_t *div = A.take<uint8_t>(no);
+    float *dx = A.take<float>(no), *dy = A.take<float>(no), *dd = A.take<float>(no), *dvc = A.take<float>(no);
+    int32_t *dl = A.take<int32_t>(no);
+    FrustumChecks *dF = A.take<FrustumChecks>(1);
+    FrustumChecks F;
+    memset(&F, 0, sizeof(F));
+    static_assert(sizeof(FisheyeView) == sizeof(orbx_fisheye_view), "orbx_fisheye_view layout");
+    memcpy(F.view, views, sizeof(FisheyeView) * (size_t)n_views);
+    F.minx = bounds4[0]; F.maxx = bounds4[1]; F.miny = bounds4[2]; F.maxy = bounds4[3];
+    F.log_scale_factor = log_scale_factor; F.nlevels = nlevels; F.cos_limit = viewing_cos_limit;
+    H2D(dF, &F, sizeof(F));
+    H2D(dp, pos, 12 * n); H2D(dn, normal, 12 * n); H2D(dmn, min_dist, 4 * n); H2D(dmx, max_dist, 4 * n);
+    hipLaunchKernelGGL(k_in_frustum_checks, dim3((n_mp + 255) / 256, n_views), dim3(256), 0, m->exec(), (const FrustumChecks *)dF, n_mp, (const float *)dp,
+                       (const float *)dn, (const float *)dmn, (const float *)dmx, div, dx, dy, dd, dl, dvc);
+    D2H(in_view, div, no); D2H(proj_x, dx, 4 * no); D2H(proj_y, dy, 4 * no); D2H(depth, dd, 4 * no); D2H(level, dl, 4 * no); D2H(view_cos, dvc, 4 * no);
+    SYNC_AND_DELIVER();
+    return ORBX_OK;
+}
+
 extern "C" int orbx_frustum_batch_device(orbx_extractor *ex, const orbx_camera *cam, const orbx_frame_pose *poses, int n_frames, const float *bounds4,
                                          float viewing_cos_limit, int n_mp, const float *d_pos, const float *d_normal, const float *d_min_dist,
                                          const float *d_max_dist, uint8_t *d_in_view, float *d_proj_x, float *d_proj_y, float *d_proj_xr,

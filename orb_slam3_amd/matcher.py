@@ -261,6 +261,21 @@ class ORBmatcher:
               "orbx_is_in_frustum")
         return out
 
+    def isInFrustumChecks(self, views, bounds, log_scale_factor, nlevels, cos_limit, pos, normal, min_dist, max_dist):
+        """Frame::isInFrustumChecks (Frame.cc:1168) for n map points and the 1 or 2 cameras of a fisheye rig.  views = [(R, t, twc, params8), ...] as the
+        reference's lines 1172-1186 compute them.  Returns dict of [n_views][n] arrays: in_view, proj_x, proj_y, depth, level, view_cos."""
+        P, Nn = _f32(np.asarray(pos).reshape(-1, 3)), _f32(np.asarray(normal).reshape(-1, 3))
+        mn, mx, b = _f32(min_dist), _f32(max_dist), _f32(bounds)
+        n, nv = len(P), len(views)
+        V = np.ascontiguousarray(np.concatenate([np.concatenate([np.asarray(x, np.float32).ravel() for x in v]) for v in views]), np.float32)
+        assert V.size == 23 * nv
+        out = dict(in_view=np.empty((nv, n), np.uint8), proj_x=np.empty((nv, n), np.float32), proj_y=np.empty((nv, n), np.float32),
+                   depth=np.empty((nv, n), np.float32), level=np.empty((nv, n), np.int32), view_cos=np.empty((nv, n), np.float32))
+        check(self._L.orbx_is_in_frustum_checks(self._h, ptr(V), nv, ptr(b), float(log_scale_factor), int(nlevels), float(cos_limit), n, ptr(P), ptr(Nn),
+                                                ptr(mn), ptr(mx), *[ptr(out[k]) for k in ("in_view", "proj_x", "proj_y", "depth", "level", "view_cos")]),
+              "orbx_is_in_frustum_checks")
+        return out
+
     # ---- fisheye-stereo twins (F.Nleft != -1): features [0, n_left) left camera, [n_left, N) right camera ----
     def SearchByProjectionFisheye(self, left: FrameView, kps_right, l2r, r2l, mp: dict, th: float = 3.0, frame_occupied=None):
         """ORBmatcher.cc:43-213 whole.  left.descriptors holds ALL n_left + n_right rows; mp: in_view, proj_x, proj_y, level,

@@ -65,6 +65,55 @@ def test_is_in_frustum_equals_reference_text(seed):
     assert len(np.unique(o["level"][iv])) >= 6 and (o["proj_x"][~iv] == -1).sum() > 100 and ((o["proj_x"] != -1) & ~iv).sum() > 100
 
 
+TUMVI_L = (190.978477, 190.973307, 254.931706, 256.897442, 0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367)   # Examples/Stereo/TUM-VI.yaml cam1
+TUMVI_R = (190.442369, 190.434438, 252.598164, 254.917230, 0.0034003171, 0.0017669271, -0.0026631290, 0.0003299517)   # cam2
+KEYS_F = ("in_view", "proj_x", "proj_y", "depth", "level", "view_cos")
+
+
+def fisheye_case(seed, n=4000):
+    """A fisheye rig frame: pose, mTrl (right-from-left, ~10 cm baseline with a small rotation), map points spread over more than a hemisphere."""
+    Rcw, tcw, Ow, _, _, lsf, nl, cosl, pos, normal, mn, mx = frustum_case(seed, n)
+    rng = np.random.default_rng(1000 + seed)
+    pos = pos.copy()
+    pos[:, :2] *= rng.uniform(0.5, 3.0, (n, 1)).astype(np.float32)   # wide field of view
+    a = rng.uniform(-0.02, 0.02, 3)
+    Rrl = (np.array([[1, -a[2], a[1]], [a[2], 1, -a[0]], [-a[1], a[0], 1]]) @ np.eye(3)).astype(np.float32)
+    trl = np.array([-0.101, 0.002, 0.001], np.float32) + rng.normal(0, 1e-3, 3).astype(np.float32)
+    tlr = (-(Rrl.astype(np.float64).T @ trl.astype(np.float64))).astype(np.float32)
+    Rwc = np.ascontiguousarray(Rcw.T)
+    bounds = np.array([0.0, 512.0, 0.0, 512.0], np.float32)
+    return dict(Rcw=Rcw, tcw=tcw, Ow=Ow, Rwc=Rwc, Rrl=Rrl, trl=trl, tlr=tlr, bounds=bounds, lsf=lsf, nl=nl, cosl=cosl, pos=pos, normal=normal, mn=mn, mx=mx)
+
+
+def fisheye_views(c, pin_name=None):
+    """(R, t, twc, params) of the left and right camera: what Frame.cc:1172-1186 compute, taken from the reference text (live or committed)."""
+    views = []
+    for right, prm in ((0, TUMVI_L), (1, TUMVI_R)):
+        v = _P.value(f"{pin_name}/view{right}", lambda: rb.ref_is_in_frustum_checks(c["Rcw"], c["tcw"], c["Ow"], c["Rwc"], c["Rrl"], c["trl"], c["tlr"], TUMVI_L, TUMVI_R,
+                                                                                   right, c["bounds"], c["lsf"], c["nl"], c["cosl"], c["pos"][:1], c["normal"][:1],
+                                                                                   c["mn"][:1], c["mx"][:1])[1])
+        views.append((v[:9], v[9:12], v[12:15], np.array(prm, np.float32)))
+    return views
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_is_in_frustum_checks_equals_reference_text(seed):
+    """Frame::isInFrustumChecks + KannalaBrandt8::project (fisheye rigs: TUM-VI): the oracle against the reference's text, both cameras, bit for bit."""
+    c = fisheye_case(seed)
+    views = fisheye_views(c, f"fisheye/{seed}")
+    for right in (0, 1):
+        o = ob.is_in_frustum_checks(views[right], c["bounds"], c["lsf"], c["nl"], c["cosl"], c["pos"], c["normal"], c["mn"], c["mx"])
+        def flat(d):
+            iv = d["in_view"].astype(bool)   # fields the reference leaves untouched on rejection: compared only where in_view
+            return [d["in_view"]] + [np.where(iv, d[k], 0) for k in KEYS_F[1:]]
+        _P.pin(f"fisheye/{seed}/{right}", flat(o), lambda: flat(rb.ref_is_in_frustum_checks(c["Rcw"], c["tcw"], c["Ow"], c["Rwc"], c["Rrl"], c["trl"], c["tlr"], TUMVI_L,
+                                                                                           TUMVI_R, right, c["bounds"], c["lsf"], c["nl"], c["cosl"], c["pos"],
+                                                                                           c["normal"], c["mn"], c["mx"])[0]))
+        iv = o["in_view"].astype(bool)
+        assert 200 < iv.sum() < len(iv) - 200 and len(np.unique(o["level"][iv])) >= 6
+        assert np.all(o["level"][~iv] == -1)
+
+
 def _distort(xy_un, cam, dist):
     """Frame::ProjectPointDistort's forward model (Frame.cc:612-636) in float64."""
     fx, fy, cx, cy = cam

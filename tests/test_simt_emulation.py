@@ -255,3 +255,15 @@ def test_branch_free_describe_math_equals_libm_and_oracle(emul_lib, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:]
+
+
+def test_device_atan2f_equals_libm_and_kb8_projection_equals_oracle(emul_lib, tmp_path):
+    """geometry_kernels.hip.h's glibc_atanf / glibc_atan2f (Frame::isInFrustumChecks -> KannalaBrandt8::project on the device) are bit-identical to the host
+    libm's: every 7th float bit pattern for atanf (the exhaustive run, stride 1, was made when the port was written: 4 278 190 082 arguments, 0 differences),
+    4 * 10^7 atan2f pairs + the special cases; kb8_project == the oracle's restatement on 4 * 10^6 points.  Device code compiled for the host."""
+    exe = tmp_path / "check_geometry_math"
+    r = subprocess.run([str(CLANG), "-std=c++17", "-O1", "-ffp-contract=off", f"-I{SIMT}", f"-I{SIMT / 'build'}", "-Wno-ignored-attributes",
+                        "-Wno-unused-value", str(SIMT / "check_geometry_math.cc"), str(SIMT / "launch.cc"), f"-L{ROOT / 'oracle'}", "-lorb_oracle", f"-Wl,-rpath,{ROOT / 'oracle'}", "-lm", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe), "7"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:]
