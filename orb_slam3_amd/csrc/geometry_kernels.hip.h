@@ -109,7 +109,9 @@ __host__ __device__ inline float glibc_atanf(float x) {
     const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
     const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
     if (id < 0) return x - x * (s1 + s2);
-    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    const float hi = id == 0 ? atanhi[0] : id == 1 ? atanhi[1] : id == 2 ? atanhi[2] : atanhi[3];   // (selects: an indexed local array would live in scratch memory)
+    const float lo = id == 0 ? atanlo[0] : id == 1 ? atanlo[1] : id == 2 ? atanlo[2] : atanlo[3];
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
     return hx < 0 ? -r : r;
 }
 __host__ __device__ inline float glibc_atan2f(float y, float x) {
@@ -176,8 +178,8 @@ static __global__ __launch_bounds__(256) void k_in_frustum_checks(const FrustumC
                                                            int32_t *__restrict__ level, float *__restrict__ view_cos) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_mp) return;
-    const FrustumChecks F = *fc;
-    const FisheyeView &V = F.view[blockIdx.y];
+    const FrustumChecks &F = *fc;
+    const FisheyeView &V = fc->view[blockIdx.y];
     const size_t o = (size_t)blockIdx.y * n_mp + i;
     const float P0 = pos[3 * i], P1 = pos[3 * i + 1], P2 = pos[3 * i + 2];
     const float mn_in = min_dist[i], mx = max_dist[i], N0 = normal[3 * i], N1 = normal[3 * i + 1], N2 = normal[3 * i + 2];

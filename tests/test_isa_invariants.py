@@ -101,8 +101,9 @@ BUDGETS = {
     "k_pyr_stream": (72, 7, 0, 0),          # two 576-thread workgroups per CU (18 waves): <= 7 waves per SIMD are needed, no spill of the task registers
     "k_pyr_base": (32, 8, 0, 0),
     "k_window_best2_tILi8": (64, 8, 0, 0),
-    "k_greedy_resolve_tILb0": (96, 5, 128, 0),   # the batched pipeline's form (beside the next batch's extraction)
-    "k_greedy_resolve_tILb1": (128, 4, 128, 0),  # single small calls: + the grid-less re-scan with four features per lane in flight
+    "k_greedy_resolve_tILb0": (104, 4, 128, 0),  # the batched pipeline's form: ONE wave per frame pair beside the next batch's extraction (round 6: lists of 6 entries, 87 -> 98 VGPRs)
+    "k_greedy_resolve_tILb1": (144, 3, 128, 0),  # forced single small calls (ORBX_RESOLVE_WAVES=1): + the grid-less re-scan with four features per lane in flight
+    "k_resolve_wide_tILi4ELb0": (96, 5, 3072, 0),   # single calls, batched map-point search: 4 waves per problem; static LDS must leave the 160 064 dynamic bytes of the largest frame
     "k_finalize": (32, 8, 64, 0),
 }
 
