@@ -265,6 +265,12 @@ void orbo_distinctive_descriptors(const uint8_t *desc, const int32_t *set_ptr, i
 
 /* Candidate-generation pre-passes (orb_oracle_geom.cc): Frame::isInFrustum (Frame.cc:512-575, Nleft == -1) with
  * MapPoint::PredictScale and Pinhole::project; cv::undistortPoints as Frame::UndistortKeyPoints / ComputeImageBounds call it. */
+void orbo_kb8_unproject(const float *params8, float px, float py, float *ray3);
+void orbo_eigen_jacobi_svd4_V(const float *A16, float *V16, float *sv4);
+float orbo_kb8_triangulate_matches(const float *cam1, const float *cam2, float x1, float y1, float x2, float y2, const float *R12, const float *t12,
+                                   float sigmaLevel, float unc);
+void orbo_kb8_epipolar_constrain(const float *cam1, const float *cam2, int n, const float *xy1, const float *xy2, const float *R12, const float *t12,
+                                 const float *sigma1, const float *sigma2, uint8_t *ok, float *tm_value);
 void orbo_kb8_project(const float *params8, float X, float Y, float Z, float *u, float *v);
 void orbo_is_in_frustum_checks(const float *R, const float *t, const float *twc, const float *params8, const float *bounds, float log_scale_factor,
                                int nlevels, float viewing_cos_limit, int n, const float *pos, const float *normal, const float *min_dist,

@@ -6,8 +6,10 @@
  * pins every decision and the operation order AS WRITTEN; a build of the reference against the real Eigen may evaluate the 3x3
  * product with packet FMAs and differ in the last ulp.  orbo_undistort_points restates cv::undistortPoints
  * from the published algorithm [OCV-recalled]: PARITY UNPINNED (OpenCV is absent from the reference tree and from this image). */
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <limits>
 
 #include "orb_oracle.h"
 
@@ -66,6 +68,155 @@ void orbo_kb8_project(const float *p, float X, float Y, float Z, float *u, float
     const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
     *u = (float)(p[0] * r * ::cos((double)psi) + p[2]);
     *v = (float)(p[1] * r * ::sin((double)psi) + p[3]);
+}
+
+/* KannalaBrandt8::unproject (KannalaBrandt8.cpp:107-142); precision = 1e-6 (KannalaBrandt8.h).  std::tan(float) = libm tanf. */
+void orbo_kb8_unproject(const float *p, float px, float py, float *ray3) {
+    const float precision = 1e-6f;
+    const float pwx = (px - p[2]) / p[0], pwy = (py - p[3]) / p[1];
+    float scale = 1.f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    theta_d = fminf(fmaxf(-3.1415926535897932384626433832795 / 2.f, theta_d), 3.1415926535897932384626433832795 / 2.f);   /* CV_PI is a double constant */
+    if (theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            float k0_theta2 = p[4] * theta2, k1_theta4 = p[5] * theta4;
+            float k2_theta6 = p[6] * theta6, k3_theta8 = p[7] * theta8;
+            float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                              (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabsf(theta_fix) < precision) break;
+        }
+        scale = std::tan(theta) / theta_d;
+    }
+    ray3[0] = pwx * scale; ray3[1] = pwy * scale; ray3[2] = 1.f;
+}
+
+/* Eigen::JacobiSVD<Matrix4f>(A, ComputeFullV).matrixV() [EIGEN-recalled: Eigen is not vendored by the reference and absent from this image -- PARITY UNPINNED;
+ * restated from Eigen 3.3/3.4's JacobiSVD.h (two-sided Jacobi, real_2x2_jacobi_svd, JacobiRotation::makeJacobi, sorted singular values)].  A, V row-major. */
+namespace {
+struct Rot { float c, s; };
+inline void rot_rows(float (*M)[4], int p, int q, Rot j) {            /* MatrixBase::applyOnTheLeft(p, q, j) */
+    if (j.c == 1.f && j.s == 0.f) return;
+    for (int i = 0; i < 4; i++) { const float x = M[p][i], y = M[q][i]; M[p][i] = j.c * x + j.s * y; M[q][i] = -j.s * x + j.c * y; }
+}
+inline void rot_cols(float (*M)[4], int p, int q, Rot j) {            /* MatrixBase::applyOnTheRight(p, q, j): the columns rotate with j.transpose() */
+    const Rot t = {j.c, -j.s};
+    if (t.c == 1.f && t.s == 0.f) return;
+    for (int i = 0; i < 4; i++) { const float x = M[i][p], y = M[i][q]; M[i][p] = t.c * x + t.s * y; M[i][q] = -t.s * x + t.c * y; }
+}
+}  // namespace
+void orbo_eigen_jacobi_svd4_V(const float *A16, float *V16, float *sv4) {
+    const float tiny = std::numeric_limits<float>::min(), precision = 2.f * std::numeric_limits<float>::epsilon();
+    float W[4][4], V[4][4];
+    float scale = 0.f;
+    for (int i = 0; i < 16; i++) scale = std::max(scale, std::fabs(A16[i]));
+    if (scale == 0.f) scale = 1.f;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) { W[i][j] = A16[4 * i + j] / scale; V[i][j] = i == j ? 1.f : 0.f; }
+    float maxDiagEntry = 0.f;
+    for (int i = 0; i < 4; i++) maxDiagEntry = std::max(maxDiagEntry, std::fabs(W[i][i]));
+    bool finished = false;
+    for (int guard = 0; !finished && guard < 64; guard++) {
+        finished = true;
+        for (int p = 1; p < 4; ++p)
+            for (int q = 0; q < p; ++q) {
+                const float threshold = std::max(tiny, precision * maxDiagEntry);
+                if (std::fabs(W[p][q]) > threshold || std::fabs(W[q][p]) > threshold) {
+                    finished = false;
+                    /* real_2x2_jacobi_svd(W, p, q, &j_left, &j_right) */
+                    float m[2][2] = {{W[p][p], W[p][q]}, {W[q][p], W[q][q]}};
+                    Rot rot1;
+                    const float t = m[0][0] + m[1][1], d = m[1][0] - m[0][1];
+                    if (std::fabs(d) < tiny) { rot1.s = 0.f; rot1.c = 1.f; }
+                    else { const float u = t / d, tmp = std::sqrt(1.f + u * u); rot1.s = 1.f / tmp; rot1.c = u / tmp; }
+                    {   /* m.applyOnTheLeft(0, 1, rot1) */
+                        for (int i = 0; i < 2; i++) { const float x = m[0][i], y = m[1][i]; m[0][i] = rot1.c * x + rot1.s * y; m[1][i] = -rot1.s * x + rot1.c * y; }
+                    }
+                    Rot jr;   /* j_right.makeJacobi(m, 0, 1): x = m(0,0), y = m(0,1), z = m(1,1) */
+                    {
+                        const float x = m[0][0], y = m[0][1], z = m[1][1], deno = 2.f * std::fabs(y);
+                        if (deno < tiny) { jr.c = 1.f; jr.s = 0.f; }
+                        else {
+                            const float tau = (x - z) / deno, w = std::sqrt(tau * tau + 1.f);
+                            const float tt = tau > 0.f ? 1.f / (tau + w) : 1.f / (tau - w);
+                            const float sign_t = tt > 0.f ? 1.f : -1.f, n = 1.f / std::sqrt(tt * tt + 1.f);
+                            jr.s = -sign_t * (y / std::fabs(y)) * std::fabs(tt) * n;
+                            jr.c = n;
+                        }
+                    }
+                    const Rot jrt = {jr.c, -jr.s};
+                    const Rot jl = {rot1.c * jrt.c - rot1.s * jrt.s, rot1.c * jrt.s + rot1.s * jrt.c};   /* rot1 * j_right.transpose() */
+                    rot_rows(W, p, q, jl);
+                    rot_cols(W, p, q, jr);
+                    rot_cols(V, p, q, jr);
+                    maxDiagEntry = std::max(maxDiagEntry, std::max(std::fabs(W[p][p]), std::fabs(W[q][q])));
+                }
+            }
+    }
+    float sv[4];
+    for (int i = 0; i < 4; i++) sv[i] = std::fabs(W[i][i]) * scale;
+    for (int i = 0; i < 4; i++) {
+        int pos = 0;
+        float best = sv[i];
+        for (int j = 1; j < 4 - i; j++) if (sv[i + j] > best) { best = sv[i + j]; pos = j; }
+        if (best == 0.f) break;
+        if (pos) { pos += i; std::swap(sv[i], sv[pos]); for (int r = 0; r < 4; r++) std::swap(V[r][i], V[r][pos]); }
+    }
+    for (int i = 0; i < 4; i++) { for (int j = 0; j < 4; j++) V16[4 * i + j] = V[i][j]; if (sv4) sv4[i] = sv[i]; }
+}
+
+/* KannalaBrandt8::TriangulateMatches (KannalaBrandt8.cpp:305-368) with Triangulate (:387-400): the value the reference returns (z1, or -1 .. -5) */
+float orbo_kb8_triangulate_matches(const float *cam1, const float *cam2, float x1, float y1, float x2, float y2, const float *R12, const float *t12,
+                                   float sigmaLevel, float unc) {
+    float r1[3], r2[3], r21[3];
+    orbo_kb8_unproject(cam1, x1, y1, r1);
+    orbo_kb8_unproject(cam2, x2, y2, r2);
+    for (int i = 0; i < 3; i++) r21[i] = (0.f + R12[3 * i] * r2[0]) + R12[3 * i + 1] * r2[1] + R12[3 * i + 2] * r2[2];
+    const float dot = (0.f + r1[0] * r21[0]) + r1[1] * r21[1] + r1[2] * r21[2];
+    const float nr1 = std::sqrt((0.f + r1[0] * r1[0]) + r1[1] * r1[1] + r1[2] * r1[2]), nr21 = std::sqrt((0.f + r21[0] * r21[0]) + r21[1] * r21[1] + r21[2] * r21[2]);
+    const float cosParallaxRays = dot / (nr1 * nr21);
+    if (cosParallaxRays > 0.9998) return -1;
+    float Tcw1[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}}, Tcw2[3][4], R21[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R21[i][j] = R12[3 * j + i];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Tcw2[i][j] = R21[i][j];
+        Tcw2[i][3] = (0.f + -R21[i][0] * t12[0]) + -R21[i][1] * t12[1] + -R21[i][2] * t12[2];   /* -R21 * t12 */
+    }
+    float A[16];
+    for (int j = 0; j < 4; j++) {
+        A[j] = r1[0] * Tcw1[2][j] - Tcw1[0][j];
+        A[4 + j] = r1[1] * Tcw1[2][j] - Tcw1[1][j];
+        A[8 + j] = r2[0] * Tcw2[2][j] - Tcw2[0][j];
+        A[12 + j] = r2[1] * Tcw2[2][j] - Tcw2[1][j];
+    }
+    float V[16];
+    orbo_eigen_jacobi_svd4_V(A, V, nullptr);
+    const float x3D[3] = {V[3] / V[15], V[7] / V[15], V[11] / V[15]};   /* matrixV().col(3).head(3) / x3Dh(3) */
+    const float z1 = x3D[2];
+    if (z1 <= 0) return -2;
+    const float z2 = ((0.f + R21[2][0] * x3D[0]) + R21[2][1] * x3D[1] + R21[2][2] * x3D[2]) + Tcw2[2][3];
+    if (z2 <= 0) return -3;
+    float u, v;
+    orbo_kb8_project(cam1, x3D[0], x3D[1], x3D[2], &u, &v);
+    const float errX1 = u - x1, errY1 = v - y1;
+    if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel) return -4;
+    float x3D2[3];
+    for (int i = 0; i < 3; i++) x3D2[i] = ((0.f + R21[i][0] * x3D[0]) + R21[i][1] * x3D[1] + R21[i][2] * x3D[2]) + Tcw2[i][3];
+    orbo_kb8_project(cam2, x3D2[0], x3D2[1], x3D2[2], &u, &v);
+    const float errX2 = u - x2, errY2 = v - y2;
+    if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -5;
+    return z1;
+}
+/* KannalaBrandt8::epipolarConstrain (:216-221) for n keypoint pairs */
+void orbo_kb8_epipolar_constrain(const float *cam1, const float *cam2, int n, const float *xy1, const float *xy2, const float *R12, const float *t12,
+                                 const float *sigma1, const float *sigma2, uint8_t *ok, float *tm_value) {
+    for (int i = 0; i < n; i++) {
+        const float z = orbo_kb8_triangulate_matches(cam1, cam2, xy1[2 * i], xy1[2 * i + 1], xy2[2 * i], xy2[2 * i + 1], R12, t12, sigma1[i], sigma2[i]);
+        ok[i] = z > 0.0001f ? 1 : 0;
+        if (tm_value) tm_value[i] = z;
+    }
 }
 
 /* Frame::isInFrustumChecks(pMP, viewingCosLimit, bRight) (Frame.cc:1168-1240) for n map points and one camera of the rig: R, t, twc are what lines

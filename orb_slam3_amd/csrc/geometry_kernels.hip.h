@@ -169,6 +169,204 @@ __host__ __device__ inline void kb8_project(const float *p, float X, float Y, fl
     *v = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
 }
 
+// glibc 2.35 tanf (sysdeps/ieee754/flt-32/s_tanf.c, k_tanf.c, e_rem_pio2f.c: fdlibm) for |x| < 3 pi / 4 -- the range KannalaBrandt8::unproject's
+// theta lives in (theta_d is clamped to pi / 2); beyond it the double tangent.  Against the host libm on EVERY float of that range (2 150 471 624 arguments):
+// bit-identical -- with the argument reduction in double (the fdlibm float reduction, 24 + 24 (+ 24) bits of pi / 2, differs from glibc on 1034 of them).
+// tests/simt/check_geometry_math.cc repeats a strided sweep.
+__host__ __device__ inline float glibc_kernel_tanf(float x, float y, int iy) {
+    const float T[13] = {3.3333334327e-01f, 1.3333334029e-01f, 5.3968254477e-02f, 2.1869488060e-02f, 8.8632395491e-03f, 3.5920790397e-03f, 1.4562094584e-03f,
+                         5.8804126456e-04f, 2.4646313977e-04f, 7.8179444245e-05f, 7.1407252108e-05f, -1.8558637748e-05f, 2.5907305826e-05f};
+    const float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+    uint32_t ux;
+    memcpy(&ux, &x, 4);
+    const int32_t hx = (int32_t)ux, ix = hx & 0x7fffffff;
+    float z, r, v, w, s;
+    if (ix < 0x39000000 && (int)x == 0) {   // |x| < 2^-13
+        if ((ix | (iy + 1)) == 0) return 1.0f / fabsf(x);
+        return iy == 1 ? x : -1.0f / x;
+    }
+    if (ix >= 0x3f2ca140) {   // |x| >= 0.6744
+        if (hx < 0) { x = -x; y = -y; }
+        z = pio4 - x; w = pio4lo - y; x = z + w; y = 0.0f;
+        if (fabsf(x) < 0x1p-13f) return (1 - ((hx >> 30) & 2)) * iy * (1.0f - 2 * iy * x);
+    }
+    z = x * x; w = z * z;
+    r = T[1] + w * (T[3] + w * (T[5] + w * (T[7] + w * (T[9] + w * T[11]))));
+    v = z * (T[2] + w * (T[4] + w * (T[6] + w * (T[8] + w * (T[10] + w * T[12])))));
+    s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T[0] * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) { v = (float)iy; return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r))); }
+    if (iy == 1) return w;
+    uint32_t u;
+    memcpy(&u, &w, 4); u &= 0xfffff000u; memcpy(&z, &u, 4);
+    v = r - (z - x);
+    float a, t;
+    t = a = -1.0f / w;
+    memcpy(&u, &t, 4); u &= 0xfffff000u; memcpy(&t, &u, 4);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+}
+__host__ __device__ inline float glibc_tanf(float x) {
+    uint32_t ux;
+    memcpy(&ux, &x, 4);
+    const int32_t hx = (int32_t)ux, ix = hx & 0x7fffffff;
+    if (ix <= 0x3f490fda) return glibc_kernel_tanf(x, 0.0f, 1);
+    if (ix >= 0x4016cbe4) return (float)tan((double)x);   // outside the camera model's range
+    // __ieee754_rem_pio2f for pi/4 < |x| < 3 pi/4 (n = +-1): the remainder in double, handed to the kernel as head + tail
+    const double r = hx > 0 ? (double)x - 1.5707963267948966 : (double)x + 1.5707963267948966;
+    const float y0 = (float)r, y1 = (float)(r - (double)y0);
+    return glibc_kernel_tanf(y0, y1, -1);   // odd quadrant
+}
+
+// KannalaBrandt8::unproject (KannalaBrandt8.cpp:107-142): Newton iterations on the distortion polynomial; precision = 1e-6 (KannalaBrandt8.h:42-59)
+__host__ __device__ inline void kb8_unproject(const float *p, float px, float py, float precision, float *rx, float *ry) {
+    const float pwx = (px - p[2]) / p[0], pwy = (py - p[3]) / p[1];
+    float scale = 1.f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    theta_d = fminf(fmaxf((float)(-3.1415926535897932384626433832795 / 2.f), theta_d), (float)(3.1415926535897932384626433832795 / 2.f));
+    if ((double)theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const float k0_theta2 = p[4] * theta2, k1_theta4 = p[5] * theta4, k2_theta6 = p[6] * theta6, k3_theta8 = p[7] * theta8;
+            const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                    (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabsf(theta_fix) < precision) break;
+        }
+        scale = glibc_tanf(theta) / theta_d;
+    }
+    *rx = pwx * scale; *ry = pwy * scale;   // ray (rx, ry, 1)
+}
+
+// Eigen::JacobiSVD<Matrix4f>(A, ComputeFullV).matrixV().col(3) -- the two-sided Jacobi iteration of Eigen 3.3 / 3.4 (Eigen/src/SVD/JacobiSVD.h,
+// Eigen/src/Jacobi/Jacobi.h) restated from the published source: scaling by the largest coefficient, sweeps over (p, q), real_2x2_jacobi_svd, rotations
+// applied in Eigen's operation order, singular values sorted with column swaps.  PARITY UNPINNED: Eigen is not vendored by the reference and absent from
+// this image; what the gate does with the result are threshold tests, which a last-bit difference moves only at a boundary.
+__host__ __device__ inline void eigen_jacobi_svd4_v3(const float (*A)[4], float *out) {
+    const float fmin_ = 1.17549435e-38f, eps2 = 2.f * 1.1920929e-07f;
+    float W[4][4], V[4][4];
+    float scale = 0.f;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) scale = fmaxf(scale, fabsf(A[i][j]));
+    if (scale == 0.f) scale = 1.f;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) { W[i][j] = A[i][j] / scale; V[i][j] = i == j ? 1.f : 0.f; }
+    float maxDiag = 0.f;
+    for (int i = 0; i < 4; i++) maxDiag = fmaxf(maxDiag, fabsf(W[i][i]));
+    bool finished = false;
+    for (int sweep = 0; !finished && sweep < 64; sweep++) {   // (Eigen loops until a sweep changes nothing; 64 bounds a NaN input)
+        finished = true;
+#pragma unroll
+        for (int p = 1; p < 4; p++)
+#pragma unroll
+            for (int q = 0; q < p; q++) {
+                const float threshold = fmaxf(fmin_, eps2 * maxDiag);
+                if (!(fabsf(W[p][q]) > threshold || fabsf(W[q][p]) > threshold)) continue;
+                finished = false;
+                // real_2x2_jacobi_svd on (W(p,p) W(p,q); W(q,p) W(q,q))
+                const float m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+                const float t = m00 + m11, d = m10 - m01;
+                float c1, s1;
+                if (fabsf(d) < fmin_) { s1 = 0.f; c1 = 1.f; }
+                else { const float u = t / d, tmp = sqrtf(1.f + u * u); s1 = 1.f / tmp; c1 = u / tmp; }
+                const float n00 = c1 * m00 + s1 * m10, n01 = c1 * m01 + s1 * m11, n11 = -s1 * m01 + c1 * m11;
+                float cr, sr;   // j_right.makeJacobi(n00, n01, n11)
+                const float deno = 2.f * fabsf(n01);
+                if (deno < fmin_) { cr = 1.f; sr = 0.f; }
+                else {
+                    const float tau = (n00 - n11) / deno, w = sqrtf(tau * tau + 1.f);
+                    const float tt = tau > 0.f ? 1.f / (tau + w) : 1.f / (tau - w);
+                    const float sign_t = tt > 0.f ? 1.f : -1.f, n = 1.f / sqrtf(tt * tt + 1.f);
+                    sr = -sign_t * (n01 / fabsf(n01)) * fabsf(tt) * n;
+                    cr = n;
+                }
+                const float cl = c1 * cr - s1 * (-sr), sl = c1 * (-sr) + s1 * cr;   // j_left = rot1 * j_right.transpose()
+                if (!(cl == 1.f && sl == 0.f))
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const float xp = W[p][i], xq = W[q][i]; W[p][i] = cl * xp + sl * xq; W[q][i] = -sl * xp + cl * xq; }
+                if (!(cr == 1.f && sr == 0.f))   // applyOnTheRight(p, q, j) rotates the columns with j.transpose() = (cr, -sr)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float xp = W[i][p], xq = W[i][q]; W[i][p] = cr * xp + (-sr) * xq; W[i][q] = sr * xp + cr * xq;
+                        const float vp = V[i][p], vq = V[i][q]; V[i][p] = cr * vp + (-sr) * vq; V[i][q] = sr * vp + cr * vq;
+                    }
+                maxDiag = fmaxf(maxDiag, fmaxf(fabsf(W[p][p]), fabsf(W[q][q])));
+            }
+    }
+    float sv[4];
+    int col[4] = {0, 1, 2, 3};
+#pragma unroll
+    for (int i = 0; i < 4; i++) sv[i] = fabsf(W[i][i]);
+    bool stop = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {   // descending, first maximum, as maxCoeff(&pos); static indices only (an indexed local array would live in scratch memory)
+        int pos = i;
+        float best = sv[i];
+#pragma unroll
+        for (int j = i + 1; j < 4; j++) if (sv[j] > best) { best = sv[j]; pos = j; }
+        stop = stop || best == 0.f;
+#pragma unroll
+        for (int j = i + 1; j < 4; j++)
+            if (!stop && pos == j) { const float ts = sv[i]; sv[i] = sv[j]; sv[j] = ts; const int tc = col[i]; col[i] = col[j]; col[j] = tc; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float v = V[i][0];
+        v = col[3] == 1 ? V[i][1] : v; v = col[3] == 2 ? V[i][2] : v; v = col[3] == 3 ? V[i][3] : v;
+        out[i] = v;
+    }
+}
+
+// KannalaBrandt8::epipolarConstrain = TriangulateMatches(...) > 0.0001f (KannalaBrandt8.cpp:216-221, 305-368, Triangulate :387-400) for keypoint kp1 of camera
+// cam1 and kp2 of cam2, R12 / t12 the relative pose (row-major), sigmaLevel / unc the two level variances
+__host__ __device__ inline bool kb8_epipolar_constrain(const float *cam1, const float *cam2, float x1, float y1, float x2, float y2, const float *R12,
+                                                       const float *t12, float sigmaLevel, float unc) {
+    float r1[3], r2[3];
+    kb8_unproject(cam1, x1, y1, 1e-6f, &r1[0], &r1[1]); r1[2] = 1.f;
+    kb8_unproject(cam2, x2, y2, 1e-6f, &r2[0], &r2[1]); r2[2] = 1.f;
+    float r21[3];
+    for (int i = 0; i < 3; i++) r21[i] = ((0.f + R12[3 * i] * r2[0]) + R12[3 * i + 1] * r2[1]) + R12[3 * i + 2] * r2[2];
+    const float dot = ((0.f + r1[0] * r21[0]) + r1[1] * r21[1]) + r1[2] * r21[2];
+    const float n1 = sqrtf(((0.f + r1[0] * r1[0]) + r1[1] * r1[1]) + r1[2] * r1[2]), n21 = sqrtf(((0.f + r21[0] * r21[0]) + r21[1] * r21[1]) + r21[2] * r21[2]);
+    const float cosParallaxRays = dot / (n1 * n21);
+    if ((double)cosParallaxRays > 0.9998) return false;
+    float R21[3][3], T2[3][4];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R21[i][j] = R12[3 * j + i];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T2[i][j] = R21[i][j];
+        T2[i][3] = ((0.f + (-R21[i][0]) * t12[0]) + (-R21[i][1]) * t12[1]) + (-R21[i][2]) * t12[2];   // -R21 * t12
+    }
+    const float T1[3][4] = {{1.f, 0.f, 0.f, 0.f}, {0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f}};
+    float A[4][4];
+    for (int j = 0; j < 4; j++) {
+        A[0][j] = r1[0] * T1[2][j] - T1[0][j];
+        A[1][j] = r1[1] * T1[2][j] - T1[1][j];
+        A[2][j] = r2[0] * T2[2][j] - T2[0][j];
+        A[3][j] = r2[1] * T2[2][j] - T2[1][j];
+    }
+    float xh[4];
+    eigen_jacobi_svd4_v3(A, xh);
+    const float X[3] = {xh[0] / xh[3], xh[1] / xh[3], xh[2] / xh[3]};
+    const float z1 = X[2];
+    if (z1 <= 0) return false;
+    const float z2 = (((0.f + R21[2][0] * X[0]) + R21[2][1] * X[1]) + R21[2][2] * X[2]) + T2[2][3];
+    if (z2 <= 0) return false;
+    float u, v;
+    kb8_project(cam1, X[0], X[1], X[2], &u, &v);
+    const float errX1 = u - x1, errY1 = v - y1;
+    if ((double)(errX1 * errX1 + errY1 * errY1) > 5.991 * (double)sigmaLevel) return false;
+    float X2[3];
+    for (int i = 0; i < 3; i++) X2[i] = (((0.f + R21[i][0] * X[0]) + R21[i][1] * X[1]) + R21[i][2] * X[2]) + T2[i][3];
+    kb8_project(cam2, X2[0], X2[1], X2[2], &u, &v);
+    const float errX2 = u - x2, errY2 = v - y2;
+    if ((double)(errX2 * errX2 + errY2 * errY2) > 5.991 * (double)unc) return false;
+    return z1 > 0.0001f;
+}
+
 // grid (ceil(n_mp / 256), n_views), block 256.  Outputs [n_views][n_mp]: the MapPoint fields the function writes when every test passes
 // (mTrackProjX/Y[R], mnTrackScaleLevel[R], mTrackViewCos[R], mTrackDepth[R]); otherwise in_view = 0, level = -1 (Frame.cc:579-580) and zeros.
 static __global__ __launch_bounds__(256) void k_in_frustum_checks(const FrustumChecks *__restrict__ fc, int n_mp, const float *__restrict__ pos,
