@@ -27,6 +27,8 @@ struct Vec {
     float squaredNorm() const { return dot(*this); }
     float norm() const { return std::sqrt(dot(*this)); }
     const Vec &transpose() const { return *this; }
+    static Vec Zero() { return Vec(); }
+    Vec<3> head(int n) const { Vec<3> r; for (int i = 0; i < 3; i++) r.v[i] = v[i]; (void)n; return r; }   /* x3Dh.head(3) */
 };
 template <int N> inline Vec<N> operator*(float s, const Vec<N> &a) { return a * s; }
 typedef Vec<2> Vector2f;
@@ -70,6 +72,8 @@ struct Matrix3f {
     }
     Matrix3f operator*(float s) const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[i][j] * s; return r; }
     Matrix3f transpose() const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[j][i]; return r; }
+    Matrix3f operator-() const { Matrix3f r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = -m[i][j]; return r; }
+    Vector3f row(int i) const { return Vector3f(m[i][0], m[i][1], m[i][2]); }
 };
 inline Matrix3f &last_product() { static thread_local Matrix3f m; return m; }
 }  // namespace Eigen

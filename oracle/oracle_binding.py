@@ -610,6 +610,32 @@ def is_in_frustum_checks(view, bounds, log_scale_factor, nlevels, cos_limit, pos
     return out
 
 
+def kb8_epipolar_constrain(cam1, cam2, xy1, xy2, R12, t12, sigma1, sigma2):
+    """KannalaBrandt8::epipolarConstrain / TriangulateMatches for n keypoint pairs.  Returns (ok uint8[n], TriangulateMatches value float32[n])."""
+    f32 = np.float32
+    c1, c2, R, t = [np.ascontiguousarray(x, f32).ravel() for x in (cam1, cam2, R12, t12)]
+    a, b = np.ascontiguousarray(xy1, f32).reshape(-1, 2), np.ascontiguousarray(xy2, f32).reshape(-1, 2)
+    s1, s2 = np.ascontiguousarray(sigma1, f32), np.ascontiguousarray(sigma2, f32)
+    n = len(a)
+    ok, val = np.zeros(n, np.uint8), np.zeros(n, f32)
+    L = lib()
+    L.orbo_kb8_epipolar_constrain.restype = None
+    L.orbo_kb8_epipolar_constrain(_p(c1), _p(c2), n, _p(a), _p(b), _p(R), _p(t), _p(s1), _p(s2), _p(ok), _p(val))
+    return ok, val
+
+
+def kb8_unproject(cam, xy):
+    f32 = np.float32
+    c = np.ascontiguousarray(cam, f32).ravel()
+    a = np.ascontiguousarray(xy, f32).reshape(-1, 2)
+    out = np.zeros((len(a), 3), f32)
+    L = lib()
+    L.orbo_kb8_unproject.restype = None
+    for i in range(len(a)):
+        L.orbo_kb8_unproject(_p(c), C.c_float(a[i, 0]), C.c_float(a[i, 1]), _p(out[i]))
+    return out
+
+
 def undistort_points(xy, cam, dist):
     """cv::undistortPoints(xy, K, dist, R=I, P=K) [OCV-recalled].  cam = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])."""
     a = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)

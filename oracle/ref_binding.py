@@ -648,3 +648,18 @@ def ref_is_in_frustum_checks(Rcw, tcw, Ow, Rwc, Rrl, trl, tlr, params_l, params_
                                       _p(P), _p(Nn), _p(mn), _p(mx), *[_p(out[k]) for k in ("in_view", "proj_x", "proj_y", "depth", "level", "view_cos")],
                                       _p(view))
     return out, view
+
+
+def ref_kb8_triangulate_matches(cam1, cam2, xy1, xy2, R12, t12, sigma1, sigma2):
+    """The reference's KannalaBrandt8::epipolarConstrain / TriangulateMatches / unprojectEig text (JacobiSVD: the oracle's restatement of Eigen's).
+    Returns (ok, TriangulateMatches value, rays [n][6])."""
+    f32 = np.float32
+    L = C.CDLL(str(_DIR / "libfrustum_ref.so"))
+    c1, c2, R, t = [np.ascontiguousarray(x, f32).ravel() for x in (cam1, cam2, R12, t12)]
+    a, b = np.ascontiguousarray(xy1, f32).reshape(-1, 2), np.ascontiguousarray(xy2, f32).reshape(-1, 2)
+    s1, s2 = _f32(sigma1), _f32(sigma2)
+    n = len(a)
+    ok, val, rays = np.zeros(n, np.uint8), np.zeros(n, f32), np.zeros((n, 6), f32)
+    L.kb8ref_triangulate_matches.restype = None
+    L.kb8ref_triangulate_matches(_p(c1), _p(c2), n, _p(a), _p(b), _p(R), _p(t), _p(s1), _p(s2), _p(ok), _p(val), _p(rays))
+    return ok, val, rays

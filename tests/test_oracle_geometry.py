@@ -114,6 +114,59 @@ def test_is_in_frustum_checks_equals_reference_text(seed):
         assert np.all(o["level"][~iv] == -1)
 
 
+def kb8_pairs(seed, n=3000):
+    """Keypoint pairs of two fisheye cameras looking at common 3-D points (+ pixel noise of several sizes, some pairs with hardly any parallax):
+    every return path of KannalaBrandt8::TriangulateMatches is taken."""
+    rng = np.random.default_rng(500 + seed)
+    a = rng.uniform(-0.05, 0.05, 3)
+    R12 = np.array([[1, -a[2], a[1]], [a[2], 1, -a[0]], [-a[1], a[0], 1]], np.float32)
+    t12 = (np.array([0.1, 0.0, 0.0]) + rng.normal(0, 0.02, 3)).astype(np.float32)
+    X1 = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(0.8, 7, n)], axis=1)
+    X2 = (R12.astype(np.float64).T @ (X1 - t12.astype(np.float64)).T).T
+    def proj(prm, X):
+        th = np.arctan2(np.hypot(X[:, 0], X[:, 1]), X[:, 2]); psi = np.arctan2(X[:, 1], X[:, 0])
+        r = th + prm[4] * th ** 3 + prm[5] * th ** 5 + prm[6] * th ** 7 + prm[7] * th ** 9
+        return np.stack([prm[0] * r * np.cos(psi) + prm[2], prm[1] * r * np.sin(psi) + prm[3]], axis=1)
+    noise = rng.choice([0.3, 1.5, 6.0], n)[:, None]
+    xy1 = (proj(TUMVI_L, X1) + noise * rng.uniform(-1, 1, (n, 2))).astype(np.float32)
+    xy2 = (proj(TUMVI_R, X2) + noise * rng.uniform(-1, 1, (n, 2))).astype(np.float32)
+    same = rng.random(n) < 0.15
+    xy2[same] = xy1[same]
+    lev = 1.44 ** rng.integers(0, 8, (n, 2))
+    return R12, t12, xy1, xy2, lev[:, 0].astype(np.float32), lev[:, 1].astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_kb8_epipolar_constrain_equals_reference_text(seed):
+    """KannalaBrandt8::epipolarConstrain = TriangulateMatches > 0.0001 (KannalaBrandt8.cpp:216-221, 305-368; Triangulate :387-400; unproject :107-142): the oracle
+    against the reference's text for all of it -- over the stand-in Eigen types, whose JacobiSVD IS the oracle's restatement of Eigen's algorithm (Eigen is absent:
+    the decomposition itself stays unpinned; the SVD is checked on its defining properties below)."""
+    R12, t12, xy1, xy2, s1, s2 = kb8_pairs(seed)
+    ok, val = ob.kb8_epipolar_constrain(TUMVI_L, TUMVI_R, xy1, xy2, R12, t12, s1, s2)
+    rays = np.concatenate([ob.kb8_unproject(TUMVI_L, xy1), ob.kb8_unproject(TUMVI_R, xy2)], axis=1)
+    _P.pin(f"kb8_epipolar/{seed}", [ok, val, rays], lambda: list(rb.ref_kb8_triangulate_matches(TUMVI_L, TUMVI_R, xy1, xy2, R12, t12, s1, s2)))
+    codes = {c: int((val == c).sum()) for c in (-1, -2, -4, -5)}
+    assert ok.sum() > 500 and min(codes.values()) > 10, (int(ok.sum()), codes)
+
+
+def test_restated_jacobi_svd_properties():
+    """The restated Eigen::JacobiSVD<Matrix4f>: V orthonormal, singular values descending and equal to numpy's, A V = U S column norms -- on random and on
+    rank-deficient matrices (the triangulation's A has a one-dimensional null space: its last column of V is what the reference reads)."""
+    rng = np.random.default_rng(0)
+    L = ob.lib()
+    for t in range(500):
+        A = rng.normal(0, 1, (4, 4)).astype(np.float32)
+        if t % 3 == 0:
+            A[3] = 0.5 * A[0] + A[1]
+        V, sv = np.zeros(16, np.float32), np.zeros(4, np.float32)
+        L.orbo_eigen_jacobi_svd4_V(ob._p(A), ob._p(V), ob._p(sv))
+        V = V.reshape(4, 4).astype(np.float64)
+        s = np.linalg.svd(A.astype(np.float64), compute_uv=False)
+        assert np.all(np.diff(sv) <= 0) and np.abs(s - sv).max() < 2e-6 * s.max()
+        assert np.abs(V.T @ V - np.eye(4)).max() < 2e-6
+        assert np.abs(np.linalg.norm(A.astype(np.float64) @ V, axis=0) - sv).max() < 3e-6 * s.max()
+
+
 def _distort(xy_un, cam, dist):
     """Frame::ProjectPointDistort's forward model (Frame.cc:612-636) in float64."""
     fx, fy, cx, cy = cam
