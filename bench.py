@@ -1087,6 +1087,17 @@ def latency_calls(osa, device, n_calls, n_cpu=5, small=False):
                      lambda: m7.SearchForTriangulationPinhole(k0, d0, s0, fva6, k1, d1, s1, fvb6, sf2, sg, Fm, ep, None, None, False, False),
                      lambda: ob.search_for_triangulation_pinhole(k0, d0, s0, None, fva6, k1, d1, s1, None, fvb6, sf2, sg, Fm, ep, False, True, fma=True),
                      lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])))
+    # the fisheye rig's form: KannalaBrandt8::epipolarConstrain (unproject, parallax, JacobiSVD triangulation, two reprojection tests) per surviving candidate
+    fk1, fnl1, fd1, fid1, fk2, fnl2, fd2, fid2, fR12, ft12, fcams = synth.make_fisheye_keyframes(np.random.default_rng(77), 1000)
+    ffv1, ffv2 = osa.FeatureVector.from_node_of_feature(fid1 % 60), osa.FeatureVector.from_node_of_feature(fid2 % 60)
+    fs1 = (np.random.default_rng(78).random(len(fk1)) < 0.3).astype(np.uint8)
+    fs2 = (np.random.default_rng(79).random(len(fk2)) < 0.3).astype(np.uint8)
+    m7k = osa.ORBmatcher(0.6, True, device=device)
+    out.append(entry("SearchForTriangulation(KF1, KF2), fisheye rig, KannalaBrandt8::epipolarConstrain on the device [orbx_search_for_triangulation_kb8]: %d x %d features"
+                     % (len(fk1), len(fk2)), "ORBmatcher.cc:907-1146 (:1036-1072), KannalaBrandt8.cpp:216-221, 305-400, LocalMapping.cc:412",
+                     lambda: m7k.SearchForTriangulationKB8(fk1, fnl1, fd1, fs1, ffv1, fk2, fnl2, fd2, fs2, ffv2, sg, sg, fcams, fcams, fR12, ft12, False),
+                     lambda: ob.search_for_triangulation_kb8(fk1, fnl1, fd1, fs1, ffv1, fk2, fnl2, fd2, fs2, ffv2, sg, sg, fcams, fcams, fR12, ft12, False, True),
+                     lambda g, c: g[0] == c[0] and np.array_equal(g[1], c[1])))
     isg = ex2.GetInverseScaleSigmaSquares()
     lvl = k0["octave"]
     qf = dict(u=k0["x"] - 2.0 + rng.normal(0, 1.2, len(k0)).astype(np.float32), v=k0["y"] - 1.0 + rng.normal(0, 1.2, len(k0)).astype(np.float32),

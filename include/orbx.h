@@ -369,6 +369,29 @@ int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1,
                                           const uint8_t *desc2, const uint8_t *skip2, int n2, const orbx_featvec *fv2,
                                           int check_orientation, const orbx_pinhole_gate *gate, int32_t *matches12);
 
+/* SearchForTriangulation between two key frames of a FISHEYE rig (pKF1->mpCamera2 && pKF2->mpCamera2) with the geometric gate on the device -- no callback:
+ * src/ORBmatcher.cc:1036-1072 picks, per candidate pair, the cameras the two features were seen by (idx < NLeft: left) and the relative pose of that camera pair,
+ * then KannalaBrandt8::epipolarConstrain (src/CameraModels/KannalaBrandt8.cpp:216-221 = TriangulateMatches :305-368 > 0.0001: unproject both keypoints,
+ * parallax test, Triangulate :387-400 (Eigen::JacobiSVD of the 4x4 system), depth tests, reprojection errors against 5.991 * mvLevelSigma2); skipped when coarse.
+ * There is no epipole-distance test for such key frames (:1026).  Float operations round as the reference text writes them; atan2f / tanf are glibc's restated
+ * bit for bit, cos / sin evaluate in double as the reference's translation unit does; Eigen's JacobiSVD is restated from its published source (Eigen is not
+ * vendored by the reference: that step's parity is UNPINNED -- DESIGN.md section 5).
+ * kps1 / kps2: ALL features of the key frame, [0, n_left) = mvKeys, [n_left, N) = mvKeysRight (pt, octave, angle are read).
+ * cam1[0] / cam1[1] = mvParameters (fx, fy, cx, cy, k0..k3) of pKF1->mpCamera / mpCamera2, cam2 likewise for pKF2.
+ * R12 / t12 [2 * right1 + right2] = Rll tll, Rlr tlr, Rrl trl, Rrr trr of :934-944 (row-major), computed by the caller's Sophus as the reference does. */
+typedef struct orbx_kb8_gate {
+    const orbx_keypoint *kps1, *kps2;
+    int n_left1, n_left2;
+    const float *level_sigma2_1, *level_sigma2_2; /* mvLevelSigma2 of pKF1 / pKF2 [nlevels] */
+    int nlevels;
+    float cam1[2][8], cam2[2][8];
+    float R12[4][9], t12[4][3];
+    int coarse;
+} orbx_kb8_gate;
+int orbx_search_for_triangulation_kb8(orbx_matcher *m, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbx_featvec *fv1, const uint8_t *desc2,
+                                      const uint8_t *skip2, int n2, const orbx_featvec *fv2, int check_orientation, const orbx_kb8_gate *gate,
+                                      int32_t *matches12);
+
 /* ---- fisheye-stereo forms (F.Nleft != -1: KannalaBrandt8 stereo rigs, both cameras' features in one Frame) ----
  * Feature indices follow the reference: [0, n_left) = left camera (F.mvKeys), [n_left, n_left + n_right) = right camera
  * (F.mvKeysRight); `left` describes the left camera (keypoints_un = mvKeys, n = n_left, image bounds, scale factors) and its

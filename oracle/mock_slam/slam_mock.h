@@ -40,6 +40,10 @@ public:
     unsigned int mnType = CAM_FISHEYE;
     unsigned int GetType() { return mnType; }
     virtual Eigen::Matrix3f toK_() { return Eigen::Matrix3f(); }
+    /* GeometricCamera.h:85-88: parameter access.  The table-driven stand-in has none (size() == 0): the adapter then keeps the host callback, which is what
+     * the shim's fisheye cases test; a real KannalaBrandt8 has 8 and goes to the device gate (tests/test_gpu_matcher.py drives that through the C ABI) */
+    virtual size_t size() { return 0; }
+    virtual float getParameter(const int) { return 0.f; }
     /* the verdicts of the epipolar test are test data: ok[idx1 * n2 + idx2], keyed by keypoint identity (class_id) */
     const uint8_t *epi_ok = nullptr;
     int epi_n2 = 0;

@@ -521,6 +521,22 @@ def search_for_triangulation_pinhole(k1, d1, s1, ur1, fv1, k2, d2, s2, ur2, fv2,
     return n, m12
 
 
+def search_for_triangulation_kb8(k1, n_left1, d1, s1, fv1, k2, n_left2, d2, s2, fv2, sigma2_1, sigma2_2, cam1, cam2, R12, t12, coarse, check_orientation):
+    """M7 between key frames of a fisheye rig with KannalaBrandt8::epipolarConstrain as the lazily evaluated gate (ORBmatcher.cc:1036-1072)."""
+    f32 = np.float32
+    k1, k2 = np.ascontiguousarray(k1, KP_DTYPE), np.ascontiguousarray(k2, KP_DTYPE)
+    d1, d2 = np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)
+    s1, s2 = np.ascontiguousarray(s1, np.uint8), np.ascontiguousarray(s2, np.uint8)
+    sg1, sg2, c1, c2, R, t = [np.ascontiguousarray(x, f32).ravel() for x in (sigma2_1, sigma2_2, cam1, cam2, R12, t12)]
+    a, b = _fv(fv1), _fv(fv2)
+    m12 = np.full(len(k1), -1, np.int32)
+    L = lib()
+    L.orbo_search_for_triangulation_kb8.restype = C.c_int
+    n = L.orbo_search_for_triangulation_kb8(_p(k1), int(n_left1), _p(d1), _p(s1), len(k1), C.byref(a), _p(k2), int(n_left2), _p(d2), _p(s2), len(k2), C.byref(b),
+                                            _p(sg1), _p(sg2), _p(c1), _p(c2), _p(R), _p(t), int(coarse), int(check_orientation), _p(m12))
+    return n, m12
+
+
 def search_by_projection_mappoints_fisheye(grid_left: OracleGrid, grid_right: OracleGrid, desc, scale_factors, l2r, r2l, mp, th, nnratio,
                                            occupied=None):
     """mp: in_view, proj_x, proj_y, level, view_cos, in_view_r, proj_xr, proj_yr, level_r, view_cos_r, desc, has_obs."""

@@ -231,6 +231,12 @@ int orbo_search_for_triangulation_pinhole(const orbo_keypoint *kps1, const uint8
                                           const float *scale_factors2, const float *level_sigma2_2, const float *F12, float ep_x,
                                           float ep_y, int coarse, int check_orientation, int fma_mode, int32_t *matches12);
 
+/* M7 between key frames of a fisheye rig: KannalaBrandt8::epipolarConstrain (orb_oracle_geom.cc) as the gate of :1036-1072, no callback */
+int orbo_search_for_triangulation_kb8(const orbo_keypoint *kps1, int n_left1, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbo_featvec *fv1,
+                                      const orbo_keypoint *kps2, int n_left2, const uint8_t *desc2, const uint8_t *skip2, int n2, const orbo_featvec *fv2,
+                                      const float *level_sigma2_1, const float *level_sigma2_2, const float *cam1, const float *cam2, const float *R12,
+                                      const float *t12, int coarse, int check_orientation, int32_t *matches12);
+
 /* M8: Frame::ComputeStereoMatches (Frame.cc:811-981).  Fills u_right/depth (N_left), and the raw Hamming stage
  * result best_idx_r / best_dist (-1 / TH_HIGH when none) for kernel-level parity. */
 int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int nl, const orbo_keypoint *kr,

@@ -766,6 +766,35 @@ int orbo_search_for_triangulation_pinhole(const orbo_keypoint *kps1, const uint8
                                          pinhole_gate, &g, matches12);
 }
 
+/* M7 between key frames of a fisheye rig (ORBmatcher.cc:1036-1072): the pair's cameras select the KannalaBrandt8 parameters and the relative pose
+ * (R12 / t12 [2 * right1 + right2] = ll, lr, rl, rr of :934-944); KannalaBrandt8::epipolarConstrain evaluated lazily where the reference evaluates it.
+ * cam1 / cam2: [2][8] parameters of (mpCamera, mpCamera2) of KF1 / KF2. */
+namespace {
+struct Kb8GateO {
+    const orbo_keypoint *k1, *k2;
+    int n_left1, n_left2;
+    const float *sigma2_1, *sigma2_2, *cam1, *cam2, *R12, *t12;
+    int coarse;
+};
+int kb8_gate(void *user, int i1, int i2) {
+    const Kb8GateO &g = *(const Kb8GateO *)user;
+    if (g.coarse) return 1;
+    const int r1 = i1 >= g.n_left1 ? 1 : 0, r2 = i2 >= g.n_left2 ? 1 : 0, sel = 2 * r1 + r2;
+    return orbo_kb8_triangulate_matches(g.cam1 + 8 * r1, g.cam2 + 8 * r2, g.k1[i1].x, g.k1[i1].y, g.k2[i2].x, g.k2[i2].y, g.R12 + 9 * sel, g.t12 + 3 * sel,
+                                        g.sigma2_1[g.k1[i1].octave], g.sigma2_2[g.k2[i2].octave]) > 0.0001f;
+}
+}  // namespace
+int orbo_search_for_triangulation_kb8(const orbo_keypoint *kps1, int n_left1, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbo_featvec *fv1,
+                                      const orbo_keypoint *kps2, int n_left2, const uint8_t *desc2, const uint8_t *skip2, int n2, const orbo_featvec *fv2,
+                                      const float *level_sigma2_1, const float *level_sigma2_2, const float *cam1, const float *cam2, const float *R12,
+                                      const float *t12, int coarse, int check_orientation, int32_t *matches12) {
+    std::vector<float> a1(n1), a2(n2);
+    for (int i = 0; i < n1; i++) a1[i] = kps1[i].angle;
+    for (int i = 0; i < n2; i++) a2[i] = kps2[i].angle;
+    Kb8GateO g{kps1, kps2, n_left1, n_left2, level_sigma2_1, level_sigma2_2, cam1, cam2, R12, t12, coarse};
+    return orbo_search_for_triangulation(desc1, a1.data(), skip1, n1, fv1, desc2, a2.data(), skip2, n2, fv2, check_orientation, kb8_gate, &g, matches12);
+}
+
 /* M8, Frame.cc:811-981 */
 int orbo_compute_stereo_matches(const orbo_keypoint *kl, const uint8_t *dl, int N, const orbo_keypoint *kr,
                                 const uint8_t *dr, int Nr, const float *scale_factors, const float *inv_scale_factors,

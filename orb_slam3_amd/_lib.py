@@ -81,6 +81,13 @@ class PinholeGate(C.Structure):
                 ("ep_x", C.c_float), ("ep_y", C.c_float), ("coarse", C.c_int), ("strict_fp", C.c_int)]
 
 
+class Kb8GateStruct(C.Structure):
+    """orbx_kb8_gate (include/orbx.h)."""
+    _fields_ = [("kps1", C.c_void_p), ("kps2", C.c_void_p), ("n_left1", C.c_int), ("n_left2", C.c_int), ("level_sigma2_1", C.c_void_p),
+                ("level_sigma2_2", C.c_void_p), ("nlevels", C.c_int), ("cam1", C.c_float * 16), ("cam2", C.c_float * 16), ("R12", C.c_float * 36),
+                ("t12", C.c_float * 12), ("coarse", C.c_int)]
+
+
 class FeatVec(C.Structure):
     """DBoW2::FeatureVector flattened: node ids ascending + CSR of feature indices."""
     _fields_ = [("node_id", C.c_void_p), ("node_ptr", C.c_void_p), ("index", C.c_void_p), ("n_nodes", C.c_int32)]
@@ -103,7 +110,7 @@ SYMBOLS = [
     "orbx_search_by_bow_frame_fisheye", "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_is_in_frustum", "orbx_is_in_frustum_checks", "orbx_frustum_batch_device",
     "orbx_set_camera", "orbx_batch_download_keypoints_un",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
-    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_stereo_batch_download_async", "orbx_stereo_download_wait", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
+    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_search_for_triangulation_kb8", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_stereo_batch_download_async", "orbx_stereo_download_wait", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
     "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors", "orbx_fuse_search",
 ]
 
@@ -195,6 +202,7 @@ def lib() -> C.CDLL:
     L.orbx_search_by_bow_keyframes.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, vp, i32, fvp, f32, i32, vp]
     L.orbx_search_for_triangulation.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, vp, i32, fvp, i32, PAIR_PREDICATE, vp, vp]
     L.orbx_search_for_triangulation_pinhole.argtypes = [vp, vp, vp, i32, fvp, vp, vp, i32, fvp, i32, C.POINTER(PinholeGate), vp]
+    L.orbx_search_for_triangulation_kb8.argtypes = [vp, vp, vp, i32, fvp, vp, vp, i32, fvp, i32, C.POINTER(Kb8GateStruct), vp]
     _lib = L
     return L
 

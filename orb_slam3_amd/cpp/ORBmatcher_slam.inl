@@ -432,6 +432,40 @@ public:
         std::vector<float> a1(n1), a2(n2);
         for (int i = 0; i < n1; i++) { skip1[i] = (pKF1->GetMapPoint(i) || bOnlyStereo) ? 1 : 0; a1[i] = key(pKF1, i).angle; }
         for (int i = 0; i < n2; i++) { skip2[i] = (pKF2->GetMapPoint(i) || bOnlyStereo) ? 1 : 0; a2[i] = key(pKF2, i).angle; }
+        // KannalaBrandt8 cameras (the reference's only CAM_FISHEYE model: 8 parameters) on both rigs: KannalaBrandt8::epipolarConstrain runs on the device
+        // (orbx_search_for_triangulation_kb8: no candidate distance returns to the host); any other camera object keeps the callback below
+        bool kb8 = pKF1->NLeft >= 0 && pKF2->NLeft >= 0;
+        for (GeometricCamera *c : {cam1[0], cam1[1], cam2[0], cam2[1]}) kb8 = kb8 && c->GetType() == GeometricCamera::CAM_FISHEYE && c->size() == 8;
+        if (kb8) {
+            std::vector<orbx_keypoint> k1(n1), k2(n2);
+            auto flat = [](const cv::KeyPoint &k) { orbx_keypoint o; o.x = k.pt.x; o.y = k.pt.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id; return o; };
+            for (int i = 0; i < n1; i++) k1[i] = flat(key(pKF1, i));
+            for (int i = 0; i < n2; i++) k2[i] = flat(key(pKF2, i));
+            orbx_kb8_gate g;
+            memset(&g, 0, sizeof(g));
+            g.kps1 = k1.data(); g.kps2 = k2.data();
+            g.n_left1 = pKF1->NLeft; g.n_left2 = pKF2->NLeft;
+            g.level_sigma2_1 = pKF1->mvLevelSigma2.data(); g.level_sigma2_2 = pKF2->mvLevelSigma2.data();
+            g.nlevels = (int)std::min(pKF1->mvLevelSigma2.size(), pKF2->mvLevelSigma2.size());
+            for (int c = 0; c < 2; c++)
+                for (int k = 0; k < 8; k++) { g.cam1[c][k] = cam1[c]->getParameter(k); g.cam2[c][k] = cam2[c]->getParameter(k); }
+            for (int a = 0; a < 2; a++)
+                for (int b = 0; b < 2; b++)
+                    for (int r = 0; r < 3; r++) {
+                        for (int c = 0; c < 3; c++) g.R12[2 * a + b][3 * r + c] = R[a][b](r, c);
+                        g.t12[2 * a + b][r] = t[a][b](r);
+                    }
+            g.coarse = bCoarse ? 1 : 0;
+            std::vector<int32_t> m12(n1, -1);
+            const FeatVec f1 = FeatVec::from(pKF1->mFeatVec), f2 = FeatVec::from(pKF2->mFeatVec);
+            orbx_featvec fa = f1.c(), fb = f2.c();
+            const int r = orbx_search_for_triangulation_kb8(m_, pKF1->mDescriptors.data, skip1.data(), n1, &fa, pKF2->mDescriptors.data, skip2.data(), n2, &fb,
+                                                            mbCheckOrientation ? 1 : 0, &g, m12.data());
+            if (r < 0) throw std::runtime_error(std::string("orbx_search_for_triangulation_kb8: ") + orbx_status_string(r));
+            vMatchedPairs.clear();
+            for (int i = 0; i < n1; i++) if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);
+            return r;
+        }
         auto gate = [&](size_t idx1, size_t idx2) -> bool {
             if (bCoarse) return true;
             const cv::KeyPoint &kp1 = key(pKF1, idx1);

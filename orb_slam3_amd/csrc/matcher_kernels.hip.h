@@ -16,6 +16,8 @@
 
 #include "orbx_internal.h"
 
+#include "geometry_kernels.hip.h"   // kb8_epipolar_constrain: the fisheye gate of SearchForTriangulation
+
 namespace orbx {
 
 typedef unsigned long long u64;
@@ -2146,6 +2148,19 @@ struct FeatVecDev { const uint32_t *node_id; const int32_t *node_ptr; const int3
 // The geometric gates of SearchForTriangulation for pinhole key frames (ORBmatcher.cc:1026-1034 epipole distance,
 // CameraModels/Pinhole.cpp:107-129 epipolarConstrain on a caller-supplied F12).  Both are pure functions of the pair, so the
 // reference's lazy evaluation order does not matter: they filter the candidates of the best-distance scan.
+// The fisheye rig's gate of SearchForTriangulation (ORBmatcher.cc:1036-1072): KannalaBrandt8::epipolarConstrain between the camera kp1 was seen by (left:
+// idx1 < NLeft of KF1) and the one of kp2, with the relative pose of that camera pair.  Lives in device memory (indexed by the pair's cameras).
+struct Kb8Gate {
+    int n_left1, n_left2;      // pKF1->NLeft, pKF2->NLeft: features [0, NLeft) are mvKeys (left camera), the rest mvKeysRight
+    const float *sigma2_1;     // pKF1->mvLevelSigma2
+    float cam[4][8];           // KannalaBrandt8::mvParameters of pKF1->mpCamera, pKF1->mpCamera2, pKF2->mpCamera, pKF2->mpCamera2
+    float R12[4][9], t12[4][3];   // [2 * right1 + right2]: Rll tll, Rlr tlr, Rrl trl, Rrr trr (:938-944), row-major
+};
+__device__ __attribute__((noinline)) bool kb8_gate(const Kb8Gate *g, float x1, float y1, float sg1, int right1, float x2, float y2, float sg2, int right2) {
+    const int sel = 2 * right1 + right2;
+    return kb8_epipolar_constrain(g->cam[right1], g->cam[2 + right2], x1, y1, x2, y2, g->R12[sel], g->t12[sel], sg1, sg2);
+}
+
 struct TriGate {
     int enabled;               // 0: no gate at all (table/callback-free bCoarse form without keypoints)
     int coarse;                // bCoarse: skip epipolarConstrain (the epipole-distance test still applies)
@@ -2156,9 +2171,16 @@ struct TriGate {
     const float *sigma2_2;     // pKF2->mvLevelSigma2
     float F[9];                // F12 row-major
     float ex, ey;              // epipole of camera 1 in image 2 (:921)
+    const Kb8Gate *kb8;        // != NULL: fisheye key frames -- k1 / k2 are mvKeys | mvKeysRight, no epipole test (:1026), KannalaBrandt8::epipolarConstrain
 };
 
 __device__ __forceinline__ bool tri_gate(const TriGate &g, int i1, int i2) {
+    if (g.kb8) {
+        if (g.coarse) return true;
+        const int o1 = g.k1[i1].octave, o2k = g.k2[i2].octave;
+        return kb8_gate(g.kb8, g.k1[i1].x, g.k1[i1].y, g.kb8->sigma2_1[o1], i1 >= g.kb8->n_left1 ? 1 : 0, g.k2[i2].x, g.k2[i2].y, g.sigma2_2[o2k],
+                        i2 >= g.kb8->n_left2 ? 1 : 0);
+    }
     const bool st1 = g.ur1 && g.ur1[i1] >= 0.f, st2 = g.ur2 && g.ur2[i2] >= 0.f;
     const float x2 = g.k2[i2].x, y2 = g.k2[i2].y;
     const int oct2 = g.k2[i2].octave;
@@ -2368,9 +2390,11 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
     if (gated && cv) {
         x2 = P.gate.k2[j].x; y2 = P.gate.k2[j].y;
         const int o2 = P.gate.k2[j].octave;
-        sc2 = P.gate.scale2[o2]; sg2 = P.gate.sigma2_2[o2];
+        sc2 = P.gate.scale2 ? P.gate.scale2[o2] : 0.f; sg2 = P.gate.sigma2_2[o2];
         st2 = P.gate.ur2 && P.gate.ur2[j] >= 0.f;
     }
+    const Kb8Gate *kb8 = gated ? P.gate.kb8 : nullptr;   // wave-uniform
+    const int right2 = (kb8 && cv && j >= kb8->n_left2) ? 1 : 0;
     const bool right = mode == 3 && j >= P.nb_left;
     if (P.debug_stop == 2) { if (dc.w[0] == 0x1234567ull && ang_b == 1.5f && cskip && x2 == 3.f) P.match[0] = 7; return; }
     bool taken = false;   // vpMapPointMatches[realIdxF] != NULL (:281) / vbMatched2[idx2] (:826): nothing but this wave's own matches sets them
@@ -2388,6 +2412,9 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
         float x1 = 0.f, y1 = 0.f;
         bool st1 = false;
         if (gated && qv) { x1 = P.gate.k1[i].x; y1 = P.gate.k1[i].y; st1 = P.gate.ur1 && P.gate.ur1[i] >= 0.f; }
+        float sg1 = 0.f;
+        int right1 = 0;
+        if (kb8 && qv) { sg1 = kb8->sigma2_1[P.gate.k1[i].octave]; right1 = i >= kb8->n_left1 ? 1 : 0; }
         int e0 = -1, e1 = -1;   // this lane's QUERY produced these histogram entries (bin << 16 | out index); mode 3 can produce two
         if (P.debug_stop == 3) { if (dqa.w[0] == 0x1234567ull && ang_a == 1.5f && qskip && x1 == 3.f && dc.w[0] == 0x1234567ull && ang_b == 1.5f && cskip) P.match[0] = 7; return; }
         const int nqc = min(64, a1 - q0);
@@ -2408,13 +2435,22 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
                 yq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1), q));
                 stq = __builtin_amdgcn_readlane((int)st1, q) != 0;
             }
+            float sg1q = 0.f;
+            int right1q = 0;
+            if (kb8) {   // wave-uniform
+                sg1q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg1), q));
+                right1q = __builtin_amdgcn_readlane(right1, q);
+            }
             uint32_t k = kNoKey32, kr = kNoKey32;   // kr: right-camera candidates of mode 3 (:302-315: best / second best kept per camera)
             if (cv && !cskip && !(taken && mode != 2)) {
                 const int d = hamming(dq, dc);
                 const uint32_t key = ((uint32_t)d << 6) | ktie;
                 if (mode == 2) {
                     bool ok = d <= ORBX_TH_LOW;   // :1017
-                    if (ok && gated) ok = tri_gate_regs(P.gate, xq, yq, stq, x2, y2, st2, sc2, sg2);
+                    if (ok && gated) {
+                        if (kb8) ok = P.gate.coarse || kb8_gate(kb8, xq, yq, sg1q, right1q, x2, y2, sg2, right2);
+                        else ok = tri_gate_regs(P.gate, xq, yq, stq, x2, y2, st2, sc2, sg2);
+                    }
                     if (ok) k = key;
                 } else if (right) {
                     kr = key;

@@ -1043,7 +1043,8 @@ namespace {
 // k_replay_bow on host pointers: mode 0 SearchByBoW(KF, Frame), 1 SearchByBoW(KF, KF), 2 SearchForTriangulation without a gate
 int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float *angle_a, const uint8_t *skip_a, int na, const orbx_featvec *fa,
                    const uint8_t *desc_b, const float *angle_b, const uint8_t *skip_b, int nb, const orbx_featvec *fb, float nnratio,
-                   int check_orientation, int32_t *match_out, int n_out, const orbx_pinhole_gate *gate = nullptr, int nb_left = 0) {
+                   int check_orientation, int32_t *match_out, int n_out, const orbx_pinhole_gate *gate = nullptr, int nb_left = 0,
+                   const orbx_kb8_gate *kgate = nullptr) {
     if (na > 65535 || nb > 65535) return ORBX_E_TOO_LARGE;
     ORBX_HIP(hipSetDevice(m->device));
     const size_t ia = (size_t)fa->node_ptr[fa->n_nodes], ib = (size_t)fb->node_ptr[fb->n_nodes];
@@ -1052,7 +1053,9 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
                         Arena::pad(4 * (size_t)fa->n_nodes + 4) + 1024 +
                         Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 8192 +
                         (gate ? Arena::pad(sizeof(orbx_keypoint) * (size_t)na) + Arena::pad(sizeof(orbx_keypoint) * (size_t)nb) +
-                                    Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 4 * Arena::pad(4 * 64) : 0);
+                                    Arena::pad(4 * (size_t)na) + Arena::pad(4 * (size_t)nb) + 4 * Arena::pad(4 * 64) : 0) +
+                        (kgate ? Arena::pad(sizeof(orbx_keypoint) * (size_t)na) + Arena::pad(sizeof(orbx_keypoint) * (size_t)nb) + 2 * Arena::pad(4 * 64) +
+                                     Arena::pad(sizeof(Kb8Gate)) : 0);
     int r = m->reserve_all(need);
     if (r != ORBX_OK) return r;
     Arena &A = m->arena;
@@ -1106,6 +1109,24 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
         if (!G.k1 || !G.k2 || !G.scale2 || !G.sigma2_2) return ORBX_E_BAD_ARG;
         for (int i = 0; i < 9; i++) G.F[i] = gate->F12[i];
         G.ex = gate->ep_x; G.ey = gate->ep_y;
+    }
+    if (kgate) {  // fisheye key frames: KannalaBrandt8::epipolarConstrain inside the kernel
+        TriGate &G = P.gate;
+        G.enabled = 1; G.coarse = kgate->coarse ? 1 : 0; G.strict = 1;
+        G.k1 = (const orbx_keypoint *)up(kgate->kps1, sizeof(orbx_keypoint) * (size_t)na);
+        G.k2 = (const orbx_keypoint *)up(kgate->kps2, sizeof(orbx_keypoint) * (size_t)nb);
+        G.sigma2_2 = (const float *)up(kgate->level_sigma2_2, 4 * (size_t)kgate->nlevels);
+        Kb8Gate K;
+        memset(&K, 0, sizeof(K));
+        K.n_left1 = kgate->n_left1; K.n_left2 = kgate->n_left2;
+        K.sigma2_1 = (const float *)up(kgate->level_sigma2_1, 4 * (size_t)kgate->nlevels);
+        memcpy(K.cam[0], kgate->cam1, sizeof(float) * 16);
+        memcpy(K.cam[2], kgate->cam2, sizeof(float) * 16);
+        memcpy(K.R12, kgate->R12, sizeof(K.R12));
+        memcpy(K.t12, kgate->t12, sizeof(K.t12));
+        if (!G.k1 || !G.k2 || !G.sigma2_2 || !K.sigma2_1) return ORBX_E_BAD_ARG;
+        G.kb8 = (const Kb8Gate *)up(&K, sizeof(K));
+        if (!G.kb8) return ORBX_E_BAD_ARG;
     }
     // the two downloads side by side (one DMA), the two zero-filled buffers side by side (one fill)
     P.match = A.take<int32_t>(n_out); P.nmatches = A.take<int32_t>(4);
@@ -1217,6 +1238,25 @@ int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1,
     for (int i = 0; i < n1; i++) a1[i] = gate->kps1_un[i].angle;
     for (int i = 0; i < n2; i++) a2[i] = gate->kps2_un[i].angle;
     return run_bow_replay(m, 2, desc1, a1.data(), skip1, n1, fv1, desc2, a2.data(), skip2, n2, fv2, 0.f, check_orientation, matches12, n1, gate);
+}
+
+// SearchForTriangulation between two key frames of a FISHEYE rig (pKF->mpCamera2 != NULL): the gate of :1036-1072 -- KannalaBrandt8::epipolarConstrain with the
+// camera pair and relative pose the two feature indices select -- evaluated inside k_replay_bow (until round 6 a host callback around a download of every
+// candidate distance)
+int orbx_search_for_triangulation_kb8(orbx_matcher *m, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbx_featvec *fv1, const uint8_t *desc2,
+                                      const uint8_t *skip2, int n2, const orbx_featvec *fv2, int check_orientation, const orbx_kb8_gate *gate,
+                                      int32_t *matches12) {
+    if (!m || !fv1 || !fv2 || (!matches12 && n1 > 0) || !gate || n1 < 0 || n2 < 0) return ORBX_E_BAD_ARG;
+    if (!gate->kps1 || !gate->kps2 || !gate->level_sigma2_1 || !gate->level_sigma2_2 || gate->nlevels <= 0 || gate->nlevels > 64) return ORBX_E_BAD_ARG;
+    if (gate->n_left1 < 0 || gate->n_left1 > n1 || gate->n_left2 < 0 || gate->n_left2 > n2) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return 0;
+    for (int i = 0; i < n1; i++) if (gate->kps1[i].octave < 0 || gate->kps1[i].octave >= gate->nlevels) return ORBX_E_BAD_ARG;
+    for (int i = 0; i < n2; i++) if (gate->kps2[i].octave < 0 || gate->kps2[i].octave >= gate->nlevels) return ORBX_E_BAD_ARG;
+    std::vector<float> a1(n1), a2(n2);  // kp.angle (:1086-1094)
+    for (int i = 0; i < n1; i++) a1[i] = gate->kps1[i].angle;
+    for (int i = 0; i < n2; i++) a2[i] = gate->kps2[i].angle;
+    return run_bow_replay(m, 2, desc1, a1.data(), skip1, n1, fv1, desc2, a2.data(), skip2, n2, fv2, 0.f, check_orientation, matches12, n1, nullptr, 0, gate);
 }
 
 }  // extern "C"

@@ -396,6 +396,23 @@ class ORBmatcher:
                   "orbx_search_for_triangulation_pinhole")
         return n, m12
 
+    def SearchForTriangulationKB8(self, kps1, n_left1, desc1, skip1, fv1: FeatureVector, kps2, n_left2, desc2, skip2, fv2: FeatureVector,
+                                  level_sigma2_1, level_sigma2_2, cam1, cam2, R12, t12, coarse=False):
+        """SearchForTriangulation between key frames of a fisheye rig: KannalaBrandt8::epipolarConstrain (ORBmatcher.cc:1036-1072) on the device.
+        kps: mvKeys | mvKeysRight; cam1 / cam2: [2][8] parameters of (mpCamera, mpCamera2); R12 [4][3][3], t12 [4][3] = ll, lr, rl, rr."""
+        from ._lib import Kb8GateStruct
+        k1, k2 = np.ascontiguousarray(kps1, KP_DTYPE), np.ascontiguousarray(kps2, KP_DTYPE)
+        d1, s1, d2, s2 = _u8(desc1), _u8(skip1), _u8(desc2), _u8(skip2)
+        sg1, sg2 = _f32(level_sigma2_1), _f32(level_sigma2_2)
+        flat = lambda x, n: (C.c_float * n)(*[float(v) for v in np.asarray(x, np.float32).ravel()])
+        g = Kb8GateStruct(k1.ctypes.data, k2.ctypes.data, int(n_left1), int(n_left2), sg1.ctypes.data, sg2.ctypes.data, len(sg1), flat(cam1, 16), flat(cam2, 16),
+                          flat(R12, 36), flat(t12, 12), int(coarse))
+        a, b = fv1.c_struct(), fv2.c_struct()
+        m12 = np.full(len(k1), -1, np.int32)
+        n = check(self._L.orbx_search_for_triangulation_kb8(self._h, ptr(d1), ptr(s1), len(k1), C.byref(a), ptr(d2), ptr(s2), len(k2), C.byref(b),
+                                                            int(self.mbCheckOrientation), C.byref(g), ptr(m12)), "orbx_search_for_triangulation_kb8")
+        return n, m12
+
     # ---- DBoW2 transform (Frame::ComputeBoW, Frame.cc:738-745) ----
     def BowTransform(self, voc: "ORBVocabulary", descriptors, levelsup: int = 4):
         """Returns (word_id[n], node_id[n]) of TemplatedVocabulary::transform for every descriptor."""

@@ -149,3 +149,58 @@ def make_scene_canvas(scene: str, seed: int, size: int = 2048) -> np.ndarray:
         t = make_texture_canvas(seed, size)
         return ((1.0 - a) * q.astype(np.float32) + a * t.astype(np.float32)).astype(np.float32)
     raise ValueError(f"unknown scene {scene!r}")
+
+
+# Examples/Stereo/TUM-VI.yaml Camera1 / Camera2: fx, fy, cx, cy, k0..k3 (KannalaBrandt8::mvParameters)
+TUMVI_L = (190.978477, 190.973307, 254.931706, 256.897442, 0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367)
+TUMVI_R = (190.442369, 190.434438, 252.598164, 254.917230, 0.0034003171, 0.0017669271, -0.0026631290, 0.0003299517)
+
+
+def make_fisheye_keyframes(rng, n_pts: int = 420):
+    """Two key frames of a TUM-VI-like fisheye rig looking at common 3-D points: features = mvKeys | mvKeysRight, descriptors noisy copies of the point's,
+    and the four relative poses of ORBmatcher.cc:934-944 (ll, lr, rl, rr).  Returns (k1, n_left1, d1, id1, k2, n_left2, d2, id2, R12, t12, cams)."""
+    from . import KP_DTYPE
+
+    def rot(a):
+        ax, ay, az = a
+        Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+        Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+        Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+        return Rz @ Ry @ Rx
+
+    def se3(R, t):
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+        return T
+    Trl = se3(rot(rng.uniform(-0.01, 0.01, 3)), [-0.101, 0.002, 0.001])     # right camera from left camera
+    Tw2 = se3(rot(rng.uniform(-0.04, 0.04, 3)), [0.25, 0.03, -0.02])         # KF2's left camera in the world = KF1's left camera frame (T1w = I)
+    Tlr = np.linalg.inv(Trl)
+    pair = [Tw2, Tw2 @ Tlr, Trl @ Tw2, Trl @ Tw2 @ Tlr]                      # Tll, Tlr, Trl, Trr: x_cam1 = T * x_cam2
+    R12 = np.stack([T[:3, :3] for T in pair]).astype(np.float32)
+    t12 = np.stack([T[:3, 3] for T in pair]).astype(np.float32)
+    P = np.stack([rng.uniform(-3, 3, n_pts), rng.uniform(-3, 3, n_pts), rng.uniform(1.0, 8, n_pts), np.ones(n_pts)], axis=1)
+    pdesc = rng.integers(0, 256, (n_pts, 32), dtype=np.uint8)
+
+    def proj(prm, X):
+        th = np.arctan2(np.hypot(X[:, 0], X[:, 1]), X[:, 2]); psi = np.arctan2(X[:, 1], X[:, 0])
+        r = th + prm[4] * th ** 3 + prm[5] * th ** 5 + prm[6] * th ** 7 + prm[7] * th ** 9
+        return np.stack([prm[0] * r * np.cos(psi) + prm[2], prm[1] * r * np.sin(psi) + prm[3]], axis=1)
+
+    def keyframe(Tcw_left):
+        parts, ids = [], []
+        for T, prm in ((Tcw_left, TUMVI_L), (Trl @ Tcw_left, TUMVI_R)):
+            X = (T @ P.T).T[:, :3]
+            uv = proj(prm, X) + rng.choice([0.2, 1.0, 5.0], n_pts)[:, None] * rng.uniform(-1, 1, (n_pts, 2))
+            seen = np.nonzero((rng.random(n_pts) < 0.7) & (uv[:, 0] > 5) & (uv[:, 0] < 507) & (uv[:, 1] > 5) & (uv[:, 1] < 507))[0]
+            k = np.zeros(len(seen), KP_DTYPE)
+            k["x"], k["y"] = uv[seen, 0], uv[seen, 1]
+            k["octave"] = rng.integers(0, 8, len(seen))
+            k["angle"] = rng.uniform(0, 360, len(seen))
+            k["size"], k["class_id"] = 31.0, -1
+            parts.append(k); ids.append(seen)
+        kps = np.concatenate(parts)
+        pid = np.concatenate(ids)
+        flip = rng.random((len(pid), 256)) < 0.04
+        return kps, len(parts[0]), pdesc[pid] ^ np.packbits(flip, axis=1, bitorder="little"), pid
+    k1, nl1, d1, id1 = keyframe(np.eye(4))
+    k2, nl2, d2, id2 = keyframe(np.linalg.inv(Tw2))
+    return k1, nl1, d1, id1, k2, nl2, d2, id2, R12, t12, np.array([TUMVI_L, TUMVI_R], np.float32)

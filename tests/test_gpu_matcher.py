@@ -706,3 +706,49 @@ def test_search_for_triangulation_pinhole_device_gates(oracle, canvas1):
             m.mbCheckOrientation = False
             n, m12 = m.SearchForTriangulationPinhole(kq, dq, z1, fq, kc, dc, zq, fc, sf, sg, F, (1e6, 1e6), None, None, False, strict)
             assert n == on and np.array_equal(m12, om), (trial, strict, m12, om)
+
+
+def _fisheye_keyframes(rng, n_pts=420):
+    from orb_slam3_amd import synth
+    return synth.make_fisheye_keyframes(rng, n_pts)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_search_for_triangulation_fisheye_gate_on_device(oracle, seed):
+    """orbx_search_for_triangulation_kb8: KannalaBrandt8::epipolarConstrain (unproject, parallax, JacobiSVD triangulation, depth, two reprojection tests) for the
+    camera pair each candidate selects, evaluated inside k_replay_bow -- against the oracle's SearchForTriangulation with the oracle's gate as its pair predicate
+    (pinned to the reference's text in tests/test_oracle_geometry.py), with and without the rotation check, and bCoarse."""
+    import orb_slam3_amd as osa
+    rng = np.random.default_rng(700 + seed)
+    k1, nl1, d1, id1, k2, nl2, d2, id2, R12, t12, cams = _fisheye_keyframes(rng)
+    sg = (np.array([1.2 ** i for i in range(8)], np.float32) ** 2).astype(np.float32)
+    nodes = 40 if seed == 1 else 4   # seed 2: more than 64 features per vocabulary node (the kernel's big-node form)
+    fv1, fv2 = osa.FeatureVector.from_node_of_feature(id1 % nodes), osa.FeatureVector.from_node_of_feature(id2 % nodes)
+    s1 = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+    s2 = (rng.random(len(k2)) < 0.2).astype(np.uint8)
+    # the gate for every pair, by camera pair
+    table = np.zeros((len(k1), len(k2)), bool)
+    for r1 in (0, 1):
+        i1 = np.arange(nl1) if r1 == 0 else np.arange(nl1, len(k1))
+        for r2 in (0, 1):
+            i2 = np.arange(nl2) if r2 == 0 else np.arange(nl2, len(k2))
+            a, b = np.repeat(i1, len(i2)), np.tile(i2, len(i1))
+            ok, _ = oracle.kb8_epipolar_constrain(cams[r1], cams[r2], np.stack([k1["x"][a], k1["y"][a]], 1), np.stack([k2["x"][b], k2["y"][b]], 1),
+                                                  R12[2 * r1 + r2], t12[2 * r1 + r2], sg[k1["octave"][a]], sg[k2["octave"][b]])
+            table[np.ix_(i1, i2)] = ok.reshape(len(i1), len(i2)).astype(bool)
+    assert 0.002 < table.mean() < 0.5
+    m = osa.ORBmatcher(0.6, True)
+    total = 0
+    for ori, coarse in ((True, False), (False, False), (True, True)):
+        m.mbCheckOrientation = ori
+        on, om = oracle.search_for_triangulation(d1, k1["angle"], s1, fv1, d2, k2["angle"], s2, fv2, ori, None if coarse else (lambda i, j: table[i, j]))
+        n, m12 = m.SearchForTriangulationKB8(k1, nl1, d1, s1, fv1, k2, nl2, d2, s2, fv2, sg, sg, cams, cams, R12, t12, coarse)
+        cn, cm = oracle.search_for_triangulation_kb8(k1, nl1, d1, s1, fv1, k2, nl2, d2, s2, fv2, sg, sg, cams, cams, R12, t12, coarse, ori)   # the lazy gate in C
+        assert cn == on and np.array_equal(cm, om)
+        assert n == on and np.array_equal(m12, om), (ori, coarse, n, on)
+        total += n
+        if not coarse:
+            hit = m12 >= 0
+            assert hit.sum() > 30 and (id1[hit] == id2[m12[hit]]).mean() > 0.9      # the gate lets the true correspondences through ...
+            assert (m12[hit] >= nl2).sum() > 5 and (np.nonzero(hit)[0] >= nl1).sum() > 5   # ... in all four camera pairs
+    assert total > 150
