@@ -2171,16 +2171,10 @@ struct TriGate {
     const float *sigma2_2;     // pKF2->mvLevelSigma2
     float F[9];                // F12 row-major
     float ex, ey;              // epipole of camera 1 in image 2 (:921)
-    const Kb8Gate *kb8;        // != NULL: fisheye key frames -- k1 / k2 are mvKeys | mvKeysRight, no epipole test (:1026), KannalaBrandt8::epipolarConstrain
+    const Kb8Gate *kb8;        // k_tri_kb8 only (fisheye key frames): k1 / k2 are mvKeys | mvKeysRight, no epipole test (:1026), KannalaBrandt8::epipolarConstrain
 };
 
 __device__ __forceinline__ bool tri_gate(const TriGate &g, int i1, int i2) {
-    if (g.kb8) {
-        if (g.coarse) return true;
-        const int o1 = g.k1[i1].octave, o2k = g.k2[i2].octave;
-        return kb8_gate(g.kb8, g.k1[i1].x, g.k1[i1].y, g.kb8->sigma2_1[o1], i1 >= g.kb8->n_left1 ? 1 : 0, g.k2[i2].x, g.k2[i2].y, g.sigma2_2[o2k],
-                        i2 >= g.kb8->n_left2 ? 1 : 0);
-    }
     const bool st1 = g.ur1 && g.ur1[i1] >= 0.f, st2 = g.ur2 && g.ur2[i2] >= 0.f;
     const float x2 = g.k2[i2].x, y2 = g.k2[i2].y;
     const int oct2 = g.k2[i2].octave;
@@ -2390,11 +2384,9 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
     if (gated && cv) {
         x2 = P.gate.k2[j].x; y2 = P.gate.k2[j].y;
         const int o2 = P.gate.k2[j].octave;
-        sc2 = P.gate.scale2 ? P.gate.scale2[o2] : 0.f; sg2 = P.gate.sigma2_2[o2];
+        sc2 = P.gate.scale2[o2]; sg2 = P.gate.sigma2_2[o2];
         st2 = P.gate.ur2 && P.gate.ur2[j] >= 0.f;
     }
-    const Kb8Gate *kb8 = gated ? P.gate.kb8 : nullptr;   // wave-uniform
-    const int right2 = (kb8 && cv && j >= kb8->n_left2) ? 1 : 0;
     const bool right = mode == 3 && j >= P.nb_left;
     if (P.debug_stop == 2) { if (dc.w[0] == 0x1234567ull && ang_b == 1.5f && cskip && x2 == 3.f) P.match[0] = 7; return; }
     bool taken = false;   // vpMapPointMatches[realIdxF] != NULL (:281) / vbMatched2[idx2] (:826): nothing but this wave's own matches sets them
@@ -2412,9 +2404,6 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
         float x1 = 0.f, y1 = 0.f;
         bool st1 = false;
         if (gated && qv) { x1 = P.gate.k1[i].x; y1 = P.gate.k1[i].y; st1 = P.gate.ur1 && P.gate.ur1[i] >= 0.f; }
-        float sg1 = 0.f;
-        int right1 = 0;
-        if (kb8 && qv) { sg1 = kb8->sigma2_1[P.gate.k1[i].octave]; right1 = i >= kb8->n_left1 ? 1 : 0; }
         int e0 = -1, e1 = -1;   // this lane's QUERY produced these histogram entries (bin << 16 | out index); mode 3 can produce two
         if (P.debug_stop == 3) { if (dqa.w[0] == 0x1234567ull && ang_a == 1.5f && qskip && x1 == 3.f && dc.w[0] == 0x1234567ull && ang_b == 1.5f && cskip) P.match[0] = 7; return; }
         const int nqc = min(64, a1 - q0);
@@ -2435,22 +2424,13 @@ __device__ __forceinline__ void replay_bow_node64(const BowProblem &P, const int
                 yq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1), q));
                 stq = __builtin_amdgcn_readlane((int)st1, q) != 0;
             }
-            float sg1q = 0.f;
-            int right1q = 0;
-            if (kb8) {   // wave-uniform
-                sg1q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg1), q));
-                right1q = __builtin_amdgcn_readlane(right1, q);
-            }
             uint32_t k = kNoKey32, kr = kNoKey32;   // kr: right-camera candidates of mode 3 (:302-315: best / second best kept per camera)
             if (cv && !cskip && !(taken && mode != 2)) {
                 const int d = hamming(dq, dc);
                 const uint32_t key = ((uint32_t)d << 6) | ktie;
                 if (mode == 2) {
                     bool ok = d <= ORBX_TH_LOW;   // :1017
-                    if (ok && gated) {
-                        if (kb8) ok = P.gate.coarse || kb8_gate(kb8, xq, yq, sg1q, right1q, x2, y2, sg2, right2);
-                        else ok = tri_gate_regs(P.gate, xq, yq, stq, x2, y2, st2, sc2, sg2);
-                    }
+                    if (ok && gated) ok = tri_gate_regs(P.gate, xq, yq, stq, x2, y2, st2, sc2, sg2);
                     if (ok) k = key;
                 } else if (right) {
                     kr = key;
@@ -2530,6 +2510,101 @@ __global__ __launch_bounds__(256) void k_replay_bow(BowProblem P) {
     if (P.debug_stop == 1) { if (a0 + a1 + b0 + b1 == -12345) P.match[0] = 7; return; }
     if (b1 - b0 <= 64) replay_bow_node64(P, a0, a1, b0, b1 - b0, lane);
     else replay_bow_big_node(P, ia, ib, lane);
+}
+
+// k_tri_kb8: SearchForTriangulation between key frames of a FISHEYE rig (:1036-1072), a wave per vocabulary node.  Its gate -- KannalaBrandt8::epipolarConstrain: two
+// Newton unprojections, a 4 x 4 JacobiSVD, two projections -- is some 10^4 instructions per pair, and SearchForTriangulation keeps no taken-state (:1011 reads
+// vbMatched2, nothing sets it): the queries of a node are independent and the gate is a pure function of the pair, so the reference's lazy order is not observable.
+// Evaluated inside k_replay_bow's query loop the gate ran once per QUERY on the few lanes whose distance passed (570 us for 1000 x 1000 features, the CPU takes 670).
+// Here the pairs of a node with distance <= TH_LOW are first COLLECTED (register-resident Hamming tiles of 64 queries x 64 candidates, ballot + mbcnt appends to
+// an LDS list), then the gate runs over the list 64 pairs at a time with every lane busy, and a pair that passes lowers its query's key with an LDS atomic
+// (distance << 16 | 0xffff - position: the later of two equal candidates wins, :1017).  grid ceil(fa.n_nodes / 4), block 256; P as for k_replay_bow mode 2.
+constexpr int kTriListCap = 2048;   // pairs per wave between two flushes (8 KB)
+__global__ __launch_bounds__(256) void k_tri_kb8(BowProblem P) {
+    __shared__ uint32_t list_s[4][kTriListCap];
+    __shared__ uint32_t keymin_s[4][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ia = (int)(blockIdx.x * 4) + wv;
+    if (ia >= P.fa.n_nodes) return;
+    const int ib = P.pair_b[ia];
+    if (ib < 0) return;
+    const int a0 = P.fa.node_ptr[ia], a1 = P.fa.node_ptr[ia + 1], b0 = P.fb.node_ptr[ib], b1 = P.fb.node_ptr[ib + 1];
+    uint32_t *list = list_s[wv], *keymin = keymin_s[wv];
+    const Kb8Gate *kb8 = P.gate.kb8;
+    int nmatches = 0;
+    for (int q0 = a0; q0 < a1; q0 += 64) {
+        const bool qv = q0 + lane < a1;
+        const int i = qv ? P.fa.index[q0 + lane] : 0;
+        const bool qskip = !qv || (P.skip_a && P.skip_a[i]);
+        const Desc dqa = load_desc(P.desc_a + (size_t)i * 32);
+        keymin[lane] = kNoKey32;
+        int m = 0;   // wave-uniform: pairs on the list
+        const u64 skipmask = __ballot(qskip);
+        const int nqc = min(64, a1 - q0);
+        auto flush = [&]() {
+            one_wave_sync();
+            for (int p0 = 0; p0 < m; p0 += 64) {
+                const int p = p0 + lane;
+                if (p < m) {
+                    const uint32_t e = list[p];
+                    const int q = (int)((e >> 16) & 63u), c = (int)(e & 0xffffu);
+                    const int i1 = P.fa.index[q0 + q], j2 = P.fb.index[b0 + c];
+                    const float x1 = P.gate.k1[i1].x, y1 = P.gate.k1[i1].y, x2 = P.gate.k2[j2].x, y2 = P.gate.k2[j2].y;
+                    const float sg1 = kb8->sigma2_1[P.gate.k1[i1].octave], sg2 = P.gate.sigma2_2[P.gate.k2[j2].octave];
+                    if (kb8_gate(kb8, x1, y1, sg1, i1 >= kb8->n_left1 ? 1 : 0, x2, y2, sg2, j2 >= kb8->n_left2 ? 1 : 0))
+                        atomicMin(&keymin[q], ((e >> 22) << 16) | (0xffffu - (uint32_t)c));
+                }
+            }
+            m = 0;
+            one_wave_sync();
+        };
+        for (int c0 = b0; c0 < b1; c0 += 64) {
+            const bool cv = c0 + lane < b1;
+            const int j = cv ? P.fb.index[c0 + lane] : 0;
+            const bool cok = cv && !(P.skip_b && P.skip_b[j]);
+            const Desc dc = load_desc(P.desc_b + (size_t)j * 32);
+            const uint32_t cpos = (uint32_t)(c0 - b0 + lane);
+            for (int qq = 0; qq < nqc; qq++) {
+                const int q = __builtin_amdgcn_readfirstlane(qq);
+                if ((skipmask >> q) & 1ull) continue;
+                Desc dq;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    dq.w[k] = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(dqa.w[k] >> 32), q) << 32) | (u64)(uint32_t)__builtin_amdgcn_readlane((int)dqa.w[k], q);
+                const int d = hamming(dq, dc);
+                const bool pass = cok && d <= ORBX_TH_LOW;   // :1017
+                const u64 b = __ballot(pass);
+                if (b == 0ull) continue;
+                if (pass) list[m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = ((uint32_t)d << 22) | ((uint32_t)q << 16) | cpos;
+                m += __popcll(b);
+                if (m > kTriListCap - 64) flush();
+            }
+        }
+        flush();
+        // ---- the chunk's results, a query per lane ----
+        const uint32_t km = keymin[lane];
+        const bool hit = qv && km != kNoKey32;   // a skipped query has no pair on the list
+        int e0 = -1;
+        if (hit) {
+            const int jw = P.fb.index[b0 + (int)(0xffffu - (km & 0xffffu))];
+            P.match[i] = jw;
+            if (P.check_orientation) {
+                const int bin = dev_rot_bin(P.angle_a[i], P.angle_b[jw]);
+                atomicAdd(&P.hist[bin], 1);
+                e0 = (bin << 16) | i;
+            }
+        }
+        const u64 hm = __ballot(hit);
+        nmatches += __popcll(hm);
+        if (P.check_orientation && hm) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&P.counters[0], __popcll(hm));
+            base = __builtin_amdgcn_readlane(base, 0);
+            if (hit) P.entries[base + __popcll(hm & ((1ull << lane) - 1ull))] = e0;
+        }
+        one_wave_sync();   // keymin is rewritten by the next chunk
+    }
+    if (lane == 0 && nmatches) atomicAdd(&P.counters[1], nmatches);
 }
 
 // the rotation-consistency filter over the matches of all nodes (:401-416, :882-897, :1120-1137) and the match count

@@ -1110,9 +1110,10 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
         for (int i = 0; i < 9; i++) G.F[i] = gate->F12[i];
         G.ex = gate->ep_x; G.ey = gate->ep_y;
     }
-    if (kgate) {  // fisheye key frames: KannalaBrandt8::epipolarConstrain inside the kernel
+    const bool kb8_kernel = kgate && !kgate->coarse;   // bCoarse: no gate at all for such key frames (no epipole test either, :1026) = k_replay_bow without a gate
+    if (kb8_kernel) {  // fisheye key frames: KannalaBrandt8::epipolarConstrain on the device (k_tri_kb8)
         TriGate &G = P.gate;
-        G.enabled = 1; G.coarse = kgate->coarse ? 1 : 0; G.strict = 1;
+        G.enabled = 1; G.coarse = 0; G.strict = 1;
         G.k1 = (const orbx_keypoint *)up(kgate->kps1, sizeof(orbx_keypoint) * (size_t)na);
         G.k2 = (const orbx_keypoint *)up(kgate->kps2, sizeof(orbx_keypoint) * (size_t)nb);
         G.sigma2_2 = (const float *)up(kgate->level_sigma2_2, 4 * (size_t)kgate->nlevels);
@@ -1135,7 +1136,10 @@ int run_bow_replay(orbx_matcher *m, int mode, const uint8_t *desc_a, const float
     P.entries = A.take<int32_t>(2 * (size_t)std::max(na, nb));
     ORBX_HIP(m->fill(P.match, 0xff, 4 * (size_t)n_out));     // -1: no match.  Both fills ride in the launch that brings the inputs (orbx_matcher::fill)
     ORBX_HIP(m->fill(P.taken_b, 0, (size_t)((const uint8_t *)(P.hist + ORBX_HISTO_LENGTH + 2) - P.taken_b)));   // taken_b, (padding,) hist + counters
-    if (fa->n_nodes > 0) hipLaunchKernelGGL(k_replay_bow, dim3((fa->n_nodes + 3) / 4), dim3(256), 0, m->exec(), P);   // a wave per vocabulary node
+    if (fa->n_nodes > 0) {   // a wave per vocabulary node
+        if (kb8_kernel) hipLaunchKernelGGL(k_tri_kb8, dim3((fa->n_nodes + 3) / 4), dim3(256), 0, m->exec(), P);
+        else hipLaunchKernelGGL(k_replay_bow, dim3((fa->n_nodes + 3) / 4), dim3(256), 0, m->exec(), P);
+    }
     hipLaunchKernelGGL(k_replay_bow_finish, dim3(1), dim3(64), 0, m->exec(), P);
     int32_t nm = 0;
     D2H(match_out, P.match, 4 * (size_t)n_out);

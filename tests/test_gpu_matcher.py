@@ -713,6 +713,30 @@ def _fisheye_keyframes(rng, n_pts=420):
     return synth.make_fisheye_keyframes(rng, n_pts)
 
 
+def test_search_for_triangulation_fisheye_every_pair_on_the_gate(oracle):
+    """The same with descriptors that are all noisy copies of ONE pattern: every pair of a vocabulary node passes the distance test, so a node's pair list
+    (k_tri_kb8, 2048 entries in LDS) fills and is flushed several times per query chunk, and the gate alone decides -- equal distances resolve to the later
+    candidate (ORBmatcher.cc:1017)."""
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    rng = np.random.default_rng(811)
+    k1, nl1, d1, id1, k2, nl2, d2, id2, R12, t12, cams = synth.make_fisheye_keyframes(rng, 170)
+    proto = _rand_desc(rng, 1)
+    d1 = _noisy_copy(rng, np.repeat(proto, len(k1), 0), 0.03)
+    d2 = _noisy_copy(rng, np.repeat(proto, len(k2), 0), 0.03)
+    sg = (np.array([1.2 ** i for i in range(8)], np.float32) ** 2).astype(np.float32)
+    fv1, fv2 = osa.FeatureVector.from_node_of_feature(id1 % 2), osa.FeatureVector.from_node_of_feature(id2 % 2)   # two nodes of ~110 x ~110 features
+    s1 = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    s2 = (rng.random(len(k2)) < 0.1).astype(np.uint8)
+    m = osa.ORBmatcher(0.6, True)
+    for ori in (True, False):
+        m.mbCheckOrientation = ori
+        on, om = oracle.search_for_triangulation_kb8(k1, nl1, d1, s1, fv1, k2, nl2, d2, s2, fv2, sg, sg, cams, cams, R12, t12, False, ori)
+        n, m12 = m.SearchForTriangulationKB8(k1, nl1, d1, s1, fv1, k2, nl2, d2, s2, fv2, sg, sg, cams, cams, R12, t12, False)
+        assert n == on and np.array_equal(m12, om), (ori, n, on)
+    assert on > 20
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_search_for_triangulation_fisheye_gate_on_device(oracle, seed):
     """orbx_search_for_triangulation_kb8: KannalaBrandt8::epipolarConstrain (unproject, parallax, JacobiSVD triangulation, depth, two reprojection tests) for the
