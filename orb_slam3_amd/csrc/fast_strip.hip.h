@@ -334,16 +334,29 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
         ns += __popcll(b);
     }
     wave_lds_sync();
-    // per-cell counts of this wave's survivors (lane c keeps the running count of cell c)
+    // per-cell counts of this wave's survivors and every survivor's rank inside its cell from ONE pair of wave scans: a survivor adds 1 to the byte field of
+    // its cell (cells 0-3 in one dword, 4-7 in a second; a chunk has 64 lanes, so a field never carries), the inclusive scan minus the lane's own field is its
+    // rank, lane 63's value holds all counts.  (Rounds 3-5: a ballot per cell in the counting loop and again, with a v_readlane and two mbcnt, in the emission:
+    // ~11 vector instructions per cell and survivor chunk, 7 cells.)  Lane c keeps the running count of cell c.
     const int ncell = (int)T.ncell;
+    auto cell_fields = [&](const int cellx, uint32_t &lo, uint32_t &hi) {
+        const uint32_t one = cellx >= 0 ? 1u << ((cellx & 3) * 8) : 0u;
+        lo = cellx < 4 ? one : 0u; hi = cellx >= 4 ? one : 0u;
+    };
+    auto lane_field = [&](const int il, const int ih) -> int {   // lane c: the chunk's count of cell c
+        const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane(il, 63), th = (uint32_t)__builtin_amdgcn_readlane(ih, 63);
+        return (int)(((lane < 4 ? tl : th) >> ((lane & 3) * 8)) & 0xffu);
+    };
     int mycnt = 0;
+    int il0 = 0, ih0 = 0;   // the first chunk's scans, used again by the emission (a wave seldom has more than 64 survivors)
     for (int e0 = 0; e0 < ns; e0 += 64) {
         const int e = e0 + lane;
         const int cellx = e < ns ? (int)(((uint32_t)(pq[e] & 0xff) * T.rcp_wcell) >> 16) : -1;
-        for (int c = 0; c < ncell; c++) {
-            const unsigned long long b = __ballot(cellx == c);
-            if (lane == c) mycnt += __popcll(b);
-        }
+        uint32_t lo, hi;
+        cell_fields(cellx, lo, hi);
+        const int il = wave_incl_scan((int)lo), ih = wave_incl_scan((int)hi);
+        if (e0 == 0) { il0 = il; ih0 = ih; }
+        mycnt += lane_field(il, ih);
     }
     if (lane < kStripMaxCells) cnt[wave * kStripMaxCells + lane] = lane < ncell ? mycnt : 0;
     __syncthreads();
@@ -357,14 +370,14 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
         const int e = e0 + lane;
         const int q = e < ns ? (int)pq[e] : 0;
         const int cellx = e < ns ? (int)(((uint32_t)(q & 0xff) * T.rcp_wcell) >> 16) : -1;
-        int pos = 0;
-        for (int c = 0; c < ncell; c++) {
-            const unsigned long long b = __ballot(cellx == c);
-            const int before = __builtin_amdgcn_readlane(base, c);
-            if (cellx == c) pos = before + __popcll(b & ((1ull << lane) - 1ull));
-            if (lane == c) base += __popcll(b);
-        }
+        uint32_t lo, hi;
+        cell_fields(cellx, lo, hi);
+        int il = il0, ih = ih0;
+        if (e0 != 0) { il = wave_incl_scan((int)lo); ih = wave_incl_scan((int)hi); }   // wave-uniform
+        const uint32_t excl = cellx < 4 ? (uint32_t)il - lo : (uint32_t)ih - hi;
+        const int pos = __shfl(base, cellx & 7) + (int)((excl >> ((cellx & 3) * 8)) & 0xffu);
         if (e < ns) slots[(size_t)cellx * T.cell_cap + pos] = pack_key((q & 0xff) + T.ox, (q >> 8) + T.oy, ps[e]);
+        if (e0 + 64 < ns) base += lane_field(il, ih);
     }
     if (wave == 0 && lane < ncell) {
         int total = 0;
