@@ -175,12 +175,15 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
             const int c = __popc(m4);
             const int incl = wave_incl_scan(c);
             int pos = qn + incl - c;
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            if (qn + tot <= qcap) {   // wave-uniform: a chunk that would run past the queue's end is dropped whole (the strip overflows: `over` below)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if ((m4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k);
-                pos += (int)(m4 >> k & 1u);
+                for (int k = 0; k < 4; k++) {
+                    if (m4 & (1u << k)) pq[pos] = (uint16_t)(e0 + k);
+                    pos += (int)(m4 >> k & 1u);
+                }
             }
-            qn += __builtin_amdgcn_readlane(incl, 63);
+            qn += tot;
 #undef FS_EVEN
 #undef FS_ODD
         }
@@ -277,12 +280,15 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
                 const int incl = wave_incl_scan(cn);
                 int pos = qn2 + incl - cn;
                 const uint32_t e0 = ((uint32_t)y << 8) | (uint32_t)x4;
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                if (qn2 + tot <= qcap) {   // wave-uniform (a chunk past the queue's end is dropped whole: the cell takes the list pass, below)
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if ((m4 & (1u << k)) && pos < qcap) pq[pos] = (uint16_t)(e0 + k);
-                    pos += (int)(m4 >> k & 1u);
+                    for (int k = 0; k < 4; k++) {
+                        if (m4 & (1u << k)) pq[pos] = (uint16_t)(e0 + k);
+                        pos += (int)(m4 >> k & 1u);
+                    }
                 }
-                qn2 += __builtin_amdgcn_readlane(incl, 63);
+                qn2 += tot;
             }
             if (qn2 > qcap) {   // this cell's candidates do not fit behind the wave's corners: the cell alone takes the list pass, its entries are dropped
                 qn2 = qstart;
@@ -325,7 +331,7 @@ __device__ __forceinline__ void fast_strip_body(const StripTile &T, const int f,
             s = ps[e];
             const int x = q & 0xff;
             const uint8_t *p = sco + ((q >> 8) + 1) * P + 1 + x + (int)(((uint32_t)x * T.rcp_wcell) >> 16);
-            keep = (s > p[-1]) & (s > p[1]) & (s > p[-P - 1]) & (s > p[-P]) & (s > p[-P + 1]) & (s > p[P - 1]) & (s > p[P]) & (s > p[P + 1]);
+            keep = s > max3i(max3i(p[-1], p[1], p[-P - 1]), max3i(p[-P], p[-P + 1], p[P - 1]), max((int)p[P], (int)p[P + 1]));   // strictly above all 8 neighbours
         }
         const unsigned long long b = __ballot(keep != 0);
         __builtin_amdgcn_wave_barrier();

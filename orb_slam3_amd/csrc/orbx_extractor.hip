@@ -593,9 +593,11 @@ static int configure(orbx_extractor *ex, int width, int height, int batch) {
             }
         }
         if (fast_strip && !strips.empty()) {
+            // a failure here must not leave the new geometry committed beside the old strip tables: width / height = 0 sends the next call through prepare again
             int rr = ex->d_strips.ensure(sizeof(StripTile) * strips.size());
-            if (rr != ORBX_OK) return rr;
-            ORBX_HIP(hipMemcpy(ex->d_strips.p, strips.data(), sizeof(StripTile) * strips.size(), hipMemcpyHostToDevice));
+            if (rr != ORBX_OK) { ex->width = 0; ex->height = 0; return rr; }
+            const hipError_t he = hipMemcpy(ex->d_strips.p, strips.data(), sizeof(StripTile) * strips.size(), hipMemcpyHostToDevice);
+            if (he != hipSuccess) { ex->width = 0; ex->height = 0; ORBX_HIP(he); }
         }
     }
     ex->n_strips = (int)strips.size();
