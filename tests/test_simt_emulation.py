@@ -205,6 +205,23 @@ def test_emulated_matcher_call_moves_its_data_in_one_dma_each_way(emul_lib, env)
     _child(HOST_CALLS, env)
 
 
+TRI_KB8 = """
+import test_gpu_matcher as tm
+tm.test_search_for_triangulation_fisheye_every_pair_on_the_gate(ob)
+tm.test_search_for_triangulation_fisheye_gate_on_device(ob, 2)
+print('emulation ok')
+"""
+
+
+@pytest.mark.parametrize("env", [{"SIMT_BLOCK_ORDER": "reverse", "SIMT_LDS_RANDOM": "5", "SIMT_MALLOC_FILL": "r2", "SIMT_LANE_ORDER": "reverse"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_emulated_fisheye_triangulation_gate(emul_lib, env):
+    """k_tri_kb8 (SearchForTriangulation between fisheye key frames, KannalaBrandt8::epipolarConstrain over an LDS pair list): nodes of more than 64 features,
+    a pair list that fills and is flushed several times per query chunk, equal distances -- == the oracle with its lazily evaluated gate, with garbage in LDS
+    and in every allocation, workgroups and lanes in reverse order (the LDS atomic min per query must not depend on it)."""
+    _child(TRI_KB8, env)
+
+
 SWITCHES = [{"ORBX_OCTREE": "seq"}, {"ORBX_FAST_QCAP": "48"}]
 
 
