@@ -41,7 +41,7 @@ public:
     unsigned int GetType() { return mnType; }
     virtual Eigen::Matrix3f toK_() { return Eigen::Matrix3f(); }
     /* GeometricCamera.h:85-88: parameter access.  The table-driven stand-in has none (size() == 0): the adapter then keeps the host callback, which is what
-     * the shim's fisheye cases test; a real KannalaBrandt8 has 8 and goes to the device gate (tests/test_gpu_matcher.py drives that through the C ABI) */
+     * the shim's table-driven fisheye cases test; class KannalaBrandt8 below has 8 and goes to the device gate (matref_search_for_triangulation_kb8_cams) */
     virtual size_t size() { return 0; }
     virtual float getParameter(const int) { return 0.f; }
     /* the verdicts of the epipolar test are test data: ok[idx1 * n2 + idx2], keyed by keypoint identity (class_id) */
@@ -78,6 +78,20 @@ public:
         K(2, 0) = 0.f; K(2, 1) = 0.f; K(2, 2) = 1.f;
         return K;
     }
+    bool epipolarConstrain(GeometricCamera *pCamera2, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const Eigen::Matrix3f &R12,
+                           const Eigen::Vector3f &t12, const float sigmaLevel, const float unc) override;
+};
+
+/* shell for CameraModels/KannalaBrandt8 (the reference's CAM_FISHEYE model: 8 parameters, include/CameraModels/KannalaBrandt8.h).  In libmatcher_ref.so
+ * epipolarConstrain is the oracle's KannalaBrandt8::epipolarConstrain (orbo_kb8_triangulate_matches > 0.0001, pinned against the reference's own text in
+ * tests/test_oracle_geometry.py): the reference's SearchForTriangulation picks the camera objects and the relative pose per pair (ORBmatcher.cc:1036-1069) and calls
+ * it.  In libmatcher_adapter.so it aborts: the adapter must take such key frames to the device gate (orbx_search_for_triangulation_kb8) and never call it. */
+class KannalaBrandt8 : public GeometricCamera {
+public:
+    std::vector<float> mvParameters;
+    explicit KannalaBrandt8(const float *p8) : mvParameters(p8, p8 + 8) { mnType = CAM_FISHEYE; }
+    size_t size() override { return mvParameters.size(); }
+    float getParameter(const int i) override { return mvParameters[i]; }
     bool epipolarConstrain(GeometricCamera *pCamera2, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const Eigen::Matrix3f &R12,
                            const Eigen::Vector3f &t12, const float sigmaLevel, const float unc) override;
 };

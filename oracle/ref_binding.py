@@ -567,6 +567,25 @@ def ref_search_for_triangulation_pinhole_cams(k1, d1, s1, ur1, fv1, k2, d2, s2, 
     return n, m12, F.reshape(3, 3)
 
 
+def ref_search_for_triangulation_kb8_cams(k1, n_left1, d1, s1, fv1, k2, n_left2, d2, s2, fv2, sigma2, cam_l, cam_r, pose1, pose2, trl, check_orientation, coarse=False):
+    """M7 between key frames of a KannalaBrandt8 stereo rig with real poses (Tcw of the left cameras, Trl; each (R 3x3, t 3)): the reference's SearchForTriangulation
+    forms the four relative poses, picks cameras and pose per pair and calls the camera's epipolarConstrain (ORBX_MATCHER_BACKEND=adapter: the adapter's KannalaBrandt8
+    route, gate on the device).  Returns (nmatches, matches12, R12 [4][3][3], t12 [4][3] -- the relative poses that build's stand-in Sophus computed)."""
+    k1, k2 = np.ascontiguousarray(k1, KP_DTYPE), np.ascontiguousarray(k2, KP_DTYPE)
+    d1, d2, s1, s2 = _u8(d1), _u8(d2), _u8(s1), _u8(s2)
+    sg, cl, cr = _f32(sigma2), _f32(cam_l), _f32(cam_r)
+    a, b = _fv(fv1), _fv(fv2)
+    flat = lambda T: _f32(np.concatenate([np.asarray(T[0], np.float32).ravel(), np.asarray(T[1], np.float32).ravel()]))
+    p1, p2, tr = flat(pose1), flat(pose2), flat(trl)
+    m12 = np.full(len(k1), -1, np.int32)
+    R, t = np.zeros(36, np.float32), np.zeros(12, np.float32)
+    L = _ml()
+    L.matref_search_for_triangulation_kb8_cams.restype = C.c_int
+    n = L.matref_search_for_triangulation_kb8_cams(_p(k1), int(n_left1), _p(d1), _p(s1), len(k1), C.byref(a), _p(k2), int(n_left2), _p(d2), _p(s2), len(k2), C.byref(b),
+                                                   _p(sg), len(sg), _p(cl), _p(cr), _p(p1), _p(p2), _p(tr), int(check_orientation), int(coarse), _p(m12), _p(R), _p(t))
+    return n, m12, R.reshape(4, 3, 3), t.reshape(4, 3)
+
+
 def ref_search_by_projection_mappoints_fisheye(kps_left, kps_right, desc, bounds, scale_factors, l2r, r2l, mp, th, nnratio, occupied=None):
     kl, kr = np.ascontiguousarray(kps_left, KP_DTYPE), np.ascontiguousarray(kps_right, KP_DTYPE)
     desc, b, sf = _u8(desc), _f32(bounds), _f32(scale_factors)

@@ -18,6 +18,22 @@ using namespace ORB_SLAM3;
 namespace ORB_SLAM3 {
 #include "ref_matcher_excerpt.inc"
 #ifdef MATREF_ADAPTER_BUILD
+bool KannalaBrandt8::epipolarConstrain(GeometricCamera *, const cv::KeyPoint &, const cv::KeyPoint &, const Eigen::Matrix3f &, const Eigen::Vector3f &, const float,
+                                       const float) {
+    fprintf(stderr, "libmatcher_adapter: KannalaBrandt8::epipolarConstrain called on the host -- the adapter must route KannalaBrandt8 rigs to the device gate\n");
+    abort();
+}
+#else
+bool KannalaBrandt8::epipolarConstrain(GeometricCamera *pCamera2, const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const Eigen::Matrix3f &R12,
+                                       const Eigen::Vector3f &t12, const float sigmaLevel, const float unc) {
+    KannalaBrandt8 *o = dynamic_cast<KannalaBrandt8 *>(pCamera2);
+    if (!o) { fprintf(stderr, "KannalaBrandt8 shell: the other camera is not a KannalaBrandt8\n"); abort(); }
+    float R[9], t[3];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[3 * i + j] = R12(i, j); t[i] = t12(i); }
+    return orbo_kb8_triangulate_matches(mvParameters.data(), o->mvParameters.data(), kp1.pt.x, kp1.pt.y, kp2.pt.x, kp2.pt.y, R, t, sigmaLevel, unc) > 0.0001f;
+}
+#endif
+#ifdef MATREF_ADAPTER_BUILD
 bool Pinhole::epipolarConstrain(GeometricCamera *, const cv::KeyPoint &, const cv::KeyPoint &, const Eigen::Matrix3f &, const Eigen::Vector3f &, const float,
                                 const float) {
     fprintf(stderr, "libmatcher_adapter: Pinhole::epipolarConstrain called on the host -- the adapter must route pinhole key frames to the device gates\n");
@@ -760,6 +776,67 @@ int matref_search_for_triangulation_fisheye(const uint8_t *desc1, const float *a
     std::vector<std::pair<size_t, size_t>> pairs;
     ORBmatcher m(0.6f, check_orientation != 0);
     int r = m.SearchForTriangulation(&K1, &K2, pairs, false, coarse != 0);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (auto &p : pairs) matches12[p.first] = (int)p.second;
+    return r;
+}
+
+/* M7 between two key frames of a KannalaBrandt8 stereo rig with real poses (LocalMapping::CreateNewMapPoints' shape for TUM-VI): features [0, n_left) = mvKeys,
+ * the rest mvKeysRight; cam_l / cam_r = the rig's two parameter sets (both key frames), pose1 / pose2 = Tcw of the LEFT cameras, trl = Trl (9 floats of R
+ * row-major + 3 of t each).  In libmatcher_ref.so the reference's own SearchForTriangulation forms Tll .. Trr (:934-944), picks cameras and pose per pair
+ * (:1036-1069) and calls the shell's epipolarConstrain (= the oracle's, pinned to the reference's KannalaBrandt8 text elsewhere); in libmatcher_adapter.so the
+ * same call must take the adapter's KannalaBrandt8 route (the shell aborts there).  R12_out [36] / t12_out [12]: the four relative poses ll, lr, rl, rr as the
+ * stand-in Sophus of this build computes them (inputs of the oracle's form of the search). */
+int matref_search_for_triangulation_kb8_cams(const orbo_keypoint *kps1, int n_left1, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbo_featvec *fv1,
+                                             const orbo_keypoint *kps2, int n_left2, const uint8_t *desc2, const uint8_t *skip2, int n2, const orbo_featvec *fv2,
+                                             const float *sigma2, int nlevels, const float *cam_l, const float *cam_r, const float *pose1, const float *pose2,
+                                             const float *trl, int check_orientation, int coarse, int32_t *matches12, float *R12_out, float *t12_out) {
+    KannalaBrandt8 cl1(cam_l), cr1(cam_r), cl2(cam_l), cr2(cam_r);
+    KeyFrame KF1, KF2;
+    KeyFrame *K[2] = {&KF1, &KF2};
+    const orbo_keypoint *P[2] = {kps1, kps2};
+    const uint8_t *D[2] = {desc1, desc2};
+    const uint8_t *S[2] = {skip1, skip2};
+    const float *T[2] = {pose1, pose2};
+    const int N[2] = {n1, n2}, NL[2] = {n_left1, n_left2};
+    GeometricCamera *cams[2][2] = {{&cl1, &cr1}, {&cl2, &cr2}};
+    std::vector<std::unique_ptr<MapPoint>> pool;
+    for (int s = 0; s < 2; s++) {
+        KeyFrame &k = *K[s];
+        k.N = N[s]; k.Nleft = NL[s]; k.NLeft = NL[s];
+        k.mpCamera = cams[s][0]; k.mpCamera2 = cams[s][1];
+        k.mvKeys.resize(NL[s]); k.mvKeysRight.resize(N[s] - NL[s]);
+        k.mDescriptors = cv::Mat(N[s] > 0 ? N[s] : 1, 32, CV_8UC1);
+        std::memcpy(k.mDescriptors.data, D[s], (size_t)N[s] * 32);
+        k.mvpMapPoints.assign(N[s], nullptr);
+        k.mvuRight.assign(N[s], -1.f);
+        k.mvScaleFactors.assign(nlevels, 1.f);
+        k.mvLevelSigma2.assign(sigma2, sigma2 + nlevels);
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) { k.Tcw.R(i, j) = T[s][3 * i + j]; k.Trl.R(i, j) = trl[3 * i + j]; }
+            k.Tcw.t(i) = T[s][9 + i]; k.Trl.t(i) = trl[9 + i];
+        }
+        for (int i = 0; i < N[s]; i++) {
+            cv::KeyPoint &kp = i < NL[s] ? k.mvKeys[i] : k.mvKeysRight[i - NL[s]];
+            kp = cv::KeyPoint(P[s][i].x, P[s][i].y, P[s][i].size, P[s][i].angle, P[s][i].response, P[s][i].octave, i);
+            if (S[s][i]) k.mvpMapPoints[i] = marker(pool);
+        }
+        k.mvKeysUn = k.mvKeys;
+    }
+    featvec(KF1.mFeatVec, fv1);
+    featvec(KF2.mFeatVec, fv2);
+    if (R12_out && t12_out) {   /* ORBmatcher.cc:925-944 on this build's stand-in Sophus */
+        const Sophus::SE3f T1w = KF1.GetPose(), Tw2 = KF2.GetPoseInverse(), Tr1w = KF1.GetRightPose(), Twr2 = KF2.GetRightPoseInverse();
+        const Sophus::SE3f Tp[4] = {T1w * Tw2, T1w * Twr2, Tr1w * Tw2, Tr1w * Twr2};
+        for (int q = 0; q < 4; q++) {
+            const Eigen::Matrix3f R = Tp[q].rotationMatrix();
+            const Eigen::Vector3f t = Tp[q].translation();
+            for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R12_out[9 * q + 3 * i + j] = R(i, j); t12_out[3 * q + i] = t(i); }
+        }
+    }
+    std::vector<std::pair<size_t, size_t>> pairs;
+    ORBmatcher m(0.6f, check_orientation != 0);
+    int r = m.SearchForTriangulation(&KF1, &KF2, pairs, false, coarse != 0);
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     for (auto &p : pairs) matches12[p.first] = (int)p.second;
     return r;

@@ -156,7 +156,7 @@ TUMVI_L = (190.978477, 190.973307, 254.931706, 256.897442, 0.0034823894, 0.00071
 TUMVI_R = (190.442369, 190.434438, 252.598164, 254.917230, 0.0034003171, 0.0017669271, -0.0026631290, 0.0003299517)
 
 
-def make_fisheye_keyframes(rng, n_pts: int = 420):
+def make_fisheye_keyframes(rng, n_pts: int = 420, with_poses: bool = False):
     """Two key frames of a TUM-VI-like fisheye rig looking at common 3-D points: features = mvKeys | mvKeysRight, descriptors noisy copies of the point's,
     and the four relative poses of ORBmatcher.cc:934-944 (ll, lr, rl, rr).  Returns (k1, n_left1, d1, id1, k2, n_left2, d2, id2, R12, t12, cams)."""
     from . import KP_DTYPE
@@ -203,4 +203,9 @@ def make_fisheye_keyframes(rng, n_pts: int = 420):
         return kps, len(parts[0]), pdesc[pid] ^ np.packbits(flip, axis=1, bitorder="little"), pid
     k1, nl1, d1, id1 = keyframe(np.eye(4))
     k2, nl2, d2, id2 = keyframe(np.linalg.inv(Tw2))
-    return k1, nl1, d1, id1, k2, nl2, d2, id2, R12, t12, np.array([TUMVI_L, TUMVI_R], np.float32)
+    out = (k1, nl1, d1, id1, k2, nl2, d2, id2, R12, t12, np.array([TUMVI_L, TUMVI_R], np.float32))
+    if with_poses:   # Tcw of the two left cameras and Trl, each (R, t) in float32: what a KeyFrame holds (GetPose, GetRelativePoseTrl)
+        T2w = np.linalg.inv(Tw2)
+        f = lambda T: (T[:3, :3].astype(np.float32), T[:3, 3].astype(np.float32))
+        out += (dict(pose1=f(np.eye(4)), pose2=f(T2w), trl=f(Trl)),)
+    return out

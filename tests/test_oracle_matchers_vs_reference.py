@@ -490,6 +490,41 @@ def test_search_for_triangulation_between_pinhole_keyframes(frames, case):
     assert on > (5 if name == "forward_epipole_in_image" else 40), on
 
 
+@pytest.mark.parametrize("case", [("tumvi_rig", 40, True, False), ("tumvi_rig_big_nodes", 3, False, False), ("tumvi_rig_coarse", 40, True, True)], ids=lambda c: c[0])
+def test_search_for_triangulation_between_kannala_brandt_rigs(case):
+    """M7 between two key frames of a KannalaBrandt8 stereo rig (TUM-VI's), the way LocalMapping::CreateNewMapPoints calls it: key frames with mvKeys | mvKeysRight,
+    two KannalaBrandt8 camera objects each, Tcw and Trl -- nothing else.  Reference side: ORBmatcher.cc:907-1146 whole -- the four relative poses of :934-944 on
+    the stand-in Sophus, camera objects and pose picked per pair (:1036-1069), the camera's epipolarConstrain (the shell forwards to the oracle's
+    KannalaBrandt8::epipolarConstrain, itself pinned to the reference's text in test_oracle_geometry.py).  The oracle's form of the search gets the four poses that
+    run used and must return the same pairs.  With ORBX_MATCHER_BACKEND=adapter the same call goes through the drop-in adapter, which must take its KannalaBrandt8
+    route (the shell's host epipolarConstrain aborts in that build): poses from the adapter's Sophus, gate inside k_tri_kb8."""
+    from orb_slam3_amd import synth
+    name, nodes, ori, coarse = case
+    rng = np.random.default_rng(sum(map(ord, name)))
+    k1, nl1, d1, id1, k2, nl2, d2, id2, _, _, cams, poses = synth.make_fisheye_keyframes(rng, 300, with_poses=True)
+    fv1, fv2 = FeatureVector.from_node_of_feature(id1 % nodes), FeatureVector.from_node_of_feature(id2 % nodes)
+    s1 = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+    s2 = (rng.random(len(k2)) < 0.2).astype(np.uint8)
+    sg = (np.array([1.2 ** i for i in range(8)], np.float32) ** 2).astype(np.float32)
+    live = {}
+
+    def run():
+        if "r" not in live:
+            live["r"] = rb.ref_search_for_triangulation_kb8_cams(k1, nl1, d1, s1, fv1, k2, nl2, d2, s2, fv2, sg, cams[0], cams[1], poses["pose1"], poses["pose2"],
+                                                                 poses["trl"], ori, coarse)
+        return live["r"]
+    R12 = _P.value(f"m7kb8/{name}/R12", lambda: run()[2]).reshape(4, 3, 3)
+    t12 = _P.value(f"m7kb8/{name}/t12", lambda: run()[3]).reshape(4, 3)
+    on, om = ob.search_for_triangulation_kb8(k1, nl1, d1, s1, fv1, k2, nl2, d2, s2, fv2, sg, sg, cams, cams, R12, t12, coarse, ori)
+    _pin(f"m7kb8/{name}", (on, om), lambda: run()[:2])
+    if rb.matcher_available() and f"m7kb8/{name}/R12" in _P.gold:   # both builds (reference, adapter) must have formed the same relative poses
+        assert np.array_equal(_P.gold[f"m7kb8/{name}/R12"].view(np.float32), run()[2].ravel()) and np.array_equal(_P.gold[f"m7kb8/{name}/t12"].view(np.float32), run()[3].ravel())
+    hit = om >= 0
+    assert on > 60 and (om[hit] >= nl2).sum() > 5 and (np.nonzero(hit)[0] >= nl1).sum() > 5, on   # matches in all camera pairings
+    if not coarse:
+        assert (id1[hit] == id2[om[hit]]).mean() > 0.9
+
+
 def _fuse_queries(rng, k0, d0, sf, th):
     n = len(k0)
     u = (k0["x"] - 2.0 + rng.normal(0, 1.5, n)).astype(np.float32)
