@@ -1245,8 +1245,8 @@ int orbx_search_for_triangulation_pinhole(orbx_matcher *m, const uint8_t *desc1,
 }
 
 // SearchForTriangulation between two key frames of a FISHEYE rig (pKF->mpCamera2 != NULL): the gate of :1036-1072 -- KannalaBrandt8::epipolarConstrain with the
-// camera pair and relative pose the two feature indices select -- evaluated inside k_replay_bow (until round 6 a host callback around a download of every
-// candidate distance)
+// camera pair and relative pose the two feature indices select -- evaluated by k_tri_kb8 over the node's list of pairs within TH_LOW (until round 6 a host
+// callback around a download of every candidate distance); bCoarse: no gate at all, k_replay_bow mode 2
 int orbx_search_for_triangulation_kb8(orbx_matcher *m, const uint8_t *desc1, const uint8_t *skip1, int n1, const orbx_featvec *fv1, const uint8_t *desc2,
                                       const uint8_t *skip2, int n2, const orbx_featvec *fv2, int check_orientation, const orbx_kb8_gate *gate,
                                       int32_t *matches12) {

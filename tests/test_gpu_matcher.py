@@ -740,7 +740,7 @@ def test_search_for_triangulation_fisheye_every_pair_on_the_gate(oracle):
 @pytest.mark.parametrize("seed", [1, 2])
 def test_search_for_triangulation_fisheye_gate_on_device(oracle, seed):
     """orbx_search_for_triangulation_kb8: KannalaBrandt8::epipolarConstrain (unproject, parallax, JacobiSVD triangulation, depth, two reprojection tests) for the
-    camera pair each candidate selects, evaluated inside k_replay_bow -- against the oracle's SearchForTriangulation with the oracle's gate as its pair predicate
+    camera pair each candidate selects, evaluated by k_tri_kb8 -- against the oracle's SearchForTriangulation with the oracle's gate as its pair predicate
     (pinned to the reference's text in tests/test_oracle_geometry.py), with and without the rotation check, and bCoarse."""
     import orb_slam3_amd as osa
     rng = np.random.default_rng(700 + seed)
