@@ -392,6 +392,12 @@ int orbx_search_for_triangulation_kb8(orbx_matcher *m, const uint8_t *desc1, con
                                       const uint8_t *skip2, int n2, const orbx_featvec *fv2, int check_orientation, const orbx_kb8_gate *gate,
                                       int32_t *matches12);
 
+/* Test hook: KannalaBrandt8::epipolarConstrain (src/CameraModels/KannalaBrandt8.cpp:216-221) of n independent keypoint pairs evaluated on the device, one verdict
+ * per pair -- the gate of orbx_search_for_triangulation_kb8 on its own.  cam1 / cam2: [2][8] parameters of (mpCamera, mpCamera2); R12 [4][9] / t12 [4][3] as in
+ * orbx_kb8_gate; sel[i] = 2 * right1 + right2 picks the cameras and the pose of pair i; sigma1 / sigma2: the two level variances per pair. */
+int orbx_debug_kb8_epipolar(orbx_matcher *m, const float *cam1_2x8, const float *cam2_2x8, const float *R12_4x9, const float *t12_4x3, int n, const float *xy1,
+                            const float *xy2, const float *sigma1, const float *sigma2, const uint8_t *sel, uint8_t *ok);
+
 /* ---- fisheye-stereo forms (F.Nleft != -1: KannalaBrandt8 stereo rigs, both cameras' features in one Frame) ----
  * Feature indices follow the reference: [0, n_left) = left camera (F.mvKeys), [n_left, n_left + n_right) = right camera
  * (F.mvKeysRight); `left` describes the left camera (keypoints_un = mvKeys, n = n_left, image bounds, scale factors) and its

@@ -110,7 +110,7 @@ SYMBOLS = [
     "orbx_search_by_bow_frame_fisheye", "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_is_in_frustum", "orbx_is_in_frustum_checks", "orbx_frustum_batch_device",
     "orbx_set_camera", "orbx_batch_download_keypoints_un",
     "orbx_search_for_initialization", "orbx_search_by_bow_frame", "orbx_search_by_bow_keyframes",
-    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_search_for_triangulation_kb8", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_stereo_batch_download_async", "orbx_stereo_download_wait", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
+    "orbx_search_for_triangulation", "orbx_search_for_triangulation_pinhole", "orbx_search_for_triangulation_kb8", "orbx_debug_kb8_epipolar", "orbx_stereo_batch_device", "orbx_stereo_batch_download", "orbx_stereo_batch_download_all", "orbx_stereo_batch_download_async", "orbx_stereo_download_wait", "orbx_search_mappoints_batch_device", "orbx_vocabulary_create",
     "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_distinctive_descriptors", "orbx_fuse_search",
 ]
 
@@ -203,6 +203,7 @@ def lib() -> C.CDLL:
     L.orbx_search_for_triangulation.argtypes = [vp, vp, vp, vp, i32, fvp, vp, vp, vp, i32, fvp, i32, PAIR_PREDICATE, vp, vp]
     L.orbx_search_for_triangulation_pinhole.argtypes = [vp, vp, vp, i32, fvp, vp, vp, i32, fvp, i32, C.POINTER(PinholeGate), vp]
     L.orbx_search_for_triangulation_kb8.argtypes = [vp, vp, vp, i32, fvp, vp, vp, i32, fvp, i32, C.POINTER(Kb8GateStruct), vp]
+    L.orbx_debug_kb8_epipolar.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -2512,6 +2512,16 @@ __global__ __launch_bounds__(256) void k_replay_bow(BowProblem P) {
     else replay_bow_big_node(P, ia, ib, lane);
 }
 
+// debug kernel (orbx_debug_kb8_epipolar): KannalaBrandt8::epipolarConstrain for n independent keypoint pairs, a lane per pair -- the device function k_tri_kb8 calls,
+// on its own, so that a test can compare EVERY verdict with the oracle on the hardware (through the search only the winning candidate of a query shows)
+__global__ __launch_bounds__(256) void k_debug_kb8_gate(const Kb8Gate *__restrict__ g, int n, const float *__restrict__ xy1, const float *__restrict__ xy2,
+                                                        const float *__restrict__ sigma1, const float *__restrict__ sigma2, const uint8_t *__restrict__ sel,
+                                                        uint8_t *__restrict__ ok) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n) return;
+    ok[i] = kb8_gate(g, xy1[2 * i], xy1[2 * i + 1], sigma1[i], sel[i] >> 1, xy2[2 * i], xy2[2 * i + 1], sigma2[i], sel[i] & 1) ? 1 : 0;
+}
+
 // k_tri_kb8: SearchForTriangulation between key frames of a FISHEYE rig (:1036-1072), a wave per vocabulary node.  Its gate -- KannalaBrandt8::epipolarConstrain: two
 // Newton unprojections, a 4 x 4 JacobiSVD, two projections -- is some 10^4 instructions per pair, and SearchForTriangulation keeps no taken-state (:1011 reads
 // vbMatched2, nothing sets it): the queries of a node are independent and the gate is a pure function of the pair, so the reference's lazy order is not observable.

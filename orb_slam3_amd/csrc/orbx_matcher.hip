@@ -1263,6 +1263,38 @@ int orbx_search_for_triangulation_kb8(orbx_matcher *m, const uint8_t *desc1, con
     return run_bow_replay(m, 2, desc1, a1.data(), skip1, n1, fv1, desc2, a2.data(), skip2, n2, fv2, 0.f, check_orientation, matches12, n1, nullptr, 0, gate);
 }
 
+// test hook: KannalaBrandt8::epipolarConstrain of n independent pairs on the device (k_debug_kb8_gate); sel[i] = 2 * right1 + right2 picks cam1[right1],
+// cam2[right2] and R12 / t12 [sel] as the search does per candidate
+int orbx_debug_kb8_epipolar(orbx_matcher *m, const float *cam1_2x8, const float *cam2_2x8, const float *R12_4x9, const float *t12_4x3, int n, const float *xy1,
+                            const float *xy2, const float *sigma1, const float *sigma2, const uint8_t *sel, uint8_t *ok) {
+    if (!m || !cam1_2x8 || !cam2_2x8 || !R12_4x9 || !t12_4x3 || n < 0 || (n > 0 && (!xy1 || !xy2 || !sigma1 || !sigma2 || !sel || !ok))) return ORBX_E_BAD_ARG;
+    if (n == 0) return ORBX_OK;
+    for (int i = 0; i < n; i++) if (sel[i] > 3) return ORBX_E_BAD_ARG;
+    ORBX_HIP(hipSetDevice(m->device));
+    const size_t N = (size_t)n;
+    int r = m->reserve_all(2 * Arena::pad(8 * N) + 2 * Arena::pad(4 * N) + 2 * Arena::pad(N) + Arena::pad(sizeof(Kb8Gate)) + 4096);
+    if (r != ORBX_OK) return r;
+    Arena &A = m->arena;
+    m->begin();
+    float *d1 = A.take<float>(2 * N), *d2 = A.take<float>(2 * N), *s1 = A.take<float>(N), *s2 = A.take<float>(N);
+    uint8_t *dsel = A.take<uint8_t>(N), *dok = A.take<uint8_t>(N);
+    Kb8Gate *dg = A.take<Kb8Gate>(1);
+    Kb8Gate K;
+    memset(&K, 0, sizeof(K));
+    memcpy(K.cam[0], cam1_2x8, sizeof(float) * 16);
+    memcpy(K.cam[2], cam2_2x8, sizeof(float) * 16);
+    memcpy(K.R12, R12_4x9, sizeof(K.R12));
+    memcpy(K.t12, t12_4x3, sizeof(K.t12));
+    H2D(dg, &K, sizeof(K));
+    H2D(d1, xy1, 8 * N); H2D(d2, xy2, 8 * N); H2D(s1, sigma1, 4 * N); H2D(s2, sigma2, 4 * N); H2D(dsel, sel, N);
+    hipLaunchKernelGGL(k_debug_kb8_gate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->exec(), (const Kb8Gate *)dg, n, (const float *)d1, (const float *)d2,
+                       (const float *)s1, (const float *)s2, (const uint8_t *)dsel, dok);
+    ORBX_HIP(hipGetLastError());
+    D2H(ok, dok, N);
+    SYNC_AND_DELIVER();
+    return ORBX_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------

@@ -413,6 +413,17 @@ class ORBmatcher:
                                                             int(self.mbCheckOrientation), C.byref(g), ptr(m12)), "orbx_search_for_triangulation_kb8")
         return n, m12
 
+    def DebugKb8Epipolar(self, cam1, cam2, R12, t12, xy1, xy2, sigma1, sigma2, sel):
+        """Test hook: KannalaBrandt8::epipolarConstrain of n independent pairs on the device (orbx_debug_kb8_epipolar); returns ok uint8[n]."""
+        c1, c2, R, t = (np.ascontiguousarray(x, np.float32).ravel() for x in (cam1, cam2, R12, t12))
+        assert len(c1) == 16 and len(c2) == 16 and len(R) == 36 and len(t) == 12
+        a, b = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2), np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+        s1, s2, se = _f32(sigma1), _f32(sigma2), _u8(sel)
+        ok = np.zeros(len(a), np.uint8)
+        check(self._L.orbx_debug_kb8_epipolar(self._h, ptr(c1), ptr(c2), ptr(R), ptr(t), len(a), ptr(a), ptr(b), ptr(s1), ptr(s2), ptr(se), ptr(ok)),
+              "orbx_debug_kb8_epipolar")
+        return ok
+
     # ---- DBoW2 transform (Frame::ComputeBoW, Frame.cc:738-745) ----
     def BowTransform(self, voc: "ORBVocabulary", descriptors, levelsup: int = 4):
         """Returns (word_id[n], node_id[n]) of TemplatedVocabulary::transform for every descriptor."""

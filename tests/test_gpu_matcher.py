@@ -713,6 +713,46 @@ def _fisheye_keyframes(rng, n_pts=420):
     return synth.make_fisheye_keyframes(rng, n_pts)
 
 
+def test_kb8_epipolar_gate_every_verdict_on_the_device(oracle):
+    """KannalaBrandt8::epipolarConstrain evaluated on the device for 200 000 independent keypoint pairs (orbx_debug_kb8_epipolar: the device function k_tri_kb8
+    calls) -- every verdict against the oracle's: true correspondences with 0.2 .. 5 px of noise (verdicts of both kinds, many near the chi-square bounds),
+    unrelated pairs, all four camera pairings of a TUM-VI-like rig, all eight level variances.  Through the search only a query's winner shows; this
+    compares the Newton unprojections, the glibc tanf / atan2f restatements, the double cos / sin and the JacobiSVD sweeps as the hardware executes them."""
+    import orb_slam3_amd as osa
+    from orb_slam3_amd import synth
+    rng = np.random.default_rng(4242)
+    chunks = []
+    for rep in range(20):
+        k1, nl1, _, id1, k2, nl2, _, id2, R12, t12, cams = synth.make_fisheye_keyframes(rng, 2500)
+        # true correspondences (same 3-D point) in all camera pairings + as many unrelated pairs
+        pos2 = {}
+        for j, p in enumerate(id2):
+            pos2.setdefault(int(p), []).append(j)
+        a, b = [], []
+        for i, p in enumerate(id1):
+            for j in pos2.get(int(p), ()):
+                a.append(i); b.append(j)
+        a, b = np.array(a), np.array(b)
+        ra, rb_ = rng.integers(0, len(k1), len(a)), rng.integers(0, len(k2), len(a))
+        a, b = np.concatenate([a, ra]), np.concatenate([b, rb_])
+        sel = (2 * (a >= nl1) + (b >= nl2)).astype(np.uint8)
+        sg = (np.array([1.2 ** i for i in range(8)], np.float32) ** 2).astype(np.float32)
+        chunks.append((np.stack([k1["x"][a], k1["y"][a]], 1), np.stack([k2["x"][b], k2["y"][b]], 1), sg[k1["octave"][a]], sg[k2["octave"][b]], sel, R12, t12, cams))
+    m = osa.ORBmatcher()
+    total = ok_sum = 0
+    for xy1, xy2, s1, s2, sel, R12, t12, cams in chunks:
+        want = np.zeros(len(sel), np.uint8)
+        for q in range(4):
+            idx = np.nonzero(sel == q)[0]
+            o, _ = oracle.kb8_epipolar_constrain(cams[q >> 1], cams[q & 1], xy1[idx], xy2[idx], R12[q], t12[q], s1[idx], s2[idx])
+            want[idx] = o
+            assert len(idx) > 500
+        got = m.DebugKb8Epipolar(cams, cams, R12, t12, xy1, xy2, s1, s2, sel)
+        assert np.array_equal(got, want), (int((got != want).sum()), len(want))
+        total += len(want); ok_sum += int(want.sum())
+    assert total > 150000 and 0.1 < ok_sum / total < 0.6, (total, ok_sum)
+
+
 def test_search_for_triangulation_fisheye_every_pair_on_the_gate(oracle):
     """The same with descriptors that are all noisy copies of ONE pattern: every pair of a vocabulary node passes the distance test, so a node's pair list
     (k_tri_kb8, 2048 entries in LDS) fills and is flushed several times per query chunk, and the gate alone decides -- equal distances resolve to the later

@@ -119,5 +119,5 @@ def test_resource_budgets(isa):
             assert m["ScratchSize"] <= scratch, (name, m)
     # no kernel spills: scratch only where a cold non-inlined call needs a frame
     for name, (_, _, m) in kernels.items():
-        if not re.search(r"k_octree|k_debug_sort|k_replay_bowE|k_tri_kb8", name):   # k_replay_bow: the cold big-node path is a non-inlined call; k_tri_kb8: the gate (kb8_gate) is one
+        if not re.search(r"k_octree|k_debug_sort|k_replay_bowE|k_tri_kb8|k_debug_kb8_gate", name):   # k_replay_bow: the cold big-node path is a non-inlined call; k_tri_kb8: the gate (kb8_gate) is one
             assert m["ScratchSize"] == 0, (name, m)

@@ -209,6 +209,7 @@ TRI_KB8 = """
 import test_gpu_matcher as tm
 tm.test_search_for_triangulation_fisheye_every_pair_on_the_gate(ob)
 tm.test_search_for_triangulation_fisheye_gate_on_device(ob, 2)
+tm.test_kb8_epipolar_gate_every_verdict_on_the_device(ob)
 print('emulation ok')
 """
 
